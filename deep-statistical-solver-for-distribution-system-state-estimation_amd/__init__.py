@@ -1,0 +1,13 @@
+"""MI355X-native (gfx950) implementation of the DSS2 message-passing + WLS-loss hot path.
+
+Drop-in modules ``networks`` (EdgeAggregation, TAGConv, MPN, SkipMPN, PFN, SkipPFN) and ``data``
+(gsp_wls_edge, get_pflow) mirror /root/reference/networks.py and /root/reference/data.py for the
+path BASELINE.json names; everything below them is hand-written HIP in libdss2_hip.so.
+"""
+from . import _lib, synthetic, topology  # noqa: F401
+from . import networks, data, parallel  # noqa: F401
+from .networks import EdgeAggregation, TAGConv, MPN, SkipMPN, PFN, SkipPFN, MessagePassing  # noqa: F401
+from .data import gsp_wls_edge, get_pflow  # noqa: F401
+
+__all__ = ["EdgeAggregation", "TAGConv", "MPN", "SkipMPN", "PFN", "SkipPFN", "MessagePassing",
+           "gsp_wls_edge", "get_pflow", "networks", "data", "parallel", "synthetic", "topology"]

@@ -1,0 +1,128 @@
+"""ctypes binding of libdss2_hip.so (the C ABI declared in include/dss2_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+The kernels only exist for gfx950; CPU tensors are rejected by the callers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdss2_hip.so")
+
+c_f32p = C.c_void_p   # all device pointers travel as integers (tensor.data_ptr())
+c_i32p = C.c_void_p
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("ld", C.c_int32), ("transpose", C.c_int32), ("koff", C.c_int32), ("kpad", C.c_int32),
+                ("ncg", C.c_int32), ("pad_", C.c_int32)]
+
+
+class GemmPropArgs(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("kreal", C.c_int32), ("kpad", C.c_int32),
+                ("Bp", C.c_void_p), ("bias", C.c_void_p), ("rowscale", C.c_void_p),
+                ("relu_src", C.c_void_p), ("ld_relu", C.c_int64),
+                ("dmask", C.c_void_p), ("ld_dmask", C.c_int64),
+                ("add_src", C.c_void_p), ("ld_add", C.c_int64),
+                ("Y", C.c_void_p), ("ldy", C.c_int64), ("hout", C.c_int32), ("ncg", C.c_int32),
+                ("relu", C.c_int32), ("nmat", C.c_int32), ("nrb", C.c_int32), ("ntiles", C.c_int32),
+                ("tile_start", C.c_void_p),
+                ("rowptr", C.c_void_p), ("col", C.c_void_p), ("w", C.c_void_p),
+                ("max_nnz", C.c_int32), ("pad_", C.c_int32)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("G", C.c_void_p), ("ldg", C.c_int64), ("hout", C.c_int32),
+                ("X", C.c_void_p), ("ldx", C.c_int64), ("hin", C.c_int32),
+                ("rowscale", C.c_void_p),
+                ("slab", C.c_void_p), ("n_split", C.c_int32), ("nmat", C.c_int32), ("nrb", C.c_int32),
+                ("ntiles", C.c_int32),
+                ("tile_start", C.c_void_p),
+                ("rowptrT", C.c_void_p), ("colT", C.c_void_p), ("wT", C.c_void_p),
+                ("max_nnz", C.c_int32), ("pad_", C.c_int32)]
+
+
+class WlsArgs(C.Structure):
+    _fields_ = [("input", C.c_void_p), ("ld_in", C.c_int64),
+                ("edge_input", C.c_void_p), ("ld_ein", C.c_int64),
+                ("output", C.c_void_p), ("ld_out", C.c_int64),
+                ("node_param", C.c_void_p), ("ld_np", C.c_int64),
+                ("edge_param", C.c_void_p), ("ld_ep", C.c_int64),
+                ("x_mean", C.c_void_p), ("x_std", C.c_void_p),
+                ("edge_mean", C.c_void_p), ("edge_std", C.c_void_p),
+                ("efrom", C.c_void_p), ("eto", C.c_void_p),
+                ("inc_rowptr", C.c_void_p), ("inc_ent", C.c_void_p),
+                ("n_nodes", C.c_int64), ("n_edges", C.c_int64),
+                ("lam_v", C.c_float), ("lam_p", C.c_float), ("lam_pf", C.c_float), ("lam_reg", C.c_float),
+                ("sums", C.c_void_p), ("partials", C.c_void_p), ("vminmax", C.c_void_p),
+                ("apq", C.c_void_p), ("loss", C.c_void_p), ("grad_output", C.c_void_p), ("pflow", C.c_void_p)]
+
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "dss2_last_error": (C.c_char_p, []),
+    "dss2_version": (C.c_int, []),
+    "dss2_topology_hash": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "dss2_segment_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                   C.c_int64, C.c_int, C.c_void_p]),
+    "dss2_pack_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dss2_edge_hidden_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                       C.c_int, C.c_int, C.c_void_p]),
+    "dss2_edge_hidden_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p]),
+    "dss2_gemm_prop": (C.c_int, [C.POINTER(GemmPropArgs), C.c_void_p]),
+    "dss2_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p]),
+    "dss2_reduce_slabs": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dss2_wls_loss_partials": (C.c_int, [C.POINTER(WlsArgs), C.c_void_p]),
+    "dss2_wls_loss_grad": (C.c_int, [C.POINTER(WlsArgs), C.c_void_p]),
+    "dss2_get_pflow": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]),
+    "dss2_gemm_prop_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dss2_wgrad_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libdss2_hip.so in-tree with hipcc --offload-arch=gfx950 (works without a GPU)."""
+    script = os.path.join(_HERE, "csrc", "build.sh")
+    res = subprocess.run(["bash", script], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"building libdss2_hip.so failed:\n{res.stdout}\n{res.stderr}")
+    if verbose:
+        print(res.stdout.strip())
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library with typed signatures.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the DSS2 HIP kernels are not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().dss2_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

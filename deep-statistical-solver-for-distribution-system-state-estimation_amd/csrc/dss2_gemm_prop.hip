@@ -1,0 +1,258 @@
+// Fused tile GEMM (fp32 MFMA 32x32x2) + Horner graph propagation in LDS, for gfx950.
+//
+// One workgroup owns one tile of <= 32*NRB consecutive node rows made of whole graphs.
+//   1. the tile's X rows are staged once in LDS (row stride kpad+4 floats: conflict-free
+//      ds_read_b128 of the A fragments);
+//   2. wave w owns 32 output columns `cg` of EVERY matrix m < NMAT and all NRB row blocks:
+//      acc[rb][m] += X[rb] . B_m[:, cg]   with v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+//      k is consumed 8 at a time: lane l holds A[row l&31][8kk + 4(l>>5) + s] and
+//      B[8kk + 4(l>>5) + s][col l&31], s = 0..3, so both operands arrive as one 16-byte load
+//      (A from LDS, B from the fragment-packed weights, 1 KiB contiguous per wave);
+//   3. Horner epilogue on the accumulators: T = G_{NMAT-1}; T = G_m + P T for m = NMAT-2..0,
+//      where P T is a CSR segmented sum over the tile's rows read from a wave-private LDS
+//      stage (column on the lane => conflict-free, no atomics, fixed order);
+//   4. bias / dropout mask / ReLU / ReLU-mask / residual, one 128-B row segment per half wave.
+#include "dss2_common.hpp"
+
+namespace dss2 {
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_weights_kernel(const dss2_pack_desc* __restrict__ descs) {
+  const dss2_pack_desc d = descs[blockIdx.y];
+  const int K = d.transpose ? d.cols : d.rows;
+  const int J = d.transpose ? d.rows : d.cols;
+  const int nkl = (K + 7) >> 3;       // k-groups covered by this block
+  const int nkk = d.kpad >> 3;        // k-groups of the whole packed matrix
+  const int total = d.ncg * nkl * 64;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63;
+  const int kkl = (idx >> 6) % nkl;
+  const int cg = (idx >> 6) / nkl;
+  const int j = cg * 32 + (lane & 31);
+  f32x4 v;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = kkl * 8 + 4 * (lane >> 5) + s;
+    float val = 0.f;
+    if (k < K && j < J) val = d.transpose ? d.src[(size_t)j * d.ld + k] : d.src[(size_t)k * d.ld + j];
+    v[s] = val;
+  }
+  f32x4* dst = reinterpret_cast<f32x4*>(d.dst);
+  dst[((size_t)cg * nkk + (d.koff >> 3) + kkl) * 64 + lane] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused GEMM + propagation
+// ------------------------------------------------------------------------------------------
+template <int NRB, int NMAT>
+__global__ void __launch_bounds__(256) gemm_prop_kernel(const dss2_gemm_prop_args p) {
+  constexpr int TM = NRB * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nthreads = blockDim.x;
+  const int nw = nthreads >> 6;
+  const int tile = blockIdx.x;
+  const int ts = p.tile_start[tile];
+  const int R = p.tile_start[tile + 1] - ts;
+  const int LDX = p.kpad + 4;
+
+  float* Xs = smem;
+  float* stage = Xs + TM * LDX;
+  int* lrow = reinterpret_cast<int*>(stage + nw * TM * 32);
+  int2* lent = reinterpret_cast<int2*>(lrow + TM + 2);
+
+  // ---- stage the X tile (zero padded to TM x kpad)
+  const bool vec_ok = ((p.kreal & 3) == 0) && ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
+  if (vec_ok) {
+    const int kq = p.kpad >> 2;
+    for (int idx = tid; idx < TM * kq; idx += nthreads) {
+      const int r = idx / kq;
+      const int c = (idx - r * kq) << 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
+      *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = v;
+    }
+  } else {
+    for (int idx = tid; idx < TM * p.kpad; idx += nthreads) {
+      const int r = idx / p.kpad;
+      const int c = idx - r * p.kpad;
+      float v = 0.f;
+      if (r < R && c < p.kreal) v = p.X[(size_t)(ts + r) * p.ldx + c];
+      Xs[r * LDX + c] = v;
+    }
+  }
+  // ---- stage the tile's CSR slice (local row pointers, local column ids, weights)
+  if (NMAT > 1) {
+    const int base = p.rowptr[ts];
+    const int nnz = p.rowptr[ts + R] - base;
+    for (int r = tid; r <= TM; r += nthreads) lrow[r] = (r <= R) ? (p.rowptr[ts + r] - base) : nnz;
+    for (int k = tid; k < nnz; k += nthreads) lent[k] = make_int2(p.col[base + k] - ts, __float_as_int(p.w[base + k]));
+  }
+  __syncthreads();
+
+  const int c32 = lane & 31;   // A row inside a row block == output column inside a column group
+  const int half = lane >> 5;
+  const int nkk = p.kpad >> 3;
+  const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(p.Bp);
+  const float* xa = Xs + c32 * LDX + half * 4;
+  float* st = stage + wave * (TM * 32);
+
+  for (int cg = wave; cg < p.ncg; cg += nw) {
+    f32x16 acc[NRB][NMAT];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][m][r] = 0.f;
+
+    f32x4 a_cur[NRB], b_cur[NMAT];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) a_cur[rb] = *reinterpret_cast<const f32x4*>(xa + rb * 32 * LDX);
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m) b_cur[m] = bp[((size_t)(m * p.ncg + cg) * nkk) * 64 + lane];
+
+    for (int kk = 0; kk < nkk; ++kk) {
+      const int kn = (kk + 1 < nkk) ? kk + 1 : kk;
+      f32x4 a_nxt[NRB], b_nxt[NMAT];
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) a_nxt[rb] = *reinterpret_cast<const f32x4*>(xa + rb * 32 * LDX + kn * 8);
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) b_nxt[m] = bp[((size_t)(m * p.ncg + cg) * nkk + kn) * 64 + lane];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m)
+            acc[rb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[rb][s], b_cur[m][s], acc[rb][m], 0, 0, 0);
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) a_cur[rb] = a_nxt[rb];
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) b_cur[m] = b_nxt[m];
+    }
+
+    // ---- Horner propagation: T = G_{NMAT-1}; T = G_m + P T
+    f32x16 T[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) T[rb] = acc[rb][NMAT - 1];
+    if (NMAT > 1) {
+#pragma unroll
+      for (int m = NMAT - 2; m >= 0; --m) {
+        wave_lds_sync();  // previous round's reads of the stage are done
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
+        wave_lds_sync();
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rb * 32 + acc_row(r, half);
+            float s = acc[rb][m][r];
+            const int e1 = lrow[row + 1];
+            for (int e = lrow[row]; e < e1; ++e) {
+              const int2 en = lent[e];
+              s = fmaf(__int_as_float(en.y), st[en.x * 32 + c32], s);
+            }
+            T[rb][r] = s;
+          }
+      }
+    }
+
+    // ---- epilogue: T -> wave-private LDS stage -> rolled, row-coalesced store loop (keeps the
+    //      address arithmetic of the five optional operands out of the unrolled register code)
+    wave_lds_sync();
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
+    wave_lds_sync();
+    const int colg = cg * 32 + c32;
+    if (colg < p.hout) {
+      const float bias = p.bias ? p.bias[colg] : 0.f;
+      for (int row = half; row < R; row += 2) {
+        const size_t grow = (size_t)(ts + row);
+        float y = st[row * 32 + c32];
+        if (p.bias) y += p.rowscale ? bias * p.rowscale[grow] : bias;
+        if (p.dmask) y *= p.dmask[grow * p.ld_dmask + colg];
+        if (p.relu) y = fmaxf(y, 0.f);
+        if (p.relu_src) y = (p.relu_src[grow * p.ld_relu + colg] > 0.f) ? y : 0.f;
+        if (p.add_src) y += p.add_src[grow * p.ld_add + colg];
+        p.Y[grow * p.ldy + colg] = y;
+      }
+    }
+  }
+}
+
+static size_t lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz) {
+  const size_t TM = (size_t)nrb * 32;
+  const int nw = ncg < 4 ? ncg : 4;
+  size_t b = TM * (size_t)(kpad + 4) * 4 + (size_t)nw * TM * 32 * 4;
+  if (nmat > 1) b += (TM + 2) * 4 + (size_t)max_nnz * 8;
+  return b;
+}
+
+template <int NRB, int NMAT>
+static int launch(const dss2_gemm_prop_args& a, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = gemm_prop_kernel<NRB, NMAT>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
+    if (e != hipSuccess) {
+      set_error("gemm_prop: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return 1;
+    }
+    attr_set = true;
+  }
+  const size_t lds = lds_bytes(NRB, NMAT, a.kpad, a.ncg, a.max_nnz);
+  const int nw = a.ncg < 4 ? a.ncg : 4;
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * nw), lds, stream, a);
+  return check_launch("gemm_prop");
+}
+
+}  // namespace dss2
+
+extern "C" size_t dss2_gemm_prop_lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz) {
+  return dss2::lds_bytes(nrb, nmat, kpad, ncg, max_nnz);
+}
+
+extern "C" int dss2_pack_weights(const dss2_pack_desc* descs, int n_desc, int max_elems, void* stream) {
+  if (n_desc <= 0) return 0;
+  dim3 grid((max_elems + 255) / 256, n_desc);
+  hipLaunchKernelGGL(dss2::pack_weights_kernel, grid, dim3(256), 0, dss2::as_stream(stream), descs);
+  return dss2::check_launch("pack_weights");
+}
+
+extern "C" int dss2_gemm_prop(const dss2_gemm_prop_args* ap, void* stream) {
+  using namespace dss2;
+  const dss2_gemm_prop_args& a = *ap;
+  if (a.ntiles <= 0) return 0;
+  if ((a.kpad & 7) || a.kpad < a.kreal || a.kpad <= 0) { set_error("gemm_prop: bad kpad %d (kreal %d)", a.kpad, a.kreal); return 2; }
+  if (a.ncg * 32 < a.hout || a.ncg <= 0) { set_error("gemm_prop: ncg %d too small for hout %d", a.ncg, a.hout); return 2; }
+  if (a.nmat > 1 && (!a.rowptr || !a.col || !a.w)) { set_error("gemm_prop: nmat > 1 needs a CSR"); return 2; }
+  if (lds_bytes(a.nrb, a.nmat, a.kpad, a.ncg, a.max_nnz) > (size_t)kMaxLdsBytes) {
+    set_error("gemm_prop: tile needs %zu B of LDS (> 160 KiB): nrb=%d kpad=%d nnz=%d",
+              lds_bytes(a.nrb, a.nmat, a.kpad, a.ncg, a.max_nnz), a.nrb, a.kpad, a.max_nnz);
+    return 3;
+  }
+  hipStream_t s = as_stream(stream);
+#define DSS2_CASE(NRB, NMAT) \
+  if (a.nrb == NRB && a.nmat == NMAT) return launch<NRB, NMAT>(a, s);
+  DSS2_CASE(1, 1) DSS2_CASE(1, 2) DSS2_CASE(1, 3) DSS2_CASE(1, 4)
+  DSS2_CASE(2, 1) DSS2_CASE(2, 2) DSS2_CASE(2, 3) DSS2_CASE(2, 4)
+  DSS2_CASE(3, 1) DSS2_CASE(3, 2) DSS2_CASE(3, 3) DSS2_CASE(3, 4)
+  DSS2_CASE(4, 1) DSS2_CASE(4, 2) DSS2_CASE(4, 3) DSS2_CASE(4, 4)
+  DSS2_CASE(6, 1) DSS2_CASE(6, 2) DSS2_CASE(6, 3) DSS2_CASE(6, 4)
+  DSS2_CASE(8, 1) DSS2_CASE(8, 2) DSS2_CASE(8, 3)
+#undef DSS2_CASE
+  set_error("gemm_prop: unsupported (nrb=%d, nmat=%d); nrb in {1,2,3,4,6,8}, nmat in 1..4, nrb*nmat <= 24", a.nrb, a.nmat);
+  return 2;
+}

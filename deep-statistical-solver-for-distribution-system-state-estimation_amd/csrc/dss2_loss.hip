@@ -1,0 +1,344 @@
+// gsp_wls_edge + get_pflow (reference data.py:328-459), forward and analytic backward, gfx950.
+//
+// Node-centric, atomics-free: thread i owns bus i and walks its incident stored branches through
+// the incidence CSR, recomputing the branch physics for each (each branch is evaluated from both
+// of its ends; the work is ~60 flops + one sincos per visit and the whole batch is a few MB).
+//   phase 0  vminmax_kernel      batch-global V_lv / V_hv           (data.py:335-336)
+//   phase 1  wls_partials_kernel in-place slack masking, flows, bus injections, per-bus
+//                                residual coefficients, 5 partial sums per workgroup (double)
+//            wls_finish_kernel   fixed-order sum of the workgroup partials -> sums[0..6]
+//   [data-parallel callers all-reduce sums here]
+//   phase 2  wls_grad_kernel     loss scalar + d loss / d output (chain rule through get_pflow)
+// The dead dense Laplacian of data.py:422-423 is not reproduced.
+#include "dss2_common.hpp"
+
+namespace dss2 {
+
+struct EdgeP { float G, B, Gs, Bs, tp, imax; };
+
+struct Flow {
+  float pf, qf, pt, qt, i_f, i_t, load_line, load_trafo, d, s, c;
+};
+
+__device__ __forceinline__ EdgeP load_edge_param(const float* ep) {
+  EdgeP e;
+  e.G = ep[0]; e.B = ep[1]; e.Gs = ep[2]; e.Bs = ep[3];
+  e.tp = ceilf(ep[5]);  // trafo flag = ceil(phase shift): 1 for CIGRE, 3 for ober_sub (data.py:367)
+  e.imax = ep[6];
+  return e;
+}
+
+// data.py:370-388 with shift = 0 (phase_shift=True => shift = 0, data.py:362-365)
+__device__ __forceinline__ Flow branch_flow(float vf, float vt, float thf, float tht, const EdgeP& e, float vlv,
+                                            float vhv) {
+  Flow f;
+  f.d = thf - tht;
+  sincosf(f.d, &f.s, &f.c);
+  const float kk = vlv * vlv;
+  const float gg = e.G + e.Gs / 2.f, bb = e.B + e.Bs / 2.f;
+  const float vv = vf * vt;
+  f.pf = (-vv * (e.G * f.c + e.B * f.s) + gg * (vf * vf)) * kk;
+  f.qf = (vv * (-e.G * f.s + e.B * f.c) - bb * (vf * vf)) * kk;
+  f.pt = (-vv * (e.G * f.c - e.B * f.s) + gg * (vt * vt)) * kk;
+  f.qt = (vv * (e.G * f.s + e.B * f.c) - bb * (vt * vt)) * kk;
+  const float sqrt3 = 1.7320508075688772f;
+  const float ratio = vhv / vlv;
+  f.i_f = hypotf(f.pf, f.qf) / (vf * vlv * sqrt3);
+  f.i_f = f.i_f / (1.f - (e.tp * (1.f - ratio)));
+  f.i_t = hypotf(f.pt, f.qt) / (vt * vlv * sqrt3);
+  f.load_line = ((1.f - e.tp) * fmaxf(f.i_f, f.i_t)) / e.imax;
+  f.load_trafo = (e.tp * fmaxf(f.i_f * vhv, f.i_t * vlv)) / e.imax;
+  return f;
+}
+
+__global__ void __launch_bounds__(1024) vminmax_kernel(const float* __restrict__ np, int64_t ld, int64_t n,
+                                                        float* __restrict__ out) {
+  __shared__ float smin[16], smax[16];
+  float lo = INFINITY, hi = -INFINITY;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const float v = np[i * ld];
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o));
+    hi = fmaxf(hi, __shfl_xor(hi, o));
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { smin[w] = lo; smax[w] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x >> 6;
+    for (int k = 1; k < nw; ++k) { lo = fminf(lo, smin[k]); hi = fmaxf(hi, smax[k]); }
+    out[0] = lo;
+    out[1] = hi;
+  }
+}
+
+struct NodeMeas { float Z[4], R[4]; };
+
+__device__ __forceinline__ NodeMeas node_meas(const float* in, const float* xm, const float* xs) {
+  NodeMeas m;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float z = in[2 * c], r = in[2 * c + 1];
+    m.Z[c] = (z != 0.f) ? (z * xs[2 * c] + xm[2 * c]) : 0.f;
+    m.R[c] = (r != 0.f) ? (r * xs[2 * c + 1] + xm[2 * c + 1]) : 0.f;
+  }
+  return m;
+}
+
+constexpr int LB = 256;  // loss kernels' block size
+
+__global__ void __launch_bounds__(LB) wls_partials_kernel(const dss2_wls_args p) {
+  __shared__ double red[LB / 64][5];
+  const int64_t i = (int64_t)blockIdx.x * LB + threadIdx.x;
+  const float vlv = p.vminmax[0], vhv = p.vminmax[1];
+  const float xs0 = p.x_std[0], xm0 = p.x_mean[0];
+  double acc[5] = {0, 0, 0, 0, 0};
+  if (i < p.n_nodes) {
+    float* o = p.output + i * p.ld_out;
+    const float mi = 1.f - p.node_param[i * p.ld_np + 1];
+    const float th_i = o[1] * mi;
+    o[1] = th_i;  // theta_i *= (1 - slack), in place on the model output (data.py:413)
+    const float v_i = o[0] * xs0 + xm0;
+    const NodeMeas nm = node_meas(p.input + i * p.ld_in, p.x_mean, p.x_std);
+    float p_i = 0.f, q_i = 0.f, s_edge = 0.f, s_t = 0.f, s_l = 0.f;
+    const int k1 = p.inc_rowptr[i + 1];
+    for (int k = p.inc_rowptr[i]; k < k1; ++k) {
+      const int en = p.inc_ent[k];
+      const int e = en & 0x7fffffff;
+      const bool to_end = en < 0;
+      const int64_t other = to_end ? p.efrom[e] : p.eto[e];
+      const float* oo = p.output + other * p.ld_out;
+      const float v_o = oo[0] * xs0 + xm0;
+      // mask is 0/1, so re-applying it to a possibly already-masked value is idempotent
+      const float th_o = oo[1] * (1.f - p.node_param[other * p.ld_np + 1]);
+      const EdgeP ep = load_edge_param(p.edge_param + (int64_t)e * p.ld_ep);
+      const Flow f = to_end ? branch_flow(v_o, v_i, th_o, th_i, ep, vlv, vhv)
+                            : branch_flow(v_i, v_o, th_i, th_o, ep, vlv, vhv);
+      if (to_end) {
+        p_i -= f.pt;
+        q_i -= f.qt;
+      } else {
+        p_i -= f.pf;
+        q_i -= f.qf;
+        // each stored edge is accounted once, at its from-end
+        const float* ei = p.edge_input + (int64_t)e * p.ld_ein;
+        const float zp = ei[0], rp = ei[1], zq = ei[2], rq = ei[3];
+        const float Zp = (zp != 0.f) ? (zp * p.edge_std[0] + p.edge_mean[0]) : 0.f;
+        const float Rp = (rp != 0.f) ? (rp * p.edge_std[1] + p.edge_mean[1]) : 0.f;
+        const float Zq = (zq != 0.f) ? (zq * p.edge_std[2] + p.edge_mean[2]) : 0.f;
+        const float Rq = (rq != 0.f) ? (rq * p.edge_std[3] + p.edge_mean[3]) : 0.f;
+        const float dp = Zp - f.pf, dq = Zq - f.qf;
+        s_edge += dp * dp * Rp * p.lam_pf + dq * dq * Rq * p.lam_pf;
+        s_t += fmaxf(fabsf(f.d) - 0.5f, 0.f);
+        s_l += fmaxf(f.load_line + f.load_trafo - 1.5f, 0.f);
+        if (p.pflow) {
+          float* pf = p.pflow + (int64_t)e * 8;
+          pf[0] = f.load_line; pf[1] = f.load_trafo; pf[2] = f.pf; pf[3] = f.qf;
+          pf[4] = f.pt; pf[5] = f.qt; pf[6] = f.i_f; pf[7] = f.i_t;
+        }
+      }
+    }
+    const float h[4] = {v_i, th_i, p_i, q_i};
+    const float lam[4] = {p.lam_v, p.lam_v, p.lam_p, p.lam_p};
+    float s_node = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d = nm.Z[c] - h[c];
+      s_node += d * d * nm.R[c] * lam[c];
+    }
+    p.apq[2 * i + 0] = -2.f * (nm.Z[2] - p_i) * nm.R[2] * p.lam_p;
+    p.apq[2 * i + 1] = -2.f * (nm.Z[3] - q_i) * nm.R[3] * p.lam_p;
+    acc[0] = s_node;
+    acc[1] = s_edge;
+    acc[2] = fmaxf(v_i - 1.1f, 0.f) + fmaxf(0.9f - v_i, 0.f);
+    acc[3] = s_t;
+    acc[4] = s_l;
+  }
+#pragma unroll
+  for (int c = 0; c < 5; ++c)
+    for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+    for (int c = 0; c < 5; ++c) red[w][c] = acc[c];
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    double s = 0;
+    for (int k = 0; k < LB / 64; ++k) s += red[k][threadIdx.x];
+    p.partials[(size_t)blockIdx.x * 5 + threadIdx.x] = s;
+  }
+}
+
+__global__ void wls_finish_kernel(const double* __restrict__ partials, int n_blocks, double* __restrict__ sums,
+                                  double n_nodes, double n_edges) {
+  const int c = threadIdx.x;
+  if (c < 5) {
+    double s = 0;
+    for (int b = 0; b < n_blocks; ++b) s += partials[(size_t)b * 5 + c];
+    sums[c] = s;
+  } else if (c == 5) {
+    sums[5] = n_nodes;
+  } else if (c == 6) {
+    sums[6] = n_edges;
+  } else if (c == 7) {
+    sums[7] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(LB) wls_grad_kernel(const dss2_wls_args p) {
+  const int64_t i = (int64_t)blockIdx.x * LB + threadIdx.x;
+  const double Nn = p.sums[5], Ee = p.sums[6];
+  const double mean_v = p.sums[2] / Nn, mean_t = p.sums[3] / Ee, mean_l = p.sums[4] / Ee;
+  if (i == 0) {
+    const double lr = (double)p.lam_reg;
+    p.loss[0] = (float)(p.sums[0] / Nn + p.sums[1] / Ee + lr * mean_v * mean_v + lr * mean_t * mean_t +
+                        lr * mean_l * mean_l);
+  }
+  if (i >= p.n_nodes) return;
+  const float invN = (float)(1.0 / Nn), invE = (float)(1.0 / Ee);
+  const float m_v = (float)(2.0 * p.lam_reg * mean_v / Nn);
+  const float m_t = (float)(2.0 * p.lam_reg * mean_t / Ee);
+  const float m_l = (float)(2.0 * p.lam_reg * mean_l / Ee);
+  const float vlv = p.vminmax[0], vhv = p.vminmax[1];
+  const float xs0 = p.x_std[0], xm0 = p.x_mean[0];
+  const float kk = vlv * vlv;
+  const float sqrt3 = 1.7320508075688772f;
+  const float ratio = vhv / vlv;
+
+  const float* o = p.output + i * p.ld_out;
+  const float mi = 1.f - p.node_param[i * p.ld_np + 1];
+  const float th_i = o[1] * mi;
+  const float v_i = o[0] * xs0 + xm0;
+  const NodeMeas nm = node_meas(p.input + i * p.ld_in, p.x_mean, p.x_std);
+  float gv = invN * (-2.f * (nm.Z[0] - v_i) * nm.R[0] * p.lam_v);
+  gv += m_v * ((v_i > 1.1f ? 1.f : 0.f) - (v_i < 0.9f ? 1.f : 0.f));
+  float gth = invN * (-2.f * (nm.Z[1] - th_i) * nm.R[1] * p.lam_v);
+  const float ap_i = p.apq[2 * i] * invN, aq_i = p.apq[2 * i + 1] * invN;
+
+  const int k1 = p.inc_rowptr[i + 1];
+  for (int k = p.inc_rowptr[i]; k < k1; ++k) {
+    const int en = p.inc_ent[k];
+    const int e = en & 0x7fffffff;
+    const bool to_end = en < 0;
+    const int64_t other = to_end ? p.efrom[e] : p.eto[e];
+    const float* oo = p.output + other * p.ld_out;
+    const float v_o = oo[0] * xs0 + xm0;
+    const float th_o = oo[1] * (1.f - p.node_param[other * p.ld_np + 1]);
+    const float ap_o = p.apq[2 * other] * invN, aq_o = p.apq[2 * other + 1] * invN;
+    const EdgeP ep = load_edge_param(p.edge_param + (int64_t)e * p.ld_ep);
+    const float vf = to_end ? v_o : v_i, vt = to_end ? v_i : v_o;
+    const float thf = to_end ? th_o : th_i, tht = to_end ? th_i : th_o;
+    const float ap_f = to_end ? ap_o : ap_i, aq_f = to_end ? aq_o : aq_i;
+    const float ap_t = to_end ? ap_i : ap_o, aq_t = to_end ? aq_i : aq_o;
+    const Flow f = branch_flow(vf, vt, thf, tht, ep, vlv, vhv);
+    // upstream gradients w.r.t. the four flows
+    const float* ei = p.edge_input + (int64_t)e * p.ld_ein;
+    const float zp = ei[0], rp = ei[1], zq = ei[2], rq = ei[3];
+    const float Zp = (zp != 0.f) ? (zp * p.edge_std[0] + p.edge_mean[0]) : 0.f;
+    const float Rp = (rp != 0.f) ? (rp * p.edge_std[1] + p.edge_mean[1]) : 0.f;
+    const float Zq = (zq != 0.f) ? (zq * p.edge_std[2] + p.edge_mean[2]) : 0.f;
+    const float Rq = (rq != 0.f) ? (rq * p.edge_std[3] + p.edge_mean[3]) : 0.f;
+    float uPf = invE * (-2.f * (Zp - f.pf) * Rp * p.lam_pf) - ap_f;
+    float uQf = invE * (-2.f * (Zq - f.qf) * Rq * p.lam_pf) - aq_f;
+    float uPt = -ap_t, uQt = -aq_t;
+    float dvf_direct = 0.f, dvt_direct = 0.f;
+    // loading penalty -> currents -> flows and voltages
+    const float loading = f.load_line + f.load_trafo;
+    if (loading > 1.5f && m_l != 0.f) {
+      const float dL_dIf = ((1.f - ep.tp) * (f.i_f >= f.i_t ? 1.f : 0.f) +
+                            ep.tp * vhv * (f.i_f * vhv >= f.i_t * vlv ? 1.f : 0.f)) / ep.imax;
+      const float dL_dIt = ((1.f - ep.tp) * (f.i_f >= f.i_t ? 0.f : 1.f) +
+                            ep.tp * vlv * (f.i_f * vhv >= f.i_t * vlv ? 0.f : 1.f)) / ep.imax;
+      const float gIf = m_l * dL_dIf, gIt = m_l * dL_dIt;
+      const float cf = vlv * sqrt3 * (1.f - (ep.tp * (1.f - ratio)));
+      const float ct = vlv * sqrt3;
+      const float Af = hypotf(f.pf, f.qf), At = hypotf(f.pt, f.qt);
+      if (Af > 0.f) {
+        uPf += gIf * f.pf / (Af * vf * cf);
+        uQf += gIf * f.qf / (Af * vf * cf);
+      }
+      if (At > 0.f) {
+        uPt += gIt * f.pt / (At * vt * ct);
+        uQt += gIt * f.qt / (At * vt * ct);
+      }
+      dvf_direct = -gIf * f.i_f / vf;
+      dvt_direct = -gIt * f.i_t / vt;
+    }
+    // |theta_i - theta_j| penalty
+    float gd = 0.f;
+    if (fabsf(f.d) > 0.5f) gd = m_t * (f.d > 0.f ? 1.f : -1.f);
+    // partial derivatives of the flows (data.py:370-376) w.r.t. vf, vt, d = thf - tht
+    const float G = ep.G, B = ep.B, gg = ep.G + ep.Gs / 2.f, bb = ep.B + ep.Bs / 2.f;
+    const float c = f.c, s = f.s, vv = vf * vt;
+    const float a1 = G * c + B * s;    // in P_from
+    const float a2 = -G * s + B * c;   // in Q_from (= d a1 / dd)
+    const float a3 = G * c - B * s;    // in P_to
+    const float a4 = G * s + B * c;    // in Q_to
+    if (!to_end) {
+      const float dPf = (-vt * a1 + 2.f * gg * vf) * kk, dQf = (vt * a2 - 2.f * bb * vf) * kk;
+      const float dPt = (-vt * a3) * kk, dQt = (vt * a4) * kk;
+      gv += uPf * dPf + uQf * dQf + uPt * dPt + uQt * dQt + dvf_direct;
+    } else {
+      const float dPf = (-vf * a1) * kk, dQf = (vf * a2) * kk;
+      const float dPt = (-vf * a3 + 2.f * gg * vt) * kk, dQt = (vf * a4 - 2.f * bb * vt) * kk;
+      gv += uPf * dPf + uQf * dQf + uPt * dPt + uQt * dQt + dvt_direct;
+    }
+    // d/dd: d a1 = a2, d a2 = -a1, d a3 = -a4, d a4 = a3
+    const float dd = (uPf * (-vv * a2) + uQf * (vv * (-a1)) + uPt * (-vv * (-a4)) + uQt * (vv * a3)) * kk + gd;
+    gth += to_end ? -dd : dd;
+  }
+  p.grad_output[2 * i + 0] = gv * xs0;
+  p.grad_output[2 * i + 1] = gth * mi;
+}
+
+__global__ void __launch_bounds__(LB) pflow_kernel(const float* __restrict__ y, int64_t ldy,
+                                                   const float* __restrict__ edge_param, int64_t ld_ep,
+                                                   const int32_t* __restrict__ efrom, const int32_t* __restrict__ eto,
+                                                   int64_t n_edges, const float* __restrict__ vminmax,
+                                                   float* __restrict__ pflow) {
+  const int64_t e = (int64_t)blockIdx.x * LB + threadIdx.x;
+  if (e >= n_edges) return;
+  const int64_t a = efrom[e], b = eto[e];
+  const EdgeP ep = load_edge_param(edge_param + e * ld_ep);
+  const Flow f = branch_flow(y[a * ldy], y[b * ldy], y[a * ldy + 1], y[b * ldy + 1], ep, vminmax[0], vminmax[1]);
+  float* pf = pflow + e * 8;
+  pf[0] = f.load_line; pf[1] = f.load_trafo; pf[2] = f.pf; pf[3] = f.qf;
+  pf[4] = f.pt; pf[5] = f.qt; pf[6] = f.i_f; pf[7] = f.i_t;
+}
+
+}  // namespace dss2
+
+using namespace dss2;
+
+extern "C" int dss2_wls_loss_partials(const dss2_wls_args* ap, void* stream) {
+  const dss2_wls_args& a = *ap;
+  if (a.n_nodes <= 0 || a.n_edges <= 0) { set_error("wls_loss: empty batch"); return 2; }
+  const int64_t nb = (a.n_nodes + LB - 1) / LB;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(vminmax_kernel, dim3(1), dim3(1024), 0, s, a.node_param, a.ld_np, a.n_nodes, a.vminmax);
+  hipLaunchKernelGGL(wls_partials_kernel, dim3((unsigned)nb), dim3(LB), 0, s, a);
+  hipLaunchKernelGGL(wls_finish_kernel, dim3(1), dim3(64), 0, s, a.partials, (int)nb, a.sums, (double)a.n_nodes,
+                     (double)a.n_edges);
+  return check_launch("wls_loss_partials");
+}
+
+extern "C" int dss2_wls_loss_grad(const dss2_wls_args* ap, void* stream) {
+  const dss2_wls_args& a = *ap;
+  if (a.n_nodes <= 0) { set_error("wls_loss: empty batch"); return 2; }
+  const int64_t nb = (a.n_nodes + LB - 1) / LB;
+  hipLaunchKernelGGL(wls_grad_kernel, dim3((unsigned)nb), dim3(LB), 0, as_stream(stream), a);
+  return check_launch("wls_loss_grad");
+}
+
+extern "C" int dss2_get_pflow(const float* y, int64_t ldy, const float* node_param, int64_t ld_np,
+                              const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
+                              int64_t n_nodes, int64_t n_edges, float* vminmax, float* pflow, void* stream) {
+  if (n_nodes <= 0 || n_edges <= 0) { set_error("get_pflow: empty batch"); return 2; }
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(vminmax_kernel, dim3(1), dim3(1024), 0, s, node_param, ld_np, n_nodes, vminmax);
+  hipLaunchKernelGGL(pflow_kernel, dim3((unsigned)((n_edges + LB - 1) / LB)), dim3(LB), 0, s, y, ldy, edge_param, ld_ep,
+                     efrom, eto, n_edges, vminmax, pflow);
+  return check_launch("get_pflow");
+}

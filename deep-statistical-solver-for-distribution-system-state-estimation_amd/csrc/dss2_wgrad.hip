@@ -1,0 +1,224 @@
+// Weight gradient of TAGConv / Linear on gfx950:  dW_m = (P^m G)^T X,  db = colsum(G).
+//
+// Persistent workgroups walk the tile list (tile = whole graphs, <= 32*NRB rows).  Per tile the
+// G slab (NB*32 output-feature columns) and the X slab (128 input-feature columns) are staged in
+// LDS; P^m G is produced in LDS by a CSR segmented sum over the transposed graph (ping-pong
+// buffers, no atomics), and every wave accumulates its 32x32 blocks of dW with fp32 MFMA
+// (32x32x2; A = Z^T read column-wise from LDS, B = X) in registers ACROSS tiles.  One slab of
+// partial sums per workgroup is written at the end; dss2_reduce_slabs adds them in fixed order.
+#include "dss2_common.hpp"
+
+namespace dss2 {
+
+constexpr int XW = 128;  // X columns per workgroup: one 32-column block per wave
+
+template <int NRB, int NMAT, int NB>
+__global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int nibg) {
+  constexpr int TM = NRB * 32;
+  constexpr int LDZ = NB * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Za = smem;
+  float* Zb = Za + TM * LDZ;
+  float* Xs = Zb + (NMAT > 1 ? TM * LDZ : 0);
+  int* lrow = reinterpret_cast<int*>(Xs + TM * XW);
+  int2* lent = reinterpret_cast<int2*>(lrow + TM + 2);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int c32 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int obg = blockIdx.y / nibg, ibg = blockIdx.y - obg * nibg;
+  const int gcol0 = obg * LDZ;
+  const int xcol0 = ibg * XW;
+  const bool wave_active = (xcol0 + wave * 32) < p.hin;
+
+  f32x16 acc[NMAT][NB];
+#pragma unroll
+  for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][ob][r] = 0.f;
+  float dbacc = 0.f;
+
+  const bool gvec = ((p.ldg & 3) == 0) && ((p.hout & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.G) & 15) == 0);
+  const bool xvec = ((p.ldx & 3) == 0) && ((p.hin & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
+
+  auto mma = [&](const float* Z, f32x16 (&a)[NB], int R) {
+    if (!wave_active) return;
+    const int n2e = (R + 1) >> 1;
+    const float* zp = Z + half * LDZ + c32;
+    const float* xp = Xs + half * XW + wave * 32 + c32;
+    for (int n2 = 0; n2 < n2e; ++n2) {
+      const float bv = xp[n2 * 2 * XW];
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob) {
+        const float av = zp[n2 * 2 * LDZ + ob * 32];
+        a[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, a[ob], 0, 0, 0);
+      }
+    }
+  };
+  auto prop = [&](const float* Zs, float* Zd) {
+    const int c = tid % LDZ;
+    for (int n = tid / LDZ; n < TM; n += 256 / LDZ) {
+      float s = 0.f;
+      const int e1 = lrow[n + 1];
+      for (int e = lrow[n]; e < e1; ++e) {
+        const int2 en = lent[e];
+        s = fmaf(__int_as_float(en.y), Zs[en.x * LDZ + c], s);
+      }
+      Zd[n * LDZ + c] = s;
+    }
+  };
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    // ---- stage G slab, X slab and the transposed-CSR slice
+    if (gvec) {
+      constexpr int Q = LDZ / 4;
+      for (int idx = tid; idx < TM * Q; idx += 256) {
+        const int r = idx / Q, c = (idx - r * Q) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < R && gcol0 + c < p.hout) v = *reinterpret_cast<const f32x4*>(p.G + (size_t)(ts + r) * p.ldg + gcol0 + c);
+        *reinterpret_cast<f32x4*>(Za + r * LDZ + c) = v;
+      }
+    } else {
+      for (int idx = tid; idx < TM * LDZ; idx += 256) {
+        const int r = idx / LDZ, c = idx - r * LDZ;
+        Za[idx] = (r < R && gcol0 + c < p.hout) ? p.G[(size_t)(ts + r) * p.ldg + gcol0 + c] : 0.f;
+      }
+    }
+    if (xvec) {
+      constexpr int Q = XW / 4;
+      for (int idx = tid; idx < TM * Q; idx += 256) {
+        const int r = idx / Q, c = (idx - r * Q) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < R && xcol0 + c < p.hin) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + xcol0 + c);
+        *reinterpret_cast<f32x4*>(Xs + r * XW + c) = v;
+      }
+    } else {
+      for (int idx = tid; idx < TM * XW; idx += 256) {
+        const int r = idx / XW, c = idx - r * XW;
+        Xs[idx] = (r < R && xcol0 + c < p.hin) ? p.X[(size_t)(ts + r) * p.ldx + xcol0 + c] : 0.f;
+      }
+    }
+    if (NMAT > 1) {
+      const int base = p.rowptrT[ts];
+      const int nnz = p.rowptrT[ts + R] - base;
+      for (int r = tid; r <= TM; r += 256) lrow[r] = (r <= R) ? (p.rowptrT[ts + r] - base) : nnz;
+      for (int k = tid; k < nnz; k += 256) lent[k] = make_int2(p.colT[base + k] - ts, __float_as_int(p.wT[base + k]));
+    }
+    __syncthreads();
+    // ---- bias gradient (column sums of G), only by the ibg == 0 slice
+    if (ibg == 0 && tid < LDZ) {
+      float s = 0.f;
+      if (p.rowscale) {
+        for (int r = 0; r < R; ++r) s = fmaf(Za[r * LDZ + tid], p.rowscale[ts + r], s);
+      } else {
+        for (int r = 0; r < R; ++r) s += Za[r * LDZ + tid];
+      }
+      dbacc += s;
+    }
+    // ---- m = 0 .. NMAT-1, ping-pong propagation
+    mma(Za, acc[0], R);
+    if (NMAT > 1) {
+      prop(Za, Zb);
+      __syncthreads();
+      mma(Zb, acc[1 % NMAT], R);
+    }
+    if (NMAT > 2) {
+      prop(Zb, Za);
+      __syncthreads();
+      mma(Za, acc[2 % NMAT], R);
+    }
+    if (NMAT > 3) {
+      prop(Za, Zb);
+      __syncthreads();
+      mma(Zb, acc[3 % NMAT], R);
+    }
+    __syncthreads();
+  }
+
+  // ---- one slab per workgroup column blockIdx.x; the y-slices tile the [nmat*hout, hin] matrix
+  const size_t stride = (size_t)p.nmat * p.hout * p.hin + p.hout;
+  float* out = p.slab + (size_t)blockIdx.x * stride;
+  if (wave_active) {
+    const int i = xcol0 + wave * 32 + c32;
+    if (i < p.hin) {
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = gcol0 + ob * 32 + acc_row(r, half);
+            if (o < p.hout) out[((size_t)m * p.hout + o) * p.hin + i] = acc[m][ob][r];
+          }
+    }
+  }
+  if (ibg == 0 && tid < LDZ && gcol0 + tid < p.hout) out[(size_t)p.nmat * p.hout * p.hin + gcol0 + tid] = dbacc;
+}
+
+static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz) {
+  const size_t TM = (size_t)nrb * 32;
+  size_t b = TM * (size_t)nb * 32 * 4 * (nmat > 1 ? 2 : 1) + TM * XW * 4;
+  if (nmat > 1) b += (TM + 2) * 4 + (size_t)max_nnz * 8;
+  return b;
+}
+
+static int pick_nb(int nrb, int nmat, int hout, int max_nnz) {
+  const int nob = (hout + 31) / 32;
+  for (int nb = 4; nb >= 1; nb >>= 1) {
+    if (nb > 1 && nb / 2 >= nob) continue;  // do not over-allocate columns
+    if (wgrad_lds(nrb, nmat, nb, max_nnz) <= (size_t)kMaxLdsBytes) return nb;
+  }
+  return 0;
+}
+
+template <int NRB, int NMAT, int NB>
+static int launch_wgrad(const dss2_wgrad_args& a, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = wgrad_kernel<NRB, NMAT, NB>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
+    if (e != hipSuccess) { set_error("wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
+    attr_set = true;
+  }
+  const int nob = (a.hout + 31) / 32, nib = (a.hin + 31) / 32;
+  const int nobg = (nob + NB - 1) / NB, nibg = (nib + 3) / 4;
+  const size_t lds = wgrad_lds(NRB, NMAT, NB, a.max_nnz);
+  hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg), dim3(256), lds, stream, a, nibg);
+  return check_launch("wgrad");
+}
+
+}  // namespace dss2
+
+extern "C" size_t dss2_wgrad_lds_bytes(int nrb, int nmat, int hout, int hin, int max_nnz) {
+  (void)hin;
+  const int nb = dss2::pick_nb(nrb, nmat, hout, max_nnz);
+  return nb ? dss2::wgrad_lds(nrb, nmat, nb, max_nnz) : (size_t)-1;
+}
+
+extern "C" int dss2_wgrad(const dss2_wgrad_args* ap, void* stream) {
+  using namespace dss2;
+  const dss2_wgrad_args& a = *ap;
+  if (a.n_split <= 0 || !a.slab) { set_error("wgrad: n_split/slab missing"); return 2; }
+  if (a.nmat > 1 && (!a.rowptrT || !a.colT || !a.wT)) { set_error("wgrad: nmat > 1 needs the transposed CSR"); return 2; }
+  const int nb = pick_nb(a.nrb, a.nmat, a.hout, a.max_nnz);
+  if (!nb) { set_error("wgrad: tile of %d rows does not fit LDS (nmat=%d nnz=%d)", a.nrb * 32, a.nmat, a.max_nnz); return 3; }
+  hipStream_t s = as_stream(stream);
+#define DSS2_CASE(NRB, NMAT, NB) \
+  if (a.nrb == NRB && a.nmat == NMAT && nb == NB) return launch_wgrad<NRB, NMAT, NB>(a, s);
+#define DSS2_NMATS(NRB, NB) DSS2_CASE(NRB, 1, NB) DSS2_CASE(NRB, 2, NB) DSS2_CASE(NRB, 3, NB) DSS2_CASE(NRB, 4, NB)
+  DSS2_NMATS(1, 1) DSS2_NMATS(1, 2) DSS2_NMATS(1, 4)
+  DSS2_NMATS(2, 1) DSS2_NMATS(2, 2) DSS2_NMATS(2, 4)
+  DSS2_NMATS(3, 1) DSS2_NMATS(3, 2) DSS2_NMATS(3, 4)
+  DSS2_NMATS(4, 1) DSS2_NMATS(4, 2) DSS2_NMATS(4, 4)
+  DSS2_NMATS(6, 1) DSS2_NMATS(6, 2)
+#undef DSS2_NMATS
+#undef DSS2_CASE
+  set_error("wgrad: unsupported (nrb=%d, nmat=%d, nb=%d)", a.nrb, a.nmat, nb);
+  return 2;
+}

@@ -1,0 +1,137 @@
+"""Drop-in for the hot-path functions of the reference's ``data.py`` on hand-written HIP kernels:
+
+    gsp_wls_edge(input, edge_input, output, x_mean, x_std, edge_mean, edge_std, edge_index,
+                 reg_coefs, num_samples, node_param, edge_param)     /root/reference/data.py:393-459
+    get_pflow(y, edge_index, node_param, edge_param, phase_shift=True)  /root/reference/data.py:328-390
+
+Same keyword names as the call sites /root/reference/dss2_run.py:140,193-194.  Preserved
+behaviour: masks are ``!= 0`` on the normalised inputs; ``output[:, 1]`` is zeroed IN PLACE at
+slack buses (data.py:413); ``phase_shift=True`` means shift = 0; trafo flag = ceil(phase shift);
+batch-global V_hv / V_lv; penalties are squares of batch means; ``mu_v``, ``mu_theta`` and
+``num_samples`` are accepted and unused.  NOT reproduced: the unused dense Laplacian of
+data.py:422-423 (O(N^2) memory, no effect on the result).
+
+Data-parallel use: ``gsp_wls_edge(..., group=pg)`` all-reduces the five batch sums and the node /
+edge counts over the process group between the two kernel phases, which gives exactly the
+single-process loss and gradient of the GLOBAL batch.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .networks import _F32, _require_gpu, _rows, _stream
+from .topology import Topology, get_topology
+
+_N_PARTIAL_BLOCKS = 5
+
+
+def _vec(t: torch.Tensor, n: int, device) -> torch.Tensor:
+    t = t.to(device=device, dtype=_F32).contiguous()
+    if t.numel() < n:
+        raise ValueError(f"expected at least {n} statistics, got {t.numel()}")
+    return t
+
+
+def _fill_args(topo: Topology, input, edge_input, output, node_param, edge_param, x_mean, x_std, edge_mean, edge_std,
+               reg_coefs, bufs) -> "_lib.WlsArgs":
+    a = _lib.WlsArgs()
+    a.input, a.ld_in = input[0].data_ptr(), input[1]
+    a.edge_input, a.ld_ein = edge_input[0].data_ptr(), edge_input[1]
+    a.output, a.ld_out = output[0].data_ptr(), output[1]
+    a.node_param, a.ld_np = node_param[0].data_ptr(), node_param[1]
+    a.edge_param, a.ld_ep = edge_param[0].data_ptr(), edge_param[1]
+    a.x_mean, a.x_std, a.edge_mean, a.edge_std = x_mean.data_ptr(), x_std.data_ptr(), edge_mean.data_ptr(), edge_std.data_ptr()
+    a.efrom, a.eto = topo.efrom.data_ptr(), topo.eto.data_ptr()
+    a.inc_rowptr, a.inc_ent = topo.inc_rowptr.data_ptr(), topo.inc_ent.data_ptr()
+    a.n_nodes, a.n_edges = topo.N, topo.E
+    a.lam_v, a.lam_p, a.lam_pf, a.lam_reg = (float(reg_coefs[k]) for k in ("lam_v", "lam_p", "lam_pf", "lam_reg"))
+    a.sums, a.partials, a.vminmax = bufs["sums"].data_ptr(), bufs["partials"].data_ptr(), bufs["vminmax"].data_ptr()
+    a.apq, a.loss, a.grad_output = bufs["apq"].data_ptr(), bufs["loss"].data_ptr(), bufs["grad"].data_ptr()
+    a.pflow = None
+    return a
+
+
+class _WlsFn(torch.autograd.Function):
+    """loss, output = f(output): `output` is modified in place (theta masked) and marked dirty."""
+
+    @staticmethod
+    def forward(ctx, output, topo, tensors, reg_coefs, group):
+        input, edge_input, node_param, edge_param, x_mean, x_std, edge_mean, edge_std = tensors
+        ctx.set_materialize_grads(False)
+        dev = output.device
+        N = topo.N
+        if output.dim() != 2 or output.size(1) != 2 or output.stride(1) != 1:
+            raise ValueError("output must be [N, 2] with unit column stride")
+        nb = (N + 255) // 256
+        bufs = {
+            "sums": torch.empty(8, dtype=torch.float64, device=dev),
+            "partials": torch.empty(nb * 5, dtype=torch.float64, device=dev),
+            "vminmax": torch.empty(2, dtype=_F32, device=dev),
+            "apq": torch.empty(N, 2, dtype=_F32, device=dev),
+            "loss": torch.empty(1, dtype=_F32, device=dev),
+            "grad": torch.empty(N, 2, dtype=_F32, device=dev),
+        }
+        a = _fill_args(topo, input, edge_input, (output, output.stride(0)), node_param, edge_param,
+                       x_mean, x_std, edge_mean, edge_std, reg_coefs, bufs)
+        st = _stream(output)
+        L = _lib.lib()
+        _lib.check(L.dss2_wls_loss_partials(C.byref(a), st), "dss2_wls_loss_partials")
+        if group is not None:   # global-batch sums and counts (exact data-parallel loss)
+            import torch.distributed as dist
+            dist.all_reduce(bufs["sums"], op=dist.ReduceOp.SUM, group=group)
+        _lib.check(L.dss2_wls_loss_grad(C.byref(a), st), "dss2_wls_loss_grad")
+        ctx.mark_dirty(output)
+        ctx.save_for_backward(bufs["grad"])
+        ctx.keep = (bufs, tensors)   # keep scratch alive until the kernels have run
+        return bufs["loss"].reshape(()), output
+
+    @staticmethod
+    def backward(ctx, gloss, gout_unused):
+        (grad,) = ctx.saved_tensors
+        g = grad * gloss if gloss is not None else None
+        if gloss is None:
+            g = torch.zeros_like(grad)
+        if gout_unused is not None:   # other consumers of the (masked) output
+            g = g + gout_unused
+        return g, None, None, None, None
+
+
+def gsp_wls_edge(input, edge_input, output, x_mean, x_std, edge_mean, edge_std, edge_index, reg_coefs,
+                 num_samples=None, node_param=None, edge_param=None, group=None):
+    """/root/reference/data.py:393-459.  Returns a 0-dim loss attached to autograd; zeroes
+    ``output[:, 1]`` at slack buses in place like the reference."""
+    _require_gpu(input, edge_input, output, node_param, edge_param, edge_index)
+    dev = output.device
+    topo = get_topology(edge_index, input.size(0))
+    tensors = (_rows(input), _rows(edge_input), _rows(node_param), _rows(edge_param),
+               _vec(x_mean, 8, dev), _vec(x_std, 8, dev), _vec(edge_mean, 4, dev), _vec(edge_std, 4, dev))
+    for k in ("lam_v", "lam_p", "lam_pf", "lam_reg"):
+        if k not in reg_coefs:
+            raise KeyError(f"reg_coefs['{k}'] missing")
+    loss, _ = _WlsFn.apply(output, topo, tensors, dict(reg_coefs), group)
+    return loss
+
+
+def get_pflow(y, edge_index, node_param, edge_param, phase_shift=True):
+    """/root/reference/data.py:328-390: (loading_lines, loading_trafo, P_from, Q_from, P_to, Q_to,
+    I_from, I_to) per stored edge.  Forward only (the reference uses it under no_grad for the
+    evaluation metrics, dss2_run.py:193-194; the training path differentiates it inside
+    gsp_wls_edge)."""
+    if not phase_shift:
+        raise NotImplementedError("phase_shift=False (shift = edge_param[:, 5]) is never used by the reference driver")
+    _require_gpu(y, edge_index, node_param, edge_param)
+    y2, ldy = _rows(y.detach())
+    npar, ld_np = _rows(node_param)
+    epar, ld_ep = _rows(edge_param)
+    topo = get_topology(edge_index, y.size(0))
+    dev = y.device
+    vmm = torch.empty(2, dtype=_F32, device=dev)
+    pf = torch.empty(topo.E, 8, dtype=_F32, device=dev)
+    _lib.check(_lib.lib().dss2_get_pflow(y2.data_ptr(), ldy, npar.data_ptr(), ld_np, epar.data_ptr(), ld_ep,
+                                         topo.efrom.data_ptr(), topo.eto.data_ptr(), topo.N, topo.E, vmm.data_ptr(),
+                                         pf.data_ptr(), _stream(y)), "dss2_get_pflow")
+    return tuple(pf[:, k] for k in range(8))

@@ -1,0 +1,539 @@
+"""Drop-in for the hot-path classes of the reference's ``networks.py``, on hand-written HIP kernels.
+
+Same names, constructor arguments, ``forward(x, edge_index, edge_attr)`` signatures and
+``state_dict`` keys as /root/reference/networks.py:159-388:
+
+    EdgeAggregation(dim_featn, dim_feate, dim_hid, dim_out)            networks.py:159-209
+    MPN / SkipMPN(dim_featn, dim_feate, dim_out, dim_hid, n_gnn_layers, K, dropout_rate)
+                                                                       networks.py:212-338
+    PFN / SkipPFN(..., L)                                              networks.py:340-388
+    TAGConv(in_channels, out_channels, K)       PyG's operator as used at networks.py:230-234
+
+All compute runs in libdss2_hip.so (include/dss2_hip.h) through ctypes; tensors must be fp32 on a
+gfx950 device.  There is no CPU or eager-PyTorch fallback: CPU tensors raise.
+
+Preserved reference behaviour: concat order [x_i | x_j | edge_attr]; first-edge-only
+``is_directed``; reverse edges with edge_attr columns 0 and 2 negated; no self loops; dropout
+applied in ``eval()`` too (a fresh nn.Dropout is built inside forward, networks.py:268); ReLU after
+dropout; no activation after the last conv; SkipMPN's residual.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .topology import Topology, get_topology
+
+_F32 = torch.float32
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _require_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("DSS2 HIP path needs GPU tensors (gfx950); there is no CPU fallback")
+        if t.is_floating_point() and t.dtype != _F32:
+            raise TypeError("DSS2 HIP path computes in fp32; got " + str(t.dtype))
+
+
+def _rows(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """A 2-D fp32 tensor usable with an explicit leading dimension (column slices of a row-major
+    matrix are fine); anything else is made contiguous."""
+    if t.dim() != 2:
+        raise ValueError("expected a 2-D tensor")
+    if t.stride(1) != 1 or (t.size(0) > 1 and t.stride(0) < t.size(1)):
+        t = t.contiguous()
+    return t, (t.stride(0) if t.size(0) > 1 else t.size(1))
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _round8(k: int) -> int:
+    return (k + 7) // 8 * 8
+
+
+def _ncg(j: int) -> int:
+    return (j + 31) // 32
+
+
+# ------------------------------------------------------------------------------------------
+# thin op wrappers over the C ABI
+# ------------------------------------------------------------------------------------------
+def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.Tensor, nmat: int, hout: int,
+              Y: torch.Tensor, bias=None, rowscale=None, relu_src=None, dmask=None, add_src=None, add_ld=0,
+              relu: bool = False, transposed: bool = False) -> None:
+    a = _lib.GemmPropArgs()
+    a.X, a.ldx, a.kreal, a.kpad = X.data_ptr(), ldx, kreal, _round8(kreal)
+    a.Bp, a.bias, a.rowscale = Bp.data_ptr(), _ptr(bias), _ptr(rowscale)
+    a.relu_src, a.ld_relu = _ptr(relu_src), (relu_src.stride(0) if relu_src is not None else 0)
+    a.dmask, a.ld_dmask = _ptr(dmask), (dmask.stride(0) if dmask is not None else 0)
+    a.add_src, a.ld_add = _ptr(add_src), add_ld
+    a.Y, a.ldy, a.hout, a.ncg = Y.data_ptr(), Y.stride(0), hout, _ncg(hout)
+    a.relu, a.nmat, a.nrb, a.ntiles = int(relu), nmat, topo.nrb, topo.ntiles
+    a.tile_start = topo.tile_start.data_ptr()
+    if transposed:
+        a.rowptr, a.col, a.w, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
+    else:
+        a.rowptr, a.col, a.w, a.max_nnz = topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.w.data_ptr(), topo.max_nnz
+    _lib.check(_lib.lib().dss2_gemm_prop(C.byref(a), _stream(Y)), "dss2_gemm_prop")
+
+
+def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int, nmat: int, out_flat: torch.Tensor,
+          rowscale=None) -> None:
+    """out_flat[nmat*hout*hin + hout] <- [dW_0 .. dW_{nmat-1}, db] (deterministic two-pass sum)."""
+    n_split = min(topo.ntiles, 256)
+    stride = nmat * hout * hin + hout
+    slab = torch.empty(n_split * stride, dtype=_F32, device=G.device)
+    a = _lib.WgradArgs()
+    a.G, a.ldg, a.hout = G.data_ptr(), G.stride(0), hout
+    a.X, a.ldx, a.hin = X.data_ptr(), X.stride(0), hin
+    a.rowscale = _ptr(rowscale)
+    a.slab, a.n_split, a.nmat, a.nrb, a.ntiles = slab.data_ptr(), n_split, nmat, topo.nrb, topo.ntiles
+    a.tile_start = topo.tile_start.data_ptr()
+    a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
+    st = _stream(G)
+    _lib.check(_lib.lib().dss2_wgrad(C.byref(a), st), "dss2_wgrad")
+    _lib.check(_lib.lib().dss2_reduce_slabs(slab.data_ptr(), n_split, stride, out_flat.data_ptr(), stride, st),
+               "dss2_reduce_slabs")
+
+
+def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, ent: torch.Tensor, n_rows: int) -> torch.Tensor:
+    """K6: out[i] = sum of msg rows listed in CSR row i (the scatter-add of aggr='add')."""
+    _require_gpu(msg)
+    msg, ldm = _rows(msg)
+    out = torch.empty(n_rows, msg.size(1), dtype=_F32, device=msg.device)
+    _lib.check(_lib.lib().dss2_segment_sum(msg.data_ptr(), ldm, rowptr.data_ptr(), ent.data_ptr(), out.data_ptr(),
+                                           out.stride(0), n_rows, msg.size(1), _stream(msg)), "dss2_segment_sum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# weight packing plans
+# ------------------------------------------------------------------------------------------
+_DESC_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("ld", "<i4"),
+                        ("transpose", "<i4"), ("koff", "<i4"), ("kpad", "<i4"), ("ncg", "<i4"), ("pad_", "<i4")])
+
+
+class _PackPlan:
+    """Fragment-packed copies (forward and data-gradient layouts) of a list of weight matrices,
+    refreshed by ONE kernel launch per forward."""
+
+    def __init__(self, groups: Sequence[Sequence[torch.Tensor]], device):
+        # groups[g] = the nmat matrices [hout, hin] of one fused GEMM (TAGConv lins, or one Linear)
+        self.groups = groups
+        self.device = device
+        self.fwd, self.bwd, self.meta = [], [], []
+        for mats in groups:
+            hout, hin = mats[0].shape
+            nm = len(mats)
+            kf, cf = _round8(hin), _ncg(hout)
+            kb, cb = _round8(hout), _ncg(hin)
+            self.fwd.append(torch.zeros(nm * cf * (kf // 8) * 256, dtype=_F32, device=device))
+            self.bwd.append(torch.zeros(nm * cb * (kb // 8) * 256, dtype=_F32, device=device))
+            self.meta.append((nm, hout, hin, kf, cf, kb, cb))
+        self.ptrs = None
+        self.table = None
+        self.max_elems = 0
+        self.version = 0
+
+    def _build_table(self):
+        recs = []
+        for g, mats in enumerate(self.groups):
+            nm, hout, hin, kf, cf, kb, cb = self.meta[g]
+            for m, w in enumerate(mats):
+                if not w.is_contiguous():
+                    raise RuntimeError("weight matrices must be contiguous")
+                recs.append((w.data_ptr(), self.fwd[g].data_ptr() + 4 * m * cf * (kf // 8) * 256, hout, hin, hin, 1, 0, kf, cf, 0))
+                recs.append((w.data_ptr(), self.bwd[g].data_ptr() + 4 * m * cb * (kb // 8) * 256, hout, hin, hin, 0, 0, kb, cb, 0))
+                self.max_elems = max(self.max_elems, cf * (kf // 8) * 64, cb * (kb // 8) * 64)
+        arr = np.array(recs, dtype=_DESC_DTYPE)
+        self.n_desc = len(recs)
+        self.table = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
+
+    def refresh(self):
+        ptrs = tuple(w.data_ptr() for mats in self.groups for w in mats)
+        if ptrs != self.ptrs:
+            self._build_table()
+            self.ptrs = ptrs
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().dss2_pack_weights(self.table.data_ptr(), self.n_desc, self.max_elems, st), "dss2_pack_weights")
+        self.version += 1
+        return self.version
+
+
+# ------------------------------------------------------------------------------------------
+# functional pieces (raw tensors in, raw tensors out); used by the autograd Functions below
+# ------------------------------------------------------------------------------------------
+def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hout, fn, fe):
+    N = topo.N
+    S = torch.empty(N, hid, dtype=_F32, device=W1.device)
+    _lib.check(_lib.lib().dss2_edge_hidden_fwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(),
+                                               topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(),
+                                               S.data_ptr(), N, hid, fn, fe, _stream(S)), "dss2_edge_hidden_fwd")
+    x0 = torch.empty(N, hout, dtype=_F32, device=W1.device)
+    # second Linear of the edge MLP after the (linear) aggregation: sum_e (W2 h_e + b2) = W2 S + deg b2
+    gemm_prop(topo, S, hid, hid, pack_w2_fwd, 1, hout, x0, bias=b2, rowscale=topo.deg)
+    return S, x0
+
+
+def _edge_aggr_backward(topo, gx0, x, ldx, ea, ldea, W1, b1, S, pack_w2_bwd, hid, hout, fn, fe, g_w1, g_w2, need_dx):
+    """g_w1: flat [hid*(2fn+fe) + hid] <- dW1, db1;  g_w2: flat [hout*hid + hout] <- dW2, db2.
+    Returns dx [N, fn] or None."""
+    N = topo.N
+    dev = gx0.device
+    wgrad(topo, gx0, hout, S, hid, 1, g_w2, rowscale=topo.deg)
+    dS = torch.empty(N, hid, dtype=_F32, device=dev)
+    gemm_prop(topo, gx0, gx0.stride(0), hout, pack_w2_bwd, 1, hid, dS)
+    n_slabs = int(min(512, max(1, (N + 15) // 16)))
+    stride = hid * (2 * fn + fe) + hid
+    slab = torch.empty(n_slabs * stride, dtype=_F32, device=dev)
+    U = torch.empty(N, 2 * hid, dtype=_F32, device=dev) if need_dx else None
+    st = _stream(gx0)
+    L = _lib.lib()
+    _lib.check(L.dss2_edge_hidden_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
+                                      topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(), slab.data_ptr(),
+                                      n_slabs, _ptr(U), 2 * hid, N, hid, fn, fe, 0, st), "dss2_edge_hidden_bwd")
+    _lib.check(L.dss2_reduce_slabs(slab.data_ptr(), n_slabs, stride, g_w1.data_ptr(), stride, st), "dss2_reduce_slabs")
+    if not need_dx:
+        return None
+    # U[:, :hid] = sum of dz over incoming edges (x enters as x_i), U[:, hid:] over outgoing (as x_j)
+    _lib.check(L.dss2_edge_hidden_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
+                                      topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.entT.data_ptr(), None,
+                                      n_slabs, U.data_ptr() + 4 * hid, 2 * hid, N, hid, fn, fe, 1, st), "dss2_edge_hidden_bwd")
+    # dx = U[:, :hid] @ W1[:, :fn] + U[:, hid:] @ W1[:, fn:2fn]   (tiny K=2*hid -> fn GEMM on the same kernel)
+    Wcat = torch.cat([W1[:, :fn], W1[:, fn:2 * fn]], dim=0).contiguous()      # [2*hid, fn]
+    plan = _PackPlan([[Wcat]], dev)
+    plan.refresh()
+    dx = torch.empty(N, fn, dtype=_F32, device=dev)
+    gemm_prop(topo, U, 2 * hid, 2 * hid, plan.bwd[0], 1, fn, dx)
+    return dx
+
+
+def _tagconv_forward(topo, h, pack_fwd, bias, nmat, hin, hout, dmask=None, relu=False, add_src=None, add_ld=0):
+    out = torch.empty(topo.N, hout, dtype=_F32, device=h.device)
+    gemm_prop(topo, h, h.stride(0), hin, pack_fwd, nmat, hout, out, bias=bias, dmask=dmask, relu=relu,
+              add_src=add_src, add_ld=add_ld)
+    return out
+
+
+def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=None, dmask=None, need_dh=True):
+    """g: gradient w.r.t. the conv's pre-activation output [N, hout] (already masked).
+    g_flat <- [dW_0..dW_K, db]; returns dh (masked by relu_src / dmask of the PREVIOUS layer)."""
+    wgrad(topo, g, hout, h, hin, nmat, g_flat)
+    if not need_dh:
+        return None
+    dh = torch.empty(topo.N, hin, dtype=_F32, device=g.device)
+    gemm_prop(topo, g, g.stride(0), hout, pack_bwd, nmat, hin, dh, relu_src=relu_src, dmask=dmask, transposed=True)
+    return dh
+
+
+# ------------------------------------------------------------------------------------------
+# modules
+# ------------------------------------------------------------------------------------------
+class MessagePassing(nn.Module):
+    """Minimal stand-in for PyG's base class so ``EdgeAggregation`` keeps its shape: the
+    gather -> message -> scatter-add engine itself is the fused HIP path, not Python."""
+
+    def __init__(self, aggr: str = "add"):
+        super().__init__()
+        if aggr != "add":
+            raise NotImplementedError("only aggr='add' is built")
+        self.aggr = aggr
+
+    def propagate(self, edge_index, **kwargs):
+        raise NotImplementedError("propagate() is fused into the HIP kernels; call forward()")
+
+
+class TAGConv(nn.Module):
+    """PyG TAGConv(in, out, K, bias=True, normalize=True) on the fused HIP kernel.
+    state_dict keys: ``bias``, ``lins.k.weight`` (k = 0..K)."""
+
+    def __init__(self, in_channels: int, out_channels: int, K: int = 3):
+        super().__init__()
+        if not 0 <= K <= 3:
+            raise NotImplementedError("TAGConv on HIP supports K in 0..3")
+        self.in_channels, self.out_channels, self.K = in_channels, out_channels, K
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.lins = nn.ModuleList([nn.Linear(in_channels, out_channels, bias=False) for _ in range(K + 1)])
+        self._plan = None
+
+    def _weights(self):
+        return [l.weight for l in self.lins]
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+        _require_gpu(x, edge_index)
+        topo = get_topology_asis(edge_index, x.size(0))
+        return _TAGConvFn.apply(x, topo, self, self.bias, *self._weights())
+
+
+class _TAGConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, topo, mod, bias, *ws):
+        x = x.contiguous()
+        if mod._plan is None or mod._plan.device != x.device:
+            mod._plan = _PackPlan([list(ws)], x.device)
+        plan = mod._plan
+        ctx.ver = plan.refresh()
+        hin, hout, nmat = mod.in_channels, mod.out_channels, mod.K + 1
+        topo.lds_check(nmat, _round8(hin), _ncg(hout))
+        out = _tagconv_forward(topo, x, plan.fwd[0], bias, nmat, hin, hout)
+        ctx.save_for_backward(x)
+        ctx.topo, ctx.mod = topo, mod
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (x,) = ctx.saved_tensors
+        mod, topo, plan = ctx.mod, ctx.topo, ctx.mod._plan
+        if plan.version != ctx.ver:
+            plan.refresh()
+        hin, hout, nmat = mod.in_channels, mod.out_channels, mod.K + 1
+        g = gout.contiguous()
+        flat = torch.empty(nmat * hout * hin + hout, dtype=_F32, device=g.device)
+        dh = _tagconv_backward(topo, g, x, plan.bwd[0], nmat, hin, hout, flat, need_dh=ctx.needs_input_grad[0])
+        gw = [flat[m * hout * hin:(m + 1) * hout * hin].view(hout, hin) for m in range(nmat)]
+        gb = flat[nmat * hout * hin:]
+        return (dh, None, None, gb, *gw)
+
+
+class EdgeAggregation(MessagePassing):
+    """/root/reference/networks.py:159-209 on HIP.  ``forward`` takes the edge list AS GIVEN
+    (the reference's MPN hands it the already doubled list)."""
+
+    def __init__(self, dim_featn, dim_feate, dim_hid, dim_out):
+        super().__init__(aggr="add")
+        self.dim_featn, self.dim_feate, self.dim_hid, self.dim_out = dim_featn, dim_feate, dim_hid, dim_out
+        self.edge_aggr = nn.Sequential(nn.Linear(dim_featn * 2 + dim_feate, dim_hid), nn.ReLU(),
+                                       nn.Linear(dim_hid, dim_out))
+        self._plan = None
+
+    def message(self, x_i, x_j, edge_attr):
+        raise NotImplementedError("message() is fused into the HIP kernel (dss2_edge_hidden_fwd)")
+
+    def forward(self, x, edge_index, edge_attr):
+        _require_gpu(x, edge_index, edge_attr)
+        topo = get_topology_asis(edge_index, x.size(0))
+        lin1, lin2 = self.edge_aggr[0], self.edge_aggr[2]
+        return _EdgeAggrFn.apply(x, edge_attr, topo, self, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+
+
+class _EdgeAggrFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ea, topo, mod, W1, b1, W2, b2):
+        x, ldx = _rows(x)
+        ea, ldea = _rows(ea)
+        if mod._plan is None or mod._plan.device != x.device:
+            mod._plan = _PackPlan([[W2]], x.device)
+        ctx.ver = mod._plan.refresh()
+        topo.lds_check(1, _round8(mod.dim_hid), _ncg(mod.dim_out))
+        S, x0 = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, mod._plan.fwd[0], mod.dim_hid, mod.dim_out,
+                                   mod.dim_featn, mod.dim_feate)
+        ctx.save_for_backward(x, ea, S, W1, b1)
+        ctx.topo, ctx.mod, ctx.ld = topo, mod, (ldx, ldea)
+        return x0
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ea, S, W1, b1 = ctx.saved_tensors
+        mod, topo = ctx.mod, ctx.topo
+        if mod._plan.version != ctx.ver:
+            mod._plan.refresh()
+        hid, hout, fn, fe = mod.dim_hid, mod.dim_out, mod.dim_featn, mod.dim_feate
+        g = g.contiguous()
+        g1 = torch.empty(hid * (2 * fn + fe) + hid, dtype=_F32, device=g.device)
+        g2 = torch.empty(hout * hid + hout, dtype=_F32, device=g.device)
+        dx = _edge_aggr_backward(topo, g, x, ctx.ld[0], ea, ctx.ld[1], W1, b1, S, mod._plan.bwd[0], hid, hout, fn, fe,
+                                 g1, g2, ctx.needs_input_grad[0])
+        nc = 2 * fn + fe
+        return (dx, None, None, None, g1[:hid * nc].view(hid, nc), g1[hid * nc:], g2[:hout * hid].view(hout, hid),
+                g2[hout * hid:])
+
+
+_asis_cache = {}
+
+
+def get_topology_asis(edge_index: torch.Tensor, num_nodes: int) -> Topology:
+    """Topology of an edge list used exactly as given (standalone EdgeAggregation / TAGConv)."""
+    from . import topology as _t
+    if not edge_index.is_cuda:
+        raise RuntimeError("DSS2 HIP path: edge_index must live on the GPU (there is no CPU fallback)")
+    key = (edge_index.device.index, int(num_nodes), int(edge_index.size(1)), _t.content_hash(edge_index))
+    topo = _asis_cache.get(key)
+    if topo is None:
+        if len(_asis_cache) >= 16:
+            _asis_cache.pop(next(iter(_asis_cache)))
+        topo = _asis_cache[key] = Topology(edge_index, num_nodes, double=False)
+    return topo
+
+
+class MPN(nn.Module):
+    """/root/reference/networks.py:212-273 on HIP (one autograd node for the whole block)."""
+
+    skip = False
+
+    def __init__(self, dim_featn, dim_feate, dim_out, dim_hid, n_gnn_layers, K, dropout_rate):
+        super().__init__()
+        self.dim_featn, self.dim_feate, self.dim_out, self.dim_hid = dim_featn, dim_feate, dim_out, dim_hid
+        self.n_gnn_layers, self.K, self.dropout_rate = n_gnn_layers, K, dropout_rate
+        if self.skip and dim_out != dim_featn:
+            raise ValueError("SkipMPN needs dim_out == dim_featn (networks.py:336)")
+        self.edge_aggr = EdgeAggregation(dim_featn, dim_feate, dim_hid, dim_hid)
+        self.convs = nn.ModuleList()
+        for l in range(n_gnn_layers):
+            self.convs.append(TAGConv(dim_hid, dim_out if l == n_gnn_layers - 1 else dim_hid, K=K))
+        self._plan = None
+
+    # -- reference helpers kept for API parity (networks.py:236-258); not used by forward()
+    def is_directed(self, edge_index):
+        from .topology import reference_is_directed
+        return reference_is_directed(edge_index)
+
+    def undirect_graph(self, edge_index, edge_attr):
+        if self.is_directed(edge_index):
+            edge_index = torch.cat([edge_index, torch.stack([edge_index[1, :], edge_index[0, :]], dim=0)], dim=1)
+            edge_attr = torch.cat([edge_attr, torch.cat([-edge_attr[:, 0:1], edge_attr[:, 1:2], -edge_attr[:, 2:3],
+                                                         edge_attr[:, 3:]], dim=1)], dim=0)
+        return edge_index, edge_attr
+
+    def _params(self) -> List[torch.Tensor]:
+        lin1, lin2 = self.edge_aggr.edge_aggr[0], self.edge_aggr.edge_aggr[2]
+        ps = [lin1.weight, lin1.bias, lin2.weight, lin2.bias]
+        for c in self.convs:
+            ps.append(c.bias)
+            ps.extend(l.weight for l in c.lins)
+        return ps
+
+    def forward(self, x, edge_index, edge_attr):
+        _require_gpu(x, edge_index, edge_attr)
+        topo = get_topology(edge_index, x.size(0))
+        return _MPNFn.apply(x, edge_attr, topo, self, *self._params())
+
+
+class SkipMPN(MPN):
+    """/root/reference/networks.py:275-338: MPN + ``input_x + x``."""
+
+    skip = True
+
+
+class _MPNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ea, topo, mod, *ps):
+        x, ldx = _rows(x)
+        ea, ldea = _rows(ea)
+        dev = x.device
+        L, nmat, hid = mod.n_gnn_layers, mod.K + 1, mod.dim_hid
+        W1, b1, W2, b2 = ps[0:4]
+        conv_ps = [ps[4 + l * (nmat + 1): 4 + (l + 1) * (nmat + 1)] for l in range(L)]   # (bias, W_0..W_K)
+        if mod._plan is None or mod._plan.device != dev:
+            mod._plan = _PackPlan([[W2]] + [list(cp[1:]) for cp in conv_ps], dev)
+        plan = mod._plan
+        ctx.ver = plan.refresh()
+        topo.lds_check(nmat, _round8(hid), _ncg(hid))
+        S, h = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, plan.fwd[0], hid, hid, mod.dim_featn, mod.dim_feate)
+        acts, masks = [h], []
+        p = float(mod.dropout_rate)
+        for l in range(L):
+            last = l == L - 1
+            hout = mod.dim_out if last else hid
+            dmask = None
+            if not last and p > 0.0:  # dropout is active regardless of .training (networks.py:268)
+                dmask = (torch.rand(topo.N, hout, device=dev) >= p).to(_F32).div_(1.0 - p) if p < 1.0 else \
+                    torch.zeros(topo.N, hout, device=dev)
+            masks.append(dmask)
+            h = _tagconv_forward(topo, h, plan.fwd[1 + l], conv_ps[l][0], nmat, hid, hout, dmask=dmask, relu=not last,
+                                 add_src=(x if (last and mod.skip) else None), add_ld=ldx)
+            if not last:
+                acts.append(h)
+        ctx.save_for_backward(x, ea, S, *acts, *[m for m in masks if m is not None], *ps)
+        ctx.meta = (topo, mod, ldx, ldea, len(acts), [m is not None for m in masks], [p_._version for p_ in ps])
+        return h
+
+    @staticmethod
+    def backward(ctx, gout):
+        topo, mod, ldx, ldea, n_acts, has_mask, versions = ctx.meta
+        saved = ctx.saved_tensors
+        x, ea, S = saved[0:3]
+        acts = list(saved[3:3 + n_acts])
+        n_masks = sum(has_mask)
+        mask_list = list(saved[3 + n_acts:3 + n_acts + n_masks])
+        ps = saved[3 + n_acts + n_masks:]
+        masks, it = [], iter(mask_list)
+        for hm in has_mask:
+            masks.append(next(it) if hm else None)
+        plan = mod._plan
+        if plan.version != ctx.ver:
+            plan.refresh()   # weights are checked unchanged by autograd's saved-tensor versioning
+        dev = gout.device
+        L, nmat, hid, fn, fe = mod.n_gnn_layers, mod.K + 1, mod.dim_hid, mod.dim_featn, mod.dim_feate
+        W1, b1 = ps[0], ps[1]
+        # one flat gradient buffer; parameter gradients are returned as views into it
+        sizes = [hid * (2 * fn + fe) + hid, hid * hid + hid]
+        for l in range(L):
+            hout = mod.dim_out if l == L - 1 else hid
+            sizes.append(nmat * hout * hid + hout)
+        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        flat = torch.empty(int(offs[-1]), dtype=_F32, device=dev)
+        g = gout.contiguous()
+        need_dx = ctx.needs_input_grad[0]
+        for l in range(L - 1, -1, -1):
+            hout = mod.dim_out if l == L - 1 else hid
+            seg = flat[offs[2 + l]:offs[3 + l]]
+            # dgrad epilogue applies the ReLU / dropout mask of the layer BELOW (its output is acts[l])
+            g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, hout, seg,
+                                  relu_src=(acts[l] if l > 0 else None), dmask=(masks[l - 1] if l > 0 else None))
+        dx = _edge_aggr_backward(topo, g, x, ldx, ea, ldea, W1, b1, S, plan.bwd[0], hid, hid, fn, fe,
+                                 flat[offs[0]:offs[1]], flat[offs[1]:offs[2]], need_dx)
+        if need_dx and mod.skip:
+            dx = dx + gout
+        hook = getattr(mod, "_grad_bucket_hook", None)
+        if hook is not None:      # data-parallel: all-reduce the flat bucket once (parallel.py)
+            hook(flat)
+        nc = 2 * fn + fe
+        g1, g2 = flat[offs[0]:offs[1]], flat[offs[1]:offs[2]]
+        grads = [g1[:hid * nc].view(hid, nc), g1[hid * nc:], g2[:hid * hid].view(hid, hid), g2[hid * hid:]]
+        for l in range(L):
+            hout = mod.dim_out if l == L - 1 else hid
+            seg = flat[offs[2 + l]:offs[3 + l]]
+            grads.append(seg[nmat * hout * hid:])                                     # bias
+            grads.extend(seg[m * hout * hid:(m + 1) * hout * hid].view(hout, hid) for m in range(nmat))
+        return (dx, None, None, None, *grads)
+
+
+class PFN(nn.Module):
+    """/root/reference/networks.py:340-363: L chained MPN blocks on the same edge inputs."""
+
+    inner = MPN
+
+    def __init__(self, dim_featn, dim_feate, dim_out, dim_hid, n_gnn_layers, K, dropout_rate, L):
+        super().__init__()
+        self.dim_featn, self.dim_feate, self.dim_out, self.dim_hid = dim_featn, dim_feate, dim_out, dim_hid
+        self.n_gnn_layers, self.K, self.dropout_rate, self.L = n_gnn_layers, K, dropout_rate, L
+        self.mpns = nn.ModuleList()
+        for l in range(L):
+            if l == L - 1:
+                self.mpns.append(MPN(dim_featn, dim_feate, dim_out, dim_hid, n_gnn_layers, K, dropout_rate))
+            else:
+                self.mpns.append(self.inner(dim_featn, dim_feate, dim_featn, dim_hid, n_gnn_layers, K, dropout_rate))
+
+    def forward(self, x, edge_index, edge_attr):
+        for m in self.mpns:
+            x = m(x, edge_index, edge_attr)
+        return x
+
+
+class SkipPFN(PFN):
+    """/root/reference/networks.py:365-388: SkipMPN blocks, last one a plain MPN."""
+
+    inner = SkipMPN

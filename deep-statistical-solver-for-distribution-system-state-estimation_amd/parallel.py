@@ -1,0 +1,98 @@
+"""Data-parallel host logic: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" for the CPU tests).  The reference is single-process; what is added here is
+exactly what sharding its batch needs:
+
+* graphs are independent, so a batch is cut into contiguous per-rank shards of whole graphs
+  (``shard_batch``) with no halo and no data-path collective in the message passing;
+* the loss is ``mean_nodes + mean_edges + lam_reg * (mean)^2 x 3`` over the GLOBAL batch
+  (/root/reference/data.py:450-455), so the five batch sums and the node / edge counts are
+  all-reduced between the two loss phases (``gsp_wls_edge(..., group=pg)``; 7 doubles);
+* every MPN block produces its parameter gradients in one flat fp32 bucket; the bucket is
+  all-reduced (SUM: each rank's loss is already normalised by the global counts) once per block
+  per step (``attach_grad_allreduce``) - a single latency-bound collective of 0.67 MB at C2/C4.
+
+These helpers are device agnostic (plain torch tensors + a process group), which is what lets the
+world_size-2 gloo tests exercise them on CPU.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Dict[str, int]:
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and initialise."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return {"rank": rank, "world": world, "local": local}
+
+
+def shard_bounds(num_graphs: int, rank: int, world: int):
+    """Contiguous, near-equal graph ranges [g0, g1) per rank."""
+    base, rem = divmod(num_graphs, world)
+    g0 = rank * base + min(rank, rem)
+    return g0, g0 + base + (1 if rank < rem else 0)
+
+
+def shard_batch(batch: Dict[str, object], rank: int, world: int) -> Dict[str, object]:
+    """Cut a collated batch (synthetic.make_batch layout, with 'graph_ptr') into this rank's whole
+    graphs; node indices are re-based to the shard.  Edges are assumed grouped by graph in graph
+    order (what PyG collation and synthetic.make_batch produce)."""
+    gp = batch["graph_ptr"]
+    g0, g1 = shard_bounds(int(batch["num_graphs"]), rank, world)
+    n0, n1 = int(gp[g0]), int(gp[g1])
+    ei = batch["edge_index"]
+    sel = (ei[0] >= n0) & (ei[0] < n1)
+    idx = sel.nonzero().flatten()
+    e0, e1 = (int(idx[0]), int(idx[-1]) + 1) if idx.numel() else (0, 0)
+    if idx.numel() != e1 - e0:
+        raise ValueError("edges of a rank's graphs are not contiguous in edge_index")
+    out = dict(batch)
+    out.update(x=batch["x"][n0:n1], y=batch["y"][n0:n1], edge_attr=batch["edge_attr"][e0:e1],
+               edge_index=(ei[:, e0:e1] - n0), num_graphs=g1 - g0, graph_ptr=gp[g0:g1 + 1] - n0)
+    return out
+
+
+def allreduce_loss_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
+    """sums[0..4] = batch sums, sums[5] = node count, sums[6] = edge count -> global values."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return sums
+
+
+def allreduce_flat_grads(flat: torch.Tensor, group=None) -> torch.Tensor:
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+def attach_grad_allreduce(model: torch.nn.Module, group=None) -> int:
+    """Install the flat-bucket all-reduce on every MPN block of `model` (MPN / SkipMPN themselves,
+    or the blocks inside PFN / SkipPFN).  Returns the number of blocks hooked."""
+    n = 0
+    for m in model.modules():
+        if hasattr(m, "convs") and hasattr(m, "edge_aggr") and hasattr(m, "_plan"):
+            m._grad_bucket_hook = (lambda flat, g=group: allreduce_flat_grads(flat, g))
+            n += 1
+    return n
+
+
+def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None) -> None:
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        for p in model.parameters():
+            dist.broadcast(p.data, src=src, group=group)

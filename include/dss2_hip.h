@@ -1,0 +1,197 @@
+/*
+ * dss2_hip.h -- C ABI of libdss2_hip.so: the MI355X (gfx950) kernels for the DSS2 hot path.
+ *
+ * The reference (TU-Delft-AI-Energy-Lab/Deep-Statistical-Solver-for-Distribution-System-State-
+ * Estimation) has no FFI layer: the path is PyTorch-eager Python (networks.py, data.py) on top of
+ * torch_geometric.  Each entry point below replaces a chain of ATen/PyG ops at the cited
+ * reference lines; the Python mirror of the reference interface (networks.MPN etc.,
+ * data.gsp_wls_edge / get_pflow) calls them through ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host; the caller (PyTorch's
+ *    caching allocator) owns every buffer, the library allocates nothing and keeps no state
+ *    except a thread-local error string;
+ *  - fp32 row-major matrices with an explicit leading dimension `ld*` (in floats), so the
+ *    reference's column slices (data.x[:, :8], data.edge_attr[:, 6:]) are passed without copies;
+ *  - all launches are asynchronous on `stream` (a hipStream_t passed as void*); no host sync;
+ *  - return 0 on success, non-zero on error; message via dss2_last_error().
+ *
+ * Graph structure ("topology", built once per distinct edge_index and cached by the caller):
+ *   directed edge list d in [0,E2): E2 = 2E when the reference's undirect_graph() doubles the
+ *   graph (networks.py:240-258; d >= E is the reverse of stored edge d-E with edge_attr columns
+ *   0 and 2 negated), else E2 = E.
+ *   CSR by target:  rowptr[N+1], col[E2] = source node, ent[E2] = stored edge id | flip<<31,
+ *                   w[E2] = gcn_norm weight deg^-1/2[src] * deg^-1/2[tgt]  (PyG TAGConv).
+ *   CSR by source (transpose): rowptrT, colT (= target node), entT, wT.
+ *   Within a row, entries are sorted by d (the order index_add visits them on the CPU).
+ *   tile_start[ntiles+1]: consecutive node ranges that contain only whole graphs (no edge
+ *   crosses a tile) with at most 32*nrb rows each; one workgroup processes one tile in LDS.
+ */
+#ifndef DSS2_HIP_H
+#define DSS2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* dss2_last_error(void);
+int dss2_version(void);
+
+/* ---- topology ------------------------------------------------------------------------- */
+
+/* 64-bit content hash of edge_index[2,E] (int64), position dependent, order of evaluation
+ * independent (integer sum), written to *hash_out (device).  Replaces nothing in the reference:
+ * it keys the CSR cache that replaces the per-call undirect_graph()/degree() work
+ * (networks.py:236-258, PyG gcn_norm).  hash_out must be zeroed by the caller. */
+int dss2_topology_hash(const int64_t* edge_index, int64_t n_elems, uint64_t* hash_out, void* stream);
+
+/* ---- K6: standalone CSR segmented sum (the scatter-add of MessagePassing aggr='add',
+ *      networks.py:164,206, measured on its own).  out[i,:] = sum_{e in row i} msg[ent[e],:]
+ *      `ent` holds row indices into msg (directed edge ids).  h % 4 == 0. */
+int dss2_segment_sum(const float* msg, int64_t ldm, const int32_t* rowptr, const int32_t* ent,
+                     float* out, int64_t ldo, int64_t n_rows, int h, void* stream);
+
+/* ---- weight packing: nn.Linear weights -> MFMA B-operand fragment order ----------------- */
+
+typedef struct dss2_pack_desc {
+  const float* src;   /* W, row-major [rows, cols] with leading dimension ld            */
+  float* dst;         /* packed matrix base: [ncg][kpad/8][64 lanes][4]                 */
+  int32_t rows, cols, ld;
+  int32_t transpose;  /* 1: B[k][j] = W[j][k] (forward, K=cols); 0: B[k][j] = W[k][j]   */
+  int32_t koff;       /* k offset of this block inside the packed matrix                */
+  int32_t kpad;       /* padded K of the packed matrix (multiple of 8)                  */
+  int32_t ncg;        /* number of 32-column groups of the packed matrix                */
+  int32_t pad_;
+} dss2_pack_desc;
+
+/* descs: device array of n_desc descriptors.  dst regions must be zero-filled by the caller
+ * once when padding exists (kpad > K or 32*ncg > J); the kernel writes only in-range elements
+ * plus explicit zeros for padded lanes of the blocks it covers. */
+int dss2_pack_weights(const dss2_pack_desc* descs, int n_desc, int max_elems, void* stream);
+
+/* ---- K1: EdgeAggregation (networks.py:159-209) ------------------------------------------ */
+
+/* S[i,:] = sum_{e: tgt(e)=i} relu(W1 . [x_i | x_src(e) | ea'(e)] + b1)      (first Linear + ReLU
+ * of networks.py:170-174,181, aggregated before the second Linear, which is linear:
+ * out = S . W2^T + deg * b2 is finished by dss2_gemm_prop with nmat = 1).
+ * fn must be 8 and fe must be 6 (the only dims the reference's data produces). h <= 256. */
+int dss2_edge_hidden_fwd(const float* x, int64_t ldx, const float* ea, int64_t ldea,
+                         const float* W1, const float* b1,
+                         const int32_t* rowptr, const int32_t* col, const int32_t* ent,
+                         float* S, int64_t n_nodes, int h, int fn, int fe, void* stream);
+
+/* Backward of the above.  dS[N,h] is the gradient w.r.t. S.
+ * by_source = 0: walks the CSR by target; accumulates per-workgroup partial dW1[h,fn*2+fe] and
+ *               db1[h] into slab[n_slabs][h*(2fn+fe) + h] (reduced by dss2_reduce_slabs) and,
+ *               if U != NULL, writes U[i,:] = sum_{e->i} dz_e          (ldu floats per row).
+ * by_source = 1: walks the transposed CSR (pass rowptrT/colT/entT); writes
+ *               U[i,:] = sum_{e: src(e)=i} dz_e; slab is not touched.
+ * Returns the number of slabs it will write through *n_slabs_out (host) when slab == NULL. */
+int dss2_edge_hidden_bwd(const float* x, int64_t ldx, const float* ea, int64_t ldea,
+                         const float* W1, const float* b1, const float* dS,
+                         const int32_t* rowptr, const int32_t* col, const int32_t* ent,
+                         float* slab, int n_slabs, float* U, int64_t ldu,
+                         int64_t n_nodes, int h, int fn, int fe, int by_source, void* stream);
+
+/* ---- K2/K4: fused tile GEMM + Horner graph propagation --------------------------------- *
+ * Y = epilogue( sum_{m=0..nmat-1} P^m (X . B_m) ),  P = A_hat given by (rowptr, col, w).
+ *  forward TAGConv (PyG TAGConv; call sites networks.py:267,271):
+ *        X = h, B_m = lins[m].weight^T, P = A_hat (CSR by target), bias, optional dropout mask
+ *        and ReLU;  mathematically sum_m lins[m](A_hat^m h) + b, evaluated as
+ *        G0 + A_hat (G1 + A_hat G2) with G_m = h W_m^T (propagation at OUTPUT width).
+ *  data-gradient of TAGConv: X = dOut, B_m = lins[m].weight, P = A_hat^T (CSR by source).
+ *  plain Linear (second Linear of the edge MLP): nmat = 1, bias scaled per row by rowscale.
+ * Epilogue order: + bias[col]*(rowscale?rowscale[row]:1); * dmask; relu; * (relu_src > 0);
+ * + add_src.  One workgroup per tile; requires nrb in {1,2,4,8} and nmat in 1..4.          */
+typedef struct dss2_gemm_prop_args {
+  const float* X; int64_t ldx; int32_t kreal; int32_t kpad;
+  const float* Bp;                 /* packed [nmat][ncg][kpad/8][64][4]                   */
+  const float* bias; const float* rowscale;
+  const float* relu_src; int64_t ld_relu;
+  const float* dmask; int64_t ld_dmask;
+  const float* add_src; int64_t ld_add;
+  float* Y; int64_t ldy; int32_t hout; int32_t ncg;
+  int32_t relu; int32_t nmat; int32_t nrb; int32_t ntiles;
+  const int32_t* tile_start;
+  const int32_t* rowptr; const int32_t* col; const float* w;
+  int32_t max_nnz; int32_t pad_;
+} dss2_gemm_prop_args;
+
+int dss2_gemm_prop(const dss2_gemm_prop_args* args_host, void* stream);
+
+/* ---- K4: weight gradient of TAGConv / Linear -------------------------------------------- *
+ * dW_m[o,i] = sum_n (P^m G)[n,o] * X[n,i]   (P = A_hat^T via the CSR by source), m < nmat,
+ * db[o] = sum_n G[n,o] * (rowscale ? rowscale[n] : 1).
+ * Partial sums per workgroup go to slab[n_split][nmat*hout*hin + hout]; finish with
+ * dss2_reduce_slabs.  Deterministic (no float atomics).                                    */
+typedef struct dss2_wgrad_args {
+  const float* G; int64_t ldg; int32_t hout;
+  const float* X; int64_t ldx; int32_t hin;
+  const float* rowscale;
+  float* slab; int32_t n_split; int32_t nmat; int32_t nrb; int32_t ntiles;
+  const int32_t* tile_start;
+  const int32_t* rowptrT; const int32_t* colT; const float* wT;
+  int32_t max_nnz; int32_t pad_;
+} dss2_wgrad_args;
+
+int dss2_wgrad(const dss2_wgrad_args* args_host, void* stream);
+
+/* out[j] = sum_{s < n_slabs} slab[s*stride + j], j < len, fixed order. */
+int dss2_reduce_slabs(const float* slab, int n_slabs, int64_t stride, float* out, int64_t len, void* stream);
+
+/* ---- K3: gsp_wls_edge + get_pflow, forward and backward (data.py:328-459) --------------- *
+ * Phase 1 (dss2_wls_loss_partials): applies theta *= (1 - slack) IN PLACE on output[:,1]
+ * (data.py:413), computes the batch-global V_hv / V_lv (data.py:335-336), the AC branch flows,
+ * bus injections and the five batch sums
+ *     sums[0] = sum_nodes sum_c delta^2 R^-1 lambda_c     sums[1] = sum_edges (same, edges)
+ *     sums[2] = sum_nodes relu(v-1.1)+relu(0.9-v)         sums[3] = sum_edges relu(|th_ij|-0.5)
+ *     sums[4] = sum_edges relu(loading-1.5)               sums[5] = N, sums[6] = E  (doubles)
+ * and the per-bus residual coefficients apq[N,2] = dJ/dp_i, dJ/dq_i (times N).
+ * Between the phases a data-parallel caller all-reduces sums[0..6].
+ * Phase 2 (dss2_wls_loss_grad): loss scalar (data.py:450-459) and d loss / d output[N,2]
+ * (gradient w.r.t. the output BEFORE the in-place masking, as autograd gives in the reference).
+ * inc_rowptr/inc_ent: incidence CSR over the STORED edges: row i lists e | end<<31 for every
+ * stored edge with from(e)=i (end 0) or to(e)=i (end 1), sorted by (end, e).              */
+typedef struct dss2_wls_args {
+  const float* input; int64_t ld_in;            /* [N,8]  data.x[:, :8]                   */
+  const float* edge_input; int64_t ld_ein;      /* [E,6]  data.edge_attr[:, :6]           */
+  float* output; int64_t ld_out;                /* [N,2]  model output (theta masked in place) */
+  const float* node_param; int64_t ld_np;       /* [N,3]  vn_kv, slack, zero_inj          */
+  const float* edge_param; int64_t ld_ep;       /* [E,7]  G,B,Gs,Bs,closed,shift,imax     */
+  const float* x_mean; const float* x_std;      /* [8]                                     */
+  const float* edge_mean; const float* edge_std;/* [6]                                     */
+  const int32_t* efrom; const int32_t* eto;     /* [E] stored edge endpoints               */
+  const int32_t* inc_rowptr; const int32_t* inc_ent;
+  int64_t n_nodes; int64_t n_edges;
+  float lam_v, lam_p, lam_pf, lam_reg;
+  double* sums;            /* [8] device                                                  */
+  double* partials;        /* [n_blocks_max*5] device scratch, n_blocks_max = 1024         */
+  float* vminmax;          /* [2] device: V_lv, V_hv                                       */
+  float* apq;              /* [N,2] device scratch                                         */
+  float* loss;             /* [1] device                                                   */
+  float* grad_output;      /* [N,2] device, contiguous                                     */
+  float* pflow;            /* optional [E,8]: get_pflow's 8 outputs per stored edge, or NULL */
+} dss2_wls_args;
+
+int dss2_wls_loss_partials(const dss2_wls_args* args_host, void* stream);
+int dss2_wls_loss_grad(const dss2_wls_args* args_host, void* stream);
+
+/* get_pflow alone (data.py:328-390; evaluation path dss2_run.py:193-194): y[N,2] = (v, theta)
+ * in physical units; writes pflow[E,8] = loading_lines, loading_trafo, P_from, Q_from, P_to,
+ * Q_to, I_from, I_to.  vminmax[2] is device scratch. */
+int dss2_get_pflow(const float* y, int64_t ldy, const float* node_param, int64_t ld_np,
+                   const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
+                   int64_t n_nodes, int64_t n_edges, float* vminmax, float* pflow, void* stream);
+
+/* LDS bytes a dss2_gemm_prop / dss2_wgrad launch will request (host-side helper; lets the
+ * caller reject configurations that do not fit the 160 KiB LDS before launching). */
+size_t dss2_gemm_prop_lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz);
+size_t dss2_wgrad_lds_bytes(int nrb, int nmat, int hout, int hin, int max_nnz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSS2_HIP_H */

@@ -1,0 +1,235 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (ctypes -> libdss2_hip.so), against
+  (a) the golden vectors produced by the reference itself, and
+  (b) the CPU oracle on the same seeded inputs (fp32, plus an fp64 referee where noted).
+Tolerances (max-normalised relative error, BASELINE.json north_star: 1e-5 on node states and loss):
+  outputs 1e-5, loss 1e-5; gradients 1e-4 (the reference's own fp32-vs-fp64 gradient noise is 2e-5)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import CASES, LOSS_CASES, case_batch, case_grads, case_state_dict, golden, load_pkg, rel_err, t
+
+pytestmark = pytest.mark.gpu
+TOL_OUT, TOL_LOSS, TOL_GRAD = 1e-5, 1e-5, 1e-4
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_pkg()
+    p._lib.lib()  # fail loudly if the extension is missing
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return p
+
+
+def _loss(mod_data, x, ei, ea, st, out, reg):
+    return mod_data.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1],
+                                 edge_mean=st[2], edge_std=st[3], edge_index=ei, reg_coefs=reg, num_samples=None,
+                                 node_param=x[:, 8:], edge_param=ea[:, 6:])
+
+
+# ---------------------------------------------------------------------------- op level
+@pytest.mark.parametrize("n_graphs,kdim,hout", [(5, 128, 128), (3, 32, 32), (7, 64, 2), (4, 8, 128), (2, 256, 64), (9, 2, 32)])
+def test_gemm_linear_matches_matmul(pkg, n_graphs, kdim, hout):
+    """nmat=1 path of dss2_gemm_prop: packing + MFMA fragment layout + epilogue, vs torch.matmul."""
+    torch.manual_seed(kdim + hout)
+    b = pkg.synthetic.make_batch(["cigre14"], n_graphs, seed=1)
+    N = b["x"].shape[0]
+    topo = pkg.topology.Topology(b["edge_index"].to(DEV), N)
+    X = torch.randn(N, kdim, device=DEV)
+    W = torch.randn(hout, kdim, device=DEV) * 0.3          # asymmetric by construction
+    bias = torch.randn(hout, device=DEV)
+    plan = pkg.networks._PackPlan([[W]], torch.device(DEV))
+    plan.refresh()
+    Y = torch.empty(N, hout, device=DEV)
+    pkg.networks.gemm_prop(topo, X, kdim, kdim, plan.fwd[0], 1, hout, Y, bias=bias)
+    ref = (X.double() @ W.double().t() + bias.double())
+    assert rel_err(Y, ref) < 2e-6
+    Y2 = torch.empty(N, kdim, device=DEV)                    # data-gradient layout: G @ W
+    pkg.networks.gemm_prop(topo, Y, hout, hout, plan.bwd[0], 1, kdim, Y2)
+    assert rel_err(Y2, Y.double() @ W.double()) < 2e-6
+
+
+@pytest.mark.parametrize("grid,hin,hout,K", [("cigre14", 128, 128, 2), ("cigre14_reswitched", 32, 8, 3),
+                                              ("ober_sub", 64, 64, 2), ("cigre14", 128, 2, 2), ("cigre14", 32, 32, 1),
+                                              ("ober179", 32, 32, 2)])
+def test_tagconv_fwd_bwd(pkg, oracle, grid, hin, hout, K):
+    torch.manual_seed(7)
+    b = pkg.synthetic.make_batch([grid], 6, seed=2)
+    N = b["x"].shape[0]
+    ei = b["edge_index"]
+    ei2, _ = oracle.undirect_graph(ei, b["edge_attr"][:, :6])
+    ref = oracle.TAGConv(hin, hout, K).double()
+    ref.bias.data.uniform_(-0.5, 0.5)
+    mine = pkg.TAGConv(hin, hout, K).to(DEV)
+    mine.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    h = torch.randn(N, hin)
+    g = torch.randn(N, hout)
+    hr = h.double().requires_grad_(True)
+    outr = ref(hr, ei2)
+    outr.backward(g.double())
+    hm = h.to(DEV).requires_grad_(True)
+    outm = mine(hm, ei2.to(DEV))
+    outm.backward(g.to(DEV))
+    assert rel_err(outm, outr) < TOL_OUT
+    assert rel_err(hm.grad, hr.grad) < TOL_OUT
+    assert rel_err(mine.bias.grad, ref.bias.grad) < TOL_GRAD
+    for a, bb in zip(mine.lins, ref.lins):
+        assert rel_err(a.weight.grad, bb.weight.grad) < TOL_GRAD
+
+
+@pytest.mark.parametrize("grid,hid", [("cigre14", 128), ("ober_sub", 32), ("cigre14_reswitched", 256), ("cigre14", 64)])
+def test_edge_aggregation_fwd_bwd(pkg, oracle, grid, hid):
+    torch.manual_seed(3)
+    b = pkg.synthetic.make_batch([grid], 5, seed=4)
+    x, ea = b["x"][:, :8], b["edge_attr"][:, :6]
+    ei2, ea2 = oracle.undirect_graph(b["edge_index"], ea)
+    ref = oracle.EdgeAggregation(8, 6, hid, hid).double()
+    mine = pkg.EdgeAggregation(8, 6, hid, hid).to(DEV)
+    mine.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    outr = ref(xr, ei2, ea2.double())
+    g = torch.randn(outr.shape)
+    outr.backward(g.double())
+    xm = x.to(DEV).contiguous().requires_grad_(True)
+    outm = mine(xm, ei2.to(DEV), ea2.to(DEV).contiguous())
+    outm.backward(g.to(DEV))
+    assert rel_err(outm, outr) < TOL_OUT
+    assert rel_err(xm.grad, xr.grad) < TOL_GRAD
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad, q.grad) < TOL_GRAD, n
+
+
+def test_segment_sum(pkg):
+    b = pkg.synthetic.make_batch(["cigre14", "cigre14_reswitched"], 64, seed=9)
+    N = b["x"].shape[0]
+    topo = pkg.topology.Topology(b["edge_index"].to(DEV), N)
+    for h in (32, 128, 256):
+        msg = torch.randn(topo.E2, h, device=DEV)
+        out = pkg.networks.segment_sum(msg, topo.rowptr, topo.perm.to(torch.int32), N)
+        tgt = torch.cat([b["edge_index"][1], b["edge_index"][0]]).to(DEV)
+        ref = torch.zeros(N, h, device=DEV, dtype=torch.float64).index_add_(0, tgt, msg.double())
+        assert rel_err(out, ref) < 1e-6
+        out2 = pkg.networks.segment_sum(msg, topo.rowptr, topo.perm.to(torch.int32), N)
+        assert torch.equal(out, out2)  # deterministic: no float atomics
+
+
+# ---------------------------------------------------------------------------- golden cases
+@pytest.mark.parametrize("name", list(CASES))
+def test_model_matches_reference_golden(pkg, oracle, name):
+    cls, args, with_loss = CASES[name]
+    g = golden(f"case_{name}.npz")
+    model = getattr(pkg, cls)(*args)
+    res = model.load_state_dict(case_state_dict(g), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model = model.to(DEV)
+    b = case_batch(g, device=DEV)
+    x, ei, ea, st = b["x"], b["edge_index"], b["edge_attr"], b["stats"]
+    out = model(x[:, :8], ei, ea[:, :6])
+    assert rel_err(out, t(g["out"])) < TOL_OUT
+    if with_loss:
+        loss = _loss(pkg.data, x, ei, ea, st, out, oracle.DEFAULT_REG_COEFS)
+        assert abs(loss.item() - float(g["loss"])) <= TOL_LOSS * abs(float(g["loss"]))
+        assert rel_err(out, t(g["out_after_loss"])) < TOL_OUT          # theta zeroed at the slack in place
+        slack = x[:, 9] > 0
+        assert (out.detach()[slack, 1] == 0).all()
+        loss.backward()
+    else:
+        out.backward(t(g["gout"], device=DEV))
+    grads = case_grads(g)
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        assert rel_err(p.grad, grads[k]) < TOL_GRAD, k
+
+
+@pytest.mark.parametrize("name", LOSS_CASES)
+def test_loss_matches_reference_golden(pkg, oracle, name):
+    g = golden(f"case_{name}.npz")
+    b = case_batch(g, device=DEV)
+    x, ei, ea, st = b["x"], b["edge_index"], b["edge_attr"], b["stats"]
+    o_leaf = t(g["output"], device=DEV).clone().requires_grad_(True)
+    o = o_leaf * 1.0
+    loss = _loss(pkg.data, x, ei, ea, st, o, oracle.DEFAULT_REG_COEFS)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= TOL_LOSS * abs(float(g["loss"]))
+    assert rel_err(o, t(g["output_after"])) < 1e-7
+    assert rel_err(o_leaf.grad, t(g["grad_output"])) < TOL_GRAD
+    yv = torch.cat([o.detach()[:, 0:1] * st[1][:1] + st[0][:1], o.detach()[:, 1:]], 1)
+    flows = torch.stack(pkg.data.get_pflow(yv, ei, x[:, 8:], ea[:, 6:]), 1)
+    assert rel_err(flows, t(g["pflow"])) < TOL_OUT
+
+
+# ---------------------------------------------------------------------------- full-size configs
+def _train_step_pair(pkg, oracle, grids, B, hid, L, K=2, seed=0, cls="MPN", dim_out=2):
+    torch.manual_seed(seed)
+    b = pkg.synthetic.make_batch(grids, B, seed=seed)
+    ref = getattr(oracle, cls)(8, 6, dim_out, hid, L, K, 0.0)
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if n.endswith("bias") and "convs" in n:
+                p.uniform_(-0.1, 0.1)
+    mine = getattr(pkg, cls)(8, 6, dim_out, hid, L, K, 0.0)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(DEV)
+    out_r, loss_r = oracle.train_step(ref, b, b["stats"])
+    out_r_pre = None
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    st = tuple(s.to(DEV) for s in b["stats"])
+    out_m = mine(x[:, :8], ei, ea[:, :6])
+    loss_m = _loss(pkg.data, x, ei, ea, st, out_m, oracle.DEFAULT_REG_COEFS)
+    loss_m.backward()
+    return ref, mine, out_r, loss_r, out_m, loss_m
+
+
+@pytest.mark.parametrize("grids,B,hid,L", [
+    (["cigre14"], 64, 32, 1),                                   # BASELINE config C1
+    (["cigre14"], 4096, 128, 4),                                # C2 (the headline configuration)
+    (["ober_sub"], 1024, 128, 4),                               # C3
+    (["cigre14", "cigre14_reswitched"], 512, 256, 8),           # C5's model on a mixed-topology shard
+])
+def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
+    ref, mine, out_r, loss_r, out_m, loss_m = _train_step_pair(pkg, oracle, grids, B, hid, L)
+    assert rel_err(out_m, out_r) < TOL_OUT
+    assert abs(loss_m.item() - loss_r.item()) <= TOL_LOSS * abs(loss_r.item())
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad, q.grad) < TOL_GRAD, n
+
+
+def test_full_size_is_deterministic_and_linear_in_gout(pkg, oracle):
+    """Size-independent properties at C2: bitwise run-to-run reproducibility (no float atomics)
+    and linearity of the backward in the incoming gradient."""
+    torch.manual_seed(0)
+    b = pkg.synthetic.make_batch(["cigre14"], 4096, seed=5)
+    m = pkg.MPN(8, 6, 2, 128, 4, 2, 0.0).to(DEV)
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    g = torch.randn(x.shape[0], 2, device=DEV)
+
+    def run(scale):
+        for p in m.parameters():
+            p.grad = None
+        out = m(x[:, :8], ei, ea[:, :6])
+        out.backward(g * scale)
+        return out.detach().clone(), [p.grad.clone() for p in m.parameters()]
+
+    o1, g1 = run(1.0)
+    o2, g2 = run(1.0)
+    assert torch.equal(o1, o2) and all(torch.equal(a, c) for a, c in zip(g1, g2))
+    _, g3 = run(2.0)
+    for a, c in zip(g1, g3):
+        assert rel_err(c, 2 * a) < 1e-6
+
+
+# ---------------------------------------------------------------------------- interface / quirks
+def test_quirks_and_errors(pkg):
+    b = pkg.synthetic.make_batch(["cigre14"], 8, seed=1)
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    m = pkg.MPN(8, 6, 2, 32, 2, 2, 0.3).to(DEV).eval()
+    with torch.no_grad():   # dropout stays active in eval() (networks.py:268)
+        assert (m(x[:, :8], ei, ea[:, :6]) - m(x[:, :8], ei, ea[:, :6])).abs().max() > 0
+    assert m.is_directed(ei) is True
+    ei2, ea2 = m.undirect_graph(ei, ea[:, :6])
+    assert ei2.shape[1] == 2 * ei.shape[1] and m.is_directed(ei2) is False
+    with pytest.raises(RuntimeError):
+        pkg.MPN(8, 6, 2, 32, 2, 2, 0.0)(b["x"][:, :8], b["edge_index"], b["edge_attr"][:, :6])  # CPU tensors
+    with pytest.raises(RuntimeError):
+        pkg.EdgeAggregation(7, 6, 32, 32).to(DEV)(x[:, :7].contiguous(), ei2, ea2)  # unsupported dims fail loudly
