@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its headline configuration (C2).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one resident batch: MPN forward -> gsp_wls_edge -> backward
+(/root/reference/dss2_run.py:138-142; optimizer excluded, gradient all-reduce included for N > 1).
+Workload at every N (weak scaling): CIGRE-14, B = 4096 graphs per GPU, MPN(8, 6, 2, H=128, L=4, K=2),
+dropout 0, fp32, synthetic states on the reference's CIGRE-14 parameter tables, random-init weights.
+Rank 0 prints ONE JSON line (contract in the task brief) with two extra objects:
+  roofline     : the dominant kernel (fused MFMA GEMM + propagation, hid->hid TAGConv launches),
+                 timed in situ with HIP events in an instrumented pass after the timed region
+  cpu_baseline : the CPU oracle (a port of the reference's PyTorch-eager path, dead dense Laplacian
+                 stripped) timed on this box's host cores on the same batch (N = 1 only)
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "deep-statistical-solver-for-distribution-system-state-estimation_amd"
+
+REG = {"mu_v": 1e-1, "mu_theta": 1e-1, "lam_v": 1e-4, "lam_p": 1e-8, "lam_pf": 1e-6, "lam_reg": 1e2}
+B_PER_GPU, HID, LAYERS, KHOPS = 4096, 128, 4, 2
+FP32_MFMA_PEAK_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="graphs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    pkg = importlib.import_module(PKG)
+    pkg._lib.lib()  # fail loudly without the HIP extension
+    import torch.distributed as dist
+    env = pkg.parallel.init_from_env("nccl")
+    rank, world, local = env["rank"], env["world"], env["local"]
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    group = dist.group.WORLD if world > 1 else None
+
+    # ---- resident inputs and model
+    torch.manual_seed(0)
+    batch = pkg.synthetic.make_batch(["cigre14"], args.batch, seed=1000 + rank)
+    x, ei, ea = batch["x"].to(dev), batch["edge_index"].to(dev), batch["edge_attr"].to(dev)
+    stats = tuple(s.to(dev) for s in batch["stats"])
+    model = pkg.MPN(8, 6, 2, HID, LAYERS, KHOPS, 0.0).to(dev)
+    if world > 1:
+        pkg.parallel.broadcast_parameters(model, 0, group)
+        pkg.parallel.attach_grad_allreduce(model, group)
+    xin, ein, npar, epar = x[:, :8], ea[:, :6], x[:, 8:], ea[:, 6:]
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        out = model(xin, ei, ein)
+        loss = pkg.gsp_wls_edge(input=xin, edge_input=ein, output=out, x_mean=stats[0], x_std=stats[1],
+                                edge_mean=stats[2], edge_std=stats[3], edge_index=ei, reg_coefs=REG,
+                                num_samples=None, node_param=npar, edge_param=epar, group=group)
+        loss.backward()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    value = args.batch * world / (dt / args.steps)
+
+    result = {
+        "metric": "grid-samples/sec fwd+bwd (WLS loss)", "value": value, "unit": "graphs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"CIGRE-14 (15 buses, 14 closed branches) B={args.batch} graphs/GPU, "
+                               f"MPN L={LAYERS} H={HID} K={KHOPS} dropout=0: forward + gsp_wls_edge + backward"
+                               + (" + RCCL grad all-reduce" if world > 1 else ""),
+                   "graphs_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                   "loss": float(loss.item())},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel, timed in situ (instrumented pass, not the timed region)
+        N, E2 = x.shape[0], 2 * ei.shape[1]
+        events = []
+        orig = pkg.networks.gemm_prop
+
+        def timed_gemm_prop(topo, X, ldx, kreal, Bp, nmat, hout, Y, **kw):
+            dominant = (kreal == HID and hout == HID and nmat == KHOPS + 1)
+            if dominant:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            orig(topo, X, ldx, kreal, Bp, nmat, hout, Y, **kw)
+            if dominant:
+                e1.record()
+                events.append((e0, e1))
+
+        pkg.networks.gemm_prop = timed_gemm_prop
+        for _ in range(min(args.steps, 20)):
+            step()
+        torch.cuda.synchronize()
+        pkg.networks.gemm_prop = orig
+        durs = sorted(a.elapsed_time(b) for a, b in events)
+        avg_ms = sum(durs) / len(durs)
+        flops = 2.0 * N * HID * (KHOPS + 1) * HID + 2.0 * KHOPS * E2 * HID
+        achieved = flops / (avg_ms * 1e-3) / 1e12
+        result["roofline"] = {
+            "kernel": "dss2::gemm_prop_kernel<2,3> (TAGConv H->H forward and data-gradient launches)",
+            "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": None,
+            "launches_timed": len(durs), "avg_launch_us": avg_ms * 1e3, "median_launch_us": durs[len(durs) // 2] * 1e3,
+            "algorithmic_flops_per_launch": flops,
+        }
+        # ---- standalone scatter-add (K6) against the HBM roofline (north_star asks for it separately)
+        topo = pkg.topology.get_topology(ei, N)
+        msg = torch.randn(E2, HID, device=dev)
+        ent = topo.perm.to(torch.int32)
+        for _ in range(5):
+            pkg.networks.segment_sum(msg, topo.rowptr, ent, N)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        e0.record()
+        for _ in range(reps):
+            pkg.networks.segment_sum(msg, topo.rowptr, ent, N)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        byts = 4.0 * E2 * HID + 4.0 * N * HID + 4.0 * E2 + 4.0 * (N + 1)
+        result["scatter_add"] = {"kernel": "dss2::segment_sum_kernel", "bound": "hbm", "achieved": byts / us / 1e3,
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / us / 1e3 / HBM_PEAK_GBS,
+                                 "avg_launch_us": us, "algorithmic_bytes_per_launch": byts,
+                                 "note": "90.6 MB working set sits inside the 256 MiB Infinity Cache"}
+
+        # ---- CPU baseline: the oracle (port of the reference's eager path) on this box's host cores
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import dss2_oracle as oracle
+            cpu_model = oracle.MPN(8, 6, 2, HID, LAYERS, KHOPS, 0.0)
+            cpu_model.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+            cpu_batch = {"x": batch["x"], "edge_index": batch["edge_index"], "edge_attr": batch["edge_attr"]}
+            oracle.train_step(cpu_model, cpu_batch, batch["stats"], REG)          # warm-up
+            n, t0 = 0, time.perf_counter()
+            while True:
+                oracle.train_step(cpu_model, cpu_batch, batch["stats"], REG)
+                n += 1
+                if time.perf_counter() - t0 > args.cpu_seconds or n >= 200:
+                    break
+            cdt = (time.perf_counter() - t0) / n
+            result["cpu_baseline"] = {
+                "value": args.batch / cdt, "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{n} steps of the same B={args.batch} CIGRE-14 batch (fwd + gsp_wls_edge + bwd), "
+                          f"PyTorch eager CPU fp32, unused dense Laplacian of data.py:422-423 stripped",
+                "host_cpus": os.cpu_count(), "ms_per_step": cdt * 1e3,
+            }
+            result["speedup_vs_cpu_baseline"] = value / (args.batch / cdt)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

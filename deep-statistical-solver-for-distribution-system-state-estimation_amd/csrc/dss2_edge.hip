@@ -197,13 +197,31 @@ __global__ void __launch_bounds__(256) segment_sum_kernel(
   }
 }
 
+// out[j] = sum_k slab[k][j].  blockDim = (64, 4): threadIdx.y owns a contiguous quarter of the slabs
+// and keeps 8 independent loads in flight; partial sums are combined in a fixed order, so the
+// result is bitwise reproducible (no atomics).
 __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ slab, int n_slabs,
                                                            int64_t stride, float* __restrict__ out, int64_t len) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= len) return;
+  __shared__ float part[4][64];
+  const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int q = threadIdx.y;
+  const int per = (n_slabs + 3) >> 2;
+  const int k0 = q * per, k1 = min(n_slabs, k0 + per);
   float s = 0.f;
-  for (int k = 0; k < n_slabs; ++k) s += slab[(size_t)k * stride + j];
-  out[j] = s;
+  if (j < len) {
+    const float* p = slab + j;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; k < k1; ++k) s += p[(size_t)k * stride];
+  }
+  part[q][threadIdx.x] = s;
+  __syncthreads();
+  if (q == 0 && j < len) out[j] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 }  // namespace dss2
@@ -259,7 +277,7 @@ extern "C" int dss2_segment_sum(const float* msg, int64_t ldm, const int32_t* ro
 
 extern "C" int dss2_reduce_slabs(const float* slab, int n_slabs, int64_t stride, float* out, int64_t len, void* stream) {
   if (len <= 0) return 0;
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, as_stream(stream), slab,
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 63) / 64)), dim3(64, 4), 0, as_stream(stream), slab,
                      n_slabs, stride, out, len);
   return check_launch("reduce_slabs");
 }

@@ -51,11 +51,16 @@ __device__ __forceinline__ Flow branch_flow(float vf, float vt, float thf, float
   return f;
 }
 
-__global__ void __launch_bounds__(1024) vminmax_kernel(const float* __restrict__ np, int64_t ld, int64_t n,
-                                                        float* __restrict__ out) {
-  __shared__ float smin[16], smax[16];
+// Stage 1 of the batch-global min/max of vn_kv: VMM_BLOCKS workgroups write (min, max) pairs to
+// vmm[2 + 2*b]; stage 2 (vminmax_finish, one wave) folds them into vmm[0..1].  min/max are
+// order independent, so the result is exact and reproducible.
+constexpr int VMM_BLOCKS = 64;
+
+__global__ void __launch_bounds__(256) vminmax_kernel(const float* __restrict__ np, int64_t ld, int64_t n,
+                                                       float* __restrict__ vmm) {
+  __shared__ float smin[4], smax[4];
   float lo = INFINITY, hi = -INFINITY;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float v = np[i * ld];
     lo = fminf(lo, v);
     hi = fmaxf(hi, v);
@@ -68,11 +73,19 @@ __global__ void __launch_bounds__(1024) vminmax_kernel(const float* __restrict__
   if ((threadIdx.x & 63) == 0) { smin[w] = lo; smax[w] = hi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int nw = blockDim.x >> 6;
-    for (int k = 1; k < nw; ++k) { lo = fminf(lo, smin[k]); hi = fmaxf(hi, smax[k]); }
-    out[0] = lo;
-    out[1] = hi;
+    for (int k = 1; k < 4; ++k) { lo = fminf(lo, smin[k]); hi = fmaxf(hi, smax[k]); }
+    vmm[2 + 2 * blockIdx.x] = lo;
+    vmm[3 + 2 * blockIdx.x] = hi;
   }
+}
+
+__global__ void __launch_bounds__(64) vminmax_finish_kernel(float* __restrict__ vmm) {
+  float lo = vmm[2 + 2 * threadIdx.x], hi = vmm[3 + 2 * threadIdx.x];
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o));
+    hi = fmaxf(hi, __shfl_xor(hi, o));
+  }
+  if (threadIdx.x == 0) { vmm[0] = lo; vmm[1] = hi; }
 }
 
 struct NodeMeas { float Z[4], R[4]; };
@@ -171,18 +184,18 @@ __global__ void __launch_bounds__(LB) wls_partials_kernel(const dss2_wls_args p)
   }
 }
 
-__global__ void wls_finish_kernel(const double* __restrict__ partials, int n_blocks, double* __restrict__ sums,
-                                  double n_nodes, double n_edges) {
-  const int c = threadIdx.x;
-  if (c < 5) {
-    double s = 0;
-    for (int b = 0; b < n_blocks; ++b) s += partials[(size_t)b * 5 + c];
-    sums[c] = s;
-  } else if (c == 5) {
+// 5 waves, wave c sums column c of the workgroup partials: lanes stride over the workgroups, then
+// a fixed-order butterfly.  Deterministic.
+__global__ void __launch_bounds__(320) wls_finish_kernel(const double* __restrict__ partials, int n_blocks,
+                                                         double* __restrict__ sums, double n_nodes, double n_edges) {
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double s = 0;
+  for (int b = lane; b < n_blocks; b += 64) s += partials[(size_t)b * 5 + c];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) sums[c] = s;
+  if (threadIdx.x == 0) {
     sums[5] = n_nodes;
-  } else if (c == 6) {
     sums[6] = n_edges;
-  } else if (c == 7) {
     sums[7] = 0;
   }
 }
@@ -317,9 +330,10 @@ extern "C" int dss2_wls_loss_partials(const dss2_wls_args* ap, void* stream) {
   if (a.n_nodes <= 0 || a.n_edges <= 0) { set_error("wls_loss: empty batch"); return 2; }
   const int64_t nb = (a.n_nodes + LB - 1) / LB;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(vminmax_kernel, dim3(1), dim3(1024), 0, s, a.node_param, a.ld_np, a.n_nodes, a.vminmax);
+  hipLaunchKernelGGL(vminmax_kernel, dim3(VMM_BLOCKS), dim3(256), 0, s, a.node_param, a.ld_np, a.n_nodes, a.vminmax);
+  hipLaunchKernelGGL(vminmax_finish_kernel, dim3(1), dim3(64), 0, s, a.vminmax);
   hipLaunchKernelGGL(wls_partials_kernel, dim3((unsigned)nb), dim3(LB), 0, s, a);
-  hipLaunchKernelGGL(wls_finish_kernel, dim3(1), dim3(64), 0, s, a.partials, (int)nb, a.sums, (double)a.n_nodes,
+  hipLaunchKernelGGL(wls_finish_kernel, dim3(1), dim3(320), 0, s, a.partials, (int)nb, a.sums, (double)a.n_nodes,
                      (double)a.n_edges);
   return check_launch("wls_loss_partials");
 }
@@ -337,7 +351,8 @@ extern "C" int dss2_get_pflow(const float* y, int64_t ldy, const float* node_par
                               int64_t n_nodes, int64_t n_edges, float* vminmax, float* pflow, void* stream) {
   if (n_nodes <= 0 || n_edges <= 0) { set_error("get_pflow: empty batch"); return 2; }
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(vminmax_kernel, dim3(1), dim3(1024), 0, s, node_param, ld_np, n_nodes, vminmax);
+  hipLaunchKernelGGL(vminmax_kernel, dim3(VMM_BLOCKS), dim3(256), 0, s, node_param, ld_np, n_nodes, vminmax);
+  hipLaunchKernelGGL(vminmax_finish_kernel, dim3(1), dim3(64), 0, s, vminmax);
   hipLaunchKernelGGL(pflow_kernel, dim3((unsigned)((n_edges + LB - 1) / LB)), dim3(LB), 0, s, y, ldy, edge_param, ld_ep,
                      efrom, eto, n_edges, vminmax, pflow);
   return check_launch("get_pflow");

@@ -70,7 +70,7 @@ class _WlsFn(torch.autograd.Function):
         bufs = {
             "sums": torch.empty(8, dtype=torch.float64, device=dev),
             "partials": torch.empty(nb * 5, dtype=torch.float64, device=dev),
-            "vminmax": torch.empty(2, dtype=_F32, device=dev),
+            "vminmax": torch.empty(130, dtype=_F32, device=dev),
             "apq": torch.empty(N, 2, dtype=_F32, device=dev),
             "loss": torch.empty(1, dtype=_F32, device=dev),
             "grad": torch.empty(N, 2, dtype=_F32, device=dev),
@@ -129,7 +129,7 @@ def get_pflow(y, edge_index, node_param, edge_param, phase_shift=True):
     epar, ld_ep = _rows(edge_param)
     topo = get_topology(edge_index, y.size(0))
     dev = y.device
-    vmm = torch.empty(2, dtype=_F32, device=dev)
+    vmm = torch.empty(130, dtype=_F32, device=dev)
     pf = torch.empty(topo.E, 8, dtype=_F32, device=dev)
     _lib.check(_lib.lib().dss2_get_pflow(y2.data_ptr(), ldy, npar.data_ptr(), ld_np, epar.data_ptr(), ld_ep,
                                          topo.efrom.data_ptr(), topo.eto.data_ptr(), topo.N, topo.E, vmm.data_ptr(),

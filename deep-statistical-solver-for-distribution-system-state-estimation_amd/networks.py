@@ -199,25 +199,28 @@ def _edge_aggr_backward(topo, gx0, x, ldx, ea, ldea, W1, b1, S, pack_w2_bwd, hid
     n_slabs = int(min(512, max(1, (N + 15) // 16)))
     stride = hid * (2 * fn + fe) + hid
     slab = torch.empty(n_slabs * stride, dtype=_F32, device=dev)
-    U = torch.empty(N, 2 * hid, dtype=_F32, device=dev) if need_dx else None
+    U = torch.empty(2, N, hid, dtype=_F32, device=dev) if need_dx else None
     st = _stream(gx0)
     L = _lib.lib()
     _lib.check(L.dss2_edge_hidden_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
                                       topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(), slab.data_ptr(),
-                                      n_slabs, _ptr(U), 2 * hid, N, hid, fn, fe, 0, st), "dss2_edge_hidden_bwd")
+                                      n_slabs, _ptr(U), hid, N, hid, fn, fe, 0, st), "dss2_edge_hidden_bwd")
     _lib.check(L.dss2_reduce_slabs(slab.data_ptr(), n_slabs, stride, g_w1.data_ptr(), stride, st), "dss2_reduce_slabs")
     if not need_dx:
         return None
-    # U[:, :hid] = sum of dz over incoming edges (x enters as x_i), U[:, hid:] over outgoing (as x_j)
+    # U[0] = sum of dz over incoming edges (x enters as x_i), U[1] over outgoing edges (as x_j)
     _lib.check(L.dss2_edge_hidden_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
                                       topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.entT.data_ptr(), None,
-                                      n_slabs, U.data_ptr() + 4 * hid, 2 * hid, N, hid, fn, fe, 1, st), "dss2_edge_hidden_bwd")
-    # dx = U[:, :hid] @ W1[:, :fn] + U[:, hid:] @ W1[:, fn:2fn]   (tiny K=2*hid -> fn GEMM on the same kernel)
-    Wcat = torch.cat([W1[:, :fn], W1[:, fn:2 * fn]], dim=0).contiguous()      # [2*hid, fn]
-    plan = _PackPlan([[Wcat]], dev)
+                                      n_slabs, U[1].data_ptr(), hid, N, hid, fn, fe, 1, st), "dss2_edge_hidden_bwd")
+    # dx = U[0] @ W1[:, :fn] + U[1] @ W1[:, fn:2fn]: two K=hid -> fn GEMMs on the tile kernel, the
+    # second one adding the first through the residual epilogue
+    plan = _PackPlan([[W1[:, :fn].contiguous()], [W1[:, fn:2 * fn].contiguous()]], dev)
     plan.refresh()
+    dx0 = torch.empty(N, fn, dtype=_F32, device=dev)
     dx = torch.empty(N, fn, dtype=_F32, device=dev)
-    gemm_prop(topo, U, 2 * hid, 2 * hid, plan.bwd[0], 1, fn, dx)
+    gemm_prop(topo, U[0], hid, hid, plan.bwd[0], 1, fn, dx0)
+    gemm_prop(topo, U[1], hid, hid, plan.bwd[1], 1, fn, dx, add_src=dx0, add_ld=fn)
+    plan.keepalive = (dx0, U)
     return dx
 
 

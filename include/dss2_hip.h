@@ -169,7 +169,7 @@ typedef struct dss2_wls_args {
   float lam_v, lam_p, lam_pf, lam_reg;
   double* sums;            /* [8] device                                                  */
   double* partials;        /* [n_blocks_max*5] device scratch, n_blocks_max = 1024         */
-  float* vminmax;          /* [2] device: V_lv, V_hv                                       */
+  float* vminmax;          /* [130] device scratch: [0]=V_lv, [1]=V_hv, then 64 partial pairs */
   float* apq;              /* [N,2] device scratch                                         */
   float* loss;             /* [1] device                                                   */
   float* grad_output;      /* [N,2] device, contiguous                                     */
@@ -181,7 +181,7 @@ int dss2_wls_loss_grad(const dss2_wls_args* args_host, void* stream);
 
 /* get_pflow alone (data.py:328-390; evaluation path dss2_run.py:193-194): y[N,2] = (v, theta)
  * in physical units; writes pflow[E,8] = loading_lines, loading_trafo, P_from, Q_from, P_to,
- * Q_to, I_from, I_to.  vminmax[2] is device scratch. */
+ * Q_to, I_from, I_to.  vminmax[130] is device scratch. */
 int dss2_get_pflow(const float* y, int64_t ldy, const float* node_param, int64_t ld_np,
                    const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
                    int64_t n_nodes, int64_t n_edges, float* vminmax, float* pflow, void* stream);

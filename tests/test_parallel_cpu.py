@@ -1,0 +1,100 @@
+"""CPU, world_size 2, gloo: the data-parallel host logic of parallel.py.
+
+The HIP kernels cannot run here, so each rank's per-shard arithmetic is supplied by the oracle
+(tests may use it as a stand-in for the kernels); what is under test is the recipe the GPU path
+uses: contiguous whole-graph shards, all-reduce of the five loss sums + counts between the two loss
+phases, SUM all-reduce of the flat gradient bucket - which must reproduce the single-process loss
+and gradients of the global batch exactly, including the squared-mean penalties."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_pkg
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dss2_oracle as oracle
+    pkg = load_pkg()
+    torch.set_num_threads(1)
+    env = pkg.parallel.init_from_env("gloo")
+    assert env["world"] == world
+    torch.manual_seed(0)
+    # ragged: 10 graphs of mixed sizes on 2 ranks, half of them outside the penalty bands
+    full = pkg.synthetic.make_batch(["cigre14", "cigre14_reswitched"], 10, seed=3, violate=0.5)
+    model = oracle.MPN(8, 6, 2, 16, 2, 2, 0.0).double()
+    with torch.no_grad():   # push the outputs outside the penalty bands so J_v, J_theta, J_loading are all active
+        for lin in model.convs[-1].lins:
+            lin.weight *= 40.0
+    pkg.parallel.broadcast_parameters(model, 0)
+    st = [s.double().clone() for s in full["stats"]]
+    st[1][0] *= 20.0        # sigma_V: v = out * sigma + mu leaves [0.9, 1.1]
+    st = tuple(st)
+    reg = oracle.DEFAULT_REG_COEFS
+
+    def local_sums(b):
+        x, ei, ea = b["x"].double(), b["edge_index"], b["edge_attr"].double()
+        out = model(x[:, :8], ei, ea[:, :6])
+        out = torch.cat([out[:, :1], out[:, 1:] * (1.0 - x[:, 9:10])], 1)
+        sums = oracle.wls_partial_sums(x[:, :8], ea[:, :6], out, st[0], st[1], st[2], st[3], ei, x[:, 8:], ea[:, 6:], reg)
+        return sums, x.shape[0], ei.shape[1]
+
+    # ---- sharded: partial sums -> all-reduce (values only) -> loss -> backward -> SUM all-reduce of the bucket
+    shard = pkg.parallel.shard_batch(full, rank, world)
+    sums, n, e = local_sums(shard)
+    glob = torch.cat([sums.detach(), torch.tensor([float(n), float(e)], dtype=torch.float64)])
+    pkg.parallel.allreduce_loss_sums(glob)
+    sums_g = sums + (glob[:5] - sums.detach())           # global value, local gradient path
+    loss = oracle.loss_from_sums(sums_g, glob[5], glob[6], reg["lam_reg"])
+    loss.backward()
+    flat = torch.cat([p.grad.flatten() for p in model.parameters()])
+    pkg.parallel.allreduce_flat_grads(flat)
+    # ---- single process reference on the whole batch
+    for p in model.parameters():
+        p.grad = None
+    b64 = {"x": full["x"].double(), "edge_index": full["edge_index"], "edge_attr": full["edge_attr"].double()}
+    _, loss_ref = oracle.train_step(model, b64, st, reg)
+    flat_ref = torch.cat([p.grad.flatten() for p in model.parameters()])
+    ok_loss = abs(loss.item() - loss_ref.item()) <= 1e-10 * abs(loss_ref.item())
+    ok_grad = (flat - flat_ref).abs().max().item() <= 1e-9 * flat_ref.abs().max().item()
+    ok_shard = int(glob[5].item()) == full["x"].shape[0] and int(glob[6].item()) == full["edge_index"].shape[1]
+    ok_pen = bool((glob[2:5] > 0).all())                 # the penalty terms are really exercised
+    ret[rank] = (ok_loss, ok_grad, ok_shard, ok_pen, shard["num_graphs"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_loss_and_grads_equal_single_process():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29600 + os.getpid() % 300
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        ok_loss, ok_grad, ok_shard, ok_pen, ng = ret[r]
+        assert ok_loss and ok_grad and ok_shard and ok_pen, (r, ret[r])
+    assert sum(ret[r][4] for r in range(world)) == 10
+
+
+def test_shard_bounds_cover_and_are_disjoint():
+    pkg = load_pkg()
+    for ng, world in [(10, 2), (4096, 8), (7, 8), (1, 1)]:
+        spans = [pkg.parallel.shard_bounds(ng, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == ng
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_attach_grad_allreduce_hooks_every_block():
+    pkg = load_pkg()
+    m = pkg.SkipPFN(8, 6, 2, 16, 2, 2, 0.0, 3)
+    assert pkg.parallel.attach_grad_allreduce(m) == 3
+    assert pkg.parallel.attach_grad_allreduce(pkg.MPN(8, 6, 2, 16, 2, 2, 0.0)) == 1
