@@ -32,7 +32,7 @@ class GemmPropArgs(C.Structure):
                 ("relu", C.c_int32), ("nmat", C.c_int32), ("nrb", C.c_int32), ("ntiles", C.c_int32),
                 ("tile_start", C.c_void_p),
                 ("rowptr", C.c_void_p), ("col", C.c_void_p), ("w", C.c_void_p),
-                ("max_nnz", C.c_int32), ("pad_", C.c_int32)]
+                ("max_nnz", C.c_int32), ("ell_width", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -43,7 +43,7 @@ class WgradArgs(C.Structure):
                 ("ntiles", C.c_int32),
                 ("tile_start", C.c_void_p),
                 ("rowptrT", C.c_void_p), ("colT", C.c_void_p), ("wT", C.c_void_p),
-                ("max_nnz", C.c_int32), ("pad_", C.c_int32)]
+                ("max_nnz", C.c_int32), ("ell_width", C.c_int32)]
 
 
 class WlsArgs(C.Structure):
@@ -85,8 +85,8 @@ _SIGNATURES = {
     "dss2_get_pflow": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
-    "dss2_gemm_prop_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "dss2_wgrad_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dss2_gemm_prop_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dss2_wgrad_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

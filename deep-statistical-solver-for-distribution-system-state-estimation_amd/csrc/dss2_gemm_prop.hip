@@ -47,8 +47,14 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const dss2_pack_desc*
 // ------------------------------------------------------------------------------------------
 // fused GEMM + propagation
 // ------------------------------------------------------------------------------------------
+// waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument):
+// the accumulators take NRB*NMAT*16 registers of the 512 per lane.
+constexpr int gemm_waves_per_simd(int nrb, int nmat) {
+  return nrb * nmat * 16 <= 64 ? 3 : (nrb * nmat * 16 <= 128 ? 2 : 1);
+}
+
 template <int NRB, int NMAT>
-__global__ void __launch_bounds__(256) gemm_prop_kernel(const dss2_gemm_prop_args p) {
+__global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop_kernel(const dss2_gemm_prop_args p) {
   constexpr int TM = NRB * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -60,15 +66,21 @@ __global__ void __launch_bounds__(256) gemm_prop_kernel(const dss2_gemm_prop_arg
   const int ts = p.tile_start[tile];
   const int R = p.tile_start[tile + 1] - ts;
   const int LDX = p.kpad + 4;
+  const int dbg = p.relu >> 8;   // diagnostics only (tools/ablate.py): 1 no MFMA, 2 no Horner, 4 no stores, 8 no X staging
 
   float* Xs = smem;
   float* stage = Xs + TM * LDX;
+  // graph slice of the tile: ELL [D][TM] {local src, weight} when the batch's max degree D is small
+  // (fixed trip count => independent LDS chains), else CSR (local row pointers + entries)
+  const int D = p.ell_width;
+  int2* ell = reinterpret_cast<int2*>(stage + nw * TM * 32);
   int* lrow = reinterpret_cast<int*>(stage + nw * TM * 32);
   int2* lent = reinterpret_cast<int2*>(lrow + TM + 2);
 
   // ---- stage the X tile (zero padded to TM x kpad)
   const bool vec_ok = ((p.kreal & 3) == 0) && ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
-  if (vec_ok) {
+  if (dbg & 8) {
+  } else if (vec_ok) {
     const int kq = p.kpad >> 2;
     for (int idx = tid; idx < TM * kq; idx += nthreads) {
       const int r = idx / kq;
@@ -88,10 +100,19 @@ __global__ void __launch_bounds__(256) gemm_prop_kernel(const dss2_gemm_prop_arg
   }
   // ---- stage the tile's CSR slice (local row pointers, local column ids, weights)
   if (NMAT > 1) {
-    const int base = p.rowptr[ts];
-    const int nnz = p.rowptr[ts + R] - base;
-    for (int r = tid; r <= TM; r += nthreads) lrow[r] = (r <= R) ? (p.rowptr[ts + r] - base) : nnz;
-    for (int k = tid; k < nnz; k += nthreads) lent[k] = make_int2(p.col[base + k] - ts, __float_as_int(p.w[base + k]));
+    if (D > 0) {
+      for (int r = tid; r < TM; r += nthreads) {
+        const int e0 = (r < R) ? p.rowptr[ts + r] : 0;
+        const int deg = (r < R) ? p.rowptr[ts + r + 1] - e0 : 0;
+        for (int k = 0; k < D; ++k)
+          ell[k * TM + r] = (k < deg) ? make_int2(p.col[e0 + k] - ts, __float_as_int(p.w[e0 + k])) : make_int2(r, 0);
+      }
+    } else {
+      const int base = p.rowptr[ts];
+      const int nnz = p.rowptr[ts + R] - base;
+      for (int r = tid; r <= TM; r += nthreads) lrow[r] = (r <= R) ? (p.rowptr[ts + r] - base) : nnz;
+      for (int k = tid; k < nnz; k += nthreads) lent[k] = make_int2(p.col[base + k] - ts, __float_as_int(p.w[base + k]));
+    }
   }
   __syncthreads();
 
@@ -111,37 +132,57 @@ __global__ void __launch_bounds__(256) gemm_prop_kernel(const dss2_gemm_prop_arg
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rb][m][r] = 0.f;
 
-    f32x4 a_cur[NRB], b_cur[NMAT];
+    // k loop, 8 k-values per step.  A fragments (LDS, ~128 cycles) are prefetched one step ahead in
+    // two register buffers; B fragments (packed weights from L2, ~1 us under load) two steps ahead
+    // in three buffers.  No register copies, and sched_barrier(0) pins "issue loads, then MFMAs", so
+    // every s_waitcnt is a counted wait that sits right before the first MFMA that needs the data.
+    f32x4 a0[NRB] = {}, a1[NRB] = {}, a2[NRB] = {}, b0[NMAT] = {}, b1[NMAT] = {}, b2[NMAT] = {};
+    auto load_a = [&](f32x4 (&a)[NRB], int kk) {
+      if (dbg & 32) return;                     // diagnostics: no A (LDS) operand stream
+      const int kc = kk < nkk ? kk : nkk - 1;   // clamped: harmless reload past the end
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) a_cur[rb] = *reinterpret_cast<const f32x4*>(xa + rb * 32 * LDX);
+      for (int rb = 0; rb < NRB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(xa + rb * 32 * LDX + kc * 8);
+    };
+    auto load_b = [&](f32x4 (&b)[NMAT], int kk) {
+      if (dbg & 16) return;                     // diagnostics: no B (L2) operand stream
+      const int kc = kk < nkk ? kk : nkk - 1;
 #pragma unroll
-    for (int m = 0; m < NMAT; ++m) b_cur[m] = bp[((size_t)(m * p.ncg + cg) * nkk) * 64 + lane];
-
-    for (int kk = 0; kk < nkk; ++kk) {
-      const int kn = (kk + 1 < nkk) ? kk + 1 : kk;
-      f32x4 a_nxt[NRB], b_nxt[NMAT];
-#pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) a_nxt[rb] = *reinterpret_cast<const f32x4*>(xa + rb * 32 * LDX + kn * 8);
-#pragma unroll
-      for (int m = 0; m < NMAT; ++m) b_nxt[m] = bp[((size_t)(m * p.ncg + cg) * nkk + kn) * 64 + lane];
+      for (int m = 0; m < NMAT; ++m) b[m] = bp[((size_t)(m * p.ncg + cg) * nkk + kc) * 64 + lane];
+    };
+    auto mma_ab = [&](const f32x4 (&a)[NRB], const f32x4 (&b)[NMAT]) {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
           for (int m = 0; m < NMAT; ++m)
-            acc[rb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[rb][s], b_cur[m][s], acc[rb][m], 0, 0, 0);
-#pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) a_cur[rb] = a_nxt[rb];
-#pragma unroll
-      for (int m = 0; m < NMAT; ++m) b_cur[m] = b_nxt[m];
+            acc[rb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][s], b[m][s], acc[rb][m], 0, 0, 0);
+    };
+    // step KK: consumes (ACUR, BCUR), issues A of step KK+1 and B of step KK+2 first (period-3 rotation)
+#define DSS2_STEP(ACUR, ANXT, BCUR, BNXT2, KK) \
+    load_a(ANXT, (KK) + 1);                    \
+    load_b(BNXT2, (KK) + 2);                   \
+    __builtin_amdgcn_sched_barrier(0);         \
+    mma_ab(ACUR, BCUR);                        \
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(a0, 0);
+    load_b(b0, 0);
+    load_b(b1, 1);
+    int kk = (dbg & 1) ? nkk : 0;
+    for (; kk + 3 <= nkk; kk += 3) {
+      DSS2_STEP(a0, a1, b0, b2, kk)
+      DSS2_STEP(a1, a2, b1, b0, kk + 1)
+      DSS2_STEP(a2, a0, b2, b1, kk + 2)
     }
+    if (kk < nkk) { DSS2_STEP(a0, a1, b0, b2, kk) }
+    if (kk + 1 < nkk) { DSS2_STEP(a1, a2, b1, b0, kk + 1) }
+#undef DSS2_STEP
 
     // ---- Horner propagation: T = G_{NMAT-1}; T = G_m + P T
     f32x16 T[NRB];
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) T[rb] = acc[rb][NMAT - 1];
-    if (NMAT > 1) {
+    if (NMAT > 1 && !(dbg & 2)) {
 #pragma unroll
       for (int m = NMAT - 2; m >= 0; --m) {
         wave_lds_sync();  // previous round's reads of the stage are done
@@ -150,19 +191,34 @@ __global__ void __launch_bounds__(256) gemm_prop_kernel(const dss2_gemm_prop_arg
 #pragma unroll
           for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
         wave_lds_sync();
+        if (D > 0) {
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
+          for (int rb = 0; rb < NRB; ++rb) T[rb] = acc[rb][m];
+          for (int k = 0; k < D; ++k) {   // uniform trip count; the NRB*16 row chains are independent
+            const int2* ek = ell + k * TM + 4 * half;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = rb * 32 + acc_row(r, half);
-            float s = acc[rb][m][r];
-            const int e1 = lrow[row + 1];
-            for (int e = lrow[row]; e < e1; ++e) {
-              const int2 en = lent[e];
-              s = fmaf(__int_as_float(en.y), st[en.x * 32 + c32], s);
-            }
-            T[rb][r] = s;
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int2 en = ek[rb * 32 + acc_row(r, 0)];
+                T[rb][r] = fmaf(__int_as_float(en.y), st[en.x * 32 + c32], T[rb][r]);
+              }
           }
+        } else {
+#pragma unroll
+          for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = rb * 32 + acc_row(r, half);
+              float s = acc[rb][m][r];
+              const int e1 = lrow[row + 1];
+              for (int e = lrow[row]; e < e1; ++e) {
+                const int2 en = lent[e];
+                s = fmaf(__int_as_float(en.y), st[en.x * 32 + c32], s);
+              }
+              T[rb][r] = s;
+            }
+        }
       }
     }
 
@@ -174,28 +230,60 @@ __global__ void __launch_bounds__(256) gemm_prop_kernel(const dss2_gemm_prop_arg
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
     wave_lds_sync();
-    const int colg = cg * 32 + c32;
-    if (colg < p.hout) {
-      const float bias = p.bias ? p.bias[colg] : 0.f;
-      for (int row = half; row < R; row += 2) {
-        const size_t grow = (size_t)(ts + row);
-        float y = st[row * 32 + c32];
-        if (p.bias) y += p.rowscale ? bias * p.rowscale[grow] : bias;
-        if (p.dmask) y *= p.dmask[grow * p.ld_dmask + colg];
-        if (p.relu) y = fmaxf(y, 0.f);
-        if (p.relu_src) y = (p.relu_src[grow * p.ld_relu + colg] > 0.f) ? y : 0.f;
-        if (p.add_src) y += p.add_src[grow * p.ld_add + colg];
-        p.Y[grow * p.ldy + colg] = y;
+    const bool vec_epi = ((p.hout & 3) == 0) && ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.Y) & 15) == 0) &&
+                         (!p.relu_src || (((p.ld_relu & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.relu_src) & 15) == 0))) &&
+                         (!p.dmask || (((p.ld_dmask & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.dmask) & 15) == 0))) &&
+                         (!p.add_src || (((p.ld_add & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.add_src) & 15) == 0)));
+    if (dbg & 4) {
+    } else if (vec_epi) {
+      // 16 B per lane: 8 lanes cover the 32 columns of a row, 8 rows (8 x 128 B) per wave instruction
+      const int cq = (lane & 7) * 4, r8 = lane >> 3;
+      const int col0 = cg * 32 + cq;
+      if (col0 < p.hout) {
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col0);
+        for (int row = r8; row < R; row += 8) {
+          const size_t grow = (size_t)(ts + row);
+          f32x4 y = *reinterpret_cast<const f32x4*>(st + row * 32 + cq);
+          if (p.bias) y += p.rowscale ? bias4 * p.rowscale[grow] : bias4;
+          if (p.dmask) y *= *reinterpret_cast<const f32x4*>(p.dmask + grow * p.ld_dmask + col0);
+          if (p.relu & 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[q] = fmaxf(y[q], 0.f);
+          }
+          if (p.relu_src) {
+            const f32x4 rs = *reinterpret_cast<const f32x4*>(p.relu_src + grow * p.ld_relu + col0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[q] = rs[q] > 0.f ? y[q] : 0.f;
+          }
+          if (p.add_src) y += *reinterpret_cast<const f32x4*>(p.add_src + grow * p.ld_add + col0);
+          *reinterpret_cast<f32x4*>(p.Y + grow * p.ldy + col0) = y;
+        }
+      }
+    } else {
+      const int colg = cg * 32 + c32;
+      if (colg < p.hout) {
+        const float bias = p.bias ? p.bias[colg] : 0.f;
+        for (int row = half; row < R; row += 2) {
+          const size_t grow = (size_t)(ts + row);
+          float y = st[row * 32 + c32];
+          if (p.bias) y += p.rowscale ? bias * p.rowscale[grow] : bias;
+          if (p.dmask) y *= p.dmask[grow * p.ld_dmask + colg];
+          if (p.relu & 1) y = fmaxf(y, 0.f);
+          if (p.relu_src) y = (p.relu_src[grow * p.ld_relu + colg] > 0.f) ? y : 0.f;
+          if (p.add_src) y += p.add_src[grow * p.ld_add + colg];
+          p.Y[grow * p.ldy + colg] = y;
+        }
       }
     }
   }
 }
 
-static size_t lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz) {
+static size_t lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz, int ell_width) {
   const size_t TM = (size_t)nrb * 32;
   const int nw = ncg < 4 ? ncg : 4;
   size_t b = TM * (size_t)(kpad + 4) * 4 + (size_t)nw * TM * 32 * 4;
-  if (nmat > 1) b += (TM + 2) * 4 + (size_t)max_nnz * 8;
+  if (nmat > 1) b += ell_width > 0 ? TM * (size_t)ell_width * 8 : (TM + 2) * 4 + (size_t)max_nnz * 8;
   return b;
 }
 
@@ -212,7 +300,7 @@ static int launch(const dss2_gemm_prop_args& a, hipStream_t stream) {
     }
     attr_set = true;
   }
-  const size_t lds = lds_bytes(NRB, NMAT, a.kpad, a.ncg, a.max_nnz);
+  const size_t lds = lds_bytes(NRB, NMAT, a.kpad, a.ncg, a.max_nnz, a.ell_width);
   const int nw = a.ncg < 4 ? a.ncg : 4;
   hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * nw), lds, stream, a);
   return check_launch("gemm_prop");
@@ -220,8 +308,8 @@ static int launch(const dss2_gemm_prop_args& a, hipStream_t stream) {
 
 }  // namespace dss2
 
-extern "C" size_t dss2_gemm_prop_lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz) {
-  return dss2::lds_bytes(nrb, nmat, kpad, ncg, max_nnz);
+extern "C" size_t dss2_gemm_prop_lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz, int ell_width) {
+  return dss2::lds_bytes(nrb, nmat, kpad, ncg, max_nnz, ell_width);
 }
 
 extern "C" int dss2_pack_weights(const dss2_pack_desc* descs, int n_desc, int max_elems, void* stream) {
@@ -238,9 +326,10 @@ extern "C" int dss2_gemm_prop(const dss2_gemm_prop_args* ap, void* stream) {
   if ((a.kpad & 7) || a.kpad < a.kreal || a.kpad <= 0) { set_error("gemm_prop: bad kpad %d (kreal %d)", a.kpad, a.kreal); return 2; }
   if (a.ncg * 32 < a.hout || a.ncg <= 0) { set_error("gemm_prop: ncg %d too small for hout %d", a.ncg, a.hout); return 2; }
   if (a.nmat > 1 && (!a.rowptr || !a.col || !a.w)) { set_error("gemm_prop: nmat > 1 needs a CSR"); return 2; }
-  if (lds_bytes(a.nrb, a.nmat, a.kpad, a.ncg, a.max_nnz) > (size_t)kMaxLdsBytes) {
+  if (a.ell_width < 0 || a.ell_width > 32) { set_error("gemm_prop: ell_width %d out of range 0..32", a.ell_width); return 2; }
+  if (lds_bytes(a.nrb, a.nmat, a.kpad, a.ncg, a.max_nnz, a.ell_width) > (size_t)kMaxLdsBytes) {
     set_error("gemm_prop: tile needs %zu B of LDS (> 160 KiB): nrb=%d kpad=%d nnz=%d",
-              lds_bytes(a.nrb, a.nmat, a.kpad, a.ncg, a.max_nnz), a.nrb, a.kpad, a.max_nnz);
+              lds_bytes(a.nrb, a.nmat, a.kpad, a.ncg, a.max_nnz, a.ell_width), a.nrb, a.kpad, a.max_nnz);
     return 3;
   }
   hipStream_t s = as_stream(stream);

@@ -20,6 +20,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int
   float* Za = smem;
   float* Zb = Za + TM * LDZ;
   float* Xs = Zb + (NMAT > 1 ? TM * LDZ : 0);
+  const int D = p.ell_width;   // > 0: ELL [D][TM] slice of the transposed graph, else CSR slice
+  int2* ell = reinterpret_cast<int2*>(Xs + TM * XW);
   int* lrow = reinterpret_cast<int*>(Xs + TM * XW);
   int2* lent = reinterpret_cast<int2*>(lrow + TM + 2);
 
@@ -49,25 +51,65 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int
     const int n2e = (R + 1) >> 1;
     const float* zp = Z + half * LDZ + c32;
     const float* xp = Xs + half * XW + wave * 32 + c32;
-    for (int n2 = 0; n2 < n2e; ++n2) {
-      const float bv = xp[n2 * 2 * XW];
+    // two operand register sets in ping-pong: the LDS reads of step n2+1 are in flight while the
+    // MFMAs of step n2 issue (no register copies => the wait sits at the first use)
+    float b0, b1, a0[NB], a1[NB];
+    auto ld = [&](float& b, float (&a)[NB], int n2) {
+      b = xp[n2 * 2 * XW];
 #pragma unroll
-      for (int ob = 0; ob < NB; ++ob) {
-        const float av = zp[n2 * 2 * LDZ + ob * 32];
-        a[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, a[ob], 0, 0, 0);
-      }
+      for (int ob = 0; ob < NB; ++ob) a[ob] = zp[n2 * 2 * LDZ + ob * 32];
+    };
+    auto mm = [&](float b, const float (&av)[NB]) {
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob) a[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob], b, a[ob], 0, 0, 0);
+    };
+    ld(b0, a0, 0);
+    int n2 = 0;
+    for (; n2 + 2 <= n2e; n2 += 2) {
+      ld(b1, a1, n2 + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(b0, a0);
+      __builtin_amdgcn_sched_barrier(0);
+      ld(b0, a0, (n2 + 2 < n2e) ? n2 + 2 : n2 + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(b1, a1);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (n2 < n2e) mm(b0, a0);
   };
   auto prop = [&](const float* Zs, float* Zd) {
+    constexpr int RSTEP = 256 / LDZ;          // rows advanced per pass of the 256 threads
+    constexpr int NI = TM / RSTEP;            // rows owned by one thread
+    constexpr int CH = (NI % 16 == 0) ? 16 : ((NI % 8 == 0) ? 8 : 4);   // NI = NRB*NB*4; rows processed together
+    static_assert(NI % CH == 0, "row chunking must tile the thread's rows exactly");
     const int c = tid % LDZ;
-    for (int n = tid / LDZ; n < TM; n += 256 / LDZ) {
-      float s = 0.f;
-      const int e1 = lrow[n + 1];
-      for (int e = lrow[n]; e < e1; ++e) {
-        const int2 en = lent[e];
-        s = fmaf(__int_as_float(en.y), Zs[en.x * LDZ + c], s);
+    const int n0 = tid / LDZ;
+    if (D > 0) {
+      for (int i0 = 0; i0 < NI; i0 += CH) {
+        float s[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) s[i] = 0.f;
+        for (int k = 0; k < D; ++k) {
+          const int2* ek = ell + k * TM + n0 + i0 * RSTEP;
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            const int2 en = ek[i * RSTEP];
+            s[i] = fmaf(__int_as_float(en.y), Zs[en.x * LDZ + c], s[i]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) Zd[(n0 + (i0 + i) * RSTEP) * LDZ + c] = s[i];
       }
-      Zd[n * LDZ + c] = s;
+    } else {
+      for (int n = n0; n < TM; n += RSTEP) {
+        float s = 0.f;
+        const int e1 = lrow[n + 1];
+        for (int e = lrow[n]; e < e1; ++e) {
+          const int2 en = lent[e];
+          s = fmaf(__int_as_float(en.y), Zs[en.x * LDZ + c], s);
+        }
+        Zd[n * LDZ + c] = s;
+      }
     }
   };
 
@@ -104,10 +146,19 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int
       }
     }
     if (NMAT > 1) {
-      const int base = p.rowptrT[ts];
-      const int nnz = p.rowptrT[ts + R] - base;
-      for (int r = tid; r <= TM; r += 256) lrow[r] = (r <= R) ? (p.rowptrT[ts + r] - base) : nnz;
-      for (int k = tid; k < nnz; k += 256) lent[k] = make_int2(p.colT[base + k] - ts, __float_as_int(p.wT[base + k]));
+      if (D > 0) {
+        for (int r = tid; r < TM; r += 256) {
+          const int e0 = (r < R) ? p.rowptrT[ts + r] : 0;
+          const int deg = (r < R) ? p.rowptrT[ts + r + 1] - e0 : 0;
+          for (int k = 0; k < D; ++k)
+            ell[k * TM + r] = (k < deg) ? make_int2(p.colT[e0 + k] - ts, __float_as_int(p.wT[e0 + k])) : make_int2(r, 0);
+        }
+      } else {
+        const int base = p.rowptrT[ts];
+        const int nnz = p.rowptrT[ts + R] - base;
+        for (int r = tid; r <= TM; r += 256) lrow[r] = (r <= R) ? (p.rowptrT[ts + r] - base) : nnz;
+        for (int k = tid; k < nnz; k += 256) lent[k] = make_int2(p.colT[base + k] - ts, __float_as_int(p.wT[base + k]));
+      }
     }
     __syncthreads();
     // ---- bias gradient (column sums of G), only by the ibg == 0 slice
@@ -160,18 +211,18 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int
   if (ibg == 0 && tid < LDZ && gcol0 + tid < p.hout) out[(size_t)p.nmat * p.hout * p.hin + gcol0 + tid] = dbacc;
 }
 
-static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz) {
+static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz, int ell_width) {
   const size_t TM = (size_t)nrb * 32;
   size_t b = TM * (size_t)nb * 32 * 4 * (nmat > 1 ? 2 : 1) + TM * XW * 4;
-  if (nmat > 1) b += (TM + 2) * 4 + (size_t)max_nnz * 8;
+  if (nmat > 1) b += ell_width > 0 ? TM * (size_t)ell_width * 8 : (TM + 2) * 4 + (size_t)max_nnz * 8;
   return b;
 }
 
-static int pick_nb(int nrb, int nmat, int hout, int max_nnz) {
+static int pick_nb(int nrb, int nmat, int hout, int max_nnz, int ell_width) {
   const int nob = (hout + 31) / 32;
   for (int nb = 4; nb >= 1; nb >>= 1) {
     if (nb > 1 && nb / 2 >= nob) continue;  // do not over-allocate columns
-    if (wgrad_lds(nrb, nmat, nb, max_nnz) <= (size_t)kMaxLdsBytes) return nb;
+    if (wgrad_lds(nrb, nmat, nb, max_nnz, ell_width) <= (size_t)kMaxLdsBytes) return nb;
   }
   return 0;
 }
@@ -188,17 +239,17 @@ static int launch_wgrad(const dss2_wgrad_args& a, hipStream_t stream) {
   }
   const int nob = (a.hout + 31) / 32, nib = (a.hin + 31) / 32;
   const int nobg = (nob + NB - 1) / NB, nibg = (nib + 3) / 4;
-  const size_t lds = wgrad_lds(NRB, NMAT, NB, a.max_nnz);
+  const size_t lds = wgrad_lds(NRB, NMAT, NB, a.max_nnz, a.ell_width);
   hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg), dim3(256), lds, stream, a, nibg);
   return check_launch("wgrad");
 }
 
 }  // namespace dss2
 
-extern "C" size_t dss2_wgrad_lds_bytes(int nrb, int nmat, int hout, int hin, int max_nnz) {
+extern "C" size_t dss2_wgrad_lds_bytes(int nrb, int nmat, int hout, int hin, int max_nnz, int ell_width) {
   (void)hin;
-  const int nb = dss2::pick_nb(nrb, nmat, hout, max_nnz);
-  return nb ? dss2::wgrad_lds(nrb, nmat, nb, max_nnz) : (size_t)-1;
+  const int nb = dss2::pick_nb(nrb, nmat, hout, max_nnz, ell_width);
+  return nb ? dss2::wgrad_lds(nrb, nmat, nb, max_nnz, ell_width) : (size_t)-1;
 }
 
 extern "C" int dss2_wgrad(const dss2_wgrad_args* ap, void* stream) {
@@ -206,7 +257,8 @@ extern "C" int dss2_wgrad(const dss2_wgrad_args* ap, void* stream) {
   const dss2_wgrad_args& a = *ap;
   if (a.n_split <= 0 || !a.slab) { set_error("wgrad: n_split/slab missing"); return 2; }
   if (a.nmat > 1 && (!a.rowptrT || !a.colT || !a.wT)) { set_error("wgrad: nmat > 1 needs the transposed CSR"); return 2; }
-  const int nb = pick_nb(a.nrb, a.nmat, a.hout, a.max_nnz);
+  if (a.ell_width < 0 || a.ell_width > 32) { set_error("wgrad: ell_width %d out of range 0..32", a.ell_width); return 2; }
+  const int nb = pick_nb(a.nrb, a.nmat, a.hout, a.max_nnz, a.ell_width);
   if (!nb) { set_error("wgrad: tile of %d rows does not fit LDS (nmat=%d nnz=%d)", a.nrb * 32, a.nmat, a.max_nnz); return 3; }
   hipStream_t s = as_stream(stream);
 #define DSS2_CASE(NRB, NMAT, NB) \

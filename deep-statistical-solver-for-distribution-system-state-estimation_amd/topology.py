@@ -22,6 +22,7 @@ from . import _lib
 _FLIP = 1 << 31
 _NRB_CHOICES = (2, 4, 3, 1, 6)   # preference order on utilisation ties (32*nrb rows per tile)
 _LDS_LIMIT = 160 * 1024
+_ELL_MAX = 8
 
 
 def reference_is_directed(edge_index: torch.Tensor) -> bool:
@@ -136,10 +137,15 @@ class Topology:
         self.ntiles = len(ts) - 1
         self.max_nnz = int((rowptr_h[ts[1:]] - rowptr_h[ts[:-1]]).max())
         self.max_nnzT = int((rowptrT_h[ts[1:]] - rowptrT_h[ts[:-1]]).max())
+        # ELL width for the in-LDS propagation (0 = use the CSR path: hubs would waste padded slots)
+        md, mdT = int(np.diff(rowptr_h).max()), int(np.diff(rowptrT_h).max())
+        self.ell = md if md <= _ELL_MAX else 0
+        self.ellT = mdT if mdT <= _ELL_MAX else 0
         self.tile_start = torch.from_numpy(ts).to(dev)
 
     def lds_check(self, nmat: int, kpad: int, ncg: int) -> None:
-        need = _lib.lib().dss2_gemm_prop_lds_bytes(self.nrb, nmat, kpad, ncg, max(self.max_nnz, self.max_nnzT))
+        need = _lib.lib().dss2_gemm_prop_lds_bytes(self.nrb, nmat, kpad, ncg, max(self.max_nnz, self.max_nnzT),
+                                                    min(self.ell, self.ellT))
         if need > _LDS_LIMIT:
             raise NotImplementedError(f"tile of {32 * self.nrb} rows x K={kpad} needs {need} B of LDS (> 160 KiB)")
 

@@ -117,7 +117,10 @@ typedef struct dss2_gemm_prop_args {
   int32_t relu; int32_t nmat; int32_t nrb; int32_t ntiles;
   const int32_t* tile_start;
   const int32_t* rowptr; const int32_t* col; const float* w;
-  int32_t max_nnz; int32_t pad_;
+  int32_t max_nnz;                 /* max CSR entries of one tile (CSR staging)            */
+  int32_t ell_width;               /* > 0: max row degree of the batch; the tile's graph    *
+                                    * slice is staged as ELL [ell_width][rows] (fixed trip  *
+                                    * count); 0: stage the CSR slice (any degree)           */
 } dss2_gemm_prop_args;
 
 int dss2_gemm_prop(const dss2_gemm_prop_args* args_host, void* stream);
@@ -134,7 +137,7 @@ typedef struct dss2_wgrad_args {
   float* slab; int32_t n_split; int32_t nmat; int32_t nrb; int32_t ntiles;
   const int32_t* tile_start;
   const int32_t* rowptrT; const int32_t* colT; const float* wT;
-  int32_t max_nnz; int32_t pad_;
+  int32_t max_nnz; int32_t ell_width;   /* as in dss2_gemm_prop_args, for the transposed CSR */
 } dss2_wgrad_args;
 
 int dss2_wgrad(const dss2_wgrad_args* args_host, void* stream);
@@ -188,8 +191,8 @@ int dss2_get_pflow(const float* y, int64_t ldy, const float* node_param, int64_t
 
 /* LDS bytes a dss2_gemm_prop / dss2_wgrad launch will request (host-side helper; lets the
  * caller reject configurations that do not fit the 160 KiB LDS before launching). */
-size_t dss2_gemm_prop_lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz);
-size_t dss2_wgrad_lds_bytes(int nrb, int nmat, int hout, int hin, int max_nnz);
+size_t dss2_gemm_prop_lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz, int ell_width);
+size_t dss2_wgrad_lds_bytes(int nrb, int nmat, int hout, int hin, int max_nnz, int ell_width);
 
 #ifdef __cplusplus
 }

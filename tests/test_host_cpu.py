@@ -22,8 +22,8 @@ def test_library_exports_every_declared_symbol():
         assert getattr(lib, name) is not None
     assert lib.dss2_version() >= 1
     # pure host helpers may be called without a GPU
-    assert lib.dss2_gemm_prop_lds_bytes(2, 3, 128, 4, 120) < 160 * 1024
-    assert lib.dss2_gemm_prop_lds_bytes(8, 3, 256, 8, 500) > 160 * 1024
+    assert lib.dss2_gemm_prop_lds_bytes(2, 3, 128, 4, 120, 3) < 160 * 1024
+    assert lib.dss2_gemm_prop_lds_bytes(8, 3, 256, 8, 500, 0) > 160 * 1024
 
 
 def test_struct_layouts_match_the_header_sizes():
