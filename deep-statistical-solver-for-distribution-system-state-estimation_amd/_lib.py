@@ -19,7 +19,7 @@ c_i32p = C.c_void_p
 class PackDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("ld", C.c_int32), ("transpose", C.c_int32), ("koff", C.c_int32), ("kpad", C.c_int32),
-                ("ncg", C.c_int32), ("pad_", C.c_int32)]
+                ("ncg", C.c_int32), ("joff", C.c_int32)]
 
 
 class GemmPropArgs(C.Structure):
@@ -32,7 +32,8 @@ class GemmPropArgs(C.Structure):
                 ("relu", C.c_int32), ("nmat", C.c_int32), ("nrb", C.c_int32), ("ntiles", C.c_int32),
                 ("tile_start", C.c_void_p),
                 ("rowptr", C.c_void_p), ("col", C.c_void_p), ("w", C.c_void_p),
-                ("max_nnz", C.c_int32), ("ell_width", C.c_int32)]
+                ("max_nnz", C.c_int32), ("ell_width", C.c_int32),
+                ("prop_in", C.c_int32), ("narrow_h", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -43,7 +44,7 @@ class WgradArgs(C.Structure):
                 ("ntiles", C.c_int32),
                 ("tile_start", C.c_void_p),
                 ("rowptrT", C.c_void_p), ("colT", C.c_void_p), ("wT", C.c_void_p),
-                ("max_nnz", C.c_int32), ("ell_width", C.c_int32)]
+                ("max_nnz", C.c_int32), ("ell_width", C.c_int32), ("narrow", C.c_int32), ("pad_", C.c_int32)]
 
 
 class WlsArgs(C.Structure):

@@ -23,25 +23,25 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const dss2_pack_desc*
   const dss2_pack_desc d = descs[blockIdx.y];
   const int K = d.transpose ? d.cols : d.rows;
   const int J = d.transpose ? d.rows : d.cols;
-  const int nkl = (K + 7) >> 3;       // k-groups covered by this block
-  const int nkk = d.kpad >> 3;        // k-groups of the whole packed matrix
-  const int total = d.ncg * nkl * 64;
+  // destination k-groups / column groups this block touches
+  const int kg0 = d.koff >> 3, kg1 = (d.koff + K + 7) >> 3;
+  const int cg0 = d.joff >> 5, cg1 = (d.joff + J + 31) >> 5;
+  const int nkl = kg1 - kg0;
+  const int nkk = d.kpad >> 3;
+  const int total = (cg1 - cg0) * nkl * 64;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int lane = idx & 63;
-  const int kkl = (idx >> 6) % nkl;
-  const int cg = (idx >> 6) / nkl;
-  const int j = cg * 32 + (lane & 31);
-  f32x4 v;
+  const int kg = kg0 + (idx >> 6) % nkl;
+  const int cg = cg0 + (idx >> 6) / nkl;
+  const int j = cg * 32 + (lane & 31) - d.joff;     // source column
+  if (j < 0 || j >= J) return;
+  float* dst = d.dst + (((size_t)cg * nkk + kg) * 64 + lane) * 4;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const int k = kkl * 8 + 4 * (lane >> 5) + s;
-    float val = 0.f;
-    if (k < K && j < J) val = d.transpose ? d.src[(size_t)j * d.ld + k] : d.src[(size_t)k * d.ld + j];
-    v[s] = val;
+    const int k = kg * 8 + 4 * (lane >> 5) + s - d.koff;   // source k
+    if (k >= 0 && k < K) dst[s] = d.transpose ? d.src[(size_t)j * d.ld + k] : d.src[(size_t)k * d.ld + j];
   }
-  f32x4* dst = reinterpret_cast<f32x4*>(d.dst);
-  dst[((size_t)cg * nkk + (d.koff >> 3) + kkl) * 64 + lane] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -77,8 +77,10 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   int* lrow = reinterpret_cast<int*>(stage + nw * TM * 32);
   int2* lent = reinterpret_cast<int2*>(lrow + TM + 2);
 
-  // ---- stage the X tile (zero padded to TM x kpad)
-  const bool vec_ok = ((p.kreal & 3) == 0) && ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
+  // ---- stage the X tile (zero padded to TM x kpad); with input-side propagation only the first
+  //      kin columns come from memory, the propagated copies are appended below
+  const int kin = p.prop_in > 0 ? p.kreal / (p.prop_in + 1) : p.kreal;
+  const bool vec_ok = ((kin & 3) == 0) && ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
   if (dbg & 8) {
   } else if (vec_ok) {
     const int kq = p.kpad >> 2;
@@ -86,7 +88,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       const int r = idx / kq;
       const int c = (idx - r * kq) << 2;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
+      if (r < R && c < kin) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
       *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = v;
     }
   } else {
@@ -94,12 +96,12 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       const int r = idx / p.kpad;
       const int c = idx - r * p.kpad;
       float v = 0.f;
-      if (r < R && c < p.kreal) v = p.X[(size_t)(ts + r) * p.ldx + c];
+      if (r < R && c < kin) v = p.X[(size_t)(ts + r) * p.ldx + c];
       Xs[r * LDX + c] = v;
     }
   }
   // ---- stage the tile's CSR slice (local row pointers, local column ids, weights)
-  if (NMAT > 1) {
+  if (NMAT > 1 || p.prop_in > 0) {
     if (D > 0) {
       for (int r = tid; r < TM; r += nthreads) {
         const int e0 = (r < R) ? p.rowptr[ts + r] : 0;
@@ -115,6 +117,28 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
     }
   }
   __syncthreads();
+  // ---- input-side propagation (narrow inputs): X_h = P X_{h-1} appended as columns [h*kin, (h+1)*kin)
+  for (int hop = 1; hop <= p.prop_in; ++hop) {
+    for (int idx = tid; idx < R * kin; idx += nthreads) {
+      const int row = idx / kin, j = idx - row * kin;
+      const float* src = Xs + (hop - 1) * kin + j;
+      float sacc = 0.f;
+      if (D > 0) {
+        for (int k = 0; k < D; ++k) {
+          const int2 en = ell[k * TM + row];
+          sacc = fmaf(__int_as_float(en.y), src[en.x * LDX], sacc);
+        }
+      } else {
+        const int e1 = lrow[row + 1];
+        for (int e = lrow[row]; e < e1; ++e) {
+          const int2 en = lent[e];
+          sacc = fmaf(__int_as_float(en.y), src[en.x * LDX], sacc);
+        }
+      }
+      Xs[row * LDX + hop * kin + j] = sacc;
+    }
+    __syncthreads();
+  }
 
   const int c32 = lane & 31;   // A row inside a row block == output column inside a column group
   const int half = lane >> 5;
@@ -279,6 +303,156 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// narrow outputs (nmat * h <= 32, e.g. the last TAGConv H -> 2): all matrices side by side in ONE
+// 32-column MFMA block (a third of the MFMA work of the column-group-per-matrix layout), all 256
+// threads stage the tile, wave w multiplies row block w, and the Horner recurrence
+// T_m = G_m + P T_{m+1} runs in place across the column blocks of a shared LDS stage.
+// ------------------------------------------------------------------------------------------
+template <int NRB>
+__global__ void __launch_bounds__(256) gemm_narrow_kernel(const dss2_gemm_prop_args p) {
+  constexpr int TM = NRB * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x;
+  const int ts = p.tile_start[tile];
+  const int R = p.tile_start[tile + 1] - ts;
+  const int LDX = p.kpad + 4;
+  const int D = p.ell_width;
+  const int h = p.narrow_h, nm = p.nmat;
+  float* Xs = smem;
+  float* st = Xs + TM * LDX;                       // [TM][32] shared stage
+  int2* ell = reinterpret_cast<int2*>(st + TM * 32);
+  int* lrow = reinterpret_cast<int*>(st + TM * 32);
+  int2* lent = reinterpret_cast<int2*>(lrow + TM + 2);
+
+  const bool vec_ok = ((p.kreal & 3) == 0) && ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
+  if (vec_ok) {
+    const int kq = p.kpad >> 2;
+    for (int idx = tid; idx < TM * kq; idx += 256) {
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
+      *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = v;
+    }
+  } else {
+    for (int idx = tid; idx < TM * p.kpad; idx += 256) {
+      const int r = idx / p.kpad, c = idx - r * p.kpad;
+      Xs[r * LDX + c] = (r < R && c < p.kreal) ? p.X[(size_t)(ts + r) * p.ldx + c] : 0.f;
+    }
+  }
+  if (nm > 1) {
+    if (D > 0) {
+      for (int r = tid; r < TM; r += 256) {
+        const int e0 = (r < R) ? p.rowptr[ts + r] : 0;
+        const int deg = (r < R) ? p.rowptr[ts + r + 1] - e0 : 0;
+        for (int k = 0; k < D; ++k)
+          ell[k * TM + r] = (k < deg) ? make_int2(p.col[e0 + k] - ts, __float_as_int(p.w[e0 + k])) : make_int2(r, 0);
+      }
+    } else {
+      const int base = p.rowptr[ts];
+      const int nnz = p.rowptr[ts + R] - base;
+      for (int r = tid; r <= TM; r += 256) lrow[r] = (r <= R) ? (p.rowptr[ts + r] - base) : nnz;
+      for (int k = tid; k < nnz; k += 256) lent[k] = make_int2(p.col[base + k] - ts, __float_as_int(p.w[base + k]));
+    }
+  }
+  __syncthreads();
+
+  const int c32 = lane & 31, half = lane >> 5;
+  const int nkk = p.kpad >> 3;
+  const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(p.Bp);
+  for (int rb = wave; rb < NRB; rb += 4) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* xa = Xs + (rb * 32 + c32) * LDX + half * 4;
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(xa), b0 = bp[lane], a1 = a0, b1 = b0;
+    int kk = 0;
+    for (; kk + 2 <= nkk; kk += 2) {
+      a1 = *reinterpret_cast<const f32x4*>(xa + (kk + 1) * 8);
+      b1 = bp[(size_t)(kk + 1) * 64 + lane];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      const int kn = (kk + 2 < nkk) ? kk + 2 : kk + 1;
+      a0 = *reinterpret_cast<const f32x4*>(xa + kn * 8);
+      b0 = bp[(size_t)kn * 64 + lane];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], b1[s], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kk < nkk) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], b0[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = acc[r];
+  }
+  __syncthreads();
+  // Horner across column blocks, in place: block m <- G_m + P * block (m+1)
+  for (int m = nm - 2; m >= 0; --m) {
+    float tmp[2];   // R*h <= 192*10 items over 256 threads: at most a few per thread
+    int cnt = 0;
+    for (int idx = tid; idx < R * h; idx += 256) {
+      const int row = idx / h, j = idx - row * h;
+      const float* src = st + (m + 1) * h + j;
+      float sacc = st[row * 32 + m * h + j];
+      if (D > 0) {
+        for (int k = 0; k < D; ++k) {
+          const int2 en = ell[k * TM + row];
+          sacc = fmaf(__int_as_float(en.y), src[en.x * 32], sacc);
+        }
+      } else {
+        const int e1 = lrow[row + 1];
+        for (int e = lrow[row]; e < e1; ++e) {
+          const int2 en = lent[e];
+          sacc = fmaf(__int_as_float(en.y), src[en.x * 32], sacc);
+        }
+      }
+      st[row * 32 + m * h + j] = sacc;   // block m is read only by its own item: no hazard
+      (void)tmp; (void)cnt;
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < R * h; idx += 256) {
+    const int row = idx / h, j = idx - row * h;
+    const size_t grow = (size_t)(ts + row);
+    float y = st[row * 32 + j];
+    if (p.bias) y += p.rowscale ? p.bias[j] * p.rowscale[grow] : p.bias[j];
+    if (p.dmask) y *= p.dmask[grow * p.ld_dmask + j];
+    if (p.relu & 1) y = fmaxf(y, 0.f);
+    if (p.relu_src) y = (p.relu_src[grow * p.ld_relu + j] > 0.f) ? y : 0.f;
+    if (p.add_src) y += p.add_src[grow * p.ld_add + j];
+    p.Y[grow * p.ldy + j] = y;
+  }
+}
+
+static size_t narrow_lds_bytes(int nrb, int nmat, int kpad, int max_nnz, int ell_width) {
+  const size_t TM = (size_t)nrb * 32;
+  size_t b = TM * (size_t)(kpad + 4) * 4 + TM * 32 * 4;
+  if (nmat > 1) b += ell_width > 0 ? TM * (size_t)ell_width * 8 : (TM + 2) * 4 + (size_t)max_nnz * 8;
+  return b;
+}
+
+template <int NRB>
+static int launch_narrow(const dss2_gemm_prop_args& a, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = gemm_narrow_kernel<NRB>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
+    if (e != hipSuccess) { set_error("gemm_narrow: hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(256), narrow_lds_bytes(NRB, a.nmat, a.kpad, a.max_nnz, a.ell_width),
+                     stream, a);
+  return check_launch("gemm_narrow");
+}
+
 static size_t lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz, int ell_width) {
   const size_t TM = (size_t)nrb * 32;
   const int nw = ncg < 4 ? ncg : 4;
@@ -300,7 +474,7 @@ static int launch(const dss2_gemm_prop_args& a, hipStream_t stream) {
     }
     attr_set = true;
   }
-  const size_t lds = lds_bytes(NRB, NMAT, a.kpad, a.ncg, a.max_nnz, a.ell_width);
+  const size_t lds = lds_bytes(NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.ncg, a.max_nnz, a.ell_width);
   const int nw = a.ncg < 4 ? a.ncg : 4;
   hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * nw), lds, stream, a);
   return check_launch("gemm_prop");
@@ -325,11 +499,26 @@ extern "C" int dss2_gemm_prop(const dss2_gemm_prop_args* ap, void* stream) {
   if (a.ntiles <= 0) return 0;
   if ((a.kpad & 7) || a.kpad < a.kreal || a.kpad <= 0) { set_error("gemm_prop: bad kpad %d (kreal %d)", a.kpad, a.kreal); return 2; }
   if (a.ncg * 32 < a.hout || a.ncg <= 0) { set_error("gemm_prop: ncg %d too small for hout %d", a.ncg, a.hout); return 2; }
-  if (a.nmat > 1 && (!a.rowptr || !a.col || !a.w)) { set_error("gemm_prop: nmat > 1 needs a CSR"); return 2; }
+  if ((a.nmat > 1 || a.prop_in > 0) && (!a.rowptr || !a.col || !a.w)) { set_error("gemm_prop: propagation needs a CSR"); return 2; }
+  if (a.prop_in > 0 && (a.nmat != 1 || a.kreal % (a.prop_in + 1) != 0)) { set_error("gemm_prop: prop_in needs nmat == 1 and kreal divisible by prop_in+1"); return 2; }
+  if (a.narrow_h > 0) {
+    if (a.nmat * a.narrow_h > 32 || a.hout != a.narrow_h || a.prop_in) { set_error("gemm_prop: narrow mode needs nmat*narrow_h <= 32 and hout == narrow_h"); return 2; }
+    if (narrow_lds_bytes(a.nrb, a.nmat, a.kpad, a.max_nnz, a.ell_width) > (size_t)kMaxLdsBytes) { set_error("gemm_prop(narrow): tile does not fit LDS"); return 3; }
+    hipStream_t sn = as_stream(stream);
+    switch (a.nrb) {
+      case 1: return launch_narrow<1>(a, sn);
+      case 2: return launch_narrow<2>(a, sn);
+      case 3: return launch_narrow<3>(a, sn);
+      case 4: return launch_narrow<4>(a, sn);
+      case 6: return launch_narrow<6>(a, sn);
+      case 8: return launch_narrow<8>(a, sn);
+      default: set_error("gemm_prop(narrow): unsupported nrb=%d", a.nrb); return 2;
+    }
+  }
   if (a.ell_width < 0 || a.ell_width > 32) { set_error("gemm_prop: ell_width %d out of range 0..32", a.ell_width); return 2; }
-  if (lds_bytes(a.nrb, a.nmat, a.kpad, a.ncg, a.max_nnz, a.ell_width) > (size_t)kMaxLdsBytes) {
+  if (lds_bytes(a.nrb, a.prop_in > 0 ? 2 : a.nmat, a.kpad, a.ncg, a.max_nnz, a.ell_width) > (size_t)kMaxLdsBytes) {
     set_error("gemm_prop: tile needs %zu B of LDS (> 160 KiB): nrb=%d kpad=%d nnz=%d",
-              lds_bytes(a.nrb, a.nmat, a.kpad, a.ncg, a.max_nnz, a.ell_width), a.nrb, a.kpad, a.max_nnz);
+              lds_bytes(a.nrb, a.prop_in > 0 ? 2 : a.nmat, a.kpad, a.ncg, a.max_nnz, a.ell_width), a.nrb, a.kpad, a.max_nnz);
     return 3;
   }
   hipStream_t s = as_stream(stream);

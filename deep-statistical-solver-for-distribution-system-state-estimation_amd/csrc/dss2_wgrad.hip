@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int
         Xs[idx] = (r < R && xcol0 + c < p.hin) ? p.X[(size_t)(ts + r) * p.ldx + xcol0 + c] : 0.f;
       }
     }
-    if (NMAT > 1) {
+    if (NMAT > 1 || p.narrow) {
       if (D > 0) {
         for (int r = tid; r < TM; r += 256) {
           const int e0 = (r < R) ? p.rowptrT[ts + r] : 0;
@@ -161,6 +161,31 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int
       }
     }
     __syncthreads();
+    // ---- narrow mode: append P^m G as column blocks [m*hout, (m+1)*hout) of the same 32-wide slab
+    if (p.narrow) {
+      const int h = p.hout;
+      for (int m = 1; m < p.nmat; ++m) {
+        for (int idx = tid; idx < R * h; idx += 256) {
+          const int row = idx / h, j = idx - row * h;
+          const float* src = Za + (m - 1) * h + j;
+          float sacc = 0.f;
+          if (D > 0) {
+            for (int k = 0; k < D; ++k) {
+              const int2 en = ell[k * TM + row];
+              sacc = fmaf(__int_as_float(en.y), src[en.x * LDZ], sacc);
+            }
+          } else {
+            const int e1 = lrow[row + 1];
+            for (int e = lrow[row]; e < e1; ++e) {
+              const int2 en = lent[e];
+              sacc = fmaf(__int_as_float(en.y), src[en.x * LDZ], sacc);
+            }
+          }
+          Za[row * LDZ + m * h + j] = sacc;
+        }
+        __syncthreads();
+      }
+    }
     // ---- bias gradient (column sums of G), only by the ibg == 0 slice
     if (ibg == 0 && tid < LDZ) {
       float s = 0.f;
@@ -204,17 +229,19 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int o = gcol0 + ob * 32 + acc_row(r, half);
-            if (o < p.hout) out[((size_t)m * p.hout + o) * p.hin + i] = acc[m][ob][r];
+            // narrow mode: row o of the single block IS row (m', j) = (o / hout, o % hout) of dW_cat
+            if (o < (p.narrow ? p.nmat * p.hout : p.hout)) out[((size_t)m * p.hout + o) * p.hin + i] = acc[m][ob][r];
           }
     }
   }
   if (ibg == 0 && tid < LDZ && gcol0 + tid < p.hout) out[(size_t)p.nmat * p.hout * p.hin + gcol0 + tid] = dbacc;
 }
 
-static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz, int ell_width) {
+// nmat here = number of MFMA matrix passes (1 in narrow mode); graph = a graph slice is staged
+static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz, int ell_width, bool graph) {
   const size_t TM = (size_t)nrb * 32;
   size_t b = TM * (size_t)nb * 32 * 4 * (nmat > 1 ? 2 : 1) + TM * XW * 4;
-  if (nmat > 1) b += ell_width > 0 ? TM * (size_t)ell_width * 8 : (TM + 2) * 4 + (size_t)max_nnz * 8;
+  if (graph) b += ell_width > 0 ? TM * (size_t)ell_width * 8 : (TM + 2) * 4 + (size_t)max_nnz * 8;
   return b;
 }
 
@@ -222,7 +249,7 @@ static int pick_nb(int nrb, int nmat, int hout, int max_nnz, int ell_width) {
   const int nob = (hout + 31) / 32;
   for (int nb = 4; nb >= 1; nb >>= 1) {
     if (nb > 1 && nb / 2 >= nob) continue;  // do not over-allocate columns
-    if (wgrad_lds(nrb, nmat, nb, max_nnz, ell_width) <= (size_t)kMaxLdsBytes) return nb;
+    if (wgrad_lds(nrb, nmat, nb, max_nnz, ell_width, nmat > 1) <= (size_t)kMaxLdsBytes) return nb;
   }
   return 0;
 }
@@ -239,7 +266,7 @@ static int launch_wgrad(const dss2_wgrad_args& a, hipStream_t stream) {
   }
   const int nob = (a.hout + 31) / 32, nib = (a.hin + 31) / 32;
   const int nobg = (nob + NB - 1) / NB, nibg = (nib + 3) / 4;
-  const size_t lds = wgrad_lds(NRB, NMAT, NB, a.max_nnz, a.ell_width);
+  const size_t lds = wgrad_lds(NRB, NMAT, NB, a.max_nnz, a.ell_width, NMAT > 1 || a.narrow);
   hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg), dim3(256), lds, stream, a, nibg);
   return check_launch("wgrad");
 }
@@ -248,8 +275,9 @@ static int launch_wgrad(const dss2_wgrad_args& a, hipStream_t stream) {
 
 extern "C" size_t dss2_wgrad_lds_bytes(int nrb, int nmat, int hout, int hin, int max_nnz, int ell_width) {
   (void)hin;
+  if (nmat > 1 && nmat * hout <= 32) return dss2::wgrad_lds(nrb, 1, 1, max_nnz, ell_width, true);   // narrow mode
   const int nb = dss2::pick_nb(nrb, nmat, hout, max_nnz, ell_width);
-  return nb ? dss2::wgrad_lds(nrb, nmat, nb, max_nnz, ell_width) : (size_t)-1;
+  return nb ? dss2::wgrad_lds(nrb, nmat, nb, max_nnz, ell_width, nmat > 1) : (size_t)-1;
 }
 
 extern "C" int dss2_wgrad(const dss2_wgrad_args* ap, void* stream) {
@@ -258,6 +286,18 @@ extern "C" int dss2_wgrad(const dss2_wgrad_args* ap, void* stream) {
   if (a.n_split <= 0 || !a.slab) { set_error("wgrad: n_split/slab missing"); return 2; }
   if (a.nmat > 1 && (!a.rowptrT || !a.colT || !a.wT)) { set_error("wgrad: nmat > 1 needs the transposed CSR"); return 2; }
   if (a.ell_width < 0 || a.ell_width > 32) { set_error("wgrad: ell_width %d out of range 0..32", a.ell_width); return 2; }
+  if (a.narrow) {
+    if (a.nmat * a.hout > 32) { set_error("wgrad: narrow mode needs nmat*hout <= 32"); return 2; }
+    hipStream_t sn = as_stream(stream);
+    switch (a.nrb) {
+      case 1: return launch_wgrad<1, 1, 1>(a, sn);
+      case 2: return launch_wgrad<2, 1, 1>(a, sn);
+      case 3: return launch_wgrad<3, 1, 1>(a, sn);
+      case 4: return launch_wgrad<4, 1, 1>(a, sn);
+      case 6: return launch_wgrad<6, 1, 1>(a, sn);
+      default: set_error("wgrad(narrow): unsupported nrb=%d", a.nrb); return 2;
+    }
+  }
   const int nb = pick_nb(a.nrb, a.nmat, a.hout, a.max_nnz, a.ell_width);
   if (!nb) { set_error("wgrad: tile of %d rows does not fit LDS (nmat=%d nnz=%d)", a.nrb * 32, a.nmat, a.max_nnz); return 3; }
   hipStream_t s = as_stream(stream);

@@ -73,14 +73,15 @@ def _ncg(j: int) -> int:
 # ------------------------------------------------------------------------------------------
 def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.Tensor, nmat: int, hout: int,
               Y: torch.Tensor, bias=None, rowscale=None, relu_src=None, dmask=None, add_src=None, add_ld=0,
-              relu: bool = False, transposed: bool = False) -> None:
+              relu: bool = False, transposed: bool = False, prop_in: int = 0, narrow_h: int = 0) -> None:
     a = _lib.GemmPropArgs()
+    a.prop_in, a.narrow_h = prop_in, narrow_h
     a.X, a.ldx, a.kreal, a.kpad = X.data_ptr(), ldx, kreal, _round8(kreal)
     a.Bp, a.bias, a.rowscale = Bp.data_ptr(), _ptr(bias), _ptr(rowscale)
     a.relu_src, a.ld_relu = _ptr(relu_src), (relu_src.stride(0) if relu_src is not None else 0)
     a.dmask, a.ld_dmask = _ptr(dmask), (dmask.stride(0) if dmask is not None else 0)
     a.add_src, a.ld_add = _ptr(add_src), add_ld
-    a.Y, a.ldy, a.hout, a.ncg = Y.data_ptr(), Y.stride(0), hout, _ncg(hout)
+    a.Y, a.ldy, a.hout, a.ncg = Y.data_ptr(), Y.stride(0), hout, (1 if narrow_h else _ncg(hout))
     a.relu, a.nmat, a.nrb, a.ntiles = int(relu), nmat, topo.nrb, topo.ntiles
     a.tile_start = topo.tile_start.data_ptr()
     if transposed:
@@ -95,7 +96,10 @@ def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.T
 def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int, nmat: int, out_flat: torch.Tensor,
           rowscale=None) -> None:
     """out_flat[nmat*hout*hin + hout] <- [dW_0 .. dW_{nmat-1}, db] (deterministic two-pass sum)."""
-    n_split = min(topo.ntiles, 256)
+    narrow = nmat > 1 and nmat * hout <= 32
+    lds = _lib.lib().dss2_wgrad_lds_bytes(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT)
+    per_cu = max(1, min(4, (160 * 1024) // max(int(lds), 1)))     # resident workgroups per CU by LDS
+    n_split = min(topo.ntiles, 256 * per_cu)
     stride = nmat * hout * hin + hout
     slab = torch.empty(n_split * stride, dtype=_F32, device=G.device)
     a = _lib.WgradArgs()
@@ -106,6 +110,7 @@ def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int,
     a.tile_start = topo.tile_start.data_ptr()
     a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
     a.ell_width = topo.ellT
+    a.narrow = int(narrow)
     st = _stream(G)
     _lib.check(_lib.lib().dss2_wgrad(C.byref(a), st), "dss2_wgrad")
     _lib.check(_lib.lib().dss2_reduce_slabs(slab.data_ptr(), n_split, stride, out_flat.data_ptr(), stride, st),
@@ -126,7 +131,14 @@ def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, ent: torch.Tensor, n_ro
 # weight packing plans
 # ------------------------------------------------------------------------------------------
 _DESC_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("ld", "<i4"),
-                        ("transpose", "<i4"), ("koff", "<i4"), ("kpad", "<i4"), ("ncg", "<i4"), ("pad_", "<i4")])
+                        ("transpose", "<i4"), ("koff", "<i4"), ("kpad", "<i4"), ("ncg", "<i4"), ("joff", "<i4")])
+
+
+def is_narrow(nmat: int, hout: int) -> bool:
+    """Layers whose nmat*hout output columns fit one 32-wide MFMA block use the packed layouts:
+    forward = matrices side by side in one column group (output-side Horner across column blocks),
+    data-gradient = matrices stacked along k (input-side propagation)."""
+    return nmat > 1 and nmat * hout <= 32
 
 
 class _PackPlan:
@@ -141,10 +153,14 @@ class _PackPlan:
         for mats in groups:
             hout, hin = mats[0].shape
             nm = len(mats)
-            kf, cf = _round8(hin), _ncg(hout)
-            kb, cb = _round8(hout), _ncg(hin)
-            self.fwd.append(torch.zeros(nm * cf * (kf // 8) * 256, dtype=_F32, device=device))
-            self.bwd.append(torch.zeros(nm * cb * (kb // 8) * 256, dtype=_F32, device=device))
+            if is_narrow(nm, hout):
+                kf, cf, kb, cb = _round8(hin), 1, _round8(nm * hout), _ncg(hin)
+                self.fwd.append(torch.zeros(cf * (kf // 8) * 256, dtype=_F32, device=device))
+                self.bwd.append(torch.zeros(cb * (kb // 8) * 256, dtype=_F32, device=device))
+            else:
+                kf, cf, kb, cb = _round8(hin), _ncg(hout), _round8(hout), _ncg(hin)
+                self.fwd.append(torch.zeros(nm * cf * (kf // 8) * 256, dtype=_F32, device=device))
+                self.bwd.append(torch.zeros(nm * cb * (kb // 8) * 256, dtype=_F32, device=device))
             self.meta.append((nm, hout, hin, kf, cf, kb, cb))
         self.ptrs = None
         self.table = None
@@ -155,12 +171,18 @@ class _PackPlan:
         recs = []
         for g, mats in enumerate(self.groups):
             nm, hout, hin, kf, cf, kb, cb = self.meta[g]
+            narrow = is_narrow(nm, hout)
             for m, w in enumerate(mats):
                 if not w.is_contiguous():
                     raise RuntimeError("weight matrices must be contiguous")
-                recs.append((w.data_ptr(), self.fwd[g].data_ptr() + 4 * m * cf * (kf // 8) * 256, hout, hin, hin, 1, 0, kf, cf, 0))
-                recs.append((w.data_ptr(), self.bwd[g].data_ptr() + 4 * m * cb * (kb // 8) * 256, hout, hin, hin, 0, 0, kb, cb, 0))
-                self.max_elems = max(self.max_elems, cf * (kf // 8) * 64, cb * (kb // 8) * 64)
+                # record = (src, dst, rows, cols, ld, transpose, koff, kpad, ncg, joff)
+                if narrow:
+                    recs.append((w.data_ptr(), self.fwd[g].data_ptr(), hout, hin, hin, 1, 0, kf, cf, m * hout))
+                    recs.append((w.data_ptr(), self.bwd[g].data_ptr(), hout, hin, hin, 0, m * hout, kb, cb, 0))
+                else:
+                    recs.append((w.data_ptr(), self.fwd[g].data_ptr() + 4 * m * cf * (kf // 8) * 256, hout, hin, hin, 1, 0, kf, cf, 0))
+                    recs.append((w.data_ptr(), self.bwd[g].data_ptr() + 4 * m * cb * (kb // 8) * 256, hout, hin, hin, 0, 0, kb, cb, 0))
+                self.max_elems = max(self.max_elems, (cf + 1) * (kf // 8 + 1) * 64, (cb + 1) * (kb // 8 + 1) * 64)
         arr = np.array(recs, dtype=_DESC_DTYPE)
         self.n_desc = len(recs)
         self.table = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
@@ -230,7 +252,7 @@ def _edge_aggr_backward(topo, gx0, x, ldx, ea, ldea, W1, b1, S, pack_w2_bwd, hid
 def _tagconv_forward(topo, h, pack_fwd, bias, nmat, hin, hout, dmask=None, relu=False, add_src=None, add_ld=0):
     out = torch.empty(topo.N, hout, dtype=_F32, device=h.device)
     gemm_prop(topo, h, h.stride(0), hin, pack_fwd, nmat, hout, out, bias=bias, dmask=dmask, relu=relu,
-              add_src=add_src, add_ld=add_ld)
+              add_src=add_src, add_ld=add_ld, narrow_h=(hout if is_narrow(nmat, hout) else 0))
     return out
 
 
@@ -241,7 +263,11 @@ def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=No
     if not need_dh:
         return None
     dh = torch.empty(topo.N, hin, dtype=_F32, device=g.device)
-    gemm_prop(topo, g, g.stride(0), hout, pack_bwd, nmat, hin, dh, relu_src=relu_src, dmask=dmask, transposed=True)
+    if is_narrow(nmat, hout):   # narrow gradient rows: propagate g on the input side, one stacked GEMM
+        gemm_prop(topo, g, g.stride(0), nmat * hout, pack_bwd, 1, hin, dh, relu_src=relu_src, dmask=dmask,
+                  transposed=True, prop_in=nmat - 1)
+    else:
+        gemm_prop(topo, g, g.stride(0), hout, pack_bwd, nmat, hin, dh, relu_src=relu_src, dmask=dmask, transposed=True)
     return dh
 
 

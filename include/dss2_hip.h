@@ -61,15 +61,16 @@ typedef struct dss2_pack_desc {
   float* dst;         /* packed matrix base: [ncg][kpad/8][64 lanes][4]                 */
   int32_t rows, cols, ld;
   int32_t transpose;  /* 1: B[k][j] = W[j][k] (forward, K=cols); 0: B[k][j] = W[k][j]   */
-  int32_t koff;       /* k offset of this block inside the packed matrix                */
+  int32_t koff;       /* k offset of this block inside the packed matrix (any value)   */
   int32_t kpad;       /* padded K of the packed matrix (multiple of 8)                  */
   int32_t ncg;        /* number of 32-column groups of the packed matrix                */
-  int32_t pad_;
+  int32_t joff;       /* column offset of this block inside the packed matrix           */
 } dss2_pack_desc;
 
-/* descs: device array of n_desc descriptors.  dst regions must be zero-filled by the caller
- * once when padding exists (kpad > K or 32*ncg > J); the kernel writes only in-range elements
- * plus explicit zeros for padded lanes of the blocks it covers. */
+/* descs: device array of n_desc descriptors.  Several descriptors may fill disjoint k / column
+ * ranges of one packed matrix (stacked or side-by-side blocks).  The kernel writes exactly the
+ * elements B[koff + k][joff + j], k < K, j < J; the caller zero-fills dst once so that padding
+ * (k >= total K, columns >= total J) stays zero. */
 int dss2_pack_weights(const dss2_pack_desc* descs, int n_desc, int max_elems, void* stream);
 
 /* ---- K1: EdgeAggregation (networks.py:159-209) ------------------------------------------ */
@@ -121,6 +122,14 @@ typedef struct dss2_gemm_prop_args {
   int32_t ell_width;               /* > 0: max row degree of the batch; the tile's graph    *
                                     * slice is staged as ELL [ell_width][rows] (fixed trip  *
                                     * count); 0: stage the CSR slice (any degree)           */
+  int32_t prop_in;                 /* > 0: INPUT-side propagation (narrow inputs): X has    *
+                                    * kreal/(prop_in+1) real columns; the kernel appends    *
+                                    * P X, P^2 X, ... in LDS and runs ONE GEMM against the  *
+                                    * k-stacked matrix [B_0; B_1; ...] (nmat must be 1)     */
+  int32_t narrow_h;                /* > 0: OUTPUT-side propagation for narrow outputs: the  *
+                                    * nmat matrices (narrow_h columns each, nmat*narrow_h   *
+                                    * <= 32) sit side by side in ONE 32-column group; the   *
+                                    * Horner recurrence runs across column blocks in LDS    */
 } dss2_gemm_prop_args;
 
 int dss2_gemm_prop(const dss2_gemm_prop_args* args_host, void* stream);
@@ -138,6 +147,10 @@ typedef struct dss2_wgrad_args {
   const int32_t* tile_start;
   const int32_t* rowptrT; const int32_t* colT; const float* wT;
   int32_t max_nnz; int32_t ell_width;   /* as in dss2_gemm_prop_args, for the transposed CSR */
+  int32_t narrow; int32_t pad_;         /* narrow != 0 (needs nmat*hout <= 32): the propagated  *
+                                         * copies P^m G are appended as extra COLUMNS of one    *
+                                         * 32-wide block instead of nmat separate blocks; same  *
+                                         * slab layout [nmat*hout*hin + hout]                   */
 } dss2_wgrad_args;
 
 int dss2_wgrad(const dss2_wgrad_args* args_host, void* stream);

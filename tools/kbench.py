@@ -26,7 +26,7 @@ Wl = [torch.randn(2, H, device=dev) * 0.1 for _ in range(nmat)]
 W1 = torch.randn(H, 22, device=dev) * 0.1; b1 = torch.randn(H, device=dev) * 0.1
 plan = nw._PackPlan([Ws, [W2], Wl], dev); plan.refresh()
 h = torch.randn(N, H, device=dev); g = torch.randn(N, H, device=dev); g2 = torch.randn(N, 2, device=dev)
-bias = torch.randn(H, device=dev); out = torch.empty(N, H, device=dev); out2 = torch.empty(N, 2, device=dev)
+bias = torch.randn(H, device=dev); bias2 = torch.randn(2, device=dev); out = torch.empty(N, H, device=dev); out2 = torch.empty(N, 2, device=dev)
 S = torch.empty(N, H, device=dev)
 flat = torch.empty(nmat * H * H + H, device=dev); flat1 = torch.empty(H * H + H, device=dev); flatl = torch.empty(nmat * 2 * H + 2, device=dev)
 xin, ein = x[:, :8], ea[:, :6]
@@ -40,8 +40,8 @@ cases = {
   "tag_wgrad H->H (wgrad+reduce)": (lambda: nw.wgrad(topo, g, H, h, H, nmat, flat), fl_gemm),
   "linear fwd H->H (gemm_prop nmat=1)": (lambda: nw.gemm_prop(topo, h, H, H, plan.fwd[1], 1, H, out, bias=bias, rowscale=topo.deg), 2.0 * N * H * H),
   "linear wgrad (nmat=1)": (lambda: nw.wgrad(topo, g, H, h, H, 1, flat1, rowscale=topo.deg), 2.0 * N * H * H),
-  "tag_fwd  H->2": (lambda: nw.gemm_prop(topo, h, H, H, plan.fwd[2], nmat, 2, out2, bias=bias[:2].contiguous()), 2.0 * N * H * nmat * 2),
-  "tag_dgrad 2->H": (lambda: nw.gemm_prop(topo, g2, 2, 2, plan.bwd[2], nmat, H, out, relu_src=h, transposed=True), 2.0 * N * H * nmat * 2),
+  "tag_fwd  H->2": (lambda: nw.gemm_prop(topo, h, H, H, plan.fwd[2], nmat, 2, out2, bias=bias2, narrow_h=2), 2.0 * N * H * nmat * 2),
+  "tag_dgrad 2->H": (lambda: nw.gemm_prop(topo, g2, 2, nmat * 2, plan.bwd[2], 1, H, out, relu_src=h, transposed=True, prop_in=nmat - 1), 2.0 * N * H * nmat * 2),
   "tag_wgrad H->2": (lambda: nw.wgrad(topo, g2, 2, h, H, nmat, flatl), 2.0 * N * H * nmat * 2),
   "edge_hidden_fwd": (lambda: pkg._lib.check(L.dss2_edge_hidden_fwd(xin.data_ptr(), 11, ein.data_ptr(), 13, W1.data_ptr(), b1.data_ptr(), topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(), S.data_ptr(), N, H, 8, 6, st), "f"), 2.0 * topo.E2 * 14 * H + 2.0 * N * 8 * H),
   "edge_hidden_bwd": (lambda: pkg._lib.check(L.dss2_edge_hidden_bwd(xin.data_ptr(), 11, ein.data_ptr(), 13, W1.data_ptr(), b1.data_ptr(), g.data_ptr(), topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(), slab1.data_ptr(), 512, None, H, N, H, 8, 6, 0, st), "b"), 4.0 * topo.E2 * 22 * H),
