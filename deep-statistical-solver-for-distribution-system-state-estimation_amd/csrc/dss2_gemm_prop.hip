@@ -12,6 +12,8 @@
 //      where P T is a CSR segmented sum over the tile's rows read from a wave-private LDS
 //      stage (column on the lane => conflict-free, no atomics, fixed order);
 //   4. bias / dropout mask / ReLU / ReLU-mask / residual, one 128-B row segment per half wave.
+#include <stdlib.h>
+
 #include "dss2_common.hpp"
 
 namespace dss2 {
@@ -68,6 +70,15 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   const int LDX = p.kpad + 4;
   const int dbg = p.relu >> 8;   // diagnostics only (tools/ablate.py): 1 no MFMA, 2 no Horner, 4 no stores, 8 no X staging
 
+  {
+    // De-phase the two workgroups that share a CU.  Speed heuristic only (never correctness): the
+    // dispatcher deals ids 0..255 to the 256 CUs first, so ids 256..511 are the co-residents that would
+    // otherwise run staging / MFMA / epilogue in lock-step with them; delaying those by a fraction of
+    // a tile (stag x ~3.4 us) lets one workgroup's epilogue overlap the other's MFMA phase (-10 %).
+    const int stag = (p.relu >> 16) & 0xff;
+    if (stag && (blockIdx.x >> 8) == 1)
+      for (int i = 0; i < stag; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   float* Xs = smem;
   float* stage = Xs + TM * LDX;
   // graph slice of the tile: ELL [D][TM] {local src, weight} when the batch's max degree D is small
@@ -453,16 +464,31 @@ static int launch_narrow(const dss2_gemm_prop_args& a, hipStream_t stream) {
   return check_launch("gemm_narrow");
 }
 
+static int gemm_waves(int ncg) {
+  static const int forced = [] { const char* e = getenv("DSS2_GEMM_WAVES"); return e ? atoi(e) : 0; }();
+  int nw = ncg < 4 ? ncg : 4;
+  if (forced > 0 && forced < nw) nw = forced;
+  return nw;
+}
+
 static size_t lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz, int ell_width) {
   const size_t TM = (size_t)nrb * 32;
-  const int nw = ncg < 4 ? ncg : 4;
+  const int nw = gemm_waves(ncg);
   size_t b = TM * (size_t)(kpad + 4) * 4 + (size_t)nw * TM * 32 * 4;
   if (nmat > 1) b += ell_width > 0 ? TM * (size_t)ell_width * 8 : (TM + 2) * 4 + (size_t)max_nnz * 8;
   return b;
 }
 
+static int gemm_stagger() {
+  static const int v = [] { const char* e = getenv("DSS2_STAGGER"); return e ? atoi(e) : 2; }();
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
 template <int NRB, int NMAT>
-static int launch(const dss2_gemm_prop_args& a, hipStream_t stream) {
+static int launch(const dss2_gemm_prop_args& a_in, hipStream_t stream) {
+  dss2_gemm_prop_args a = a_in;
+  // compute-heavy multi-round launches only: 2 co-resident workgroups, >= 2 rounds of 256
+  if (!(a.relu >> 16) && a.ntiles >= 512 && NMAT > 1 && a.kpad >= 64) a.relu |= gemm_stagger() << 16;
   static bool attr_set = false;
   auto kern = gemm_prop_kernel<NRB, NMAT>;
   if (!attr_set) {
@@ -475,7 +501,7 @@ static int launch(const dss2_gemm_prop_args& a, hipStream_t stream) {
     attr_set = true;
   }
   const size_t lds = lds_bytes(NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.ncg, a.max_nnz, a.ell_width);
-  const int nw = a.ncg < 4 ? a.ncg : 4;
+  const int nw = gemm_waves(a.ncg);
   hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * nw), lds, stream, a);
   return check_launch("gemm_prop");
 }

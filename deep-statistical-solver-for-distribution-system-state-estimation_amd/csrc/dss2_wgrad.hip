@@ -12,10 +12,24 @@ namespace dss2 {
 
 constexpr int XW = 128;  // X columns per workgroup: one 32-column block per wave
 
+// NB >= 2: 8 waves (two per SIMD).  Wave w multiplies input-feature block (w & 3) against the
+// output-feature blocks of half (w >> 2).  Half 0 runs "MFMA, then its share of the propagation",
+// half 1 "bias sums + propagation share, then MFMA", so on every SIMD the VALU/LDS propagation of
+// one wave sits under the MFMAs of the other.  NB == 1 (narrow / tiny outputs): 4 waves.
+template <int NB> struct WgradGeom {
+  static constexpr int NW = NB >= 2 ? 8 : 4;
+  static constexpr int NT = NW * 64;
+  static constexpr int NBW = NB >= 2 ? NB / 2 : 1;   // output blocks per wave
+};
+
 template <int NRB, int NMAT, int NB>
-__global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int nibg) {
+__global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgrad_args p, int nibg) {
   constexpr int TM = NRB * 32;
   constexpr int LDZ = NB * 32;
+  constexpr int NW = WgradGeom<NB>::NW, NT = WgradGeom<NB>::NT, NBW = WgradGeom<NB>::NBW;
+  constexpr int NG4 = TM * LDZ / 4 / NT;   // float4 of the G slab per thread
+  constexpr int NX4 = TM * XW / 4 / NT;    // float4 of the X slab per thread
+  static_assert(NG4 * NT * 4 == TM * LDZ && NX4 * NT * 4 == TM * XW, "slabs must tile the threads");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Za = smem;
   float* Zb = Za + TM * LDZ;
@@ -29,16 +43,17 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int
   const int lane = tid & 63;
   const int c32 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ibw = wave & 3, obh = wave >> 2;
   const int obg = blockIdx.y / nibg, ibg = blockIdx.y - obg * nibg;
   const int gcol0 = obg * LDZ;
   const int xcol0 = ibg * XW;
-  const bool wave_active = (xcol0 + wave * 32) < p.hin;
+  const bool wave_active = (xcol0 + ibw * 32) < p.hin;
 
-  f32x16 acc[NMAT][NB];
+  f32x16 acc[NMAT][NBW];
 #pragma unroll
   for (int m = 0; m < NMAT; ++m)
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob)
+    for (int ob = 0; ob < NBW; ++ob)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][ob][r] = 0.f;
   float dbacc = 0.f;
@@ -46,22 +61,22 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int
   const bool gvec = ((p.ldg & 3) == 0) && ((p.hout & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.G) & 15) == 0);
   const bool xvec = ((p.ldx & 3) == 0) && ((p.hin & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
 
-  auto mma = [&](const float* Z, f32x16 (&a)[NB], int R) {
+  auto mma = [&](const float* Z, f32x16 (&a)[NBW], int R) {
     if (!wave_active) return;
     const int n2e = (R + 1) >> 1;
-    const float* zp = Z + half * LDZ + c32;
-    const float* xp = Xs + half * XW + wave * 32 + c32;
+    const float* zp = Z + half * LDZ + obh * NBW * 32 + c32;
+    const float* xp = Xs + half * XW + ibw * 32 + c32;
     // two operand register sets in ping-pong: the LDS reads of step n2+1 are in flight while the
     // MFMAs of step n2 issue (no register copies => the wait sits at the first use)
-    float b0, b1, a0[NB], a1[NB];
-    auto ld = [&](float& b, float (&a)[NB], int n2) {
+    float b0, b1, a0[NBW], a1[NBW];
+    auto ld = [&](float& b, float (&av)[NBW], int n2) {
       b = xp[n2 * 2 * XW];
 #pragma unroll
-      for (int ob = 0; ob < NB; ++ob) a[ob] = zp[n2 * 2 * LDZ + ob * 32];
+      for (int ob = 0; ob < NBW; ++ob) av[ob] = zp[n2 * 2 * LDZ + ob * 32];
     };
-    auto mm = [&](float b, const float (&av)[NB]) {
+    auto mm = [&](float b, const float (&av)[NBW]) {
 #pragma unroll
-      for (int ob = 0; ob < NB; ++ob) a[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob], b, a[ob], 0, 0, 0);
+      for (int ob = 0; ob < NBW; ++ob) a[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob], b, a[ob], 0, 0, 0);
     };
     ld(b0, a0, 0);
     int n2 = 0;
@@ -78,9 +93,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int
     if (n2 < n2e) mm(b0, a0);
   };
   auto prop = [&](const float* Zs, float* Zd) {
-    constexpr int RSTEP = 256 / LDZ;          // rows advanced per pass of the 256 threads
+    constexpr int RSTEP = NT / LDZ;           // rows advanced per pass of the NT threads
     constexpr int NI = TM / RSTEP;            // rows owned by one thread
-    constexpr int CH = (NI % 16 == 0) ? 16 : ((NI % 8 == 0) ? 8 : 4);   // NI = NRB*NB*4; rows processed together
+    constexpr int CH = (NI % 16 == 0) ? 16 : ((NI % 8 == 0) ? 8 : ((NI % 4 == 0) ? 4 : ((NI % 2 == 0) ? 2 : 1)));
     static_assert(NI % CH == 0, "row chunking must tile the thread's rows exactly");
     const int c = tid % LDZ;
     const int n0 = tid / LDZ;
@@ -112,42 +127,100 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int
       }
     }
   };
+  // bias gradient (column sums of G): the last LDZ threads of the workgroup (half 1 when 8 waves)
+  auto bias_sums = [&](int ts, int R) {
+    const int t = tid - (NT - LDZ);
+    if (ibg != 0 || t < 0) return;
+    float s = 0.f;
+    if (p.rowscale) {
+      for (int r = 0; r < R; ++r) s = fmaf(Za[r * LDZ + t], p.rowscale[ts + r], s);
+    } else {
+      for (int r = 0; r < R; ++r) s += Za[r * LDZ + t];
+    }
+    dbacc += s;
+  };
+  // one MFMA phase + the propagation that feeds the next one, ordered per half (see kernel comment)
+  auto phase = [&](const float* Zs, float* Zd, f32x16 (&a)[NBW], int R, bool do_prop, bool do_bias, int ts) {
+    if (NW == 8 && obh == 1) {
+      if (do_bias) bias_sums(ts, R);
+      if (do_prop) prop(Zs, Zd);
+      mma(Zs, a, R);
+    } else {
+      mma(Zs, a, R);
+      if (NW == 4 && do_bias) bias_sums(ts, R);
+      if (do_prop) prop(Zs, Zd);
+    }
+  };
 
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  // register prefetch of the next tile's slabs (issued right after the staging barrier, consumed at
+  // the top of the next iteration: the global-load latency hides under the MFMA phases)
+  // (G and X take the 16-byte register-prefetch path independently; a slab whose shape or alignment
+  // does not allow it is staged directly with scalar loads at the top of the iteration)
+  f32x4 pg[NG4], px[NX4];
+  auto issue_loads = [&](int tile) {
     const int ts = p.tile_start[tile];
     const int R = p.tile_start[tile + 1] - ts;
-    // ---- stage G slab, X slab and the transposed-CSR slice
+    constexpr int QG = LDZ / 4, QX = XW / 4;
     if (gvec) {
-      constexpr int Q = LDZ / 4;
-      for (int idx = tid; idx < TM * Q; idx += 256) {
-        const int r = idx / Q, c = (idx - r * Q) * 4;
+#pragma unroll
+      for (int i = 0; i < NG4; ++i) {
+        const int idx = tid + i * NT;
+        const int r = idx / QG, c = (idx - r * QG) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (r < R && gcol0 + c < p.hout) v = *reinterpret_cast<const f32x4*>(p.G + (size_t)(ts + r) * p.ldg + gcol0 + c);
-        *reinterpret_cast<f32x4*>(Za + r * LDZ + c) = v;
+        pg[i] = v;
+      }
+    }
+    if (xvec) {
+#pragma unroll
+      for (int i = 0; i < NX4; ++i) {
+        const int idx = tid + i * NT;
+        const int r = idx / QX, c = (idx - r * QX) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < R && xcol0 + c < p.hin) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + xcol0 + c);
+        px[i] = v;
+      }
+    }
+  };
+  auto write_slabs = [&](int ts, int R) {
+    constexpr int QG = LDZ / 4, QX = XW / 4;
+    if (gvec) {
+#pragma unroll
+      for (int i = 0; i < NG4; ++i) {
+        const int idx = tid + i * NT;
+        const int r = idx / QG, c = (idx - r * QG) * 4;
+        *reinterpret_cast<f32x4*>(Za + r * LDZ + c) = pg[i];
       }
     } else {
-      for (int idx = tid; idx < TM * LDZ; idx += 256) {
+      for (int idx = tid; idx < TM * LDZ; idx += NT) {
         const int r = idx / LDZ, c = idx - r * LDZ;
         Za[idx] = (r < R && gcol0 + c < p.hout) ? p.G[(size_t)(ts + r) * p.ldg + gcol0 + c] : 0.f;
       }
     }
     if (xvec) {
-      constexpr int Q = XW / 4;
-      for (int idx = tid; idx < TM * Q; idx += 256) {
-        const int r = idx / Q, c = (idx - r * Q) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < R && xcol0 + c < p.hin) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + xcol0 + c);
-        *reinterpret_cast<f32x4*>(Xs + r * XW + c) = v;
+#pragma unroll
+      for (int i = 0; i < NX4; ++i) {
+        const int idx = tid + i * NT;
+        const int r = idx / QX, c = (idx - r * QX) * 4;
+        *reinterpret_cast<f32x4*>(Xs + r * XW + c) = px[i];
       }
     } else {
-      for (int idx = tid; idx < TM * XW; idx += 256) {
+      for (int idx = tid; idx < TM * XW; idx += NT) {
         const int r = idx / XW, c = idx - r * XW;
         Xs[idx] = (r < R && xcol0 + c < p.hin) ? p.X[(size_t)(ts + r) * p.ldx + xcol0 + c] : 0.f;
       }
     }
+  };
+
+  if ((int)blockIdx.x < p.ntiles) issue_loads(blockIdx.x);
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    // ---- stage G slab, X slab and the transposed-graph slice
+    write_slabs(ts, R);
     if (NMAT > 1 || p.narrow) {
       if (D > 0) {
-        for (int r = tid; r < TM; r += 256) {
+        for (int r = tid; r < TM; r += NT) {
           const int e0 = (r < R) ? p.rowptrT[ts + r] : 0;
           const int deg = (r < R) ? p.rowptrT[ts + r + 1] - e0 : 0;
           for (int k = 0; k < D; ++k)
@@ -156,16 +229,20 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int
       } else {
         const int base = p.rowptrT[ts];
         const int nnz = p.rowptrT[ts + R] - base;
-        for (int r = tid; r <= TM; r += 256) lrow[r] = (r <= R) ? (p.rowptrT[ts + r] - base) : nnz;
-        for (int k = tid; k < nnz; k += 256) lent[k] = make_int2(p.colT[base + k] - ts, __float_as_int(p.wT[base + k]));
+        for (int r = tid; r <= TM; r += NT) lrow[r] = (r <= R) ? (p.rowptrT[ts + r] - base) : nnz;
+        for (int k = tid; k < nnz; k += NT) lent[k] = make_int2(p.colT[base + k] - ts, __float_as_int(p.wT[base + k]));
       }
     }
     __syncthreads();
+    {
+      const int next = tile + gridDim.x;
+      if (next < p.ntiles) issue_loads(next);
+    }
     // ---- narrow mode: append P^m G as column blocks [m*hout, (m+1)*hout) of the same 32-wide slab
     if (p.narrow) {
       const int h = p.hout;
       for (int m = 1; m < p.nmat; ++m) {
-        for (int idx = tid; idx < R * h; idx += 256) {
+        for (int idx = tid; idx < R * h; idx += NT) {
           const int row = idx / h, j = idx - row * h;
           const float* src = Za + (m - 1) * h + j;
           float sacc = 0.f;
@@ -186,32 +263,19 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int
         __syncthreads();
       }
     }
-    // ---- bias gradient (column sums of G), only by the ibg == 0 slice
-    if (ibg == 0 && tid < LDZ) {
-      float s = 0.f;
-      if (p.rowscale) {
-        for (int r = 0; r < R; ++r) s = fmaf(Za[r * LDZ + tid], p.rowscale[ts + r], s);
-      } else {
-        for (int r = 0; r < R; ++r) s += Za[r * LDZ + tid];
-      }
-      dbacc += s;
-    }
     // ---- m = 0 .. NMAT-1, ping-pong propagation
-    mma(Za, acc[0], R);
+    phase(Za, Zb, acc[0], R, NMAT > 1, true, ts);
     if (NMAT > 1) {
-      prop(Za, Zb);
       __syncthreads();
-      mma(Zb, acc[1 % NMAT], R);
+      phase(Zb, Za, acc[1 % NMAT], R, NMAT > 2, false, ts);
     }
     if (NMAT > 2) {
-      prop(Zb, Za);
       __syncthreads();
-      mma(Za, acc[2 % NMAT], R);
+      phase(Za, Zb, acc[2 % NMAT], R, NMAT > 3, false, ts);
     }
     if (NMAT > 3) {
-      prop(Za, Zb);
       __syncthreads();
-      mma(Zb, acc[3 % NMAT], R);
+      phase(Zb, Za, acc[3 % NMAT], R, false, false, ts);
     }
     __syncthreads();
   }
@@ -220,21 +284,24 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const dss2_wgrad_args p, int
   const size_t stride = (size_t)p.nmat * p.hout * p.hin + p.hout;
   float* out = p.slab + (size_t)blockIdx.x * stride;
   if (wave_active) {
-    const int i = xcol0 + wave * 32 + c32;
+    const int i = xcol0 + ibw * 32 + c32;
     if (i < p.hin) {
 #pragma unroll
       for (int m = 0; m < NMAT; ++m)
 #pragma unroll
-        for (int ob = 0; ob < NB; ++ob)
+        for (int ob = 0; ob < NBW; ++ob)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int o = gcol0 + ob * 32 + acc_row(r, half);
+            const int o = gcol0 + (obh * NBW + ob) * 32 + acc_row(r, half);
             // narrow mode: row o of the single block IS row (m', j) = (o / hout, o % hout) of dW_cat
             if (o < (p.narrow ? p.nmat * p.hout : p.hout)) out[((size_t)m * p.hout + o) * p.hin + i] = acc[m][ob][r];
           }
     }
   }
-  if (ibg == 0 && tid < LDZ && gcol0 + tid < p.hout) out[(size_t)p.nmat * p.hout * p.hin + gcol0 + tid] = dbacc;
+  {
+    const int t = tid - (NT - LDZ);
+    if (ibg == 0 && t >= 0 && gcol0 + t < p.hout) out[(size_t)p.nmat * p.hout * p.hin + gcol0 + t] = dbacc;
+  }
 }
 
 // nmat here = number of MFMA matrix passes (1 in narrow mode); graph = a graph slice is staged
@@ -267,7 +334,7 @@ static int launch_wgrad(const dss2_wgrad_args& a, hipStream_t stream) {
   const int nob = (a.hout + 31) / 32, nib = (a.hin + 31) / 32;
   const int nobg = (nob + NB - 1) / NB, nibg = (nib + 3) / 4;
   const size_t lds = wgrad_lds(NRB, NMAT, NB, a.max_nnz, a.ell_width, NMAT > 1 || a.narrow);
-  hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg), dim3(256), lds, stream, a, nibg);
+  hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg), dim3(WgradGeom<NB>::NT), lds, stream, a, nibg);
   return check_launch("wgrad");
 }
 

@@ -35,5 +35,6 @@ def t(a, reps=30):
 print(f"nrb={topo.nrb} ntiles={topo.ntiles} ell={topo.ell}")
 for name, dbg in [("full", 0), ("no MFMA", 1), ("no Horner", 2), ("no stores", 4), ("no X staging", 8), ("no MFMA+Horner", 3),
                   ("only staging (no MFMA/Horner/stores)", 7), ("only MFMA (no staging/Horner/stores)", 14), ("nothing (launch+ELL+barrier)", 15),
-                  ("only MFMA, no B stream", 14 | 16), ("only MFMA, no A stream", 14 | 32), ("only MFMA, no A/B streams (pure issue)", 14 | 48)]:
+                  ("only MFMA, no B stream", 14 | 16), ("only MFMA, no A stream", 14 | 32), ("only MFMA, no A/B streams (pure issue)", 14 | 48),
+                  ("full, stagger 1", 1 << 8), ("full, stagger 2", 2 << 8), ("full, stagger 3", 3 << 8), ("full, stagger 4", 4 << 8)]:
     print(f"{name:42s} {t(args(dbg)):8.1f} us")
