@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdss2_hip.so")
+LIB_PATH = os.environ.get("DSS2_LIB", os.path.join(_HERE, "libdss2_hip.so"))   # DSS2_LIB: diagnostic builds only
 
 c_f32p = C.c_void_p   # all device pointers travel as integers (tensor.data_ptr())
 c_i32p = C.c_void_p
@@ -33,7 +33,7 @@ class GemmPropArgs(C.Structure):
                 ("tile_start", C.c_void_p),
                 ("rowptr", C.c_void_p), ("col", C.c_void_p), ("w", C.c_void_p),
                 ("max_nnz", C.c_int32), ("ell_width", C.c_int32),
-                ("prop_in", C.c_int32), ("narrow_h", C.c_int32)]
+                ("prop_in", C.c_int32), ("narrow_h", C.c_int32), ("ell_tiles", C.c_void_p)]
 
 
 class WgradArgs(C.Structure):
@@ -44,7 +44,8 @@ class WgradArgs(C.Structure):
                 ("ntiles", C.c_int32),
                 ("tile_start", C.c_void_p),
                 ("rowptrT", C.c_void_p), ("colT", C.c_void_p), ("wT", C.c_void_p),
-                ("max_nnz", C.c_int32), ("ell_width", C.c_int32), ("narrow", C.c_int32), ("pad_", C.c_int32)]
+                ("max_nnz", C.c_int32), ("ell_width", C.c_int32), ("ell_tiles", C.c_void_p), ("narrow", C.c_int32),
+                ("pad_", C.c_int32)]
 
 
 class WlsArgs(C.Structure):

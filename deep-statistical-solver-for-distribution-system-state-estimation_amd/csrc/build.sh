@@ -4,17 +4,18 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
-OUT="$HERE/../libdss2_hip.so"
+OUT="${DSS2_OUT:-$HERE/../libdss2_hip.so}"
+OBJ="${DSS2_OBJ:-$HERE/obj}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
-mkdir -p "$HERE/obj"
+mkdir -p "$OBJ"
 pids=()
 for src in dss2_api dss2_gemm_prop dss2_edge dss2_wgrad dss2_loss; do
-  if [ ! -f "$HERE/obj/$src.o" ] || [ "$HERE/$src.hip" -nt "$HERE/obj/$src.o" ] || [ "$HERE/dss2_common.hpp" -nt "$HERE/obj/$src.o" ] || [ "$ROOT/include/dss2_hip.h" -nt "$HERE/obj/$src.o" ]; then
-    $HIPCC $FLAGS "$@" -c "$HERE/$src.hip" -o "$HERE/obj/$src.o" &
+  if [ ! -f "$OBJ/$src.o" ] || [ "$HERE/$src.hip" -nt "$OBJ/$src.o" ] || [ "$HERE/dss2_common.hpp" -nt "$OBJ/$src.o" ] || [ "$ROOT/include/dss2_hip.h" -nt "$OBJ/$src.o" ]; then
+    $HIPCC $FLAGS "$@" -c "$HERE/$src.hip" -o "$OBJ/$src.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/obj/*.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/*.o
 echo "built $OUT"

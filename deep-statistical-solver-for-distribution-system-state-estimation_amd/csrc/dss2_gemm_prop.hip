@@ -49,32 +49,47 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const dss2_pack_desc*
 // ------------------------------------------------------------------------------------------
 // fused GEMM + propagation
 // ------------------------------------------------------------------------------------------
+#ifdef DSS2_STAMPS
+// Diagnostic build only (csrc/build.sh -DDSS2_STAMPS -> libdss2_hip_stamps.so): per-wave phase stamps.
+// Values go to a buffer of their own that no kernel reads; no output depends on them.
+__device__ unsigned long long g_stamps[8192 * 8];
+#define DSS2_STAMP(slot)                                                                       \
+  do {                                                                                         \
+    unsigned long long t_;                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    if (lane == 0 && (stamp_tile * 4 + wave) < 8192) g_stamps[(stamp_tile * 4 + wave) * 8 + (slot)] = t_; \
+  } while (0)
+#else
+#define DSS2_STAMP(slot) do {} while (0)
+#endif
+
 // waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument):
 // the accumulators take NRB*NMAT*16 registers of the 512 per lane.
 constexpr int gemm_waves_per_simd(int nrb, int nmat) {
-  return nrb * nmat * 16 <= 64 ? 3 : (nrb * nmat * 16 <= 128 ? 2 : 1);
+  return nrb * nmat * 16 <= 128 ? 2 : 1;
 }
 
 template <int NRB, int NMAT>
 __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop_kernel(const dss2_gemm_prop_args p) {
   constexpr int TM = NRB * 32;
+  constexpr int PF = 8;    // float4 registers per thread for the next tile's X rows (covers 64 x 128 floats / 256 threads)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nthreads = blockDim.x;
   const int nw = nthreads >> 6;
-  const int tile = blockIdx.x;
-  const int ts = p.tile_start[tile];
-  const int R = p.tile_start[tile + 1] - ts;
   const int LDX = p.kpad + 4;
+  int stamp_tile = blockIdx.x; (void)stamp_tile;
+  DSS2_STAMP(0);
   const int dbg = p.relu >> 8;   // diagnostics only (tools/ablate.py): 1 no MFMA, 2 no Horner, 4 no stores, 8 no X staging
-
   {
     // De-phase the two workgroups that share a CU.  Speed heuristic only (never correctness): the
     // dispatcher deals ids 0..255 to the 256 CUs first, so ids 256..511 are the co-residents that would
     // otherwise run staging / MFMA / epilogue in lock-step with them; delaying those by a fraction of
-    // a tile (stag x ~3.4 us) lets one workgroup's epilogue overlap the other's MFMA phase (-10 %).
+    // a tile (stag x ~3.4 us) lets one workgroup's epilogue overlap the other's MFMA phase.
     const int stag = (p.relu >> 16) & 0xff;
     if (stag && (blockIdx.x >> 8) == 1)
       for (int i = 0; i < stag; ++i) __builtin_amdgcn_s_sleep(127);
@@ -87,14 +102,58 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   int2* ell = reinterpret_cast<int2*>(stage + nw * TM * 32);
   int* lrow = reinterpret_cast<int*>(stage + nw * TM * 32);
   int2* lent = reinterpret_cast<int2*>(lrow + TM + 2);
+  const bool need_graph = NMAT > 1 || p.prop_in > 0;
 
-  // ---- stage the X tile (zero padded to TM x kpad); with input-side propagation only the first
-  //      kin columns come from memory, the propagated copies are appended below
+  // with input-side propagation only the first kin columns come from memory
   const int kin = p.prop_in > 0 ? p.kreal / (p.prop_in + 1) : p.kreal;
+  const int kq = p.kpad >> 2;
   const bool vec_ok = ((kin & 3) == 0) && ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
-  if (dbg & 8) {
+  // register prefetch: the NEXT tile's X rows (and its precomputed ELL slice) are requested right after
+  // the staging barrier of the current tile and land while the MFMA loop runs
+  const bool pf_x = vec_ok && (TM * kq <= PF * nthreads) && !(dbg & 8);
+  const bool pf_e = need_graph && D > 0 && p.ell_tiles != nullptr && (D * TM <= 2 * nthreads);
+  f32x4 px[PF];
+  int2 pe[2];
+  auto issue_prefetch = [&](int tile) {
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    if (pf_x) {
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const int idx = tid + i * nthreads;
+        const int r = idx / kq, c = (idx - r * kq) << 2;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (idx < TM * kq && r < R && c < kin) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
+        px[i] = v;
+      }
+    }
+    if (pf_e) {
+      const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * nthreads;
+        pe[i] = idx < D * TM ? src[idx] : make_int2(0, 0);
+      }
+    }
+  };
+
+  if ((int)blockIdx.x < p.ntiles) issue_prefetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  const int ts = p.tile_start[tile];
+  const int R = p.tile_start[tile + 1] - ts;
+  stamp_tile = tile;
+  DSS2_STAMP(1);
+
+  // ---- stage the X tile (zero padded to TM x kpad)
+  if (pf_x) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int idx = tid + i * nthreads;
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      if (idx < TM * kq) *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = px[i];
+    }
+  } else if (dbg & 8) {
   } else if (vec_ok) {
-    const int kq = p.kpad >> 2;
     for (int idx = tid; idx < TM * kq; idx += nthreads) {
       const int r = idx / kq;
       const int c = (idx - r * kq) << 2;
@@ -111,9 +170,18 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       Xs[r * LDX + c] = v;
     }
   }
-  // ---- stage the tile's CSR slice (local row pointers, local column ids, weights)
-  if (NMAT > 1 || p.prop_in > 0) {
-    if (D > 0) {
+  // ---- stage the tile's graph slice
+  if (need_graph) {
+    if (pf_e) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * nthreads;
+        if (idx < D * TM) ell[idx] = pe[i];
+      }
+    } else if (D > 0 && p.ell_tiles != nullptr) {
+      const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
+      for (int idx = tid; idx < D * TM; idx += nthreads) ell[idx] = src[idx];
+    } else if (D > 0) {
       for (int r = tid; r < TM; r += nthreads) {
         const int e0 = (r < R) ? p.rowptr[ts + r] : 0;
         const int deg = (r < R) ? p.rowptr[ts + r + 1] - e0 : 0;
@@ -151,6 +219,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
     __syncthreads();
   }
 
+  DSS2_STAMP(2);
   const int c32 = lane & 31;   // A row inside a row block == output column inside a column group
   const int half = lane >> 5;
   const int nkk = p.kpad >> 3;
@@ -167,22 +236,27 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rb][m][r] = 0.f;
 
-    // k loop, 8 k-values per step.  A fragments (LDS, ~128 cycles) are prefetched one step ahead in
-    // two register buffers; B fragments (packed weights from L2, ~1 us under load) two steps ahead
-    // in three buffers.  No register copies, and sched_barrier(0) pins "issue loads, then MFMAs", so
-    // every s_waitcnt is a counted wait that sits right before the first MFMA that needs the data.
-    f32x4 a0[NRB] = {}, a1[NRB] = {}, a2[NRB] = {}, b0[NMAT] = {}, b1[NMAT] = {}, b2[NMAT] = {};
-    auto load_a = [&](f32x4 (&a)[NRB], int kk) {
-      if (dbg & 32) return;                     // diagnostics: no A (LDS) operand stream
+    // epilogue constants requested now so that their latency hides under the MFMA loop
+    const int ecol0 = cg * 32 + (lane & 7) * 4;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && ecol0 < p.hout && (p.hout & 3) == 0) bias4 = *reinterpret_cast<const f32x4*>(p.bias + ecol0);
+
+    // k loop, 8 k-values per step, A (LDS) and B (packed weights, L2) fragments prefetched one step
+    // ahead in two register buffers in ping-pong.  No register copies, and sched_barrier(0) pins "issue
+    // the next buffer's loads, then this buffer's MFMAs" (left alone, the scheduler sinks the loads to
+    // the end of the MFMA block and the next block starts on vmcnt(0)); every wait is then a counted
+    // s_waitcnt right before the first MFMA that needs the data.
+    f32x4 a0[NRB] = {}, a1[NRB] = {}, b0[NMAT] = {}, b1[NMAT] = {};
+    auto load_ab = [&](f32x4 (&a)[NRB], f32x4 (&b)[NMAT], int kk) {
       const int kc = kk < nkk ? kk : nkk - 1;   // clamped: harmless reload past the end
+      if (!(dbg & 32)) {
 #pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(xa + rb * 32 * LDX + kc * 8);
-    };
-    auto load_b = [&](f32x4 (&b)[NMAT], int kk) {
-      if (dbg & 16) return;                     // diagnostics: no B (L2) operand stream
-      const int kc = kk < nkk ? kk : nkk - 1;
+        for (int rb = 0; rb < NRB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(xa + rb * 32 * LDX + kc * 8);
+      }
+      if (!(dbg & 16)) {
 #pragma unroll
-      for (int m = 0; m < NMAT; ++m) b[m] = bp[((size_t)(m * p.ncg + cg) * nkk + kc) * 64 + lane];
+        for (int m = 0; m < NMAT; ++m) b[m] = bp[((size_t)(m * p.ncg + cg) * nkk + kc) * 64 + lane];
+      }
     };
     auto mma_ab = [&](const f32x4 (&a)[NRB], const f32x4 (&b)[NMAT]) {
 #pragma unroll
@@ -193,26 +267,27 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
           for (int m = 0; m < NMAT; ++m)
             acc[rb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][s], b[m][s], acc[rb][m], 0, 0, 0);
     };
-    // step KK: consumes (ACUR, BCUR), issues A of step KK+1 and B of step KK+2 first (period-3 rotation)
-#define DSS2_STEP(ACUR, ANXT, BCUR, BNXT2, KK) \
-    load_a(ANXT, (KK) + 1);                    \
-    load_b(BNXT2, (KK) + 2);                   \
-    __builtin_amdgcn_sched_barrier(0);         \
-    mma_ab(ACUR, BCUR);                        \
-    __builtin_amdgcn_sched_barrier(0);
-    load_a(a0, 0);
-    load_b(b0, 0);
-    load_b(b1, 1);
+    load_ab(a0, b0, 0);
     int kk = (dbg & 1) ? nkk : 0;
-    for (; kk + 3 <= nkk; kk += 3) {
-      DSS2_STEP(a0, a1, b0, b2, kk)
-      DSS2_STEP(a1, a2, b1, b0, kk + 1)
-      DSS2_STEP(a2, a0, b2, b1, kk + 2)
+    for (; kk + 2 <= nkk; kk += 2) {
+      load_ab(a1, b1, kk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_ab(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_ab(a0, b0, kk + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_ab(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (kk < nkk) { DSS2_STEP(a0, a1, b0, b2, kk) }
-    if (kk + 1 < nkk) { DSS2_STEP(a1, a2, b1, b0, kk + 1) }
-#undef DSS2_STEP
+    if (kk < nkk) mma_ab(a0, b0);   // odd number of k steps
+    // next tile's X rows / ELL slice: requested now, consumed at the top of the next iteration; the
+    // latency hides under the Horner + store phases and the registers are not live during the MFMAs
+    if (cg == wave) {
+      const int next = tile + gridDim.x;
+      if (next < p.ntiles) issue_prefetch(next);
+    }
 
+    DSS2_STAMP(3);
     // ---- Horner propagation: T = G_{NMAT-1}; T = G_m + P T
     f32x16 T[NRB];
 #pragma unroll
@@ -229,15 +304,19 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
         if (D > 0) {
 #pragma unroll
           for (int rb = 0; rb < NRB; ++rb) T[rb] = acc[rb][m];
-          for (int k = 0; k < D; ++k) {   // uniform trip count; the NRB*16 row chains are independent
+          for (int k = 0; k < D; ++k) {   // uniform trip count; the 16 row chains of a block are independent
             const int2* ek = ell + k * TM + 4 * half;
 #pragma unroll
-            for (int rb = 0; rb < NRB; ++rb)
+            for (int rb = 0; rb < NRB; ++rb) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const int2 en = ek[rb * 32 + acc_row(r, 0)];
                 T[rb][r] = fmaf(__int_as_float(en.y), st[en.x * 32 + c32], T[rb][r]);
               }
+              // one row block (16 chains, ~48 temporaries) at a time: unbounded, the scheduler hoists all
+              // NRB*32 LDS reads and the allocator spills into scratch in this phase
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
         } else {
 #pragma unroll
@@ -257,6 +336,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       }
     }
 
+    DSS2_STAMP(4);
     // ---- epilogue: T -> wave-private LDS stage -> rolled, row-coalesced store loop (keeps the
     //      address arithmetic of the five optional operands out of the unrolled register code)
     wave_lds_sync();
@@ -275,24 +355,39 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       const int cq = (lane & 7) * 4, r8 = lane >> 3;
       const int col0 = cg * 32 + cq;
       if (col0 < p.hout) {
-        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col0);
-        for (int row = r8; row < R; row += 8) {
-          const size_t grow = (size_t)(ts + row);
-          f32x4 y = *reinterpret_cast<const f32x4*>(st + row * 32 + cq);
-          if (p.bias) y += p.rowscale ? bias4 * p.rowscale[grow] : bias4;
-          if (p.dmask) y *= *reinterpret_cast<const f32x4*>(p.dmask + grow * p.ld_dmask + col0);
-          if (p.relu & 1) {
+        // rows r8, r8+8, ...: operands of 2 rows are requested together, then finished and stored
+        for (int row0 = r8; row0 < R; row0 += 16) {
+          f32x4 y[2], rs[2], dm[2], ad[2];
+          float rsc[2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) y[q] = fmaxf(y[q], 0.f);
+          for (int u = 0; u < 2; ++u) {
+            const int row = row0 + 8 * u;
+            const bool ok = row < R;
+            const size_t grow = (size_t)(ts + (ok ? row : 0));
+            y[u] = *reinterpret_cast<const f32x4*>(st + (ok ? row : 0) * 32 + cq);
+            if (p.rowscale) rsc[u] = p.rowscale[grow];
+            if (p.dmask) dm[u] = *reinterpret_cast<const f32x4*>(p.dmask + grow * p.ld_dmask + col0);
+            if (p.relu_src) rs[u] = *reinterpret_cast<const f32x4*>(p.relu_src + grow * p.ld_relu + col0);
+            if (p.add_src) ad[u] = *reinterpret_cast<const f32x4*>(p.add_src + grow * p.ld_add + col0);
           }
-          if (p.relu_src) {
-            const f32x4 rs = *reinterpret_cast<const f32x4*>(p.relu_src + grow * p.ld_relu + col0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) y[q] = rs[q] > 0.f ? y[q] : 0.f;
+          for (int u = 0; u < 2; ++u) {
+            const int row = row0 + 8 * u;
+            if (row >= R) continue;
+            f32x4 v = y[u];
+            if (p.bias) v += p.rowscale ? bias4 * rsc[u] : bias4;
+            if (p.dmask) v *= dm[u];
+            if (p.relu & 1) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            if (p.relu_src) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = rs[u][q] > 0.f ? v[q] : 0.f;
+            }
+            if (p.add_src) v += ad[u];
+            *reinterpret_cast<f32x4*>(p.Y + (size_t)(ts + row) * p.ldy + col0) = v;
           }
-          if (p.add_src) y += *reinterpret_cast<const f32x4*>(p.add_src + grow * p.ld_add + col0);
-          *reinterpret_cast<f32x4*>(p.Y + grow * p.ldy + col0) = y;
         }
       }
     } else {
@@ -311,8 +406,20 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
         }
       }
     }
+    DSS2_STAMP(5);
   }
+  DSS2_STAMP(6);
+  __syncthreads();   // every wave is done with Xs / the graph slice before the next tile is staged
+  }  // persistent tile loop
 }
+
+#ifdef DSS2_STAMPS
+}  // namespace dss2
+extern "C" int dss2_debug_read_stamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dss2::g_stamps), sizeof(unsigned long long) * n);
+}
+namespace dss2 {
+#endif
 
 // ------------------------------------------------------------------------------------------
 // narrow outputs (nmat * h <= 32, e.g. the last TAGConv H -> 2): all matrices side by side in ONE
@@ -355,7 +462,10 @@ __global__ void __launch_bounds__(256) gemm_narrow_kernel(const dss2_gemm_prop_a
     }
   }
   if (nm > 1) {
-    if (D > 0) {
+    if (D > 0 && p.ell_tiles != nullptr) {
+      const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
+      for (int idx = tid; idx < D * TM; idx += 256) ell[idx] = src[idx];
+    } else if (D > 0) {
       for (int r = tid; r < TM; r += 256) {
         const int e0 = (r < R) ? p.rowptr[ts + r] : 0;
         const int deg = (r < R) ? p.rowptr[ts + r + 1] - e0 : 0;
@@ -502,7 +612,11 @@ static int launch(const dss2_gemm_prop_args& a_in, hipStream_t stream) {
   }
   const size_t lds = lds_bytes(NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.ncg, a.max_nnz, a.ell_width);
   const int nw = gemm_waves(a.ncg);
-  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * nw), lds, stream, a);
+  // persistent over tiles: at most two workgroups per CU are co-resident at the LDS sizes of the
+  // compute-heavy shapes, so 512 workgroups cover the chip; each walks tiles blockIdx.x, +grid, ...
+  static const int pgrid = [] { const char* e = getenv("DSS2_GEMM_GRID"); return e ? atoi(e) : 0; }();
+  const int grid = (pgrid > 0 && a.ntiles > pgrid) ? pgrid : a.ntiles;   // DSS2_GEMM_GRID=512: persistent variant
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, stream, a);
   return check_launch("gemm_prop");
 }
 

@@ -219,7 +219,10 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     // ---- stage G slab, X slab and the transposed-graph slice
     write_slabs(ts, R);
     if (NMAT > 1 || p.narrow) {
-      if (D > 0) {
+      if (D > 0 && p.ell_tiles != nullptr) {
+        const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
+        for (int idx = tid; idx < D * TM; idx += NT) ell[idx] = src[idx];
+      } else if (D > 0) {
         for (int r = tid; r < TM; r += NT) {
           const int e0 = (r < R) ? p.rowptrT[ts + r] : 0;
           const int deg = (r < R) ? p.rowptrT[ts + r + 1] - e0 : 0;

@@ -86,10 +86,10 @@ def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.T
     a.tile_start = topo.tile_start.data_ptr()
     if transposed:
         a.rowptr, a.col, a.w, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
-        a.ell_width = topo.ellT
+        a.ell_width, a.ell_tiles = topo.ellT, _ptr(topo.ellT_tiles)
     else:
         a.rowptr, a.col, a.w, a.max_nnz = topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.w.data_ptr(), topo.max_nnz
-        a.ell_width = topo.ell
+        a.ell_width, a.ell_tiles = topo.ell, _ptr(topo.ell_tiles)
     _lib.check(_lib.lib().dss2_gemm_prop(C.byref(a), _stream(Y)), "dss2_gemm_prop")
 
 
@@ -109,7 +109,7 @@ def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int,
     a.slab, a.n_split, a.nmat, a.nrb, a.ntiles = slab.data_ptr(), n_split, nmat, topo.nrb, topo.ntiles
     a.tile_start = topo.tile_start.data_ptr()
     a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
-    a.ell_width = topo.ellT
+    a.ell_width, a.ell_tiles = topo.ellT, _ptr(topo.ellT_tiles)
     a.narrow = int(narrow)
     st = _stream(G)
     _lib.check(_lib.lib().dss2_wgrad(C.byref(a), st), "dss2_wgrad")

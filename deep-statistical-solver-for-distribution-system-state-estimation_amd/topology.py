@@ -142,6 +142,27 @@ class Topology:
         self.ell = md if md <= _ELL_MAX else 0
         self.ellT = mdT if mdT <= _ELL_MAX else 0
         self.tile_start = torch.from_numpy(ts).to(dev)
+        # per-tile ELL slices [ntiles, D, 32*nrb] of {local source row, weight bits}: what the kernels stage
+        # in LDS for the in-tile propagation, precomputed here so that staging is one coalesced copy
+        self.ell_tiles = self._ell_tiles(self.rowptr, self.col, self.w, self.ell)
+        self.ellT_tiles = self._ell_tiles(self.rowptrT, self.colT, self.wT, self.ellT)
+
+    def _ell_tiles(self, rowptr, col, w, width):
+        if width <= 0:
+            return None
+        dev, tm, nt = self.device, 32 * self.nrb, self.ntiles
+        ts = self.tile_start.to(torch.int64)
+        rp = rowptr.to(torch.int64)
+        deg = rp[1:] - rp[:-1]
+        rows = torch.repeat_interleave(torch.arange(self.N, device=dev), deg)
+        k = torch.arange(rows.numel(), device=dev) - rp[rows]
+        tile = torch.searchsorted(ts, rows, right=True) - 1
+        r = rows - ts[tile]
+        out = torch.zeros(nt, width, tm, 2, dtype=torch.int32, device=dev)
+        out[:, :, :, 0] = torch.arange(tm, dtype=torch.int32, device=dev)      # padding: {own row, weight 0}
+        out[tile, k, r, 0] = (col.to(torch.int64) - ts[tile]).to(torch.int32)
+        out[tile, k, r, 1] = w.view(torch.int32)
+        return out.contiguous()
 
     def lds_check(self, nmat: int, kpad: int, ncg: int) -> None:
         need = _lib.lib().dss2_gemm_prop_lds_bytes(self.nrb, nmat, kpad, ncg, max(self.max_nnz, self.max_nnzT),

@@ -130,6 +130,10 @@ typedef struct dss2_gemm_prop_args {
                                     * nmat matrices (narrow_h columns each, nmat*narrow_h   *
                                     * <= 32) sit side by side in ONE 32-column group; the   *
                                     * Horner recurrence runs across column blocks in LDS    */
+  const void* ell_tiles;           /* optional: per-tile ELL slices precomputed once per     *
+                                    * topology, int2 {local src, weight bits}[ntiles]        *
+                                    * [ell_width][32*nrb] (rows >= tile rows: {row, 0});      *
+                                    * NULL: the kernel derives the slice from the CSR         */
 } dss2_gemm_prop_args;
 
 int dss2_gemm_prop(const dss2_gemm_prop_args* args_host, void* stream);
@@ -147,6 +151,7 @@ typedef struct dss2_wgrad_args {
   const int32_t* tile_start;
   const int32_t* rowptrT; const int32_t* colT; const float* wT;
   int32_t max_nnz; int32_t ell_width;   /* as in dss2_gemm_prop_args, for the transposed CSR */
+  const void* ell_tiles;                /* per-tile ELL slices of the transposed graph, or NULL   */
   int32_t narrow; int32_t pad_;         /* narrow != 0 (needs nmat*hout <= 32): the propagated  *
                                          * copies P^m G are appended as extra COLUMNS of one    *
                                          * 32-wide block instead of nmat separate blocks; same  *

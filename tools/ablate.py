@@ -22,6 +22,7 @@ def args(dbg, nm=nmat, bp=None):
     a.relu, a.nmat, a.nrb, a.ntiles = 1 | (dbg << 8), nm, topo.nrb, topo.ntiles
     a.tile_start = topo.tile_start.data_ptr()
     a.rowptr, a.col, a.w, a.max_nnz, a.ell_width = topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.w.data_ptr(), topo.max_nnz, topo.ell
+    a.ell_tiles = topo.ell_tiles.data_ptr()
     return a
 
 st = torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Launch ONLY one kernel shape repeatedly (for rocprofv3 --pmc): argv[1] in {fwd, dgrad, wgrad}."""
+import importlib, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+pkg = importlib.import_module("deep-statistical-solver-for-distribution-system-state-estimation_amd")
+nw = pkg.networks
+dev = torch.device("cuda:0"); H, nmat = 128, 3
+b = pkg.synthetic.make_batch(["cigre14"], 4096, seed=0)
+ei = b["edge_index"].to(dev); N = b["x"].shape[0]
+topo = pkg.topology.get_topology(ei, N)
+Ws = [torch.randn(H, H, device=dev) * 0.1 for _ in range(nmat)]
+plan = nw._PackPlan([Ws], dev); plan.refresh()
+h = torch.randn(N, H, device=dev); g = torch.randn(N, H, device=dev); out = torch.empty(N, H, device=dev)
+bias = torch.randn(H, device=dev); flat = torch.empty(nmat * H * H + H, device=dev)
+which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
+    if which == "fwd":
+        nw.gemm_prop(topo, h, H, H, plan.fwd[0], nmat, H, out, bias=bias, relu=True)
+    elif which == "dgrad":
+        nw.gemm_prop(topo, g, H, H, plan.bwd[0], nmat, H, out, relu_src=h, transposed=True)
+    else:
+        nw.wgrad(topo, g, H, h, H, nmat, flat)
+torch.cuda.synchronize()
