@@ -132,7 +132,7 @@ def main():
         flops = 2.0 * N * HID * (KHOPS + 1) * HID + 2.0 * KHOPS * E2 * HID
         achieved = flops / (avg_ms * 1e-3) / 1e12
         result["roofline"] = {
-            "kernel": "dss2::gemm_prop_kernel<2,3> (TAGConv H->H forward and data-gradient launches)",
+            "kernel": "dss2::gemm_prop_kernel<2,3,false> (TAGConv H->H forward and data-gradient launches)",
             "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
             "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": None,
             "launches_timed": len(durs), "avg_launch_us": avg_ms * 1e3, "median_launch_us": durs[len(durs) // 2] * 1e3,
