@@ -52,7 +52,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    group = dist.group.WORLD if world > 1 else None
+    distributed = dist.is_initialized()          # true under torch.distributed.run, also at world size 1
+    group = dist.group.WORLD if distributed else None
 
     # ---- resident inputs and model
     torch.manual_seed(0)
@@ -60,7 +61,7 @@ def main():
     x, ei, ea = batch["x"].to(dev), batch["edge_index"].to(dev), batch["edge_attr"].to(dev)
     stats = tuple(s.to(dev) for s in batch["stats"])
     model = pkg.MPN(8, 6, 2, HID, LAYERS, KHOPS, 0.0).to(dev)
-    if world > 1:
+    if distributed:
         pkg.parallel.broadcast_parameters(model, 0, group)
         pkg.parallel.attach_grad_allreduce(model, group)
     xin, ein, npar, epar = x[:, :8], ea[:, :6], x[:, 8:], ea[:, 6:]
@@ -76,7 +77,7 @@ def main():
         return loss
 
     def sync():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -88,7 +89,7 @@ def main():
         loss = step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -101,7 +102,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"CIGRE-14 (15 buses, 14 closed branches) B={args.batch} graphs/GPU, "
                                f"MPN L={LAYERS} H={HID} K={KHOPS} dropout=0: forward + gsp_wls_edge + backward"
-                               + (" + RCCL grad all-reduce" if world > 1 else ""),
+                               + (" + RCCL loss-sum and gradient all-reduce" if distributed else ""),
                    "graphs_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                    "loss": float(loss.item())},
     }
@@ -181,7 +182,7 @@ def main():
             }
             result["speedup_vs_cpu_baseline"] = value / (args.batch / cdt)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -939,19 +939,25 @@ static bool use_v2(const dss2_gemm_prop_args& a) {
   return lds2_bytes(a.nrb, a.kpad, a.nmat > 1 ? a.ell_width : 0) <= (size_t)kMaxLdsBytes;
 }
 
-static int gemm_waves(int ncg) {
+static size_t lds_bytes_nw(int nrb, int nmat, int kpad, int nw, int max_nnz, int ell_width) {
+  const size_t TM = (size_t)nrb * 32;
+  size_t b = TM * (size_t)(kpad + 4) * 4 + (size_t)nw * 32 * (TM + 4) * 4;   // X tile + wave stages
+  if (nmat > 1) b += ell_width > 0 ? TM * (size_t)ell_width * 8 : (TM + 2) * 4 + (size_t)max_nnz * 8;
+  return b;
+}
+
+// waves per workgroup: one per 32-column group up to 4, fewer if the wave-private stages would not
+// fit the 160 KiB LDS next to the X tile (large tiles); DSS2_GEMM_WAVES forces a smaller count
+static int gemm_waves(int ncg, int nrb, int nmat, int kpad, int max_nnz, int ell_width) {
   static const int forced = [] { const char* e = getenv("DSS2_GEMM_WAVES"); return e ? atoi(e) : 0; }();
   int nw = ncg < 4 ? ncg : 4;
   if (forced > 0 && forced < nw) nw = forced;
+  while (nw > 1 && lds_bytes_nw(nrb, nmat, kpad, nw, max_nnz, ell_width) > (size_t)kMaxLdsBytes) --nw;
   return nw;
 }
 
 static size_t lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz, int ell_width) {
-  const size_t TM = (size_t)nrb * 32;
-  const int nw = gemm_waves(ncg);
-  size_t b = TM * (size_t)(kpad + 4) * 4 + (size_t)nw * 32 * (TM + 4) * 4;
-  if (nmat > 1) b += ell_width > 0 ? TM * (size_t)ell_width * 8 : (TM + 2) * 4 + (size_t)max_nnz * 8;
-  return b;
+  return lds_bytes_nw(nrb, nmat, kpad, gemm_waves(ncg, nrb, nmat, kpad, max_nnz, ell_width), max_nnz, ell_width);
 }
 
 static int gemm_stagger() {
@@ -976,7 +982,7 @@ static int launch(const dss2_gemm_prop_args& a_in, hipStream_t stream) {
     attr_set = true;
   }
   const size_t lds = lds_bytes(NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.ncg, a.max_nnz, a.ell_width);
-  const int nw = gemm_waves(a.ncg);
+  const int nw = gemm_waves(a.ncg, NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.max_nnz, a.ell_width);
   // persistent over tiles: at most two workgroups per CU are co-resident at the LDS sizes of the
   // compute-heavy shapes, so 512 workgroups cover the chip; each walks tiles blockIdx.x, +grid, ...
   static const int pgrid = [] { const char* e = getenv("DSS2_GEMM_GRID"); return e ? atoi(e) : 0; }();
@@ -1036,7 +1042,8 @@ extern "C" int dss2_gemm_prop(const dss2_gemm_prop_args* ap, void* stream) {
   // Horner on the matrix pipe when the dense A_hat fits the dead X region and every wave runs the
   // column-group loop exactly once (the barriers around the A_hat build must be uniform)
   static const int hm_env = [] { const char* e = getenv("DSS2_HORNER_MFMA"); return e ? atoi(e) : 0; }();   // measured slower at C2 (91 vs 86 us)
-  const bool hm = hm_env && a.nmat > 1 && a.ell_width > 0 && a.ncg <= 4 && a.nrb * 32 <= a.kpad && a.prop_in == 0;
+  const bool hm = hm_env && a.nmat > 1 && a.ell_width > 0 && a.nrb * 32 <= a.kpad && a.prop_in == 0 &&
+                  gemm_waves(a.ncg, a.nrb, a.nmat, a.kpad, a.max_nnz, a.ell_width) == a.ncg;
 #define DSS2_CASEH(NRB, NMAT) \
   if (hm && a.nrb == NRB && a.nmat == NMAT) return launch<NRB, NMAT, true>(a, s);
   DSS2_CASEH(1, 2) DSS2_CASEH(1, 3) DSS2_CASEH(1, 4) DSS2_CASEH(2, 2) DSS2_CASEH(2, 3) DSS2_CASEH(2, 4)

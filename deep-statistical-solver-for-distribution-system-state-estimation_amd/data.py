@@ -81,8 +81,8 @@ class _WlsFn(torch.autograd.Function):
         L = _lib.lib()
         _lib.check(L.dss2_wls_loss_partials(C.byref(a), st), "dss2_wls_loss_partials")
         if group is not None:   # global-batch sums and counts (exact data-parallel loss)
-            import torch.distributed as dist
-            dist.all_reduce(bufs["sums"], op=dist.ReduceOp.SUM, group=group)
+            from . import parallel
+            parallel.allreduce_loss_sums(bufs["sums"], group)
         _lib.check(L.dss2_wls_loss_grad(C.byref(a), st), "dss2_wls_loss_grad")
         ctx.mark_dirty(output)
         ctx.save_for_backward(bufs["grad"])

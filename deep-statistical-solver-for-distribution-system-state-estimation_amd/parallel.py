@@ -28,7 +28,8 @@ def init_from_env(backend: Optional[str] = None) -> Dict[str, int]:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # torch.distributed.run sets both
+    if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -70,13 +71,13 @@ def shard_batch(batch: Dict[str, object], rank: int, world: int) -> Dict[str, ob
 
 def allreduce_loss_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
     """sums[0..4] = batch sums, sums[5] = node count, sums[6] = edge count -> global values."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     return sums
 
 
 def allreduce_flat_grads(flat: torch.Tensor, group=None) -> torch.Tensor:
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 
