@@ -141,13 +141,32 @@ def is_narrow(nmat: int, hout: int) -> bool:
     return nmat > 1 and nmat * hout <= 32
 
 
+class _MatView:
+    """A [rows, cols] block of a row-major parameter tensor (leading dimension ld, element offset
+    off): lets the pack kernel read e.g. W1[:, :fn] in place, without a copy per step."""
+
+    def __init__(self, t: torch.Tensor, rows: int, cols: int, ld: int, off: int = 0):
+        self.t, self.shape, self.ld, self.off = t, (rows, cols), ld, off
+
+    def data_ptr(self) -> int:
+        return self.t.data_ptr() + 4 * self.off
+
+    def is_contiguous(self) -> bool:
+        return self.t.is_contiguous()
+
+
+def _as_view(w):
+    return w if isinstance(w, _MatView) else _MatView(w, w.shape[0], w.shape[1], w.shape[1], 0)
+
+
 class _PackPlan:
     """Fragment-packed copies (forward and data-gradient layouts) of a list of weight matrices,
     refreshed by ONE kernel launch per forward."""
 
     def __init__(self, groups: Sequence[Sequence[torch.Tensor]], device):
-        # groups[g] = the nmat matrices [hout, hin] of one fused GEMM (TAGConv lins, or one Linear)
-        self.groups = groups
+        # groups[g] = the nmat matrices [hout, hin] of one fused GEMM (TAGConv lins, or one Linear);
+        # entries are Parameters or _MatView blocks of a Parameter
+        self.groups = groups = [[_as_view(w) for w in mats] for mats in groups]
         self.device = device
         self.fwd, self.bwd, self.meta = [], [], []
         for mats in groups:
@@ -177,11 +196,11 @@ class _PackPlan:
                     raise RuntimeError("weight matrices must be contiguous")
                 # record = (src, dst, rows, cols, ld, transpose, koff, kpad, ncg, joff)
                 if narrow:
-                    recs.append((w.data_ptr(), self.fwd[g].data_ptr(), hout, hin, hin, 1, 0, kf, cf, m * hout))
-                    recs.append((w.data_ptr(), self.bwd[g].data_ptr(), hout, hin, hin, 0, m * hout, kb, cb, 0))
+                    recs.append((w.data_ptr(), self.fwd[g].data_ptr(), hout, hin, w.ld, 1, 0, kf, cf, m * hout))
+                    recs.append((w.data_ptr(), self.bwd[g].data_ptr(), hout, hin, w.ld, 0, m * hout, kb, cb, 0))
                 else:
-                    recs.append((w.data_ptr(), self.fwd[g].data_ptr() + 4 * m * cf * (kf // 8) * 256, hout, hin, hin, 1, 0, kf, cf, 0))
-                    recs.append((w.data_ptr(), self.bwd[g].data_ptr() + 4 * m * cb * (kb // 8) * 256, hout, hin, hin, 0, 0, kb, cb, 0))
+                    recs.append((w.data_ptr(), self.fwd[g].data_ptr() + 4 * m * cf * (kf // 8) * 256, hout, hin, w.ld, 1, 0, kf, cf, 0))
+                    recs.append((w.data_ptr(), self.bwd[g].data_ptr() + 4 * m * cb * (kb // 8) * 256, hout, hin, w.ld, 0, 0, kb, cb, 0))
                 self.max_elems = max(self.max_elems, (cf + 1) * (kf // 8 + 1) * 64, (cb + 1) * (kb // 8 + 1) * 64)
         arr = np.array(recs, dtype=_DESC_DTYPE)
         self.n_desc = len(recs)
@@ -213,7 +232,8 @@ def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hou
     return S, x0
 
 
-def _edge_aggr_backward(topo, gx0, x, ldx, ea, ldea, W1, b1, S, pack_w2_bwd, hid, hout, fn, fe, g_w1, g_w2, need_dx):
+def _edge_aggr_backward(topo, gx0, x, ldx, ea, ldea, W1, b1, S, pack_w2_bwd, hid, hout, fn, fe, g_w1, g_w2, need_dx,
+                        pack_dx=None):
     """g_w1: flat [hid*(2fn+fe) + hid] <- dW1, db1;  g_w2: flat [hout*hid + hout] <- dW2, db2.
     Returns dx [N, fn] or None."""
     N = topo.N
@@ -237,16 +257,20 @@ def _edge_aggr_backward(topo, gx0, x, ldx, ea, ldea, W1, b1, S, pack_w2_bwd, hid
     _lib.check(L.dss2_edge_hidden_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
                                       topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.entT.data_ptr(), None,
                                       n_slabs, U[1].data_ptr(), hid, N, hid, fn, fe, 1, st), "dss2_edge_hidden_bwd")
-    # dx = U[0] @ W1[:, :fn] + U[1] @ W1[:, fn:2fn]: two K=hid -> fn GEMMs on the tile kernel, the
-    # second one adding the first through the residual epilogue
-    plan = _PackPlan([[W1[:, :fn].contiguous()], [W1[:, fn:2 * fn].contiguous()]], dev)
-    plan.refresh()
+    # dx = U[0] @ W1[:, :fn] + U[1] @ W1[:, fn:2fn]: two K=hid -> fn GEMMs on the tile kernel (the two W1
+    # blocks are packed in place by the module's pack launch), the second adding the first through the
+    # residual epilogue
     dx0 = torch.empty(N, fn, dtype=_F32, device=dev)
     dx = torch.empty(N, fn, dtype=_F32, device=dev)
-    gemm_prop(topo, U[0], hid, hid, plan.bwd[0], 1, fn, dx0)
-    gemm_prop(topo, U[1], hid, hid, plan.bwd[1], 1, fn, dx, add_src=dx0, add_ld=fn)
-    plan.keepalive = (dx0, U)
+    gemm_prop(topo, U[0], hid, hid, pack_dx[0], 1, fn, dx0)
+    gemm_prop(topo, U[1], hid, hid, pack_dx[1], 1, fn, dx, add_src=dx0, add_ld=fn)
     return dx
+
+
+def _dx_views(W1, hid, fn, fe):
+    """W1[:, :fn] (x enters as x_i) and W1[:, fn:2fn] (as x_j) as in-place blocks for the pack kernel."""
+    ld = 2 * fn + fe
+    return [[_MatView(W1, hid, fn, ld, 0)], [_MatView(W1, hid, fn, ld, fn)]]
 
 
 def _tagconv_forward(topo, h, pack_fwd, bias, nmat, hin, hout, dmask=None, relu=False, add_src=None, add_ld=0):
@@ -367,7 +391,7 @@ class _EdgeAggrFn(torch.autograd.Function):
         x, ldx = _rows(x)
         ea, ldea = _rows(ea)
         if mod._plan is None or mod._plan.device != x.device:
-            mod._plan = _PackPlan([[W2]], x.device)
+            mod._plan = _PackPlan([[W2]] + _dx_views(W1, mod.dim_hid, mod.dim_featn, mod.dim_feate), x.device)
         ctx.ver = mod._plan.refresh()
         topo.lds_check(1, _round8(mod.dim_hid), _ncg(mod.dim_out))
         S, x0 = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, mod._plan.fwd[0], mod.dim_hid, mod.dim_out,
@@ -387,7 +411,7 @@ class _EdgeAggrFn(torch.autograd.Function):
         g1 = torch.empty(hid * (2 * fn + fe) + hid, dtype=_F32, device=g.device)
         g2 = torch.empty(hout * hid + hout, dtype=_F32, device=g.device)
         dx = _edge_aggr_backward(topo, g, x, ctx.ld[0], ea, ctx.ld[1], W1, b1, S, mod._plan.bwd[0], hid, hout, fn, fe,
-                                 g1, g2, ctx.needs_input_grad[0])
+                                 g1, g2, ctx.needs_input_grad[0], pack_dx=(mod._plan.bwd[1], mod._plan.bwd[2]))
         nc = 2 * fn + fe
         return (dx, None, None, None, g1[:hid * nc].view(hid, nc), g1[hid * nc:], g2[:hout * hid].view(hout, hid),
                 g2[hout * hid:])
@@ -469,7 +493,8 @@ class _MPNFn(torch.autograd.Function):
         W1, b1, W2, b2 = ps[0:4]
         conv_ps = [ps[4 + l * (nmat + 1): 4 + (l + 1) * (nmat + 1)] for l in range(L)]   # (bias, W_0..W_K)
         if mod._plan is None or mod._plan.device != dev:
-            mod._plan = _PackPlan([[W2]] + [list(cp[1:]) for cp in conv_ps], dev)
+            mod._plan = _PackPlan([[W2]] + [list(cp[1:]) for cp in conv_ps] +
+                                  _dx_views(W1, hid, mod.dim_featn, mod.dim_feate), dev)
         plan = mod._plan
         ctx.ver = plan.refresh()
         topo.lds_check(nmat, _round8(hid), _ncg(hid))
@@ -526,7 +551,8 @@ class _MPNFn(torch.autograd.Function):
             g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, hout, seg,
                                   relu_src=(acts[l] if l > 0 else None), dmask=(masks[l - 1] if l > 0 else None))
         dx = _edge_aggr_backward(topo, g, x, ldx, ea, ldea, W1, b1, S, plan.bwd[0], hid, hid, fn, fe,
-                                 flat[offs[0]:offs[1]], flat[offs[1]:offs[2]], need_dx)
+                                 flat[offs[0]:offs[1]], flat[offs[1]:offs[2]], need_dx,
+                                 pack_dx=(plan.bwd[1 + L], plan.bwd[2 + L]))
         if need_dx and mod.skip:
             dx = dx + gout
         hook = getattr(mod, "_grad_bucket_hook", None)
