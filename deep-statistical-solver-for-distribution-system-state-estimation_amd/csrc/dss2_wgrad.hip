@@ -6,6 +6,8 @@
 // buffers, no atomics), and every wave accumulates its 32x32 blocks of dW with fp32 MFMA
 // (32x32x2; A = Z^T read column-wise from LDS, B = X) in registers ACROSS tiles.  One slab of
 // partial sums per workgroup is written at the end; dss2_reduce_slabs adds them in fixed order.
+#include <stdlib.h>
+
 #include "dss2_common.hpp"
 
 namespace dss2 {
@@ -317,7 +319,9 @@ static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz, int ell_width, b
 
 static int pick_nb(int nrb, int nmat, int hout, int max_nnz, int ell_width) {
   const int nob = (hout + 31) / 32;
+  static const int nb_max = [] { const char* e = getenv("DSS2_WGRAD_NB"); return e ? atoi(e) : 4; }();   // tuning knob
   for (int nb = 4; nb >= 1; nb >>= 1) {
+    if (nb > nb_max) continue;
     if (nb > 1 && nb / 2 >= nob) continue;  // do not over-allocate columns
     if (wgrad_lds(nrb, nmat, nb, max_nnz, ell_width, nmat > 1) <= (size_t)kMaxLdsBytes) return nb;
   }
