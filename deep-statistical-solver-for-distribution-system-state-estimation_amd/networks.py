@@ -223,9 +223,15 @@ class _PackPlan:
 def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hout, fn, fe):
     N = topo.N
     S = torch.empty(N, hid, dtype=_F32, device=W1.device)
-    _lib.check(_lib.lib().dss2_edge_hidden_fwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(),
-                                               topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(),
-                                               S.data_ptr(), N, hid, fn, fe, _stream(S)), "dss2_edge_hidden_fwd")
+    if topo.ell_ent_tiles is not None and EDGE_TILE_KERNELS:
+        _lib.check(_lib.lib().dss2_edge_tile_fwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(),
+                                                 topo.tile_start.data_ptr(), topo.ell_ent_tiles.data_ptr(), topo.ell,
+                                                 topo.nrb, topo.ntiles, S.data_ptr(), hid, fn, fe, _stream(S)),
+                   "dss2_edge_tile_fwd")
+    else:   # general graphs (hub nodes beyond the ELL width): row-per-wave kernel on the CSR
+        _lib.check(_lib.lib().dss2_edge_hidden_fwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(),
+                                                   topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(),
+                                                   S.data_ptr(), N, hid, fn, fe, _stream(S)), "dss2_edge_hidden_fwd")
     x0 = torch.empty(N, hout, dtype=_F32, device=W1.device)
     # second Linear of the edge MLP after the (linear) aggregation: sum_e (W2 h_e + b2) = W2 S + deg b2
     gemm_prop(topo, S, hid, hid, pack_w2_fwd, 1, hout, x0, bias=b2, rowscale=topo.deg)
@@ -241,22 +247,35 @@ def _edge_aggr_backward(topo, gx0, x, ldx, ea, ldea, W1, b1, S, pack_w2_bwd, hid
     wgrad(topo, gx0, hout, S, hid, 1, g_w2, rowscale=topo.deg)
     dS = torch.empty(N, hid, dtype=_F32, device=dev)
     gemm_prop(topo, gx0, gx0.stride(0), hout, pack_w2_bwd, 1, hid, dS)
-    n_slabs = int(min(512, max(1, (N + 15) // 16)))
     stride = hid * (2 * fn + fe) + hid
+    tiled = topo.ell_ent_tiles is not None and topo.ellT_ent_tiles is not None and EDGE_TILE_KERNELS
+    n_slabs = min(topo.ntiles, 512) if tiled else int(min(512, max(1, (N + 15) // 16)))
     slab = torch.empty(n_slabs * stride, dtype=_F32, device=dev)
     U = torch.empty(2, N, hid, dtype=_F32, device=dev) if need_dx else None
     st = _stream(gx0)
     L = _lib.lib()
-    _lib.check(L.dss2_edge_hidden_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
-                                      topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(), slab.data_ptr(),
-                                      n_slabs, _ptr(U), hid, N, hid, fn, fe, 0, st), "dss2_edge_hidden_bwd")
+    if tiled:
+        _lib.check(L.dss2_edge_tile_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
+                                        topo.tile_start.data_ptr(), topo.ell_ent_tiles.data_ptr(), topo.ell, topo.nrb,
+                                        topo.ntiles, slab.data_ptr(), n_slabs, _ptr(U), hid, hid, fn, fe, 0, st),
+                   "dss2_edge_tile_bwd")
+    else:
+        _lib.check(L.dss2_edge_hidden_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
+                                          topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(), slab.data_ptr(),
+                                          n_slabs, _ptr(U), hid, N, hid, fn, fe, 0, st), "dss2_edge_hidden_bwd")
     _lib.check(L.dss2_reduce_slabs(slab.data_ptr(), n_slabs, stride, g_w1.data_ptr(), stride, st), "dss2_reduce_slabs")
     if not need_dx:
         return None
     # U[0] = sum of dz over incoming edges (x enters as x_i), U[1] over outgoing edges (as x_j)
-    _lib.check(L.dss2_edge_hidden_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
-                                      topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.entT.data_ptr(), None,
-                                      n_slabs, U[1].data_ptr(), hid, N, hid, fn, fe, 1, st), "dss2_edge_hidden_bwd")
+    if tiled:
+        _lib.check(L.dss2_edge_tile_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
+                                        topo.tile_start.data_ptr(), topo.ellT_ent_tiles.data_ptr(), topo.ellT, topo.nrb,
+                                        topo.ntiles, None, n_slabs, U[1].data_ptr(), hid, hid, fn, fe, 1, st),
+                   "dss2_edge_tile_bwd")
+    else:
+        _lib.check(L.dss2_edge_hidden_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
+                                          topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.entT.data_ptr(), None,
+                                          n_slabs, U[1].data_ptr(), hid, N, hid, fn, fe, 1, st), "dss2_edge_hidden_bwd")
     # dx = U[0] @ W1[:, :fn] + U[1] @ W1[:, fn:2fn]: two K=hid -> fn GEMMs on the tile kernel (the two W1
     # blocks are packed in place by the module's pack launch), the second adding the first through the
     # residual epilogue
@@ -283,6 +302,7 @@ def _tagconv_forward(topo, h, pack_fwd, bias, nmat, hin, hout, dmask=None, relu=
 import os as _os
 
 _SIDE_STREAMS = {}
+EDGE_TILE_KERNELS = _os.environ.get("DSS2_EDGE_TILE", "1") == "1"       # 0 = row-per-wave CSR kernels
 WGRAD_SIDE_STREAM = _os.environ.get("DSS2_WGRAD_STREAM", "1") == "1"   # +3 % at C2; 0 = single stream
 
 

@@ -146,8 +146,11 @@ class Topology:
         # in LDS for the in-tile propagation, precomputed here so that staging is one coalesced copy
         self.ell_tiles = self._ell_tiles(self.rowptr, self.col, self.w, self.ell)
         self.ellT_tiles = self._ell_tiles(self.rowptrT, self.colT, self.wT, self.ellT)
+        # same slices carrying the stored edge id | flip instead of the weight (edge-MLP kernels); -1 = empty
+        self.ell_ent_tiles = self._ell_tiles(self.rowptr, self.col, self.ent, self.ell, ids=True)
+        self.ellT_ent_tiles = self._ell_tiles(self.rowptrT, self.colT, self.entT, self.ellT, ids=True)
 
-    def _ell_tiles(self, rowptr, col, w, width):
+    def _ell_tiles(self, rowptr, col, w, width, ids=False):
         if width <= 0:
             return None
         dev, tm, nt = self.device, 32 * self.nrb, self.ntiles
@@ -159,9 +162,12 @@ class Topology:
         tile = torch.searchsorted(ts, rows, right=True) - 1
         r = rows - ts[tile]
         out = torch.zeros(nt, width, tm, 2, dtype=torch.int32, device=dev)
-        out[:, :, :, 0] = torch.arange(tm, dtype=torch.int32, device=dev)      # padding: {own row, weight 0}
+        if ids:
+            out[:, :, :, 1] = -1                                                    # padding: empty slot
+        else:
+            out[:, :, :, 0] = torch.arange(tm, dtype=torch.int32, device=dev)      # padding: {own row, weight 0}
         out[tile, k, r, 0] = (col.to(torch.int64) - ts[tile]).to(torch.int32)
-        out[tile, k, r, 1] = w.view(torch.int32)
+        out[tile, k, r, 1] = w if ids else w.view(torch.int32)
         return out.contiguous()
 
     def lds_check(self, nmat: int, kpad: int, ncg: int) -> None:

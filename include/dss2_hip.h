@@ -97,6 +97,20 @@ int dss2_edge_hidden_bwd(const float* x, int64_t ldx, const float* ea, int64_t l
                          float* slab, int n_slabs, float* U, int64_t ldu,
                          int64_t n_nodes, int h, int fn, int fe, int by_source, void* stream);
 
+/* Tile-based variants of the two functions above (same arithmetic, same outputs): one workgroup per
+ * tile with the tile's x rows, an ELL slice carrying edge ids and the gathered edge_attr rows staged
+ * in LDS.  ell_ent: int2 {local other node, stored edge id | flip<<31 (-1 = empty slot)}
+ * [ntiles][ell_width][32*nrb], built once per topology from the CSR by target (forward, backward with
+ * by_source = 0) or by source (by_source = 1).  min(n_slabs, ntiles) persistent workgroups walk the
+ * tiles and write one partial slab each. */
+int dss2_edge_tile_fwd(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1,
+                       const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width,
+                       int nrb, int ntiles, float* S, int h, int fn, int fe, void* stream);
+int dss2_edge_tile_bwd(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1,
+                       const float* b1, const float* dS, const int32_t* tile_start, const void* ell_ent,
+                       int ell_width, int nrb, int ntiles, float* slab, int n_slabs, float* U, int64_t ldu,
+                       int h, int fn, int fe, int by_source, void* stream);
+
 /* ---- K2/K4: fused tile GEMM + Horner graph propagation --------------------------------- *
  * Y = epilogue( sum_{m=0..nmat-1} P^m (X . B_m) ),  P = A_hat given by (rowptr, col, w).
  *  forward TAGConv (PyG TAGConv; call sites networks.py:267,271):

@@ -32,6 +32,7 @@ flat = torch.empty(nmat * H * H + H, device=dev); flat1 = torch.empty(H * H + H,
 xin, ein = x[:, :8], ea[:, :6]
 L = pkg._lib.lib(); st = torch.cuda.current_stream().cuda_stream
 slab1 = torch.empty(512 * (H * 23), device=dev); g1 = torch.empty(H * 23, device=dev)
+slab2 = torch.empty(topo.ntiles * (H * 23), device=dev)
 
 fl_gemm = 2.0 * N * H * nmat * H + 2.0 * a.K * topo.E2 * H
 cases = {
@@ -45,6 +46,8 @@ cases = {
   "tag_wgrad H->2": (lambda: nw.wgrad(topo, g2, 2, h, H, nmat, flatl), 2.0 * N * H * nmat * 2),
   "edge_hidden_fwd": (lambda: pkg._lib.check(L.dss2_edge_hidden_fwd(xin.data_ptr(), 11, ein.data_ptr(), 13, W1.data_ptr(), b1.data_ptr(), topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(), S.data_ptr(), N, H, 8, 6, st), "f"), 2.0 * topo.E2 * 14 * H + 2.0 * N * 8 * H),
   "edge_hidden_bwd": (lambda: pkg._lib.check(L.dss2_edge_hidden_bwd(xin.data_ptr(), 11, ein.data_ptr(), 13, W1.data_ptr(), b1.data_ptr(), g.data_ptr(), topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(), slab1.data_ptr(), 512, None, H, N, H, 8, 6, 0, st), "b"), 4.0 * topo.E2 * 22 * H),
+  "edge_tile_fwd": (lambda: pkg._lib.check(L.dss2_edge_tile_fwd(xin.data_ptr(), 11, ein.data_ptr(), 13, W1.data_ptr(), b1.data_ptr(), topo.tile_start.data_ptr(), topo.ell_ent_tiles.data_ptr(), topo.ell, topo.nrb, topo.ntiles, S.data_ptr(), H, 8, 6, st), "f"), 2.0 * topo.E2 * 14 * H + 2.0 * N * 8 * H),
+  "edge_tile_bwd": (lambda: pkg._lib.check(L.dss2_edge_tile_bwd(xin.data_ptr(), 11, ein.data_ptr(), 13, W1.data_ptr(), b1.data_ptr(), g.data_ptr(), topo.tile_start.data_ptr(), topo.ell_ent_tiles.data_ptr(), topo.ell, topo.nrb, topo.ntiles, slab2.data_ptr(), 512, None, H, H, 8, 6, 0, st), "b"), 4.0 * topo.E2 * 22 * H),
   "pack_weights": (lambda: plan.refresh(), 1.0),
 }
 res = {k: [] for k in cases}
