@@ -1,0 +1,130 @@
+"""The build's own runner for the hot path: what /root/reference/dss2_run.py does around it.
+
+Reproduces the training loop (dss2_run.py:131-147) and the per-epoch evaluation
+(dss2_run.py:165-224) with the reference's knobs as arguments and its defaults:
+feature slicing ``x[:, :8] / edge_attr[:, :6] / x[:, 8:] / edge_attr[:, 6:]`` (:138,140),
+``reg_coefs`` (:104-112), Adamax lr 3e-3 (:91-92), batch_size 64, the hyper-parameter dict (:72-82).
+The model is the MPN / SkipMPN / PFN / SkipPFN line (:88), not the default GAT (out of scope).
+Data: the reference ships samples for CIGRE-14 only and its loader (data_from_pickles) is host-side
+and out of scope, so batches come from ``synthetic.make_batch`` (same layout), collated once and kept
+resident on the GPU (re-used tensors take the no-sync topology fast path).
+
+    python tools/train.py --case cigre14 --model SkipPFN --epochs 5
+"""
+from __future__ import annotations
+
+import argparse
+import time
+from typing import Dict, List
+
+import torch
+
+from . import data as dss2_data
+from . import networks, synthetic
+from .optim import FusedAdamax
+
+REG_COEFS = {"mu_v": 1e-1, "mu_theta": 1e-1, "lam_v": 1e-4, "lam_p": 1e-8, "lam_pf": 1e-6, "lam_reg": 1e2}
+HYPER = {"dim_nodes": 8, "dim_lines": 6, "dim_out": 2, "dim_hid": 32, "gnn_layers": 8, "K": 2, "dropout_rate": 0.3, "L": 5}
+
+
+def build_model(name: str, hp: Dict) -> torch.nn.Module:
+    cls = getattr(networks, name)
+    a = (hp["dim_nodes"], hp["dim_lines"], hp["dim_out"], hp["dim_hid"], hp["gnn_layers"], hp["K"], hp["dropout_rate"])
+    return cls(*a, hp["L"]) if name in ("PFN", "SkipPFN") else cls(*a)
+
+
+def make_loaders(case: str, n_graphs: int, batch_size: int, device, seed: int = 0, split: float = 0.9):
+    """Pre-collated, device-resident batches (train / test) with one set of normalisation statistics."""
+    full = synthetic.make_batch([case], n_graphs, seed=seed)
+    stats = tuple(s.to(device) for s in full["stats"])
+    n_train = int(split * n_graphs)
+
+    def batches(g0, g1, seed_off):
+        out = []
+        for b0 in range(g0, g1, batch_size):
+            nb = min(batch_size, g1 - b0)
+            b = synthetic.make_batch([case], nb, seed=seed + 1 + seed_off + b0, stats=full["stats"])
+            out.append({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in b.items() if k != "stats"})
+        return out
+
+    return batches(0, n_train, 0), batches(n_train, n_graphs, 10_000), stats
+
+
+def train_epoch(model, opt, loader: List[Dict], stats, reg_coefs, group=None) -> float:
+    model.train()
+    total = torch.zeros((), device=stats[0].device)
+    for data in loader:                                              # dss2_run.py:134-144
+        opt.zero_grad()
+        x, ei, ea = data["x"], data["edge_index"], data["edge_attr"]
+        out = model(x[:, :8], ei, ea[:, :6])
+        loss = dss2_data.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=stats[0], x_std=stats[1],
+                                      edge_mean=stats[2], edge_std=stats[3], edge_index=ei, reg_coefs=reg_coefs,
+                                      num_samples=data["num_graphs"], node_param=x[:, 8:], edge_param=ea[:, 6:], group=group)
+        loss.backward()
+        opt.step()
+        total += loss.detach()
+    return float(total / len(loader))                                # one host sync per epoch (:147)
+
+
+@torch.no_grad()
+def evaluate(model, loader: List[Dict], stats) -> Dict[str, float]:
+    """dss2_run.py:165-224: RMSE / MAE of V and theta, and of line / trafo loading from get_pflow."""
+    model.eval()                                                     # dropout stays active, as in the reference
+    acc = {k: 0.0 for k in ("rmse_v", "mae_v", "rmse_th", "mae_th", "rmse_loading", "mae_loading",
+                            "rmse_loading_trafos", "mae_loading_trafos")}
+    for data in loader:
+        x, ei, ea, y = data["x"], data["edge_index"], data["edge_attr"], data["y"]
+        out = model(x[:, :8], ei, ea[:, :6])
+        out = torch.cat([out[:, 0:1] * stats[1][:1] + stats[0][:1], out[:, 1:]], dim=1)      # :183
+        out[:, 1:] *= (1.0 - x[:, 9:10])                                                     # :184
+        acc["rmse_v"] += torch.sqrt(torch.mean((out[:, :1] - y[:, :1]) ** 2)).item()
+        acc["rmse_th"] += torch.sqrt(torch.mean((out[:, 1:] - y[:, 1:]) ** 2)).item()
+        acc["mae_v"] += (out[:, :1] - y[:, :1]).abs().mean().item()
+        acc["mae_th"] += (out[:, 1:] - y[:, 1:]).abs().mean().item()
+        t_lines, t_trafos = dss2_data.get_pflow(y, ei, node_param=x[:, 8:], edge_param=ea[:, 6:])[0:2]   # :193
+        o_lines, o_trafos = dss2_data.get_pflow(out, ei, node_param=x[:, 8:], edge_param=ea[:, 6:])[0:2]  # :194
+        for tag, t_, o_ in (("loading", t_lines, o_lines), ("loading_trafos", t_trafos, o_trafos)):
+            nz = t_ != 0                                                                     # :196-200
+            if nz.any():
+                d = o_[nz] - t_[nz]
+                acc["rmse_" + tag] += torch.sqrt(torch.mean(d ** 2)).item()
+                acc["mae_" + tag] += d.abs().mean().item()
+    return {k: v / max(len(loader), 1) for k, v in acc.items()}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--case", default="cigre14", choices=["cigre14", "cigre14_reswitched", "ober_sub", "ober179"])
+    ap.add_argument("--model", default="SkipPFN", choices=["MPN", "SkipMPN", "PFN", "SkipPFN"])
+    ap.add_argument("--graphs", type=int, default=720)
+    ap.add_argument("--batch-size", type=int, default=64)
+    ap.add_argument("--epochs", type=int, default=600)
+    ap.add_argument("--lr", type=float, default=3e-3)
+    for k, v in HYPER.items():
+        ap.add_argument("--" + k.replace("_", "-"), type=type(v), default=v)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--save", default="")
+    a = ap.parse_args(argv)
+    hp = {k: getattr(a, k) for k in HYPER}
+    if a.model == "SkipMPN":
+        hp["dim_out"] = hp["dim_nodes"]
+    dev = torch.device("cuda")
+    torch.manual_seed(a.seed)
+    train_loader, test_loader, stats = make_loaders(a.case, a.graphs, a.batch_size, dev, a.seed)
+    model = build_model(a.model, hp).to(dev)
+    opt = FusedAdamax(model.parameters(), lr=a.lr)
+    print(f"device:{dev}  train batches {len(train_loader)}  test batches {len(test_loader)}  model {a.model} {hp}")
+    for epoch in range(a.epochs):
+        t0 = time.perf_counter()
+        tl = train_epoch(model, opt, train_loader, stats, REG_COEFS)
+        m = evaluate(model, test_loader, stats) if hp["dim_out"] == 2 else {}
+        torch.cuda.synchronize()
+        print(f"epoch {epoch:4d}  train_loss {tl:.6g}  " + "  ".join(f"{k} {v:.4g}" for k, v in m.items()) +
+              f"  ({time.perf_counter() - t0:.2f} s)", flush=True)
+    if a.save:                                                       # dss2_run.py:240-247
+        torch.save({"epoch": a.epochs - 1, "model_state_dict": model.state_dict(), "optimizer_state_dict": opt.state_dict()},
+                   a.save)
+
+
+if __name__ == "__main__":
+    main()

@@ -221,6 +221,17 @@ int dss2_get_pflow(const float* y, int64_t ldy, const float* node_param, int64_t
                    const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
                    int64_t n_nodes, int64_t n_edges, float* vminmax, float* pflow, void* stream);
 
+/* ---- optimizer step (/root/reference/dss2_run.py:91-92,143: Adamax, lr 3e-3) ---
+ * torch.optim.Adamax semantics on n_desc tensors in ONE launch.  descs: device array.  `step` is the
+ * 1-based step count (bias correction 1 - beta1^step).  grad pointers may be views of the flat
+ * gradient bucket the backward produces. */
+typedef struct dss2_adamax_desc {
+  float* param; const float* grad; float* exp_avg; float* exp_inf; int64_t n;
+} dss2_adamax_desc;
+
+int dss2_adamax_step(const dss2_adamax_desc* descs, int n_desc, int64_t max_n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, void* stream);
+
 /* LDS bytes a dss2_gemm_prop / dss2_wgrad launch will request (host-side helper; lets the
  * caller reject configurations that do not fit the 160 KiB LDS before launching). */
 size_t dss2_gemm_prop_lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz, int ell_width);

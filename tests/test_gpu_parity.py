@@ -277,3 +277,52 @@ def test_hipgraph_replay_matches_eager(pkg, oracle):
     torch.cuda.synchronize()
     assert l_graph == l_eager
     assert all(torch.equal(a, p.grad) for a, p in zip(g_graph, model.parameters()))
+
+
+def test_fused_adamax_matches_torch(pkg):
+    """dss2_adamax_step vs torch.optim.Adamax (the reference's optimizer, dss2_run.py:91-92) on the same
+    gradients for three steps; state keys are torch's."""
+    torch.manual_seed(0)
+    shapes = [(128, 22), (128,), (128, 128), (2, 128), (2,), (1,)]
+    ps_ref = [torch.randn(s).requires_grad_(True) for s in shapes]
+    ps_gpu = [p.detach().clone().to(DEV).requires_grad_(True) for p in ps_ref]
+    o_ref = torch.optim.Adamax(ps_ref, lr=3e-3)
+    o_gpu = pkg.FusedAdamax(ps_gpu, lr=3e-3)
+    for step in range(3):
+        for a, b in zip(ps_ref, ps_gpu):
+            g = torch.randn(a.shape) * (10.0 ** (step - 1))
+            a.grad = g.clone()
+            b.grad = g.to(DEV)
+        o_ref.step()
+        o_gpu.step()
+    for a, b in zip(ps_ref, ps_gpu):
+        assert rel_err(b, a) < 1e-6
+        sa, sb = o_ref.state[a], o_gpu.state[b]
+        assert set(sb.keys()) == {"step", "exp_avg", "exp_inf"} and float(sb["step"]) == float(sa["step"]) == 3.0
+        assert rel_err(sb["exp_avg"], sa["exp_avg"]) < 1e-6 and rel_err(sb["exp_inf"], sa["exp_inf"]) < 1e-6
+
+
+def test_runner_trains_and_tracks_the_oracle(pkg, oracle):
+    """Five optimizer steps of the runner's loop (FusedAdamax, lr 3e-3) against the oracle + torch Adamax from
+    the same initial weights on the same batch: the loss trajectories agree and the loss goes down."""
+    torch.manual_seed(0)
+    b = pkg.synthetic.make_batch(["cigre14"], 64, seed=3)
+    ref = oracle.MPN(8, 6, 2, 32, 2, 2, 0.0)
+    mine = pkg.MPN(8, 6, 2, 32, 2, 2, 0.0)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(DEV)
+    o_ref = torch.optim.Adamax(ref.parameters(), lr=3e-3)
+    o_gpu = pkg.FusedAdamax(mine.parameters(), lr=3e-3)
+    dev_b = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items() if k != "stats"}
+    st = tuple(s.to(DEV) for s in b["stats"])
+    l_ref, l_gpu = [], []
+    for _ in range(5):
+        _, lr_ = oracle.train_step(ref, b, b["stats"])
+        o_ref.step()
+        l_ref.append(lr_.item())
+        l_gpu.append(pkg.runner.train_epoch(mine, o_gpu, [dev_b], st, pkg.runner.REG_COEFS))
+    assert l_gpu[-1] < l_gpu[0]
+    for a, c in zip(l_gpu, l_ref):
+        assert abs(a - c) <= 1e-4 * abs(c), (l_gpu, l_ref)
+    m = pkg.runner.evaluate(mine, [dev_b], st)
+    assert all(v == v and v >= 0 for v in m.values())          # finite metrics
