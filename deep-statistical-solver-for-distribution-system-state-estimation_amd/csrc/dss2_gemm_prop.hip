@@ -83,7 +83,7 @@ constexpr int gemm_waves_per_simd(int nrb, int nmat) {
 template <int NRB, int NMAT, bool HM>   // HM: Horner propagation on the matrix pipe (dense A_hat), else VALU/ELL
 __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop_kernel(const dss2_gemm_prop_args p) {
   constexpr int TM = NRB * 32;
-  constexpr int PF = 8;    // float4 registers per thread for the next tile's X rows (covers 64 x 128 floats / 256 threads)
+  constexpr int PF = 8;    // float4 registers per thread for the batched X staging (64 x 128 floats / 256 threads)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -91,14 +91,13 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   const int nthreads = blockDim.x;
   const int nw = nthreads >> 6;
   const int LDX = p.kpad + 4;
-  int stamp_tile = blockIdx.x; (void)stamp_tile;
+  const int tile = blockIdx.x;
+  int stamp_tile = tile; (void)stamp_tile;
   DSS2_STAMP(0);
   const int dbg = p.relu >> 8;   // diagnostics only (tools/ablate.py): 1 no MFMA, 2 no Horner, 4 no stores, 8 no X staging
   {
-    // De-phase the two workgroups that share a CU.  Speed heuristic only (never correctness): the
-    // dispatcher deals ids 0..255 to the 256 CUs first, so ids 256..511 are the co-residents that would
-    // otherwise run staging / MFMA / epilogue in lock-step with them; delaying those by a fraction of
-    // a tile (stag x ~3.4 us) lets one workgroup's epilogue overlap the other's MFMA phase.
+    // Optional de-phasing of the two workgroups that share a CU (DSS2_STAGGER; off by default: the gain
+    // was box dependent).  Speed heuristic only: ids 256..511 are the co-residents of ids 0..255.
     const int stag = (p.relu >> 16) & 0xff;
     if (stag && (blockIdx.x >> 8) == 1)
       for (int i = 0; i < stag; ++i) __builtin_amdgcn_s_sleep(127);
@@ -116,55 +115,34 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   constexpr int LDA = TM + 4;
   constexpr bool mfma_horner = HM && NMAT > 1;
 
+  const int ts = p.tile_start[tile];
+  const int R = p.tile_start[tile + 1] - ts;
+  DSS2_STAMP(1);
   // with input-side propagation only the first kin columns come from memory
   const int kin = p.prop_in > 0 ? p.kreal / (p.prop_in + 1) : p.kreal;
   const int kq = p.kpad >> 2;
   const bool vec_ok = ((kin & 3) == 0) && ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
-  // register prefetch: the NEXT tile's X rows (and its precomputed ELL slice) are requested right after
-  // the staging barrier of the current tile and land while the MFMA loop runs
-  const bool pf_x = vec_ok && (TM * kq <= PF * nthreads) && !(dbg & 8);
-  const bool pf_e = need_graph && D > 0 && p.ell_tiles != nullptr && (D * TM <= 2 * nthreads);
-  f32x4 px[PF];
-  int2 pe[2];
-  auto issue_prefetch = [&](int tile) {
-    const int ts = p.tile_start[tile];
-    const int R = p.tile_start[tile + 1] - ts;
-    if (pf_x) {
-#pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        const int idx = tid + i * nthreads;
-        const int r = idx / kq, c = (idx - r * kq) << 2;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (idx < TM * kq && r < R && c < kin) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
-        px[i] = v;
-      }
-    }
-    if (pf_e) {
-      const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * nthreads;
-        pe[i] = idx < D * TM ? src[idx] : make_int2(0, 0);
-      }
-    }
-  };
 
-  if ((int)blockIdx.x < p.ntiles) issue_prefetch(blockIdx.x);
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-  const int ts = p.tile_start[tile];
-  const int R = p.tile_start[tile + 1] - ts;
-  stamp_tile = tile;
-  DSS2_STAMP(1);
-
-  // ---- stage the X tile (zero padded to TM x kpad)
-  if (pf_x) {
+  // ---- stage the X tile (zero padded to TM x kpad).  All of a thread's 16-byte loads are issued
+  //      before the first LDS write (one exposed memory latency instead of one per load: the rolled
+  //      load->wait->write loop cost 13-20 K cycles per tile under load, measured with stamps)
+  if (dbg & 8) {
+  } else if (vec_ok && TM * kq <= PF * nthreads) {
+    f32x4 px[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int idx = tid + i * nthreads;
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < TM * kq && r < R && c < kin) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
+      px[i] = v;
+    }
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int idx = tid + i * nthreads;
       const int r = idx / kq, c = (idx - r * kq) << 2;
       if (idx < TM * kq) *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = px[i];
     }
-  } else if (dbg & 8) {
   } else if (vec_ok) {
     for (int idx = tid; idx < TM * kq; idx += nthreads) {
       const int r = idx / kq;
@@ -182,15 +160,9 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       Xs[r * LDX + c] = v;
     }
   }
-  // ---- stage the tile's graph slice
+  // ---- stage the tile's graph slice (precomputed per-tile ELL: one coalesced copy)
   if (need_graph) {
-    if (pf_e) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * nthreads;
-        if (idx < D * TM) ell[idx] = pe[i];
-      }
-    } else if (D > 0 && p.ell_tiles != nullptr) {
+    if (D > 0 && p.ell_tiles != nullptr) {
       const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
       for (int idx = tid; idx < D * TM; idx += nthreads) ell[idx] = src[idx];
     } else if (D > 0) {
@@ -292,12 +264,6 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       __builtin_amdgcn_sched_barrier(0);
     }
     if (kk < nkk) mma_ab(a0, b0);   // odd number of k steps
-    // next tile's X rows / ELL slice: requested now, consumed at the top of the next iteration; the
-    // latency hides under the Horner + store phases and the registers are not live during the MFMAs
-    if (cg == wave) {
-      const int next = tile + gridDim.x;
-      if (next < p.ntiles) issue_prefetch(next);
-    }
 
     DSS2_STAMP(3);
     // ---- Horner propagation: T = G_{NMAT-1}; T = G_m + P T
@@ -465,9 +431,6 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
     }
     DSS2_STAMP(5);
   }
-  DSS2_STAMP(6);
-  __syncthreads();   // every wave is done with Xs / the graph slice before the next tile is staged
-  }  // persistent tile loop
 }
 
 #ifdef DSS2_STAMPS
@@ -985,9 +948,7 @@ static int launch(const dss2_gemm_prop_args& a_in, hipStream_t stream) {
   const int nw = gemm_waves(a.ncg, NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.max_nnz, a.ell_width);
   // persistent over tiles: at most two workgroups per CU are co-resident at the LDS sizes of the
   // compute-heavy shapes, so 512 workgroups cover the chip; each walks tiles blockIdx.x, +grid, ...
-  static const int pgrid = [] { const char* e = getenv("DSS2_GEMM_GRID"); return e ? atoi(e) : 0; }();
-  const int grid = (pgrid > 0 && a.ntiles > pgrid) ? pgrid : a.ntiles;   // DSS2_GEMM_GRID=512: persistent variant
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * nw), lds, stream, a);
   return check_launch("gemm_prop");
 }
 
