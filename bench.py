@@ -40,11 +40,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="graphs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-wgrad", action="store_true",
+                    help="run the weight-gradient chain on a side stream beside the data-gradient chain (+3 %% at C2; "
+                         "per-kernel durations then include the overlap)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
     pkg = importlib.import_module(PKG)
     pkg._lib.lib()  # fail loudly without the HIP extension
+    pkg.networks.WGRAD_SIDE_STREAM = bool(args.overlap_wgrad)
     import torch.distributed as dist
     env = pkg.parallel.init_from_env("nccl")
     rank, world, local = env["rank"], env["world"], env["local"]
@@ -123,26 +127,34 @@ def main():
                 e1.record()
                 events.append((e0, e1))
 
-        # the weight-gradient chain normally runs on a side stream beside these launches; for the kernel's
-        # own roofline it is timed alone on the GPU (single stream) in this instrumented pass
-        side = pkg.networks.WGRAD_SIDE_STREAM
-        pkg.networks.WGRAD_SIDE_STREAM = False
-        pkg.networks.gemm_prop = timed_gemm_prop
-        for _ in range(min(args.steps, 20)):
-            step()
-        torch.cuda.synchronize()
-        pkg.networks.gemm_prop = orig
-        pkg.networks.WGRAD_SIDE_STREAM = side
-        durs = sorted(a.elapsed_time(b) for a, b in events)
-        avg_ms = sum(durs) / len(durs)
+        def timed_pass(n_steps):
+            events.clear()
+            pkg.networks.gemm_prop = timed_gemm_prop
+            for _ in range(n_steps):
+                step()
+            torch.cuda.synchronize()
+            pkg.networks.gemm_prop = orig
+            durs = sorted(a.elapsed_time(b) for a, b in events)
+            return sum(durs) / len(durs), durs[len(durs) // 2], len(durs)
+
         flops = 2.0 * N * HID * (KHOPS + 1) * HID + 2.0 * KHOPS * E2 * HID
-        achieved = flops / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC runs (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                traffic = json.load(fh)["gemm_prop_kernel<2,3,false>"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+        # in situ, exactly as the timed region runs (single stream unless --overlap-wgrad): the average
+        # agrees with `rocprofv3 --kernel-trace --stats` of this same command (profiles/)
+        avg_ms, med_ms, n_l = timed_pass(min(args.steps, 20))
         result["roofline"] = {
             "kernel": "dss2::gemm_prop_kernel<2,3,false> (TAGConv H->H forward and data-gradient launches)",
-            "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-            "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": None,
-            "launches_timed": len(durs), "avg_launch_us": avg_ms * 1e3, "median_launch_us": durs[len(durs) // 2] * 1e3,
+            "bound": "mfma", "achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": flops / (avg_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "traffic": traffic,
+            "launches_timed": n_l, "avg_launch_us": avg_ms * 1e3, "median_launch_us": med_ms * 1e3,
             "algorithmic_flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": 2.0 * 4 * N * HID + 4.0 * (KHOPS + 1) * HID * HID,
+            "mode": "side-stream overlap on" if pkg.networks.WGRAD_SIDE_STREAM else "single stream",
         }
         # ---- standalone scatter-add (K6) against the HBM roofline (north_star asks for it separately)
         topo = pkg.topology.get_topology(ei, N)

@@ -303,7 +303,7 @@ import os as _os
 
 _SIDE_STREAMS = {}
 EDGE_TILE_KERNELS = _os.environ.get("DSS2_EDGE_TILE", "1") == "1"       # 0 = row-per-wave CSR kernels
-WGRAD_SIDE_STREAM = _os.environ.get("DSS2_WGRAD_STREAM", "1") == "1"   # +3 % at C2; 0 = single stream
+WGRAD_SIDE_STREAM = _os.environ.get("DSS2_WGRAD_STREAM", "0") == "1"   # opt-in: +3 % at C2 (kernels then overlap)
 
 
 def _side_stream(device):
