@@ -33,7 +33,8 @@ class GemmPropArgs(C.Structure):
                 ("tile_start", C.c_void_p),
                 ("rowptr", C.c_void_p), ("col", C.c_void_p), ("w", C.c_void_p),
                 ("max_nnz", C.c_int32), ("ell_width", C.c_int32),
-                ("prop_in", C.c_int32), ("narrow_h", C.c_int32), ("ell_tiles", C.c_void_p)]
+                ("prop_in", C.c_int32), ("narrow_h", C.c_int32),
+                ("prebias", C.c_void_p), ("pre_rowscale", C.c_void_p), ("ell_tiles", C.c_void_p)]
 
 
 class WgradArgs(C.Structure):
@@ -44,8 +45,16 @@ class WgradArgs(C.Structure):
                 ("ntiles", C.c_int32),
                 ("tile_start", C.c_void_p),
                 ("rowptrT", C.c_void_p), ("colT", C.c_void_p), ("wT", C.c_void_p),
-                ("max_nnz", C.c_int32), ("ell_width", C.c_int32), ("ell_tiles", C.c_void_p), ("narrow", C.c_int32),
-                ("pad_", C.c_int32)]
+                ("max_nnz", C.c_int32), ("ell_width", C.c_int32), ("ell_tiles", C.c_void_p), ("rowscale2", C.c_void_p),
+                ("narrow", C.c_int32), ("pad_", C.c_int32)]
+
+
+class SgemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p * 4), ("B", C.c_void_p * 4), ("C", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p),
+                ("c_off", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32),
+                ("ldc", C.c_int32), ("transA", C.c_int32), ("transB", C.c_int32), ("nbatch", C.c_int32),
+                ("accumulate", C.c_int32)]
 
 
 class WlsArgs(C.Structure):
@@ -93,6 +102,7 @@ _SIGNATURES = {
     "dss2_get_pflow": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
+    "dss2_small_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dss2_adamax_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_int, C.c_void_p]),
     "dss2_gemm_prop_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -219,7 +219,6 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       for (int m = 0; m < NMAT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rb][m][r] = 0.f;
-
     // epilogue constants requested now so that their latency hides under the MFMA loop
     const int ecol0 = cg * 32 + (lane & 7) * 4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -362,6 +361,15 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
     DSS2_STAMP(4);
     // ---- epilogue: T -> wave-private LDS stage -> rolled, row-coalesced store loop (keeps the
     //      address arithmetic of the five optional operands out of the unrolled register code)
+    // row-scaled pre-bias (a Linear folded into this layer): sum_m P^m (s (x) pb_m) = sum_m (P^m s) (x) pb_m,
+    // a rank-NMAT term of the output; pre_rowscale holds the rows [s, P s, P^2 s, P^3 s]
+    f32x4 pb4[NMAT];
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m) pb4[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.prebias && ecol0 < p.hout && (p.hout & 3) == 0) {
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) pb4[m] = *reinterpret_cast<const f32x4*>(p.prebias + (size_t)m * p.hout + ecol0);
+    }
     wave_lds_sync();
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb)
@@ -380,7 +388,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       if (col0 < p.hout) {
         // rows r8, r8+8, ...: operands of 2 rows are requested together, then finished and stored
         for (int row0 = r8; row0 < R; row0 += 16) {
-          f32x4 y[2], rs[2], dm[2], ad[2];
+          f32x4 y[2], rs[2], dm[2], ad[2], ps[2];
           float rsc[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
@@ -389,6 +397,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
             const size_t grow = (size_t)(ts + (ok ? row : 0));
             y[u] = *reinterpret_cast<const f32x4*>(st + (ok ? row : 0) * 32 + cq);
             if (p.rowscale) rsc[u] = p.rowscale[grow];
+            if (p.prebias) ps[u] = *reinterpret_cast<const f32x4*>(p.pre_rowscale + grow * 4);
             if (p.dmask) dm[u] = *reinterpret_cast<const f32x4*>(p.dmask + grow * p.ld_dmask + col0);
             if (p.relu_src) rs[u] = *reinterpret_cast<const f32x4*>(p.relu_src + grow * p.ld_relu + col0);
             if (p.add_src) ad[u] = *reinterpret_cast<const f32x4*>(p.add_src + grow * p.ld_add + col0);
@@ -399,6 +408,10 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
             if (row >= R) continue;
             f32x4 v = y[u];
             if (p.bias) v += p.rowscale ? bias4 * rsc[u] : bias4;
+            if (p.prebias) {
+#pragma unroll
+              for (int m = 0; m < NMAT; ++m) v += pb4[m] * ps[u][m];
+            }
             if (p.dmask) v *= dm[u];
             if (p.relu & 1) {
 #pragma unroll
@@ -421,6 +434,10 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
           const size_t grow = (size_t)(ts + row);
           float y = st[row * 32 + c32];
           if (p.bias) y += p.rowscale ? bias * p.rowscale[grow] : bias;
+          if (p.prebias) {
+#pragma unroll
+            for (int m = 0; m < NMAT; ++m) y = fmaf(p.prebias[(size_t)m * p.hout + colg], p.pre_rowscale[grow * 4 + m], y);
+          }
           if (p.dmask) y *= p.dmask[grow * p.ld_dmask + colg];
           if (p.relu & 1) y = fmaxf(y, 0.f);
           if (p.relu_src) y = (p.relu_src[grow * p.ld_relu + colg] > 0.f) ? y : 0.f;
@@ -896,7 +913,7 @@ static int launch2(const dss2_gemm_prop_args& a, hipStream_t stream) {
 
 static bool use_v2(const dss2_gemm_prop_args& a) {
   static const int enabled = [] { const char* e = getenv("DSS2_GEMM_V2"); return e ? atoi(e) : 0; }();
-  if (!enabled || a.prop_in > 0 || a.narrow_h > 0 || a.ncg > 4 || a.nrb > 2 || a.ntiles < 2) return false;
+  if (!enabled || a.prop_in > 0 || a.narrow_h > 0 || a.ncg > 4 || a.nrb > 2 || a.ntiles < 2 || a.prebias) return false;
   if (a.nmat > 1 && (a.ell_width <= 0 || a.ell_tiles == nullptr)) return false;
   if (a.nmat > 3) return false;
   return lds2_bytes(a.nrb, a.kpad, a.nmat > 1 ? a.ell_width : 0) <= (size_t)kMaxLdsBytes;
@@ -973,6 +990,7 @@ extern "C" int dss2_gemm_prop(const dss2_gemm_prop_args* ap, void* stream) {
   if (a.ncg * 32 < a.hout || a.ncg <= 0) { set_error("gemm_prop: ncg %d too small for hout %d", a.ncg, a.hout); return 2; }
   if ((a.nmat > 1 || a.prop_in > 0) && (!a.rowptr || !a.col || !a.w)) { set_error("gemm_prop: propagation needs a CSR"); return 2; }
   if (a.prop_in > 0 && (a.nmat != 1 || a.kreal % (a.prop_in + 1) != 0)) { set_error("gemm_prop: prop_in needs nmat == 1 and kreal divisible by prop_in+1"); return 2; }
+  if (a.prebias && (!a.pre_rowscale || a.narrow_h > 0 || a.prop_in > 0)) { set_error("gemm_prop: prebias needs pre_rowscale and the general kernel"); return 2; }
   if (a.narrow_h > 0) {
     if (a.nmat * a.narrow_h > 32 || a.hout != a.narrow_h || a.prop_in) { set_error("gemm_prop: narrow mode needs nmat*narrow_h <= 32 and hout == narrow_h"); return 2; }
     if (narrow_lds_bytes(a.nrb, a.nmat, a.kpad, a.max_nnz, a.ell_width) > (size_t)kMaxLdsBytes) { set_error("gemm_prop(narrow): tile does not fit LDS"); return 3; }

@@ -22,7 +22,110 @@ __global__ void __launch_bounds__(256) adamax_kernel(const dss2_adamax_desc* __r
   }
 }
 
+// Batched small dense products in weight space (a few 128^3 products per step; one launch).
+// One 32 x 32 tile of C per workgroup.  The operands are tiny (<= a few hundred KB, L2-resident) and the
+// kernel is latency-bound: a whole K-chunk of 128 is requested at once (32 loads in flight per thread),
+// the next chunk's loads are issued before the current chunk is multiplied out of LDS.
+constexpr int SG_T = 32, SG_KC = 128, SG_LDA = SG_KC + 4;
+template <bool tA, bool tB>
+__device__ __forceinline__ void small_gemm_body(const dss2_sgemm_desc* __restrict__ dp, float* base_out,
+                                                float (&As)[SG_T][SG_LDA], float (&Bs)[SG_KC][SG_T + 1]) {
+  // every field once, into scalars (the descriptor itself stays in global memory)
+  const int M = dp->M, N = dp->N, K = dp->K, lda = dp->lda, ldb = dp->ldb, ldc = dp->ldc;
+  const bool accum = dp->accumulate != 0;
+  const int nbatch = dp->nbatch;
+  const float* u = dp->u;
+  const float* v = dp->v;
+  float* C = dp->c_off >= 0 ? base_out + dp->c_off : dp->C;
+  const int tn = (N + SG_T - 1) / SG_T, tm = (M + SG_T - 1) / SG_T;
+  if ((int)blockIdx.x >= tm * tn) return;
+  const int i0 = ((int)blockIdx.x / tn) * SG_T, j0 = ((int)blockIdx.x % tn) * SG_T;
+  const int t = threadIdx.x, lo = t & 31, hi = t >> 5;   // lo runs along the contiguous memory direction
+  const int kchunks = (K + SG_KC - 1) / SG_KC;
+  const int nchunks = nbatch * kchunks;
+  float ra[16], rb[16];
+  // unconditional loads from clamped addresses (one batch of 32 in flight), masked afterwards
+  auto issue = [&](int c) {
+    const int bidx = c / kchunks, k0 = (c - bidx * kchunks) * SG_KC;
+    const float* A = dp->A[bidx];   // uniform scalar loads from the descriptor
+    const float* B = dp->B[bidx];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      // A(i,k): row-major [M,K] (k contiguous) or, transposed, stored [K,M] (i contiguous)
+      const int i = tA ? lo : hi + 8 * (q >> 2), k = tA ? hi + 8 * q : lo + 32 * (q & 3);
+      const int gi = min(i0 + i, M - 1), gk = min(k0 + k, K - 1);
+      const float av = tA ? A[(size_t)gk * lda + gi] : A[(size_t)gi * lda + gk];
+      ra[q] = av * (((i0 + i) < M && (k0 + k) < K) ? 1.f : 0.f);   // (a select would let the compiler branch around the load)
+      // B(k,j): row-major [K,N] (j contiguous) or, transposed, stored [N,K] (k contiguous)
+      const int kb = tB ? lo + 32 * (q & 3) : hi + 8 * q, j = tB ? hi + 8 * (q >> 2) : lo;
+      const int gj = min(j0 + j, N - 1), gkb = min(k0 + kb, K - 1);
+      const float bv = tB ? B[(size_t)gj * ldb + gkb] : B[(size_t)gkb * ldb + gj];
+      rb[q] = bv * (((j0 + j) < N && (k0 + kb) < K) ? 1.f : 0.f);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      if (tA) As[lo][hi + 8 * q] = ra[q]; else As[hi + 8 * (q >> 2)][lo + 32 * (q & 3)] = ra[q];
+      if (tB) Bs[lo + 32 * (q & 3)][hi + 8 * (q >> 2)] = rb[q]; else Bs[hi + 8 * q][lo] = rb[q];
+    }
+  };
+  float s[4] = {0.f, 0.f, 0.f, 0.f};   // rows hi + 8 q, column lo
+  if (nchunks > 0) issue(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();
+    stage();
+    __syncthreads();
+    if (c + 1 < nchunks) issue(c + 1);
+    for (int k = 0; k < SG_KC; k += 8) {
+      float bv[8];
+      f32x4 av[4][2];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) bv[kk] = Bs[k + kk][lo];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        av[q][0] = *reinterpret_cast<const f32x4*>(&As[hi + 8 * q][k]);
+        av[q][1] = *reinterpret_cast<const f32x4*>(&As[hi + 8 * q][k + 4]);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = fmaf(av[q][kk >> 2][kk & 3], bv[kk], s[q]);
+    }
+  }
+  const int j = j0 + lo;
+  if (j < N) {
+    const float vj = u ? v[j] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + hi + 8 * q;
+      if (i >= M) continue;
+      float r = s[q];
+      if (u) r = fmaf(u[i], vj, r);
+      float* cp = C + (size_t)i * ldc + j;
+      *cp = accum ? *cp + r : r;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) small_gemm_kernel(const dss2_sgemm_desc* __restrict__ descs, float* base_out) {
+  __shared__ __attribute__((aligned(16))) float As[SG_T][SG_LDA];   // As[i][k]
+  __shared__ float Bs[SG_KC][SG_T + 1];                             // Bs[k][j]
+  const dss2_sgemm_desc* dp = descs + blockIdx.y;
+  const bool ta = dp->transA != 0, tb = dp->transB != 0;
+  if (ta) { if (tb) small_gemm_body<true, true>(dp, base_out, As, Bs); else small_gemm_body<true, false>(dp, base_out, As, Bs); }
+  else    { if (tb) small_gemm_body<false, true>(dp, base_out, As, Bs); else small_gemm_body<false, false>(dp, base_out, As, Bs); }
+}
+
 }  // namespace dss2
+
+extern "C" int dss2_small_gemm(const dss2_sgemm_desc* descs, int n_desc, int max_tiles, float* base_out, void* stream) {
+  if (n_desc <= 0) return 0;
+  if (max_tiles <= 0) { dss2::set_error("small_gemm: max_tiles must be positive"); return 2; }
+  hipLaunchKernelGGL(dss2::small_gemm_kernel, dim3(max_tiles, n_desc), dim3(256), 0, dss2::as_stream(stream),
+                     descs, base_out);
+  return dss2::check_launch("small_gemm");
+}
 
 extern "C" int dss2_adamax_step(const dss2_adamax_desc* descs, int n_desc, int64_t max_n, float lr, float beta1,
                                 float beta2, float eps, float weight_decay, int step, void* stream) {

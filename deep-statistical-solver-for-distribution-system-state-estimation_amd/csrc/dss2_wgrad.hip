@@ -37,8 +37,9 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   float* Zb = Za + TM * LDZ;
   float* Xs = Zb + (NMAT > 1 ? TM * LDZ : 0);
   const int D = p.ell_width;   // > 0: ELL [D][TM] slice of the transposed graph, else CSR slice
-  int2* ell = reinterpret_cast<int2*>(Xs + TM * XW);
-  int* lrow = reinterpret_cast<int*>(Xs + TM * XW);
+  f32x4* Dsc = reinterpret_cast<f32x4*>(Xs + TM * XW);   // [TM] row scales of the tile (rowscale2)
+  int2* ell = reinterpret_cast<int2*>(Xs + TM * XW + TM * 4);
+  int* lrow = reinterpret_cast<int*>(Xs + TM * XW + TM * 4);
   int2* lent = reinterpret_cast<int2*>(lrow + TM + 2);
 
   const int tid = threadIdx.x;
@@ -59,6 +60,9 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][ob][r] = 0.f;
   float dbacc = 0.f;
+  float dbs[NMAT];   // scaled column sums per matrix (rowscale2), same threads as dbacc
+#pragma unroll
+  for (int m = 0; m < NMAT; ++m) dbs[m] = 0.f;
 
   const bool gvec = ((p.ldg & 3) == 0) && ((p.hout & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.G) & 15) == 0);
   const bool xvec = ((p.ldx & 3) == 0) && ((p.hin & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
@@ -134,7 +138,20 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     const int t = tid - (NT - LDZ);
     if (ibg != 0 || t < 0) return;
     float s = 0.f;
-    if (p.rowscale) {
+    if (p.rowscale2) {   // plain sums + one scaled sum per matrix, scales [s, P s, P^2 s, P^3 s] per row
+      float sm[NMAT];
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) sm[m] = 0.f;
+      for (int r = 0; r < R; ++r) {
+        const float z = Za[r * LDZ + t];
+        const f32x4 d = Dsc[r];
+        s += z;
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) sm[m] = fmaf(z, d[m], sm[m]);
+      }
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) dbs[m] += sm[m];
+    } else if (p.rowscale) {
       for (int r = 0; r < R; ++r) s = fmaf(Za[r * LDZ + t], p.rowscale[ts + r], s);
     } else {
       for (int r = 0; r < R; ++r) s += Za[r * LDZ + t];
@@ -220,6 +237,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     const int R = p.tile_start[tile + 1] - ts;
     // ---- stage G slab, X slab and the transposed-graph slice
     write_slabs(ts, R);
+    if (p.rowscale2 && tid < R) Dsc[tid] = reinterpret_cast<const f32x4*>(p.rowscale2)[ts + tid];
     if (NMAT > 1 || p.narrow) {
       if (D > 0 && p.ell_tiles != nullptr) {
         const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
@@ -286,7 +304,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   }
 
   // ---- one slab per workgroup column blockIdx.x; the y-slices tile the [nmat*hout, hin] matrix
-  const size_t stride = (size_t)p.nmat * p.hout * p.hin + p.hout;
+  const size_t stride = (size_t)p.nmat * p.hout * p.hin + p.hout + (p.rowscale2 ? (size_t)p.nmat * p.hout : 0);
   float* out = p.slab + (size_t)blockIdx.x * stride;
   if (wave_active) {
     const int i = xcol0 + ibw * 32 + c32;
@@ -305,14 +323,20 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   }
   {
     const int t = tid - (NT - LDZ);
-    if (ibg == 0 && t >= 0 && gcol0 + t < p.hout) out[(size_t)p.nmat * p.hout * p.hin + gcol0 + t] = dbacc;
+    if (ibg == 0 && t >= 0 && gcol0 + t < p.hout) {
+      out[(size_t)p.nmat * p.hout * p.hin + gcol0 + t] = dbacc;
+      if (p.rowscale2) {
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) out[(size_t)p.nmat * p.hout * p.hin + p.hout + (size_t)m * p.hout + gcol0 + t] = dbs[m];
+      }
+    }
   }
 }
 
 // nmat here = number of MFMA matrix passes (1 in narrow mode); graph = a graph slice is staged
 static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz, int ell_width, bool graph) {
   const size_t TM = (size_t)nrb * 32;
-  size_t b = TM * (size_t)nb * 32 * 4 * (nmat > 1 ? 2 : 1) + TM * XW * 4;
+  size_t b = TM * (size_t)nb * 32 * 4 * (nmat > 1 ? 2 : 1) + TM * XW * 4 + TM * 16;
   if (graph) b += ell_width > 0 ? TM * (size_t)ell_width * 8 : (TM + 2) * 4 + (size_t)max_nnz * 8;
   return b;
 }
@@ -360,6 +384,7 @@ extern "C" int dss2_wgrad(const dss2_wgrad_args* ap, void* stream) {
   if (a.n_split <= 0 || !a.slab) { set_error("wgrad: n_split/slab missing"); return 2; }
   if (a.nmat > 1 && (!a.rowptrT || !a.colT || !a.wT)) { set_error("wgrad: nmat > 1 needs the transposed CSR"); return 2; }
   if (a.ell_width < 0 || a.ell_width > 32) { set_error("wgrad: ell_width %d out of range 0..32", a.ell_width); return 2; }
+  if (a.rowscale2 && a.narrow) { set_error("wgrad: rowscale2 is not supported in narrow mode"); return 2; }
   if (a.narrow) {
     if (a.nmat * a.hout > 32) { set_error("wgrad: narrow mode needs nmat*hout <= 32"); return 2; }
     hipStream_t sn = as_stream(stream);

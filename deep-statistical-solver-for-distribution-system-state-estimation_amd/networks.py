@@ -20,6 +20,7 @@ dropout; no activation after the last conv; SkipMPN's residual.
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -73,8 +74,10 @@ def _ncg(j: int) -> int:
 # ------------------------------------------------------------------------------------------
 def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.Tensor, nmat: int, hout: int,
               Y: torch.Tensor, bias=None, rowscale=None, relu_src=None, dmask=None, add_src=None, add_ld=0,
-              relu: bool = False, transposed: bool = False, prop_in: int = 0, narrow_h: int = 0) -> None:
+              relu: bool = False, transposed: bool = False, prop_in: int = 0, narrow_h: int = 0,
+              prebias=None, pre_rowscale=None) -> None:
     a = _lib.GemmPropArgs()
+    a.prebias, a.pre_rowscale = _ptr(prebias), _ptr(pre_rowscale)
     a.prop_in, a.narrow_h = prop_in, narrow_h
     a.X, a.ldx, a.kreal, a.kpad = X.data_ptr(), ldx, kreal, _round8(kreal)
     a.Bp, a.bias, a.rowscale = Bp.data_ptr(), _ptr(bias), _ptr(rowscale)
@@ -94,18 +97,19 @@ def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.T
 
 
 def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int, nmat: int, out_flat: torch.Tensor,
-          rowscale=None) -> None:
-    """out_flat[nmat*hout*hin + hout] <- [dW_0 .. dW_{nmat-1}, db] (deterministic two-pass sum)."""
-    narrow = nmat > 1 and nmat * hout <= 32
+          rowscale=None, rowscale2=None) -> None:
+    """out_flat[nmat*hout*hin + hout] <- [dW_0 .. dW_{nmat-1}, db] (deterministic two-pass sum); with
+    rowscale2 additionally [nmat*hout] scaled column sums of P^m G (one block per matrix)."""
+    narrow = nmat > 1 and nmat * hout <= 32 and rowscale2 is None
     lds = _lib.lib().dss2_wgrad_lds_bytes(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT)
     per_cu = max(1, min(4, (160 * 1024) // max(int(lds), 1)))     # resident workgroups per CU by LDS
     n_split = min(topo.ntiles, 256 * per_cu)
-    stride = nmat * hout * hin + hout
+    stride = nmat * hout * hin + hout + (nmat * hout if rowscale2 is not None else 0)
     slab = torch.empty(n_split * stride, dtype=_F32, device=G.device)
     a = _lib.WgradArgs()
     a.G, a.ldg, a.hout = G.data_ptr(), G.stride(0), hout
     a.X, a.ldx, a.hin = X.data_ptr(), X.stride(0), hin
-    a.rowscale = _ptr(rowscale)
+    a.rowscale, a.rowscale2 = _ptr(rowscale), _ptr(rowscale2)
     a.slab, a.n_split, a.nmat, a.nrb, a.ntiles = slab.data_ptr(), n_split, nmat, topo.nrb, topo.ntiles
     a.tile_start = topo.tile_start.data_ptr()
     a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
@@ -132,6 +136,92 @@ def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, ent: torch.Tensor, n_ro
 # ------------------------------------------------------------------------------------------
 _DESC_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("ld", "<i4"),
                         ("transpose", "<i4"), ("koff", "<i4"), ("kpad", "<i4"), ("ncg", "<i4"), ("joff", "<i4")])
+
+
+_SG_DTYPE = np.dtype([("A", "<u8", (4,)), ("B", "<u8", (4,)), ("C", "<u8"), ("u", "<u8"), ("v", "<u8"), ("c_off", "<i8"),
+                      ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"),
+                      ("transA", "<i4"), ("transB", "<i4"), ("nbatch", "<i4"), ("accumulate", "<i4")])
+
+
+def _sg(A, B, M, N, K, lda, ldb, ldc, C=0, c_off=-1, tA=0, tB=0, u=0, v=0):
+    A = list(A) + [0] * (4 - len(A))
+    B = list(B) + [0] * (4 - len(B))
+    nb = sum(1 for a in A if a)
+    return (A, B, C, u, v, c_off, M, N, K, lda, ldb, ldc, tA, tB, nb, 0)
+
+
+class _FoldPlan:
+    """The edge MLP's second Linear folded into the first TAGConv (same mathematics):
+        conv0(S W2^T + deg b2^T) = sum_m A^m (S (W_m W2)^T) + sum_m (A^m deg) (W_m b2)^T + bias
+    so conv 0 runs directly on the aggregated hidden S with folded weights Wf_m = W_m W2 and a
+    rank-(K+1) bias term bf_m = W_m b2 scaled by the topology constants A^m deg in the epilogue: the
+    H x H GEMM of the Linear, its data-gradient and its weight-gradient (3 launches + a slab reduction
+    per step) disappear.  Chain rule back, in
+    weight space (one batched small-GEMM launch):
+        dW_m = dWf_m W2^T + dbf_m (x) b2 ;  dW2 = sum_m W_m^T dWf_m ;  db2 = sum_m W_m^T dbf_m."""
+
+    def __init__(self, W2, b2, ws, device, off_w2: int, off_conv0: int):
+        nm, (ho, hid) = len(ws), ws[0].shape
+        self.nm, self.ho, self.hid, self.device = nm, ho, hid, device
+        self.Wf = torch.zeros(nm, ho, hid, dtype=_F32, device=device)
+        self.bf = torch.zeros(nm, ho, dtype=_F32, device=device)
+        # wgrad of the folded conv writes here: [nm*ho*hid dWf][ho db][nm*ho dbf]
+        self.gfold = torch.zeros(nm * ho * hid + ho + nm * ho, dtype=_F32, device=device)
+        self.one = torch.ones(1, dtype=_F32, device=device)
+        self.params = (W2, b2, list(ws))
+        self.off_w2, self.off_conv0 = off_w2, off_conv0
+        self.ptrs = None
+
+    def _tables(self):
+        W2, b2, ws = self.params
+        nm, ho, hid = self.nm, self.ho, self.hid
+        f4 = 4
+        fwd, bwd = [], []
+        for m, w in enumerate(ws):
+            fwd.append(_sg([w.data_ptr()], [W2.data_ptr()], ho, hid, hid, hid, hid, hid, C=self.Wf[m].data_ptr()))
+            fwd.append(_sg([w.data_ptr()], [b2.data_ptr()], ho, 1, hid, hid, 1, 1, C=self.bf[m].data_ptr()))
+        g = self.gfold.data_ptr()
+        dWf = [g + f4 * m * ho * hid for m in range(nm)]
+        db = g + f4 * nm * ho * hid
+        dbf = [db + f4 * ho + f4 * m * ho for m in range(nm)]
+        for m, w in enumerate(ws):   # dW_m = dWf_m W2^T + dbf_m (x) b2
+            bwd.append(_sg([dWf[m]], [W2.data_ptr()], ho, hid, hid, hid, hid, hid, c_off=self.off_conv0 + m * ho * hid,
+                           tB=1, u=dbf[m], v=b2.data_ptr()))
+        # conv0.bias gradient: plain copy of the unscaled column sums (K = 0, rank-1 term with v = 1)
+        bwd.append(_sg([], [], ho, 1, 0, 1, 1, 1, c_off=self.off_conv0 + nm * ho * hid, u=db, v=self.one.data_ptr()))
+        # dW2 = sum_m W_m^T dWf_m ; db2 = sum_m W_m^T dbf_m
+        bwd.append(_sg([w.data_ptr() for w in ws], dWf, hid, hid, ho, hid, hid, hid, c_off=self.off_w2, tA=1))
+        bwd.append(_sg([w.data_ptr() for w in ws], dbf, hid, 1, ho, hid, 1, 1, c_off=self.off_w2 + hid * hid, tA=1))
+
+        def tab(recs):
+            arr = np.zeros(len(recs), dtype=_SG_DTYPE)
+            for i, r in enumerate(recs):
+                arr[i] = tuple(r)
+            return (torch.from_numpy(arr.view(np.uint8).copy()).to(self.device), len(recs),
+                    max(((r[6] + 31) // 32) * ((r[7] + 31) // 32) for r in recs))
+        self.fwd_tab, self.bwd_tab = tab(fwd), tab(bwd)
+
+    def _check(self):
+        W2, b2, ws = self.params
+        ptrs = (W2.data_ptr(), b2.data_ptr()) + tuple(w.data_ptr() for w in ws)
+        if ptrs != self.ptrs:
+            self._tables()
+            self.ptrs = ptrs
+
+    def refresh_forward(self):
+        self._check()
+        t, n, mx = self.fwd_tab
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().dss2_small_gemm(t.data_ptr(), n, mx, None, st), "dss2_small_gemm")
+
+    def backward(self, flat: torch.Tensor):
+        self._check()
+        t, n, mx = self.bwd_tab
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().dss2_small_gemm(t.data_ptr(), n, mx, flat.data_ptr(), st), "dss2_small_gemm")
+
+
+FOLD_W2 = _os.environ.get("DSS2_FOLD_W2", "1") == "1"   # 0 = run the edge MLP's second Linear as its own GEMMs
 
 
 def is_narrow(nmat: int, hout: int) -> bool:
@@ -220,7 +310,7 @@ class _PackPlan:
 # ------------------------------------------------------------------------------------------
 # functional pieces (raw tensors in, raw tensors out); used by the autograd Functions below
 # ------------------------------------------------------------------------------------------
-def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hout, fn, fe):
+def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hout, fn, fe, second_linear=True):
     N = topo.N
     S = torch.empty(N, hid, dtype=_F32, device=W1.device)
     if topo.ell_ent_tiles is not None and EDGE_TILE_KERNELS:
@@ -232,6 +322,8 @@ def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hou
         _lib.check(_lib.lib().dss2_edge_hidden_fwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(),
                                                    topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(),
                                                    S.data_ptr(), N, hid, fn, fe, _stream(S)), "dss2_edge_hidden_fwd")
+    if not second_linear:   # folded into the consumer (see _FoldPlan)
+        return S, None
     x0 = torch.empty(N, hout, dtype=_F32, device=W1.device)
     # second Linear of the edge MLP after the (linear) aggregation: sum_e (W2 h_e + b2) = W2 S + deg b2
     gemm_prop(topo, S, hid, hid, pack_w2_fwd, 1, hout, x0, bias=b2, rowscale=topo.deg)
@@ -239,14 +331,17 @@ def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hou
 
 
 def _edge_aggr_backward(topo, gx0, x, ldx, ea, ldea, W1, b1, S, pack_w2_bwd, hid, hout, fn, fe, g_w1, g_w2, need_dx,
-                        pack_dx=None):
+                        pack_dx=None, dS=None):
     """g_w1: flat [hid*(2fn+fe) + hid] <- dW1, db1;  g_w2: flat [hout*hid + hout] <- dW2, db2.
+    With ``dS`` given (second Linear folded into the consumer) gx0 / g_w2 are not used.
     Returns dx [N, fn] or None."""
     N = topo.N
-    dev = gx0.device
-    wgrad(topo, gx0, hout, S, hid, 1, g_w2, rowscale=topo.deg)
-    dS = torch.empty(N, hid, dtype=_F32, device=dev)
-    gemm_prop(topo, gx0, gx0.stride(0), hout, pack_w2_bwd, 1, hid, dS)
+    if dS is None:
+        wgrad(topo, gx0, hout, S, hid, 1, g_w2, rowscale=topo.deg)
+        dS = torch.empty(N, hid, dtype=_F32, device=gx0.device)
+        gemm_prop(topo, gx0, gx0.stride(0), hout, pack_w2_bwd, 1, hid, dS)
+    gx0 = dS
+    dev = dS.device
     stride = hid * (2 * fn + fe) + hid
     tiled = topo.ell_ent_tiles is not None and topo.ellT_ent_tiles is not None and EDGE_TILE_KERNELS
     n_slabs = min(topo.ntiles, 512) if tiled else int(min(512, max(1, (N + 15) // 16)))
@@ -292,14 +387,14 @@ def _dx_views(W1, hid, fn, fe):
     return [[_MatView(W1, hid, fn, ld, 0)], [_MatView(W1, hid, fn, ld, fn)]]
 
 
-def _tagconv_forward(topo, h, pack_fwd, bias, nmat, hin, hout, dmask=None, relu=False, add_src=None, add_ld=0):
+def _tagconv_forward(topo, h, pack_fwd, bias, nmat, hin, hout, dmask=None, relu=False, add_src=None, add_ld=0,
+                     prebias=None, pre_rowscale=None):
     out = torch.empty(topo.N, hout, dtype=_F32, device=h.device)
     gemm_prop(topo, h, h.stride(0), hin, pack_fwd, nmat, hout, out, bias=bias, dmask=dmask, relu=relu,
-              add_src=add_src, add_ld=add_ld, narrow_h=(hout if is_narrow(nmat, hout) else 0))
+              add_src=add_src, add_ld=add_ld, narrow_h=(hout if (is_narrow(nmat, hout) and prebias is None) else 0),
+              prebias=prebias, pre_rowscale=pre_rowscale)
     return out
 
-
-import os as _os
 
 _SIDE_STREAMS = {}
 EDGE_TILE_KERNELS = _os.environ.get("DSS2_EDGE_TILE", "1") == "1"       # 0 = row-per-wave CSR kernels
@@ -313,7 +408,8 @@ def _side_stream(device):
     return s
 
 
-def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=None, dmask=None, need_dh=True):
+def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=None, dmask=None, need_dh=True,
+                      rowscale2=None):
     """g: gradient w.r.t. the conv's pre-activation output [N, hout] (already masked).
     g_flat <- [dW_0..dW_K, db]; returns dh (masked by relu_src / dmask of the PREVIOUS layer).
     The weight gradient only feeds the flat gradient buffer, so it may run on a side stream beside the
@@ -328,13 +424,13 @@ def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=No
         h.record_stream(side)
         g_flat.record_stream(side)
         with torch.cuda.stream(side):
-            wgrad(topo, g, hout, h, hin, nmat, g_flat)
+            wgrad(topo, g, hout, h, hin, nmat, g_flat, rowscale2=rowscale2)
     else:
-        wgrad(topo, g, hout, h, hin, nmat, g_flat)
+        wgrad(topo, g, hout, h, hin, nmat, g_flat, rowscale2=rowscale2)
     if not need_dh:
         return None
     dh = torch.empty(topo.N, hin, dtype=_F32, device=g.device)
-    if is_narrow(nmat, hout):   # narrow gradient rows: propagate g on the input side, one stacked GEMM
+    if is_narrow(nmat, hout) and rowscale2 is None:   # narrow gradient rows: propagate g on the input side, one stacked GEMM
         gemm_prop(topo, g, g.stride(0), nmat * hout, pack_bwd, 1, hin, dh, relu_src=relu_src, dmask=dmask,
                   transposed=True, prop_in=nmat - 1)
     else:
@@ -497,6 +593,7 @@ class MPN(nn.Module):
         for l in range(n_gnn_layers):
             self.convs.append(TAGConv(dim_hid, dim_out if l == n_gnn_layers - 1 else dim_hid, K=K))
         self._plan = None
+        self._fold = None
 
     # -- reference helpers kept for API parity (networks.py:236-258); not used by forward()
     def is_directed(self, edge_index):
@@ -517,6 +614,15 @@ class MPN(nn.Module):
             ps.append(c.bias)
             ps.extend(l.weight for l in c.lins)
         return ps
+
+    def _flat_offsets(self) -> np.ndarray:
+        """Element offsets of [W1|b1], [W2|b2], [conv l: W_0..W_K | bias] in the flat gradient buffer."""
+        hid, fn, fe, nmat, L = self.dim_hid, self.dim_featn, self.dim_feate, self.K + 1, self.n_gnn_layers
+        sizes = [hid * (2 * fn + fe) + hid, hid * hid + hid]
+        for l in range(L):
+            hout = self.dim_out if l == L - 1 else hid
+            sizes.append(nmat * hout * hid + hout)
+        return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
 
     def forward(self, x, edge_index, edge_attr):
         _require_gpu(x, edge_index, edge_attr)
@@ -539,13 +645,25 @@ class _MPNFn(torch.autograd.Function):
         L, nmat, hid = mod.n_gnn_layers, mod.K + 1, mod.dim_hid
         W1, b1, W2, b2 = ps[0:4]
         conv_ps = [ps[4 + l * (nmat + 1): 4 + (l + 1) * (nmat + 1)] for l in range(L)]   # (bias, W_0..W_K)
-        if mod._plan is None or mod._plan.device != dev:
-            mod._plan = _PackPlan([[W2]] + [list(cp[1:]) for cp in conv_ps] +
-                                  _dx_views(W1, hid, mod.dim_featn, mod.dim_feate), dev)
-        plan = mod._plan
+        hout0 = mod.dim_out if L == 1 else hid
+        fold_on = FOLD_W2 and not is_narrow(nmat, hout0)
+        if mod._plan is None or mod._plan.device != dev or (mod._fold is not None) != fold_on:
+            offs = mod._flat_offsets()
+            mod._fold = _FoldPlan(W2, b2, conv_ps[0][1:], dev, int(offs[1]), int(offs[2])) if fold_on else None
+            conv_groups = [list(cp[1:]) for cp in conv_ps]
+            if fold_on:   # conv 0 is packed from the folded weights
+                conv_groups[0] = [mod._fold.Wf[m] for m in range(nmat)]
+            mod._plan = _PackPlan([[W2]] + conv_groups + _dx_views(W1, hid, mod.dim_featn, mod.dim_feate), dev)
+        plan, fold = mod._plan, mod._fold
+        if fold is not None:
+            fold.params = (W2, b2, list(conv_ps[0][1:]))
+            fold.refresh_forward()
         ctx.ver = plan.refresh()
         topo.lds_check(nmat, _round8(hid), _ncg(hid))
-        S, h = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, plan.fwd[0], hid, hid, mod.dim_featn, mod.dim_feate)
+        S, h = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, plan.fwd[0], hid, hid, mod.dim_featn, mod.dim_feate,
+                                  second_linear=fold is None)
+        if fold is not None:
+            h = S            # conv 0 consumes the aggregated hidden directly
         acts, masks = [h], []
         p = float(mod.dropout_rate)
         for l in range(L):
@@ -556,17 +674,19 @@ class _MPNFn(torch.autograd.Function):
                 dmask = (torch.rand(topo.N, hout, device=dev) >= p).to(_F32).div_(1.0 - p) if p < 1.0 else \
                     torch.zeros(topo.N, hout, device=dev)
             masks.append(dmask)
+            pre = (fold.bf, topo.deg_pows) if (fold is not None and l == 0) else (None, None)
             h = _tagconv_forward(topo, h, plan.fwd[1 + l], conv_ps[l][0], nmat, hid, hout, dmask=dmask, relu=not last,
-                                 add_src=(x if (last and mod.skip) else None), add_ld=ldx)
+                                 add_src=(x if (last and mod.skip) else None), add_ld=ldx,
+                                 prebias=pre[0], pre_rowscale=pre[1])
             if not last:
                 acts.append(h)
         ctx.save_for_backward(x, ea, S, *acts, *[m for m in masks if m is not None], *ps)
-        ctx.meta = (topo, mod, ldx, ldea, len(acts), [m is not None for m in masks], [p_._version for p_ in ps])
+        ctx.meta = (topo, mod, ldx, ldea, len(acts), [m is not None for m in masks], fold is not None)
         return h
 
     @staticmethod
     def backward(ctx, gout):
-        topo, mod, ldx, ldea, n_acts, has_mask, versions = ctx.meta
+        topo, mod, ldx, ldea, n_acts, has_mask, folded = ctx.meta
         saved = ctx.saved_tensors
         x, ea, S = saved[0:3]
         acts = list(saved[3:3 + n_acts])
@@ -576,30 +696,39 @@ class _MPNFn(torch.autograd.Function):
         masks, it = [], iter(mask_list)
         for hm in has_mask:
             masks.append(next(it) if hm else None)
-        plan = mod._plan
+        plan, fold = mod._plan, mod._fold
+        if folded != (fold is not None):
+            raise RuntimeError("DSS2_FOLD_W2 / the module's plan changed between forward and backward")
         if plan.version != ctx.ver:
+            if fold is not None:
+                fold.refresh_forward()
             plan.refresh()   # weights are checked unchanged by autograd's saved-tensor versioning
         dev = gout.device
         L, nmat, hid, fn, fe = mod.n_gnn_layers, mod.K + 1, mod.dim_hid, mod.dim_featn, mod.dim_feate
         W1, b1 = ps[0], ps[1]
         # one flat gradient buffer; parameter gradients are returned as views into it
-        sizes = [hid * (2 * fn + fe) + hid, hid * hid + hid]
-        for l in range(L):
-            hout = mod.dim_out if l == L - 1 else hid
-            sizes.append(nmat * hout * hid + hout)
-        offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        offs = mod._flat_offsets()
         flat = torch.empty(int(offs[-1]), dtype=_F32, device=dev)
         g = gout.contiguous()
         need_dx = ctx.needs_input_grad[0]
         for l in range(L - 1, -1, -1):
             hout = mod.dim_out if l == L - 1 else hid
             seg = flat[offs[2 + l]:offs[3 + l]]
+            if l == 0 and fold is not None:
+                # folded conv 0: weight gradient w.r.t. Wf / bf into the plan's buffer, data gradient is dS;
+                # one small-GEMM launch then writes dW_m, conv0.bias, dW2, db2 into the flat buffer
+                wgrad(topo, g, hout, S, hid, nmat, fold.gfold, rowscale2=topo.deg_pows)
+                dS = torch.empty(topo.N, hid, dtype=_F32, device=dev)
+                gemm_prop(topo, g, g.stride(0), hout, plan.bwd[1], nmat, hid, dS, transposed=True)
+                fold.backward(flat)
+                g = None
+                break
             # dgrad epilogue applies the ReLU / dropout mask of the layer BELOW (its output is acts[l])
             g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, hout, seg,
                                   relu_src=(acts[l] if l > 0 else None), dmask=(masks[l - 1] if l > 0 else None))
         dx = _edge_aggr_backward(topo, g, x, ldx, ea, ldea, W1, b1, S, plan.bwd[0], hid, hid, fn, fe,
                                  flat[offs[0]:offs[1]], flat[offs[1]:offs[2]], need_dx,
-                                 pack_dx=(plan.bwd[1 + L], plan.bwd[2 + L]))
+                                 pack_dx=(plan.bwd[1 + L], plan.bwd[2 + L]), dS=(dS if fold is not None else None))
         if need_dx and mod.skip:
             dx = dx + gout
         if WGRAD_SIDE_STREAM:

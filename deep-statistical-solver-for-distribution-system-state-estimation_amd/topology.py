@@ -93,6 +93,7 @@ class Topology:
         dis = dis.masked_fill(dis == float("inf"), 0.0)
         w_d = dis[src] * dis[tgt]
         self.deg = degf.contiguous()
+        self._deg_pows = None
         self.col = src[perm].to(torch.int32).contiguous()
         self.ent = eid[perm].to(torch.int32).contiguous()
         self.w = w_d[perm].contiguous()
@@ -149,6 +150,22 @@ class Topology:
         # same slices carrying the stored edge id | flip instead of the weight (edge-MLP kernels); -1 = empty
         self.ell_ent_tiles = self._ell_tiles(self.rowptr, self.col, self.ent, self.ell, ids=True)
         self.ellT_ent_tiles = self._ell_tiles(self.rowptrT, self.colT, self.entT, self.ellT, ids=True)
+
+    @property
+    def deg_pows(self) -> torch.Tensor:
+        """[N, 4] fp32, column m = A_hat^m deg (A_hat = the gcn_norm propagation matrix): the row scales of
+        a bias folded through m propagations (networks._FoldPlan).  Built once per topology, in fp64."""
+        if self._deg_pows is None:
+            rp = self.rowptr.to(torch.int64)
+            rows = torch.repeat_interleave(torch.arange(self.N, device=self.device), rp[1:] - rp[:-1])
+            col, w = self.col.to(torch.int64), self.w.to(torch.float64)
+            v = self.deg.to(torch.float64)
+            cols = [v]
+            for _ in range(3):
+                v = torch.zeros(self.N, dtype=torch.float64, device=self.device).index_add_(0, rows, w * v[col])
+                cols.append(v)
+            self._deg_pows = torch.stack(cols, dim=1).to(torch.float32).contiguous()
+        return self._deg_pows
 
     def _ell_tiles(self, rowptr, col, w, width, ids=False):
         if width <= 0:

@@ -144,6 +144,13 @@ typedef struct dss2_gemm_prop_args {
                                     * nmat matrices (narrow_h columns each, nmat*narrow_h   *
                                     * <= 32) sit side by side in ONE 32-column group; the   *
                                     * Horner recurrence runs across column blocks in LDS    */
+  const float* prebias;            /* optional [nmat][hout] with pre_rowscale [N][4]: adds the  *
+                                    * rank-nmat term sum_m pre_rowscale[row][m] * prebias[m][col] *
+                                    * before the activation.  With pre_rowscale rows             *
+                                    * [s, P s, P^2 s, P^3 s] this is sum_m P^m (s (x) prebias_m): *
+                                    * a row-scaled bias inside every X B_m, i.e. the edge MLP's   *
+                                    * second Linear folded in (s = deg, prebias_m = W_m b2)       */
+  const float* pre_rowscale;
   const void* ell_tiles;           /* optional: per-tile ELL slices precomputed once per     *
                                     * topology, int2 {local src, weight bits}[ntiles]        *
                                     * [ell_width][32*nrb] (rows >= tile rows: {row, 0});      *
@@ -166,6 +173,10 @@ typedef struct dss2_wgrad_args {
   const int32_t* rowptrT; const int32_t* colT; const float* wT;
   int32_t max_nnz; int32_t ell_width;   /* as in dss2_gemm_prop_args, for the transposed CSR */
   const void* ell_tiles;                /* per-tile ELL slices of the transposed graph, or NULL   */
+  const float* rowscale2;               /* optional [N][4] (16-byte aligned): additionally emit, for *
+                                         * every m, sum_n rowscale2[n][m] G[n, o] (the gradient of  *
+                                         * dss2_gemm_prop's prebias_m when rowscale2 is its          *
+                                         * pre_rowscale); slab = [nmat*hout*hin][hout][nmat*hout]    */
   int32_t narrow; int32_t pad_;         /* narrow != 0 (needs nmat*hout <= 32): the propagated  *
                                          * copies P^m G are appended as extra COLUMNS of one    *
                                          * 32-wide block instead of nmat separate blocks; same  *
@@ -220,6 +231,19 @@ int dss2_wls_loss_grad(const dss2_wls_args* args_host, void* stream);
 int dss2_get_pflow(const float* y, int64_t ldy, const float* node_param, int64_t ld_np,
                    const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
                    int64_t n_nodes, int64_t n_edges, float* vminmax, float* pflow, void* stream);
+
+/* ---- batched small dense products in weight space (folding the edge MLP's second Linear into conv 0
+ *      and the chain rule back): C[M,N] (+)= sum_b op(A_b)[M,K] . op(B_b)[K,N]  (+ u[i] * v[j]).     */
+typedef struct dss2_sgemm_desc {
+  const float* A[4]; const float* B[4];    /* nbatch <= 4 operand pairs, summed                 */
+  float* C;
+  const float* u; const float* v;          /* optional rank-1 term                              */
+  int64_t c_off;                           /* >= 0: C = base_out + c_off (elements); < 0: use C */
+  int32_t M, N, K, lda, ldb, ldc, transA, transB, nbatch, accumulate;
+} dss2_sgemm_desc;
+
+/* max_tiles = max over the descriptors of ceil(M/32) * ceil(N/32); descs is a DEVICE array */
+int dss2_small_gemm(const dss2_sgemm_desc* descs, int n_desc, int max_tiles, float* base_out, void* stream);
 
 /* ---- optimizer step (/root/reference/dss2_run.py:91-92,143: Adamax, lr 3e-3) ---
  * torch.optim.Adamax semantics on n_desc tensors in ONE launch.  descs: device array.  `step` is the

@@ -191,26 +191,52 @@ def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
     ref, mine, out_r, loss_r, out_m, loss_m = _train_step_pair(pkg, oracle, grids, B, hid, L)
     assert rel_err(out_m, out_r) < TOL_OUT
     assert abs(loss_m.item() - loss_r.item()) <= TOL_LOSS * abs(loss_r.item())
-    # gradients: fp64 referee.  The HIP path must be as close to the exact gradient as the fp32
-    # reference arithmetic itself is (x3), or within TOL_GRAD, whichever is looser.
+    # gradients: fp64 referee evaluated on the HIP path's own ReLU gate pattern.  A pre-activation within
+    # an ulp of 0 may take the other sign under a different fp32 summation order; such a flipped gate is
+    # not an arithmetic error, but it moves one row of a weight gradient (and everything upstream of it)
+    # by ~1/N_nodes.  Pinning the gates removes that ambiguity, so the tolerance can be tight (1e-5,
+    # max-normalised); the flipped gates themselves must be few and must sit at |pre-activation| ~ 0.
     b = pkg.synthetic.make_batch(grids, B, seed=0)
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    gates = []
+    sd = mine.state_dict()
+    with torch.no_grad():
+        for l in range(L - 1):   # conv l's pre-activation = output of the same model truncated after conv l
+            trunc = pkg.MPN(8, 6, hid, hid, l + 1, 2, 0.0)
+            trunc.load_state_dict({k: v for k, v in sd.items() if k in trunc.state_dict()})
+            gates.append((trunc.to(DEV)(x[:, :8], ei, ea[:, :6]) > 0).cpu())
     ref64 = type(ref)(8, 6, 2, hid, L, 2, 0.0).double()
     ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
-    b64 = {"x": b["x"].double(), "edge_index": b["edge_index"], "edge_attr": b["edge_attr"].double()}
-    _, loss64 = oracle.train_step(ref64, b64, tuple(s.double() for s in b["stats"]))
+    x64, ea64 = b["x"].double(), b["edge_attr"].double()
+    st64 = tuple(s.double() for s in b["stats"])
+    ei2, ea2 = oracle.undirect_graph(b["edge_index"], ea64[:, :6])
+    h = ref64.edge_aggr(x64[:, :8], ei2, ea2)
+    n_flip, n_gate = 0, 0
+    for l in range(L - 1):
+        pre = ref64.convs[l](h, ei2)
+        flipped = (pre > 0) != gates[l]
+        n_flip, n_gate = n_flip + int(flipped.sum()), n_gate + flipped.numel()
+        if flipped.any():   # only razor-edge pre-activations may differ in sign
+            assert pre[flipped].abs().max() <= 1e-5 * pre.abs().max(), (l, pre[flipped].abs().max().item())
+        h = pre * gates[l].double()
+    out64 = ref64.convs[-1](h, ei2)
+    loss64 = oracle.gsp_wls_edge(input=x64[:, :8], edge_input=ea64[:, :6], output=out64, x_mean=st64[0], x_std=st64[1],
+                                 edge_mean=st64[2], edge_std=st64[3], edge_index=b["edge_index"],
+                                 reg_coefs=oracle.DEFAULT_REG_COEFS, num_samples=None, node_param=x64[:, 8:],
+                                 edge_param=ea64[:, 6:])
+    loss64.backward()
+    assert n_flip <= max(2, 1e-5 * n_gate), (n_flip, n_gate)
+    assert rel_err(out_m, out64) < TOL_OUT
     assert abs(loss_m.item() - loss64.item()) <= TOL_LOSS * abs(loss64.item())
-    # An isolated ReLU gate can flip (a pre-activation within one ulp of 0 gets the other sign under
-    # a different fp32 summation order); that moves one row of a weight gradient by ~1e-4 of its max
-    # without being an arithmetic error.  So: max-normalised error < TOL_GRAD, or - for at most a
-    # handful of flipped gates - tiny in the 2-norm with < 1 % of the elements touched.
-    for (n, p), (_, q), (_, q64) in zip(mine.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
-        e_mine, e_ref = rel_err(p.grad, q64.grad), rel_err(q.grad, q64.grad)
-        if e_mine < max(TOL_GRAD, 3 * e_ref):
+    for (n, p), (_, q64) in zip(mine.named_parameters(), ref64.named_parameters()):
+        e = rel_err(p.grad, q64.grad)
+        if e < 1e-5:
             continue
-        d = (p.grad.double().cpu() - q64.grad).abs()
-        l2 = (d.norm() / q64.grad.norm()).item()
-        frac = (d > 1e-5 * q64.grad.abs().max()).double().mean().item()
-        assert e_mine < 1e-3 and l2 < 5e-5 and frac < 0.01, (n, e_mine, e_ref, l2, frac)
+        # the edge MLP's own per-edge gates are not observable from outside (the kernels recompute them);
+        # a flipped one moves single rows of the first Linear's gradient by ~1/N_edges
+        assert n.startswith("edge_aggr.edge_aggr.0."), (n, e)
+        d = (p.grad.double().cpu() - q64.grad).abs().reshape(p.shape[0], -1).amax(1)
+        assert e < 1e-3 and int((d > 1e-5 * q64.grad.abs().max()).sum()) <= 2, (n, e)
 
 
 def test_full_size_is_deterministic_and_linear_in_gout(pkg, oracle):
