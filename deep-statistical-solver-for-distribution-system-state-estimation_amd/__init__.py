@@ -5,12 +5,13 @@ Drop-in modules ``networks`` (EdgeAggregation, TAGConv, MPN, SkipMPN, PFN, SkipP
 path BASELINE.json names; everything below them is hand-written HIP in libdss2_hip.so.
 """
 from . import _lib, synthetic, topology  # noqa: F401
-from . import networks, data, parallel, graphs, optim  # noqa: F401
+from . import networks, data, parallel, graphs, optim, dataset  # noqa: F401
 from .optim import FusedAdamax  # noqa: F401
 from . import runner  # noqa: F401
 from .networks import EdgeAggregation, TAGConv, MPN, SkipMPN, PFN, SkipPFN, MessagePassing  # noqa: F401
 from .data import gsp_wls_edge, get_pflow  # noqa: F401
+from .dataset import data_from_pickles, DataLoader, DeviceDataset  # noqa: F401
 
 __all__ = ["EdgeAggregation", "TAGConv", "MPN", "SkipMPN", "PFN", "SkipPFN", "MessagePassing",
-           "gsp_wls_edge", "get_pflow", "FusedAdamax", "networks", "data", "parallel", "graphs", "optim", "synthetic",
+           "gsp_wls_edge", "get_pflow", "data_from_pickles", "DataLoader", "DeviceDataset", "FusedAdamax", "dataset", "networks", "data", "parallel", "graphs", "optim", "synthetic",
            "topology"]

@@ -49,6 +49,11 @@ class WgradArgs(C.Structure):
                 ("narrow", C.c_int32), ("pad_", C.c_int32)]
 
 
+class CollateDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("chunk", C.c_int32), ("kind", C.c_int32),
+                ("shared", C.c_int32), ("pad_", C.c_int32), ("nodes_per_sample", C.c_int64)]
+
+
 class SgemmDesc(C.Structure):
     _fields_ = [("A", C.c_void_p * 4), ("B", C.c_void_p * 4), ("C", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p),
                 ("c_off", C.c_int64),
@@ -103,6 +108,14 @@ _SIGNATURES = {
                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
     "dss2_small_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dss2_measure_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                     C.c_double, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dss2_measure_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_void_p, C.c_int64,
+                                     C.c_void_p]),
+    "dss2_masked_zscore": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dss2_masked_zscore_scratch_doubles": (C.c_int64, [C.c_int64]),
+    "dss2_collate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "dss2_adamax_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_int, C.c_void_p]),
     "dss2_gemm_prop_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

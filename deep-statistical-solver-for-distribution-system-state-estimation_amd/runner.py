@@ -5,11 +5,13 @@ Reproduces the training loop (dss2_run.py:131-147) and the per-epoch evaluation
 feature slicing ``x[:, :8] / edge_attr[:, :6] / x[:, 8:] / edge_attr[:, 6:]`` (:138,140),
 ``reg_coefs`` (:104-112), Adamax lr 3e-3 (:91-92), batch_size 64, the hyper-parameter dict (:72-82).
 The model is the MPN / SkipMPN / PFN / SkipPFN line (:88), not the default GAT (out of scope).
-Data: the reference ships samples for CIGRE-14 only and its loader (data_from_pickles) is host-side
-and out of scope, so batches come from ``synthetic.make_batch`` (same layout), collated once and kept
+Data: either a folder in the reference's layout (``--data-folder``: ``dataset.data_from_pickles`` ->
+shuffle -> 0.9 split -> ``dataset.DataLoader``, dss2_run.py:56-69, measurement model / z-score / collation
+on the device) or synthetic batches from ``synthetic.make_batch`` (same layout), collated once and kept
 resident on the GPU (re-used tensors take the no-sync topology fast path).
 
     python tools/train.py --case cigre14 --model SkipPFN --epochs 5
+    python tools/train.py --data-folder /path/to/data/cigre14/ --model SkipPFN --epochs 5
 """
 from __future__ import annotations
 
@@ -50,16 +52,23 @@ def make_loaders(case: str, n_graphs: int, batch_size: int, device, seed: int = 
     return batches(0, n_train, 0), batches(n_train, n_graphs, 10_000), stats
 
 
-def train_epoch(model, opt, loader: List[Dict], stats, reg_coefs, group=None) -> float:
+def _fields(data):
+    """A batch is a dict (synthetic loaders) or a dataset.Batch (device loader): (x, edge_index, edge_attr, y, B)."""
+    if isinstance(data, dict):
+        return data["x"], data["edge_index"], data["edge_attr"], data.get("y"), data["num_graphs"]
+    return data.x, data.edge_index, data.edge_attr, data.y, data.num_graphs
+
+
+def train_epoch(model, opt, loader, stats, reg_coefs, group=None) -> float:
     model.train()
     total = torch.zeros((), device=stats[0].device)
     for data in loader:                                              # dss2_run.py:134-144
         opt.zero_grad()
-        x, ei, ea = data["x"], data["edge_index"], data["edge_attr"]
+        x, ei, ea, _, num_graphs = _fields(data)
         out = model(x[:, :8], ei, ea[:, :6])
         loss = dss2_data.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=stats[0], x_std=stats[1],
                                       edge_mean=stats[2], edge_std=stats[3], edge_index=ei, reg_coefs=reg_coefs,
-                                      num_samples=data["num_graphs"], node_param=x[:, 8:], edge_param=ea[:, 6:], group=group)
+                                      num_samples=num_graphs, node_param=x[:, 8:], edge_param=ea[:, 6:], group=group)
         loss.backward()
         opt.step()
         total += loss.detach()
@@ -67,13 +76,13 @@ def train_epoch(model, opt, loader: List[Dict], stats, reg_coefs, group=None) ->
 
 
 @torch.no_grad()
-def evaluate(model, loader: List[Dict], stats) -> Dict[str, float]:
+def evaluate(model, loader, stats) -> Dict[str, float]:
     """dss2_run.py:165-224: RMSE / MAE of V and theta, and of line / trafo loading from get_pflow."""
     model.eval()                                                     # dropout stays active, as in the reference
     acc = {k: 0.0 for k in ("rmse_v", "mae_v", "rmse_th", "mae_th", "rmse_loading", "mae_loading",
                             "rmse_loading_trafos", "mae_loading_trafos")}
     for data in loader:
-        x, ei, ea, y = data["x"], data["edge_index"], data["edge_attr"], data["y"]
+        x, ei, ea, y, _ = _fields(data)
         out = model(x[:, :8], ei, ea[:, :6])
         out = torch.cat([out[:, 0:1] * stats[1][:1] + stats[0][:1], out[:, 1:]], dim=1)      # :183
         out[:, 1:] *= (1.0 - x[:, 9:10])                                                     # :184
@@ -104,13 +113,27 @@ def main(argv=None):
         ap.add_argument("--" + k.replace("_", "-"), type=type(v), default=v)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--save", default="")
+    ap.add_argument("--data-folder", default="", help="folder with the reference's pickles (nodes, edges, labels, noise_param)")
     a = ap.parse_args(argv)
     hp = {k: getattr(a, k) for k in HYPER}
     if a.model == "SkipMPN":
         hp["dim_out"] = hp["dim_nodes"]
     dev = torch.device("cuda")
     torch.manual_seed(a.seed)
-    train_loader, test_loader, stats = make_loaders(a.case, a.graphs, a.batch_size, dev, a.seed)
+    if a.data_folder:                                                # dss2_run.py:47-69
+        import numpy as np
+        from . import dataset as dss2_dataset
+        cigre = "cigre" in a.data_folder
+        meas_v = np.array([0, 1, 12, 7, 11, 14] if cigre else [35, 16, 52, 47, 6, 48, 59, 27, 37, 56])
+        meas_pf = np.array([0, 10] if cigre else [40, 43, 11, 21, 54, 57])
+        ds, *stats = dss2_dataset.data_from_pickles(a.data_folder, 8, 6, 4, 2, meas_v, meas_pf, device=dev)
+        ds = ds.shuffled()
+        n_train = int(0.9 * len(ds))
+        train_loader = dss2_dataset.DataLoader(ds[0:n_train], batch_size=a.batch_size, shuffle=True)
+        test_loader = dss2_dataset.DataLoader(ds[n_train:], batch_size=a.batch_size, shuffle=False)
+        stats = tuple(stats)
+    else:
+        train_loader, test_loader, stats = make_loaders(a.case, a.graphs, a.batch_size, dev, a.seed)
     model = build_model(a.model, hp).to(dev)
     opt = FusedAdamax(model.parameters(), lr=a.lr)
     print(f"device:{dev}  train batches {len(train_loader)}  test batches {len(test_loader)}  model {a.model} {hp}")

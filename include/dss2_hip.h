@@ -245,6 +245,46 @@ typedef struct dss2_sgemm_desc {
 /* max_tiles = max over the descriptors of ceil(M/32) * ceil(N/32); descs is a DEVICE array */
 int dss2_small_gemm(const dss2_sgemm_desc* descs, int n_desc, int max_tiles, float* base_out, void* stream);
 
+/* ---- dataset side: what sits in front of the path in every training step.
+ *      Replaces the arithmetic of data_from_pickles (/root/reference/data.py:119-190) and the
+ *      torch_geometric DataLoader collation the driver relies on (/root/reference/dss2_run.py:68-69,134).
+ *      Samples of one case have uniform shapes (n buses, e closed branches).                            */
+
+/* measurement model, nodes (data.py:119-141).  nodes [rows][7] float64 = (vm_pu, va_rad, p_mw, q_mvar, vn_kv,
+ * bool_slack, bool_zero_inj); meas_v_mask [n_per_sample] bytes (1 = voltage magnitude measured at that bus);
+ * z [rows][4] float64 standard-normal draws (the reference's np.random.normal(0, |std|) = z * |std|).
+ * x [rows][11] float32 <- (V, 1/var, theta, 1/var, P, 1/var, Q, 1/var, vn_kv, bool_slack, bool_zero_inj),
+ * NOT yet normalised.  float64 arithmetic rounded once, like numpy.                                      */
+int dss2_measure_nodes(const double* nodes, const uint8_t* meas_v_mask, int32_t n_per_sample, const double* z,
+                       double v_noise, double pm_noise, double p_noise, double zero_inj_coef, float* x, int64_t rows,
+                       void* stream);
+
+/* measurement model, closed branches (data.py:144-167).  edges [rows][11] float64 = (from_bus, to_bus, p_from_mw,
+ * q_from_mvar, G, B, Gs, Bs, closed line, phase shift, imax or sn); z [rows][2].
+ * edge_attr [rows][13] float32 <- (P, 1/var, Q, 1/var, G, B | G, B, Gs, Bs, closed, shift, imax_or_sn).     */
+int dss2_measure_edges(const double* edges, const uint8_t* meas_pflow_mask, int32_t e_per_sample, const double* z,
+                       double p_noise, float* edge_attr, int64_t rows, void* stream);
+
+/* masked z-score (data.py:179-190): for the first num_feat (<= 16) columns, mean / std over the NON-ZERO entries,
+ * out = nan_to_num((t - mean) * (t != 0) / std); the other columns are copied.  mean/stdv [num_feat] are written
+ * (nan -> 0 like the reference).  In place allowed (out == t, ld_out == ld).  scratch: device doubles,
+ * dss2_masked_zscore_scratch_doubles(rows) of them.  Deterministic (fixed-order double partial sums).     */
+int dss2_masked_zscore(const float* t, int64_t rows, int32_t ld, int32_t num_feat, float* out, int32_t ld_out,
+                       float* mean, float* stdv, double* scratch, void* stream);
+int64_t dss2_masked_zscore_scratch_doubles(int64_t rows);
+
+/* batch collation (PyG Batch semantics): for slot b of the batch and sample s = sample_ids[b] (NULL: s = b),
+ * kind 0: dst[b][0..chunk) = src[s][0..chunk)                    (float rows of x / edge_attr / y, chunk floats)
+ * kind 1: dst[r][b*chunk + j] = src[s][r][j] + b * nodes_per_sample   (int64 edge_index, chunk = e; shared != 0:
+ *         every sample uses the one [2][e] list at src).   descs_host: HOST array of 1..4 descriptors, passed
+ *         to the kernel by value (no descriptor copy); sample_ids: DEVICE int64 [batch].                     */
+typedef struct dss2_collate_desc {
+  const void* src; void* dst;
+  int32_t chunk; int32_t kind; int32_t shared; int32_t pad_;
+  int64_t nodes_per_sample;
+} dss2_collate_desc;
+int dss2_collate(const dss2_collate_desc* descs_host, int32_t n_desc, const int64_t* sample_ids, int64_t batch, void* stream);
+
 /* ---- optimizer step (/root/reference/dss2_run.py:91-92,143: Adamax, lr 3e-3) ---
  * torch.optim.Adamax semantics on n_desc tensors in ONE launch.  descs: device array.  `step` is the
  * 1-based step count (bias correction 1 - beta1^step).  grad pointers may be views of the flat

@@ -14,6 +14,9 @@ Fixtures written:
     tests/golden/cigre14_real64.npz     64 real CIGRE-14 samples through data_from_pickles (seeded)
     tests/golden/physics_known.npz      pandapower branch/bus results for 5 samples (known answers)
     tests/golden/case_<name>.npz        model / loss cases (weights, inputs, reference outputs)
+    tests/golden/dataset64.npz          raw tables of 64 real CIGRE-14 samples, the standard-normal draws
+                                        the reference consumed, and its data_from_pickles output on them
+                                        (python tests/golden/make_goldens.py dataset64 writes only this one)
 """
 import os
 import pickle
@@ -67,6 +70,47 @@ def real_cigre():
          x_mean=x_mean, x_std=x_std, edge_mean=e_mean, edge_std=e_std)
     return dict(x=b.x, edge_index=b.edge_index, edge_attr=b.edge_attr, y=b.y,
                 stats=(x_mean, x_std, e_mean, e_std))
+
+
+def dataset64():
+    """data_from_pickles on the first 64 CIGRE-14 samples (pickles truncated into a temp folder), with the
+    raw tables and the standard-normal draws saved beside the reference's output."""
+    import tempfile
+    src = f"{REF}/data/cigre14/"
+    tmp = tempfile.mkdtemp(prefix="dss2_ds64_") + "/"
+    tabs = {}
+    for name in ["nodes", "edges", "labels"]:
+        tabs[name] = pickle.load(open(src + name, "rb"))[:64]
+        pickle.dump(tabs[name], open(tmp + name, "wb"))
+    noise_df = pickle.load(open(src + "noise_param", "rb"))
+    pickle.dump(noise_df, open(tmp + "noise_param", "wb"))
+    meas_v, meas_pf = np.array([0, 1, 12, 7, 11, 14]), np.array([0, 10])
+    np.random.seed(7)
+    ds, x_mean, x_std, e_mean, e_std = ref_data.data_from_pickles(tmp, 8, 6, 4, 2, meas_v, meas_pf)
+    b = collate(ds)
+    # the draws the reference consumed: per sample normal(0, |x_std|) [n, 4], then normal(0, |e_std|) [e, 2]
+    np.random.seed(7)
+    zn, ze = [], []
+    for i in range(64):
+        zn.append(np.random.standard_normal([15, 4]))
+        ze.append(np.random.standard_normal([14, 2]))
+    ncols = ["vm_pu", "va_rad", "p_mw", "q_mvar", "vn_kv", "bool_slack", "bool_zero_inj"]
+    ecols = ["from_bus", "to_bus", "p_from_mw", "q_from_mvar", "G", "B", "Gs", "Bs", "closed line", "phase shift",
+             "imax or sn"]
+    nodes = np.stack([t[ncols].values.astype(np.float64) for t in tabs["nodes"]])
+    edges = np.stack([t[t["closed line"] == 1.0][ecols].values.astype(np.float64) for t in tabs["edges"]])
+    labels = np.stack([t.values.astype(np.float64) for t in tabs["labels"]])
+    noise = {k: float(noise_df[k].values[0]) for k in ["p_noise", "v_noise", "pm_noise", "zero_inj_coef"]}
+    # the restatement must reproduce the reference from these inputs (draw order / shapes are right)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dss2_dataset_oracle as dso
+    o = dso.data_from_tables(nodes, edges, labels, noise, meas_v, meas_pf, np.stack(zn), np.stack(ze))
+    assert torch.equal(o["x"], b.x) and torch.equal(o["edge_attr"], b.edge_attr) and torch.equal(o["y"], b.y)
+    assert torch.equal(o["x_mean"], x_mean) and torch.equal(o["edge_std"], e_std)
+    save("dataset64.npz", nodes=nodes, edges=edges, labels=labels, z_nodes=np.stack(zn), z_edges=np.stack(ze),
+         meas_v=meas_v, meas_pflow=meas_pf, noise_keys=np.array(list(noise.keys())),
+         noise_vals=np.array(list(noise.values())), x=b.x, edge_index=b.edge_index, edge_attr=b.edge_attr, y=b.y,
+         x_mean=x_mean, x_std=x_std, edge_mean=e_mean, edge_std=e_std)
 
 
 def physics_known():
@@ -192,4 +236,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "dataset64":
+        dataset64()
+    else:
+        main()

@@ -1,0 +1,139 @@
+"""GPU: device-side measurement model, masked z-score, collation and loader (dataset.py over the C ABI) against
+the reference's data_from_pickles output (golden dataset64.npz) and the dataset oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _noise(g):
+    return {str(k): float(v) for k, v in zip(g["noise_keys"], g["noise_vals"])}
+
+
+@pytest.fixture(scope="module")
+def built(pkg):
+    g = golden("dataset64.npz")
+    ds, *stats = pkg.dataset.data_from_tables(g["nodes"], g["edges"], g["labels"], _noise(g), 8, 6, g["meas_v"],
+                                              g["meas_pflow"], device=DEV, z_nodes=g["z_nodes"], z_edges=g["z_edges"])
+    return g, ds, stats
+
+
+def test_device_pipeline_matches_reference_data_from_pickles(pkg, built):
+    g, ds, stats = built
+    x, ea = ds.x.reshape(-1, 11).cpu(), ds.edge_attr.reshape(-1, 13).cpu()
+    gx, gea = t(g["x"]), t(g["edge_attr"])
+    # raw parameter columns and labels are copies: exact
+    assert torch.equal(x[:, 8:], gx[:, 8:]) and torch.equal(ea[:, 6:], gea[:, 6:]) and torch.equal(ds.y.reshape(-1, 2).cpu(), t(g["y"]))
+    # A column whose measured entries are all the same number has zero variance; the reference's fp32 column sum
+    # (960 rows, torch's CPU summation order) is off by one ulp there, so its "std" is that ulp and its z-scores
+    # are +-1 of pure rounding noise (cov_theta at the slack bus, column 3).  The device path sums exactly and
+    # returns 0 for such a column (std 0 -> nan -> 0, the reference's own rule, data.py:181-182).
+    degenerate = [c for c in range(8) if len(torch.unique(gx[:, c][gx[:, c] != 0])) == 1]
+    assert degenerate == [3]
+    assert (x[:, 3] == 0).all() and stats[1][3].item() == 0.0
+    keep = [c for c in range(8) if c not in degenerate]
+    # zeros ("not measured") are preserved exactly; measured entries agree to fp32 rounding of the statistics
+    assert torch.equal(x[:, keep] == 0, gx[:, keep] == 0) and torch.equal(ea[:, :6] == 0, gea[:, :6] == 0)
+    assert torch.allclose(x[:, keep], gx[:, keep], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(ea[:, :6], gea[:, :6], rtol=1e-5, atol=1e-6)
+    for mine, key in zip(stats, ("x_mean", "x_std", "edge_mean", "edge_std")):
+        sel = keep if key == "x_std" else slice(None)
+        assert torch.allclose(mine.cpu()[sel], t(g[key])[sel], rtol=1e-6, atol=0), key
+
+
+def test_measurement_kernels_are_bit_exact_before_normalisation(pkg, built, oracle):
+    """The un-normalised features are float64 arithmetic rounded once: identical bits to numpy."""
+    import ctypes as C
+    import dss2_dataset_oracle as dso
+    g = golden("dataset64.npz")
+    S, n, e = 64, 15, 14
+    L = pkg._lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    nd, zn = t(g["nodes"], device=DEV).reshape(-1, 7), t(g["z_nodes"], device=DEV).reshape(-1, 4)
+    ed, ze = t(g["edges"], device=DEV).reshape(-1, 11), t(g["z_edges"], device=DEV).reshape(-1, 2)
+    mv = torch.zeros(n, dtype=torch.uint8); mv[t(g["meas_v"])] = 1
+    mp = torch.zeros(e, dtype=torch.uint8); mp[t(g["meas_pflow"])] = 1
+    x = torch.empty(S * n, 11, device=DEV); ea = torch.empty(S * e, 13, device=DEV)
+    nz = _noise(g)
+    pkg._lib.check(L.dss2_measure_nodes(nd.data_ptr(), mv.to(DEV).data_ptr(), n, zn.data_ptr(), nz["v_noise"], nz["pm_noise"],
+                                        nz["p_noise"], nz["zero_inj_coef"], x.data_ptr(), S * n, st), "measure_nodes")
+    pkg._lib.check(L.dss2_measure_edges(ed.data_ptr(), mp.to(DEV).data_ptr(), e, ze.data_ptr(), nz["p_noise"], ea.data_ptr(),
+                                        S * e, st), "measure_edges")
+    for i in (0, 17, 63):
+        xo = dso.measure_nodes(g["nodes"][i, :, 0:4], g["nodes"][i, :, 5], g["nodes"][i, :, 6], g["meas_v"], nz, g["z_nodes"][i])
+        eo = dso.measure_edges(g["edges"][i, :, 2:4], g["edges"][i, :, 4:6], g["meas_pflow"], nz, g["z_edges"][i])
+        assert torch.equal(x[i * n:(i + 1) * n, :8].cpu(), xo)
+        assert torch.equal(ea[i * e:(i + 1) * e, :6].cpu(), eo)
+
+
+def test_masked_zscore_kernel_edge_cases(pkg):
+    a = torch.tensor([[0.0, 2.0, 5.0], [0.0, 4.0, 5.0], [0.0, 0.0, 5.0]], device=DEV)
+    out, mean, std = pkg.dataset.masked_zscore(a.clone(), 2)
+    assert mean.tolist() == [0.0, 3.0] and std.tolist() == [0.0, 1.0]
+    assert out.cpu().tolist() == [[0.0, -1.0, 5.0], [0.0, 1.0, 5.0], [0.0, 0.0, 5.0]]
+    # large, ragged row count: against torch in float64
+    torch.manual_seed(0)
+    b = torch.randn(100_003, 13, device=DEV) * (torch.rand(100_003, 13, device=DEV) > 0.3)
+    o, m, s = pkg.dataset.masked_zscore(b.clone(), 6)
+    b64, mask = b.double()[:, :6], (b[:, :6] != 0)
+    m64 = (b64 * mask).sum(0) / mask.sum(0)
+    s64 = torch.sqrt((((b64 - m64) ** 2) * mask).sum(0) / mask.sum(0))
+    assert torch.allclose(m.double(), m64, rtol=1e-6, atol=1e-9) and torch.allclose(s.double(), s64, rtol=1e-6)
+    assert torch.allclose(o[:, :6].double(), (b64 - m64) * mask / s64, rtol=1e-5, atol=1e-6)
+    assert torch.equal(o[:, 6:], b[:, 6:])
+    o2, _, _ = pkg.dataset.masked_zscore(b.clone(), 6)
+    assert torch.equal(o, o2)                                   # deterministic
+
+
+def test_loader_collates_like_the_reference_loader(pkg, built):
+    import dss2_dataset_oracle as dso
+    g, ds, _ = built
+    n, e = 15, 14
+    loader = pkg.dataset.DataLoader(ds, batch_size=24, shuffle=False)
+    assert len(loader) == 3
+    sizes, first_ei = [], None
+    for k, b in enumerate(loader):
+        B = b.num_graphs
+        sizes.append(B)
+        lo = k * 24
+        xs = [ds.x[s].cpu() for s in range(lo, lo + B)]
+        eis = [ds.edge_index[s].cpu() for s in range(lo, lo + B)]
+        x, ei, ea, y = dso.collate(xs, eis, [ds.edge_attr[s].cpu() for s in range(lo, lo + B)], [ds.y[s].cpu() for s in range(lo, lo + B)])
+        assert torch.equal(b.x.cpu(), x) and torch.equal(b.edge_index.cpu(), ei)
+        assert torch.equal(b.edge_attr.cpu(), ea) and torch.equal(b.y.cpu(), y)
+        if k == 0:
+            first_ei = b.edge_index
+        elif B == 24:
+            assert b.edge_index is first_ei          # one topology: the batch edge list is built once per batch size
+    assert sizes == [24, 24, 16]
+    # the full collated set equals the reference's own collated batch
+    full = next(iter(pkg.dataset.DataLoader(ds, batch_size=64)))
+    assert torch.equal(full.edge_index.cpu(), t(g["edge_index"]))
+    # shuffling: every sample exactly once per epoch, a different order
+    gen = torch.Generator(device=DEV); gen.manual_seed(3)
+    rows = torch.cat([b.y for b in pkg.dataset.DataLoader(ds, batch_size=10, shuffle=True, generator=gen)]).cpu()
+    ref = ds.y.reshape(-1, 2).cpu()
+    assert rows.shape == ref.shape and not torch.equal(rows, ref)
+    w = torch.rand(30, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    key = lambda a: a.reshape(64, -1)[torch.argsort(a.reshape(64, -1).double() @ w)]     # canonical sample order
+    assert torch.equal(key(rows), key(ref))
+    # list-like use of the dataset (dss2_run.py:59-66)
+    sub = ds.shuffled(gen)[0:57]
+    assert len(sub) == 57 and len(ds[57:]) == 7 and ds[3].x.shape == (15, 11)
+
+
+def test_training_from_the_device_loader(pkg, built):
+    """dss2_run.py:131-147 on batches that never left the device."""
+    g, ds, stats = built
+    torch.manual_seed(0)
+    model = pkg.MPN(8, 6, 2, 32, 2, 2, 0.0).to(DEV)
+    opt = pkg.FusedAdamax(model.parameters(), lr=3e-3)
+    losses = [pkg.runner.train_epoch(model, opt, pkg.dataset.DataLoader(ds, batch_size=16, shuffle=True), tuple(stats),
+                                     pkg.runner.REG_COEFS) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    m = pkg.runner.evaluate(model, pkg.dataset.DataLoader(ds, batch_size=32), tuple(stats))
+    assert all(np.isfinite(v) for v in m.values())
