@@ -44,6 +44,9 @@ def main():
                     help="run the weight-gradient chain on a side stream beside the data-gradient chain (+3 %% at C2; "
                          "per-kernel durations then include the overlap)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--ramp-seconds", type=float, default=2.0,
+                    help="untimed load before the W warm-up steps: a fresh MI355X needs ~1 s of sustained work to reach "
+                         "its steady clocks (measured: the first ~100 steps of a process run 40 %% slower)")
     args = ap.parse_args()
 
     pkg = importlib.import_module(PKG)
@@ -85,6 +88,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ramp_steps, t_ramp = 0, time.perf_counter() + args.ramp_seconds       # clock ramp (see --ramp-seconds), untimed
+    while time.perf_counter() < t_ramp:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        ramp_steps += 20
     for _ in range(args.warmup):
         step()
     sync()
@@ -108,7 +117,7 @@ def main():
                                f"MPN L={LAYERS} H={HID} K={KHOPS} dropout=0: forward + gsp_wls_edge + backward"
                                + (" + RCCL loss-sum and gradient all-reduce" if distributed else ""),
                    "graphs_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                   "loss": float(loss.item())},
+                   "loss": float(loss.item()), "clock_ramp_steps_before_warmup": ramp_steps},
     }
 
     if rank == 0:

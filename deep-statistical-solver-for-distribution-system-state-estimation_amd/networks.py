@@ -720,6 +720,8 @@ class _MPNFn(torch.autograd.Function):
                 wgrad(topo, g, hout, S, hid, nmat, fold.gfold, rowscale2=topo.deg_pows)
                 dS = torch.empty(topo.N, hid, dtype=_F32, device=dev)
                 gemm_prop(topo, g, g.stride(0), hout, plan.bwd[1], nmat, hid, dS, transposed=True)
+                # (a side stream for this launch was measured: the cross-stream event waits cost more than the
+                # 17 us they hide)
                 fold.backward(flat)
                 g = None
                 break
