@@ -24,8 +24,16 @@ template <int NB> struct WgradGeom {
   static constexpr int NBW = NB >= 2 ? NB / 2 : 1;   // output blocks per wave
 };
 
+// Several layers of identical shape in ONE launch (blockIdx.z = layer): the layers of a block are
+// independent once all output gradients exist, and at small H one layer alone cannot fill the chip.
+constexpr int WGRAD_MAX_BATCH = 8;
+struct WgradBatch { const float* G[WGRAD_MAX_BATCH]; const float* X[WGRAD_MAX_BATCH]; float* slab[WGRAD_MAX_BATCH]; int n; long long slab_stride; };
+
 template <int NRB, int NMAT, int NB>
-__global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgrad_args p, int nibg) {
+__global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgrad_args p, int nibg, const WgradBatch wb) {
+  const float* __restrict__ Gp = wb.n > 0 ? wb.G[blockIdx.z] : p.G;
+  const float* __restrict__ Xp = wb.n > 0 ? wb.X[blockIdx.z] : p.X;
+  float* __restrict__ slabp = wb.n > 0 ? wb.slab[blockIdx.z] : p.slab;
   constexpr int TM = NRB * 32;
   constexpr int LDZ = NB * 32;
   constexpr int NW = WgradGeom<NB>::NW, NT = WgradGeom<NB>::NT, NBW = WgradGeom<NB>::NBW;
@@ -64,8 +72,8 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
 #pragma unroll
   for (int m = 0; m < NMAT; ++m) dbs[m] = 0.f;
 
-  const bool gvec = ((p.ldg & 3) == 0) && ((p.hout & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.G) & 15) == 0);
-  const bool xvec = ((p.ldx & 3) == 0) && ((p.hin & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
+  const bool gvec = ((p.ldg & 3) == 0) && ((p.hout & 3) == 0) && ((reinterpret_cast<uintptr_t>(Gp) & 15) == 0);
+  const bool xvec = ((p.ldx & 3) == 0) && ((p.hin & 3) == 0) && ((reinterpret_cast<uintptr_t>(Xp) & 15) == 0);
 
   auto mma = [&](const float* Z, f32x16 (&a)[NBW], int R) {
     if (!wave_active) return;
@@ -186,7 +194,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
         const int idx = tid + i * NT;
         const int r = idx / QG, c = (idx - r * QG) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < R && gcol0 + c < p.hout) v = *reinterpret_cast<const f32x4*>(p.G + (size_t)(ts + r) * p.ldg + gcol0 + c);
+        if (r < R && gcol0 + c < p.hout) v = *reinterpret_cast<const f32x4*>(Gp + (size_t)(ts + r) * p.ldg + gcol0 + c);
         pg[i] = v;
       }
     }
@@ -196,7 +204,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
         const int idx = tid + i * NT;
         const int r = idx / QX, c = (idx - r * QX) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < R && xcol0 + c < p.hin) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + xcol0 + c);
+        if (r < R && xcol0 + c < p.hin) v = *reinterpret_cast<const f32x4*>(Xp + (size_t)(ts + r) * p.ldx + xcol0 + c);
         px[i] = v;
       }
     }
@@ -213,7 +221,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     } else {
       for (int idx = tid; idx < TM * LDZ; idx += NT) {
         const int r = idx / LDZ, c = idx - r * LDZ;
-        Za[idx] = (r < R && gcol0 + c < p.hout) ? p.G[(size_t)(ts + r) * p.ldg + gcol0 + c] : 0.f;
+        Za[idx] = (r < R && gcol0 + c < p.hout) ? Gp[(size_t)(ts + r) * p.ldg + gcol0 + c] : 0.f;
       }
     }
     if (xvec) {
@@ -226,7 +234,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     } else {
       for (int idx = tid; idx < TM * XW; idx += NT) {
         const int r = idx / XW, c = idx - r * XW;
-        Xs[idx] = (r < R && xcol0 + c < p.hin) ? p.X[(size_t)(ts + r) * p.ldx + xcol0 + c] : 0.f;
+        Xs[idx] = (r < R && xcol0 + c < p.hin) ? Xp[(size_t)(ts + r) * p.ldx + xcol0 + c] : 0.f;
       }
     }
   };
@@ -305,7 +313,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
 
   // ---- one slab per workgroup column blockIdx.x; the y-slices tile the [nmat*hout, hin] matrix
   const size_t stride = (size_t)p.nmat * p.hout * p.hin + p.hout + (p.rowscale2 ? (size_t)p.nmat * p.hout : 0);
-  float* out = p.slab + (size_t)blockIdx.x * stride;
+  float* out = slabp + (size_t)blockIdx.x * (wb.slab_stride > 0 ? (size_t)wb.slab_stride : stride);
   if (wave_active) {
     const int i = xcol0 + ibw * 32 + c32;
     if (i < p.hin) {
@@ -353,7 +361,7 @@ static int pick_nb(int nrb, int nmat, int hout, int max_nnz, int ell_width) {
 }
 
 template <int NRB, int NMAT, int NB>
-static int launch_wgrad(const dss2_wgrad_args& a, hipStream_t stream) {
+static int launch_wgrad(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb) {
   static bool attr_set = false;
   auto kern = wgrad_kernel<NRB, NMAT, NB>;
   if (!attr_set) {
@@ -365,7 +373,7 @@ static int launch_wgrad(const dss2_wgrad_args& a, hipStream_t stream) {
   const int nob = (a.hout + 31) / 32, nib = (a.hin + 31) / 32;
   const int nobg = (nob + NB - 1) / NB, nibg = (nib + 3) / 4;
   const size_t lds = wgrad_lds(NRB, NMAT, NB, a.max_nnz, a.ell_width, NMAT > 1 || a.narrow);
-  hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg), dim3(WgradGeom<NB>::NT), lds, stream, a, nibg);
+  hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg, wb.n > 0 ? wb.n : 1), dim3(WgradGeom<NB>::NT), lds, stream, a, nibg, wb);
   return check_launch("wgrad");
 }
 
@@ -378,9 +386,8 @@ extern "C" size_t dss2_wgrad_lds_bytes(int nrb, int nmat, int hout, int hin, int
   return nb ? dss2::wgrad_lds(nrb, nmat, nb, max_nnz, ell_width, nmat > 1) : (size_t)-1;
 }
 
-extern "C" int dss2_wgrad(const dss2_wgrad_args* ap, void* stream) {
+static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::WgradBatch& wb) {
   using namespace dss2;
-  const dss2_wgrad_args& a = *ap;
   if (a.n_split <= 0 || !a.slab) { set_error("wgrad: n_split/slab missing"); return 2; }
   if (a.nmat > 1 && (!a.rowptrT || !a.colT || !a.wT)) { set_error("wgrad: nmat > 1 needs the transposed CSR"); return 2; }
   if (a.ell_width < 0 || a.ell_width > 32) { set_error("wgrad: ell_width %d out of range 0..32", a.ell_width); return 2; }
@@ -389,11 +396,11 @@ extern "C" int dss2_wgrad(const dss2_wgrad_args* ap, void* stream) {
     if (a.nmat * a.hout > 32) { set_error("wgrad: narrow mode needs nmat*hout <= 32"); return 2; }
     hipStream_t sn = as_stream(stream);
     switch (a.nrb) {
-      case 1: return launch_wgrad<1, 1, 1>(a, sn);
-      case 2: return launch_wgrad<2, 1, 1>(a, sn);
-      case 3: return launch_wgrad<3, 1, 1>(a, sn);
-      case 4: return launch_wgrad<4, 1, 1>(a, sn);
-      case 6: return launch_wgrad<6, 1, 1>(a, sn);
+      case 1: return launch_wgrad<1, 1, 1>(a, sn, wb);
+      case 2: return launch_wgrad<2, 1, 1>(a, sn, wb);
+      case 3: return launch_wgrad<3, 1, 1>(a, sn, wb);
+      case 4: return launch_wgrad<4, 1, 1>(a, sn, wb);
+      case 6: return launch_wgrad<6, 1, 1>(a, sn, wb);
       default: set_error("wgrad(narrow): unsupported nrb=%d", a.nrb); return 2;
     }
   }
@@ -401,7 +408,7 @@ extern "C" int dss2_wgrad(const dss2_wgrad_args* ap, void* stream) {
   if (!nb) { set_error("wgrad: tile of %d rows does not fit LDS (nmat=%d nnz=%d)", a.nrb * 32, a.nmat, a.max_nnz); return 3; }
   hipStream_t s = as_stream(stream);
 #define DSS2_CASE(NRB, NMAT, NB) \
-  if (a.nrb == NRB && a.nmat == NMAT && nb == NB) return launch_wgrad<NRB, NMAT, NB>(a, s);
+  if (a.nrb == NRB && a.nmat == NMAT && nb == NB) return launch_wgrad<NRB, NMAT, NB>(a, s, wb);
 #define DSS2_NMATS(NRB, NB) DSS2_CASE(NRB, 1, NB) DSS2_CASE(NRB, 2, NB) DSS2_CASE(NRB, 3, NB) DSS2_CASE(NRB, 4, NB)
   DSS2_NMATS(1, 1) DSS2_NMATS(1, 2) DSS2_NMATS(1, 4)
   DSS2_NMATS(2, 1) DSS2_NMATS(2, 2) DSS2_NMATS(2, 4)
@@ -412,4 +419,25 @@ extern "C" int dss2_wgrad(const dss2_wgrad_args* ap, void* stream) {
 #undef DSS2_CASE
   set_error("wgrad: unsupported (nrb=%d, nmat=%d, nb=%d)", a.nrb, a.nmat, nb);
   return 2;
+}
+
+extern "C" int dss2_wgrad(const dss2_wgrad_args* ap, void* stream) {
+  dss2::WgradBatch wb = {};
+  return wgrad_dispatch(*ap, stream, wb);
+}
+
+extern "C" int dss2_wgrad_batched(const dss2_wgrad_args* ap, const float* const* Gs, const float* const* Xs, float* const* slabs,
+                                  int64_t slab_stride, int n_layers, void* stream) {
+  if (n_layers < 1 || n_layers > dss2::WGRAD_MAX_BATCH) { dss2::set_error("wgrad_batched: 1..%d layers, got %d", dss2::WGRAD_MAX_BATCH, n_layers); return 2; }
+  if (!Gs || !Xs || !slabs) { dss2::set_error("wgrad_batched: null pointer table"); return 2; }
+  dss2::WgradBatch wb = {};
+  wb.n = n_layers;
+  wb.slab_stride = slab_stride;
+  for (int l = 0; l < n_layers; ++l) {
+    if (!Gs[l] || !Xs[l] || !slabs[l]) { dss2::set_error("wgrad_batched: layer %d has a null pointer", l); return 2; }
+    wb.G[l] = Gs[l]; wb.X[l] = Xs[l]; wb.slab[l] = slabs[l];
+  }
+  dss2_wgrad_args a = *ap;
+  a.G = Gs[0]; a.X = Xs[0]; a.slab = slabs[0];
+  return wgrad_dispatch(a, stream, wb);
 }

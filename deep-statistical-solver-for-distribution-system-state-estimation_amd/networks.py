@@ -102,7 +102,7 @@ def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int,
     rowscale2 additionally [nmat*hout] scaled column sums of P^m G (one block per matrix)."""
     narrow = nmat > 1 and nmat * hout <= 32 and rowscale2 is None
     lds = _lib.lib().dss2_wgrad_lds_bytes(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT)
-    per_cu = max(1, min(4, (160 * 1024) // max(int(lds), 1)))     # resident workgroups per CU by LDS
+    per_cu = max(1, min(_WGRAD_PER_CU, (160 * 1024) // max(int(lds), 1)))     # resident workgroups per CU by LDS
     n_split = min(topo.ntiles, 256 * per_cu)
     stride = nmat * hout * hin + hout + (nmat * hout if rowscale2 is not None else 0)
     slab = torch.empty(n_split * stride, dtype=_F32, device=G.device)
@@ -118,6 +118,34 @@ def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int,
     st = _stream(G)
     _lib.check(_lib.lib().dss2_wgrad(C.byref(a), st), "dss2_wgrad")
     _lib.check(_lib.lib().dss2_reduce_slabs(slab.data_ptr(), n_split, stride, out_flat.data_ptr(), stride, st),
+               "dss2_reduce_slabs")
+
+
+def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Sequence[torch.Tensor], hin: int, nmat: int,
+                  out_flat: torch.Tensor) -> None:
+    """len(Gs) layers of identical shape in one launch + one reduction:
+    out_flat[l * (nmat*hout*hin + hout) + ...] <- [dW_0 .. dW_{nmat-1}, db] of layer l."""
+    nl = len(Gs)
+    lds = _lib.lib().dss2_wgrad_lds_bytes(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT)
+    per_cu = max(1, min(_WGRAD_PER_CU, (160 * 1024) // max(int(lds), 1)))
+    n_split = min(topo.ntiles, max(1, (256 * per_cu) // nl))       # the layers share the chip
+    stride = nmat * hout * hin + hout
+    slab = torch.empty(n_split * nl * stride, dtype=_F32, device=Gs[0].device)
+    a = _lib.WgradArgs()
+    a.ldg, a.hout, a.ldx, a.hin = Gs[0].stride(0), hout, Xs[0].stride(0), hin
+    for g_, x_ in zip(Gs, Xs):
+        if g_.stride(0) != a.ldg or x_.stride(0) != a.ldx or g_.shape != Gs[0].shape or x_.shape != Xs[0].shape:
+            raise ValueError("wgrad_batched: layers must share shapes and leading dimensions")
+    a.n_split, a.nmat, a.nrb, a.ntiles = n_split, nmat, topo.nrb, topo.ntiles
+    a.tile_start = topo.tile_start.data_ptr()
+    a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
+    a.ell_width, a.ell_tiles = topo.ellT, _ptr(topo.ellT_tiles)
+    PtrArr = C.c_void_p * nl
+    gs, xs = PtrArr(*[g_.data_ptr() for g_ in Gs]), PtrArr(*[x_.data_ptr() for x_ in Xs])
+    sl = PtrArr(*[slab.data_ptr() + 4 * l * stride for l in range(nl)])
+    st = _stream(Gs[0])
+    _lib.check(_lib.lib().dss2_wgrad_batched(C.byref(a), gs, xs, sl, nl * stride, nl, st), "dss2_wgrad_batched")
+    _lib.check(_lib.lib().dss2_reduce_slabs(slab.data_ptr(), n_split, nl * stride, out_flat.data_ptr(), nl * stride, st),
                "dss2_reduce_slabs")
 
 
@@ -221,6 +249,7 @@ class _FoldPlan:
         _lib.check(_lib.lib().dss2_small_gemm(t.data_ptr(), n, mx, flat.data_ptr(), st), "dss2_small_gemm")
 
 
+_WGRAD_PER_CU = int(_os.environ.get("DSS2_WGRAD_PER_CU", "2"))   # cap on persistent wgrad workgroups per CU (= slabs / 256)
 FOLD_W2 = _os.environ.get("DSS2_FOLD_W2", "1") == "1"   # 0 = run the edge MLP's second Linear as its own GEMMs
 
 
@@ -399,6 +428,7 @@ def _tagconv_forward(topo, h, pack_fwd, bias, nmat, hin, hout, dmask=None, relu=
 _SIDE_STREAMS = {}
 EDGE_TILE_KERNELS = _os.environ.get("DSS2_EDGE_TILE", "1") == "1"       # 0 = row-per-wave CSR kernels
 WGRAD_SIDE_STREAM = _os.environ.get("DSS2_WGRAD_STREAM", "0") == "1"   # opt-in: +3 % at C2 (kernels then overlap)
+WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"          # hid->hid layers of a block: one wgrad launch
 
 
 def _side_stream(device):
@@ -409,12 +439,14 @@ def _side_stream(device):
 
 
 def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=None, dmask=None, need_dh=True,
-                      rowscale2=None):
+                      rowscale2=None, defer_wgrad=False):
     """g: gradient w.r.t. the conv's pre-activation output [N, hout] (already masked).
     g_flat <- [dW_0..dW_K, db]; returns dh (masked by relu_src / dmask of the PREVIOUS layer).
     The weight gradient only feeds the flat gradient buffer, so it may run on a side stream beside the
     data-gradient chain (the caller joins the streams before it hands the buffer to autograd)."""
-    if WGRAD_SIDE_STREAM and need_dh:
+    if defer_wgrad:      # the caller batches this layer's weight gradient with its siblings (wgrad_batched)
+        pass
+    elif WGRAD_SIDE_STREAM and need_dh:
         main = torch.cuda.current_stream(g.device)
         side = _side_stream(g.device)
         side.wait_stream(main)                      # g (and h) are ready on the main stream
@@ -711,6 +743,7 @@ class _MPNFn(torch.autograd.Function):
         flat = torch.empty(int(offs[-1]), dtype=_F32, device=dev)
         g = gout.contiguous()
         need_dx = ctx.needs_input_grad[0]
+        deferred = []
         for l in range(L - 1, -1, -1):
             hout = mod.dim_out if l == L - 1 else hid
             seg = flat[offs[2 + l]:offs[3 + l]]
@@ -726,8 +759,23 @@ class _MPNFn(torch.autograd.Function):
                 g = None
                 break
             # dgrad epilogue applies the ReLU / dropout mask of the layer BELOW (its output is acts[l])
+            defer = WGRAD_BATCH and not WGRAD_SIDE_STREAM and hout == hid and not is_narrow(nmat, hout)
+            if defer:
+                deferred.append((l, g, acts[l]))
             g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, hout, seg,
-                                  relu_src=(acts[l] if l > 0 else None), dmask=(masks[l - 1] if l > 0 else None))
+                                  relu_src=(acts[l] if l > 0 else None), dmask=(masks[l - 1] if l > 0 else None),
+                                  defer_wgrad=defer)
+        # weight gradients of the hid -> hid layers: independent of each other, so one launch (and one slab
+        # reduction) covers up to 8 consecutive layers; their segments in the flat buffer are contiguous
+        deferred.reverse()
+        for c0 in range(0, len(deferred), 8):
+            chunk = deferred[c0:c0 + 8]
+            l0, l1 = chunk[0][0], chunk[-1][0]
+            out = flat[offs[2 + l0]:offs[3 + l1]]
+            if len(chunk) == 1:
+                wgrad(topo, chunk[0][1], hid, chunk[0][2], hid, nmat, out)
+            else:
+                wgrad_batched(topo, [c[1] for c in chunk], hid, [c[2] for c in chunk], hid, nmat, out)
         dx = _edge_aggr_backward(topo, g, x, ldx, ea, ldea, W1, b1, S, plan.bwd[0], hid, hid, fn, fe,
                                  flat[offs[0]:offs[1]], flat[offs[1]:offs[2]], need_dx,
                                  pack_dx=(plan.bwd[1 + L], plan.bwd[2 + L]), dS=(dS if fold is not None else None))
