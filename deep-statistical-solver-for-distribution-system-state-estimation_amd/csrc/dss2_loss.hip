@@ -321,6 +321,80 @@ __global__ void __launch_bounds__(LB) pflow_kernel(const float* __restrict__ y, 
   pf[4] = f.pt; pf[5] = f.qt; pf[6] = f.i_f; pf[7] = f.i_t;
 }
 
+
+// ---- evaluation metrics of one test batch (dss2_run.py:178-206), accumulated on the device ------------
+// yhat = (v de-normalised, theta masked at the slack) (:183-184); then squared / absolute errors of v and
+// theta, of the line and trafo loadings where the true loading is non-zero (:196-205), and the sums for
+// the per-column standard deviations (:207-208).  18 double sums per block, fixed-order finish.
+constexpr int EV_SUMS = 18;
+__global__ void __launch_bounds__(LB) eval_denorm_kernel(const float* __restrict__ out, int64_t ldo,
+                                                         const float* __restrict__ node_param, int64_t ld_np,
+                                                         const float* __restrict__ x_mean, const float* __restrict__ x_std,
+                                                         float* __restrict__ yhat, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * LB + threadIdx.x;
+  if (i >= n) return;
+  yhat[2 * i + 0] = out[i * ldo] * x_std[0] + x_mean[0];
+  yhat[2 * i + 1] = out[i * ldo + 1] * (1.f - node_param[i * ld_np + 1]);
+}
+
+__global__ void __launch_bounds__(256) eval_partials_kernel(const float* __restrict__ yhat, const float* __restrict__ y, int64_t ldy,
+                                                            const float* __restrict__ pf_true, const float* __restrict__ pf_out,
+                                                            int64_t n, int64_t ne, double* __restrict__ partials) {
+  __shared__ double red[4][EV_SUMS];
+  double s[EV_SUMS];
+#pragma unroll
+  for (int k = 0; k < EV_SUMS; ++k) s[k] = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float a0 = yhat[2 * i], a1 = yhat[2 * i + 1], b0 = y[i * ldy], b1 = y[i * ldy + 1];
+    const float dv = a0 - b0, dt = a1 - b1;
+    s[0] += (double)(dv * dv); s[1] += (double)fabsf(dv);
+    s[2] += (double)(dt * dt); s[3] += (double)fabsf(dt);
+    s[4] += a0; s[5] += (double)a0 * a0; s[6] += a1; s[7] += (double)a1 * a1;
+    s[8] += b0; s[9] += (double)b0 * b0; s[10] += b1; s[11] += (double)b1 * b1;
+  }
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {       // 0: line loading, 1: trafo loading
+      const float t = pf_true[e * 8 + c];
+      if (t != 0.f) {
+        const float d = pf_out[e * 8 + c] - t;
+        s[12 + 3 * c] += (double)(d * d); s[13 + 3 * c] += (double)fabsf(d); s[14 + 3 * c] += 1.0;
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < EV_SUMS; ++k) {
+    double a = s[k];
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    if (lane == 0) red[wave][k] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < EV_SUMS)
+    partials[(size_t)blockIdx.x * EV_SUMS + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// acc[0..9] += rmse_v, mae_v, rmse_th, mae_th, rmse_loading, mae_loading, rmse_loading_trafos, mae_loading_trafos,
+//              prop_std_v, prop_std_th   (the per-batch quantities the reference sums over the test loader)
+__global__ void eval_finish_kernel(const double* __restrict__ partials, int nb, double n, double* __restrict__ acc) {
+  __shared__ double t[EV_SUMS];
+  if (threadIdx.x < EV_SUMS) {
+    double v = 0.0;
+    for (int b = 0; b < nb; ++b) v += partials[(size_t)b * EV_SUMS + threadIdx.x];
+    t[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  acc[0] += sqrt(t[0] / n); acc[1] += t[1] / n;
+  acc[2] += sqrt(t[2] / n); acc[3] += t[3] / n;
+  acc[4] += sqrt(t[12] / t[14]); acc[5] += t[13] / t[14];       // empty selection: 0/0 = nan, like mse_loss of nothing
+  acc[6] += sqrt(t[15] / t[17]); acc[7] += t[16] / t[17];
+  auto sd = [&](double sx, double sxx) { return sqrt((sxx - sx * sx / n) / (n - 1.0)); };   // unbiased, torch.std
+  acc[8] += sd(t[4], t[5]) / sd(t[8], t[9]) * 100.0;
+  acc[9] += sd(t[6], t[7]) / sd(t[10], t[11]) * 100.0;
+}
+
 }  // namespace dss2
 
 using namespace dss2;
@@ -356,4 +430,28 @@ extern "C" int dss2_get_pflow(const float* y, int64_t ldy, const float* node_par
   hipLaunchKernelGGL(pflow_kernel, dim3((unsigned)((n_edges + LB - 1) / LB)), dim3(LB), 0, s, y, ldy, edge_param, ld_ep,
                      efrom, eto, n_edges, vminmax, pflow);
   return check_launch("get_pflow");
+}
+
+extern "C" int64_t dss2_eval_scratch_doubles(void) { return 256 * dss2::EV_SUMS; }
+
+extern "C" int dss2_eval_batch(const float* out, int64_t ldo, const float* y, int64_t ldy, const float* node_param, int64_t ld_np,
+                               const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
+                               int64_t n_nodes, int64_t n_edges, const float* x_mean, const float* x_std, float* yhat,
+                               float* pf_true, float* pf_out, float* vminmax, double* scratch, double* acc, void* stream) {
+  if (n_nodes <= 1 || n_edges <= 0) { set_error("eval_batch: needs at least 2 nodes and 1 edge"); return 2; }
+  if (!out || !y || !node_param || !edge_param || !efrom || !eto || !x_mean || !x_std || !yhat || !pf_true || !pf_out ||
+      !vminmax || !scratch || !acc) { set_error("eval_batch: null argument"); return 2; }
+  hipStream_t s = as_stream(stream);
+  const unsigned nbn = (unsigned)((n_nodes + LB - 1) / LB), nbe = (unsigned)((n_edges + LB - 1) / LB);
+  hipLaunchKernelGGL(eval_denorm_kernel, dim3(nbn), dim3(LB), 0, s, out, ldo, node_param, ld_np, x_mean, x_std, yhat, n_nodes);
+  hipLaunchKernelGGL(vminmax_kernel, dim3(VMM_BLOCKS), dim3(256), 0, s, node_param, ld_np, n_nodes, vminmax);
+  hipLaunchKernelGGL(vminmax_finish_kernel, dim3(1), dim3(64), 0, s, vminmax);
+  hipLaunchKernelGGL(pflow_kernel, dim3(nbe), dim3(LB), 0, s, y, ldy, edge_param, ld_ep, efrom, eto, n_edges, vminmax, pf_true);
+  hipLaunchKernelGGL(pflow_kernel, dim3(nbe), dim3(LB), 0, s, yhat, (int64_t)2, edge_param, ld_ep, efrom, eto, n_edges, vminmax, pf_out);
+  int64_t m = n_nodes > n_edges ? n_nodes : n_edges;
+  int nb = (int)((m + 255) / 256);
+  if (nb > 256) nb = 256;
+  hipLaunchKernelGGL(eval_partials_kernel, dim3(nb), dim3(256), 0, s, yhat, y, ldy, pf_true, pf_out, n_nodes, n_edges, scratch);
+  hipLaunchKernelGGL(eval_finish_kernel, dim3(1), dim3(64), 0, s, scratch, nb, (double)n_nodes, acc);
+  return check_launch("eval_batch");
 }

@@ -135,3 +135,35 @@ def get_pflow(y, edge_index, node_param, edge_param, phase_shift=True):
                                          topo.efrom.data_ptr(), topo.eto.data_ptr(), topo.N, topo.E, vmm.data_ptr(),
                                          pf.data_ptr(), _stream(y)), "dss2_get_pflow")
     return tuple(pf[:, k] for k in range(8))
+
+
+EVAL_METRICS = ("rmse_v", "mae_v", "rmse_th", "mae_th", "rmse_loading", "mae_loading", "rmse_loading_trafos",
+                "mae_loading_trafos", "prop_std_v", "prop_std_th")
+
+
+def eval_batch(out, y, x, edge_index, edge_attr, x_mean, x_std, acc: torch.Tensor) -> torch.Tensor:
+    """/root/reference/dss2_run.py:178-208 for one test batch without leaving the device: ``acc`` (10 doubles,
+    EVAL_METRICS order) += the batch's RMSE / MAE of V and theta, of the line and trafo loadings, and the
+    std ratios.  ``x`` is the full [N, 11] node tensor (features + vn_kv, slack, zero_inj), ``edge_attr`` the
+    full [E, 13] one.  Returns yhat [N, 2] (de-normalised V, slack-masked theta)."""
+    _require_gpu(out, y, x, edge_index, edge_attr)
+    if acc.dtype != torch.float64 or acc.numel() < 10 or not acc.is_contiguous():
+        raise ValueError("acc must be a contiguous float64 tensor of 10 elements")
+    o2, ldo = _rows(out.detach())
+    y2, ldy = _rows(y)
+    npar, ld_np = _rows(x[:, 8:])
+    epar, ld_ep = _rows(edge_attr[:, 6:])
+    dev = out.device
+    topo = get_topology(edge_index, out.size(0))
+    L = _lib.lib()
+    xm, xs = _vec(x_mean, 1, dev), _vec(x_std, 1, dev)
+    yhat = torch.empty(topo.N, 2, dtype=_F32, device=dev)
+    pft = torch.empty(topo.E, 8, dtype=_F32, device=dev)
+    pfo = torch.empty(topo.E, 8, dtype=_F32, device=dev)
+    vmm = torch.empty(130, dtype=_F32, device=dev)
+    scratch = torch.empty(int(L.dss2_eval_scratch_doubles()), dtype=torch.float64, device=dev)
+    _lib.check(L.dss2_eval_batch(o2.data_ptr(), ldo, y2.data_ptr(), ldy, npar.data_ptr(), ld_np, epar.data_ptr(), ld_ep,
+                                 topo.efrom.data_ptr(), topo.eto.data_ptr(), topo.N, topo.E, xm.data_ptr(), xs.data_ptr(),
+                                 yhat.data_ptr(), pft.data_ptr(), pfo.data_ptr(), vmm.data_ptr(), scratch.data_ptr(),
+                                 acc.data_ptr(), _stream(out)), "dss2_eval_batch")
+    return yhat

@@ -77,28 +77,19 @@ def train_epoch(model, opt, loader, stats, reg_coefs, group=None) -> float:
 
 @torch.no_grad()
 def evaluate(model, loader, stats) -> Dict[str, float]:
-    """dss2_run.py:165-224: RMSE / MAE of V and theta, and of line / trafo loading from get_pflow."""
+    """dss2_run.py:165-224: RMSE / MAE of V and theta and of the line / trafo loadings from get_pflow, and the
+    std ratios, averaged over the test batches.  The ten per-batch quantities are accumulated on the device
+    (``data.eval_batch``); one device-to-host copy per evaluation."""
     model.eval()                                                     # dropout stays active, as in the reference
-    acc = {k: 0.0 for k in ("rmse_v", "mae_v", "rmse_th", "mae_th", "rmse_loading", "mae_loading",
-                            "rmse_loading_trafos", "mae_loading_trafos")}
+    acc = torch.zeros(10, dtype=torch.float64, device=stats[0].device)
+    n = 0
     for data in loader:
         x, ei, ea, y, _ = _fields(data)
         out = model(x[:, :8], ei, ea[:, :6])
-        out = torch.cat([out[:, 0:1] * stats[1][:1] + stats[0][:1], out[:, 1:]], dim=1)      # :183
-        out[:, 1:] *= (1.0 - x[:, 9:10])                                                     # :184
-        acc["rmse_v"] += torch.sqrt(torch.mean((out[:, :1] - y[:, :1]) ** 2)).item()
-        acc["rmse_th"] += torch.sqrt(torch.mean((out[:, 1:] - y[:, 1:]) ** 2)).item()
-        acc["mae_v"] += (out[:, :1] - y[:, :1]).abs().mean().item()
-        acc["mae_th"] += (out[:, 1:] - y[:, 1:]).abs().mean().item()
-        t_lines, t_trafos = dss2_data.get_pflow(y, ei, node_param=x[:, 8:], edge_param=ea[:, 6:])[0:2]   # :193
-        o_lines, o_trafos = dss2_data.get_pflow(out, ei, node_param=x[:, 8:], edge_param=ea[:, 6:])[0:2]  # :194
-        for tag, t_, o_ in (("loading", t_lines, o_lines), ("loading_trafos", t_trafos, o_trafos)):
-            nz = t_ != 0                                                                     # :196-200
-            if nz.any():
-                d = o_[nz] - t_[nz]
-                acc["rmse_" + tag] += torch.sqrt(torch.mean(d ** 2)).item()
-                acc["mae_" + tag] += d.abs().mean().item()
-    return {k: v / max(len(loader), 1) for k, v in acc.items()}
+        dss2_data.eval_batch(out, y, x, ei, ea, stats[0], stats[1], acc)
+        n += 1
+    vals = (acc / max(n, 1)).cpu().tolist()
+    return dict(zip(dss2_data.EVAL_METRICS, vals))
 
 
 def main(argv=None):

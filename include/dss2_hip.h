@@ -242,6 +242,20 @@ int dss2_get_pflow(const float* y, int64_t ldy, const float* node_param, int64_t
                    const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
                    int64_t n_nodes, int64_t n_edges, float* vminmax, float* pflow, void* stream);
 
+/* ---- evaluation metrics of one test batch (/root/reference/dss2_run.py:178-208), kept on the
+ *      device: yhat[N,2] <- (out[:,0] * x_std[0] + x_mean[0], out[:,1] * (1 - slack)); get_pflow of the labels y and
+ *      of yhat (pf_true / pf_out [E,8] as dss2_get_pflow); then
+ *      acc[0..9] += rmse_v, mae_v, rmse_th, mae_th, rmse_loading, mae_loading, rmse_loading_trafos,
+ *                   mae_loading_trafos, prop_std_v, prop_std_th
+ *      (loadings compared where the true loading != 0; std unbiased like torch.std): the ten per-batch
+ *      quantities the reference sums over its test loader, so an epoch's evaluation needs ONE device-to-host copy.
+ *      scratch: dss2_eval_scratch_doubles() device doubles; vminmax: 130 device floats.                          */
+int dss2_eval_batch(const float* out, int64_t ldo, const float* y, int64_t ldy, const float* node_param, int64_t ld_np,
+                    const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
+                    int64_t n_nodes, int64_t n_edges, const float* x_mean, const float* x_std, float* yhat,
+                    float* pf_true, float* pf_out, float* vminmax, double* scratch, double* acc, void* stream);
+int64_t dss2_eval_scratch_doubles(void);
+
 /* ---- batched small dense products in weight space (folding the edge MLP's second Linear into conv 0
  *      and the chain rule back): C[M,N] (+)= sum_b op(A_b)[M,K] . op(B_b)[K,N]  (+ u[i] * v[j]).     */
 typedef struct dss2_sgemm_desc {

@@ -137,3 +137,30 @@ def test_training_from_the_device_loader(pkg, built):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     m = pkg.runner.evaluate(model, pkg.dataset.DataLoader(ds, batch_size=32), tuple(stats))
     assert all(np.isfinite(v) for v in m.values())
+
+
+def test_device_side_evaluation_metrics(pkg, oracle, built):
+    """dss2_run.py:178-208: the ten per-batch test metrics accumulated on the device (dss2_eval_batch) against the
+    oracle's torch restatement, on real CIGRE-14 samples."""
+    g, ds, stats = built
+    torch.manual_seed(1)
+    model = pkg.MPN(8, 6, 2, 32, 2, 2, 0.0).to(DEV)
+    acc = torch.zeros(10, dtype=torch.float64, device=DEV)
+    want = {k: 0.0 for k in pkg.data.EVAL_METRICS}
+    n = 0
+    with torch.no_grad():
+        for b in pkg.dataset.DataLoader(ds, batch_size=24):
+            out = model(b.x[:, :8], b.edge_index, b.edge_attr[:, :6])
+            yhat = pkg.data.eval_batch(out, b.y, b.x, b.edge_index, b.edge_attr, stats[0], stats[1], acc)
+            m, yh = oracle.eval_batch_metrics(out.cpu().double(), b.y.cpu().double(), b.x.cpu().double(), b.edge_index.cpu(),
+                                              b.edge_attr.cpu().double(), stats[0].cpu().double(), stats[1].cpu().double())
+            assert torch.allclose(yhat.cpu().double(), yh, rtol=1e-6, atol=1e-7)
+            for k in want:
+                want[k] += m[k]
+            n += 1
+    got = dict(zip(pkg.data.EVAL_METRICS, acc.cpu().tolist()))
+    for k in want:
+        assert abs(got[k] - want[k]) <= 2e-5 * abs(want[k]) + 1e-9, (k, got[k], want[k])
+    ev = pkg.runner.evaluate(model, pkg.dataset.DataLoader(ds, batch_size=24), tuple(stats))
+    for k in want:
+        assert abs(ev[k] - want[k] / n) <= 2e-5 * abs(want[k] / n) + 1e-9, k
