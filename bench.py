@@ -9,8 +9,8 @@ A step = one pass of the hot path over one resident batch: MPN forward -> gsp_wl
 Workload at every N (weak scaling): CIGRE-14, B = 4096 graphs per GPU, MPN(8, 6, 2, H=128, L=4, K=2),
 dropout 0, fp32, synthetic states on the reference's CIGRE-14 parameter tables, random-init weights.
 Rank 0 prints ONE JSON line (contract in the task brief) with two extra objects:
-  roofline     : the dominant kernel (fused MFMA GEMM + propagation, hid->hid TAGConv launches),
-                 timed in situ with HIP events in an instrumented pass after the timed region
+  roofline     : the dominant kernel (fused MFMA GEMM + propagation over chains of hid->hid TAGConv
+                 layers), timed in situ with HIP events in an instrumented pass after the timed region
   cpu_baseline : the CPU oracle (a port of the reference's PyTorch-eager path, dead dense Laplacian
                  stripped) timed on this box's host cores on the same batch (N = 1 only)
 """
@@ -121,48 +121,65 @@ def main():
     }
 
     if rank == 0:
-        # ---- roofline of the dominant kernel, timed in situ (instrumented pass, not the timed region)
+        # ---- roofline of the dominant kernel, timed in situ (instrumented pass, not the timed region).
+        # The H -> H TAGConv layers (forward) and their data-gradients (backward) run as layer chains
+        # (gemm_chain_kernel: one launch per chain, activation tile resident in LDS); FLOPs per launch =
+        # layers in the chain x the per-layer GEMM + propagation FLOPs.
         N, E2 = x.shape[0], 2 * ei.shape[1]
         events = []
-        orig = pkg.networks.gemm_prop
+        nw_mod = pkg.networks
+        orig_chain, orig_single = nw_mod.gemm_prop_chain, nw_mod.gemm_prop
 
-        def timed_gemm_prop(topo, X, ldx, kreal, Bp, nmat, hout, Y, **kw):
+        def timed_chain(topo, X, hid, nmat, layers, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig_chain(topo, X, hid, nmat, layers, **kw)
+            e1.record()
+            events.append((e0, e1, len(layers)))
+
+        def timed_single(topo, X, ldx, kreal, Bp, nmat, hout, Y, **kw):   # DSS2_CHAIN=0: one launch per layer
             dominant = (kreal == HID and hout == HID and nmat == KHOPS + 1)
             if dominant:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            orig(topo, X, ldx, kreal, Bp, nmat, hout, Y, **kw)
+            orig_single(topo, X, ldx, kreal, Bp, nmat, hout, Y, **kw)
             if dominant:
                 e1.record()
-                events.append((e0, e1))
+                events.append((e0, e1, 1))
 
         def timed_pass(n_steps):
             events.clear()
-            pkg.networks.gemm_prop = timed_gemm_prop
+            nw_mod.gemm_prop_chain, nw_mod.gemm_prop = timed_chain, timed_single
             for _ in range(n_steps):
                 step()
             torch.cuda.synchronize()
-            pkg.networks.gemm_prop = orig
-            durs = sorted(a.elapsed_time(b) for a, b in events)
-            return sum(durs) / len(durs), durs[len(durs) // 2], len(durs)
+            nw_mod.gemm_prop_chain, nw_mod.gemm_prop = orig_chain, orig_single
+            durs = sorted(a.elapsed_time(b) for a, b, _ in events)
+            layers = sum(n for _, _, n in events)
+            return sum(durs) / len(durs), durs[len(durs) // 2], len(durs), layers / len(durs)
 
-        flops = 2.0 * N * HID * (KHOPS + 1) * HID + 2.0 * KHOPS * E2 * HID
+        flops_layer = 2.0 * N * HID * (KHOPS + 1) * HID + 2.0 * KHOPS * E2 * HID
+        bytes_layer = 4.0 * N * HID + 4.0 * (KHOPS + 1) * HID * HID          # write the output once + the weights
+        avg_ms, med_ms, n_l, layers_per_launch = timed_pass(min(args.steps, 20))
+        chained = layers_per_launch > 1
+        kname = "gemm_chain_kernel<2,3>" if chained else "gemm_prop_kernel<2,3,false>"
         traffic = None
         try:   # HBM bytes per launch from the committed PMC runs (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                traffic = json.load(fh)["gemm_prop_kernel<2,3,false>"]["hbm_bytes_per_launch"]
+                traffic = json.load(fh)[kname]["hbm_bytes_per_launch"]
         except Exception:
             pass
+        flops = flops_layer * layers_per_launch
         # in situ, exactly as the timed region runs (single stream unless --overlap-wgrad): the average
         # agrees with `rocprofv3 --kernel-trace --stats` of this same command (profiles/)
-        avg_ms, med_ms, n_l = timed_pass(min(args.steps, 20))
         result["roofline"] = {
-            "kernel": "dss2::gemm_prop_kernel<2,3,false> (TAGConv H->H forward and data-gradient launches)",
+            "kernel": f"dss2::{kname} (TAGConv H->H layers, forward and data-gradient"
+                      + (f", {layers_per_launch:.0f} layers chained per launch)" if chained else ")"),
             "bound": "mfma", "achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
             "frac": flops / (avg_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "traffic": traffic,
-            "launches_timed": n_l, "avg_launch_us": avg_ms * 1e3, "median_launch_us": med_ms * 1e3,
-            "algorithmic_flops_per_launch": flops,
-            "algorithmic_bytes_per_launch": 2.0 * 4 * N * HID + 4.0 * (KHOPS + 1) * HID * HID,
+            "launches_timed": n_l, "layers_per_launch": layers_per_launch, "avg_launch_us": avg_ms * 1e3,
+            "median_launch_us": med_ms * 1e3, "algorithmic_flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": 4.0 * N * HID + bytes_layer * layers_per_launch,
             "mode": "side-stream overlap on" if pkg.networks.WGRAD_SIDE_STREAM else "single stream",
         }
         # ---- standalone scatter-add (K6) against the HBM roofline (north_star asks for it separately)

@@ -49,6 +49,11 @@ class WgradArgs(C.Structure):
                 ("narrow", C.c_int32), ("pad_", C.c_int32)]
 
 
+class ChainLayer(C.Structure):
+    _fields_ = [("Bp", C.c_void_p), ("bias", C.c_void_p), ("relu_src", C.c_void_p), ("dmask", C.c_void_p),
+                ("add_src", C.c_void_p), ("prebias", C.c_void_p), ("Y", C.c_void_p), ("relu", C.c_int32), ("pad_", C.c_int32)]
+
+
 class CollateDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("chunk", C.c_int32), ("kind", C.c_int32),
                 ("shared", C.c_int32), ("pad_", C.c_int32), ("nodes_per_sample", C.c_int64)]
@@ -100,6 +105,8 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dss2_gemm_prop": (C.c_int, [C.POINTER(GemmPropArgs), C.c_void_p]),
+    "dss2_gemm_prop_chain": (C.c_int, [C.POINTER(GemmPropArgs), C.c_void_p, C.c_int, C.c_void_p]),
+    "dss2_gemm_prop_chain_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p]),
     "dss2_wgrad_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "dss2_reduce_slabs": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),

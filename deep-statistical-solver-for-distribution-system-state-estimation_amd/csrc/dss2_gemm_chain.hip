@@ -1,0 +1,278 @@
+// Layer-chained variant of gemm_prop (keep a graph resident in LDS across layers).
+//
+// Tiles hold whole graphs, so layer l+1 of a tile depends only on layer l of the SAME tile: a chain of
+// H -> H TAGConv layers (forward) or of their data-gradients (backward) runs inside one workgroup with the
+// activation tile staying in LDS.  Every layer's output still goes to HBM once (the backward pass and the
+// weight gradients read it), but it is never read back, and the per-launch ramp/drain is paid once per
+// chain instead of once per layer.  Per layer: MFMA over the X tile -> barrier (everyone is done reading
+// X) -> Horner in the wave-private stage -> epilogue to HBM and, in place, into the X tile -> barrier.
+//
+// Restricted to what the hot configurations need (the general kernel covers the rest): ELL tile slices,
+// 16-byte aligned operands, one 32-column group per wave (H <= 128), H_in == H_out for every layer.
+#include "dss2_common.hpp"
+
+namespace dss2 {
+
+constexpr int CHAIN_MAX = 8;
+struct ChainTable { dss2_chain_layer l[CHAIN_MAX]; int n; };
+
+constexpr int chain_waves_per_simd(int nrb, int nmat) { return nrb * nmat * 16 <= 128 ? 2 : 1; }
+
+template <int NRB, int NMAT>
+__global__ void __launch_bounds__(256, chain_waves_per_simd(NRB, NMAT)) gemm_chain_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
+  constexpr int TM = NRB * 32;
+  constexpr int PF = 8;
+  constexpr int LDA = TM + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nthreads = blockDim.x;
+  const int nw = nthreads >> 6;
+  const int LDX = p.kpad + 4;
+  const int tile = blockIdx.x;
+  float* Xs = smem;
+  float* stage = Xs + TM * LDX;
+  const int D = p.ell_width;
+  int2* ell = reinterpret_cast<int2*>(stage + nw * 32 * LDA);
+  const int ts = p.tile_start[tile];
+  const int R = p.tile_start[tile + 1] - ts;
+  const int kq = p.kpad >> 2;
+
+  // ---- stage the first layer's input tile (zero padded to TM x kpad) and the tile's ELL slice
+  if (TM * kq <= PF * nthreads) {
+    f32x4 px[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int idx = tid + i * nthreads;
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < TM * kq && r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
+      px[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int idx = tid + i * nthreads;
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      if (idx < TM * kq) *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = px[i];
+    }
+  } else {
+    for (int idx = tid; idx < TM * kq; idx += nthreads) {
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
+      *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = v;
+    }
+  }
+  {
+    const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
+    for (int idx = tid; idx < D * TM; idx += nthreads) ell[idx] = src[idx];
+  }
+  __syncthreads();
+
+  const int c32 = lane & 31, half = lane >> 5;
+  const int nkk = p.kpad >> 3;
+  const float* xa = Xs + c32 * LDX + half * 4;
+  float* st = stage + wave * (32 * LDA);   // wave-private [TM][32] row-major
+  const int cg = wave;                      // one column group per wave
+  const int ecol0 = cg * 32 + (lane & 7) * 4;
+  const int cq = (lane & 7) * 4, r8 = lane >> 3;
+  const bool ecol_ok = ecol0 < p.hout;
+
+  for (int li = 0; li < ct.n; ++li) {
+    const dss2_chain_layer& L = ct.l[li];    // uniform: scalar loads from the kernel-argument segment
+    const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(L.Bp);
+    f32x16 acc[NRB][NMAT];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][m][r] = 0.f;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (L.bias && ecol_ok) bias4 = *reinterpret_cast<const f32x4*>(L.bias + ecol0);
+
+    // ---- MFMA over the X tile: 8 k per step, A (LDS) / B (packed weights, L2) ping-pong prefetch
+    f32x4 a0[NRB] = {}, a1[NRB] = {}, b0[NMAT] = {}, b1[NMAT] = {};
+    auto load_ab = [&](f32x4 (&a)[NRB], f32x4 (&b)[NMAT], int kk) {
+      const int kc = kk < nkk ? kk : nkk - 1;
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(xa + rb * 32 * LDX + kc * 8);
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) b[m] = bp[((size_t)(m * p.ncg + cg) * nkk + kc) * 64 + lane];
+    };
+    auto mma_ab = [&](const f32x4 (&a)[NRB], const f32x4 (&b)[NMAT]) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m)
+            acc[rb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][s], b[m][s], acc[rb][m], 0, 0, 0);
+    };
+    load_ab(a0, b0, 0);
+    int kk = 0;
+    for (; kk + 2 <= nkk; kk += 2) {
+      load_ab(a1, b1, kk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_ab(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_ab(a0, b0, kk + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_ab(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kk < nkk) mma_ab(a0, b0);
+    // every wave is done with this layer's X tile: the epilogue below overwrites it in place
+    if (li + 1 < ct.n) __syncthreads();
+
+    // ---- Horner: T = G_{NMAT-1}; T = G_m + P T   (ELL slice, wave-private stage)
+    f32x16 T[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) T[rb] = acc[rb][NMAT - 1];
+#pragma unroll
+    for (int m = NMAT - 2; m >= 0; --m) {
+      wave_lds_sync();
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
+      wave_lds_sync();
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) T[rb] = acc[rb][m];
+      for (int k = 0; k < D; ++k) {
+        const int2* ek = ell + k * TM + 4 * half;
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int2 en = ek[rb * 32 + acc_row(r, 0)];
+            T[rb][r] = fmaf(__int_as_float(en.y), st[en.x * 32 + c32], T[rb][r]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+
+    // ---- epilogue: T -> stage -> 16-byte rows -> HBM (and the next layer's X tile)
+    f32x4 pb4[NMAT];
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m) pb4[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (L.prebias && ecol_ok) {
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) pb4[m] = *reinterpret_cast<const f32x4*>(L.prebias + (size_t)m * p.hout + ecol0);
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
+    wave_lds_sync();
+    const int col0 = cg * 32 + cq;
+    const bool keep = li + 1 < ct.n;
+    if (col0 < p.hout) {
+      for (int row0 = r8; row0 < R; row0 += 16) {
+        f32x4 y[2], rs[2], dm[2], ad[2], ps[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int row = row0 + 8 * u;
+          const bool ok = row < R;
+          const size_t grow = (size_t)(ts + (ok ? row : 0));
+          y[u] = *reinterpret_cast<const f32x4*>(st + (ok ? row : 0) * 32 + cq);
+          if (L.prebias) ps[u] = *reinterpret_cast<const f32x4*>(p.pre_rowscale + grow * 4);
+          if (L.dmask) dm[u] = *reinterpret_cast<const f32x4*>(L.dmask + grow * p.ld_dmask + col0);
+          if (L.relu_src) rs[u] = *reinterpret_cast<const f32x4*>(L.relu_src + grow * p.ld_relu + col0);
+          if (L.add_src) ad[u] = *reinterpret_cast<const f32x4*>(L.add_src + grow * p.ld_add + col0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int row = row0 + 8 * u;
+          if (row >= R) continue;
+          f32x4 v = y[u];
+          if (L.bias) v += bias4;
+          if (L.prebias) {
+#pragma unroll
+            for (int m = 0; m < NMAT; ++m) v += pb4[m] * ps[u][m];
+          }
+          if (L.dmask) v *= dm[u];
+          if (L.relu & 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+          }
+          if (L.relu_src) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = rs[u][q] > 0.f ? v[q] : 0.f;
+          }
+          if (L.add_src) v += ad[u];
+          *reinterpret_cast<f32x4*>(L.Y + (size_t)(ts + row) * p.ldy + col0) = v;
+          if (keep) *reinterpret_cast<f32x4*>(Xs + row * LDX + col0) = v;
+        }
+      }
+    }
+    if (keep) __syncthreads();   // the next layer's X tile is complete
+  }
+}
+
+static size_t chain_lds_bytes(int nrb, int kpad, int nw, int ell_width) {
+  const size_t TM = (size_t)nrb * 32;
+  return TM * (size_t)(kpad + 4) * 4 + (size_t)nw * 32 * (TM + 4) * 4 + TM * (size_t)ell_width * 8;
+}
+
+template <int NRB, int NMAT>
+static int launch_chain(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = gemm_chain_kernel<NRB, NMAT>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
+    if (e != hipSuccess) { set_error("gemm_prop_chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg), chain_lds_bytes(NRB, a.kpad, a.ncg, a.ell_width), stream, a, ct);
+  return check_launch("gemm_prop_chain");
+}
+
+}  // namespace dss2
+
+extern "C" int dss2_gemm_prop_chain_supported(int nrb, int nmat, int kreal, int hout, int ell_width) {
+  using namespace dss2;
+  if (nmat < 2 || nmat > 4 || nrb * nmat > 9 || !(nrb == 1 || nrb == 2 || nrb == 3 || nrb == 4)) return 0;
+  if (kreal != hout || (hout & 3) != 0 || hout > 128 || ell_width <= 0 || ell_width > 32) return 0;
+  const int kpad = (kreal + 7) / 8 * 8, ncg = (hout + 31) / 32;
+  return chain_lds_bytes(nrb, kpad, ncg, ell_width) <= (size_t)kMaxLdsBytes ? 1 : 0;
+}
+
+extern "C" int dss2_gemm_prop_chain(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, void* stream) {
+  using namespace dss2;
+  const dss2_gemm_prop_args& a = *ap;
+  if (n_layers < 1 || n_layers > CHAIN_MAX || !layers) { set_error("gemm_prop_chain: 1..%d layers, got %d", CHAIN_MAX, n_layers); return 2; }
+  if (a.ntiles <= 0) return 0;
+  if (!dss2_gemm_prop_chain_supported(a.nrb, a.nmat, a.kreal, a.hout, a.ell_width) || !a.ell_tiles || a.prop_in || a.narrow_h ||
+      a.rowscale || a.kpad != (a.kreal + 7) / 8 * 8 || a.ncg != (a.hout + 31) / 32) {
+    set_error("gemm_prop_chain: unsupported shape (nrb=%d nmat=%d k=%d hout=%d ell=%d); use dss2_gemm_prop per layer",
+              a.nrb, a.nmat, a.kreal, a.hout, a.ell_width);
+    return 2;
+  }
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (!a.X || !al16(a.X) || (a.ldx & 3) || (a.ldy & 3) || (a.ld_relu & 3) || (a.ld_dmask & 3) || (a.ld_add & 3)) {
+    set_error("gemm_prop_chain: operands must be 16-byte aligned with leading dimensions divisible by 4"); return 2;
+  }
+  ChainTable ct = {};
+  ct.n = n_layers;
+  bool any_pre = false;
+  for (int i = 0; i < n_layers; ++i) {
+    const dss2_chain_layer& L = layers[i];
+    if (!L.Bp || !L.Y || !al16(L.Y) || !al16(L.bias) || !al16(L.relu_src) || !al16(L.dmask) || !al16(L.add_src) || !al16(L.prebias)) {
+      set_error("gemm_prop_chain: layer %d has a missing or misaligned operand", i); return 2;
+    }
+    any_pre = any_pre || L.prebias;
+    ct.l[i] = L;
+  }
+  if (any_pre && !a.pre_rowscale) { set_error("gemm_prop_chain: prebias needs pre_rowscale"); return 2; }
+  hipStream_t s = as_stream(stream);
+#define DSS2_CASE(NRB, NMAT) if (a.nrb == NRB && a.nmat == NMAT) return launch_chain<NRB, NMAT>(a, ct, s);
+  DSS2_CASE(1, 2) DSS2_CASE(1, 3) DSS2_CASE(1, 4) DSS2_CASE(2, 2) DSS2_CASE(2, 3) DSS2_CASE(2, 4)
+  DSS2_CASE(3, 2) DSS2_CASE(3, 3) DSS2_CASE(4, 2)
+#undef DSS2_CASE
+  set_error("gemm_prop_chain: unsupported (nrb=%d, nmat=%d)", a.nrb, a.nmat);
+  return 2;
+}

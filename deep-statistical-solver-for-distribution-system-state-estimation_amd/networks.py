@@ -96,6 +96,40 @@ def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.T
     _lib.check(_lib.lib().dss2_gemm_prop(C.byref(a), _stream(Y)), "dss2_gemm_prop")
 
 
+def chain_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bool:
+    """True when n >= 2 consecutive hid -> hid layers can run as one chained launch (dss2_gemm_prop_chain)."""
+    ell, tiles = (topo.ellT, topo.ellT_tiles) if transposed else (topo.ell, topo.ell_tiles)
+    return CHAIN_LAYERS and tiles is not None and bool(
+        _lib.lib().dss2_gemm_prop_chain_supported(topo.nrb, nmat, hid, hid, ell))
+
+
+def gemm_prop_chain(topo: Topology, X: torch.Tensor, hid: int, nmat: int, layers: Sequence[dict], transposed: bool = False,
+                    pre_rowscale=None) -> None:
+    """layers: dicts with Bp, Y and optionally bias, relu, relu_src, dmask, prebias; every tensor is [N, hid]
+    contiguous.  Layer i reads layer i-1's output from LDS; every Y is written once."""
+    a = _lib.GemmPropArgs()
+    a.X, a.ldx, a.kreal, a.kpad = X.data_ptr(), X.stride(0), hid, _round8(hid)
+    a.hout, a.ncg, a.ldy, a.ld_relu, a.ld_dmask, a.ld_add = hid, _ncg(hid), hid, hid, hid, hid
+    a.nmat, a.nrb, a.ntiles = nmat, topo.nrb, topo.ntiles
+    a.tile_start = topo.tile_start.data_ptr()
+    a.pre_rowscale = _ptr(pre_rowscale)
+    if transposed:
+        a.rowptr, a.col, a.w, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
+        a.ell_width, a.ell_tiles = topo.ellT, _ptr(topo.ellT_tiles)
+    else:
+        a.rowptr, a.col, a.w, a.max_nnz = topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.w.data_ptr(), topo.max_nnz
+        a.ell_width, a.ell_tiles = topo.ell, _ptr(topo.ell_tiles)
+    tab = (_lib.ChainLayer * len(layers))()
+    for d, ly in zip(tab, layers):
+        for t_ in (ly["Y"], ly.get("relu_src"), ly.get("dmask")):
+            if t_ is not None and (t_.stride(0) != hid or t_.stride(1) != 1):
+                raise ValueError("gemm_prop_chain: [N, hid] contiguous tensors expected")
+        d.Bp, d.Y, d.bias = ly["Bp"].data_ptr(), ly["Y"].data_ptr(), _ptr(ly.get("bias"))
+        d.relu_src, d.dmask, d.prebias = _ptr(ly.get("relu_src")), _ptr(ly.get("dmask")), _ptr(ly.get("prebias"))
+        d.relu = int(bool(ly.get("relu", False)))
+    _lib.check(_lib.lib().dss2_gemm_prop_chain(C.byref(a), C.addressof(tab), len(layers), _stream(X)), "dss2_gemm_prop_chain")
+
+
 def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int, nmat: int, out_flat: torch.Tensor,
           rowscale=None, rowscale2=None) -> None:
     """out_flat[nmat*hout*hin + hout] <- [dW_0 .. dW_{nmat-1}, db] (deterministic two-pass sum); with
@@ -428,6 +462,7 @@ def _tagconv_forward(topo, h, pack_fwd, bias, nmat, hin, hout, dmask=None, relu=
 _SIDE_STREAMS = {}
 EDGE_TILE_KERNELS = _os.environ.get("DSS2_EDGE_TILE", "1") == "1"       # 0 = row-per-wave CSR kernels
 WGRAD_SIDE_STREAM = _os.environ.get("DSS2_WGRAD_STREAM", "0") == "1"   # opt-in: +3 % at C2 (kernels then overlap)
+CHAIN_LAYERS = _os.environ.get("DSS2_CHAIN", "1") == "1"               # hid->hid layers of a block: one chained launch
 WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"          # hid->hid layers of a block: one wgrad launch
 
 
@@ -698,13 +733,29 @@ class _MPNFn(torch.autograd.Function):
             h = S            # conv 0 consumes the aggregated hidden directly
         acts, masks = [h], []
         p = float(mod.dropout_rate)
-        for l in range(L):
+
+        def drop_mask(hout):   # dropout is active regardless of .training (networks.py:268)
+            if p <= 0.0:
+                return None
+            return (torch.rand(topo.N, hout, device=dev) >= p).to(_F32).div_(1.0 - p) if p < 1.0 else \
+                torch.zeros(topo.N, hout, device=dev)
+
+        # the hid -> hid layers 0 .. L-2 as ONE chained launch (activation tile stays in LDS between layers)
+        n_chain = L - 1 if (L - 1 >= 2 and chain_supported(topo, nmat, hid, False)) else 0
+        if n_chain:
+            layers = []
+            for l in range(n_chain):
+                masks.append(drop_mask(hid))
+                out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
+                layers.append(dict(Bp=plan.fwd[1 + l], Y=out_l, bias=conv_ps[l][0], relu=True, dmask=masks[l],
+                                   prebias=(fold.bf if (fold is not None and l == 0) else None)))
+                acts.append(out_l)
+            gemm_prop_chain(topo, h, hid, nmat, layers, pre_rowscale=(topo.deg_pows if fold is not None else None))
+            h = acts[-1]
+        for l in range(n_chain, L):
             last = l == L - 1
             hout = mod.dim_out if last else hid
-            dmask = None
-            if not last and p > 0.0:  # dropout is active regardless of .training (networks.py:268)
-                dmask = (torch.rand(topo.N, hout, device=dev) >= p).to(_F32).div_(1.0 - p) if p < 1.0 else \
-                    torch.zeros(topo.N, hout, device=dev)
+            dmask = None if last else drop_mask(hout)
             masks.append(dmask)
             pre = (fold.bf, topo.deg_pows) if (fold is not None and l == 0) else (None, None)
             h = _tagconv_forward(topo, h, plan.fwd[1 + l], conv_ps[l][0], nmat, hid, hout, dmask=dmask, relu=not last,
@@ -744,7 +795,33 @@ class _MPNFn(torch.autograd.Function):
         g = gout.contiguous()
         need_dx = ctx.needs_input_grad[0]
         deferred = []
-        for l in range(L - 1, -1, -1):
+        l_start = L - 1
+        dS = None
+        if L >= 3 and not WGRAD_SIDE_STREAM and WGRAD_BATCH and chain_supported(topo, nmat, hid, True):
+            # last layer on its own; then the data-gradients of layers L-2 .. 0 as ONE chained launch
+            l = L - 1
+            g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, mod.dim_out, flat[offs[2 + l]:offs[3 + l]],
+                                  relu_src=acts[l], dmask=masks[l - 1])
+            gl = [None] * (L - 1)                   # gl[l]: gradient w.r.t. layer l's pre-activation output
+            gl[L - 2] = g
+            layers = []
+            for l in range(L - 2, -1, -1):
+                out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
+                layers.append(dict(Bp=plan.bwd[1 + l], Y=out_l, relu_src=(acts[l] if l > 0 else None),
+                                   dmask=(masks[l - 1] if l > 0 else None)))
+                if l > 0:
+                    gl[l - 1] = out_l
+            gemm_prop_chain(topo, g, hid, nmat, layers, transposed=True)
+            d_in = layers[-1]["Y"]                  # gradient w.r.t. conv 0's input: dS (folded) or dx0
+            if fold is not None:
+                wgrad(topo, gl[0], hid, S, hid, nmat, fold.gfold, rowscale2=topo.deg_pows)
+                fold.backward(flat)
+                dS, g = d_in, None
+            else:
+                g = d_in
+            deferred = [(l, gl[l], acts[l]) for l in range(L - 2, (0 if fold is not None else -1), -1)]
+            l_start = -1
+        for l in range(l_start, -1, -1):
             hout = mod.dim_out if l == L - 1 else hid
             seg = flat[offs[2 + l]:offs[3 + l]]
             if l == 0 and fold is not None:

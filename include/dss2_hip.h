@@ -159,6 +159,22 @@ typedef struct dss2_gemm_prop_args {
 
 int dss2_gemm_prop(const dss2_gemm_prop_args* args_host, void* stream);
 
+/* ---- layer chain: n_layers (<= 8) H -> H layers of dss2_gemm_prop in ONE launch, the activation
+ *      tile staying in LDS from layer to layer (tiles hold whole graphs, so a tile's next layer depends on that tile
+ *      only).  args describes the first layer's input X and everything the layers share (shapes, leading
+ *      dimensions ldy / ld_relu / ld_dmask / ld_add, topology, pre_rowscale); per layer: packed weights, bias,
+ *      epilogue operands and the output Y (every layer's output is still written once: the backward pass and the
+ *      weight gradients read it).  Forward chain of TAGConv layers (/root/reference/networks.py:266-269 iterated)
+ *      or, with the transposed graph and packs, the chain of their data-gradients.
+ *      Supported: dss2_gemm_prop_chain_supported(...) != 0 (ELL slices, kreal == hout <= 128, hout % 4 == 0,
+ *      16-byte aligned operands); otherwise call dss2_gemm_prop per layer.                                          */
+typedef struct dss2_chain_layer {
+  const float* Bp; const float* bias; const float* relu_src; const float* dmask; const float* add_src;
+  const float* prebias; float* Y; int32_t relu; int32_t pad_;
+} dss2_chain_layer;
+int dss2_gemm_prop_chain(const dss2_gemm_prop_args* args_host, const dss2_chain_layer* layers_host, int n_layers, void* stream);
+int dss2_gemm_prop_chain_supported(int nrb, int nmat, int kreal, int hout, int ell_width);
+
 /* ---- K4: weight gradient of TAGConv / Linear -------------------------------------------- *
  * dW_m[o,i] = sum_n (P^m G)[n,o] * X[n,i]   (P = A_hat^T via the CSR by source), m < nmat,
  * db[o] = sum_n G[n,o] * (rowscale ? rowscale[n] : 1).
