@@ -8,7 +8,8 @@
 // X) -> Horner in the wave-private stage -> epilogue to HBM and, in place, into the X tile -> barrier.
 //
 // Restricted to what the hot configurations need (the general kernel covers the rest): ELL tile slices,
-// 16-byte aligned operands, one 32-column group per wave (H <= 128), H_in == H_out for every layer.
+// 16-byte aligned operands, one 32-column group per wave (4 waves for H <= 128, 8 waves up to H = 256),
+// H_in == H_out for every layer.
 #include "dss2_common.hpp"
 
 namespace dss2 {
@@ -18,8 +19,8 @@ struct ChainTable { dss2_chain_layer l[CHAIN_MAX]; int n; };
 
 constexpr int chain_waves_per_simd(int nrb, int nmat) { return nrb * nmat * 16 <= 128 ? 2 : 1; }
 
-template <int NRB, int NMAT>
-__global__ void __launch_bounds__(256, chain_waves_per_simd(NRB, NMAT)) gemm_chain_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
+template <int NRB, int NMAT, int NW>   // NW: waves per workgroup the kernel is compiled for (one 32-column group per wave)
+__global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB, NMAT)) gemm_chain_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
   constexpr int TM = NRB * 32;
   constexpr int PF = 8;
   constexpr int LDA = TM + 4;
@@ -218,10 +219,10 @@ static size_t chain_lds_bytes(int nrb, int kpad, int nw, int ell_width) {
   return TM * (size_t)(kpad + 4) * 4 + (size_t)nw * 32 * (TM + 4) * 4 + TM * (size_t)ell_width * 8;
 }
 
-template <int NRB, int NMAT>
+template <int NRB, int NMAT, int NW>
 static int launch_chain(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = gemm_chain_kernel<NRB, NMAT>;
+  auto kern = gemm_chain_kernel<NRB, NMAT, NW>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
     if (e != hipSuccess) { set_error("gemm_prop_chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
@@ -236,7 +237,7 @@ static int launch_chain(const dss2_gemm_prop_args& a, const ChainTable& ct, hipS
 extern "C" int dss2_gemm_prop_chain_supported(int nrb, int nmat, int kreal, int hout, int ell_width) {
   using namespace dss2;
   if (nmat < 2 || nmat > 4 || nrb * nmat > 9 || !(nrb == 1 || nrb == 2 || nrb == 3 || nrb == 4)) return 0;
-  if (kreal != hout || (hout & 3) != 0 || hout > 128 || ell_width <= 0 || ell_width > 32) return 0;
+  if (kreal != hout || (hout & 3) != 0 || hout > 256 || ell_width <= 0 || ell_width > 32) return 0;
   const int kpad = (kreal + 7) / 8 * 8, ncg = (hout + 31) / 32;
   return chain_lds_bytes(nrb, kpad, ncg, ell_width) <= (size_t)kMaxLdsBytes ? 1 : 0;
 }
@@ -269,7 +270,9 @@ extern "C" int dss2_gemm_prop_chain(const dss2_gemm_prop_args* ap, const dss2_ch
   }
   if (any_pre && !a.pre_rowscale) { set_error("gemm_prop_chain: prebias needs pre_rowscale"); return 2; }
   hipStream_t s = as_stream(stream);
-#define DSS2_CASE(NRB, NMAT) if (a.nrb == NRB && a.nmat == NMAT) return launch_chain<NRB, NMAT>(a, ct, s);
+#define DSS2_CASE(NRB, NMAT)                                                             \
+  if (a.nrb == NRB && a.nmat == NMAT)                                                    \
+    return a.ncg <= 4 ? launch_chain<NRB, NMAT, 4>(a, ct, s) : launch_chain<NRB, NMAT, 8>(a, ct, s);
   DSS2_CASE(1, 2) DSS2_CASE(1, 3) DSS2_CASE(1, 4) DSS2_CASE(2, 2) DSS2_CASE(2, 3) DSS2_CASE(2, 4)
   DSS2_CASE(3, 2) DSS2_CASE(3, 3) DSS2_CASE(4, 2)
 #undef DSS2_CASE

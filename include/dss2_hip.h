@@ -166,7 +166,7 @@ int dss2_gemm_prop(const dss2_gemm_prop_args* args_host, void* stream);
  *      epilogue operands and the output Y (every layer's output is still written once: the backward pass and the
  *      weight gradients read it).  Forward chain of TAGConv layers (/root/reference/networks.py:266-269 iterated)
  *      or, with the transposed graph and packs, the chain of their data-gradients.
- *      Supported: dss2_gemm_prop_chain_supported(...) != 0 (ELL slices, kreal == hout <= 128, hout % 4 == 0,
+ *      Supported: dss2_gemm_prop_chain_supported(...) != 0 (ELL slices, kreal == hout <= 256, hout % 4 == 0,
  *      16-byte aligned operands); otherwise call dss2_gemm_prop per layer.                                          */
 typedef struct dss2_chain_layer {
   const float* Bp; const float* bias; const float* relu_src; const float* dmask; const float* add_src;
