@@ -107,29 +107,37 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     if (n2 < n2e) mm(b0, a0);
   };
   auto prop = [&](const float* Zs, float* Zd) {
-    constexpr int RSTEP = NT / LDZ;           // rows advanced per pass of the NT threads
-    constexpr int NI = TM / RSTEP;            // rows owned by one thread
-    constexpr int CH = (NI % 16 == 0) ? 16 : ((NI % 8 == 0) ? 8 : ((NI % 4 == 0) ? 4 : ((NI % 2 == 0) ? 2 : 1)));
-    static_assert(NI % CH == 0, "row chunking must tile the thread's rows exactly");
-    const int c = tid % LDZ;
-    const int n0 = tid / LDZ;
     if (D > 0) {
+      // 16 bytes per lane: a thread owns 4 consecutive columns of its rows, so one ELL entry (broadcast) and one
+      // ds_read_b128 serve 4 elements -- a quarter of the LDS instructions of a column-per-thread layout, which
+      // matters because this VALU/LDS phase shares its SIMD with the other half's back-to-back MFMAs
+      constexpr int Q = LDZ / 4;               // float4 groups per row
+      constexpr int RSTEP = NT / Q;            // rows advanced per pass of the NT threads
+      constexpr int NI = TM / RSTEP;           // rows owned by one thread
+      static_assert(NT % Q == 0 && TM % RSTEP == 0, "float4 propagation must tile the slab exactly");
+      const int c4 = (tid % Q) * 4;
+      const int n0 = tid / Q;
+      constexpr int CH = (NI % 2 == 0) ? 2 : 1;   // rows in flight per thread (register budget: the accumulators own it)
       for (int i0 = 0; i0 < NI; i0 += CH) {
-        float s[CH];
+        f32x4 s[CH];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) s[i] = 0.f;
+        for (int i = 0; i < CH; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < D; ++k) {
           const int2* ek = ell + k * TM + n0 + i0 * RSTEP;
 #pragma unroll
           for (int i = 0; i < CH; ++i) {
             const int2 en = ek[i * RSTEP];
-            s[i] = fmaf(__int_as_float(en.y), Zs[en.x * LDZ + c], s[i]);
+            const f32x4 z = *reinterpret_cast<const f32x4*>(Zs + en.x * LDZ + c4);
+            s[i] += z * __int_as_float(en.y);
           }
         }
 #pragma unroll
-        for (int i = 0; i < CH; ++i) Zd[(n0 + (i0 + i) * RSTEP) * LDZ + c] = s[i];
+        for (int i = 0; i < CH; ++i) *reinterpret_cast<f32x4*>(Zd + (n0 + (i0 + i) * RSTEP) * LDZ + c4) = s[i];
       }
     } else {
+      constexpr int RSTEP = NT / LDZ;
+      const int c = tid % LDZ;
+      const int n0 = tid / LDZ;
       for (int n = n0; n < TM; n += RSTEP) {
         float s = 0.f;
         const int e1 = lrow[n + 1];

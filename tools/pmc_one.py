@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Launch ONLY one kernel shape repeatedly (for rocprofv3 --pmc): argv[1] in {fwd, dgrad, wgrad}."""
+"""Launch ONLY one kernel shape repeatedly (for rocprofv3 --pmc): argv[1] in {fwd, dgrad, wgrad, chain, wgrad2}."""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -19,6 +19,12 @@ for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
         nw.gemm_prop(topo, h, H, H, plan.fwd[0], nmat, H, out, bias=bias, relu=True)
     elif which == "dgrad":
         nw.gemm_prop(topo, g, H, H, plan.bwd[0], nmat, H, out, relu_src=h, transposed=True)
+    elif which == "chain":       # 3 chained H -> H layers (the C2 forward chain)
+        outs = [torch.empty(N, H, device=dev) for _ in range(3)]
+        nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=plan.fwd[0], Y=o, bias=bias, relu=True) for o in outs])
+    elif which == "wgrad2":      # two layers batched in one launch (the C2 backward)
+        flat2 = torch.empty(2 * (nmat * H * H + H), device=dev)
+        nw.wgrad_batched(topo, [g, g], H, [h, h], H, nmat, flat2)
     else:
         nw.wgrad(topo, g, H, h, H, nmat, flat)
 torch.cuda.synchronize()
