@@ -18,6 +18,26 @@ constexpr int XW = 128;  // X columns per workgroup: one 32-column block per wav
 // output-feature blocks of half (w >> 2).  Half 0 runs "MFMA, then its share of the propagation",
 // half 1 "bias sums + propagation share, then MFMA", so on every SIMD the VALU/LDS propagation of
 // one wave sits under the MFMAs of the other.  NB == 1 (narrow / tiny outputs): 4 waves.
+#ifdef DSS2_STAMPS
+// Diagnostic build only (-DDSS2_STAMPS): per-wave phase stamps of the SECOND tile of every workgroup.
+__device__ unsigned long long g_wstamps[512 * 8 * 16];
+#define WSTAMP(slot)                                                                                   \
+  do {                                                                                                 \
+    if (stamp_on) {                                                                                    \
+      unsigned long long t_;                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      if (lane == 0 && blockIdx.x < 512 && blockIdx.z == 0) g_wstamps[(blockIdx.x * 8 + wave) * 16 + (slot)] = t_; \
+    }                                                                                                  \
+  } while (0)
+#else
+#define WSTAMP(slot) do {} while (0)
+#endif
+
+// propagate-first schedule (three G slabs in LDS): K = 2 on tiles of at most 64 rows
+constexpr bool wgrad_pf(int nrb, int nmat) { return nmat == 3 && nrb <= 2; }
+
 template <int NB> struct WgradGeom {
   static constexpr int NW = NB >= 2 ? 8 : 4;
   static constexpr int NT = NW * 64;
@@ -41,9 +61,15 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   constexpr int NX4 = TM * XW / 4 / NT;    // float4 of the X slab per thread
   static_assert(NG4 * NT * 4 == TM * LDZ && NX4 * NT * 4 == TM * XW, "slabs must tile the threads");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // PF ("propagate first"): all (P^T)^m G slabs side by side in LDS, both propagations up front at full VALU
+  // speed, then ONE uninterrupted MFMA phase over the three slabs.  Phase stamps of the interleaved schedule
+  // (tools/wstamps.py) showed MFMAs at 70 % and the propagation 3x slower when they share a SIMD, plus two
+  // extra barriers per tile; PF needs a third slab, which fits for the hot shapes.
+  constexpr bool PF = wgrad_pf(NRB, NMAT);
   float* Za = smem;
   float* Zb = Za + TM * LDZ;
-  float* Xs = Zb + (NMAT > 1 ? TM * LDZ : 0);
+  float* Zc = Zb + TM * LDZ;                                  // only with PF
+  float* Xs = Za + (PF ? NMAT : (NMAT > 1 ? 2 : 1)) * TM * LDZ;
   const int D = p.ell_width;   // > 0: ELL [D][TM] slice of the transposed graph, else CSR slice
   f32x4* Dsc = reinterpret_cast<f32x4*>(Xs + TM * XW);   // [TM] row scales of the tile (rowscale2)
   int2* ell = reinterpret_cast<int2*>(Xs + TM * XW + TM * 4);
@@ -150,40 +176,53 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     }
   };
   // bias gradient (column sums of G): the last LDZ threads of the workgroup (half 1 when 8 waves)
+  // (rows >= R of the slab are zero, so the loops run over all TM rows with a fixed trip count, unrolled with
+  //  four independent partial sums: the LDS latency is paid per batch instead of per row)
   auto bias_sums = [&](int ts, int R) {
     const int t = tid - (NT - LDZ);
     if (ibg != 0 || t < 0) return;
-    float s = 0.f;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.rowscale2) {   // plain sums + one scaled sum per matrix, scales [s, P s, P^2 s, P^3 s] per row
       float sm[NMAT];
 #pragma unroll
       for (int m = 0; m < NMAT; ++m) sm[m] = 0.f;
-      for (int r = 0; r < R; ++r) {
+#pragma unroll 8
+      for (int r = 0; r < TM; ++r) {
         const float z = Za[r * LDZ + t];
         const f32x4 d = Dsc[r];
-        s += z;
+        s4[r & 3] += z;
 #pragma unroll
         for (int m = 0; m < NMAT; ++m) sm[m] = fmaf(z, d[m], sm[m]);
       }
 #pragma unroll
       for (int m = 0; m < NMAT; ++m) dbs[m] += sm[m];
     } else if (p.rowscale) {
-      for (int r = 0; r < R; ++r) s = fmaf(Za[r * LDZ + t], p.rowscale[ts + r], s);
+#pragma unroll 8
+      for (int r = 0; r < TM; ++r) s4[r & 3] = fmaf(Za[r * LDZ + t], r < R ? p.rowscale[ts + r] : 0.f, s4[r & 3]);
     } else {
-      for (int r = 0; r < R; ++r) s += Za[r * LDZ + t];
+#pragma unroll 16
+      for (int r = 0; r < TM; ++r) s4[r & 3] += Za[r * LDZ + t];
     }
-    dbacc += s;
+    dbacc += (s4[0] + s4[1]) + (s4[2] + s4[3]);
   };
   // one MFMA phase + the propagation that feeds the next one, ordered per half (see kernel comment)
-  auto phase = [&](const float* Zs, float* Zd, f32x16 (&a)[NBW], int R, bool do_prop, bool do_bias, int ts) {
+  bool stamp_on = false; (void)stamp_on;
+  auto phase = [&](const float* Zs, float* Zd, f32x16 (&a)[NBW], int R, bool do_prop, bool do_bias, int ts, int s0) {
+    (void)s0;
     if (NW == 8 && obh == 1) {
       if (do_bias) bias_sums(ts, R);
+      WSTAMP(s0);
       if (do_prop) prop(Zs, Zd);
+      WSTAMP(s0 + 1);
       mma(Zs, a, R);
+      WSTAMP(s0 + 2);
     } else {
       mma(Zs, a, R);
+      WSTAMP(s0);
       if (NW == 4 && do_bias) bias_sums(ts, R);
+      WSTAMP(s0 + 1);
       if (do_prop) prop(Zs, Zd);
+      WSTAMP(s0 + 2);
     }
   };
 
@@ -251,9 +290,13 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const int ts = p.tile_start[tile];
     const int R = p.tile_start[tile + 1] - ts;
+#ifdef DSS2_STAMPS
+    stamp_on = (tile == (int)blockIdx.x + (int)gridDim.x);
+#endif
+    WSTAMP(0);
     // ---- stage G slab, X slab and the transposed-graph slice
     write_slabs(ts, R);
-    if (p.rowscale2 && tid < R) Dsc[tid] = reinterpret_cast<const f32x4*>(p.rowscale2)[ts + tid];
+    if (p.rowscale2 && tid < TM) Dsc[tid] = tid < R ? reinterpret_cast<const f32x4*>(p.rowscale2)[ts + tid] : f32x4{0.f, 0.f, 0.f, 0.f};
     if (NMAT > 1 || p.narrow) {
       if (D > 0 && p.ell_tiles != nullptr) {
         const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
@@ -273,10 +316,13 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
       }
     }
     __syncthreads();
-    {
-      const int next = tile + gridDim.x;
-      if (next < p.ntiles) issue_loads(next);
-    }
+    WSTAMP(1);
+    const int next = tile + gridDim.x;
+    // Next tile's slabs -> registers.  Issuing a wave's sixteen 16-byte loads blocks it for 2-5 K cycles (the CU's
+    // vector-memory pipe moves 64 B/clk; tools/wstamps.py), so with PF it is done inside the MFMA phase, the two
+    // halves at different points: while one wave of a SIMD feeds the memory pipe the other keeps the MFMA pipe busy.
+    if (!PF && next < p.ntiles) issue_loads(next);
+    WSTAMP(2);
     // ---- narrow mode: append P^m G as column blocks [m*hout, (m+1)*hout) of the same 32-wide slab
     if (p.narrow) {
       const int h = p.hout;
@@ -303,20 +349,43 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
       }
     }
     // ---- m = 0 .. NMAT-1, ping-pong propagation
-    phase(Za, Zb, acc[0], R, NMAT > 1, true, ts);
+    if constexpr (PF) {
+      // bias sums: the two waves that own them run them inside the MFMA phase (their SIMD partners keep the
+      // matrix pipe busy meanwhile) instead of holding everybody at the propagation barrier
+      if (NW == 4) bias_sums(ts, R);
+      WSTAMP(3);
+      prop(Za, Zb);
+      __syncthreads();
+      WSTAMP(4);
+      prop(Zb, Zc);
+      __syncthreads();
+      WSTAMP(5);
+      if (obh == 0 && next < p.ntiles) issue_loads(next);
+      mma(Za, acc[0], R);
+      if (obh != 0 && next < p.ntiles) issue_loads(next);
+      if (NW == 8) bias_sums(ts, R);
+      mma(Zb, acc[1 % NMAT], R);
+      mma(Zc, acc[2 % NMAT], R);
+      WSTAMP(6);
+    } else {
+    phase(Za, Zb, acc[0], R, NMAT > 1, true, ts, 3);
     if (NMAT > 1) {
       __syncthreads();
-      phase(Zb, Za, acc[1 % NMAT], R, NMAT > 2, false, ts);
+      WSTAMP(6);
+      phase(Zb, Za, acc[1 % NMAT], R, NMAT > 2, false, ts, 7);
     }
     if (NMAT > 2) {
       __syncthreads();
-      phase(Za, Zb, acc[2 % NMAT], R, NMAT > 3, false, ts);
+      WSTAMP(10);
+      phase(Za, Zb, acc[2 % NMAT], R, NMAT > 3, false, ts, 11);
     }
     if (NMAT > 3) {
       __syncthreads();
-      phase(Zb, Za, acc[3 % NMAT], R, false, false, ts);
+      phase(Zb, Za, acc[3 % NMAT], R, false, false, ts, 11);
+    }
     }
     __syncthreads();
+    WSTAMP(14);
   }
 
   // ---- one slab per workgroup column blockIdx.x; the y-slices tile the [nmat*hout, hin] matrix
@@ -352,7 +421,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
 // nmat here = number of MFMA matrix passes (1 in narrow mode); graph = a graph slice is staged
 static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz, int ell_width, bool graph) {
   const size_t TM = (size_t)nrb * 32;
-  size_t b = TM * (size_t)nb * 32 * 4 * (nmat > 1 ? 2 : 1) + TM * XW * 4 + TM * 16;
+  size_t b = TM * (size_t)nb * 32 * 4 * (wgrad_pf(nrb, nmat) ? 3 : (nmat > 1 ? 2 : 1)) + TM * XW * 4 + TM * 16;
   if (graph) b += ell_width > 0 ? TM * (size_t)ell_width * 8 : (TM + 2) * 4 + (size_t)max_nnz * 8;
   return b;
 }
@@ -449,3 +518,9 @@ extern "C" int dss2_wgrad_batched(const dss2_wgrad_args* ap, const float* const*
   a.G = Gs[0]; a.X = Xs[0]; a.slab = slabs[0];
   return wgrad_dispatch(a, stream, wb);
 }
+
+#ifdef DSS2_STAMPS
+extern "C" int dss2_debug_read_wstamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dss2::g_wstamps), sizeof(unsigned long long) * n);
+}
+#endif
