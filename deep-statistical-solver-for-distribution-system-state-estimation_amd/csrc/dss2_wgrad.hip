@@ -143,19 +143,24 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
       static_assert(NT % Q == 0 && TM % RSTEP == 0, "float4 propagation must tile the slab exactly");
       const int c4 = (tid % Q) * 4;
       const int n0 = tid / Q;
-      constexpr int CH = (NI % 2 == 0) ? 2 : 1;   // rows in flight per thread (register budget: the accumulators own it)
+      // rows in flight per thread: with PF the next-tile prefetch registers are not live during the propagation,
+      // so all of a thread's rows go at once and the ELL entries of hop k+1 are requested before hop k's data
+      // (the entry -> data -> fma chain is latency-bound); otherwise two rows (the accumulators own the budget)
+      constexpr int CH = PF ? NI : ((NI % 2 == 0) ? 2 : 1);
       for (int i0 = 0; i0 < NI; i0 += CH) {
         f32x4 s[CH];
+        int2 en[CH], en_next[CH];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < CH; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; en[i] = ell[n0 + (i0 + i) * RSTEP]; }
         for (int k = 0; k < D; ++k) {
-          const int2* ek = ell + k * TM + n0 + i0 * RSTEP;
+          const int kn = k + 1 < D ? k + 1 : k;
 #pragma unroll
-          for (int i = 0; i < CH; ++i) {
-            const int2 en = ek[i * RSTEP];
-            const f32x4 z = *reinterpret_cast<const f32x4*>(Zs + en.x * LDZ + c4);
-            s[i] += z * __int_as_float(en.y);
-          }
+          for (int i = 0; i < CH; ++i) en_next[i] = ell[kn * TM + n0 + (i0 + i) * RSTEP];
+          f32x4 z[CH];
+#pragma unroll
+          for (int i = 0; i < CH; ++i) z[i] = *reinterpret_cast<const f32x4*>(Zs + en[i].x * LDZ + c4);
+#pragma unroll
+          for (int i = 0; i < CH; ++i) { s[i] += z[i] * __int_as_float(en[i].y); en[i] = en_next[i]; }
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i) *reinterpret_cast<f32x4*>(Zd + (n0 + (i0 + i) * RSTEP) * LDZ + c4) = s[i];
