@@ -72,8 +72,9 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   float* Xs = Za + (PF ? NMAT : (NMAT > 1 ? 2 : 1)) * TM * LDZ;
   const int D = p.ell_width;   // > 0: ELL [D][TM] slice of the transposed graph, else CSR slice
   f32x4* Dsc = reinterpret_cast<f32x4*>(Xs + TM * XW);   // [TM] row scales of the tile (rowscale2)
-  int2* ell = reinterpret_cast<int2*>(Xs + TM * XW + TM * 4);
-  int* lrow = reinterpret_cast<int*>(Xs + TM * XW + TM * 4);
+  f32x4* Bsum = reinterpret_cast<f32x4*>(Xs + TM * XW + TM * 4);   // [NT] running partial column sums (fast_bias)
+  int2* ell = reinterpret_cast<int2*>(Xs + TM * XW + TM * 4 + NT * 4);
+  int* lrow = reinterpret_cast<int*>(Xs + TM * XW + TM * 4 + NT * 4);
   int2* lent = reinterpret_cast<int2*>(lrow + TM + 2);
 
   const int tid = threadIdx.x;
@@ -100,6 +101,12 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
 
   const bool gvec = ((p.ldg & 3) == 0) && ((p.hout & 3) == 0) && ((reinterpret_cast<uintptr_t>(Gp) & 15) == 0);
   const bool xvec = ((p.ldx & 3) == 0) && ((p.hin & 3) == 0) && ((reinterpret_cast<uintptr_t>(Xp) & 15) == 0);
+  // Plain bias gradient (column sums of G) without a per-tile pass: a thread's prefetched 16-byte pieces of the G
+  // slab all sit in the same four columns (NT is a multiple of the row length), so it keeps a running partial sum
+  // of those columns across ALL its tiles (in its own LDS slot: the register file is full); the partials meet
+  // once, after the last tile.
+  const bool fast_bias = gvec && !p.rowscale && !p.rowscale2 && ibg == 0 && (NT % (LDZ / 4) == 0);
+  if (fast_bias) Bsum[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto mma = [&](const float* Z, f32x16 (&a)[NBW], int R) {
     if (!wave_active) return;
@@ -215,7 +222,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   auto phase = [&](const float* Zs, float* Zd, f32x16 (&a)[NBW], int R, bool do_prop, bool do_bias, int ts, int s0) {
     (void)s0;
     if (NW == 8 && obh == 1) {
-      if (do_bias) bias_sums(ts, R);
+      if (do_bias && !fast_bias) bias_sums(ts, R);
       WSTAMP(s0);
       if (do_prop) prop(Zs, Zd);
       WSTAMP(s0 + 1);
@@ -224,7 +231,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     } else {
       mma(Zs, a, R);
       WSTAMP(s0);
-      if (NW == 4 && do_bias) bias_sums(ts, R);
+      if (NW == 4 && do_bias && !fast_bias) bias_sums(ts, R);
       WSTAMP(s0 + 1);
       if (do_prop) prop(Zs, Zd);
       WSTAMP(s0 + 2);
@@ -269,6 +276,12 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
         const int idx = tid + i * NT;
         const int r = idx / QG, c = (idx - r * QG) * 4;
         *reinterpret_cast<f32x4*>(Za + r * LDZ + c) = pg[i];
+      }
+      if (fast_bias) {                      // rows >= R were loaded as zeros
+        f32x4 sp = pg[0];
+#pragma unroll
+        for (int i = 1; i < NG4; ++i) sp += pg[i];
+        Bsum[tid] += sp;
       }
     } else {
       for (int idx = tid; idx < TM * LDZ; idx += NT) {
@@ -357,7 +370,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     if constexpr (PF) {
       // bias sums: the two waves that own them run them inside the MFMA phase (their SIMD partners keep the
       // matrix pipe busy meanwhile) instead of holding everybody at the propagation barrier
-      if (NW == 4) bias_sums(ts, R);
+      if (NW == 4 && !fast_bias) bias_sums(ts, R);
       WSTAMP(3);
       prop(Za, Zb);
       __syncthreads();
@@ -368,7 +381,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
       if (obh == 0 && next < p.ntiles) issue_loads(next);
       mma(Za, acc[0], R);
       if (obh != 0 && next < p.ntiles) issue_loads(next);
-      if (NW == 8) bias_sums(ts, R);
+      if (NW == 8 && !fast_bias) bias_sums(ts, R);
       mma(Zb, acc[1 % NMAT], R);
       mma(Zc, acc[2 % NMAT], R);
       WSTAMP(6);
@@ -393,6 +406,18 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     WSTAMP(14);
   }
 
+  if (fast_bias) {   // (uniform) partial column sums -> LDS [NT / (LDZ/4)][LDZ] -> the owner threads
+    constexpr int QG = LDZ / 4;
+    *reinterpret_cast<f32x4*>(Za + (tid / QG) * LDZ + (tid % QG) * 4) = Bsum[tid];    // the slabs are dead: last tile done
+    __syncthreads();
+    const int t = tid - (NT - LDZ);
+    if (t >= 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < NT / QG; ++q) s += Za[q * LDZ + t];
+      dbacc += s;
+    }
+  }
   // ---- one slab per workgroup column blockIdx.x; the y-slices tile the [nmat*hout, hin] matrix
   const size_t stride = (size_t)p.nmat * p.hout * p.hin + p.hout + (p.rowscale2 ? (size_t)p.nmat * p.hout : 0);
   float* out = slabp + (size_t)blockIdx.x * (wb.slab_stride > 0 ? (size_t)wb.slab_stride : stride);
@@ -427,6 +452,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
 static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz, int ell_width, bool graph) {
   const size_t TM = (size_t)nrb * 32;
   size_t b = TM * (size_t)nb * 32 * 4 * (wgrad_pf(nrb, nmat) ? 3 : (nmat > 1 ? 2 : 1)) + TM * XW * 4 + TM * 16;
+  b += (size_t)(nb >= 2 ? 512 : 256) * 16;   // running bias partials, one 16-byte slot per thread
   if (graph) b += ell_width > 0 ? TM * (size_t)ell_width * 8 : (TM + 2) * 4 + (size_t)max_nnz * 8;
   return b;
 }
