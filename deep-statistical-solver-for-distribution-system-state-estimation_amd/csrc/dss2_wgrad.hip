@@ -47,13 +47,18 @@ template <int NB> struct WgradGeom {
 // Several layers of identical shape in ONE launch (blockIdx.z = layer): the layers of a block are
 // independent once all output gradients exist, and at small H one layer alone cannot fill the chip.
 constexpr int WGRAD_MAX_BATCH = 8;
-struct WgradBatch { const float* G[WGRAD_MAX_BATCH]; const float* X[WGRAD_MAX_BATCH]; float* slab[WGRAD_MAX_BATCH]; int n; long long slab_stride; };
+struct WgradBatch {
+  const float* G[WGRAD_MAX_BATCH]; const float* X[WGRAD_MAX_BATCH]; float* slab[WGRAD_MAX_BATCH];
+  const float* rowscale2[WGRAD_MAX_BATCH];   // per layer (NULL: plain layer)
+  int n; long long slab_stride;
+};
 
 template <int NRB, int NMAT, int NB>
 __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgrad_args p, int nibg, const WgradBatch wb) {
   const float* __restrict__ Gp = wb.n > 0 ? wb.G[blockIdx.z] : p.G;
   const float* __restrict__ Xp = wb.n > 0 ? wb.X[blockIdx.z] : p.X;
   float* __restrict__ slabp = wb.n > 0 ? wb.slab[blockIdx.z] : p.slab;
+  const float* __restrict__ rs2 = wb.n > 0 ? wb.rowscale2[blockIdx.z] : p.rowscale2;
   constexpr int TM = NRB * 32;
   constexpr int LDZ = NB * 32;
   constexpr int NW = WgradGeom<NB>::NW, NT = WgradGeom<NB>::NT, NBW = WgradGeom<NB>::NBW;
@@ -105,7 +110,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   // slab all sit in the same four columns (NT is a multiple of the row length), so it keeps a running partial sum
   // of those columns across ALL its tiles (in its own LDS slot: the register file is full); the partials meet
   // once, after the last tile.
-  const bool fast_bias = gvec && !p.rowscale && !p.rowscale2 && ibg == 0 && (NT % (LDZ / 4) == 0);
+  const bool fast_bias = gvec && !p.rowscale && !rs2 && ibg == 0 && (NT % (LDZ / 4) == 0);
   if (fast_bias) Bsum[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto mma = [&](const float* Z, f32x16 (&a)[NBW], int R) {
@@ -194,7 +199,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     const int t = tid - (NT - LDZ);
     if (ibg != 0 || t < 0) return;
     float s4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.rowscale2) {   // plain sums + one scaled sum per matrix, scales [s, P s, P^2 s, P^3 s] per row
+    if (rs2) {   // plain sums + one scaled sum per matrix, scales [s, P s, P^2 s, P^3 s] per row
       float sm[NMAT];
 #pragma unroll
       for (int m = 0; m < NMAT; ++m) sm[m] = 0.f;
@@ -314,7 +319,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     WSTAMP(0);
     // ---- stage G slab, X slab and the transposed-graph slice
     write_slabs(ts, R);
-    if (p.rowscale2 && tid < TM) Dsc[tid] = tid < R ? reinterpret_cast<const f32x4*>(p.rowscale2)[ts + tid] : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (rs2 && tid < TM) Dsc[tid] = tid < R ? reinterpret_cast<const f32x4*>(rs2)[ts + tid] : f32x4{0.f, 0.f, 0.f, 0.f};
     if (NMAT > 1 || p.narrow) {
       if (D > 0 && p.ell_tiles != nullptr) {
         const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
@@ -419,7 +424,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     }
   }
   // ---- one slab per workgroup column blockIdx.x; the y-slices tile the [nmat*hout, hin] matrix
-  const size_t stride = (size_t)p.nmat * p.hout * p.hin + p.hout + (p.rowscale2 ? (size_t)p.nmat * p.hout : 0);
+  const size_t stride = (size_t)p.nmat * p.hout * p.hin + p.hout + (rs2 ? (size_t)p.nmat * p.hout : 0);
   float* out = slabp + (size_t)blockIdx.x * (wb.slab_stride > 0 ? (size_t)wb.slab_stride : stride);
   if (wave_active) {
     const int i = xcol0 + ibw * 32 + c32;
@@ -440,7 +445,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     const int t = tid - (NT - LDZ);
     if (ibg == 0 && t >= 0 && gcol0 + t < p.hout) {
       out[(size_t)p.nmat * p.hout * p.hin + gcol0 + t] = dbacc;
-      if (p.rowscale2) {
+      if (rs2) {
 #pragma unroll
         for (int m = 0; m < NMAT; ++m) out[(size_t)p.nmat * p.hout * p.hin + p.hout + (size_t)m * p.hout + gcol0 + t] = dbs[m];
       }
@@ -535,7 +540,7 @@ extern "C" int dss2_wgrad(const dss2_wgrad_args* ap, void* stream) {
 }
 
 extern "C" int dss2_wgrad_batched(const dss2_wgrad_args* ap, const float* const* Gs, const float* const* Xs, float* const* slabs,
-                                  int64_t slab_stride, int n_layers, void* stream) {
+                                  const float* const* rowscale2s, int64_t slab_stride, int n_layers, void* stream) {
   if (n_layers < 1 || n_layers > dss2::WGRAD_MAX_BATCH) { dss2::set_error("wgrad_batched: 1..%d layers, got %d", dss2::WGRAD_MAX_BATCH, n_layers); return 2; }
   if (!Gs || !Xs || !slabs) { dss2::set_error("wgrad_batched: null pointer table"); return 2; }
   dss2::WgradBatch wb = {};
@@ -544,9 +549,12 @@ extern "C" int dss2_wgrad_batched(const dss2_wgrad_args* ap, const float* const*
   for (int l = 0; l < n_layers; ++l) {
     if (!Gs[l] || !Xs[l] || !slabs[l]) { dss2::set_error("wgrad_batched: layer %d has a null pointer", l); return 2; }
     wb.G[l] = Gs[l]; wb.X[l] = Xs[l]; wb.slab[l] = slabs[l];
+    wb.rowscale2[l] = rowscale2s ? rowscale2s[l] : nullptr;
+    if (wb.rowscale2[l] && slab_stride <= 0) { dss2::set_error("wgrad_batched: per-layer rowscale2 needs an explicit slab_stride"); return 2; }
   }
   dss2_wgrad_args a = *ap;
   a.G = Gs[0]; a.X = Xs[0]; a.slab = slabs[0];
+  a.rowscale2 = nullptr;   // per layer, from the table
   return wgrad_dispatch(a, stream, wb);
 }
 

@@ -156,15 +156,19 @@ def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int,
 
 
 def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Sequence[torch.Tensor], hin: int, nmat: int,
-                  out_flat: torch.Tensor) -> None:
-    """len(Gs) layers of identical shape in one launch + one reduction:
-    out_flat[l * (nmat*hout*hin + hout) + ...] <- [dW_0 .. dW_{nmat-1}, db] of layer l."""
+                  out_flat: torch.Tensor, first_rowscale2=None, first_out=None) -> None:
+    """len(Gs) layers of identical shape in one launch:
+    out_flat[j * (nmat*hout*hin + hout) + ...] <- [dW_0 .. dW_{nmat-1}, db] of the plain layers, in order.
+    With ``first_rowscale2`` layer 0 is a folded layer (see ``wgrad``): its result, with the extra nmat*hout
+    scaled sums, goes to ``first_out`` and the remaining layers to ``out_flat`` (two slab reductions)."""
     nl = len(Gs)
     lds = _lib.lib().dss2_wgrad_lds_bytes(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT)
     per_cu = max(1, min(_WGRAD_PER_CU, (160 * 1024) // max(int(lds), 1)))
     n_split = min(topo.ntiles, max(1, (256 * per_cu) // nl))       # the layers share the chip
     stride = nmat * hout * hin + hout
-    slab = torch.empty(n_split * nl * stride, dtype=_F32, device=Gs[0].device)
+    lens = [stride + (nmat * hout if (first_rowscale2 is not None and l == 0) else 0) for l in range(nl)]
+    total = sum(lens)
+    slab = torch.empty(n_split * total, dtype=_F32, device=Gs[0].device)
     a = _lib.WgradArgs()
     a.ldg, a.hout, a.ldx, a.hin = Gs[0].stride(0), hout, Xs[0].stride(0), hin
     for g_, x_ in zip(Gs, Xs):
@@ -176,11 +180,19 @@ def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Seq
     a.ell_width, a.ell_tiles = topo.ellT, _ptr(topo.ellT_tiles)
     PtrArr = C.c_void_p * nl
     gs, xs = PtrArr(*[g_.data_ptr() for g_ in Gs]), PtrArr(*[x_.data_ptr() for x_ in Xs])
-    sl = PtrArr(*[slab.data_ptr() + 4 * l * stride for l in range(nl)])
+    offs = [sum(lens[:l]) for l in range(nl)]
+    sl = PtrArr(*[slab.data_ptr() + 4 * o for o in offs])
+    rs = PtrArr(*[(first_rowscale2.data_ptr() if (first_rowscale2 is not None and l == 0) else None) for l in range(nl)])
     st = _stream(Gs[0])
-    _lib.check(_lib.lib().dss2_wgrad_batched(C.byref(a), gs, xs, sl, nl * stride, nl, st), "dss2_wgrad_batched")
-    _lib.check(_lib.lib().dss2_reduce_slabs(slab.data_ptr(), n_split, nl * stride, out_flat.data_ptr(), nl * stride, st),
-               "dss2_reduce_slabs")
+    L_ = _lib.lib()
+    _lib.check(L_.dss2_wgrad_batched(C.byref(a), gs, xs, sl, rs, total, nl, st), "dss2_wgrad_batched")
+    if first_rowscale2 is not None:
+        _lib.check(L_.dss2_reduce_slabs(slab.data_ptr(), n_split, total, first_out.data_ptr(), lens[0], st), "dss2_reduce_slabs")
+        if nl > 1:
+            _lib.check(L_.dss2_reduce_slabs(slab.data_ptr() + 4 * lens[0], n_split, total, out_flat.data_ptr(),
+                                            total - lens[0], st), "dss2_reduce_slabs")
+    else:
+        _lib.check(L_.dss2_reduce_slabs(slab.data_ptr(), n_split, total, out_flat.data_ptr(), total, st), "dss2_reduce_slabs")
 
 
 def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, ent: torch.Tensor, n_rows: int) -> torch.Tensor:
@@ -813,13 +825,24 @@ class _MPNFn(torch.autograd.Function):
                     gl[l - 1] = out_l
             gemm_prop_chain(topo, g, hid, nmat, layers, transposed=True)
             d_in = layers[-1]["Y"]                  # gradient w.r.t. conv 0's input: dS (folded) or dx0
-            if fold is not None:
-                wgrad(topo, gl[0], hid, S, hid, nmat, fold.gfold, rowscale2=topo.deg_pows)
+            # (joining conv 0 pays only when the tiles still divide evenly over the workgroups the layers share:
+            #  at C2 three layers x 85 workgroups leave a 13-vs-12-tile tail that costs more than the launch saves)
+            ns3 = max(1, (256 * _WGRAD_PER_CU) // (L - 1))
+            even = -(-topo.ntiles // ns3) * ns3 <= 1.03 * topo.ntiles
+            if fold is not None and L - 1 <= 8 and even:
+                # the folded conv 0 (input S, extra scaled bias sums) and the plain layers 1 .. L-2 in ONE launch
+                wgrad_batched(topo, gl, hid, [S] + acts[1:L - 1], hid, nmat, flat[offs[3]:offs[2 + L - 1]],
+                              first_rowscale2=topo.deg_pows, first_out=fold.gfold)
                 fold.backward(flat)
                 dS, g = d_in, None
             else:
-                g = d_in
-            deferred = [(l, gl[l], acts[l]) for l in range(L - 2, (0 if fold is not None else -1), -1)]
+                if fold is not None:
+                    wgrad(topo, gl[0], hid, S, hid, nmat, fold.gfold, rowscale2=topo.deg_pows)
+                    fold.backward(flat)
+                    dS, g = d_in, None
+                else:
+                    g = d_in
+                deferred = [(l, gl[l], acts[l]) for l in range(L - 2, (0 if fold is not None else -1), -1)]
             l_start = -1
         for l in range(l_start, -1, -1):
             hout = mod.dim_out if l == L - 1 else hid

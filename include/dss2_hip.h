@@ -203,13 +203,15 @@ int dss2_wgrad(const dss2_wgrad_args* args_host, void* stream);
 
 /* The same for n_layers (<= 8) layers of IDENTICAL shape and leading dimensions in one launch (one grid
  * slice per layer): Gs / Xs / slabs are HOST arrays of device pointers replacing args->G / X / slab;
+ * rowscale2s (NULL, or a HOST array with NULL entries for plain layers) replaces args->rowscale2 per layer;
  * every other field of args applies to all layers.  slab_stride (elements, 0 = the dense per-layer
  * stride): distance between consecutive workgroups' partial results inside slabs[l]; with slabs[l] =
- * base + l * len and slab_stride = n_layers * len, ONE dss2_reduce_slabs call finishes all layers.
- * The layers of a block are independent once their output gradients exist; at small H a single layer
- * cannot fill the chip.                                                                                 */
+ * base + (offset of layer l) and slab_stride = the sum of the layers' lengths, ONE dss2_reduce_slabs call
+ * finishes all layers (or one call per destination buffer).  The layers of a block are independent once
+ * their output gradients exist; at small H a single layer cannot fill the chip.                          */
 int dss2_wgrad_batched(const dss2_wgrad_args* args_host, const float* const* Gs, const float* const* Xs,
-                       float* const* slabs, int64_t slab_stride, int n_layers, void* stream);
+                       float* const* slabs, const float* const* rowscale2s, int64_t slab_stride, int n_layers,
+                       void* stream);
 
 /* out[j] = sum_{s < n_slabs} slab[s*stride + j], j < len, fixed order. */
 int dss2_reduce_slabs(const float* slab, int n_slabs, int64_t stride, float* out, int64_t len, void* stream);
