@@ -352,3 +352,53 @@ def test_runner_trains_and_tracks_the_oracle(pkg, oracle):
         assert abs(a - c) <= 1e-4 * abs(c), (l_gpu, l_ref)
     m = pkg.runner.evaluate(mine, [dev_b], st)
     assert all(v == v and v >= 0 for v in m.values())          # finite metrics
+
+
+# ---------------------------------------------------------------------------- launch-structure variants
+@pytest.mark.parametrize("grids,B,hid,L,cls,p", [
+    (["cigre14"], 256, 128, 4, "MPN", 0.0),                     # C2's model: 3-layer chains, 2-layer batch
+    (["cigre14", "cigre14_reswitched"], 96, 256, 5, "MPN", 0.0),  # 8-wave chain (H = 256), mixed topologies
+    (["ober_sub"], 24, 64, 4, "SkipMPN", 0.0),                  # 96-row tiles, narrow H -> 8 last layer, residual
+    (["cigre14"], 128, 32, 6, "MPN", 0.3),                      # dropout masks inside the chain, H = 32
+])
+def test_chained_and_batched_launches_equal_per_layer_launches(pkg, oracle, grids, B, hid, L, cls, p):
+    """The layer chain (dss2_gemm_prop_chain), the batched weight gradient (dss2_wgrad_batched) and the folded
+    second Linear are re-associations of launches, not of arithmetic inside a layer: with the same weights and the
+    same dropout masks the chained forward must equal the per-layer forward BIT FOR BIT, and the gradients must
+    agree to fp32 summation-order noise with the unfolded / unbatched path."""
+    nw = pkg.networks
+    b = pkg.synthetic.make_batch(grids, B, seed=3)
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    st = tuple(s.to(DEV) for s in b["stats"])
+    dim_out = 8 if cls == "SkipMPN" else 2
+    torch.manual_seed(11)
+    model = getattr(pkg, cls)(8, 6, dim_out, hid, L, 2, p).to(DEV)
+    saved = (nw.CHAIN_LAYERS, nw.WGRAD_BATCH, nw.FOLD_W2)
+
+    def run(chain, batch, fold):
+        nw.CHAIN_LAYERS, nw.WGRAD_BATCH, nw.FOLD_W2 = chain, batch, fold
+        for q in model.parameters():
+            q.grad = None
+        torch.manual_seed(5)                       # same dropout masks
+        out = model(x[:, :8], ei, ea[:, :6])
+        o = out.detach().clone()
+        if dim_out == 2:
+            loss = _loss(pkg.data, x, ei, ea, st, out, oracle.DEFAULT_REG_COEFS)
+        else:
+            loss = (out * torch.linspace(-1, 1, out.numel(), device=DEV).view_as(out)).sum()
+        loss.backward()
+        return o, [q.grad.clone() for q in model.parameters()]
+
+    try:
+        o_ref, g_ref = run(False, False, True)     # per-layer launches (fold on: same forward arithmetic)
+        o_chain, g_chain = run(True, True, True)
+        o_unfold, g_unfold = run(False, False, False)
+    finally:
+        nw.CHAIN_LAYERS, nw.WGRAD_BATCH, nw.FOLD_W2 = saved
+    assert torch.equal(o_chain, o_ref)
+    for a, c, (n, _) in zip(g_ref, g_chain, model.named_parameters()):
+        assert rel_err(c, a) < 2e-6, n
+    # folding the second Linear re-associates one matrix product: fp32 rounding level, not bitwise
+    assert rel_err(o_unfold, o_ref) < 2e-6
+    for a, c, (n, _) in zip(g_ref, g_unfold, model.named_parameters()):
+        assert rel_err(c, a) < 5e-5, n
