@@ -210,7 +210,14 @@ def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
     x64, ea64 = b["x"].double(), b["edge_attr"].double()
     st64 = tuple(s.double() for s in b["stats"])
     ei2, ea2 = oracle.undirect_graph(b["edge_index"], ea64[:, :6])
+    edge_hidden = {}
+
+    def keep_hidden(mod, inp, outp):       # hidden activations of the edge MLP, with their gradient after backward
+        outp.retain_grad()
+        edge_hidden["z"], edge_hidden["h"] = inp[0], outp
+    hook = ref64.edge_aggr.edge_aggr[1].register_forward_hook(keep_hidden)
     h = ref64.edge_aggr(x64[:, :8], ei2, ea2)
+    hook.remove()
     n_flip, n_gate = 0, 0
     for l in range(L - 1):
         pre = ref64.convs[l](h, ei2)
@@ -232,11 +239,22 @@ def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
         e = rel_err(p.grad, q64.grad)
         if e < 1e-5:
             continue
-        # the edge MLP's own per-edge gates are not observable from outside (the kernels recompute them);
-        # a flipped one moves single rows of the first Linear's gradient by ~1/N_edges
+        # The edge MLP's own per-edge gates are not observable from outside (the kernels recompute them), so they
+        # cannot be pinned.  Instead every deviation must be EXPLAINED by ambiguous gates: a gate is ambiguous when
+        # |z| is within the fp32 rounding scale of its 22-term dot product (4e-6 * sum_k |w_k c_k|); flipping it
+        # toggles that edge's contribution g * c to the row, so the deviation of row o is bounded by the sum of
+        # |g| |c| over the ambiguous gates of unit o.  (With heavy-tailed inverse-variance inputs a single such
+        # edge can carry more than 1e-5 of the largest gradient entry.)
         assert n.startswith("edge_aggr.edge_aggr.0."), (n, e)
-        d = (p.grad.double().cpu() - q64.grad).abs().reshape(p.shape[0], -1).amax(1)
-        assert e < 1e-3 and int((d > 1e-5 * q64.grad.abs().max()).sum()) <= 2, (n, e)
+        lin1 = ref64.edge_aggr.edge_aggr[0]
+        c = torch.cat([x64[:, :8][ei2[1]], x64[:, :8][ei2[0]], ea2], dim=1)              # [E2, 22]: x_i | x_j | ea
+        z = edge_hidden["z"].detach()
+        scale = c.abs() @ lin1.weight.detach().abs().t() + lin1.bias.detach().abs()
+        amb = (z.abs() <= 4e-6 * scale).double() * edge_hidden["h"].grad.abs()           # |g| on ambiguous gates
+        bound = amb.t() @ c.abs() if n.endswith("weight") else amb.sum(0)
+        dev = (p.grad.double().cpu() - q64.grad).abs()
+        assert (dev <= bound + 1e-5 * q64.grad.abs().max()).all(), (n, e, (dev - bound).max().item())
+        assert e < 1e-3, (n, e)
 
 
 def test_full_size_is_deterministic_and_linear_in_gout(pkg, oracle):
