@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="graphs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap-wgrad", action="store_true",

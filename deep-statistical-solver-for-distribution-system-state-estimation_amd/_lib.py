@@ -49,6 +49,11 @@ class WgradArgs(C.Structure):
                 ("narrow", C.c_int32), ("pad_", C.c_int32)]
 
 
+class ReduceDesc(C.Structure):
+    _fields_ = [("slab", C.c_void_p), ("out", C.c_void_p), ("stride", C.c_int64), ("len", C.c_int64),
+                ("n_slabs", C.c_int32), ("pad_", C.c_int32)]
+
+
 class ChainLayer(C.Structure):
     _fields_ = [("Bp", C.c_void_p), ("bias", C.c_void_p), ("relu_src", C.c_void_p), ("dmask", C.c_void_p),
                 ("add_src", C.c_void_p), ("prebias", C.c_void_p), ("Y", C.c_void_p), ("relu", C.c_int32), ("pad_", C.c_int32)]
@@ -109,6 +114,7 @@ _SIGNATURES = {
     "dss2_gemm_prop_chain_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p]),
     "dss2_wgrad_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "dss2_reduce_slabs_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "dss2_reduce_slabs": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "dss2_wls_loss_partials": (C.c_int, [C.POINTER(WlsArgs), C.c_void_p]),
     "dss2_wls_loss_grad": (C.c_int, [C.POINTER(WlsArgs), C.c_void_p]),

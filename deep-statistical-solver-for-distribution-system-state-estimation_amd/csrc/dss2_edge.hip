@@ -376,6 +376,33 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restri
   if (q == 0 && j < len) out[j] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// several reductions in one launch (blockIdx.y = reduction): the small ones are launch/latency-bound on their own
+struct ReduceTable { dss2_reduce_desc d[8]; };
+__global__ void __launch_bounds__(256) reduce_slabs_multi_kernel(const ReduceTable tab) {
+  __shared__ float part[4][64];
+  const dss2_reduce_desc& d = tab.d[blockIdx.y];
+  const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if ((int64_t)blockIdx.x * 64 >= d.len) return;          // uniform per workgroup
+  const int q = threadIdx.y;
+  const int per = (d.n_slabs + 3) >> 2;
+  const int k0 = q * per, k1 = min(d.n_slabs, k0 + per);
+  float s = 0.f;
+  if (j < d.len) {
+    const float* p = d.slab + j;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * d.stride];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; k < k1; ++k) s += p[(size_t)k * d.stride];
+  }
+  part[q][threadIdx.x] = s;
+  __syncthreads();
+  if (q == 0 && j < d.len) d.out[j] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
 }  // namespace dss2
 
 using namespace dss2;
@@ -759,4 +786,20 @@ extern "C" int dss2_reduce_slabs(const float* slab, int n_slabs, int64_t stride,
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 63) / 64)), dim3(64, 4), 0, as_stream(stream), slab,
                      n_slabs, stride, out, len);
   return check_launch("reduce_slabs");
+}
+
+extern "C" int dss2_reduce_slabs_multi(const dss2_reduce_desc* descs_host, int n_desc, void* stream) {
+  if (n_desc <= 0) return 0;
+  if (!descs_host || n_desc > 8) { set_error("reduce_slabs_multi: 1..8 descriptors, got %d", n_desc); return 2; }
+  ReduceTable tab = {};
+  int64_t max_len = 0;
+  for (int i = 0; i < n_desc; ++i) {
+    tab.d[i] = descs_host[i];
+    if (!tab.d[i].slab || !tab.d[i].out || tab.d[i].n_slabs <= 0 || tab.d[i].len < 0) { set_error("reduce_slabs_multi: descriptor %d is incomplete", i); return 2; }
+    if (tab.d[i].len > max_len) max_len = tab.d[i].len;
+  }
+  if (max_len == 0) return 0;
+  hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3((unsigned)((max_len + 63) / 64), (unsigned)n_desc), dim3(64, 4), 0,
+                     as_stream(stream), tab);
+  return check_launch("reduce_slabs_multi");
 }

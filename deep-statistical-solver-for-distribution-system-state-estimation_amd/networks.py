@@ -131,7 +131,7 @@ def gemm_prop_chain(topo: Topology, X: torch.Tensor, hid: int, nmat: int, layers
 
 
 def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int, nmat: int, out_flat: torch.Tensor,
-          rowscale=None, rowscale2=None) -> None:
+          rowscale=None, rowscale2=None, pending=None) -> None:
     """out_flat[nmat*hout*hin + hout] <- [dW_0 .. dW_{nmat-1}, db] (deterministic two-pass sum); with
     rowscale2 additionally [nmat*hout] scaled column sums of P^m G (one block per matrix)."""
     narrow = nmat > 1 and nmat * hout <= 32 and rowscale2 is None
@@ -151,12 +151,11 @@ def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int,
     a.narrow = int(narrow)
     st = _stream(G)
     _lib.check(_lib.lib().dss2_wgrad(C.byref(a), st), "dss2_wgrad")
-    _lib.check(_lib.lib().dss2_reduce_slabs(slab.data_ptr(), n_split, stride, out_flat.data_ptr(), stride, st),
-               "dss2_reduce_slabs")
+    _reduce(slab, 0, n_split, stride, out_flat, stride, pending)
 
 
 def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Sequence[torch.Tensor], hin: int, nmat: int,
-                  out_flat: torch.Tensor, first_rowscale2=None, first_out=None) -> None:
+                  out_flat: torch.Tensor, first_rowscale2=None, first_out=None, pending=None) -> None:
     """len(Gs) layers of identical shape in one launch:
     out_flat[j * (nmat*hout*hin + hout) + ...] <- [dW_0 .. dW_{nmat-1}, db] of the plain layers, in order.
     With ``first_rowscale2`` layer 0 is a folded layer (see ``wgrad``): its result, with the extra nmat*hout
@@ -187,12 +186,32 @@ def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Seq
     L_ = _lib.lib()
     _lib.check(L_.dss2_wgrad_batched(C.byref(a), gs, xs, sl, rs, total, nl, st), "dss2_wgrad_batched")
     if first_rowscale2 is not None:
-        _lib.check(L_.dss2_reduce_slabs(slab.data_ptr(), n_split, total, first_out.data_ptr(), lens[0], st), "dss2_reduce_slabs")
+        _reduce(slab, 0, n_split, total, first_out, lens[0], pending)
         if nl > 1:
-            _lib.check(L_.dss2_reduce_slabs(slab.data_ptr() + 4 * lens[0], n_split, total, out_flat.data_ptr(),
-                                            total - lens[0], st), "dss2_reduce_slabs")
+            _reduce(slab, lens[0], n_split, total, out_flat, total - lens[0], pending)
     else:
-        _lib.check(L_.dss2_reduce_slabs(slab.data_ptr(), n_split, total, out_flat.data_ptr(), total, st), "dss2_reduce_slabs")
+        _reduce(slab, 0, n_split, total, out_flat, total, pending)
+
+
+def _reduce(slab: torch.Tensor, slab_off: int, n_slabs: int, stride: int, out: torch.Tensor, length: int, pending) -> None:
+    """out[:length] <- fixed-order sum of the slabs; with ``pending`` (a list) the reduction is only recorded, and
+    ``reduce_pending`` later runs all recorded ones in one launch (the slab tensors are kept alive by the list)."""
+    if pending is not None:
+        pending.append((slab, slab.data_ptr() + 4 * slab_off, n_slabs, stride, out, length))
+        return
+    _lib.check(_lib.lib().dss2_reduce_slabs(slab.data_ptr() + 4 * slab_off, n_slabs, stride, out.data_ptr(), length,
+                                            _stream(slab)), "dss2_reduce_slabs")
+
+
+def reduce_pending(pending) -> None:
+    for c0 in range(0, len(pending), 8):
+        chunk = pending[c0:c0 + 8]
+        descs = (_lib.ReduceDesc * len(chunk))()
+        for d, (slab, ptr, n_slabs, stride, out, length) in zip(descs, chunk):
+            d.slab, d.out, d.stride, d.len, d.n_slabs = ptr, out.data_ptr(), stride, length, n_slabs
+        _lib.check(_lib.lib().dss2_reduce_slabs_multi(C.addressof(descs), len(chunk), _stream(chunk[0][0])),
+                   "dss2_reduce_slabs_multi")
+    pending.clear()
 
 
 def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, ent: torch.Tensor, n_rows: int) -> torch.Tensor:
@@ -406,7 +425,7 @@ def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hou
 
 
 def _edge_aggr_backward(topo, gx0, x, ldx, ea, ldea, W1, b1, S, pack_w2_bwd, hid, hout, fn, fe, g_w1, g_w2, need_dx,
-                        pack_dx=None, dS=None):
+                        pack_dx=None, dS=None, pending=None):
     """g_w1: flat [hid*(2fn+fe) + hid] <- dW1, db1;  g_w2: flat [hout*hid + hout] <- dW2, db2.
     With ``dS`` given (second Linear folded into the consumer) gx0 / g_w2 are not used.
     Returns dx [N, fn] or None."""
@@ -433,7 +452,7 @@ def _edge_aggr_backward(topo, gx0, x, ldx, ea, ldea, W1, b1, S, pack_w2_bwd, hid
         _lib.check(L.dss2_edge_hidden_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
                                           topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(), slab.data_ptr(),
                                           n_slabs, _ptr(U), hid, N, hid, fn, fe, 0, st), "dss2_edge_hidden_bwd")
-    _lib.check(L.dss2_reduce_slabs(slab.data_ptr(), n_slabs, stride, g_w1.data_ptr(), stride, st), "dss2_reduce_slabs")
+    _reduce(slab, 0, n_slabs, stride, g_w1, stride, pending)
     if not need_dx:
         return None
     # U[0] = sum of dz over incoming edges (x enters as x_i), U[1] over outgoing edges (as x_j)
@@ -486,7 +505,7 @@ def _side_stream(device):
 
 
 def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=None, dmask=None, need_dh=True,
-                      rowscale2=None, defer_wgrad=False):
+                      rowscale2=None, defer_wgrad=False, pending=None):
     """g: gradient w.r.t. the conv's pre-activation output [N, hout] (already masked).
     g_flat <- [dW_0..dW_K, db]; returns dh (masked by relu_src / dmask of the PREVIOUS layer).
     The weight gradient only feeds the flat gradient buffer, so it may run on a side stream beside the
@@ -505,7 +524,7 @@ def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=No
         with torch.cuda.stream(side):
             wgrad(topo, g, hout, h, hin, nmat, g_flat, rowscale2=rowscale2)
     else:
-        wgrad(topo, g, hout, h, hin, nmat, g_flat, rowscale2=rowscale2)
+        wgrad(topo, g, hout, h, hin, nmat, g_flat, rowscale2=rowscale2, pending=pending)
     if not need_dh:
         return None
     dh = torch.empty(topo.N, hin, dtype=_F32, device=g.device)
@@ -809,11 +828,14 @@ class _MPNFn(torch.autograd.Function):
         deferred = []
         l_start = L - 1
         dS = None
+        pending = None          # slab reductions recorded here run in ONE launch at the end (chained path)
+        fold_late = False
         if L >= 3 and not WGRAD_SIDE_STREAM and WGRAD_BATCH and chain_supported(topo, nmat, hid, True):
             # last layer on its own; then the data-gradients of layers L-2 .. 0 as ONE chained launch
+            pending = []
             l = L - 1
             g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, mod.dim_out, flat[offs[2 + l]:offs[3 + l]],
-                                  relu_src=acts[l], dmask=masks[l - 1])
+                                  relu_src=acts[l], dmask=masks[l - 1], pending=pending)
             gl = [None] * (L - 1)                   # gl[l]: gradient w.r.t. layer l's pre-activation output
             gl[L - 2] = g
             layers = []
@@ -832,13 +854,13 @@ class _MPNFn(torch.autograd.Function):
             if fold is not None and L - 1 <= 8 and even:
                 # the folded conv 0 (input S, extra scaled bias sums) and the plain layers 1 .. L-2 in ONE launch
                 wgrad_batched(topo, gl, hid, [S] + acts[1:L - 1], hid, nmat, flat[offs[3]:offs[2 + L - 1]],
-                              first_rowscale2=topo.deg_pows, first_out=fold.gfold)
-                fold.backward(flat)
+                              first_rowscale2=topo.deg_pows, first_out=fold.gfold, pending=pending)
+                fold_late = True        # the chain rule of the fold needs the reduced gfold
                 dS, g = d_in, None
             else:
                 if fold is not None:
-                    wgrad(topo, gl[0], hid, S, hid, nmat, fold.gfold, rowscale2=topo.deg_pows)
-                    fold.backward(flat)
+                    wgrad(topo, gl[0], hid, S, hid, nmat, fold.gfold, rowscale2=topo.deg_pows, pending=pending)
+                    fold_late = True
                     dS, g = d_in, None
                 else:
                     g = d_in
@@ -873,12 +895,17 @@ class _MPNFn(torch.autograd.Function):
             l0, l1 = chunk[0][0], chunk[-1][0]
             out = flat[offs[2 + l0]:offs[3 + l1]]
             if len(chunk) == 1:
-                wgrad(topo, chunk[0][1], hid, chunk[0][2], hid, nmat, out)
+                wgrad(topo, chunk[0][1], hid, chunk[0][2], hid, nmat, out, pending=pending)
             else:
-                wgrad_batched(topo, [c[1] for c in chunk], hid, [c[2] for c in chunk], hid, nmat, out)
+                wgrad_batched(topo, [c[1] for c in chunk], hid, [c[2] for c in chunk], hid, nmat, out, pending=pending)
         dx = _edge_aggr_backward(topo, g, x, ldx, ea, ldea, W1, b1, S, plan.bwd[0], hid, hid, fn, fe,
                                  flat[offs[0]:offs[1]], flat[offs[1]:offs[2]], need_dx,
-                                 pack_dx=(plan.bwd[1 + L], plan.bwd[2 + L]), dS=(dS if fold is not None else None))
+                                 pack_dx=(plan.bwd[1 + L], plan.bwd[2 + L]), dS=(dS if fold is not None else None),
+                                 pending=pending)
+        if pending:
+            reduce_pending(pending)     # all slab reductions of the block in one launch
+        if fold_late:
+            fold.backward(flat)
         if need_dx and mod.skip:
             dx = dx + gout
         if WGRAD_SIDE_STREAM:

@@ -216,6 +216,12 @@ int dss2_wgrad_batched(const dss2_wgrad_args* args_host, const float* const* Gs,
 /* out[j] = sum_{s < n_slabs} slab[s*stride + j], j < len, fixed order. */
 int dss2_reduce_slabs(const float* slab, int n_slabs, int64_t stride, float* out, int64_t len, void* stream);
 
+/* up to 8 such reductions in ONE launch (same fixed order per output); descs_host: HOST array, passed by value */
+typedef struct dss2_reduce_desc {
+  const float* slab; float* out; int64_t stride; int64_t len; int32_t n_slabs; int32_t pad_;
+} dss2_reduce_desc;
+int dss2_reduce_slabs_multi(const dss2_reduce_desc* descs_host, int n_desc, void* stream);
+
 /* ---- K3: gsp_wls_edge + get_pflow, forward and backward (data.py:328-459) --------------- *
  * Phase 1 (dss2_wls_loss_partials): applies theta *= (1 - slack) IN PLACE on output[:,1]
  * (data.py:413), computes the batch-global V_hv / V_lv (data.py:335-336), the AC branch flows,
