@@ -52,9 +52,9 @@ __device__ __forceinline__ Flow branch_flow(float vf, float vt, float thf, float
 }
 
 // Stage 1 of the batch-global min/max of vn_kv: VMM_BLOCKS workgroups write (min, max) pairs to
-// vmm[2 + 2*b]; stage 2 (vminmax_finish, one wave) folds them into vmm[0..1].  min/max are
+// vmm[2 + 2*b]; stage 2 (vminmax_fold, in every consumer wave) folds them.  min/max are
 // order independent, so the result is exact and reproducible.
-constexpr int VMM_BLOCKS = 64;
+constexpr int VMM_BLOCKS = 64;   // == wavefront size (vminmax_fold)
 
 __global__ void __launch_bounds__(256) vminmax_kernel(const float* __restrict__ np, int64_t ld, int64_t n,
                                                        float* __restrict__ vmm) {
@@ -79,13 +79,17 @@ __global__ void __launch_bounds__(256) vminmax_kernel(const float* __restrict__ 
   }
 }
 
-__global__ void __launch_bounds__(64) vminmax_finish_kernel(float* __restrict__ vmm) {
-  float lo = vmm[2 + 2 * threadIdx.x], hi = vmm[3 + 2 * threadIdx.x];
+// Stage 2 is done by the consumers themselves: every wave folds the VMM_BLOCKS (= 64, one per lane) partial pairs
+// with a butterfly -- one coalesced load and twelve cross-lane ops instead of a kernel launch of its own.
+__device__ __forceinline__ void vminmax_fold(const float* __restrict__ vmm, float& vlv, float& vhv) {
+  const int lane = threadIdx.x & 63;
+  float lo = vmm[2 + 2 * lane], hi = vmm[3 + 2 * lane];
   for (int o = 32; o > 0; o >>= 1) {
     lo = fminf(lo, __shfl_xor(lo, o));
     hi = fmaxf(hi, __shfl_xor(hi, o));
   }
-  if (threadIdx.x == 0) { vmm[0] = lo; vmm[1] = hi; }
+  vlv = lo;
+  vhv = hi;
 }
 
 struct NodeMeas { float Z[4], R[4]; };
@@ -106,7 +110,8 @@ constexpr int LB = 256;  // loss kernels' block size
 __global__ void __launch_bounds__(LB) wls_partials_kernel(const dss2_wls_args p) {
   __shared__ double red[LB / 64][5];
   const int64_t i = (int64_t)blockIdx.x * LB + threadIdx.x;
-  const float vlv = p.vminmax[0], vhv = p.vminmax[1];
+  float vlv, vhv;
+  vminmax_fold(p.vminmax, vlv, vhv);
   const float xs0 = p.x_std[0], xm0 = p.x_mean[0];
   double acc[5] = {0, 0, 0, 0, 0};
   if (i < p.n_nodes) {
@@ -202,6 +207,8 @@ __global__ void __launch_bounds__(320) wls_finish_kernel(const double* __restric
 
 __global__ void __launch_bounds__(LB) wls_grad_kernel(const dss2_wls_args p) {
   const int64_t i = (int64_t)blockIdx.x * LB + threadIdx.x;
+  float vlv, vhv;
+  vminmax_fold(p.vminmax, vlv, vhv);   // all lanes (before any early return)
   const double Nn = p.sums[5], Ee = p.sums[6];
   const double mean_v = p.sums[2] / Nn, mean_t = p.sums[3] / Ee, mean_l = p.sums[4] / Ee;
   if (i == 0) {
@@ -214,7 +221,7 @@ __global__ void __launch_bounds__(LB) wls_grad_kernel(const dss2_wls_args p) {
   const float m_v = (float)(2.0 * p.lam_reg * mean_v / Nn);
   const float m_t = (float)(2.0 * p.lam_reg * mean_t / Ee);
   const float m_l = (float)(2.0 * p.lam_reg * mean_l / Ee);
-  const float vlv = p.vminmax[0], vhv = p.vminmax[1];
+  
   const float xs0 = p.x_std[0], xm0 = p.x_mean[0];
   const float kk = vlv * vlv;
   const float sqrt3 = 1.7320508075688772f;
@@ -312,10 +319,12 @@ __global__ void __launch_bounds__(LB) pflow_kernel(const float* __restrict__ y, 
                                                    int64_t n_edges, const float* __restrict__ vminmax,
                                                    float* __restrict__ pflow) {
   const int64_t e = (int64_t)blockIdx.x * LB + threadIdx.x;
+  float vlv, vhv;
+  vminmax_fold(vminmax, vlv, vhv);     // all lanes (before the early return)
   if (e >= n_edges) return;
   const int64_t a = efrom[e], b = eto[e];
   const EdgeP ep = load_edge_param(edge_param + e * ld_ep);
-  const Flow f = branch_flow(y[a * ldy], y[b * ldy], y[a * ldy + 1], y[b * ldy + 1], ep, vminmax[0], vminmax[1]);
+  const Flow f = branch_flow(y[a * ldy], y[b * ldy], y[a * ldy + 1], y[b * ldy + 1], ep, vlv, vhv);
   float* pf = pflow + e * 8;
   pf[0] = f.load_line; pf[1] = f.load_trafo; pf[2] = f.pf; pf[3] = f.qf;
   pf[4] = f.pt; pf[5] = f.qt; pf[6] = f.i_f; pf[7] = f.i_t;
@@ -405,7 +414,6 @@ extern "C" int dss2_wls_loss_partials(const dss2_wls_args* ap, void* stream) {
   const int64_t nb = (a.n_nodes + LB - 1) / LB;
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(vminmax_kernel, dim3(VMM_BLOCKS), dim3(256), 0, s, a.node_param, a.ld_np, a.n_nodes, a.vminmax);
-  hipLaunchKernelGGL(vminmax_finish_kernel, dim3(1), dim3(64), 0, s, a.vminmax);
   hipLaunchKernelGGL(wls_partials_kernel, dim3((unsigned)nb), dim3(LB), 0, s, a);
   hipLaunchKernelGGL(wls_finish_kernel, dim3(1), dim3(320), 0, s, a.partials, (int)nb, a.sums, (double)a.n_nodes,
                      (double)a.n_edges);
@@ -426,7 +434,6 @@ extern "C" int dss2_get_pflow(const float* y, int64_t ldy, const float* node_par
   if (n_nodes <= 0 || n_edges <= 0) { set_error("get_pflow: empty batch"); return 2; }
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(vminmax_kernel, dim3(VMM_BLOCKS), dim3(256), 0, s, node_param, ld_np, n_nodes, vminmax);
-  hipLaunchKernelGGL(vminmax_finish_kernel, dim3(1), dim3(64), 0, s, vminmax);
   hipLaunchKernelGGL(pflow_kernel, dim3((unsigned)((n_edges + LB - 1) / LB)), dim3(LB), 0, s, y, ldy, edge_param, ld_ep,
                      efrom, eto, n_edges, vminmax, pflow);
   return check_launch("get_pflow");
@@ -445,7 +452,6 @@ extern "C" int dss2_eval_batch(const float* out, int64_t ldo, const float* y, in
   const unsigned nbn = (unsigned)((n_nodes + LB - 1) / LB), nbe = (unsigned)((n_edges + LB - 1) / LB);
   hipLaunchKernelGGL(eval_denorm_kernel, dim3(nbn), dim3(LB), 0, s, out, ldo, node_param, ld_np, x_mean, x_std, yhat, n_nodes);
   hipLaunchKernelGGL(vminmax_kernel, dim3(VMM_BLOCKS), dim3(256), 0, s, node_param, ld_np, n_nodes, vminmax);
-  hipLaunchKernelGGL(vminmax_finish_kernel, dim3(1), dim3(64), 0, s, vminmax);
   hipLaunchKernelGGL(pflow_kernel, dim3(nbe), dim3(LB), 0, s, y, ldy, edge_param, ld_ep, efrom, eto, n_edges, vminmax, pf_true);
   hipLaunchKernelGGL(pflow_kernel, dim3(nbe), dim3(LB), 0, s, yhat, (int64_t)2, edge_param, ld_ep, efrom, eto, n_edges, vminmax, pf_out);
   int64_t m = n_nodes > n_edges ? n_nodes : n_edges;

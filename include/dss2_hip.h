@@ -249,7 +249,7 @@ typedef struct dss2_wls_args {
   float lam_v, lam_p, lam_pf, lam_reg;
   double* sums;            /* [8] device                                                  */
   double* partials;        /* [n_blocks_max*5] device scratch, n_blocks_max = 1024         */
-  float* vminmax;          /* [130] device scratch: [0]=V_lv, [1]=V_hv, then 64 partial pairs */
+  float* vminmax;          /* [130] device scratch: [2+2b], [3+2b] = (min, max) of vn_kv over workgroup b < 64 */
   float* apq;              /* [N,2] device scratch                                         */
   float* loss;             /* [1] device                                                   */
   float* grad_output;      /* [N,2] device, contiguous                                     */
