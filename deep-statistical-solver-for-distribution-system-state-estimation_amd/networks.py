@@ -494,7 +494,8 @@ _SIDE_STREAMS = {}
 EDGE_TILE_KERNELS = _os.environ.get("DSS2_EDGE_TILE", "1") == "1"       # 0 = row-per-wave CSR kernels
 WGRAD_SIDE_STREAM = _os.environ.get("DSS2_WGRAD_STREAM", "0") == "1"   # opt-in: +3 % at C2 (kernels then overlap)
 CHAIN_LAYERS = _os.environ.get("DSS2_CHAIN", "1") == "1"               # hid->hid layers of a block: one chained launch
-WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"          # hid->hid layers of a block: one wgrad launch
+WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"
+WGRAD_JOIN_FOLDED = None    # None: join the folded conv 0 into the batched launch only when the tiles divide evenly          # hid->hid layers of a block: one wgrad launch
 
 
 def _side_stream(device):
@@ -851,6 +852,8 @@ class _MPNFn(torch.autograd.Function):
             #  at C2 three layers x 85 workgroups leave a 13-vs-12-tile tail that costs more than the launch saves)
             ns3 = max(1, (256 * _WGRAD_PER_CU) // (L - 1))
             even = -(-topo.ntiles // ns3) * ns3 <= 1.03 * topo.ntiles
+            if WGRAD_JOIN_FOLDED is not None:
+                even = bool(WGRAD_JOIN_FOLDED)
             if fold is not None and L - 1 <= 8 and even:
                 # the folded conv 0 (input S, extra scaled bias sums) and the plain layers 1 .. L-2 in ONE launch
                 wgrad_batched(topo, gl, hid, [S] + acts[1:L - 1], hid, nmat, flat[offs[3]:offs[2 + L - 1]],

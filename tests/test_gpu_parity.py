@@ -410,12 +410,17 @@ def test_chained_and_batched_launches_equal_per_layer_launches(pkg, oracle, grid
     try:
         o_ref, g_ref = run(False, False, True)     # per-layer launches (fold on: same forward arithmetic)
         o_chain, g_chain = run(True, True, True)
+        nw.WGRAD_JOIN_FOLDED = True                # folded conv 0 in the same batched launch as the plain layers
+        o_join, g_join = run(True, True, True)
+        nw.WGRAD_JOIN_FOLDED = False
+        o_sep, g_sep = run(True, True, True)
         o_unfold, g_unfold = run(False, False, False)
     finally:
         nw.CHAIN_LAYERS, nw.WGRAD_BATCH, nw.FOLD_W2 = saved
-    assert torch.equal(o_chain, o_ref)
-    for a, c, (n, _) in zip(g_ref, g_chain, model.named_parameters()):
-        assert rel_err(c, a) < 2e-6, n
+        nw.WGRAD_JOIN_FOLDED = None
+    assert torch.equal(o_chain, o_ref) and torch.equal(o_join, o_ref) and torch.equal(o_sep, o_ref)
+    for a, c, j, sp, (n, _) in zip(g_ref, g_chain, g_join, g_sep, model.named_parameters()):
+        assert rel_err(c, a) < 2e-6 and rel_err(j, a) < 2e-6 and rel_err(sp, a) < 2e-6, n
     # folding the second Linear re-associates one matrix product: fp32 rounding level, not bitwise
     assert rel_err(o_unfold, o_ref) < 2e-6
     for a, c, (n, _) in zip(g_ref, g_unfold, model.named_parameters()):
