@@ -485,12 +485,26 @@ __global__ void __launch_bounds__(256) gemm_narrow_kernel(const dss2_gemm_prop_a
 
   const bool vec_ok = ((p.kreal & 3) == 0) && ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
   if (vec_ok) {
+    // all of a thread's 16-byte loads are issued before the first LDS write (one exposed memory latency instead
+    // of one per load: the rolled load -> write loop made this HBM-bound kernel latency-bound, 21.6 us at C2)
+    constexpr int PFN = 8;
     const int kq = p.kpad >> 2;
-    for (int idx = tid; idx < TM * kq; idx += 256) {
-      const int r = idx / kq, c = (idx - r * kq) << 2;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
-      *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = v;
+    for (int base = 0; base < TM * kq; base += PFN * 256) {
+      f32x4 px[PFN];
+#pragma unroll
+      for (int i = 0; i < PFN; ++i) {
+        const int idx = base + tid + i * 256;
+        const int r = idx / kq, c = (idx - r * kq) << 2;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (idx < TM * kq && r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
+        px[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < PFN; ++i) {
+        const int idx = base + tid + i * 256;
+        const int r = idx / kq, c = (idx - r * kq) << 2;
+        if (idx < TM * kq) *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = px[i];
+      }
     }
   } else {
     for (int idx = tid; idx < TM * p.kpad; idx += 256) {
