@@ -603,6 +603,118 @@ __global__ void __launch_bounds__(256) gemm_narrow_kernel(const dss2_gemm_prop_a
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Very narrow outputs (nmat * h <= 8, e.g. the last TAGConv H -> 2 with K = 2): a streaming variant of the
+// narrow kernel.  The work is a skinny product (6 outputs per row), i.e. HBM-bound, but the tile kernel above
+// keeps a 34 KB X tile in LDS (3 workgroups per CU) and feeds 16 dependent MFMA steps from L2, which makes it
+// latency-bound (20 us for 31 MB).  Here nothing of X is staged: four threads own a row, each loads eight
+// 16-byte pieces straight into registers (all in flight), multiplies them with the weight rows held in LDS,
+// and a 2-step butterfly finishes the dot products; only the [rows x 8] result goes through LDS for the
+// Horner recurrence across column blocks.  LDS is ~8 KB, so many workgroups per CU hide the memory latency.
+// ------------------------------------------------------------------------------------------
+constexpr int NS_MAXO = 8;      // outputs per row (nmat * h), zero padded
+template <int NRB>
+__global__ void __launch_bounds__(256) gemm_narrow_stream_kernel(const dss2_gemm_prop_args p) {
+  constexpr int TM = NRB * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x;
+  const int ts = p.tile_start[tile];
+  const int R = p.tile_start[tile + 1] - ts;
+  const int D = p.ell_width;
+  const int h = p.narrow_h, nm = p.nmat, no = nm * h;
+  const int kp = p.kpad;
+  float* Ws = smem;                               // [NS_MAXO][kp]
+  float* Gs = Ws + NS_MAXO * kp;                  // [TM][NS_MAXO]
+  int2* ell = reinterpret_cast<int2*>(Gs + TM * NS_MAXO);
+  // weights: unpack the MFMA fragment order [k/8][lane][4] of the single 32-column group
+  for (int idx = tid; idx < NS_MAXO * kp; idx += 256) {
+    const int j = idx / kp, k = idx - j * kp;
+    Ws[idx] = j < no ? p.Bp[(((size_t)(k >> 3) * 64 + ((k & 7) >> 2) * 32 + j) << 2) + (k & 3)] : 0.f;
+  }
+  if (nm > 1) {
+    const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
+    for (int idx = tid; idx < D * TM; idx += 256) ell[idx] = src[idx];
+  }
+  __syncthreads();
+  const int cq = kp >> 2;                          // columns per thread (a quarter of the row), multiple of 4
+  for (int item = tid; item < TM * 4; item += 256) {
+    const int row = item >> 2, q = item & 3;
+    float acc[NS_MAXO];
+#pragma unroll
+    for (int j = 0; j < NS_MAXO; ++j) acc[j] = 0.f;
+    const float* xr = p.X + (size_t)(ts + (row < R ? row : 0)) * p.ldx + q * cq;
+    for (int c0 = 0; c0 < cq; c0 += 32) {          // eight 16-byte loads in flight per pass
+      f32x4 xv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + 4 * i;
+        xv[i] = (row < R && c < cq && q * cq + c < p.kreal) ? *reinterpret_cast<const f32x4*>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + 4 * i;
+        if (c < cq) {
+#pragma unroll
+          for (int j = 0; j < NS_MAXO; ++j) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(Ws + j * kp + q * cq + c);
+            acc[j] = fmaf(xv[i][0], wv[0], fmaf(xv[i][1], wv[1], fmaf(xv[i][2], wv[2], fmaf(xv[i][3], wv[3], acc[j]))));
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NS_MAXO; ++j) {             // the four quarters of a row sit in adjacent lanes
+      acc[j] += __shfl_xor(acc[j], 1);
+      acc[j] += __shfl_xor(acc[j], 2);
+    }
+    if (q == 0) {
+#pragma unroll
+      for (int j = 0; j < NS_MAXO; ++j) Gs[row * NS_MAXO + j] = acc[j];
+    }
+  }
+  __syncthreads();
+  // Horner across column blocks, in place: block m <- G_m + P * block (m+1)
+  for (int m = nm - 2; m >= 0; --m) {
+    for (int idx = tid; idx < R * h; idx += 256) {
+      const int row = idx / h, j = idx - row * h;
+      const float* src = Gs + (m + 1) * h + j;
+      float sacc = Gs[row * NS_MAXO + m * h + j];
+      for (int k = 0; k < D; ++k) {
+        const int2 en = ell[k * TM + row];
+        sacc = fmaf(__int_as_float(en.y), src[en.x * NS_MAXO], sacc);
+      }
+      Gs[row * NS_MAXO + m * h + j] = sacc;
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < R * h; idx += 256) {
+    const int row = idx / h, j = idx - row * h;
+    const size_t grow = (size_t)(ts + row);
+    float y = Gs[row * NS_MAXO + j];
+    if (p.bias) y += p.rowscale ? p.bias[j] * p.rowscale[grow] : p.bias[j];
+    if (p.dmask) y *= p.dmask[grow * p.ld_dmask + j];
+    if (p.relu & 1) y = fmaxf(y, 0.f);
+    if (p.relu_src) y = (p.relu_src[grow * p.ld_relu + j] > 0.f) ? y : 0.f;
+    if (p.add_src) y += p.add_src[grow * p.ld_add + j];
+    p.Y[grow * p.ldy + j] = y;
+  }
+}
+
+static bool narrow_stream_ok(const dss2_gemm_prop_args& a) {
+  static const int enabled = [] { const char* e = getenv("DSS2_NARROW_STREAM"); return e ? atoi(e) : 1; }();
+  return enabled && a.nmat * a.narrow_h <= NS_MAXO && (a.kpad & 15) == 0 && (a.kreal & 3) == 0 && (a.ldx & 3) == 0 &&
+         (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && a.nrb <= 4 && (a.nmat == 1 || (a.ell_width > 0 && a.ell_tiles));
+}
+
+template <int NRB>
+static int launch_narrow_stream(const dss2_gemm_prop_args& a, hipStream_t stream) {
+  const size_t lds = (size_t)NS_MAXO * a.kpad * 4 + (size_t)NRB * 32 * NS_MAXO * 4 +
+                     (a.nmat > 1 ? (size_t)NRB * 32 * a.ell_width * 8 : 0);
+  hipLaunchKernelGGL(gemm_narrow_stream_kernel<NRB>, dim3(a.ntiles), dim3(256), lds, stream, a);
+  return check_launch("gemm_narrow_stream");
+}
+
 static size_t narrow_lds_bytes(int nrb, int nmat, int kpad, int max_nnz, int ell_width) {
   const size_t TM = (size_t)nrb * 32;
   size_t b = TM * (size_t)(kpad + 4) * 4 + TM * 32 * 4;
@@ -1009,6 +1121,14 @@ extern "C" int dss2_gemm_prop(const dss2_gemm_prop_args* ap, void* stream) {
     if (a.nmat * a.narrow_h > 32 || a.hout != a.narrow_h || a.prop_in) { set_error("gemm_prop: narrow mode needs nmat*narrow_h <= 32 and hout == narrow_h"); return 2; }
     if (narrow_lds_bytes(a.nrb, a.nmat, a.kpad, a.max_nnz, a.ell_width) > (size_t)kMaxLdsBytes) { set_error("gemm_prop(narrow): tile does not fit LDS"); return 3; }
     hipStream_t sn = as_stream(stream);
+    if (narrow_stream_ok(a)) {
+      switch (a.nrb) {
+        case 1: return launch_narrow_stream<1>(a, sn);
+        case 2: return launch_narrow_stream<2>(a, sn);
+        case 3: return launch_narrow_stream<3>(a, sn);
+        default: return launch_narrow_stream<4>(a, sn);
+      }
+    }
     switch (a.nrb) {
       case 1: return launch_narrow<1>(a, sn);
       case 2: return launch_narrow<2>(a, sn);
