@@ -453,6 +453,110 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient of a very narrow layer (nmat * hout <= 8: the last TAGConv H -> 2), streaming variant.
+// dW_cat[j][i] = sum_rows (P^m G)[row][o] * X[row][i] with j = m * hout + o is a rank-8 update per row: HBM-bound
+// (X is read once), but the MFMA tile kernel stages a 34 KB X slab per workgroup and runs one 32-wide MFMA block
+// for 6 useful columns.  Here a thread owns 4 consecutive input columns and keeps its 8 x 4 partial sums in
+// registers over all tiles of the workgroup; rows stream straight from HBM (eight 16-byte loads in flight per
+// thread), the propagated gradient rows [rows x 8] live in LDS and are read as broadcasts.
+// ------------------------------------------------------------------------------------------
+constexpr int WN_MAXO = 8;
+template <int NRB>
+__global__ void __launch_bounds__(256) wgrad_narrow_stream_kernel(const dss2_wgrad_args p) {
+  constexpr int TM = NRB * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int D = p.ell_width;
+  const int h = p.hout, nm = p.nmat;
+  const int tpr = p.hin >> 2;                 // threads per row (4 input columns each); divides 256
+  const int nrg = 256 / tpr;                  // row groups
+  const int c4 = (tid % tpr) * 4, rg = tid / tpr;
+  float* Gp = smem;                           // [TM][WN_MAXO]
+  int2* ell = reinterpret_cast<int2*>(Gp + TM * WN_MAXO);
+  float* red = reinterpret_cast<float*>(ell + (nm > 1 ? D * TM : 0));   // [nrg][WN_MAXO][hin] at the end
+  f32x4 acc[WN_MAXO];
+#pragma unroll
+  for (int j = 0; j < WN_MAXO; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbv = 0.f;                            // thread tid < hout: column sum of G[:, tid]
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    for (int idx = tid; idx < TM * WN_MAXO; idx += 256) {
+      const int row = idx / WN_MAXO, j = idx - row * WN_MAXO;
+      Gp[idx] = (row < R && j < h) ? p.G[(size_t)(ts + row) * p.ldg + j] : 0.f;
+    }
+    if (nm > 1) {
+      const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
+      for (int idx = tid; idx < D * TM; idx += 256) ell[idx] = src[idx];
+    }
+    __syncthreads();
+    for (int m = 1; m < nm; ++m) {            // (P^T)^m G appended as columns [m*h, (m+1)*h)
+      for (int idx = tid; idx < R * h; idx += 256) {
+        const int row = idx / h, j = idx - row * h;
+        float s = 0.f;
+        for (int k = 0; k < D; ++k) {
+          const int2 en = ell[k * TM + row];
+          s = fmaf(__int_as_float(en.y), Gp[en.x * WN_MAXO + (m - 1) * h + j], s);
+        }
+        Gp[row * WN_MAXO + m * h + j] = s;
+      }
+      __syncthreads();
+    }
+    if (tid < h) {
+      float s = 0.f;
+      for (int row = 0; row < R; ++row) s += Gp[row * WN_MAXO + tid];
+      dbv += s;
+    }
+    for (int r0 = rg; r0 < TM; r0 += 8 * nrg) {   // eight rows (16-byte loads) in flight per thread
+      f32x4 xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = r0 + u * nrg;
+        xv[u] = (row < R) ? *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + row) * p.ldx + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int row = r0 + u * nrg;
+        if (row < TM) {
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(Gp + row * WN_MAXO), g1 = *reinterpret_cast<const f32x4*>(Gp + row * WN_MAXO + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { acc[j] += xv[u] * g0[j]; acc[4 + j] += xv[u] * g1[j]; }
+        }
+      }
+    }
+    __syncthreads();                          // Gp / ell are rewritten by the next tile
+  }
+  // ---- reduce the row groups through LDS, write the slab [nmat*hout*hin][hout]
+#pragma unroll
+  for (int j = 0; j < WN_MAXO; ++j) *reinterpret_cast<f32x4*>(red + ((size_t)rg * WN_MAXO + j) * p.hin + c4) = acc[j];
+  __syncthreads();
+  float* out = p.slab + (size_t)blockIdx.x * ((size_t)nm * h * p.hin + h);
+  for (int idx = tid; idx < nm * h * p.hin; idx += 256) {
+    const int j = idx / p.hin, i = idx - j * p.hin;
+    float s = 0.f;
+    for (int g = 0; g < nrg; ++g) s += red[((size_t)g * WN_MAXO + j) * p.hin + i];
+    out[idx] = s;
+  }
+  if (tid < h) out[(size_t)nm * h * p.hin + tid] = dbv;
+}
+
+static bool wgrad_narrow_stream_ok(const dss2_wgrad_args& a) {
+  static const int enabled = [] { const char* e = getenv("DSS2_NARROW_STREAM"); return e ? atoi(e) : 1; }();
+  const int tpr = a.hin >> 2;
+  return enabled && a.narrow && a.nmat * a.hout <= WN_MAXO && (a.hin & 3) == 0 && tpr > 0 && tpr <= 256 && (256 % tpr) == 0 &&
+         (a.ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && !a.rowscale && a.nrb <= 4 &&
+         (a.nmat == 1 || (a.ell_width > 0 && a.ell_tiles));
+}
+
+template <int NRB>
+static int launch_wgrad_narrow_stream(const dss2_wgrad_args& a, hipStream_t stream) {
+  const size_t lds = (size_t)NRB * 32 * WN_MAXO * 4 + (a.nmat > 1 ? (size_t)a.ell_width * NRB * 32 * 8 : 0) +
+                     (size_t)256 * 4 * WN_MAXO * 4;     // red: nrg * 8 * hin floats = 256 * 4 * 8
+  hipLaunchKernelGGL(wgrad_narrow_stream_kernel<NRB>, dim3(a.n_split), dim3(256), lds, stream, a);
+  return check_launch("wgrad_narrow_stream");
+}
+
 // nmat here = number of MFMA matrix passes (1 in narrow mode); graph = a graph slice is staged
 static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz, int ell_width, bool graph) {
   const size_t TM = (size_t)nrb * 32;
@@ -508,6 +612,14 @@ static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::Wg
   if (a.narrow) {
     if (a.nmat * a.hout > 32) { set_error("wgrad: narrow mode needs nmat*hout <= 32"); return 2; }
     hipStream_t sn = as_stream(stream);
+    if (wb.n == 0 && wgrad_narrow_stream_ok(a)) {
+      switch (a.nrb) {
+        case 1: return launch_wgrad_narrow_stream<1>(a, sn);
+        case 2: return launch_wgrad_narrow_stream<2>(a, sn);
+        case 3: return launch_wgrad_narrow_stream<3>(a, sn);
+        default: return launch_wgrad_narrow_stream<4>(a, sn);
+      }
+    }
     switch (a.nrb) {
       case 1: return launch_wgrad<1, 1, 1>(a, sn, wb);
       case 2: return launch_wgrad<2, 1, 1>(a, sn, wb);
