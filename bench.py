@@ -89,11 +89,18 @@ def main():
         torch.cuda.synchronize()
 
     ramp_steps, t_ramp = 0, time.perf_counter() + args.ramp_seconds       # clock ramp (see --ramp-seconds), untimed
-    while time.perf_counter() < t_ramp:
+    while args.ramp_seconds > 0:
         for _ in range(20):
             step()
         torch.cuda.synchronize()
         ramp_steps += 20
+        go = time.perf_counter() < t_ramp
+        if distributed:      # the steps contain collectives: every rank must run the same number of them
+            flag = torch.tensor([int(go)], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            go = bool(flag.item())
+        if not go:
+            break
     for _ in range(args.warmup):
         step()
     sync()
