@@ -127,47 +127,49 @@ def main():
                    "loss": float(loss.item()), "clock_ramp_steps_before_warmup": ramp_steps},
     }
 
-    if rank == 0:
-        # ---- roofline of the dominant kernel, timed in situ (instrumented pass, not the timed region).
-        # The H -> H TAGConv layers (forward) and their data-gradients (backward) run as layer chains
-        # (gemm_chain_kernel: one launch per chain, activation tile resident in LDS); FLOPs per launch =
-        # layers in the chain x the per-layer GEMM + propagation FLOPs.
-        N, E2 = x.shape[0], 2 * ei.shape[1]
-        events = []
-        nw_mod = pkg.networks
-        orig_chain, orig_single = nw_mod.gemm_prop_chain, nw_mod.gemm_prop
+    # ---- instrumented pass: EVERY rank runs it (the steps contain collectives); rank 0 reports
+    # ---- roofline of the dominant kernel, timed in situ (instrumented pass, not the timed region).
+    # The H -> H TAGConv layers (forward) and their data-gradients (backward) run as layer chains
+    # (gemm_chain_kernel: one launch per chain, activation tile resident in LDS); FLOPs per launch =
+    # layers in the chain x the per-layer GEMM + propagation FLOPs.
+    N, E2 = x.shape[0], 2 * ei.shape[1]
+    events = []
+    nw_mod = pkg.networks
+    orig_chain, orig_single = nw_mod.gemm_prop_chain, nw_mod.gemm_prop
 
-        def timed_chain(topo, X, hid, nmat, layers, **kw):
+    def timed_chain(topo, X, hid, nmat, layers, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_chain(topo, X, hid, nmat, layers, **kw)
+        e1.record()
+        events.append((e0, e1, len(layers)))
+
+    def timed_single(topo, X, ldx, kreal, Bp, nmat, hout, Y, **kw):   # DSS2_CHAIN=0: one launch per layer
+        dominant = (kreal == HID and hout == HID and nmat == KHOPS + 1)
+        if dominant:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            orig_chain(topo, X, hid, nmat, layers, **kw)
+        orig_single(topo, X, ldx, kreal, Bp, nmat, hout, Y, **kw)
+        if dominant:
             e1.record()
-            events.append((e0, e1, len(layers)))
+            events.append((e0, e1, 1))
 
-        def timed_single(topo, X, ldx, kreal, Bp, nmat, hout, Y, **kw):   # DSS2_CHAIN=0: one launch per layer
-            dominant = (kreal == HID and hout == HID and nmat == KHOPS + 1)
-            if dominant:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            orig_single(topo, X, ldx, kreal, Bp, nmat, hout, Y, **kw)
-            if dominant:
-                e1.record()
-                events.append((e0, e1, 1))
+    def timed_pass(n_steps):
+        events.clear()
+        nw_mod.gemm_prop_chain, nw_mod.gemm_prop = timed_chain, timed_single
+        for _ in range(n_steps):
+            step()
+        torch.cuda.synchronize()
+        nw_mod.gemm_prop_chain, nw_mod.gemm_prop = orig_chain, orig_single
+        durs = sorted(a.elapsed_time(b) for a, b, _ in events)
+        layers = sum(n for _, _, n in events)
+        return sum(durs) / len(durs), durs[len(durs) // 2], len(durs), layers / len(durs)
 
-        def timed_pass(n_steps):
-            events.clear()
-            nw_mod.gemm_prop_chain, nw_mod.gemm_prop = timed_chain, timed_single
-            for _ in range(n_steps):
-                step()
-            torch.cuda.synchronize()
-            nw_mod.gemm_prop_chain, nw_mod.gemm_prop = orig_chain, orig_single
-            durs = sorted(a.elapsed_time(b) for a, b, _ in events)
-            layers = sum(n for _, _, n in events)
-            return sum(durs) / len(durs), durs[len(durs) // 2], len(durs), layers / len(durs)
+    avg_ms, med_ms, n_l, layers_per_launch = timed_pass(min(args.steps, 20))
 
+    if rank == 0:
         flops_layer = 2.0 * N * HID * (KHOPS + 1) * HID + 2.0 * KHOPS * E2 * HID
         bytes_layer = 4.0 * N * HID + 4.0 * (KHOPS + 1) * HID * HID          # write the output once + the weights
-        avg_ms, med_ms, n_l, layers_per_launch = timed_pass(min(args.steps, 20))
         chained = layers_per_launch > 1
         kname = "gemm_chain_kernel<2,3>" if chained else "gemm_prop_kernel<2,3,false>"
         traffic = None
