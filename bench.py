@@ -117,7 +117,7 @@ def main():
     value = args.batch * world / (dt / args.steps)
 
     result = {
-        "metric": "grid-samples/sec fwd+bwd (WLS loss)", "value": value, "unit": "graphs/s", "n_gpus": world,
+        "metric": "grid-samples/sec fwd+bwd (WLS loss), CIGRE-14 batch=4096, 1/2/4/8 GPU", "value": value, "unit": "graphs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"CIGRE-14 (15 buses, 14 closed branches) B={args.batch} graphs/GPU, "
