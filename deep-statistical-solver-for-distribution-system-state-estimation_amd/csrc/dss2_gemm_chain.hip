@@ -19,9 +19,15 @@ struct ChainTable { dss2_chain_layer l[CHAIN_MAX]; int n; };
 
 constexpr int chain_waves_per_simd(int nrb, int nmat) { return nrb * nmat * 16 <= 128 ? 2 : 1; }
 
-template <int NRB, int NMAT, int NW>   // NW: waves per workgroup the kernel is compiled for (one 32-column group per wave)
-__global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB, NMAT)) gemm_chain_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
+// NW: waves per workgroup the kernel is compiled for.  RS: row split -- RS waves share one 32-column group, each owning
+// NRB / RS of the tile's row blocks (its accumulators, its rows of the group's stage and of the epilogue); the
+// Horner gather reads the other waves' rows, so with RS > 1 the stage hand-offs are workgroup barriers.  RS = 2
+// gives narrow layers (H <= 64: one or two column groups) enough waves to hide their latencies.
+template <int NRB, int NMAT, int NW, int RS>
+__global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT)) gemm_chain_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
+  static_assert(NRB % RS == 0, "row split must divide the row blocks");
   constexpr int TM = NRB * 32;
+  constexpr int NRW = NRB / RS;          // row blocks per wave
   constexpr int PF = 8;
   constexpr int LDA = TM + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -35,7 +41,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB, NMAT)) gemm
   float* Xs = smem;
   float* stage = Xs + TM * LDX;
   const int D = p.ell_width;
-  int2* ell = reinterpret_cast<int2*>(stage + nw * 32 * LDA);
+  int2* ell = reinterpret_cast<int2*>(stage + (nw / RS) * 32 * LDA);   // one stage per column group
   const int ts = p.tile_start[tile];
   const int R = p.tile_start[tile + 1] - ts;
   const int kq = p.kpad >> 2;
@@ -74,8 +80,9 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB, NMAT)) gemm
   const int c32 = lane & 31, half = lane >> 5;
   const int nkk = p.kpad >> 3;
   const float* xa = Xs + c32 * LDX + half * 4;
-  float* st = stage + wave * (32 * LDA);   // wave-private [TM][32] row-major
-  const int cg = wave;                      // one column group per wave
+  const int cg = wave / RS, rs = wave - cg * RS;   // column group, and which share of its row blocks
+  float* st = stage + cg * (32 * LDA);      // per column group [TM][32] row-major (wave-private when RS == 1)
+  auto stage_sync = [&]() { if (RS == 1) wave_lds_sync(); else __syncthreads(); };
   const int ecol0 = cg * 32 + (lane & 7) * 4;
   const int cq = (lane & 7) * 4, r8 = lane >> 3;
   const bool ecol_ok = ecol0 < p.hout;
@@ -83,9 +90,9 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB, NMAT)) gemm
   for (int li = 0; li < ct.n; ++li) {
     const dss2_chain_layer& L = ct.l[li];    // uniform: scalar loads from the kernel-argument segment
     const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(L.Bp);
-    f32x16 acc[NRB][NMAT];
+    f32x16 acc[NRW][NMAT];
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
+    for (int rb = 0; rb < NRW; ++rb)
 #pragma unroll
       for (int m = 0; m < NMAT; ++m)
 #pragma unroll
@@ -94,19 +101,19 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB, NMAT)) gemm
     if (L.bias && ecol_ok) bias4 = *reinterpret_cast<const f32x4*>(L.bias + ecol0);
 
     // ---- MFMA over the X tile: 8 k per step, A (LDS) / B (packed weights, L2) ping-pong prefetch
-    f32x4 a0[NRB] = {}, a1[NRB] = {}, b0[NMAT] = {}, b1[NMAT] = {};
-    auto load_ab = [&](f32x4 (&a)[NRB], f32x4 (&b)[NMAT], int kk) {
+    f32x4 a0[NRW] = {}, a1[NRW] = {}, b0[NMAT] = {}, b1[NMAT] = {};
+    auto load_ab = [&](f32x4 (&a)[NRW], f32x4 (&b)[NMAT], int kk) {
       const int kc = kk < nkk ? kk : nkk - 1;
 #pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(xa + rb * 32 * LDX + kc * 8);
+      for (int rb = 0; rb < NRW; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(xa + (rs * NRW + rb) * 32 * LDX + kc * 8);
 #pragma unroll
       for (int m = 0; m < NMAT; ++m) b[m] = bp[((size_t)(m * p.ncg + cg) * nkk + kc) * 64 + lane];
     };
-    auto mma_ab = [&](const f32x4 (&a)[NRB], const f32x4 (&b)[NMAT]) {
+    auto mma_ab = [&](const f32x4 (&a)[NRW], const f32x4 (&b)[NMAT]) {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
+        for (int rb = 0; rb < NRW; ++rb)
 #pragma unroll
           for (int m = 0; m < NMAT; ++m)
             acc[rb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][s], b[m][s], acc[rb][m], 0, 0, 0);
@@ -128,26 +135,26 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB, NMAT)) gemm
     if (li + 1 < ct.n) __syncthreads();
 
     // ---- Horner: T = G_{NMAT-1}; T = G_m + P T   (ELL slice, wave-private stage)
-    f32x16 T[NRB];
+    f32x16 T[NRW];
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) T[rb] = acc[rb][NMAT - 1];
+    for (int rb = 0; rb < NRW; ++rb) T[rb] = acc[rb][NMAT - 1];
 #pragma unroll
     for (int m = NMAT - 2; m >= 0; --m) {
-      wave_lds_sync();
+      stage_sync();
 #pragma unroll
-      for (int rb = 0; rb < NRB; ++rb)
+      for (int rb = 0; rb < NRW; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
-      wave_lds_sync();
+        for (int r = 0; r < 16; ++r) st[((rs * NRW + rb) * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
+      stage_sync();
 #pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) T[rb] = acc[rb][m];
+      for (int rb = 0; rb < NRW; ++rb) T[rb] = acc[rb][m];
       for (int k = 0; k < D; ++k) {
         const int2* ek = ell + k * TM + 4 * half;
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
+        for (int rb = 0; rb < NRW; ++rb) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int2 en = ek[rb * 32 + acc_row(r, 0)];
+            const int2 en = ek[(rs * NRW + rb) * 32 + acc_row(r, 0)];
             T[rb][r] = fmaf(__int_as_float(en.y), st[en.x * 32 + c32], T[rb][r]);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -163,23 +170,24 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB, NMAT)) gemm
 #pragma unroll
       for (int m = 0; m < NMAT; ++m) pb4[m] = *reinterpret_cast<const f32x4*>(L.prebias + (size_t)m * p.hout + ecol0);
     }
-    wave_lds_sync();
+    stage_sync();      // (RS > 1: the other waves are done gathering from the stage)
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
+    for (int rb = 0; rb < NRW; ++rb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
-    wave_lds_sync();
+      for (int r = 0; r < 16; ++r) st[((rs * NRW + rb) * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
+    wave_lds_sync();   // the epilogue of a wave reads only the rows it wrote itself
     const int col0 = cg * 32 + cq;
     const bool keep = li + 1 < ct.n;
+    const int rlo = rs * NRW * 32, rhi = min(R, (rs + 1) * NRW * 32);     // this wave's rows
     if (col0 < p.hout) {
-      for (int row0 = r8; row0 < R; row0 += 16) {
+      for (int row0 = rlo + r8; row0 < rhi; row0 += 16) {
         f32x4 y[2], rs[2], dm[2], ad[2], ps[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int row = row0 + 8 * u;
-          const bool ok = row < R;
-          const size_t grow = (size_t)(ts + (ok ? row : 0));
-          y[u] = *reinterpret_cast<const f32x4*>(st + (ok ? row : 0) * 32 + cq);
+          const bool ok = row < rhi;
+          const size_t grow = (size_t)(ts + (ok ? row : rlo));
+          y[u] = *reinterpret_cast<const f32x4*>(st + (ok ? row : rlo) * 32 + cq);
           if (L.prebias) ps[u] = *reinterpret_cast<const f32x4*>(p.pre_rowscale + grow * 4);
           if (L.dmask) dm[u] = *reinterpret_cast<const f32x4*>(L.dmask + grow * p.ld_dmask + col0);
           if (L.relu_src) rs[u] = *reinterpret_cast<const f32x4*>(L.relu_src + grow * p.ld_relu + col0);
@@ -188,7 +196,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB, NMAT)) gemm
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int row = row0 + 8 * u;
-          if (row >= R) continue;
+          if (row >= rhi) continue;
           f32x4 v = y[u];
           if (L.bias) v += bias4;
           if (L.prebias) {
@@ -214,21 +222,29 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB, NMAT)) gemm
   }
 }
 
-static size_t chain_lds_bytes(int nrb, int kpad, int nw, int ell_width) {
+static size_t chain_lds_bytes(int nrb, int kpad, int ncg, int ell_width) {
   const size_t TM = (size_t)nrb * 32;
-  return TM * (size_t)(kpad + 4) * 4 + (size_t)nw * 32 * (TM + 4) * 4 + TM * (size_t)ell_width * 8;
+  return TM * (size_t)(kpad + 4) * 4 + (size_t)ncg * 32 * (TM + 4) * 4 + TM * (size_t)ell_width * 8;
 }
 
-template <int NRB, int NMAT, int NW>
+// row split: two waves per column group for narrow layers on two-row-block tiles (DSS2_CHAIN_RS overrides: 1 or 2)
+static int chain_row_split(int nrb, int ncg) {
+  static const int forced = [] { const char* e = getenv("DSS2_CHAIN_RS"); return e ? atoi(e) : 0; }();
+  if (nrb % 2 != 0 || 2 * ncg > 8) return 1;
+  if (forced == 1 || forced == 2) return forced;
+  return ncg <= 2 ? 2 : 1;
+}
+
+template <int NRB, int NMAT, int NW, int RS>
 static int launch_chain(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = gemm_chain_kernel<NRB, NMAT, NW>;
+  auto kern = gemm_chain_kernel<NRB, NMAT, NW, RS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
     if (e != hipSuccess) { set_error("gemm_prop_chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg), chain_lds_bytes(NRB, a.kpad, a.ncg, a.ell_width), stream, a, ct);
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg * RS), chain_lds_bytes(NRB, a.kpad, a.ncg, a.ell_width), stream, a, ct);
   return check_launch("gemm_prop_chain");
 }
 
@@ -270,12 +286,18 @@ extern "C" int dss2_gemm_prop_chain(const dss2_gemm_prop_args* ap, const dss2_ch
   }
   if (any_pre && !a.pre_rowscale) { set_error("gemm_prop_chain: prebias needs pre_rowscale"); return 2; }
   hipStream_t s = as_stream(stream);
+  const int rsplit = chain_row_split(a.nrb, a.ncg);
 #define DSS2_CASE(NRB, NMAT)                                                             \
-  if (a.nrb == NRB && a.nmat == NMAT)                                                    \
-    return a.ncg <= 4 ? launch_chain<NRB, NMAT, 4>(a, ct, s) : launch_chain<NRB, NMAT, 8>(a, ct, s);
+  if (a.nrb == NRB && a.nmat == NMAT && rsplit == 1)                                     \
+    return a.ncg <= 4 ? launch_chain<NRB, NMAT, 4, 1>(a, ct, s) : launch_chain<NRB, NMAT, 8, 1>(a, ct, s);
+#define DSS2_CASE2(NRB, NMAT)                                                            \
+  if (a.nrb == NRB && a.nmat == NMAT && rsplit == 2)                                     \
+    return 2 * a.ncg <= 4 ? launch_chain<NRB, NMAT, 4, 2>(a, ct, s) : launch_chain<NRB, NMAT, 8, 2>(a, ct, s);
   DSS2_CASE(1, 2) DSS2_CASE(1, 3) DSS2_CASE(1, 4) DSS2_CASE(2, 2) DSS2_CASE(2, 3) DSS2_CASE(2, 4)
   DSS2_CASE(3, 2) DSS2_CASE(3, 3) DSS2_CASE(4, 2)
+  DSS2_CASE2(2, 2) DSS2_CASE2(2, 3) DSS2_CASE2(2, 4) DSS2_CASE2(4, 2)
 #undef DSS2_CASE
+#undef DSS2_CASE2
   set_error("gemm_prop_chain: unsupported (nrb=%d, nmat=%d)", a.nrb, a.nmat);
   return 2;
 }
