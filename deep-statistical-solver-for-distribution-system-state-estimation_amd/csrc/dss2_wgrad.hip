@@ -76,10 +76,13 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   float* Zc = Zb + TM * LDZ;                                  // only with PF
   float* Xs = Za + (PF ? NMAT : (NMAT > 1 ? 2 : 1)) * TM * LDZ;
   const int D = p.ell_width;   // > 0: ELL [D][TM] slice of the transposed graph, else CSR slice
-  f32x4* Dsc = reinterpret_cast<f32x4*>(Xs + TM * XW);   // [TM] row scales of the tile (rowscale2)
-  f32x4* Bsum = reinterpret_cast<f32x4*>(Xs + TM * XW + TM * 4);   // [NT] running partial column sums (fast_bias)
-  int2* ell = reinterpret_cast<int2*>(Xs + TM * XW + TM * 4 + NT * 4);
-  int* lrow = reinterpret_cast<int*>(Xs + TM * XW + TM * 4 + NT * 4);
+  // X slab row length: XW (four 32-column blocks, one per wave) -- except in the 4-wave kernels (NB == 1: narrow
+  // hidden widths), where it shrinks to the input width so that more workgroups fit a CU (H = 32: 8 KB, not 32)
+  const int xw = (NB == 1) ? min(XW, ((p.hin + 31) >> 5) << 5) : XW;
+  f32x4* Dsc = reinterpret_cast<f32x4*>(Xs + TM * xw);   // [TM] row scales of the tile (rowscale2)
+  f32x4* Bsum = reinterpret_cast<f32x4*>(Xs + TM * xw + TM * 4);   // [NT] running partial column sums (fast_bias)
+  int2* ell = reinterpret_cast<int2*>(Xs + TM * xw + TM * 4 + NT * 4);
+  int* lrow = reinterpret_cast<int*>(Xs + TM * xw + TM * 4 + NT * 4);
   int2* lent = reinterpret_cast<int2*>(lrow + TM + 2);
 
   const int tid = threadIdx.x;
@@ -117,12 +120,12 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     if (!wave_active) return;
     const int n2e = (R + 1) >> 1;
     const float* zp = Z + half * LDZ + obh * NBW * 32 + c32;
-    const float* xp = Xs + half * XW + ibw * 32 + c32;
+    const float* xp = Xs + half * xw + ibw * 32 + c32;
     // two operand register sets in ping-pong: the LDS reads of step n2+1 are in flight while the
     // MFMAs of step n2 issue (no register copies => the wait sits at the first use)
     float b0, b1, a0[NBW], a1[NBW];
     auto ld = [&](float& b, float (&av)[NBW], int n2) {
-      b = xp[n2 * 2 * XW];
+      b = xp[n2 * 2 * xw];
 #pragma unroll
       for (int ob = 0; ob < NBW; ++ob) av[ob] = zp[n2 * 2 * LDZ + ob * 32];
     };
@@ -251,7 +254,8 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   auto issue_loads = [&](int tile) {
     const int ts = p.tile_start[tile];
     const int R = p.tile_start[tile + 1] - ts;
-    constexpr int QG = LDZ / 4, QX = XW / 4;
+    constexpr int QG = LDZ / 4;
+    const int QX = xw >> 2;
     if (gvec) {
 #pragma unroll
       for (int i = 0; i < NG4; ++i) {
@@ -268,13 +272,14 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
         const int idx = tid + i * NT;
         const int r = idx / QX, c = (idx - r * QX) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < R && xcol0 + c < p.hin) v = *reinterpret_cast<const f32x4*>(Xp + (size_t)(ts + r) * p.ldx + xcol0 + c);
+        if (idx < TM * QX && r < R && xcol0 + c < p.hin) v = *reinterpret_cast<const f32x4*>(Xp + (size_t)(ts + r) * p.ldx + xcol0 + c);
         px[i] = v;
       }
     }
   };
   auto write_slabs = [&](int ts, int R) {
-    constexpr int QG = LDZ / 4, QX = XW / 4;
+    constexpr int QG = LDZ / 4;
+    const int QX = xw >> 2;
     if (gvec) {
 #pragma unroll
       for (int i = 0; i < NG4; ++i) {
@@ -299,11 +304,11 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
       for (int i = 0; i < NX4; ++i) {
         const int idx = tid + i * NT;
         const int r = idx / QX, c = (idx - r * QX) * 4;
-        *reinterpret_cast<f32x4*>(Xs + r * XW + c) = px[i];
+        if (idx < TM * QX) *reinterpret_cast<f32x4*>(Xs + r * xw + c) = px[i];
       }
     } else {
-      for (int idx = tid; idx < TM * XW; idx += NT) {
-        const int r = idx / XW, c = idx - r * XW;
+      for (int idx = tid; idx < TM * xw; idx += NT) {
+        const int r = idx / xw, c = idx - r * xw;
         Xs[idx] = (r < R && xcol0 + c < p.hin) ? Xp[(size_t)(ts + r) * p.ldx + xcol0 + c] : 0.f;
       }
     }
@@ -558,9 +563,10 @@ static int launch_wgrad_narrow_stream(const dss2_wgrad_args& a, hipStream_t stre
 }
 
 // nmat here = number of MFMA matrix passes (1 in narrow mode); graph = a graph slice is staged
-static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz, int ell_width, bool graph) {
+static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz, int ell_width, bool graph, int hin = XW) {
   const size_t TM = (size_t)nrb * 32;
-  size_t b = TM * (size_t)nb * 32 * 4 * (wgrad_pf(nrb, nmat) ? 3 : (nmat > 1 ? 2 : 1)) + TM * XW * 4 + TM * 16;
+  const size_t xw = nb == 1 ? (size_t)((((hin + 31) >> 5) << 5) < XW ? (((hin + 31) >> 5) << 5) : XW) : (size_t)XW;
+  size_t b = TM * (size_t)nb * 32 * 4 * (wgrad_pf(nrb, nmat) ? 3 : (nmat > 1 ? 2 : 1)) + TM * xw * 4 + TM * 16;
   b += (size_t)(nb >= 2 ? 512 : 256) * 16;   // running bias partials, one 16-byte slot per thread
   if (graph) b += ell_width > 0 ? TM * (size_t)ell_width * 8 : (TM + 2) * 4 + (size_t)max_nnz * 8;
   return b;
@@ -589,7 +595,7 @@ static int launch_wgrad(const dss2_wgrad_args& a, hipStream_t stream, const Wgra
   }
   const int nob = (a.hout + 31) / 32, nib = (a.hin + 31) / 32;
   const int nobg = (nob + NB - 1) / NB, nibg = (nib + 3) / 4;
-  const size_t lds = wgrad_lds(NRB, NMAT, NB, a.max_nnz, a.ell_width, NMAT > 1 || a.narrow);
+  const size_t lds = wgrad_lds(NRB, NMAT, NB, a.max_nnz, a.ell_width, NMAT > 1 || a.narrow, a.hin);
   hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg, wb.n > 0 ? wb.n : 1), dim3(WgradGeom<NB>::NT), lds, stream, a, nibg, wb);
   return check_launch("wgrad");
 }
@@ -597,10 +603,9 @@ static int launch_wgrad(const dss2_wgrad_args& a, hipStream_t stream, const Wgra
 }  // namespace dss2
 
 extern "C" size_t dss2_wgrad_lds_bytes(int nrb, int nmat, int hout, int hin, int max_nnz, int ell_width) {
-  (void)hin;
-  if (nmat > 1 && nmat * hout <= 32) return dss2::wgrad_lds(nrb, 1, 1, max_nnz, ell_width, true);   // narrow mode
+  if (nmat > 1 && nmat * hout <= 32) return dss2::wgrad_lds(nrb, 1, 1, max_nnz, ell_width, true, hin);   // narrow mode
   const int nb = dss2::pick_nb(nrb, nmat, hout, max_nnz, ell_width);
-  return nb ? dss2::wgrad_lds(nrb, nmat, nb, max_nnz, ell_width, nmat > 1) : (size_t)-1;
+  return nb ? dss2::wgrad_lds(nrb, nmat, nb, max_nnz, ell_width, nmat > 1, hin) : (size_t)-1;
 }
 
 static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::WgradBatch& wb) {

@@ -136,7 +136,7 @@ def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int,
     rowscale2 additionally [nmat*hout] scaled column sums of P^m G (one block per matrix)."""
     narrow = nmat > 1 and nmat * hout <= 32 and rowscale2 is None
     lds = _lib.lib().dss2_wgrad_lds_bytes(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT)
-    per_cu = max(1, min(_WGRAD_PER_CU, (160 * 1024) // max(int(lds), 1)))     # resident workgroups per CU by LDS
+    per_cu = _wgrad_per_cu(int(lds))
     n_split = min(topo.ntiles, 256 * per_cu)
     stride = nmat * hout * hin + hout + (nmat * hout if rowscale2 is not None else 0)
     slab = torch.empty(n_split * stride, dtype=_F32, device=G.device)
@@ -162,7 +162,7 @@ def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Seq
     scaled sums, goes to ``first_out`` and the remaining layers to ``out_flat`` (two slab reductions)."""
     nl = len(Gs)
     lds = _lib.lib().dss2_wgrad_lds_bytes(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT)
-    per_cu = max(1, min(_WGRAD_PER_CU, (160 * 1024) // max(int(lds), 1)))
+    per_cu = _wgrad_per_cu(int(lds))
     n_split = min(topo.ntiles, max(1, (256 * per_cu) // nl))       # the layers share the chip
     stride = nmat * hout * hin + hout
     lens = [stride + (nmat * hout if (first_rowscale2 is not None and l == 0) else 0) for l in range(nl)]
@@ -315,6 +315,13 @@ class _FoldPlan:
 
 
 _WGRAD_PER_CU = int(_os.environ.get("DSS2_WGRAD_PER_CU", "2"))   # cap on persistent wgrad workgroups per CU (= slabs / 256)
+
+
+def _wgrad_per_cu(lds: int) -> int:
+    """Persistent weight-gradient workgroups per CU: what LDS allows, capped at 2 -- every extra workgroup is another
+    slab to write and reduce (measured at H = 32, where LDS would allow 4: caps 1 / 2 / 3 / 4 -> 2.73 / 2.15 / 2.32 /
+    2.27 ms per SkipPFN step)."""
+    return max(1, min(_WGRAD_PER_CU, (160 * 1024) // max(lds, 1)))
 FOLD_W2 = _os.environ.get("DSS2_FOLD_W2", "1") == "1"   # 0 = run the edge MLP's second Linear as its own GEMMs
 
 
@@ -850,7 +857,7 @@ class _MPNFn(torch.autograd.Function):
             d_in = layers[-1]["Y"]                  # gradient w.r.t. conv 0's input: dS (folded) or dx0
             # (joining conv 0 pays only when the tiles still divide evenly over the workgroups the layers share:
             #  at C2 three layers x 85 workgroups leave a 13-vs-12-tile tail that costs more than the launch saves)
-            ns3 = max(1, (256 * _WGRAD_PER_CU) // (L - 1))
+            ns3 = max(1, (256 * 2) // (L - 1))
             even = -(-topo.ntiles // ns3) * ns3 <= 1.03 * topo.ntiles
             if WGRAD_JOIN_FOLDED is not None:
                 even = bool(WGRAD_JOIN_FOLDED)
