@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   // Horner propagation on the matrix pipe (see below): dense A_hat of the tile as MFMA operand
   constexpr int LDA = TM + 4;
   constexpr bool mfma_horner = HM && NMAT > 1;
+  constexpr bool SEQ = !HM && NMAT > 1 && NRB * NMAT >= 16;   // one matrix at a time (see below)
 
   const int ts = p.tile_start[tile];
   const int R = p.tile_start[tile + 1] - ts;
@@ -212,6 +213,93 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   float* st = stage + wave * (32 * LDA);   // wave-private: [TM][32] row-major, or [32][TM+4] transposed
 
   for (int cg = wave; cg < p.ncg; cg += nw) {
+    // epilogue constants requested now so that their latency hides under the MFMA loop
+    const int ecol0 = cg * 32 + (lane & 7) * 4;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && ecol0 < p.hout && (p.hout & 3) == 0) bias4 = *reinterpret_cast<const f32x4*>(p.bias + ecol0);
+    f32x16 T[NRB];
+    if constexpr (SEQ) {
+      // Matrix-sequential mode for tall tiles (NRB * NMAT accumulators would not fit the register file: 6 x 3 spilled
+      // 359 registers and ran at 14 % of peak).  One matrix at a time, highest hop first:
+      //   T <- X B_{K};   T <- X B_m + P T  (m = K-1 .. 0)
+      // with T parked in the wave's LDS stage during the MFMA pass of the next matrix (the gather needs it there
+      // anyway).  Same MFMA count; the X tile is read NMAT times from LDS instead of once.
+#pragma unroll 1
+      for (int m = NMAT - 1; m >= 0; --m) {
+        f32x16 accm[NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accm[rb][r] = 0.f;
+        f32x4 sa0[NRB] = {}, sa1[NRB] = {}, sb0 = {}, sb1 = {};
+        auto sload = [&](f32x4 (&a)[NRB], f32x4& b, int kk) {
+          const int kc = kk < nkk ? kk : nkk - 1;
+#pragma unroll
+          for (int rb = 0; rb < NRB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(xa + rb * 32 * LDX + kc * 8);
+          b = bp[((size_t)(m * p.ncg + cg) * nkk + kc) * 64 + lane];
+        };
+        auto smma = [&](const f32x4 (&a)[NRB], const f32x4& b) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) accm[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][s], b[s], accm[rb], 0, 0, 0);
+        };
+        sload(sa0, sb0, 0);
+        int kk = 0;
+        for (; kk + 2 <= nkk; kk += 2) {
+          sload(sa1, sb1, kk + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          smma(sa0, sb0);
+          __builtin_amdgcn_sched_barrier(0);
+          sload(sa0, sb0, kk + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          smma(sa1, sb1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kk < nkk) smma(sa0, sb0);
+        if (m < NMAT - 1) {            // T (in the stage since the end of the previous pass) <- accm + P T
+          if (D > 0) {
+            for (int k = 0; k < D; ++k) {
+              const int2* ek = ell + k * TM + 4 * half;
+#pragma unroll
+              for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  const int2 en = ek[rb * 32 + acc_row(r, 0)];
+                  accm[rb][r] = fmaf(__int_as_float(en.y), st[en.x * 32 + c32], accm[rb][r]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + acc_row(r, half);
+                float s = accm[rb][r];
+                const int e1 = lrow[row + 1];
+                for (int e = lrow[row]; e < e1; ++e) {
+                  const int2 en = lent[e];
+                  s = fmaf(__int_as_float(en.y), st[en.x * 32 + c32], s);
+                }
+                accm[rb][r] = s;
+              }
+          }
+        }
+        if (m > 0) {                   // park T in the stage for the next pass
+          wave_lds_sync();
+#pragma unroll
+          for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = accm[rb][r];
+          wave_lds_sync();
+        } else {
+#pragma unroll
+          for (int rb = 0; rb < NRB; ++rb) T[rb] = accm[rb];
+        }
+      }
+    } else {
     f32x16 acc[NRB][NMAT];
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb)
@@ -219,10 +307,6 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       for (int m = 0; m < NMAT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rb][m][r] = 0.f;
-    // epilogue constants requested now so that their latency hides under the MFMA loop
-    const int ecol0 = cg * 32 + (lane & 7) * 4;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && ecol0 < p.hout && (p.hout & 3) == 0) bias4 = *reinterpret_cast<const f32x4*>(p.bias + ecol0);
 
     // k loop, 8 k-values per step, A (LDS) and B (packed weights, L2) fragments prefetched one step
     // ahead in two register buffers in ping-pong.  No register copies, and sched_barrier(0) pins "issue
@@ -266,7 +350,6 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
 
     DSS2_STAMP(3);
     // ---- Horner propagation: T = G_{NMAT-1}; T = G_m + P T
-    f32x16 T[NRB];
     if constexpr (mfma_horner) {
       // On the matrix pipe.  VALU/LDS-heavy Horner code is starved when it shares a SIMD with another
       // wave's back-to-back fp32 MFMAs (measured 3.5x slower), so the propagation is expressed as
@@ -358,6 +441,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       }
     }
     }
+    }   // !SEQ
     DSS2_STAMP(4);
     // ---- epilogue: T -> wave-private LDS stage -> rolled, row-coalesced store loop (keeps the
     //      address arithmetic of the five optional operands out of the unrolled register code)

@@ -425,3 +425,27 @@ def test_chained_and_batched_launches_equal_per_layer_launches(pkg, oracle, grid
     assert rel_err(o_unfold, o_ref) < 2e-6
     for a, c, (n, _) in zip(g_ref, g_unfold, model.named_parameters()):
         assert rel_err(c, a) < 5e-5, n
+
+
+@pytest.mark.parametrize("hid,L,K", [(128, 4, 2), (64, 3, 3)])
+def test_tall_tiles_matrix_sequential(pkg, oracle, hid, L, K):
+    """179-bus graphs need 192-row tiles (nrb = 6): NRB * NMAT accumulators no longer fit the register file, so the
+    tile kernel runs one matrix at a time (T parked in the LDS stage between passes).  Against the fp64 oracle."""
+    torch.manual_seed(0)
+    b = pkg.synthetic.make_batch(["ober179"], 12, seed=0)
+    ref = oracle.MPN(8, 6, 2, hid, L, K, 0.0).double()
+    mine = pkg.MPN(8, 6, 2, hid, L, K, 0.0)
+    mine.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    mine = mine.to(DEV)
+    b64 = {"x": b["x"].double(), "edge_index": b["edge_index"], "edge_attr": b["edge_attr"].double()}
+    out64, l64 = oracle.train_step(ref, b64, tuple(s.double() for s in b["stats"]))
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    st = tuple(s.to(DEV) for s in b["stats"])
+    assert pkg.topology.get_topology(ei, x.shape[0]).nrb == 6
+    out = mine(x[:, :8], ei, ea[:, :6])
+    loss = _loss(pkg.data, x, ei, ea, st, out, oracle.DEFAULT_REG_COEFS)
+    loss.backward()
+    assert rel_err(out, out64) < TOL_OUT
+    assert abs(loss.item() - l64.item()) <= TOL_LOSS * abs(l64.item())
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad, q.grad) < 2e-5, n
