@@ -90,11 +90,15 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nthreads = blockDim.x;
   const int nw = nthreads >> 6;
-  const int LDX = p.kpad + 4;
+  // K-halved staging (matrix-sequential mode only, flag bit 24 of p.relu set by the launcher): the X tile is staged in
+  // two halves of kpad/2 columns per matrix pass, so that a tall tile (192 rows x 128 columns = 101 KB) leaves room for
+  // four wave stages instead of two -- twice the waves, for 3x the (L2-resident) X reads.
+  const bool khalf = ((p.relu >> 24) & 1) != 0;
+  const int LDX = (khalf ? (p.kpad >> 1) : p.kpad) + 4;
   const int tile = blockIdx.x;
   int stamp_tile = tile; (void)stamp_tile;
   DSS2_STAMP(0);
-  const int dbg = p.relu >> 8;   // diagnostics only (tools/ablate.py): 1 no MFMA, 2 no Horner, 4 no stores, 8 no X staging
+  const int dbg = (p.relu >> 8) & 0xff;   // diagnostics only (tools/ablate.py): 1 no MFMA, 2 no Horner, 4 no stores, 8 no X staging
   {
     // Optional de-phasing of the two workgroups that share a CU (DSS2_STAGGER; off by default: the gain
     // was box dependent).  Speed heuristic only: ids 256..511 are the co-residents of ids 0..255.
@@ -127,7 +131,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   // ---- stage the X tile (zero padded to TM x kpad).  All of a thread's 16-byte loads are issued
   //      before the first LDS write (one exposed memory latency instead of one per load: the rolled
   //      load->wait->write loop cost 13-20 K cycles per tile under load, measured with stamps)
-  if (dbg & 8) {
+  if ((dbg & 8) || khalf) {
   } else if (vec_ok && TM * kq <= PF * nthreads) {
     f32x4 px[PF];
 #pragma unroll
@@ -232,31 +236,58 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
 #pragma unroll
           for (int r = 0; r < 16; ++r) accm[rb][r] = 0.f;
         f32x4 sa0[NRB] = {}, sa1[NRB] = {}, sb0 = {}, sb1 = {};
-        auto sload = [&](f32x4 (&a)[NRB], f32x4& b, int kk) {
-          const int kc = kk < nkk ? kk : nkk - 1;
-#pragma unroll
-          for (int rb = 0; rb < NRB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(xa + rb * 32 * LDX + kc * 8);
-          b = bp[((size_t)(m * p.ncg + cg) * nkk + kc) * 64 + lane];
-        };
         auto smma = [&](const f32x4 (&a)[NRB], const f32x4& b) {
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) accm[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][s], b[s], accm[rb], 0, 0, 0);
         };
-        sload(sa0, sb0, 0);
-        int kk = 0;
-        for (; kk + 2 <= nkk; kk += 2) {
-          sload(sa1, sb1, kk + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          smma(sa0, sb0);
-          __builtin_amdgcn_sched_barrier(0);
-          sload(sa0, sb0, kk + 2);
-          __builtin_amdgcn_sched_barrier(0);
-          smma(sa1, sb1);
-          __builtin_amdgcn_sched_barrier(0);
+        for (int hf = 0; hf < (khalf ? 2 : 1); ++hf) {
+          const int nkh = khalf ? (nkk >> 1) : nkk;      // k-steps in this half
+          const int kb = hf * nkh;                      // first k-step (B fragment index) of this half
+          if (khalf) {                                  // (uniform: every wave has exactly one column group)
+            __syncthreads();                            // everyone is done with the previous half
+            const int kh4 = p.kpad >> 3;                // 16-byte pieces per row in a half
+            for (int base = 0; base < TM * kh4; base += PF * nthreads) {
+              f32x4 px[PF];
+#pragma unroll
+              for (int i = 0; i < PF; ++i) {
+                const int idx = base + tid + i * nthreads;
+                const int r = idx / kh4, c = (idx - r * kh4) << 2;
+                const int cglob = hf * (p.kpad >> 1) + c;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (idx < TM * kh4 && r < R && cglob < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + cglob);
+                px[i] = v;
+              }
+#pragma unroll
+              for (int i = 0; i < PF; ++i) {
+                const int idx = base + tid + i * nthreads;
+                const int r = idx / kh4, c = (idx - r * kh4) << 2;
+                if (idx < TM * kh4) *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = px[i];
+              }
+            }
+            __syncthreads();
+          }
+          auto sload2 = [&](f32x4 (&a)[NRB], f32x4& b, int kk) {
+            const int kc = kk < nkh ? kk : nkh - 1;
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(xa + rb * 32 * LDX + kc * 8);
+            b = bp[((size_t)(m * p.ncg + cg) * nkk + kb + kc) * 64 + lane];
+          };
+          sload2(sa0, sb0, 0);
+          int kk = 0;
+          for (; kk + 2 <= nkh; kk += 2) {
+            sload2(sa1, sb1, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            smma(sa0, sb0);
+            __builtin_amdgcn_sched_barrier(0);
+            sload2(sa0, sb0, kk + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            smma(sa1, sb1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (kk < nkh) smma(sa0, sb0);
         }
-        if (kk < nkk) smma(sa0, sb0);
         if (m < NMAT - 1) {            // T (in the stage since the end of the previous pass) <- accm + P T
           if (D > 0) {
             for (int k = 0; k < D; ++k) {
@@ -1171,8 +1202,18 @@ static int launch(const dss2_gemm_prop_args& a_in, hipStream_t stream) {
     }
     attr_set = true;
   }
-  const size_t lds = lds_bytes(NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.ncg, a.max_nnz, a.ell_width);
-  const int nw = gemm_waves(a.ncg, NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.max_nnz, a.ell_width);
+  size_t lds = lds_bytes(NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.ncg, a.max_nnz, a.ell_width);
+  int nw = gemm_waves(a.ncg, NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.max_nnz, a.ell_width);
+  // tall tiles in matrix-sequential mode: stage the X tile in two K halves if that lets every column group have its wave
+  constexpr bool seq = !HM && NMAT > 1 && NRB * NMAT >= 16;
+  static const int kh_env = [] { const char* e = getenv("DSS2_GEMM_KHALF"); return e ? atoi(e) : 1; }();
+  const bool vec = ((a.kreal & 3) == 0) && ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
+  if (seq && kh_env && a.prop_in == 0 && a.ncg <= 4 && nw < a.ncg && (a.kpad & 15) == 0 && vec && a.ell_width > 0 &&
+      lds_bytes_nw(NRB, NMAT, a.kpad / 2, a.ncg, a.max_nnz, a.ell_width) <= (size_t)kMaxLdsBytes) {
+    nw = a.ncg;
+    lds = lds_bytes_nw(NRB, NMAT, a.kpad / 2, a.ncg, a.max_nnz, a.ell_width);
+    a.relu |= 1 << 24;
+  }
   // persistent over tiles: at most two workgroups per CU are co-resident at the LDS sizes of the
   // compute-heavy shapes, so 512 workgroups cover the chip; each walks tiles blockIdx.x, +grid, ...
   hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * nw), lds, stream, a);
