@@ -43,7 +43,9 @@ def main():
     ap.add_argument("--overlap-wgrad", action="store_true",
                     help="run the weight-gradient chain on a side stream beside the data-gradient chain (+3 %% at C2; "
                          "per-kernel durations then include the overlap)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="CPU time budget per thread count of the cpu_baseline sweep")
+    ap.add_argument("--min-window-seconds", type=float, default=0.5,
+                    help="repeat the K-step timed window until this much timed work has accumulated; the median window is reported")
     ap.add_argument("--ramp-seconds", type=float, default=2.0,
                     help="untimed load before the W warm-up steps: a fresh MI355X needs ~1 s of sustained work to reach "
                          "its steady clocks (measured: the first ~100 steps of a process run 40 %% slower)")
@@ -55,8 +57,9 @@ def main():
     import torch.distributed as dist
     env = pkg.parallel.init_from_env("nccl")
     rank, world, local = env["rank"], env["world"], env["local"]
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 as `python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     distributed = dist.is_initialized()          # true under torch.distributed.run, also at world size 1
@@ -103,16 +106,31 @@ def main():
             break
     for _ in range(args.warmup):
         step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    sync()
-    dt = time.perf_counter() - t0
-    if distributed:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    # Timed region: EXACTLY K steps between barrier + synchronize on both sides.  K steps of this workload can be as
+    # short as 16 ms, which is a fragile sample, so the K-step window is repeated until >= --min-window-seconds of
+    # timed work has accumulated and the MEDIAN window is reported (every window is bracketed the same way and its
+    # duration is the max over ranks).
+    windows = []
+    while True:
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        sync()
+        dt = time.perf_counter() - t0
+        if distributed:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        windows.append(dt)
+        go = sum(windows) < args.min_window_seconds and len(windows) < 200
+        if distributed:
+            flag = torch.tensor([int(go)], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            go = bool(flag.item())
+        if not go:
+            break
+    dt = sorted(windows)[len(windows) // 2]
     ms = dt / args.steps * 1e3
     value = args.batch * world / (dt / args.steps)
 
@@ -124,7 +142,8 @@ def main():
                                f"MPN L={LAYERS} H={HID} K={KHOPS} dropout=0: forward + gsp_wls_edge + backward"
                                + (" + RCCL loss-sum and gradient all-reduce" if distributed else ""),
                    "graphs_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                   "loss": float(loss.item()), "clock_ramp_steps_before_warmup": ramp_steps},
+                   "loss": float(loss.item()), "clock_ramp_steps_before_warmup": ramp_steps,
+                   "timed_windows": len(windows), "window_ms_min_median_max": [min(windows) * 1e3, dt * 1e3, max(windows) * 1e3]},
     }
 
     # ---- instrumented pass: EVERY rank runs it (the steps contain collectives); rank 0 reports
@@ -172,10 +191,12 @@ def main():
         bytes_layer = 4.0 * N * HID + 4.0 * (KHOPS + 1) * HID * HID          # write the output once + the weights
         chained = layers_per_launch > 1
         kname = "gemm_chain_kernel<2,3>" if chained else "gemm_prop_kernel<2,3,false>"
-        traffic = None
-        try:   # HBM bytes per launch from the committed PMC runs (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                traffic = json.load(fh)[kname]["hbm_bytes_per_launch"]
+        traffic, traffic_source = None, None
+        try:   # HBM bytes per launch from the committed PMC runs (FETCH_SIZE x2 on gfx950 + WRITE_SIZE): a pointer to
+               # the rocprofv3 --pmc evidence under profiles/, NOT a counter read during this run
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                rec = json.load(fh)[kname]
+            traffic, traffic_source = rec["hbm_bytes_per_launch"], rec.get("source", "profiles/pmc_traffic.json")
         except Exception:
             pass
         flops = flops_layer * layers_per_launch
@@ -186,53 +207,111 @@ def main():
                       + (f", {layers_per_launch:.0f} layers chained per launch)" if chained else ")"),
             "bound": "mfma", "achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
             "frac": flops / (avg_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "traffic": traffic,
+            "traffic_source": traffic_source,
             "launches_timed": n_l, "layers_per_launch": layers_per_launch, "avg_launch_us": avg_ms * 1e3,
             "median_launch_us": med_ms * 1e3, "algorithmic_flops_per_launch": flops,
             "algorithmic_bytes_per_launch": 4.0 * N * HID + bytes_layer * layers_per_launch,
             "mode": "side-stream overlap on" if pkg.networks.WGRAD_SIDE_STREAM else "single stream",
         }
-        # ---- standalone scatter-add (K6) against the HBM roofline (north_star asks for it separately)
-        topo = pkg.topology.get_topology(ei, N)
-        msg = torch.randn(E2, HID, device=dev)
-        ent = topo.perm.to(torch.int32)
-        for _ in range(5):
-            pkg.networks.segment_sum(msg, topo.rowptr, ent, N)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 50
-        e0.record()
-        for _ in range(reps):
-            pkg.networks.segment_sum(msg, topo.rowptr, ent, N)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / reps * 1e3
-        byts = 4.0 * E2 * HID + 4.0 * N * HID + 4.0 * E2 + 4.0 * (N + 1)
-        result["scatter_add"] = {"kernel": "dss2::segment_sum_kernel", "bound": "hbm", "achieved": byts / us / 1e3,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / us / 1e3 / HBM_PEAK_GBS,
-                                 "avg_launch_us": us, "algorithmic_bytes_per_launch": byts,
-                                 "note": "90.6 MB working set sits inside the 256 MiB Infinity Cache"}
+        # ---- standalone scatter-add (K6) against the HBM roofline (north_star asks for it separately), at two sizes:
+        # the C2 batch (90.9 MB: sits inside the 256 MiB Infinity Cache) and B = 32768 graphs (msg 470 MB + out 252 MB:
+        # cache-busting) -- the second one is the number to hold against HBM.
+        def scatter_point(n_graphs):
+            if n_graphs == args.batch:
+                ei_s, n_s = ei, N
+            else:
+                reps = n_graphs // args.batch
+                npg = N // args.batch
+                ei_s = torch.cat([ei + k * N for k in range(reps)], 1)      # block-diagonal copies of the batch
+                n_s = npg * args.batch * reps
+            topo = pkg.topology.get_topology(ei_s, n_s)
+            e2 = 2 * ei_s.shape[1]
+            msg = torch.randn(e2, HID, device=dev)
+            ent = topo.perm.to(torch.int32)
+            for _ in range(5):
+                pkg.networks.segment_sum(msg, topo.rowptr, ent, n_s)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps_t = 50 if n_graphs == args.batch else 20
+            e0.record()
+            for _ in range(reps_t):
+                pkg.networks.segment_sum(msg, topo.rowptr, ent, n_s)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / reps_t * 1e3
+            byts = 4.0 * e2 * HID + 4.0 * n_s * HID + 4.0 * e2 + 4.0 * (n_s + 1)
+            return {"graphs": n_graphs, "achieved": byts / us / 1e3, "frac": byts / us / 1e3 / HBM_PEAK_GBS,
+                    "frac_of_measured_copy_rate_6290": byts / us / 1e3 / 6290.0, "avg_launch_us": us,
+                    "algorithmic_bytes_per_launch": byts}
+        small = scatter_point(args.batch)
+        result["scatter_add"] = {"kernel": "dss2::segment_sum_kernel", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "cache_resident": small, "frac_cache_resident": small["frac"],
+                                 "note": "cache_resident: the C2 batch (90.9 MB working set < 256 MiB Infinity Cache); "
+                                         "cache_busting: B = 32768 graphs (722 MB), the HBM number"}
+        try:
+            big = scatter_point(8 * args.batch)
+            result["scatter_add"].update(cache_busting=big, frac_cache_busting=big["frac"], achieved=big["achieved"],
+                                         frac=big["frac"])
+        except Exception as exc:      # e.g. a box short of memory: report the cache-resident point only
+            result["scatter_add"].update(cache_busting=f"skipped: {exc}", achieved=small["achieved"], frac=small["frac"])
+        torch.cuda.empty_cache()
 
-        # ---- CPU baseline: the oracle (port of the reference's eager path) on this box's host cores
+        # ---- CPU baseline (SURVEY 8d / BASELINE.md 3): the oracle -- a port of the reference's PyTorch-eager path --
+        # on this box's host cores, same batch.  Thread sweep, best-of reported as `value`; plus the single-thread
+        # number, one "as-is" step (with the reference's unused dense Laplacian, data.py:422-423: 15.1 GB at C2)
+        # and configuration C1.  Every leg: one warm-up step, then >= 3 timed steps within --cpu-seconds.
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import dss2_oracle as oracle
             cpu_model = oracle.MPN(8, 6, 2, HID, LAYERS, KHOPS, 0.0)
             cpu_model.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
             cpu_batch = {"x": batch["x"], "edge_index": batch["edge_index"], "edge_attr": batch["edge_attr"]}
-            oracle.train_step(cpu_model, cpu_batch, batch["stats"], REG)          # warm-up
-            n, t0 = 0, time.perf_counter()
-            while True:
-                oracle.train_step(cpu_model, cpu_batch, batch["stats"], REG)
-                n += 1
-                if time.perf_counter() - t0 > args.cpu_seconds or n >= 200:
-                    break
-            cdt = (time.perf_counter() - t0) / n
-            result["cpu_baseline"] = {
-                "value": args.batch / cdt, "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": f"{n} steps of the same B={args.batch} CIGRE-14 batch (fwd + gsp_wls_edge + bwd), "
-                          f"PyTorch eager CPU fp32, unused dense Laplacian of data.py:422-423 stripped",
-                "host_cpus": os.cpu_count(), "ms_per_step": cdt * 1e3,
+            ncpu = os.cpu_count() or 1
+            max_threads = torch.get_num_threads()
+
+            def time_leg(mdl, bt, stats_, n_graphs, threads, as_is=False, budget=args.cpu_seconds):
+                torch.set_num_threads(threads)
+                oracle.train_step(mdl, bt, stats_, REG, as_is_laplacian=as_is)          # warm-up
+                n, t0 = 0, time.perf_counter()
+                while True:
+                    oracle.train_step(mdl, bt, stats_, REG, as_is_laplacian=as_is)
+                    n += 1
+                    el = time.perf_counter() - t0
+                    if (n >= 3 and el > budget) or n >= 50:
+                        break
+                return {"threads": threads, "graphs_per_s": n_graphs / (el / n), "ms_per_step": el / n * 1e3, "steps": n}
+
+            sweep = [time_leg(cpu_model, cpu_batch, batch["stats"], args.batch, th)
+                     for th in sorted({th for th in (1, 8, 16, 32, 64, max_threads) if th <= max(ncpu, 1)})]
+            best = max(sweep, key=lambda r: r["graphs_per_s"])
+            one = [r for r in sweep if r["threads"] == 1][0]
+            cb = {
+                "value": best["graphs_per_s"], "unit": "graphs/s", "cores": best["threads"], "kind": "port",
+                "sample": f"best of a thread sweep {[r['threads'] for r in sweep]} on the same B={args.batch} CIGRE-14 batch "
+                          f"(fwd + gsp_wls_edge + bwd, PyTorch eager CPU fp32, >= 3 steps per leg after one warm-up), "
+                          f"unused dense Laplacian of data.py:422-423 stripped",
+                "threads_best": best["threads"], "ms_per_step": best["ms_per_step"], "threads_1": one,
+                "thread_sweep": sweep, "host_cpus": ncpu,
             }
-            result["speedup_vs_cpu_baseline"] = value / (args.batch / cdt)
+            # as-is: with the dead dense Laplacian (N^2 fp32 zero-fill per step), needs ~2x 15.1 GB of free RAM
+            need = 2.2 * 4.0 * N * N
+            try:
+                import psutil
+                avail = psutil.virtual_memory().available
+            except Exception:
+                avail = 0
+            if avail > need:
+                cb["as_is_with_dense_laplacian"] = time_leg(cpu_model, cpu_batch, batch["stats"], args.batch, best["threads"],
+                                                            as_is=True, budget=min(args.cpu_seconds, 8.0))
+            else:
+                cb["as_is_with_dense_laplacian"] = f"skipped: needs {need / 1e9:.0f} GB of free host RAM, {avail / 1e9:.0f} GB available"
+            # C1: the reference's own CPU-runnable configuration (B = 64, H = 32, 1 layer)
+            c1b = pkg.synthetic.make_batch(["cigre14"], 64, seed=2000)
+            c1m = oracle.MPN(8, 6, 2, 32, 1, 2, 0.0)
+            c1 = [time_leg(c1m, c1b, c1b["stats"], 64, th, budget=1.0) for th in (1, min(8, ncpu))]
+            cb["c1_cigre14_b64_h32_l1"] = max(c1, key=lambda r: r["graphs_per_s"])
+            torch.set_num_threads(max_threads)
+            result["cpu_baseline"] = cb
+            result["speedup_vs_cpu_baseline"] = value / cb["value"]
         print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()

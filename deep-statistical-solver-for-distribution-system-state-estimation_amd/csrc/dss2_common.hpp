@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 kernels of libdss2_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -38,5 +39,21 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 constexpr int kMaxLdsBytes = 160 * 1024;
+
+// Opt a kernel into > 64 KB of dynamic LDS, once per (kernel, device): `done` is the kernel's own bitmask of the devices
+// that already have the attribute (the attribute belongs to the device's code object, and the autograd thread may
+// launch beside the main thread, hence the atomic).  A process that drives several GPUs sets it on each of them.
+inline int ensure_max_lds(const void* kern, std::atomic<uint32_t>& done, const char* what) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = -1;
+  if (dev >= 0 && ((done.load(std::memory_order_acquire) >> dev) & 1u)) return 0;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+    return 1;
+  }
+  if (dev >= 0) done.fetch_or(1u << dev, std::memory_order_release);
+  return 0;
+}
 
 }  // namespace dss2

@@ -701,19 +701,19 @@ static int launch_edge_mfma(const EdgeTileArgs& a, int grid, bool bwd, hipStream
   const int nw = a.h >> 5;                  // one wave per 32-column group of the hidden layer (<= 8)
   const size_t lds = edge_mfma_lds(NRB * 32, a.D, nw, bwd);
   if (bwd && a.U) {
-    static bool attr_u = false;
+    static std::atomic<uint32_t> lds_done{0};
     auto kern = edge_mfma_bwd_kernel<NRB, true>;
-    if (!attr_u) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes); attr_u = true; }
+    if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "edge_mfma_bwd")) return 1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, s, a);
   } else if (bwd) {
-    static bool attr_b = false;
+    static std::atomic<uint32_t> lds_done{0};
     auto kern = edge_mfma_bwd_kernel<NRB, false>;
-    if (!attr_b) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes); attr_b = true; }
+    if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "edge_mfma_bwd")) return 1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, s, a);
   } else {
-    static bool attr_f = false;
+    static std::atomic<uint32_t> lds_done{0};
     auto kern = edge_mfma_fwd_kernel<NRB>;
-    if (!attr_f) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes); attr_f = true; }
+    if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "edge_mfma_fwd")) return 1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, s, a);
   }
   return check_launch(bwd ? "edge_mfma_bwd" : "edge_mfma_fwd");

@@ -237,13 +237,9 @@ static int chain_row_split(int nrb, int ncg) {
 
 template <int NRB, int NMAT, int NW, int RS>
 static int launch_chain(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t stream) {
-  static bool attr_set = false;
+  static std::atomic<uint32_t> lds_done{0};
   auto kern = gemm_chain_kernel<NRB, NMAT, NW, RS>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
-    if (e != hipSuccess) { set_error("gemm_prop_chain: hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
-    attr_set = true;
-  }
+  if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop_chain")) return 1;
   hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg * RS), chain_lds_bytes(NRB, a.kpad, a.ncg, a.ell_width), stream, a, ct);
   return check_launch("gemm_prop_chain");
 }

@@ -80,7 +80,7 @@ constexpr int gemm_waves_per_simd(int nrb, int nmat) {
   return nrb * nmat * 16 <= 128 ? 2 : 1;
 }
 
-template <int NRB, int NMAT, bool HM>   // HM: Horner propagation on the matrix pipe (dense A_hat), else VALU/ELL
+template <int NRB, int NMAT>
 __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop_kernel(const dss2_gemm_prop_args p) {
   constexpr int TM = NRB * 32;
   constexpr int PF = 8;    // float4 registers per thread for the batched X staging (64 x 128 floats / 256 threads)
@@ -99,13 +99,6 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   int stamp_tile = tile; (void)stamp_tile;
   DSS2_STAMP(0);
   const int dbg = (p.relu >> 8) & 0xff;   // diagnostics only (tools/ablate.py): 1 no MFMA, 2 no Horner, 4 no stores, 8 no X staging
-  {
-    // Optional de-phasing of the two workgroups that share a CU (DSS2_STAGGER; off by default: the gain
-    // was box dependent).  Speed heuristic only: ids 256..511 are the co-residents of ids 0..255.
-    const int stag = (p.relu >> 16) & 0xff;
-    if (stag && (blockIdx.x >> 8) == 1)
-      for (int i = 0; i < stag; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   float* Xs = smem;
   float* stage = Xs + TM * LDX;
   // graph slice of the tile: ELL [D][TM] {local src, weight} when the batch's max degree D is small
@@ -115,10 +108,8 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   int* lrow = reinterpret_cast<int*>(stage + nw * 32 * (TM + 4));
   int2* lent = reinterpret_cast<int2*>(lrow + TM + 2);
   const bool need_graph = NMAT > 1 || p.prop_in > 0;
-  // Horner propagation on the matrix pipe (see below): dense A_hat of the tile as MFMA operand
   constexpr int LDA = TM + 4;
-  constexpr bool mfma_horner = HM && NMAT > 1;
-  constexpr bool SEQ = !HM && NMAT > 1 && NRB * NMAT >= 16;   // one matrix at a time (see below)
+  constexpr bool SEQ = NMAT > 1 && NRB * NMAT >= 16;   // one matrix at a time (see below)
 
   const int ts = p.tile_start[tile];
   const int R = p.tile_start[tile + 1] - ts;
@@ -381,51 +372,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
 
     DSS2_STAMP(3);
     // ---- Horner propagation: T = G_{NMAT-1}; T = G_m + P T
-    if constexpr (mfma_horner) {
-      // On the matrix pipe.  VALU/LDS-heavy Horner code is starved when it shares a SIMD with another
-      // wave's back-to-back fp32 MFMAs (measured 3.5x slower), so the propagation is expressed as
-      // MFMA work instead: the tile's dense A_hat [TM][TM] is built once in the (now dead) X region,
-      // T_{m+1} is written TRANSPOSED to the wave's stage so that both operands are 16-byte LDS reads,
-      // and acc[.][m] (= G_m) is the C-in:  acc[.][m] <- G_m + A_hat . T_{m+1}.  Zero entries add exact
-      // zeros; the k order is ascending source row, as in the sparse sum.
-      __syncthreads();                                   // every wave is done reading Xs
-      float* Ad = Xs;                                    // [TM][LDA]
-      for (int idx = tid; idx < TM * LDA / 4; idx += nthreads) reinterpret_cast<f32x4*>(Ad)[idx] = f32x4{0.f, 0.f, 0.f, 0.f};
-      __syncthreads();
-      for (int idx = tid; idx < D * TM; idx += nthreads) {
-        const int2 en = ell[idx];
-        const int r = idx % TM;
-        const float wv = __int_as_float(en.y);
-        if (wv != 0.f) atomicAdd(&Ad[r * LDA + en.x], wv);   // parallel edges accumulate
-      }
-      __syncthreads();
-#pragma unroll
-      for (int m = NMAT - 2; m >= 0; --m) {
-        wave_lds_sync();
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f32x4 v = {acc[rb][m + 1][4 * q], acc[rb][m + 1][4 * q + 1], acc[rb][m + 1][4 * q + 2], acc[rb][m + 1][4 * q + 3]};
-            *reinterpret_cast<f32x4*>(st + c32 * LDA + rb * 32 + 8 * q + 4 * half) = v;
-          }
-        wave_lds_sync();
-        const float* tb = st + c32 * LDA + 4 * half;
-        const float* ta = Ad + c32 * LDA + 4 * half;
-        for (int k8 = 0; k8 < TM / 8; ++k8) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(tb + k8 * 8);
-#pragma unroll
-          for (int rb = 0; rb < NRB; ++rb) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(ta + rb * 32 * LDA + k8 * 8);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-              acc[rb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[rb][m], 0, 0, 0);
-          }
-        }
-      }
-#pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) T[rb] = acc[rb][0];
-    } else {
+    {
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) T[rb] = acc[rb][NMAT - 1];
     if (NMAT > 1 && !(dbg & 2)) {
@@ -839,325 +786,12 @@ static size_t narrow_lds_bytes(int nrb, int nmat, int kpad, int max_nnz, int ell
 
 template <int NRB>
 static int launch_narrow(const dss2_gemm_prop_args& a, hipStream_t stream) {
-  static bool attr_set = false;
+  static std::atomic<uint32_t> lds_done{0};
   auto kern = gemm_narrow_kernel<NRB>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
-    if (e != hipSuccess) { set_error("gemm_narrow: hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
-    attr_set = true;
-  }
+  if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_narrow")) return 1;
   hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(256), narrow_lds_bytes(NRB, a.nmat, a.kpad, a.max_nnz, a.ell_width),
                      stream, a);
   return check_launch("gemm_narrow");
-}
-
-// ------------------------------------------------------------------------------------------
-// Two-team persistent variant (the fast path for H <= 128 outputs and tiles of <= 64 rows).
-//
-// Measured on the one-tile-per-workgroup kernel above (in-kernel stamps, tools/stamps.py): per tile a
-// wave spends ~25-31 K cycles in the MFMA loop and another 15-30 K in staging, Horner and stores,
-// and two co-resident workgroups run those phases in lock-step or collide at random, so the MFMA
-// pipe is busy only ~50 % of the time.  Here ONE 8-wave workgroup per CU walks the CU's tiles and
-// its two 4-wave teams (waves w and w+4 share a SIMD) ALTERNATE by construction:
-//     step s:  team (s & 1)      : MFMA loop of its current tile            (owns the matrix pipe)
-//              the other team    : Horner + stores of its previous tile, then stages its next tile
-//     __syncthreads()
-// so all VALU / LDS / global-memory work of one team sits under the other team's MFMAs, and the
-// pipe is never shared.  Each team has its own X buffer and ping-pong ELL slices; stages are
-// wave-private; the accumulators stay in registers from a team's MFMA step to its epilogue step.
-// ------------------------------------------------------------------------------------------
-template <int NRB, int NMAT>
-__global__ void __launch_bounds__(512, 2) gemm_prop2_kernel(const dss2_gemm_prop_args p) {
-  constexpr int TM = NRB * 32;
-  constexpr int PF = 8;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
-  const int team = wave >> 2, w4 = wave & 3;
-  const int ttid = tid & 255;                                   // thread index inside the team
-  const int LDX = p.kpad + 4;
-  const int D = p.ell_width;
-  const int kq = p.kpad >> 2;
-  const int nkk = p.kpad >> 3;
-  const int c32 = lane & 31, half = lane >> 5;
-
-  float* Xs = smem + team * (TM * LDX);                         // team X buffer
-  float* st = smem + 2 * (TM * LDX) + wave * (TM * 32);         // wave-private stage
-  int2* ell_base = reinterpret_cast<int2*>(smem + 2 * (TM * LDX) + 8 * (TM * 32)) + team * 2 * (D * TM);
-
-  const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(p.Bp);
-  const float* xa = Xs + c32 * LDX + half * 4;
-  const int cg = w4;                                            // ncg <= 4: one column group per wave
-  const bool has_cg = cg < p.ncg;
-  const bool vec_ok = ((p.kreal & 3) == 0) && ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0) &&
-                      (TM * kq <= PF * 256);
-
-  // item `it` of this team = tile blockIdx.x + (2*it + team) * gridDim.x
-  auto tile_of = [&](int it) { return (int)blockIdx.x + (2 * it + team) * (int)gridDim.x; };
-
-  auto stage_tile = [&](int it) {
-    const int tile = tile_of(it);
-    const int ts = p.tile_start[tile];
-    const int R = p.tile_start[tile + 1] - ts;
-    int2* ell = ell_base + (it & 1) * (D * TM);
-    if (vec_ok) {
-      f32x4 px[PF];
-#pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        const int idx = ttid + i * 256;
-        const int r = idx / kq, c = (idx - r * kq) << 2;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (idx < TM * kq && r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
-        px[i] = v;
-      }
-      if (NMAT > 1) {
-        const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
-        for (int idx = ttid; idx < D * TM; idx += 256) ell[idx] = src[idx];
-      }
-#pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        const int idx = ttid + i * 256;
-        const int r = idx / kq, c = (idx - r * kq) << 2;
-        if (idx < TM * kq) *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = px[i];
-      }
-    } else {
-      for (int idx = ttid; idx < TM * p.kpad; idx += 256) {
-        const int r = idx / p.kpad, c = idx - r * p.kpad;
-        Xs[r * LDX + c] = (r < R && c < p.kreal) ? p.X[(size_t)(ts + r) * p.ldx + c] : 0.f;
-      }
-      if (NMAT > 1) {
-        const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
-        for (int idx = ttid; idx < D * TM; idx += 256) ell[idx] = src[idx];
-      }
-    }
-  };
-
-  f32x16 acc[NRB][NMAT];
-  auto mfma_phase = [&]() {
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-      for (int m = 0; m < NMAT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rb][m][r] = 0.f;
-    if (!has_cg) return;
-    f32x4 a0[NRB], a1[NRB], b0[NMAT], b1[NMAT];
-    auto load_ab = [&](f32x4 (&a)[NRB], f32x4 (&b)[NMAT], int kk) {
-      const int kc = kk < nkk ? kk : nkk - 1;
-#pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(xa + rb * 32 * LDX + kc * 8);
-#pragma unroll
-      for (int m = 0; m < NMAT; ++m) b[m] = bp[((size_t)(m * p.ncg + cg) * nkk + kc) * 64 + lane];
-    };
-    auto mma_ab = [&](const f32x4 (&a)[NRB], const f32x4 (&b)[NMAT]) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-          for (int m = 0; m < NMAT; ++m)
-            acc[rb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][s], b[m][s], acc[rb][m], 0, 0, 0);
-    };
-    load_ab(a0, b0, 0);
-    int kk = 0;
-    for (; kk + 2 <= nkk; kk += 2) {
-      load_ab(a1, b1, kk + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_ab(a0, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      load_ab(a0, b0, kk + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_ab(a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (kk < nkk) mma_ab(a0, b0);
-  };
-
-  auto epilogue_phase = [&](int it) {
-    if (!has_cg) return;
-    const int tile = tile_of(it);
-    const int ts = p.tile_start[tile];
-    const int R = p.tile_start[tile + 1] - ts;
-    const int2* ell = ell_base + (it & 1) * (D * TM);
-    const int ecol0 = cg * 32 + (lane & 7) * 4;
-    const bool vec_epi = ((p.hout & 3) == 0) && ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.Y) & 15) == 0) &&
-                         (!p.bias || ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) &&
-                         (!p.relu_src || (((p.ld_relu & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.relu_src) & 15) == 0))) &&
-                         (!p.dmask || (((p.ld_dmask & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.dmask) & 15) == 0))) &&
-                         (!p.add_src || (((p.ld_add & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.add_src) & 15) == 0)));
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (vec_epi && p.bias && ecol0 < p.hout) bias4 = *reinterpret_cast<const f32x4*>(p.bias + ecol0);
-    // ---- Horner: T = G_{NMAT-1}; T = G_m + P T  (ELL slice, wave-private stage)
-    f32x16 T[NRB];
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) T[rb] = acc[rb][NMAT - 1];
-    if (NMAT > 1) {
-#pragma unroll
-      for (int m = NMAT - 2; m >= 0; --m) {
-        wave_lds_sync();
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
-        wave_lds_sync();
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) T[rb] = acc[rb][m];
-        for (int k = 0; k < D; ++k) {
-          const int2* ek = ell + k * TM + 4 * half;
-#pragma unroll
-          for (int rb = 0; rb < NRB; ++rb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int2 en = ek[rb * 32 + acc_row(r, 0)];
-              T[rb][r] = fmaf(__int_as_float(en.y), st[en.x * 32 + c32], T[rb][r]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
-    wave_lds_sync();
-    if (vec_epi) {
-      const int cq = (lane & 7) * 4, r8 = lane >> 3;
-      const int col0 = cg * 32 + cq;
-      if (col0 < p.hout) {
-        for (int row0 = r8; row0 < R; row0 += 16) {
-          f32x4 y[2], rs[2], dm[2], ad[2];
-          float rsc[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int row = row0 + 8 * u;
-            const bool ok = row < R;
-            const size_t grow = (size_t)(ts + (ok ? row : 0));
-            y[u] = *reinterpret_cast<const f32x4*>(st + (ok ? row : 0) * 32 + cq);
-            if (p.rowscale) rsc[u] = p.rowscale[grow];
-            if (p.dmask) dm[u] = *reinterpret_cast<const f32x4*>(p.dmask + grow * p.ld_dmask + col0);
-            if (p.relu_src) rs[u] = *reinterpret_cast<const f32x4*>(p.relu_src + grow * p.ld_relu + col0);
-            if (p.add_src) ad[u] = *reinterpret_cast<const f32x4*>(p.add_src + grow * p.ld_add + col0);
-          }
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int row = row0 + 8 * u;
-            if (row >= R) continue;
-            f32x4 v = y[u];
-            if (p.bias) v += p.rowscale ? bias4 * rsc[u] : bias4;
-            if (p.dmask) v *= dm[u];
-            if (p.relu & 1) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-            }
-            if (p.relu_src) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = rs[u][q] > 0.f ? v[q] : 0.f;
-            }
-            if (p.add_src) v += ad[u];
-            *reinterpret_cast<f32x4*>(p.Y + (size_t)(ts + row) * p.ldy + col0) = v;
-          }
-        }
-      }
-    } else {
-      const int colg = cg * 32 + c32;
-      if (colg < p.hout) {
-        const float bias = p.bias ? p.bias[colg] : 0.f;
-        for (int row = half; row < R; row += 2) {
-          const size_t grow = (size_t)(ts + row);
-          float y = st[row * 32 + c32];
-          if (p.bias) y += p.rowscale ? bias * p.rowscale[grow] : bias;
-          if (p.dmask) y *= p.dmask[grow * p.ld_dmask + colg];
-          if (p.relu & 1) y = fmaxf(y, 0.f);
-          if (p.relu_src) y = (p.relu_src[grow * p.ld_relu + colg] > 0.f) ? y : 0.f;
-          if (p.add_src) y += p.add_src[grow * p.ld_add + colg];
-          p.Y[grow * p.ldy + colg] = y;
-        }
-      }
-    }
-  };
-
-  // number of items of each team in this workgroup's tile list
-  const int nj = ((int)blockIdx.x < p.ntiles) ? (p.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-  const int n_mine = (nj + 1 - team) / 2;          // team 0: ceil(nj/2), team 1: floor(nj/2)
-  const int inphase = (p.relu >> 26) & 1;          // schedule knob (see launch2)
-  if (n_mine > 0) stage_tile(0);
-  __syncthreads();
-  if (inphase) {
-    // Both teams multiply in the same step (sharing the matrix pipe), then both run Horner + stores +
-    // staging in the next: measured, VALU/LDS-heavy epilogue work takes ~3.5x longer when it shares a
-    // SIMD with another wave's back-to-back fp32 MFMAs (44-46 K vs 12 K cycles per tile), so the
-    // alternating schedule's critical path is the starved epilogue, not the MFMAs.
-    const int n_max = (nj + 1) / 2;
-    for (int it = 0; it < n_max; ++it) {
-      DSS2_STAMP2(6 * it);
-      if (it < n_mine) mfma_phase();
-      DSS2_STAMP2(6 * it + 1);
-      __syncthreads();
-      DSS2_STAMP2(6 * it + 2);
-      if (it < n_mine) {
-        epilogue_phase(it);
-        if (it + 1 < n_mine) stage_tile(it + 1);
-      }
-      DSS2_STAMP2(6 * it + 3);
-      __syncthreads();
-      DSS2_STAMP2(6 * it + 4);
-    }
-    return;
-  }
-  const int nsteps = nj + 1;
-  for (int s = 0; s < nsteps; ++s) {
-    DSS2_STAMP2(3 * s);
-    if ((s & 1) == team) {
-      const int it = s >> 1;
-      if (it < n_mine) mfma_phase();
-    } else if (s >= 1) {
-      const int it = (s - 1) >> 1;                  // the item this team multiplied in step s-1
-      if (it < n_mine) {
-        epilogue_phase(it);
-        if (it + 1 < n_mine) stage_tile(it + 1);
-      }
-    }
-    DSS2_STAMP2(3 * s + 1);
-    __syncthreads();
-    DSS2_STAMP2(3 * s + 2);
-  }
-}
-
-static size_t lds2_bytes(int nrb, int kpad, int ell_width) {
-  const size_t TM = (size_t)nrb * 32;
-  return 2 * TM * (size_t)(kpad + 4) * 4 + 8 * TM * 32 * 4 + 4 * TM * (size_t)ell_width * 8;
-}
-
-template <int NRB, int NMAT>
-static int launch2(const dss2_gemm_prop_args& a, hipStream_t stream) {
-  static bool attr_set = false;
-  auto kern = gemm_prop2_kernel<NRB, NMAT>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
-    if (e != hipSuccess) { set_error("gemm_prop2: hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
-    attr_set = true;
-  }
-  // one workgroup per CU; each needs >= 2 tiles for the teams to alternate
-  int grid = (a.ntiles + 1) / 2;
-  if (grid > 256) grid = 256;
-  static const int inphase = [] { const char* e = getenv("DSS2_V2_INPHASE"); return e ? atoi(e) & 1 : 1; }();
-  dss2_gemm_prop_args b = a;
-  b.relu = (b.relu & 0xffffff) | (inphase << 26);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds2_bytes(NRB, a.kpad, a.ell_width), stream, b);
-  return check_launch("gemm_prop2");
-}
-
-static bool use_v2(const dss2_gemm_prop_args& a) {
-  static const int enabled = [] { const char* e = getenv("DSS2_GEMM_V2"); return e ? atoi(e) : 0; }();
-  if (!enabled || a.prop_in > 0 || a.narrow_h > 0 || a.ncg > 4 || a.nrb > 2 || a.ntiles < 2 || a.prebias) return false;
-  if (a.nmat > 1 && (a.ell_width <= 0 || a.ell_tiles == nullptr)) return false;
-  if (a.nmat > 3) return false;
-  return lds2_bytes(a.nrb, a.kpad, a.nmat > 1 ? a.ell_width : 0) <= (size_t)kMaxLdsBytes;
 }
 
 static size_t lds_bytes_nw(int nrb, int nmat, int kpad, int nw, int max_nnz, int ell_width) {
@@ -1168,11 +802,9 @@ static size_t lds_bytes_nw(int nrb, int nmat, int kpad, int nw, int max_nnz, int
 }
 
 // waves per workgroup: one per 32-column group up to 4, fewer if the wave-private stages would not
-// fit the 160 KiB LDS next to the X tile (large tiles); DSS2_GEMM_WAVES forces a smaller count
+// fit the 160 KiB LDS next to the X tile (large tiles)
 static int gemm_waves(int ncg, int nrb, int nmat, int kpad, int max_nnz, int ell_width) {
-  static const int forced = [] { const char* e = getenv("DSS2_GEMM_WAVES"); return e ? atoi(e) : 0; }();
   int nw = ncg < 4 ? ncg : 4;
-  if (forced > 0 && forced < nw) nw = forced;
   while (nw > 1 && lds_bytes_nw(nrb, nmat, kpad, nw, max_nnz, ell_width) > (size_t)kMaxLdsBytes) --nw;
   return nw;
 }
@@ -1181,31 +813,16 @@ static size_t lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz, int e
   return lds_bytes_nw(nrb, nmat, kpad, gemm_waves(ncg, nrb, nmat, kpad, max_nnz, ell_width), max_nnz, ell_width);
 }
 
-static int gemm_stagger() {
-  static const int v = [] { const char* e = getenv("DSS2_STAGGER"); return e ? atoi(e) : 0; }();   // off: gain was box dependent (0..-10 %)
-  return v < 0 ? 0 : (v > 255 ? 255 : v);
-}
-
-template <int NRB, int NMAT, bool HM>
+template <int NRB, int NMAT>
 static int launch(const dss2_gemm_prop_args& a_in, hipStream_t stream) {
   dss2_gemm_prop_args a = a_in;
-  // compute-heavy multi-round launches only: 2 co-resident workgroups, >= 2 rounds of 256
-  if (!(a.relu >> 16) && a.ntiles >= 512 && NMAT > 1 && a.kpad >= 64) a.relu |= gemm_stagger() << 16;
-  static bool attr_set = false;
-  auto kern = gemm_prop_kernel<NRB, NMAT, HM>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
-    if (e != hipSuccess) {
-      set_error("gemm_prop: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return 1;
-    }
-    attr_set = true;
-  }
+  static std::atomic<uint32_t> lds_done{0};
+  auto kern = gemm_prop_kernel<NRB, NMAT>;
+  if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop")) return 1;
   size_t lds = lds_bytes(NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.ncg, a.max_nnz, a.ell_width);
   int nw = gemm_waves(a.ncg, NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.max_nnz, a.ell_width);
   // tall tiles in matrix-sequential mode: stage the X tile in two K halves if that lets every column group have its wave
-  constexpr bool seq = !HM && NMAT > 1 && NRB * NMAT >= 16;
+  constexpr bool seq = NMAT > 1 && NRB * NMAT >= 16;
   static const int kh_env = [] { const char* e = getenv("DSS2_GEMM_KHALF"); return e ? atoi(e) : 1; }();
   const bool vec = ((a.kreal & 3) == 0) && ((a.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
   if (seq && kh_env && a.prop_in == 0 && a.ncg <= 4 && nw < a.ncg && (a.kpad & 15) == 0 && vec && a.ell_width > 0 &&
@@ -1271,24 +888,8 @@ extern "C" int dss2_gemm_prop(const dss2_gemm_prop_args* ap, void* stream) {
     return 3;
   }
   hipStream_t s = as_stream(stream);
-  if (use_v2(a)) {
-#define DSS2_CASE2(NRB, NMAT) \
-    if (a.nrb == NRB && a.nmat == NMAT) return launch2<NRB, NMAT>(a, s);
-    DSS2_CASE2(1, 1) DSS2_CASE2(1, 2) DSS2_CASE2(1, 3) DSS2_CASE2(2, 1) DSS2_CASE2(2, 2) DSS2_CASE2(2, 3)
-#undef DSS2_CASE2
-  }
-  // Horner on the matrix pipe when the dense A_hat fits the dead X region and every wave runs the
-  // column-group loop exactly once (the barriers around the A_hat build must be uniform)
-  static const int hm_env = [] { const char* e = getenv("DSS2_HORNER_MFMA"); return e ? atoi(e) : 0; }();   // measured slower at C2 (91 vs 86 us)
-  const bool hm = hm_env && a.nmat > 1 && a.ell_width > 0 && a.nrb * 32 <= a.kpad && a.prop_in == 0 &&
-                  gemm_waves(a.ncg, a.nrb, a.nmat, a.kpad, a.max_nnz, a.ell_width) == a.ncg;
-#define DSS2_CASEH(NRB, NMAT) \
-  if (hm && a.nrb == NRB && a.nmat == NMAT) return launch<NRB, NMAT, true>(a, s);
-  DSS2_CASEH(1, 2) DSS2_CASEH(1, 3) DSS2_CASEH(1, 4) DSS2_CASEH(2, 2) DSS2_CASEH(2, 3) DSS2_CASEH(2, 4)
-  DSS2_CASEH(3, 2) DSS2_CASEH(3, 3) DSS2_CASEH(3, 4) DSS2_CASEH(4, 2) DSS2_CASEH(4, 3)
-#undef DSS2_CASEH
 #define DSS2_CASE(NRB, NMAT) \
-  if (a.nrb == NRB && a.nmat == NMAT) return launch<NRB, NMAT, false>(a, s);
+  if (a.nrb == NRB && a.nmat == NMAT) return launch<NRB, NMAT>(a, s);
   DSS2_CASE(1, 1) DSS2_CASE(1, 2) DSS2_CASE(1, 3) DSS2_CASE(1, 4)
   DSS2_CASE(2, 1) DSS2_CASE(2, 2) DSS2_CASE(2, 3) DSS2_CASE(2, 4)
   DSS2_CASE(3, 1) DSS2_CASE(3, 2) DSS2_CASE(3, 3) DSS2_CASE(3, 4)

@@ -28,11 +28,12 @@ __device__ __forceinline__ EdgeP load_edge_param(const float* ep) {
   return e;
 }
 
-// data.py:370-388 with shift = 0 (phase_shift=True => shift = 0, data.py:362-365)
+// data.py:370-388.  shift: 0 with the reference's default phase_shift=True (data.py:362-363, the training path);
+// edge_param[:, 5] with phase_shift=False (data.py:364-365)
 __device__ __forceinline__ Flow branch_flow(float vf, float vt, float thf, float tht, const EdgeP& e, float vlv,
-                                            float vhv) {
+                                            float vhv, float shift = 0.f) {
   Flow f;
-  f.d = thf - tht;
+  f.d = thf - tht - shift;
   sincosf(f.d, &f.s, &f.c);
   const float kk = vlv * vlv;
   const float gg = e.G + e.Gs / 2.f, bb = e.B + e.Bs / 2.f;
@@ -317,14 +318,15 @@ __global__ void __launch_bounds__(LB) pflow_kernel(const float* __restrict__ y, 
                                                    const float* __restrict__ edge_param, int64_t ld_ep,
                                                    const int32_t* __restrict__ efrom, const int32_t* __restrict__ eto,
                                                    int64_t n_edges, const float* __restrict__ vminmax,
-                                                   float* __restrict__ pflow) {
+                                                   float* __restrict__ pflow, int apply_shift) {
   const int64_t e = (int64_t)blockIdx.x * LB + threadIdx.x;
   float vlv, vhv;
   vminmax_fold(vminmax, vlv, vhv);     // all lanes (before the early return)
   if (e >= n_edges) return;
   const int64_t a = efrom[e], b = eto[e];
   const EdgeP ep = load_edge_param(edge_param + e * ld_ep);
-  const Flow f = branch_flow(y[a * ldy], y[b * ldy], y[a * ldy + 1], y[b * ldy + 1], ep, vlv, vhv);
+  const float shift = apply_shift ? edge_param[e * ld_ep + 5] : 0.f;
+  const Flow f = branch_flow(y[a * ldy], y[b * ldy], y[a * ldy + 1], y[b * ldy + 1], ep, vlv, vhv, shift);
   float* pf = pflow + e * 8;
   pf[0] = f.load_line; pf[1] = f.load_trafo; pf[2] = f.pf; pf[3] = f.qf;
   pf[4] = f.pt; pf[5] = f.qt; pf[6] = f.i_f; pf[7] = f.i_t;
@@ -430,12 +432,13 @@ extern "C" int dss2_wls_loss_grad(const dss2_wls_args* ap, void* stream) {
 
 extern "C" int dss2_get_pflow(const float* y, int64_t ldy, const float* node_param, int64_t ld_np,
                               const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
-                              int64_t n_nodes, int64_t n_edges, float* vminmax, float* pflow, void* stream) {
+                              int64_t n_nodes, int64_t n_edges, float* vminmax, float* pflow, int apply_shift,
+                              void* stream) {
   if (n_nodes <= 0 || n_edges <= 0) { set_error("get_pflow: empty batch"); return 2; }
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(vminmax_kernel, dim3(VMM_BLOCKS), dim3(256), 0, s, node_param, ld_np, n_nodes, vminmax);
   hipLaunchKernelGGL(pflow_kernel, dim3((unsigned)((n_edges + LB - 1) / LB)), dim3(LB), 0, s, y, ldy, edge_param, ld_ep,
-                     efrom, eto, n_edges, vminmax, pflow);
+                     efrom, eto, n_edges, vminmax, pflow, apply_shift);
   return check_launch("get_pflow");
 }
 
@@ -452,8 +455,8 @@ extern "C" int dss2_eval_batch(const float* out, int64_t ldo, const float* y, in
   const unsigned nbn = (unsigned)((n_nodes + LB - 1) / LB), nbe = (unsigned)((n_edges + LB - 1) / LB);
   hipLaunchKernelGGL(eval_denorm_kernel, dim3(nbn), dim3(LB), 0, s, out, ldo, node_param, ld_np, x_mean, x_std, yhat, n_nodes);
   hipLaunchKernelGGL(vminmax_kernel, dim3(VMM_BLOCKS), dim3(256), 0, s, node_param, ld_np, n_nodes, vminmax);
-  hipLaunchKernelGGL(pflow_kernel, dim3(nbe), dim3(LB), 0, s, y, ldy, edge_param, ld_ep, efrom, eto, n_edges, vminmax, pf_true);
-  hipLaunchKernelGGL(pflow_kernel, dim3(nbe), dim3(LB), 0, s, yhat, (int64_t)2, edge_param, ld_ep, efrom, eto, n_edges, vminmax, pf_out);
+  hipLaunchKernelGGL(pflow_kernel, dim3(nbe), dim3(LB), 0, s, y, ldy, edge_param, ld_ep, efrom, eto, n_edges, vminmax, pf_true, 0);
+  hipLaunchKernelGGL(pflow_kernel, dim3(nbe), dim3(LB), 0, s, yhat, (int64_t)2, edge_param, ld_ep, efrom, eto, n_edges, vminmax, pf_out, 0);
   int64_t m = n_nodes > n_edges ? n_nodes : n_edges;
   int nb = (int)((m + 255) / 256);
   if (nb > 256) nb = 256;

@@ -585,14 +585,9 @@ static int pick_nb(int nrb, int nmat, int hout, int max_nnz, int ell_width) {
 
 template <int NRB, int NMAT, int NB>
 static int launch_wgrad(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb) {
-  static bool attr_set = false;
+  static std::atomic<uint32_t> lds_done{0};
   auto kern = wgrad_kernel<NRB, NMAT, NB>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
-    if (e != hipSuccess) { set_error("wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
-    attr_set = true;
-  }
+  if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "wgrad")) return 1;
   const int nob = (a.hout + 31) / 32, nib = (a.hin + 31) / 32;
   const int nobg = (nob + NB - 1) / NB, nibg = (nib + 3) / 4;
   const size_t lds = wgrad_lds(NRB, NMAT, NB, a.max_nnz, a.ell_width, NMAT > 1 || a.narrow, a.hin);

@@ -95,8 +95,12 @@ class _WlsFn(torch.autograd.Function):
         g = grad * gloss if gloss is not None else None
         if gloss is None:
             g = torch.zeros_like(grad)
-        if gout_unused is not None:   # other consumers of the (masked) output
+        if gout_unused is not None:
+            # other consumers of the MASKED output: theta_out = theta_in * (1 - slack) (data.py:413), so their gradient
+            # reaches the pre-mask theta scaled by (1 - slack), i.e. not at all at slack buses
             g = g + gout_unused
+            npar = ctx.keep[1][2][0]
+            g[:, 1] = g[:, 1] - gout_unused[:, 1] * npar[:, 1]
         return g, None, None, None, None
 
 
@@ -120,9 +124,8 @@ def get_pflow(y, edge_index, node_param, edge_param, phase_shift=True):
     """/root/reference/data.py:328-390: (loading_lines, loading_trafo, P_from, Q_from, P_to, Q_to,
     I_from, I_to) per stored edge.  Forward only (the reference uses it under no_grad for the
     evaluation metrics, dss2_run.py:193-194; the training path differentiates it inside
-    gsp_wls_edge)."""
-    if not phase_shift:
-        raise NotImplementedError("phase_shift=False (shift = edge_param[:, 5]) is never used by the reference driver")
+    gsp_wls_edge).  ``phase_shift`` keeps the reference's inverted sense: True (default) means shift = 0,
+    False subtracts edge_param[:, 5] from the angle difference (data.py:362-365)."""
     _require_gpu(y, edge_index, node_param, edge_param)
     y2, ldy = _rows(y.detach())
     npar, ld_np = _rows(node_param)
@@ -133,7 +136,7 @@ def get_pflow(y, edge_index, node_param, edge_param, phase_shift=True):
     pf = torch.empty(topo.E, 8, dtype=_F32, device=dev)
     _lib.check(_lib.lib().dss2_get_pflow(y2.data_ptr(), ldy, npar.data_ptr(), ld_np, epar.data_ptr(), ld_ep,
                                          topo.efrom.data_ptr(), topo.eto.data_ptr(), topo.N, topo.E, vmm.data_ptr(),
-                                         pf.data_ptr(), _stream(y)), "dss2_get_pflow")
+                                         pf.data_ptr(), int(not phase_shift), _stream(y)), "dss2_get_pflow")
     return tuple(pf[:, k] for k in range(8))
 
 

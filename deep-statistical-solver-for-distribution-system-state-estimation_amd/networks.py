@@ -96,6 +96,9 @@ def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.T
     _lib.check(_lib.lib().dss2_gemm_prop(C.byref(a), _stream(Y)), "dss2_gemm_prop")
 
 
+CHAIN_MAX = 8      # layers per dss2_gemm_prop_chain launch (csrc/dss2_gemm_chain.hip)
+
+
 def chain_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bool:
     """True when n >= 2 consecutive hid -> hid layers can run as one chained launch (dss2_gemm_prop_chain)."""
     ell, tiles = (topo.ellT, topo.ellT_tiles) if transposed else (topo.ell, topo.ell_tiles)
@@ -106,7 +109,13 @@ def chain_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bo
 def gemm_prop_chain(topo: Topology, X: torch.Tensor, hid: int, nmat: int, layers: Sequence[dict], transposed: bool = False,
                     pre_rowscale=None) -> None:
     """layers: dicts with Bp, Y and optionally bias, relu, relu_src, dmask, prebias; every tensor is [N, hid]
-    contiguous.  Layer i reads layer i-1's output from LDS; every Y is written once."""
+    contiguous.  Layer i reads layer i-1's output from LDS; every Y is written once.  The library chains at most
+    CHAIN_MAX layers per launch; deeper stacks run as consecutive launches (the next one reads the previous one's last Y)."""
+    if len(layers) > CHAIN_MAX:
+        for c0 in range(0, len(layers), CHAIN_MAX):
+            gemm_prop_chain(topo, X if c0 == 0 else layers[c0 - 1]["Y"], hid, nmat, layers[c0:c0 + CHAIN_MAX],
+                            transposed=transposed, pre_rowscale=pre_rowscale)
+        return
     a = _lib.GemmPropArgs()
     a.X, a.ldx, a.kreal, a.kpad = X.data_ptr(), X.stride(0), hid, _round8(hid)
     a.hout, a.ncg, a.ldy, a.ld_relu, a.ld_dmask, a.ld_add = hid, _ncg(hid), hid, hid, hid, hid

@@ -17,6 +17,11 @@ class FusedAdamax(torch.optim.Optimizer):
     def __init__(self, params, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._table = {}
+        self.table_builds = 0      # diagnostics: how often the descriptor table had to be rebuilt
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._table = {}           # the state tensors were replaced
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -40,17 +45,21 @@ class FusedAdamax(torch.optim.Optimizer):
             for p in ps:
                 self.state[p]["step"] = torch.tensor(float(step))
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
-            key = tuple((p.data_ptr(), g.data_ptr()) for p, g in zip(ps, grads))
+            # the descriptor table is keyed by every address it holds; the gradient tensors themselves are NOT kept
+            # (holding them would pin the previous flat gradient buffer, the next backward would allocate elsewhere
+            # and the table would be rebuilt every step)
+            key = tuple((p.data_ptr(), g.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_inf"].data_ptr())
+                        for p, g in zip(ps, grads))
             cached = self._table.get(gi)
-            if cached is None or cached[0] != key:       # gradient views move every backward: rebuild the table
-                arr = np.array([(p.data_ptr(), g.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
-                                 self.state[p]["exp_inf"].data_ptr(), p.numel()) for p, g in zip(ps, grads)], dtype=_DESC)
+            if cached is None or cached[0] != key:
+                arr = np.array([k + (p.numel(),) for k, p in zip(key, ps)], dtype=_DESC)
                 host = torch.from_numpy(arr.view(np.uint8).copy())
                 dev_tab = cached[1] if cached is not None and cached[1].numel() == host.numel() else \
                     torch.empty(host.numel(), dtype=torch.uint8, device=ps[0].device)
                 dev_tab.copy_(host.pin_memory(), non_blocking=True)
-                cached = (key, dev_tab, max(p.numel() for p in ps), grads)
+                cached = (key, dev_tab, max(p.numel() for p in ps))
                 self._table[gi] = cached
+                self.table_builds += 1
             b1, b2 = group["betas"]
             st = torch.cuda.current_stream(ps[0].device).cuda_stream
             _lib.check(_lib.lib().dss2_adamax_step(cached[1].data_ptr(), len(ps), cached[2], float(group["lr"]), float(b1),

@@ -9,15 +9,17 @@ exactly what sharding its batch needs:
   all-reduced between the two loss phases (``gsp_wls_edge(..., group=pg)``; 7 doubles);
 * every MPN block produces its parameter gradients in one flat fp32 bucket; the bucket is
   all-reduced (SUM: each rank's loss is already normalised by the global counts) once per block
-  per step (``attach_grad_allreduce``) - a single latency-bound collective of 0.67 MB at C2/C4.
+  per step (``attach_grad_allreduce``) - a single latency-bound collective of 0.67 MB at C2/C4;
+  ``async_op=True`` lets the collectives of a PFN stack overlap the backward of the blocks below.
 
 These helpers are device agnostic (plain torch tensors + a process group), which is what lets the
 world_size-2 gloo tests exercise them on CPU.
 """
 from __future__ import annotations
 
+import datetime
 import os
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -35,11 +37,16 @@ def init_from_env(backend: Optional[str] = None) -> Dict[str, int]:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # every collective wait is bounded: past the timeout the process-group watchdog aborts the communicator and
+        # the process exits non-zero instead of hanging the node (DSS2_COLLECTIVE_TIMEOUT_S, default 120 s)
+        timeout = datetime.timedelta(seconds=float(os.environ.get("DSS2_COLLECTIVE_TIMEOUT_S", "120")))
         if backend == "nccl":
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout,
+                                    device_id=torch.device("cuda", local))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
     return {"rank": rank, "world": world, "local": local}
 
 
@@ -76,20 +83,46 @@ def allreduce_loss_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
     return sums
 
 
-def allreduce_flat_grads(flat: torch.Tensor, group=None) -> torch.Tensor:
+def allreduce_flat_grads(flat: torch.Tensor, group=None, pending: Optional[List] = None) -> torch.Tensor:
+    """SUM all-reduce of one block's flat gradient bucket.  With ``pending`` (a list) the collective is issued
+    asynchronously (it runs on the backend's own stream while the main stream goes on with the backward of the block
+    below) and its work handle is appended; ``wait_grad_allreduce`` joins all of them before the optimizer."""
     if dist.is_initialized():
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if pending is not None:
+            pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 
 
-def attach_grad_allreduce(model: torch.nn.Module, group=None) -> int:
+def attach_grad_allreduce(model: torch.nn.Module, group=None, async_op: bool = False) -> int:
     """Install the flat-bucket all-reduce on every MPN block of `model` (MPN / SkipMPN themselves,
-    or the blocks inside PFN / SkipPFN).  Returns the number of blocks hooked."""
+    or the blocks inside PFN / SkipPFN).  Returns the number of blocks hooked.
+
+    ``async_op=True``: each block's collective is launched as soon as that block's backward has produced its bucket
+    and overlaps the backward of the blocks below it (a PFN / SkipPFN stack then has its L collectives in flight
+    instead of L serialised ones); call ``wait_grad_allreduce(model)`` after ``loss.backward()`` and before reading
+    the gradients (the wait is a stream dependency, not a host block)."""
     n = 0
+    pending = [] if async_op else None
+    model._dss2_pending_allreduce = pending
     for m in model.modules():
         if hasattr(m, "convs") and hasattr(m, "edge_aggr") and hasattr(m, "_plan"):
-            m._grad_bucket_hook = (lambda flat, g=group: allreduce_flat_grads(flat, g))
+            m._grad_bucket_hook = (lambda flat, g=group, q=pending: allreduce_flat_grads(flat, g, q))
             n += 1
+    return n
+
+
+def wait_grad_allreduce(model: torch.nn.Module) -> int:
+    """Join the asynchronous gradient collectives issued during the last backward (no-op for the blocking mode).
+    Returns how many were joined."""
+    pending = getattr(model, "_dss2_pending_allreduce", None)
+    if not pending:
+        return 0
+    n = len(pending)
+    for w in pending:
+        w.wait()          # current stream waits for the collective; bounded by the process group's timeout
+    pending.clear()
     return n
 
 

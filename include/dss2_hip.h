@@ -261,10 +261,12 @@ int dss2_wls_loss_grad(const dss2_wls_args* args_host, void* stream);
 
 /* get_pflow alone (data.py:328-390; evaluation path dss2_run.py:193-194): y[N,2] = (v, theta)
  * in physical units; writes pflow[E,8] = loading_lines, loading_trafo, P_from, Q_from, P_to,
- * Q_to, I_from, I_to.  vminmax[130] is device scratch. */
+ * Q_to, I_from, I_to.  vminmax[130] is device scratch.  apply_shift != 0: the angle difference is
+ * theta_i - theta_j - edge_param[:, 5] (the reference's phase_shift=False, data.py:364-365); 0: shift = 0
+ * (phase_shift=True, the default and what gsp_wls_edge uses). */
 int dss2_get_pflow(const float* y, int64_t ldy, const float* node_param, int64_t ld_np,
                    const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
-                   int64_t n_nodes, int64_t n_edges, float* vminmax, float* pflow, void* stream);
+                   int64_t n_nodes, int64_t n_edges, float* vminmax, float* pflow, int apply_shift, void* stream);
 
 /* ---- evaluation metrics of one test batch (/root/reference/dss2_run.py:178-208), kept on the
  *      device: yhat[N,2] <- (out[:,0] * x_std[0] + x_mean[0], out[:,1] * (1 - slack)); get_pflow of the labels y and

@@ -1,0 +1,101 @@
+"""Child process of tests/test_gpu_rccl.py (never imported by pytest: the leading underscore keeps it out of collection).
+
+Started as a FRESH process (RANK=0, WORLD_SIZE=1, MASTER_ADDR=127.0.0.1) before anything in it touches the GPU, it runs
+the product's own data-parallel branches on the one GPU of the box, over the "nccl" backend (= RCCL on ROCm):
+
+  * ``gsp_wls_edge(..., group=WORLD)``: the all-reduce of the 7 loss sums between the two loss kernels (data.py),
+  * the flat-bucket gradient all-reduce hook at the end of every MPN block's backward (networks._MPNFn.backward,
+    parallel.attach_grad_allreduce), blocking and ``async_op=True`` + ``wait_grad_allreduce``,
+  * the same step captured into a hipGraph (graphs.GraphedStep) with the collectives inside the capture.
+
+At world size 1 a SUM all-reduce is the identity, so loss and every gradient must be BITWISE equal to the
+non-distributed step.  Prints one JSON object on the last line of stdout.
+"""
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "deep-statistical-solver-for-distribution-system-state-estimation_amd"
+REG = {"mu_v": 1e-1, "mu_theta": 1e-1, "lam_v": 1e-4, "lam_p": 1e-8, "lam_pf": 1e-6, "lam_reg": 1e2}
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    pkg = importlib.import_module(PKG)
+    pkg._lib.lib()
+    env = pkg.parallel.init_from_env("nccl")
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    dev = torch.device("cuda", env["local"])
+    group = dist.group.WORLD
+    res = {"backend": dist.get_backend(), "world": dist.get_world_size(), "cases": {}}
+
+    models = {
+        "MPN_C2_model": lambda: pkg.MPN(8, 6, 2, 128, 4, 2, 0.0),          # BASELINE config C2's model
+        "SkipPFN_5_blocks": lambda: pkg.SkipPFN(8, 6, 2, 32, 3, 2, 0.0, 5),   # 5 blocks -> 5 gradient collectives per step
+    }
+    for name, build in models.items():
+        torch.manual_seed(0)
+        b = pkg.synthetic.make_batch(["cigre14", "cigre14_reswitched"], 256, seed=3, violate=0.5)   # penalties active
+        x, ei, ea = b["x"].to(dev), b["edge_index"].to(dev), b["edge_attr"].to(dev)
+        st = tuple(s.to(dev) for s in b["stats"])
+        model = build().to(dev)
+        calls = []
+
+        def step(grp):
+            for p in model.parameters():
+                p.grad = None
+            out = model(x[:, :8], ei, ea[:, :6])
+            loss = pkg.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1],
+                                    edge_mean=st[2], edge_std=st[3], edge_index=ei, reg_coefs=REG, num_samples=None,
+                                    node_param=x[:, 8:], edge_param=ea[:, 6:], group=grp)
+            loss.backward()
+            return loss
+
+        def snapshot(loss):
+            torch.cuda.synchronize()
+            return loss.detach().clone(), [p.grad.detach().clone() for p in model.parameters()]
+
+        l0, g0 = snapshot(step(None))                                     # non-distributed reference
+        c = {}
+        # ---- blocking collectives
+        n_hooks = pkg.parallel.attach_grad_allreduce(model, group)
+        orig = pkg.parallel.allreduce_flat_grads
+
+        def counting(flat, g=None, pending=None):
+            calls.append(int(flat.numel()))
+            return orig(flat, g, pending)
+        pkg.parallel.allreduce_flat_grads = counting
+        l1, g1 = snapshot(step(group))
+        c["hooks_attached"], c["grad_allreduces_per_step"], c["bucket_elems"] = n_hooks, len(calls), list(calls)
+        c["blocking_bitwise"] = bool(torch.equal(l0, l1) and all(torch.equal(a, q) for a, q in zip(g0, g1)))
+        # ---- asynchronous collectives, joined before the gradients are read
+        calls.clear()
+        pkg.parallel.attach_grad_allreduce(model, group, async_op=True)
+        loss = step(group)
+        c["async_joined"] = pkg.parallel.wait_grad_allreduce(model)
+        l2, g2 = snapshot(loss)
+        c["async_bitwise"] = bool(torch.equal(l0, l2) and all(torch.equal(a, q) for a, q in zip(g0, g2)))
+        # ---- the same step inside a hipGraph capture (collectives captured with it)
+        pkg.parallel.attach_grad_allreduce(model, group)
+        try:
+            gs = pkg.graphs.GraphedStep(lambda: step(group))
+            lg = gs.replay()
+            l3, g3 = snapshot(lg)
+            c["graph_capture"] = "ok"
+            c["graph_bitwise"] = bool(torch.equal(l0, l3) and all(torch.equal(a, q) for a, q in zip(g0, g3)))
+        except Exception as exc:      # capture of RCCL collectives unsupported on this stack: eager is the fallback
+            c["graph_capture"] = f"unsupported: {type(exc).__name__}: {str(exc)[:200]}"
+        pkg.parallel.allreduce_flat_grads = orig
+        res["cases"][name] = c
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

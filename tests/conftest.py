@@ -81,3 +81,22 @@ CASES = {
     "mpn_undirected_input": ("MPN", (8, 6, 2, 32, 2, 2, 0.0), False),
 }
 LOSS_CASES = ["loss_real", "loss_violate_cigre", "loss_violate_ober"]
+
+
+def tagconv_known_answers():
+    """tests/golden/tagconv_known_answers.json: (x, lins, bias, {case: (edge_index, {K: expected out})}); expected entries
+    are stored as exact pairs [a, b] = a + b / sqrt(2) (hand-derived, see the file)."""
+    import json
+    with open(os.path.join(GOLDEN, "tagconv_known_answers.json")) as fh:
+        z = json.load(fh)
+    x = torch.tensor(z["x"], dtype=torch.float64)
+    lins = [torch.tensor(w, dtype=torch.float64) for w in z["lins"]]
+    bias = torch.tensor(z["bias"], dtype=torch.float64)
+    cases = {}
+    for name, c in z["cases"].items():
+        exp = {}
+        for K, v in c["out"].items():
+            a = torch.tensor(v, dtype=torch.float64)
+            exp[int(K)] = a[..., 0] + a[..., 1] / (2.0 ** 0.5)
+        cases[name] = (torch.tensor(c["edge_index"], dtype=torch.int64), exp)
+    return x, lins, bias, cases

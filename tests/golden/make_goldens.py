@@ -180,6 +180,24 @@ def loss_case(name, batch, seed=0):
          grad_output=o_leaf.grad, pflow=torch.stack(flows, 1))
 
 
+def extras():
+    """Fixtures added after the first set (the first set is not regenerated: python make_goldens.py extras).
+    case_pflow_shift.npz: the reference's get_pflow(..., phase_shift=False) (shift = edge_param[:, 5], data.py:364-365) on
+    the inputs of the three committed loss cases."""
+    arrays = {}
+    for name in ["loss_real", "loss_violate_cigre", "loss_violate_ober"]:
+        z = np.load(os.path.join(HERE, f"case_{name}.npz"))
+        x, ei, ea = torch.from_numpy(z["x"]), torch.from_numpy(z["edge_index"]), torch.from_numpy(z["edge_attr"])
+        o = torch.from_numpy(z["output_after"])
+        yv = torch.cat([o[:, 0:1] * torch.from_numpy(z["x_std"])[:1] + torch.from_numpy(z["x_mean"])[:1], o[:, 1:]], 1)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")      # data.py:365 wraps a tensor in torch.tensor(...)
+            flows = ref_data.get_pflow(yv, ei, x[:, 8:], ea[:, 6:], phase_shift=False)
+        arrays[f"{name}/pflow_shift"] = torch.stack(flows, 1)
+    save("case_pflow_shift.npz", **arrays)
+
+
 def main():
     grids()
     real = real_cigre()
@@ -238,5 +256,7 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dataset64":
         dataset64()
+    elif len(sys.argv) > 1 and sys.argv[1] == "extras":
+        extras()
     else:
         main()

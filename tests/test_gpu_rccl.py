@@ -1,0 +1,42 @@
+"""GPU (-m gpu): the product's own RCCL branches, executed on the one GPU of the box in a fresh child process under
+torch.distributed's env:// rendezvous at world size 1 (tests/_rccl_child.py).  The world_size-2 gloo tests
+(tests/test_parallel_cpu.py) validate the sharding recipe with the oracle; THIS test runs the lines the recipe
+lives in: data.py's loss-sum all-reduce and the gradient-bucket hook of networks._MPNFn.backward."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_rccl_world1_step_is_bitwise_the_non_distributed_step():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0", DSS2_COLLECTIVE_TIMEOUT_S="120")
+    # a new interpreter: nothing in it has touched the GPU before it initialises the process group
+    p = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_child.py")], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-4000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["backend"] == "nccl" and res["world"] == 1
+    mpn, pfn = res["cases"]["MPN_C2_model"], res["cases"]["SkipPFN_5_blocks"]
+    assert mpn["hooks_attached"] == 1 and mpn["grad_allreduces_per_step"] == 1 and mpn["bucket_elems"] == [168066]
+    assert pfn["hooks_attached"] == 5 and pfn["grad_allreduces_per_step"] == 5
+    for c in (mpn, pfn):
+        assert c["blocking_bitwise"], c
+        assert c["async_bitwise"] and c["async_joined"] == c["hooks_attached"], c
+        # capture of the collectives: must either work bitwise or be reported as unsupported (eager fallback)
+        assert c["graph_capture"] == "ok" or c["graph_capture"].startswith("unsupported"), c
+        if c["graph_capture"] == "ok":
+            assert c["graph_bitwise"], c
+    print("RCCL world-1:", json.dumps(res))

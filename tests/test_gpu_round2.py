@@ -1,0 +1,175 @@
+"""GPU (-m gpu), round-2 additions: anchors and edge cases called out by the round-1 review.
+All calls go through the C ABI (ctypes -> libdss2_hip.so)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import LOSS_CASES, case_batch, golden, load_pkg, rel_err, t, tagconv_known_answers
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_pkg()
+    p._lib.lib()
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return p
+
+
+def test_tagconv_matches_hand_derived_known_answers(pkg):
+    """PyG TAGConv semantics against paper-and-pencil literals (tests/golden/tagconv_known_answers.json), on two
+    block-diagonal copies of each 3-node graph so that batching offsets are exercised too."""
+    x, lins, bias, cases = tagconv_known_answers()
+    for name, (ei, exp) in cases.items():
+        ei2 = torch.cat([ei, ei + 3], 1).to(DEV)
+        x2 = torch.cat([x, x], 0).float().to(DEV)
+        for K, want in exp.items():
+            conv = pkg.TAGConv(2, 2, K)
+            with torch.no_grad():
+                conv.bias.copy_(bias.float())
+                for k in range(K + 1):
+                    conv.lins[k].weight.copy_(lins[k].float())
+            got = conv.to(DEV)(x2, ei2)
+            want2 = torch.cat([want, want], 0)
+            assert (got.double().cpu() - want2).abs().max() < 2e-6, (name, K, got, want2)
+
+
+def test_get_pflow_phase_shift_false_matches_reference(pkg):
+    """get_pflow(..., phase_shift=False) (shift = edge_param[:, 5], data.py:364-365) vs the reference's own output."""
+    gs = golden("case_pflow_shift.npz")
+    for name in LOSS_CASES:
+        g = golden(f"case_{name}.npz")
+        b = case_batch(g, device=DEV)
+        x, ei, ea, st = b["x"], b["edge_index"], b["edge_attr"], b["stats"]
+        o = t(g["output_after"], device=DEV)
+        yv = torch.cat([o[:, 0:1] * st[1][:1] + st[0][:1], o[:, 1:]], 1)
+        flows = torch.stack(pkg.data.get_pflow(yv, ei, x[:, 8:], ea[:, 6:], phase_shift=False), 1)
+        assert rel_err(flows, t(gs[f"{name}/pflow_shift"])) < 1e-5
+        flows0 = torch.stack(pkg.data.get_pflow(yv, ei, x[:, 8:], ea[:, 6:]), 1)
+        assert rel_err(flows0, t(g["pflow"])) < 1e-5
+
+
+@pytest.mark.parametrize("L,hid", [(10, 32), (18, 32), (10, 128)])
+def test_deep_stacks_chunk_the_layer_chain(pkg, oracle, L, hid):
+    """n_gnn_layers - 1 > 8 hid->hid layers: the library chains at most 8 layers per launch, deeper stacks run as
+    consecutive chain launches (forward and data-gradient).  Against the fp64 oracle."""
+    torch.manual_seed(1)
+    b = pkg.synthetic.make_batch(["cigre14", "cigre14_reswitched"], 24, seed=4)
+    ref = oracle.MPN(8, 6, 2, hid, L, 2, 0.0).double()
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if "convs" in n and "lins" in n:
+                p.mul_(1.6)        # keep activations alive through 17 ReLU layers
+    mine = pkg.MPN(8, 6, 2, hid, L, 2, 0.0)
+    mine.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    mine = mine.to(DEV)
+    launches = []
+    b64 = {"x": b["x"].double(), "edge_index": b["edge_index"], "edge_attr": b["edge_attr"].double()}
+    out64, l64 = oracle.train_step(ref, b64, tuple(s.double() for s in b["stats"]))
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    st = tuple(s.to(DEV) for s in b["stats"])
+    real_chain = pkg.networks.gemm_prop_chain
+    def counting(topo, X, h, nmat, layers, **kw):
+        if len(layers) <= pkg.networks.CHAIN_MAX:
+            launches.append(len(layers))
+        return real_chain(topo, X, h, nmat, layers, **kw)
+    pkg.networks.gemm_prop_chain = counting
+    try:
+        out = mine(x[:, :8], ei, ea[:, :6])
+        loss = pkg.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2],
+                                edge_std=st[3], edge_index=ei, reg_coefs=oracle.DEFAULT_REG_COEFS, num_samples=None,
+                                node_param=x[:, 8:], edge_param=ea[:, 6:])
+        loss.backward()
+    finally:
+        pkg.networks.gemm_prop_chain = real_chain
+    assert max(launches) <= 8 and sum(launches) == 2 * (L - 1), launches      # forward + data-gradient chains
+    assert rel_err(out, out64) < 1e-5
+    assert abs(loss.item() - l64.item()) <= 1e-5 * abs(l64.item())
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad, q.grad) < 1e-4, n
+
+
+def _star_batch(n_graphs, leaves, seed):
+    """Star graphs (one hub with `leaves` neighbours): doubled in-degree of the hub = leaves > the ELL width limit (8),
+    so every kernel takes its general CSR path (row-per-wave edge MLP, CSR staging in the tile kernels)."""
+    g = torch.Generator().manual_seed(seed)
+    n = leaves + 1
+    src = torch.zeros(leaves, dtype=torch.int64)
+    dst = torch.arange(1, n)
+    ei = torch.cat([torch.stack([src, dst]) + k * n for k in range(n_graphs)], 1)
+    x = torch.randn(n_graphs * n, 8, generator=g)
+    ea = torch.randn(ei.shape[1], 6, generator=g)
+    return x, ei, ea
+
+
+@pytest.mark.parametrize("cls,hid,L,leaves", [("MPN", 64, 3, 11), ("SkipMPN", 32, 2, 20)])
+def test_hub_graphs_take_the_csr_paths(pkg, oracle, cls, hid, L, leaves):
+    torch.manual_seed(2)
+    x, ei, ea = _star_batch(7, leaves, seed=5)
+    dim_out = 8 if cls == "SkipMPN" else 2
+    ref = getattr(oracle, cls)(8, 6, dim_out, hid, L, 2, 0.0).double()
+    mine = getattr(pkg, cls)(8, 6, dim_out, hid, L, 2, 0.0)
+    mine.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    mine = mine.to(DEV)
+    g = torch.randn(x.shape[0], dim_out)
+    xr = x.double().requires_grad_(True)
+    outr = ref(xr, ei, ea.double())
+    outr.backward(g.double())
+    xm = x.to(DEV).requires_grad_(True)
+    topo = pkg.topology.get_topology(ei.to(DEV), x.shape[0])
+    assert topo.ell == 0 and topo.ellT == 0           # hubs: no ELL slices, CSR everywhere
+    outm = mine(xm, ei.to(DEV), ea.to(DEV))
+    outm.backward(g.to(DEV))
+    assert rel_err(outm, outr) < 1e-5
+    assert rel_err(xm.grad, xr.grad) < 1e-4
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad, q.grad) < 1e-4, n
+
+
+def test_fused_adamax_descriptor_table_is_reused(pkg):
+    """The descriptor table is rebuilt only when an address changes: a steady training loop builds it once (or twice,
+    while the allocator settles), and load_state_dict drops it (its state pointers are stale)."""
+    torch.manual_seed(0)
+    b = pkg.synthetic.make_batch(["cigre14"], 32, seed=1)
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    model = pkg.MPN(8, 6, 2, 32, 3, 2, 0.0).to(DEV)
+    opt = pkg.FusedAdamax(model.parameters(), lr=3e-3)
+    for _ in range(8):
+        opt.zero_grad()
+        model(x[:, :8], ei, ea[:, :6]).square().mean().backward()
+        opt.step()
+    assert opt.table_builds <= 3, opt.table_builds
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)
+    builds = opt.table_builds
+    opt.zero_grad()
+    model(x[:, :8], ei, ea[:, :6]).square().mean().backward()
+    opt.step()
+    assert opt.table_builds == builds + 1             # rebuilt against the re-loaded state tensors
+
+
+def test_gradient_of_other_consumers_of_the_masked_output(pkg, oracle):
+    """gsp_wls_edge masks theta in place (data.py:413); a second consumer of that (masked) output contributes a
+    gradient that must not reach the pre-mask theta at slack buses -- exactly what autograd does in the reference."""
+    g = golden("case_loss_violate_cigre.npz")
+    b = case_batch(g, device=DEV)
+    bc = case_batch(g)
+    wts = torch.linspace(-1.0, 2.0, b["x"].shape[0] * 2).view(-1, 2)
+
+    def run(mod, bb, dev, leaf):
+        x, ei, ea, st = bb["x"], bb["edge_index"], bb["edge_attr"], bb["stats"]
+        o = leaf * 1.0
+        loss = mod.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=o, x_mean=st[0], x_std=st[1], edge_mean=st[2],
+                                edge_std=st[3], edge_index=ei, reg_coefs=oracle.DEFAULT_REG_COEFS, num_samples=None,
+                                node_param=x[:, 8:], edge_param=ea[:, 6:])
+        (loss + (o * wts.to(dev)).sum()).backward()
+        return leaf.grad
+
+    lg = t(g["output"], device=DEV).clone().requires_grad_(True)
+    lc = t(g["output"]).clone().requires_grad_(True)
+    gg, gc = run(pkg.data, b, DEV, lg), run(oracle, bc, "cpu", lc)
+    assert rel_err(gg, gc) < 1e-5
+    slack = bc["x"][:, 9] > 0
+    assert slack.any() and (gg.cpu()[slack, 1] == 0).all()

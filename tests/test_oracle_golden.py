@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import CASES, LOSS_CASES, case_batch, case_grads, case_state_dict, golden, rel_err, t
+from conftest import CASES, LOSS_CASES, case_batch, case_grads, case_state_dict, golden, rel_err, t, tagconv_known_answers
 
 # fp32 noise floor of the reference path itself is ~6e-7 (out), ~1.2e-6 (loss), ~2e-5 (grads)
 TOL_OUT, TOL_LOSS, TOL_GRAD = 2e-6, 5e-6, 5e-5
@@ -109,3 +109,33 @@ def test_structural_facts(oracle):
     x, ea = t(real["x"]), t(real["edge_attr"])
     with torch.no_grad():
         assert (m(x[:, :8], ei, ea[:, :6]) - m(x[:, :8], ei, ea[:, :6])).abs().max() > 0
+
+
+def test_oracle_get_pflow_with_phase_shift_matches_reference(oracle):
+    """get_pflow(..., phase_shift=False): shift = edge_param[:, 5] (data.py:364-365), golden from the reference itself."""
+    gs = golden("case_pflow_shift.npz")
+    for name in LOSS_CASES:
+        g = golden(f"case_{name}.npz")
+        b = case_batch(g)
+        x, ei, ea, st = b["x"], b["edge_index"], b["edge_attr"], b["stats"]
+        o = t(g["output_after"])
+        yv = torch.cat([o[:, 0:1] * st[1][:1] + st[0][:1], o[:, 1:]], 1)
+        flows = torch.stack(oracle.get_pflow(yv, ei, x[:, 8:], ea[:, 6:], phase_shift=False), 1)
+        assert rel_err(flows, t(gs[f"{name}/pflow_shift"])) < TOL_OUT
+        assert rel_err(flows, t(g["pflow"])) > 1e-3          # the shift changes the flows on the trafo branches
+
+
+def test_oracle_tagconv_matches_hand_derived_known_answers(oracle):
+    """An anchor for PyG's TAGConv / gcn_norm semantics that does not come from the oracle's author's stand-in: exact
+    paper-and-pencil outputs on a 3-node path graph (degrees 1/2/1, all weights 1/sqrt2) and on a directed 3-node DAG
+    that separates in-degree from out-degree normalisation and exercises the deg = 0 -> 0 rule, K = 0..3, with bias."""
+    x, lins, bias, cases = tagconv_known_answers()
+    for name, (ei, exp) in cases.items():
+        for K, want in exp.items():
+            conv = oracle.TAGConv(2, 2, K).double()
+            with torch.no_grad():
+                conv.bias.copy_(bias)
+                for k in range(K + 1):
+                    conv.lins[k].weight.copy_(lins[k])
+            got = conv(x, ei)
+            assert (got - want).abs().max() < 1e-13, (name, K)
