@@ -10,8 +10,8 @@ from .optim import FusedAdamax  # noqa: F401
 from . import runner  # noqa: F401
 from .networks import EdgeAggregation, TAGConv, MPN, SkipMPN, PFN, SkipPFN, MessagePassing  # noqa: F401
 from .data import gsp_wls_edge, get_pflow  # noqa: F401
-from .dataset import data_from_pickles, DataLoader, DeviceDataset  # noqa: F401
+from .dataset import data_from_pickles, DataLoader, DeviceDataset, MixedDataset  # noqa: F401
 
 __all__ = ["EdgeAggregation", "TAGConv", "MPN", "SkipMPN", "PFN", "SkipPFN", "MessagePassing",
-           "gsp_wls_edge", "get_pflow", "data_from_pickles", "DataLoader", "DeviceDataset", "FusedAdamax", "dataset", "networks", "data", "parallel", "graphs", "optim", "synthetic",
+           "gsp_wls_edge", "get_pflow", "data_from_pickles", "DataLoader", "DeviceDataset", "MixedDataset", "FusedAdamax", "dataset", "networks", "data", "parallel", "graphs", "optim", "synthetic",
            "topology"]

@@ -49,6 +49,23 @@ class WgradArgs(C.Structure):
                 ("narrow", C.c_int32), ("pad_", C.c_int32)]
 
 
+class CsrBuildArgs(C.Structure):
+    _fields_ = [("edge_index", C.c_void_p), ("n_edges", C.c_int64), ("n_nodes", C.c_int64), ("doubled", C.c_int32), ("pad_", C.c_int32),
+                ("rowptr", C.c_void_p), ("col", C.c_void_p), ("ent", C.c_void_p), ("perm", C.c_void_p), ("w", C.c_void_p),
+                ("rowptrT", C.c_void_p), ("colT", C.c_void_p), ("entT", C.c_void_p), ("permT", C.c_void_p), ("wT", C.c_void_p),
+                ("inc_rowptr", C.c_void_p), ("inc_ent", C.c_void_p), ("efrom", C.c_void_p), ("eto", C.c_void_p),
+                ("deg", C.c_void_p), ("lastcut", C.c_void_p), ("meta", C.c_void_p), ("work", C.c_void_p)]
+
+
+class EllBuildArgs(C.Structure):
+    _fields_ = [("rowptr", C.c_void_p), ("col", C.c_void_p), ("ent", C.c_void_p), ("w", C.c_void_p),
+                ("rowptrT", C.c_void_p), ("colT", C.c_void_p), ("entT", C.c_void_p), ("wT", C.c_void_p),
+                ("tile_start", C.c_void_p), ("ntiles", C.c_int32), ("tm", C.c_int32), ("ell_width", C.c_int32),
+                ("ellT_width", C.c_int32),
+                ("ell_tiles", C.c_void_p), ("ell_ent_tiles", C.c_void_p), ("ellT_tiles", C.c_void_p),
+                ("ellT_ent_tiles", C.c_void_p), ("meta", C.c_void_p)]
+
+
 class ReduceDesc(C.Structure):
     _fields_ = [("slab", C.c_void_p), ("out", C.c_void_p), ("stride", C.c_int64), ("len", C.c_int64),
                 ("n_slabs", C.c_int32), ("pad_", C.c_int32)]
@@ -92,7 +109,13 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "dss2_last_error": (C.c_char_p, []),
     "dss2_version": (C.c_int, []),
-    "dss2_topology_hash": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "dss2_topology_probe": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "dss2_csr_build": (C.c_int, [C.POINTER(CsrBuildArgs), C.c_void_p]),
+    "dss2_csr_build_work_ints": (C.c_int64, [C.c_int64, C.c_int64, C.c_int]),
+    "dss2_tiles_uniform": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    "dss2_tiles_walk": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dss2_ell_tiles_build": (C.c_int, [C.POINTER(EllBuildArgs), C.c_void_p]),
+    "dss2_deg_pows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dss2_segment_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                    C.c_int64, C.c_int, C.c_void_p]),
     "dss2_pack_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -134,6 +157,7 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "dss2_masked_zscore_scratch_doubles": (C.c_int64, [C.c_int64]),
     "dss2_collate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dss2_collate_ragged": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "dss2_adamax_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                    C.c_int, C.c_void_p]),
     "dss2_gemm_prop_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

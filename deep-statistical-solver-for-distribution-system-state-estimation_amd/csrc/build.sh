@@ -10,7 +10,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
 mkdir -p "$OBJ"
 pids=()
-for src in dss2_api dss2_gemm_prop dss2_gemm_chain dss2_edge dss2_wgrad dss2_loss dss2_optim dss2_dataset; do
+for src in dss2_api dss2_gemm_prop dss2_gemm_chain dss2_edge dss2_wgrad dss2_loss dss2_optim dss2_dataset dss2_topology; do
   if [ ! -f "$OBJ/$src.o" ] || [ "$HERE/$src.hip" -nt "$OBJ/$src.o" ] || [ "$HERE/dss2_common.hpp" -nt "$OBJ/$src.o" ] || [ "$ROOT/include/dss2_hip.h" -nt "$OBJ/$src.o" ]; then
     $HIPCC $FLAGS "$@" -c "$HERE/$src.hip" -o "$OBJ/$src.o" &
     pids+=($!)

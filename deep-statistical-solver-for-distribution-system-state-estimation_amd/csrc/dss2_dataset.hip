@@ -167,6 +167,34 @@ __global__ void __launch_bounds__(256) collate_kernel(const CollateTable tab, co
   }
 }
 
+// Ragged variant for batches that mix cases with different closed-branch counts (BASELINE config C5: cigre14 and
+// cigre14_reswitched in one batch): one launch per case, item j = the j-th sample of that case in the batch, copied to
+// the row offsets of ITS slot (the host decides the batch composition and uploads the three small offset arrays; it
+// never reads anything back).  kind 0: dst[(off[j]) * width ...] <- src[samp[j]][0..chunk) with off = node_off
+// (shared == 0) or edge_off (shared != 0 reuses the flag as "edge-row operand");  kind 1: edge_index,
+// dst[r][edge_off[j] + k] = src[samp[j]][r][k] + node_off[j], dst row stride = e_total.
+struct RaggedArgs { dss2_collate_desc d[4]; const long long* samp; const long long* node_off; const long long* edge_off; long long e_total; };
+__global__ void __launch_bounds__(256) collate_ragged_kernel(const RaggedArgs a) {
+  const dss2_collate_desc& d = a.d[blockIdx.y];
+  const long long j = blockIdx.x;
+  const long long s = a.samp[j];
+  if (d.kind == 0) {
+    const long long row = d.shared ? a.edge_off[j] : a.node_off[j];
+    const float* src = static_cast<const float*>(d.src) + s * d.chunk;
+    float* dst = static_cast<float*>(d.dst) + row * d.nodes_per_sample;       // nodes_per_sample = floats per row here
+    for (int k = threadIdx.x; k < d.chunk; k += blockDim.x) dst[k] = src[k];
+  } else {
+    const int e = d.chunk;
+    const long long* src = static_cast<const long long*>(d.src) + (d.shared ? 0 : s * 2 * e);
+    long long* dst = static_cast<long long*>(d.dst);
+    const long long noff = a.node_off[j], eoff = a.edge_off[j];
+    for (int k = threadIdx.x; k < 2 * e; k += blockDim.x) {
+      const int row = k / e, i = k - row * e;
+      dst[(long long)row * a.e_total + eoff + i] = src[k] + noff;
+    }
+  }
+}
+
 }  // namespace dss2
 
 using namespace dss2;
@@ -229,4 +257,23 @@ extern "C" int dss2_collate(const dss2_collate_desc* descs_host, int32_t n_desc,
   hipLaunchKernelGGL(collate_kernel, dim3((unsigned)batch, (unsigned)n_desc), dim3(256), 0, as_stream(stream), tab,
                      reinterpret_cast<const long long*>(sample_ids), (long long)batch);
   return check_launch("collate");
+}
+
+extern "C" int dss2_collate_ragged(const dss2_collate_desc* descs_host, int32_t n_desc, const int64_t* samp,
+                                   const int64_t* node_off, const int64_t* edge_off, int64_t count, int64_t e_total,
+                                   void* stream) {
+  using namespace dss2;
+  if (count <= 0) return 0;
+  if (!descs_host || n_desc < 1 || n_desc > 4 || !samp || !node_off || !edge_off) { set_error("collate_ragged: bad arguments"); return 2; }
+  RaggedArgs a = {};
+  for (int i = 0; i < n_desc; ++i) {
+    a.d[i] = descs_host[i];
+    if (!a.d[i].src || !a.d[i].dst || a.d[i].chunk <= 0) { set_error("collate_ragged: descriptor %d is incomplete", i); return 2; }
+  }
+  a.samp = reinterpret_cast<const long long*>(samp);
+  a.node_off = reinterpret_cast<const long long*>(node_off);
+  a.edge_off = reinterpret_cast<const long long*>(edge_off);
+  a.e_total = e_total;
+  hipLaunchKernelGGL(collate_ragged_kernel, dim3((unsigned)count, (unsigned)n_desc), dim3(256), 0, as_stream(stream), a);
+  return check_launch("collate_ragged");
 }

@@ -684,14 +684,13 @@ static size_t edge_mfma_lds(int TM, int D, int nw, bool bwd) {
 }
 
 static bool edge_mfma_ok(int h, int nrb, int D, bool bwd = false) {
-  // Defaults: backward on the matrix pipe (55 -> 40 us at C2), forward on the VALU kernel.  The MFMA forward is
-  // only 2 us faster and, although its output agrees with fp64 to 2e-7 like the VALU kernel's, the full-size
-  // gradient test of the 70-bus configuration then finds an edge-MLP weight-gradient deviation of 3e-5 that
-  // its gate-ambiguity bound does not explain (not understood yet), so it stays opt-in.
+  // Default: both passes on the matrix pipe (forward 26 -> 24 us, backward 55 -> 40 us at C2), so that the forward's
+  // ReLU gates and the gates the backward recomputes come from the same arithmetic.  DSS2_EDGE_MFMA=0 (or _FWD / _BWD)
+  // selects the VALU tile kernels, which also serve shapes the MFMA kernels do not cover (h % 32 != 0, tall tiles).
   // (read per call: lets a test switch paths inside one process)
   const char* env = getenv("DSS2_EDGE_MFMA");
   const char* env2 = getenv(bwd ? "DSS2_EDGE_MFMA_BWD" : "DSS2_EDGE_MFMA_FWD");
-  const int enabled = env2 ? atoi(env2) : (env ? atoi(env) : (bwd ? 1 : 0));
+  const int enabled = env2 ? atoi(env2) : (env ? atoi(env) : 1);
   if (!enabled || (h & 31) || h > 256 || !(nrb == 1 || nrb == 2 || nrb == 3)) return false;
   return edge_mfma_lds(nrb * 32, D, h >> 5, true) <= (size_t)kMaxLdsBytes;
 }

@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import topology as _topology
 from .networks import _F32, _stream
 
 NODE_COLS = ["vm_pu", "va_rad", "p_mw", "q_mvar", "vn_kv", "bool_slack", "bool_zero_inj"]
@@ -79,6 +80,23 @@ class DeviceDataset:
         self.shared_topology = bool((edge_index == edge_index[0:1]).all().item())   # once per dataset
         self.ids = ids if ids is not None else torch.arange(self.S, device=x.device)
         self._ei_cache: Dict[int, torch.Tensor] = {}
+        # host-side facts about the samples' edge lists, once per dataset: what lets a batch's graph structure be built
+        # without any device-to-host copy (topology.TopologyHint)
+        ei_h = (edge_index[0:1] if self.shared_topology else edge_index).cpu().numpy()
+        first = ei_h[0]
+        self.directed = not bool(((first[0] == first[1, 0]) & (first[1] == first[0, 0])).any())   # networks.py:236-238 on sample 0
+        self._sample_directed = None if self.shared_topology else \
+            ~((ei_h[:, 0, :] == ei_h[:, 1, 0:1]) & (ei_h[:, 1, :] == ei_h[:, 0, 0:1])).any(axis=1)
+        deg_in = np.stack([np.bincount(g[1], minlength=self.n) for g in ei_h])
+        deg_out = np.stack([np.bincount(g[0], minlength=self.n) for g in ei_h])
+        self.max_degree_doubled = int((deg_in + deg_out).max())
+        self.max_degree_asis = int(max(deg_in.max(), deg_out.max()))
+
+    def hint(self, first_sample: Optional[int] = None) -> "_topology.TopologyHint":
+        d = self.directed if (self._sample_directed is None or first_sample is None) else bool(self._sample_directed[first_sample])
+        return _topology.TopologyHint(directed=d, nodes_per_graph=self.n,
+                                      max_degree=self.max_degree_doubled if d else self.max_degree_asis,
+                                      max_edges_per_graph=self.e)
 
     @property
     def device(self):
@@ -130,7 +148,96 @@ class DeviceDataset:
         y = torch.empty(B * self.n, self.y.size(2), dtype=_F32, device=dev)
         self._launch([(self.x, x, self.n * self.x.size(2), 0), (self.edge_attr, ea, self.e * self.edge_attr.size(2), 0),
                       (self.y, y, self.n * self.y.size(2), 0)], ids, B)
-        return Batch(x, self.batch_edge_index(B, ids), ea, y, B)
+        ei = self.batch_edge_index(B, ids)
+        if self.shared_topology:
+            # the batch edge_index of this size is one cached tensor: its structure is built (and attached) once
+            if _topology._last.get((id(ei), "ref")) is None:
+                _topology.register_topology(ei, B * self.n, _topology.Topology(ei, B * self.n, hint=self.hint()))
+        # (samples with individual edge lists: the first graph of the batch decides the doubling rule, which the host
+        #  would have to read back; those batches take the cached / probed path of topology.get_topology)
+        return Batch(x, ei, ea, y, B)
+
+    @classmethod
+    def from_batch(cls, batch: Dict[str, object], device=None) -> "DeviceDataset":
+        """Per-sample store from a collated single-topology batch in the synthetic.make_batch layout."""
+        dev = _need_gpu(device)
+        S = int(batch["num_graphs"])
+        x, ea, y, ei = batch["x"], batch["edge_attr"], batch["y"], batch["edge_index"]
+        n, e = x.shape[0] // S, ea.shape[0] // S
+        if n * S != x.shape[0] or e * S != ea.shape[0]:
+            raise ValueError("from_batch needs a batch of one topology (uniform bus and branch counts)")
+        ei = ei.view(2, S, e).permute(1, 0, 2) - (torch.arange(S) * n).view(S, 1, 1)
+        return cls(x.view(S, n, -1).to(dev).contiguous(), ea.view(S, e, -1).to(dev).contiguous(),
+                   y.view(S, n, -1).to(dev).contiguous(), ei.contiguous().to(dev))
+
+
+class MixedDataset:
+    """Samples of several cases with the SAME bus count but different closed-branch sets in one data list (BASELINE
+    config C5: cigre14 + cigre14_reswitched, "variable edge_index per sample").  Global sample g = sample
+    ``g - start[p]`` of part p.  The batch composition is decided on the HOST (a numpy permutation: which sample goes to
+    which slot, hence every slot's edge offset), uploaded as three small index arrays per part, and collated by one
+    ``dss2_collate_ragged`` launch per part; the batch's graph structure is then built on the device from a
+    TopologyHint.  Nothing is read back: a shuffled mixed-topology epoch has no host synchronisation at all."""
+
+    def __init__(self, parts: Sequence[DeviceDataset], ids: Optional[np.ndarray] = None):
+        if len({p.n for p in parts}) != 1:
+            raise NotImplementedError("mixed datasets need the same bus count in every part")
+        self.parts = list(parts)
+        self.n = parts[0].n
+        self.start = np.concatenate([[0], np.cumsum([p.S for p in parts])]).astype(np.int64)
+        self.ids = np.arange(self.start[-1], dtype=np.int64) if ids is None else np.asarray(ids, dtype=np.int64)
+
+    @property
+    def device(self):
+        return self.parts[0].device
+
+    def __len__(self):
+        return int(self.ids.size)
+
+    def __getitem__(self, i):
+        if not isinstance(i, slice):
+            raise TypeError("MixedDataset supports slices (train / test splits); iterate it through DataLoader")
+        return MixedDataset(self.parts, self.ids[i])
+
+    def shuffled(self, rng: Optional[np.random.Generator] = None) -> "MixedDataset":
+        rng = rng or np.random.default_rng()
+        return MixedDataset(self.parts, rng.permutation(self.ids))
+
+    def collate(self, ids: np.ndarray) -> Batch:
+        B, n, dev = int(ids.size), self.n, self.device
+        part = np.searchsorted(self.start, ids, side="right") - 1           # part of every slot
+        e_slot = np.asarray([p.e for p in self.parts], dtype=np.int64)[part]
+        edge_off = np.concatenate([[0], np.cumsum(e_slot)]).astype(np.int64)
+        E = int(edge_off[-1])
+        p0 = self.parts[0]
+        x = torch.empty(B * n, p0.x.size(2), dtype=_F32, device=dev)
+        y = torch.empty(B * n, p0.y.size(2), dtype=_F32, device=dev)
+        ea = torch.empty(E, p0.edge_attr.size(2), dtype=_F32, device=dev)
+        ei = torch.empty(2, E, dtype=torch.int64, device=dev)
+        L = _lib.lib()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        for k, p in enumerate(self.parts):
+            slots = np.nonzero(part == k)[0]
+            if slots.size == 0:
+                continue
+            tab = np.stack([ids[slots] - self.start[k], slots * n, edge_off[slots]]).astype(np.int64)
+            tab_d = torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)      # 3 x count int64, host -> device only
+            descs = (_lib.CollateDesc * 4)()
+            items = [(p.x, x, n * p.x.size(2), 0, 0, p.x.size(2)), (p.y, y, n * p.y.size(2), 0, 0, p.y.size(2)),
+                     (p.edge_attr, ea, p.e * p.edge_attr.size(2), 0, 1, p.edge_attr.size(2)),
+                     (p.edge_index, ei, p.e, 1, int(p.shared_topology), 0)]
+            for d, (src, dst, chunk, kind, shared, width) in zip(descs, items):
+                d.src, d.dst, d.chunk, d.kind, d.shared, d.nodes_per_sample = src.data_ptr(), dst.data_ptr(), chunk, kind, shared, width
+            _lib.check(L.dss2_collate_ragged(C.addressof(descs), 4, tab_d[0].data_ptr(), tab_d[1].data_ptr(), tab_d[2].data_ptr(),
+                                             int(slots.size), E, st), "dss2_collate_ragged")
+        first = self.parts[int(part[0])]
+        hint = _topology.TopologyHint(
+            directed=first.hint(int(ids[0] - self.start[part[0]])).directed, nodes_per_graph=n,
+            max_degree=max(p.max_degree_doubled for p in self.parts), max_edges_per_graph=max(p.e for p in self.parts))
+        if not hint.directed:
+            hint = _topology.TopologyHint(False, n, max(p.max_degree_asis for p in self.parts), hint.max_edges_per_graph)
+        _topology.register_topology(ei, B * n, _topology.Topology(ei, B * n, hint=hint))
+        return Batch(x, ei, ea, y, B)
 
 
 class DataLoader:
@@ -147,6 +254,18 @@ class DataLoader:
 
     def __iter__(self):
         ds = self.dataset
+        if isinstance(ds, MixedDataset):     # batch composition on the host (numpy), data movement on the device
+            ids = ds.ids
+            if self.shuffle:
+                self._rng = getattr(self, "_rng", None) or np.random.default_rng(
+                    None if self.generator is None else int(self.generator.initial_seed()))
+                ids = self._rng.permutation(ids)
+            for a in range(0, ids.size, self.batch_size):
+                b = min(a + self.batch_size, ids.size)
+                if self.drop_last and b - a < self.batch_size:
+                    break
+                yield ds.collate(ids[a:b])
+            return
         ids = ds.ids
         if self.shuffle:   # permutation drawn on the device: no host round trip
             ids = ids[torch.randperm(ids.numel(), device=ids.device, generator=self.generator)]

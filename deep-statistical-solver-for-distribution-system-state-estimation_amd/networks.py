@@ -675,21 +675,9 @@ class _EdgeAggrFn(torch.autograd.Function):
                 g2[hout * hid:])
 
 
-_asis_cache = {}
-
-
 def get_topology_asis(edge_index: torch.Tensor, num_nodes: int) -> Topology:
-    """Topology of an edge list used exactly as given (standalone EdgeAggregation / TAGConv)."""
-    from . import topology as _t
-    if not edge_index.is_cuda:
-        raise RuntimeError("DSS2 HIP path: edge_index must live on the GPU (there is no CPU fallback)")
-    key = (edge_index.device.index, int(num_nodes), int(edge_index.size(1)), _t.content_hash(edge_index))
-    topo = _asis_cache.get(key)
-    if topo is None:
-        if len(_asis_cache) >= 16:
-            _asis_cache.pop(next(iter(_asis_cache)))
-        topo = _asis_cache[key] = Topology(edge_index, num_nodes, double=False)
-    return topo
+    """Topology of an edge list used exactly as given (standalone EdgeAggregation / TAGConv / propagate)."""
+    return get_topology(edge_index, num_nodes, double=False)
 
 
 class MPN(nn.Module):

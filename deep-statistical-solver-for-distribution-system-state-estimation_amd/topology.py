@@ -1,20 +1,31 @@
-"""Per-topology graph structure for the HIP kernels (built once per distinct edge_index, cached).
+"""Per-topology graph structure for the HIP kernels, built ON THE DEVICE (``dss2_csr_build`` and friends,
+csrc/dss2_topology.hip) once per distinct edge_index and cached.
 
 Replaces, per forward call of the reference: ``MPN.is_directed`` / ``undirect_graph``
 (/root/reference/networks.py:236-258: host sync + 3 cats), PyG ``gcn_norm`` (degree, pow,
 masked_fill, 2 gathers per TAGConv call) and PyG's per-call scatter index handling.
 
-Built with torch index ops on the tensor's own device (sort / bincount / cumsum: plumbing, run
-once per topology), then frozen as int32/fp32 device arrays in the layout include/dss2_hip.h
-documents: CSR by target, CSR by source, incidence CSR of the stored edges, whole-graph tiles.
+Two parts, built separately:
+
+* the CSR part (always): CSR by target / by source of the (doubled) directed edge list, incidence CSR of the stored
+  edges, int32 endpoints, in-degrees, gcn_norm weights -- all the loss kernels, ``MessagePassing.propagate`` and
+  ``segment_sum`` need; asynchronous, any graph size;
+* the tile part (lazily, when a tile kernel asks for it): whole-graph tiles of <= 32*nrb rows and the per-tile ELL
+  slices the tile kernels stage in LDS.  A connected component above 192 rows has no tile structure
+  (``NotImplementedError`` from the network kernels only).
+
+Host synchronisation: none when the caller passes a :class:`TopologyHint` (the device data loader does: it knows
+its samples' sizes and degrees); otherwise one 24-byte copy for the cache key + directedness and one 64-byte copy of
+the build statistics on a cache miss.  There is no CPU path: CPU tensors raise.
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 import weakref
+from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
-import numpy as np
 import torch
 
 from . import _lib
@@ -23,169 +34,209 @@ _FLIP = 1 << 31
 _NRB_CHOICES = (2, 4, 3, 1, 6)   # preference order on utilisation ties (32*nrb rows per tile)
 _LDS_LIMIT = 160 * 1024
 _ELL_MAX = 8
+_TILE_ATTRS = frozenset(["nrb", "ntiles", "tile_start", "utilisation", "max_segment", "max_nnz", "max_nnzT", "ell", "ellT",
+                         "ell_tiles", "ellT_tiles", "ell_ent_tiles", "ellT_ent_tiles"])
+
+
+@dataclass(frozen=True)
+class TopologyHint:
+    """What a caller that assembled the batch itself knows without looking at the device (dataset.DataLoader does):
+    with it the whole structure is built without a single device-to-host copy."""
+    directed: bool               # MPN.is_directed of the batch: its first edge has no reverse edge (networks.py:236-238)
+    nodes_per_graph: int         # every graph of the batch has this many nodes, in consecutive rows
+    max_degree: int              # upper bound of the in- and out-degree on the directed (doubled) list
+    max_edges_per_graph: int     # upper bound of the stored edges of one graph
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def probe(edge_index: torch.Tensor) -> Tuple[int, int, bool]:
+    """(hash1, hash2, is_directed) of edge_index in one kernel + one 24-byte device-to-host copy."""
+    ei = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
+    out = torch.zeros(3, dtype=torch.int64, device=ei.device)
+    _lib.check(_lib.lib().dss2_topology_probe(ei.data_ptr(), ei.size(1), out.data_ptr(), _stream(ei.device)), "dss2_topology_probe")
+    h1, h2, rev = out.tolist()
+    return h1, h2, rev == 0
 
 
 def reference_is_directed(edge_index: torch.Tensor) -> bool:
     """/root/reference/networks.py:236-238: looks only at the first edge of the batch:
     is there NO edge (v0 -> u0) among the edges leaving v0?  (One host sync; cached per topology.)"""
+    if edge_index.is_cuda:
+        return probe(edge_index)[2]
     u0, v0 = edge_index[0, 0], edge_index[1, 0]
     cand = edge_index[1, edge_index[0, :] == v0]
     return not bool((cand == u0).any().item())
-
-
-def _csr(key: torch.Tensor, n: int):
-    """Stable sort permutation and int32 row pointer for grouping by `key` (values in [0, n))."""
-    perm = torch.sort(key, stable=True).indices
-    cnt = torch.bincount(key, minlength=n)
-    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=key.device)
-    torch.cumsum(cnt, 0, out=rowptr[1:])
-    return perm, rowptr.to(torch.int32), cnt
-
-
-def _pack_tiles(bounds: np.ndarray, tm: int) -> np.ndarray:
-    """Greedy: consecutive whole segments (bounds = sorted cut positions incl. 0 and N) per tile of
-    at most tm rows.  Returns tile_start (len ntiles+1) or None if a segment exceeds tm."""
-    seg = np.diff(bounds)
-    if seg.max() > tm:
-        return None
-    if (seg == seg[0]).all():  # uniform graphs: closed form
-        per = tm // int(seg[0])
-        idx = np.arange(0, len(seg), per)
-        return np.append(bounds[idx], bounds[-1]).astype(np.int32)
-    out, i, nb = [int(bounds[0])], 0, len(bounds)
-    while i < nb - 1:
-        j = int(np.searchsorted(bounds, bounds[i] + tm, side="right")) - 1
-        out.append(int(bounds[j]))
-        i = j
-    return np.asarray(out, dtype=np.int32)
 
 
 class Topology:
     """Frozen device-side structure of one batched graph.  See include/dss2_hip.h."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, nrb: Optional[int] = None,
-                 double: Optional[bool] = None):
-        """double=None: the reference's rule (MPN.is_directed on the first edge); False: use the
-        edge list exactly as given (standalone EdgeAggregation / TAGConv); True: always double."""
+                 double: Optional[bool] = None, hint: Optional[TopologyHint] = None):
+        """double=None: the reference's rule (MPN.is_directed on the first edge; from the hint when given); False: use
+        the edge list exactly as given (standalone EdgeAggregation / TAGConv / propagate); True: always double."""
         if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype != torch.int64:
             raise ValueError("edge_index must be an int64 tensor of shape [2, E]")
-        dev = edge_index.device
-        ei = edge_index
-        N, E = int(num_nodes), int(ei.size(1))
+        N, E = int(num_nodes), int(edge_index.size(1))
         if E == 0 or N == 0:
             raise ValueError("empty graph batch")
-        if N >= 2 ** 31 or 2 * E >= 2 ** 31:
+        if N >= 2 ** 31 - 4 or 2 * E >= 2 ** 31 - 4:
             raise ValueError("graph too large for the int32 CSR")
+        if not edge_index.is_cuda:
+            raise RuntimeError("DSS2 HIP path: edge_index must live on the GPU (there is no CPU fallback)")
+        dev = edge_index.device
+        ei = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
         self.N, self.E, self.device = N, E, dev
-        self.directed = reference_is_directed(ei) if double is None else bool(double)
-        ar = torch.arange(E, device=dev)
-        if self.directed:  # networks.py:242-254: append reversed edges, flag them for the sign flip
-            src = torch.cat([ei[0], ei[1]])
-            tgt = torch.cat([ei[1], ei[0]])
-            eid = torch.cat([ar, ar - _FLIP])
+        self.hint, self._nrb_forced = hint, nrb
+        if double is not None:
+            self.directed = bool(double)
+        elif hint is not None:
+            self.directed = bool(hint.directed)
         else:
-            src, tgt, eid = ei[0], ei[1], ar
-        self.E2 = int(src.numel())
-        # ---- PyG gcn_norm(add_self_loops=False): in-degree on the (doubled) graph
-        perm, self.rowptr, cnt = _csr(tgt, N)
-        degf = cnt.to(torch.float32)
-        dis = degf.pow(-0.5)
-        dis = dis.masked_fill(dis == float("inf"), 0.0)
-        w_d = dis[src] * dis[tgt]
-        self.deg = degf.contiguous()
+            self.directed = probe(ei)[2]
+        self.E2 = E2 = 2 * E if self.directed else E
+        L = _lib.lib()
+        # one int32 arena for every array (16-byte aligned slices), one for the build's scratch
+        sizes = [("rowptr", N + 1), ("col", E2), ("ent", E2), ("perm", E2), ("w", E2), ("rowptrT", N + 1), ("colT", E2),
+                 ("entT", E2), ("permT", E2), ("wT", E2), ("inc_rowptr", N + 1), ("inc_ent", 2 * E), ("efrom", E), ("eto", E),
+                 ("deg", N), ("_lastcut", N + 1), ("_meta", 16)]
+        total = sum((n + 3) // 4 * 4 for _, n in sizes)
+        arena = torch.empty(total, dtype=torch.int32, device=dev)
+        off = 0
+        for name, n in sizes:
+            v = arena[off:off + n]
+            if name in ("w", "wT", "deg"):
+                v = v.view(torch.float32)
+            setattr(self, name, v)
+            off += (n + 3) // 4 * 4
+        work = torch.empty(int(L.dss2_csr_build_work_ints(N, E, int(self.directed))), dtype=torch.int32, device=dev)
+        a = _lib.CsrBuildArgs()
+        a.edge_index, a.n_edges, a.n_nodes, a.doubled = ei.data_ptr(), E, N, int(self.directed)
+        for name, _ in sizes:
+            setattr(a, name.lstrip("_"), getattr(self, name).data_ptr())
+        a.work = work.data_ptr()
+        _lib.check(L.dss2_csr_build(C.byref(a), _stream(dev)), "dss2_csr_build")
+        self._keep = (ei,)            # the build reads edge_index asynchronously
         self._deg_pows = None
-        self.col = src[perm].to(torch.int32).contiguous()
-        self.ent = eid[perm].to(torch.int32).contiguous()
-        self.w = w_d[perm].contiguous()
-        self.perm = perm  # directed-edge id of each CSR entry (for the standalone segment_sum)
-        permT, self.rowptrT, _ = _csr(src, N)
-        self.colT = tgt[permT].to(torch.int32).contiguous()
-        self.entT = eid[permT].to(torch.int32).contiguous()
-        self.wT = w_d[permT].contiguous()
-        # ---- incidence CSR of the STORED edges (loss: bus injections, data.py:428-429)
-        nodes = torch.cat([ei[0], ei[1]])
-        inc = torch.cat([ar, ar - _FLIP])          # end 0 = from-end, end 1 (flag) = to-end
-        permI, self.inc_rowptr, _ = _csr(nodes, N)
-        self.inc_ent = inc[permI].to(torch.int32).contiguous()
-        self.efrom = ei[0].to(torch.int32).contiguous()
-        self.eto = ei[1].to(torch.int32).contiguous()
-        # ---- whole-graph tiles: a cut before row p is legal iff no edge spans it
-        lo, hi = torch.minimum(src, tgt), torch.maximum(src, tgt)
-        cover = torch.zeros(N + 2, dtype=torch.int32, device=dev)
-        one = torch.ones_like(lo, dtype=torch.int32)
-        cover.index_add_(0, lo + 1, one)
-        cover.index_add_(0, hi + 1, -one)
-        cuts = (torch.cumsum(cover, 0)[: N + 1] == 0).nonzero().flatten().cpu().numpy().astype(np.int64)
-        bounds = np.unique(np.concatenate([cuts, [0, N]]))
-        rowptr_h = self.rowptr.cpu().numpy().astype(np.int64)
-        rowptrT_h = self.rowptrT.cpu().numpy().astype(np.int64)
-        self.max_segment = int(np.diff(bounds).max())
+        self._stats = None
+        self._tiles_built = False
+
+    # ---- lazily built tile part -------------------------------------------------------------------------------
+    def __getattr__(self, name):
+        if name in _TILE_ATTRS and not self.__dict__.get("_tiles_built", True):
+            self._build_tiles()
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+    def stats(self) -> Dict[str, int]:
+        """Exact build statistics (one 64-byte device-to-host copy, cached): degrees, segments, error flag."""
+        if self._stats is None:
+            m = self._meta.tolist()
+            self._stats = dict(max_deg=m[0], max_degT=m[1], max_segment=m[2], n_segments=m[3], min_segment=m[4], error=m[5],
+                               max_nnz=m[6], max_nnzT=m[7], ntiles_cand=m[8:16])
+            if m[5] == 1:
+                raise ValueError("edge_index holds node ids outside [0, num_nodes)")
+            if m[5] == 2:
+                raise ValueError("TopologyHint.max_degree is smaller than a row of the batch")
+        return self._stats
+
+    def _build_tiles(self) -> None:
+        L = _lib.lib()
+        dev, N = self.device, self.N
         env = os.environ.get("DSS2_NRB")
-        choices = (int(nrb),) if nrb else ((int(env),) if env else _NRB_CHOICES)
-        best = None
-        for cand in choices:
-            ts = _pack_tiles(bounds, 32 * cand)
-            if ts is None:
-                continue
-            util = N / float((len(ts) - 1) * 32 * cand)
-            if best is None or util > best[0] + 0.03:
-                best = (util, cand, ts)
-        if best is None:
-            raise NotImplementedError(
-                f"largest connected component has {self.max_segment} nodes; the LDS-resident tile kernels "
-                f"support up to {32 * max(choices)} nodes per graph")
-        self.utilisation, self.nrb, ts = best
-        self.ntiles = len(ts) - 1
-        self.max_nnz = int((rowptr_h[ts[1:]] - rowptr_h[ts[:-1]]).max())
-        self.max_nnzT = int((rowptrT_h[ts[1:]] - rowptrT_h[ts[:-1]]).max())
-        # ELL width for the in-LDS propagation (0 = use the CSR path: hubs would waste padded slots)
-        md, mdT = int(np.diff(rowptr_h).max()), int(np.diff(rowptrT_h).max())
-        self.ell = md if md <= _ELL_MAX else 0
-        self.ellT = mdT if mdT <= _ELL_MAX else 0
-        self.tile_start = torch.from_numpy(ts).to(dev)
-        # per-tile ELL slices [ntiles, D, 32*nrb] of {local source row, weight bits}: what the kernels stage
-        # in LDS for the in-tile propagation, precomputed here so that staging is one coalesced copy
-        self.ell_tiles = self._ell_tiles(self.rowptr, self.col, self.w, self.ell)
-        self.ellT_tiles = self._ell_tiles(self.rowptrT, self.colT, self.wT, self.ellT)
-        # same slices carrying the stored edge id | flip instead of the weight (edge-MLP kernels); -1 = empty
-        self.ell_ent_tiles = self._ell_tiles(self.rowptr, self.col, self.ent, self.ell, ids=True)
-        self.ellT_ent_tiles = self._ell_tiles(self.rowptrT, self.colT, self.entT, self.ellT, ids=True)
+        choices = (int(self._nrb_forced),) if self._nrb_forced else ((int(env),) if env else _NRB_CHOICES)
+        st = _stream(dev)
+        hint = self.hint
+        if hint is not None and N % hint.nodes_per_graph == 0:
+            # ---- no device-to-host copy: uniform graphs => closed-form tiles, degrees from the hint
+            n, G = hint.nodes_per_graph, N // hint.nodes_per_graph
+            best = None
+            for cand in choices:
+                per = (32 * cand) // n
+                if per == 0:
+                    continue
+                nt = -(-G // per)
+                util = N / float(nt * 32 * cand)
+                if best is None or util > best[0] + 0.03:
+                    best = (util, cand, nt, per)
+            if best is None:
+                raise NotImplementedError(f"graphs of {n} nodes; the LDS-resident tile kernels support up to {32 * max(choices)} nodes per graph")
+            util, nrb, nt, per = best
+            tile_start = torch.empty(nt + 1, dtype=torch.int32, device=dev)
+            _lib.check(L.dss2_tiles_uniform(tile_start.data_ptr(), nt, per * n, N, st), "dss2_tiles_uniform")
+            max_deg = max_degT = int(hint.max_degree)
+            max_segment = n
+            nnz_bound = per * hint.max_edges_per_graph * (2 if self.directed else 1)
+            exact_nnz = False
+        else:
+            # ---- general batch: greedy packing for every candidate row budget in one launch, then ONE copy of the statistics
+            cap = N
+            cands = [torch.empty(cap + 1, dtype=torch.int32, device=dev) for _ in choices]
+            tm_host = (C.c_int32 * len(choices))(*[32 * c for c in choices])
+            ptrs = (C.c_void_p * len(choices))(*[t.data_ptr() for t in cands])
+            _lib.check(L.dss2_tiles_walk(self._lastcut.data_ptr(), N, tm_host, len(choices), ptrs, cap,
+                                         self._meta[8:].data_ptr(), st), "dss2_tiles_walk")
+            self._stats = None
+            s = self.stats()
+            max_deg, max_degT, max_segment = s["max_deg"], s["max_degT"], s["max_segment"]
+            best = None
+            for i, cand in enumerate(choices):
+                nt = s["ntiles_cand"][i]
+                if nt <= 0:
+                    continue
+                util = N / float(nt * 32 * cand)
+                if best is None or util > best[0] + 0.03:
+                    best = (util, cand, nt, i)
+            if best is None:
+                raise NotImplementedError(
+                    f"largest connected component has {max_segment} nodes; the LDS-resident tile kernels "
+                    f"support up to {32 * max(choices)} nodes per graph")
+            util, nrb, nt, i = best
+            tile_start = cands[i][:nt + 1].clone()
+            nnz_bound, exact_nnz = 0, True
+        ell = max_deg if max_deg <= _ELL_MAX else 0
+        ellT = max_degT if max_degT <= _ELL_MAX else 0
+        tm = 32 * nrb
+
+        def slab(width):
+            return torch.empty(nt, width, tm, 2, dtype=torch.int32, device=dev) if width > 0 else None
+        ell_tiles, ell_ent_tiles, ellT_tiles, ellT_ent_tiles = slab(ell), slab(ell), slab(ellT), slab(ellT)
+        b = _lib.EllBuildArgs()
+        b.rowptr, b.col, b.ent, b.w = self.rowptr.data_ptr(), self.col.data_ptr(), self.ent.data_ptr(), self.w.data_ptr()
+        b.rowptrT, b.colT, b.entT, b.wT = self.rowptrT.data_ptr(), self.colT.data_ptr(), self.entT.data_ptr(), self.wT.data_ptr()
+        b.tile_start, b.ntiles, b.tm, b.ell_width, b.ellT_width = tile_start.data_ptr(), nt, tm, ell, ellT
+        b.ell_tiles, b.ell_ent_tiles = (ell_tiles.data_ptr() if ell else None), (ell_ent_tiles.data_ptr() if ell else None)
+        b.ellT_tiles, b.ellT_ent_tiles = (ellT_tiles.data_ptr() if ellT else None), (ellT_ent_tiles.data_ptr() if ellT else None)
+        b.meta = self._meta.data_ptr()
+        _lib.check(L.dss2_ell_tiles_build(C.byref(b), st), "dss2_ell_tiles_build")
+        if exact_nnz and (ell == 0 or ellT == 0):      # CSR staging in the tile kernels (hub graphs): exact sizes needed
+            self._stats = None
+            s = self.stats()
+            max_nnz, max_nnzT = s["max_nnz"], s["max_nnzT"]
+        elif exact_nnz:                                 # ELL staging: the CSR size of a tile is not used by any kernel
+            max_nnz, max_nnzT = max_deg * tm, max_degT * tm
+        else:
+            max_nnz = max_nnzT = nnz_bound
+        self.__dict__.update(nrb=nrb, ntiles=nt, tile_start=tile_start, utilisation=util, max_segment=max_segment,
+                             max_nnz=max_nnz, max_nnzT=max_nnzT, ell=ell, ellT=ellT, ell_tiles=ell_tiles,
+                             ellT_tiles=ellT_tiles, ell_ent_tiles=ell_ent_tiles, ellT_ent_tiles=ellT_ent_tiles)
+        self._tiles_built = True
 
     @property
     def deg_pows(self) -> torch.Tensor:
         """[N, 4] fp32, column m = A_hat^m deg (A_hat = the gcn_norm propagation matrix): the row scales of
         a bias folded through m propagations (networks._FoldPlan).  Built once per topology, in fp64."""
         if self._deg_pows is None:
-            rp = self.rowptr.to(torch.int64)
-            rows = torch.repeat_interleave(torch.arange(self.N, device=self.device), rp[1:] - rp[:-1])
-            col, w = self.col.to(torch.int64), self.w.to(torch.float64)
-            v = self.deg.to(torch.float64)
-            cols = [v]
-            for _ in range(3):
-                v = torch.zeros(self.N, dtype=torch.float64, device=self.device).index_add_(0, rows, w * v[col])
-                cols.append(v)
-            self._deg_pows = torch.stack(cols, dim=1).to(torch.float32).contiguous()
+            out = torch.empty(self.N, 4, dtype=torch.float32, device=self.device)
+            work = torch.empty(2 * self.N, dtype=torch.float64, device=self.device)
+            _lib.check(_lib.lib().dss2_deg_pows(self.rowptr.data_ptr(), self.col.data_ptr(), self.w.data_ptr(),
+                                                self.deg.data_ptr(), self.N, out.data_ptr(), work.data_ptr(),
+                                                _stream(self.device)), "dss2_deg_pows")
+            self._deg_pows = out
         return self._deg_pows
-
-    def _ell_tiles(self, rowptr, col, w, width, ids=False):
-        if width <= 0:
-            return None
-        dev, tm, nt = self.device, 32 * self.nrb, self.ntiles
-        ts = self.tile_start.to(torch.int64)
-        rp = rowptr.to(torch.int64)
-        deg = rp[1:] - rp[:-1]
-        rows = torch.repeat_interleave(torch.arange(self.N, device=dev), deg)
-        k = torch.arange(rows.numel(), device=dev) - rp[rows]
-        tile = torch.searchsorted(ts, rows, right=True) - 1
-        r = rows - ts[tile]
-        out = torch.zeros(nt, width, tm, 2, dtype=torch.int32, device=dev)
-        if ids:
-            out[:, :, :, 1] = -1                                                    # padding: empty slot
-        else:
-            out[:, :, :, 0] = torch.arange(tm, dtype=torch.int32, device=dev)      # padding: {own row, weight 0}
-        out[tile, k, r, 0] = (col.to(torch.int64) - ts[tile]).to(torch.int32)
-        out[tile, k, r, 1] = w if ids else w.view(torch.int32)
-        return out.contiguous()
 
     def lds_check(self, nmat: int, kpad: int, ncg: int) -> None:
         need = _lib.lib().dss2_gemm_prop_lds_bytes(self.nrb, nmat, kpad, ncg, max(self.max_nnz, self.max_nnzT),
@@ -198,40 +249,49 @@ class Topology:
 # cache: identity fast path (same tensor object, unmodified) -> no sync; otherwise content hash
 # ------------------------------------------------------------------------------------------
 _by_hash: Dict[Tuple, Topology] = {}
-_last: Dict[int, Tuple] = {}   # id(tensor) -> (weakref, version, data_ptr, num_nodes, topo)
+_last: Dict[Tuple[int, str], Tuple] = {}   # (id(tensor), mode) -> (weakref, version, data_ptr, num_nodes, topo)
 _MAX_CACHE = 64
 
 
-def content_hash(edge_index: torch.Tensor) -> int:
-    """64-bit device-side hash of edge_index (one tiny kernel + one 8-byte D2H)."""
-    ei = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
-    out = torch.zeros(1, dtype=torch.int64, device=ei.device)
-    stream = torch.cuda.current_stream(ei.device).cuda_stream
-    _lib.check(_lib.lib().dss2_topology_hash(ei.data_ptr(), ei.numel(), out.data_ptr(), stream), "dss2_topology_hash")
-    return int(out.item())
+def _mode(double: Optional[bool]) -> str:
+    return "ref" if double is None else ("dbl" if double else "asis")
 
 
-def get_topology(edge_index: torch.Tensor, num_nodes: int) -> Topology:
+def register_topology(edge_index: torch.Tensor, num_nodes: int, topo: Topology, double: Optional[bool] = None) -> Topology:
+    """Attach an already built structure to this very tensor object: the next ``get_topology(edge_index, ...)`` (the
+    model's forward, the loss) returns it without hashing or synchronising.  Used by dataset.DataLoader."""
+    if len(_last) >= _MAX_CACHE:
+        _last.pop(next(iter(_last)))
+    key = (id(edge_index), _mode(double))
+
+    def _drop(ref, key=key):            # the tensor died: release its structure (device arrays) with it
+        hit = _last.get(key)
+        if hit is not None and hit[0] is ref:
+            _last.pop(key, None)
+    _last[key] = (weakref.ref(edge_index, _drop), edge_index._version, edge_index.data_ptr(), int(num_nodes), topo)
+    return topo
+
+
+def get_topology(edge_index: torch.Tensor, num_nodes: int, double: Optional[bool] = None) -> Topology:
+    """The cached structure of this batch.  double=None: the reference's doubling rule (MPN / the loss);
+    False: the edge list exactly as given (standalone EdgeAggregation / TAGConv / MessagePassing.propagate)."""
     if not edge_index.is_cuda:
         raise RuntimeError("DSS2 HIP path: edge_index must live on the GPU (there is no CPU fallback)")
-    key_id = id(edge_index)
-    hit = _last.get(key_id)
+    mode = _mode(double)
+    hit = _last.get((id(edge_index), mode))
     if hit is not None:
         ref, ver, ptr, nn, topo = hit
         if ref() is edge_index and ver == edge_index._version and ptr == edge_index.data_ptr() and nn == num_nodes:
             return topo
-    h = content_hash(edge_index)
-    key = (edge_index.device.index, int(num_nodes), int(edge_index.size(1)), h)
+    h1, h2, directed = probe(edge_index)
+    key = (edge_index.device.index, int(num_nodes), int(edge_index.size(1)), h1, h2, mode)
     topo = _by_hash.get(key)
     if topo is None:
-        topo = Topology(edge_index, num_nodes)
+        topo = Topology(edge_index, num_nodes, double=(directed if double is None else double))
         if len(_by_hash) >= _MAX_CACHE:
             _by_hash.pop(next(iter(_by_hash)))
         _by_hash[key] = topo
-    if len(_last) >= _MAX_CACHE:
-        _last.pop(next(iter(_last)))
-    _last[key_id] = (weakref.ref(edge_index), edge_index._version, edge_index.data_ptr(), num_nodes, topo)
-    return topo
+    return register_topology(edge_index, num_nodes, topo, double)
 
 
 def clear_cache() -> None:

@@ -42,11 +42,61 @@ int dss2_version(void);
 
 /* ---- topology ------------------------------------------------------------------------- */
 
-/* 64-bit content hash of edge_index[2,E] (int64), position dependent, order of evaluation
- * independent (integer sum), written to *hash_out (device).  Replaces nothing in the reference:
- * it keys the CSR cache that replaces the per-call undirect_graph()/degree() work
- * (networks.py:236-258, PyG gcn_norm).  hash_out must be zeroed by the caller. */
-int dss2_topology_hash(const int64_t* edge_index, int64_t n_elems, uint64_t* hash_out, void* stream);
+/* Content hash + the reference's directedness rule in ONE pass over edge_index[2,E] (int64):
+ *   out3[0], out3[1] = two independent 64-bit position-dependent hashes (wrapping integer sums: independent of the
+ *                      order of evaluation) -- together the 128-bit key of the caller's structure cache;
+ *   out3[2]          = number of edges (v0 -> u0) that reverse the batch's FIRST edge (u0 -> v0):
+ *                      MPN.is_directed(edge_index) <=> out3[2] == 0  (networks.py:236-238, first edge only).
+ * out3 must be zeroed by the caller; one 24-byte device-to-host copy replaces the reference's per-forward sync. */
+int dss2_topology_probe(const int64_t* edge_index, int64_t n_edges, uint64_t* out3, void* stream);
+
+/* ---- dss2_csr_build: the whole per-topology structure on the device, no host round trip.
+ * Replaces MPN.undirect_graph's concatenations (networks.py:240-258), PyG gcn_norm / degree (per TAGConv call) and the
+ * index handling of PyG's scatter: counting sort of the directed edge list by target, by source, and of the stored
+ * edges by incident bus (integer atomics for counts and slot claims, then a per-row sort by directed edge id, so the
+ * result is independent of the order the atomics land in).  doubled != 0: directed list d in [0, 2E), d >= E is the
+ * reverse of stored edge d - E (flip flag in ent); 0: the list is used as given.
+ * Outputs (device, caller-allocated): the arrays of the header comment (E2 = doubled ? 2E : E), perm / permT
+ * (directed edge id of every CSR entry), efrom / eto, deg[N] (in-degree as float), and
+ *   lastcut[N+1]: largest q' <= q such that no edge spans the boundary before row q' (a legal tile cut);
+ *   meta[16] (int32): 0 max in-degree, 1 max out-degree, 2 longest / 4 shortest whole-graph segment, 3 number of
+ *   segments, 5 error flag (1: endpoint outside [0, N); 2: ELL width smaller than a row), 6 / 7 max CSR entries per
+ *   tile (by target / by source, written by dss2_ell_tiles_build), 8.. ntiles per candidate (dss2_tiles_walk).
+ * work: dss2_csr_build_work_ints(N, E, doubled) int32 of device scratch. */
+typedef struct dss2_csr_build_args {
+  const int64_t* edge_index; int64_t n_edges; int64_t n_nodes; int32_t doubled; int32_t pad_;
+  int32_t* rowptr; int32_t* col; int32_t* ent; int32_t* perm; float* w;
+  int32_t* rowptrT; int32_t* colT; int32_t* entT; int32_t* permT; float* wT;
+  int32_t* inc_rowptr; int32_t* inc_ent; int32_t* efrom; int32_t* eto;
+  float* deg; int32_t* lastcut; int32_t* meta; int32_t* work;
+} dss2_csr_build_args;
+int dss2_csr_build(const dss2_csr_build_args* args_host, void* stream);
+int64_t dss2_csr_build_work_ints(int64_t n_nodes, int64_t n_edges, int doubled);
+
+/* tile_start[ntiles+1] for batches of equal-size graphs (closed form): tile t starts at min(t * rows_per_tile, N). */
+int dss2_tiles_uniform(int32_t* tile_start, int32_t ntiles, int32_t rows_per_tile, int64_t n_nodes, void* stream);
+/* general batches: greedy packing of whole segments for n_cand (<= 8) candidate row budgets tm_host[c] at once, from
+ * lastcut; tile_starts_host[c]: device array of cap + 1 ints; ntiles_dev[c] <- number of tiles, or -1 when a segment
+ * exceeds the budget.  Sequential per candidate (each start depends on the previous one). */
+int dss2_tiles_walk(const int32_t* lastcut, int64_t n_nodes, const int32_t* tm_host, int32_t n_cand,
+                    int32_t* const* tile_starts_host, int32_t cap, int32_t* ntiles_dev, void* stream);
+
+/* per-tile ELL slices of both CSRs, [ntiles][width][tm] int2 each (width 0: skipped, pointers may be NULL):
+ *   ell_tiles / ellT_tiles          {local other node, weight bits}, empty slot {own row, 0}     (tile kernels)
+ *   ell_ent_tiles / ellT_ent_tiles  {local other node, stored edge id | flip}, empty slot {0, -1} (edge-MLP kernels)
+ * also meta[6], meta[7] <- max CSR entries of one tile (atomic max). */
+typedef struct dss2_ell_build_args {
+  const int32_t* rowptr; const int32_t* col; const int32_t* ent; const float* w;
+  const int32_t* rowptrT; const int32_t* colT; const int32_t* entT; const float* wT;
+  const int32_t* tile_start; int32_t ntiles; int32_t tm; int32_t ell_width; int32_t ellT_width;
+  void* ell_tiles; void* ell_ent_tiles; void* ellT_tiles; void* ellT_ent_tiles; int32_t* meta;
+} dss2_ell_build_args;
+int dss2_ell_tiles_build(const dss2_ell_build_args* args_host, void* stream);
+
+/* out[N,4] <- columns [deg, A deg, A^2 deg, A^3 deg] (A = the gcn_norm propagation matrix of the CSR), accumulated in
+ * float64 in CSR order: the row scales of a bias folded through m propagations.  work: 2 N device doubles. */
+int dss2_deg_pows(const int32_t* rowptr, const int32_t* col, const float* w, const float* deg, int64_t n_nodes,
+                  float* out, double* work, void* stream);
 
 /* ---- K6: standalone CSR segmented sum (the scatter-add of MessagePassing aggr='add',
  *      networks.py:164,206, measured on its own).  out[i,:] = sum_{e in row i} msg[ent[e],:]
@@ -334,6 +384,17 @@ typedef struct dss2_collate_desc {
   int64_t nodes_per_sample;
 } dss2_collate_desc;
 int dss2_collate(const dss2_collate_desc* descs_host, int32_t n_desc, const int64_t* sample_ids, int64_t batch, void* stream);
+
+/* Ragged collation for batches that mix cases with different closed-branch counts per sample (BASELINE config C5):
+ * one call per case; item j < count is the j-th sample of that case in the batch: sample samp[j] of the case's store,
+ * written at node row node_off[j] / edge row edge_off[j] of the batch (DEVICE int64 arrays, uploaded by the host, which
+ * decides the batch composition and reads nothing back).  Descriptor fields are re-used:
+ *   kind 0: chunk floats per sample; nodes_per_sample = floats per ROW of dst; shared != 0: an edge-row operand
+ *           (offset by edge_off), else a node-row operand (node_off);
+ *   kind 1: edge_index, chunk = e of this case; dst[r][edge_off[j] + k] = src[samp[j]][r][k] + node_off[j] with dst row
+ *           stride e_total (shared != 0: one [2][e] list for every sample). */
+int dss2_collate_ragged(const dss2_collate_desc* descs_host, int32_t n_desc, const int64_t* samp, const int64_t* node_off,
+                        const int64_t* edge_off, int64_t count, int64_t e_total, void* stream);
 
 /* ---- optimizer step (/root/reference/dss2_run.py:91-92,143: Adamax, lr 3e-3) ---
  * torch.optim.Adamax semantics on n_desc tensors in ONE launch.  descs: device array.  `step` is the

@@ -164,3 +164,87 @@ def test_device_side_evaluation_metrics(pkg, oracle, built):
     ev = pkg.runner.evaluate(model, pkg.dataset.DataLoader(ds, batch_size=24), tuple(stats))
     for k in want:
         assert abs(ev[k] - want[k] / n) <= 2e-5 * abs(want[k] / n) + 1e-9, k
+
+
+def _mixed(pkg, S=96, seed=5):
+    """Two cases with the same buses and different closed-branch sets (14 / 15 branches), normalised with common stats."""
+    full = pkg.synthetic.make_batch(["cigre14", "cigre14_reswitched"], 64, seed=seed)
+    parts_h = [pkg.synthetic.make_batch([g], S, seed=seed + 1 + k, stats=full["stats"]) for k, g in enumerate(["cigre14", "cigre14_reswitched"])]
+    parts = [pkg.dataset.DeviceDataset.from_batch(p, device=DEV) for p in parts_h]
+    return parts_h, parts, tuple(s.to(DEV) for s in full["stats"])
+
+
+def test_mixed_topology_loader_collates_without_host_sync(pkg, oracle):
+    """BASELINE config C5's defining property: a new mix of 14- and 15-branch graphs in every batch.  The host picks the
+    composition, the device moves the data and builds the graph structure; nothing is read back (sync-debug "error")."""
+    parts_h, parts, stats = _mixed(pkg)
+    ds = pkg.dataset.MixedDataset(parts)
+    assert len(ds) == 192 and [p.e for p in parts] == [14, 15] and all(p.directed for p in parts)
+    gen = torch.Generator().manual_seed(3)
+    loader = pkg.dataset.DataLoader(ds, batch_size=80, shuffle=True, generator=gen)
+    model = pkg.MPN(8, 6, 2, 32, 3, 2, 0.0).to(DEV)
+    first = next(iter(loader))
+    model(first.x[:, :8], first.edge_index, first.edge_attr[:, :6]).sum().backward()      # warm-up (plans, allocator)
+    torch.cuda.synchronize()
+    seen, batches = [], []
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for bt in loader:
+            out = model(bt.x[:, :8], bt.edge_index, bt.edge_attr[:, :6])
+            loss = pkg.gsp_wls_edge(input=bt.x[:, :8], edge_input=bt.edge_attr[:, :6], output=out, x_mean=stats[0], x_std=stats[1],
+                                    edge_mean=stats[2], edge_std=stats[3], edge_index=bt.edge_index,
+                                    reg_coefs=oracle.DEFAULT_REG_COEFS, num_samples=bt.num_graphs, node_param=bt.x[:, 8:],
+                                    edge_param=bt.edge_attr[:, 6:])
+            loss.backward()
+            batches.append(bt)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert [b.num_graphs for b in batches] == [80, 80, 32]
+    # every batch is the PyG collation of its samples: rebuild it on the host from the per-sample stores
+    rng = np.random.default_rng(int(gen.initial_seed()))
+    rng.permutation(np.arange(192))                      # the warm-up iteration above drew the first permutation
+    ids_all = rng.permutation(np.arange(192))
+    n = 15
+    for k, bt in enumerate(batches):
+        ids = ids_all[80 * k:80 * k + 80]
+        xs, eas, ys, eis = [], [], [], []
+        for slot, g in enumerate(ids):
+            p, s = (0, g) if g < 96 else (1, g - 96)
+            h, e = parts_h[p], parts[p].e
+            xs.append(h["x"][s * n:(s + 1) * n]); ys.append(h["y"][s * n:(s + 1) * n])
+            eas.append(h["edge_attr"][s * e:(s + 1) * e])
+            eis.append(h["edge_index"][:, s * e:(s + 1) * e] - s * n + slot * n)
+        assert torch.equal(bt.x.cpu(), torch.cat(xs)) and torch.equal(bt.y.cpu(), torch.cat(ys))
+        assert torch.equal(bt.edge_attr.cpu(), torch.cat(eas)) and torch.equal(bt.edge_index.cpu(), torch.cat(eis, 1))
+        seen.extend(ids.tolist())
+        # the structure attached to the batch equals a fresh un-hinted build of the same edge list
+        topo = pkg.topology.get_topology(bt.edge_index, bt.x.shape[0])
+        assert topo.hint is not None and topo.stats()["error"] == 0
+        ref = pkg.topology.Topology(bt.edge_index.clone(), bt.x.shape[0])
+        for f in ["rowptr", "col", "ent", "w", "rowptrT", "colT", "entT", "wT", "inc_rowptr", "inc_ent", "tile_start", "ell_tiles",
+                  "ellT_tiles", "ell_ent_tiles", "ellT_ent_tiles"]:
+            assert torch.equal(getattr(topo, f), getattr(ref, f)), f
+    assert sorted(seen) == list(range(192))
+
+
+def test_mixed_topology_batch_step_matches_the_oracle(pkg, oracle):
+    parts_h, parts, stats = _mixed(pkg, S=24)
+    ds = pkg.dataset.MixedDataset(parts)
+    bt = next(iter(pkg.dataset.DataLoader(ds, batch_size=48, shuffle=True, generator=torch.Generator().manual_seed(9))))
+    torch.manual_seed(0)
+    ref = oracle.MPN(8, 6, 2, 64, 3, 2, 0.0)
+    mine = pkg.MPN(8, 6, 2, 64, 3, 2, 0.0)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(DEV)
+    hb = {"x": bt.x.cpu(), "edge_index": bt.edge_index.cpu(), "edge_attr": bt.edge_attr.cpu()}
+    out_r, loss_r = oracle.train_step(ref, hb, tuple(s.cpu() for s in stats))
+    out = mine(bt.x[:, :8], bt.edge_index, bt.edge_attr[:, :6])
+    loss = pkg.gsp_wls_edge(input=bt.x[:, :8], edge_input=bt.edge_attr[:, :6], output=out, x_mean=stats[0], x_std=stats[1],
+                            edge_mean=stats[2], edge_std=stats[3], edge_index=bt.edge_index, reg_coefs=oracle.DEFAULT_REG_COEFS,
+                            num_samples=None, node_param=bt.x[:, 8:], edge_param=bt.edge_attr[:, 6:])
+    loss.backward()
+    assert (out.detach().cpu() - out_r).abs().max() <= 1e-5 * out_r.abs().max()
+    assert abs(loss.item() - loss_r.item()) <= 1e-5 * abs(loss_r.item())
+    for (n_, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert (p.grad.cpu() - q.grad).abs().max() <= 3e-4 * q.grad.abs().max(), n_

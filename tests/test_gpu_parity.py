@@ -78,8 +78,10 @@ def test_tagconv_fwd_bwd(pkg, oracle, grid, hin, hout, K):
         assert rel_err(a.weight.grad, bb.weight.grad) < TOL_GRAD
 
 
+@pytest.mark.parametrize("mfma", ["1", "0"])     # matrix-pipe kernels (default) and the VALU tile kernels
 @pytest.mark.parametrize("grid,hid", [("cigre14", 128), ("ober_sub", 32), ("cigre14_reswitched", 256), ("cigre14", 64)])
-def test_edge_aggregation_fwd_bwd(pkg, oracle, grid, hid):
+def test_edge_aggregation_fwd_bwd(pkg, oracle, grid, hid, mfma, monkeypatch):
+    monkeypatch.setenv("DSS2_EDGE_MFMA", mfma)      # read per call by the library
     torch.manual_seed(3)
     b = pkg.synthetic.make_batch([grid], 5, seed=4)
     x, ea = b["x"][:, :8], b["edge_attr"][:, :6]
@@ -160,6 +162,13 @@ def test_loss_matches_reference_golden(pkg, oracle, name):
 
 
 # ---------------------------------------------------------------------------- full-size configs
+def _referee_loss(oracle, x64, ea64, out64, st64, edge_index):
+    return oracle.gsp_wls_edge(input=x64[:, :8], edge_input=ea64[:, :6], output=out64, x_mean=st64[0], x_std=st64[1],
+                               edge_mean=st64[2], edge_std=st64[3], edge_index=edge_index,
+                               reg_coefs=oracle.DEFAULT_REG_COEFS, num_samples=None, node_param=x64[:, 8:],
+                               edge_param=ea64[:, 6:])
+
+
 def _train_step_pair(pkg, oracle, grids, B, hid, L, K=2, seed=0, cls="MPN", dim_out=2):
     torch.manual_seed(seed)
     b = pkg.synthetic.make_batch(grids, B, seed=seed)
@@ -193,8 +202,10 @@ def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
     assert abs(loss_m.item() - loss_r.item()) <= TOL_LOSS * abs(loss_r.item())
     # gradients, first against the plain fp32 oracle with NOTHING pinned (1e-4: the oracle's own fp32-vs-fp64 gradient
     # noise is 2e-5 and a razor-edge ReLU gate that falls the other way moves a weight-gradient row by ~1/N_nodes) ...
+    # (one flipped gate weighs ~1/N_nodes of a gradient row, so small batches get a tolerance of a few gates)
+    tol_unpinned = max(TOL_GRAD, 3.0 / out_m.shape[0])
     for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
-        assert rel_err(p.grad, q.grad) < TOL_GRAD, ("fp32 oracle, un-pinned", n, rel_err(p.grad, q.grad))
+        assert rel_err(p.grad, q.grad) < tol_unpinned, ("fp32 oracle, un-pinned", n, rel_err(p.grad, q.grad))
     # ... then tightly: fp64 referee evaluated on the HIP path's own ReLU gate pattern.  A pre-activation within
     # an ulp of 0 may take the other sign under a different fp32 summation order; such a flipped gate is
     # not an arithmetic error, but it moves one row of a weight gradient (and everything upstream of it)
@@ -231,10 +242,27 @@ def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
             assert pre[flipped].abs().max() <= 1e-5 * pre.abs().max(), (l, pre[flipped].abs().max().item())
         h = pre * gates[l].double()
     out64 = ref64.convs[-1](h, ei2)
-    loss64 = oracle.gsp_wls_edge(input=x64[:, :8], edge_input=ea64[:, :6], output=out64, x_mean=st64[0], x_std=st64[1],
-                                 edge_mean=st64[2], edge_std=st64[3], edge_index=b["edge_index"],
-                                 reg_coefs=oracle.DEFAULT_REG_COEFS, num_samples=None, node_param=x64[:, 8:],
-                                 edge_param=ea64[:, 6:])
+    # The loss has one more non-smooth point that fp32 noise decides: loading = max(I_from, I_to) (data.py:387-388).
+    # For a branch without shunt admittance the two current magnitudes are EQUAL in exact arithmetic, so which end
+    # receives the gradient of an active relu(loading - 1.5) is a coin flip in any finite precision (diagnosed with
+    # tools/diag_edge_mfma.py: a 1e-7 change of the outputs moved d loss/d theta of two neighbouring buses by a factor
+    # 2.5 and every weight gradient by 3e-5).  Like the conv gates, the branch is pinned to the HIP path's own choice
+    # (read from its get_pflow on its own output); everything else stays un-pinned.
+    with torch.no_grad():
+        st_d = tuple(s.to(DEV) for s in b["stats"])
+        yv = torch.cat([out_m[:, 0:1] * st_d[1][:1] + st_d[0][:1], out_m[:, 1:]], 1)
+        fl = pkg.data.get_pflow(yv, ei, x[:, 8:], ea[:, 6:])
+        vhv, vlv = x[:, 8].max(), x[:, 8].min()
+        pins = iter([(fl[6] >= fl[7]).cpu(), (fl[6] * vhv >= fl[7] * vlv).cpu()])
+    real_max = torch.maximum
+    torch.maximum = lambda a_, b_: torch.where(next(pins), a_, b_)
+    try:
+        loss64 = _referee_loss(oracle, x64, ea64, out64, st64, b["edge_index"])
+    finally:
+        torch.maximum = real_max
+    with torch.no_grad():
+        loss64_unpinned = _referee_loss(oracle, x64, ea64, out64.detach().clone(), st64, b["edge_index"])
+    assert abs(loss64.item() - loss64_unpinned.item()) <= 1e-9 * abs(loss64.item())     # the pin only decides near-ties
     loss64.backward()
     assert n_flip <= max(2, 1e-5 * n_gate), (n_flip, n_gate)
     assert rel_err(out_m, out64) < TOL_OUT

@@ -32,24 +32,34 @@ def test_struct_layouts_match_the_header_sizes():
     import subprocess
     import tempfile
     pkg = load_pkg()
-    src = ('#include <stdio.h>\n#include "dss2_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(dss2_pack_desc), '
-           'sizeof(dss2_gemm_prop_args), sizeof(dss2_wgrad_args), sizeof(dss2_wls_args));return 0;}\n')
+    src = ('#include <stdio.h>\n#include "dss2_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(dss2_pack_desc), '
+           'sizeof(dss2_gemm_prop_args), sizeof(dss2_wgrad_args), sizeof(dss2_wls_args), sizeof(dss2_csr_build_args), '
+           'sizeof(dss2_ell_build_args));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "p.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "p.c"), "-o", os.path.join(d, "p")])
         sizes = [int(v) for v in subprocess.check_output([os.path.join(d, "p")]).split()]
     L = pkg._lib
-    assert sizes == [ctypes.sizeof(L.PackDesc), ctypes.sizeof(L.GemmPropArgs), ctypes.sizeof(L.WgradArgs), ctypes.sizeof(L.WlsArgs)]
+    assert sizes == [ctypes.sizeof(L.PackDesc), ctypes.sizeof(L.GemmPropArgs), ctypes.sizeof(L.WgradArgs), ctypes.sizeof(L.WlsArgs),
+                     ctypes.sizeof(L.CsrBuildArgs), ctypes.sizeof(L.EllBuildArgs)]
     assert pkg.networks._DESC_DTYPE.itemsize == sizes[0]
 
 
+@pytest.fixture(scope="module")
+def topo_oracle():
+    import dss2_topology_oracle
+    return dss2_topology_oracle
+
+
 @pytest.mark.parametrize("grids,B", [(["cigre14"], 9), (["cigre14", "cigre14_reswitched"], 33), (["ober_sub"], 5), (["ober179"], 3)])
-def test_topology_structure(oracle, grids, B):
+def test_topology_oracle_structure(oracle, topo_oracle, grids, B):
+    """The structure oracle (oracle/dss2_topology_oracle.py: what the device-side build must reproduce bit for bit,
+    tests/test_gpu_topology.py) against the path oracle's PyG restatement: doubling, row order, gcn_norm weights."""
     pkg = load_pkg()
     b = pkg.synthetic.make_batch(grids, B, seed=7)
     ei, N = b["edge_index"], b["x"].shape[0]
     E = ei.shape[1]
-    topo = pkg.topology.Topology(ei, N)
+    topo = topo_oracle.TopologyOracle(ei, N)
     assert topo.directed is True and oracle.is_directed(ei) is True and topo.E2 == 2 * E
     ei2, _ = oracle.undirect_graph(ei, b["edge_attr"][:, :6])
     src, tgt = ei2[0].numpy(), ei2[1].numpy()
@@ -63,7 +73,7 @@ def test_topology_structure(oracle, grids, B):
     assert ((ent & 0x7fffffff) == perm % E).all() and ((ent < 0) == (perm >= E)).all()
     # gcn_norm weights and degrees equal the oracle's, bit for bit
     w_ref = oracle.gcn_norm_no_self_loops(ei2, N, torch.float32)
-    assert torch.equal(topo.w, w_ref[topo.perm])
+    assert torch.equal(topo.w, w_ref[topo.perm.long()])
     assert torch.equal(topo.deg, oracle.degree(ei2[1], N))
     # transposed CSR holds the same edges grouped by source
     rpT, colT = topo.rowptrT.numpy(), topo.colT.numpy()
@@ -81,20 +91,23 @@ def test_topology_structure(oracle, grids, B):
     assert topo.max_nnz == max(rp[ts[1:]] - rp[ts[:-1]])
 
 
-def test_topology_edge_cases():
+def test_topology_edge_cases(topo_oracle):
     pkg = load_pkg()
     ei = torch.tensor([[0, 1, 1, 2], [1, 0, 2, 1]])      # already undirected: no doubling, no flips
-    topo = pkg.topology.Topology(ei, 4)                   # node 3 is isolated
+    topo = topo_oracle.TopologyOracle(ei, 4)              # node 3 is isolated
     assert topo.directed is False and topo.E2 == 4 and (topo.ent.numpy() >= 0).all()
     assert topo.deg.tolist() == [1.0, 2.0, 1.0, 0.0] and torch.isfinite(topo.w).all()
+    n = 400                                                # a component larger than the biggest tile has no tile part
+    chain = torch.stack([torch.arange(n - 1), torch.arange(1, n)])
+    assert topo_oracle.TopologyOracle(chain, n).tiled is False
+    # the product class validates its input and has no CPU path
     with pytest.raises(ValueError):
         pkg.topology.Topology(torch.zeros(2, 0, dtype=torch.int64), 3)       # empty
     with pytest.raises(ValueError):
         pkg.topology.Topology(torch.zeros(2, 3, dtype=torch.int32), 3)       # wrong dtype
-    n = 400                                                # a component larger than the biggest tile fails loudly
-    chain = torch.stack([torch.arange(n - 1), torch.arange(1, n)])
-    with pytest.raises(NotImplementedError):
-        pkg.topology.Topology(chain, n)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.topology.Topology(ei, 4)
+    assert pkg.topology.reference_is_directed(ei) is False and pkg.topology.reference_is_directed(chain) is True
 
 
 def test_interface_parity_and_loud_failure():

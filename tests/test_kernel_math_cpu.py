@@ -9,6 +9,8 @@ import torch
 
 from conftest import LOSS_CASES, case_batch, golden, load_pkg, t
 
+import dss2_topology_oracle as topo_oracle   # structure oracle (CSR / incidence layout of include/dss2_hip.h)
+
 
 def _emulate_wls(topo, x, ea, out, st, reg):
     """Transliteration of wls_partials_kernel + wls_grad_kernel (node-centric, incidence CSR)."""
@@ -127,7 +129,7 @@ def test_loss_kernel_math(oracle, name):
     e_sub = int((ei[0] < n_sub).sum())
     x, ea, ei = x[:n_sub], ea[:e_sub], ei[:, :e_sub]
     out0 = t(g["output"])[:n_sub]
-    topo = pkg.topology.Topology(ei, n_sub)
+    topo = topo_oracle.TopologyOracle(ei, n_sub)
     loss, grad, out_after, _ = _emulate_wls(topo, x, ea, out0, st, oracle.DEFAULT_REG_COEFS)
     d = torch.float64
     o_leaf = out0.to(d).clone().requires_grad_(True)
@@ -159,7 +161,7 @@ def test_horner_tagconv_and_its_gradients(oracle):
     torch.manual_seed(0)
     b = pkg.synthetic.make_batch(["cigre14", "cigre14_reswitched"], 4, seed=3)
     N = b["x"].shape[0]
-    topo = pkg.topology.Topology(b["edge_index"], N)
+    topo = topo_oracle.TopologyOracle(b["edge_index"], N)
     A = _dense_ahat(topo)
     AT = torch.zeros_like(A)
     rp, col, w = topo.rowptrT.numpy(), topo.colT.numpy(), topo.wT.double().numpy()
@@ -193,7 +195,7 @@ def test_edge_aggregation_aggregate_then_linear(oracle):
     torch.manual_seed(1)
     b = pkg.synthetic.make_batch(["cigre14"], 3, seed=5)
     N = b["x"].shape[0]
-    topo = pkg.topology.Topology(b["edge_index"], N)
+    topo = topo_oracle.TopologyOracle(b["edge_index"], N)
     ea_mod = oracle.EdgeAggregation(8, 6, 16, 16).double()
     x, ea = b["x"][:, :8].double(), b["edge_attr"][:, :6].double()
     ei2, ea2 = oracle.undirect_graph(b["edge_index"], ea)

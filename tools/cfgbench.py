@@ -57,3 +57,52 @@ for name, grids, B, cls, args in CFG:
         assert abs(lgv - l.item()) <= 1e-5 * abs(l.item()), (lgv, l.item())
     topo = pkg.topology.get_topology(ei, x.shape[0])
     print(f"{name:44s} N={x.shape[0]:7d} nrb={topo.nrb} util={topo.utilisation:.2f}  {dt*1e3:8.3f} ms/step  {B/dt/1e6:7.3f} M graphs/s | hipGraph {dtg*1e3:8.3f} ms  {B/dtg/1e6:7.3f} M graphs/s  loss={l.item():.4g}", flush=True)
+
+
+# ---- C5 as BASELINE.json words it ("variable edge_index per sample"): a NEW Bernoulli(0.5) mix of cigre14 / reswitched
+# graphs every step through dataset.DataLoader (host picks the composition; ragged collation + structure build on the
+# device, no host sync).  Reported: the step on a resident batch, the same step with a fresh batch (collation + graph
+# structure) per step, and the per-step batch-assembly cost alone.
+if not sel or any("C5" in s_ for s_ in sel):
+    import numpy as np
+    B, S = 4096, 8192
+    full = pkg.synthetic.make_batch(["cigre14", "cigre14_reswitched"], 256, seed=1)
+    parts = [pkg.dataset.DeviceDataset.from_batch(pkg.synthetic.make_batch([g], S, seed=2 + k, stats=full["stats"]), device=dev)
+             for k, g in enumerate(["cigre14", "cigre14_reswitched"])]
+    ds = pkg.dataset.MixedDataset(parts)
+    st = tuple(s_.to(dev) for s_ in full["stats"])
+    model = pkg.MPN(8, 6, 2, 256, 8, 2, 0.0).to(dev)
+    rng = np.random.default_rng(0)
+
+    def fresh():
+        return ds.collate(rng.choice(2 * S, size=B, replace=False))
+
+    def step(bt):
+        for p in model.parameters(): p.grad = None
+        out = model(bt.x[:, :8], bt.edge_index, bt.edge_attr[:, :6])
+        loss = pkg.gsp_wls_edge(input=bt.x[:, :8], edge_input=bt.edge_attr[:, :6], output=out, x_mean=st[0], x_std=st[1],
+                                edge_mean=st[2], edge_std=st[3], edge_index=bt.edge_index, reg_coefs=REG, num_samples=None,
+                                node_param=bt.x[:, 8:], edge_param=bt.edge_attr[:, 6:])
+        loss.backward(); return loss
+    bt0 = fresh()
+    for _ in range(5): step(bt0)
+    n = 20
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): step(bt0)
+    torch.cuda.synchronize(); t_res = (time.perf_counter() - t0) / n
+    for _ in range(3): step(fresh())
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): step(fresh())
+    torch.cuda.synchronize(); t_new = (time.perf_counter() - t0) / n
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        bt = fresh(); pkg.topology.get_topology(bt.edge_index, bt.x.shape[0]).nrb
+    torch.cuda.synchronize(); t_asm = (time.perf_counter() - t0) / n
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        bt = fresh(); pkg.topology.get_topology(bt.edge_index, bt.x.shape[0]).nrb
+    e1.record(); torch.cuda.synchronize()
+    print(f"C5 shuffled (new topology mix every step) B={B} H=256 L=8: resident batch {t_res*1e3:.3f} ms/step | fresh batch per step "
+          f"{t_new*1e3:.3f} ms/step ({B/t_new/1e6:.3f} M graphs/s) | batch assembly alone (ragged collate + device CSR/tile/ELL build): "
+          f"{t_asm*1e3:.3f} ms wall, {e0.elapsed_time(e1)/n:.3f} ms GPU = {100*t_asm/t_new:.1f} % of the step", flush=True)
