@@ -118,6 +118,7 @@ _SIGNATURES = {
     "dss2_deg_pows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dss2_segment_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                    C.c_int64, C.c_int, C.c_void_p]),
+    "dss2_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "dss2_pack_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dss2_edge_hidden_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,

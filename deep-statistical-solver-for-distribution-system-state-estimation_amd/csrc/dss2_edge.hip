@@ -349,6 +349,38 @@ __global__ void __launch_bounds__(256) segment_sum_kernel(
   }
 }
 
+// Any feature width (MessagePassing.propagate with a user-defined message): one thread per output element, the
+// entries of a row are summed in CSR order (ascending directed edge id, the order index_add_ visits them).
+__global__ void __launch_bounds__(256) segment_sum_generic_kernel(
+    const float* __restrict__ msg, int64_t ldm, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ent,
+    float* __restrict__ out, int64_t ldo, int64_t n_rows, int h) {
+  const int64_t total = n_rows * h;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / h;
+    const int c = (int)(idx - i * h);
+    float s = 0.f;
+    const int e1 = rowptr[i + 1];
+    for (int e = rowptr[i]; e < e1; ++e) s += msg[(int64_t)ent[e] * ldm + c];
+    out[i * ldo + c] = s;
+  }
+}
+
+// out[r, :] = src[idx[r], :]: the gather half of MessagePassing.propagate (x_j = x[edge_index[0]], x_i = x[edge_index[1]])
+// and the backward of the segmented sum.  VEC: 16-byte lanes (h % 4 == 0, aligned operands).
+template <bool VEC>
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ src, int64_t lds, const int32_t* __restrict__ idx,
+                                                          float* __restrict__ out, int64_t ldo, int64_t n_rows, int h) {
+  const int per = VEC ? h >> 2 : h;
+  const int64_t total = n_rows * per;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / per;
+    const int c = (int)(t - r * per);
+    const int64_t s = idx[r];
+    if (VEC) *reinterpret_cast<f32x4*>(out + r * ldo + 4 * c) = *reinterpret_cast<const f32x4*>(src + s * lds + 4 * c);
+    else out[r * ldo + c] = src[s * lds + c];
+  }
+}
+
 // out[j] = sum_k slab[k][j].  blockDim = (64, 4): threadIdx.y owns a contiguous quarter of the slabs
 // and keeps 8 independent loads in flight; partial sums are combined in a fixed order, so the
 // result is bitwise reproducible (no atomics).
@@ -769,15 +801,36 @@ extern "C" int dss2_edge_tile_bwd(const float* x, int64_t ldx, const float* ea, 
 
 extern "C" int dss2_segment_sum(const float* msg, int64_t ldm, const int32_t* rowptr, const int32_t* ent, float* out,
                                 int64_t ldo, int64_t n_rows, int h, void* stream) {
-  if (h != 32 && h != 64 && h != 128 && h != 256) { set_error("segment_sum: h=%d unsupported (32/64/128/256)", h); return 2; }
-  if ((ldm & 3) || (ldo & 3)) { set_error("segment_sum: leading dimensions must be multiples of 4"); return 2; }
+  if (h <= 0) { set_error("segment_sum: h=%d", h); return 2; }
   if (n_rows <= 0) return 0;
+  const bool fast = (h == 32 || h == 64 || h == 128 || h == 256) && !(ldm & 3) && !(ldo & 3) &&
+                    !(reinterpret_cast<uintptr_t>(msg) & 15) && !(reinterpret_cast<uintptr_t>(out) & 15);
+  if (!fast) {      // any width / alignment: one thread per output element
+    int64_t blocks = (n_rows * h + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(segment_sum_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), msg, ldm, rowptr,
+                       ent, out, ldo, n_rows, h);
+    return check_launch("segment_sum");
+  }
   const int gpb = 256 / (h / 4);
   int64_t blocks = (n_rows + gpb - 1) / gpb;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), msg, ldm, rowptr, ent,
                      out, ldo, n_rows, h);
   return check_launch("segment_sum");
+}
+
+extern "C" int dss2_gather_rows(const float* src, int64_t lds, const int32_t* idx, float* out, int64_t ldo, int64_t n_rows,
+                                int h, void* stream) {
+  if (h <= 0) { set_error("gather_rows: h=%d", h); return 2; }
+  if (n_rows <= 0) return 0;
+  const bool vec = !(h & 3) && !(lds & 3) && !(ldo & 3) && !(reinterpret_cast<uintptr_t>(src) & 15) &&
+                   !(reinterpret_cast<uintptr_t>(out) & 15);
+  int64_t blocks = (n_rows * (vec ? h / 4 : h) + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (vec) hipLaunchKernelGGL(gather_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, lds, idx, out, ldo, n_rows, h);
+  else hipLaunchKernelGGL(gather_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, lds, idx, out, ldo, n_rows, h);
+  return check_launch("gather_rows");
 }
 
 extern "C" int dss2_reduce_slabs(const float* slab, int n_slabs, int64_t stride, float* out, int64_t len, void* stream) {

@@ -51,7 +51,7 @@ def _fill_args(topo: Topology, input, edge_input, output, node_param, edge_param
     a.lam_v, a.lam_p, a.lam_pf, a.lam_reg = (float(reg_coefs[k]) for k in ("lam_v", "lam_p", "lam_pf", "lam_reg"))
     a.sums, a.partials, a.vminmax = bufs["sums"].data_ptr(), bufs["partials"].data_ptr(), bufs["vminmax"].data_ptr()
     a.apq, a.loss, a.grad_output = bufs["apq"].data_ptr(), bufs["loss"].data_ptr(), bufs["grad"].data_ptr()
-    a.pflow = None
+    a.pflow = bufs["pflow"].data_ptr() if bufs.get("pflow") is not None else None
     return a
 
 
@@ -59,7 +59,7 @@ class _WlsFn(torch.autograd.Function):
     """loss, output = f(output): `output` is modified in place (theta masked) and marked dirty."""
 
     @staticmethod
-    def forward(ctx, output, topo, tensors, reg_coefs, group):
+    def forward(ctx, output, topo, tensors, reg_coefs, group, pflow_out=None):
         input, edge_input, node_param, edge_param, x_mean, x_std, edge_mean, edge_std = tensors
         ctx.set_materialize_grads(False)
         dev = output.device
@@ -74,6 +74,7 @@ class _WlsFn(torch.autograd.Function):
             "apq": torch.empty(N, 2, dtype=_F32, device=dev),
             "loss": torch.empty(1, dtype=_F32, device=dev),
             "grad": torch.empty(N, 2, dtype=_F32, device=dev),
+            "pflow": pflow_out,
         }
         a = _fill_args(topo, input, edge_input, (output, output.stride(0)), node_param, edge_param,
                        x_mean, x_std, edge_mean, edge_std, reg_coefs, bufs)
@@ -101,13 +102,15 @@ class _WlsFn(torch.autograd.Function):
             g = g + gout_unused
             npar = ctx.keep[1][2][0]
             g[:, 1] = g[:, 1] - gout_unused[:, 1] * npar[:, 1]
-        return g, None, None, None, None
+        return g, None, None, None, None, None
 
 
 def gsp_wls_edge(input, edge_input, output, x_mean, x_std, edge_mean, edge_std, edge_index, reg_coefs,
-                 num_samples=None, node_param=None, edge_param=None, group=None):
+                 num_samples=None, node_param=None, edge_param=None, group=None, pflow_out=None):
     """/root/reference/data.py:393-459.  Returns a 0-dim loss attached to autograd; zeroes
-    ``output[:, 1]`` at slack buses in place like the reference."""
+    ``output[:, 1]`` at slack buses in place like the reference.  Beyond the reference's arguments: ``group`` (data-
+    parallel loss, see the module docstring) and ``pflow_out``, an optional contiguous [E, 8] fp32 buffer that receives
+    the eight get_pflow quantities exactly as the loss kernel computed them (diagnostics / tests)."""
     _require_gpu(input, edge_input, output, node_param, edge_param, edge_index)
     dev = output.device
     topo = get_topology(edge_index, input.size(0))
@@ -116,7 +119,10 @@ def gsp_wls_edge(input, edge_input, output, x_mean, x_std, edge_mean, edge_std, 
     for k in ("lam_v", "lam_p", "lam_pf", "lam_reg"):
         if k not in reg_coefs:
             raise KeyError(f"reg_coefs['{k}'] missing")
-    loss, _ = _WlsFn.apply(output, topo, tensors, dict(reg_coefs), group)
+    if pflow_out is not None and (pflow_out.dtype != _F32 or tuple(pflow_out.shape) != (topo.E, 8) or not pflow_out.is_contiguous()
+                                  or pflow_out.device != dev):
+        raise ValueError("pflow_out must be a contiguous [E, 8] fp32 tensor on the output's device")
+    loss, _ = _WlsFn.apply(output, topo, tensors, dict(reg_coefs), group, pflow_out)
     return loss
 
 

@@ -227,6 +227,8 @@ def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, ent: torch.Tensor, n_ro
     """K6: out[i] = sum of msg rows listed in CSR row i (the scatter-add of aggr='add')."""
     _require_gpu(msg)
     msg, ldm = _rows(msg)
+    if ent.dtype != torch.int32:
+        ent = ent.to(torch.int32)
     out = torch.empty(n_rows, msg.size(1), dtype=_F32, device=msg.device)
     _lib.check(_lib.lib().dss2_segment_sum(msg.data_ptr(), ldm, rowptr.data_ptr(), ent.data_ptr(), out.data_ptr(),
                                            out.stride(0), n_rows, msg.size(1), _stream(msg)), "dss2_segment_sum")
@@ -556,18 +558,105 @@ def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=No
 # ------------------------------------------------------------------------------------------
 # modules
 # ------------------------------------------------------------------------------------------
-class MessagePassing(nn.Module):
-    """Minimal stand-in for PyG's base class so ``EdgeAggregation`` keeps its shape: the
-    gather -> message -> scatter-add engine itself is the fused HIP path, not Python."""
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """out[r] = src[idx[r]] (idx: int32 device tensor): dss2_gather_rows."""
+    src, lds = _rows(src)
+    out = torch.empty(idx.numel(), src.size(1), dtype=_F32, device=src.device)
+    _lib.check(_lib.lib().dss2_gather_rows(src.data_ptr(), lds, idx.data_ptr(), out.data_ptr(), out.stride(0) if out.size(0) > 1 else out.size(1),
+                                           idx.numel(), src.size(1), _stream(src)), "dss2_gather_rows")
+    return out
 
-    def __init__(self, aggr: str = "add"):
+
+class _GatherFn(torch.autograd.Function):
+    """x_j = x[edge_index[0]] (by_source) / x_i = x[edge_index[1]] of PyG's propagate; the backward of a gather is the
+    segmented sum over the CSR grouped by that end."""
+
+    @staticmethod
+    def forward(ctx, x, topo, by_source):
+        ctx.topo, ctx.by_source, ctx.n = topo, by_source, x.size(0)
+        return gather_rows(x, topo.efrom if by_source else topo.eto)
+
+    @staticmethod
+    def backward(ctx, g):
+        t = ctx.topo
+        rp, perm = (t.rowptrT, t.permT) if ctx.by_source else (t.rowptr, t.perm)
+        return segment_sum(g.contiguous(), rp, perm, ctx.n), None, None
+
+
+class _SegmentSumFn(torch.autograd.Function):
+    """aggr='add': out[i] = sum of the messages of the edges whose target is i; backward = gather by target."""
+
+    @staticmethod
+    def forward(ctx, msg, topo):
+        ctx.topo = topo
+        return segment_sum(msg, topo.rowptr, topo.perm, topo.N)
+
+    @staticmethod
+    def backward(ctx, g):
+        return gather_rows(g.contiguous(), ctx.topo.eto), None
+
+
+class MessagePassing(nn.Module):
+    """PyG's ``MessagePassing(aggr='add')`` base class as the reference uses it (networks.py:7,159,164,206), on the HIP
+    gather / segmented-sum kernels: ``propagate(edge_index, **kwargs)`` gathers every ``foo_j`` / ``foo_i`` parameter of
+    ``message()`` from ``kwargs['foo']`` at the source / target end of each edge (flow='source_to_target'), passes other
+    parameters through by name, ignores keyword arguments ``message()`` does not name (which is why the ``norm`` of
+    networks.py:206 is dead), sums the messages per target node (``dim_size`` = rows of the gathered tensor) and calls
+    ``update()``.  Differentiable.  ``edge_index`` is used exactly as given.  ``EdgeAggregation.forward`` does not come
+    through here -- it runs the fused edge-MLP kernels -- but ``EdgeAggregation.propagate`` works and gives the same
+    numbers (tests), as does any user subclass with its own ``message``."""
+
+    def __init__(self, aggr: str = "add", flow: str = "source_to_target", node_dim: int = 0):
         super().__init__()
         if aggr != "add":
             raise NotImplementedError("only aggr='add' is built")
-        self.aggr = aggr
+        if flow != "source_to_target" or node_dim != 0:
+            raise NotImplementedError("only flow='source_to_target', node_dim=0 are built (the reference's defaults)")
+        self.aggr, self.flow, self.node_dim = aggr, flow, node_dim
 
-    def propagate(self, edge_index, **kwargs):
-        raise NotImplementedError("propagate() is fused into the HIP kernels; call forward()")
+    def message(self, x_j):
+        return x_j
+
+    def update(self, aggr_out):
+        return aggr_out
+
+    def propagate(self, edge_index, size=None, **kwargs):
+        import inspect
+        _require_gpu(edge_index)
+        params = inspect.signature(self.message).parameters
+        n_nodes = None if size is None else int(size if isinstance(size, int) else size[1])
+        for name in params:
+            if name.endswith(("_i", "_j")) and torch.is_tensor(kwargs.get(name[:-2])):
+                n_nodes = int(kwargs[name[:-2]].size(0)) if n_nodes is None else n_nodes
+        if n_nodes is None:
+            raise ValueError("propagate: cannot infer the number of nodes (pass size= or a *_i / *_j message argument)")
+        topo = get_topology_asis(edge_index, n_nodes)
+        args = {}
+        for name, prm in params.items():
+            base = name[:-2] if name.endswith(("_i", "_j")) else None
+            if base is not None and base in kwargs:
+                t = kwargs[base]
+                if not torch.is_tensor(t):
+                    args[name] = t
+                    continue
+                _require_gpu(t)
+                flat = t if t.dim() == 2 else t.reshape(t.size(0), -1)
+                if t.is_floating_point():
+                    g = _GatherFn.apply(flat, topo, name.endswith("_j"))
+                else:       # index / flag tensors: plain device gather, nothing to differentiate
+                    g = flat.index_select(0, (topo.efrom if name.endswith("_j") else topo.eto).long())
+                args[name] = g if t.dim() == 2 else g.reshape((topo.E,) + tuple(t.shape[1:]))
+            elif name in kwargs:
+                args[name] = kwargs[name]
+            elif prm.default is inspect.Parameter.empty and prm.kind not in (prm.VAR_KEYWORD, prm.VAR_POSITIONAL):
+                raise TypeError(f"propagate: message() needs '{name}' but it was not passed")
+        msg = self.message(**args)
+        _require_gpu(msg)
+        m2 = msg if msg.dim() == 2 else msg.reshape(msg.size(0), -1)
+        if m2.size(0) != topo.E:
+            raise ValueError(f"message() returned {m2.size(0)} rows for {topo.E} edges")
+        out = _SegmentSumFn.apply(m2.contiguous(), topo)
+        return self.update(out if msg.dim() == 2 else out.reshape((n_nodes,) + tuple(msg.shape[1:])))
 
 
 class TAGConv(nn.Module):
@@ -634,7 +723,9 @@ class EdgeAggregation(MessagePassing):
         self._plan = None
 
     def message(self, x_i, x_j, edge_attr):
-        raise NotImplementedError("message() is fused into the HIP kernel (dss2_edge_hidden_fwd)")
+        """networks.py:176-181, the reference expression.  ``forward`` does not call it (the fused kernels evaluate the same
+        arithmetic with the second Linear moved behind the aggregation); it serves ``propagate`` and subclasses."""
+        return self.edge_aggr(torch.cat([x_i, x_j, edge_attr], dim=-1))
 
     def forward(self, x, edge_index, edge_attr):
         _require_gpu(x, edge_index, edge_attr)

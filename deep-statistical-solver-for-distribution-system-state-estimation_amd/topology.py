@@ -223,6 +223,7 @@ class Topology:
         self.__dict__.update(nrb=nrb, ntiles=nt, tile_start=tile_start, utilisation=util, max_segment=max_segment,
                              max_nnz=max_nnz, max_nnzT=max_nnzT, ell=ell, ellT=ellT, ell_tiles=ell_tiles,
                              ellT_tiles=ellT_tiles, ell_ent_tiles=ell_ent_tiles, ellT_ent_tiles=ellT_ent_tiles)
+        self._stats = None            # (the ELL build added the per-tile entry counts to the statistics)
         self._tiles_built = True
 
     @property

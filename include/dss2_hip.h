@@ -100,9 +100,16 @@ int dss2_deg_pows(const int32_t* rowptr, const int32_t* col, const float* w, con
 
 /* ---- K6: standalone CSR segmented sum (the scatter-add of MessagePassing aggr='add',
  *      networks.py:164,206, measured on its own).  out[i,:] = sum_{e in row i} msg[ent[e],:]
- *      `ent` holds row indices into msg (directed edge ids).  h % 4 == 0. */
+ *      `ent` holds row indices into msg (directed edge ids).  h in {32, 64, 128, 256} with 16-byte aligned operands
+ *      takes the HBM-rate kernel (16-byte lanes); any other width / alignment a one-thread-per-element kernel.
+ *      Summation order inside a row = CSR order (ascending directed edge id): deterministic, no atomics. */
 int dss2_segment_sum(const float* msg, int64_t ldm, const int32_t* rowptr, const int32_t* ent,
                      float* out, int64_t ldo, int64_t n_rows, int h, void* stream);
+
+/* out[r,:] = src[idx[r],:], r < n_rows: the gather half of PyG MessagePassing.propagate (x_j = x[edge_index[0]],
+ * x_i = x[edge_index[1]]; call site networks.py:206) and the backward of the segmented sum. */
+int dss2_gather_rows(const float* src, int64_t lds, const int32_t* idx, float* out, int64_t ldo, int64_t n_rows, int h,
+                     void* stream);
 
 /* ---- weight packing: nn.Linear weights -> MFMA B-operand fragment order ----------------- */
 

@@ -10,6 +10,11 @@ the product's own data-parallel branches on the one GPU of the box, over the "nc
 
 At world size 1 a SUM all-reduce is the identity, so loss and every gradient must be BITWISE equal to the
 non-distributed step.  Prints one JSON object on the last line of stdout.
+
+    python _rccl_child.py eager     blocking and asynchronous collectives
+    python _rccl_child.py graph     the step with its collectives inside a hipGraph capture (a separate process: a
+                                    failing capture can take the process down, which must not take the eager result
+                                    with it)
 """
 import importlib
 import json
@@ -23,6 +28,7 @@ REG = {"mu_v": 1e-1, "mu_theta": 1e-1, "lam_v": 1e-4, "lam_p": 1e-8, "lam_pf": 1
 
 
 def main():
+    mode = sys.argv[1] if len(sys.argv) > 1 else "eager"
     import torch
     import torch.distributed as dist
     pkg = importlib.import_module(PKG)
@@ -59,8 +65,26 @@ def main():
             torch.cuda.synchronize()
             return loss.detach().clone(), [p.grad.detach().clone() for p in model.parameters()]
 
-        l0, g0 = snapshot(step(None))                                     # non-distributed reference
         c = {}
+        if mode == "graph":
+            # canonical capture order (graphs.GraphedStep): capture BEFORE any eager step has created AccumulateGrad
+            # nodes on the default stream; the non-distributed reference runs afterwards on the capture stream
+            pkg.parallel.attach_grad_allreduce(model, group)
+            print(f"[{name}] capturing", file=sys.stderr, flush=True)
+            gs = pkg.graphs.GraphedStep(lambda: step(group))
+            print(f"[{name}] captured, replaying", file=sys.stderr, flush=True)
+            l3, g3 = snapshot(gs.replay())
+            for m in model.modules():
+                if hasattr(m, "_grad_bucket_hook"):
+                    m._grad_bucket_hook = None
+            with torch.cuda.stream(gs.stream):
+                l0, g0 = snapshot(step(None))
+            c["graph_capture"] = "ok"
+            c["graph_bitwise"] = bool(torch.equal(l0, l3) and all(torch.equal(a, q) for a, q in zip(g0, g3)))
+            res["cases"][name] = c
+            continue
+        l0, g0 = snapshot(step(None))                                     # non-distributed reference
+        print(f"[{name}] reference step done", file=sys.stderr, flush=True)
         # ---- blocking collectives
         n_hooks = pkg.parallel.attach_grad_allreduce(model, group)
         orig = pkg.parallel.allreduce_flat_grads
@@ -79,16 +103,6 @@ def main():
         c["async_joined"] = pkg.parallel.wait_grad_allreduce(model)
         l2, g2 = snapshot(loss)
         c["async_bitwise"] = bool(torch.equal(l0, l2) and all(torch.equal(a, q) for a, q in zip(g0, g2)))
-        # ---- the same step inside a hipGraph capture (collectives captured with it)
-        pkg.parallel.attach_grad_allreduce(model, group)
-        try:
-            gs = pkg.graphs.GraphedStep(lambda: step(group))
-            lg = gs.replay()
-            l3, g3 = snapshot(lg)
-            c["graph_capture"] = "ok"
-            c["graph_bitwise"] = bool(torch.equal(l0, l3) and all(torch.equal(a, q) for a, q in zip(g0, g3)))
-        except Exception as exc:      # capture of RCCL collectives unsupported on this stack: eager is the fallback
-            c["graph_capture"] = f"unsupported: {type(exc).__name__}: {str(exc)[:200]}"
         pkg.parallel.allreduce_flat_grads = orig
         res["cases"][name] = c
     torch.cuda.synchronize()

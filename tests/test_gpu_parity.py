@@ -22,10 +22,10 @@ def pkg():
     return p
 
 
-def _loss(mod_data, x, ei, ea, st, out, reg):
+def _loss(mod_data, x, ei, ea, st, out, reg, **kw):
     return mod_data.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1],
                                  edge_mean=st[2], edge_std=st[3], edge_index=ei, reg_coefs=reg, num_samples=None,
-                                 node_param=x[:, 8:], edge_param=ea[:, 6:])
+                                 node_param=x[:, 8:], edge_param=ea[:, 6:], **kw)
 
 
 # ---------------------------------------------------------------------------- op level
@@ -185,9 +185,10 @@ def _train_step_pair(pkg, oracle, grids, B, hid, L, K=2, seed=0, cls="MPN", dim_
     x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
     st = tuple(s.to(DEV) for s in b["stats"])
     out_m = mine(x[:, :8], ei, ea[:, :6])
-    loss_m = _loss(pkg.data, x, ei, ea, st, out_m, oracle.DEFAULT_REG_COEFS)
+    flows_m = torch.empty(ei.shape[1], 8, device=DEV)       # get_pflow as the loss kernel itself evaluated it
+    loss_m = _loss(pkg.data, x, ei, ea, st, out_m, oracle.DEFAULT_REG_COEFS, pflow_out=flows_m)
     loss_m.backward()
-    return ref, mine, out_r, loss_r, out_m, loss_m
+    return ref, mine, out_r, loss_r, out_m, loss_m, flows_m
 
 
 @pytest.mark.parametrize("grids,B,hid,L", [
@@ -197,7 +198,7 @@ def _train_step_pair(pkg, oracle, grids, B, hid, L, K=2, seed=0, cls="MPN", dim_
     (["cigre14", "cigre14_reswitched"], 512, 256, 8),           # C5's model on a mixed-topology shard
 ])
 def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
-    ref, mine, out_r, loss_r, out_m, loss_m = _train_step_pair(pkg, oracle, grids, B, hid, L)
+    ref, mine, out_r, loss_r, out_m, loss_m, flows_m = _train_step_pair(pkg, oracle, grids, B, hid, L)
     assert rel_err(out_m, out_r) < TOL_OUT
     assert abs(loss_m.item() - loss_r.item()) <= TOL_LOSS * abs(loss_r.item())
     # gradients, first against the plain fp32 oracle with NOTHING pinned (1e-4: the oracle's own fp32-vs-fp64 gradient
@@ -248,12 +249,10 @@ def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
     # tools/diag_edge_mfma.py: a 1e-7 change of the outputs moved d loss/d theta of two neighbouring buses by a factor
     # 2.5 and every weight gradient by 3e-5).  Like the conv gates, the branch is pinned to the HIP path's own choice
     # (read from its get_pflow on its own output); everything else stays un-pinned.
-    with torch.no_grad():
-        st_d = tuple(s.to(DEV) for s in b["stats"])
-        yv = torch.cat([out_m[:, 0:1] * st_d[1][:1] + st_d[0][:1], out_m[:, 1:]], 1)
-        fl = pkg.data.get_pflow(yv, ei, x[:, 8:], ea[:, 6:])
-        vhv, vlv = x[:, 8].max(), x[:, 8].min()
-        pins = iter([(fl[6] >= fl[7]).cpu(), (fl[6] * vhv >= fl[7] * vlv).cpu()])
+    # (the loss kernel exports its own I_from / I_to: recomputing them outside would round differently at the ties)
+    vhv, vlv = b["x"][:, 8].max(), b["x"][:, 8].min()
+    i_f, i_t = flows_m[:, 6].cpu(), flows_m[:, 7].cpu()
+    pins = iter([i_f >= i_t, i_f * vhv >= i_t * vlv])
     real_max = torch.maximum
     torch.maximum = lambda a_, b_: torch.where(next(pins), a_, b_)
     try:

@@ -173,3 +173,69 @@ def test_gradient_of_other_consumers_of_the_masked_output(pkg, oracle):
     assert rel_err(gg, gc) < 1e-5
     slack = bc["x"][:, 9] > 0
     assert slack.any() and (gg.cpu()[slack, 1] == 0).all()
+
+
+@pytest.mark.parametrize("feat", [7, 128])
+def test_message_passing_propagate_with_a_user_message(pkg, oracle, feat):
+    """PyG MessagePassing.propagate semantics on the HIP gather / segmented-sum kernels: *_j from the
+    source end, *_i from the target end, other arguments by name, unknown keyword arguments ignored, sum per target.
+    A toy subclass with its own message(), forward and backward, against index ops + index_add_ in fp64."""
+    torch.manual_seed(4)
+    b = pkg.synthetic.make_batch(["cigre14", "cigre14_reswitched"], 11, seed=2)
+    ei, _ = oracle.undirect_graph(b["edge_index"], b["edge_attr"][:, :6])
+    N, E = b["x"].shape[0], ei.shape[1]
+    lin = torch.nn.Linear(5, feat).double()
+
+    def message(x_i, x_j, edge_attr, norm, scale=0.5):
+        return norm.view(-1, 1) * torch.tanh(lin(x_j - x_i)) * edge_attr[:, :3].sum(1, keepdim=True) * scale
+
+    class Toy(pkg.MessagePassing):
+        def __init__(self):
+            super().__init__(aggr="add")
+            self.lin = torch.nn.Linear(5, feat)
+
+        def message(self, x_i, x_j, edge_attr, norm, scale=0.5):
+            return norm.view(-1, 1) * torch.tanh(self.lin(x_j - x_i)) * edge_attr[:, :3].sum(1, keepdim=True) * scale
+
+        def forward(self, x, edge_index, edge_attr, norm):
+            return self.propagate(edge_index, x=x, edge_attr=edge_attr, norm=norm, not_a_message_argument=123)
+
+    toy = Toy()
+    toy.lin.load_state_dict({k: v.float() for k, v in lin.state_dict().items()})
+    toy = toy.to(DEV)
+    x, ea, nrm = torch.randn(N, 5), torch.randn(E, 4), torch.rand(E) + 0.5
+    g = torch.randn(N, feat)
+    xr, ear, nr = (v.double().requires_grad_(True) for v in (x, ea, nrm))
+    out_r = oracle.scatter_sum(message(xr[ei[1]], xr[ei[0]], ear, nr), ei[1], N)
+    out_r.backward(g.double())
+    xm, eam, nm = (v.to(DEV).requires_grad_(True) for v in (x, ea, nrm))
+    out_m = toy(xm, ei.to(DEV), eam, nm)
+    out_m.backward(g.to(DEV))
+    assert rel_err(out_m, out_r) < 1e-5
+    assert rel_err(xm.grad, xr.grad) < 1e-5 and rel_err(eam.grad, ear.grad) < 1e-5 and rel_err(nm.grad, nr.grad) < 1e-5
+    assert rel_err(toy.lin.weight.grad, lin.weight.grad) < 1e-5 and rel_err(toy.lin.bias.grad, lin.bias.grad) < 1e-5
+    out2 = toy(xm, ei.to(DEV), eam, nm)
+    assert torch.equal(out2, out_m)                       # deterministic (no float atomics)
+    base = pkg.MessagePassing()                            # default message(x_j) = x_j: out[i] = sum of the sources' rows
+    agg = base.propagate(ei.to(DEV), x=xm.detach())
+    assert rel_err(agg, oracle.scatter_sum(x.double()[ei[0]], ei[1], N)) < 1e-6
+
+
+def test_edge_aggregation_message_and_propagate_are_the_reference_expression(pkg, oracle):
+    """EdgeAggregation.message() is networks.py:181 and .propagate() runs it through the generic engine; forward() (the fused
+    kernels: aggregate, then the second Linear) must give the same numbers."""
+    torch.manual_seed(6)
+    b = pkg.synthetic.make_batch(["ober_sub"], 3, seed=8)
+    x, ea = b["x"][:, :8], b["edge_attr"][:, :6]
+    ei2, ea2 = oracle.undirect_graph(b["edge_index"], ea)
+    ref = oracle.EdgeAggregation(8, 6, 64, 64).double()
+    mine = pkg.EdgeAggregation(8, 6, 64, 64)
+    mine.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    mine = mine.to(DEV)
+    xd, ed, eid = x.to(DEV).contiguous(), ea2.to(DEV).contiguous(), ei2.to(DEV)
+    out_ref = ref(x.double(), ei2, ea2.double())
+    out_fused = mine(xd, eid, ed)
+    out_prop = mine.propagate(eid, x=xd, edge_attr=ed, norm=torch.ones(ei2.shape[1], device=DEV))   # norm: ignored, as in networks.py:206
+    assert rel_err(out_fused, out_ref) < 1e-5 and rel_err(out_prop, out_ref) < 1e-5
+    msg = mine.message(xd[eid[1]], xd[eid[0]], ed)
+    assert rel_err(msg, ref.edge_aggr(torch.cat([x.double()[ei2[1]], x.double()[ei2[0]], ea2.double()], -1))) < 1e-5
