@@ -34,7 +34,9 @@ class GemmPropArgs(C.Structure):
                 ("rowptr", C.c_void_p), ("col", C.c_void_p), ("w", C.c_void_p),
                 ("max_nnz", C.c_int32), ("ell_width", C.c_int32),
                 ("prop_in", C.c_int32), ("narrow_h", C.c_int32),
-                ("prebias", C.c_void_p), ("pre_rowscale", C.c_void_p), ("ell_tiles", C.c_void_p)]
+                ("prebias", C.c_void_p), ("pre_rowscale", C.c_void_p), ("ell_tiles", C.c_void_p),
+                ("drop_state", C.c_void_p), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float), ("drop_id", C.c_int32),
+                ("pad2_", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -73,7 +75,7 @@ class ReduceDesc(C.Structure):
 
 class ChainLayer(C.Structure):
     _fields_ = [("Bp", C.c_void_p), ("bias", C.c_void_p), ("relu_src", C.c_void_p), ("dmask", C.c_void_p),
-                ("add_src", C.c_void_p), ("prebias", C.c_void_p), ("Y", C.c_void_p), ("relu", C.c_int32), ("pad_", C.c_int32)]
+                ("add_src", C.c_void_p), ("prebias", C.c_void_p), ("Y", C.c_void_p), ("relu", C.c_int32), ("drop_id", C.c_int32)]
 
 
 class CollateDesc(C.Structure):
@@ -119,6 +121,9 @@ _SIGNATURES = {
     "dss2_segment_sum": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                    C.c_int64, C.c_int, C.c_void_p]),
     "dss2_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    "dss2_rng_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
+    "dss2_dropout_mask": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dss2_dropout_params": (None, [C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "dss2_pack_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dss2_edge_hidden_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,

@@ -40,6 +40,36 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 constexpr int kMaxLdsBytes = 160 * 1024;
 
+// ---- in-kernel dropout (nn.Dropout between the TAGConv layers, /root/reference/networks.py:268) ---------------------------
+// Counter-based: the keep/drop decision of element (row, col) of layer `id` is a pure function of (seed, offset, id, row,
+// col), so the forward epilogue and the backward epilogue regenerate the same mask instead of storing and re-reading an
+// [N, H] fp32 tensor per layer.  Philox4x32-10 (Salmon et al., SC'11), one call per 4 consecutive columns.
+struct DropSpec {            // by value inside the kernel argument structs
+  const uint64_t* state;     // device {seed, offset} snapshot of this forward call (dss2_rng_next), or NULL = no dropout
+  uint32_t thr;              // keep iff random uint32 >= thr  (thr = p * 2^32)
+  float scale;               // 1 / (1 - p)  (0 for p >= 1: everything is dropped)
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// multipliers (0 or scale) of columns 4*cgroup .. 4*cgroup+3 of `row` in the mask of layer `id`
+__device__ __forceinline__ f32x4 dropout_mult4(uint64_t seed, uint64_t offset, uint32_t id, uint32_t row, uint32_t cgroup,
+                                               uint32_t thr, float scale) {
+  uint32_t r[4];
+  philox4x32_10(row, cgroup, id, (uint32_t)offset, (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32), r);
+  return f32x4{r[0] >= thr ? scale : 0.f, r[1] >= thr ? scale : 0.f, r[2] >= thr ? scale : 0.f, r[3] >= thr ? scale : 0.f};
+}
+
 // Opt a kernel into > 64 KB of dynamic LDS, once per (kernel, device): `done` is the kernel's own bitmask of the devices
 // that already have the attribute (the attribute belongs to the device's code object, and the autograd thread may
 // launch beside the main thread, hence the atomic).  A process that drives several GPUs sets it on each of them.

@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
   const int nw = nthreads >> 6;
   const int LDX = p.kpad + 4;
   const int tile = blockIdx.x;
+  const uint64_t drop_seed = p.drop_state ? p.drop_state[0] : 0, drop_off = p.drop_state ? p.drop_state[1] : 0;
   float* Xs = smem;
   float* stage = Xs + TM * LDX;
   const int D = p.ell_width;
@@ -204,6 +205,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
             for (int m = 0; m < NMAT; ++m) v += pb4[m] * ps[u][m];
           }
           if (L.dmask) v *= dm[u];
+          if (L.drop_id) v *= dropout_mult4(drop_seed, drop_off, (uint32_t)L.drop_id, (uint32_t)(ts + row), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
           if (L.relu & 1) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
@@ -278,6 +280,7 @@ extern "C" int dss2_gemm_prop_chain(const dss2_gemm_prop_args* ap, const dss2_ch
       set_error("gemm_prop_chain: layer %d has a missing or misaligned operand", i); return 2;
     }
     any_pre = any_pre || L.prebias;
+    if (L.drop_id && !a.drop_state) { set_error("gemm_prop_chain: layer %d asks for in-kernel dropout without drop_state", i); return 2; }
     ct.l[i] = L;
   }
   if (any_pre && !a.pre_rowscale) { set_error("gemm_prop_chain: prebias needs pre_rowscale"); return 2; }

@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   const bool khalf = ((p.relu >> 24) & 1) != 0;
   const int LDX = (khalf ? (p.kpad >> 1) : p.kpad) + 4;
   const int tile = blockIdx.x;
+  const uint64_t drop_seed = p.drop_id ? p.drop_state[0] : 0, drop_off = p.drop_id ? p.drop_state[1] : 0;   // uniform scalar loads
   int stamp_tile = tile; (void)stamp_tile;
   DSS2_STAMP(0);
   const int dbg = (p.relu >> 8) & 0xff;   // diagnostics only (tools/ablate.py): 1 no MFMA, 2 no Horner, 4 no stores, 8 no X staging
@@ -475,6 +476,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
               for (int m = 0; m < NMAT; ++m) v += pb4[m] * ps[u][m];
             }
             if (p.dmask) v *= dm[u];
+            if (p.drop_id) v *= dropout_mult4(drop_seed, drop_off, (uint32_t)p.drop_id, (uint32_t)(ts + row), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
             if (p.relu & 1) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
@@ -501,6 +503,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
             for (int m = 0; m < NMAT; ++m) y = fmaf(p.prebias[(size_t)m * p.hout + colg], p.pre_rowscale[grow * 4 + m], y);
           }
           if (p.dmask) y *= p.dmask[grow * p.ld_dmask + colg];
+          if (p.drop_id) y *= dropout_mult4(drop_seed, drop_off, (uint32_t)p.drop_id, (uint32_t)grow, (uint32_t)(colg >> 2), p.drop_thr, p.drop_scale)[colg & 3];
           if (p.relu & 1) y = fmaxf(y, 0.f);
           if (p.relu_src) y = (p.relu_src[grow * p.ld_relu + colg] > 0.f) ? y : 0.f;
           if (p.add_src) y += p.add_src[grow * p.ld_add + colg];
@@ -859,6 +862,7 @@ extern "C" int dss2_gemm_prop(const dss2_gemm_prop_args* ap, void* stream) {
   if ((a.nmat > 1 || a.prop_in > 0) && (!a.rowptr || !a.col || !a.w)) { set_error("gemm_prop: propagation needs a CSR"); return 2; }
   if (a.prop_in > 0 && (a.nmat != 1 || a.kreal % (a.prop_in + 1) != 0)) { set_error("gemm_prop: prop_in needs nmat == 1 and kreal divisible by prop_in+1"); return 2; }
   if (a.prebias && (!a.pre_rowscale || a.narrow_h > 0 || a.prop_in > 0)) { set_error("gemm_prop: prebias needs pre_rowscale and the general kernel"); return 2; }
+  if (a.drop_id && (!a.drop_state || a.narrow_h > 0)) { set_error("gemm_prop: in-kernel dropout needs drop_state and the general kernel"); return 2; }
   if (a.narrow_h > 0) {
     if (a.nmat * a.narrow_h > 32 || a.hout != a.narrow_h || a.prop_in) { set_error("gemm_prop: narrow mode needs nmat*narrow_h <= 32 and hout == narrow_h"); return 2; }
     if (narrow_lds_bytes(a.nrb, a.nmat, a.kpad, a.max_nnz, a.ell_width) > (size_t)kMaxLdsBytes) { set_error("gemm_prop(narrow): tile does not fit LDS"); return 3; }
@@ -877,7 +881,6 @@ extern "C" int dss2_gemm_prop(const dss2_gemm_prop_args* ap, void* stream) {
       case 3: return launch_narrow<3>(a, sn);
       case 4: return launch_narrow<4>(a, sn);
       case 6: return launch_narrow<6>(a, sn);
-      case 8: return launch_narrow<8>(a, sn);
       default: set_error("gemm_prop(narrow): unsupported nrb=%d", a.nrb); return 2;
     }
   }
@@ -895,8 +898,7 @@ extern "C" int dss2_gemm_prop(const dss2_gemm_prop_args* ap, void* stream) {
   DSS2_CASE(3, 1) DSS2_CASE(3, 2) DSS2_CASE(3, 3) DSS2_CASE(3, 4)
   DSS2_CASE(4, 1) DSS2_CASE(4, 2) DSS2_CASE(4, 3) DSS2_CASE(4, 4)
   DSS2_CASE(6, 1) DSS2_CASE(6, 2) DSS2_CASE(6, 3) DSS2_CASE(6, 4)
-  DSS2_CASE(8, 1) DSS2_CASE(8, 2) DSS2_CASE(8, 3)
 #undef DSS2_CASE
-  set_error("gemm_prop: unsupported (nrb=%d, nmat=%d); nrb in {1,2,3,4,6,8}, nmat in 1..4, nrb*nmat <= 24", a.nrb, a.nmat);
+  set_error("gemm_prop: unsupported (nrb=%d, nmat=%d); nrb in {1,2,3,4,6}, nmat in 1..4", a.nrb, a.nmat);
   return 2;
 }

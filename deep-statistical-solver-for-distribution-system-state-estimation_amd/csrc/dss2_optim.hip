@@ -138,3 +138,59 @@ extern "C" int dss2_adamax_step(const dss2_adamax_desc* descs, int n_desc, int64
                      beta1, beta2, eps, weight_decay, bc1);
   return dss2::check_launch("adamax_step");
 }
+
+
+// ---- dropout random state (see dss2_hip.h) -------------------------------------------------------------------------------
+namespace dss2 {
+__global__ void rng_next_kernel(unsigned long long* __restrict__ state, unsigned long long* __restrict__ snap,
+                                unsigned long long host_seed, int use_host_seed) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (use_host_seed) { snap[0] = host_seed; snap[1] = 0; }
+  else { snap[0] = state[0]; snap[1] = state[1]; state[1] = state[1] + 1; }
+}
+
+__global__ void __launch_bounds__(256) dropout_mask_kernel(const uint64_t* __restrict__ snap, uint32_t id, uint32_t thr, float scale,
+                                                           int64_t n_rows, int h, float* __restrict__ out, int64_t ldo) {
+  const uint64_t seed = snap[0], off = snap[1];
+  const int groups = (h + 3) >> 2;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_rows * groups; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / groups;
+    const int g = (int)(t - row * groups);
+    const f32x4 m = dropout_mult4(seed, off, id, (uint32_t)row, (uint32_t)g, thr, scale);
+    for (int q = 0; q < 4; ++q)
+      if (4 * g + q < h) out[row * ldo + 4 * g + q] = m[q];
+  }
+}
+}  // namespace dss2
+
+extern "C" int dss2_rng_next(uint64_t* state, uint64_t* snapshot, uint64_t host_seed, int use_host_seed, void* stream) {
+  if (!snapshot || (!use_host_seed && !state)) { dss2::set_error("rng_next: null argument"); return 2; }
+  hipLaunchKernelGGL(dss2::rng_next_kernel, dim3(1), dim3(64), 0, dss2::as_stream(stream),
+                     reinterpret_cast<unsigned long long*>(state), reinterpret_cast<unsigned long long*>(snapshot),
+                     (unsigned long long)host_seed, use_host_seed);
+  return dss2::check_launch("rng_next");
+}
+
+// p -> (threshold, scale) exactly as the Python side computes them for the kernels (one definition: this one)
+extern "C" void dss2_dropout_params(float p, uint32_t* thr, float* scale) {
+  if (p <= 0.f) { *thr = 0u; *scale = 1.f; }
+  else if (p >= 1.f) { *thr = 0u; *scale = 0.f; }
+  else {
+    const double t = (double)p * 4294967296.0;
+    *thr = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+    *scale = 1.f / (1.f - p);
+  }
+}
+
+extern "C" int dss2_dropout_mask(const uint64_t* snapshot, int32_t drop_id, float p, int64_t n_rows, int h, float* out,
+                                 int64_t ldo, void* stream) {
+  if (!snapshot || !out || drop_id <= 0 || h <= 0) { dss2::set_error("dropout_mask: bad arguments"); return 2; }
+  if (n_rows <= 0) return 0;
+  uint32_t thr; float scale;
+  dss2_dropout_params(p, &thr, &scale);
+  int64_t blocks = (n_rows * ((h + 3) / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dss2::dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, dss2::as_stream(stream), snapshot,
+                     (uint32_t)drop_id, thr, scale, n_rows, h, out, ldo);
+  return dss2::check_launch("dropout_mask");
+}

@@ -75,8 +75,12 @@ def _ncg(j: int) -> int:
 def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.Tensor, nmat: int, hout: int,
               Y: torch.Tensor, bias=None, rowscale=None, relu_src=None, dmask=None, add_src=None, add_ld=0,
               relu: bool = False, transposed: bool = False, prop_in: int = 0, narrow_h: int = 0,
-              prebias=None, pre_rowscale=None) -> None:
+              prebias=None, pre_rowscale=None, drop=None) -> None:
+    """drop = (snapshot, p, drop_id): in-kernel dropout mask of layer drop_id (see dropout_snapshot)."""
     a = _lib.GemmPropArgs()
+    if drop is not None and drop[2] > 0:
+        a.drop_state, a.drop_id = drop[0].data_ptr(), int(drop[2])
+        a.drop_thr, a.drop_scale = _dropout_params(drop[1])
     a.prebias, a.pre_rowscale = _ptr(prebias), _ptr(pre_rowscale)
     a.prop_in, a.narrow_h = prop_in, narrow_h
     a.X, a.ldx, a.kreal, a.kpad = X.data_ptr(), ldx, kreal, _round8(kreal)
@@ -107,16 +111,19 @@ def chain_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bo
 
 
 def gemm_prop_chain(topo: Topology, X: torch.Tensor, hid: int, nmat: int, layers: Sequence[dict], transposed: bool = False,
-                    pre_rowscale=None) -> None:
+                    pre_rowscale=None, drop=None) -> None:
     """layers: dicts with Bp, Y and optionally bias, relu, relu_src, dmask, prebias; every tensor is [N, hid]
     contiguous.  Layer i reads layer i-1's output from LDS; every Y is written once.  The library chains at most
     CHAIN_MAX layers per launch; deeper stacks run as consecutive launches (the next one reads the previous one's last Y)."""
     if len(layers) > CHAIN_MAX:
         for c0 in range(0, len(layers), CHAIN_MAX):
             gemm_prop_chain(topo, X if c0 == 0 else layers[c0 - 1]["Y"], hid, nmat, layers[c0:c0 + CHAIN_MAX],
-                            transposed=transposed, pre_rowscale=pre_rowscale)
+                            transposed=transposed, pre_rowscale=pre_rowscale, drop=drop)
         return
     a = _lib.GemmPropArgs()
+    if drop is not None:            # (snapshot, p); the layers name their masks with "drop_id"
+        a.drop_state = drop[0].data_ptr()
+        a.drop_thr, a.drop_scale = _dropout_params(drop[1])
     a.X, a.ldx, a.kreal, a.kpad = X.data_ptr(), X.stride(0), hid, _round8(hid)
     a.hout, a.ncg, a.ldy, a.ld_relu, a.ld_dmask, a.ld_add = hid, _ncg(hid), hid, hid, hid, hid
     a.nmat, a.nrb, a.ntiles = nmat, topo.nrb, topo.ntiles
@@ -136,6 +143,7 @@ def gemm_prop_chain(topo: Topology, X: torch.Tensor, hid: int, nmat: int, layers
         d.Bp, d.Y, d.bias = ly["Bp"].data_ptr(), ly["Y"].data_ptr(), _ptr(ly.get("bias"))
         d.relu_src, d.dmask, d.prebias = _ptr(ly.get("relu_src")), _ptr(ly.get("dmask")), _ptr(ly.get("prebias"))
         d.relu = int(bool(ly.get("relu", False)))
+        d.drop_id = int(ly.get("drop_id", 0)) if drop is not None else 0
     _lib.check(_lib.lib().dss2_gemm_prop_chain(C.byref(a), C.addressof(tab), len(layers), _stream(X)), "dss2_gemm_prop_chain")
 
 
@@ -500,11 +508,52 @@ def _dx_views(W1, hid, fn, fe):
 
 
 def _tagconv_forward(topo, h, pack_fwd, bias, nmat, hin, hout, dmask=None, relu=False, add_src=None, add_ld=0,
-                     prebias=None, pre_rowscale=None):
+                     prebias=None, pre_rowscale=None, drop=None):
     out = torch.empty(topo.N, hout, dtype=_F32, device=h.device)
+    narrow = is_narrow(nmat, hout) and prebias is None and (drop is None or drop[2] == 0)
     gemm_prop(topo, h, h.stride(0), hin, pack_fwd, nmat, hout, out, bias=bias, dmask=dmask, relu=relu,
-              add_src=add_src, add_ld=add_ld, narrow_h=(hout if (is_narrow(nmat, hout) and prebias is None) else 0),
-              prebias=prebias, pre_rowscale=pre_rowscale)
+              add_src=add_src, add_ld=add_ld, narrow_h=(hout if narrow else 0),
+              prebias=prebias, pre_rowscale=pre_rowscale, drop=drop)
+    return out
+
+
+_DROP_PARAMS = {}
+
+
+def _dropout_params(p: float):
+    """(threshold, scale) of a dropout rate: keep iff Philox uint32 >= threshold (dss2_dropout_params)."""
+    v = _DROP_PARAMS.get(p)
+    if v is None:
+        thr, sc = C.c_uint32(), C.c_float()
+        _lib.lib().dss2_dropout_params(float(p), C.byref(thr), C.byref(sc))
+        v = _DROP_PARAMS[p] = (thr.value, sc.value)
+    return v
+
+
+def dropout_snapshot(mod: nn.Module, device) -> torch.Tensor:
+    """The {seed, offset} pair (device int64[2]) the kernels of ONE forward call and its backward read to regenerate
+    their dropout masks (nn.Dropout, networks.py:268, without storing [N, H] masks).  Eager: the seed is drawn from
+    torch's CPU generator (as nn.Dropout consumes torch's generator in the reference), so ``torch.manual_seed``
+    reproduces a run.  Inside a hipGraph capture a by-value seed would be frozen into the graph, so the module's
+    device-side state is used and advanced by the captured kernel itself: every replay sees fresh masks."""
+    st = getattr(mod, "_rng_state", None)
+    if st is None or st.device != device:
+        seed0 = int(torch.empty((), dtype=torch.int64).random_().item())
+        st = mod._rng_state = torch.tensor([seed0, 0], dtype=torch.int64).to(device)
+    snap = torch.empty(2, dtype=torch.int64, device=device)
+    host_seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    capturing = torch.cuda.is_current_stream_capturing()
+    _lib.check(_lib.lib().dss2_rng_next(st.data_ptr(), snap.data_ptr(), host_seed, int(not capturing),
+                                        torch.cuda.current_stream(device).cuda_stream), "dss2_rng_next")
+    return snap
+
+
+def dropout_mask(snapshot: torch.Tensor, p: float, drop_id: int, n_rows: int, h: int) -> torch.Tensor:
+    """The [n_rows, h] multipliers (0 or 1/(1-p)) the kernels apply for layer mask ``drop_id`` of that forward call
+    (dss2_dropout_mask): lets a test hand the very same masks to the CPU oracle."""
+    out = torch.empty(n_rows, h, dtype=_F32, device=snapshot.device)
+    _lib.check(_lib.lib().dss2_dropout_mask(snapshot.data_ptr(), drop_id, float(p), n_rows, h, out.data_ptr(), h,
+                                            torch.cuda.current_stream(snapshot.device).cuda_stream), "dss2_dropout_mask")
     return out
 
 
@@ -524,7 +573,7 @@ def _side_stream(device):
 
 
 def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=None, dmask=None, need_dh=True,
-                      rowscale2=None, defer_wgrad=False, pending=None):
+                      rowscale2=None, defer_wgrad=False, pending=None, drop=None):
     """g: gradient w.r.t. the conv's pre-activation output [N, hout] (already masked).
     g_flat <- [dW_0..dW_K, db]; returns dh (masked by relu_src / dmask of the PREVIOUS layer).
     The weight gradient only feeds the flat gradient buffer, so it may run on a side stream beside the
@@ -549,9 +598,10 @@ def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=No
     dh = torch.empty(topo.N, hin, dtype=_F32, device=g.device)
     if is_narrow(nmat, hout) and rowscale2 is None:   # narrow gradient rows: propagate g on the input side, one stacked GEMM
         gemm_prop(topo, g, g.stride(0), nmat * hout, pack_bwd, 1, hin, dh, relu_src=relu_src, dmask=dmask,
-                  transposed=True, prop_in=nmat - 1)
+                  transposed=True, prop_in=nmat - 1, drop=drop)
     else:
-        gemm_prop(topo, g, g.stride(0), hout, pack_bwd, nmat, hin, dh, relu_src=relu_src, dmask=dmask, transposed=True)
+        gemm_prop(topo, g, g.stride(0), hout, pack_bwd, nmat, hin, dh, relu_src=relu_src, dmask=dmask, transposed=True,
+                  drop=drop)
     return dh
 
 
@@ -858,54 +908,52 @@ class _MPNFn(torch.autograd.Function):
                                   second_linear=fold is None)
         if fold is not None:
             h = S            # conv 0 consumes the aggregated hidden directly
-        acts, masks = [h], []
+        acts = [h]
         p = float(mod.dropout_rate)
+        # dropout is active regardless of .training (a fresh nn.Dropout is built inside forward, networks.py:268).  The
+        # masks are not tensors: the epilogues regenerate them from (snapshot, layer id) in forward and backward.
+        snap = dropout_snapshot(mod, dev) if p > 0.0 else None
+        mod._last_dropout = (snap, p)
 
-        def drop_mask(hout):   # dropout is active regardless of .training (networks.py:268)
-            if p <= 0.0:
-                return None
-            return (torch.rand(topo.N, hout, device=dev) >= p).to(_F32).div_(1.0 - p) if p < 1.0 else \
-                torch.zeros(topo.N, hout, device=dev)
+        def drop_id(l):            # mask applied to conv l's output (none after the last conv)
+            return l + 1 if (snap is not None and l < L - 1) else 0
 
         # the hid -> hid layers 0 .. L-2 as ONE chained launch (activation tile stays in LDS between layers)
         n_chain = L - 1 if (L - 1 >= 2 and chain_supported(topo, nmat, hid, False)) else 0
         if n_chain:
             layers = []
             for l in range(n_chain):
-                masks.append(drop_mask(hid))
                 out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
-                layers.append(dict(Bp=plan.fwd[1 + l], Y=out_l, bias=conv_ps[l][0], relu=True, dmask=masks[l],
+                layers.append(dict(Bp=plan.fwd[1 + l], Y=out_l, bias=conv_ps[l][0], relu=True, drop_id=drop_id(l),
                                    prebias=(fold.bf if (fold is not None and l == 0) else None)))
                 acts.append(out_l)
-            gemm_prop_chain(topo, h, hid, nmat, layers, pre_rowscale=(topo.deg_pows if fold is not None else None))
+            gemm_prop_chain(topo, h, hid, nmat, layers, pre_rowscale=(topo.deg_pows if fold is not None else None),
+                            drop=((snap, p) if snap is not None else None))
             h = acts[-1]
         for l in range(n_chain, L):
             last = l == L - 1
             hout = mod.dim_out if last else hid
-            dmask = None if last else drop_mask(hout)
-            masks.append(dmask)
             pre = (fold.bf, topo.deg_pows) if (fold is not None and l == 0) else (None, None)
-            h = _tagconv_forward(topo, h, plan.fwd[1 + l], conv_ps[l][0], nmat, hid, hout, dmask=dmask, relu=not last,
+            h = _tagconv_forward(topo, h, plan.fwd[1 + l], conv_ps[l][0], nmat, hid, hout, relu=not last,
                                  add_src=(x if (last and mod.skip) else None), add_ld=ldx,
-                                 prebias=pre[0], pre_rowscale=pre[1])
+                                 prebias=pre[0], pre_rowscale=pre[1],
+                                 drop=((snap, p, drop_id(l)) if snap is not None else None))
             if not last:
                 acts.append(h)
-        ctx.save_for_backward(x, ea, S, *acts, *[m for m in masks if m is not None], *ps)
-        ctx.meta = (topo, mod, ldx, ldea, len(acts), [m is not None for m in masks], fold is not None)
+        ctx.save_for_backward(x, ea, S, *acts, *ps)
+        ctx.meta = (topo, mod, ldx, ldea, len(acts), (snap, p), fold is not None)
         return h
 
     @staticmethod
     def backward(ctx, gout):
-        topo, mod, ldx, ldea, n_acts, has_mask, folded = ctx.meta
+        topo, mod, ldx, ldea, n_acts, (snap, p_drop), folded = ctx.meta
         saved = ctx.saved_tensors
         x, ea, S = saved[0:3]
         acts = list(saved[3:3 + n_acts])
-        n_masks = sum(has_mask)
-        mask_list = list(saved[3 + n_acts:3 + n_acts + n_masks])
-        ps = saved[3 + n_acts + n_masks:]
-        masks, it = [], iter(mask_list)
-        for hm in has_mask:
-            masks.append(next(it) if hm else None)
+        ps = saved[3 + n_acts:]
+
+        def drop_of(l):            # the mask that was applied to conv l's output: (snapshot, p, id) or None
+            return (snap, p_drop, l + 1) if snap is not None else None
         plan, fold = mod._plan, mod._fold
         if folded != (fold is not None):
             raise RuntimeError("DSS2_FOLD_W2 / the module's plan changed between forward and backward")
@@ -931,17 +979,17 @@ class _MPNFn(torch.autograd.Function):
             pending = []
             l = L - 1
             g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, mod.dim_out, flat[offs[2 + l]:offs[3 + l]],
-                                  relu_src=acts[l], dmask=masks[l - 1], pending=pending)
+                                  relu_src=acts[l], drop=drop_of(l - 1), pending=pending)
             gl = [None] * (L - 1)                   # gl[l]: gradient w.r.t. layer l's pre-activation output
             gl[L - 2] = g
             layers = []
             for l in range(L - 2, -1, -1):
                 out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
                 layers.append(dict(Bp=plan.bwd[1 + l], Y=out_l, relu_src=(acts[l] if l > 0 else None),
-                                   dmask=(masks[l - 1] if l > 0 else None)))
+                                   drop_id=(l if (l > 0 and snap is not None) else 0)))      # mask of conv l-1: id (l-1)+1
                 if l > 0:
                     gl[l - 1] = out_l
-            gemm_prop_chain(topo, g, hid, nmat, layers, transposed=True)
+            gemm_prop_chain(topo, g, hid, nmat, layers, transposed=True, drop=((snap, p_drop) if snap is not None else None))
             d_in = layers[-1]["Y"]                  # gradient w.r.t. conv 0's input: dS (folded) or dx0
             # (joining conv 0 pays only when the tiles still divide evenly over the workgroups the layers share:
             #  at C2 three layers x 85 workgroups leave a 13-vs-12-tile tail that costs more than the launch saves)
@@ -983,7 +1031,7 @@ class _MPNFn(torch.autograd.Function):
             if defer:
                 deferred.append((l, g, acts[l]))
             g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, hout, seg,
-                                  relu_src=(acts[l] if l > 0 else None), dmask=(masks[l - 1] if l > 0 else None),
+                                  relu_src=(acts[l] if l > 0 else None), drop=(drop_of(l - 1) if l > 0 else None),
                                   defer_wgrad=defer)
         # weight gradients of the hid -> hid layers: independent of each other, so one launch (and one slab
         # reduction) covers up to 8 consecutive layers; their segments in the flat buffer are contiguous

@@ -265,10 +265,10 @@ def register_topology(edge_index: torch.Tensor, num_nodes: int, topo: Topology, 
         _last.pop(next(iter(_last)))
     key = (id(edge_index), _mode(double))
 
-    def _drop(ref, key=key):            # the tensor died: release its structure (device arrays) with it
-        hit = _last.get(key)
+    def _drop(ref, key=key, table=_last):   # the tensor died: release its structure (device arrays) with it
+        hit = table.get(key)
         if hit is not None and hit[0] is ref:
-            _last.pop(key, None)
+            table.pop(key, None)
     _last[key] = (weakref.ref(edge_index, _drop), edge_index._version, edge_index.data_ptr(), int(num_nodes), topo)
     return topo
 

@@ -212,6 +212,12 @@ typedef struct dss2_gemm_prop_args {
                                     * topology, int2 {local src, weight bits}[ntiles]        *
                                     * [ell_width][32*nrb] (rows >= tile rows: {row, 0});      *
                                     * NULL: the kernel derives the slice from the CSR         */
+  /* in-kernel dropout (nn.Dropout of networks.py:268, regenerated instead of stored): drop_state = device {seed,   *
+   * offset} of this forward call (dss2_rng_next) or NULL; the epilogue multiplies element (row, col) by 0 or       *
+   * drop_scale = 1/(1-p) according to Philox4x32-10(seed, offset, drop_id, row, col/4) >= drop_thr = p * 2^32,     *
+   * where drop_id > 0 names the layer whose mask this is (0: no dropout; in a chain: per layer).  Applied where     *
+   * `dmask` (an explicit [N, hout] multiplier tensor, still supported) is applied.                                 */
+  const uint64_t* drop_state; uint32_t drop_thr; float drop_scale; int32_t drop_id; int32_t pad2_;
 } dss2_gemm_prop_args;
 
 int dss2_gemm_prop(const dss2_gemm_prop_args* args_host, void* stream);
@@ -227,10 +233,22 @@ int dss2_gemm_prop(const dss2_gemm_prop_args* args_host, void* stream);
  *      16-byte aligned operands); otherwise call dss2_gemm_prop per layer.                                          */
 typedef struct dss2_chain_layer {
   const float* Bp; const float* bias; const float* relu_src; const float* dmask; const float* add_src;
-  const float* prebias; float* Y; int32_t relu; int32_t pad_;
+  const float* prebias; float* Y; int32_t relu; int32_t drop_id;   /* drop_id: as in dss2_gemm_prop_args, per layer */
 } dss2_chain_layer;
 int dss2_gemm_prop_chain(const dss2_gemm_prop_args* args_host, const dss2_chain_layer* layers_host, int n_layers, void* stream);
 int dss2_gemm_prop_chain_supported(int nrb, int nmat, int kreal, int hout, int ell_width);
+
+/* ---- dropout random state.  state[2] = persistent device {seed, offset}; snapshot[2] <- the pair this forward call's
+ * kernels (forward AND backward) read.  use_host_seed != 0: snapshot = {host_seed, 0} (eager mode: the host draws the seed
+ * from torch's generator, so torch.manual_seed reproduces); 0: snapshot = {state.seed, state.offset++} (inside a hipGraph
+ * capture, where a by-value seed would be frozen into the graph: every replay advances the device-side offset). */
+int dss2_rng_next(uint64_t* state, uint64_t* snapshot, uint64_t host_seed, int use_host_seed, void* stream);
+/* the mask a kernel with (snapshot, drop_id, p) applies, written out as [n_rows, h] multipliers (0 or 1/(1-p)): lets a
+ * test feed the very same mask to the CPU oracle. */
+int dss2_dropout_mask(const uint64_t* snapshot, int32_t drop_id, float p, int64_t n_rows, int h, float* out, int64_t ldo,
+                      void* stream);
+/* host helper: drop_thr / drop_scale for a dropout rate p (the one definition both sides use) */
+void dss2_dropout_params(float p, uint32_t* thr, float* scale);
 
 /* ---- K4: weight gradient of TAGConv / Linear -------------------------------------------- *
  * dW_m[o,i] = sum_n (P^m G)[n,o] * X[n,i]   (P = A_hat^T via the CSR by source), m < nmat,

@@ -28,10 +28,15 @@ def _child(mode):
                           text=True, timeout=900)
 
 
+def _result(p):
+    """the child's JSON line (RCCL prints its own lines after it at teardown)"""
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+
+
 def test_rccl_world1_step_is_bitwise_the_non_distributed_step():
     p = _child("eager")
     assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-4000:]
-    res = json.loads(p.stdout.strip().splitlines()[-1])
+    res = _result(p)
     assert res["backend"] == "nccl" and res["world"] == 1
     mpn, pfn = res["cases"]["MPN_C2_model"], res["cases"]["SkipPFN_5_blocks"]
     assert mpn["hooks_attached"] == 1 and mpn["grad_allreduces_per_step"] == 1 and mpn["bucket_elems"] == [168066]
@@ -49,7 +54,7 @@ def test_rccl_collectives_inside_hipgraph_capture():
     p = _child("graph")
     outcome = {"returncode": p.returncode}
     if p.returncode == 0:
-        res = json.loads(p.stdout.strip().splitlines()[-1])
+        res = _result(p)
         for c in res["cases"].values():
             assert c["graph_capture"] == "ok" and c["graph_bitwise"], c
         outcome["cases"] = res["cases"]

@@ -239,3 +239,90 @@ def test_edge_aggregation_message_and_propagate_are_the_reference_expression(pkg
     assert rel_err(out_fused, out_ref) < 1e-5 and rel_err(out_prop, out_ref) < 1e-5
     msg = mine.message(xd[eid[1]], xd[eid[0]], ed)
     assert rel_err(msg, ref.edge_aggr(torch.cat([x.double()[ei2[1]], x.double()[ei2[0]], ea2.double()], -1))) < 1e-5
+
+
+def _export_masks(pkg, block, n_rows, hid):
+    snap, p = block._last_dropout
+    return [pkg.networks.dropout_mask(snap, p, l + 1, n_rows, hid).cpu() for l in range(block.n_gnn_layers - 1)]
+
+
+@pytest.mark.parametrize("cls,args,grids,B", [
+    ("MPN", (8, 6, 2, 32, 4, 2, 0.3), ["cigre14"], 64),                        # chained layers, H = 32
+    ("MPN", (8, 6, 2, 128, 4, 2, 0.3), ["cigre14", "cigre14_reswitched"], 96),   # C2's model with the driver's dropout rate
+    ("MPN", (8, 6, 2, 64, 2, 2, 0.5), ["ober_sub"], 6),                        # single hidden layer (no chain), 96-row tiles
+    ("SkipPFN", (8, 6, 2, 32, 3, 2, 0.3, 3), ["cigre14"], 48),                 # the driver's model line, small
+])
+def test_in_kernel_dropout_matches_the_oracle_on_the_same_masks(pkg, oracle, cls, args, grids, B):
+    """dropout_rate > 0 (the reference driver runs 0.3, dss2_run.py:80): the masks are regenerated inside the forward and
+    backward epilogues (Philox, no [N, H] mask tensors).  The oracle consumes the very masks the kernels applied
+    (dss2_dropout_mask); outputs, loss and every gradient must then agree like in the p = 0 tests."""
+    torch.manual_seed(0)
+    b = pkg.synthetic.make_batch(grids, B, seed=6)
+    ref = getattr(oracle, cls)(*args).double()
+    mine = getattr(pkg, cls)(*args)
+    mine.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    mine = mine.to(DEV)
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    st = tuple(s.to(DEV) for s in b["stats"])
+    torch.manual_seed(123)
+    out = mine(x[:, :8], ei, ea[:, :6])
+    out_pre = out.detach().clone()                 # (the loss masks theta in place later)
+    blocks_m = list(mine.mpns) if hasattr(mine, "mpns") else [mine]
+    blocks_r = list(ref.mpns) if hasattr(ref, "mpns") else [ref]
+    N, hid, p = x.shape[0], args[3], args[6]
+    for bm, br in zip(blocks_m, blocks_r):
+        br.dropout_masks = _export_masks(pkg, bm, N, hid)
+        for m in br.dropout_masks:
+            vals = set(torch.unique(m).tolist())
+            assert vals <= {0.0, float(torch.tensor(1.0 / (1.0 - p), dtype=torch.float32))}
+            assert abs((m == 0).float().mean().item() - p) < 0.02          # the rate is what was asked for
+    masks = [m for br in blocks_r for m in br.dropout_masks]
+    assert all(not torch.equal(masks[0], m) for m in masks[1:])              # every layer / block has its own mask
+    loss = pkg.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2],
+                            edge_std=st[3], edge_index=ei, reg_coefs=oracle.DEFAULT_REG_COEFS, num_samples=None,
+                            node_param=x[:, 8:], edge_param=ea[:, 6:])
+    loss.backward()
+    b64 = {"x": b["x"].double(), "edge_index": b["edge_index"], "edge_attr": b["edge_attr"].double()}
+    out64, l64 = oracle.train_step(ref, b64, tuple(s.double() for s in b["stats"]))
+    assert rel_err(out, out64) < 1e-5
+    assert abs(loss.item() - l64.item()) <= 1e-5 * abs(l64.item())
+    for (n, q), (_, r) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert rel_err(q.grad, r.grad) < 1e-4, n
+    # same torch seed -> same masks (bitwise the same output); another draw -> other masks
+    torch.manual_seed(123)
+    out2 = mine(x[:, :8], ei, ea[:, :6])
+    out3 = mine(x[:, :8], ei, ea[:, :6])
+    assert torch.equal(out2.detach(), out_pre) and not torch.equal(out3.detach(), out2.detach())
+
+
+def test_in_kernel_dropout_inside_a_hipgraph_draws_new_masks_per_replay(pkg, oracle):
+    torch.manual_seed(0)
+    b = pkg.synthetic.make_batch(["cigre14"], 64, seed=2)
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    model = pkg.MPN(8, 6, 2, 32, 3, 2, 0.3).to(DEV)
+    outs = []
+
+    def step():
+        for q in model.parameters():
+            q.grad = None
+        out = model(x[:, :8], ei, ea[:, :6])
+        out.square().mean().backward()
+        return out
+
+    gs = pkg.graphs.GraphedStep(step)
+    for _ in range(3):
+        o = gs.replay()
+        snap, p = model._last_dropout
+        outs.append((o.detach().clone(), snap.clone(), model.convs[0].bias.grad.clone()))
+    torch.cuda.synchronize()
+    assert not torch.equal(outs[0][0], outs[1][0]) and not torch.equal(outs[1][0], outs[2][0])
+    offs = [int(s[1][1]) for s in outs]
+    assert offs[1] == offs[0] + 1 and offs[2] == offs[1] + 1                # the captured kernel advances the device-side offset
+    # forward and backward of one replay used the same masks: the replayed gradient equals an eager step on those masks
+    m_last = [pkg.networks.dropout_mask(outs[2][1], 0.3, l + 1, x.shape[0], 32).cpu() for l in range(2)]
+    ref = oracle.MPN(8, 6, 2, 32, 3, 2, 0.3).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in model.state_dict().items()})
+    ref.dropout_masks = m_last
+    o64 = ref(b["x"][:, :8].double(), b["edge_index"], b["edge_attr"][:, :6].double())
+    o64.square().mean().backward()
+    assert rel_err(outs[2][0], o64) < 1e-5 and rel_err(outs[2][2], ref.convs[0].bias.grad) < 1e-4

@@ -66,6 +66,33 @@ def main():
                     grads={n: p.grad.clone() for n, p in mine.named_parameters()})
 
     a, m = run(False), run(True)
+    # ---- HIP's d loss / d output against the fp64 oracle's, both evaluated at the HIP (MFMA forward) output
+    o64 = m["out"].double().cpu().requires_grad_(True)
+    x64, ea64 = b["x"].double(), b["edge_attr"].double()
+    st64 = tuple(s.double() for s in b["stats"])
+    l64 = oracle.gsp_wls_edge(input=x64[:, :8], edge_input=ea64[:, :6], output=o64 * 1.0, x_mean=st64[0], x_std=st64[1],
+                              edge_mean=st64[2], edge_std=st64[3], edge_index=b["edge_index"], reg_coefs=oracle.DEFAULT_REG_COEFS,
+                              num_samples=None, node_param=x64[:, 8:], edge_param=ea64[:, 6:])
+    l64.backward()
+    g64 = o64.grad
+    dd = (m["dout"].double().cpu() - g64).abs()
+    sc = g64.abs().max()
+    bad = (dd > 1e-5 * sc).any(1).nonzero().flatten()
+    print(f"HIP vs fp64 d loss/d out at the same output: rel {dd.max().item() / sc.item():.3e}; nodes off by > 1e-5 max: {bad.numel()} {bad[:12].tolist()}")
+    ei = b["edge_index"]
+    yv = torch.cat([m["out"][:, 0:1] * st[1][:1] + st[0][:1], m["out"][:, 1:] * (1 - x[:, 9:10])], 1)
+    fl = torch.stack(pkg.data.get_pflow(yv, b["edge_index"].to(DEV), x[:, 8:], ea[:, 6:]), 1).cpu()
+    fl64 = torch.stack(oracle.get_pflow(yv.double().cpu(), ei, x64[:, 8:], ea64[:, 6:]), 1)
+    for i in bad[:6].tolist():
+        for e in ((ei[0] == i) | (ei[1] == i)).nonzero().flatten().tolist()[:4]:
+            print(f"      edge {e} ({ei[0, e].item()}->{ei[1, e].item()}): HIP loading_line {fl[e, 0]:.6g} loading_trafo {fl[e, 1]:.6g} "
+                  f"I_from {fl[e, 6]:.9g} I_to {fl[e, 7]:.9g} | fp64 I_from {fl64[e, 6]:.12g} I_to {fl64[e, 7]:.12g} "
+                  f"theta_ij {(yv[ei[0, e], 1] - yv[ei[1, e], 1]).item():.6g}")
+    for i in bad[:6].tolist():
+        inc = ((ei[0] == i) | (ei[1] == i)).nonzero().flatten().tolist()
+        print(f"   node {i}: HIP {m['dout'][i].tolist()} fp64 {g64[i].tolist()}  incident stored edges {inc} "
+              f"params {[b['edge_attr'][e, 6:].tolist() for e in inc[:3]]}")
+
     print(f"out   rel diff {rel(m['out'], a['out']):.3e}   loss {a['loss']:.9g} vs {m['loss']:.9g}")
     d = (m["dout"] - a["dout"]).abs()
     scale = a["dout"].abs().max()
