@@ -536,12 +536,11 @@ def dropout_snapshot(mod: nn.Module, device) -> torch.Tensor:
     torch's CPU generator (as nn.Dropout consumes torch's generator in the reference), so ``torch.manual_seed``
     reproduces a run.  Inside a hipGraph capture a by-value seed would be frozen into the graph, so the module's
     device-side state is used and advanced by the captured kernel itself: every replay sees fresh masks."""
+    host_seed = int(torch.empty((), dtype=torch.int64).random_().item())       # exactly ONE generator draw per forward call
     st = getattr(mod, "_rng_state", None)
     if st is None or st.device != device:
-        seed0 = int(torch.empty((), dtype=torch.int64).random_().item())
-        st = mod._rng_state = torch.tensor([seed0, 0], dtype=torch.int64).to(device)
+        st = mod._rng_state = torch.tensor([host_seed ^ 0x5DEECE66D, 0], dtype=torch.int64).to(device)
     snap = torch.empty(2, dtype=torch.int64, device=device)
-    host_seed = int(torch.empty((), dtype=torch.int64).random_().item())
     capturing = torch.cuda.is_current_stream_capturing()
     _lib.check(_lib.lib().dss2_rng_next(st.data_ptr(), snap.data_ptr(), host_seed, int(not capturing),
                                         torch.cuda.current_stream(device).cuda_stream), "dss2_rng_next")
