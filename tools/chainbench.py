@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""GPU: the layer-chain kernel alone at C2 shapes (forward chain of 3 H->H layers, backward chain with ReLU gates) and the
+whole C2 step, HIP events.  For A/B runs of kernel variants: DSS2_LIB=<other build> / DSS2_CHAIN_SX=0|1 python tools/chainbench.py"""
+import importlib, os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+pkg = importlib.import_module("deep-statistical-solver-for-distribution-system-state-estimation_amd")
+nw = pkg.networks
+dev = torch.device("cuda:0")
+grid, B, H = (sys.argv[1] if len(sys.argv) > 1 else "cigre14"), int(sys.argv[2]) if len(sys.argv) > 2 else 4096, int(sys.argv[3]) if len(sys.argv) > 3 else 128
+nmat, nl = 3, 3
+b = pkg.synthetic.make_batch([grid], B, seed=0)
+x, ei, ea = b["x"].to(dev), b["edge_index"].to(dev), b["edge_attr"].to(dev)
+N = x.shape[0]
+topo = pkg.topology.get_topology(ei, N)
+Ws = [torch.randn(H, H, device=dev) * 0.1 for _ in range(nmat)]
+plan = nw._PackPlan([Ws], dev); plan.refresh()
+h = torch.randn(N, H, device=dev); g = torch.randn(N, H, device=dev); bias = torch.randn(H, device=dev)
+outs = [torch.empty(N, H, device=dev) for _ in range(nl)]
+acts = [torch.randn(N, H, device=dev) for _ in range(nl)]
+fwd = lambda: nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=plan.fwd[0], Y=o, bias=bias, relu=True) for o in outs])
+bwd = lambda: nw.gemm_prop_chain(topo, g, H, nmat, [dict(Bp=plan.bwd[0], Y=o, relu_src=a_) for o, a_ in zip(outs, acts)], transposed=True)
+fl = nl * (2.0 * N * H * nmat * H + 2.0 * (nmat - 1) * topo.E2 * H)
+for _ in range(300):   # clock ramp
+    fwd()
+torch.cuda.synchronize()
+for name, fn in (("forward chain", fwd), ("backward chain", bwd)):
+    ts = []
+    for r in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): fn()
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 20 * 1e3)
+    ts.sort()
+    print(f"{name:16s} {grid} B={B} H={H} nrb={topo.nrb}: median {ts[3]:7.1f} us  min {ts[0]:7.1f} us  {fl / ts[3] / 1e6:6.1f} TFLOP/s = {fl / ts[3] / 1e6 / 157.3:.3f} of fp32 MFMA peak")
+# whole step
+REG = {"mu_v": 1e-1, "mu_theta": 1e-1, "lam_v": 1e-4, "lam_p": 1e-8, "lam_pf": 1e-6, "lam_reg": 1e2}
+st = tuple(s.to(dev) for s in b["stats"])
+model = pkg.MPN(8, 6, 2, H, 4, 2, 0.0).to(dev)
+def step():
+    for p in model.parameters(): p.grad = None
+    out = model(x[:, :8], ei, ea[:, :6])
+    loss = pkg.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2],
+                            edge_std=st[3], edge_index=ei, reg_coefs=REG, num_samples=None, node_param=x[:, 8:], edge_param=ea[:, 6:])
+    loss.backward()
+for _ in range(200): step()
+torch.cuda.synchronize()
+ts = []
+for r in range(5):
+    t0 = time.perf_counter()
+    for _ in range(50): step()
+    torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 50 * 1e3)
+ts.sort()
+print(f"whole step (MPN L=4): median {ts[2]:.4f} ms  min {ts[0]:.4f} ms  -> {B / ts[2] / 1e3:.3f} M graphs/s")
