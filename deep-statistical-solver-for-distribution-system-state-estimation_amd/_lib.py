@@ -78,6 +78,10 @@ class ChainLayer(C.Structure):
                 ("add_src", C.c_void_p), ("prebias", C.c_void_p), ("Y", C.c_void_p), ("relu", C.c_int32), ("drop_id", C.c_int32)]
 
 
+class AdamaxDesc(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_inf", C.c_void_p), ("n", C.c_int64)]
+
+
 class CollateDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("chunk", C.c_int32), ("kind", C.c_int32),
                 ("shared", C.c_int32), ("pad_", C.c_int32), ("nodes_per_sample", C.c_int64)]
@@ -164,8 +168,8 @@ _SIGNATURES = {
     "dss2_masked_zscore_scratch_doubles": (C.c_int64, [C.c_int64]),
     "dss2_collate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "dss2_collate_ragged": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
-    "dss2_adamax_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
-                                   C.c_int, C.c_void_p]),
+    "dss2_adamax_step": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "dss2_adamax_step_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "dss2_gemm_prop_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
 }

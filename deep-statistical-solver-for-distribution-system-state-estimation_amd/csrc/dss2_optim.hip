@@ -6,9 +6,20 @@
 
 namespace dss2 {
 
-__global__ void __launch_bounds__(256) adamax_kernel(const dss2_adamax_desc* __restrict__ descs, float lr, float beta1,
-                                                     float beta2, float eps, float weight_decay, float bias_corr1) {
-  const dss2_adamax_desc d = descs[blockIdx.y];
+__global__ void adamax_tick_kernel(float* __restrict__ step_dev) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) step_dev[0] += 1.f;
+}
+
+// step_dev != NULL: the 1-based step count lives on the device (already advanced by adamax_tick_kernel), so the launch can
+// sit inside a hipGraph and every replay uses the next count; NULL: bias_corr1 was computed by the host.
+constexpr int ADAMAX_CHUNK = 96;      // descriptors per launch, by value in the kernel arguments (96 x 40 B < 4 KB)
+struct AdamaxTable { dss2_adamax_desc d[ADAMAX_CHUNK]; };
+
+__global__ void __launch_bounds__(256) adamax_kernel(const AdamaxTable tab, float lr, float beta1,
+                                                     float beta2, float eps, float weight_decay, float bias_corr1,
+                                                     const float* __restrict__ step_dev) {
+  const dss2_adamax_desc& d = tab.d[blockIdx.y];
+  if (step_dev) bias_corr1 = 1.f - powf(beta1, step_dev[0]);
   const float clr = lr / bias_corr1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * blockDim.x) {
     float g = d.grad[i];
@@ -127,16 +138,39 @@ extern "C" int dss2_small_gemm(const dss2_sgemm_desc* descs, int n_desc, int max
   return dss2::check_launch("small_gemm");
 }
 
-extern "C" int dss2_adamax_step(const dss2_adamax_desc* descs, int n_desc, int64_t max_n, float lr, float beta1,
+static int adamax_launch(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, float bc1, const float* step_dev, hipStream_t s) {
+  for (int c0 = 0; c0 < n_desc; c0 += dss2::ADAMAX_CHUNK) {
+    const int n = n_desc - c0 < dss2::ADAMAX_CHUNK ? n_desc - c0 : dss2::ADAMAX_CHUNK;
+    dss2::AdamaxTable tab = {};
+    int64_t max_n = 0;
+    for (int i = 0; i < n; ++i) {
+      tab.d[i] = descs_host[c0 + i];
+      if (!tab.d[i].param || !tab.d[i].grad || !tab.d[i].exp_avg || !tab.d[i].exp_inf) { dss2::set_error("adamax_step: descriptor %d is incomplete", c0 + i); return 2; }
+      if (tab.d[i].n > max_n) max_n = tab.d[i].n;
+    }
+    int64_t bx = (max_n + 255) / 256;
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(dss2::adamax_kernel, dim3((unsigned)bx, n), dim3(256), 0, s, tab, lr, beta1, beta2, eps, weight_decay, bc1, step_dev);
+  }
+  return dss2::check_launch("adamax_step");
+}
+
+extern "C" int dss2_adamax_step(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1,
                                 float beta2, float eps, float weight_decay, int step, void* stream) {
   if (n_desc <= 0) return 0;
+  if (!descs_host) { dss2::set_error("adamax_step: null descriptor table"); return 2; }
   if (step < 1) { dss2::set_error("adamax_step: step must be >= 1"); return 2; }
-  int64_t bx = (max_n + 255) / 256;
-  if (bx > 64) bx = 64;
-  const float bc1 = 1.f - powf(beta1, (float)step);
-  hipLaunchKernelGGL(dss2::adamax_kernel, dim3((unsigned)bx, n_desc), dim3(256), 0, dss2::as_stream(stream), descs, lr,
-                     beta1, beta2, eps, weight_decay, bc1);
-  return dss2::check_launch("adamax_step");
+  return adamax_launch(descs_host, n_desc, lr, beta1, beta2, eps, weight_decay, 1.f - powf(beta1, (float)step), nullptr, dss2::as_stream(stream));
+}
+
+extern "C" int dss2_adamax_step_dev(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, float* step_dev, void* stream) {
+  if (n_desc <= 0) return 0;
+  if (!descs_host || !step_dev) { dss2::set_error("adamax_step_dev: null argument"); return 2; }
+  hipLaunchKernelGGL(dss2::adamax_tick_kernel, dim3(1), dim3(64), 0, dss2::as_stream(stream), step_dev);
+  return adamax_launch(descs_host, n_desc, lr, beta1, beta2, eps, weight_decay, 1.f, step_dev, dss2::as_stream(stream));
 }
 
 

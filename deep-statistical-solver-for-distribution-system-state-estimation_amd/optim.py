@@ -5,23 +5,52 @@ State keys (``exp_avg``, ``exp_inf``, ``step``) match torch's, so optimizer chec
 (``optimizer_state_dict`` in dss2_run.py:240-247) load either way.  No CPU fallback."""
 from __future__ import annotations
 
-import numpy as np
+import ctypes as C
+
 import torch
 
 from . import _lib
 
-_DESC = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_inf", "<u8"), ("n", "<i8")])
 
 
 class FusedAdamax(torch.optim.Optimizer):
-    def __init__(self, params, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable: bool = False):
+        """capturable=True (as in torch's optimizers): the step count lives on the device, so ``step()`` may be captured
+        into a hipGraph together with forward + loss + backward (graphs.GraphedStep) and every replay advances it."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.capturable = bool(capturable)
         self._table = {}
         self.table_builds = 0      # diagnostics: how often the descriptor table had to be rebuilt
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._table = {}           # the state tensors were replaced
+        for g in self.param_groups:
+            g.pop("_step", None)   # re-derived from the loaded per-parameter steps
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for g in sd["param_groups"]:
+            g.pop("_step", None)   # internal: torch's format keeps the count per parameter (state[...]["step"])
+        return sd
+
+    @torch.no_grad()
+    def init_state(self) -> None:
+        """Create the optimizer state of every parameter now (normally done lazily by the first step).  Needed before
+        capturing ``step()`` into a hipGraph without warm-up steps: state created INSIDE a capture would be re-zeroed by
+        every replay."""
+        for group in self.param_groups:
+            ps = list(group["params"])
+            if not ps:
+                continue
+            if group.get("_step") is None:
+                group["_step"] = (torch.zeros((), dtype=torch.float32, device=ps[0].device) if self.capturable else torch.tensor(0.0))
+            for p in ps:
+                st = self.state[p]
+                if "exp_avg" not in st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_inf"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] = group["_step"]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -33,36 +62,53 @@ class FusedAdamax(torch.optim.Optimizer):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
+            dev = ps[0].device
             for p in ps:
                 if not p.is_cuda or p.dtype != torch.float32:
                     raise RuntimeError("FusedAdamax needs fp32 GPU parameters (there is no CPU fallback)")
+            # one step tensor shared by every parameter of the group (torch keeps one per parameter with the same value):
+            # advanced ONCE per step -- on the host, or by the kernel itself when capturable
+            shared = group.get("_step")
+            if shared is None:
+                known = [self.state[p]["step"] for p in ps if "step" in self.state[p]]
+                first = float(known[0]) if known else 0.0
+                shared = group["_step"] = (torch.tensor(first, dtype=torch.float32, device=dev) if self.capturable
+                                           else torch.tensor(first))
+            for p in ps:
                 st = self.state[p]
-                if not st:
-                    st["step"] = torch.tensor(0.0)
+                if "exp_avg" not in st:
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_inf"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            step = int(self.state[ps[0]]["step"]) + 1
-            for p in ps:
-                self.state[p]["step"] = torch.tensor(float(step))
+                    self._table.pop(gi, None)
+                if st.get("step") is not shared:
+                    st["step"] = shared
+            if not self.capturable:
+                shared += 1.0
+                step = int(shared)
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
-            # the descriptor table is keyed by every address it holds; the gradient tensors themselves are NOT kept
-            # (holding them would pin the previous flat gradient buffer, the next backward would allocate elsewhere
-            # and the table would be rebuilt every step)
-            key = tuple((p.data_ptr(), g.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_inf"].data_ptr())
-                        for p, g in zip(ps, grads))
+            # host-side descriptor table, passed to the kernels BY VALUE (no device copy to keep alive, capture-safe);
+            # parameter and state addresses are written once, the gradient addresses every step (the flat gradient
+            # buckets of the backward move)
             cached = self._table.get(gi)
-            if cached is None or cached[0] != key:
-                arr = np.array([k + (p.numel(),) for k, p in zip(key, ps)], dtype=_DESC)
-                host = torch.from_numpy(arr.view(np.uint8).copy())
-                dev_tab = cached[1] if cached is not None and cached[1].numel() == host.numel() else \
-                    torch.empty(host.numel(), dtype=torch.uint8, device=ps[0].device)
-                dev_tab.copy_(host.pin_memory(), non_blocking=True)
-                cached = (key, dev_tab, max(p.numel() for p in ps))
-                self._table[gi] = cached
+            pkey = tuple(p.data_ptr() for p in ps)
+            if cached is None or cached[1] != pkey:
+                tab = (_lib.AdamaxDesc * len(ps))()
+                for d, p in zip(tab, ps):
+                    stp = self.state[p]
+                    d.param, d.exp_avg, d.exp_inf, d.n = p.data_ptr(), stp["exp_avg"].data_ptr(), stp["exp_inf"].data_ptr(), p.numel()
+                cached = self._table[gi] = (tab, pkey)
                 self.table_builds += 1
+            tab = cached[0]
+            for d, g in zip(tab, grads):
+                d.grad = g.data_ptr()
             b1, b2 = group["betas"]
-            st = torch.cuda.current_stream(ps[0].device).cuda_stream
-            _lib.check(_lib.lib().dss2_adamax_step(cached[1].data_ptr(), len(ps), cached[2], float(group["lr"]), float(b1),
-                                                   float(b2), float(group["eps"]), float(group["weight_decay"]), step, st),
-                       "dss2_adamax_step")
+            st = torch.cuda.current_stream(dev).cuda_stream
+            if self.capturable:
+                _lib.check(_lib.lib().dss2_adamax_step_dev(C.addressof(tab), len(ps), float(group["lr"]), float(b1),
+                                                           float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                                           shared.data_ptr(), st), "dss2_adamax_step_dev")
+            else:
+                _lib.check(_lib.lib().dss2_adamax_step(C.addressof(tab), len(ps), float(group["lr"]), float(b1),
+                                                       float(b2), float(group["eps"]), float(group["weight_decay"]), step, st),
+                           "dss2_adamax_step")
         return loss

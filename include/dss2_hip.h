@@ -422,15 +422,19 @@ int dss2_collate_ragged(const dss2_collate_desc* descs_host, int32_t n_desc, con
                         const int64_t* edge_off, int64_t count, int64_t e_total, void* stream);
 
 /* ---- optimizer step (/root/reference/dss2_run.py:91-92,143: Adamax, lr 3e-3) ---
- * torch.optim.Adamax semantics on n_desc tensors in ONE launch.  descs: device array.  `step` is the
- * 1-based step count (bias correction 1 - beta1^step).  grad pointers may be views of the flat
- * gradient bucket the backward produces. */
+ * torch.optim.Adamax semantics on n_desc tensors, 96 tensors per launch.  descs_host: HOST array, passed to the kernels by
+ * value (no descriptor copy, nothing to keep alive, safe inside a hipGraph capture).  `step` is the 1-based step count
+ * (bias correction 1 - beta1^step).  grad pointers may be views of the flat gradient bucket the backward produces. */
 typedef struct dss2_adamax_desc {
   float* param; const float* grad; float* exp_avg; float* exp_inf; int64_t n;
 } dss2_adamax_desc;
 
-int dss2_adamax_step(const dss2_adamax_desc* descs, int n_desc, int64_t max_n, float lr, float beta1,
-                     float beta2, float eps, float weight_decay, int step, void* stream);
+int dss2_adamax_step(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, void* stream);
+/* the same with the step count on the device (float, like torch's capturable optimizers): *step_dev is advanced by one and
+ * then used for the bias correction, so the launches can be captured into a hipGraph with the rest of the step. */
+int dss2_adamax_step_dev(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, float* step_dev, void* stream);
 
 /* LDS bytes a dss2_gemm_prop / dss2_wgrad launch will request (host-side helper; lets the
  * caller reject configurations that do not fit the 160 KiB LDS before launching). */
