@@ -52,7 +52,7 @@ class WgradArgs(C.Structure):
 
 
 class CsrBuildArgs(C.Structure):
-    _fields_ = [("edge_index", C.c_void_p), ("n_edges", C.c_int64), ("n_nodes", C.c_int64), ("doubled", C.c_int32), ("pad_", C.c_int32),
+    _fields_ = [("edge_index", C.c_void_p), ("n_edges", C.c_int64), ("n_nodes", C.c_int64), ("doubled", C.c_int32), ("no_flip", C.c_int32),
                 ("rowptr", C.c_void_p), ("col", C.c_void_p), ("ent", C.c_void_p), ("perm", C.c_void_p), ("w", C.c_void_p),
                 ("rowptrT", C.c_void_p), ("colT", C.c_void_p), ("entT", C.c_void_p), ("permT", C.c_void_p), ("wT", C.c_void_p),
                 ("inc_rowptr", C.c_void_p), ("inc_ent", C.c_void_p), ("efrom", C.c_void_p), ("eto", C.c_void_p),
@@ -127,6 +127,8 @@ _SIGNATURES = {
     "dss2_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "dss2_rng_next": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]),
     "dss2_dropout_mask": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dss2_gate_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int32, C.c_float, C.c_int,
+                                 C.c_void_p]),
     "dss2_dropout_params": (None, [C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "dss2_pack_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dss2_edge_hidden_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
@@ -136,6 +138,11 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p]),
+    "dss2_edge_combine_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "dss2_edge_combine_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int,
+                                        C.c_int, C.c_int, C.c_void_p]),
     "dss2_edge_tile_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p]),

@@ -174,6 +174,117 @@ __global__ void __launch_bounds__(256) edge_hidden_bwd_kernel(
 
 
 // ------------------------------------------------------------------------------------------
+// EdgeAggregation with node features of ANY width (MultiMPN / MaskEmbdMultiMPN interleave it with TAGConv layers, so
+// its input is the hidden activation, networks.py:486-498).  The first Linear acts on [x_i | x_j | ea]:
+//     z_e = W1a x_i + W1b x_j + W1c ea_e + b1,
+// so the two node products are ONE tile GEMM per node, AB = X [W1a; W1b]^T  ([N, 2 hid], dss2_gemm_prop), and only the
+// per-edge combination lives here: S[i] = sum_{e -> i} relu(A[i] + B[src(e)] + W1c ea'_e + b1)   (row per wave, lanes over
+// the hidden features, W1c and b1 in registers; fe <= 8).  Backward: dz_e = dS[i] (z_e > 0); by target it writes
+// dAB[i, :hid] = sum dz and the slabs of dW1c / db1, by source dAB[j, hid:] = sum over the edges leaving j.
+// ------------------------------------------------------------------------------------------
+constexpr int EC_MAXFE = 8;
+
+struct EdgeCombineArgs {
+  const float* AB; int64_t ldab; const float* ea; int64_t ldea; const float* W1c; int64_t ldw; const float* b1;
+  const float* dS; const int32_t* rowptr; const int32_t* col; const int32_t* ent;
+  float* S; float* dAB; float* slab; int64_t n_nodes; int h, fe, by_source;
+};
+
+template <int FPL, bool BWD>
+__global__ void __launch_bounds__(256) edge_combine_kernel(const EdgeCombineArgs p) {
+  __shared__ float red[BWD ? 256 * (EC_MAXFE + 1) : 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wpb = blockDim.x >> 6;
+  const int h = p.h, fe = p.fe;
+  float w[FPL][EC_MAXFE], b[FPL], dw[BWD ? FPL : 1][EC_MAXFE], db[BWD ? FPL : 1];
+#pragma unroll
+  for (int f = 0; f < FPL; ++f) {
+    const int j = lane + 64 * f;
+    b[f] = j < h ? p.b1[j] : 0.f;
+    if (BWD) db[f] = 0.f;
+#pragma unroll
+    for (int k = 0; k < EC_MAXFE; ++k) {
+      w[f][k] = (j < h && k < fe) ? p.W1c[(size_t)j * p.ldw + k] : 0.f;
+      if (BWD) dw[f][k] = 0.f;
+    }
+  }
+  for (int64_t i = (int64_t)blockIdx.x * wpb + wave; i < p.n_nodes; i += (int64_t)gridDim.x * wpb) {
+    float own[FPL], g[FPL], acc[FPL];
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) {
+      const int j = lane + 64 * f;
+      // rows are targets (own = A part) or, in the by-source pass, sources (own = B part)
+      own[f] = j < h ? p.AB[i * p.ldab + (BWD && p.by_source ? h : 0) + j] : 0.f;
+      g[f] = (BWD && !p.by_source && j < h) ? p.dS[i * h + j] : 0.f;
+      acc[f] = 0.f;
+    }
+    const int e1 = p.rowptr[i + 1];
+    for (int e = p.rowptr[i]; e < e1; ++e) {
+      const int64_t other = p.col[e];
+      const int en = p.ent[e];
+      const int eid = en & 0x7fffffff;
+      const float sgn = en < 0 ? -1.f : 1.f;
+      float a[EC_MAXFE];
+#pragma unroll
+      for (int k = 0; k < EC_MAXFE; ++k) a[k] = k < fe ? p.ea[(int64_t)eid * p.ldea + k] : 0.f;
+      a[0] *= sgn;          // reverse edges of the reference's MPN doubling carry (-c0, c1, -c2, ...); the Multi* variants
+      a[2] *= sgn;          // double WITHOUT sign flips (networks.py:519-523): their structure sets no flip flag
+#pragma unroll
+      for (int f = 0; f < FPL; ++f) {
+        const int j = lane + 64 * f;
+        const float oth = j < h ? p.AB[other * p.ldab + (BWD && p.by_source ? 0 : h) + j] : 0.f;
+        float z = (own[f] + oth) + b[f];
+#pragma unroll
+        for (int k = 0; k < EC_MAXFE; ++k) z = fmaf(w[f][k], a[k], z);
+        if (!BWD) {
+          acc[f] += fmaxf(z, 0.f);
+        } else {
+          const float gg = p.by_source ? ((j < h) ? p.dS[other * h + j] : 0.f) : g[f];
+          const float dz = z > 0.f ? gg : 0.f;
+          acc[f] += dz;
+          if (!p.by_source) {
+            db[f] += dz;
+#pragma unroll
+            for (int k = 0; k < EC_MAXFE; ++k) dw[f][k] = fmaf(dz, a[k], dw[f][k]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < FPL; ++f) {
+      const int j = lane + 64 * f;
+      if (j < h) {
+        if (!BWD) p.S[i * h + j] = acc[f];
+        else p.dAB[i * p.ldab + (p.by_source ? h : 0) + j] = acc[f];
+      }
+    }
+  }
+  if (!BWD) return;
+  if (p.by_source || !p.slab) return;
+  float* out = p.slab + (size_t)blockIdx.x * ((size_t)h * fe + h);      // [h][fe] dW1c, then [h] db1
+  for (int wv = 0; wv < wpb; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int f = 0; f < FPL; ++f) {
+        const int j = lane + 64 * f;
+        if (j < h) {
+#pragma unroll
+          for (int k = 0; k < EC_MAXFE; ++k) red[j * (EC_MAXFE + 1) + k] = (wv ? red[j * (EC_MAXFE + 1) + k] : 0.f) + dw[f][k];
+          red[j * (EC_MAXFE + 1) + EC_MAXFE] = (wv ? red[j * (EC_MAXFE + 1) + EC_MAXFE] : 0.f) + db[f];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int idx = threadIdx.x; idx < h * fe; idx += blockDim.x) {
+    const int j = idx / fe, k = idx - j * fe;
+    out[idx] = red[j * (EC_MAXFE + 1) + k];
+  }
+  for (int j = threadIdx.x; j < h; j += blockDim.x) out[(size_t)h * fe + j] = red[j * (EC_MAXFE + 1) + EC_MAXFE];
+}
+
+// ------------------------------------------------------------------------------------------
 // Tile-based variants (used when the topology provides per-tile ELL slices with edge ids).
 // One workgroup = one tile of whole graphs (<= TMAX rows).  Staged in LDS: the tile's x rows, an ELL
 // slice {local other-node, stored edge id | flip} per (slot, row), and the gathered, sign-corrected
@@ -797,6 +908,38 @@ extern "C" int dss2_edge_tile_bwd(const float* x, int64_t ldx, const float* ea, 
   if (!by_source && edge_mfma_ok(h, nrb, ell_width, true))
     return dispatch_edge_mfma(a, nrb, n_slabs < ntiles ? n_slabs : ntiles, true, as_stream(stream));
   return launch_edge_tile<true>(a, n_slabs < ntiles ? n_slabs : ntiles, as_stream(stream));
+}
+
+extern "C" int dss2_edge_combine_fwd(const float* AB, int64_t ldab, const float* ea, int64_t ldea, const float* W1c, int64_t ldw,
+                                     const float* b1, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* S,
+                                     int64_t n_nodes, int h, int fe, void* stream) {
+  if (h <= 0 || h > 256 || fe < 0 || fe > EC_MAXFE) { set_error("edge_combine_fwd: h=%d (1..256) / fe=%d (0..8) unsupported", h, fe); return 2; }
+  if (n_nodes <= 0) return 0;
+  EdgeCombineArgs a{AB, ldab, ea, ldea, W1c, ldw, b1, nullptr, rowptr, col, ent, S, nullptr, nullptr, n_nodes, h, fe, 0};
+  int64_t blocks = (n_nodes + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  const int fpl = (h + 63) / 64;
+#define L(FPL) hipLaunchKernelGGL((edge_combine_kernel<FPL, false>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a)
+  if (fpl == 1) L(1); else if (fpl == 2) L(2); else if (fpl == 3) L(3); else L(4);
+#undef L
+  return check_launch("edge_combine_fwd");
+}
+
+extern "C" int dss2_edge_combine_bwd(const float* AB, int64_t ldab, const float* ea, int64_t ldea, const float* W1c, int64_t ldw,
+                                     const float* b1, const float* dS, const int32_t* rowptr, const int32_t* col,
+                                     const int32_t* ent, float* dAB, float* slab, int n_slabs, int64_t n_nodes, int h, int fe,
+                                     int by_source, void* stream) {
+  if (h <= 0 || h > 256 || fe < 0 || fe > EC_MAXFE) { set_error("edge_combine_bwd: h=%d (1..256) / fe=%d (0..8) unsupported", h, fe); return 2; }
+  if (!by_source && (!slab || n_slabs <= 0)) { set_error("edge_combine_bwd: slab missing"); return 2; }
+  if (n_nodes <= 0) return 0;
+  EdgeCombineArgs a{AB, ldab, ea, ldea, W1c, ldw, b1, dS, rowptr, col, ent, nullptr, dAB, slab, n_nodes, h, fe, by_source};
+  int64_t blocks = by_source ? (n_nodes + 3) / 4 : n_slabs;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  const int fpl = (h + 63) / 64;
+#define L(FPL) hipLaunchKernelGGL((edge_combine_kernel<FPL, true>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a)
+  if (fpl == 1) L(1); else if (fpl == 2) L(2); else if (fpl == 3) L(3); else L(4);
+#undef L
+  return check_launch("edge_combine_bwd");
 }
 
 extern "C" int dss2_segment_sum(const float* msg, int64_t ldm, const int32_t* rowptr, const int32_t* ent, float* out,

@@ -228,3 +228,41 @@ extern "C" int dss2_dropout_mask(const uint64_t* snapshot, int32_t drop_id, floa
                      (uint32_t)drop_id, thr, scale, n_rows, h, out, ldo);
   return dss2::check_launch("dropout_mask");
 }
+
+
+// ---- gradient through "dropout, then ReLU" of a layer output (networks.py:268-269 between the layers of the Multi* variants):
+//      gpre = g * mask * (y > 0), y = the layer's post-activation output, mask regenerated from the layer's dropout spec.
+namespace dss2 {
+__global__ void __launch_bounds__(256) gate_grad_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ out,
+                                                        int64_t n_rows, int h, const uint64_t* __restrict__ snap, uint32_t id,
+                                                        uint32_t thr, float scale, int relu) {
+  const uint64_t seed = snap ? snap[0] : 0, off = snap ? snap[1] : 0;
+  const int groups = (h + 3) >> 2;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_rows * groups; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / groups;
+    const int gq = (int)(t - row * groups);
+    f32x4 m = {1.f, 1.f, 1.f, 1.f};
+    if (snap) m = dropout_mult4(seed, off, id, (uint32_t)row, (uint32_t)gq, thr, scale);
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * gq + q;
+      if (c < h) {
+        const int64_t i = row * h + c;
+        out[i] = (!relu || y[i] > 0.f) ? g[i] * m[q] : 0.f;
+      }
+    }
+  }
+}
+}  // namespace dss2
+
+extern "C" int dss2_gate_grad(const float* g, const float* y, float* out, int64_t n_rows, int h, const uint64_t* snapshot,
+                              int32_t drop_id, float p, int relu, void* stream) {
+  if (!g || !out || (relu && !y) || h <= 0) { dss2::set_error("gate_grad: bad arguments"); return 2; }
+  if (n_rows <= 0) return 0;
+  uint32_t thr = 0; float scale = 1.f;
+  if (snapshot) dss2_dropout_params(p, &thr, &scale);
+  int64_t blocks = (n_rows * ((h + 3) / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dss2::gate_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, dss2::as_stream(stream), g, y, out, n_rows, h,
+                     snapshot, (uint32_t)drop_id, thr, scale, relu);
+  return dss2::check_launch("gate_grad");
+}

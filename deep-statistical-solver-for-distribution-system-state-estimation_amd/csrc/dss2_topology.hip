@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) topo_probe_kernel(const int64_t* __restri
 }
 
 struct BuildPtrs {
-  const int64_t* ei; int64_t E, N, E2; int doubled;
+  const int64_t* ei; int64_t E, N, E2; int doubled; int no_flip;
   int32_t *cnt, *cntT, *cntI, *cover;           // work: [N+1] each (cover: [N+2])
   int32_t *keys, *keysT, *keysI;                // work: [E2], [E2], [2E]
   int32_t *bsum;                                // work: [4][nblk]
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256) topo_finalize_kernel(const BuildPtrs p, c
       const int src = flip ? b : a, tgt = flip ? a : b;
       // gcn_norm(add_self_loops=False): in-degree on the (doubled) directed list, both CSRs carry the same weight
       const float wv = __fmul_rn(inv_sqrt_deg(f.rowptr[src + 1] - f.rowptr[src]), inv_sqrt_deg(f.rowptr[tgt + 1] - f.rowptr[tgt]));
-      const int en = (int)((uint32_t)e | (flip ? kFlip : 0u));
+      const int en = (int)((uint32_t)e | ((flip && !p.no_flip) ? kFlip : 0u));
       if (which == 0) { f.col[e0 + k] = src; f.ent[e0 + k] = en; f.perm[e0 + k] = d; f.w[e0 + k] = wv; }
       else { f.colT[e0 + k] = tgt; f.entT[e0 + k] = en; f.permT[e0 + k] = d; f.wT[e0 + k] = wv; }
     }
@@ -390,7 +390,7 @@ extern "C" int dss2_csr_build(const dss2_csr_build_args* ap, void* stream) {
   const int nblk = (int)((N + 2 + kScanChunk - 1) / kScanChunk + 1);
   int32_t* wk = a.work;
   BuildPtrs p;
-  p.ei = a.edge_index; p.E = E; p.N = N; p.E2 = E2; p.doubled = a.doubled ? 1 : 0; p.meta = a.meta;
+  p.ei = a.edge_index; p.E = E; p.N = N; p.E2 = E2; p.doubled = a.doubled ? 1 : 0; p.no_flip = a.no_flip ? 1 : 0; p.meta = a.meta;
   p.cnt = wk; wk += N + 1;
   p.cntT = wk; wk += N + 1;
   p.cntI = wk; wk += N + 1;

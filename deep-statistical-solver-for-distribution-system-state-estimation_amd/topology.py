@@ -75,9 +75,11 @@ class Topology:
     """Frozen device-side structure of one batched graph.  See include/dss2_hip.h."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, nrb: Optional[int] = None,
-                 double: Optional[bool] = None, hint: Optional[TopologyHint] = None):
+                 double: Optional[bool] = None, hint: Optional[TopologyHint] = None, flip: bool = True):
         """double=None: the reference's rule (MPN.is_directed on the first edge; from the hint when given); False: use
-        the edge list exactly as given (standalone EdgeAggregation / TAGConv / propagate); True: always double."""
+        the edge list exactly as given (standalone EdgeAggregation / TAGConv / propagate); True: always double.
+        flip=False: reverse edges carry no sign-flip flag (the Multi* / MaskEmbd* variants duplicate edge_attr unchanged,
+        /root/reference/networks.py:440-444, where MPN negates columns 0 and 2, :250-254)."""
         if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype != torch.int64:
             raise ValueError("edge_index must be an int64 tensor of shape [2, E]")
         N, E = int(num_nodes), int(edge_index.size(1))
@@ -115,6 +117,8 @@ class Topology:
         work = torch.empty(int(L.dss2_csr_build_work_ints(N, E, int(self.directed))), dtype=torch.int32, device=dev)
         a = _lib.CsrBuildArgs()
         a.edge_index, a.n_edges, a.n_nodes, a.doubled = ei.data_ptr(), E, N, int(self.directed)
+        a.no_flip = int(not flip)
+        self.flip = bool(flip)
         for name, _ in sizes:
             setattr(a, name.lstrip("_"), getattr(self, name).data_ptr())
         a.work = work.data_ptr()
@@ -254,16 +258,17 @@ _last: Dict[Tuple[int, str], Tuple] = {}   # (id(tensor), mode) -> (weakref, ver
 _MAX_CACHE = 64
 
 
-def _mode(double: Optional[bool]) -> str:
-    return "ref" if double is None else ("dbl" if double else "asis")
+def _mode(double: Optional[bool], flip: bool = True) -> str:
+    return ("ref" if double is None else ("dbl" if double else "asis")) + ("" if flip else "-noflip")
 
 
-def register_topology(edge_index: torch.Tensor, num_nodes: int, topo: Topology, double: Optional[bool] = None) -> Topology:
+def register_topology(edge_index: torch.Tensor, num_nodes: int, topo: Topology, double: Optional[bool] = None,
+                      flip: bool = True) -> Topology:
     """Attach an already built structure to this very tensor object: the next ``get_topology(edge_index, ...)`` (the
     model's forward, the loss) returns it without hashing or synchronising.  Used by dataset.DataLoader."""
     if len(_last) >= _MAX_CACHE:
         _last.pop(next(iter(_last)))
-    key = (id(edge_index), _mode(double))
+    key = (id(edge_index), _mode(double, flip))
 
     def _drop(ref, key=key, table=_last):   # the tensor died: release its structure (device arrays) with it
         hit = table.get(key)
@@ -273,12 +278,12 @@ def register_topology(edge_index: torch.Tensor, num_nodes: int, topo: Topology, 
     return topo
 
 
-def get_topology(edge_index: torch.Tensor, num_nodes: int, double: Optional[bool] = None) -> Topology:
+def get_topology(edge_index: torch.Tensor, num_nodes: int, double: Optional[bool] = None, flip: bool = True) -> Topology:
     """The cached structure of this batch.  double=None: the reference's doubling rule (MPN / the loss);
     False: the edge list exactly as given (standalone EdgeAggregation / TAGConv / MessagePassing.propagate)."""
     if not edge_index.is_cuda:
         raise RuntimeError("DSS2 HIP path: edge_index must live on the GPU (there is no CPU fallback)")
-    mode = _mode(double)
+    mode = _mode(double, flip)
     hit = _last.get((id(edge_index), mode))
     if hit is not None:
         ref, ver, ptr, nn, topo = hit
@@ -288,11 +293,11 @@ def get_topology(edge_index: torch.Tensor, num_nodes: int, double: Optional[bool
     key = (edge_index.device.index, int(num_nodes), int(edge_index.size(1)), h1, h2, mode)
     topo = _by_hash.get(key)
     if topo is None:
-        topo = Topology(edge_index, num_nodes, double=(directed if double is None else double))
+        topo = Topology(edge_index, num_nodes, double=(directed if double is None else double), flip=flip)
         if len(_by_hash) >= _MAX_CACHE:
             _by_hash.pop(next(iter(_by_hash)))
         _by_hash[key] = topo
-    return register_topology(edge_index, num_nodes, topo, double)
+    return register_topology(edge_index, num_nodes, topo, double, flip)
 
 
 def clear_cache() -> None:

@@ -64,7 +64,9 @@ int dss2_topology_probe(const int64_t* edge_index, int64_t n_edges, uint64_t* ou
  *   tile (by target / by source, written by dss2_ell_tiles_build), 8.. ntiles per candidate (dss2_tiles_walk).
  * work: dss2_csr_build_work_ints(N, E, doubled) int32 of device scratch. */
 typedef struct dss2_csr_build_args {
-  const int64_t* edge_index; int64_t n_edges; int64_t n_nodes; int32_t doubled; int32_t pad_;
+  const int64_t* edge_index; int64_t n_edges; int64_t n_nodes; int32_t doubled;
+  int32_t no_flip;   /* doubled only: 1 = reverse edges carry NO sign-flip flag in ent / entT (the Multi* / MaskEmbd* variants of
+                      * the reference duplicate edge_attr unchanged, networks.py:440-444; MPN negates columns 0 and 2) */
   int32_t* rowptr; int32_t* col; int32_t* ent; int32_t* perm; float* w;
   int32_t* rowptrT; int32_t* colT; int32_t* entT; int32_t* permT; float* wT;
   int32_t* inc_rowptr; int32_t* inc_ent; int32_t* efrom; int32_t* eto;
@@ -153,6 +155,21 @@ int dss2_edge_hidden_bwd(const float* x, int64_t ldx, const float* ea, int64_t l
                          const int32_t* rowptr, const int32_t* col, const int32_t* ent,
                          float* slab, int n_slabs, float* U, int64_t ldu,
                          int64_t n_nodes, int h, int fn, int fe, int by_source, void* stream);
+
+/* EdgeAggregation with node features of any width (networks.py:159-209 as MultiMPN / MaskEmbdMultiMPN instantiate it on the
+ * hidden activation, networks.py:486-498).  AB[N, 2h] = X [W1[:, :d] ; W1[:, d:2d]]^T (one dss2_gemm_prop); W1c = &W1[0][2d]
+ * with row stride ldw = 2d + fe; fe <= 8; h <= 256.
+ *   fwd: S[i,:] = sum_{e: tgt(e)=i} relu(AB[i, :h] + AB[src(e), h:] + W1c ea'(e) + b1)
+ *   bwd: dz_e = dS[tgt(e)] (z_e > 0).  by_source = 0 (CSR by target): dAB[i, :h] = sum dz, slab[n_slabs][h*fe + h] =
+ *        partial dW1c, db1 (finish with dss2_reduce_slabs); by_source = 1 (CSR by source): dAB[j, h:] = sum dz.
+ * Reverse edges flagged in `ent` negate edge_attr columns 0 and 2 (the reference's MPN doubling); the Multi* variants double
+ * without sign flips, i.e. their structure carries no flags. */
+int dss2_edge_combine_fwd(const float* AB, int64_t ldab, const float* ea, int64_t ldea, const float* W1c, int64_t ldw,
+                          const float* b1, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* S,
+                          int64_t n_nodes, int h, int fe, void* stream);
+int dss2_edge_combine_bwd(const float* AB, int64_t ldab, const float* ea, int64_t ldea, const float* W1c, int64_t ldw,
+                          const float* b1, const float* dS, const int32_t* rowptr, const int32_t* col, const int32_t* ent,
+                          float* dAB, float* slab, int n_slabs, int64_t n_nodes, int h, int fe, int by_source, void* stream);
 
 /* Tile-based variants of the two functions above (same arithmetic, same outputs): one workgroup per
  * tile with the tile's x rows, an ELL slice carrying edge ids and the gathered edge_attr rows staged
@@ -247,6 +264,10 @@ int dss2_rng_next(uint64_t* state, uint64_t* snapshot, uint64_t host_seed, int u
  * test feed the very same mask to the CPU oracle. */
 int dss2_dropout_mask(const uint64_t* snapshot, int32_t drop_id, float p, int64_t n_rows, int h, float* out, int64_t ldo,
                       void* stream);
+/* gradient through "dropout, then ReLU" of a contiguous [n_rows, h] layer output y (networks.py:268-269):
+ * out = g * mask * (y > 0), mask = the (snapshot, drop_id, p) mask (snapshot NULL: no dropout); relu == 0: mask only. */
+int dss2_gate_grad(const float* g, const float* y, float* out, int64_t n_rows, int h, const uint64_t* snapshot,
+                   int32_t drop_id, float p, int relu, void* stream);
 /* host helper: drop_thr / drop_scale for a dropout rate p (the one definition both sides use) */
 void dss2_dropout_params(float p, uint32_t* thr, float* scale);
 

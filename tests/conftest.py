@@ -100,3 +100,19 @@ def tagconv_known_answers():
             exp[int(K)] = a[..., 0] + a[..., 1] / (2.0 ** 0.5)
         cases[name] = (torch.tensor(c["edge_index"], dtype=torch.int64), exp)
     return x, lins, bias, cases
+
+
+# the per-layer-interleaved variants (networks.py:390-735): golden name -> (class name, ctor args)
+MULTI_CASES = {
+    "multimpn": ("MultiMPN", (8, 6, 2, 32, 3, 2, 0.0)),
+    "multimpn_h128": ("MultiMPN", (8, 6, 2, 128, 2, 2, 0.0)),
+    "maskembdmpn": ("MaskEmbdMPN", (8, 6, 2, 32, 3, 2, 0.0)),
+    "maskembdmultimpn": ("MaskEmbdMultiMPN", (8, 6, 2, 32, 2, 2, 0.0)),
+    "maskembdmultimpn_nomp": ("MaskEmbdMultiMPN_NoMP", (8, 6, 2, 8, 3, 2, 0.0)),
+}
+
+
+def multi_case_data(g, dtype=torch.float32, device=None):
+    import types
+    return types.SimpleNamespace(x=t(g["x"], dtype, device), edge_index=t(g["edge_index"], device=device),
+                                 edge_attr=t(g["edge_attr"], dtype, device))

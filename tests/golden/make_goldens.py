@@ -196,6 +196,39 @@ def extras():
             flows = ref_data.get_pflow(yv, ei, x[:, 8:], ea[:, 6:], phase_shift=False)
         arrays[f"{name}/pflow_shift"] = torch.stack(flows, 1)
     save("case_pflow_shift.npz", **arrays)
+    # ---- the per-layer-interleaved variants (networks.py:390-735): forward(data) + backward of a random output gradient
+    import types
+    z = np.load(os.path.join(HERE, "cigre14_real64.npz"))
+    x11, ei, ea13 = torch.from_numpy(z["x"]), torch.from_numpy(z["edge_index"]), torch.from_numpy(z["edge_attr"])
+    feats = x11[:, :8]
+    torch.manual_seed(40)
+    types_onehot = torch.nn.functional.one_hot(torch.randint(0, 4, (x11.shape[0],)), 4).float()
+    x_masked = torch.cat([types_onehot, feats, (feats != 0).float()], dim=1)           # [N, 4 + 8 + 8]
+    feats8 = torch.cat([types_onehot, feats, (feats != 0).float()], dim=1)
+    N = ref_networks
+    variants = {
+        "multimpn": (N.MultiMPN, (8, 6, 2, 32, 3, 2, 0.0), feats),
+        "multimpn_h128": (N.MultiMPN, (8, 6, 2, 128, 2, 2, 0.0), feats),
+        "maskembdmpn": (N.MaskEmbdMPN, (8, 6, 2, 32, 3, 2, 0.0), x_masked),
+        "maskembdmultimpn": (N.MaskEmbdMultiMPN, (8, 6, 2, 32, 2, 2, 0.0), x_masked),
+        "maskembdmultimpn_nomp": (N.MaskEmbdMultiMPN_NoMP, (8, 6, 2, 8, 3, 2, 0.0), x_masked),
+    }
+    for k, (name, (cls, args, xin)) in enumerate(variants.items()):
+        torch.manual_seed(50 + k)
+        model = cls(*args)
+        with torch.no_grad():
+            for n_, p_ in model.named_parameters():
+                if n_.endswith("bias") and ("convs" in n_ or ("layers" in n_ and "edge_aggr" not in n_)):
+                    p_.uniform_(-0.2, 0.2)          # non-trivial TAGConv biases (PyG initialises them to zero)
+        data = types.SimpleNamespace(x=xin, edge_index=ei, edge_attr=ea13[:, :6])
+        out = model(data)
+        torch.manual_seed(60 + k)
+        gout = torch.randn_like(out)
+        out.backward(gout)
+        arr = {f"param/{kk}": v.clone() for kk, v in model.state_dict().items()}
+        arr.update({f"grad/{kk}": p_.grad.clone() for kk, p_ in model.named_parameters()})
+        arr.update(x=xin, edge_index=ei, edge_attr=ea13[:, :6], out=out.detach(), gout=gout)
+        save(f"case_{name}.npz", **arr)
 
 
 def main():

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import CASES, LOSS_CASES, case_batch, case_grads, case_state_dict, golden, rel_err, t, tagconv_known_answers
+from conftest import MULTI_CASES, multi_case_data, CASES, LOSS_CASES, case_batch, case_grads, case_state_dict, golden, rel_err, t, tagconv_known_answers
 
 # fp32 noise floor of the reference path itself is ~6e-7 (out), ~1.2e-6 (loss), ~2e-5 (grads)
 TOL_OUT, TOL_LOSS, TOL_GRAD = 2e-6, 5e-6, 5e-5
@@ -139,3 +139,20 @@ def test_oracle_tagconv_matches_hand_derived_known_answers(oracle):
                     conv.lins[k].weight.copy_(lins[k])
             got = conv(x, ei)
             assert (got - want).abs().max() < 1e-13, (name, K)
+
+
+@pytest.mark.parametrize("name", list(MULTI_CASES))
+def test_oracle_multi_variants_match_reference(oracle, name):
+    """MaskEmbdMPN / MultiMPN / MaskEmbdMultiMPN / MaskEmbdMultiMPN_NoMP (networks.py:390-735): the oracle's restatement
+    against goldens produced by the reference's own classes (forward(data) + backward of a stored output gradient)."""
+    cls, args = MULTI_CASES[name]
+    g = golden(f"case_{name}.npz")
+    model = getattr(oracle, cls)(*args)
+    res = model.load_state_dict(case_state_dict(g), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    out = model(multi_case_data(g))
+    assert rel_err(out, t(g["out"])) < TOL_OUT
+    out.backward(t(g["gout"]))
+    grads = case_grads(g)
+    for k, p in model.named_parameters():
+        assert rel_err(p.grad, grads[k]) < TOL_GRAD, k
