@@ -843,10 +843,14 @@ static int launch_edge_mfma(const EdgeTileArgs& a, int grid, bool bwd, hipStream
   const int nw = a.h >> 5;                  // one wave per 32-column group of the hidden layer (<= 8)
   const size_t lds = edge_mfma_lds(NRB * 32, a.D, nw, bwd);
   if (bwd && a.U) {
-    static std::atomic<uint32_t> lds_done{0};
-    auto kern = edge_mfma_bwd_kernel<NRB, true>;
-    if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "edge_mfma_bwd")) return 1;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, s, a);
+    if constexpr (NRB <= 2) {
+      static std::atomic<uint32_t> lds_done{0};
+      auto kern = edge_mfma_bwd_kernel<NRB, true>;
+      if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "edge_mfma_bwd")) return 1;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, s, a);
+    } else {
+      set_error("edge_mfma_bwd with U: tiles above 64 rows are served by the VALU kernel"); return 2;
+    }
   } else if (bwd) {
     static std::atomic<uint32_t> lds_done{0};
     auto kern = edge_mfma_bwd_kernel<NRB, false>;
@@ -865,8 +869,7 @@ static int dispatch_edge_mfma(const EdgeTileArgs& a, int nrb, int grid, bool bwd
   switch (nrb) {
     case 1: return launch_edge_mfma<1>(a, grid, bwd, s);
     case 2: return launch_edge_mfma<2>(a, grid, bwd, s);
-    case 3: return launch_edge_mfma<3>(a, grid, bwd, s);
-    default: return launch_edge_mfma<4>(a, grid, bwd, s);
+    default: return launch_edge_mfma<3>(a, grid, bwd, s);
   }
 }
 
@@ -905,7 +908,9 @@ extern "C" int dss2_edge_tile_bwd(const float* x, int64_t ldx, const float* ea, 
   EdgeTileArgs a{x, ldx, ea, ldea, W1, b1, dS, tile_start, reinterpret_cast<const int2*>(ell_ent), nullptr, slab, U, ldu,
                  h, ell_width, nrb * 32, by_source, ntiles};
   // n_slabs workgroups walk the tiles (the slab buffer holds one partial per workgroup)
-  if (!by_source && edge_mfma_ok(h, nrb, ell_width, true))
+  // (96-row tiles WITH the per-row sums U, the PFN inner-block case: that instantiation misses its register budget, so it is
+  //  not compiled -- the VALU tile kernel below serves it)
+  if (!by_source && edge_mfma_ok(h, nrb, ell_width, true) && !(nrb == 3 && U))
     return dispatch_edge_mfma(a, nrb, n_slabs < ntiles ? n_slabs : ntiles, true, as_stream(stream));
   return launch_edge_tile<true>(a, n_slabs < ntiles ? n_slabs : ntiles, as_stream(stream));
 }

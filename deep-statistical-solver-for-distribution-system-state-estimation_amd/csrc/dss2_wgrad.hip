@@ -572,12 +572,25 @@ static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz, int ell_width, b
   return b;
 }
 
+// (nrb, nmat, nb) instantiations whose 8-wave register budget (256 VGPRs: two waves per SIMD) the compiler misses, i.e. that
+// spill into scratch (tools/kernel_resources.py, profiles/r02_kernel_resources.txt; tests/test_host_cpu.py keeps this list
+// honest).  They are neither dispatched nor compiled: the next narrower NB re-reads the X slab once more per output-block
+// group instead.
+constexpr bool wgrad_spills(int nrb, int nmat, int nb) {
+  constexpr int bad[][3] = {{1, 4, 4}, {2, 4, 4}, {3, 2, 4}, {3, 3, 4}, {3, 4, 4}, {4, 2, 2}, {4, 2, 4}, {4, 3, 4}, {4, 4, 4},
+                            {6, 2, 2}, {6, 3, 2}, {6, 4, 2}};
+  for (const auto& b : bad)
+    if (b[0] == nrb && b[1] == nmat && b[2] == nb) return true;
+  return false;
+}
+
 static int pick_nb(int nrb, int nmat, int hout, int max_nnz, int ell_width) {
   const int nob = (hout + 31) / 32;
   static const int nb_max = [] { const char* e = getenv("DSS2_WGRAD_NB"); return e ? atoi(e) : 4; }();   // tuning knob
   for (int nb = 4; nb >= 1; nb >>= 1) {
     if (nb > nb_max) continue;
     if (nb > 1 && nb / 2 >= nob) continue;  // do not over-allocate columns
+    if (wgrad_spills(nrb, nmat, nb)) continue;
     if (wgrad_lds(nrb, nmat, nb, max_nnz, ell_width, nmat > 1) <= (size_t)kMaxLdsBytes) return nb;
   }
   return 0;
@@ -633,7 +646,7 @@ static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::Wg
   if (!nb) { set_error("wgrad: tile of %d rows does not fit LDS (nmat=%d nnz=%d)", a.nrb * 32, a.nmat, a.max_nnz); return 3; }
   hipStream_t s = as_stream(stream);
 #define DSS2_CASE(NRB, NMAT, NB) \
-  if (a.nrb == NRB && a.nmat == NMAT && nb == NB) return launch_wgrad<NRB, NMAT, NB>(a, s, wb);
+  if constexpr (!wgrad_spills(NRB, NMAT, NB)) { if (a.nrb == NRB && a.nmat == NMAT && nb == NB) return launch_wgrad<NRB, NMAT, NB>(a, s, wb); }
 #define DSS2_NMATS(NRB, NB) DSS2_CASE(NRB, 1, NB) DSS2_CASE(NRB, 2, NB) DSS2_CASE(NRB, 3, NB) DSS2_CASE(NRB, 4, NB)
   DSS2_NMATS(1, 1) DSS2_NMATS(1, 2) DSS2_NMATS(1, 4)
   DSS2_NMATS(2, 1) DSS2_NMATS(2, 2) DSS2_NMATS(2, 4)

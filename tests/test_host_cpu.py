@@ -139,3 +139,28 @@ def test_product_package_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg_dir, fn)).read()
             assert "dss2_oracle" not in src and "import oracle" not in src, fn
+
+
+def test_no_kernel_in_the_library_spills_registers():
+    """Every kernel compiled into libdss2_hip.so stays inside its register budget (0 spilled VGPRs, 0 bytes of scratch):
+    instantiations that miss it are excluded at compile time (e.g. wgrad_spills in csrc/dss2_wgrad.hip) and their shapes
+    are served by a narrower one.  Re-compiles the kernel sources with -Rpass-analysis=kernel-resource-usage (hipcc
+    cross-compiles without a GPU; the files are compiled in parallel)."""
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    csrc = os.path.join(ROOT, "deep-statistical-solver-for-distribution-system-state-estimation_amd", "csrc")
+    files = sorted(f for f in os.listdir(csrc) if f.endswith(".hip"))
+    assert len(files) >= 9
+
+    def scan(fn):
+        out = subprocess.run(["python", os.path.join(ROOT, "tools", "kernel_resources.py"), os.path.join(csrc, fn)],
+                             capture_output=True, text=True, timeout=900).stdout
+        rows = [ln.split() for ln in out.splitlines()[1:] if ln.strip()]
+        return fn, [(" ".join(r[:-6]), int(r[-4]), int(r[-3])) for r in rows if r[-4].isdigit()]
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        results = list(ex.map(scan, files))
+    n_kernels = sum(len(k) for _, k in results)
+    assert n_kernels > 100, n_kernels
+    bad = [(fn, name, sp, scr) for fn, ks in results for name, sp, scr in ks if sp or scr]
+    assert not bad, bad

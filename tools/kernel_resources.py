@@ -4,8 +4,9 @@
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
+import tempfile
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", f"-I{ROOT}/include",
-       f"-I{os.path.dirname(os.path.abspath(src))}", "-c", src, "-o", "/tmp/_kr.o",
+       f"-I{os.path.dirname(os.path.abspath(src))}", "-c", src, "-o", tempfile.mktemp(suffix=".o", prefix="_kr"),
        "-Rpass-analysis=kernel-resource-usage"] + sys.argv[2:]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
