@@ -229,30 +229,45 @@ __device__ __forceinline__ float inv_sqrt_deg(int d) {   // torch CPU deg.pow(-0
 // blockIdx.y: 0 = CSR by target, 1 = CSR by source, 2 = incidence + degrees + segment statistics
 __global__ void __launch_bounds__(256) topo_finalize_kernel(const BuildPtrs p, const FinalPtrs f) {
   const int which = blockIdx.y;
-  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < p.N; r += (int64_t)gridDim.x * blockDim.x) {
-    if (which == 2) {
+  if (which == 2) {
+    // statistics: per-thread partials over the grid-stride loop, one wave reduction, ONE atomic per wave and slot (every
+    // row hammering the same five words would serialise the whole kernel in the L2 atomic unit)
+    int mdeg = 0, mdegT = 0, smax = 0, smin = 0x7fffffff, scnt = 0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < p.N; r += (int64_t)gridDim.x * blockDim.x) {
       const int i0 = f.inc_rowptr[r], ni = f.inc_rowptr[r + 1] - i0;
       sort_row(p.keysI + i0, ni);
       for (int k = 0; k < ni; ++k) f.inc_ent[i0 + k] = p.keysI[i0 + k];
       const int d = f.rowptr[r + 1] - f.rowptr[r];
       f.deg[r] = (float)d;
-      atomicMax(p.meta + 0, d);
-      atomicMax(p.meta + 1, f.rowptrT[r + 1] - f.rowptrT[r]);
+      mdeg = max(mdeg, d);
+      mdegT = max(mdegT, f.rowptrT[r + 1] - f.rowptrT[r]);
       const int q = (int)r + 1;                    // a legal cut at q closes the segment [lastcut[q - 1], q)
       if (f.lastcut[q] == q) {
         const int len = q - f.lastcut[q - 1];
-        atomicMax(p.meta + 2, len);
-        atomicAdd(p.meta + 3, 1);
-        atomicMin(p.meta + 4, len);
+        smax = max(smax, len);
+        smin = min(smin, len);
+        ++scnt;
       }
-      continue;
     }
+    for (int o = 32; o > 0; o >>= 1) {
+      mdeg = max(mdeg, __shfl_xor(mdeg, o));
+      mdegT = max(mdegT, __shfl_xor(mdegT, o));
+      smax = max(smax, __shfl_xor(smax, o));
+      smin = min(smin, __shfl_xor(smin, o));
+      scnt += __shfl_xor(scnt, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMax(p.meta + 0, mdeg);
+      atomicMax(p.meta + 1, mdegT);
+      if (scnt) { atomicMax(p.meta + 2, smax); atomicAdd(p.meta + 3, scnt); atomicMin(p.meta + 4, smin); }
+    }
+    return;
+  }
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < p.N; r += (int64_t)gridDim.x * blockDim.x) {
     const int32_t* rp = which == 0 ? f.rowptr : f.rowptrT;
     int32_t* keys = which == 0 ? p.keys : p.keysT;
     const int e0 = rp[r], n = rp[r + 1] - e0;
-    sort_row(keys + e0, n);
-    for (int k = 0; k < n; ++k) {
-      const int d = keys[e0 + k];
+    auto emit = [&](int k, int d) {
       const bool flip = d >= p.E;
       const int e = flip ? d - (int)p.E : d;
       const int a = f.efrom[e], b = f.eto[e];
@@ -262,6 +277,27 @@ __global__ void __launch_bounds__(256) topo_finalize_kernel(const BuildPtrs p, c
       const int en = (int)((uint32_t)e | ((flip && !p.no_flip) ? kFlip : 0u));
       if (which == 0) { f.col[e0 + k] = src; f.ent[e0 + k] = en; f.perm[e0 + k] = d; f.w[e0 + k] = wv; }
       else { f.colT[e0 + k] = tgt; f.entT[e0 + k] = en; f.permT[e0 + k] = d; f.wT[e0 + k] = wv; }
+    };
+    constexpr int RMAX = 8;
+    if (n <= RMAX) {
+      // the usual case (grid buses have a handful of branches): the row's slots are sorted in REGISTERS and the dependent
+      // lookups of its entries (endpoints, degrees) are then independent of each other, so their latencies overlap
+      int kreg[RMAX];
+#pragma unroll
+      for (int k = 0; k < RMAX; ++k) kreg[k] = k < n ? keys[e0 + k] : 0x7fffffff;
+#pragma unroll
+      for (int i = 1; i < RMAX; ++i)
+#pragma unroll
+        for (int j = i; j > 0; --j) {
+          const int lo = min(kreg[j - 1], kreg[j]), hi = max(kreg[j - 1], kreg[j]);
+          kreg[j - 1] = lo; kreg[j] = hi;
+        }
+#pragma unroll
+      for (int k = 0; k < RMAX; ++k)
+        if (k < n) emit(k, kreg[k]);
+    } else {
+      sort_row(keys + e0, n);
+      for (int k = 0; k < n; ++k) emit(k, keys[e0 + k]);
     }
   }
 }
