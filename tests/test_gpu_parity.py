@@ -196,6 +196,7 @@ def _train_step_pair(pkg, oracle, grids, B, hid, L, K=2, seed=0, cls="MPN", dim_
     (["cigre14"], 4096, 128, 4),                                # C2 (the headline configuration)
     (["ober_sub"], 1024, 128, 4),                               # C3
     (["cigre14", "cigre14_reswitched"], 512, 256, 8),           # C5's model on a mixed-topology shard
+    (["ober179"], 1024, 128, 4),                                # C3 read as "~180 buses": the synthetic 179-bus feeder, full size
 ])
 def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
     ref, mine, out_r, loss_r, out_m, loss_m, flows_m = _train_step_pair(pkg, oracle, grids, B, hid, L)

@@ -1,18 +1,48 @@
 #!/bin/bash
 # Round-end measurement set on the GPU box (run through gpurun): writes everything under gpurun_out/final/.
-#   bench line (with CPU baseline), rocprofv3 kernel stats of the same program, PMC passes for the two dominant
-#   kernels, the per-configuration table and the collate micro-benchmark.
+#   bench line (with the CPU baseline sweep), rocprofv3 kernel stats of the same program, PMC passes for the dominant
+#   kernels and for the cache-busting scatter-add, the per-configuration table, the driver's model line, batch assembly.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/final_stats -o s -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
-cp /tmp/final_stats/*kernel_stats.csv $O/kernel_stats_bench_c2.csv
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/final_stats -o s -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+find /tmp/final_stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_bench_c2.csv \;
+cd $R
 bash tools/pmc_one.sh chain > $O/pmc_gemm_chain.txt 2>&1
 bash tools/pmc_one.sh wgrad2 > $O/pmc_wgrad_batched.txt 2>&1
 rm -rf $R/gpurun_out/pmc1_*
+# scatter-add, cache-busting working set: FETCH_SIZE and WRITE_SIZE in separate passes (no trace domains besides kernel-trace)
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_scatter_$c -- python3 $R/tools/pmc_scatter.py 32768 10 > /dev/null 2>&1
+done
+python3 - > $O/pmc_scatter_add_b32768.txt <<'PY'
+import csv, glob, collections
+agg = collections.defaultdict(list); dur = []
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"/tmp/pmc_scatter_{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "segment_sum_kernel" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for f in glob.glob(f"/tmp/pmc_scatter_{c}/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "segment_sum_kernel" in r["Kernel_Name"]:
+                dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+dur.sort()
+print("dss2::segment_sum_kernel, B = 32768 CIGRE-14 graphs, H = 128 (msg 470 MB, out 252 MB, indices 5.6 MB)")
+print(f"launches {len(dur)}  median {dur[len(dur)//2]:.1f} us (under the counter passes)")
+f = sum(agg["FETCH_SIZE"]) / max(len(agg["FETCH_SIZE"]), 1); w = sum(agg["WRITE_SIZE"]) / max(len(agg["WRITE_SIZE"]), 1)
+print(f"FETCH_SIZE mean {f:.1f} KB (x2 on gfx950 for wide streaming reads = {2*f/1e3:.1f} MB)   WRITE_SIZE mean {w:.1f} KB = {w/1e3:.1f} MB")
+alg = 4.0 * 917504 * 128 + 4.0 * 491520 * 128 + 4.0 * 917504 + 4.0 * 491521
+print(f"HBM bytes per launch (2 x FETCH + WRITE) = {(2*f + w)*1e3/1e6:.1f} MB vs algorithmic {alg/1e6:.1f} MB")
+PY
+cd $R
 python3 tools/cfgbench.py > $O/cfgbench.txt 2>&1
+python3 tools/driverline.py > $O/driverline.txt 2>&1
 python3 tools/collate_bench.py > $O/collate_bench.txt 2>&1
+python3 tools/chainbench.py > $O/chainbench.txt 2>&1
 ls -la $O
