@@ -68,6 +68,14 @@ class EllBuildArgs(C.Structure):
                 ("ellT_ent_tiles", C.c_void_p), ("meta", C.c_void_p)]
 
 
+class CsrAxpyArgs(C.Structure):
+    _fields_ = [("rowptr", C.c_void_p), ("col", C.c_void_p), ("w", C.c_void_p), ("T", C.c_void_p), ("ldt", C.c_int64),
+                ("add", C.c_void_p), ("ld_add", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64), ("bias", C.c_void_p),
+                ("relu_src", C.c_void_p), ("ld_relu", C.c_int64), ("add_src", C.c_void_p), ("ld_src", C.c_int64),
+                ("drop_state", C.c_void_p), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float), ("drop_id", C.c_int32),
+                ("relu", C.c_int32), ("n_rows", C.c_int64), ("h", C.c_int32), ("pad_", C.c_int32)]
+
+
 class ReduceDesc(C.Structure):
     _fields_ = [("slab", C.c_void_p), ("out", C.c_void_p), ("stride", C.c_int64), ("len", C.c_int64),
                 ("n_slabs", C.c_int32), ("pad_", C.c_int32)]
@@ -130,6 +138,7 @@ _SIGNATURES = {
     "dss2_gate_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int32, C.c_float, C.c_int,
                                  C.c_void_p]),
     "dss2_dropout_params": (None, [C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
+    "dss2_csr_axpy": (C.c_int, [C.POINTER(CsrAxpyArgs), C.c_void_p]),
     "dss2_pack_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dss2_edge_hidden_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,

@@ -492,6 +492,58 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// One hop of the TAGConv propagation in GLOBAL memory, for graphs whose connected components exceed the LDS-resident
+// tiles (> 192 buses): out[i,:] = epi( add[i,:] + sum_{e in row i} w[e] * T[col[e],:] ), rows sorted as in the CSR.
+// A group of h/4 lanes owns a row and moves float4 (h % 4 == 0); HBM / L2-bound gather.  Epilogue (last hop of a layer
+// only): + bias, * in-kernel dropout mask, ReLU, * (relu_src > 0), + add_src -- the order of dss2_gemm_prop's epilogue.
+// ------------------------------------------------------------------------------------------
+struct CsrAxpyArgs {
+  const int32_t* rowptr; const int32_t* col; const float* w;
+  const float* T; int64_t ldt; const float* add; int64_t ld_add; float* out; int64_t ldo;
+  const float* bias; const float* relu_src; int64_t ld_relu; const float* add_src; int64_t ld_src;
+  const uint64_t* drop_state; uint32_t drop_thr; float drop_scale; int32_t drop_id; int32_t relu;
+  int64_t n_rows; int h;
+};
+template <int VEC>
+__global__ void __launch_bounds__(256) csr_axpy_kernel(const CsrAxpyArgs p) {
+  using V = float __attribute__((ext_vector_type(VEC)));
+  const int nv = (p.h + VEC - 1) / VEC;
+  const int64_t total = p.n_rows * nv;
+  const uint64_t seed = p.drop_id ? p.drop_state[0] : 0, off = p.drop_id ? p.drop_state[1] : 0;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / nv;
+    const int c = (int)(t - i * nv) * VEC;
+    V s;
+    if (p.add) s = *reinterpret_cast<const V*>(p.add + i * p.ld_add + c);
+    else s = V(0.f);
+    const int e1 = p.rowptr[i + 1];
+    for (int e = p.rowptr[i]; e < e1; ++e) {
+      const V v = *reinterpret_cast<const V*>(p.T + (int64_t)p.col[e] * p.ldt + c);
+      const float wv = p.w[e];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) s[q] = fmaf(wv, v[q], s[q]);
+    }
+    if (p.bias) s += *reinterpret_cast<const V*>(p.bias + c);
+    if (p.drop_id) {     // the mask is defined per group of four columns (dropout_mult4)
+      const f32x4 m = dropout_mult4(seed, off, (uint32_t)p.drop_id, (uint32_t)i, (uint32_t)(c >> 2), p.drop_thr, p.drop_scale);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) s[q] *= m[(c + q) & 3];
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) s[q] = fmaxf(s[q], 0.f);
+    }
+    if (p.relu_src) {
+      const V r = *reinterpret_cast<const V*>(p.relu_src + i * p.ld_relu + c);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) s[q] = r[q] > 0.f ? s[q] : 0.f;
+    }
+    if (p.add_src) s += *reinterpret_cast<const V*>(p.add_src + i * p.ld_src + c);
+    *reinterpret_cast<V*>(p.out + i * p.ldo + c) = s;
+  }
+}
+
 // out[j] = sum_k slab[k][j].  blockDim = (64, 4): threadIdx.y owns a contiguous quarter of the slabs
 // and keeps 8 independent loads in flight; partial sums are combined in a fixed order, so the
 // result is bitwise reproducible (no atomics).
@@ -945,6 +997,24 @@ extern "C" int dss2_edge_combine_bwd(const float* AB, int64_t ldab, const float*
   if (fpl == 1) L(1); else if (fpl == 2) L(2); else if (fpl == 3) L(3); else L(4);
 #undef L
   return check_launch("edge_combine_bwd");
+}
+
+extern "C" int dss2_csr_axpy(const dss2_csr_axpy_args* ap, void* stream) {
+  const dss2_csr_axpy_args& a = *ap;
+  if (a.n_rows <= 0) return 0;
+  if (!a.rowptr || !a.col || !a.w || !a.T || !a.out || a.h <= 0) { set_error("csr_axpy: bad arguments"); return 2; }
+  if (a.drop_id && !a.drop_state) { set_error("csr_axpy: in-kernel dropout needs drop_state"); return 2; }
+  auto al = [](const void* q, int64_t ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0; };
+  const bool vec = (a.h & 3) == 0 && al(a.T, a.ldt) && al(a.out, a.ldo) && (!a.add || al(a.add, a.ld_add)) &&
+                   (!a.relu_src || al(a.relu_src, a.ld_relu)) && (!a.add_src || al(a.add_src, a.ld_src)) &&
+                   (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
+  CsrAxpyArgs k{a.rowptr, a.col, a.w, a.T, a.ldt, a.add, a.ld_add, a.out, a.ldo, a.bias, a.relu_src, a.ld_relu, a.add_src, a.ld_src,
+                a.drop_state, a.drop_thr, a.drop_scale, a.drop_id, a.relu, a.n_rows, a.h};
+  int64_t blocks = (a.n_rows * (vec ? a.h / 4 : a.h) + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (vec) hipLaunchKernelGGL(csr_axpy_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), k);
+  else hipLaunchKernelGGL(csr_axpy_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), k);
+  return check_launch("csr_axpy");
 }
 
 extern "C" int dss2_segment_sum(const float* msg, int64_t ldm, const int32_t* rowptr, const int32_t* ent, float* out,

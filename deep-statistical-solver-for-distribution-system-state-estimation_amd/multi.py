@@ -29,7 +29,7 @@ import torch.nn as nn
 from . import _lib
 from .networks import (_F32, _DESC_DTYPE, _MPNFn, _PackPlan, _MatView, _ncg, _require_gpu, _round8, _rows, _stream,
                        MPN, TAGConv, dropout_snapshot, gemm_prop, is_narrow, wgrad, _reduce, _tagconv_forward,
-                       _tagconv_backward)
+                       _tagconv_backward, _tagconv_forward_global, _tagconv_backward_global)
 from .topology import Topology, get_topology
 
 
@@ -182,14 +182,14 @@ class _TAGConvPostFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, topo, mod, bias, *ws):
         x = x.contiguous()
-        if mod._plan is None or mod._plan.device != x.device:
-            mod._plan = _PackPlan([list(ws)], x.device)
+        if mod._plan is None or mod._plan.device != x.device or mod._plan.stacked != topo.global_only:
+            mod._plan = _PackPlan([list(ws)], x.device, stacked=topo.global_only)
         plan = mod._plan
         ctx.ver = plan.refresh()
         hin, hout, nmat = mod.in_channels, mod.out_channels, mod.K + 1
         topo.lds_check(nmat, _round8(hin), _ncg(hout))
         relu, snap, p = _post_spec(mod, x.device)
-        out = _tagconv_forward(topo, x, plan.fwd[0], bias, nmat, hin, hout, relu=relu,
+        out = (_tagconv_forward_global if topo.global_only else _tagconv_forward)(topo, x, plan.fwd[0], bias, nmat, hin, hout, relu=relu,
                                drop=((snap, p, 1) if snap is not None else None))
         ctx.save_for_backward(x, out)
         ctx.meta = (topo, mod, relu, snap, p)
@@ -205,7 +205,10 @@ class _TAGConvPostFn(torch.autograd.Function):
         hin, hout, nmat = mod.in_channels, mod.out_channels, mod.K + 1
         g = _gate(gout, y, snap, p) if relu else gout.contiguous()
         flat = torch.empty(nmat * hout * hin + hout, dtype=_F32, device=g.device)
-        dh = _tagconv_backward(topo, g, x, plan.bwd[0], nmat, hin, hout, flat, need_dh=ctx.needs_input_grad[0])
+        if plan.stacked != topo.global_only:
+            raise RuntimeError("the module's weight layouts changed between forward and backward")
+        dh = (_tagconv_backward_global if topo.global_only else _tagconv_backward)(
+            topo, g, x, plan.bwd[0], nmat, hin, hout, flat, need_dh=ctx.needs_input_grad[0])
         gw = [flat[m * hout * hin:(m + 1) * hout * hin].view(hout, hin) for m in range(nmat)]
         return (dh, None, None, flat[nmat * hout * hin:], *gw)
 
@@ -251,7 +254,12 @@ class _MaskEmbdFn(torch.autograd.Function):
         gemm_prop(topo, g, fn, fn, plan.bwd[1], 1, h, dh1, relu_src=h1)
         g1 = torch.empty(h * fn + h, dtype=_F32, device=dev)
         wgrad(topo, dh1, h, mask, fn, 1, g1)
-        return None, None, None, None, g1[:h * fn].view(h, fn), g1[h * fn:], g2[:fn * h].view(fn, h), g2[fn * h:]
+        dmask = None
+        if ctx.needs_input_grad[0]:          # data.x requires grad: the mask columns receive dh1 W1, the features g itself
+            dmask = torch.empty(topo.N, fn, dtype=_F32, device=dev)
+            gemm_prop(topo, dh1, h, h, plan.bwd[0], 1, fn, dmask)
+        dx = g if ctx.needs_input_grad[1] else None
+        return dmask, dx, None, None, g1[:h * fn].view(h, fn), g1[h * fn:], g2[:fn * h].view(fn, h), g2[fn * h:]
 
 
 def _mask_embd(mod: nn.Module, data_x: torch.Tensor, topo: Topology):

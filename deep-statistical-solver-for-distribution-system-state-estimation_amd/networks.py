@@ -77,6 +77,10 @@ def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.T
               relu: bool = False, transposed: bool = False, prop_in: int = 0, narrow_h: int = 0,
               prebias=None, pre_rowscale=None, drop=None) -> None:
     """drop = (snapshot, p, drop_id): in-kernel dropout mask of layer drop_id (see dropout_snapshot)."""
+    if topo.global_only and (nmat > 1 or prop_in > 0):
+        raise NotImplementedError(f"largest connected component has {topo.max_segment} nodes: the fused GEMM + propagation "
+                                  "kernels hold a whole graph in LDS (<= 192 nodes); use the MPN / TAGConv modules, which "
+                                  "switch to the global-memory propagation path")
     a = _lib.GemmPropArgs()
     if drop is not None and drop[2] > 0:
         a.drop_state, a.drop_id = drop[0].data_ptr(), int(drop[2])
@@ -148,9 +152,12 @@ def gemm_prop_chain(topo: Topology, X: torch.Tensor, hid: int, nmat: int, layers
 
 
 def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int, nmat: int, out_flat: torch.Tensor,
-          rowscale=None, rowscale2=None, pending=None) -> None:
+          rowscale=None, rowscale2=None, pending=None, out_len: Optional[int] = None) -> None:
     """out_flat[nmat*hout*hin + hout] <- [dW_0 .. dW_{nmat-1}, db] (deterministic two-pass sum); with
-    rowscale2 additionally [nmat*hout] scaled column sums of P^m G (one block per matrix)."""
+    rowscale2 additionally [nmat*hout] scaled column sums of P^m G (one block per matrix).  ``out_len``: reduce only
+    the first out_len elements of the result."""
+    if topo.global_only and nmat > 1:
+        raise NotImplementedError("wgrad with propagation needs LDS-resident graph tiles (graphs of <= 192 nodes)")
     narrow = nmat > 1 and nmat * hout <= 32 and rowscale2 is None
     lds = _lib.lib().dss2_wgrad_lds_bytes(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT)
     per_cu = _wgrad_per_cu(int(lds))
@@ -168,7 +175,7 @@ def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int,
     a.narrow = int(narrow)
     st = _stream(G)
     _lib.check(_lib.lib().dss2_wgrad(C.byref(a), st), "dss2_wgrad")
-    _reduce(slab, 0, n_split, stride, out_flat, stride, pending)
+    _reduce(slab, 0, n_split, stride, out_flat, stride if out_len is None else out_len, pending)
 
 
 def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Sequence[torch.Tensor], hin: int, nmat: int,
@@ -373,17 +380,20 @@ class _PackPlan:
     """Fragment-packed copies (forward and data-gradient layouts) of a list of weight matrices,
     refreshed by ONE kernel launch per forward."""
 
-    def __init__(self, groups: Sequence[Sequence[torch.Tensor]], device):
+    def __init__(self, groups: Sequence[Sequence[torch.Tensor]], device, stacked: bool = False):
         # groups[g] = the nmat matrices [hout, hin] of one fused GEMM (TAGConv lins, or one Linear);
-        # entries are Parameters or _MatView blocks of a Parameter
+        # entries are Parameters or _MatView blocks of a Parameter.
+        # stacked: every group uses the narrow layouts whatever its width -- forward = matrices side by side along the
+        # output columns, data-gradient = stacked along k -- as ONE plain GEMM (the global-memory propagation path)
         self.groups = groups = [[_as_view(w) for w in mats] for mats in groups]
         self.device = device
+        self.stacked = stacked
         self.fwd, self.bwd, self.meta = [], [], []
         for mats in groups:
             hout, hin = mats[0].shape
             nm = len(mats)
-            if is_narrow(nm, hout):
-                kf, cf, kb, cb = _round8(hin), 1, _round8(nm * hout), _ncg(hin)
+            if is_narrow(nm, hout) or (stacked and nm > 1):
+                kf, cf, kb, cb = _round8(hin), _ncg(nm * hout), _round8(nm * hout), _ncg(hin)
                 self.fwd.append(torch.zeros(cf * (kf // 8) * 256, dtype=_F32, device=device))
                 self.bwd.append(torch.zeros(cb * (kb // 8) * 256, dtype=_F32, device=device))
             else:
@@ -400,7 +410,7 @@ class _PackPlan:
         recs = []
         for g, mats in enumerate(self.groups):
             nm, hout, hin, kf, cf, kb, cb = self.meta[g]
-            narrow = is_narrow(nm, hout)
+            narrow = is_narrow(nm, hout) or (self.stacked and nm > 1)
             for m, w in enumerate(mats):
                 if not w.is_contiguous():
                     raise RuntimeError("weight matrices must be contiguous")
@@ -515,6 +525,72 @@ def _tagconv_forward(topo, h, pack_fwd, bias, nmat, hin, hout, dmask=None, relu=
               add_src=add_src, add_ld=add_ld, narrow_h=(hout if narrow else 0),
               prebias=prebias, pre_rowscale=pre_rowscale, drop=drop)
     return out
+
+
+def csr_axpy(topo: Topology, T: torch.Tensor, out: torch.Tensor, h: int, add=None, transposed: bool = False, bias=None,
+             relu: bool = False, relu_src=None, add_src=None, add_ld: int = 0, drop=None) -> None:
+    """out[:, :h] = epi(add[:, :h] + A_hat T[:, :h]) -- one propagation hop in global memory (dss2_csr_axpy); T, add and
+    out may be column blocks of wider row-major buffers (their stride(0) is the leading dimension)."""
+    a = _lib.CsrAxpyArgs()
+    if transposed:
+        a.rowptr, a.col, a.w = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr()
+    else:
+        a.rowptr, a.col, a.w = topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.w.data_ptr()
+    a.T, a.ldt, a.out, a.ldo = T.data_ptr(), T.stride(0), out.data_ptr(), out.stride(0)
+    a.add, a.ld_add = _ptr(add), (add.stride(0) if add is not None else 0)
+    a.bias, a.relu = _ptr(bias), int(relu)
+    a.relu_src, a.ld_relu = _ptr(relu_src), (relu_src.stride(0) if relu_src is not None else 0)
+    a.add_src, a.ld_src = _ptr(add_src), add_ld
+    if drop is not None and drop[2] > 0:
+        a.drop_state, a.drop_id = drop[0].data_ptr(), int(drop[2])
+        a.drop_thr, a.drop_scale = _dropout_params(drop[1])
+    a.n_rows, a.h = topo.N, h
+    _lib.check(_lib.lib().dss2_csr_axpy(C.byref(a), _stream(out)), "dss2_csr_axpy")
+
+
+def _tagconv_forward_global(topo, h, pack_fwd, bias, nmat, hin, hout, relu=False, add_src=None, add_ld=0, drop=None):
+    """TAGConv for graphs beyond the LDS-resident tiles (> 192 nodes): ONE plain tile GEMM X [W_0|..|W_K]^T, then K
+    propagation hops in global memory in Horner order, the last one carrying the epilogue.  ``pack_fwd`` is the stacked
+    layout of _PackPlan(stacked=True)."""
+    N, dev = topo.N, h.device
+    out = torch.empty(N, hout, dtype=_F32, device=dev)
+    if nmat == 1:
+        gemm_prop(topo, h, h.stride(0), hin, pack_fwd, 1, hout, out, bias=bias, relu=relu, add_src=add_src, add_ld=add_ld, drop=drop)
+        return out
+    wcat = nmat * hout
+    Gc = torch.empty(N, (wcat + 3) // 4 * 4, dtype=_F32, device=dev)
+    gemm_prop(topo, h, h.stride(0), hin, pack_fwd, 1, wcat, Gc)
+    T = Gc[:, (nmat - 1) * hout:]
+    for m in range(nmat - 2, -1, -1):
+        blk = Gc[:, m * hout:(m + 1) * hout]
+        if m > 0:
+            csr_axpy(topo, T, blk, hout, add=blk)          # in place: T_m = G_m + A_hat T_{m+1}
+            T = blk
+        else:
+            csr_axpy(topo, T, out, hout, add=blk, bias=bias, relu=relu, add_src=add_src, add_ld=add_ld, drop=drop)
+    return out
+
+
+def _tagconv_backward_global(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=None, need_dh=True, pending=None, drop=None):
+    """Backward of _tagconv_forward_global.  Z = [g | A^T g | .. | (A^T)^K g] (K hops in global memory); then
+    dW_m = Z_m^T h and db as ONE weight-gradient launch on the stacked Z, dh = Z [W_0; ..; W_K] as ONE plain GEMM."""
+    N, dev = topo.N, g.device
+    if nmat == 1:
+        Z, wcat = g, hout
+    else:
+        wcat = nmat * hout
+        Z = torch.empty(N, (wcat + 3) // 4 * 4, dtype=_F32, device=dev)
+        if Z.size(1) != wcat:
+            Z[:, wcat:].zero_()
+        Z[:, :hout].copy_(g)
+        for m in range(1, nmat):
+            csr_axpy(topo, Z[:, (m - 1) * hout:], Z[:, m * hout:], hout, transposed=True)
+    wgrad(topo, Z, wcat, h, hin, 1, g_flat, pending=pending, out_len=wcat * hin + hout)
+    if not need_dh:
+        return None
+    dh = torch.empty(N, hin, dtype=_F32, device=dev)
+    gemm_prop(topo, Z, Z.stride(0), wcat, pack_bwd, 1, hin, dh, relu_src=relu_src, drop=drop)
+    return dh
 
 
 _DROP_PARAMS = {}
@@ -734,13 +810,13 @@ class _TAGConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, topo, mod, bias, *ws):
         x = x.contiguous()
-        if mod._plan is None or mod._plan.device != x.device:
-            mod._plan = _PackPlan([list(ws)], x.device)
+        if mod._plan is None or mod._plan.device != x.device or mod._plan.stacked != topo.global_only:
+            mod._plan = _PackPlan([list(ws)], x.device, stacked=topo.global_only)
         plan = mod._plan
         ctx.ver = plan.refresh()
         hin, hout, nmat = mod.in_channels, mod.out_channels, mod.K + 1
         topo.lds_check(nmat, _round8(hin), _ncg(hout))
-        out = _tagconv_forward(topo, x, plan.fwd[0], bias, nmat, hin, hout)
+        out = (_tagconv_forward_global if topo.global_only else _tagconv_forward)(topo, x, plan.fwd[0], bias, nmat, hin, hout)
         ctx.save_for_backward(x)
         ctx.topo, ctx.mod = topo, mod
         return out
@@ -754,7 +830,10 @@ class _TAGConvFn(torch.autograd.Function):
         hin, hout, nmat = mod.in_channels, mod.out_channels, mod.K + 1
         g = gout.contiguous()
         flat = torch.empty(nmat * hout * hin + hout, dtype=_F32, device=g.device)
-        dh = _tagconv_backward(topo, g, x, plan.bwd[0], nmat, hin, hout, flat, need_dh=ctx.needs_input_grad[0])
+        if plan.stacked != topo.global_only:
+            raise RuntimeError("the module's weight layouts changed between forward and backward")
+        dh = (_tagconv_backward_global if topo.global_only else _tagconv_backward)(
+            topo, g, x, plan.bwd[0], nmat, hin, hout, flat, need_dh=ctx.needs_input_grad[0])
         gw = [flat[m * hout * hin:(m + 1) * hout * hin].view(hout, hin) for m in range(nmat)]
         gb = flat[nmat * hout * hin:]
         return (dh, None, None, gb, *gw)
@@ -889,14 +968,15 @@ class _MPNFn(torch.autograd.Function):
         W1, b1, W2, b2 = ps[0:4]
         conv_ps = [ps[4 + l * (nmat + 1): 4 + (l + 1) * (nmat + 1)] for l in range(L)]   # (bias, W_0..W_K)
         hout0 = mod.dim_out if L == 1 else hid
-        fold_on = FOLD_W2 and not is_narrow(nmat, hout0)
-        if mod._plan is None or mod._plan.device != dev or (mod._fold is not None) != fold_on:
+        glob = topo.global_only       # graphs beyond the LDS-resident tiles: plain GEMMs + propagation hops in global memory
+        fold_on = FOLD_W2 and not is_narrow(nmat, hout0) and not glob
+        if mod._plan is None or mod._plan.device != dev or (mod._fold is not None) != fold_on or mod._plan.stacked != glob:
             offs = mod._flat_offsets()
             mod._fold = _FoldPlan(W2, b2, conv_ps[0][1:], dev, int(offs[1]), int(offs[2])) if fold_on else None
             conv_groups = [list(cp[1:]) for cp in conv_ps]
             if fold_on:   # conv 0 is packed from the folded weights
                 conv_groups[0] = [mod._fold.Wf[m] for m in range(nmat)]
-            mod._plan = _PackPlan([[W2]] + conv_groups + _dx_views(W1, hid, mod.dim_featn, mod.dim_feate), dev)
+            mod._plan = _PackPlan([[W2]] + conv_groups + _dx_views(W1, hid, mod.dim_featn, mod.dim_feate), dev, stacked=glob)
         plan, fold = mod._plan, mod._fold
         if fold is not None:
             fold.params = (W2, b2, list(conv_ps[0][1:]))
@@ -932,6 +1012,13 @@ class _MPNFn(torch.autograd.Function):
         for l in range(n_chain, L):
             last = l == L - 1
             hout = mod.dim_out if last else hid
+            if glob:
+                h = _tagconv_forward_global(topo, h, plan.fwd[1 + l], conv_ps[l][0], nmat, hid, hout, relu=not last,
+                                            add_src=(x if (last and mod.skip) else None), add_ld=ldx,
+                                            drop=((snap, p, drop_id(l)) if snap is not None else None))
+                if not last:
+                    acts.append(h)
+                continue
             pre = (fold.bf, topo.deg_pows) if (fold is not None and l == 0) else (None, None)
             h = _tagconv_forward(topo, h, plan.fwd[1 + l], conv_ps[l][0], nmat, hid, hout, relu=not last,
                                  add_src=(x if (last and mod.skip) else None), add_ld=ldx,
@@ -940,12 +1027,12 @@ class _MPNFn(torch.autograd.Function):
             if not last:
                 acts.append(h)
         ctx.save_for_backward(x, ea, S, *acts, *ps)
-        ctx.meta = (topo, mod, ldx, ldea, len(acts), (snap, p), fold is not None)
+        ctx.meta = (topo, mod, ldx, ldea, len(acts), (snap, p), fold is not None, glob)
         return h
 
     @staticmethod
     def backward(ctx, gout):
-        topo, mod, ldx, ldea, n_acts, (snap, p_drop), folded = ctx.meta
+        topo, mod, ldx, ldea, n_acts, (snap, p_drop), folded, glob = ctx.meta
         saved = ctx.saved_tensors
         x, ea, S = saved[0:3]
         acts = list(saved[3:3 + n_acts])
@@ -954,7 +1041,7 @@ class _MPNFn(torch.autograd.Function):
         def drop_of(l):            # the mask that was applied to conv l's output: (snapshot, p, id) or None
             return (snap, p_drop, l + 1) if snap is not None else None
         plan, fold = mod._plan, mod._fold
-        if folded != (fold is not None):
+        if folded != (fold is not None) or plan.stacked != glob:
             raise RuntimeError("DSS2_FOLD_W2 / the module's plan changed between forward and backward")
         if plan.version != ctx.ver:
             if fold is not None:
@@ -1026,6 +1113,11 @@ class _MPNFn(torch.autograd.Function):
                 g = None
                 break
             # dgrad epilogue applies the ReLU / dropout mask of the layer BELOW (its output is acts[l])
+            if glob:
+                g = _tagconv_backward_global(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, hout, seg,
+                                             relu_src=(acts[l] if l > 0 else None),
+                                             drop=(drop_of(l - 1) if l > 0 else None))
+                continue
             defer = WGRAD_BATCH and not WGRAD_SIDE_STREAM and hout == hid and not is_narrow(nmat, hout)
             if defer:
                 deferred.append((l, g, acts[l]))

@@ -11,8 +11,9 @@ Two parts, built separately:
   edges, int32 endpoints, in-degrees, gcn_norm weights -- all the loss kernels, ``MessagePassing.propagate`` and
   ``segment_sum`` need; asynchronous, any graph size;
 * the tile part (lazily, when a tile kernel asks for it): whole-graph tiles of <= 32*nrb rows and the per-tile ELL
-  slices the tile kernels stage in LDS.  A connected component above 192 rows has no tile structure
-  (``NotImplementedError`` from the network kernels only).
+  slices the tile kernels stage in LDS.  A connected component above 192 rows has no graph-aligned tiles:
+  ``global_only`` is set, the plain GEMMs run on uniform 64-row tiles and the propagation in global memory
+  (networks._tagconv_forward_global).
 
 Host synchronisation: none when the caller passes a :class:`TopologyHint` (the device data loader does: it knows
 its samples' sizes and degrees); otherwise one 24-byte copy for the cache key + directedness and one 64-byte copy of
@@ -34,7 +35,7 @@ _FLIP = 1 << 31
 _NRB_CHOICES = (2, 4, 3, 1, 6)   # preference order on utilisation ties (32*nrb rows per tile)
 _LDS_LIMIT = 160 * 1024
 _ELL_MAX = 8
-_TILE_ATTRS = frozenset(["nrb", "ntiles", "tile_start", "utilisation", "max_segment", "max_nnz", "max_nnzT", "ell", "ellT",
+_TILE_ATTRS = frozenset(["global_only", "nrb", "ntiles", "tile_start", "utilisation", "max_segment", "max_nnz", "max_nnzT", "ell", "ellT",
                          "ell_tiles", "ellT_tiles", "ell_ent_tiles", "ellT_ent_tiles"])
 
 
@@ -167,7 +168,7 @@ class Topology:
                 if best is None or util > best[0] + 0.03:
                     best = (util, cand, nt, per)
             if best is None:
-                raise NotImplementedError(f"graphs of {n} nodes; the LDS-resident tile kernels support up to {32 * max(choices)} nodes per graph")
+                return self._global_tiles(n)
             util, nrb, nt, per = best
             tile_start = torch.empty(nt + 1, dtype=torch.int32, device=dev)
             _lib.check(L.dss2_tiles_uniform(tile_start.data_ptr(), nt, per * n, N, st), "dss2_tiles_uniform")
@@ -195,9 +196,7 @@ class Topology:
                 if best is None or util > best[0] + 0.03:
                     best = (util, cand, nt, i)
             if best is None:
-                raise NotImplementedError(
-                    f"largest connected component has {max_segment} nodes; the LDS-resident tile kernels "
-                    f"support up to {32 * max(choices)} nodes per graph")
+                return self._global_tiles(max_segment)
             util, nrb, nt, i = best
             tile_start = cands[i][:nt + 1].clone()
             nnz_bound, exact_nnz = 0, True
@@ -224,10 +223,22 @@ class Topology:
             max_nnz, max_nnzT = max_deg * tm, max_degT * tm
         else:
             max_nnz = max_nnzT = nnz_bound
-        self.__dict__.update(nrb=nrb, ntiles=nt, tile_start=tile_start, utilisation=util, max_segment=max_segment,
+        self.__dict__.update(global_only=False, nrb=nrb, ntiles=nt, tile_start=tile_start, utilisation=util, max_segment=max_segment,
                              max_nnz=max_nnz, max_nnzT=max_nnzT, ell=ell, ellT=ellT, ell_tiles=ell_tiles,
                              ellT_tiles=ellT_tiles, ell_ent_tiles=ell_ent_tiles, ellT_ent_tiles=ellT_ent_tiles)
         self._stats = None            # (the ELL build added the per-tile entry counts to the statistics)
+        self._tiles_built = True
+
+    def _global_tiles(self, max_segment: int) -> None:
+        """A connected component exceeds the largest LDS-resident tile (192 rows): no graph-aligned tiles exist.  The
+        plain GEMMs still run on uniform 64-row tiles; the propagation hops run in global memory on the CSR
+        (dss2_csr_axpy) and the edge MLP on the row-per-wave CSR kernels (networks._tagconv_forward_global)."""
+        nt = -(-self.N // 64)
+        tile_start = torch.empty(nt + 1, dtype=torch.int32, device=self.device)
+        _lib.check(_lib.lib().dss2_tiles_uniform(tile_start.data_ptr(), nt, 64, self.N, _stream(self.device)), "dss2_tiles_uniform")
+        self.__dict__.update(global_only=True, nrb=2, ntiles=nt, tile_start=tile_start, utilisation=self.N / float(nt * 64),
+                             max_segment=max_segment, max_nnz=0, max_nnzT=0, ell=0, ellT=0, ell_tiles=None, ellT_tiles=None,
+                             ell_ent_tiles=None, ellT_ent_tiles=None)
         self._tiles_built = True
 
     @property
@@ -244,6 +255,12 @@ class Topology:
         return self._deg_pows
 
     def lds_check(self, nmat: int, kpad: int, ncg: int) -> None:
+        if self.global_only:     # plain GEMMs only: forward K=kpad -> nmat*hout columns, data-gradient K=nmat*hout -> kpad
+            f = _lib.lib().dss2_gemm_prop_lds_bytes
+            need = max(f(self.nrb, 1, kpad, nmat * ncg, 0, 0), f(self.nrb, 1, nmat * ncg * 32, (kpad + 31) // 32, 0, 0))
+            if need > _LDS_LIMIT:
+                raise NotImplementedError(f"global-memory path: a 64-row tile x K={nmat * ncg * 32} needs {need} B of LDS (> 160 KiB)")
+            return
         need = _lib.lib().dss2_gemm_prop_lds_bytes(self.nrb, nmat, kpad, ncg, max(self.max_nnz, self.max_nnzT),
                                                     min(self.ell, self.ellT))
         if need > _LDS_LIMIT:

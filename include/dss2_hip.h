@@ -271,6 +271,22 @@ int dss2_gate_grad(const float* g, const float* y, float* out, int64_t n_rows, i
 /* host helper: drop_thr / drop_scale for a dropout rate p (the one definition both sides use) */
 void dss2_dropout_params(float p, uint32_t* thr, float* scale);
 
+/* ---- one propagation hop in global memory: out[i,:] = epi(add[i,:] + sum_{e in CSR row i} w[e] T[col[e],:]).  The TAGConv
+ *      path for graphs whose connected components exceed the LDS-resident tiles (> 192 buses): a layer is then one plain
+ *      tile GEMM (dss2_gemm_prop, nmat = 1, the K+1 matrices side by side) and K of these hops; epilogue fields as in
+ *      dss2_gemm_prop_args, applied in the same order (bias, dropout, relu, relu_src gate, add_src).  float4 lanes when h % 4 == 0 and
+ *      every operand is 16-byte aligned, scalar lanes otherwise.                                                          */
+typedef struct dss2_csr_axpy_args {
+  const int32_t* rowptr; const int32_t* col; const float* w;
+  const float* T; int64_t ldt;             /* gathered operand [N, >= h]                        */
+  const float* add; int64_t ld_add;        /* optional addend (G_m of the Horner recurrence)     */
+  float* out; int64_t ldo;
+  const float* bias; const float* relu_src; int64_t ld_relu; const float* add_src; int64_t ld_src;
+  const uint64_t* drop_state; uint32_t drop_thr; float drop_scale; int32_t drop_id; int32_t relu;
+  int64_t n_rows; int32_t h; int32_t pad_;
+} dss2_csr_axpy_args;
+int dss2_csr_axpy(const dss2_csr_axpy_args* args_host, void* stream);
+
 /* ---- K4: weight gradient of TAGConv / Linear -------------------------------------------- *
  * dW_m[o,i] = sum_n (P^m G)[n,o] * X[n,i]   (P = A_hat^T via the CSR by source), m < nmat,
  * db[o] = sum_n G[n,o] * (rowscale ? rowscale[n] : 1).
