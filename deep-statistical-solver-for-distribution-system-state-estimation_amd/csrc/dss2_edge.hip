@@ -572,7 +572,8 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restri
 }
 
 // several reductions in one launch (blockIdx.y = reduction): the small ones are launch/latency-bound on their own
-struct ReduceTable { dss2_reduce_desc d[8]; };
+constexpr int REDUCE_MAX_DESC = 32;      // by-value table: 32 x 40 B of the 4 KiB kernel-argument space
+struct ReduceTable { dss2_reduce_desc d[REDUCE_MAX_DESC]; };
 __global__ void __launch_bounds__(256) reduce_slabs_multi_kernel(const ReduceTable tab) {
   __shared__ float part[4][64];
   const dss2_reduce_desc& d = tab.d[blockIdx.y];
@@ -1060,7 +1061,7 @@ extern "C" int dss2_reduce_slabs(const float* slab, int n_slabs, int64_t stride,
 
 extern "C" int dss2_reduce_slabs_multi(const dss2_reduce_desc* descs_host, int n_desc, void* stream) {
   if (n_desc <= 0) return 0;
-  if (!descs_host || n_desc > 8) { set_error("reduce_slabs_multi: 1..8 descriptors, got %d", n_desc); return 2; }
+  if (!descs_host || n_desc > REDUCE_MAX_DESC) { set_error("reduce_slabs_multi: 1..%d descriptors, got %d", REDUCE_MAX_DESC, n_desc); return 2; }
   ReduceTable tab = {};
   int64_t max_len = 0;
   for (int i = 0; i < n_desc; ++i) {

@@ -228,8 +228,8 @@ def _reduce(slab: torch.Tensor, slab_off: int, n_slabs: int, stride: int, out: t
 
 
 def reduce_pending(pending) -> None:
-    for c0 in range(0, len(pending), 8):
-        chunk = pending[c0:c0 + 8]
+    for c0 in range(0, len(pending), 32):
+        chunk = pending[c0:c0 + 32]
         descs = (_lib.ReduceDesc * len(chunk))()
         for d, (slab, ptr, n_slabs, stride, out, length) in zip(descs, chunk):
             d.slab, d.out, d.stride, d.len, d.n_slabs = ptr, out.data_ptr(), stride, length, n_slabs
@@ -269,6 +269,20 @@ def _sg(A, B, M, N, K, lda, ldb, ldc, C=0, c_off=-1, tA=0, tB=0, u=0, v=0):
     return (A, B, C, u, v, c_off, M, N, K, lda, ldb, ldc, tA, tB, nb, 0)
 
 
+def _sg_table(recs, device):
+    """(device table, record count, largest output in 32x32 blocks) of a list of small-GEMM records."""
+    arr = np.zeros(len(recs), dtype=_SG_DTYPE)
+    for i, r in enumerate(recs):
+        arr[i] = tuple(r)
+    return (torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(recs),
+            max(((r[6] + 31) // 32) * ((r[7] + 31) // 32) for r in recs))
+
+
+def _small_gemm(tab, base, device) -> None:
+    t, cnt, mx = tab
+    _lib.check(_lib.lib().dss2_small_gemm(t.data_ptr(), cnt, mx, base, torch.cuda.current_stream(device).cuda_stream), "dss2_small_gemm")
+
+
 class _FoldPlan:
     """The edge MLP's second Linear folded into the first TAGConv (same mathematics):
         conv0(S W2^T + deg b2^T) = sum_m A^m (S (W_m W2)^T) + sum_m (A^m deg) (W_m b2)^T + bias
@@ -291,11 +305,14 @@ class _FoldPlan:
         self.off_w2, self.off_conv0 = off_w2, off_conv0
         self.ptrs = None
 
-    def _tables(self):
+    def records(self, base_off: int = 0):
+        """(forward, backward) small-GEMM records; backward outputs are element offsets from the flat gradient buffer
+        handed to the launch, shifted by ``base_off`` (a stack's blocks share ONE buffer and ONE launch)."""
         W2, b2, ws = self.params
         nm, ho, hid = self.nm, self.ho, self.hid
         f4 = 4
         fwd, bwd = [], []
+        off_conv0, off_w2 = self.off_conv0 + base_off, self.off_w2 + base_off
         for m, w in enumerate(ws):
             fwd.append(_sg([w.data_ptr()], [W2.data_ptr()], ho, hid, hid, hid, hid, hid, C=self.Wf[m].data_ptr()))
             fwd.append(_sg([w.data_ptr()], [b2.data_ptr()], ho, 1, hid, hid, 1, 1, C=self.bf[m].data_ptr()))
@@ -304,25 +321,25 @@ class _FoldPlan:
         db = g + f4 * nm * ho * hid
         dbf = [db + f4 * ho + f4 * m * ho for m in range(nm)]
         for m, w in enumerate(ws):   # dW_m = dWf_m W2^T + dbf_m (x) b2
-            bwd.append(_sg([dWf[m]], [W2.data_ptr()], ho, hid, hid, hid, hid, hid, c_off=self.off_conv0 + m * ho * hid,
+            bwd.append(_sg([dWf[m]], [W2.data_ptr()], ho, hid, hid, hid, hid, hid, c_off=off_conv0 + m * ho * hid,
                            tB=1, u=dbf[m], v=b2.data_ptr()))
         # conv0.bias gradient: plain copy of the unscaled column sums (K = 0, rank-1 term with v = 1)
-        bwd.append(_sg([], [], ho, 1, 0, 1, 1, 1, c_off=self.off_conv0 + nm * ho * hid, u=db, v=self.one.data_ptr()))
+        bwd.append(_sg([], [], ho, 1, 0, 1, 1, 1, c_off=off_conv0 + nm * ho * hid, u=db, v=self.one.data_ptr()))
         # dW2 = sum_m W_m^T dWf_m ; db2 = sum_m W_m^T dbf_m
-        bwd.append(_sg([w.data_ptr() for w in ws], dWf, hid, hid, ho, hid, hid, hid, c_off=self.off_w2, tA=1))
-        bwd.append(_sg([w.data_ptr() for w in ws], dbf, hid, 1, ho, hid, 1, 1, c_off=self.off_w2 + hid * hid, tA=1))
+        bwd.append(_sg([w.data_ptr() for w in ws], dWf, hid, hid, ho, hid, hid, hid, c_off=off_w2, tA=1))
+        bwd.append(_sg([w.data_ptr() for w in ws], dbf, hid, 1, ho, hid, 1, 1, c_off=off_w2 + hid * hid, tA=1))
+        return fwd, bwd
 
-        def tab(recs):
-            arr = np.zeros(len(recs), dtype=_SG_DTYPE)
-            for i, r in enumerate(recs):
-                arr[i] = tuple(r)
-            return (torch.from_numpy(arr.view(np.uint8).copy()).to(self.device), len(recs),
-                    max(((r[6] + 31) // 32) * ((r[7] + 31) // 32) for r in recs))
-        self.fwd_tab, self.bwd_tab = tab(fwd), tab(bwd)
+    def _tables(self):
+        fwd, bwd = self.records()
+        self.fwd_tab, self.bwd_tab = _sg_table(fwd, self.device), _sg_table(bwd, self.device)
+
+    def pointers(self):
+        W2, b2, ws = self.params
+        return (W2.data_ptr(), b2.data_ptr()) + tuple(w.data_ptr() for w in ws)
 
     def _check(self):
-        W2, b2, ws = self.params
-        ptrs = (W2.data_ptr(), b2.data_ptr()) + tuple(w.data_ptr() for w in ws)
+        ptrs = self.pointers()
         if ptrs != self.ptrs:
             self._tables()
             self.ptrs = ptrs
@@ -380,7 +397,7 @@ class _PackPlan:
     """Fragment-packed copies (forward and data-gradient layouts) of a list of weight matrices,
     refreshed by ONE kernel launch per forward."""
 
-    def __init__(self, groups: Sequence[Sequence[torch.Tensor]], device, stacked: bool = False):
+    def __init__(self, groups: Sequence[Sequence[torch.Tensor]], device, stacked: bool = False, stacked_groups=()):
         # groups[g] = the nmat matrices [hout, hin] of one fused GEMM (TAGConv lins, or one Linear);
         # entries are Parameters or _MatView blocks of a Parameter.
         # stacked: every group uses the narrow layouts whatever its width -- forward = matrices side by side along the
@@ -388,11 +405,12 @@ class _PackPlan:
         self.groups = groups = [[_as_view(w) for w in mats] for mats in groups]
         self.device = device
         self.stacked = stacked
+        self._stk = [bool(len(mats) > 1 and (stacked or g in stacked_groups)) for g, mats in enumerate(groups)]
         self.fwd, self.bwd, self.meta = [], [], []
-        for mats in groups:
+        for g, mats in enumerate(groups):
             hout, hin = mats[0].shape
             nm = len(mats)
-            if is_narrow(nm, hout) or (stacked and nm > 1):
+            if is_narrow(nm, hout) or self._stk[g]:
                 kf, cf, kb, cb = _round8(hin), _ncg(nm * hout), _round8(nm * hout), _ncg(hin)
                 self.fwd.append(torch.zeros(cf * (kf // 8) * 256, dtype=_F32, device=device))
                 self.bwd.append(torch.zeros(cb * (kb // 8) * 256, dtype=_F32, device=device))
@@ -406,11 +424,15 @@ class _PackPlan:
         self.max_elems = 0
         self.version = 0
 
-    def _build_table(self):
+    def pointers(self):
+        return tuple(w.data_ptr() for mats in self.groups for w in mats)
+
+    def records(self):
+        """The pack kernel's descriptor records of this plan (a stack concatenates those of its blocks into one launch)."""
         recs = []
         for g, mats in enumerate(self.groups):
             nm, hout, hin, kf, cf, kb, cb = self.meta[g]
-            narrow = is_narrow(nm, hout) or (self.stacked and nm > 1)
+            narrow = is_narrow(nm, hout) or self._stk[g]
             for m, w in enumerate(mats):
                 if not w.is_contiguous():
                     raise RuntimeError("weight matrices must be contiguous")
@@ -422,12 +444,16 @@ class _PackPlan:
                     recs.append((w.data_ptr(), self.fwd[g].data_ptr() + 4 * m * cf * (kf // 8) * 256, hout, hin, w.ld, 1, 0, kf, cf, 0))
                     recs.append((w.data_ptr(), self.bwd[g].data_ptr() + 4 * m * cb * (kb // 8) * 256, hout, hin, w.ld, 0, 0, kb, cb, 0))
                 self.max_elems = max(self.max_elems, (cf + 1) * (kf // 8 + 1) * 64, (cb + 1) * (kb // 8 + 1) * 64)
+        return recs
+
+    def _build_table(self):
+        recs = self.records()
         arr = np.array(recs, dtype=_DESC_DTYPE)
         self.n_desc = len(recs)
         self.table = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
 
     def refresh(self):
-        ptrs = tuple(w.data_ptr() for mats in self.groups for w in mats)
+        ptrs = self.pointers()
         if ptrs != self.ptrs:
             self._build_table()
             self.ptrs = ptrs
@@ -461,13 +487,14 @@ def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hou
 
 
 def _edge_aggr_backward(topo, gx0, x, ldx, ea, ldea, W1, b1, S, pack_w2_bwd, hid, hout, fn, fe, g_w1, g_w2, need_dx,
-                        pack_dx=None, dS=None, pending=None):
+                        pack_dx=None, dS=None, pending=None, dx_add=None):
     """g_w1: flat [hid*(2fn+fe) + hid] <- dW1, db1;  g_w2: flat [hout*hid + hout] <- dW2, db2.
     With ``dS`` given (second Linear folded into the consumer) gx0 / g_w2 are not used.
-    Returns dx [N, fn] or None."""
+    pack_dx = (W1[:, :fn] packed, W1[:, fn:2fn] packed[, both stacked along k]); dx_add [N, fn] is added to the result
+    (the skip connection's gradient).  Returns dx [N, fn] or None."""
     N = topo.N
     if dS is None:
-        wgrad(topo, gx0, hout, S, hid, 1, g_w2, rowscale=topo.deg)
+        wgrad(topo, gx0, hout, S, hid, 1, g_w2, rowscale=topo.deg, pending=pending)
         dS = torch.empty(N, hid, dtype=_F32, device=gx0.device)
         gemm_prop(topo, gx0, gx0.stride(0), hout, pack_w2_bwd, 1, hid, dS)
     gx0 = dS
@@ -476,45 +503,61 @@ def _edge_aggr_backward(topo, gx0, x, ldx, ea, ldea, W1, b1, S, pack_w2_bwd, hid
     tiled = topo.ell_ent_tiles is not None and topo.ellT_ent_tiles is not None and EDGE_TILE_KERNELS
     n_slabs = min(topo.ntiles, 512) if tiled else int(min(512, max(1, (N + 15) // 16)))
     slab = torch.empty(n_slabs * stride, dtype=_F32, device=dev)
-    U = torch.empty(2, N, hid, dtype=_F32, device=dev) if need_dx else None
-    st = _stream(gx0)
     L = _lib.lib()
+    # U0 = sum of dz over incoming edges (x enters as x_i), U1 over outgoing edges (as x_j).  Side by side in one [N, 2 hid]
+    # buffer when the K = 2 hid tile fits LDS: dx is then ONE GEMM [U0 | U1] [W1[:, :fn] ; W1[:, fn:2fn]]
+    merged = bool(need_dx and pack_dx is not None and len(pack_dx) > 2 and pack_dx[2] is not None and DX_MERGE and
+                  L.dss2_gemm_prop_lds_bytes(topo.nrb, 1, _round8(2 * hid), 1, 0, 0) <= 160 * 1024)
+    if not need_dx:
+        U = u0 = u1 = None
+        ldu = hid
+    elif merged:
+        U = torch.empty(N, 2 * hid, dtype=_F32, device=dev)
+        u0, u1, ldu = U, U[:, hid:], 2 * hid
+    else:
+        U = torch.empty(2, N, hid, dtype=_F32, device=dev)
+        u0, u1, ldu = U[0], U[1], hid
+    st = _stream(gx0)
     if tiled:
         _lib.check(L.dss2_edge_tile_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
                                         topo.tile_start.data_ptr(), topo.ell_ent_tiles.data_ptr(), topo.ell, topo.nrb,
-                                        topo.ntiles, slab.data_ptr(), n_slabs, _ptr(U), hid, hid, fn, fe, 0, st),
+                                        topo.ntiles, slab.data_ptr(), n_slabs, _ptr(u0), ldu, hid, fn, fe, 0, st),
                    "dss2_edge_tile_bwd")
     else:
         _lib.check(L.dss2_edge_hidden_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
                                           topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(), slab.data_ptr(),
-                                          n_slabs, _ptr(U), hid, N, hid, fn, fe, 0, st), "dss2_edge_hidden_bwd")
+                                          n_slabs, _ptr(u0), ldu, N, hid, fn, fe, 0, st), "dss2_edge_hidden_bwd")
     _reduce(slab, 0, n_slabs, stride, g_w1, stride, pending)
     if not need_dx:
         return None
-    # U[0] = sum of dz over incoming edges (x enters as x_i), U[1] over outgoing edges (as x_j)
     if tiled:
         _lib.check(L.dss2_edge_tile_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
                                         topo.tile_start.data_ptr(), topo.ellT_ent_tiles.data_ptr(), topo.ellT, topo.nrb,
-                                        topo.ntiles, None, n_slabs, U[1].data_ptr(), hid, hid, fn, fe, 1, st),
+                                        topo.ntiles, None, n_slabs, u1.data_ptr(), ldu, hid, fn, fe, 1, st),
                    "dss2_edge_tile_bwd")
     else:
         _lib.check(L.dss2_edge_hidden_bwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(), dS.data_ptr(),
                                           topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.entT.data_ptr(), None,
-                                          n_slabs, U[1].data_ptr(), hid, N, hid, fn, fe, 1, st), "dss2_edge_hidden_bwd")
-    # dx = U[0] @ W1[:, :fn] + U[1] @ W1[:, fn:2fn]: two K=hid -> fn GEMMs on the tile kernel (the two W1
-    # blocks are packed in place by the module's pack launch), the second adding the first through the
-    # residual epilogue
-    dx0 = torch.empty(N, fn, dtype=_F32, device=dev)
+                                          n_slabs, u1.data_ptr(), ldu, N, hid, fn, fe, 1, st), "dss2_edge_hidden_bwd")
     dx = torch.empty(N, fn, dtype=_F32, device=dev)
-    gemm_prop(topo, U[0], hid, hid, pack_dx[0], 1, fn, dx0)
-    gemm_prop(topo, U[1], hid, hid, pack_dx[1], 1, fn, dx, add_src=dx0, add_ld=fn)
-    return dx
+    if merged:
+        gemm_prop(topo, U, 2 * hid, 2 * hid, pack_dx[2], 1, fn, dx, add_src=dx_add,
+                  add_ld=(dx_add.stride(0) if dx_add is not None else 0))
+        return dx
+    # two K = hid -> fn GEMMs on the tile kernel (the two W1 blocks are packed in place by the module's pack launch), the
+    # second adding the first through the residual epilogue
+    dx0 = torch.empty(N, fn, dtype=_F32, device=dev)
+    gemm_prop(topo, u0, hid, hid, pack_dx[0], 1, fn, dx0)
+    gemm_prop(topo, u1, hid, hid, pack_dx[1], 1, fn, dx, add_src=dx0, add_ld=fn)
+    return dx if dx_add is None else dx + dx_add
 
 
 def _dx_views(W1, hid, fn, fe):
-    """W1[:, :fn] (x enters as x_i) and W1[:, fn:2fn] (as x_j) as in-place blocks for the pack kernel."""
+    """W1[:, :fn] (x enters as x_i) and W1[:, fn:2fn] (as x_j) as in-place blocks for the pack kernel: each alone, and
+    both as one group (packed stacked along k for the merged dx GEMM, see _edge_aggr_backward)."""
     ld = 2 * fn + fe
-    return [[_MatView(W1, hid, fn, ld, 0)], [_MatView(W1, hid, fn, ld, fn)]]
+    a, b = _MatView(W1, hid, fn, ld, 0), _MatView(W1, hid, fn, ld, fn)
+    return [[a], [b], [a, b]]
 
 
 def _tagconv_forward(topo, h, pack_fwd, bias, nmat, hin, hout, dmask=None, relu=False, add_src=None, add_ld=0,
@@ -637,6 +680,8 @@ EDGE_TILE_KERNELS = _os.environ.get("DSS2_EDGE_TILE", "1") == "1"       # 0 = ro
 WGRAD_SIDE_STREAM = _os.environ.get("DSS2_WGRAD_STREAM", "0") == "1"   # opt-in: +3 % at C2 (kernels then overlap)
 CHAIN_LAYERS = _os.environ.get("DSS2_CHAIN", "1") == "1"               # hid->hid layers of a block: one chained launch
 WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"
+STACK_NODE = _os.environ.get("DSS2_STACK_NODE", "1") == "1"              # PFN / SkipPFN as ONE autograd node (_PFNFn)
+DX_MERGE = _os.environ.get("DSS2_DX_MERGE", "1") == "1"                  # dx of the edge MLP as ONE K = 2 hid GEMM
 WGRAD_JOIN_FOLDED = None    # None: join the folded conv 0 into the batched launch only when the tiles divide evenly          # hid->hid layers of a block: one wgrad launch
 
 
@@ -868,7 +913,7 @@ class _EdgeAggrFn(torch.autograd.Function):
         x, ldx = _rows(x)
         ea, ldea = _rows(ea)
         if mod._plan is None or mod._plan.device != x.device:
-            mod._plan = _PackPlan([[W2]] + _dx_views(W1, mod.dim_hid, mod.dim_featn, mod.dim_feate), x.device)
+            mod._plan = _PackPlan([[W2]] + _dx_views(W1, mod.dim_hid, mod.dim_featn, mod.dim_feate), x.device, stacked_groups=(3,))
         ctx.ver = mod._plan.refresh()
         topo.lds_check(1, _round8(mod.dim_hid), _ncg(mod.dim_out))
         S, x0 = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, mod._plan.fwd[0], mod.dim_hid, mod.dim_out,
@@ -888,7 +933,7 @@ class _EdgeAggrFn(torch.autograd.Function):
         g1 = torch.empty(hid * (2 * fn + fe) + hid, dtype=_F32, device=g.device)
         g2 = torch.empty(hout * hid + hout, dtype=_F32, device=g.device)
         dx = _edge_aggr_backward(topo, g, x, ctx.ld[0], ea, ctx.ld[1], W1, b1, S, mod._plan.bwd[0], hid, hout, fn, fe,
-                                 g1, g2, ctx.needs_input_grad[0], pack_dx=(mod._plan.bwd[1], mod._plan.bwd[2]))
+                                 g1, g2, ctx.needs_input_grad[0], pack_dx=tuple(mod._plan.bwd[1:4]))
         nc = 2 * fn + fe
         return (dx, None, None, None, g1[:hid * nc].view(hid, nc), g1[hid * nc:], g2[:hout * hid].view(hout, hid),
                 g2[hout * hid:])
@@ -958,207 +1003,359 @@ class SkipMPN(MPN):
     skip = True
 
 
-class _MPNFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, ea, topo, mod, *ps):
-        x, ldx = _rows(x)
-        ea, ldea = _rows(ea)
-        dev = x.device
-        L, nmat, hid = mod.n_gnn_layers, mod.K + 1, mod.dim_hid
-        W1, b1, W2, b2 = ps[0:4]
-        conv_ps = [ps[4 + l * (nmat + 1): 4 + (l + 1) * (nmat + 1)] for l in range(L)]   # (bias, W_0..W_K)
-        hout0 = mod.dim_out if L == 1 else hid
-        glob = topo.global_only       # graphs beyond the LDS-resident tiles: plain GEMMs + propagation hops in global memory
-        fold_on = FOLD_W2 and not is_narrow(nmat, hout0) and not glob
-        if mod._plan is None or mod._plan.device != dev or (mod._fold is not None) != fold_on or mod._plan.stacked != glob:
-            offs = mod._flat_offsets()
-            mod._fold = _FoldPlan(W2, b2, conv_ps[0][1:], dev, int(offs[1]), int(offs[2])) if fold_on else None
-            conv_groups = [list(cp[1:]) for cp in conv_ps]
-            if fold_on:   # conv 0 is packed from the folded weights
-                conv_groups[0] = [mod._fold.Wf[m] for m in range(nmat)]
-            mod._plan = _PackPlan([[W2]] + conv_groups + _dx_views(W1, hid, mod.dim_featn, mod.dim_feate), dev, stacked=glob)
-        plan, fold = mod._plan, mod._fold
+def _ensure_plans(mod, topo, dev, ps):
+    """(pack plan, fold plan or None, global-memory mode) of an MPN block, created on first use / when the mode changes."""
+    L, nmat, hid = mod.n_gnn_layers, mod.K + 1, mod.dim_hid
+    W1, b1, W2, b2 = ps[0:4]
+    conv_ps = [ps[4 + l * (nmat + 1): 4 + (l + 1) * (nmat + 1)] for l in range(L)]   # (bias, W_0..W_K)
+    hout0 = mod.dim_out if L == 1 else hid
+    glob = topo.global_only       # graphs beyond the LDS-resident tiles: plain GEMMs + propagation hops in global memory
+    fold_on = FOLD_W2 and not is_narrow(nmat, hout0) and not glob
+    if mod._plan is None or mod._plan.device != dev or (mod._fold is not None) != fold_on or mod._plan.stacked != glob:
+        offs = mod._flat_offsets()
+        mod._fold = _FoldPlan(W2, b2, conv_ps[0][1:], dev, int(offs[1]), int(offs[2])) if fold_on else None
+        conv_groups = [list(cp[1:]) for cp in conv_ps]
+        if fold_on:   # conv 0 is packed from the folded weights
+            conv_groups[0] = [mod._fold.Wf[m] for m in range(nmat)]
+        mod._plan = _PackPlan([[W2]] + conv_groups + _dx_views(W1, hid, mod.dim_featn, mod.dim_feate), dev, stacked=glob,
+                              stacked_groups=(L + 3,))
+    if mod._fold is not None:
+        mod._fold.params = (W2, b2, list(conv_ps[0][1:]))
+    return mod._plan, mod._fold, glob
+
+
+def _mpn_forward(mod, topo, x, ea, ps, stack=None):
+    """One MPN block forward on raw tensors.  ``stack`` (a _StackRun, PFN / SkipPFN): the weight packing, the fold and the
+    dropout snapshot were already done for all blocks of the stack in one launch each.
+    Returns (out, tensors to keep for backward, meta)."""
+    x, ldx = _rows(x)
+    ea, ldea = _rows(ea)
+    dev = x.device
+    L, nmat, hid = mod.n_gnn_layers, mod.K + 1, mod.dim_hid
+    W1, b1, W2, b2 = ps[0:4]
+    conv_ps = [ps[4 + l * (nmat + 1): 4 + (l + 1) * (nmat + 1)] for l in range(L)]   # (bias, W_0..W_K)
+    plan, fold, glob = _ensure_plans(mod, topo, dev, ps)
+    if stack is None:
         if fold is not None:
-            fold.params = (W2, b2, list(conv_ps[0][1:]))
             fold.refresh_forward()
-        ctx.ver = plan.refresh()
-        topo.lds_check(nmat, _round8(hid), _ncg(hid))
-        S, h = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, plan.fwd[0], hid, hid, mod.dim_featn, mod.dim_feate,
-                                  second_linear=fold is None)
-        if fold is not None:
-            h = S            # conv 0 consumes the aggregated hidden directly
-        acts = [h]
-        p = float(mod.dropout_rate)
-        # dropout is active regardless of .training (a fresh nn.Dropout is built inside forward, networks.py:268).  The
-        # masks are not tensors: the epilogues regenerate them from (snapshot, layer id) in forward and backward.
-        snap = dropout_snapshot(mod, dev) if p > 0.0 else None
-        mod._last_dropout = (snap, p)
+        ver = plan.refresh()
+    else:
+        ver = plan.version
+    topo.lds_check(nmat, _round8(hid), _ncg(hid))
+    S, h = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, plan.fwd[0], hid, hid, mod.dim_featn, mod.dim_feate,
+                              second_linear=fold is None)
+    if fold is not None:
+        h = S            # conv 0 consumes the aggregated hidden directly
+    acts = [h]
+    p = float(mod.dropout_rate)
+    # dropout is active regardless of .training (a fresh nn.Dropout is built inside forward, networks.py:268).  The
+    # masks are not tensors: the epilogues regenerate them from (snapshot, layer id) in forward and backward.
+    if p <= 0.0:
+        snap, base = None, 0
+    elif stack is not None:
+        snap, base = stack.snapshot, stack.drop_base(mod)
+    else:
+        snap, base = dropout_snapshot(mod, dev), 0
+    mod._last_dropout, mod._drop_base = (snap, p), base
 
-        def drop_id(l):            # mask applied to conv l's output (none after the last conv)
-            return l + 1 if (snap is not None and l < L - 1) else 0
+    def drop_id(l):            # mask applied to conv l's output (none after the last conv)
+        return base + l + 1 if (snap is not None and l < L - 1) else 0
 
-        # the hid -> hid layers 0 .. L-2 as ONE chained launch (activation tile stays in LDS between layers)
-        n_chain = L - 1 if (L - 1 >= 2 and chain_supported(topo, nmat, hid, False)) else 0
-        if n_chain:
-            layers = []
-            for l in range(n_chain):
-                out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
-                layers.append(dict(Bp=plan.fwd[1 + l], Y=out_l, bias=conv_ps[l][0], relu=True, drop_id=drop_id(l),
-                                   prebias=(fold.bf if (fold is not None and l == 0) else None)))
-                acts.append(out_l)
-            gemm_prop_chain(topo, h, hid, nmat, layers, pre_rowscale=(topo.deg_pows if fold is not None else None),
-                            drop=((snap, p) if snap is not None else None))
-            h = acts[-1]
-        for l in range(n_chain, L):
-            last = l == L - 1
-            hout = mod.dim_out if last else hid
-            if glob:
-                h = _tagconv_forward_global(topo, h, plan.fwd[1 + l], conv_ps[l][0], nmat, hid, hout, relu=not last,
-                                            add_src=(x if (last and mod.skip) else None), add_ld=ldx,
-                                            drop=((snap, p, drop_id(l)) if snap is not None else None))
-                if not last:
-                    acts.append(h)
-                continue
-            pre = (fold.bf, topo.deg_pows) if (fold is not None and l == 0) else (None, None)
-            h = _tagconv_forward(topo, h, plan.fwd[1 + l], conv_ps[l][0], nmat, hid, hout, relu=not last,
-                                 add_src=(x if (last and mod.skip) else None), add_ld=ldx,
-                                 prebias=pre[0], pre_rowscale=pre[1],
-                                 drop=((snap, p, drop_id(l)) if snap is not None else None))
+    # the hid -> hid layers 0 .. L-2 as ONE chained launch (activation tile stays in LDS between layers)
+    n_chain = L - 1 if (L - 1 >= 2 and chain_supported(topo, nmat, hid, False)) else 0
+    if n_chain:
+        layers = []
+        for l in range(n_chain):
+            out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
+            layers.append(dict(Bp=plan.fwd[1 + l], Y=out_l, bias=conv_ps[l][0], relu=True, drop_id=drop_id(l),
+                               prebias=(fold.bf if (fold is not None and l == 0) else None)))
+            acts.append(out_l)
+        gemm_prop_chain(topo, h, hid, nmat, layers, pre_rowscale=(topo.deg_pows if fold is not None else None),
+                        drop=((snap, p) if snap is not None else None))
+        h = acts[-1]
+    for l in range(n_chain, L):
+        last = l == L - 1
+        hout = mod.dim_out if last else hid
+        if glob:
+            h = _tagconv_forward_global(topo, h, plan.fwd[1 + l], conv_ps[l][0], nmat, hid, hout, relu=not last,
+                                        add_src=(x if (last and mod.skip) else None), add_ld=ldx,
+                                        drop=((snap, p, drop_id(l)) if snap is not None else None))
             if not last:
                 acts.append(h)
-        ctx.save_for_backward(x, ea, S, *acts, *ps)
-        ctx.meta = (topo, mod, ldx, ldea, len(acts), (snap, p), fold is not None, glob)
-        return h
+            continue
+        pre = (fold.bf, topo.deg_pows) if (fold is not None and l == 0) else (None, None)
+        h = _tagconv_forward(topo, h, plan.fwd[1 + l], conv_ps[l][0], nmat, hid, hout, relu=not last,
+                             add_src=(x if (last and mod.skip) else None), add_ld=ldx,
+                             prebias=pre[0], pre_rowscale=pre[1],
+                             drop=((snap, p, drop_id(l)) if snap is not None else None))
+        if not last:
+            acts.append(h)
+    meta = (ldx, ldea, len(acts), (snap, p, base), fold is not None, glob, ver)
+    return h, [x, ea, S] + acts, meta
 
-    @staticmethod
-    def backward(ctx, gout):
-        topo, mod, ldx, ldea, n_acts, (snap, p_drop), folded, glob = ctx.meta
-        saved = ctx.saved_tensors
-        x, ea, S = saved[0:3]
-        acts = list(saved[3:3 + n_acts])
-        ps = saved[3 + n_acts:]
 
-        def drop_of(l):            # the mask that was applied to conv l's output: (snapshot, p, id) or None
-            return (snap, p_drop, l + 1) if snap is not None else None
-        plan, fold = mod._plan, mod._fold
-        if folded != (fold is not None) or plan.stacked != glob:
-            raise RuntimeError("DSS2_FOLD_W2 / the module's plan changed between forward and backward")
-        if plan.version != ctx.ver:
-            if fold is not None:
-                fold.refresh_forward()
-            plan.refresh()   # weights are checked unchanged by autograd's saved-tensor versioning
-        dev = gout.device
-        L, nmat, hid, fn, fe = mod.n_gnn_layers, mod.K + 1, mod.dim_hid, mod.dim_featn, mod.dim_feate
-        W1, b1 = ps[0], ps[1]
-        # one flat gradient buffer; parameter gradients are returned as views into it
-        offs = mod._flat_offsets()
+def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=None):
+    """Backward of _mpn_forward.  Standalone (flat is None): allocates the block's flat gradient buffer, runs its slab
+    reductions and the fold's chain rule, calls the all-reduce hook.  Inside a stack: ``flat`` is the block's slice of the
+    stack's buffer and every slab reduction is only recorded in ``pending``; the caller runs them (and the chain rule of
+    all folds) in one launch each after the last block.  Returns (dx, parameter gradients as views into flat, fold_late)."""
+    ldx, ldea, n_acts, (snap, p_drop, base), folded, glob, ver = meta
+    x, ea, S = saved[0:3]
+    acts = list(saved[3:3 + n_acts])
+    in_stack = flat is not None
+
+    def drop_of(l):            # the mask that was applied to conv l's output: (snapshot, p, id) or None
+        return (snap, p_drop, base + l + 1) if snap is not None else None
+    plan, fold = mod._plan, mod._fold
+    if folded != (fold is not None) or plan.stacked != glob:
+        raise RuntimeError("DSS2_FOLD_W2 / the module's plan changed between forward and backward")
+    if plan.version != ver:
+        if fold is not None:
+            fold.refresh_forward()
+        plan.refresh()   # weights are checked unchanged by autograd's saved-tensor versioning
+    dev = gout.device
+    L, nmat, hid, fn, fe = mod.n_gnn_layers, mod.K + 1, mod.dim_hid, mod.dim_featn, mod.dim_feate
+    W1, b1 = ps[0], ps[1]
+    # one flat gradient buffer; parameter gradients are returned as views into it
+    offs = mod._flat_offsets()
+    if flat is None:
         flat = torch.empty(int(offs[-1]), dtype=_F32, device=dev)
-        g = gout.contiguous()
-        need_dx = ctx.needs_input_grad[0]
-        deferred = []
-        l_start = L - 1
-        dS = None
-        pending = None          # slab reductions recorded here run in ONE launch at the end (chained path)
-        fold_late = False
-        if L >= 3 and not WGRAD_SIDE_STREAM and WGRAD_BATCH and chain_supported(topo, nmat, hid, True):
-            # last layer on its own; then the data-gradients of layers L-2 .. 0 as ONE chained launch
+    g = gout.contiguous()
+    deferred = []
+    l_start = L - 1
+    dS = None
+    # slab reductions recorded in ``pending`` run in ONE launch at the end (chained path; always inside a stack)
+    fold_late = False
+    if L >= 3 and not WGRAD_SIDE_STREAM and WGRAD_BATCH and chain_supported(topo, nmat, hid, True):
+        # last layer on its own; then the data-gradients of layers L-2 .. 0 as ONE chained launch
+        if pending is None:
             pending = []
-            l = L - 1
-            g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, mod.dim_out, flat[offs[2 + l]:offs[3 + l]],
-                                  relu_src=acts[l], drop=drop_of(l - 1), pending=pending)
-            gl = [None] * (L - 1)                   # gl[l]: gradient w.r.t. layer l's pre-activation output
-            gl[L - 2] = g
-            layers = []
-            for l in range(L - 2, -1, -1):
-                out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
-                layers.append(dict(Bp=plan.bwd[1 + l], Y=out_l, relu_src=(acts[l] if l > 0 else None),
-                                   drop_id=(l if (l > 0 and snap is not None) else 0)))      # mask of conv l-1: id (l-1)+1
-                if l > 0:
-                    gl[l - 1] = out_l
-            gemm_prop_chain(topo, g, hid, nmat, layers, transposed=True, drop=((snap, p_drop) if snap is not None else None))
-            d_in = layers[-1]["Y"]                  # gradient w.r.t. conv 0's input: dS (folded) or dx0
-            # (joining conv 0 pays only when the tiles still divide evenly over the workgroups the layers share:
-            #  at C2 three layers x 85 workgroups leave a 13-vs-12-tile tail that costs more than the launch saves)
-            ns3 = max(1, (256 * 2) // (L - 1))
-            even = -(-topo.ntiles // ns3) * ns3 <= 1.03 * topo.ntiles
-            if WGRAD_JOIN_FOLDED is not None:
-                even = bool(WGRAD_JOIN_FOLDED)
-            if fold is not None and L - 1 <= 8 and even:
-                # the folded conv 0 (input S, extra scaled bias sums) and the plain layers 1 .. L-2 in ONE launch
-                wgrad_batched(topo, gl, hid, [S] + acts[1:L - 1], hid, nmat, flat[offs[3]:offs[2 + L - 1]],
-                              first_rowscale2=topo.deg_pows, first_out=fold.gfold, pending=pending)
-                fold_late = True        # the chain rule of the fold needs the reduced gfold
+        l = L - 1
+        g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, mod.dim_out, flat[offs[2 + l]:offs[3 + l]],
+                              relu_src=acts[l], drop=drop_of(l - 1), pending=pending)
+        gl = [None] * (L - 1)                   # gl[l]: gradient w.r.t. layer l's pre-activation output
+        gl[L - 2] = g
+        layers = []
+        for l in range(L - 2, -1, -1):
+            out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
+            layers.append(dict(Bp=plan.bwd[1 + l], Y=out_l, relu_src=(acts[l] if l > 0 else None),
+                               drop_id=(base + l if (l > 0 and snap is not None) else 0)))      # mask of conv l-1: id (l-1)+1
+            if l > 0:
+                gl[l - 1] = out_l
+        gemm_prop_chain(topo, g, hid, nmat, layers, transposed=True, drop=((snap, p_drop) if snap is not None else None))
+        d_in = layers[-1]["Y"]                  # gradient w.r.t. conv 0's input: dS (folded) or dx0
+        # (joining conv 0 pays only when the tiles still divide evenly over the workgroups the layers share:
+        #  at C2 three layers x 85 workgroups leave a 13-vs-12-tile tail that costs more than the launch saves)
+        ns3 = max(1, (256 * 2) // (L - 1))
+        even = -(-topo.ntiles // ns3) * ns3 <= 1.03 * topo.ntiles
+        if WGRAD_JOIN_FOLDED is not None:
+            even = bool(WGRAD_JOIN_FOLDED)
+        if fold is not None and L - 1 <= 8 and even:
+            # the folded conv 0 (input S, extra scaled bias sums) and the plain layers 1 .. L-2 in ONE launch
+            wgrad_batched(topo, gl, hid, [S] + acts[1:L - 1], hid, nmat, flat[offs[3]:offs[2 + L - 1]],
+                          first_rowscale2=topo.deg_pows, first_out=fold.gfold, pending=pending)
+            fold_late = True        # the chain rule of the fold needs the reduced gfold
+            dS, g = d_in, None
+        else:
+            if fold is not None:
+                wgrad(topo, gl[0], hid, S, hid, nmat, fold.gfold, rowscale2=topo.deg_pows, pending=pending)
+                fold_late = True
                 dS, g = d_in, None
             else:
-                if fold is not None:
-                    wgrad(topo, gl[0], hid, S, hid, nmat, fold.gfold, rowscale2=topo.deg_pows, pending=pending)
-                    fold_late = True
-                    dS, g = d_in, None
-                else:
-                    g = d_in
-                deferred = [(l, gl[l], acts[l]) for l in range(L - 2, (0 if fold is not None else -1), -1)]
-            l_start = -1
-        for l in range(l_start, -1, -1):
-            hout = mod.dim_out if l == L - 1 else hid
-            seg = flat[offs[2 + l]:offs[3 + l]]
-            if l == 0 and fold is not None:
-                # folded conv 0: weight gradient w.r.t. Wf / bf into the plan's buffer, data gradient is dS;
-                # one small-GEMM launch then writes dW_m, conv0.bias, dW2, db2 into the flat buffer
-                wgrad(topo, g, hout, S, hid, nmat, fold.gfold, rowscale2=topo.deg_pows)
-                dS = torch.empty(topo.N, hid, dtype=_F32, device=dev)
-                gemm_prop(topo, g, g.stride(0), hout, plan.bwd[1], nmat, hid, dS, transposed=True)
-                # (a side stream for this launch was measured: the cross-stream event waits cost more than the
-                # 17 us they hide)
-                fold.backward(flat)
-                g = None
-                break
-            # dgrad epilogue applies the ReLU / dropout mask of the layer BELOW (its output is acts[l])
-            if glob:
-                g = _tagconv_backward_global(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, hout, seg,
-                                             relu_src=(acts[l] if l > 0 else None),
-                                             drop=(drop_of(l - 1) if l > 0 else None))
-                continue
-            defer = WGRAD_BATCH and not WGRAD_SIDE_STREAM and hout == hid and not is_narrow(nmat, hout)
-            if defer:
-                deferred.append((l, g, acts[l]))
-            g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, hout, seg,
-                                  relu_src=(acts[l] if l > 0 else None), drop=(drop_of(l - 1) if l > 0 else None),
-                                  defer_wgrad=defer)
-        # weight gradients of the hid -> hid layers: independent of each other, so one launch (and one slab
-        # reduction) covers up to 8 consecutive layers; their segments in the flat buffer are contiguous
-        deferred.reverse()
-        for c0 in range(0, len(deferred), 8):
-            chunk = deferred[c0:c0 + 8]
-            l0, l1 = chunk[0][0], chunk[-1][0]
-            out = flat[offs[2 + l0]:offs[3 + l1]]
-            if len(chunk) == 1:
-                wgrad(topo, chunk[0][1], hid, chunk[0][2], hid, nmat, out, pending=pending)
-            else:
-                wgrad_batched(topo, [c[1] for c in chunk], hid, [c[2] for c in chunk], hid, nmat, out, pending=pending)
-        dx = _edge_aggr_backward(topo, g, x, ldx, ea, ldea, W1, b1, S, plan.bwd[0], hid, hid, fn, fe,
-                                 flat[offs[0]:offs[1]], flat[offs[1]:offs[2]], need_dx,
-                                 pack_dx=(plan.bwd[1 + L], plan.bwd[2 + L]), dS=(dS if fold is not None else None),
-                                 pending=pending)
+                g = d_in
+            deferred = [(l, gl[l], acts[l]) for l in range(L - 2, (0 if fold is not None else -1), -1)]
+        l_start = -1
+    for l in range(l_start, -1, -1):
+        hout = mod.dim_out if l == L - 1 else hid
+        seg = flat[offs[2 + l]:offs[3 + l]]
+        if l == 0 and fold is not None:
+            # folded conv 0: weight gradient w.r.t. Wf / bf into the plan's buffer, data gradient is dS;
+            # one small-GEMM launch then writes dW_m, conv0.bias, dW2, db2 into the flat buffer
+            wgrad(topo, g, hout, S, hid, nmat, fold.gfold, rowscale2=topo.deg_pows, pending=pending)
+            dS = torch.empty(topo.N, hid, dtype=_F32, device=dev)
+            gemm_prop(topo, g, g.stride(0), hout, plan.bwd[1], nmat, hid, dS, transposed=True)
+            fold_late = True
+            g = None
+            break
+        # dgrad epilogue applies the ReLU / dropout mask of the layer BELOW (its output is acts[l])
+        if glob:
+            g = _tagconv_backward_global(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, hout, seg,
+                                         relu_src=(acts[l] if l > 0 else None),
+                                         drop=(drop_of(l - 1) if l > 0 else None), pending=pending)
+            continue
+        defer = WGRAD_BATCH and not WGRAD_SIDE_STREAM and hout == hid and not is_narrow(nmat, hout)
+        if defer:
+            deferred.append((l, g, acts[l]))
+        g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, hout, seg,
+                              relu_src=(acts[l] if l > 0 else None), drop=(drop_of(l - 1) if l > 0 else None),
+                              defer_wgrad=defer, pending=pending)
+    # weight gradients of the hid -> hid layers: independent of each other, so one launch (and one slab
+    # reduction) covers up to 8 consecutive layers; their segments in the flat buffer are contiguous
+    deferred.reverse()
+    for c0 in range(0, len(deferred), 8):
+        chunk = deferred[c0:c0 + 8]
+        l0, l1 = chunk[0][0], chunk[-1][0]
+        out = flat[offs[2 + l0]:offs[3 + l1]]
+        if len(chunk) == 1:
+            wgrad(topo, chunk[0][1], hid, chunk[0][2], hid, nmat, out, pending=pending)
+        else:
+            wgrad_batched(topo, [c[1] for c in chunk], hid, [c[2] for c in chunk], hid, nmat, out, pending=pending)
+    dx = _edge_aggr_backward(topo, g, x, ldx, ea, ldea, W1, b1, S, plan.bwd[0], hid, hid, fn, fe,
+                             flat[offs[0]:offs[1]], flat[offs[1]:offs[2]], need_dx,
+                             pack_dx=tuple(plan.bwd[1 + L:4 + L]), dS=(dS if fold is not None else None),
+                             pending=pending, dx_add=(gout if (need_dx and mod.skip) else None))
+    if not in_stack:
         if pending:
             reduce_pending(pending)     # all slab reductions of the block in one launch
         if fold_late:
             fold.backward(flat)
-        if need_dx and mod.skip:
-            dx = dx + gout
         if WGRAD_SIDE_STREAM:
             torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
         hook = getattr(mod, "_grad_bucket_hook", None)
         if hook is not None:      # data-parallel: all-reduce the flat bucket once (parallel.py)
             hook(flat)
-        nc = 2 * fn + fe
-        g1, g2 = flat[offs[0]:offs[1]], flat[offs[1]:offs[2]]
-        grads = [g1[:hid * nc].view(hid, nc), g1[hid * nc:], g2[:hid * hid].view(hid, hid), g2[hid * hid:]]
-        for l in range(L):
-            hout = mod.dim_out if l == L - 1 else hid
-            seg = flat[offs[2 + l]:offs[3 + l]]
-            grads.append(seg[nmat * hout * hid:])                                     # bias
-            grads.extend(seg[m * hout * hid:(m + 1) * hout * hid].view(hout, hid) for m in range(nmat))
+    nc = 2 * fn + fe
+    g1, g2 = flat[offs[0]:offs[1]], flat[offs[1]:offs[2]]
+    grads = [g1[:hid * nc].view(hid, nc), g1[hid * nc:], g2[:hid * hid].view(hid, hid), g2[hid * hid:]]
+    for l in range(L):
+        hout = mod.dim_out if l == L - 1 else hid
+        seg = flat[offs[2 + l]:offs[3 + l]]
+        grads.append(seg[nmat * hout * hid:])                                     # bias
+        grads.extend(seg[m * hout * hid:(m + 1) * hout * hid].view(hout, hid) for m in range(nmat))
+    return dx, grads, fold_late
+
+
+class _MPNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ea, topo, mod, *ps):
+        out, saved, meta = _mpn_forward(mod, topo, x, ea, ps)
+        ctx.save_for_backward(*saved, *ps)
+        ctx.meta = (topo, mod, meta, len(saved))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        topo, mod, meta, n_saved = ctx.meta
+        saved = ctx.saved_tensors
+        dx, grads, _ = _mpn_backward(mod, topo, saved[:n_saved], saved[n_saved:], meta, gout, ctx.needs_input_grad[0])
         return (dx, None, None, None, *grads)
+
+
+class _StackPlan:
+    """What the blocks of a PFN / SkipPFN stack share per step: ONE small-GEMM launch folding every block's second Linear,
+    ONE pack launch for every block's weights, ONE dropout snapshot (layer ids offset per block), ONE flat gradient buffer
+    (block b at base[b]), ONE slab-reduction launch and ONE chain-rule launch for all folds.  The merged descriptor tables
+    are rebuilt only when a parameter or plan buffer moves."""
+
+    DROP_STRIDE = 64      # dropout mask ids of block b: b * DROP_STRIDE + layer + 1
+
+    def __init__(self, blocks, device):
+        self.blocks, self.device = list(blocks), device
+        sizes = [int(m._flat_offsets()[-1]) for m in self.blocks]
+        self.base = [0]
+        for s in sizes:
+            self.base.append(self.base[-1] + s)
+        self.total = self.base[-1]
+        self.key = None
+        self.fold_fwd = self.fold_bwd = self.pack_tab = None
+        self.table_builds = 0
+
+    def refresh(self, topo, params):
+        plans = [_ensure_plans(m, topo, self.device, ps) for m, ps in zip(self.blocks, params)]
+        key = tuple((id(p), id(f), p.pointers(), f.pointers() if f is not None else None) for p, f, _ in plans)
+        if key != self.key:
+            fwd, bwd, recs, max_elems = [], [], [], 0
+            for b, (p, f, _) in enumerate(plans):
+                if f is not None:
+                    f_, b_ = f.records(self.base[b])
+                    fwd += f_
+                    bwd += b_
+                recs += p.records()
+                max_elems = max(max_elems, p.max_elems)
+            self.fold_fwd = _sg_table(fwd, self.device) if fwd else None
+            self.fold_bwd = _sg_table(bwd, self.device) if bwd else None
+            arr = np.array(recs, dtype=_DESC_DTYPE)
+            self.pack_tab = (torch.from_numpy(arr.view(np.uint8).copy()).to(self.device), len(recs), max_elems)
+            self.key = key
+            self.table_builds += 1
+        if self.fold_fwd is not None:
+            _small_gemm(self.fold_fwd, None, self.device)
+        t, cnt, mx = self.pack_tab
+        _lib.check(_lib.lib().dss2_pack_weights(t.data_ptr(), cnt, mx, torch.cuda.current_stream(self.device).cuda_stream),
+                   "dss2_pack_weights")
+        for p, _, _ in plans:
+            p.version += 1
+
+
+class _StackRun:
+    """Per-forward state of a stack (what one call's blocks and its backward share)."""
+
+    def __init__(self, plan: _StackPlan, snapshot):
+        self.plan, self.snapshot = plan, snapshot
+
+    def drop_base(self, mod) -> int:
+        return self.plan.blocks.index(mod) * _StackPlan.DROP_STRIDE
+
+
+class _PFNFn(torch.autograd.Function):
+    """All blocks of a PFN / SkipPFN as ONE autograd node: the per-block housekeeping launches (fold, pack, dropout state,
+    slab reductions, chain rule of the folds, gradient all-reduce) run once per stack, and every gradient of the stack is
+    complete when the node returns (autograd may accumulate into existing .grad tensors right away)."""
+
+    @staticmethod
+    def forward(ctx, x, ea, topo, pfn, n_per_block, *ps):
+        blocks = list(pfn.mpns)
+        dev = x.device
+        bounds = np.concatenate([[0], np.cumsum(n_per_block)])
+        params = [ps[bounds[b]:bounds[b + 1]] for b in range(len(blocks))]
+        sp = pfn._stack_plan
+        if sp is None or sp.device != dev:
+            sp = pfn._stack_plan = _StackPlan(blocks, dev)
+        sp.refresh(topo, params)
+        snap = dropout_snapshot(pfn, dev) if float(pfn.dropout_rate) > 0.0 else None
+        run = _StackRun(sp, snap)
+        saved, metas, counts = [], [], []
+        for m, bp in zip(blocks, params):
+            x, sv, meta = _mpn_forward(m, topo, x, ea, bp, stack=run)
+            saved += sv
+            metas.append(meta)
+            counts.append(len(sv))
+        ctx.save_for_backward(*saved, *ps)
+        ctx.meta = (topo, pfn, metas, counts, bounds)
+        return x
+
+    @staticmethod
+    def backward(ctx, gout):
+        topo, pfn, metas, counts, bounds = ctx.meta
+        blocks = list(pfn.mpns)
+        sp = pfn._stack_plan
+        st = ctx.saved_tensors
+        n_saved = sum(counts)
+        saved, ps = st[:n_saved], st[n_saved:]
+        dev = gout.device
+        flat = torch.empty(sp.total, dtype=_F32, device=dev)
+        pending, grads_all, any_fold = [], [None] * len(blocks), False
+        sbounds = np.concatenate([[0], np.cumsum(counts)])
+        g = gout
+        for b in range(len(blocks) - 1, -1, -1):
+            m = blocks[b]
+            need_dx = b > 0 or ctx.needs_input_grad[0]
+            g, grads_all[b], fl = _mpn_backward(m, topo, saved[sbounds[b]:sbounds[b + 1]], ps[bounds[b]:bounds[b + 1]], metas[b],
+                                                g, need_dx, flat=flat[sp.base[b]:sp.base[b + 1]],
+                                                pending=pending)
+            any_fold = any_fold or fl
+        if pending:
+            reduce_pending(pending)
+        if any_fold:
+            if sp.fold_bwd is None:
+                raise RuntimeError("the stack's fold tables are missing")
+            _small_gemm(sp.fold_bwd, flat.data_ptr(), dev)
+        if WGRAD_SIDE_STREAM:
+            torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+        hook = getattr(blocks[0], "_grad_bucket_hook", None)
+        if hook is not None:      # data-parallel: ONE all-reduce for the whole stack's bucket
+            hook(flat)
+        return (g, None, None, None, None, *[t_ for gr in grads_all for t_ in gr])
 
 
 class PFN(nn.Module):
@@ -1176,11 +1373,17 @@ class PFN(nn.Module):
                 self.mpns.append(MPN(dim_featn, dim_feate, dim_out, dim_hid, n_gnn_layers, K, dropout_rate))
             else:
                 self.mpns.append(self.inner(dim_featn, dim_feate, dim_featn, dim_hid, n_gnn_layers, K, dropout_rate))
+        self._stack_plan = None
 
     def forward(self, x, edge_index, edge_attr):
-        for m in self.mpns:
-            x = m(x, edge_index, edge_attr)
-        return x
+        _require_gpu(x, edge_index, edge_attr)
+        if not STACK_NODE or self.n_gnn_layers + 1 >= _StackPlan.DROP_STRIDE:
+            for m in self.mpns:
+                x = m(x, edge_index, edge_attr)
+            return x
+        topo = get_topology(edge_index, x.size(0))
+        params = [m._params() for m in self.mpns]
+        return _PFNFn.apply(x, edge_attr, topo, self, tuple(len(p) for p in params), *[t_ for p in params for t_ in p])
 
 
 class SkipPFN(PFN):

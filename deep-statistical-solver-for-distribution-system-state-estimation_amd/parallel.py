@@ -97,7 +97,9 @@ def allreduce_flat_grads(flat: torch.Tensor, group=None, pending: Optional[List]
 
 def attach_grad_allreduce(model: torch.nn.Module, group=None, async_op: bool = False) -> int:
     """Install the flat-bucket all-reduce on every MPN block of `model` (MPN / SkipMPN themselves,
-    or the blocks inside PFN / SkipPFN).  Returns the number of blocks hooked.
+    or the blocks inside PFN / SkipPFN).  Returns the number of blocks hooked.  A PFN / SkipPFN stack runs as one
+    autograd node with ONE gradient bucket (networks._PFNFn): it issues a single collective per step, through the hook
+    of its first block.
 
     ``async_op=True``: each block's collective is launched as soon as that block's backward has produced its bucket
     and overlaps the backward of the blocks below it (a PFN / SkipPFN stack then has its L collectives in flight

@@ -244,7 +244,8 @@ def test_edge_aggregation_message_and_propagate_are_the_reference_expression(pkg
 
 def _export_masks(pkg, block, n_rows, hid):
     snap, p = block._last_dropout
-    return [pkg.networks.dropout_mask(snap, p, l + 1, n_rows, hid).cpu() for l in range(block.n_gnn_layers - 1)]
+    base = getattr(block, "_drop_base", 0)          # blocks of a PFN stack share one snapshot, ids offset per block
+    return [pkg.networks.dropout_mask(snap, p, base + l + 1, n_rows, hid).cpu() for l in range(block.n_gnn_layers - 1)]
 
 
 @pytest.mark.parametrize("cls,args,grids,B", [

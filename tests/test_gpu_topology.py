@@ -87,13 +87,15 @@ def test_device_build_edge_cases(pkg):
         _check(topo, ref)
     # forced doubling of a list that already holds both directions (parallel edges)
     _check(pkg.topology.Topology(ei.to(DEV), 7, double=True), topo_oracle.TopologyOracle(ei, 7, double=True))
-    # a component above the largest tile: the CSR part (what the loss and propagate use) is built, the tile part raises
+    # a component above the largest tile: the CSR part is built as always; the tile part degrades to uniform 64-row tiles
+    # without graph structure (global-memory propagation path, tests/test_gpu_large_graphs.py)
     n = 400
     chain = torch.stack([torch.arange(n - 1), torch.arange(1, n)])
     topo = pkg.topology.Topology(chain.to(DEV), n)
     _check(topo, topo_oracle.TopologyOracle(chain, n), tiles=False)
-    with pytest.raises(NotImplementedError):
-        topo.nrb
+    assert topo.global_only and topo.nrb == 2 and topo.ntiles == -(-n // 64) and topo.ell_tiles is None
+    assert topo.tile_start.tolist() == [min(64 * i, n) for i in range(topo.ntiles + 1)]
+    assert topo.stats()["max_segment"] == n
     # node ids outside [0, N) are reported, not dereferenced
     bad = pkg.topology.Topology(torch.tensor([[0, 1], [1, 9]]).to(DEV), 3)
     with pytest.raises(ValueError):
