@@ -54,7 +54,7 @@ struct WgradBatch {
 };
 
 template <int NRB, int NMAT, int NB>
-__global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgrad_args p, int nibg, const WgradBatch wb) {
+__global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgrad_args p, int nibg, const WgradBatch wb, int ksplit) {
   const float* __restrict__ Gp = wb.n > 0 ? wb.G[blockIdx.z] : p.G;
   const float* __restrict__ Xp = wb.n > 0 ? wb.X[blockIdx.z] : p.X;
   float* __restrict__ slabp = wb.n > 0 ? wb.slab[blockIdx.z] : p.slab;
@@ -89,10 +89,18 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   const int lane = tid & 63;
   const int c32 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ibw = wave & 3, obh = wave >> 2;
+  const int obh = wave >> 2;
   const int obg = blockIdx.y / nibg, ibg = blockIdx.y - obg * nibg;
   const int gcol0 = obg * LDZ;
   const int xcol0 = ibg * XW;
+  // K split (4-wave kernels, narrow inputs): with one or two 32-column input blocks only one or two of the four waves
+  // would own an accumulator (H = 32: 96 MFMAs per tile on ONE wave).  The idle waves take a share of the tile's rows
+  // (k steps j = ks, ks + KS, ..) for the same output block instead; the partial accumulators meet once, after the last
+  // tile, in a fixed order through LDS.
+  const int nib_act = min(4, (p.hin - xcol0 + 31) >> 5);
+  const int KS = (NB == 1 && ksplit) ? (nib_act == 1 ? 4 : (nib_act == 2 ? 2 : 1)) : 1;
+  const int ibw = KS > 1 ? (wave & 3) % nib_act : (wave & 3);
+  const int ks = KS > 1 ? (wave & 3) / nib_act : 0;
   const bool wave_active = (xcol0 + ibw * 32) < p.hin;
 
   f32x16 acc[NMAT][NBW];
@@ -118,16 +126,19 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
 
   auto mma = [&](const float* Z, f32x16 (&a)[NBW], int R) {
     if (!wave_active) return;
-    const int n2e = (R + 1) >> 1;
-    const float* zp = Z + half * LDZ + obh * NBW * 32 + c32;
-    const float* xp = Xs + half * xw + ibw * 32 + c32;
+    const int n2a = (R + 1) >> 1;
+    const int n2e = n2a > ks ? (n2a - ks + KS - 1) / KS : 0;      // this wave's share of the k steps
+    if (n2e == 0) return;
+    const float* zp = Z + (half + 2 * ks) * LDZ + obh * NBW * 32 + c32;
+    const float* xp = Xs + (half + 2 * ks) * xw + ibw * 32 + c32;
+    const int zstep = KS * 2 * LDZ, xstep = KS * 2 * xw;
     // two operand register sets in ping-pong: the LDS reads of step n2+1 are in flight while the
     // MFMAs of step n2 issue (no register copies => the wait sits at the first use)
     float b0, b1, a0[NBW], a1[NBW];
     auto ld = [&](float& b, float (&av)[NBW], int n2) {
-      b = xp[n2 * 2 * xw];
+      b = xp[n2 * xstep];
 #pragma unroll
-      for (int ob = 0; ob < NBW; ++ob) av[ob] = zp[n2 * 2 * LDZ + ob * 32];
+      for (int ob = 0; ob < NBW; ++ob) av[ob] = zp[n2 * zstep + ob * 32];
     };
     auto mm = [&](float b, const float (&av)[NBW]) {
 #pragma unroll
@@ -428,10 +439,28 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
       dbacc += s;
     }
   }
+  if (KS > 1) {      // (uniform) K-split partial accumulators -> the ks = 0 wave of each input block, fixed order
+    __syncthreads();  // the slabs are dead
+    float* red = smem;   // [KS - 1][nib_act][16][64]
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m) {
+      if (ks > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(((ks - 1) * nib_act + ibw) * 16 + r) * 64 + lane] = acc[m][0][r];
+      }
+      __syncthreads();
+      if (ks == 0) {
+        for (int q = 1; q < KS; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][0][r] += red[(((q - 1) * nib_act + ibw) * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+  }
   // ---- one slab per workgroup column blockIdx.x; the y-slices tile the [nmat*hout, hin] matrix
   const size_t stride = (size_t)p.nmat * p.hout * p.hin + p.hout + (rs2 ? (size_t)p.nmat * p.hout : 0);
   float* out = slabp + (size_t)blockIdx.x * (wb.slab_stride > 0 ? (size_t)wb.slab_stride : stride);
-  if (wave_active) {
+  if (wave_active && ks == 0) {
     const int i = xcol0 + ibw * 32 + c32;
     if (i < p.hin) {
 #pragma unroll
@@ -569,6 +598,7 @@ static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz, int ell_width, b
   size_t b = TM * (size_t)nb * 32 * 4 * (wgrad_pf(nrb, nmat) ? 3 : (nmat > 1 ? 2 : 1)) + TM * xw * 4 + TM * 16;
   b += (size_t)(nb >= 2 ? 512 : 256) * 16;   // running bias partials, one 16-byte slot per thread
   if (graph) b += ell_width > 0 ? TM * (size_t)ell_width * 8 : (TM + 2) * 4 + (size_t)max_nnz * 8;
+  if (nb == 1 && b < 3 * 16 * 64 * 4) b = 3 * 16 * 64 * 4;     // the K-split's final reduction: three partial accumulators
   return b;
 }
 
@@ -604,7 +634,8 @@ static int launch_wgrad(const dss2_wgrad_args& a, hipStream_t stream, const Wgra
   const int nob = (a.hout + 31) / 32, nib = (a.hin + 31) / 32;
   const int nobg = (nob + NB - 1) / NB, nibg = (nib + 3) / 4;
   const size_t lds = wgrad_lds(NRB, NMAT, NB, a.max_nnz, a.ell_width, NMAT > 1 || a.narrow, a.hin);
-  hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg, wb.n > 0 ? wb.n : 1), dim3(WgradGeom<NB>::NT), lds, stream, a, nibg, wb);
+  static const int ksplit = [] { const char* e = getenv("DSS2_WGRAD_KSPLIT"); return e ? atoi(e) : 1; }();
+  hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg, wb.n > 0 ? wb.n : 1), dim3(WgradGeom<NB>::NT), lds, stream, a, nibg, wb, ksplit);
   return check_launch("wgrad");
 }
 
