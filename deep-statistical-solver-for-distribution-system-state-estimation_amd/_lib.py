@@ -36,7 +36,7 @@ class GemmPropArgs(C.Structure):
                 ("prop_in", C.c_int32), ("narrow_h", C.c_int32),
                 ("prebias", C.c_void_p), ("pre_rowscale", C.c_void_p), ("ell_tiles", C.c_void_p),
                 ("drop_state", C.c_void_p), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float), ("drop_id", C.c_int32),
-                ("pad2_", C.c_int32)]
+                ("b_format", C.c_int32)]
 
 
 class WgradArgs(C.Structure):
@@ -161,6 +161,7 @@ _SIGNATURES = {
     "dss2_gemm_prop": (C.c_int, [C.POINTER(GemmPropArgs), C.c_void_p]),
     "dss2_gemm_prop_chain": (C.c_int, [C.POINTER(GemmPropArgs), C.c_void_p, C.c_int, C.c_void_p]),
     "dss2_gemm_prop_chain_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dss2_gemm_prop_chain16_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p]),
     "dss2_wgrad_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "dss2_reduce_slabs_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

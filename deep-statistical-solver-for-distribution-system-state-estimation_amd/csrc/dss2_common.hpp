@@ -28,6 +28,28 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 // 32x32 MFMA accumulator register r of lane -> row inside the 32-row block
 // (col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); CDNA4 C/D layout.
+// ---- fp32 on the bf16 matrix pipe ("bf16x6") -----------------------------------------------------------------------------
+// v = h + m + l with three bf16 pieces of 8 significant bits each (every residual is exact in fp32), so
+//   a * b = ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh) + O(2^-27 |a b|):
+// six v_mfma_f32_32x32x16_bf16 (fp32 accumulation inside the MFMA) reproduce the fp32 product below fp32's own rounding,
+// at 6 x 2 = 12 cycles per unit of k against 32 for v_mfma_f32_32x32x2_f32 (MI355X: the fp32 MFMA runs at 1/16 of bf16).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)v;
+  const float r1 = v - (float)h;
+  m = (__bf16)r1;
+  l = (__bf16)(r1 - (float)m);
+}
+__device__ __forceinline__ void split3x4(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    __bf16 a, b, c;
+    split3(v[q], a, b, c);
+    h[q] = a; m[q] = b; l[q] = c;
+  }
+}
+
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 // Orders LDS traffic between lanes of ONE wave (DS ops of a wave execute in order; this keeps

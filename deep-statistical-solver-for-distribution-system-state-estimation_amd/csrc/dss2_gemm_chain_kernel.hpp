@@ -1,0 +1,301 @@
+// Layer-chained variant of gemm_prop (keep a graph resident in LDS across layers).
+//
+// Tiles hold whole graphs, so layer l+1 of a tile depends only on layer l of the SAME tile: a chain of
+// H -> H TAGConv layers (forward) or of their data-gradients (backward) runs inside one workgroup with the
+// activation tile staying in LDS.  Every layer's output still goes to HBM once (the backward pass and the
+// weight gradients read it), but it is never read back, and the per-launch ramp/drain is paid once per
+// chain instead of once per layer.  Per layer: MFMA over the X tile -> barrier (everyone is done reading
+// X) -> Horner in the wave-private stage -> epilogue to HBM and, in place, into the X tile -> barrier.
+//
+// Restricted to what the hot configurations need (the general kernel covers the rest): ELL tile slices,
+// 16-byte aligned operands, one 32-column group per wave (4 waves for H <= 128, 8 waves up to H = 256),
+// H_in == H_out for every layer.
+#pragma once
+#include "dss2_common.hpp"
+
+namespace dss2 {
+
+constexpr int CHAIN_MAX = 8;
+struct ChainTable { dss2_chain_layer l[CHAIN_MAX]; int n; };
+
+constexpr int chain_waves_per_simd(int nrb, int nmat) { return nrb * nmat * 16 <= 128 ? 2 : 1; }
+
+// NW: waves per workgroup the kernel is compiled for.  RS: row split -- RS waves share one 32-column group, each owning
+// NRB / RS of the tile's row blocks (its accumulators, its rows of the group's stage and of the epilogue); the
+// Horner gather reads the other waves' rows, so with RS > 1 the stage hand-offs are workgroup barriers.  RS = 2
+// gives narrow layers (H <= 64: one or two column groups) enough waves to hide their latencies.
+//
+// B16: the tile GEMM on the bf16 matrix pipe, fp32-accurate ("bf16x6", dss2_common.hpp: split3).  The weights come as
+// bf16x3 fragments (dss2_pack_weights, transpose | 2: [m][col group][k/16][plane][lane][8]); the activation tile stays fp32
+// in LDS (same footprint, two workgroups per CU as before) and a wave splits its A fragment -- 8 consecutive k of its row
+// -- into the three bf16 pieces in registers (VALU work that issues in the shadow of the MFMAs).  Per 16 k and
+// (row block, matrix): six v_mfma_f32_32x32x16_bf16 = 192 cycles against 512 for eight v_mfma_f32_32x32x2_f32.
+template <int NRB, int NMAT, int NW, int RS, bool B16>
+__global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT)) gemm_chain_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
+  static_assert(NRB % RS == 0, "row split must divide the row blocks");
+  constexpr int TM = NRB * 32;
+  constexpr int NRW = NRB / RS;          // row blocks per wave
+  constexpr int PF = 8;
+  constexpr int LDA = TM + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nthreads = blockDim.x;
+  const int nw = nthreads >> 6;
+  const int LDX = p.kpad + 4;
+  const int tile = blockIdx.x;
+  const uint64_t drop_seed = p.drop_state ? p.drop_state[0] : 0, drop_off = p.drop_state ? p.drop_state[1] : 0;
+  float* Xs = smem;
+  float* stage = Xs + TM * LDX;
+  const int D = p.ell_width;
+  int2* ell = reinterpret_cast<int2*>(stage + (nw / RS) * 32 * LDA);   // one stage per column group
+  const int ts = p.tile_start[tile];
+  const int R = p.tile_start[tile + 1] - ts;
+  const int kq = p.kpad >> 2;
+
+  // ---- stage the first layer's input tile (zero padded to TM x kpad) and the tile's ELL slice
+  if (TM * kq <= PF * nthreads) {
+    f32x4 px[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int idx = tid + i * nthreads;
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < TM * kq && r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
+      px[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int idx = tid + i * nthreads;
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      if (idx < TM * kq) *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = px[i];
+    }
+  } else {
+    for (int idx = tid; idx < TM * kq; idx += nthreads) {
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
+      *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = v;
+    }
+  }
+  {
+    const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
+    for (int idx = tid; idx < D * TM; idx += nthreads) ell[idx] = src[idx];
+  }
+  __syncthreads();
+
+  const int c32 = lane & 31, half = lane >> 5;
+  const int nkk = p.kpad >> 3;
+  const float* xa = Xs + c32 * LDX + half * 4;
+  const int cg = wave / RS, rs = wave - cg * RS;   // column group, and which share of its row blocks
+  float* st = stage + cg * (32 * LDA);      // per column group [TM][32] row-major (wave-private when RS == 1)
+  auto stage_sync = [&]() { if (RS == 1) wave_lds_sync(); else __syncthreads(); };
+  const int ecol0 = cg * 32 + (lane & 7) * 4;
+  const int cq = (lane & 7) * 4, r8 = lane >> 3;
+  const bool ecol_ok = ecol0 < p.hout;
+
+  for (int li = 0; li < ct.n; ++li) {
+    const dss2_chain_layer& L = ct.l[li];    // uniform: scalar loads from the kernel-argument segment
+    const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(L.Bp);
+    f32x16 acc[NRW][NMAT];
+#pragma unroll
+    for (int rb = 0; rb < NRW; ++rb)
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][m][r] = 0.f;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (L.bias && ecol_ok) bias4 = *reinterpret_cast<const f32x4*>(L.bias + ecol0);
+
+    if constexpr (B16) {
+      // ---- bf16x6: 16 k per step; B fragments (L2) ping-pong, A fragment read as fp32 from LDS and split in registers
+      const bf16x8* __restrict__ bp16 = reinterpret_cast<const bf16x8*>(L.Bp);
+      const int nks = p.kpad >> 4;
+      const float* xa16 = Xs + c32 * LDX + half * 8;
+      bf16x8 b0[3][NMAT], b1[3][NMAT];
+      auto load_b = [&](bf16x8 (&b)[3][NMAT], int ks) {
+        const int kc = ks < nks ? ks : nks - 1;
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) b[pl][m] = bp16[(((size_t)(m * p.ncg + cg) * nks + kc) * 3 + pl) * 64 + lane];
+      };
+      auto step16 = [&](const bf16x8 (&b)[3][NMAT], int ks) {
+#pragma unroll
+        for (int rb = 0; rb < NRW; ++rb) {
+          const float* src = xa16 + (rs * NRW + rb) * 32 * LDX + ks * 16;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+          bf16x8 ah, am, al;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            __bf16 h_, m_, l_;
+            split3(v0[q], h_, m_, l_); ah[q] = h_; am[q] = m_; al[q] = l_;
+            split3(v1[q], h_, m_, l_); ah[4 + q] = h_; am[4 + q] = m_; al[4 + q] = l_;
+          }
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m) {      // smallest terms first
+            f32x16 c = acc[rb][m];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[0][m], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[1][m], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[2][m], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[0][m], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[1][m], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[0][m], c, 0, 0, 0);
+            acc[rb][m] = c;
+          }
+        }
+      };
+      load_b(b0, 0);
+      int ks = 0;
+      for (; ks + 2 <= nks; ks += 2) {
+        load_b(b1, ks + 1);
+        step16(b0, ks);
+        load_b(b0, ks + 2);
+        step16(b1, ks + 1);
+      }
+      if (ks < nks) step16(b0, ks);
+    } else {
+    // ---- MFMA over the X tile: 8 k per step, A (LDS) / B (packed weights, L2) ping-pong prefetch
+    f32x4 a0[NRW] = {}, a1[NRW] = {}, b0[NMAT] = {}, b1[NMAT] = {};
+    auto load_ab = [&](f32x4 (&a)[NRW], f32x4 (&b)[NMAT], int kk) {
+      const int kc = kk < nkk ? kk : nkk - 1;
+#pragma unroll
+      for (int rb = 0; rb < NRW; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(xa + (rs * NRW + rb) * 32 * LDX + kc * 8);
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) b[m] = bp[((size_t)(m * p.ncg + cg) * nkk + kc) * 64 + lane];
+    };
+    auto mma_ab = [&](const f32x4 (&a)[NRW], const f32x4 (&b)[NMAT]) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rb = 0; rb < NRW; ++rb)
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m)
+            acc[rb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][s], b[m][s], acc[rb][m], 0, 0, 0);
+    };
+    load_ab(a0, b0, 0);
+    int kk = 0;
+    for (; kk + 2 <= nkk; kk += 2) {
+      load_ab(a1, b1, kk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_ab(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_ab(a0, b0, kk + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_ab(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kk < nkk) mma_ab(a0, b0);
+    }
+    // every wave is done with this layer's X tile: the epilogue below overwrites it in place
+    if (li + 1 < ct.n) __syncthreads();
+
+    // ---- Horner: T = G_{NMAT-1}; T = G_m + P T   (ELL slice, wave-private stage)
+    f32x16 T[NRW];
+#pragma unroll
+    for (int rb = 0; rb < NRW; ++rb) T[rb] = acc[rb][NMAT - 1];
+#pragma unroll
+    for (int m = NMAT - 2; m >= 0; --m) {
+      stage_sync();
+#pragma unroll
+      for (int rb = 0; rb < NRW; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[((rs * NRW + rb) * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
+      stage_sync();
+#pragma unroll
+      for (int rb = 0; rb < NRW; ++rb) T[rb] = acc[rb][m];
+      for (int k = 0; k < D; ++k) {
+        const int2* ek = ell + k * TM + 4 * half;
+#pragma unroll
+        for (int rb = 0; rb < NRW; ++rb) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int2 en = ek[(rs * NRW + rb) * 32 + acc_row(r, 0)];
+            T[rb][r] = fmaf(__int_as_float(en.y), st[en.x * 32 + c32], T[rb][r]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+
+    // ---- epilogue: T -> stage -> 16-byte rows -> HBM (and the next layer's X tile)
+    f32x4 pb4[NMAT];
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m) pb4[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (L.prebias && ecol_ok) {
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) pb4[m] = *reinterpret_cast<const f32x4*>(L.prebias + (size_t)m * p.hout + ecol0);
+    }
+    stage_sync();      // (RS > 1: the other waves are done gathering from the stage)
+#pragma unroll
+    for (int rb = 0; rb < NRW; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[((rs * NRW + rb) * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
+    wave_lds_sync();   // the epilogue of a wave reads only the rows it wrote itself
+    const int col0 = cg * 32 + cq;
+    const bool keep = li + 1 < ct.n;
+    const int rlo = rs * NRW * 32, rhi = min(R, (rs + 1) * NRW * 32);     // this wave's rows
+    if (col0 < p.hout) {
+      for (int row0 = rlo + r8; row0 < rhi; row0 += 16) {
+        f32x4 y[2], rs[2], dm[2], ad[2], ps[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int row = row0 + 8 * u;
+          const bool ok = row < rhi;
+          const size_t grow = (size_t)(ts + (ok ? row : rlo));
+          y[u] = *reinterpret_cast<const f32x4*>(st + (ok ? row : rlo) * 32 + cq);
+          if (L.prebias) ps[u] = *reinterpret_cast<const f32x4*>(p.pre_rowscale + grow * 4);
+          if (L.dmask) dm[u] = *reinterpret_cast<const f32x4*>(L.dmask + grow * p.ld_dmask + col0);
+          if (L.relu_src) rs[u] = *reinterpret_cast<const f32x4*>(L.relu_src + grow * p.ld_relu + col0);
+          if (L.add_src) ad[u] = *reinterpret_cast<const f32x4*>(L.add_src + grow * p.ld_add + col0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int row = row0 + 8 * u;
+          if (row >= rhi) continue;
+          f32x4 v = y[u];
+          if (L.bias) v += bias4;
+          if (L.prebias) {
+#pragma unroll
+            for (int m = 0; m < NMAT; ++m) v += pb4[m] * ps[u][m];
+          }
+          if (L.dmask) v *= dm[u];
+          if (L.drop_id) v *= dropout_mult4(drop_seed, drop_off, (uint32_t)L.drop_id, (uint32_t)(ts + row), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
+          if (L.relu & 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+          }
+          if (L.relu_src) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = rs[u][q] > 0.f ? v[q] : 0.f;
+          }
+          if (L.add_src) v += ad[u];
+          *reinterpret_cast<f32x4*>(L.Y + (size_t)(ts + row) * p.ldy + col0) = v;
+          if (keep) *reinterpret_cast<f32x4*>(Xs + row * LDX + col0) = v;
+        }
+      }
+    }
+    if (keep) __syncthreads();   // the next layer's X tile is complete
+  }
+}
+
+inline size_t chain_lds_bytes(int nrb, int kpad, int ncg, int ell_width) {
+  const size_t TM = (size_t)nrb * 32;
+  return TM * (size_t)(kpad + 4) * 4 + (size_t)ncg * 32 * (TM + 4) * 4 + TM * (size_t)ell_width * 8;
+}
+
+template <int NRB, int NMAT, int NW, int RS, bool B16 = false>
+inline int launch_chain(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t stream) {
+  static std::atomic<uint32_t> lds_done{0};
+  auto kern = gemm_chain_kernel<NRB, NMAT, NW, RS, B16>;
+  if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop_chain")) return 1;
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg * RS), chain_lds_bytes(NRB, a.kpad, a.ncg, a.ell_width), stream, a, ct);
+  return check_launch("gemm_prop_chain");
+}
+
+
+// the bf16x6 instantiations live in their own translation unit (dss2_gemm_chain16.hip, compiled without packed fp32 ops)
+int launch_chain16(const dss2_gemm_prop_args& a, const ChainTable& ct, int rsplit, hipStream_t s);
+
+}  // namespace dss2

@@ -65,6 +65,10 @@ def _round8(k: int) -> int:
     return (k + 7) // 8 * 8
 
 
+def _round16(k: int) -> int:
+    return (k + 15) // 16 * 16
+
+
 def _ncg(j: int) -> int:
     return (j + 31) // 32
 
@@ -114,21 +118,28 @@ def chain_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bo
         _lib.lib().dss2_gemm_prop_chain_supported(topo.nrb, nmat, hid, hid, ell))
 
 
+def chain16_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bool:
+    """True when the chain can run its tile GEMM on the bf16 matrix pipe (bf16x6, fp32-accurate; dss2_gemm_chain16.hip)."""
+    ell, tiles = (topo.ellT, topo.ellT_tiles) if transposed else (topo.ell, topo.ell_tiles)
+    return CHAIN_BF16 and tiles is not None and bool(_lib.lib().dss2_gemm_prop_chain16_supported(topo.nrb, nmat, hid, hid, ell))
+
+
 def gemm_prop_chain(topo: Topology, X: torch.Tensor, hid: int, nmat: int, layers: Sequence[dict], transposed: bool = False,
-                    pre_rowscale=None, drop=None) -> None:
+                    pre_rowscale=None, drop=None, b_format: int = 0) -> None:
     """layers: dicts with Bp, Y and optionally bias, relu, relu_src, dmask, prebias; every tensor is [N, hid]
     contiguous.  Layer i reads layer i-1's output from LDS; every Y is written once.  The library chains at most
     CHAIN_MAX layers per launch; deeper stacks run as consecutive launches (the next one reads the previous one's last Y)."""
     if len(layers) > CHAIN_MAX:
         for c0 in range(0, len(layers), CHAIN_MAX):
             gemm_prop_chain(topo, X if c0 == 0 else layers[c0 - 1]["Y"], hid, nmat, layers[c0:c0 + CHAIN_MAX],
-                            transposed=transposed, pre_rowscale=pre_rowscale, drop=drop)
+                            transposed=transposed, pre_rowscale=pre_rowscale, drop=drop, b_format=b_format)
         return
     a = _lib.GemmPropArgs()
+    a.b_format = b_format          # 1: every layer's Bp holds bf16x3 fragments (_PackPlan.fwd16 / bwd16)
     if drop is not None:            # (snapshot, p); the layers name their masks with "drop_id"
         a.drop_state = drop[0].data_ptr()
         a.drop_thr, a.drop_scale = _dropout_params(drop[1])
-    a.X, a.ldx, a.kreal, a.kpad = X.data_ptr(), X.stride(0), hid, _round8(hid)
+    a.X, a.ldx, a.kreal, a.kpad = X.data_ptr(), X.stride(0), hid, (_round16(hid) if b_format == 1 else _round8(hid))
     a.hout, a.ncg, a.ldy, a.ld_relu, a.ld_dmask, a.ld_add = hid, _ncg(hid), hid, hid, hid, hid
     a.nmat, a.nrb, a.ntiles = nmat, topo.nrb, topo.ntiles
     a.tile_start = topo.tile_start.data_ptr()
@@ -397,7 +408,8 @@ class _PackPlan:
     """Fragment-packed copies (forward and data-gradient layouts) of a list of weight matrices,
     refreshed by ONE kernel launch per forward."""
 
-    def __init__(self, groups: Sequence[Sequence[torch.Tensor]], device, stacked: bool = False, stacked_groups=()):
+    def __init__(self, groups: Sequence[Sequence[torch.Tensor]], device, stacked: bool = False, stacked_groups=(),
+                 bf16_groups=()):
         # groups[g] = the nmat matrices [hout, hin] of one fused GEMM (TAGConv lins, or one Linear);
         # entries are Parameters or _MatView blocks of a Parameter.
         # stacked: every group uses the narrow layouts whatever its width -- forward = matrices side by side along the
@@ -419,6 +431,16 @@ class _PackPlan:
                 self.fwd.append(torch.zeros(nm * cf * (kf // 8) * 256, dtype=_F32, device=device))
                 self.bwd.append(torch.zeros(nm * cb * (kb // 8) * 256, dtype=_F32, device=device))
             self.meta.append((nm, hout, hin, kf, cf, kb, cb))
+        # bf16_groups: additionally the bf16x3 fragment layout (fp32-accurate tile GEMM on the bf16 matrix pipe,
+        # csrc/dss2_gemm_chain16.hip): [matrix][col group][k/16][3 planes][64 lanes][8 bf16]
+        self.fwd16, self.bwd16 = {}, {}
+        for g in bf16_groups:
+            nm, hout, hin = self.meta[g][0:3]
+            if is_narrow(nm, hout) or self._stk[g]:
+                raise ValueError("bf16x3 packing is for plain per-matrix layouts")
+            kf, cf, kb, cb = _round16(hin), _ncg(hout), _round16(hout), _ncg(hin)
+            self.fwd16[g] = torch.zeros(nm * cf * (kf // 16) * 768, dtype=_F32, device=device)
+            self.bwd16[g] = torch.zeros(nm * cb * (kb // 16) * 768, dtype=_F32, device=device)
         self.ptrs = None
         self.table = None
         self.max_elems = 0
@@ -444,6 +466,10 @@ class _PackPlan:
                     recs.append((w.data_ptr(), self.fwd[g].data_ptr() + 4 * m * cf * (kf // 8) * 256, hout, hin, w.ld, 1, 0, kf, cf, 0))
                     recs.append((w.data_ptr(), self.bwd[g].data_ptr() + 4 * m * cb * (kb // 8) * 256, hout, hin, w.ld, 0, 0, kb, cb, 0))
                 self.max_elems = max(self.max_elems, (cf + 1) * (kf // 8 + 1) * 64, (cb + 1) * (kb // 8 + 1) * 64)
+                if g in self.fwd16:      # transpose | 2: bf16x3 layout
+                    k16, b16 = _round16(hin), _round16(hout)
+                    recs.append((w.data_ptr(), self.fwd16[g].data_ptr() + 4 * m * cf * (k16 // 16) * 768, hout, hin, w.ld, 3, 0, k16, cf, 0))
+                    recs.append((w.data_ptr(), self.bwd16[g].data_ptr() + 4 * m * cb * (b16 // 16) * 768, hout, hin, w.ld, 2, 0, b16, cb, 0))
         return recs
 
     def _build_table(self):
@@ -679,6 +705,7 @@ _SIDE_STREAMS = {}
 EDGE_TILE_KERNELS = _os.environ.get("DSS2_EDGE_TILE", "1") == "1"       # 0 = row-per-wave CSR kernels
 WGRAD_SIDE_STREAM = _os.environ.get("DSS2_WGRAD_STREAM", "0") == "1"   # opt-in: +3 % at C2 (kernels then overlap)
 CHAIN_LAYERS = _os.environ.get("DSS2_CHAIN", "1") == "1"               # hid->hid layers of a block: one chained launch
+CHAIN_BF16 = _os.environ.get("DSS2_CHAIN_BF16", "1") == "1"            # its tile GEMM as bf16x6 on the bf16 matrix pipe (fp32-accurate)
 WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"
 STACK_NODE = _os.environ.get("DSS2_STACK_NODE", "1") == "1"              # PFN / SkipPFN as ONE autograd node (_PFNFn)
 DX_MERGE = _os.environ.get("DSS2_DX_MERGE", "1") == "1"                  # dx of the edge MLP as ONE K = 2 hid GEMM
@@ -1011,14 +1038,16 @@ def _ensure_plans(mod, topo, dev, ps):
     hout0 = mod.dim_out if L == 1 else hid
     glob = topo.global_only       # graphs beyond the LDS-resident tiles: plain GEMMs + propagation hops in global memory
     fold_on = FOLD_W2 and not is_narrow(nmat, hout0) and not glob
-    if mod._plan is None or mod._plan.device != dev or (mod._fold is not None) != fold_on or mod._plan.stacked != glob:
+    b16 = tuple(range(1, L)) if (CHAIN_BF16 and not glob and L >= 3 and hid % 4 == 0 and hid <= 128 and not is_narrow(nmat, hid)) else ()
+    if (mod._plan is None or mod._plan.device != dev or (mod._fold is not None) != fold_on or mod._plan.stacked != glob
+            or tuple(sorted(mod._plan.fwd16)) != b16):
         offs = mod._flat_offsets()
         mod._fold = _FoldPlan(W2, b2, conv_ps[0][1:], dev, int(offs[1]), int(offs[2])) if fold_on else None
         conv_groups = [list(cp[1:]) for cp in conv_ps]
         if fold_on:   # conv 0 is packed from the folded weights
             conv_groups[0] = [mod._fold.Wf[m] for m in range(nmat)]
         mod._plan = _PackPlan([[W2]] + conv_groups + _dx_views(W1, hid, mod.dim_featn, mod.dim_feate), dev, stacked=glob,
-                              stacked_groups=(L + 3,))
+                              stacked_groups=(L + 3,), bf16_groups=b16)
     if mod._fold is not None:
         mod._fold.params = (W2, b2, list(conv_ps[0][1:]))
     return mod._plan, mod._fold, glob
@@ -1065,13 +1094,14 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
     n_chain = L - 1 if (L - 1 >= 2 and chain_supported(topo, nmat, hid, False)) else 0
     if n_chain:
         layers = []
+        use16 = bool(plan.fwd16) and chain16_supported(topo, nmat, hid, False)
         for l in range(n_chain):
             out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
-            layers.append(dict(Bp=plan.fwd[1 + l], Y=out_l, bias=conv_ps[l][0], relu=True, drop_id=drop_id(l),
-                               prebias=(fold.bf if (fold is not None and l == 0) else None)))
+            layers.append(dict(Bp=(plan.fwd16[1 + l] if use16 else plan.fwd[1 + l]), Y=out_l, bias=conv_ps[l][0], relu=True,
+                               drop_id=drop_id(l), prebias=(fold.bf if (fold is not None and l == 0) else None)))
             acts.append(out_l)
         gemm_prop_chain(topo, h, hid, nmat, layers, pre_rowscale=(topo.deg_pows if fold is not None else None),
-                        drop=((snap, p) if snap is not None else None))
+                        drop=((snap, p) if snap is not None else None), b_format=int(use16))
         h = acts[-1]
     for l in range(n_chain, L):
         last = l == L - 1
@@ -1136,13 +1166,15 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         gl = [None] * (L - 1)                   # gl[l]: gradient w.r.t. layer l's pre-activation output
         gl[L - 2] = g
         layers = []
+        use16 = bool(plan.bwd16) and chain16_supported(topo, nmat, hid, True)
         for l in range(L - 2, -1, -1):
             out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
-            layers.append(dict(Bp=plan.bwd[1 + l], Y=out_l, relu_src=(acts[l] if l > 0 else None),
+            layers.append(dict(Bp=(plan.bwd16[1 + l] if use16 else plan.bwd[1 + l]), Y=out_l, relu_src=(acts[l] if l > 0 else None),
                                drop_id=(base + l if (l > 0 and snap is not None) else 0)))      # mask of conv l-1: id (l-1)+1
             if l > 0:
                 gl[l - 1] = out_l
-        gemm_prop_chain(topo, g, hid, nmat, layers, transposed=True, drop=((snap, p_drop) if snap is not None else None))
+        gemm_prop_chain(topo, g, hid, nmat, layers, transposed=True, drop=((snap, p_drop) if snap is not None else None),
+                        b_format=int(use16))
         d_in = layers[-1]["Y"]                  # gradient w.r.t. conv 0's input: dS (folded) or dx0
         # (joining conv 0 pays only when the tiles still divide evenly over the workgroups the layers share:
         #  at C2 three layers x 85 workgroups leave a 13-vs-12-tile tail that costs more than the launch saves)

@@ -119,7 +119,9 @@ typedef struct dss2_pack_desc {
   const float* src;   /* W, row-major [rows, cols] with leading dimension ld            */
   float* dst;         /* packed matrix base: [ncg][kpad/8][64 lanes][4]                 */
   int32_t rows, cols, ld;
-  int32_t transpose;  /* 1: B[k][j] = W[j][k] (forward, K=cols); 0: B[k][j] = W[k][j]   */
+  int32_t transpose;  /* bit 0: 1: B[k][j] = W[j][k] (forward, K=cols); 0: B[k][j] = W[k][j].
+                       * bit 1: write the bf16x3 layout [ncg][kpad/16][3 planes][64 lanes][8 bf16] (kpad a multiple of 16):
+                       * every weight split into three bf16 pieces h + m + l for the fp32-accurate bf16 MFMA path        */
   int32_t koff;       /* k offset of this block inside the packed matrix (any value)   */
   int32_t kpad;       /* padded K of the packed matrix (multiple of 8)                  */
   int32_t ncg;        /* number of 32-column groups of the packed matrix                */
@@ -234,7 +236,8 @@ typedef struct dss2_gemm_prop_args {
    * drop_scale = 1/(1-p) according to Philox4x32-10(seed, offset, drop_id, row, col/4) >= drop_thr = p * 2^32,     *
    * where drop_id > 0 names the layer whose mask this is (0: no dropout; in a chain: per layer).  Applied where     *
    * `dmask` (an explicit [N, hout] multiplier tensor, still supported) is applied.                                 */
-  const uint64_t* drop_state; uint32_t drop_thr; float drop_scale; int32_t drop_id; int32_t pad2_;
+  const uint64_t* drop_state; uint32_t drop_thr; float drop_scale; int32_t drop_id;
+  int32_t b_format;   /* layout of the packed weights: 0 = fp32 fragments; 1 = bf16x3 fragments (dss2_gemm_prop_chain only) */
 } dss2_gemm_prop_args;
 
 int dss2_gemm_prop(const dss2_gemm_prop_args* args_host, void* stream);
@@ -254,6 +257,10 @@ typedef struct dss2_chain_layer {
 } dss2_chain_layer;
 int dss2_gemm_prop_chain(const dss2_gemm_prop_args* args_host, const dss2_chain_layer* layers_host, int n_layers, void* stream);
 int dss2_gemm_prop_chain_supported(int nrb, int nmat, int kreal, int hout, int ell_width);
+/* != 0: the chain can also run with args.b_format = 1 -- weights packed as bf16x3 fragments, the tile GEMM as six
+ * v_mfma_f32_32x32x16_bf16 per fp32 product term set (h/m/l splits of both operands, fp32 accumulation): fp32-accurate
+ * results at 12 instead of 32 MFMA cycles per unit of k.  Two-row-block tiles, H <= 128. */
+int dss2_gemm_prop_chain16_supported(int nrb, int nmat, int kreal, int hout, int ell_width);
 
 /* ---- dropout random state.  state[2] = persistent device {seed, offset}; snapshot[2] <- the pair this forward call's
  * kernels (forward AND backward) read.  use_host_seed != 0: snapshot = {host_seed, 0} (eager mode: the host draws the seed

@@ -14,12 +14,15 @@ x, ei, ea = b["x"].to(dev), b["edge_index"].to(dev), b["edge_attr"].to(dev)
 N = x.shape[0]
 topo = pkg.topology.get_topology(ei, N)
 Ws = [torch.randn(H, H, device=dev) * 0.1 for _ in range(nmat)]
-plan = nw._PackPlan([Ws], dev); plan.refresh()
+B16 = os.environ.get("CHAINBENCH_BF16", "1") == "1" and nw.chain16_supported(topo, nmat, H, False)
+plan = nw._PackPlan([Ws], dev, bf16_groups=((0,) if B16 else ())); plan.refresh()
+pf, pb = (plan.fwd16[0], plan.bwd16[0]) if B16 else (plan.fwd[0], plan.bwd[0])
+print("tile GEMM:", "bf16x6 (v_mfma_f32_32x32x16_bf16 x 6)" if B16 else "fp32 (v_mfma_f32_32x32x2_f32)")
 h = torch.randn(N, H, device=dev); g = torch.randn(N, H, device=dev); bias = torch.randn(H, device=dev)
 outs = [torch.empty(N, H, device=dev) for _ in range(nl)]
 acts = [torch.randn(N, H, device=dev) for _ in range(nl)]
-fwd = lambda: nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=plan.fwd[0], Y=o, bias=bias, relu=True) for o in outs])
-bwd = lambda: nw.gemm_prop_chain(topo, g, H, nmat, [dict(Bp=plan.bwd[0], Y=o, relu_src=a_) for o, a_ in zip(outs, acts)], transposed=True)
+fwd = lambda: nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=pf, Y=o, bias=bias, relu=True) for o in outs], b_format=int(B16))
+bwd = lambda: nw.gemm_prop_chain(topo, g, H, nmat, [dict(Bp=pb, Y=o, relu_src=a_) for o, a_ in zip(outs, acts)], transposed=True, b_format=int(B16))
 fl = nl * (2.0 * N * H * nmat * H + 2.0 * (nmat - 1) * topo.E2 * H)
 for _ in range(300):   # clock ramp
     fwd()
@@ -34,6 +37,8 @@ for name, fn in (("forward chain", fwd), ("backward chain", bwd)):
         ts.append(e0.elapsed_time(e1) / 20 * 1e3)
     ts.sort()
     print(f"{name:16s} {grid} B={B} H={H} nrb={topo.nrb}: median {ts[3]:7.1f} us  min {ts[0]:7.1f} us  {fl / ts[3] / 1e6:6.1f} TFLOP/s = {fl / ts[3] / 1e6 / 157.3:.3f} of fp32 MFMA peak")
+if os.environ.get("CHAINBENCH_STEP", "1") != "1":
+    sys.exit(0)
 # whole step
 REG = {"mu_v": 1e-1, "mu_theta": 1e-1, "lam_v": 1e-4, "lam_p": 1e-8, "lam_pf": 1e-6, "lam_reg": 1e2}
 st = tuple(s.to(dev) for s in b["stats"])
