@@ -23,10 +23,12 @@ extern "C" int dss2_gemm_prop_chain_supported(int nrb, int nmat, int kreal, int 
 
 extern "C" int dss2_gemm_prop_chain16_supported(int nrb, int nmat, int kreal, int hout, int ell_width) {
   using namespace dss2;
-  // two-row-block tiles, one wave per column group (H <= 128) or the row split for H <= 64
-  if (nrb != 2 || nmat < 2 || nmat > 4 || kreal != hout || (hout & 3) || hout > 128 || ell_width <= 0 || ell_width > 32) return 0;
-  if (nmat == 4 && chain_row_split(nrb, (hout + 31) / 32) != 2) return 0;     // <2,4,4,1> would spill registers: fp32 path
-  return chain_lds_bytes(nrb, (kreal + 15) / 16 * 16, (hout + 31) / 32, ell_width) <= (size_t)kMaxLdsBytes ? 1 : 0;
+  // the shapes of the fp32 chain whose bf16x6 instantiation exists without register spills (dss2_gemm_chain16.hip)
+  if (!dss2_gemm_prop_chain_supported(nrb, nmat, kreal, hout, ell_width)) return 0;
+  const int ncg = (hout + 31) / 32, rsplit = chain_row_split(nrb, ncg);
+  if (nrb == 2 && nmat == 4 && rsplit != 2) return 0;
+  if (nrb == 3 && nmat == 3 && ncg > 4) return 0;
+  return chain_lds_bytes(nrb, (kreal + 15) / 16 * 16, ncg, ell_width) <= (size_t)kMaxLdsBytes ? 1 : 0;
 }
 
 extern "C" int dss2_gemm_prop_chain(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, void* stream) {

@@ -12,12 +12,19 @@
 namespace dss2 {
 
 int launch_chain16(const dss2_gemm_prop_args& a, const ChainTable& ct, int rsplit, hipStream_t s) {
-#define DSS2_CASE16(NMAT)                                                                                      \
-  if (a.nmat == NMAT) return rsplit == 2 ? launch_chain<2, NMAT, 4, 2, true>(a, ct, s) : launch_chain<2, NMAT, 4, 1, true>(a, ct, s);
-  DSS2_CASE16(2) DSS2_CASE16(3)
+#define DSS2_CASE16(NRB, NMAT)                                                           \
+  if (a.nrb == NRB && a.nmat == NMAT && rsplit == 1)                                     \
+    return a.ncg <= 4 ? launch_chain<NRB, NMAT, 4, 1, true>(a, ct, s) : launch_chain<NRB, NMAT, 8, 1, true>(a, ct, s);
+#define DSS2_CASE16_2(NRB, NMAT)                                                         \
+  if (a.nrb == NRB && a.nmat == NMAT && rsplit == 2)                                     \
+    return 2 * a.ncg <= 4 ? launch_chain<NRB, NMAT, 4, 2, true>(a, ct, s) : launch_chain<NRB, NMAT, 8, 2, true>(a, ct, s);
+  DSS2_CASE16(1, 2) DSS2_CASE16(1, 3) DSS2_CASE16(1, 4) DSS2_CASE16(2, 2) DSS2_CASE16(2, 3)
+  DSS2_CASE16(3, 2) DSS2_CASE16(4, 2)
+  if (a.nrb == 3 && a.nmat == 3 && rsplit == 1 && a.ncg <= 4) return launch_chain<3, 3, 4, 1, true>(a, ct, s);   // (8 waves would spill)
+  DSS2_CASE16_2(2, 2) DSS2_CASE16_2(2, 3) DSS2_CASE16_2(2, 4) DSS2_CASE16_2(4, 2)
 #undef DSS2_CASE16
-  if (a.nmat == 4 && rsplit == 2) return launch_chain<2, 4, 4, 2, true>(a, ct, s);
-  set_error("gemm_prop_chain(bf16x6): unsupported (nmat=%d, row split %d)", a.nmat, rsplit);
+#undef DSS2_CASE16_2
+  set_error("gemm_prop_chain(bf16x6): unsupported (nrb=%d, nmat=%d, row split %d)", a.nrb, a.nmat, rsplit);
   return 2;
 }
 

@@ -1038,7 +1038,7 @@ def _ensure_plans(mod, topo, dev, ps):
     hout0 = mod.dim_out if L == 1 else hid
     glob = topo.global_only       # graphs beyond the LDS-resident tiles: plain GEMMs + propagation hops in global memory
     fold_on = FOLD_W2 and not is_narrow(nmat, hout0) and not glob
-    b16 = tuple(range(1, L)) if (CHAIN_BF16 and not glob and L >= 3 and hid % 4 == 0 and hid <= 128 and not is_narrow(nmat, hid)) else ()
+    b16 = tuple(range(1, L)) if (CHAIN_BF16 and not glob and L >= 3 and hid % 4 == 0 and hid <= 256 and not is_narrow(nmat, hid)) else ()
     if (mod._plan is None or mod._plan.device != dev or (mod._fold is not None) != fold_on or mod._plan.stacked != glob
             or tuple(sorted(mod._plan.fwd16)) != b16):
         offs = mod._flat_offsets()

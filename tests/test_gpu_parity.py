@@ -205,7 +205,9 @@ def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
     # gradients, first against the plain fp32 oracle with NOTHING pinned (1e-4: the oracle's own fp32-vs-fp64 gradient
     # noise is 2e-5 and a razor-edge ReLU gate that falls the other way moves a weight-gradient row by ~1/N_nodes) ...
     # (one flipped gate weighs ~1/N_nodes of a gradient row, so small batches get a tolerance of a few gates)
-    tol_unpinned = max(TOL_GRAD, 3.0 / out_m.shape[0])
+    # (8 gates' worth: the deep stack on the small shard -- 8 layers x 256 units on 7 680 nodes, 14 M gates -- flips a
+    #  handful against the fp32 oracle; the pinned comparison below is the tight one)
+    tol_unpinned = max(TOL_GRAD, 8.0 / out_m.shape[0])
     for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
         assert rel_err(p.grad, q.grad) < tol_unpinned, ("fp32 oracle, un-pinned", n, rel_err(p.grad, q.grad))
     # ... then tightly: fp64 referee evaluated on the HIP path's own ReLU gate pattern.  A pre-activation within
@@ -215,13 +217,12 @@ def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
     # max-normalised); the flipped gates themselves must be few and must sit at |pre-activation| ~ 0.
     b = pkg.synthetic.make_batch(grids, B, seed=0)
     x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
-    gates = []
-    sd = mine.state_dict()
+    # the gates the kernels themselves applied: sign of the activations the forward pass kept for its backward (the same
+    # launches as the step above -- the forward is bitwise reproducible), not of a re-evaluation by other kernels
     with torch.no_grad():
-        for l in range(L - 1):   # conv l's pre-activation = output of the same model truncated after conv l
-            trunc = pkg.MPN(8, 6, hid, hid, l + 1, 2, 0.0)
-            trunc.load_state_dict({k: v for k, v in sd.items() if k in trunc.state_dict()})
-            gates.append((trunc.to(DEV)(x[:, :8], ei, ea[:, :6]) > 0).cpu())
+        topo = pkg.topology.get_topology(ei, x.shape[0])
+        _, kept, _ = pkg.networks._mpn_forward(mine, topo, x[:, :8], ea[:, :6], mine._params())
+    gates = [(a_ > 0).cpu() for a_ in kept[4:4 + L - 1]]        # kept = [x, edge_attr, S, conv-0 input, act_1 .. act_{L-1}]
     ref64 = type(ref)(8, 6, 2, hid, L, 2, 0.0).double()
     ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
     x64, ea64 = b["x"].double(), b["edge_attr"].double()
@@ -274,12 +275,9 @@ def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
     assert n_flip <= max(2, 1e-5 * n_gate), (n_flip, n_gate)
     assert rel_err(out_m, out64) < TOL_OUT
     assert abs(loss_m.item() - loss64.item()) <= TOL_LOSS * abs(loss64.item())
-    # (TOL_GRAD / 2 = 5e-5: the bf16x6 tile GEMM of the layer chain carries about 3x the rounding of the fp32 MFMA chain, and
-    #  a bias gradient is a column sum over all N rows with heavy cancellation; measured at C2: convs.1.bias 3.1e-5, every
-    #  weight matrix <= 1.1e-5, against < 1e-5 throughout on the fp32 MFMA path -- tools/accuracy_bf16x6.py)
     for (n, p), (_, q64) in zip(mine.named_parameters(), ref64.named_parameters()):
         e = rel_err(p.grad, q64.grad)
-        if e < TOL_GRAD / 2:
+        if e < 1e-5:
             continue
         # The edge MLP's own per-edge gates are not observable from outside (the kernels recompute them), so they
         # cannot be pinned.  Instead every deviation must be EXPLAINED by ambiguous gates: a gate is ambiguous when
