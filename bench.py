@@ -30,6 +30,7 @@ PKG = "deep-statistical-solver-for-distribution-system-state-estimation_amd"
 REG = {"mu_v": 1e-1, "mu_theta": 1e-1, "lam_v": 1e-4, "lam_p": 1e-8, "lam_pf": 1e-6, "lam_reg": 1e2}
 B_PER_GPU, HID, LAYERS, KHOPS = 4096, 128, 4, 2
 FP32_MFMA_PEAK_TF = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+BF16_MFMA_PEAK_TF = 2500.0     # same table: Peak BF16 MFMA, dense
 HBM_PEAK_GBS = 8000.0
 
 
@@ -190,7 +191,9 @@ def main():
         flops_layer = 2.0 * N * HID * (KHOPS + 1) * HID + 2.0 * KHOPS * E2 * HID
         bytes_layer = 4.0 * N * HID + 4.0 * (KHOPS + 1) * HID * HID          # write the output once + the weights
         chained = layers_per_launch > 1
-        kname = "gemm_chain_kernel<2,3>" if chained else "gemm_prop_kernel<2,3,false>"
+        bf16x6 = bool(chained and pkg.networks.CHAIN_BF16 and pkg.networks.chain16_supported(
+            pkg.topology.get_topology(ei, N), KHOPS + 1, HID, False))
+        kname = ("gemm_chain_kernel<2,3,4,1,true>" if bf16x6 else "gemm_chain_kernel<2,3>") if chained else "gemm_prop_kernel<2,3,false>"
         traffic, traffic_source = None, None
         try:   # HBM bytes per launch from the committed PMC runs (FETCH_SIZE x2 on gfx950 + WRITE_SIZE): a pointer to
                # the rocprofv3 --pmc evidence under profiles/, NOT a counter read during this run
@@ -213,6 +216,15 @@ def main():
             "algorithmic_bytes_per_launch": 4.0 * N * HID + bytes_layer * layers_per_launch,
             "mode": "side-stream overlap on" if pkg.networks.WGRAD_SIDE_STREAM else "single stream",
         }
+        if bf16x6:
+            # The tile GEMM runs on the bf16 matrix pipe as six v_mfma_f32_32x32x16_bf16 per fp32 product group (operands split
+            # into three bf16 pieces, fp32 accumulation: fp32-accurate, tools/accuracy_bf16x6.py).  `peak` / `frac` above stay
+            # the dense fp32 MFMA peak, the peak of the dtype the path computes in; against the pipe it actually occupies the
+            # bound is the dense bf16 peak / 6 executed flops per algorithmic flop, reported beside it.
+            r = result["roofline"]
+            r["pipe"] = "bf16 MFMA, 6 instructions per fp32 product group (bf16x6)"
+            r["peak_bf16_pipe_equiv"] = BF16_MFMA_PEAK_TF / 6.0
+            r["frac_bf16_pipe"] = r["achieved"] / (BF16_MFMA_PEAK_TF / 6.0)
         # ---- standalone scatter-add (K6) against the HBM roofline (north_star asks for it separately), at two sizes:
         # the C2 batch (90.9 MB: sits inside the 256 MiB Infinity Cache) and B = 32768 graphs (msg 470 MB + out 252 MB:
         # cache-busting) -- the second one is the number to hold against HBM.

@@ -45,4 +45,8 @@ python3 tools/cfgbench.py > $O/cfgbench.txt 2>&1
 python3 tools/driverline.py > $O/driverline.txt 2>&1
 python3 tools/collate_bench.py > $O/collate_bench.txt 2>&1
 python3 tools/chainbench.py > $O/chainbench.txt 2>&1
+CHAINBENCH_BF16=0 CHAINBENCH_STEP=0 python3 tools/chainbench.py > $O/chainbench_fp32_mfma.txt 2>&1
+python3 tools/accuracy_bf16x6.py > $O/accuracy_bf16x6.txt 2>&1
+bash tools/driverline_trace.sh 64 > /dev/null 2>&1; cp $R/gpurun_out/driverline_trace_B64.txt $O/ 2>/dev/null
+bash tools/driverline_trace.sh 4096 > /dev/null 2>&1; cp $R/gpurun_out/driverline_trace_B4096.txt $O/ 2>/dev/null
 ls -la $O

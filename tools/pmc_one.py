@@ -10,7 +10,8 @@ b = pkg.synthetic.make_batch(["cigre14"], 4096, seed=0)
 ei = b["edge_index"].to(dev); N = b["x"].shape[0]
 topo = pkg.topology.get_topology(ei, N)
 Ws = [torch.randn(H, H, device=dev) * 0.1 for _ in range(nmat)]
-plan = nw._PackPlan([Ws], dev); plan.refresh()
+B16 = nw.chain16_supported(topo, nmat, H, False)          # the product path: tile GEMM of the chain as bf16x6
+plan = nw._PackPlan([Ws], dev, bf16_groups=((0,) if B16 else ())); plan.refresh()
 h = torch.randn(N, H, device=dev); g = torch.randn(N, H, device=dev); out = torch.empty(N, H, device=dev)
 bias = torch.randn(H, device=dev); flat = torch.empty(nmat * H * H + H, device=dev)
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
@@ -21,7 +22,8 @@ for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
         nw.gemm_prop(topo, g, H, H, plan.bwd[0], nmat, H, out, relu_src=h, transposed=True)
     elif which == "chain":       # 3 chained H -> H layers (the C2 forward chain)
         outs = [torch.empty(N, H, device=dev) for _ in range(3)]
-        nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=plan.fwd[0], Y=o, bias=bias, relu=True) for o in outs])
+        nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=(plan.fwd16[0] if B16 else plan.fwd[0]), Y=o, bias=bias, relu=True) for o in outs],
+                           b_format=int(B16))
     elif which == "wgrad2":      # two layers batched in one launch (the C2 backward)
         flat2 = torch.empty(2 * (nmat * H * H + H), device=dev)
         nw.wgrad_batched(topo, [g, g], H, [h, h], H, nmat, flat2)
