@@ -5,7 +5,7 @@
 // op_sel broadcasts, and those returned wrong values in lanes 48..63 -- run-to-run different -- whenever a second
 // workgroup's v_mfma_f32_32x32x16_bf16 stream shared the SIMD (two workgroups per CU, > 256 tiles); the same source with
 // v_fmac_f32 (or one workgroup per CU, or the fp32 MFMA instantiation) is bitwise reproducible and matches the fp32 path
-// to 5e-7 (tools/accuracy_bf16x6.py; DESIGN.md section 4.2 has the bisection).  Plain VALU ops are also the cheaper
+// to 5e-7 (tools/accuracy_bf16x6.py; DESIGN.md section 4.1a has the bisection).  Plain VALU ops are also the cheaper
 // fillers beside MFMAs (MI355X_MICROARCH.md).
 #include "dss2_gemm_chain_kernel.hpp"
 
