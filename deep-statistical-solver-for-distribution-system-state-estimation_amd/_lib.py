@@ -48,7 +48,7 @@ class WgradArgs(C.Structure):
                 ("tile_start", C.c_void_p),
                 ("rowptrT", C.c_void_p), ("colT", C.c_void_p), ("wT", C.c_void_p),
                 ("max_nnz", C.c_int32), ("ell_width", C.c_int32), ("ell_tiles", C.c_void_p), ("rowscale2", C.c_void_p),
-                ("narrow", C.c_int32), ("pad_", C.c_int32)]
+                ("narrow", C.c_int32), ("mfma_bf16", C.c_int32)]
 
 
 class CsrBuildArgs(C.Structure):
@@ -188,6 +188,7 @@ _SIGNATURES = {
     "dss2_adamax_step": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "dss2_adamax_step_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "dss2_gemm_prop_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dss2_wgrad_lds_bytes_ex": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
 }
 

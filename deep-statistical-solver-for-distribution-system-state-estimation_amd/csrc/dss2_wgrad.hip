@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "dss2_common.hpp"
+#include "dss2_wgrad_batch.hpp"
 
 namespace dss2 {
 
@@ -44,14 +45,6 @@ template <int NB> struct WgradGeom {
   static constexpr int NBW = NB >= 2 ? NB / 2 : 1;   // output blocks per wave
 };
 
-// Several layers of identical shape in ONE launch (blockIdx.z = layer): the layers of a block are
-// independent once all output gradients exist, and at small H one layer alone cannot fill the chip.
-constexpr int WGRAD_MAX_BATCH = 8;
-struct WgradBatch {
-  const float* G[WGRAD_MAX_BATCH]; const float* X[WGRAD_MAX_BATCH]; float* slab[WGRAD_MAX_BATCH];
-  const float* rowscale2[WGRAD_MAX_BATCH];   // per layer (NULL: plain layer)
-  int n; long long slab_stride;
-};
 
 template <int NRB, int NMAT, int NB>
 __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgrad_args p, int nibg, const WgradBatch wb, int ksplit) {
@@ -641,10 +634,20 @@ static int launch_wgrad(const dss2_wgrad_args& a, hipStream_t stream, const Wgra
 
 }  // namespace dss2
 
+extern "C" size_t dss2_wgrad_lds_bytes_ex(int nrb, int nmat, int hout, int hin, int max_nnz, int ell_width, int mfma_bf16);
+
 extern "C" size_t dss2_wgrad_lds_bytes(int nrb, int nmat, int hout, int hin, int max_nnz, int ell_width) {
   if (nmat > 1 && nmat * hout <= 32) return dss2::wgrad_lds(nrb, 1, 1, max_nnz, ell_width, true, hin);   // narrow mode
   const int nb = dss2::pick_nb(nrb, nmat, hout, max_nnz, ell_width);
   return nb ? dss2::wgrad_lds(nrb, nmat, nb, max_nnz, ell_width, nmat > 1, hin) : (size_t)-1;
+}
+
+extern "C" size_t dss2_wgrad_lds_bytes_ex(int nrb, int nmat, int hout, int hin, int max_nnz, int ell_width, int mfma_bf16) {
+  if (mfma_bf16) {
+    const size_t b = dss2::wgrad16_lds_bytes(nrb, nmat, hout, hin, ell_width);
+    if (b != 0 && b <= (size_t)dss2::kMaxLdsBytes) return b;
+  }
+  return dss2_wgrad_lds_bytes(nrb, nmat, hout, hin, max_nnz, ell_width);
 }
 
 static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::WgradBatch& wb) {
@@ -673,6 +676,7 @@ static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::Wg
       default: set_error("wgrad(narrow): unsupported nrb=%d", a.nrb); return 2;
     }
   }
+  if (wgrad16_covers(a)) return launch_wgrad16(a, as_stream(stream), wb);          // bf16x6 kernel (dss2_wgrad16.hip)
   const int nb = pick_nb(a.nrb, a.nmat, a.hout, a.max_nnz, a.ell_width);
   if (!nb) { set_error("wgrad: tile of %d rows does not fit LDS (nmat=%d nnz=%d)", a.nrb * 32, a.nmat, a.max_nnz); return 3; }
   hipStream_t s = as_stream(stream);

@@ -1,0 +1,312 @@
+// Weight gradient of TAGConv on the bf16 matrix pipe, fp32-accurate (bf16x6, dss2_common.hpp: split3):
+//   dW_m = (P^m G)^T X,  db = colsum(G)   -- the same contract, slab layout and fixed-order reduction as dss2_wgrad.hip.
+//
+// The contraction runs over the ROWS of a tile, which is the slow dimension of the row-major slabs, while
+// v_mfma_f32_32x32x16_bf16 wants 8 consecutive k per lane.  So every element is split ONCE, where it is produced (the
+// staging pass for G and X, the propagation pass for P G and P^2 G), and stored as three bf16 planes in a TRANSPOSED image
+// [plane][column][64 rows]: a wave's operand fragment is then one ds_read_b128 per plane, and the MFMA phase has no VALU
+// work at all (the first bf16x6 attempt split per wave and step: VALU-bound, slower than fp32 -- profiles/
+// r02_chain_experiments.txt).  A thread owns a pair of rows of four columns, so a transposed store is one ds_write_b32 per
+// column and plane.  Rows of a column are swizzled by 16-byte chunk (chunk ^ (column & 7)): conflict-free b128 reads
+// without padding, which the 160 KB budget does not have:
+//     fp32 G / P G (propagation ping-pong)   2 x 64 x 68 x 4     34.0 KB
+//     transposed planes of G, P G, P^2 G     3 x 3 x 64 x 128 B  72.0 KB
+//     transposed planes of X (128 columns)   3 x 128 x 128 B     48.0 KB
+//     row scales, ELL slice (D <= 8)                              5.0 KB
+// One workgroup of 8 waves per CU, persistent over tiles; a workgroup owns 128 output columns in two passes of 64 (the X
+// planes are staged once per tile); wave w multiplies input block (w & 3) with output block (w >> 2) of the pass: 72 MFMAs
+// per tile, pass and wave, against 768 fp32 MFMAs of twice the length per tile and wave in dss2_wgrad.hip.
+// Two-row-block tiles (64 rows), K <= 2, ELL slices; everything else runs the fp32 kernel.
+// Built without packed fp32 VALU ops like dss2_gemm_chain16.hip (see there).
+#include <stdlib.h>
+
+#include "dss2_wgrad_batch.hpp"
+
+namespace dss2 {
+
+constexpr int W16_TM = 64, W16_ZC = 64, W16_XW = 128, W16_NT = 512, W16_LDZF = 68, W16_DMAX = 8;
+
+// byte offset of (column, row) inside one plane of a transposed image: 128 B per column, 16-byte chunks of 8 rows swizzled
+// (the swizzle key ((col >> 1) ^ (col >> 4)) & 7 makes BOTH access patterns conflict-free: the transposed stores of a wave --
+//  16 column groups four columns apart x 4 row pairs of one chunk -- and the b128 operand reads of 16 consecutive columns)
+__device__ __forceinline__ int tp_key(int col) { return ((col >> 1) ^ (col >> 4)) & 7; }
+__device__ __forceinline__ int tp_off(int col, int row) { return col * 128 + ((((row >> 3) ^ tp_key(col)) << 4) | ((row & 7) << 1)); }
+
+__device__ __forceinline__ uint32_t pack2(__bf16 lo, __bf16 hi) {
+  return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
+}
+
+// rows (2 rp, 2 rp + 1) x columns (c0 .. c0+3), c0 a multiple of 4 -> the three planes of a transposed image with NCOLS
+// columns.  off0 = tp_off(c0, 2 rp), off2 = tp_off(c0 + 2, 2 rp); columns c0 + 1 / c0 + 3 share their keys (+128 bytes),
+// so a unit costs two address registers and the rest are immediate offsets
+template <int NCOLS>
+__device__ __forceinline__ void store_planes(char* img, int off0, int off2, const f32x4 v0, const f32x4 v1) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    __bf16 h0, m0, l0, h1, m1, l1;
+    split3(v0[q], h0, m0, l0);
+    split3(v1[q], h1, m1, l1);
+    char* dst = img + ((q & 2) ? off2 : off0) + (q & 1) * 128;
+    *reinterpret_cast<uint32_t*>(dst) = pack2(h0, h1);
+    *reinterpret_cast<uint32_t*>(dst + NCOLS * 128) = pack2(m0, m1);
+    *reinterpret_cast<uint32_t*>(dst + 2 * NCOLS * 128) = pack2(l0, l1);
+  }
+}
+
+// NP: passes of 64 output columns per workgroup (the X planes are staged once for all of them).  RS2: layers with the extra
+// scaled column sums (rowscale2, the folded first layer); their 12 more accumulator registers per pass only fit with NP = 1.
+template <int NMAT, int NP, bool RS2>
+__global__ void __launch_bounds__(W16_NT) wgrad16_kernel(const dss2_wgrad_args p, int nibg, const WgradBatch wb) {
+  constexpr int TM = W16_TM, ZC = W16_ZC, XW = W16_XW, NT = W16_NT, LDZF = W16_LDZF;
+  const float* __restrict__ Gp = wb.n > 0 ? wb.G[blockIdx.z] : p.G;
+  const float* __restrict__ Xp = wb.n > 0 ? wb.X[blockIdx.z] : p.X;
+  float* __restrict__ slabp = wb.n > 0 ? wb.slab[blockIdx.z] : p.slab;
+  const float* __restrict__ rs2 = RS2 ? (wb.n > 0 ? wb.rowscale2[blockIdx.z] : p.rowscale2) : nullptr;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Zf0 = smem;
+  float* Zf1 = Zf0 + TM * LDZF;
+  char* ZT = reinterpret_cast<char*>(Zf1 + TM * LDZF);          // [NMAT][3 planes][ZC columns][128 B]
+  char* XT = ZT + NMAT * 3 * ZC * 128;                            // [3 planes][XW columns][128 B]
+  int2* ell = reinterpret_cast<int2*>(XT + 3 * XW * 128);        // [D][TM]
+  const int D = p.ell_width;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, c32 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ibw = wave & 3, obh = wave >> 2;
+  const int obg = blockIdx.y / nibg, ibg = blockIdx.y - obg * nibg;
+  const int gcol0 = obg * (NP * ZC), xcol0 = ibg * XW;          // a workgroup owns NP x 64 output columns, one pass each
+  const bool in_active = (xcol0 + ibw * 32) < p.hin;
+
+  // staging units: a thread owns rows (2 rp, 2 rp + 1) of four columns.  G slab of a pass: 32 x 16 units, one per thread;
+  // X slab: 32 x 32 units, two per thread
+  const int g_cg = tid & 15, g_rp = tid >> 4;
+  const int x_cg = tid & 31, x_rp0 = tid >> 5;          // second unit: x_rp0 + 16
+  const int g_off0 = tp_off(4 * g_cg, 2 * g_rp), g_off2 = tp_off(4 * g_cg + 2, 2 * g_rp);
+  const int x_off0[2] = {tp_off(4 * x_cg, 2 * x_rp0), tp_off(4 * x_cg, 2 * x_rp0 + 32)};
+  const int x_off2[2] = {tp_off(4 * x_cg + 2, 2 * x_rp0), tp_off(4 * x_cg + 2, 2 * x_rp0 + 32)};
+  // global rows of a tile through ONE uniform base per tile and 32-bit per-thread offsets (a tile spans < 2^31 bytes)
+  const uint32_t g_goff = (uint32_t)((2 * g_rp) * p.ldg + 4 * g_cg) * 4u, x_goff = (uint32_t)((2 * x_rp0) * p.ldx + 4 * x_cg) * 4u;
+
+  f32x16 acc[NP][NMAT];
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ps][m][r] = 0.f;
+  f32x4 bsum[NP];                             // running column sums of this thread's four G columns (its rows, all its tiles)
+  f32x4 bs2[NP][RS2 ? NMAT : 1];              // ... scaled by rowscale2[row][m] (the folded layer's bias terms)
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    bsum[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < (RS2 ? NMAT : 1); ++m) bs2[ps][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // Register prefetch, staggered so that at most 16 prefetch registers are live inside an MFMA phase (96 accumulator
+  // registers + operands leave no more under the 256-VGPR budget of an 8-wave workgroup): the next tile's X rows are
+  // requested before the last pass's propagation, its first G slice after the last MFMA phase (covered by the X split of
+  // the next tile), the G slice of pass ps + 1 right after pass ps is staged.
+  f32x4 pg[2], px[4];
+  auto load_g = [&](int tile, int ps) {
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    const char* base = reinterpret_cast<const char*>(Gp + (size_t)ts * p.ldg + gcol0 + ps * ZC);      // uniform
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = 2 * g_rp + u, c = gcol0 + ps * ZC + 4 * g_cg;
+      pg[u] = (r < R && c < p.hout) ? *reinterpret_cast<const f32x4*>(base + g_goff + (uint32_t)(u * p.ldg) * 4u) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto load_x = [&](int tile) {
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    const char* base = reinterpret_cast<const char*>(Xp + (size_t)ts * p.ldx + xcol0);      // uniform
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = 2 * (x_rp0 + 16 * i) + u, c = xcol0 + 4 * x_cg;
+        px[2 * i + u] = (r < R && c < p.hin) ? *reinterpret_cast<const f32x4*>(base + x_goff + (uint32_t)((32 * i + u) * p.ldx) * 4u)
+                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  };
+  // one propagation hop: Zd = P Zs on this thread's unit; fp32 copy for the next hop (if any) and the transposed planes
+  auto prop = [&](const float* Zs, float* Zd, char* img) {
+    f32x4 s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = 2 * g_rp + u;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < D; ++k) {
+        const int2 en = ell[k * TM + row];
+        const f32x4 z = *reinterpret_cast<const f32x4*>(Zs + en.x * LDZF + 4 * g_cg);
+        const float w = __int_as_float(en.y);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = fmaf(w, z[q], a[q]);
+      }
+      s[u] = a;
+      if (Zd) *reinterpret_cast<f32x4*>(Zd + row * LDZF + 4 * g_cg) = a;
+    }
+    store_planes<ZC>(img, g_off0, g_off2, s[0], s[1]);
+  };
+
+  if ((int)blockIdx.x < p.ntiles) { load_x(blockIdx.x); load_g(blockIdx.x, 0); }
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    const int next = tile + gridDim.x;
+    // ---- the tile's X planes (shared by all passes) and ELL slice
+#pragma unroll
+    for (int i = 0; i < 2; ++i) store_planes<XW>(XT, x_off0[i], x_off2[i], px[2 * i], px[2 * i + 1]);
+    {
+      const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
+      for (int idx = tid; idx < D * TM; idx += NT) ell[idx] = src[idx];
+    }
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      // ---- stage this pass's G columns: fp32 (first hop's input) and planes; bias partial sums
+#pragma unroll
+      for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(Zf0 + (2 * g_rp + u) * LDZF + 4 * g_cg) = pg[u];
+      store_planes<ZC>(ZT, g_off0, g_off2, pg[0], pg[1]);
+      bsum[ps] += pg[0] + pg[1];
+      if constexpr (RS2) {
+        if (rs2) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int r = 2 * g_rp + u;
+            if (r < R) {
+              const f32x4 d = *reinterpret_cast<const f32x4*>(rs2 + (size_t)(ts + r) * 4);
+#pragma unroll
+              for (int m = 0; m < NMAT; ++m) bs2[ps][m] += pg[u] * d[m];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const bool last_pass = ps == NP - 1;      // (a pass beyond hout stages zeros and stores nothing)
+      if (!last_pass) load_g(tile, ps + 1);
+      else if (next < p.ntiles) load_x(next);
+      // ---- P G, P^2 G
+      if (NMAT > 1) {
+        prop(Zf0, NMAT > 2 ? Zf1 : nullptr, ZT + 3 * ZC * 128);
+        if (NMAT > 2) {
+          __syncthreads();
+          prop(Zf1, nullptr, ZT + 2 * 3 * ZC * 128);
+        }
+        __syncthreads();
+      }
+      // ---- MFMA phase: 4 steps of 16 rows, six bf16 MFMAs per matrix and step, operands straight from the planes
+      if (in_active && gcol0 + ps * ZC + obh * 32 < p.hout) {
+        const int nsteps = (R + 15) >> 4;
+        const int zc = obh * 32 + c32, xc = ibw * 32 + c32;
+        const int zkey = tp_key(zc), xkey = tp_key(xc);
+        for (int ks = 0; ks < nsteps; ++ks) {
+          const int choff = xc * 128 + (((2 * ks + half) ^ xkey) << 4);
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(XT + choff);
+          const bf16x8 bm = *reinterpret_cast<const bf16x8*>(XT + XW * 128 + choff);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(XT + 2 * XW * 128 + choff);
+          const int zoff = zc * 128 + (((2 * ks + half) ^ zkey) << 4);
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m) {
+            const char* zi = ZT + m * 3 * ZC * 128 + zoff;
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(zi);
+            const bf16x8 am = *reinterpret_cast<const bf16x8*>(zi + ZC * 128);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(zi + 2 * ZC * 128);
+            f32x16 c = acc[ps][m];        // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+            acc[ps][m] = c;
+          }
+        }
+      }
+      if (last_pass && next < p.ntiles) load_g(next, 0);
+      __syncthreads();          // the Z planes and fp32 slabs are free for the next pass / tile
+    }
+  }
+
+  // ---- one slab per workgroup column blockIdx.x; the y-slices tile the [nmat*hout, hin] matrix
+  const size_t stride = (size_t)p.nmat * p.hout * p.hin + p.hout + (rs2 ? (size_t)p.nmat * p.hout : 0);
+  float* out = slabp + (size_t)blockIdx.x * (wb.slab_stride > 0 ? (size_t)wb.slab_stride : stride);
+  if (in_active) {
+    const int i = xcol0 + ibw * 32 + c32;
+    if (i < p.hin) {
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps)
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = gcol0 + ps * ZC + obh * 32 + acc_row(r, half);
+            if (o < p.hout) out[((size_t)m * p.hout + o) * p.hin + i] = acc[ps][m][r];
+          }
+    }
+  }
+  if (ibg == 0) {   // (uniform) column sums: the 32 threads that share a column group meet in LDS, fixed order
+    f32x4* red = reinterpret_cast<f32x4*>(smem);          // [1 + NMAT][NT], one pass at a time
+    const int nsum = rs2 ? 1 + NMAT : 1;
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      __syncthreads();
+      red[tid] = bsum[ps];
+      if constexpr (RS2) {
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) red[(1 + m) * NT + tid] = bs2[ps][m];
+      }
+      __syncthreads();
+      for (int j = tid; j < nsum * ZC; j += NT) {
+        const int which = j / ZC, col = j - which * ZC;
+        float s = 0.f;
+        for (int rp = 0; rp < 32; ++rp) s += red[which * NT + rp * 16 + (col >> 2)][col & 3];
+        const int o = gcol0 + ps * ZC + col;
+        if (o < p.hout) out[(size_t)p.nmat * p.hout * p.hin + (which == 0 ? 0 : p.hout + (size_t)(which - 1) * p.hout) + o] = s;
+      }
+    }
+  }
+}
+
+size_t wgrad16_lds_bytes(int nrb, int nmat, int hout, int hin, int ell_width) {
+  if (nrb != 2 || nmat < 2 || nmat > 3 || ell_width < 1 || ell_width > W16_DMAX || hout <= 32 || (hout & 3) || (hin & 3)) return 0;
+  size_t b = 2 * (size_t)W16_TM * W16_LDZF * 4 + (size_t)nmat * 3 * W16_ZC * 128 + 3 * (size_t)W16_XW * 128 + (size_t)ell_width * W16_TM * 8;
+  const size_t red = (size_t)(1 + nmat) * W16_NT * 16;          // the final column-sum exchange reuses the front of the buffer
+  return b > red ? b : red;
+}
+
+bool wgrad16_covers(const dss2_wgrad_args& a) {
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return a.mfma_bf16 && !a.narrow && !a.rowscale && a.ell_tiles && al16(a.G) && al16(a.X) && (a.ldg & 3) == 0 && (a.ldx & 3) == 0 &&
+         (!a.rowscale2 || al16(a.rowscale2)) && wgrad16_lds_bytes(a.nrb, a.nmat, a.hout, a.hin, a.ell_width) != 0 &&
+         wgrad16_lds_bytes(a.nrb, a.nmat, a.hout, a.hin, a.ell_width) <= (size_t)kMaxLdsBytes;
+}
+
+template <int NMAT, int NP, bool RS2>
+static int launch16(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb) {
+  static std::atomic<uint32_t> lds_done{0};
+  auto kern = wgrad16_kernel<NMAT, NP, RS2>;
+  if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "wgrad(bf16x6)")) return 1;
+  const int nobg = (a.hout + NP * W16_ZC - 1) / (NP * W16_ZC), nibg = (a.hin + W16_XW - 1) / W16_XW;
+  hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg, wb.n > 0 ? wb.n : 1), dim3(W16_NT),
+                     wgrad16_lds_bytes(a.nrb, a.nmat, a.hout, a.hin, a.ell_width), stream, a, nibg, wb);
+  return check_launch("wgrad(bf16x6)");
+}
+
+int launch_wgrad16(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb) {
+  bool rs2 = a.rowscale2 != nullptr;
+  for (int l = 0; l < wb.n; ++l) {
+    if ((reinterpret_cast<uintptr_t>(wb.G[l]) | reinterpret_cast<uintptr_t>(wb.X[l]) | reinterpret_cast<uintptr_t>(wb.rowscale2[l])) & 15) {
+      set_error("wgrad(bf16x6): layer %d has a misaligned operand", l); return 2;
+    }
+    rs2 = rs2 || wb.rowscale2[l] != nullptr;
+  }
+  if (a.nmat == 2) return rs2 ? launch16<2, 1, true>(a, stream, wb) : launch16<2, 2, false>(a, stream, wb);
+  if (a.nmat == 3) return rs2 ? launch16<3, 1, true>(a, stream, wb) : launch16<3, 2, false>(a, stream, wb);
+  set_error("wgrad(bf16x6): unsupported nmat=%d", a.nmat);
+  return 2;
+}
+
+}  // namespace dss2

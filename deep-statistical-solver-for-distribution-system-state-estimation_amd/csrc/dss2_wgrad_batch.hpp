@@ -1,0 +1,21 @@
+#pragma once
+// Shared by dss2_wgrad.hip (fp32 MFMA) and dss2_wgrad16.hip (bf16x6).
+#include "dss2_common.hpp"
+
+namespace dss2 {
+
+// Several layers of identical shape in ONE launch (blockIdx.z = layer): the layers of a block are
+// independent once all output gradients exist, and at small H one layer alone cannot fill the chip.
+constexpr int WGRAD_MAX_BATCH = 8;
+struct WgradBatch {
+  const float* G[WGRAD_MAX_BATCH]; const float* X[WGRAD_MAX_BATCH]; float* slab[WGRAD_MAX_BATCH];
+  const float* rowscale2[WGRAD_MAX_BATCH];   // per layer (NULL: plain layer)
+  int n; long long slab_stride;
+};
+
+// dss2_wgrad16.hip: the bf16x6 kernel.  wgrad16_lds_bytes: dynamic LDS of its launch (0: shape not covered)
+size_t wgrad16_lds_bytes(int nrb, int nmat, int hout, int hin, int ell_width);
+bool wgrad16_covers(const dss2_wgrad_args& a);
+int launch_wgrad16(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb);
+
+}  // namespace dss2

@@ -170,7 +170,8 @@ def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int,
     if topo.global_only and nmat > 1:
         raise NotImplementedError("wgrad with propagation needs LDS-resident graph tiles (graphs of <= 192 nodes)")
     narrow = nmat > 1 and nmat * hout <= 32 and rowscale2 is None
-    lds = _lib.lib().dss2_wgrad_lds_bytes(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT)
+    b16 = int(WGRAD_BF16 and rowscale is None and not narrow)
+    lds = _lib.lib().dss2_wgrad_lds_bytes_ex(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT, b16)
     per_cu = _wgrad_per_cu(int(lds))
     n_split = min(topo.ntiles, 256 * per_cu)
     stride = nmat * hout * hin + hout + (nmat * hout if rowscale2 is not None else 0)
@@ -183,7 +184,7 @@ def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int,
     a.tile_start = topo.tile_start.data_ptr()
     a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
     a.ell_width, a.ell_tiles = topo.ellT, _ptr(topo.ellT_tiles)
-    a.narrow = int(narrow)
+    a.narrow, a.mfma_bf16 = int(narrow), b16
     st = _stream(G)
     _lib.check(_lib.lib().dss2_wgrad(C.byref(a), st), "dss2_wgrad")
     _reduce(slab, 0, n_split, stride, out_flat, stride if out_len is None else out_len, pending)
@@ -196,7 +197,7 @@ def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Seq
     With ``first_rowscale2`` layer 0 is a folded layer (see ``wgrad``): its result, with the extra nmat*hout
     scaled sums, goes to ``first_out`` and the remaining layers to ``out_flat`` (two slab reductions)."""
     nl = len(Gs)
-    lds = _lib.lib().dss2_wgrad_lds_bytes(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT)
+    lds = _lib.lib().dss2_wgrad_lds_bytes_ex(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT, int(WGRAD_BF16))
     per_cu = _wgrad_per_cu(int(lds))
     n_split = min(topo.ntiles, max(1, (256 * per_cu) // nl))       # the layers share the chip
     stride = nmat * hout * hin + hout
@@ -209,6 +210,7 @@ def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Seq
         if g_.stride(0) != a.ldg or x_.stride(0) != a.ldx or g_.shape != Gs[0].shape or x_.shape != Xs[0].shape:
             raise ValueError("wgrad_batched: layers must share shapes and leading dimensions")
     a.n_split, a.nmat, a.nrb, a.ntiles = n_split, nmat, topo.nrb, topo.ntiles
+    a.mfma_bf16 = int(WGRAD_BF16)
     a.tile_start = topo.tile_start.data_ptr()
     a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
     a.ell_width, a.ell_tiles = topo.ellT, _ptr(topo.ellT_tiles)
@@ -705,6 +707,7 @@ _SIDE_STREAMS = {}
 EDGE_TILE_KERNELS = _os.environ.get("DSS2_EDGE_TILE", "1") == "1"       # 0 = row-per-wave CSR kernels
 WGRAD_SIDE_STREAM = _os.environ.get("DSS2_WGRAD_STREAM", "0") == "1"   # opt-in: +3 % at C2 (kernels then overlap)
 CHAIN_LAYERS = _os.environ.get("DSS2_CHAIN", "1") == "1"               # hid->hid layers of a block: one chained launch
+WGRAD_BF16 = _os.environ.get("DSS2_WGRAD_BF16", "1") == "1"            # weight gradients as bf16x6 where the kernel covers the shape
 CHAIN_BF16 = _os.environ.get("DSS2_CHAIN_BF16", "1") == "1"            # its tile GEMM as bf16x6 on the bf16 matrix pipe (fp32-accurate)
 WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"
 STACK_NODE = _os.environ.get("DSS2_STACK_NODE", "1") == "1"              # PFN / SkipPFN as ONE autograd node (_PFNFn)
@@ -1182,7 +1185,8 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         even = -(-topo.ntiles // ns3) * ns3 <= 1.03 * topo.ntiles
         if WGRAD_JOIN_FOLDED is not None:
             even = bool(WGRAD_JOIN_FOLDED)
-        if fold is not None and L - 1 <= 8 and even:
+        if fold is not None and L - 1 <= 8 and even and (WGRAD_JOIN_FOLDED is not None or not WGRAD_BF16):
+            # (bf16x6 weight gradient: the folded layer's extra sums only fit the one-pass kernel, so it runs on its own)
             # the folded conv 0 (input S, extra scaled bias sums) and the plain layers 1 .. L-2 in ONE launch
             wgrad_batched(topo, gl, hid, [S] + acts[1:L - 1], hid, nmat, flat[offs[3]:offs[2 + L - 1]],
                           first_rowscale2=topo.deg_pows, first_out=fold.gfold, pending=pending)

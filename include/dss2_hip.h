@@ -312,13 +312,19 @@ typedef struct dss2_wgrad_args {
                                          * every m, sum_n rowscale2[n][m] G[n, o] (the gradient of  *
                                          * dss2_gemm_prop's prebias_m when rowscale2 is its          *
                                          * pre_rowscale); slab = [nmat*hout*hin][hout][nmat*hout]    */
-  int32_t narrow; int32_t pad_;         /* narrow != 0 (needs nmat*hout <= 32): the propagated  *
+  int32_t narrow; int32_t mfma_bf16;    /* mfma_bf16 != 0: products as bf16x6 on the bf16 matrix *
+                                         * pipe (fp32-accurate) where that kernel covers the     *
+                                         * shape (64-row tiles, K <= 2, ELL slices, 16-byte      *
+                                         * aligned operands), else the fp32 MFMA kernel.         *
+                                         * narrow != 0 (needs nmat*hout <= 32): the propagated  *
                                          * copies P^m G are appended as extra COLUMNS of one    *
                                          * 32-wide block instead of nmat separate blocks; same  *
                                          * slab layout [nmat*hout*hin + hout]                   */
 } dss2_wgrad_args;
 
 int dss2_wgrad(const dss2_wgrad_args* args_host, void* stream);
+/* dynamic LDS of the kernel dss2_wgrad launches for this shape (callers size n_split by it); _ex: with args.mfma_bf16 */
+size_t dss2_wgrad_lds_bytes_ex(int nrb, int nmat, int hout, int hin, int max_nnz, int ell_width, int mfma_bf16);
 
 /* The same for n_layers (<= 8) layers of IDENTICAL shape and leading dimensions in one launch (one grid
  * slice per layer): Gs / Xs / slabs are HOST arrays of device pointers replacing args->G / X / slab;
