@@ -650,6 +650,15 @@ extern "C" size_t dss2_wgrad_lds_bytes_ex(int nrb, int nmat, int hout, int hin, 
   return dss2_wgrad_lds_bytes(nrb, nmat, hout, hin, max_nnz, ell_width);
 }
 
+// Workgroups a launch puts on EACH tile-list slice (grid.y): callers that want one workgroup per CU divide their n_split by
+// it.  Only the one-pass bf16x6 kernel (layers with rowscale2) splits the output columns over grid.y at H > 64.
+extern "C" int dss2_wgrad_y_slices(int nrb, int nmat, int hout, int hin, int ell_width, int mfma_bf16, int has_rowscale2) {
+  if (!mfma_bf16 || !has_rowscale2) return 1;
+  const size_t b = dss2::wgrad16_lds_bytes(nrb, nmat, hout, hin, ell_width);
+  if (b == 0 || b > (size_t)dss2::kMaxLdsBytes) return 1;
+  return ((hout + 63) / 64) * ((hin + 127) / 128);
+}
+
 static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::WgradBatch& wb) {
   using namespace dss2;
   if (a.n_split <= 0 || !a.slab) { set_error("wgrad: n_split/slab missing"); return 2; }

@@ -173,7 +173,8 @@ def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int,
     b16 = int(WGRAD_BF16 and rowscale is None and not narrow)
     lds = _lib.lib().dss2_wgrad_lds_bytes_ex(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT, b16)
     per_cu = _wgrad_per_cu(int(lds))
-    n_split = min(topo.ntiles, 256 * per_cu)
+    ys = _lib.lib().dss2_wgrad_y_slices(topo.nrb, nmat, hout, hin, topo.ellT, b16, int(rowscale2 is not None))
+    n_split = min(topo.ntiles, max(1, (256 * per_cu) // ys))
     stride = nmat * hout * hin + hout + (nmat * hout if rowscale2 is not None else 0)
     slab = torch.empty(n_split * stride, dtype=_F32, device=G.device)
     a = _lib.WgradArgs()

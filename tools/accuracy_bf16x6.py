@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU: accuracy of the bf16x6 tile GEMM (DSS2_CHAIN_BF16=1, default) against the fp32-MFMA path (=0), both measured against
+"""GPU: accuracy of the bf16x6 kernels (DSS2_CHAIN_BF16=1 DSS2_WGRAD_BF16=1, default) against the fp32-MFMA path (both =0), both measured against
 the fp64 CPU oracle on the same weights and batch: max-normalised error of the output, relative error of the loss, worst
 max-normalised error over the parameter gradients.  Runs both settings in child processes."""
 import importlib, json, os, subprocess, sys
@@ -42,7 +42,7 @@ if __name__ == "__main__":
     else:
         rows = {}
         for mode in ("1", "0"):
-            env = dict(os.environ, DSS2_CHAIN_BF16=mode)
+            env = dict(os.environ, DSS2_CHAIN_BF16=mode, DSS2_WGRAD_BF16=mode)
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
             if not line:
