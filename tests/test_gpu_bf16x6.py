@@ -1,0 +1,128 @@
+"""The bf16x6 kernels (fp32-accurate products on the bf16 matrix pipe: layer chain and weight gradient) against the fp32-MFMA
+kernels they replace, shape by shape, on the same inputs -- and the full-size co-residency case that exposed the packed-fp32
+trap (two workgroups per CU, layer with a folded bias): bitwise reproducible, equal to the fp32 form to rounding."""
+import pytest
+import torch
+
+from conftest import load_pkg, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_pkg()
+
+
+def _topo(pkg, grids, B, seed=0):
+    b = pkg.synthetic.make_batch(grids, B, seed=seed)
+    ei = b["edge_index"].to(DEV)
+    N = b["x"].shape[0]
+    return pkg.topology.get_topology(ei, N), N
+
+
+@pytest.mark.parametrize("grids,B,H,nmat,n_layers,with_rs2", [
+    (["cigre14"], 300, 128, 3, 1, False),        # the C2 shape, single layer
+    (["cigre14"], 300, 128, 3, 2, False),        # two layers batched
+    (["cigre14"], 257, 128, 3, 1, True),         # folded first layer: extra scaled column sums (one-pass kernel), odd tile count
+    (["cigre14"], 300, 128, 3, 3, True),         # batch whose first layer has the scaled sums
+    (["cigre14", "cigre14_reswitched"], 200, 100, 3, 2, False),   # H = 100: partial second pass, 100 of 128 X columns
+    (["cigre14"], 128, 64, 2, 1, False),         # K = 1, one pass
+    (["cigre14"], 96, 48, 3, 1, True),           # H = 48 (> 32): half-empty pass
+    (["cigre14"], 64, 256, 3, 2, False),         # H = 256: two output groups x two input groups over grid.y
+])
+def test_weight_gradient_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat, n_layers, with_rs2):
+    nw = pkg.networks
+    topo, N = _topo(pkg, grids, B)
+    assert topo.nrb == 2
+    torch.manual_seed(1)
+    Gs = [torch.randn(N, H, device=DEV) for _ in range(n_layers)]
+    Xs = [torch.randn(N, H, device=DEV) for _ in range(n_layers)]
+    rs2 = torch.rand(N, 4, device=DEV) if with_rs2 else None
+    stride = nmat * H * H + H
+    saved = nw.WGRAD_BF16
+
+    def run(bf16):
+        nw.WGRAD_BF16 = bf16
+        if n_layers == 1:
+            out = torch.zeros(stride + (nmat * H if with_rs2 else 0), device=DEV)
+            nw.wgrad(topo, Gs[0], H, Xs[0], H, nmat, out, rowscale2=rs2)
+            return [out]
+        out = torch.zeros((n_layers - (1 if with_rs2 else 0)) * stride, device=DEV)
+        first = torch.zeros(stride + nmat * H, device=DEV) if with_rs2 else None
+        nw.wgrad_batched(topo, Gs, H, Xs, H, nmat, out, first_rowscale2=rs2, first_out=first)
+        return [out] + ([first] if with_rs2 else [])
+    try:
+        ref = run(False)
+        got = run(True)
+        got2 = run(True)
+    finally:
+        nw.WGRAD_BF16 = saved
+    lds = pkg._lib.lib().dss2_wgrad_lds_bytes_ex
+    covered = lds(2, nmat, H, H, topo.max_nnzT, topo.ellT, 1) != lds(2, nmat, H, H, topo.max_nnzT, topo.ellT, 0)
+    assert covered                                                     # these shapes do run the bf16x6 kernel
+    for a, b_, c in zip(got, ref, got2):
+        assert torch.equal(a, c)                                       # fixed-order sums: bitwise reproducible
+        assert rel_err(a, b_) < 2e-6
+
+
+def test_shapes_outside_the_bf16x6_weight_gradient_fall_back(pkg):
+    """H <= 32 (the K-split 4-wave kernel), K = 3, tall tiles: the fp32 kernel runs, results unchanged by the switch."""
+    nw = pkg.networks
+    saved = nw.WGRAD_BF16
+    try:
+        for grids, B, H, nmat in ((["cigre14"], 64, 32, 3), (["cigre14"], 64, 64, 4), (["ober_sub"], 12, 64, 3)):
+            topo, N = _topo(pkg, grids, B)
+            torch.manual_seed(2)
+            G, X = torch.randn(N, H, device=DEV), torch.randn(N, H, device=DEV)
+            outs = []
+            for mode in (False, True):
+                nw.WGRAD_BF16 = mode
+                o = torch.zeros(nmat * H * H + H, device=DEV)
+                nw.wgrad(topo, G, H, X, H, nmat, o)
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1])
+    finally:
+        nw.WGRAD_BF16 = saved
+
+
+@pytest.mark.parametrize("grids,B,H,nmat,nl", [
+    (["cigre14"], 4096, 128, 3, 3),              # C2 at full size: two workgroups per CU
+    (["cigre14"], 512, 64, 3, 4),                # row split (two waves per column group)
+    (["cigre14"], 256, 32, 4, 3),                # K = 3 on the row-split kernel
+    (["ober_sub"], 64, 128, 3, 3),               # 96-row tiles, one wave per SIMD
+    (["cigre14"], 300, 256, 3, 2),               # H = 256: eight waves
+    (["cigre14"], 200, 100, 3, 3),               # H = 100: k padded to 112
+])
+def test_layer_chain_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat, nl):
+    """Forward form with bias / ReLU / folded bias (prebias + row scales) in the first layer, backward form with ReLU gates:
+    bf16x6 against the fp32 MFMA chain, twice (bitwise reproducible)."""
+    nw = pkg.networks
+    topo, N = _topo(pkg, grids, B)
+    assert nw.chain16_supported(topo, nmat, H, False) and nw.chain16_supported(topo, nmat, H, True)
+    torch.manual_seed(3)
+    Ws = [torch.randn(H, H, device=DEV) * (1.5 / H ** 0.5) for _ in range(nmat)]
+    plan = nw._PackPlan([Ws], DEV, bf16_groups=(0,))
+    plan.refresh()
+    h, g = torch.randn(N, H, device=DEV), torch.randn(N, H, device=DEV)
+    bias, pbias, prs = torch.randn(H, device=DEV), torch.randn(nmat, H, device=DEV), torch.rand(N, 4, device=DEV)
+    acts = [torch.randn(N, H, device=DEV) for _ in range(nl)]
+
+    def fwd(fmt):
+        outs = [torch.empty(N, H, device=DEV) for _ in range(nl)]
+        layers = [dict(Bp=(plan.fwd16[0] if fmt else plan.fwd[0]), Y=o, bias=bias, relu=True) for o in outs]
+        layers[0]["prebias"] = pbias
+        nw.gemm_prop_chain(topo, h, H, nmat, layers, pre_rowscale=prs, b_format=fmt)
+        return outs
+
+    def bwd(fmt):
+        outs = [torch.empty(N, H, device=DEV) for _ in range(nl)]
+        layers = [dict(Bp=(plan.bwd16[0] if fmt else plan.bwd[0]), Y=o, relu_src=a_) for o, a_ in zip(outs, acts)]
+        nw.gemm_prop_chain(topo, g, H, nmat, layers, transposed=True, b_format=fmt)
+        return outs
+    for fn in (fwd, bwd):
+        ref, a, b_ = fn(0), fn(1), fn(1)
+        for r, x, y in zip(ref, a, b_):
+            assert torch.equal(x, y)
+            assert rel_err(x, r) < 3e-6
