@@ -134,17 +134,26 @@ __global__ void __launch_bounds__(W16_NT) wgrad16_kernel(const dss2_wgrad_args p
   };
   // one propagation hop: Zd = P Zs on this thread's unit; fp32 copy for the next hop (if any) and the transposed planes
   auto prop = [&](const float* Zs, float* Zd, char* img) {
+    // four ELL entries of a row first, then their four gathers: independent entry -> row -> fma chains in flight (the
+    // dependent pairs of a k-by-k loop left this phase latency-bound: 35 of the kernel's 98 us)
     f32x4 s[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int row = 2 * g_rp + u;
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      for (int k = 0; k < D; ++k) {
-        const int2 en = ell[k * TM + row];
-        const f32x4 z = *reinterpret_cast<const f32x4*>(Zs + en.x * LDZF + 4 * g_cg);
-        const float w = __int_as_float(en.y);
+      for (int k0 = 0; k0 < D; k0 += 4) {
+        int2 en[4];
+        f32x4 z[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] = fmaf(w, z[q], a[q]);
+        for (int k = 0; k < 4; ++k) en[k] = k0 + k < D ? ell[(k0 + k) * TM + row] : make_int2(row, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[k] = *reinterpret_cast<const f32x4*>(Zs + en[k].x * LDZF + 4 * g_cg);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float w = __int_as_float(en[k].y);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a[q] = fmaf(w, z[k][q], a[q]);
+        }
       }
       s[u] = a;
       if (Zd) *reinterpret_cast<f32x4*>(Zd + row * LDZF + 4 * g_cg) = a;
