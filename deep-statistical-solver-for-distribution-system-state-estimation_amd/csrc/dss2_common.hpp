@@ -41,6 +41,20 @@ __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l)
   m = (__bf16)r1;
   l = (__bf16)(r1 - (float)m);
 }
+// The same split for two values at once, each piece delivered as the packed pair {lo = piece of a, hi = piece of b}: one
+// v_cvt_pk_bf16_f32 per piece and pair (the scalar form costs one conversion per piece and VALUE, plus the packing).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ void split3_pair(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = cvt_pk_bf16(a, b);
+  const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+  m = cvt_pk_bf16(ra, rb);
+  l = cvt_pk_bf16(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u));
+}
+
 __device__ __forceinline__ void split3x4(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {

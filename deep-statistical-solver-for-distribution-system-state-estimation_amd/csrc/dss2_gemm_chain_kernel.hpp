@@ -126,13 +126,14 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
         for (int rb = 0; rb < NRW; ++rb) {
           const float* src = xa16 + (rs * NRW + rb) * 32 * LDX + ks * 16;
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
-          bf16x8 ah, am, al;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            __bf16 h_, m_, l_;
-            split3(v0[q], h_, m_, l_); ah[q] = h_; am[q] = m_; al[q] = l_;
-            split3(v1[q], h_, m_, l_); ah[4 + q] = h_; am[4 + q] = m_; al[4 + q] = l_;
-          }
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          uint32_t sh[4], sm[4], sl[4];
+          split3_pair(v0[0], v0[1], sh[0], sm[0], sl[0]);
+          split3_pair(v0[2], v0[3], sh[1], sm[1], sl[1]);
+          split3_pair(v1[0], v1[1], sh[2], sm[2], sl[2]);
+          split3_pair(v1[2], v1[3], sh[3], sm[3], sl[3]);
+          const u32x4 uh = {sh[0], sh[1], sh[2], sh[3]}, um = {sm[0], sm[1], sm[2], sm[3]}, ul = {sl[0], sl[1], sl[2], sl[3]};
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, uh), am = __builtin_bit_cast(bf16x8, um), al = __builtin_bit_cast(bf16x8, ul);
 #pragma unroll
           for (int m = 0; m < NMAT; ++m) {      // smallest terms first
             f32x16 c = acc[rb][m];

@@ -32,10 +32,6 @@ constexpr int W16_TM = 64, W16_ZC = 64, W16_XW = 128, W16_NT = 512, W16_LDZF = 6
 __device__ __forceinline__ int tp_key(int col) { return ((col >> 1) ^ (col >> 4)) & 7; }
 __device__ __forceinline__ int tp_off(int col, int row) { return col * 128 + ((((row >> 3) ^ tp_key(col)) << 4) | ((row & 7) << 1)); }
 
-__device__ __forceinline__ uint32_t pack2(__bf16 lo, __bf16 hi) {
-  return (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
-}
-
 // rows (2 rp, 2 rp + 1) x columns (c0 .. c0+3), c0 a multiple of 4 -> the three planes of a transposed image with NCOLS
 // columns.  off0 = tp_off(c0, 2 rp), off2 = tp_off(c0 + 2, 2 rp); columns c0 + 1 / c0 + 3 share their keys (+128 bytes),
 // so a unit costs two address registers and the rest are immediate offsets
@@ -43,13 +39,12 @@ template <int NCOLS>
 __device__ __forceinline__ void store_planes(char* img, int off0, int off2, const f32x4 v0, const f32x4 v1) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    __bf16 h0, m0, l0, h1, m1, l1;
-    split3(v0[q], h0, m0, l0);
-    split3(v1[q], h1, m1, l1);
+    uint32_t h, m, l;
+    split3_pair(v0[q], v1[q], h, m, l);          // {row 2 rp, row 2 rp + 1} of column c0 + q: exactly the stored dword
     char* dst = img + ((q & 2) ? off2 : off0) + (q & 1) * 128;
-    *reinterpret_cast<uint32_t*>(dst) = pack2(h0, h1);
-    *reinterpret_cast<uint32_t*>(dst + NCOLS * 128) = pack2(m0, m1);
-    *reinterpret_cast<uint32_t*>(dst + 2 * NCOLS * 128) = pack2(l0, l1);
+    *reinterpret_cast<uint32_t*>(dst) = h;
+    *reinterpret_cast<uint32_t*>(dst + NCOLS * 128) = m;
+    *reinterpret_cast<uint32_t*>(dst + 2 * NCOLS * 128) = l;
   }
 }
 
