@@ -651,12 +651,14 @@ extern "C" size_t dss2_wgrad_lds_bytes_ex(int nrb, int nmat, int hout, int hin, 
 }
 
 // Workgroups a launch puts on EACH tile-list slice (grid.y): callers that want one workgroup per CU divide their n_split by
-// it.  Only the one-pass bf16x6 kernel (layers with rowscale2) splits the output columns over grid.y at H > 64.
+// it.  The bf16x6 kernel is one workgroup per CU by LDS, so its column groups over grid.y (H > 128; H > 64 for layers with
+// rowscale2) would otherwise run in rounds, each round writing its own slabs.
 extern "C" int dss2_wgrad_y_slices(int nrb, int nmat, int hout, int hin, int ell_width, int mfma_bf16, int has_rowscale2) {
-  if (!mfma_bf16 || !has_rowscale2) return 1;
+  if (!mfma_bf16) return 1;
   const size_t b = dss2::wgrad16_lds_bytes(nrb, nmat, hout, hin, ell_width);
   if (b == 0 || b > (size_t)dss2::kMaxLdsBytes) return 1;
-  return ((hout + 63) / 64) * ((hin + 127) / 128);
+  const int out_cols = has_rowscale2 ? 64 : 128;          // output columns per workgroup: one pass / two passes of 64
+  return ((hout + out_cols - 1) / out_cols) * ((hin + 127) / 128);
 }
 
 static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::WgradBatch& wb) {

@@ -200,7 +200,8 @@ def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Seq
     nl = len(Gs)
     lds = _lib.lib().dss2_wgrad_lds_bytes_ex(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT, int(WGRAD_BF16))
     per_cu = _wgrad_per_cu(int(lds))
-    n_split = min(topo.ntiles, max(1, (256 * per_cu) // nl))       # the layers share the chip
+    ys = _lib.lib().dss2_wgrad_y_slices(topo.nrb, nmat, hout, hin, topo.ellT, int(WGRAD_BF16), int(first_rowscale2 is not None))
+    n_split = min(topo.ntiles, max(1, (256 * per_cu) // (nl * ys)))       # the layers share the chip
     stride = nmat * hout * hin + hout
     lens = [stride + (nmat * hout if (first_rowscale2 is not None and l == 0) else 0) for l in range(nl)]
     total = sum(lens)
