@@ -226,6 +226,28 @@ def lib():
     return _lib
 
 
+_RAW_STREAM = None
+
+
+def stream_ptr(device) -> int:
+    """hipStream_t of torch's current stream on `device` as an integer.  torch._C._cuda_getCurrentRawStream is the call
+    torch's own compiled-kernel launchers use: ~0.3 us against ~5 us for torch.cuda.current_stream(device).cuda_stream,
+    which a step pays 14 times."""
+    global _RAW_STREAM
+    if _RAW_STREAM is None:
+        import torch
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        _RAW_STREAM = raw if raw is not None else (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+    if isinstance(device, int):
+        idx = device
+    else:
+        import torch
+        idx = (device if isinstance(device, torch.device) else torch.device(device)).index
+        if idx is None:
+            idx = torch.cuda.current_device()
+    return _RAW_STREAM(idx)
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().dss2_last_error()

@@ -137,7 +137,7 @@ class DeviceDataset:
             d.src, d.dst, d.chunk, d.kind = src.data_ptr(), dst.data_ptr(), chunk, kind
             d.shared, d.nodes_per_sample = int(self.shared_topology), self.n
         _lib.check(_lib.lib().dss2_collate(C.addressof(descs), len(items), ids.data_ptr(), B,
-                                           torch.cuda.current_stream(self.device).cuda_stream), "dss2_collate")
+                                           _lib.stream_ptr(self.device)), "dss2_collate")
 
     def collate(self, ids: torch.Tensor) -> Batch:
         """ids: int64 device tensor of sample numbers (positions in the underlying store)."""
@@ -215,7 +215,7 @@ class MixedDataset:
         ea = torch.empty(E, p0.edge_attr.size(2), dtype=_F32, device=dev)
         ei = torch.empty(2, E, dtype=torch.int64, device=dev)
         L = _lib.lib()
-        st = torch.cuda.current_stream(dev).cuda_stream
+        st = _lib.stream_ptr(dev)
         for k, p in enumerate(self.parts):
             slots = np.nonzero(part == k)[0]
             if slots.size == 0:
@@ -290,7 +290,7 @@ def data_from_tables(nodes: np.ndarray, edges: np.ndarray, labels: np.ndarray, n
         raise ValueError("the measurement model produces 8 node and 6 edge features (dss2_run.py:72-75)")
     S, n, e = nodes.shape[0], nodes.shape[1], edges.shape[1]
     L = _lib.lib()
-    st = torch.cuda.current_stream(dev).cuda_stream
+    st = _lib.stream_ptr(dev)
     f64 = torch.float64
     nd = torch.as_tensor(np.ascontiguousarray(nodes, dtype=np.float64)).to(dev).reshape(S * n, 7)
     ed = torch.as_tensor(np.ascontiguousarray(edges, dtype=np.float64)).to(dev).reshape(S * e, 11)

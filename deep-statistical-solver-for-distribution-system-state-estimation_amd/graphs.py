@@ -21,8 +21,12 @@ class GraphedStep:
     Capture follows the canonical order: warm-up and capture on a side stream BEFORE any eager step has
     created AccumulateGrad nodes on the default stream."""
 
-    def __init__(self, step_fn: Callable[[], torch.Tensor], warmup: int = 3):
-        self.stream = torch.cuda.Stream()
+    def __init__(self, step_fn: Callable[[], torch.Tensor], warmup: int = 3, capture_error_mode: str = "global", stream=None):
+        """capture_error_mode: passed to torch.cuda.graph.  "thread_local" lets other threads of the process (the
+        process-group watchdog of a step that contains RCCL collectives) issue HIP calls during the capture."""
+        # stream: capture on this (non-default) stream -- e.g. the one the caller has run its eager steps on, so that the
+        # autograd graph's AccumulateGrad nodes already belong to it
+        self.stream = stream if stream is not None else torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):
@@ -30,7 +34,7 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
+        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=capture_error_mode):
             self.loss = step_fn()
 
     def replay(self) -> torch.Tensor:

@@ -80,7 +80,7 @@ class _StackedPack:
             self.table = torch.from_numpy(np.array(recs, dtype=_DESC_DTYPE).view(np.uint8).copy()).to(self.device)
             self.ptr = W.data_ptr()
         _lib.check(_lib.lib().dss2_pack_weights(self.table.data_ptr(), 4, self.max_elems,
-                                                torch.cuda.current_stream(self.device).cuda_stream), "dss2_pack_weights")
+                                                _lib.stream_ptr(self.device)), "dss2_pack_weights")
 
 
 class _EdgeAggrGeneralFn(torch.autograd.Function):

@@ -34,7 +34,7 @@ _F32 = torch.float32
 
 
 def _stream(t: torch.Tensor) -> int:
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _lib.stream_ptr(t.device)
 
 
 def _require_gpu(*tensors: torch.Tensor) -> None:
@@ -295,7 +295,7 @@ def _sg_table(recs, device):
 
 def _small_gemm(tab, base, device) -> None:
     t, cnt, mx = tab
-    _lib.check(_lib.lib().dss2_small_gemm(t.data_ptr(), cnt, mx, base, torch.cuda.current_stream(device).cuda_stream), "dss2_small_gemm")
+    _lib.check(_lib.lib().dss2_small_gemm(t.data_ptr(), cnt, mx, base, _lib.stream_ptr(device)), "dss2_small_gemm")
 
 
 class _FoldPlan:
@@ -362,13 +362,13 @@ class _FoldPlan:
     def refresh_forward(self):
         self._check()
         t, n, mx = self.fwd_tab
-        st = torch.cuda.current_stream(self.device).cuda_stream
+        st = _lib.stream_ptr(self.device)
         _lib.check(_lib.lib().dss2_small_gemm(t.data_ptr(), n, mx, None, st), "dss2_small_gemm")
 
     def backward(self, flat: torch.Tensor):
         self._check()
         t, n, mx = self.bwd_tab
-        st = torch.cuda.current_stream(self.device).cuda_stream
+        st = _lib.stream_ptr(self.device)
         _lib.check(_lib.lib().dss2_small_gemm(t.data_ptr(), n, mx, flat.data_ptr(), st), "dss2_small_gemm")
 
 
@@ -487,7 +487,7 @@ class _PackPlan:
         if ptrs != self.ptrs:
             self._build_table()
             self.ptrs = ptrs
-        st = torch.cuda.current_stream(self.device).cuda_stream
+        st = _lib.stream_ptr(self.device)
         _lib.check(_lib.lib().dss2_pack_weights(self.table.data_ptr(), self.n_desc, self.max_elems, st), "dss2_pack_weights")
         self.version += 1
         return self.version
@@ -692,7 +692,7 @@ def dropout_snapshot(mod: nn.Module, device) -> torch.Tensor:
     snap = torch.empty(2, dtype=torch.int64, device=device)
     capturing = torch.cuda.is_current_stream_capturing()
     _lib.check(_lib.lib().dss2_rng_next(st.data_ptr(), snap.data_ptr(), host_seed, int(not capturing),
-                                        torch.cuda.current_stream(device).cuda_stream), "dss2_rng_next")
+                                        _lib.stream_ptr(device)), "dss2_rng_next")
     return snap
 
 
@@ -701,7 +701,7 @@ def dropout_mask(snapshot: torch.Tensor, p: float, drop_id: int, n_rows: int, h:
     (dss2_dropout_mask): lets a test hand the very same masks to the CPU oracle."""
     out = torch.empty(n_rows, h, dtype=_F32, device=snapshot.device)
     _lib.check(_lib.lib().dss2_dropout_mask(snapshot.data_ptr(), drop_id, float(p), n_rows, h, out.data_ptr(), h,
-                                            torch.cuda.current_stream(snapshot.device).cuda_stream), "dss2_dropout_mask")
+                                            _lib.stream_ptr(snapshot.device)), "dss2_dropout_mask")
     return out
 
 
@@ -1319,7 +1319,7 @@ class _StackPlan:
         if self.fold_fwd is not None:
             _small_gemm(self.fold_fwd, None, self.device)
         t, cnt, mx = self.pack_tab
-        _lib.check(_lib.lib().dss2_pack_weights(t.data_ptr(), cnt, mx, torch.cuda.current_stream(self.device).cuda_stream),
+        _lib.check(_lib.lib().dss2_pack_weights(t.data_ptr(), cnt, mx, _lib.stream_ptr(self.device)),
                    "dss2_pack_weights")
         for p, _, _ in plans:
             p.version += 1

@@ -102,7 +102,7 @@ class FusedAdamax(torch.optim.Optimizer):
             for d, g in zip(tab, grads):
                 d.grad = g.data_ptr()
             b1, b2 = group["betas"]
-            st = torch.cuda.current_stream(dev).cuda_stream
+            st = _lib.stream_ptr(dev)
             if self.capturable:
                 _lib.check(_lib.lib().dss2_adamax_step_dev(C.addressof(tab), len(ps), float(group["lr"]), float(b1),
                                                            float(b2), float(group["eps"]), float(group["weight_decay"]),

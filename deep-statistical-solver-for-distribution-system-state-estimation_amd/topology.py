@@ -50,7 +50,7 @@ class TopologyHint:
 
 
 def _stream(dev) -> int:
-    return torch.cuda.current_stream(dev).cuda_stream
+    return _lib.stream_ptr(dev)
 
 
 def probe(edge_index: torch.Tensor) -> Tuple[int, int, bool]:

@@ -71,7 +71,7 @@ def main():
             # nodes on the default stream; the non-distributed reference runs afterwards on the capture stream
             pkg.parallel.attach_grad_allreduce(model, group)
             print(f"[{name}] capturing", file=sys.stderr, flush=True)
-            gs = pkg.graphs.GraphedStep(lambda: step(group))
+            gs = pkg.graphs.GraphedStep(lambda: step(group), capture_error_mode=os.environ.get("DSS2_CAPTURE_MODE", "thread_local"))
             print(f"[{name}] captured, replaying", file=sys.stderr, flush=True)
             l3, g3 = snapshot(gs.replay())
             for m in model.modules():

@@ -48,9 +48,10 @@ def test_rccl_world1_step_is_bitwise_the_non_distributed_step():
 
 
 def test_rccl_collectives_inside_hipgraph_capture():
-    """Does a step with its RCCL collectives capture into a hipGraph on this stack?  If it does, the replay must be
-    bitwise the eager step.  If the capture fails (or takes the child process down), the multi-GPU path stays eager --
-    bench.py and runner.py never capture distributed steps -- and the outcome is recorded."""
+    """A step WITH its RCCL collectives (loss sums, gradient bucket) captured into a hipGraph and replayed: must be bitwise
+    the eager step.  The capture needs capture_error_mode="thread_local" (graphs.GraphedStep): in the default global mode
+    the process-group watchdog's event queries abort the process during the capture (round 2, first attempt).  bench.py
+    times distributed steps both ways behind a watchdog timer.  The outcome is recorded either way."""
     p = _child("graph")
     outcome = {"returncode": p.returncode}
     if p.returncode == 0:
