@@ -1014,14 +1014,22 @@ class MPN(nn.Module):
             ps.extend(l.weight for l in c.lins)
         return ps
 
-    def _flat_offsets(self) -> np.ndarray:
-        """Element offsets of [W1|b1], [W2|b2], [conv l: W_0..W_K | bias] in the flat gradient buffer."""
+    def _flat_offsets(self):
+        """Element offsets of [W1|b1], [W2|b2], [conv l: W_0..W_K | bias] in the flat gradient buffer (a list of ints;
+        the model's dimensions are fixed at construction, so it is computed once)."""
+        cached = self.__dict__.get("_flat_offs")
+        if cached is not None:
+            return cached
         hid, fn, fe, nmat, L = self.dim_hid, self.dim_featn, self.dim_feate, self.K + 1, self.n_gnn_layers
         sizes = [hid * (2 * fn + fe) + hid, hid * hid + hid]
         for l in range(L):
             hout = self.dim_out if l == L - 1 else hid
             sizes.append(nmat * hout * hid + hout)
-        return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        offs = [0]
+        for s_ in sizes:
+            offs.append(offs[-1] + s_)
+        self.__dict__["_flat_offs"] = offs
+        return offs
 
     def forward(self, x, edge_index, edge_attr):
         _require_gpu(x, edge_index, edge_attr)
@@ -1252,14 +1260,20 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         hook = getattr(mod, "_grad_bucket_hook", None)
         if hook is not None:      # data-parallel: all-reduce the flat bucket once (parallel.py)
             hook(flat)
-    nc = 2 * fn + fe
-    g1, g2 = flat[offs[0]:offs[1]], flat[offs[1]:offs[2]]
-    grads = [g1[:hid * nc].view(hid, nc), g1[hid * nc:], g2[:hid * hid].view(hid, hid), g2[hid * hid:]]
-    for l in range(L):
-        hout = mod.dim_out if l == L - 1 else hid
-        seg = flat[offs[2 + l]:offs[3 + l]]
-        grads.append(seg[nmat * hout * hid:])                                     # bias
-        grads.extend(seg[m * hout * hid:(m + 1) * hout * hid].view(hout, hid) for m in range(nmat))
+    # parameter gradients = views into the flat buffer, in the order of MPN._params(): one split call for all pieces
+    lay = mod.__dict__.get("_grad_layout")
+    if lay is None:
+        nc = 2 * fn + fe
+        pieces = [(hid * nc, (hid, nc)), (hid, None), (hid * hid, (hid, hid)), (hid, None)]      # W1, b1, W2, b2
+        order = [0, 1, 2, 3]
+        for l in range(L):
+            hout = mod.dim_out if l == L - 1 else hid
+            base = len(pieces)
+            pieces += [(hout * hid, (hout, hid))] * nmat + [(hout, None)]                       # stored [W_0..W_K | bias]
+            order += [base + nmat] + list(range(base, base + nmat))                              # returned bias first
+        lay = mod.__dict__["_grad_layout"] = ([sz for sz, _ in pieces], [sh for _, sh in pieces], order)
+    parts = flat.split(lay[0])
+    grads = [parts[i] if lay[1][i] is None else parts[i].view(lay[1][i]) for i in lay[2]]
     return dx, grads, fold_late
 
 
