@@ -1,4 +1,6 @@
 #!/bin/bash
+# rocprofv3 kernel timeline of one bench.py step in distributed mode at world size 1 (RANK=0 WORLD_SIZE=1): shows the host-side gaps the
+# two per-step collectives open in an eager step (tools/host_rate.py has the host-vs-GPU time per step).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533
 cd /tmp; rm -rf /tmp/dtrace
