@@ -205,39 +205,6 @@ def main():
 
     avg_ms, med_ms, n_l, layers_per_launch = timed_pass(min(args.steps, 20))
 
-    # ---- the SAME step replayed as a hipGraph (graphs.GraphedStep), timed the same way; the faster mode is reported.
-    # Eager: 19 launches through the C ABI per step, ~0.41 ms of host work on a quiet box (hidden by the 0.58 ms of GPU work)
-    # but up to 0.8 ms on a loaded host -- and two collectives more per step when distributed -- which then bounds the step.
-    # Replay has no host work.  Distributed steps are captured WITH their RCCL collectives (capture_error_mode =
-    # "thread_local": the process-group watchdog may touch HIP during the capture; tests/test_gpu_rccl.py).  A watchdog
-    # timer prints the eager result and exits 0 if a capture or a replay ever hangs.
-    if not args.no_graph:
-        import threading
-
-        def bail():
-            result["config"]["hipgraph"] = f"no answer within {args.graph_timeout:.0f} s: eager result reported"
-            if rank == 0:
-                print(json.dumps(result), flush=True)
-            os._exit(0)
-        timer = threading.Timer(args.graph_timeout, bail)
-        timer.daemon = True
-        timer.start()
-        try:
-            graphed = pkg.graphs.GraphedStep(step, stream=work_stream, capture_error_mode="thread_local")
-            for _ in range(max(args.warmup, 5)):
-                graphed.replay()
-            gw, _ = timed_windows(graphed.replay)
-            gdt = sorted(gw)[len(gw) // 2]
-            result["config"]["ms_per_step_by_mode"]["hipGraph replay"] = gdt / args.steps * 1e3
-            if gdt < dt:
-                dt, ms, windows, mode = gdt, gdt / args.steps * 1e3, gw, "hipGraph replay"
-                value = args.batch * world / (dt / args.steps)
-                result.update(value=value, ms_per_step=ms)
-                result["config"].update(mode=mode, timed_windows=len(gw),
-                                        window_ms_min_median_max=[min(gw) * 1e3, gdt * 1e3, max(gw) * 1e3])
-        except Exception as exc:          # capture not possible on this stack: the eager numbers stand
-            result["config"]["hipgraph"] = f"failed: {type(exc).__name__}: {exc}"[:300]
-        timer.cancel()
 
     if rank == 0:
         flops_layer = 2.0 * N * HID * (KHOPS + 1) * HID + 2.0 * KHOPS * E2 * HID
@@ -277,6 +244,41 @@ def main():
             r["pipe"] = "bf16 MFMA, 6 instructions per fp32 product group (bf16x6)"
             r["peak_bf16_pipe_equiv"] = BF16_MFMA_PEAK_TF / 6.0
             r["frac_bf16_pipe"] = r["achieved"] / (BF16_MFMA_PEAK_TF / 6.0)
+    # ---- the SAME step replayed as a hipGraph (graphs.GraphedStep), timed the same way; the faster mode is reported.
+    # Eager: 19 launches through the C ABI per step, ~0.41 ms of host work on a quiet box (hidden by the 0.58 ms of GPU work)
+    # but up to 0.8 ms on a loaded host -- and two collectives more per step when distributed -- which then bounds the step.
+    # Replay has no host work.  Distributed steps are captured WITH their RCCL collectives (capture_error_mode =
+    # "thread_local": the process-group watchdog may touch HIP during the capture; tests/test_gpu_rccl.py).  A watchdog
+    # timer prints the eager result and exits 0 if a capture or a replay ever hangs.
+    if not args.no_graph:
+        import threading
+
+        def bail():
+            result["config"]["hipgraph"] = f"no answer within {args.graph_timeout:.0f} s: eager result reported"
+            if rank == 0:
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+        timer = threading.Timer(args.graph_timeout, bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            graphed = pkg.graphs.GraphedStep(step, stream=work_stream, capture_error_mode="thread_local")
+            for _ in range(max(args.warmup, 5)):
+                graphed.replay()
+            gw, _ = timed_windows(graphed.replay)
+            gdt = sorted(gw)[len(gw) // 2]
+            result["config"]["ms_per_step_by_mode"]["hipGraph replay"] = gdt / args.steps * 1e3
+            if gdt < dt:
+                dt, ms, windows, mode = gdt, gdt / args.steps * 1e3, gw, "hipGraph replay"
+                value = args.batch * world / (dt / args.steps)
+                result.update(value=value, ms_per_step=ms)
+                result["config"].update(mode=mode, timed_windows=len(gw),
+                                        window_ms_min_median_max=[min(gw) * 1e3, gdt * 1e3, max(gw) * 1e3])
+        except Exception as exc:          # capture not possible on this stack: the eager numbers stand
+            result["config"]["hipgraph"] = f"failed: {type(exc).__name__}: {exc}"[:300]
+        timer.cancel()
+
+    if rank == 0:
         # ---- standalone scatter-add (K6) against the HBM roofline (north_star asks for it separately), at two sizes:
         # the C2 batch (90.9 MB: sits inside the 256 MiB Infinity Cache) and B = 32768 graphs (msg 470 MB + out 252 MB:
         # cache-busting) -- the second one is the number to hold against HBM.
