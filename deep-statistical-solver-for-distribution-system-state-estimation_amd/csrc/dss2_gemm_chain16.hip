@@ -29,3 +29,9 @@ int launch_chain16(const dss2_gemm_prop_args& a, const ChainTable& ct, int rspli
 }
 
 }  // namespace dss2
+
+#ifdef DSS2_CHAIN_STAMPS
+extern "C" int dss2_debug_read_cstamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dss2::g_cstamps), sizeof(unsigned long long) * n);
+}
+#endif

@@ -15,6 +15,22 @@
 
 namespace dss2 {
 
+#ifdef DSS2_CHAIN_STAMPS
+// Diagnostic build only (csrc/build.sh -DDSS2_CHAIN_STAMPS, tools/cstamps.py): s_memtime stamps of every wave of the first
+// 2048 workgroups at the phase boundaries of every layer.  They go to a buffer no kernel reads.
+__device__ unsigned long long g_cstamps[2048 * 8 * 64];
+#define CSTAMP(slot)                                                                                         \
+  do {                                                                                                       \
+    unsigned long long t_;                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (lane == 0 && blockIdx.x < 2048 && (slot) < 64) g_cstamps[((size_t)blockIdx.x * 8 + wave) * 64 + (slot)] = t_; \
+  } while (0)
+#else
+#define CSTAMP(slot) do {} while (0)
+#endif
+
 constexpr int CHAIN_MAX = 8;
 struct ChainTable { dss2_chain_layer l[CHAIN_MAX]; int n; };
 
@@ -83,7 +99,9 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
     const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
     for (int idx = tid; idx < D * TM; idx += nthreads) ell[idx] = src[idx];
   }
+  CSTAMP(0);
   __syncthreads();
+  CSTAMP(1);
 
   const int c32 = lane & 31, half = lane >> 5;
   const int nkk = p.kpad >> 3;
@@ -189,8 +207,10 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
     }
     if (kk < nkk) mma_ab(a0, b0);
     }
+    CSTAMP(2 + li * 6 + 0);      // GEMM phase done
     // every wave is done with this layer's X tile: the epilogue below overwrites it in place
     if (li + 1 < ct.n) __syncthreads();
+    CSTAMP(2 + li * 6 + 1);
 
     // ---- Horner: T = G_{NMAT-1}; T = G_m + P T   (ELL slice, wave-private stage)
     f32x16 T[NRW];
@@ -220,6 +240,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
       }
     }
 
+    CSTAMP(2 + li * 6 + 2);      // Horner done
     // ---- epilogue: T -> stage -> 16-byte rows -> HBM (and the next layer's X tile)
     f32x4 pb4[NMAT];
 #pragma unroll
@@ -234,10 +255,52 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[((rs * NRW + rb) * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
     wave_lds_sync();   // the epilogue of a wave reads only the rows it wrote itself
+    CSTAMP(2 + li * 6 + 5);      // T staged for the epilogue
     const int col0 = cg * 32 + cq;
     const bool keep = li + 1 < ct.n;
     const int rlo = rs * NRW * 32, rhi = min(R, (rs + 1) * NRW * 32);     // this wave's rows
-    if (col0 < p.hout) {
+    // Common case (no folded bias, mask tensor, residual or in-kernel dropout: the plain forward layers and every
+    // data-gradient layer): fixed trip count, every LDS / global read of the wave's rows issued before the first use, the
+    // uniform flags tested once.  (The general loop below re-tests seven uniform flags per 16 rows through short basic
+    // blocks and waits for its reads one pair at a time: 6.4 K of a layer's 29 K cycles, tools/cstamps.py.)
+    // (only where a wave owns at most two row blocks: with more, the batch's 32 registers push the tall-tile instantiations into spills)
+    const bool simple = NRW <= 2 && !L.prebias && !L.dmask && !L.add_src && !L.drop_id;
+    if (col0 < p.hout && simple) {
+      constexpr int NIT = NRW * 2;      // 16 rows per pass of the wave's 64 lanes; two passes per batch
+      const bool has_rs = L.relu_src != nullptr, has_bias = L.bias != nullptr, do_relu = (L.relu & 1) != 0;
+#pragma unroll 1
+      for (int it0 = 0; it0 < NIT; it0 += 2) {
+        f32x4 y[2][2], gate[2][2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int row = rlo + r8 + 16 * (it0 + it) + 8 * u;
+            const int rr = row < rhi ? row : rlo;
+            y[it][u] = *reinterpret_cast<const f32x4*>(st + rr * 32 + cq);
+            if (has_rs) gate[it][u] = *reinterpret_cast<const f32x4*>(L.relu_src + (size_t)(ts + rr) * p.ld_relu + col0);
+          }
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int row = rlo + r8 + 16 * (it0 + it) + 8 * u;
+            if (row >= rhi) continue;
+            f32x4 v = y[it][u];
+            if (has_bias) v += bias4;
+            if (do_relu) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            if (has_rs) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = gate[it][u][q] > 0.f ? v[q] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(L.Y + (size_t)(ts + row) * p.ldy + col0) = v;
+            if (keep) *reinterpret_cast<f32x4*>(Xs + row * LDX + col0) = v;
+          }
+      }
+    } else if (col0 < p.hout) {
       for (int row0 = rlo + r8; row0 < rhi; row0 += 16) {
         f32x4 y[2], rs[2], dm[2], ad[2], ps[2];
 #pragma unroll
@@ -277,7 +340,9 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
         }
       }
     }
+    CSTAMP(2 + li * 6 + 3);      // epilogue done
     if (keep) __syncthreads();   // the next layer's X tile is complete
+    CSTAMP(2 + li * 6 + 4);
   }
 }
 

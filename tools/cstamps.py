@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""GPU diagnostic (needs the -DDSS2_CHAIN_STAMPS build: DSS2_OUT=<pkg>/libdss2_cstamps.so DSS2_OBJ=/tmp/obj_cst bash csrc/build.sh -DDSS2_CHAIN_STAMPS; run with DSS2_LIB=<pkg>/libdss2_cstamps.so): s_memtime phase stamps of the bf16x6
+layer chain (forward, 3 layers, C2 shape) -- per layer: GEMM phase, barrier wait, Horner, epilogue, barrier wait, as the
+median over workgroups and waves.  argv[1] = graphs in the batch (1024: one workgroup per CU; 4096: two per CU, two rounds)."""
+import ctypes as C, importlib, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+pkg = importlib.import_module("deep-statistical-solver-for-distribution-system-state-estimation_amd")
+nw = pkg.networks
+dev = torch.device("cuda:0"); H, nmat, nl = 128, 3, 3
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+b = pkg.synthetic.make_batch(["cigre14"], B, seed=0)
+ei = b["edge_index"].to(dev); N = b["x"].shape[0]
+topo = pkg.topology.get_topology(ei, N)
+Ws = [torch.randn(H, H, device=dev) * 0.1 for _ in range(nmat)]
+plan = nw._PackPlan([Ws], dev, bf16_groups=(0,)); plan.refresh()
+h = torch.randn(N, H, device=dev); bias = torch.randn(H, device=dev)
+outs = [torch.empty(N, H, device=dev) for _ in range(nl)]
+run = lambda: nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=plan.fwd16[0], Y=o, bias=bias, relu=True) for o in outs], b_format=1)
+for _ in range(200): run()
+torch.cuda.synchronize()
+run(); torch.cuda.synchronize()
+nwg = min(topo.ntiles, 2048)
+buf = (C.c_ulonglong * (nwg * 8 * 64))()
+lib = pkg._lib.lib()
+lib.dss2_debug_read_cstamps.argtypes = [C.c_void_p, C.c_int]
+assert lib.dss2_debug_read_cstamps(buf, nwg * 8 * 64) == 0
+st = np.frombuffer(buf, dtype=np.uint64).reshape(nwg, 8, 64)[:, :4, :].astype(np.int64)      # 4 waves per workgroup
+us = lambda d: float(np.median(d))      # s_memtime ticks = shader cycles
+print(f"B={B}: {topo.ntiles} tiles; shader cycles (median over workgroups x waves)")
+print(f"  first barrier wait: {us(st[:, :, 1] - st[:, :, 0]):.0f}")
+tot = 0
+for li in range(nl):
+    s = lambda i: st[:, :, 2 + li * 6 + i]
+    prev = st[:, :, 1] if li == 0 else st[:, :, 2 + (li - 1) * 6 + 4]
+    gemm, bar1, horner, epi, bar2 = us(s(0) - prev), us(s(1) - s(0)), us(s(2) - s(1)), us(s(3) - s(2)), us(s(4) - s(3))
+    epi_a = us(s(5) - s(2))
+    print(f"  layer {li}: GEMM {gemm:7.0f}  barrier {bar1:5.0f}  Horner {horner:6.0f}  epilogue {epi:6.0f} (T -> stage {epi_a:5.0f}, rows -> HBM / X tile {epi - epi_a:5.0f})  barrier {bar2:5.0f}   sum {gemm + bar1 + horner + epi + bar2:7.0f} cycles")
+wg = st[:, :, 2 + (nl - 1) * 6 + 3].max(axis=1) - st[:, :, 0].min(axis=1)
+print(f"  per workgroup, first stamp -> last epilogue: median {np.median(wg):.0f} cycles, max {wg.max():.0f}")
