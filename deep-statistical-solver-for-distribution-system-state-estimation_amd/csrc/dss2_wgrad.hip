@@ -657,8 +657,8 @@ extern "C" int dss2_wgrad_y_slices(int nrb, int nmat, int hout, int hin, int ell
   if (!mfma_bf16) return 1;
   const size_t b = dss2::wgrad16_lds_bytes(nrb, nmat, hout, hin, ell_width);
   if (b == 0 || b > (size_t)dss2::kMaxLdsBytes) return 1;
-  const int out_cols = has_rowscale2 ? 64 : 128;          // output columns per workgroup: one pass / two passes of 64
-  return ((hout + out_cols - 1) / out_cols) * ((hin + 127) / 128);
+  (void)has_rowscale2;
+  return ((hout + 127) / 128) * ((hin + 127) / 128);          // a workgroup owns 128 output x 128 input columns
 }
 
 static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::WgradBatch& wb) {

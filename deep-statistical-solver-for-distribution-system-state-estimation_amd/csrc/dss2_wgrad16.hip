@@ -49,7 +49,8 @@ __device__ __forceinline__ void store_planes(char* img, int off0, int off2, cons
 }
 
 // NP: passes of 64 output columns per workgroup (the X planes are staged once for all of them).  RS2: layers with the extra
-// scaled column sums (rowscale2, the folded first layer); their 12 more accumulator registers per pass only fit with NP = 1.
+// scaled column sums (rowscale2, the folded first layer): 12 more accumulator registers per pass -- <3, 2, true> sits at exactly
+// 256 VGPRs.
 template <int NMAT, int NP, bool RS2>
 __global__ void __launch_bounds__(W16_NT) wgrad16_kernel(const dss2_wgrad_args p, int nibg, const WgradBatch wb) {
   constexpr int TM = W16_TM, ZC = W16_ZC, XW = W16_XW, NT = W16_NT, LDZF = W16_LDZF;
@@ -307,8 +308,8 @@ int launch_wgrad16(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatc
     }
     rs2 = rs2 || wb.rowscale2[l] != nullptr;
   }
-  if (a.nmat == 2) return rs2 ? launch16<2, 1, true>(a, stream, wb) : launch16<2, 2, false>(a, stream, wb);
-  if (a.nmat == 3) return rs2 ? launch16<3, 1, true>(a, stream, wb) : launch16<3, 2, false>(a, stream, wb);
+  if (a.nmat == 2) return rs2 ? launch16<2, 2, true>(a, stream, wb) : launch16<2, 2, false>(a, stream, wb);
+  if (a.nmat == 3) return rs2 ? launch16<3, 2, true>(a, stream, wb) : launch16<3, 2, false>(a, stream, wb);
   set_error("wgrad(bf16x6): unsupported nmat=%d", a.nmat);
   return 2;
 }

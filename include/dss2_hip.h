@@ -325,8 +325,8 @@ typedef struct dss2_wgrad_args {
 int dss2_wgrad(const dss2_wgrad_args* args_host, void* stream);
 /* dynamic LDS of the kernel dss2_wgrad launches for this shape (callers size n_split by it); _ex: with args.mfma_bf16 */
 size_t dss2_wgrad_lds_bytes_ex(int nrb, int nmat, int hout, int hin, int max_nnz, int ell_width, int mfma_bf16);
-/* workgroups the launch puts on each of the n_split tile-list slices (> 1 only for the bf16x6 kernel at H > 128, or > 64 for
- * layers with rowscale2): a caller that wants one workgroup per CU divides its n_split by it                               */
+/* workgroups the launch puts on each of the n_split tile-list slices (> 1 only for the bf16x6 kernel at H > 128): a caller
+ * that wants one workgroup per CU divides its n_split by it                                                                */
 int dss2_wgrad_y_slices(int nrb, int nmat, int hout, int hin, int ell_width, int mfma_bf16, int has_rowscale2);
 
 /* The same for n_layers (<= 8) layers of IDENTICAL shape and leading dimensions in one launch (one grid
