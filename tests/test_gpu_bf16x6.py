@@ -100,7 +100,12 @@ def test_layer_chain_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat, nl):
     bf16x6 against the fp32 MFMA chain, twice (bitwise reproducible)."""
     nw = pkg.networks
     topo, N = _topo(pkg, grids, B)
-    assert nw.chain16_supported(topo, nmat, H, False) and nw.chain16_supported(topo, nmat, H, True)
+    saved16 = nw.CHAIN_BF16
+    nw.CHAIN_BF16 = True                     # (the environment may have switched the default off: these shapes are covered)
+    try:
+        assert nw.chain16_supported(topo, nmat, H, False) and nw.chain16_supported(topo, nmat, H, True)
+    finally:
+        nw.CHAIN_BF16 = saved16
     torch.manual_seed(3)
     Ws = [torch.randn(H, H, device=DEV) * (1.5 / H ** 0.5) for _ in range(nmat)]
     plan = nw._PackPlan([Ws], DEV, bf16_groups=(0,))

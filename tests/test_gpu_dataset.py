@@ -245,7 +245,18 @@ def test_mixed_topology_batch_step_matches_the_oracle(pkg, oracle):
                             num_samples=None, node_param=bt.x[:, 8:], edge_param=bt.edge_attr[:, 6:])
     loss.backward()
     assert (out.detach().cpu().double() - out_r).abs().max() <= 1e-5 * out_r.abs().max()
-    assert abs(loss.item() - loss_r.item()) <= 1e-5 * abs(loss_r.item())
+    # the loss of this small mixed batch is ill-conditioned (large terms cancelling): the reference's own fp32 evaluation is
+    # 1-2e-5 away from the fp64 one, so the bound is "1e-5, or no worse than twice the fp32 reference's own distance"
+    ref32 = oracle.MPN(8, 6, 2, 64, 3, 2, 0.0)
+    ref32.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    hb32 = {"x": bt.x.cpu(), "edge_index": bt.edge_index.cpu(), "edge_attr": bt.edge_attr.cpu()}
+    with torch.no_grad():
+        o32 = ref32(hb32["x"][:, :8], hb32["edge_index"], hb32["edge_attr"][:, :6])
+        st32 = tuple(s.cpu() for s in stats)
+        l32 = oracle.gsp_wls_edge(input=hb32["x"][:, :8], edge_input=hb32["edge_attr"][:, :6], output=o32, x_mean=st32[0], x_std=st32[1],
+                                  edge_mean=st32[2], edge_std=st32[3], edge_index=hb32["edge_index"], reg_coefs=oracle.DEFAULT_REG_COEFS,
+                                  num_samples=None, node_param=hb32["x"][:, 8:], edge_param=hb32["edge_attr"][:, 6:])
+    assert abs(loss.item() - loss_r.item()) <= max(1e-5 * abs(loss_r.item()), 2.0 * abs(l32.item() - loss_r.item()))
     tol = max(1e-4, 3.0 / bt.x.shape[0])        # un-pinned ReLU gates: one flipped gate moves a gradient row by ~1/N_nodes
     for (n_, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
         assert (p.grad.cpu().double() - q.grad).abs().max() <= tol * q.grad.abs().max(), n_
