@@ -35,6 +35,8 @@ constexpr int CHAIN_MAX = 8;
 struct ChainTable { dss2_chain_layer l[CHAIN_MAX]; int n; };
 
 constexpr int chain_waves_per_simd(int nrb, int nmat) { return nrb * nmat * 16 <= 128 ? 2 : 1; }
+constexpr bool chain_rm(int nrb, int rs, bool b16) { return b16 && rs == 2 && nrb == 2; }
+constexpr int CHAIN_RM_STRIDE = 36;      // floats per stage row in the RM layout (16-byte aligned, rows 4 apart on different banks)
 
 // NW: waves per workgroup the kernel is compiled for.  RS: row split -- RS waves share one 32-column group, each owning
 // NRB / RS of the tile's row blocks (its accumulators, its rows of the group's stage and of the epilogue); the
@@ -53,6 +55,13 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
   constexpr int NRW = NRB / RS;          // row blocks per wave
   constexpr int PF = 8;
   constexpr int LDA = TM + 4;
+  // RM ("row-major Horner", narrow bf16x6 layers: two waves per 32-column group, one row block each): every matrix of the
+  // group goes to its own stage slot once, and the hops run on 16-byte row pieces (a lane owns 4 columns of 4 rows: one ELL
+  // entry and one ds_read_b128 per neighbour instead of 4 + 4 LDS reads in the accumulator layout), ending in the lanes --
+  // and the row-major form -- the epilogue wants.  At H = 32 a layer is a chain of LDS / L2 latencies, not MFMA time.
+  constexpr bool RM = chain_rm(NRB, RS, B16);
+  constexpr int SST = RM ? CHAIN_RM_STRIDE : 32;      // stage row stride (floats)
+  constexpr bool PFB = RM && NMAT <= 3;               // next layer's first weight fragments prefetched (K = 3 would spill)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -65,7 +74,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
   float* Xs = smem;
   float* stage = Xs + TM * LDX;
   const int D = p.ell_width;
-  int2* ell = reinterpret_cast<int2*>(stage + (nw / RS) * 32 * LDA);   // one stage per column group
+  int2* ell = reinterpret_cast<int2*>(stage + (RM ? (nw / RS) * NMAT * TM * SST : (nw / RS) * 32 * LDA));   // one stage per column group (RM: per group and matrix)
   const int ts = p.tile_start[tile];
   const int R = p.tile_start[tile + 1] - ts;
   const int kq = p.kpad >> 2;
@@ -107,12 +116,20 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
   const int nkk = p.kpad >> 3;
   const float* xa = Xs + c32 * LDX + half * 4;
   const int cg = wave / RS, rs = wave - cg * RS;   // column group, and which share of its row blocks
-  float* st = stage + cg * (32 * LDA);      // per column group [TM][32] row-major (wave-private when RS == 1)
+  float* st = RM ? stage + cg * NMAT * (TM * SST) : stage + cg * (32 * LDA);      // per column group [TM][32] row-major (wave-private when RS == 1)
   auto stage_sync = [&]() { if (RS == 1) wave_lds_sync(); else __syncthreads(); };
   const int ecol0 = cg * 32 + (lane & 7) * 4;
   const int cq = (lane & 7) * 4, r8 = lane >> 3;
   const bool ecol_ok = ecol0 < p.hout;
 
+  bf16x8 bnext[3][NMAT];      // PFB: the next layer's first weight fragments
+  if constexpr (PFB) {
+    const bf16x8* __restrict__ src = reinterpret_cast<const bf16x8*>(ct.l[0].Bp);
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bnext[pl][m] = src[(((size_t)(m * p.ncg + cg) * (p.kpad >> 4)) * 3 + pl) * 64 + lane];
+  }
   for (int li = 0; li < ct.n; ++li) {
     const dss2_chain_layer& L = ct.l[li];    // uniform: scalar loads from the kernel-argument segment
     const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(L.Bp);
@@ -132,13 +149,14 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
       const int nks = p.kpad >> 4;
       const float* xa16 = Xs + c32 * LDX + half * 8;
       bf16x8 b0[3][NMAT], b1[3][NMAT];
-      auto load_b = [&](bf16x8 (&b)[3][NMAT], int ks) {
+      auto load_bp = [&](const bf16x8* __restrict__ src, bf16x8 (&b)[3][NMAT], int ks) {
         const int kc = ks < nks ? ks : nks - 1;
 #pragma unroll
         for (int m = 0; m < NMAT; ++m)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) b[pl][m] = bp16[(((size_t)(m * p.ncg + cg) * nks + kc) * 3 + pl) * 64 + lane];
+          for (int pl = 0; pl < 3; ++pl) b[pl][m] = src[(((size_t)(m * p.ncg + cg) * nks + kc) * 3 + pl) * 64 + lane];
       };
+      auto load_b = [&](bf16x8 (&b)[3][NMAT], int ks) { load_bp(bp16, b, ks); };
       auto step16 = [&](const bf16x8 (&b)[3][NMAT], int ks) {
 #pragma unroll
         for (int rb = 0; rb < NRW; ++rb) {
@@ -165,15 +183,26 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
           }
         }
       };
-      load_b(b0, 0);
+      if constexpr (PFB) {
+        // the first fragments of a layer were requested during the previous layer's Horner / epilogue
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) b0[pl][m] = bnext[pl][m];
+      } else {
+        load_b(b0, 0);
+      }
       int ks = 0;
       for (; ks + 2 <= nks; ks += 2) {
         load_b(b1, ks + 1);
         step16(b0, ks);
-        load_b(b0, ks + 2);
+        if (!RM || ks + 2 < nks) load_b(b0, ks + 2);
         step16(b1, ks + 1);
       }
       if (ks < nks) step16(b0, ks);
+      if constexpr (PFB) {
+        if (li + 1 < ct.n) load_bp(reinterpret_cast<const bf16x8*>(ct.l[li + 1].Bp), bnext, 0);
+      }
     } else {
     // ---- MFMA over the X tile: 8 k per step, A (LDS) / B (packed weights, L2) ping-pong prefetch
     f32x4 a0[NRW] = {}, a1[NRW] = {}, b0[NMAT] = {}, b1[NMAT] = {};
@@ -209,11 +238,44 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
     }
     CSTAMP(2 + li * 6 + 0);      // GEMM phase done
     // every wave is done with this layer's X tile: the epilogue below overwrites it in place
-    if (li + 1 < ct.n) __syncthreads();
+    if (!RM && li + 1 < ct.n) __syncthreads();      // (RM: the barrier after the stage writes below orders the same accesses)
     CSTAMP(2 + li * 6 + 1);
 
+    if constexpr (RM) {
+      // ---- Horner on row pieces: slot m holds G_m; U = G_m + P (slot m+1), written back to slot m for the next hop
+      // (no barrier needed before these writes: the previous layer's gathers ended before its closing barrier)
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[m * (TM * SST) + (rs * 32 + acc_row(r, half)) * SST + c32] = acc[0][m][r];
+      stage_sync();
+      const int rrow = rs * 32 + r8;      // this lane's rows: rrow + 8 i
+      f32x4 U[4];
+#pragma unroll
+      for (int m = NMAT - 2; m >= 0; --m) {
+        const float* src = st + (m + 1) * (TM * SST) + cq;
+        float* own = st + m * (TM * SST) + rrow * SST + cq;
+        int2 en[4], en_next[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { en[i] = ell[rrow + 8 * i]; U[i] = *reinterpret_cast<const f32x4*>(own + 8 * i * SST); }
+        for (int k = 0; k < D; ++k) {
+          const int kn = k + 1 < D ? k + 1 : k;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) en_next[i] = ell[kn * TM + rrow + 8 * i];
+          f32x4 z[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) z[i] = *reinterpret_cast<const f32x4*>(src + en[i].x * SST);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { U[i] += z[i] * __int_as_float(en[i].y); en[i] = en_next[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(own + 8 * i * SST) = U[i];      // (m == 0: the epilogue's rows, same lanes)
+        if (m > 0) stage_sync();
+      }
+    }
     // ---- Horner: T = G_{NMAT-1}; T = G_m + P T   (ELL slice, wave-private stage)
     f32x16 T[NRW];
+    if constexpr (!RM) {
 #pragma unroll
     for (int rb = 0; rb < NRW; ++rb) T[rb] = acc[rb][NMAT - 1];
 #pragma unroll
@@ -239,6 +301,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
         }
       }
     }
+    }
 
     CSTAMP(2 + li * 6 + 2);      // Horner done
     // ---- epilogue: T -> stage -> 16-byte rows -> HBM (and the next layer's X tile)
@@ -249,12 +312,14 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
 #pragma unroll
       for (int m = 0; m < NMAT; ++m) pb4[m] = *reinterpret_cast<const f32x4*>(L.prebias + (size_t)m * p.hout + ecol0);
     }
+    if constexpr (!RM) {
     stage_sync();      // (RS > 1: the other waves are done gathering from the stage)
 #pragma unroll
     for (int rb = 0; rb < NRW; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[((rs * NRW + rb) * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
     wave_lds_sync();   // the epilogue of a wave reads only the rows it wrote itself
+    }
     CSTAMP(2 + li * 6 + 5);      // T staged for the epilogue
     const int col0 = cg * 32 + cq;
     const bool keep = li + 1 < ct.n;
@@ -277,7 +342,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
           for (int u = 0; u < 2; ++u) {
             const int row = rlo + r8 + 16 * (it0 + it) + 8 * u;
             const int rr = row < rhi ? row : rlo;
-            y[it][u] = *reinterpret_cast<const f32x4*>(st + rr * 32 + cq);
+            y[it][u] = *reinterpret_cast<const f32x4*>(st + rr * SST + cq);
             if (has_rs) gate[it][u] = *reinterpret_cast<const f32x4*>(L.relu_src + (size_t)(ts + rr) * p.ld_relu + col0);
           }
 #pragma unroll
@@ -308,7 +373,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
           const int row = row0 + 8 * u;
           const bool ok = row < rhi;
           const size_t grow = (size_t)(ts + (ok ? row : rlo));
-          y[u] = *reinterpret_cast<const f32x4*>(st + (ok ? row : rlo) * 32 + cq);
+          y[u] = *reinterpret_cast<const f32x4*>(st + (ok ? row : rlo) * SST + cq);
           if (L.prebias) ps[u] = *reinterpret_cast<const f32x4*>(p.pre_rowscale + grow * 4);
           if (L.dmask) dm[u] = *reinterpret_cast<const f32x4*>(L.dmask + grow * p.ld_dmask + col0);
           if (L.relu_src) rs[u] = *reinterpret_cast<const f32x4*>(L.relu_src + grow * p.ld_relu + col0);
@@ -346,9 +411,10 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
   }
 }
 
-inline size_t chain_lds_bytes(int nrb, int kpad, int ncg, int ell_width) {
+inline size_t chain_lds_bytes(int nrb, int kpad, int ncg, int ell_width, int rm_nmat = 0) {      // rm_nmat > 0: the RM stage (one slot per matrix)
   const size_t TM = (size_t)nrb * 32;
-  return TM * (size_t)(kpad + 4) * 4 + (size_t)ncg * 32 * (TM + 4) * 4 + TM * (size_t)ell_width * 8;
+  const size_t stage = rm_nmat > 0 ? (size_t)ncg * rm_nmat * TM * CHAIN_RM_STRIDE * 4 : (size_t)ncg * 32 * (TM + 4) * 4;
+  return TM * (size_t)(kpad + 4) * 4 + stage + TM * (size_t)ell_width * 8;
 }
 
 template <int NRB, int NMAT, int NW, int RS, bool B16 = false>
@@ -356,7 +422,7 @@ inline int launch_chain(const dss2_gemm_prop_args& a, const ChainTable& ct, hipS
   static std::atomic<uint32_t> lds_done{0};
   auto kern = gemm_chain_kernel<NRB, NMAT, NW, RS, B16>;
   if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop_chain")) return 1;
-  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg * RS), chain_lds_bytes(NRB, a.kpad, a.ncg, a.ell_width), stream, a, ct);
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg * RS), chain_lds_bytes(NRB, a.kpad, a.ncg, a.ell_width, chain_rm(NRB, RS, B16) ? NMAT : 0), stream, a, ct);
   return check_launch("gemm_prop_chain");
 }
 
