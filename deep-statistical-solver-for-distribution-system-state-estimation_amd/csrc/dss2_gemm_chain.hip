@@ -28,7 +28,7 @@ extern "C" int dss2_gemm_prop_chain16_supported(int nrb, int nmat, int kreal, in
   const int ncg = (hout + 31) / 32, rsplit = chain_row_split(nrb, ncg);
   if (nrb == 2 && nmat == 4 && rsplit != 2) return 0;
   if (nrb == 3 && nmat == 3 && ncg > 4) return 0;
-  return chain_lds_bytes(nrb, (kreal + 15) / 16 * 16, ncg, ell_width, chain_rm(nrb, rsplit, true) ? nmat : 0) <= (size_t)kMaxLdsBytes ? 1 : 0;
+  return chain_lds_bytes(nrb, (kreal + 15) / 16 * 16, ncg, ell_width, chain_rm(nrb, rsplit, true, nmat) ? nmat : 0) <= (size_t)kMaxLdsBytes ? 1 : 0;
 }
 
 extern "C" int dss2_gemm_prop_chain(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, void* stream) {

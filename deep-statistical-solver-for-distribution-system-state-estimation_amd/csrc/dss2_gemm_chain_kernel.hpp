@@ -35,7 +35,7 @@ constexpr int CHAIN_MAX = 8;
 struct ChainTable { dss2_chain_layer l[CHAIN_MAX]; int n; };
 
 constexpr int chain_waves_per_simd(int nrb, int nmat) { return nrb * nmat * 16 <= 128 ? 2 : 1; }
-constexpr bool chain_rm(int nrb, int rs, bool b16) { return b16 && rs == 2 && nrb == 2; }
+constexpr bool chain_rm(int nrb, int rs, bool b16, int nmat) { return b16 && rs == 2 && nrb == 2 && nmat <= 3; }      // (K = 3 would spill)
 constexpr int CHAIN_RM_STRIDE = 36;      // floats per stage row in the RM layout (16-byte aligned, rows 4 apart on different banks)
 
 // NW: waves per workgroup the kernel is compiled for.  RS: row split -- RS waves share one 32-column group, each owning
@@ -59,9 +59,11 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
   // group goes to its own stage slot once, and the hops run on 16-byte row pieces (a lane owns 4 columns of 4 rows: one ELL
   // entry and one ds_read_b128 per neighbour instead of 4 + 4 LDS reads in the accumulator layout), ending in the lanes --
   // and the row-major form -- the epilogue wants.  At H = 32 a layer is a chain of LDS / L2 latencies, not MFMA time.
-  constexpr bool RM = chain_rm(NRB, RS, B16);
+  constexpr bool RM = chain_rm(NRB, RS, B16, NMAT);
   constexpr int SST = RM ? CHAIN_RM_STRIDE : 32;      // stage row stride (floats)
-  constexpr bool PFB = RM && NMAT <= 3;               // next layer's first weight fragments prefetched (K = 3 would spill)
+  // (prefetching the next layer's first weight fragments across the Horner / epilogue phases -- PFB -- measured slower: the
+  //  36 extra live registers spill once the barriers no longer drain the loads; kept as a switch for the record)
+  constexpr bool PFB = false;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -117,7 +119,10 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
   const float* xa = Xs + c32 * LDX + half * 4;
   const int cg = wave / RS, rs = wave - cg * RS;   // column group, and which share of its row blocks
   float* st = RM ? stage + cg * NMAT * (TM * SST) : stage + cg * (32 * LDA);      // per column group [TM][32] row-major (wave-private when RS == 1)
-  auto stage_sync = [&]() { if (RS == 1) wave_lds_sync(); else __syncthreads(); };
+  // (workgroup barriers of the layer loop drain LDS only: nothing a wave writes to global memory is read back in this kernel)
+  // (K = 3 with a row split keeps the full fence: the LDS-only form costs that instantiation 20 spilled registers)
+  auto wg_barrier = [&]() { if constexpr (RS == 2 && NMAT >= 4) __syncthreads(); else lds_barrier(); };
+  auto stage_sync = [&]() { if (RS == 1) wave_lds_sync(); else wg_barrier(); };
   const int ecol0 = cg * 32 + (lane & 7) * 4;
   const int cq = (lane & 7) * 4, r8 = lane >> 3;
   const bool ecol_ok = ecol0 < p.hout;
@@ -238,7 +243,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
     }
     CSTAMP(2 + li * 6 + 0);      // GEMM phase done
     // every wave is done with this layer's X tile: the epilogue below overwrites it in place
-    if (!RM && li + 1 < ct.n) __syncthreads();      // (RM: the barrier after the stage writes below orders the same accesses)
+    if (!RM && li + 1 < ct.n) wg_barrier();      // (RM: the barrier after the stage writes below orders the same accesses)
     CSTAMP(2 + li * 6 + 1);
 
     if constexpr (RM) {
@@ -406,7 +411,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
       }
     }
     CSTAMP(2 + li * 6 + 3);      // epilogue done
-    if (keep) __syncthreads();   // the next layer's X tile is complete
+    if (keep) wg_barrier();   // the next layer's X tile is complete
     CSTAMP(2 + li * 6 + 4);
   }
 }
@@ -422,7 +427,7 @@ inline int launch_chain(const dss2_gemm_prop_args& a, const ChainTable& ct, hipS
   static std::atomic<uint32_t> lds_done{0};
   auto kern = gemm_chain_kernel<NRB, NMAT, NW, RS, B16>;
   if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop_chain")) return 1;
-  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg * RS), chain_lds_bytes(NRB, a.kpad, a.ncg, a.ell_width, chain_rm(NRB, RS, B16) ? NMAT : 0), stream, a, ct);
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg * RS), chain_lds_bytes(NRB, a.kpad, a.ncg, a.ell_width, chain_rm(NRB, RS, B16, NMAT) ? NMAT : 0), stream, a, ct);
   return check_launch("gemm_prop_chain");
 }
 

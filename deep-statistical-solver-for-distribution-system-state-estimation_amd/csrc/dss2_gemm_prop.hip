@@ -247,9 +247,11 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       //   T <- X B_{K};   T <- X B_m + P T  (m = K-1 .. 0)
       // with T parked in the wave's LDS stage during the MFMA pass of the next matrix (the gather needs it there
       // anyway).  Same MFMA count; the X tile is read NMAT times from LDS instead of once.
-#pragma unroll 1
-      for (int m = NMAT - 1; m >= 0; --m) {
-        f32x16 accm[NRB];
+      constexpr int NPH = NRB * 2;      // 16-byte pieces per thread of one half of the X tile (256 threads, kpad <= 128)
+      f32x4 pxh[NPH];
+      // one pass (matrix m) as a function of its accumulator: the last pass (m = 0) is peeled off the loop and accumulates
+      // straight into T -- a T assigned on the last trip of a rolled loop holds its 16 NRB registers through every trip
+      auto seq_pass = [&](const int m, f32x16 (&accm)[NRB]) {
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -265,8 +267,33 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
           const int nkh = khalf ? (nkk >> 1) : nkk;      // k-steps in this half
           const int kb = hf * nkh;                      // first k-step (B fragment index) of this half
           if (khalf) {                                  // (uniform: every wave has exactly one column group)
-            __syncthreads();                            // everyone is done with the previous half
             const int kh4 = p.kpad >> 3;                // 16-byte pieces per row in a half
+            // the OTHER half's pieces were requested right after the previous staging (register prefetch under the MFMA
+            // pass): only the very first staging of a tile pays its memory latency in the open
+            const bool pre_ok = TM * kh4 <= NPH * nthreads;
+            auto load_half = [&](int h) {
+#pragma unroll
+              for (int i = 0; i < NPH; ++i) {
+                const int idx = tid + i * nthreads;
+                const int r = idx / kh4, c = (idx - r * kh4) << 2;
+                const int cglob = h * (p.kpad >> 1) + c;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (idx < TM * kh4 && r < R && cglob < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + cglob);
+                pxh[i] = v;
+              }
+            };
+            lds_barrier();                              // everyone is done with the previous half
+            if (pre_ok) {
+              if (m == NMAT - 1 && hf == 0) load_half(0);
+#pragma unroll
+              for (int i = 0; i < NPH; ++i) {
+                const int idx = tid + i * nthreads;
+                const int r = idx / kh4, c = (idx - r * kh4) << 2;
+                if (idx < TM * kh4) *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = pxh[i];
+              }
+              lds_barrier();
+              if (!(m == 0 && hf == 1)) load_half(1 - hf);
+            } else {
             for (int base = 0; base < TM * kh4; base += PF * nthreads) {
               f32x4 px[PF];
 #pragma unroll
@@ -285,7 +312,8 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
                 if (idx < TM * kh4) *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = px[i];
               }
             }
-            __syncthreads();
+            lds_barrier();
+            }
           }
           auto sload2 = [&](f32x4 (&a)[NRB], f32x4& b, int kk) {
             const int kc = kk < nkh ? kk : nkh - 1;
@@ -337,18 +365,20 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
               }
           }
         }
-        if (m > 0) {                   // park T in the stage for the next pass
-          wave_lds_sync();
+      };
+#pragma unroll 1
+      for (int m = NMAT - 1; m >= 1; --m) {
+        f32x16 accm[NRB];
+        seq_pass(m, accm);
+        // park T in the stage for the next pass
+        wave_lds_sync();
 #pragma unroll
-          for (int rb = 0; rb < NRB; ++rb)
+        for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = accm[rb][r];
-          wave_lds_sync();
-        } else {
-#pragma unroll
-          for (int rb = 0; rb < NRB; ++rb) T[rb] = accm[rb];
-        }
+          for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = accm[rb][r];
+        wave_lds_sync();
       }
+      seq_pass(0, T);
     } else {
     f32x16 acc[NRB][NMAT];
 #pragma unroll

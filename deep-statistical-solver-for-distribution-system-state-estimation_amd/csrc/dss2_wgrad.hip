@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
         for (int k = tid; k < nnz; k += NT) lent[k] = make_int2(p.colT[base + k] - ts, __float_as_int(p.wT[base + k]));
       }
     }
-    __syncthreads();
+    lds_barrier();
     WSTAMP(1);
     const int next = tile + gridDim.x;
     // Next tile's slabs -> registers.  Issuing a wave's sixteen 16-byte loads blocks it for 2-5 K cycles (the CU's
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
           }
           Za[row * LDZ + m * h + j] = sacc;
         }
-        __syncthreads();
+        lds_barrier();
       }
     }
     // ---- m = 0 .. NMAT-1, ping-pong propagation
@@ -387,10 +387,10 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
       if (NW == 4 && !fast_bias) bias_sums(ts, R);
       WSTAMP(3);
       prop(Za, Zb);
-      __syncthreads();
+      lds_barrier();
       WSTAMP(4);
       prop(Zb, Zc);
-      __syncthreads();
+      lds_barrier();
       WSTAMP(5);
       if (obh == 0 && next < p.ntiles) issue_loads(next);
       mma(Za, acc[0], R);
@@ -402,21 +402,21 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     } else {
     phase(Za, Zb, acc[0], R, NMAT > 1, true, ts, 3);
     if (NMAT > 1) {
-      __syncthreads();
+      lds_barrier();
       WSTAMP(6);
       phase(Zb, Za, acc[1 % NMAT], R, NMAT > 2, false, ts, 7);
     }
     if (NMAT > 2) {
-      __syncthreads();
+      lds_barrier();
       WSTAMP(10);
       phase(Za, Zb, acc[2 % NMAT], R, NMAT > 3, false, ts, 11);
     }
     if (NMAT > 3) {
-      __syncthreads();
+      lds_barrier();
       phase(Zb, Za, acc[3 % NMAT], R, false, false, ts, 11);
     }
     }
-    __syncthreads();
+    lds_barrier();
     WSTAMP(14);
   }
 

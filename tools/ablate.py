@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 pkg = importlib.import_module("deep-statistical-solver-for-distribution-system-state-estimation_amd")
 nw, L = pkg.networks, pkg._lib
 dev = torch.device("cuda:0"); H, nmat = 128, 3
-b = pkg.synthetic.make_batch(["cigre14"], 4096, seed=0)
+GRID = sys.argv[1] if len(sys.argv) > 1 else "cigre14"; NB = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+b = pkg.synthetic.make_batch([GRID], NB, seed=0)
 ei = b["edge_index"].to(dev); N = b["x"].shape[0]
 topo = pkg.topology.get_topology(ei, N)
 Ws = [torch.randn(H, H, device=dev) * 0.1 for _ in range(nmat)]

@@ -8,7 +8,7 @@ pkg = importlib.import_module("deep-statistical-solver-for-distribution-system-s
 nw = pkg.networks
 dev = torch.device("cuda:0")
 grid, B, H = (sys.argv[1] if len(sys.argv) > 1 else "cigre14"), int(sys.argv[2]) if len(sys.argv) > 2 else 4096, int(sys.argv[3]) if len(sys.argv) > 3 else 128
-nmat, nl = 3, 3
+nmat, nl = 3, int(sys.argv[4]) if len(sys.argv) > 4 else 3      # argv: grid, graphs, hidden width, chained layers
 b = pkg.synthetic.make_batch([grid], B, seed=0)
 x, ei, ea = b["x"].to(dev), b["edge_index"].to(dev), b["edge_attr"].to(dev)
 N = x.shape[0]

@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """GPU diagnostic (needs the -DDSS2_CHAIN_STAMPS build: DSS2_OUT=<pkg>/libdss2_cstamps.so DSS2_OBJ=/tmp/obj_cst bash csrc/build.sh -DDSS2_CHAIN_STAMPS; run with DSS2_LIB=<pkg>/libdss2_cstamps.so): s_memtime phase stamps of the bf16x6
-layer chain (forward, 3 layers, C2 shape) -- per layer: GEMM phase, barrier wait, Horner, epilogue, barrier wait, as the
+layer chain (forward; argv: graphs, hidden width (128), layers (3): the C2 shape by default) -- per layer: GEMM phase, barrier wait, Horner, epilogue, barrier wait, as the
 median over workgroups and waves.  argv[1] = graphs in the batch (1024: one workgroup per CU; 4096: two per CU, two rounds)."""
 import ctypes as C, importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 pkg = importlib.import_module("deep-statistical-solver-for-distribution-system-state-estimation_amd")
 nw = pkg.networks
-dev = torch.device("cuda:0"); H, nmat, nl = 128, 3, 3
+dev = torch.device("cuda:0"); nmat = 3
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+nl = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 b = pkg.synthetic.make_batch(["cigre14"], B, seed=0)
 ei = b["edge_index"].to(dev); N = b["x"].shape[0]
 topo = pkg.topology.get_topology(ei, N)
@@ -25,7 +27,9 @@ buf = (C.c_ulonglong * (nwg * 8 * 64))()
 lib = pkg._lib.lib()
 lib.dss2_debug_read_cstamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.dss2_debug_read_cstamps(buf, nwg * 8 * 64) == 0
-st = np.frombuffer(buf, dtype=np.uint64).reshape(nwg, 8, 64)[:, :4, :].astype(np.int64)      # 4 waves per workgroup
+ncg = (H + 31) // 32
+nwav = min(8, ncg * (2 if ncg <= 2 else 1))      # waves per workgroup (row split for narrow layers)
+st = np.frombuffer(buf, dtype=np.uint64).reshape(nwg, 8, 64)[:, :nwav, :].astype(np.int64)
 us = lambda d: float(np.median(d))      # s_memtime ticks = shader cycles
 print(f"B={B}: {topo.ntiles} tiles; shader cycles (median over workgroups x waves)")
 print(f"  first barrier wait: {us(st[:, :, 1] - st[:, :, 0]):.0f}")
