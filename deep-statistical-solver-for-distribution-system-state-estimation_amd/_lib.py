@@ -162,6 +162,7 @@ _SIGNATURES = {
     "dss2_gemm_prop_chain": (C.c_int, [C.POINTER(GemmPropArgs), C.c_void_p, C.c_int, C.c_void_p]),
     "dss2_gemm_prop_chain_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_gemm_prop_chain16_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dss2_gemm_prop16_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p]),
     "dss2_wgrad_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "dss2_reduce_slabs_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

@@ -107,7 +107,11 @@ constexpr int gemm_waves_per_simd(int nrb, int nmat) {
   return nrb * nmat * 16 <= 128 ? 2 : 1;
 }
 
-template <int NRB, int NMAT>
+// B16 (matrix-sequential tall tiles with K-halved staging only): the tile GEMM as bf16x6 -- weights packed as bf16x3
+// fragments (dss2_pack_weights, transpose | 2), the wave's A fragments (8 consecutive k of its rows, fp32 in LDS) split into
+// three bf16 pieces in registers, six v_mfma_f32_32x32x16_bf16 per 16 k and row block, smallest terms first (the layer
+// chain's scheme, dss2_gemm_chain_kernel.hpp).  One workgroup per CU at these LDS sizes, one wave per SIMD.
+template <int NRB, int NMAT, bool B16 = false>
 __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop_kernel(const dss2_gemm_prop_args p) {
   constexpr int TM = NRB * 32;
   constexpr int PF = 8;    // float4 registers per thread for the batched X staging (64 x 128 floats / 256 threads)
@@ -315,6 +319,50 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
             lds_barrier();
             }
           }
+          if constexpr (B16) {
+            // 16 k per step; the B fragments (three planes, L2) one step ahead; A read as fp32 and split in registers
+            const bf16x8* __restrict__ bp16 = reinterpret_cast<const bf16x8*>(p.Bp);
+            const int nks = p.kpad >> 4, nsh = nkh >> 1, sb = kb >> 1;      // k16 steps: per matrix, in this half, first of this half
+            const float* xa16 = Xs + c32 * LDX + half * 8;
+            bf16x8 bq0[3], bq1[3];
+            auto load_b16 = [&](bf16x8 (&b)[3], int s) {
+              const int sc = s < nsh ? s : nsh - 1;
+#pragma unroll
+              for (int pl = 0; pl < 3; ++pl) b[pl] = bp16[(((size_t)(m * p.ncg + cg) * nks + sb + sc) * 3 + pl) * 64 + lane];
+            };
+            auto step16 = [&](const bf16x8 (&b)[3], int s) {
+#pragma unroll
+              for (int rb = 0; rb < NRB; ++rb) {
+                const float* src = xa16 + rb * 32 * LDX + s * 16;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                uint32_t sh[4], sm[4], sl[4];
+                split3_pair(v0[0], v0[1], sh[0], sm[0], sl[0]);
+                split3_pair(v0[2], v0[3], sh[1], sm[1], sl[1]);
+                split3_pair(v1[0], v1[1], sh[2], sm[2], sl[2]);
+                split3_pair(v1[2], v1[3], sh[3], sm[3], sl[3]);
+                const u32x4 uh = {sh[0], sh[1], sh[2], sh[3]}, um = {sm[0], sm[1], sm[2], sm[3]}, ul = {sl[0], sl[1], sl[2], sl[3]};
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, uh), am = __builtin_bit_cast(bf16x8, um), al = __builtin_bit_cast(bf16x8, ul);
+                f32x16 c = accm[rb];        // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[0], c, 0, 0, 0);
+                accm[rb] = c;
+              }
+            };
+            load_b16(bq0, 0);
+            int s = 0;
+            for (; s + 2 <= nsh; s += 2) {
+              load_b16(bq1, s + 1);
+              step16(bq0, s);
+              load_b16(bq0, s + 2);
+              step16(bq1, s + 1);
+            }
+            if (s < nsh) step16(bq0, s);
+          } else {
           auto sload2 = [&](f32x4 (&a)[NRB], f32x4& b, int kk) {
             const int kc = kk < nkh ? kk : nkh - 1;
 #pragma unroll
@@ -335,6 +383,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
           }
           if (kk < nkh) smma(sa0, sb0);
         }
+          }
         if (m < NMAT - 1) {            // T (in the stage since the end of the previous pass) <- accm + P T
           if (D > 0) {
             for (int k = 0; k < D; ++k) {
@@ -873,11 +922,20 @@ static size_t lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz, int e
   return lds_bytes_nw(nrb, nmat, kpad, gemm_waves(ncg, nrb, nmat, kpad, max_nnz, ell_width), max_nnz, ell_width);
 }
 
-template <int NRB, int NMAT>
+// bf16x6 variant: the matrix-sequential, K-halved configuration only (every column group its own wave)
+static bool gemm16_shape_ok(int nrb, int nmat, int kreal, int hout, int max_nnz, int ell_width) {
+  const int kpad = (kreal + 15) / 16 * 16, ncg = (hout + 31) / 32;
+  const bool seq = nmat > 1 && nrb * nmat >= 16;
+  return seq && (nrb == 6 || nrb == 4) && ncg <= 4 && (kpad & 31) == 0 && (kreal & 3) == 0 && (hout & 3) == 0 && ell_width > 0 && ell_width <= 32 &&
+         gemm_waves(ncg, nrb, nmat, kpad, max_nnz, ell_width) < ncg &&
+         lds_bytes_nw(nrb, nmat, kpad / 2, ncg, max_nnz, ell_width) <= (size_t)kMaxLdsBytes;
+}
+
+template <int NRB, int NMAT, bool B16 = false>
 static int launch(const dss2_gemm_prop_args& a_in, hipStream_t stream) {
   dss2_gemm_prop_args a = a_in;
   static std::atomic<uint32_t> lds_done{0};
-  auto kern = gemm_prop_kernel<NRB, NMAT>;
+  auto kern = gemm_prop_kernel<NRB, NMAT, B16>;
   if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop")) return 1;
   size_t lds = lds_bytes(NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.ncg, a.max_nnz, a.ell_width);
   int nw = gemm_waves(a.ncg, NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.max_nnz, a.ell_width);
@@ -890,6 +948,9 @@ static int launch(const dss2_gemm_prop_args& a_in, hipStream_t stream) {
     nw = a.ncg;
     lds = lds_bytes_nw(NRB, NMAT, a.kpad / 2, a.ncg, a.max_nnz, a.ell_width);
     a.relu |= 1 << 24;
+  } else if (B16) {
+    set_error("gemm_prop(bf16x6): needs the K-halved matrix-sequential configuration (nrb=%d nmat=%d kpad=%d ncg=%d)", NRB, NMAT, a.kpad, a.ncg);
+    return 2;
   }
   // persistent over tiles: at most two workgroups per CU are co-resident at the LDS sizes of the
   // compute-heavy shapes, so 512 workgroups cover the chip; each walks tiles blockIdx.x, +grid, ...
@@ -901,6 +962,11 @@ static int launch(const dss2_gemm_prop_args& a_in, hipStream_t stream) {
 
 extern "C" size_t dss2_gemm_prop_lds_bytes(int nrb, int nmat, int kpad, int ncg, int max_nnz, int ell_width) {
   return dss2::lds_bytes(nrb, nmat, kpad, ncg, max_nnz, ell_width);
+}
+
+extern "C" int dss2_gemm_prop16_supported(int nrb, int nmat, int kreal, int hout, int max_nnz, int ell_width) {
+  if (!((nrb == 6 && (nmat == 3 || nmat == 4)) || (nrb == 4 && nmat == 4))) return 0;
+  return dss2::gemm16_shape_ok(nrb, nmat, kreal, hout, max_nnz, ell_width) ? 1 : 0;
 }
 
 extern "C" int dss2_pack_weights(const dss2_pack_desc* descs, int n_desc, int max_elems, void* stream) {
@@ -948,6 +1014,19 @@ extern "C" int dss2_gemm_prop(const dss2_gemm_prop_args* ap, void* stream) {
     return 3;
   }
   hipStream_t s = as_stream(stream);
+  if (a.b_format == 1) {
+    if (!gemm16_shape_ok(a.nrb, a.nmat, a.kreal, a.hout, a.max_nnz, a.ell_width) || a.prop_in || a.rowscale || (a.kpad & 15) ||
+        a.kpad != (a.kreal + 15) / 16 * 16 || (a.ldx & 3) || (reinterpret_cast<uintptr_t>(a.X) & 15)) {
+      set_error("gemm_prop(bf16x6): unsupported shape (nrb=%d nmat=%d k=%d kpad=%d hout=%d)", a.nrb, a.nmat, a.kreal, a.kpad, a.hout);
+      return 2;
+    }
+    if (a.nrb == 6 && a.nmat == 3) return launch<6, 3, true>(a, s);
+    if (a.nrb == 6 && a.nmat == 4) return launch<6, 4, true>(a, s);
+    if (a.nrb == 4 && a.nmat == 4) return launch<4, 4, true>(a, s);
+    set_error("gemm_prop(bf16x6): no instantiation for nrb=%d nmat=%d", a.nrb, a.nmat);
+    return 2;
+  }
+  if (a.b_format != 0) { set_error("gemm_prop: unknown b_format %d", a.b_format); return 2; }
 #define DSS2_CASE(NRB, NMAT) \
   if (a.nrb == NRB && a.nmat == NMAT) return launch<NRB, NMAT>(a, s);
   DSS2_CASE(1, 1) DSS2_CASE(1, 2) DSS2_CASE(1, 3) DSS2_CASE(1, 4)

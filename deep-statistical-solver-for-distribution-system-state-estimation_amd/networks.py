@@ -79,8 +79,10 @@ def _ncg(j: int) -> int:
 def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.Tensor, nmat: int, hout: int,
               Y: torch.Tensor, bias=None, rowscale=None, relu_src=None, dmask=None, add_src=None, add_ld=0,
               relu: bool = False, transposed: bool = False, prop_in: int = 0, narrow_h: int = 0,
-              prebias=None, pre_rowscale=None, drop=None) -> None:
-    """drop = (snapshot, p, drop_id): in-kernel dropout mask of layer drop_id (see dropout_snapshot)."""
+              prebias=None, pre_rowscale=None, drop=None, b_format: int = 0) -> None:
+    """drop = (snapshot, p, drop_id): in-kernel dropout mask of layer drop_id (see dropout_snapshot).
+    b_format = 1: Bp holds bf16x3 fragments (_PackPlan.fwd16 / bwd16) and the tile GEMM runs as bf16x6 -- the tall-tile
+    shapes of gemm16_supported only."""
     if topo.global_only and (nmat > 1 or prop_in > 0):
         raise NotImplementedError(f"largest connected component has {topo.max_segment} nodes: the fused GEMM + propagation "
                                   "kernels hold a whole graph in LDS (<= 192 nodes); use the MPN / TAGConv modules, which "
@@ -91,7 +93,8 @@ def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.T
         a.drop_thr, a.drop_scale = _dropout_params(drop[1])
     a.prebias, a.pre_rowscale = _ptr(prebias), _ptr(pre_rowscale)
     a.prop_in, a.narrow_h = prop_in, narrow_h
-    a.X, a.ldx, a.kreal, a.kpad = X.data_ptr(), ldx, kreal, _round8(kreal)
+    a.X, a.ldx, a.kreal, a.kpad = X.data_ptr(), ldx, kreal, (_round16(kreal) if b_format == 1 else _round8(kreal))
+    a.b_format = b_format
     a.Bp, a.bias, a.rowscale = Bp.data_ptr(), _ptr(bias), _ptr(rowscale)
     a.relu_src, a.ld_relu = _ptr(relu_src), (relu_src.stride(0) if relu_src is not None else 0)
     a.dmask, a.ld_dmask = _ptr(dmask), (dmask.stride(0) if dmask is not None else 0)
@@ -122,6 +125,13 @@ def chain16_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> 
     """True when the chain can run its tile GEMM on the bf16 matrix pipe (bf16x6, fp32-accurate; dss2_gemm_chain16.hip)."""
     ell, tiles = (topo.ellT, topo.ellT_tiles) if transposed else (topo.ell, topo.ell_tiles)
     return CHAIN_BF16 and tiles is not None and bool(_lib.lib().dss2_gemm_prop_chain16_supported(topo.nrb, nmat, hid, hid, ell))
+
+
+def gemm16_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bool:
+    """True when a single hid -> hid layer (dss2_gemm_prop) can take bf16x3 weights: the tall tiles (128 / 192 rows) that
+    run matrix-sequentially with K-halved staging and therefore have no layer chain."""
+    ell, tiles, nnz = (topo.ellT, topo.ellT_tiles, topo.max_nnzT) if transposed else (topo.ell, topo.ell_tiles, topo.max_nnz)
+    return CHAIN_BF16 and tiles is not None and bool(_lib.lib().dss2_gemm_prop16_supported(topo.nrb, nmat, hid, hid, nnz, ell))
 
 
 def gemm_prop_chain(topo: Topology, X: torch.Tensor, hid: int, nmat: int, layers: Sequence[dict], transposed: bool = False,
@@ -591,12 +601,12 @@ def _dx_views(W1, hid, fn, fe):
 
 
 def _tagconv_forward(topo, h, pack_fwd, bias, nmat, hin, hout, dmask=None, relu=False, add_src=None, add_ld=0,
-                     prebias=None, pre_rowscale=None, drop=None):
+                     prebias=None, pre_rowscale=None, drop=None, b_format=0):
     out = torch.empty(topo.N, hout, dtype=_F32, device=h.device)
     narrow = is_narrow(nmat, hout) and prebias is None and (drop is None or drop[2] == 0)
     gemm_prop(topo, h, h.stride(0), hin, pack_fwd, nmat, hout, out, bias=bias, dmask=dmask, relu=relu,
               add_src=add_src, add_ld=add_ld, narrow_h=(hout if narrow else 0),
-              prebias=prebias, pre_rowscale=pre_rowscale, drop=drop)
+              prebias=prebias, pre_rowscale=pre_rowscale, drop=drop, b_format=b_format)
     return out
 
 
@@ -725,7 +735,7 @@ def _side_stream(device):
 
 
 def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=None, dmask=None, need_dh=True,
-                      rowscale2=None, defer_wgrad=False, pending=None, drop=None):
+                      rowscale2=None, defer_wgrad=False, pending=None, drop=None, b_format=0):
     """g: gradient w.r.t. the conv's pre-activation output [N, hout] (already masked).
     g_flat <- [dW_0..dW_K, db]; returns dh (masked by relu_src / dmask of the PREVIOUS layer).
     The weight gradient only feeds the flat gradient buffer, so it may run on a side stream beside the
@@ -753,7 +763,7 @@ def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=No
                   transposed=True, prop_in=nmat - 1, drop=drop)
     else:
         gemm_prop(topo, g, g.stride(0), hout, pack_bwd, nmat, hin, dh, relu_src=relu_src, dmask=dmask, transposed=True,
-                  drop=drop)
+                  drop=drop, b_format=b_format)
     return dh
 
 
@@ -1051,7 +1061,8 @@ def _ensure_plans(mod, topo, dev, ps):
     hout0 = mod.dim_out if L == 1 else hid
     glob = topo.global_only       # graphs beyond the LDS-resident tiles: plain GEMMs + propagation hops in global memory
     fold_on = FOLD_W2 and not is_narrow(nmat, hout0) and not glob
-    b16 = tuple(range(1, L)) if (CHAIN_BF16 and not glob and L >= 3 and hid % 4 == 0 and hid <= 256 and not is_narrow(nmat, hid)) else ()
+    b16 = tuple(range(1, L)) if (CHAIN_BF16 and not glob and hid % 4 == 0 and hid <= 256 and not is_narrow(nmat, hid) and L >= 2
+                                 and (L >= 3 or gemm16_supported(topo, nmat, hid, False))) else ()
     if (mod._plan is None or mod._plan.device != dev or (mod._fold is not None) != fold_on or mod._plan.stacked != glob
             or tuple(sorted(mod._plan.fwd16)) != b16):
         offs = mod._flat_offsets()
@@ -1127,10 +1138,11 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
                 acts.append(h)
             continue
         pre = (fold.bf, topo.deg_pows) if (fold is not None and l == 0) else (None, None)
-        h = _tagconv_forward(topo, h, plan.fwd[1 + l], conv_ps[l][0], nmat, hid, hout, relu=not last,
+        g16 = (not last) and (1 + l) in plan.fwd16 and gemm16_supported(topo, nmat, hid, False)      # tall tiles: bf16x6 per layer
+        h = _tagconv_forward(topo, h, (plan.fwd16[1 + l] if g16 else plan.fwd[1 + l]), conv_ps[l][0], nmat, hid, hout, relu=not last,
                              add_src=(x if (last and mod.skip) else None), add_ld=ldx,
                              prebias=pre[0], pre_rowscale=pre[1],
-                             drop=((snap, p, drop_id(l)) if snap is not None else None))
+                             drop=((snap, p, drop_id(l)) if snap is not None else None), b_format=int(g16))
         if not last:
             acts.append(h)
     meta = (ldx, ldea, len(acts), (snap, p, base), fold is not None, glob, ver)
@@ -1219,7 +1231,8 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
             # one small-GEMM launch then writes dW_m, conv0.bias, dW2, db2 into the flat buffer
             wgrad(topo, g, hout, S, hid, nmat, fold.gfold, rowscale2=topo.deg_pows, pending=pending)
             dS = torch.empty(topo.N, hid, dtype=_F32, device=dev)
-            gemm_prop(topo, g, g.stride(0), hout, plan.bwd[1], nmat, hid, dS, transposed=True)
+            g16 = hout == hid and 1 in plan.bwd16 and gemm16_supported(topo, nmat, hid, True)
+            gemm_prop(topo, g, g.stride(0), hout, (plan.bwd16[1] if g16 else plan.bwd[1]), nmat, hid, dS, transposed=True, b_format=int(g16))
             fold_late = True
             g = None
             break
@@ -1232,9 +1245,10 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         defer = WGRAD_BATCH and not WGRAD_SIDE_STREAM and hout == hid and not is_narrow(nmat, hout)
         if defer:
             deferred.append((l, g, acts[l]))
-        g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, hout, seg,
+        g16 = hout == hid and (1 + l) in plan.bwd16 and gemm16_supported(topo, nmat, hid, True)
+        g = _tagconv_backward(topo, g, acts[l], (plan.bwd16[1 + l] if g16 else plan.bwd[1 + l]), nmat, hid, hout, seg,
                               relu_src=(acts[l] if l > 0 else None), drop=(drop_of(l - 1) if l > 0 else None),
-                              defer_wgrad=defer, pending=pending)
+                              defer_wgrad=defer, pending=pending, b_format=int(g16))
     # weight gradients of the hid -> hid layers: independent of each other, so one launch (and one slab
     # reduction) covers up to 8 consecutive layers; their segments in the flat buffer are contiguous
     deferred.reverse()

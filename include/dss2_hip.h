@@ -237,7 +237,8 @@ typedef struct dss2_gemm_prop_args {
    * where drop_id > 0 names the layer whose mask this is (0: no dropout; in a chain: per layer).  Applied where     *
    * `dmask` (an explicit [N, hout] multiplier tensor, still supported) is applied.                                 */
   const uint64_t* drop_state; uint32_t drop_thr; float drop_scale; int32_t drop_id;
-  int32_t b_format;   /* layout of the packed weights: 0 = fp32 fragments; 1 = bf16x3 fragments (dss2_gemm_prop_chain only) */
+  int32_t b_format;   /* layout of the packed weights: 0 = fp32 fragments; 1 = bf16x3 fragments (dss2_gemm_prop_chain, and
+                         dss2_gemm_prop where dss2_gemm_prop16_supported(...) != 0; kpad is then a multiple of 16) */
 } dss2_gemm_prop_args;
 
 int dss2_gemm_prop(const dss2_gemm_prop_args* args_host, void* stream);
@@ -261,6 +262,9 @@ int dss2_gemm_prop_chain_supported(int nrb, int nmat, int kreal, int hout, int e
  * v_mfma_f32_32x32x16_bf16 per fp32 product term set (h/m/l splits of both operands, fp32 accumulation): fp32-accurate
  * results at 12 instead of 32 MFMA cycles per unit of k.  Two-row-block tiles, H <= 128. */
 int dss2_gemm_prop_chain16_supported(int nrb, int nmat, int kreal, int hout, int ell_width);
+/* != 0: dss2_gemm_prop (one layer) accepts args.b_format = 1 for this shape -- the tall tiles (128 / 192 rows) that run
+ * matrix-sequentially with the X tile staged in two K halves; same bf16x6 arithmetic as the chain. */
+int dss2_gemm_prop16_supported(int nrb, int nmat, int kreal, int hout, int max_nnz, int ell_width);
 
 /* ---- dropout random state.  state[2] = persistent device {seed, offset}; snapshot[2] <- the pair this forward call's
  * kernels (forward AND backward) read.  use_host_seed != 0: snapshot = {host_seed, 0} (eager mode: the host draws the seed

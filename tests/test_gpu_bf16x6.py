@@ -131,3 +131,47 @@ def test_layer_chain_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat, nl):
         for r, x, y in zip(ref, a, b_):
             assert torch.equal(x, y)
             assert rel_err(x, r) < 3e-6
+
+
+@pytest.mark.parametrize("grids,B,H,nmat", [
+    (["ober179"], 40, 128, 3),                   # 192-row tiles: matrix-sequential, X staged in two K halves
+    (["ober179"], 9, 96, 3),                     # H = 96: the whole X tile fits beside three wave stages -> no K halves -> fp32 kernel
+    (["ober179"], 12, 128, 4),                   # K = 3
+])
+def test_tall_tile_layer_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat):
+    """dss2_gemm_prop with b_format = 1 (tall tiles have no layer chain): forward form with bias / ReLU / folded bias,
+    data-gradient form with a ReLU gate, against the fp32 MFMA kernel, twice (bitwise reproducible)."""
+    nw = pkg.networks
+    topo, N = _topo(pkg, grids, B)
+    saved16 = nw.CHAIN_BF16
+    nw.CHAIN_BF16 = True
+    try:
+        ok = nw.gemm16_supported(topo, nmat, H, False) and nw.gemm16_supported(topo, nmat, H, True)
+    finally:
+        nw.CHAIN_BF16 = saved16
+    assert topo.nrb == 6
+    if H == 96:
+        assert not ok      # (bf16x6 exists for the K-halved configuration only; the model code then keeps the fp32 weights)
+        return
+    assert ok
+    torch.manual_seed(5)
+    Ws = [torch.randn(H, H, device=DEV) * (1.5 / H ** 0.5) for _ in range(nmat)]
+    plan = nw._PackPlan([Ws], DEV, bf16_groups=(0,))
+    plan.refresh()
+    h, g, act = torch.randn(N, H, device=DEV), torch.randn(N, H, device=DEV), torch.randn(N, H, device=DEV)
+    bias, pbias, prs = torch.randn(H, device=DEV), torch.randn(nmat, H, device=DEV), torch.rand(N, 4, device=DEV)
+
+    def fwd(fmt):
+        out = torch.empty(N, H, device=DEV)
+        nw.gemm_prop(topo, h, H, H, (plan.fwd16[0] if fmt else plan.fwd[0]), nmat, H, out, bias=bias, relu=True, prebias=pbias,
+                     pre_rowscale=prs, b_format=fmt)
+        return out
+
+    def bwd(fmt):
+        out = torch.empty(N, H, device=DEV)
+        nw.gemm_prop(topo, g, H, H, (plan.bwd16[0] if fmt else plan.bwd[0]), nmat, H, out, relu_src=act, transposed=True, b_format=fmt)
+        return out
+    for fn in (fwd, bwd):
+        r, x, y = fn(0), fn(1), fn(1)
+        assert torch.equal(x, y)
+        assert rel_err(x, r) < 3e-6
