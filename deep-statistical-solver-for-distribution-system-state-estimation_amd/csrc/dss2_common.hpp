@@ -74,15 +74,6 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Workgroup barrier for hand-offs through LDS ONLY.  __syncthreads() is a workgroup-scope fence over every address space:
-// "s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier", so each barrier also waits for the wave's outstanding global loads
-// (prefetches in flight on purpose) and for the write acknowledgements of its global stores (rows that no wave of this
-// kernel reads back).  Here only the DS operations are drained.  The compiler's own wait-count insertion still guards
-// every use of a loaded register; the "memory" clobber keeps it from moving LDS accesses across the hand-off.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 constexpr int kMaxLdsBytes = 160 * 1024;
 
 // ---- in-kernel dropout (nn.Dropout between the TAGConv layers, /root/reference/networks.py:268) ---------------------------

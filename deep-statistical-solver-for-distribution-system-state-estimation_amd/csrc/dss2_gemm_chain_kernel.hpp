@@ -119,10 +119,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
   const float* xa = Xs + c32 * LDX + half * 4;
   const int cg = wave / RS, rs = wave - cg * RS;   // column group, and which share of its row blocks
   float* st = RM ? stage + cg * NMAT * (TM * SST) : stage + cg * (32 * LDA);      // per column group [TM][32] row-major (wave-private when RS == 1)
-  // (workgroup barriers of the layer loop drain LDS only: nothing a wave writes to global memory is read back in this kernel)
-  // (K = 3 with a row split keeps the full fence: the LDS-only form costs that instantiation 20 spilled registers)
-  auto wg_barrier = [&]() { if constexpr (RS == 2 && NMAT >= 4) __syncthreads(); else lds_barrier(); };
-  auto stage_sync = [&]() { if (RS == 1) wave_lds_sync(); else wg_barrier(); };
+  auto stage_sync = [&]() { if (RS == 1) wave_lds_sync(); else __syncthreads(); };
   const int ecol0 = cg * 32 + (lane & 7) * 4;
   const int cq = (lane & 7) * 4, r8 = lane >> 3;
   const bool ecol_ok = ecol0 < p.hout;
@@ -243,7 +240,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
     }
     CSTAMP(2 + li * 6 + 0);      // GEMM phase done
     // every wave is done with this layer's X tile: the epilogue below overwrites it in place
-    if (!RM && li + 1 < ct.n) wg_barrier();      // (RM: the barrier after the stage writes below orders the same accesses)
+    if (!RM && li + 1 < ct.n) __syncthreads();      // (RM: the barrier after the stage writes below orders the same accesses)
     CSTAMP(2 + li * 6 + 1);
 
     if constexpr (RM) {
@@ -411,7 +408,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
       }
     }
     CSTAMP(2 + li * 6 + 3);      // epilogue done
-    if (keep) wg_barrier();   // the next layer's X tile is complete
+    if (keep) __syncthreads();   // the next layer's X tile is complete
     CSTAMP(2 + li * 6 + 4);
   }
 }

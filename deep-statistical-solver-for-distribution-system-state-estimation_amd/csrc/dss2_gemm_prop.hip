@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
                 pxh[i] = v;
               }
             };
-            lds_barrier();                              // everyone is done with the previous half
+            __syncthreads();                              // everyone is done with the previous half
             if (pre_ok) {
               if (m == NMAT - 1 && hf == 0) load_half(0);
 #pragma unroll
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
                 const int r = idx / kh4, c = (idx - r * kh4) << 2;
                 if (idx < TM * kh4) *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = pxh[i];
               }
-              lds_barrier();
+              __syncthreads();
               if (!(m == 0 && hf == 1)) load_half(1 - hf);
             } else {
             for (int base = 0; base < TM * kh4; base += PF * nthreads) {
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
                 if (idx < TM * kh4) *reinterpret_cast<f32x4*>(Xs + r * LDX + c) = px[i];
               }
             }
-            lds_barrier();
+            __syncthreads();
             }
           }
           if constexpr (B16) {

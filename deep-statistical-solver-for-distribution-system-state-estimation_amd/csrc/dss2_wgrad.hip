@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
         for (int k = tid; k < nnz; k += NT) lent[k] = make_int2(p.colT[base + k] - ts, __float_as_int(p.wT[base + k]));
       }
     }
-    lds_barrier();
+    __syncthreads();
     WSTAMP(1);
     const int next = tile + gridDim.x;
     // Next tile's slabs -> registers.  Issuing a wave's sixteen 16-byte loads blocks it for 2-5 K cycles (the CU's
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
           }
           Za[row * LDZ + m * h + j] = sacc;
         }
-        lds_barrier();
+        __syncthreads();
       }
     }
     // ---- m = 0 .. NMAT-1, ping-pong propagation
@@ -387,10 +387,10 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
       if (NW == 4 && !fast_bias) bias_sums(ts, R);
       WSTAMP(3);
       prop(Za, Zb);
-      lds_barrier();
+      __syncthreads();
       WSTAMP(4);
       prop(Zb, Zc);
-      lds_barrier();
+      __syncthreads();
       WSTAMP(5);
       if (obh == 0 && next < p.ntiles) issue_loads(next);
       mma(Za, acc[0], R);
@@ -402,21 +402,21 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     } else {
     phase(Za, Zb, acc[0], R, NMAT > 1, true, ts, 3);
     if (NMAT > 1) {
-      lds_barrier();
+      __syncthreads();
       WSTAMP(6);
       phase(Zb, Za, acc[1 % NMAT], R, NMAT > 2, false, ts, 7);
     }
     if (NMAT > 2) {
-      lds_barrier();
+      __syncthreads();
       WSTAMP(10);
       phase(Za, Zb, acc[2 % NMAT], R, NMAT > 3, false, ts, 11);
     }
     if (NMAT > 3) {
-      lds_barrier();
+      __syncthreads();
       phase(Zb, Za, acc[3 % NMAT], R, false, false, ts, 11);
     }
     }
-    lds_barrier();
+    __syncthreads();
     WSTAMP(14);
   }
 

@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(W16_NT) wgrad16_kernel(const dss2_wgrad_args p
           }
         }
       }
-      lds_barrier();
+      __syncthreads();
       const bool last_pass = ps == NP - 1;      // (a pass beyond hout stages zeros and stores nothing)
       if (!last_pass) load_g(tile, ps + 1);
       else if (next < p.ntiles) load_x(next);
@@ -197,10 +197,10 @@ __global__ void __launch_bounds__(W16_NT) wgrad16_kernel(const dss2_wgrad_args p
       if (NMAT > 1) {
         prop(Zf0, NMAT > 2 ? Zf1 : nullptr, ZT + 3 * ZC * 128);
         if (NMAT > 2) {
-          lds_barrier();
+          __syncthreads();
           prop(Zf1, nullptr, ZT + 2 * 3 * ZC * 128);
         }
-        lds_barrier();
+        __syncthreads();
       }
       // ---- MFMA phase: 4 steps of 16 rows, six bf16 MFMAs per matrix and step, operands straight from the planes
       if (in_active && gcol0 + ps * ZC + obh * 32 < p.hout) {
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(W16_NT) wgrad16_kernel(const dss2_wgrad_args p
         }
       }
       if (last_pass && next < p.ntiles) load_g(next, 0);
-      lds_barrier();          // the Z planes and fp32 slabs are free for the next pass / tile
+      __syncthreads();          // the Z planes and fp32 slabs are free for the next pass / tile
     }
   }
 
