@@ -39,6 +39,13 @@ __device__ unsigned long long g_wstamps[512 * 8 * 16];
 // propagate-first schedule (three G slabs in LDS): K = 2 on tiles of at most 64 rows
 constexpr bool wgrad_pf(int nrb, int nmat) { return nmat == 3 && nrb <= 2; }
 
+// grouped operand reads in the MFMA loop (see mma): where the register budget has room
+// (the four excluded instantiations sit at the 256-register limit already and would spill 1-12 registers)
+constexpr bool wgrad_fast_mma(int nrb, int nmat, int nb) {
+  return !((nrb == 2 && nmat == 3 && nb == 4) || (nrb == 3 && nmat == 2 && nb == 2) || (nrb == 4 && nmat == 4 && nb == 2) ||
+           (nrb == 4 && nmat == 1 && nb == 4));
+}
+
 template <int NB> struct WgradGeom {
   static constexpr int NW = NB >= 2 ? 8 : 4;
   static constexpr int NT = NW * 64;
@@ -117,6 +124,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   const bool fast_bias = gvec && !p.rowscale && !rs2 && ibg == 0 && (NT % (LDZ / 4) == 0);
   if (fast_bias) Bsum[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  constexpr bool FASTMMA = wgrad_fast_mma(NRB, NMAT, NB);
   auto mma = [&](const float* Z, f32x16 (&a)[NBW], int R) {
     if (!wave_active) return;
     const int n2a = (R + 1) >> 1;
@@ -137,8 +145,54 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
 #pragma unroll
       for (int ob = 0; ob < NBW; ++ob) a[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ob], b, a[ob], 0, 0, 0);
     };
-    ld(b0, a0, 0);
     int n2 = 0;
+    if constexpr (FASTMMA) {
+      // Groups of four k steps with compile-time strides (no K split, full-width X slab): the operand reads take
+      // immediate offsets, so a step is 2 ds_read_b32 + 1 MFMA instead of ~14 instructions of address arithmetic,
+      // clamping and waits -- one wave per SIMD issues ~4 cycles per instruction and the rolled loop ran at ~120
+      // cycles per 64-cycle MFMA (tools/wstamps.py ober179: 11.5 K cycles for the 96 MFMAs of a phase).
+      if (KS == 1 && xw == XW) {
+        constexpr int U = 4;
+        const float* zq = Z + half * LDZ + obh * NBW * 32 + c32;
+        const float* xq = Xs + half * XW + ibw * 32 + c32;
+        float bq[2][U], aq[2][U][NBW];
+        auto ldg = [&](float (&b)[U], float (&av)[U][NBW], int g) {
+          const float* zg = zq + g * (U * 2 * LDZ);
+          const float* xg = xq + g * (U * 2 * XW);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            b[u] = xg[u * 2 * XW];
+#pragma unroll
+            for (int ob = 0; ob < NBW; ++ob) av[u][ob] = zg[u * 2 * LDZ + ob * 32];
+          }
+        };
+        auto mmg = [&](const float (&b)[U], const float (&av)[U][NBW]) {
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ob = 0; ob < NBW; ++ob) a[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][ob], b[u], a[ob], 0, 0, 0);
+        };
+        const int ng = n2e / U;
+        if (ng > 0) {
+          ldg(bq[0], aq[0], 0);
+          int g = 0;
+          for (; g + 2 <= ng; g += 2) {
+            ldg(bq[1], aq[1], g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mmg(bq[0], aq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < ng) ldg(bq[0], aq[0], g + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mmg(bq[1], aq[1]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (g < ng) mmg(bq[0], aq[0]);
+        }
+        n2 = ng * U;
+        if (n2 >= n2e) return;
+      }
+    }
+    ld(b0, a0, n2);
     for (; n2 + 2 <= n2e; n2 += 2) {
       ld(b1, a1, n2 + 1);
       __builtin_amdgcn_sched_barrier(0);

@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 pkg = importlib.import_module("deep-statistical-solver-for-distribution-system-state-estimation_amd")
 nw = pkg.networks
 dev = torch.device("cuda:0"); H, nmat = 128, 3
-b = pkg.synthetic.make_batch(["cigre14"], 4096, seed=0)
+GRID = sys.argv[1] if len(sys.argv) > 1 else "cigre14"; NB_ = int(sys.argv[2]) if len(sys.argv) > 2 else 4096      # argv: grid, graphs
+b = pkg.synthetic.make_batch([GRID], NB_, seed=0)
 ei = b["edge_index"].to(dev); N = b["x"].shape[0]
 topo = pkg.topology.get_topology(ei, N)
 h = torch.randn(N, H, device=dev); g = torch.randn(N, H, device=dev); flat = torch.empty(nmat * H * H + H, device=dev)
@@ -31,6 +32,16 @@ if os.environ.get("WSTAMP_PF", "1") == "1":     # propagate-first schedule (NMAT
     show("MFMA over the three slabs", t[:, :, 6] - t[:, :, 5])
     show("closing barrier", t[:, :, 14] - t[:, :, 6])
     show("tile total", t[:, :, 14] - t[:, :, 0])
+    sys.exit(0)
+if topo.nrb >= 4:      # tall tiles: the 4-wave kernel (NB = 1): every wave runs MFMA -> bias sums -> propagation per phase
+    for ph, s0 in (("phase 0", 3), ("phase 1", 7), ("phase 2", 11)):
+        start = t[:, :4, 2] if s0 == 3 else t[:, :4, s0 - 1]
+        show(f"{ph}: MFMA", h0[:, :, s0] - start)
+        show(f"{ph}: bias sums", h0[:, :, s0 + 1] - h0[:, :, s0])
+        show(f"{ph}: propagation", h0[:, :, s0 + 2] - h0[:, :, s0 + 1])
+        end = h0[:, :, 6] if s0 == 3 else (h0[:, :, 10] if s0 == 7 else h0[:, :, 14])
+        show(f"{ph}: closing barrier", end - h0[:, :, s0 + 2])
+    show("tile total", h0[:, :, 14] - h0[:, :, 0])
     sys.exit(0)
 for ph, s0 in (("phase 0", 3), ("phase 1", 7), ("phase 2", 11)):
     start = t[:, :, 2] if s0 == 3 else t[:, :, s0 - 1]
