@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
       // clamping and waits -- one wave per SIMD issues ~4 cycles per instruction and the rolled loop ran at ~120
       // cycles per 64-cycle MFMA (tools/wstamps.py ober179: 11.5 K cycles for the 96 MFMAs of a phase).
       if (KS == 1 && xw == XW) {
-        constexpr int U = 4;
+        constexpr int U = (NB == 1 && NRB >= 4) ? 8 : 4;      // (tall tiles: one wave per SIMD, registers to spare)
         const float* zq = Z + half * LDZ + obh * NBW * 32 + c32;
         const float* xq = Xs + half * XW + ibw * 32 + c32;
         float bq[2][U], aq[2][U][NBW];
@@ -219,7 +219,8 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
       // rows in flight per thread: with PF the next-tile prefetch registers are not live during the propagation,
       // so all of a thread's rows go at once and the ELL entries of hop k+1 are requested before hop k's data
       // (the entry -> data -> fma chain is latency-bound); otherwise two rows (the accumulators own the budget)
-      constexpr int CH = PF ? NI : ((NI % 2 == 0) ? 2 : 1);
+      // (tall tiles on the 4-wave kernel run one wave per SIMD: the register file has room for all rows at once there too)
+      constexpr int CH = (PF || (NB == 1 && NRB >= 6)) ? NI : ((NI % 2 == 0) ? 2 : 1);
       for (int i0 = 0; i0 < NI; i0 += CH) {
         f32x4 s[CH];
         int2 en[CH], en_next[CH];
