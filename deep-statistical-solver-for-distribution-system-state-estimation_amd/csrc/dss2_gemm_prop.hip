@@ -554,7 +554,46 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       // 16 B per lane: 8 lanes cover the 32 columns of a row, 8 rows (8 x 128 B) per wave instruction
       const int cq = (lane & 7) * 4, r8 = lane >> 3;
       const int col0 = cg * 32 + cq;
-      if (col0 < p.hout) {
+      // Tall tiles, common case (no folded bias, mask tensor, residual, row scale or in-kernel dropout): the uniform flags
+      // tested once, the LDS / gate reads of 4 rows per lane issued before the first use.  One wave per SIMD issues an
+      // instruction every ~4 cycles, and the general loop below spends most of them on flag tests and short waits (the
+      // epilogue is 64 of this kernel's 299 us at the 179-bus shape, tools/ablate.py).
+      const bool simple = SEQ && !p.prebias && !p.dmask && !p.add_src && !p.drop_id && !p.rowscale;
+      if (col0 < p.hout && simple) {
+        const bool has_rs = p.relu_src != nullptr, has_bias = p.bias != nullptr, do_relu = (p.relu & 1) != 0;
+        constexpr int NP4 = 2;      // passes of 16 rows per batch (four spill 13 registers in the 192-row instantiations)
+#pragma unroll 1
+        for (int rowb = r8; rowb < R; rowb += 16 * NP4) {
+          f32x4 y[NP4][2], gate[NP4][2];
+#pragma unroll
+          for (int it = 0; it < NP4; ++it)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int row = rowb + 16 * it + 8 * u;
+              const int rr = row < R ? row : 0;
+              y[it][u] = *reinterpret_cast<const f32x4*>(st + rr * 32 + cq);
+              if (has_rs) gate[it][u] = *reinterpret_cast<const f32x4*>(p.relu_src + (size_t)(ts + rr) * p.ld_relu + col0);
+            }
+#pragma unroll
+          for (int it = 0; it < NP4; ++it)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int row = rowb + 16 * it + 8 * u;
+              if (row >= R) continue;
+              f32x4 v = y[it][u];
+              if (has_bias) v += bias4;
+              if (do_relu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+              }
+              if (has_rs) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = gate[it][u][q] > 0.f ? v[q] : 0.f;
+              }
+              *reinterpret_cast<f32x4*>(p.Y + (size_t)(ts + row) * p.ldy + col0) = v;
+            }
+        }
+      } else if (col0 < p.hout) {
         // rows r8, r8+8, ...: operands of 2 rows are requested together, then finished and stored
         for (int row0 = r8; row0 < R; row0 += 16) {
           f32x4 y[2], rs[2], dm[2], ad[2], ps[2];
