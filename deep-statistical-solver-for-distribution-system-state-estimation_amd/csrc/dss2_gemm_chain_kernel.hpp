@@ -331,7 +331,10 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
     // uniform flags tested once.  (The general loop below re-tests seven uniform flags per 16 rows through short basic
     // blocks and waits for its reads one pair at a time: 6.4 K of a layer's 29 K cycles, tools/cstamps.py.)
     // (only where a wave owns at most two row blocks: with more, the batch's 32 registers push the tall-tile instantiations into spills)
-    const bool simple = NRW <= 2 && !L.prebias && !L.dmask && !L.add_src && !L.drop_id;
+    // (instantiations with one wave per SIMD have the register file to themselves: the fast path also serves their three or
+    //  four row blocks -- the 96-row tiles of C3 -- ; at two waves per SIMD it is limited to two row blocks)
+    constexpr bool SIMPLE_OK = NRW <= 2 || (NW == 4 && chain_waves_per_simd(NRW, NMAT) == 1);
+    const bool simple = SIMPLE_OK && !L.prebias && !L.dmask && !L.add_src && !L.drop_id;
     if (col0 < p.hout && simple) {
       constexpr int NIT = NRW * 2;      // 16 rows per pass of the wave's 64 lanes; two passes per batch
       const bool has_rs = L.relu_src != nullptr, has_bias = L.bias != nullptr, do_relu = (L.relu & 1) != 0;
