@@ -111,8 +111,14 @@ constexpr int gemm_waves_per_simd(int nrb, int nmat) {
 // fragments (dss2_pack_weights, transpose | 2), the wave's A fragments (8 consecutive k of its rows, fp32 in LDS) split into
 // three bf16 pieces in registers, six v_mfma_f32_32x32x16_bf16 per 16 k and row block, smallest terms first (the layer
 // chain's scheme, dss2_gemm_chain_kernel.hpp).  One workgroup per CU at these LDS sizes, one wave per SIMD.
-template <int NRB, int NMAT, bool B16 = false>
-__global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop_kernel(const dss2_gemm_prop_args p) {
+// RSP (bf16x6 tall tiles only): row split -- RSP waves share a column group, each owning NRB / RSP of the tile's row blocks (its
+// accumulators, its rows of the group's stage and of the epilogue); the Horner gather reads the other wave's rows, so the
+// stage hand-offs become workgroup barriers.  Two waves per SIMD instead of one: the VALU-issue-bound phases (A split,
+// Horner, epilogue, staging) of one wave run beside the MFMAs of the other.
+template <int NRB, int NMAT, bool B16 = false, int RSP = 1>
+__global__ void __launch_bounds__(256 * RSP, RSP > 1 ? 2 : gemm_waves_per_simd(NRB, NMAT)) gemm_prop_kernel(const dss2_gemm_prop_args p) {
+  static_assert(RSP == 1 || (B16 && NRB % RSP == 0), "row split: bf16x6 tall tiles only");
+  constexpr int NRW = NRB / RSP;      // row blocks per wave
   constexpr int TM = NRB * 32;
   constexpr int PF = 8;    // float4 registers per thread for the batched X staging (64 x 128 floats / 256 threads)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -136,8 +142,8 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   // graph slice of the tile: ELL [D][TM] {local src, weight} when the batch's max degree D is small
   // (fixed trip count => independent LDS chains), else CSR (local row pointers + entries)
   const int D = p.ell_width;
-  int2* ell = reinterpret_cast<int2*>(stage + nw * 32 * (TM + 4));
-  int* lrow = reinterpret_cast<int*>(stage + nw * 32 * (TM + 4));
+  int2* ell = reinterpret_cast<int2*>(stage + (nw / RSP) * 32 * (TM + 4));
+  int* lrow = reinterpret_cast<int*>(stage + (nw / RSP) * 32 * (TM + 4));
   int2* lent = reinterpret_cast<int2*>(lrow + TM + 2);
   const bool need_graph = NMAT > 1 || p.prop_in > 0;
   constexpr int LDA = TM + 4;
@@ -237,9 +243,12 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
   const int nkk = p.kpad >> 3;
   const f32x4* __restrict__ bp = reinterpret_cast<const f32x4*>(p.Bp);
   const float* xa = Xs + c32 * LDX + half * 4;
-  float* st = stage + wave * (32 * LDA);   // wave-private: [TM][32] row-major, or [32][TM+4] transposed
+  const int cgw = wave / RSP, rb0 = (wave - cgw * RSP) * NRW;      // column group of this wave; its first row block
+  float* st = stage + cgw * (32 * LDA);   // wave-private (RSP > 1: shared by the group's waves): [TM][32] row-major, or [32][TM+4] transposed
+  auto stage_sync = [&]() { if (RSP == 1) wave_lds_sync(); else __syncthreads(); };
+  const int rlo = rb0 * 32, rhi = min(R, (rb0 + NRW) * 32);      // this wave's rows in the epilogue
 
-  for (int cg = wave; cg < p.ncg; cg += nw) {
+  for (int cg = cgw; cg < p.ncg; cg += nw / RSP) {
     // epilogue constants requested now so that their latency hides under the MFMA loop
     const int ecol0 = cg * 32 + (lane & 7) * 4;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -251,13 +260,13 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       //   T <- X B_{K};   T <- X B_m + P T  (m = K-1 .. 0)
       // with T parked in the wave's LDS stage during the MFMA pass of the next matrix (the gather needs it there
       // anyway).  Same MFMA count; the X tile is read NMAT times from LDS instead of once.
-      constexpr int NPH = NRB * 2;      // 16-byte pieces per thread of one half of the X tile (256 threads, kpad <= 128)
+      constexpr int NPH = NRB * 2 / RSP;      // 16-byte pieces per thread of one half of the X tile (256 RSP threads, kpad <= 128)
       f32x4 pxh[NPH];
       // one pass (matrix m) as a function of its accumulator: the last pass (m = 0) is peeled off the loop and accumulates
       // straight into T -- a T assigned on the last trip of a rolled loop holds its 16 NRB registers through every trip
       auto seq_pass = [&](const int m, f32x16 (&accm)[NRB]) {
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
+        for (int rb = 0; rb < NRW; ++rb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) accm[rb][r] = 0.f;
         f32x4 sa0[NRB] = {}, sa1[NRB] = {}, sb0 = {}, sb1 = {};
@@ -274,7 +283,8 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
             const int kh4 = p.kpad >> 3;                // 16-byte pieces per row in a half
             // the OTHER half's pieces were requested right after the previous staging (register prefetch under the MFMA
             // pass): only the very first staging of a tile pays its memory latency in the open
-            const bool pre_ok = TM * kh4 <= NPH * nthreads;
+            // (not with a row split: the 24 prefetch registers spill at two waves per SIMD, and the other wave of the SIMD covers the latency)
+            const bool pre_ok = RSP == 1 && TM * kh4 <= NPH * nthreads;
             auto load_half = [&](int h) {
 #pragma unroll
               for (int i = 0; i < NPH; ++i) {
@@ -332,8 +342,8 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
             };
             auto step16 = [&](const bf16x8 (&b)[3], int s) {
 #pragma unroll
-              for (int rb = 0; rb < NRB; ++rb) {
-                const float* src = xa16 + rb * 32 * LDX + s * 16;
+              for (int rb = 0; rb < NRW; ++rb) {
+                const float* src = xa16 + (rb0 + rb) * 32 * LDX + s * 16;
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 uint32_t sh[4], sm[4], sl[4];
@@ -389,10 +399,10 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
             for (int k = 0; k < D; ++k) {
               const int2* ek = ell + k * TM + 4 * half;
 #pragma unroll
-              for (int rb = 0; rb < NRB; ++rb) {
+              for (int rb = 0; rb < NRW; ++rb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                  const int2 en = ek[rb * 32 + acc_row(r, 0)];
+                  const int2 en = ek[(rb0 + rb) * 32 + acc_row(r, 0)];
                   accm[rb][r] = fmaf(__int_as_float(en.y), st[en.x * 32 + c32], accm[rb][r]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -400,10 +410,10 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
             }
           } else {
 #pragma unroll
-            for (int rb = 0; rb < NRB; ++rb)
+            for (int rb = 0; rb < NRW; ++rb)
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
-                const int row = rb * 32 + acc_row(r, half);
+                const int row = (rb0 + rb) * 32 + acc_row(r, half);
                 float s = accm[rb][r];
                 const int e1 = lrow[row + 1];
                 for (int e = lrow[row]; e < e1; ++e) {
@@ -420,12 +430,12 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
         f32x16 accm[NRB];
         seq_pass(m, accm);
         // park T in the stage for the next pass
-        wave_lds_sync();
+        stage_sync();
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
+        for (int rb = 0; rb < NRW; ++rb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = accm[rb][r];
-        wave_lds_sync();
+          for (int r = 0; r < 16; ++r) st[((rb0 + rb) * 32 + acc_row(r, half)) * 32 + c32] = accm[rb][r];
+        stage_sync();
       }
       seq_pass(0, T);
     } else {
@@ -539,12 +549,12 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
 #pragma unroll
       for (int m = 0; m < NMAT; ++m) pb4[m] = *reinterpret_cast<const f32x4*>(p.prebias + (size_t)m * p.hout + ecol0);
     }
-    wave_lds_sync();
+    stage_sync();      // (RSP > 1: the group's other wave is done gathering from the stage)
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
+    for (int rb = 0; rb < NRW; ++rb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[(rb * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
-    wave_lds_sync();
+      for (int r = 0; r < 16; ++r) st[((rb0 + rb) * 32 + acc_row(r, half)) * 32 + c32] = T[rb][r];
+    wave_lds_sync();      // the row loops below read only the rows this wave wrote itself
     const bool vec_epi = ((p.hout & 3) == 0) && ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.Y) & 15) == 0) &&
                          (!p.relu_src || (((p.ld_relu & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.relu_src) & 15) == 0))) &&
                          (!p.dmask || (((p.ld_dmask & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.dmask) & 15) == 0))) &&
@@ -563,14 +573,14 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
         const bool has_rs = p.relu_src != nullptr, has_bias = p.bias != nullptr, do_relu = (p.relu & 1) != 0;
         constexpr int NP4 = 2;      // passes of 16 rows per batch (four spill 13 registers in the 192-row instantiations)
 #pragma unroll 1
-        for (int rowb = r8; rowb < R; rowb += 16 * NP4) {
+        for (int rowb = rlo + r8; rowb < rhi; rowb += 16 * NP4) {
           f32x4 y[NP4][2], gate[NP4][2];
 #pragma unroll
           for (int it = 0; it < NP4; ++it)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
               const int row = rowb + 16 * it + 8 * u;
-              const int rr = row < R ? row : 0;
+              const int rr = row < rhi ? row : rlo;
               y[it][u] = *reinterpret_cast<const f32x4*>(st + rr * 32 + cq);
               if (has_rs) gate[it][u] = *reinterpret_cast<const f32x4*>(p.relu_src + (size_t)(ts + rr) * p.ld_relu + col0);
             }
@@ -579,7 +589,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
               const int row = rowb + 16 * it + 8 * u;
-              if (row >= R) continue;
+              if (row >= rhi) continue;
               f32x4 v = y[it][u];
               if (has_bias) v += bias4;
               if (do_relu) {
@@ -595,15 +605,15 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
         }
       } else if (col0 < p.hout) {
         // rows r8, r8+8, ...: operands of 2 rows are requested together, then finished and stored
-        for (int row0 = r8; row0 < R; row0 += 16) {
+        for (int row0 = rlo + r8; row0 < rhi; row0 += 16) {
           f32x4 y[2], rs[2], dm[2], ad[2], ps[2];
           float rsc[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int row = row0 + 8 * u;
-            const bool ok = row < R;
-            const size_t grow = (size_t)(ts + (ok ? row : 0));
-            y[u] = *reinterpret_cast<const f32x4*>(st + (ok ? row : 0) * 32 + cq);
+            const bool ok = row < rhi;
+            const size_t grow = (size_t)(ts + (ok ? row : rlo));
+            y[u] = *reinterpret_cast<const f32x4*>(st + (ok ? row : rlo) * 32 + cq);
             if (p.rowscale) rsc[u] = p.rowscale[grow];
             if (p.prebias) ps[u] = *reinterpret_cast<const f32x4*>(p.pre_rowscale + grow * 4);
             if (p.dmask) dm[u] = *reinterpret_cast<const f32x4*>(p.dmask + grow * p.ld_dmask + col0);
@@ -613,7 +623,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int row = row0 + 8 * u;
-            if (row >= R) continue;
+            if (row >= rhi) continue;
             f32x4 v = y[u];
             if (p.bias) v += p.rowscale ? bias4 * rsc[u] : bias4;
             if (p.prebias) {
@@ -639,7 +649,7 @@ __global__ void __launch_bounds__(256, gemm_waves_per_simd(NRB, NMAT)) gemm_prop
       const int colg = cg * 32 + c32;
       if (colg < p.hout) {
         const float bias = p.bias ? p.bias[colg] : 0.f;
-        for (int row = half; row < R; row += 2) {
+        for (int row = rlo + half; row < rhi; row += 2) {
           const size_t grow = (size_t)(ts + row);
           float y = st[row * 32 + c32];
           if (p.bias) y += p.rowscale ? bias * p.rowscale[grow] : bias;
@@ -970,11 +980,11 @@ static bool gemm16_shape_ok(int nrb, int nmat, int kreal, int hout, int max_nnz,
          lds_bytes_nw(nrb, nmat, kpad / 2, ncg, max_nnz, ell_width) <= (size_t)kMaxLdsBytes;
 }
 
-template <int NRB, int NMAT, bool B16 = false>
+template <int NRB, int NMAT, bool B16 = false, int RSP = 1>
 static int launch(const dss2_gemm_prop_args& a_in, hipStream_t stream) {
   dss2_gemm_prop_args a = a_in;
   static std::atomic<uint32_t> lds_done{0};
-  auto kern = gemm_prop_kernel<NRB, NMAT, B16>;
+  auto kern = gemm_prop_kernel<NRB, NMAT, B16, RSP>;
   if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop")) return 1;
   size_t lds = lds_bytes(NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.ncg, a.max_nnz, a.ell_width);
   int nw = gemm_waves(a.ncg, NRB, a.prop_in > 0 ? 2 : NMAT, a.kpad, a.max_nnz, a.ell_width);
@@ -993,7 +1003,7 @@ static int launch(const dss2_gemm_prop_args& a_in, hipStream_t stream) {
   }
   // persistent over tiles: at most two workgroups per CU are co-resident at the LDS sizes of the
   // compute-heavy shapes, so 512 workgroups cover the chip; each walks tiles blockIdx.x, +grid, ...
-  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * nw), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * nw * RSP), lds, stream, a);
   return check_launch("gemm_prop");
 }
 
@@ -1059,9 +1069,10 @@ extern "C" int dss2_gemm_prop(const dss2_gemm_prop_args* ap, void* stream) {
       set_error("gemm_prop(bf16x6): unsupported shape (nrb=%d nmat=%d k=%d kpad=%d hout=%d)", a.nrb, a.nmat, a.kreal, a.kpad, a.hout);
       return 2;
     }
-    if (a.nrb == 6 && a.nmat == 3) return launch<6, 3, true>(a, s);
-    if (a.nrb == 6 && a.nmat == 4) return launch<6, 4, true>(a, s);
-    if (a.nrb == 4 && a.nmat == 4) return launch<4, 4, true>(a, s);
+    static const int rs_env = [] { const char* e = getenv("DSS2_GEMM_RS"); return e ? atoi(e) : 2; }();
+    if (a.nrb == 6 && a.nmat == 3) return rs_env == 2 ? launch<6, 3, true, 2>(a, s) : launch<6, 3, true>(a, s);
+    if (a.nrb == 6 && a.nmat == 4) return rs_env == 2 ? launch<6, 4, true, 2>(a, s) : launch<6, 4, true>(a, s);
+    if (a.nrb == 4 && a.nmat == 4) return rs_env == 2 ? launch<4, 4, true, 2>(a, s) : launch<4, 4, true>(a, s);
     set_error("gemm_prop(bf16x6): no instantiation for nrb=%d nmat=%d", a.nrb, a.nmat);
     return 2;
   }

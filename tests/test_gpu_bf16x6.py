@@ -137,6 +137,7 @@ def test_layer_chain_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat, nl):
     (["ober179"], 40, 128, 3),                   # 192-row tiles: matrix-sequential, X staged in two K halves
     (["ober179"], 9, 96, 3),                     # H = 96: the whole X tile fits beside three wave stages -> no K halves -> fp32 kernel
     (["ober179"], 12, 128, 4),                   # K = 3
+    (["ober179"], 700, 128, 3),                  # every CU busy, several rounds of workgroups (two waves per SIMD: row split)
 ])
 def test_tall_tile_layer_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat):
     """dss2_gemm_prop with b_format = 1 (tall tiles have no layer chain): forward form with bias / ReLU / folded bias,
