@@ -7,6 +7,8 @@
 // v_fmac_f32 (or one workgroup per CU, or the fp32 MFMA instantiation) is bitwise reproducible and matches the fp32 path
 // to 5e-7 (tools/accuracy_bf16x6.py; DESIGN.md section 4.1a has the bisection).  Plain VALU ops are also the cheaper
 // fillers beside MFMAs (MI355X_MICROARCH.md).
+#include <stdlib.h>
+
 #include "dss2_gemm_chain_kernel.hpp"
 
 namespace dss2 {
@@ -20,6 +22,10 @@ int launch_chain16(const dss2_gemm_prop_args& a, const ChainTable& ct, int rspli
     return 2 * a.ncg <= 4 ? launch_chain<NRB, NMAT, 4, 2, true>(a, ct, s) : launch_chain<NRB, NMAT, 8, 2, true>(a, ct, s);
   DSS2_CASE16(1, 2) DSS2_CASE16(1, 3) DSS2_CASE16(1, 4) DSS2_CASE16(2, 2) DSS2_CASE16(2, 3)
   DSS2_CASE16(3, 2) DSS2_CASE16(4, 2)
+  // 96-row tiles: three waves per column group (one row block each, twelve waves = three per SIMD) instead of one wave per SIMD
+  // with three row blocks -- the VALU-issue-bound phases of a wave run beside the other waves' MFMAs (DSS2_CHAIN_RS3=0: four waves)
+  static const int rs3 = [] { const char* e = getenv("DSS2_CHAIN_RS3"); return e ? atoi(e) : 1; }();
+  if (a.nrb == 3 && a.nmat == 3 && rsplit == 1 && a.ncg <= 4 && rs3) return launch_chain<3, 3, 12, 3, true>(a, ct, s);
   if (a.nrb == 3 && a.nmat == 3 && rsplit == 1 && a.ncg <= 4) return launch_chain<3, 3, 4, 1, true>(a, ct, s);   // (8 waves would spill)
   DSS2_CASE16_2(2, 2) DSS2_CASE16_2(2, 3) DSS2_CASE16_2(2, 4) DSS2_CASE16_2(4, 2)
 #undef DSS2_CASE16

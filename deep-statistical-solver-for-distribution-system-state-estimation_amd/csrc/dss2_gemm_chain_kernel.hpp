@@ -49,7 +49,7 @@ constexpr int CHAIN_RM_STRIDE = 36;      // floats per stage row in the RM layou
 // -- into the three bf16 pieces in registers (VALU work that issues in the shadow of the MFMAs).  Per 16 k and
 // (row block, matrix): six v_mfma_f32_32x32x16_bf16 = 192 cycles against 512 for eight v_mfma_f32_32x32x2_f32.
 template <int NRB, int NMAT, int NW, int RS, bool B16>
-__global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT)) gemm_chain_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
+__global__ void __launch_bounds__(NW * 64, RS == 3 ? 3 : chain_waves_per_simd(NRB / RS, NMAT)) gemm_chain_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
   static_assert(NRB % RS == 0, "row split must divide the row blocks");
   constexpr int TM = NRB * 32;
   constexpr int NRW = NRB / RS;          // row blocks per wave
@@ -195,6 +195,14 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
         load_b(b0, 0);
       }
       int ks = 0;
+      if constexpr (RS == 3) {
+        // three waves per SIMD (168-register budget): one fragment set, the other waves cover its L2 latency
+        step16(b0, 0);
+        for (ks = 1; ks < nks; ++ks) {
+          load_b(b0, ks);
+          step16(b0, ks);
+        }
+      } else {
       for (; ks + 2 <= nks; ks += 2) {
         load_b(b1, ks + 1);
         step16(b0, ks);
@@ -202,6 +210,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
         step16(b1, ks + 1);
       }
       if (ks < nks) step16(b0, ks);
+      }
       if constexpr (PFB) {
         if (li + 1 < ct.n) load_bp(reinterpret_cast<const bf16x8*>(ct.l[li + 1].Bp), bnext, 0);
       }
@@ -371,10 +380,11 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
           }
       }
     } else if (col0 < p.hout) {
-      for (int row0 = rlo + r8; row0 < rhi; row0 += 16) {
-        f32x4 y[2], rs[2], dm[2], ad[2], ps[2];
+      constexpr int EU = RS == 3 ? 1 : 2;      // rows in flight per lane (three waves per SIMD: the smaller register budget)
+      for (int row0 = rlo + r8; row0 < rhi; row0 += 8 * EU) {
+        f32x4 y[EU], rs[EU], dm[EU], ad[EU], ps[EU];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < EU; ++u) {
           const int row = row0 + 8 * u;
           const bool ok = row < rhi;
           const size_t grow = (size_t)(ts + (ok ? row : rlo));
@@ -385,7 +395,7 @@ __global__ void __launch_bounds__(NW * 64, chain_waves_per_simd(NRB / RS, NMAT))
           if (L.add_src) ad[u] = *reinterpret_cast<const f32x4*>(L.add_src + grow * p.ld_add + col0);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < EU; ++u) {
           const int row = row0 + 8 * u;
           if (row >= rhi) continue;
           f32x4 v = y[u];
