@@ -46,6 +46,11 @@ constexpr bool wgrad_fast_mma(int nrb, int nmat, int nb) {
            (nrb == 4 && nmat == 1 && nb == 4));
 }
 
+// four-entries-at-a-time propagation (see prop): five instantiations have no room for its 24-48 transient registers
+constexpr bool wgrad_prop4(int nrb, int nmat, int nb) {
+  return !((nrb == 2 && nmat == 2 && (nb == 2 || nb == 4)) || (nrb == 3 && nmat == 2 && nb == 2) || (nrb == 4 && (nmat == 3 || nmat == 4) && nb == 2));
+}
+
 template <int NB> struct WgradGeom {
   static constexpr int NW = NB >= 2 ? 8 : 4;
   static constexpr int NT = NW * 64;
@@ -221,6 +226,37 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
       // (the entry -> data -> fma chain is latency-bound); otherwise two rows (the accumulators own the budget)
       // (tall tiles on the 4-wave kernel run one wave per SIMD: the register file has room for all rows at once there too)
       constexpr int CH = (PF || (NB == 1 && NRB >= 6)) ? NI : ((NI % 2 == 0) ? 2 : 1);
+      if constexpr (CH <= 2 && !PF && wgrad_prop4(NRB, NMAT, NB)) {
+        // few rows in flight (the accumulators own the register budget): then four ELL entries of a row are requested
+        // together and their four gathers after them -- two LDS latencies per four neighbours instead of one per neighbour
+        // (tools/wstamps.py ober_sub: the propagation, 3.4-4.0 K cycles, outlasted the other half's 3.1 K of MFMAs)
+        for (int i0 = 0; i0 < NI; i0 += CH) {
+          f32x4 s[CH];
+#pragma unroll
+          for (int i = 0; i < CH; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int k0 = 0; k0 < D; k0 += 4) {
+            int2 en[CH][4];
+            f32x4 z[CH][4];
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const int row = n0 + (i0 + i) * RSTEP;
+                en[i][k] = k0 + k < D ? ell[(k0 + k) * TM + row] : make_int2(row, 0);
+              }
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) z[i][k] = *reinterpret_cast<const f32x4*>(Zs + en[i][k].x * LDZ + c4);
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) s[i] += z[i][k] * __int_as_float(en[i][k].y);
+          }
+#pragma unroll
+          for (int i = 0; i < CH; ++i) *reinterpret_cast<f32x4*>(Zd + (n0 + (i0 + i) * RSTEP) * LDZ + c4) = s[i];
+        }
+      } else {
       for (int i0 = 0; i0 < NI; i0 += CH) {
         f32x4 s[CH];
         int2 en[CH], en_next[CH];
@@ -238,6 +274,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i) *reinterpret_cast<f32x4*>(Zd + (n0 + (i0 + i) * RSTEP) * LDZ + c4) = s[i];
+      }
       }
     } else {
       constexpr int RSTEP = NT / LDZ;
