@@ -6,7 +6,8 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 pkg = importlib.import_module("deep-statistical-solver-for-distribution-system-state-estimation_amd")
 nw = pkg.networks
-dev = torch.device("cuda:0"); H, nmat = 128, 3
+dev = torch.device("cuda:0"); nmat = 3
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 128      # argv: grid, graphs, hidden width
 GRID = sys.argv[1] if len(sys.argv) > 1 else "cigre14"; NB_ = int(sys.argv[2]) if len(sys.argv) > 2 else 4096      # argv: grid, graphs
 b = pkg.synthetic.make_batch([GRID], NB_, seed=0)
 ei = b["edge_index"].to(dev); N = b["x"].shape[0]
