@@ -35,6 +35,44 @@ BF16_MFMA_PEAK_TF = 2500.0     # same table: Peak BF16 MFMA, dense
 HBM_PEAK_GBS = 8000.0
 
 
+def spawn_ranks(n: int) -> int:
+    """One child per GPU via `python -m torch.distributed.run` on a free loopback port; stdout / stderr pass through."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args) -> int:
+    """The launch path without a GPU: gloo process group from the launcher's environment, one all-reduce, one JSON line."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        print(f"--gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    total = rank + 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        total = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if total != world * (world + 1) // 2:
+        return 3
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": total, "steps": args.steps, "warmup": args.warmup}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,7 +91,18 @@ def main():
     ap.add_argument("--ramp-seconds", type=float, default=2.0,
                     help="untimed load before the W warm-up steps: a fresh MI355X needs ~1 s of sustained work to reach "
                          "its steady clocks (measured: the first ~100 steps of a process run 40 %% slower)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous path only (gloo on CPU, no GPU call): every rank joins the process group, one "
+                         "all-reduce checks it, rank 0 prints a JSON line marked dry_run (tests/test_bench_launch_cpu.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python3 bench.py --gpus N` without a launcher: start one fresh child process per GPU through torch's own
+        # launcher BEFORE this process has touched the GPU (nothing above initialises HIP), relay what the ranks print
+        # and leave with their exit code.  A process that has initialised the GPU is never re-executed.
+        raise SystemExit(spawn_ranks(args.gpus))
+    if args.dry_run:
+        raise SystemExit(dry_run(args))
 
     pkg = importlib.import_module(PKG)
     pkg._lib.lib()  # fail loudly without the HIP extension
@@ -228,7 +277,7 @@ def main():
             "kernel": f"dss2::{kname} (TAGConv H->H layers, forward and data-gradient"
                       + (f", {layers_per_launch:.0f} layers chained per launch)" if chained else ")"),
             "bound": "mfma", "achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-            "frac": flops / (avg_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "traffic": traffic,
+            "frac": flops / (avg_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "peak_pipe": "fp32 MFMA", "traffic": traffic,
             "traffic_source": traffic_source,
             "launches_timed": n_l, "layers_per_launch": layers_per_launch, "avg_launch_us": avg_ms * 1e3,
             "median_launch_us": med_ms * 1e3, "algorithmic_flops_per_launch": flops,
@@ -237,13 +286,15 @@ def main():
         }
         if bf16x6:
             # The tile GEMM runs on the bf16 matrix pipe as six v_mfma_f32_32x32x16_bf16 per fp32 product group (operands split
-            # into three bf16 pieces, fp32 accumulation: fp32-accurate, tools/accuracy_bf16x6.py).  `peak` / `frac` above stay
-            # the dense fp32 MFMA peak, the peak of the dtype the path computes in; against the pipe it actually occupies the
-            # bound is the dense bf16 peak / 6 executed flops per algorithmic flop, reported beside it.
+            # into three bf16 pieces, fp32 accumulation: fp32-accurate, tools/accuracy_bf16x6.py).  The bound of the pipe the
+            # kernel executes on is the dense bf16 peak / 6 executed flops per algorithmic flop: THAT is `peak` and `frac`.
+            # The ratio to the fp32 MFMA peak (which this kernel can exceed) is kept as a secondary field only.
             r = result["roofline"]
-            r["pipe"] = "bf16 MFMA, 6 instructions per fp32 product group (bf16x6)"
-            r["peak_bf16_pipe_equiv"] = BF16_MFMA_PEAK_TF / 6.0
-            r["frac_bf16_pipe"] = r["achieved"] / (BF16_MFMA_PEAK_TF / 6.0)
+            r["frac_of_fp32_mfma_peak"] = r["achieved"] / FP32_MFMA_PEAK_TF
+            r["peak"] = BF16_MFMA_PEAK_TF / 6.0
+            r["frac"] = r["achieved"] / r["peak"]
+            r["peak_pipe"] = "bf16 MFMA dense peak (2500 TF) / 6 instructions per fp32 product group (bf16x6)"
+            r["frac_bf16_pipe"] = r["frac"]
     # ---- the SAME step replayed as a hipGraph (graphs.GraphedStep), timed the same way; the faster mode is reported.
     # Eager: 19 launches through the C ABI per step, ~0.41 ms of host work on a quiet box (hidden by the 0.58 ms of GPU work)
     # but up to 0.8 ms on a loaded host -- and two collectives more per step when distributed -- which then bounds the step.
@@ -255,9 +306,10 @@ def main():
 
         def bail():
             result["config"]["hipgraph"] = f"no answer within {args.graph_timeout:.0f} s: eager result reported"
+            result["partial"] = "hipGraph leg hung and was abandoned; value / ms_per_step are the eager measurement"
             if rank == 0:
                 print(json.dumps(result), flush=True)
-            os._exit(0)
+            os._exit(0 if world == 1 else 4)      # distributed: the other ranks are stuck in a collective -- make the launcher fail loudly
         timer = threading.Timer(args.graph_timeout, bail)
         timer.daemon = True
         timer.start()

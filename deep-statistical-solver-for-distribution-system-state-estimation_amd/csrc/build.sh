@@ -11,15 +11,33 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # the feature and says so; that line is filtered.
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
 NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"
+NOPK_SRCS="dss2_gemm_chain16 dss2_wgrad16"
 mkdir -p "$OBJ"
 pids=()
 for src in dss2_api dss2_gemm_prop dss2_gemm_chain dss2_gemm_chain16 dss2_edge dss2_wgrad dss2_wgrad16 dss2_loss dss2_optim dss2_dataset dss2_topology; do
   if [ ! -f "$OBJ/$src.o" ] || [ "$HERE/$src.hip" -nt "$OBJ/$src.o" ] || [ "$HERE/dss2_common.hpp" -nt "$OBJ/$src.o" ] || [ "$HERE/dss2_gemm_chain_kernel.hpp" -nt "$OBJ/$src.o" ] || [ "$HERE/dss2_wgrad_batch.hpp" -nt "$OBJ/$src.o" ] || [ "$ROOT/include/dss2_hip.h" -nt "$OBJ/$src.o" ]; then
-    extra=""; case "$src" in dss2_gemm_chain16|dss2_wgrad16) extra="$NOPK";; esac
+    extra=""; case " $NOPK_SRCS " in *" $src "*) extra="$NOPK";; esac
     $HIPCC $FLAGS $extra "$@" -c "$HERE/$src.hip" -o "$OBJ/$src.o" 2> >(grep -v "is not a recognized feature for this target" >&2) &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+# The NOPK translation units must really be free of packed fp32 VALU ops: the flag is passed with -Xclang and the host
+# pass's "not a recognized feature" line is filtered above, so a toolchain that silently ignored it on the DEVICE pass
+# would give no other signal.  Disassemble the gfx950 code objects and fail the build if one v_pk_*_f32 is left.
+OBJDUMP="${OBJDUMP:-/opt/rocm/lib/llvm/bin/llvm-objdump}"
+for src in $NOPK_SRCS; do
+  tmp="$(mktemp -d)"
+  cp "$OBJ/$src.o" "$tmp/x.o"
+  (cd "$tmp" && "$OBJDUMP" --offloading x.o >/dev/null)
+  co="$(ls "$tmp"/x.o.*gfx950* 2>/dev/null | head -1)"
+  if [ -z "$co" ]; then echo "build.sh: no gfx950 code object found in $src.o" >&2; rm -rf "$tmp"; exit 1; fi
+  npk="$("$OBJDUMP" -d "$co" | grep -c -E 'v_pk_(fma|mul|add)_f32' || true)"
+  rm -rf "$tmp"
+  if [ "$npk" != "0" ]; then
+    echo "build.sh: $src.hip was compiled with $npk packed fp32 VALU instructions: '-target-feature -packed-fp32-ops' did not take effect" >&2
+    exit 1
+  fi
+done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/*.o
 echo "built $OUT"

@@ -32,6 +32,16 @@ class FusedAdamax(torch.optim.Optimizer):
         sd = super().state_dict()
         for g in sd["param_groups"]:
             g.pop("_step", None)   # internal: torch's format keeps the count per parameter (state[...]["step"])
+        # Internally every parameter of a group shares ONE step tensor.  Exported as is, pickle / deepcopy would keep the
+        # aliasing, and torch.optim.Adamax loading such a checkpoint would advance the shared tensor once per PARAMETER
+        # per iteration (wrong bias correction).  torch's format is one independent tensor per parameter: export clones.
+        state = {}
+        for k, st in sd["state"].items():
+            st = dict(st)
+            if torch.is_tensor(st.get("step")):
+                st["step"] = st["step"].detach().clone()
+            state[k] = st
+        sd["state"] = state
         return sd
 
     @torch.no_grad()

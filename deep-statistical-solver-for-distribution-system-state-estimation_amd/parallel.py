@@ -104,13 +104,27 @@ def attach_grad_allreduce(model: torch.nn.Module, group=None, async_op: bool = F
     ``async_op=True``: each block's collective is launched as soon as that block's backward has produced its bucket
     and overlaps the backward of the blocks below it (a PFN / SkipPFN stack then has its L collectives in flight
     instead of L serialised ones); call ``wait_grad_allreduce(model)`` after ``loss.backward()`` and before reading
-    the gradients (the wait is a stream dependency, not a host block)."""
+    the gradients (the wait is a stream dependency, not a host block).  The asynchronous mode requires the ``.grad`` of
+    every parameter to be None when backward runs (see ``hook`` below); a step that finds gradients in place reduces its
+    buckets with blocking collectives instead."""
     n = 0
     pending = [] if async_op else None
     model._dss2_pending_allreduce = pending
+    params = [p for p in model.parameters()]
+
+    def hook(flat, g=group, q=pending):
+        # The asynchronous mode hands autograd VIEWS of a bucket whose collective is still in flight.  That is only
+        # sound while AccumulateGrad adopts those views as the .grad tensors, i.e. while every .grad is None
+        # (``zero_grad(set_to_none=True)``, torch's default).  With a .grad already in place (gradient accumulation,
+        # ``set_to_none=False``) autograd would run ``p.grad += view`` on the compute stream beside the collective and
+        # the reduced values would never reach p.grad: such a step falls back to the blocking collective.
+        if q is not None and any(p.grad is not None for p in params):
+            q = None
+        return allreduce_flat_grads(flat, g, q)
+
     for m in model.modules():
         if hasattr(m, "convs") and hasattr(m, "edge_aggr") and hasattr(m, "_plan"):
-            m._grad_bucket_hook = (lambda flat, g=group, q=pending: allreduce_flat_grads(flat, g, q))
+            m._grad_bucket_hook = hook
             n += 1
     return n
 

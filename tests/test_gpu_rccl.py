@@ -52,18 +52,25 @@ def test_rccl_collectives_inside_hipgraph_capture():
     """A step WITH its RCCL collectives (loss sums, gradient bucket) captured into a hipGraph and replayed: must be bitwise
     the eager step.  The capture needs capture_error_mode="thread_local" (graphs.GraphedStep): in the default global mode
     the process-group watchdog's event queries abort the process during the capture (round 2, first attempt).  bench.py
-    times distributed steps both ways behind a watchdog timer.  The outcome is recorded either way."""
+    times distributed steps both ways behind a watchdog timer.  The outcome is recorded either way; a child that exits non-zero FAILS the test."""
     p = _child("graph")
     outcome = {"returncode": p.returncode}
-    if p.returncode == 0:
-        res = _result(p)
-        for c in res["cases"].values():
-            assert c["graph_capture"] == "ok" and c["graph_bitwise"], c
-        outcome["cases"] = res["cases"]
-    else:
+    try:
+        _record_and_check(p, outcome)
+    finally:
+        out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
+        if os.path.isdir(out_dir):
+            with open(os.path.join(out_dir, "rccl_graph_capture.json"), "w") as fh:
+                json.dump(outcome, fh, indent=1)
+        print("RCCL collectives in hipGraph capture:", json.dumps(outcome)[:1500])
+
+
+def _record_and_check(p, outcome):
+    if p.returncode != 0:
         outcome["stderr_tail"] = p.stderr[-1500:]
-    out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
-    if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, "rccl_graph_capture.json"), "w") as fh:
-            json.dump(outcome, fh, indent=1)
-    print("RCCL collectives in hipGraph capture:", json.dumps(outcome)[:1500])
+    # bench.py defaults to this capture path for distributed runs: a crash of the child is a failure, not a note
+    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-4000:]
+    res = _result(p)
+    outcome["cases"] = res["cases"]
+    for c in res["cases"].values():
+        assert c["graph_capture"] == "ok" and c["graph_bitwise"], c

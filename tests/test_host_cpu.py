@@ -164,3 +164,27 @@ def test_no_kernel_in_the_library_spills_registers():
     assert n_kernels > 100, n_kernels
     bad = [(fn, name, sp, scr) for fn, ks in results for name, sp, scr in ks if sp or scr]
     assert not bad, bad
+
+
+def test_fused_adamax_checkpoint_has_one_step_tensor_per_parameter():
+    """internally the parameters of a group share one step tensor; a checkpoint must not export that aliasing
+    (torch.optim.Adamax would then advance the count once per PARAMETER per iteration)."""
+    import copy
+    pkg = load_pkg()
+    ps = [torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2, 2))]
+    opt = pkg.FusedAdamax(ps, lr=3e-3)
+    opt.init_state()
+    opt.param_groups[0]["_step"] += 5.0                       # as after five steps
+    sd = copy.deepcopy(opt.state_dict())
+    steps = [sd["state"][i]["step"] for i in range(2)]
+    assert steps[0] is not steps[1] and steps[0].data_ptr() != steps[1].data_ptr()
+    assert all(float(s) == 5.0 for s in steps)
+    assert "_step" not in sd["param_groups"][0]
+    ref = torch.optim.Adamax([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=3e-3)
+    ref.load_state_dict(sd)
+    for p in ref.param_groups[0]["params"]:
+        p.grad = torch.ones_like(p)
+    ref.step()
+    assert [float(ref.state[p]["step"]) for p in ref.param_groups[0]["params"]] == [6.0, 6.0]
+    # and the export did not detach the optimizer's own shared counter
+    assert opt.state[ps[0]]["step"] is opt.state[ps[1]]["step"]

@@ -98,3 +98,67 @@ def test_attach_grad_allreduce_hooks_every_block():
     m = pkg.SkipPFN(8, 6, 2, 16, 2, 2, 0.0, 3)
     assert pkg.parallel.attach_grad_allreduce(m) == 3
     assert pkg.parallel.attach_grad_allreduce(pkg.MPN(8, 6, 2, 16, 2, 2, 0.0)) == 1
+
+
+class _BucketBlock(torch.nn.Module):
+    """A block with the attributes attach_grad_allreduce looks for, whose backward follows networks._MPNFn's protocol on
+    CPU tensors: gradients are produced in ONE flat bucket, the bucket hook is called, VIEWS of the bucket are returned."""
+
+    def __init__(self):
+        super().__init__()
+        self.convs, self.edge_aggr, self._plan = torch.nn.ModuleList(), torch.nn.Identity(), None
+        self.w = torch.nn.Parameter(torch.arange(6.0).view(2, 3))
+        self.b = torch.nn.Parameter(torch.ones(4))
+
+    def forward(self, scale):
+        return _BucketFn.apply(scale, self, self.w, self.b)
+
+
+class _BucketFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scale, mod, w, b):
+        ctx.mod, ctx.scale = mod, float(scale)
+        return (w.sum() + b.sum()) * scale
+
+    @staticmethod
+    def backward(ctx, g):
+        flat = torch.full((10,), ctx.scale, dtype=torch.float32) * g
+        hook = getattr(ctx.mod, "_grad_bucket_hook", None)
+        if hook is not None:
+            hook(flat)
+        return None, None, flat[:6].view(2, 3), flat[6:]
+
+
+def _async_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    pkg = load_pkg()
+    torch.set_num_threads(1)
+    pkg.parallel.init_from_env("gloo")
+    m = _BucketBlock()
+    assert pkg.parallel.attach_grad_allreduce(m, async_op=True) == 1
+    tot = float(sum(r + 1 for r in range(world)))            # rank r contributes (r + 1) per element
+    # step 1: .grad is None -> asynchronous collective, joined by wait_grad_allreduce
+    m(torch.tensor(rank + 1.0)).backward()
+    joined1 = pkg.parallel.wait_grad_allreduce(m)
+    ok1 = bool((m.w.grad == tot).all() and (m.b.grad == tot).all())
+    # step 2 WITHOUT clearing the gradients (accumulation): autograd adds the views into the existing .grad right away, so
+    # the hook must have reduced the bucket before it returns (blocking fallback) -- nothing is left to join
+    m(torch.tensor(rank + 1.0)).backward()
+    joined2 = pkg.parallel.wait_grad_allreduce(m)
+    ok2 = bool((m.w.grad == 2 * tot).all() and (m.b.grad == 2 * tot).all())
+    ret[rank] = (ok1, joined1, ok2, joined2)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_bucket_hook_with_gradients_already_in_place():
+    """async_op=True is only sound while .grad is None; with gradients in place the hook must fall back
+    to a blocking collective, otherwise `p.grad += view` races the all-reduce and the reduced values never arrive."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_async_worker, args=(world, 29950 + os.getpid() % 40, ret), nprocs=world, join=True)
+    for r in range(world):
+        ok1, j1, ok2, j2 = ret[r]
+        assert ok1 and j1 == 1, ret[r]
+        assert ok2 and j2 == 0, ret[r]
