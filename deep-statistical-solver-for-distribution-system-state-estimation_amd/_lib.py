@@ -116,7 +116,30 @@ class WlsArgs(C.Structure):
                 ("n_nodes", C.c_int64), ("n_edges", C.c_int64),
                 ("lam_v", C.c_float), ("lam_p", C.c_float), ("lam_pf", C.c_float), ("lam_reg", C.c_float),
                 ("sums", C.c_void_p), ("partials", C.c_void_p), ("vminmax", C.c_void_p),
-                ("apq", C.c_void_p), ("loss", C.c_void_p), ("grad_output", C.c_void_p), ("pflow", C.c_void_p)]
+                ("apq", C.c_void_p), ("loss", C.c_void_p), ("grad_output", C.c_void_p), ("pflow", C.c_void_p),
+                ("flags", C.c_int32), ("counter", C.c_void_p), ("gscale", C.c_void_p)]
+
+
+WLS_VMM_CACHED, WLS_FUSED_FINISH, WLS_NO_LOSS_WRITE = 1, 2, 4
+
+
+class StackDims(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("n_hh", C.c_int32), ("dout_inner", C.c_int32), ("dout_last", C.c_int32),
+                ("skip_inner", C.c_int32), ("skip_last", C.c_int32)]
+
+
+class StackArgs(C.Structure):
+    _fields_ = [("dims", StackDims),
+                ("x", C.c_void_p), ("ldx", C.c_int64), ("ea", C.c_void_p), ("ldea", C.c_int64), ("wpack", C.c_void_p),
+                ("tile_start", C.c_void_p), ("ntiles", C.c_int32), ("tm", C.c_int32),
+                ("ell_w", C.c_void_p), ("ell_e", C.c_void_p), ("ell_width", C.c_int32),
+                ("ellT_w", C.c_void_p), ("ellT_e", C.c_void_p), ("ellT_width", C.c_int32),
+                ("deg_pows", C.c_void_p), ("xs", C.c_void_p), ("acts", C.c_void_p),
+                ("out", C.c_void_p), ("ldo", C.c_int64), ("gout", C.c_void_p), ("ldg", C.c_int64),
+                ("dxbuf", C.c_void_p), ("dx_out", C.c_void_p),
+                ("slab", C.c_void_p), ("slab_stride", C.c_int64), ("n_wg", C.c_int32),
+                ("drop_state", C.c_void_p), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float), ("drop_stride", C.c_int32),
+                ("n_nodes", C.c_int64)]
 
 
 _SIGNATURES = {
@@ -169,6 +192,7 @@ _SIGNATURES = {
     "dss2_reduce_slabs": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "dss2_wls_loss_partials": (C.c_int, [C.POINTER(WlsArgs), C.c_void_p]),
     "dss2_wls_loss_grad": (C.c_int, [C.POINTER(WlsArgs), C.c_void_p]),
+    "dss2_wls_loss_value": (C.c_int, [C.POINTER(WlsArgs), C.c_void_p]),
     "dss2_get_pflow": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_int, C.c_void_p]),
@@ -188,6 +212,17 @@ _SIGNATURES = {
     "dss2_collate_ragged": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "dss2_adamax_step": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "dss2_adamax_step_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "dss2_stack_wpack_words": (C.c_int64, [C.POINTER(StackDims)]),
+    "dss2_stack_flat_floats": (C.c_int64, [C.POINTER(StackDims)]),
+    "dss2_stack_supported": (C.c_int, [C.POINTER(StackDims), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dss2_stack_pack": (C.c_int, [C.POINTER(StackDims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
+                                  C.c_void_p, C.c_void_p]),
+    "dss2_stack_forward": (C.c_int, [C.POINTER(StackArgs), C.c_void_p]),
+    "dss2_stack_backward": (C.c_int, [C.POINTER(StackArgs), C.c_void_p]),
+    "dss2_stack_reduce": (C.c_int, [C.POINTER(StackDims), C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dss2_stack_fold_scratch_floats": (C.c_int64, [C.POINTER(StackDims)]),
+    "dss2_adamax_step_flat": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                        C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dss2_gemm_prop_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad_y_slices": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad_lds_bytes_ex": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

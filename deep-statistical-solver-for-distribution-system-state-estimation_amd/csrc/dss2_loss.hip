@@ -188,6 +188,38 @@ __global__ void __launch_bounds__(LB) wls_partials_kernel(const dss2_wls_args p)
     for (int k = 0; k < LB / 64; ++k) s += red[k][threadIdx.x];
     p.partials[(size_t)blockIdx.x * 5 + threadIdx.x] = s;
   }
+  if (!(p.flags & DSS2_WLS_FUSED_FINISH)) return;
+  // ---- the last workgroup to arrive finishes: fixed-order sum over the workgroups (independent of WHICH one is last)
+  __shared__ unsigned last_flag;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last_flag = atomicAdd(p.counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!last_flag) return;
+  __threadfence();
+  __shared__ double tot[5];
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;      // LB = 256: waves 0..3 take columns 0..3, wave 0 also column 4
+  for (int col = c; col < 5; col += LB / 64) {
+    double s = 0;
+    for (int b = lane; b < (int)gridDim.x; b += 64) s += __builtin_nontemporal_load(p.partials + (size_t)b * 5 + col);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) { p.sums[col] = s; tot[col] = s; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double Nn = (double)p.n_nodes, Ee = (double)p.n_edges, lr = (double)p.lam_reg;
+    p.sums[5] = Nn; p.sums[6] = Ee; p.sums[7] = 0;
+    const double mv = tot[2] / Nn, mt = tot[3] / Ee, ml = tot[4] / Ee;
+    p.loss[0] = (float)(tot[0] / Nn + tot[1] / Ee + lr * mv * mv + lr * mt * mt + lr * ml * ml);
+    *p.counter = 0u;      // ready for the next launch (a hipGraph replay included)
+  }
+}
+
+__global__ void wls_value_kernel(const double* __restrict__ sums, float lam_reg, float* __restrict__ loss) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double Nn = sums[5], Ee = sums[6], lr = (double)lam_reg;
+  const double mv = sums[2] / Nn, mt = sums[3] / Ee, ml = sums[4] / Ee;
+  loss[0] = (float)(sums[0] / Nn + sums[1] / Ee + lr * mv * mv + lr * mt * mt + lr * ml * ml);
 }
 
 // 5 waves, wave c sums column c of the workgroup partials: lanes stride over the workgroups, then
@@ -212,7 +244,7 @@ __global__ void __launch_bounds__(LB) wls_grad_kernel(const dss2_wls_args p) {
   vminmax_fold(p.vminmax, vlv, vhv);   // all lanes (before any early return)
   const double Nn = p.sums[5], Ee = p.sums[6];
   const double mean_v = p.sums[2] / Nn, mean_t = p.sums[3] / Ee, mean_l = p.sums[4] / Ee;
-  if (i == 0) {
+  if (i == 0 && !(p.flags & DSS2_WLS_NO_LOSS_WRITE)) {
     const double lr = (double)p.lam_reg;
     p.loss[0] = (float)(p.sums[0] / Nn + p.sums[1] / Ee + lr * mean_v * mean_v + lr * mean_t * mean_t +
                         lr * mean_l * mean_l);
@@ -310,8 +342,9 @@ __global__ void __launch_bounds__(LB) wls_grad_kernel(const dss2_wls_args p) {
     const float dd = (uPf * (-vv * a2) + uQf * (vv * (-a1)) + uPt * (-vv * (-a4)) + uQt * (vv * a3)) * kk + gd;
     gth += to_end ? -dd : dd;
   }
-  p.grad_output[2 * i + 0] = gv * xs0;
-  p.grad_output[2 * i + 1] = gth * mi;
+  const float gs = p.gscale ? p.gscale[0] : 1.f;      // upstream gradient of the loss (1 for loss.backward())
+  p.grad_output[2 * i + 0] = gv * xs0 * gs;
+  p.grad_output[2 * i + 1] = gth * mi * gs;
 }
 
 __global__ void __launch_bounds__(LB) pflow_kernel(const float* __restrict__ y, int64_t ldy,
@@ -415,11 +448,20 @@ extern "C" int dss2_wls_loss_partials(const dss2_wls_args* ap, void* stream) {
   if (a.n_nodes <= 0 || a.n_edges <= 0) { set_error("wls_loss: empty batch"); return 2; }
   const int64_t nb = (a.n_nodes + LB - 1) / LB;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(vminmax_kernel, dim3(VMM_BLOCKS), dim3(256), 0, s, a.node_param, a.ld_np, a.n_nodes, a.vminmax);
+  if ((a.flags & DSS2_WLS_FUSED_FINISH) && !a.counter) { set_error("wls_loss: DSS2_WLS_FUSED_FINISH needs a counter word"); return 2; }
+  if (!(a.flags & DSS2_WLS_VMM_CACHED))
+    hipLaunchKernelGGL(vminmax_kernel, dim3(VMM_BLOCKS), dim3(256), 0, s, a.node_param, a.ld_np, a.n_nodes, a.vminmax);
   hipLaunchKernelGGL(wls_partials_kernel, dim3((unsigned)nb), dim3(LB), 0, s, a);
-  hipLaunchKernelGGL(wls_finish_kernel, dim3(1), dim3(320), 0, s, a.partials, (int)nb, a.sums, (double)a.n_nodes,
-                     (double)a.n_edges);
+  if (!(a.flags & DSS2_WLS_FUSED_FINISH))
+    hipLaunchKernelGGL(wls_finish_kernel, dim3(1), dim3(320), 0, s, a.partials, (int)nb, a.sums, (double)a.n_nodes,
+                       (double)a.n_edges);
   return check_launch("wls_loss_partials");
+}
+
+extern "C" int dss2_wls_loss_value(const dss2_wls_args* ap, void* stream) {
+  if (!ap->sums || !ap->loss) { set_error("wls_loss_value: null argument"); return 2; }
+  hipLaunchKernelGGL(wls_value_kernel, dim3(1), dim3(64), 0, as_stream(stream), ap->sums, ap->lam_reg, ap->loss);
+  return check_launch("wls_loss_value");
 }
 
 extern "C" int dss2_wls_loss_grad(const dss2_wls_args* ap, void* stream) {

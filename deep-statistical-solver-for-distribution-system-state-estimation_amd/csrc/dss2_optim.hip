@@ -33,6 +33,37 @@ __global__ void __launch_bounds__(256) adamax_kernel(const AdamaxTable tab, floa
   }
 }
 
+// One launch for every tensor of a flat gradient bucket (descriptor table in device memory, see dss2_hip.h).
+__global__ void __launch_bounds__(256) adamax_flat_kernel(const dss2_adamax_flat_desc* __restrict__ descs,
+                                                          const float* __restrict__ grad_base, float lr, float beta1, float beta2,
+                                                          float eps, float weight_decay, float bias_corr1, float* step_dev,
+                                                          unsigned* counter) {
+  const dss2_adamax_flat_desc d = descs[blockIdx.y];
+  if (step_dev) bias_corr1 = 1.f - powf(beta1, step_dev[0] + 1.f);      // this step's (1-based) count
+  const float clr = lr / bias_corr1;
+  const float* __restrict__ grad = grad_base + d.grad_off;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * blockDim.x) {
+    float g = grad[i];
+    const float p = d.param[i];
+    if (weight_decay != 0.f) g = fmaf(weight_decay, p, g);
+    const float m = fmaf(beta1, d.exp_avg[i], (1.f - beta1) * g);
+    const float u = fmaxf(beta2 * d.exp_inf[i], fabsf(g) + eps);
+    d.exp_avg[i] = m;
+    d.exp_inf[i] = u;
+    d.param[i] = p - clr * (m / u);
+  }
+  if (!step_dev) return;
+  // the last workgroup to finish advances the device-side count (every workgroup has read it by then)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(counter, 1u) == gridDim.x * gridDim.y - 1) {
+      step_dev[0] += 1.f;
+      *counter = 0u;
+    }
+  }
+}
+
 // Batched small dense products in weight space (a few 128^3 products per step; one launch).
 // One 32 x 32 tile of C per workgroup.  The operands are tiny (<= a few hundred KB, L2-resident) and the
 // kernel is latency-bound: a whole K-chunk of 128 is requested at once (32 loads in flight per thread),
@@ -163,6 +194,21 @@ extern "C" int dss2_adamax_step(const dss2_adamax_desc* descs_host, int n_desc, 
   if (!descs_host) { dss2::set_error("adamax_step: null descriptor table"); return 2; }
   if (step < 1) { dss2::set_error("adamax_step: step must be >= 1"); return 2; }
   return adamax_launch(descs_host, n_desc, lr, beta1, beta2, eps, weight_decay, 1.f - powf(beta1, (float)step), nullptr, dss2::as_stream(stream));
+}
+
+extern "C" int dss2_adamax_step_flat(const dss2_adamax_flat_desc* descs_dev, int n_desc, int64_t max_n, const float* grad_base,
+                                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* step_dev,
+                                     uint32_t* counter, void* stream) {
+  if (n_desc <= 0) return 0;
+  if (!descs_dev || !grad_base || n_desc > 65535) { dss2::set_error("adamax_step_flat: bad arguments"); return 2; }
+  if (step < 0 || (step == 0 && (!step_dev || !counter))) { dss2::set_error("adamax_step_flat: step >= 1, or step == 0 with step_dev and counter"); return 2; }
+  int64_t bx = (max_n + 4095) / 4096;      // a workgroup walks up to 16 elements per thread: few, fat workgroups (and few
+  if (bx > 64) bx = 64;                    // arrivals at the step counter's word)
+  if (bx < 1) bx = 1;
+  const float bc1 = step > 0 ? 1.f - powf(beta1, (float)step) : 1.f;
+  hipLaunchKernelGGL(dss2::adamax_flat_kernel, dim3((unsigned)bx, n_desc), dim3(256), 0, dss2::as_stream(stream), descs_dev, grad_base,
+                     lr, beta1, beta2, eps, weight_decay, bc1, step > 0 ? nullptr : step_dev, counter);
+  return dss2::check_launch("adamax_step_flat");
 }
 
 extern "C" int dss2_adamax_step_dev(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1,

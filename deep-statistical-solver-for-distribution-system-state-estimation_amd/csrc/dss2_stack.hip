@@ -1,0 +1,1012 @@
+// Whole-stack kernels for the reference driver's own model line (include/dss2_hip.h "whole-stack kernels").
+//
+//   /root/reference/networks.py:340-388  PFN / SkipPFN: PFN-L chained MPN / SkipMPN blocks on the same edge inputs
+//   /root/reference/networks.py:212-338  one block: EdgeAggregation -> TAGConv x L (dropout, ReLU between) [-> + input]
+//   /root/reference/dss2_run.py:72-88    SkipPFN(dim_hid 32, 8 layers, K 2, dropout 0.3, L 5), batch_size 64
+//
+// At dim_hid = 32 a layer is 0.2 MFLOP per graph: nothing is MFMA- or HBM-bound, every per-layer launch is a chain of
+// launch / L2 / LDS latencies (round 2: 67 launches per training step, 0.93 ms at B = 64).  Here ONE forward launch walks a
+// tile of whole graphs (<= 64 rows) through every block of the stack and ONE backward launch walks it back:
+//
+//   forward, per block:  edge MLP (first Linear + ReLU, summed per target; VALU, weights in registers)            -> S
+//                        conv 0 on S with the edge MLP's second Linear folded in (Wf_m = W_m W2, rank-3 bias term)
+//                        conv 1 .. n_hh-1 (H -> H), each: tile GEMM [64 x 32] x [32 x 96] as bf16x6 on the bf16 matrix
+//                        pipe (six waves: row block x matrix), two Horner hops on 16-byte row pieces in LDS, bias /
+//                        in-kernel dropout (Philox, dss2_common.hpp) / ReLU, output to HBM once (the backward needs it)
+//                        and in place into the LDS tile
+//                        head H -> dout (<= 8): one 32-column GEMM, two hops on dout-wide rows, bias, residual; the
+//                        8-wide block output is the next block's input and never leaves LDS on its way there
+//   backward, per block (reverse), per tile of the workgroup:
+//                        head / conv l: Z = [g | A^T g | (A^T)^2 g] by two hops; then ONE MFMA phase in which three waves
+//                        accumulate dW_k += Z_k^T a_l (fp32 MFMA, persistent accumulators: block q = 3 l + k lives on wave
+//                        q mod 8, slot q / 8), two waves compute the data gradient Z [W_0; W_1; W_2] (bf16x6, K = 96) and
+//                        the spare waves the bias sums; gate by the saved activation + regenerated dropout mask
+//                        edge MLP: gates recomputed with the forward's own arithmetic (edge_z), dW1 / db1 in registers,
+//                        dx = U0 W1[:, :8] + U1 W1[:, 8:16] (+ residual) handed to the block below through HBM (8 floats / row)
+//                        one slab of weight gradients per workgroup and block; dss2_stack_reduce sums the slabs in a fixed
+//                        order and applies the chain rule of the fold.
+//
+// No float atomics: results are bitwise reproducible.  Shapes outside (dim_hid 32, K 2, 8 / 6 input features, tiles <= 64
+// rows with ELL slices, <= 8 layers per block) run the per-block kernels (dss2_stack_supported).
+#include "dss2_common.hpp"
+
+namespace dss2 {
+
+#ifdef DSS2_STACK_STAMPS
+// Diagnostic build only (csrc/build.sh -DDSS2_STACK_STAMPS, tools/sstamps.py): s_memtime stamps of every wave of the first 64
+// workgroups at the phase boundaries of the first block a workgroup processes (forward: block 0; backward: the last block,
+// first tile).  They go to a buffer no kernel reads.
+__device__ unsigned long long g_sstamps[2][64 * 8 * 128];
+#define SSTAMP(which, on)                                                                                     \
+  do {                                                                                                        \
+    if (on) {                                                                                                 \
+      unsigned long long t_;                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      if (lane == 0 && blockIdx.x < 64 && sidx < 128) g_sstamps[which][((size_t)blockIdx.x * 8 + wave) * 128 + sidx] = t_; \
+      ++sidx;                                                                                                 \
+    }                                                                                                         \
+  } while (0)
+#else
+#define SSTAMP(which, on) do {} while (0)
+#endif
+
+constexpr int SH = 32, SNM = 3, SFN = 8, SFC = 22, SW1LD = 24, STM = 64, SXLD = 36, SZLD = 100;
+constexpr int S_MAX_HH = 7, S_MAX_ELL = 8;
+
+// ---- wpack layout (32-bit words), per block -------------------------------------------------------------------------------
+constexpr int WP_W1 = 0, WP_B1 = SH * SW1LD, WP_CONV0 = WP_B1 + SH;
+constexpr int WP_FRAG = 3 * 64 * 4;                          // one k-group of 16: 3 planes x 64 lanes x 8 bf16
+constexpr int WP_CONV_FWD = 0;                               // [m][kg 0..1][plane][lane][4 words]
+constexpr int WP_CONV_BWD = SNM * 2 * WP_FRAG;               // [kg 0..5][plane][lane][4]   (k = 32 m + j)
+constexpr int WP_CONV_BIAS = WP_CONV_BWD + 6 * WP_FRAG;      // [32]
+constexpr int WP_CONV_PRE = WP_CONV_BIAS + SH;               // [3][32]  (conv 0: bf_m = W_m b2)
+constexpr int WP_CONV_STRIDE = WP_CONV_PRE + SNM * SH;
+constexpr int WP_HEAD_FWD = 0, WP_HEAD_BWD = 2 * WP_FRAG, WP_HEAD_BIAS = 4 * WP_FRAG, WP_HEAD_WORDS = WP_HEAD_BIAS + 8;
+__host__ __device__ inline int wp_head(int n_hh) { return WP_CONV0 + n_hh * WP_CONV_STRIDE; }
+__host__ __device__ inline int wp_block_words(int n_hh) { return wp_head(n_hh) + WP_HEAD_WORDS; }
+
+// ---- flat gradient layout (floats), per block = networks.MPN._flat_offsets -------------------------------------------------
+constexpr int FL_W1 = 0, FL_B1 = SH * SFC, FL_W2 = FL_B1 + SH, FL_B2 = FL_W2 + SH * SH, FL_CONV0 = FL_B2 + SH;
+constexpr int FL_CONV_STRIDE = SNM * SH * SH + SH;
+__host__ __device__ inline int fl_head(int n_hh) { return FL_CONV0 + n_hh * FL_CONV_STRIDE; }
+__host__ __device__ inline int fl_block(int n_hh, int dout) { return fl_head(n_hh) + SNM * dout * SH + dout; }
+__host__ __device__ inline int params_per_block(int n_hh) { return 4 + 4 * (n_hh + 1); }
+
+__device__ __forceinline__ uint32_t bf16_bits(__bf16 v) { return (uint32_t)__builtin_bit_cast(uint16_t, v); }
+
+// eight fp32 values -> the three bf16x8 planes (4 words each)
+__device__ __forceinline__ void split8_store(const float (&v)[8], uint32_t* dst /* plane h */, int plane_stride) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    uint32_t h, m, l;
+    split3_pair(v[2 * w], v[2 * w + 1], h, m, l);
+    dst[w] = h; dst[plane_stride + w] = m; dst[2 * plane_stride + w] = l;
+  }
+}
+
+// =====================================================================================================================
+// pack: fold + bf16x3 fragments + fp32 copies, one launch per step
+// =====================================================================================================================
+__global__ void __launch_bounds__(256) stack_pack_kernel(const dss2_stack_dims d, const float* const* __restrict__ params,
+                                                         uint32_t* __restrict__ wpack, unsigned long long* rng_state,
+                                                         unsigned long long* rng_snap, unsigned long long host_seed,
+                                                         int use_host_seed, float* tick) {
+  __shared__ float src[SH][SH + 1], wm[SH][SH + 1], w2s[SH][SH + 1];
+  const int tid = threadIdx.x;
+  const int per_block = d.n_hh * SNM + 2;
+  const int b = blockIdx.x / per_block, u = blockIdx.x - b * per_block;
+  const float* const* P = params + (size_t)b * params_per_block(d.n_hh);
+  uint32_t* wb = wpack + (size_t)b * wp_block_words(d.n_hh);
+  if (blockIdx.x == 0 && tid == 0) {
+    if (rng_snap) {
+      if (use_host_seed) { rng_snap[0] = host_seed; rng_snap[1] = 0; }
+      else { rng_snap[0] = rng_state[0]; rng_snap[1] = rng_state[1]; rng_state[1] = rng_state[1] + 1; }
+    }
+    if (tick) tick[0] += 1.f;
+  }
+  const int dout = (b == d.n_blocks - 1) ? d.dout_last : d.dout_inner;
+  if (u < d.n_hh * SNM) {
+    const int l = u / SNM, m = u - l * SNM;
+    const float* W = P[4 + 4 * l + 1 + m];
+    uint32_t* cw = wb + WP_CONV0 + l * WP_CONV_STRIDE;
+    if (l == 0) {
+      const float* W2 = P[2];
+      const float* b2 = P[3];
+      for (int idx = tid; idx < SH * SH; idx += 256) { wm[idx >> 5][idx & 31] = W[idx]; w2s[idx >> 5][idx & 31] = W2[idx]; }
+      __syncthreads();
+      for (int idx = tid; idx < SH * SH; idx += 256) {
+        const int j = idx >> 5, c = idx & 31;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < SH; ++i) s = fmaf(wm[j][i], w2s[i][c], s);
+        src[j][c] = s;
+      }
+      if (tid < SH) {
+        float s = 0.f;
+        for (int i = 0; i < SH; ++i) s = fmaf(wm[tid][i], b2[i], s);
+        reinterpret_cast<float*>(cw + WP_CONV_PRE)[m * SH + tid] = s;
+      }
+    } else {
+      for (int idx = tid; idx < SH * SH; idx += 256) src[idx >> 5][idx & 31] = W[idx];
+      if (tid < SH) reinterpret_cast<float*>(cw + WP_CONV_PRE)[m * SH + tid] = 0.f;
+    }
+    __syncthreads();
+    const int t = tid & 127, kg = t >> 6, lane = t & 63, c32 = lane & 31, half = lane >> 5;
+    float v[8];
+    if (tid < 128) {      // forward operand: B[k = in][j = out] = src[j][k]
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = src[c32][16 * kg + 8 * half + q];
+      split8_store(v, cw + WP_CONV_FWD + (m * 2 + kg) * WP_FRAG + lane * 4, 256);
+    } else {              // data-gradient operand: B[k = 32 m + j][i = in] = src[j][i]
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = src[16 * kg + 8 * half + q][c32];
+      split8_store(v, cw + WP_CONV_BWD + (m * 2 + kg) * WP_FRAG + lane * 4, 256);
+    }
+  } else if (u == d.n_hh * SNM) {
+    // head: three [dout][32] matrices side by side in one 32-column group (forward) / stacked along k (data-gradient)
+    float* hs = &src[0][0];      // [3 * dout][33]
+    for (int idx = tid; idx < SNM * dout * SH; idx += 256) {
+      const int jj = idx >> 5, i = idx & 31, m = jj / dout, o = jj - m * dout;
+      hs[jj * (SH + 1) + i] = P[4 + 4 * d.n_hh + 1 + m][o * SH + i];
+    }
+    __syncthreads();
+    uint32_t* hw = wb + wp_head(d.n_hh);
+    const int t = tid & 127, kg = t >> 6, lane = t & 63, c32 = lane & 31, half = lane >> 5;
+    float v[8];
+    if (tid < 128) {      // B[k = i][jj = c32] = W_m[o][i]
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = c32 < SNM * dout ? hs[c32 * (SH + 1) + 16 * kg + 8 * half + q] : 0.f;
+      split8_store(v, hw + WP_HEAD_FWD + kg * WP_FRAG + lane * 4, 256);
+    } else {              // B[kk = m dout + o][i = c32] = W_m[o][i]
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int kk = 16 * kg + 8 * half + q; v[q] = kk < SNM * dout ? hs[kk * (SH + 1) + c32] : 0.f; }
+      split8_store(v, hw + WP_HEAD_BWD + kg * WP_FRAG + lane * 4, 256);
+    }
+    if (tid < 8) reinterpret_cast<float*>(hw + WP_HEAD_BIAS)[tid] = tid < dout ? P[4 + 4 * d.n_hh][tid] : 0.f;
+  } else {
+    float* f = reinterpret_cast<float*>(wb);
+    for (int idx = tid; idx < SH * SW1LD; idx += 256) {
+      const int j = idx / SW1LD, q = idx - j * SW1LD;
+      f[WP_W1 + idx] = q < SFC ? P[0][j * SFC + q] : 0.f;
+    }
+    if (tid < SH) f[WP_B1 + tid] = P[1][tid];
+    for (int idx = tid; idx < d.n_hh * SH; idx += 256) {
+      const int l = idx >> 5, c = idx & 31;
+      f[WP_CONV0 + l * WP_CONV_STRIDE + WP_CONV_BIAS + c] = P[4 + 4 * l][c];
+    }
+  }
+}
+
+// =====================================================================================================================
+// shared device pieces
+// =====================================================================================================================
+// z = b1[j] + W1[j, :] . [x_target | x_source | edge_attr]  -- networks.py:181 concat order; ONE definition, so the gates
+// the backward recomputes are bit for bit the forward's
+__device__ __forceinline__ float edge_z(const float (&w)[SW1LD], float b, f32x4 ta, f32x4 tb, f32x4 sa, f32x4 sb, f32x4 e0, f32x4 e1) {
+  float z = b;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) z = fmaf(w[q], ta[q], z);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) z = fmaf(w[4 + q], tb[q], z);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) z = fmaf(w[8 + q], sa[q], z);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) z = fmaf(w[12 + q], sb[q], z);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) z = fmaf(w[16 + q], e0[q], z);
+  z = fmaf(w[20], e1[0], z);
+  z = fmaf(w[21], e1[1], z);
+  return z;
+}
+
+// the tile's slice of an {other node, ent} ELL table -> other[D][64] (-1 = empty) and the sign-corrected edge_attr rows [D][64][8]
+__device__ __forceinline__ void stage_edges(const int32_t* __restrict__ ell_e, int tile, int D, int tm, const float* __restrict__ ea,
+                                            int64_t ldea, int* other, float* eaL, int tid, int nthreads) {
+  const int2* src = reinterpret_cast<const int2*>(ell_e) + (size_t)tile * D * tm;
+  for (int idx = tid; idx < D * STM; idx += nthreads) {
+    const int k = idx >> 6, r = idx & 63;
+    int2 en = make_int2(0, -1);
+    if (r < tm) en = src[k * tm + r];
+    const bool ok = en.y != -1;
+    other[idx] = ok ? en.x : -1;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      const float* e = ea + (int64_t)(en.y & 0x7fffffff) * ldea;
+      const float sgn = en.y < 0 ? -1.f : 1.f;
+      a = f32x4{e[0] * sgn, e[1], e[2] * sgn, e[3]};
+      c = f32x4{e[4], e[5], 0.f, 0.f};
+    }
+    *reinterpret_cast<f32x4*>(eaL + idx * 8) = a;
+    *reinterpret_cast<f32x4*>(eaL + idx * 8 + 4) = c;
+  }
+}
+
+__device__ __forceinline__ void stage_ell_w(const int32_t* __restrict__ ell_w, int tile, int D, int tm, int2* dst, int tid, int nthreads) {
+  const int2* src = reinterpret_cast<const int2*>(ell_w) + (size_t)tile * D * tm;
+  for (int idx = tid; idx < D * STM; idx += nthreads) {
+    const int k = idx >> 6, r = idx & 63;
+    dst[idx] = r < tm ? src[k * tm + r] : make_int2(r, 0);
+  }
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// acc += A[32 rows of this lane's row block][16 k] x B (bf16x6): arow -> 8 consecutive fp32 of this lane's row and k-half
+__device__ __forceinline__ f32x16 mma6(f32x16 c, const float* arow, const bf16x8 bh, const bf16x8 bm, const bf16x8 bl) {
+  const f32x4 v0 = *reinterpret_cast<const f32x4*>(arow), v1 = *reinterpret_cast<const f32x4*>(arow + 4);
+  uint32_t sh[4], sm[4], sl[4];
+  split3_pair(v0[0], v0[1], sh[0], sm[0], sl[0]);
+  split3_pair(v0[2], v0[3], sh[1], sm[1], sl[1]);
+  split3_pair(v1[0], v1[1], sh[2], sm[2], sl[2]);
+  split3_pair(v1[2], v1[3], sh[3], sm[3], sl[3]);
+  const bf16x8 ah = __builtin_bit_cast(bf16x8, u32x4{sh[0], sh[1], sh[2], sh[3]});
+  const bf16x8 am = __builtin_bit_cast(bf16x8, u32x4{sm[0], sm[1], sm[2], sm[3]});
+  const bf16x8 al = __builtin_bit_cast(bf16x8, u32x4{sl[0], sl[1], sl[2], sl[3]});
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);      // smallest terms first
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+  return c;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+// =====================================================================================================================
+// forward
+// =====================================================================================================================
+__global__ void __launch_bounds__(512, 2) stack_fwd_kernel(const dss2_stack_args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int D = p.ell_width;
+  float* Xs = smem;                                   // [64][36]  the activation tile
+  float* G = Xs + STM * SXLD;                         // [3][64][36]  G_m = X W_m^T, then the Horner partials
+  float* x8 = G + SNM * STM * SXLD;                   // [64][8]   block input
+  float* dps = x8 + STM * SFN;                        // [64][4]   A^m deg
+  float* eaL = dps + STM * 4;                         // [D][64][8]
+  int2* ellw = reinterpret_cast<int2*>(eaL + D * STM * 8);      // [D][64]
+  int* other = reinterpret_cast<int*>(ellw + D * STM);          // [D][64]
+  const int tid = threadIdx.x, lane = tid & 63, c32 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x;
+  const int ts = p.tile_start[tile], R = p.tile_start[tile + 1] - ts;
+  const int n_hh = p.dims.n_hh, NB = p.dims.n_blocks;
+  const int64_t N = p.n_nodes;
+  const uint64_t dseed = p.drop_state ? p.drop_state[0] : 0, doff = p.drop_state ? p.drop_state[1] : 0;
+  const int blk_words = wp_block_words(n_hh);
+
+  // ---- stage what every block of the stack reads: input rows, ELL slices, edge features, bias row scales
+  for (int idx = tid; idx < STM * SFN; idx += 512) {
+    const int r = idx >> 3, c = idx & 7;
+    x8[idx] = r < R ? p.x[(int64_t)(ts + r) * p.ldx + c] : 0.f;
+  }
+  if (tid < STM) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (tid < R) v = *reinterpret_cast<const f32x4*>(p.deg_pows + (int64_t)(ts + tid) * 4);
+    *reinterpret_cast<f32x4*>(dps + tid * 4) = v;
+  }
+  stage_ell_w(p.ell_w, tile, D, p.tm, ellw, tid, 512);
+  stage_edges(p.ell_e, tile, D, p.tm, p.ea, p.ldea, other, eaL, tid, 512);
+
+  // MFMA roles: waves 0..5 = (row block, matrix); the head runs on the two waves with m == 0
+  const int mm = wave % SNM, rb = wave / SNM;
+  const bool mma_wave = wave < 2 * SNM;
+  const int prow = tid >> 3, pcq = (tid & 7) * 4;      // row piece of the hops / epilogue: 4 columns of one row
+  const int hrow = tid >> 3, ho = tid & 7;             // head item: one output of one row
+  bf16x8 nb[2][3];                                     // the NEXT unit's weight fragments of this wave (requested one unit ahead)
+  auto load_conv = [&](int b, int l) {
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(p.wpack + (size_t)b * blk_words + WP_CONV0 + l * WP_CONV_STRIDE + WP_CONV_FWD);
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) nb[kg][pl] = src[((mm * 2 + kg) * 3 + pl) * 64 + lane];
+  };
+  auto load_head = [&](int b) {
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(p.wpack + (size_t)b * blk_words + wp_head(n_hh) + WP_HEAD_FWD);
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) nb[kg][pl] = src[(kg * 3 + pl) * 64 + lane];
+  };
+  if (mma_wave) load_conv(0, 0);
+  [[maybe_unused]] int sidx = 0;
+  SSTAMP(0, true);                 // 0: staging issued
+  __syncthreads();
+  SSTAMP(0, true);                 // 1: staged
+
+  for (int b = 0; b < NB; ++b) {
+    const float* wf = reinterpret_cast<const float*>(p.wpack + (size_t)b * blk_words);
+    const int dout = (b == NB - 1) ? p.dims.dout_last : p.dims.dout_inner;
+    const bool skip = (b == NB - 1) ? p.dims.skip_last != 0 : p.dims.skip_inner != 0;
+    float* act_b = p.acts + (size_t)b * (n_hh + 1) * N * SH;
+    // ---- edge MLP: S[r][j] = sum over incoming edges of relu(b1 + W1 [x_r | x_src | ea])
+    {
+      float w[SW1LD];
+#pragma unroll
+      for (int q4 = 0; q4 < SW1LD / 4; ++q4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wf + WP_W1 + c32 * SW1LD + q4 * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q4 * 4 + q] = v[q];
+      }
+      const float bb = wf[WP_B1 + c32];
+      const int stream = wave * 2 + half;
+#pragma unroll 1
+      for (int t = 0; t < STM / 16; ++t) {
+        const int r = stream + 16 * t;
+        const f32x4 ta = *reinterpret_cast<const f32x4*>(x8 + r * SFN), tb = *reinterpret_cast<const f32x4*>(x8 + r * SFN + 4);
+        float acc = 0.f;
+        for (int k = 0; k < D; ++k) {
+          const int o = other[k * STM + r];
+          if (o >= 0) {
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(x8 + o * SFN), sb = *reinterpret_cast<const f32x4*>(x8 + o * SFN + 4);
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8), e1 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8 + 4);
+            acc += fmaxf(edge_z(w, bb, ta, tb, sa, sb, e0, e1), 0.f);
+          }
+        }
+        Xs[r * SXLD + c32] = acc;
+        if (r < R) act_b[(size_t)(ts + r) * SH + c32] = acc;
+      }
+    }
+    SSTAMP(0, b == 0);             // 2: edge phase done
+    __syncthreads();
+    SSTAMP(0, b == 0);             // 3
+
+    // ---- the H -> H layers
+    for (int l = 0; l < n_hh; ++l) {
+      const float* cw = wf + WP_CONV0 + l * WP_CONV_STRIDE;
+      const uint32_t did = p.drop_state ? (uint32_t)(b * p.drop_stride + l + 1) : 0u;
+      if (mma_wave) {
+        bf16x8 bq[2][3];
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) bq[kg][pl] = nb[kg][pl];
+        f32x16 acc = zero16();
+        const float* arow = Xs + (rb * 32 + c32) * SXLD + half * 8;
+        acc = mma6(acc, arow, bq[0][0], bq[0][1], bq[0][2]);
+        acc = mma6(acc, arow + 16, bq[1][0], bq[1][1], bq[1][2]);
+        // request the next unit's fragments now: they arrive during the hops
+        if (l + 1 < n_hh) load_conv(b, l + 1);
+        else if (mm == 0) load_head(b);
+        float* g = G + mm * (STM * SXLD) + (rb * 32) * SXLD + c32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[acc_row(r, half) * SXLD] = acc[r];
+      }
+      // (the dropout multipliers depend on (row, column, layer) only: computed here, off the critical path)
+      f32x4 mult = {1.f, 1.f, 1.f, 1.f};
+      if (did) mult = dropout_mult4(dseed, doff, did, (uint32_t)(ts + prow), (uint32_t)(pcq >> 2), p.drop_thr, p.drop_scale);
+      f32x4 v = *reinterpret_cast<const f32x4*>(cw + WP_CONV_BIAS + pcq);      // bias (+ folded rank-3 term of conv 0)
+      if (l == 0) {
+        const f32x4 ps = *reinterpret_cast<const f32x4*>(dps + prow * 4);
+#pragma unroll
+        for (int m = 0; m < SNM; ++m) v += *reinterpret_cast<const f32x4*>(cw + WP_CONV_PRE + m * SH + pcq) * ps[m];
+      }
+      SSTAMP(0, b == 0);           // 4 + 6 l: MFMA + mask done
+      __syncthreads();
+      SSTAMP(0, b == 0);           // 5 + 6 l
+      {   // hop 1: G_1 <- G_1 + A G_2
+        float* own = G + 1 * (STM * SXLD) + prow * SXLD + pcq;
+        const float* src = G + 2 * (STM * SXLD) + pcq;
+        f32x4 U = *reinterpret_cast<const f32x4*>(own);
+        for (int k = 0; k < D; ++k) {
+          const int2 en = ellw[k * STM + prow];
+          U += *reinterpret_cast<const f32x4*>(src + en.x * SXLD) * __int_as_float(en.y);
+        }
+        *reinterpret_cast<f32x4*>(own) = U;
+      }
+      SSTAMP(0, b == 0);           // 6 + 6 l: hop 1 done
+      __syncthreads();
+      SSTAMP(0, b == 0);           // 7 + 6 l
+      {   // hop 2 + epilogue: out = G_0 + A G_1 + bias terms -> dropout -> ReLU -> HBM and the tile
+        const float* src = G + 1 * (STM * SXLD) + pcq;
+        f32x4 U = *reinterpret_cast<const f32x4*>(G + prow * SXLD + pcq);
+        for (int k = 0; k < D; ++k) {
+          const int2 en = ellw[k * STM + prow];
+          U += *reinterpret_cast<const f32x4*>(src + en.x * SXLD) * __int_as_float(en.y);
+        }
+        v += U;
+        v *= mult;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = prow < R ? fmaxf(v[q], 0.f) : 0.f;
+        if (prow < R) *reinterpret_cast<f32x4*>(act_b + ((size_t)(l + 1) * N + ts + prow) * SH + pcq) = v;
+        *reinterpret_cast<f32x4*>(Xs + prow * SXLD + pcq) = v;
+      }
+      SSTAMP(0, b == 0);           // 8 + 6 l: hop 2 + epilogue done
+      __syncthreads();
+      SSTAMP(0, b == 0);           // 9 + 6 l
+    }
+
+    // ---- head: H -> dout, three matrices side by side in one 32-column group
+    if (mma_wave && mm == 0) {
+      bf16x8 bq[2][3];
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bq[kg][pl] = nb[kg][pl];
+      f32x16 acc = zero16();
+      const float* arow = Xs + (rb * 32 + c32) * SXLD + half * 8;
+      acc = mma6(acc, arow, bq[0][0], bq[0][1], bq[0][2]);
+      acc = mma6(acc, arow + 16, bq[1][0], bq[1][1], bq[1][2]);
+      float* g = G + (rb * 32) * SXLD + c32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[acc_row(r, half) * SXLD] = acc[r];
+    }
+    if (mma_wave && b + 1 < NB) load_conv(b + 1, 0);
+    const float hbias = ho < dout ? wf[wp_head(n_hh) + WP_HEAD_BIAS + ho] : 0.f;
+    __syncthreads();
+    if (ho < dout) {      // T1 = G_1 + A G_2  (dout-wide)
+      float t1 = G[hrow * SXLD + dout + ho];
+      for (int k = 0; k < D; ++k) {
+        const int2 en = ellw[k * STM + hrow];
+        t1 = fmaf(__int_as_float(en.y), G[en.x * SXLD + 2 * dout + ho], t1);
+      }
+      G[STM * SXLD + hrow * SXLD + ho] = t1;
+    }
+    __syncthreads();
+    if (ho < dout) {
+      float o = G[hrow * SXLD + ho];
+      for (int k = 0; k < D; ++k) {
+        const int2 en = ellw[k * STM + hrow];
+        o = fmaf(__int_as_float(en.y), G[STM * SXLD + en.x * SXLD + ho], o);
+      }
+      o += hbias;
+      if (skip) o += x8[hrow * SFN + ho];
+      if (b + 1 < NB) {
+        x8[hrow * SFN + ho] = hrow < R ? o : 0.f;      // the next block's input stays in LDS
+        if (hrow < R) p.xs[((size_t)(b + 1) * N + ts + hrow) * SFN + ho] = o;
+      } else if (hrow < R) {
+        p.out[(int64_t)(ts + hrow) * p.ldo + ho] = o;
+      }
+    }
+    __syncthreads();
+    SSTAMP(0, b == 0);             // 4 + 6 n_hh: head done
+  }
+  SSTAMP(0, true);                 // last: all blocks done
+}
+
+static size_t stack_fwd_lds(int D) { return (size_t)(STM * SXLD * 4 + STM * SFN + STM * 4 + D * STM * 8) * 4 + (size_t)D * STM * 8 + (size_t)D * STM * 4; }
+
+// =====================================================================================================================
+// backward
+// =====================================================================================================================
+__device__ __forceinline__ f32x16 wgrad_block(f32x16 acc, const float* zcol, const float* acol, int half) {
+  // acc[j][i] += sum over the tile's 64 rows of Z[row][j] a[row][i]   (fp32 MFMA: k = row, two rows per instruction)
+#pragma unroll 8
+  for (int s = 0; s < 32; ++s) {
+    const int row = s + 32 * half;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zcol[row * SZLD], acol[row * SXLD], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+__global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int D = p.ell_width, DT = p.ellT_width;
+  float* Z = smem;                                    // [64][100]: Z_0 = g | Z_1 = A^T g | Z_2 = (A^T)^2 g
+  float* A0 = Z + STM * SZLD;                         // [64][36] x 2: the layer's saved input activation (ping-pong)
+  float* A1 = A0 + STM * SXLD;
+  float* stg = A1 + STM * SXLD;                       // [64][36]: data gradient before the gate; U0 in the edge phase
+  float* U1 = stg + STM * SXLD;                       // [64][36]
+  float* x8 = U1 + STM * SXLD;                        // [64][8] block input
+  float* gx = x8 + STM * SFN;                         // [64][8] gradient of the block output
+  float* dps = gx + STM * SFN;                        // [64][4]
+  float* w1L = dps + STM * 4;                         // [32][24]
+  float* accS = w1L + SH * SW1LD;                     // bias sums: db[l][32] (l < 7) | dbf[3][32] | dbh[8]
+  constexpr int ACC_DBF = S_MAX_HH * SH, ACC_DBH = ACC_DBF + SNM * SH, ACC_WORDS = ACC_DBH + 8;
+  float* eaL = accS + ACC_WORDS;                      // [D][64][8]
+  float* eaT = eaL + D * STM * 8;                     // [DT][64][8]
+  int2* ellTw = reinterpret_cast<int2*>(eaT + DT * STM * 8);    // [DT][64]
+  int* other = reinterpret_cast<int*>(ellTw + DT * STM);        // [D][64]
+  int* otherT = other + D * STM;                                // [DT][64]
+  const int tid = threadIdx.x, lane = tid & 63, c32 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_hh = p.dims.n_hh, NB = p.dims.n_blocks;
+  const int64_t N = p.n_nodes;
+  const uint64_t dseed = p.drop_state ? p.drop_state[0] : 0, doff = p.drop_state ? p.drop_state[1] : 0;
+  const int blk_words = wp_block_words(n_hh);
+  const int prow = tid >> 3, pcq = (tid & 7) * 4, ho = tid & 7;
+  const int bsz_inner = fl_block(n_hh, p.dims.dout_inner);
+  float* Abuf[2] = {A0, A1};
+
+  for (int b = NB - 1; b >= 0; --b) {
+    const float* wf = reinterpret_cast<const float*>(p.wpack + (size_t)b * blk_words);
+    const int dout = (b == NB - 1) ? p.dims.dout_last : p.dims.dout_inner;
+    const bool skip = (b == NB - 1) ? p.dims.skip_last != 0 : p.dims.skip_inner != 0;
+    const bool need_dx = b > 0 || p.dx_out != nullptr;
+    const float* act_b = p.acts + (size_t)b * (n_hh + 1) * N * SH;
+    const float* xin = b == 0 ? p.x : p.xs + (size_t)b * N * SFN;
+    const int64_t ldxin = b == 0 ? p.ldx : SFN;
+    // persistent over this workgroup's tiles: weight-gradient accumulators
+    f32x16 acc0 = zero16(), acc1 = zero16(), acc2 = zero16();
+    float dw[SFC], db1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < SFC; ++q) dw[q] = 0.f;
+    const float bb = wf[WP_B1 + c32];
+    for (int idx = tid; idx < SH * SW1LD; idx += 512) w1L[idx] = wf[WP_W1 + idx];
+    for (int idx = tid; idx < ACC_WORDS; idx += 512) accS[idx] = 0.f;
+
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+      const int ts = p.tile_start[tile], R = p.tile_start[tile + 1] - ts;
+      [[maybe_unused]] int sidx = 0;
+      [[maybe_unused]] const bool st_on = b == NB - 1 && tile == (int)blockIdx.x;
+      SSTAMP(1, st_on);            // 0
+      // ---- stage the tile
+      for (int idx = tid; idx < STM * SFN; idx += 512) {
+        const int r = idx >> 3, c = idx & 7;
+        x8[idx] = r < R ? xin[(int64_t)(ts + r) * ldxin + c] : 0.f;
+        float g = 0.f;
+        if (r < R) {
+          if (b == NB - 1) { if (c < dout) g = p.gout[(int64_t)(ts + r) * p.ldg + c]; }
+          else g = p.dxbuf[(int64_t)(ts + r) * SFN + c];
+        }
+        gx[idx] = g;
+      }
+      if (tid < STM) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (tid < R) v = *reinterpret_cast<const f32x4*>(p.deg_pows + (int64_t)(ts + tid) * 4);
+        *reinterpret_cast<f32x4*>(dps + tid * 4) = v;
+      }
+      stage_ell_w(p.ellT_w, tile, DT, p.tm, ellTw, tid, 512);
+      stage_edges(p.ell_e, tile, D, p.tm, p.ea, p.ldea, other, eaL, tid, 512);
+      if (need_dx) stage_edges(p.ellT_e, tile, DT, p.tm, p.ea, p.ldea, otherT, eaT, tid, 512);
+      {   // the head's input activation h_{n_hh}
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (prow < R) v = *reinterpret_cast<const f32x4*>(act_b + ((size_t)n_hh * N + ts + prow) * SH + pcq);
+        *reinterpret_cast<f32x4*>(Abuf[n_hh & 1] + prow * SXLD + pcq) = v;
+      }
+      SSTAMP(1, st_on);            // 1: staging issued
+      __syncthreads();
+      SSTAMP(1, st_on);            // 2: staged
+
+      // ---- units u = n_hh (head), n_hh - 1 .. 0 (H -> H layers; conv 0 folded)
+      for (int u = n_hh; u >= 0; --u) {
+        const bool head = u == n_hh;
+        float* Acur = Abuf[u & 1];
+        // the input activation of the unit below, requested now, stored after the MFMA phase
+        f32x4 apf = {0.f, 0.f, 0.f, 0.f};
+        if (u > 0 && prow < R) apf = *reinterpret_cast<const f32x4*>(act_b + ((size_t)(u - 1) * N + ts + prow) * SH + pcq);
+        const int q0 = 3 * u;
+        const int wd0 = (q0 + 3) & 7, wd1 = (q0 + 4) & 7, wsp = (q0 + 5) & 7, wsp2 = (q0 + 6) & 7;
+        const bool dgrad_wave = wave == wd0 || wave == wd1;
+        const int drb = wave == wd1 ? 1 : 0;
+        // data-gradient operand fragments of this unit (L2), requested before the hops
+        bf16x8 bq[3][3];      // k-groups 0..2 now; 3..5 (H -> H layers) at the start of the MFMA phase, behind the first 18 MFMAs
+        const bf16x8* bsrc = reinterpret_cast<const bf16x8*>(p.wpack + (size_t)b * blk_words +
+                                                            (head ? wp_head(n_hh) + WP_HEAD_BWD : WP_CONV0 + u * WP_CONV_STRIDE + WP_CONV_BWD));
+        if (dgrad_wave) {
+#pragma unroll
+          for (int kg = 0; kg < 3; ++kg)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bq[kg][pl] = bsrc[((head && kg > 1 ? 1 : kg) * 3 + pl) * 64 + lane];
+        }
+        if (head) {
+          // Z[:, 0:dout] = g, then two dout-wide hops; columns 3 dout .. 31 zero
+          if (ho < dout) Z[prow * SZLD + ho] = gx[prow * SFN + ho];
+          for (int c = 3 * dout + ho; c < 32; c += 8) Z[prow * SZLD + c] = 0.f;
+          __syncthreads();
+          if (ho < dout) {
+            float t = 0.f;
+            for (int k = 0; k < DT; ++k) { const int2 en = ellTw[k * STM + prow]; t = fmaf(__int_as_float(en.y), Z[en.x * SZLD + ho], t); }
+            Z[prow * SZLD + dout + ho] = t;
+          }
+          __syncthreads();
+          if (ho < dout) {
+            float t = 0.f;
+            for (int k = 0; k < DT; ++k) { const int2 en = ellTw[k * STM + prow]; t = fmaf(__int_as_float(en.y), Z[en.x * SZLD + dout + ho], t); }
+            Z[prow * SZLD + 2 * dout + ho] = t;
+          }
+          __syncthreads();
+        } else {
+#pragma unroll
+          for (int m = 1; m < SNM; ++m) {
+            f32x4 U = {0.f, 0.f, 0.f, 0.f};
+            const float* src = Z + (m - 1) * SH + pcq;
+            for (int k = 0; k < DT; ++k) {
+              const int2 en = ellTw[k * STM + prow];
+              U += *reinterpret_cast<const f32x4*>(src + en.x * SZLD) * __int_as_float(en.y);
+            }
+            *reinterpret_cast<f32x4*>(Z + prow * SZLD + m * SH + pcq) = U;
+            __syncthreads();
+          }
+        }
+        SSTAMP(1, st_on);          // 3 + 5 i: hops done (i = n_hh - u)
+        // ---- ONE MFMA phase: weight gradients (3 waves), data gradient (2 waves), bias sums (spare waves)
+        {
+          const int nblk = head ? 1 : SNM;
+          for (int k = 0; k < nblk; ++k) {
+            const int q = q0 + k;
+            if (wave == (q & 7)) {
+              const float* zc = Z + k * SH + c32;
+              const float* ac = Acur + c32;
+              const int slot = q >> 3;
+              if (slot == 0) acc0 = wgrad_block(acc0, zc, ac, half);
+              else if (slot == 1) acc1 = wgrad_block(acc1, zc, ac, half);
+              else acc2 = wgrad_block(acc2, zc, ac, half);
+            }
+          }
+          if (dgrad_wave) {
+            f32x16 acc = zero16();
+            const float* arow = Z + (drb * 32 + c32) * SZLD + half * 8;
+            if (head) {
+              acc = mma6(acc, arow, bq[0][0], bq[0][1], bq[0][2]);
+              acc = mma6(acc, arow + 16, bq[1][0], bq[1][1], bq[1][2]);
+            } else {
+              bf16x8 b2[3][3];
+#pragma unroll
+              for (int kg = 0; kg < 3; ++kg)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b2[kg][pl] = bsrc[((3 + kg) * 3 + pl) * 64 + lane];
+#pragma unroll
+              for (int kg = 0; kg < 3; ++kg) acc = mma6(acc, arow + kg * 16, bq[kg][0], bq[kg][1], bq[kg][2]);
+#pragma unroll
+              for (int kg = 0; kg < 3; ++kg) acc = mma6(acc, arow + (3 + kg) * 16, b2[kg][0], b2[kg][1], b2[kg][2]);
+            }
+            float* g = stg + (drb * 32) * SXLD + c32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[acc_row(r, half) * SXLD] = acc[r];
+          }
+          if (wave == wsp) {
+            if (head) {      // db_head[o] += sum_rows g[row][o]
+              float s = 0.f;
+              const int o = lane & 7, part = lane >> 3;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) s += gx[(part * 8 + i) * SFN + o];
+              s += __shfl_xor(s, 8); s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+              if (lane < 8 && lane < dout) accS[ACC_DBH + lane] += s;
+            } else {         // db_u[c] += sum_rows g[row][c]
+              float s = 0.f;
+#pragma unroll 8
+              for (int i = 0; i < 32; ++i) s += Z[(i + 32 * half) * SZLD + c32];
+              s += __shfl_xor(s, 32);
+              if (lane < 32) accS[u * SH + lane] += s;
+            }
+          }
+          if (wave == wsp2 && u == 0) {      // folded conv 0: the bias term sum_m (A^m deg) bf_m^T  =>  dbf_m[c] += sum_rows (A^m deg)[row] g[row][c]
+#pragma unroll
+            for (int m = 0; m < SNM; ++m) {
+              float s = 0.f;
+#pragma unroll 8
+              for (int i = 0; i < 32; ++i) { const int row = i + 32 * half; s = fmaf(dps[row * 4 + m], Z[row * SZLD + c32], s); }
+              s += __shfl_xor(s, 32);
+              if (lane < 32) accS[ACC_DBF + m * SH + lane] += s;
+            }
+          }
+        }
+        SSTAMP(1, st_on);          // 4 + 5 i: this wave's MFMA-phase work done
+        __syncthreads();
+        SSTAMP(1, st_on);          // 5 + 5 i
+        // ---- gate: gradient w.r.t. the pre-activation output of the unit below (u > 0); u == 0: dS, no gate
+        {
+          f32x4 v = *reinterpret_cast<const f32x4*>(stg + prow * SXLD + pcq);
+          if (u > 0) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Acur + prow * SXLD + pcq);
+            f32x4 mult = {1.f, 1.f, 1.f, 1.f};
+            if (p.drop_state) mult = dropout_mult4(dseed, doff, (uint32_t)(b * p.drop_stride + u), (uint32_t)(ts + prow), (uint32_t)(pcq >> 2), p.drop_thr, p.drop_scale);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = a[q] > 0.f ? v[q] * mult[q] : 0.f;
+            *reinterpret_cast<f32x4*>(Abuf[(u - 1) & 1] + prow * SXLD + pcq) = apf;
+          }
+          if (prow >= R) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(Z + prow * SZLD + pcq) = v;
+        }
+        SSTAMP(1, st_on);          // 6 + 5 i: gate done
+        __syncthreads();
+        SSTAMP(1, st_on);          // 7 + 5 i
+      }
+
+      // ---- edge MLP backward: dS = Z[:, 0:32]
+      {
+        const int stream = wave * 2 + half;
+        float w[SW1LD];      // this lane's row of W1 (from the LDS copy: not kept live across the units above)
+#pragma unroll
+        for (int q4 = 0; q4 < SW1LD / 4; ++q4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(w1L + c32 * SW1LD + q4 * 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w[q4 * 4 + q] = v[q];
+        }
+#pragma unroll 1
+        for (int t = 0; t < STM / 16; ++t) {      // by target: dW1, db1, U0
+          const int r = stream + 16 * t;
+          const f32x4 ta = *reinterpret_cast<const f32x4*>(x8 + r * SFN), tb = *reinterpret_cast<const f32x4*>(x8 + r * SFN + 4);
+          const float gS = Z[r * SZLD + c32];
+          float u0 = 0.f;
+          for (int k = 0; k < D; ++k) {
+            const int o = other[k * STM + r];
+            if (o >= 0) {
+              const f32x4 sa = *reinterpret_cast<const f32x4*>(x8 + o * SFN), sb = *reinterpret_cast<const f32x4*>(x8 + o * SFN + 4);
+              const f32x4 e0 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8), e1 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8 + 4);
+              const float dz = edge_z(w, bb, ta, tb, sa, sb, e0, e1) > 0.f ? gS : 0.f;
+              u0 += dz;
+              db1 += dz;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                dw[q] = fmaf(dz, ta[q], dw[q]); dw[4 + q] = fmaf(dz, tb[q], dw[4 + q]);
+                dw[8 + q] = fmaf(dz, sa[q], dw[8 + q]); dw[12 + q] = fmaf(dz, sb[q], dw[12 + q]);
+                dw[16 + q] = fmaf(dz, e0[q], dw[16 + q]);
+              }
+              dw[20] = fmaf(dz, e1[0], dw[20]); dw[21] = fmaf(dz, e1[1], dw[21]);
+            }
+          }
+          stg[r * SXLD + c32] = u0;
+        }
+        if (need_dx) {
+#pragma unroll 1
+          for (int t = 0; t < STM / 16; ++t) {    // by source: U1
+            const int r = stream + 16 * t;
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(x8 + r * SFN), sb = *reinterpret_cast<const f32x4*>(x8 + r * SFN + 4);
+            float u1 = 0.f;
+            for (int k = 0; k < DT; ++k) {
+              const int o = otherT[k * STM + r];
+              if (o >= 0) {
+                const f32x4 ta = *reinterpret_cast<const f32x4*>(x8 + o * SFN), tb = *reinterpret_cast<const f32x4*>(x8 + o * SFN + 4);
+                const f32x4 e0 = *reinterpret_cast<const f32x4*>(eaT + (k * STM + r) * 8), e1 = *reinterpret_cast<const f32x4*>(eaT + (k * STM + r) * 8 + 4);
+                u1 += edge_z(w, bb, ta, tb, sa, sb, e0, e1) > 0.f ? Z[o * SZLD + c32] : 0.f;
+              }
+            }
+            U1[r * SXLD + c32] = u1;
+          }
+        }
+      }
+      SSTAMP(1, st_on);            // 3 + 5 (n_hh + 1): edge passes done
+      __syncthreads();
+      if (need_dx) {      // dx[row][c] = U0[row] . W1[:, c] + U1[row] . W1[:, 8 + c] (+ residual)
+        float s = skip ? gx[prow * SFN + ho] : 0.f;
+#pragma unroll 8
+        for (int j = 0; j < SH; ++j) {
+          s = fmaf(stg[prow * SXLD + j], w1L[j * SW1LD + ho], s);
+          s = fmaf(U1[prow * SXLD + j], w1L[j * SW1LD + SFN + ho], s);
+        }
+        if (prow < R) {
+          if (b > 0) p.dxbuf[(int64_t)(ts + prow) * SFN + ho] = s;
+          else p.dx_out[(int64_t)(ts + prow) * SFN + ho] = s;
+        }
+      }
+      __syncthreads();
+      SSTAMP(1, st_on);            // 4 + 5 (n_hh + 1): tile done
+    }
+
+    // ---- block end: this workgroup's slab of the block's weight gradients
+    {
+      float* sl = p.slab + (size_t)blockIdx.x * p.slab_stride + (size_t)b * bsz_inner;
+      // (the lane offset is made opaque here: otherwise the compiler forms the sixteen 64-bit store addresses of every slot
+      //  at the top of the block loop and carries them -- spilled -- through the whole tile loop)
+      int lane_off = 4 * half * SH + c32;
+      asm volatile("" : "+v"(lane_off));
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int q = 8 * s + wave;
+        const f32x16& a = s == 0 ? acc0 : (s == 1 ? acc1 : acc2);
+        if (q < 3 * n_hh) {
+          float* dst = sl + FL_CONV0 + (q / 3) * FL_CONV_STRIDE + (q % 3) * (SH * SH) + lane_off;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[acc_row(r, 0) * SH] = a[r];
+        } else if (q == 3 * n_hh) {
+          float* dst = sl + fl_head(n_hh) + lane_off;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const int jj = acc_row(r, half); if (jj < SNM * dout) dst[acc_row(r, 0) * SH] = a[r]; }
+        }
+      }
+      __syncthreads();      // every wave is done with the tile buffers: they become the W1 reduction scratch
+      float* red = smem;     // [16 streams][32][24]
+      {
+        const int stream = wave * 2 + half;
+        float* dst = red + (stream * SH + c32) * SW1LD;
+#pragma unroll
+        for (int q = 0; q < SFC; ++q) dst[q] = dw[q];
+        dst[SFC] = db1;
+      }
+      __syncthreads();
+      int t2 = tid;
+      asm volatile("" : "+v"(t2));      // (same reason as lane_off above)
+      for (int idx = t2; idx < SH * SW1LD; idx += 512) {
+        const int j = idx / SW1LD, q = idx - j * SW1LD;
+        if (q > SFC) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int st = 0; st < 16; ++st) s += red[(st * SH + j) * SW1LD + q];
+        if (q < SFC) sl[FL_W1 + j * SFC + q] = s; else sl[FL_B1 + j] = s;
+      }
+      for (int idx = t2; idx < n_hh * SH; idx += 512) sl[FL_CONV0 + (idx >> 5) * FL_CONV_STRIDE + SNM * SH * SH + (idx & 31)] = accS[idx];
+      if (t2 < SNM * SH) sl[FL_W2 + t2] = accS[ACC_DBF + t2];      // dbf_m travels in the W2 section (the reduce kernel knows)
+      if (t2 < dout) sl[fl_head(n_hh) + SNM * dout * SH + t2] = accS[ACC_DBH + t2];
+    }
+    // the block below reads the dx rows this workgroup has just written (global memory): make them visible
+    __threadfence();
+    __syncthreads();
+  }
+}
+
+static size_t stack_bwd_lds(int D, int DT) {
+  const size_t f = (size_t)STM * SZLD + 4 * STM * SXLD + 2 * STM * SFN + STM * 4 + SH * SW1LD + (S_MAX_HH * SH + SNM * SH + 8) +
+                   (size_t)(D + DT) * STM * 8;
+  return f * 4 + (size_t)DT * STM * 8 + (size_t)(D + DT) * STM * 4;
+}
+
+// =====================================================================================================================
+// reduce: fixed-order sum of the slabs + chain rule of the fold
+// =====================================================================================================================
+// Stage 1: flat[i] = sum over the slabs, for every i (the folded sections hold dWf | db0 | dbf afterwards).  A workgroup owns
+// 64 consecutive floats; its 256 threads are 16 slab lanes x 16 float4 columns: lane s sums slabs s, s + 16, .. (independent
+// loads, all in flight), the 16 partial sums meet in LDS and are added in lane order -- fixed order, bitwise reproducible.
+// The folded sections [W2 | b2 | conv 0] of every block (they hold dbf | .. | dWf | db0 here) are ALSO written to `gsrc`,
+// the read-only source of stage 2, which overwrites them in `flat` with the chain rule's results.
+__global__ void __launch_bounds__(256) stack_reduce_kernel(const float* __restrict__ slab, int n_slabs, int64_t stride,
+                                                           float* __restrict__ flat, int64_t total, float* __restrict__ gsrc,
+                                                           int bsz_inner, int n_blocks) {
+  __shared__ f32x4 part[16][16];
+  const int tid = threadIdx.x, cl = tid & 15, sl = tid >> 4;
+  const int64_t i4 = ((int64_t)blockIdx.x * 16 + cl) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i4 + 4 <= total) {
+    int k = sl;
+#pragma unroll 1
+    for (; k + 48 < n_slabs; k += 64) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(slab + (size_t)k * stride + i4);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(slab + (size_t)(k + 16) * stride + i4);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(slab + (size_t)(k + 32) * stride + i4);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(slab + (size_t)(k + 48) * stride + i4);
+      s += a; s += b; s += c; s += d;
+    }
+    for (; k < n_slabs; k += 16) s += *reinterpret_cast<const f32x4*>(slab + (size_t)k * stride + i4);
+  } else if (i4 < total) {
+    for (int k = sl; k < n_slabs; k += 16)
+      for (int q = 0; i4 + q < total; ++q) s[q] += slab[(size_t)k * stride + i4 + q];
+  }
+  part[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && i4 < total) {
+    f32x4 t = part[0][cl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += part[k][cl];
+    if (i4 + 4 <= total) *reinterpret_cast<f32x4*>(flat + i4) = t;
+    else for (int q = 0; i4 + q < total; ++q) flat[i4 + q] = t[q];
+    int b = (int)(i4 / bsz_inner);
+    if (b > n_blocks - 1) b = n_blocks - 1;
+    const int rel = (int)(i4 - (int64_t)b * bsz_inner);      // (section bounds and block sizes are multiples of 4)
+    constexpr int span = FL_CONV0 + FL_CONV_STRIDE - FL_W2;
+    if (rel >= FL_W2 && rel < FL_W2 + span) *reinterpret_cast<f32x4*>(gsrc + (size_t)b * span + (rel - FL_W2)) = t;
+  }
+}
+
+// Stage 2: the chain rule of the fold.  Workgroup (b, r): r < 3 writes dW_r of conv 0, r == 3 writes dW2 and db2, into
+// `flat`; all of them read the reduced folded gradients from `gsrc` (stage 1's copy), so no workgroup reads what another
+// overwrites.  conv 0's bias gradient (db0) is already in place.
+__global__ void __launch_bounds__(256) stack_fold_bwd_kernel(const dss2_stack_dims d, const float* const* __restrict__ params,
+                                                             const float* __restrict__ gsrc, float* __restrict__ flat) {
+  __shared__ float A[SNM][SH][SH + 1], Bm[SNM][SH][SH + 1], dbf[SNM][SH], b2s[SH];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x >> 2, r = blockIdx.x & 3;
+  const int bsz_inner = fl_block(d.n_hh, d.dout_inner);
+  const float* const* P = params + (size_t)b * params_per_block(d.n_hh);
+  const float* gs = gsrc + (size_t)b * (FL_CONV0 + FL_CONV_STRIDE - FL_W2);      // [dbf 96 | pad .. | dWf 3072 | db0 32] = the W2|b2|conv0 span
+  const float* dWf = gs + (FL_CONV0 - FL_W2);
+  float* fb = flat + (size_t)b * bsz_inner;
+  if (tid < SNM * SH) dbf[tid >> 5][tid & 31] = gs[tid];
+  if (tid < SH) b2s[tid] = P[3][tid];
+  if (r < SNM) {
+    // dW_r[j][i] = sum_c dWf_r[j][c] W2[i][c] + dbf_r[j] b2[i]
+    for (int idx = tid; idx < SH * SH; idx += 256) { A[0][idx >> 5][idx & 31] = dWf[r * SH * SH + idx]; Bm[0][idx >> 5][idx & 31] = P[2][idx]; }
+    __syncthreads();
+    for (int idx = tid; idx < SH * SH; idx += 256) {
+      const int j = idx >> 5, i = idx & 31;
+      float s = dbf[r][j] * b2s[i];
+#pragma unroll
+      for (int c = 0; c < SH; ++c) s = fmaf(A[0][j][c], Bm[0][i][c], s);
+      fb[FL_CONV0 + r * SH * SH + idx] = s;
+    }
+    return;
+  }
+  // dW2[i][c] = sum_m sum_j W_m[j][i] dWf_m[j][c];  db2[i] = sum_m sum_j W_m[j][i] dbf_m[j]
+  for (int idx = tid; idx < SNM * SH * SH; idx += 256) {
+    const int m = idx >> 10, j = (idx >> 5) & 31, c = idx & 31;
+    A[m][j][c] = dWf[idx];
+    Bm[m][j][c] = P[4 + 1 + m][j * SH + c];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < SH * SH; idx += 256) {
+    const int i = idx >> 5, c = idx & 31;
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < SNM; ++m)
+      for (int j = 0; j < SH; ++j) s = fmaf(Bm[m][j][i], A[m][j][c], s);
+    fb[FL_W2 + idx] = s;
+  }
+  if (tid < SH) {
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < SNM; ++m)
+      for (int j = 0; j < SH; ++j) s = fmaf(Bm[m][j][tid], dbf[m][j], s);
+    fb[FL_B2 + tid] = s;
+  }
+}
+
+static bool dims_ok(const dss2_stack_dims& d) {
+  return d.n_blocks >= 1 && d.n_blocks <= 64 && d.n_hh >= 1 && d.n_hh <= S_MAX_HH && d.dout_last >= 1 && d.dout_last <= 8 &&
+         (d.n_blocks == 1 || d.dout_inner == SFN) && (!d.skip_last || d.dout_last == SFN);
+}
+
+}  // namespace dss2
+
+using namespace dss2;
+
+#ifdef DSS2_STACK_STAMPS
+extern "C" int dss2_debug_read_sstamps(unsigned long long* host_out, int which) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dss2::g_sstamps), sizeof(unsigned long long) * 64 * 8 * 128,
+                                  sizeof(unsigned long long) * 64 * 8 * 128 * (size_t)which);
+}
+#endif
+
+extern "C" int64_t dss2_stack_wpack_words(const dss2_stack_dims* d) { return (int64_t)d->n_blocks * wp_block_words(d->n_hh); }
+
+extern "C" int64_t dss2_stack_fold_scratch_floats(const dss2_stack_dims* d) { return (int64_t)d->n_blocks * (FL_CONV0 + FL_CONV_STRIDE - FL_W2); }
+
+extern "C" int64_t dss2_stack_flat_floats(const dss2_stack_dims* d) {
+  return (int64_t)(d->n_blocks - 1) * fl_block(d->n_hh, d->dout_inner) + fl_block(d->n_hh, d->dout_last);
+}
+
+extern "C" int dss2_stack_supported(const dss2_stack_dims* d, int hid, int nmat, int fn, int fe, int nrb, int ell_width, int ellT_width) {
+  return (dims_ok(*d) && hid == SH && nmat == SNM && fn == SFN && fe == 6 && (nrb == 1 || nrb == 2) && ell_width >= 1 &&
+          ell_width <= S_MAX_ELL && ellT_width >= 1 && ellT_width <= S_MAX_ELL) ? 1 : 0;
+}
+
+extern "C" int dss2_stack_pack(const dss2_stack_dims* d, const float* const* params, uint32_t* wpack, uint64_t* rng_state,
+                               uint64_t* rng_snapshot, uint64_t host_seed, int use_host_seed, float* tick, void* stream) {
+  if (!dims_ok(*d) || !params || !wpack) { set_error("stack_pack: bad arguments"); return 2; }
+  if (rng_snapshot && !use_host_seed && !rng_state) { set_error("stack_pack: rng_state missing"); return 2; }
+  hipLaunchKernelGGL(stack_pack_kernel, dim3(d->n_blocks * (d->n_hh * SNM + 2)), dim3(256), 0, as_stream(stream), *d, params, wpack,
+                     reinterpret_cast<unsigned long long*>(rng_state), reinterpret_cast<unsigned long long*>(rng_snapshot),
+                     (unsigned long long)host_seed, use_host_seed, tick);
+  return check_launch("stack_pack");
+}
+
+static int stack_args_ok(const dss2_stack_args& a, const char* what) {
+  if (!dims_ok(a.dims)) { set_error("%s: unsupported dimensions", what); return 2; }
+  if (a.tm != 32 && a.tm != 64) { set_error("%s: tiles of %d rows (needs 32 or 64)", what, a.tm); return 2; }
+  if (a.ell_width < 1 || a.ell_width > S_MAX_ELL) { set_error("%s: ELL width %d", what, a.ell_width); return 2; }
+  if (!a.x || !a.ea || !a.wpack || !a.tile_start || !a.ell_w || !a.ell_e || !a.deg_pows || !a.acts || (a.dims.n_blocks > 1 && !a.xs)) {
+    set_error("%s: null argument", what); return 2;
+  }
+  return 0;
+}
+
+extern "C" int dss2_stack_forward(const dss2_stack_args* ap, void* stream) {
+  const dss2_stack_args& a = *ap;
+  if (a.ntiles <= 0) return 0;
+  if (int rc = stack_args_ok(a, "stack_forward")) return rc;
+  if (!a.out) { set_error("stack_forward: null output"); return 2; }
+  static std::atomic<uint32_t> done{0};
+  if (ensure_max_lds(reinterpret_cast<const void*>(stack_fwd_kernel), done, "stack_forward")) return 1;
+  hipLaunchKernelGGL(stack_fwd_kernel, dim3(a.ntiles), dim3(512), stack_fwd_lds(a.ell_width), as_stream(stream), a);
+  return check_launch("stack_forward");
+}
+
+extern "C" int dss2_stack_backward(const dss2_stack_args* ap, void* stream) {
+  const dss2_stack_args& a = *ap;
+  if (a.ntiles <= 0) return 0;
+  if (int rc = stack_args_ok(a, "stack_backward")) return rc;
+  if (a.ellT_width < 1 || a.ellT_width > S_MAX_ELL || !a.ellT_w || !a.ellT_e) { set_error("stack_backward: transposed ELL slices missing"); return 2; }
+  if (!a.gout || !a.slab || a.n_wg < 1 || a.n_wg > a.ntiles || (a.dims.n_blocks > 1 && !a.dxbuf)) { set_error("stack_backward: bad arguments"); return 2; }
+  if (a.slab_stride < dss2_stack_flat_floats(&a.dims)) { set_error("stack_backward: slab stride too small"); return 2; }
+  static std::atomic<uint32_t> done{0};
+  if (ensure_max_lds(reinterpret_cast<const void*>(stack_bwd_kernel), done, "stack_backward")) return 1;
+  hipLaunchKernelGGL(stack_bwd_kernel, dim3(a.n_wg), dim3(512), stack_bwd_lds(a.ell_width, a.ellT_width), as_stream(stream), a);
+  return check_launch("stack_backward");
+}
+
+extern "C" int dss2_stack_reduce(const dss2_stack_dims* d, const float* slab, int32_t n_slabs, int64_t slab_stride,
+                                 const float* const* params, float* flat, float* fold_scratch, void* stream) {
+  if (!dims_ok(*d) || !slab || !params || !flat || !fold_scratch || n_slabs < 1 || (slab_stride & 3)) { set_error("stack_reduce: bad arguments"); return 2; }
+  const int64_t total = dss2_stack_flat_floats(d);
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(stack_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, slab, (int)n_slabs, slab_stride, flat, total,
+                     fold_scratch, fl_block(d->n_hh, d->dout_inner), d->n_blocks);
+  hipLaunchKernelGGL(stack_fold_bwd_kernel, dim3(d->n_blocks * 4), dim3(256), 0, s, *d, params, fold_scratch, flat);
+  return check_launch("stack_reduce");
+}

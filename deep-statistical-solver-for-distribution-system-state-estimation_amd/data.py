@@ -50,16 +50,59 @@ def _fill_args(topo: Topology, input, edge_input, output, node_param, edge_param
     a.n_nodes, a.n_edges = topo.N, topo.E
     a.lam_v, a.lam_p, a.lam_pf, a.lam_reg = (float(reg_coefs[k]) for k in ("lam_v", "lam_p", "lam_pf", "lam_reg"))
     a.sums, a.partials, a.vminmax = bufs["sums"].data_ptr(), bufs["partials"].data_ptr(), bufs["vminmax"].data_ptr()
-    a.apq, a.loss, a.grad_output = bufs["apq"].data_ptr(), bufs["loss"].data_ptr(), bufs["grad"].data_ptr()
+    a.apq, a.loss = bufs["apq"].data_ptr(), bufs["loss"].data_ptr()
+    a.grad_output = bufs["grad"].data_ptr() if bufs.get("grad") is not None else None
     a.pflow = bufs["pflow"].data_ptr() if bufs.get("pflow") is not None else None
     return a
 
 
+_VMM_CACHE = {}        # id(base tensor) -> (weakref, version, data_ptr, shape, strides, vminmax scratch)
+_COUNTERS = {}         # device -> zeroed int32 word of the fused finish (the kernel re-zeroes it after every use)
+
+
+def _vminmax_scratch(node_param: torch.Tensor):
+    """(scratch [130], valid): the per-workgroup (min, max) pairs of ``node_param[:, 0]`` (vn_kv) are a constant of the
+    batch tensor, so they are computed once per tensor and not once per step: the cache is keyed by the identity of the
+    tensor that owns the storage (``x`` for the usual ``x[:, 8:]`` view), its version counter, address and layout, and an
+    entry dies with its tensor."""
+    import weakref
+    base = node_param._base if node_param._base is not None else node_param
+    key = id(base)
+    sig = (base._version, node_param.data_ptr(), tuple(node_param.shape), tuple(node_param.stride()))
+    hit = _VMM_CACHE.get(key)
+    if hit is not None and hit[0]() is base and hit[1] == sig:
+        return hit[2], True
+    vmm = torch.empty(130, dtype=_F32, device=node_param.device)
+    if torch.cuda.is_current_stream_capturing():
+        return vmm, False       # computed by the captured launch on every replay; never cached (a capture executes nothing)
+    if len(_VMM_CACHE) >= 64:
+        _VMM_CACHE.pop(next(iter(_VMM_CACHE)))
+
+    def _drop(ref, key=key):
+        h = _VMM_CACHE.get(key)
+        if h is not None and h[0] is ref:
+            _VMM_CACHE.pop(key, None)
+    _VMM_CACHE[key] = (weakref.ref(base, _drop), sig, vmm)
+    return vmm, False
+
+
+def _counter(dev) -> torch.Tensor:
+    c = _COUNTERS.get(dev)
+    if c is None:
+        c = _COUNTERS[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return c
+
+
 class _WlsFn(torch.autograd.Function):
-    """loss, output = f(output): `output` is modified in place (theta masked) and marked dirty."""
+    """loss, output = f(output): `output` is modified in place (theta masked) and marked dirty.
+
+    Forward = ONE launch (`dss2_wls_loss_partials`: flows, injections, residual coefficients, the five batch sums; its last
+    workgroup sums the partials in a fixed order and writes the loss); backward = ONE launch (`dss2_wls_loss_grad`, which
+    takes autograd's upstream gradient as a device scalar).  Data-parallel: the sums are all-reduced after the forward
+    launch and a one-thread launch re-evaluates the loss from the global sums."""
 
     @staticmethod
-    def forward(ctx, output, topo, tensors, reg_coefs, group, pflow_out=None):
+    def forward(ctx, output, topo, tensors, reg_coefs, group, pflow_out=None, node_param_orig=None):
         input, edge_input, node_param, edge_param, x_mean, x_std, edge_mean, edge_std = tensors
         ctx.set_materialize_grads(False)
         dev = output.device
@@ -67,42 +110,56 @@ class _WlsFn(torch.autograd.Function):
         if output.dim() != 2 or output.size(1) != 2 or output.stride(1) != 1:
             raise ValueError("output must be [N, 2] with unit column stride")
         nb = (N + 255) // 256
+        vmm, vmm_valid = _vminmax_scratch(node_param_orig if node_param_orig is not None else node_param[0])
         bufs = {
             "sums": torch.empty(8, dtype=torch.float64, device=dev),
             "partials": torch.empty(nb * 5, dtype=torch.float64, device=dev),
-            "vminmax": torch.empty(130, dtype=_F32, device=dev),
+            "vminmax": vmm,
             "apq": torch.empty(N, 2, dtype=_F32, device=dev),
             "loss": torch.empty(1, dtype=_F32, device=dev),
-            "grad": torch.empty(N, 2, dtype=_F32, device=dev),
+            "grad": None,
             "pflow": pflow_out,
         }
         a = _fill_args(topo, input, edge_input, (output, output.stride(0)), node_param, edge_param,
                        x_mean, x_std, edge_mean, edge_std, reg_coefs, bufs)
+        a.flags = _lib.WLS_FUSED_FINISH | (_lib.WLS_VMM_CACHED if vmm_valid else 0)
+        a.counter = _counter(dev).data_ptr()
         st = _stream(output)
         L = _lib.lib()
         _lib.check(L.dss2_wls_loss_partials(C.byref(a), st), "dss2_wls_loss_partials")
         if group is not None:   # global-batch sums and counts (exact data-parallel loss)
             from . import parallel
             parallel.allreduce_loss_sums(bufs["sums"], group)
-        _lib.check(L.dss2_wls_loss_grad(C.byref(a), st), "dss2_wls_loss_grad")
+            _lib.check(L.dss2_wls_loss_value(C.byref(a), st), "dss2_wls_loss_value")
         ctx.mark_dirty(output)
-        ctx.save_for_backward(bufs["grad"])
-        ctx.keep = (bufs, tensors)   # keep scratch alive until the kernels have run
+        ctx.save_for_backward(output)        # (the backward launch reads the masked output: autograd checks it is unmodified)
+        ctx.keep = (bufs, tensors, topo, dict(reg_coefs))   # scratch and operands of the backward launch
         return bufs["loss"].reshape(()), output
 
     @staticmethod
     def backward(ctx, gloss, gout_unused):
-        (grad,) = ctx.saved_tensors
-        g = grad * gloss if gloss is not None else None
+        bufs, tensors, topo, reg_coefs = ctx.keep
+        (output,) = ctx.saved_tensors
+        input, edge_input, node_param, edge_param, x_mean, x_std, edge_mean, edge_std = tensors
+        dev = output.device
         if gloss is None:
-            g = torch.zeros_like(grad)
+            g = torch.zeros(topo.N, 2, dtype=_F32, device=dev)
+        else:
+            g = bufs["grad"] = torch.empty(topo.N, 2, dtype=_F32, device=dev)
+            gl = gloss if (gloss.dtype == _F32 and gloss.is_cuda) else gloss.to(device=dev, dtype=_F32)
+            a = _fill_args(topo, input, edge_input, (output, output.stride(0)), node_param, edge_param,
+                           x_mean, x_std, edge_mean, edge_std, reg_coefs, bufs)
+            a.flags = _lib.WLS_NO_LOSS_WRITE
+            a.gscale = gl.data_ptr()
+            _lib.check(_lib.lib().dss2_wls_loss_grad(C.byref(a), _stream(output)), "dss2_wls_loss_grad")
+            ctx.keep_g = gl
         if gout_unused is not None:
             # other consumers of the MASKED output: theta_out = theta_in * (1 - slack) (data.py:413), so their gradient
             # reaches the pre-mask theta scaled by (1 - slack), i.e. not at all at slack buses
             g = g + gout_unused
-            npar = ctx.keep[1][2][0]
+            npar = node_param[0]
             g[:, 1] = g[:, 1] - gout_unused[:, 1] * npar[:, 1]
-        return g, None, None, None, None, None
+        return g, None, None, None, None, None, None
 
 
 def gsp_wls_edge(input, edge_input, output, x_mean, x_std, edge_mean, edge_std, edge_index, reg_coefs,
@@ -122,7 +179,7 @@ def gsp_wls_edge(input, edge_input, output, x_mean, x_std, edge_mean, edge_std, 
     if pflow_out is not None and (pflow_out.dtype != _F32 or tuple(pflow_out.shape) != (topo.E, 8) or not pflow_out.is_contiguous()
                                   or pflow_out.device != dev):
         raise ValueError("pflow_out must be a contiguous [E, 8] fp32 tensor on the output's device")
-    loss, _ = _WlsFn.apply(output, topo, tensors, dict(reg_coefs), group, pflow_out)
+    loss, _ = _WlsFn.apply(output, topo, tensors, dict(reg_coefs), group, pflow_out, node_param)
     return loss
 
 

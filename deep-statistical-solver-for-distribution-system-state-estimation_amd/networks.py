@@ -1044,6 +1044,10 @@ class MPN(nn.Module):
     def forward(self, x, edge_index, edge_attr):
         _require_gpu(x, edge_index, edge_attr)
         topo = get_topology(edge_index, x.size(0))
+        from . import stack as _stack
+        dims = _stack.route(self, [self], topo)
+        if dims is not None:          # dim_hid 32, K 2: the whole-stack kernels (one launch forward, one backward)
+            return _stack.run(self, [self], dims, topo, x, edge_attr)
         return _MPNFn.apply(x, edge_attr, topo, self, *self._params())
 
 
@@ -1448,6 +1452,11 @@ class PFN(nn.Module):
                 x = m(x, edge_index, edge_attr)
             return x
         topo = get_topology(edge_index, x.size(0))
+        from . import stack as _stack
+        blocks = list(self.mpns)
+        dims = _stack.route(self, blocks, topo)
+        if dims is not None:          # the reference driver's own model line: ONE launch for all blocks of the stack
+            return _stack.run(self, blocks, dims, topo, x, edge_attr)
         params = [m._params() for m in self.mpns]
         return _PFNFn.apply(x, edge_attr, topo, self, tuple(len(p) for p in params), *[t_ for p in params for t_ in p])
 

@@ -20,11 +20,13 @@ class FusedAdamax(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.capturable = bool(capturable)
         self._table = {}
+        self._flat_table = {}
         self.table_builds = 0      # diagnostics: how often the descriptor table had to be rebuilt
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._table = {}           # the state tensors were replaced
+        self._flat_table = {}
         for g in self.param_groups:
             g.pop("_step", None)   # re-derived from the loaded per-parameter steps
 
@@ -62,6 +64,39 @@ class FusedAdamax(torch.optim.Optimizer):
                     st["exp_inf"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] = group["_step"]
 
+    def _step_flat(self, gi, group, ps, shared, step, dev) -> bool:
+        """ONE launch for all tensors when every gradient is a contiguous view of one flat bucket (what the backward of
+        this library hands to autograd): the descriptor table lives on the device and holds the gradients' offsets inside
+        the bucket, which do not change from step to step; only the bucket's address travels with the launch."""
+        g0 = ps[0].grad
+        base = g0.untyped_storage().data_ptr()
+        for p in ps:
+            g = p.grad
+            if not g.is_contiguous() or g.dtype != torch.float32 or g.untyped_storage().data_ptr() != base:
+                return False
+        offs = tuple(p.grad.storage_offset() for p in ps)
+        key = (tuple(p.data_ptr() for p in ps), offs)
+        cached = self._flat_table.get(gi)
+        if cached is None or cached[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                return False      # (a table upload cannot be captured: the by-value path below serves this step)
+            import numpy as np
+            arr = np.zeros((len(ps), 5), dtype=np.int64)
+            for i, p in enumerate(ps):
+                stp = self.state[p]
+                arr[i] = (p.data_ptr(), offs[i], stp["exp_avg"].data_ptr(), stp["exp_inf"].data_ptr(), p.numel())
+            tab = torch.from_numpy(arr).to(dev)
+            cached = self._flat_table[gi] = (key, tab, max(p.numel() for p in ps),
+                                             torch.zeros(1, dtype=torch.int32, device=dev))
+            self.table_builds += 1
+        _, tab, max_n, counter = cached
+        b1, b2 = group["betas"]
+        _lib.check(_lib.lib().dss2_adamax_step_flat(tab.data_ptr(), len(ps), max_n, base, float(group["lr"]), float(b1), float(b2),
+                                                    float(group["eps"]), float(group["weight_decay"]), int(step),
+                                                    (shared.data_ptr() if self.capturable else None), counter.data_ptr(),
+                                                    _lib.stream_ptr(dev)), "dss2_adamax_step_flat")
+        return True
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -90,11 +125,14 @@ class FusedAdamax(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_inf"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     self._table.pop(gi, None)
+                    self._flat_table.pop(gi, None)
                 if st.get("step") is not shared:
                     st["step"] = shared
             if not self.capturable:
                 shared += 1.0
                 step = int(shared)
+            if self._step_flat(gi, group, ps, shared, step if not self.capturable else 0, dev):
+                continue
             grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
             # host-side descriptor table, passed to the kernels BY VALUE (no device copy to keep alive, capture-safe);
             # parameter and state addresses are written once, the gradient addresses every step (the flat gradient

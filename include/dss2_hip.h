@@ -386,10 +386,20 @@ typedef struct dss2_wls_args {
   float* loss;             /* [1] device                                                   */
   float* grad_output;      /* [N,2] device, contiguous                                     */
   float* pflow;            /* optional [E,8]: get_pflow's 8 outputs per stored edge, or NULL */
+  int32_t flags;           /* DSS2_WLS_* below                                             */
+  uint32_t* counter;       /* DSS2_WLS_FUSED_FINISH: one device word, zero before the first use (the kernel re-zeroes it) */
+  const float* gscale;     /* dss2_wls_loss_grad: optional DEVICE scalar, the upstream gradient of the loss (autograd's
+                              grad_output): the kernel scales d loss / d output by it instead of a separate multiply */
 } dss2_wls_args;
+#define DSS2_WLS_VMM_CACHED 1     /* vminmax[] already holds this node_param's partial (min, max) pairs: no vminmax launch */
+#define DSS2_WLS_FUSED_FINISH 2   /* the LAST workgroup of the partials kernel to finish sums the workgroup partials in a
+                                     fixed order into sums[0..7] and writes the (local-batch) loss: no finish launch */
+#define DSS2_WLS_NO_LOSS_WRITE 4  /* dss2_wls_loss_grad leaves loss[0] alone */
 
 int dss2_wls_loss_partials(const dss2_wls_args* args_host, void* stream);
 int dss2_wls_loss_grad(const dss2_wls_args* args_host, void* stream);
+/* loss[0] <- the loss of the batch sums[0..6] describe (after a data-parallel caller has all-reduced them) */
+int dss2_wls_loss_value(const dss2_wls_args* args_host, void* stream);
 
 /* get_pflow alone (data.py:328-390; evaluation path dss2_run.py:193-194): y[N,2] = (v, theta)
  * in physical units; writes pflow[E,8] = loading_lines, loading_trafo, P_from, Q_from, P_to,
@@ -492,6 +502,84 @@ int dss2_adamax_step(const dss2_adamax_desc* descs_host, int n_desc, float lr, f
  * then used for the bias correction, so the launches can be captured into a hipGraph with the rest of the step. */
 int dss2_adamax_step_dev(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1, float beta2, float eps,
                          float weight_decay, float* step_dev, void* stream);
+
+/* ---- whole-stack kernels ("keep a graph resident in LDS across all L blocks") -------------------
+ * /root/reference/networks.py:340-388 (PFN / SkipPFN: PFN-L chained MPN / SkipMPN blocks on the same edge inputs) and
+ * :212-338 (one block), for the reference driver's own model line (dss2_run.py:72-88: dim_hid 32, K = 2, 8 layers,
+ * 5 blocks, dropout 0.3).  One launch walks a tile of whole graphs through EVERY block of the stack: edge MLP ->
+ * aggregation -> the H -> H TAGConv layers (conv 0 on the aggregated hidden with the edge MLP's second Linear folded
+ * in) -> the narrow head -> residual, the 8-wide block output handed to the next block in LDS.  The backward launch
+ * walks the same tiles through the blocks in reverse with data- and weight-gradients fused (weight gradients stay in
+ * MFMA accumulators / LDS across a workgroup's tiles; one slab per workgroup and block, summed in a fixed order by
+ * dss2_stack_reduce, which also applies the chain rule of the fold).  Covers dim_hid == 32, K == 2, dim_featn == 8,
+ * dim_feate == 6, block output widths <= 8, 2..8 layers per block, tiles of <= 64 rows with ELL slices; every other shape
+ * runs the per-block kernels above.
+ *
+ * params: DEVICE table of the blocks' parameter pointers in MPN._params() order, per block
+ *   [W1 (hid x 22), b1, W2 (hid x hid), b2, then per conv: bias, W_0, W_1, W_2]  = 4 + 4 * (n_hh + 1) pointers.
+ * wpack: uint32 scratch of dss2_stack_wpack_words() elements, rewritten by dss2_stack_pack every step (weights change).
+ * Gradient layout of dss2_stack_reduce's output = the blocks' flat layouts back to back, per block
+ *   [W1 | b1] [W2 | b2] then per conv [W_0 W_1 W_2 | bias]   (networks.MPN._flat_offsets). */
+typedef struct dss2_stack_dims {
+  int32_t n_blocks;        /* MPN blocks in the stack (1: a single MPN / SkipMPN) */
+  int32_t n_hh;            /* H -> H TAGConv layers per block = n_gnn_layers - 1, 1..7 */
+  int32_t dout_inner;      /* output width of blocks 0 .. n_blocks-2 (= dim_featn = 8) */
+  int32_t dout_last;       /* output width of the last block, <= 8 */
+  int32_t skip_inner;      /* SkipMPN residual on the inner blocks */
+  int32_t skip_last;       /* ... on the last block (a standalone SkipMPN) */
+} dss2_stack_dims;
+
+typedef struct dss2_stack_args {
+  dss2_stack_dims dims;
+  const float* x; int64_t ldx;               /* [N, 8] input of block 0 */
+  const float* ea; int64_t ldea;             /* [E, 6] stored edge features */
+  const uint32_t* wpack;
+  const int32_t* tile_start; int32_t ntiles; int32_t tm;      /* tm = 32 * nrb: row stride of the ELL tile slices */
+  const int32_t* ell_w; const int32_t* ell_e; int32_t ell_width;        /* by target: {local col, weight} / {local col, ent} */
+  const int32_t* ellT_w; const int32_t* ellT_e; int32_t ellT_width;     /* by source (backward only) */
+  const float* deg_pows;                     /* [N, 4] column m = A^m deg */
+  float* xs;                                 /* [n_blocks][N][8]: slot b = input of block b (slot 0 unused) */
+  float* acts;                               /* [n_blocks][n_hh + 1][N][32]: slot 0 = aggregated hidden S, slot l = h_l */
+  float* out; int64_t ldo;                   /* forward: [N, dout_last] */
+  const float* gout; int64_t ldg;            /* backward: gradient of out */
+  float* dxbuf;                              /* backward scratch [N][8]: gradient between blocks */
+  float* dx_out;                             /* backward, optional: gradient of x [N][8] */
+  float* slab; int64_t slab_stride; int32_t n_wg;     /* backward: n_wg persistent workgroups, one slab each */
+  const uint64_t* drop_state; uint32_t drop_thr; float drop_scale; int32_t drop_stride;   /* mask id = b * drop_stride + l + 1 */
+  int64_t n_nodes;
+} dss2_stack_args;
+
+int64_t dss2_stack_wpack_words(const dss2_stack_dims* dims);
+int64_t dss2_stack_flat_floats(const dss2_stack_dims* dims);
+/* 1 when the shape is covered (see above); 0 otherwise (the caller then runs the per-block kernels) */
+int dss2_stack_supported(const dss2_stack_dims* dims, int hid, int nmat, int fn, int fe, int nrb, int ell_width, int ellT_width);
+/* fold (Wf_m = W_m W2, bf_m = W_m b2 of conv 0), bf16x3 fragment packing of every matrix for the forward and the
+ * data-gradient GEMMs, copies of W1 / b1 / biases -- ONE launch per step.  rng_state / rng_snapshot (optional): the
+ * dropout state hand-over of dss2_rng_next done by the same launch.  tick (optional): *tick += 1 (the device-side step
+ * count of a capturable optimizer). */
+int dss2_stack_pack(const dss2_stack_dims* dims, const float* const* params, uint32_t* wpack, uint64_t* rng_state,
+                    uint64_t* rng_snapshot, uint64_t host_seed, int use_host_seed, float* tick, void* stream);
+int dss2_stack_forward(const dss2_stack_args* args, void* stream);
+int dss2_stack_backward(const dss2_stack_args* args, void* stream);
+/* flat[i] = sum over the n_slabs slabs (fixed order; slab_stride a multiple of 4), then the chain rule of the fold: conv 0's
+ * and W2 / b2's gradients from the folded ones (dW_m = dWf_m W2^T + dbf_m (x) b2; dW2 = sum_m W_m^T dWf_m;
+ * db2 = sum_m W_m^T dbf_m).  Two launches. */
+int dss2_stack_reduce(const dss2_stack_dims* dims, const float* slab, int32_t n_slabs, int64_t slab_stride,
+                      const float* const* params, float* flat, float* fold_scratch, void* stream);
+int64_t dss2_stack_fold_scratch_floats(const dss2_stack_dims* dims);      /* size of fold_scratch (device floats) */
+
+/* The same update as ONE launch for any number of tensors whose gradients are views of ONE flat bucket (what every
+ * backward of this library produces: networks._MPNFn / _PFNFn / stack._FusedStackFn): descs_dev is a DEVICE table that
+ * holds, per tensor, the element offset of its gradient inside the bucket -- constant from step to step, so the table is
+ * written once -- and grad_base, the bucket's address of THIS step, travels by value.  step >= 1: host-side step count;
+ * step == 0: the count lives in *step_dev (float) and is advanced by the launch itself (its last workgroup to finish;
+ * counter = one device word, zero before the first use), so the launch can be captured into a hipGraph. */
+typedef struct dss2_adamax_flat_desc {
+  float* param; int64_t grad_off; float* exp_avg; float* exp_inf; int64_t n;
+} dss2_adamax_flat_desc;
+int dss2_adamax_step_flat(const dss2_adamax_flat_desc* descs_dev, int n_desc, int64_t max_n, const float* grad_base, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int step, float* step_dev,
+                          uint32_t* counter, void* stream);
 
 /* LDS bytes a dss2_gemm_prop / dss2_wgrad launch will request (host-side helper; lets the
  * caller reject configurations that do not fit the 160 KiB LDS before launching). */

@@ -1,0 +1,201 @@
+"""GPU (-m gpu): the whole-stack kernels (csrc/dss2_stack.hip, stack.py) -- the reference driver's own model line
+SkipPFN(dim_hid 32, 8 layers, K 2, dropout 0.3, L 5) (/root/reference/dss2_run.py:72-88, networks.py:340-388) as ONE
+forward and ONE backward launch.  Checked against the fp64 oracle (on the very dropout masks the kernels applied), against
+the per-block kernels (DSS2_STACK_KERNEL=0 path, same library), for bitwise reproducibility, on ragged mixed-topology
+tiles, with an input that requires a gradient, and inside a hipGraph with the optimizer.  The golden cases skipmpn / pfn /
+skippfn / mpn_undirected_input of tests/test_gpu_parity.py run through this path too (it is the default route)."""
+import importlib
+
+import pytest
+import torch
+
+from conftest import PKG_NAME, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _stack_mod():
+    return importlib.import_module(PKG_NAME + ".stack")
+
+
+def _blocks(m):
+    return list(m.mpns) if hasattr(m, "mpns") else [m]
+
+
+def _train(pkg, oracle, model, b, with_input_grad=False):
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    st = tuple(s.to(DEV) for s in b["stats"])
+    for q in model.parameters():
+        q.grad = None
+    xin = x[:, :8].clone().requires_grad_(True) if with_input_grad else x[:, :8]
+    out = model(xin, ei, ea[:, :6])
+    if out.size(1) == 2:
+        loss = pkg.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2],
+                                edge_std=st[3], edge_index=ei, reg_coefs=oracle.DEFAULT_REG_COEFS, num_samples=None,
+                                node_param=x[:, 8:], edge_param=ea[:, 6:])
+    else:       # a SkipMPN block on its own has 8 outputs: no WLS loss on those
+        loss = (out * torch.linspace(-1.0, 1.0, out.numel(), device=out.device).view_as(out)).sum()
+    loss.backward()
+    grads = [q.grad.detach().clone() for q in model.parameters()]
+    # (the loss masks theta at the slack buses in place, data.py:413: `out` is returned as the oracle's train_step returns it)
+    return out.detach().clone(), loss.detach().clone(), grads, (xin.grad.detach().clone() if with_input_grad else None)
+
+
+def _oracle_run(pkg, oracle, cls, args, model, b, with_input_grad=False):
+    """fp64 oracle on the masks the kernels applied in the model's LAST forward."""
+    ref = getattr(oracle, cls)(*args).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in model.state_dict().items()})
+    N, hid, p = b["x"].shape[0], args[3], args[6]
+    if p > 0:
+        for bm, br in zip(_blocks(model), _blocks(ref)):
+            snap, pp = bm._last_dropout
+            base = getattr(bm, "_drop_base", 0)
+            br.dropout_masks = [pkg.networks.dropout_mask(snap, pp, base + l + 1, N, hid).cpu() for l in range(bm.n_gnn_layers - 1)]
+    b64 = {"x": b["x"].double(), "edge_index": b["edge_index"], "edge_attr": b["edge_attr"].double()}
+    if with_input_grad:
+        xin = b64["x"][:, :8].clone().requires_grad_(True)
+        b64 = dict(b64, x=torch.cat([xin, b64["x"][:, 8:]], 1))
+    if args[2] == 2:
+        out64, l64 = oracle.train_step(ref, b64, tuple(s.double() for s in b["stats"]))
+    else:
+        out64 = ref(b64["x"][:, :8], b64["edge_index"], b64["edge_attr"][:, :6])
+        l64 = (out64 * torch.linspace(-1.0, 1.0, out64.numel(), dtype=torch.float64).view_as(out64)).sum()
+        l64.backward()
+    return ref, out64, l64, (xin.grad if with_input_grad else None)
+
+
+@pytest.mark.parametrize("cls,args,grids,B", [
+    ("SkipPFN", (8, 6, 2, 32, 8, 2, 0.3, 5), ["cigre14"], 64),                       # the driver's line at the driver's batch size
+    ("SkipPFN", (8, 6, 2, 32, 8, 2, 0.0, 5), ["cigre14"], 64),
+    ("SkipPFN", (8, 6, 2, 32, 8, 2, 0.3, 5), ["cigre14", "cigre14_reswitched"], 301),   # ragged tiles, a one-cycle topology, a short last tile
+    ("PFN", (8, 6, 2, 32, 4, 2, 0.3, 3), ["cigre14"], 37),
+    ("MPN", (8, 6, 2, 32, 5, 2, 0.3), ["cigre14"], 50),                               # one block
+    ("SkipMPN", (8, 6, 8, 32, 3, 2, 0.0), ["cigre14_reswitched"], 19),                # one block with the residual, 8 outputs
+    ("MPN", (8, 6, 2, 32, 2, 2, 0.5), ["cigre14"], 8),                                # a single H -> H layer
+])
+def test_whole_stack_kernels_match_the_oracle(pkg, oracle, cls, args, grids, B):
+    st = _stack_mod()
+    torch.manual_seed(0)
+    b = pkg.synthetic.make_batch(grids, B, seed=11)
+    model = getattr(pkg, cls)(*args).to(DEV)
+    with torch.no_grad():                      # biases away from zero (TAGConv's default init) so their gradients' paths carry signal
+        for q in model.parameters():
+            if q.dim() == 1:
+                q.uniform_(-0.2, 0.2)
+    torch.manual_seed(5)
+    out, loss, grads, _ = _train(pkg, oracle, model, b)
+    assert model.__dict__.get("_fused_plan") is not None, "the whole-stack path was not taken"
+    ref, out64, l64, _ = _oracle_run(pkg, oracle, cls, args, model, b)
+    assert rel_err(out, out64) < 1e-5
+    assert abs(loss.item() - l64.item()) <= 1e-5 * abs(l64.item())
+    for (n, _), g, r in zip(model.named_parameters(), grads, ref.parameters()):
+        assert rel_err(g, r.grad) < 1e-4, n
+    # bitwise reproducible: same torch seed -> same masks -> same bits, forward and backward
+    torch.manual_seed(5)
+    out2, loss2, grads2, _ = _train(pkg, oracle, model, b)
+    assert torch.equal(out, out2) and torch.equal(loss, loss2)
+    for (n, _), g, g2 in zip(model.named_parameters(), grads, grads2):
+        assert torch.equal(g, g2), n
+    # the per-block kernels (the route for every other shape) on the same masks: same numbers to fp32 rounding
+    st.STACK_KERNEL = False
+    try:
+        model.__dict__.pop("_fused_route", None)
+        for m in _blocks(model):
+            m.__dict__.pop("_fused_route", None)
+        torch.manual_seed(5)
+        out3, loss3, grads3, _ = _train(pkg, oracle, model, b)
+    finally:
+        st.STACK_KERNEL = True
+        model.__dict__.pop("_fused_route", None)
+        for m in _blocks(model):
+            m.__dict__.pop("_fused_route", None)
+    assert rel_err(out3, out) < 1e-5 and abs(loss3.item() - loss.item()) <= 1e-5 * abs(loss.item())
+    for (n, _), g, g3 in zip(model.named_parameters(), grads, grads3):
+        assert rel_err(g, g3) < 1e-4, n
+
+
+def test_whole_stack_input_gradient(pkg, oracle):
+    """x.requires_grad: the backward launch also returns dx of block 0 (the reference's autograd would)."""
+    cls, args = "SkipPFN", (8, 6, 2, 32, 3, 2, 0.3, 3)
+    torch.manual_seed(1)
+    b = pkg.synthetic.make_batch(["cigre14"], 21, seed=4)
+    model = getattr(pkg, cls)(*args).to(DEV)
+    torch.manual_seed(9)
+    out, loss, grads, dx = _train(pkg, oracle, model, b, with_input_grad=True)
+    ref, out64, l64, dx64 = _oracle_run(pkg, oracle, cls, args, model, b, with_input_grad=True)
+    assert rel_err(out, out64) < 1e-5 and rel_err(dx, dx64) < 1e-4
+    for (n, _), g, r in zip(model.named_parameters(), grads, ref.parameters()):
+        assert rel_err(g, r.grad) < 1e-4, n
+
+
+def test_whole_stack_full_batch_against_the_per_block_kernels(pkg, oracle):
+    """B = 4096 (1024 tiles, four per persistent backward workgroup): the two routes agree, and the fused one is bitwise
+    reproducible at that size."""
+    st = _stack_mod()
+    torch.manual_seed(0)
+    b = pkg.synthetic.make_batch(["cigre14"], 4096, seed=3)
+    model = pkg.SkipPFN(8, 6, 2, 32, 8, 2, 0.3, 5).to(DEV)
+    torch.manual_seed(2)
+    out, loss, grads, _ = _train(pkg, oracle, model, b)
+    torch.manual_seed(2)
+    out2, loss2, grads2, _ = _train(pkg, oracle, model, b)
+    assert torch.equal(out, out2) and all(torch.equal(g, g2) for g, g2 in zip(grads, grads2))
+    st.STACK_KERNEL = False
+    try:
+        model.__dict__.pop("_fused_route", None)
+        torch.manual_seed(2)
+        out3, loss3, grads3, _ = _train(pkg, oracle, model, b)
+    finally:
+        st.STACK_KERNEL = True
+        model.__dict__.pop("_fused_route", None)
+    assert rel_err(out3, out) < 1e-5 and abs(loss3.item() - loss.item()) <= 1e-5 * abs(loss.item())
+    for (n, _), g, g3 in zip(model.named_parameters(), grads, grads3):
+        assert rel_err(g, g3) < 2e-4, n
+
+
+def test_whole_stack_route_covers_only_what_it_was_built_for(pkg):
+    st = _stack_mod()
+    b = pkg.synthetic.make_batch(["cigre14"], 8, seed=0)
+    bo = pkg.synthetic.make_batch(["ober_sub"], 4, seed=0)
+    topo = pkg.topology.get_topology(b["edge_index"].to(DEV), b["x"].shape[0])
+    topo_o = pkg.topology.get_topology(bo["edge_index"].to(DEV), bo["x"].shape[0])
+    yes = [pkg.SkipPFN(8, 6, 2, 32, 8, 2, 0.3, 5), pkg.PFN(8, 6, 2, 32, 2, 2, 0.0, 2), pkg.MPN(8, 6, 2, 32, 4, 2, 0.0)]
+    no = [pkg.MPN(8, 6, 2, 64, 4, 2, 0.0), pkg.MPN(8, 6, 2, 32, 1, 2, 0.0), pkg.MPN(8, 6, 2, 32, 3, 3, 0.0),
+          pkg.MPN(8, 6, 2, 32, 10, 2, 0.0)]
+    for m in yes:
+        assert st.supported(_blocks(m), topo) is not None, type(m).__name__
+        assert st.supported(_blocks(m), topo_o) is None           # 70-bus graphs: 96-row tiles, per-block kernels
+    for m in no:
+        assert st.supported(_blocks(m), topo) is None
+
+
+def test_whole_stack_training_step_inside_a_hipgraph(pkg, oracle):
+    """forward + loss + backward + FusedAdamax(capturable) of the driver's model as ONE replayed hipGraph: every replay draws
+    new masks and trains; the parameters after k replays equal k eager steps on the same masks (same device-side offsets)."""
+    torch.manual_seed(0)
+    b = pkg.synthetic.make_batch(["cigre14"], 64, seed=1)
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    st = tuple(s.to(DEV) for s in b["stats"])
+    model = pkg.SkipPFN(8, 6, 2, 32, 8, 2, 0.3, 5).to(DEV)
+    opt = pkg.FusedAdamax(model.parameters(), lr=3e-3, capturable=True)
+    losses = []
+
+    def train_step():
+        for q in model.parameters():
+            q.grad = None
+        out = model(x[:, :8], ei, ea[:, :6])
+        loss = pkg.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2],
+                                edge_std=st[3], edge_index=ei, reg_coefs=oracle.DEFAULT_REG_COEFS, num_samples=None,
+                                node_param=x[:, 8:], edge_param=ea[:, 6:])
+        loss.backward()
+        opt.step()
+        return loss
+    g = pkg.graphs.GraphedStep(train_step)
+    for _ in range(30):
+        losses.append(float(g.replay().item()))
+    snap, _ = model._last_dropout
+    assert int(snap[1].item()) >= 29                                   # the captured pack kernel advances the dropout offset
+    assert all(l == l and l < 1e30 for l in losses)                   # finite
+    assert min(losses[-5:]) < losses[0]                                # it trains
+    assert len(set(losses)) > 25                                       # new masks every replay

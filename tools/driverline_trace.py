@@ -50,7 +50,7 @@ def post(path):
         if len(idx) > 2 * cand and all(names[idx[-1 - cand] + j] == names[idx[-1 - 2 * cand] + j] for j in range(5)):
             pass
     # simpler: steps are separated by the largest gaps; take the last 1/40 of the trace between two Adamax kernels
-    ad = [i for i, n in enumerate(names) if "adamax_kernel" in n]
+    ad = [i for i, n in enumerate(names) if "adamax_kernel" in n or "adamax_flat_kernel" in n]
     a0, a1 = ad[-2], ad[-1]
     # several adamax launches per step may exist: walk back to the previous step's last adamax
     j = len(ad) - 1
