@@ -53,7 +53,7 @@ __device__ unsigned long long g_sstamps[2][64 * 8 * 128];
 #endif
 
 constexpr int SH = 32, SNM = 3, SFN = 8, SFC = 22, SW1LD = 24, STM = 64, SXLD = 36, SZLD = 100;
-constexpr int S_MAX_HH = 7, S_MAX_ELL = 8;
+constexpr int S_MAX_HH = 7, S_MAX_ELL = 4;      // (ELL width <= 4: the backward keeps a row's entries in registers and its LDS is full)
 
 // ---- wpack layout (32-bit words), per block -------------------------------------------------------------------------------
 constexpr int WP_W1 = 0, WP_B1 = SH * SW1LD, WP_CONV0 = WP_B1 + SH;
@@ -185,20 +185,15 @@ __global__ void __launch_bounds__(256) stack_pack_kernel(const dss2_stack_dims d
 // z = b1[j] + W1[j, :] . [x_target | x_source | edge_attr]  -- networks.py:181 concat order; ONE definition, so the gates
 // the backward recomputes are bit for bit the forward's
 __device__ __forceinline__ float edge_z(const float (&w)[SW1LD], float b, f32x4 ta, f32x4 tb, f32x4 sa, f32x4 sb, f32x4 e0, f32x4 e1) {
-  float z = b;
+  // three independent chains (target, source, edge features), then two adds: a third of the dependent-FMA latency
+  float zt = b, zs = 0.f, ze = 0.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) z = fmaf(w[q], ta[q], z);
+  for (int q = 0; q < 4; ++q) { zt = fmaf(w[q], ta[q], zt); zs = fmaf(w[8 + q], sa[q], zs); ze = fmaf(w[16 + q], e0[q], ze); }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) z = fmaf(w[4 + q], tb[q], z);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) z = fmaf(w[8 + q], sa[q], z);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) z = fmaf(w[12 + q], sb[q], z);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) z = fmaf(w[16 + q], e0[q], z);
-  z = fmaf(w[20], e1[0], z);
-  z = fmaf(w[21], e1[1], z);
-  return z;
+  for (int q = 0; q < 4; ++q) { zt = fmaf(w[4 + q], tb[q], zt); zs = fmaf(w[12 + q], sb[q], zs); }
+  ze = fmaf(w[20], e1[0], ze);
+  ze = fmaf(w[21], e1[1], ze);
+  return (zt + zs) + ze;
 }
 
 // the tile's slice of an {other node, ent} ELL table -> other[D][64] (-1 = empty) and the sign-corrected edge_attr rows [D][64][8]
@@ -229,6 +224,15 @@ __device__ __forceinline__ void stage_ell_w(const int32_t* __restrict__ ell_w, i
     const int k = idx >> 6, r = idx & 63;
     dst[idx] = r < tm ? src[k * tm + r] : make_int2(r, 0);
   }
+}
+
+// Workgroup barrier that drains LDS traffic only.  __syncthreads() is a full workgroup fence: it also waits for every
+// outstanding GLOBAL access of the wave (s_waitcnt vmcnt(0)) -- the activation stores of the forward epilogues and the
+// operand prefetches these kernels keep in flight across phases -- which put an L2 / HBM round trip (~1-2 K cycles) on
+// the critical path of every phase.  All cross-wave hand-offs inside a tile go through LDS, so draining lgkmcnt is enough;
+// the one hand-off through global memory (dx between the blocks of the backward) keeps __threadfence + __syncthreads.
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -294,10 +298,14 @@ __global__ void __launch_bounds__(512, 2) stack_fwd_kernel(const dss2_stack_args
   }
   stage_ell_w(p.ell_w, tile, D, p.tm, ellw, tid, 512);
   stage_edges(p.ell_e, tile, D, p.tm, p.ea, p.ldea, other, eaL, tid, 512);
+  if (p.tm <= 32)      // rows 32..63 of the tile buffers are never produced: keep them zero (finite) for the pad-row hops
+    for (int idx = tid; idx < 32 * SXLD * 4; idx += 512) { const int bsel = idx / (32 * SXLD); smem[bsel * STM * SXLD + 32 * SXLD + idx % (32 * SXLD)] = 0.f; }
 
   // MFMA roles: waves 0..5 = (row block, matrix); the head runs on the two waves with m == 0
   const int mm = wave % SNM, rb = wave / SNM;
-  const bool mma_wave = wave < 2 * SNM;
+  const bool short_t = p.tm <= 32;                     // 32-row tiles (small batches: twice the workgroups): row block 1 is empty
+  const bool mma_wave = wave < (short_t ? SNM : 2 * SNM);
+  const int n_et = short_t ? 2 : STM / 16;             // row quads of the edge phase
   const int prow = tid >> 3, pcq = (tid & 7) * 4;      // row piece of the hops / epilogue: 4 columns of one row
   const int hrow = tid >> 3, ho = tid & 7;             // head item: one output of one row
   bf16x8 nb[2][3];                                     // the NEXT unit's weight fragments of this wave (requested one unit ahead)
@@ -318,7 +326,7 @@ __global__ void __launch_bounds__(512, 2) stack_fwd_kernel(const dss2_stack_args
   if (mma_wave) load_conv(0, 0);
   [[maybe_unused]] int sidx = 0;
   SSTAMP(0, true);                 // 0: staging issued
-  __syncthreads();
+  wg_barrier();
   SSTAMP(0, true);                 // 1: staged
 
   for (int b = 0; b < NB; ++b) {
@@ -338,24 +346,25 @@ __global__ void __launch_bounds__(512, 2) stack_fwd_kernel(const dss2_stack_args
       const float bb = wf[WP_B1 + c32];
       const int stream = wave * 2 + half;
 #pragma unroll 1
-      for (int t = 0; t < STM / 16; ++t) {
+      for (int t = 0; t < n_et; ++t) {
         const int r = stream + 16 * t;
         const f32x4 ta = *reinterpret_cast<const f32x4*>(x8 + r * SFN), tb = *reinterpret_cast<const f32x4*>(x8 + r * SFN + 4);
         float acc = 0.f;
-        for (int k = 0; k < D; ++k) {
+#pragma unroll 2
+        for (int k = 0; k < D; ++k) {      // branch-free: empty slots read row 0 and contribute nothing
           const int o = other[k * STM + r];
-          if (o >= 0) {
-            const f32x4 sa = *reinterpret_cast<const f32x4*>(x8 + o * SFN), sb = *reinterpret_cast<const f32x4*>(x8 + o * SFN + 4);
-            const f32x4 e0 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8), e1 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8 + 4);
-            acc += fmaxf(edge_z(w, bb, ta, tb, sa, sb, e0, e1), 0.f);
-          }
+          const int oc = o < 0 ? 0 : o;
+          const f32x4 sa = *reinterpret_cast<const f32x4*>(x8 + oc * SFN), sb = *reinterpret_cast<const f32x4*>(x8 + oc * SFN + 4);
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8), e1 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8 + 4);
+          const float z = edge_z(w, bb, ta, tb, sa, sb, e0, e1);
+          acc += o >= 0 ? fmaxf(z, 0.f) : 0.f;
         }
         Xs[r * SXLD + c32] = acc;
         if (r < R) act_b[(size_t)(ts + r) * SH + c32] = acc;
       }
     }
     SSTAMP(0, b == 0);             // 2: edge phase done
-    __syncthreads();
+    wg_barrier();
     SSTAMP(0, b == 0);             // 3
 
     // ---- the H -> H layers
@@ -368,16 +377,15 @@ __global__ void __launch_bounds__(512, 2) stack_fwd_kernel(const dss2_stack_args
         for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) bq[kg][pl] = nb[kg][pl];
-        f32x16 acc = zero16();
         const float* arow = Xs + (rb * 32 + c32) * SXLD + half * 8;
-        acc = mma6(acc, arow, bq[0][0], bq[0][1], bq[0][2]);
-        acc = mma6(acc, arow + 16, bq[1][0], bq[1][1], bq[1][2]);
+        const f32x16 acc = mma6(zero16(), arow, bq[0][0], bq[0][1], bq[0][2]);            // two independent chains
+        const f32x16 acc1 = mma6(zero16(), arow + 16, bq[1][0], bq[1][1], bq[1][2]);
         // request the next unit's fragments now: they arrive during the hops
         if (l + 1 < n_hh) load_conv(b, l + 1);
         else if (mm == 0) load_head(b);
         float* g = G + mm * (STM * SXLD) + (rb * 32) * SXLD + c32;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g[acc_row(r, half) * SXLD] = acc[r];
+        for (int r = 0; r < 16; ++r) g[acc_row(r, half) * SXLD] = acc[r] + acc1[r];
       }
       // (the dropout multipliers depend on (row, column, layer) only: computed here, off the critical path)
       f32x4 mult = {1.f, 1.f, 1.f, 1.f};
@@ -389,7 +397,7 @@ __global__ void __launch_bounds__(512, 2) stack_fwd_kernel(const dss2_stack_args
         for (int m = 0; m < SNM; ++m) v += *reinterpret_cast<const f32x4*>(cw + WP_CONV_PRE + m * SH + pcq) * ps[m];
       }
       SSTAMP(0, b == 0);           // 4 + 6 l: MFMA + mask done
-      __syncthreads();
+      wg_barrier();
       SSTAMP(0, b == 0);           // 5 + 6 l
       {   // hop 1: G_1 <- G_1 + A G_2
         float* own = G + 1 * (STM * SXLD) + prow * SXLD + pcq;
@@ -402,7 +410,7 @@ __global__ void __launch_bounds__(512, 2) stack_fwd_kernel(const dss2_stack_args
         *reinterpret_cast<f32x4*>(own) = U;
       }
       SSTAMP(0, b == 0);           // 6 + 6 l: hop 1 done
-      __syncthreads();
+      wg_barrier();
       SSTAMP(0, b == 0);           // 7 + 6 l
       {   // hop 2 + epilogue: out = G_0 + A G_1 + bias terms -> dropout -> ReLU -> HBM and the tile
         const float* src = G + 1 * (STM * SXLD) + pcq;
@@ -419,7 +427,7 @@ __global__ void __launch_bounds__(512, 2) stack_fwd_kernel(const dss2_stack_args
         *reinterpret_cast<f32x4*>(Xs + prow * SXLD + pcq) = v;
       }
       SSTAMP(0, b == 0);           // 8 + 6 l: hop 2 + epilogue done
-      __syncthreads();
+      wg_barrier();
       SSTAMP(0, b == 0);           // 9 + 6 l
     }
 
@@ -440,7 +448,7 @@ __global__ void __launch_bounds__(512, 2) stack_fwd_kernel(const dss2_stack_args
     }
     if (mma_wave && b + 1 < NB) load_conv(b + 1, 0);
     const float hbias = ho < dout ? wf[wp_head(n_hh) + WP_HEAD_BIAS + ho] : 0.f;
-    __syncthreads();
+    wg_barrier();
     if (ho < dout) {      // T1 = G_1 + A G_2  (dout-wide)
       float t1 = G[hrow * SXLD + dout + ho];
       for (int k = 0; k < D; ++k) {
@@ -449,7 +457,7 @@ __global__ void __launch_bounds__(512, 2) stack_fwd_kernel(const dss2_stack_args
       }
       G[STM * SXLD + hrow * SXLD + ho] = t1;
     }
-    __syncthreads();
+    wg_barrier();
     if (ho < dout) {
       float o = G[hrow * SXLD + ho];
       for (int k = 0; k < D; ++k) {
@@ -465,7 +473,7 @@ __global__ void __launch_bounds__(512, 2) stack_fwd_kernel(const dss2_stack_args
         p.out[(int64_t)(ts + hrow) * p.ldo + ho] = o;
       }
     }
-    __syncthreads();
+    wg_barrier();
     SSTAMP(0, b == 0);             // 4 + 6 n_hh: head done
   }
   SSTAMP(0, true);                 // last: all blocks done
@@ -476,31 +484,79 @@ static size_t stack_fwd_lds(int D) { return (size_t)(STM * SXLD * 4 + STM * SFN 
 // =====================================================================================================================
 // backward
 // =====================================================================================================================
-__device__ __forceinline__ f32x16 wgrad_block(f32x16 acc, const float* zcol, const float* acol, int half) {
-  // acc[j][i] += sum over the tile's 64 rows of Z[row][j] a[row][i]   (fp32 MFMA: k = row, two rows per instruction)
-#pragma unroll 8
-  for (int s = 0; s < 32; ++s) {
-    const int row = s + 32 * half;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(zcol[row * SZLD], acol[row * SXLD], acc, 0, 0, 0);
+constexpr int STLD = 68;      // row stride of the transposed fp32 copies [column][64 rows]: 16-byte rows of 4 consecutive tile
+                              // rows, conflict-free ds_read_b128 for 32 lanes on 32 consecutive columns (68 c mod 64 = 4 c)
+
+// acc[j][i] += sum over the tile's 64 rows of Z[row][j] a[row][i]   (fp32 MFMA: k = row, two rows per instruction).  Both
+// operands come from the TRANSPOSED copies: lane (c32, half) reads four consecutive rows of its column per ds_read_b128,
+// 16 reads feed 32 MFMAs (the row-major form needed 64 scalar reads and ran at 2.5x the pipe time).
+__device__ __forceinline__ f32x16 wgrad_block(f32x16 acc, const float* zt /* ZT + (col block + c32) * STLD + 32 half */,
+                                              const float* at /* AT + c32 * STLD + 32 half */, bool short_t) {
+  // operands of the next eight MFMAs are requested before the current eight are issued (LDS latency behind 512 cycles of MFMA)
+  f32x4 a0 = *reinterpret_cast<const f32x4*>(zt), b0 = *reinterpret_cast<const f32x4*>(at);
+  f32x4 a1 = *reinterpret_cast<const f32x4*>(zt + 4), b1 = *reinterpret_cast<const f32x4*>(at + 4);
+#pragma unroll
+  for (int t = 0; t < 8; t += 2) {
+    f32x4 na0 = a0, nb0 = b0, na1 = a1, nb1 = b1;
+    if (t + 2 < 8) {
+      na0 = *reinterpret_cast<const f32x4*>(zt + 4 * (t + 2)); nb0 = *reinterpret_cast<const f32x4*>(at + 4 * (t + 2));
+      na1 = *reinterpret_cast<const f32x4*>(zt + 4 * (t + 3)); nb1 = *reinterpret_cast<const f32x4*>(at + 4 * (t + 3));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
+    if (short_t && t == 2) break;      // 32-row tiles: 16 rows per half
   }
   return acc;
+}
+
+// column sums of a [64][ld] fp32 tile, 32 columns, ONE wave: lane (r8 = lane >> 3, cq = 4 (lane & 7)) adds rows r8 + 8 i; the
+// eight row lanes meet through a wave-private LDS scratch [8][32] (one round trip: cross-lane shuffles are ds_bpermute, a
+// dependent chain of three LDS latencies per value); lanes 0..31 return the sum of their column.  `scale`: optional per-row
+// factor [64][4], column m.
+__device__ __forceinline__ float colsum32(const float* tile, int ld, int lane, const float* scale, int m, float* scratch) {
+  const int r8 = lane >> 3, cq = (lane & 7) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = r8 + 8 * i;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * ld + cq);
+    if (scale) s += v * scale[row * 4 + m]; else s += v;
+  }
+  wave_lds_sync();      // (the previous call's readers are done)
+  *reinterpret_cast<f32x4*>(scratch + r8 * SH + cq) = s;
+  wave_lds_sync();
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) t += scratch[k * SH + (lane & 31)];
+  return t;
 }
 
 __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int D = p.ell_width, DT = p.ellT_width;
   float* Z = smem;                                    // [64][100]: Z_0 = g | Z_1 = A^T g | Z_2 = (A^T)^2 g
-  float* A0 = Z + STM * SZLD;                         // [64][36] x 2: the layer's saved input activation (ping-pong)
+  float* A0 = Z + STM * SZLD;                         // [64][36] x 2: the unit's saved input activation (ping-pong)
   float* A1 = A0 + STM * SXLD;
-  float* stg = A1 + STM * SXLD;                       // [64][36]: data gradient before the gate; U0 in the edge phase
-  float* U1 = stg + STM * SXLD;                       // [64][36]
-  float* x8 = U1 + STM * SXLD;                        // [64][8] block input
+  float* stg = A1 + STM * SXLD;                       // [64][36] x 2: data gradient before the gate, one per k half; U0 / U1 in the edge phase
+  float* stg2 = stg + STM * SXLD;
+  float* ZT = stg2 + STM * SXLD;                      // [96][68]: Z transposed (weight-gradient operand)
+  float* AT0 = ZT + 3 * SH * STLD;                    // [32][68] x 2: the activation transposed
+  float* AT1 = AT0 + SH * STLD;
+  float* x8 = AT1 + SH * STLD;                        // [64][8] block input
   float* gx = x8 + STM * SFN;                         // [64][8] gradient of the block output
   float* dps = gx + STM * SFN;                        // [64][4]
   float* w1L = dps + STM * 4;                         // [32][24]
-  float* accS = w1L + SH * SW1LD;                     // bias sums: db[l][32] (l < 7) | dbf[3][32] | dbh[8]
-  constexpr int ACC_DBF = S_MAX_HH * SH, ACC_DBH = ACC_DBF + SNM * SH, ACC_WORDS = ACC_DBH + 8;
-  float* eaL = accS + ACC_WORDS;                      // [D][64][8]
+  float* w1T = w1L + SH * SW1LD;                      // [16][36]: W1[:, 0:16] transposed (dx)
+  float* accS = w1T + 16 * SXLD;                      // bias sums: db[l][32] (l < 7) | dbf[3][32] | dbh[8] | dW1 [32][24] (col 22 = db1)
+  constexpr int ACC_DBF = S_MAX_HH * SH, ACC_DBH = ACC_DBF + SNM * SH, ACC_W1 = ACC_DBH + 8, ACC_WORDS = ACC_W1 + SH * SW1LD;
+  float* csum = accS + ACC_WORDS;                     // [8][32] scratch of the bias-sum wave
+  bf16x8* wfrag = reinterpret_cast<bf16x8*>(csum + 8 * SH);         // [6 k-groups][3 planes][64 lanes]: the unit's data-gradient operand
+  float* eaL = reinterpret_cast<float*>(wfrag + 6 * 3 * 64);        // [D][64][8]
   float* eaT = eaL + D * STM * 8;                     // [DT][64][8]
   int2* ellTw = reinterpret_cast<int2*>(eaT + DT * STM * 8);    // [DT][64]
   int* other = reinterpret_cast<int*>(ellTw + DT * STM);        // [D][64]
@@ -514,6 +570,10 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
   const int prow = tid >> 3, pcq = (tid & 7) * 4, ho = tid & 7;
   const int bsz_inner = fl_block(n_hh, p.dims.dout_inner);
   float* Abuf[2] = {A0, A1};
+  float* ATbuf[2] = {AT0, AT1};
+  const bool short_t = p.tm <= 32;      // 32-row tiles: rows 32..63 are zero padding everywhere
+  const int n_et = short_t ? 2 : STM / 16;
+  int staged_tile = -1;      // the tile whose block-independent operands (ELL slices, edge features, row scales) are in LDS
 
   for (int b = NB - 1; b >= 0; --b) {
     const float* wf = reinterpret_cast<const float*>(p.wpack + (size_t)b * blk_words);
@@ -525,11 +585,13 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
     const int64_t ldxin = b == 0 ? p.ldx : SFN;
     // persistent over this workgroup's tiles: weight-gradient accumulators
     f32x16 acc0 = zero16(), acc1 = zero16(), acc2 = zero16();
-    float dw[SFC], db1 = 0.f;
-#pragma unroll
-    for (int q = 0; q < SFC; ++q) dw[q] = 0.f;
     const float bb = wf[WP_B1 + c32];
-    for (int idx = tid; idx < SH * SW1LD; idx += 512) w1L[idx] = wf[WP_W1 + idx];
+    for (int idx = tid; idx < SH * SW1LD; idx += 512) {
+      const float v = wf[WP_W1 + idx];
+      w1L[idx] = v;
+      const int j = idx / SW1LD, q = idx - j * SW1LD;
+      if (q < 2 * SFN) w1T[q * SXLD + j] = v;
+    }
     for (int idx = tid; idx < ACC_WORDS; idx += 512) accS[idx] = 0.f;
 
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
@@ -548,22 +610,36 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
         }
         gx[idx] = g;
       }
-      if (tid < STM) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (tid < R) v = *reinterpret_cast<const f32x4*>(p.deg_pows + (int64_t)(ts + tid) * 4);
-        *reinterpret_cast<f32x4*>(dps + tid * 4) = v;
+      if (tile != staged_tile) {      // (a workgroup with ONE tile -- small batches -- stages these once for all blocks)
+        if (tid < STM) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (tid < R) v = *reinterpret_cast<const f32x4*>(p.deg_pows + (int64_t)(ts + tid) * 4);
+          *reinterpret_cast<f32x4*>(dps + tid * 4) = v;
+        }
+        stage_ell_w(p.ellT_w, tile, DT, p.tm, ellTw, tid, 512);
+        stage_edges(p.ell_e, tile, D, p.tm, p.ea, p.ldea, other, eaL, tid, 512);
+        stage_edges(p.ellT_e, tile, DT, p.tm, p.ea, p.ldea, otherT, eaT, tid, 512);
+        staged_tile = tile;
       }
-      stage_ell_w(p.ellT_w, tile, DT, p.tm, ellTw, tid, 512);
-      stage_edges(p.ell_e, tile, D, p.tm, p.ea, p.ldea, other, eaL, tid, 512);
-      if (need_dx) stage_edges(p.ellT_e, tile, DT, p.tm, p.ea, p.ldea, otherT, eaT, tid, 512);
-      {   // the head's input activation h_{n_hh}
+      {   // the head's data-gradient operand fragments (2 k-groups)
+        const bf16x8* bsrc = reinterpret_cast<const bf16x8*>(p.wpack + (size_t)b * blk_words + wp_head(n_hh) + WP_HEAD_BWD);
+        if (tid < 2 * 3 * 64) wfrag[tid] = bsrc[tid];
+      }
+      {   // the head's input activation h_{n_hh}, row-major (gate) and transposed (weight-gradient operand)
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (prow < R) v = *reinterpret_cast<const f32x4*>(act_b + ((size_t)n_hh * N + ts + prow) * SH + pcq);
         *reinterpret_cast<f32x4*>(Abuf[n_hh & 1] + prow * SXLD + pcq) = v;
+        float* at = ATbuf[n_hh & 1] + pcq * STLD + prow;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) at[q * STLD] = v[q];
       }
       SSTAMP(1, st_on);            // 1: staging issued
-      __syncthreads();
+      wg_barrier();
       SSTAMP(1, st_on);            // 2: staged
+      // this thread's row of the transposed ELL slice: the same for every hop of every unit of the tile (DT <= 4)
+      int2 en4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) en4[k] = k < DT ? ellTw[k * STM + prow] : make_int2(prow, 0);
 
       // ---- units u = n_hh (head), n_hh - 1 .. 0 (H -> H layers; conv 0 folded)
       for (int u = n_hh; u >= 0; --u) {
@@ -572,87 +648,85 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
         // the input activation of the unit below, requested now, stored after the MFMA phase
         f32x4 apf = {0.f, 0.f, 0.f, 0.f};
         if (u > 0 && prow < R) apf = *reinterpret_cast<const f32x4*>(act_b + ((size_t)(u - 1) * N + ts + prow) * SH + pcq);
+        // wave roles of this unit: weight gradient blocks q = 3 u + k on wave q mod 8 (slot q / 8); data gradient on the next
+        // four waves (row block x k half); bias sums on the last one
         const int q0 = 3 * u;
-        const int wd0 = (q0 + 3) & 7, wd1 = (q0 + 4) & 7, wsp = (q0 + 5) & 7, wsp2 = (q0 + 6) & 7;
-        const bool dgrad_wave = wave == wd0 || wave == wd1;
-        const int drb = wave == wd1 ? 1 : 0;
-        // data-gradient operand fragments of this unit (L2), requested before the hops
-        bf16x8 bq[3][3];      // k-groups 0..2 now; 3..5 (H -> H layers) at the start of the MFMA phase, behind the first 18 MFMAs
-        const bf16x8* bsrc = reinterpret_cast<const bf16x8*>(p.wpack + (size_t)b * blk_words +
-                                                            (head ? wp_head(n_hh) + WP_HEAD_BWD : WP_CONV0 + u * WP_CONV_STRIDE + WP_CONV_BWD));
-        if (dgrad_wave) {
+        const int di = (wave - (q0 + 3)) & 7;            // 0..3: data-gradient wave
+        const int drb = di & 1, dkh = di >> 1;
+        const bool dgrad_wave = di < 4 && (!head || di < 2) && !(short_t && drb);
+        const bool sum_wave = wave == ((q0 + 7) & 7);
+        // the data-gradient operand fragments of the unit BELOW: L2 -> registers now, -> LDS in this unit's gate phase (after
+        // its MFMA phase has read this unit's), so their L2 latency hides behind the hops and the MFMA phase
+        bf16x8 wpf[3];
+        if (u > 0) {
+          const bf16x8* bsrc = reinterpret_cast<const bf16x8*>(p.wpack + (size_t)b * blk_words + WP_CONV0 + (u - 1) * WP_CONV_STRIDE + WP_CONV_BWD);
 #pragma unroll
-          for (int kg = 0; kg < 3; ++kg)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) bq[kg][pl] = bsrc[((head && kg > 1 ? 1 : kg) * 3 + pl) * 64 + lane];
+          for (int i = 0; i < 3; ++i) wpf[i] = bsrc[tid + 512 * i < 6 * 3 * 64 ? tid + 512 * i : 0];
         }
         if (head) {
-          // Z[:, 0:dout] = g, then two dout-wide hops; columns 3 dout .. 31 zero
-          if (ho < dout) Z[prow * SZLD + ho] = gx[prow * SFN + ho];
-          for (int c = 3 * dout + ho; c < 32; c += 8) Z[prow * SZLD + c] = 0.f;
-          __syncthreads();
+          // Z[:, 0:dout] = g, then two dout-wide hops; columns 3 dout .. 31 zero (every value also into the transposed copy)
+          if (ho < dout) { const float g = gx[prow * SFN + ho]; Z[prow * SZLD + ho] = g; ZT[ho * STLD + prow] = g; }
+          for (int c = 3 * dout + ho; c < 32; c += 8) { Z[prow * SZLD + c] = 0.f; ZT[c * STLD + prow] = 0.f; }
+          wg_barrier();
           if (ho < dout) {
             float t = 0.f;
-            for (int k = 0; k < DT; ++k) { const int2 en = ellTw[k * STM + prow]; t = fmaf(__int_as_float(en.y), Z[en.x * SZLD + ho], t); }
-            Z[prow * SZLD + dout + ho] = t;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t = fmaf(__int_as_float(en4[k].y), Z[en4[k].x * SZLD + ho], t);
+            Z[prow * SZLD + dout + ho] = t; ZT[(dout + ho) * STLD + prow] = t;
           }
-          __syncthreads();
+          wg_barrier();
           if (ho < dout) {
             float t = 0.f;
-            for (int k = 0; k < DT; ++k) { const int2 en = ellTw[k * STM + prow]; t = fmaf(__int_as_float(en.y), Z[en.x * SZLD + dout + ho], t); }
-            Z[prow * SZLD + 2 * dout + ho] = t;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t = fmaf(__int_as_float(en4[k].y), Z[en4[k].x * SZLD + dout + ho], t);
+            Z[prow * SZLD + 2 * dout + ho] = t; ZT[(2 * dout + ho) * STLD + prow] = t;
           }
-          __syncthreads();
+          wg_barrier();
         } else {
 #pragma unroll
           for (int m = 1; m < SNM; ++m) {
-            f32x4 U = {0.f, 0.f, 0.f, 0.f};
             const float* src = Z + (m - 1) * SH + pcq;
-            for (int k = 0; k < DT; ++k) {
-              const int2 en = ellTw[k * STM + prow];
-              U += *reinterpret_cast<const f32x4*>(src + en.x * SZLD) * __int_as_float(en.y);
-            }
+            f32x4 zz[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) zz[k] = *reinterpret_cast<const f32x4*>(src + en4[k].x * SZLD);      // all four gathers in flight
+            f32x4 U = zz[0] * __int_as_float(en4[0].y);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) U += zz[k] * __int_as_float(en4[k].y);
             *reinterpret_cast<f32x4*>(Z + prow * SZLD + m * SH + pcq) = U;
-            __syncthreads();
+            float* zt = ZT + (m * SH + pcq) * STLD + prow;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zt[q * STLD] = U[q];
+            wg_barrier();
           }
         }
         SSTAMP(1, st_on);          // 3 + 5 i: hops done (i = n_hh - u)
-        // ---- ONE MFMA phase: weight gradients (3 waves), data gradient (2 waves), bias sums (spare waves)
+        // ---- ONE MFMA phase: weight gradients (3 waves), data gradient (4 waves), bias sums (1 wave)
         {
           const int nblk = head ? 1 : SNM;
           for (int k = 0; k < nblk; ++k) {
             const int q = q0 + k;
             if (wave == (q & 7)) {
-              const float* zc = Z + k * SH + c32;
-              const float* ac = Acur + c32;
+              const int rbase = short_t ? 16 * half : 32 * half;      // 32-row tiles: k runs over rows 0..31 only
+              const float* zt = ZT + (k * SH + c32) * STLD + rbase;
+              const float* at = ATbuf[u & 1] + c32 * STLD + rbase;
               const int slot = q >> 3;
-              if (slot == 0) acc0 = wgrad_block(acc0, zc, ac, half);
-              else if (slot == 1) acc1 = wgrad_block(acc1, zc, ac, half);
-              else acc2 = wgrad_block(acc2, zc, ac, half);
+              if (slot == 0) acc0 = wgrad_block(acc0, zt, at, short_t);
+              else if (slot == 1) acc1 = wgrad_block(acc1, zt, at, short_t);
+              else acc2 = wgrad_block(acc2, zt, at, short_t);
             }
           }
           if (dgrad_wave) {
-            f32x16 acc = zero16();
-            const float* arow = Z + (drb * 32 + c32) * SZLD + half * 8;
-            if (head) {
-              acc = mma6(acc, arow, bq[0][0], bq[0][1], bq[0][2]);
-              acc = mma6(acc, arow + 16, bq[1][0], bq[1][1], bq[1][2]);
-            } else {
-              bf16x8 b2[3][3];
+            // rows drb * 32 .., k-groups 3 dkh .. 3 dkh + 2 (head: 0, 1): two independent accumulation chains
+            const float* arow = Z + (drb * 32 + c32) * SZLD + half * 8 + (head ? 0 : dkh * 48);
+            const bf16x8* bq = wfrag + (head ? 0 : 3 * dkh) * 3 * 64 + lane;      // [k-group][plane][lane]
+            f32x16 a0 = mma6(zero16(), arow, bq[0], bq[64], bq[128]);
+            f32x16 a1 = mma6(zero16(), arow + 16, bq[192], bq[256], bq[320]);
+            if (!head) a0 = mma6(a0, arow + 32, bq[384], bq[448], bq[512]);
+            float* g = (dkh ? stg2 : stg) + (drb * 32) * SXLD + c32;
 #pragma unroll
-              for (int kg = 0; kg < 3; ++kg)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) b2[kg][pl] = bsrc[((3 + kg) * 3 + pl) * 64 + lane];
-#pragma unroll
-              for (int kg = 0; kg < 3; ++kg) acc = mma6(acc, arow + kg * 16, bq[kg][0], bq[kg][1], bq[kg][2]);
-#pragma unroll
-              for (int kg = 0; kg < 3; ++kg) acc = mma6(acc, arow + (3 + kg) * 16, b2[kg][0], b2[kg][1], b2[kg][2]);
-            }
-            float* g = stg + (drb * 32) * SXLD + c32;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g[acc_row(r, half) * SXLD] = acc[r];
+            for (int r = 0; r < 16; ++r) g[acc_row(r, half) * SXLD] = a0[r] + a1[r];
           }
-          if (wave == wsp) {
+          if (sum_wave) {
             if (head) {      // db_head[o] += sum_rows g[row][o]
               float s = 0.f;
               const int o = lane & 7, part = lane >> 3;
@@ -660,44 +734,50 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
               for (int i = 0; i < 8; ++i) s += gx[(part * 8 + i) * SFN + o];
               s += __shfl_xor(s, 8); s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
               if (lane < 8 && lane < dout) accS[ACC_DBH + lane] += s;
-            } else {         // db_u[c] += sum_rows g[row][c]
-              float s = 0.f;
-#pragma unroll 8
-              for (int i = 0; i < 32; ++i) s += Z[(i + 32 * half) * SZLD + c32];
-              s += __shfl_xor(s, 32);
+            } else {         // db_u[c] += sum_rows g[row][c];  folded conv 0 also dbf_m[c] += sum_rows (A^m deg)[row] g[row][c]
+              float s = colsum32(Z, SZLD, lane, nullptr, 0, csum);
               if (lane < 32) accS[u * SH + lane] += s;
-            }
-          }
-          if (wave == wsp2 && u == 0) {      // folded conv 0: the bias term sum_m (A^m deg) bf_m^T  =>  dbf_m[c] += sum_rows (A^m deg)[row] g[row][c]
+              if (u == 0) {
 #pragma unroll
-            for (int m = 0; m < SNM; ++m) {
-              float s = 0.f;
-#pragma unroll 8
-              for (int i = 0; i < 32; ++i) { const int row = i + 32 * half; s = fmaf(dps[row * 4 + m], Z[row * SZLD + c32], s); }
-              s += __shfl_xor(s, 32);
-              if (lane < 32) accS[ACC_DBF + m * SH + lane] += s;
+                for (int m = 0; m < SNM; ++m) {
+                  s = colsum32(Z, SZLD, lane, dps, m, csum);
+                  if (lane < 32) accS[ACC_DBF + m * SH + lane] += s;
+                }
+              }
             }
           }
         }
+        // the gate's dropout multipliers depend on (row, column, unit) only: issued here, they fill the MFMA waits
+        f32x4 mult = {1.f, 1.f, 1.f, 1.f};
+        if (u > 0 && p.drop_state) mult = dropout_mult4(dseed, doff, (uint32_t)(b * p.drop_stride + u), (uint32_t)(ts + prow), (uint32_t)(pcq >> 2), p.drop_thr, p.drop_scale);
         SSTAMP(1, st_on);          // 4 + 5 i: this wave's MFMA-phase work done
-        __syncthreads();
+        wg_barrier();
         SSTAMP(1, st_on);          // 5 + 5 i
         // ---- gate: gradient w.r.t. the pre-activation output of the unit below (u > 0); u == 0: dS, no gate
         {
           f32x4 v = *reinterpret_cast<const f32x4*>(stg + prow * SXLD + pcq);
+          if (!head) v += *reinterpret_cast<const f32x4*>(stg2 + prow * SXLD + pcq);
           if (u > 0) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(Acur + prow * SXLD + pcq);
-            f32x4 mult = {1.f, 1.f, 1.f, 1.f};
-            if (p.drop_state) mult = dropout_mult4(dseed, doff, (uint32_t)(b * p.drop_stride + u), (uint32_t)(ts + prow), (uint32_t)(pcq >> 2), p.drop_thr, p.drop_scale);
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = a[q] > 0.f ? v[q] * mult[q] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { const int f = tid + 512 * i; if (f < 6 * 3 * 64) wfrag[f] = wpf[i]; }
             *reinterpret_cast<f32x4*>(Abuf[(u - 1) & 1] + prow * SXLD + pcq) = apf;
+            float* at = ATbuf[(u - 1) & 1] + pcq * STLD + prow;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) at[q * STLD] = apf[q];
           }
           if (prow >= R) v = f32x4{0.f, 0.f, 0.f, 0.f};
           *reinterpret_cast<f32x4*>(Z + prow * SZLD + pcq) = v;
+          if (u > 0) {
+            float* zt = ZT + pcq * STLD + prow;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zt[q * STLD] = v[q];
+          }
         }
         SSTAMP(1, st_on);          // 6 + 5 i: gate done
-        __syncthreads();
+        wg_barrier();
         SSTAMP(1, st_on);          // 7 + 5 i
       }
 
@@ -711,64 +791,87 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
 #pragma unroll
           for (int q = 0; q < 4; ++q) w[q4 * 4 + q] = v[q];
         }
+        float dw[SFC], db1 = 0.f;      // this stream's share of dW1 / db1 for THIS tile (summed over the streams below)
+#pragma unroll
+        for (int q = 0; q < SFC; ++q) dw[q] = 0.f;
 #pragma unroll 1
-        for (int t = 0; t < STM / 16; ++t) {      // by target: dW1, db1, U0
+        for (int t = 0; t < n_et; ++t) {      // by target: dW1, db1, U0
           const int r = stream + 16 * t;
           const f32x4 ta = *reinterpret_cast<const f32x4*>(x8 + r * SFN), tb = *reinterpret_cast<const f32x4*>(x8 + r * SFN + 4);
           const float gS = Z[r * SZLD + c32];
           float u0 = 0.f;
           for (int k = 0; k < D; ++k) {
             const int o = other[k * STM + r];
-            if (o >= 0) {
-              const f32x4 sa = *reinterpret_cast<const f32x4*>(x8 + o * SFN), sb = *reinterpret_cast<const f32x4*>(x8 + o * SFN + 4);
-              const f32x4 e0 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8), e1 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8 + 4);
-              const float dz = edge_z(w, bb, ta, tb, sa, sb, e0, e1) > 0.f ? gS : 0.f;
-              u0 += dz;
-              db1 += dz;
+            if (o < 0) continue;
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(x8 + o * SFN), sb = *reinterpret_cast<const f32x4*>(x8 + o * SFN + 4);
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8), e1 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8 + 4);
+            const float dz = edge_z(w, bb, ta, tb, sa, sb, e0, e1) > 0.f ? gS : 0.f;
+            u0 += dz;
+            db1 += dz;
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                dw[q] = fmaf(dz, ta[q], dw[q]); dw[4 + q] = fmaf(dz, tb[q], dw[4 + q]);
-                dw[8 + q] = fmaf(dz, sa[q], dw[8 + q]); dw[12 + q] = fmaf(dz, sb[q], dw[12 + q]);
-                dw[16 + q] = fmaf(dz, e0[q], dw[16 + q]);
-              }
-              dw[20] = fmaf(dz, e1[0], dw[20]); dw[21] = fmaf(dz, e1[1], dw[21]);
+            for (int q = 0; q < 4; ++q) {
+              dw[q] = fmaf(dz, ta[q], dw[q]); dw[4 + q] = fmaf(dz, tb[q], dw[4 + q]);
+              dw[8 + q] = fmaf(dz, sa[q], dw[8 + q]); dw[12 + q] = fmaf(dz, sb[q], dw[12 + q]);
+              dw[16 + q] = fmaf(dz, e0[q], dw[16 + q]);
             }
+            dw[20] = fmaf(dz, e1[0], dw[20]); dw[21] = fmaf(dz, e1[1], dw[21]);
           }
           stg[r * SXLD + c32] = u0;
         }
         if (need_dx) {
 #pragma unroll 1
-          for (int t = 0; t < STM / 16; ++t) {    // by source: U1
+          for (int t = 0; t < n_et; ++t) {    // by source: U1
             const int r = stream + 16 * t;
             const f32x4 sa = *reinterpret_cast<const f32x4*>(x8 + r * SFN), sb = *reinterpret_cast<const f32x4*>(x8 + r * SFN + 4);
             float u1 = 0.f;
             for (int k = 0; k < DT; ++k) {
               const int o = otherT[k * STM + r];
-              if (o >= 0) {
-                const f32x4 ta = *reinterpret_cast<const f32x4*>(x8 + o * SFN), tb = *reinterpret_cast<const f32x4*>(x8 + o * SFN + 4);
-                const f32x4 e0 = *reinterpret_cast<const f32x4*>(eaT + (k * STM + r) * 8), e1 = *reinterpret_cast<const f32x4*>(eaT + (k * STM + r) * 8 + 4);
-                u1 += edge_z(w, bb, ta, tb, sa, sb, e0, e1) > 0.f ? Z[o * SZLD + c32] : 0.f;
-              }
+              if (o < 0) continue;
+              const f32x4 ta = *reinterpret_cast<const f32x4*>(x8 + o * SFN), tb = *reinterpret_cast<const f32x4*>(x8 + o * SFN + 4);
+              const f32x4 e0 = *reinterpret_cast<const f32x4*>(eaT + (k * STM + r) * 8), e1 = *reinterpret_cast<const f32x4*>(eaT + (k * STM + r) * 8 + 4);
+              u1 += edge_z(w, bb, ta, tb, sa, sb, e0, e1) > 0.f ? Z[o * SZLD + c32] : 0.f;
             }
-            U1[r * SXLD + c32] = u1;
+            stg2[r * SXLD + c32] = u1;
           }
+        }
+        // the streams' shares of dW1 / db1: the two halves of a wave meet by shuffle, the eight waves through scratch
+        // (ZT: free since the last unit's MFMA phase), in a fixed order
+#pragma unroll
+        for (int q = 0; q < SFC; ++q) dw[q] += __shfl_xor(dw[q], 32);
+        db1 += __shfl_xor(db1, 32);
+        if (half == 0) {
+          float* red = ZT + (wave * SH + c32) * SW1LD;      // [8 waves][32][24] = 6144 floats <= ZT
+#pragma unroll
+          for (int q = 0; q < SFC; ++q) red[q] = dw[q];
+          red[SFC] = db1;
         }
       }
       SSTAMP(1, st_on);            // 3 + 5 (n_hh + 1): edge passes done
-      __syncthreads();
-      if (need_dx) {      // dx[row][c] = U0[row] . W1[:, c] + U1[row] . W1[:, 8 + c] (+ residual)
-        float s = skip ? gx[prow * SFN + ho] : 0.f;
-#pragma unroll 8
-        for (int j = 0; j < SH; ++j) {
-          s = fmaf(stg[prow * SXLD + j], w1L[j * SW1LD + ho], s);
-          s = fmaf(U1[prow * SXLD + j], w1L[j * SW1LD + SFN + ho], s);
+      wg_barrier();
+      for (int idx = tid; idx < SH * SW1LD; idx += 512) {      // fixed-order sum over the 8 waves, accumulated over the tiles
+        const int q = idx % SW1LD;
+        if (q > SFC) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) s += ZT[st * (SH * SW1LD) + idx];
+        accS[ACC_W1 + idx] += s;
+      }
+      if (need_dx) {      // dx[row][c] = U0[row] . W1[:, c] + U1[row] . W1[:, 8 + c] (+ residual): four partial sums, fixed order
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j4 = 0; j4 < SH / 4; ++j4) {
+          const f32x4 u0 = *reinterpret_cast<const f32x4*>(stg + prow * SXLD + 4 * j4), u1 = *reinterpret_cast<const f32x4*>(stg2 + prow * SXLD + 4 * j4);
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(w1T + ho * SXLD + 4 * j4), wb = *reinterpret_cast<const f32x4*>(w1T + (SFN + ho) * SXLD + 4 * j4);
+          s4 += u0 * wa;
+          s4 += u1 * wb;
         }
+        const float s = (skip ? gx[prow * SFN + ho] : 0.f) + ((s4[0] + s4[1]) + (s4[2] + s4[3]));
         if (prow < R) {
           if (b > 0) p.dxbuf[(int64_t)(ts + prow) * SFN + ho] = s;
           else p.dx_out[(int64_t)(ts + prow) * SFN + ho] = s;
         }
       }
-      __syncthreads();
+      wg_barrier();
       SSTAMP(1, st_on);            // 4 + 5 (n_hh + 1): tile done
     }
 
@@ -777,8 +880,8 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
       float* sl = p.slab + (size_t)blockIdx.x * p.slab_stride + (size_t)b * bsz_inner;
       // (the lane offset is made opaque here: otherwise the compiler forms the sixteen 64-bit store addresses of every slot
       //  at the top of the block loop and carries them -- spilled -- through the whole tile loop)
-      int lane_off = 4 * half * SH + c32;
-      asm volatile("" : "+v"(lane_off));
+      int lane_off = 4 * half * SH + c32, h4 = 4 * half;
+      asm volatile("" : "+v"(lane_off), "+v"(h4));
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const int q = 8 * s + wave;
@@ -790,28 +893,15 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
         } else if (q == 3 * n_hh) {
           float* dst = sl + fl_head(n_hh) + lane_off;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { const int jj = acc_row(r, half); if (jj < SNM * dout) dst[acc_row(r, 0) * SH] = a[r]; }
+          for (int r = 0; r < 16; ++r) { const int jj = acc_row(r, 0) + h4; if (jj < SNM * dout) dst[acc_row(r, 0) * SH] = a[r]; }
         }
       }
-      __syncthreads();      // every wave is done with the tile buffers: they become the W1 reduction scratch
-      float* red = smem;     // [16 streams][32][24]
-      {
-        const int stream = wave * 2 + half;
-        float* dst = red + (stream * SH + c32) * SW1LD;
-#pragma unroll
-        for (int q = 0; q < SFC; ++q) dst[q] = dw[q];
-        dst[SFC] = db1;
-      }
-      __syncthreads();
       int t2 = tid;
       asm volatile("" : "+v"(t2));      // (same reason as lane_off above)
       for (int idx = t2; idx < SH * SW1LD; idx += 512) {
         const int j = idx / SW1LD, q = idx - j * SW1LD;
-        if (q > SFC) continue;
-        float s = 0.f;
-#pragma unroll
-        for (int st = 0; st < 16; ++st) s += red[(st * SH + j) * SW1LD + q];
-        if (q < SFC) sl[FL_W1 + j * SFC + q] = s; else sl[FL_B1 + j] = s;
+        if (q < SFC) sl[FL_W1 + j * SFC + q] = accS[ACC_W1 + idx];
+        else if (q == SFC) sl[FL_B1 + j] = accS[ACC_W1 + idx];
       }
       for (int idx = t2; idx < n_hh * SH; idx += 512) sl[FL_CONV0 + (idx >> 5) * FL_CONV_STRIDE + SNM * SH * SH + (idx & 31)] = accS[idx];
       if (t2 < SNM * SH) sl[FL_W2 + t2] = accS[ACC_DBF + t2];      // dbf_m travels in the W2 section (the reduce kernel knows)
@@ -824,9 +914,9 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
 }
 
 static size_t stack_bwd_lds(int D, int DT) {
-  const size_t f = (size_t)STM * SZLD + 4 * STM * SXLD + 2 * STM * SFN + STM * 4 + SH * SW1LD + (S_MAX_HH * SH + SNM * SH + 8) +
-                   (size_t)(D + DT) * STM * 8;
-  return f * 4 + (size_t)DT * STM * 8 + (size_t)(D + DT) * STM * 4;
+  const size_t f = (size_t)STM * SZLD + 4 * STM * SXLD + 3 * SH * STLD + 2 * SH * STLD + 2 * STM * SFN + STM * 4 + SH * SW1LD + 16 * SXLD +
+                   (S_MAX_HH * SH + SNM * SH + 8 + SH * SW1LD + 8 * SH) + (size_t)(D + DT) * STM * 8;
+  return f * 4 + (size_t)6 * 3 * 64 * 16 + (size_t)DT * STM * 8 + (size_t)(D + DT) * STM * 4;
 }
 
 // =====================================================================================================================

@@ -49,17 +49,36 @@ def dims_of(blocks) -> Optional[_lib.StackDims]:
     return d
 
 
+STACK_NRB = _os.environ.get("DSS2_STACK_NRB", "auto")      # tile height of the whole-stack kernels: auto | 1 | 2
+
+
+def tiles_of(topo):
+    """The tile set the whole-stack kernels run on.  They are latency-bound per tile (one workgroup walks a tile through ~45
+    dependent phases), so as long as 64-row tiles leave CUs idle, 32-row tiles -- twice as many workgroups, half the work
+    per phase -- are faster (B = 64: 16 -> 32 workgroups); big batches keep the 64-row tiles (less overhead per graph)."""
+    if topo.global_only or topo.nrb > 2:
+        return None
+    if STACK_NRB in ("1", "2"):
+        return topo.tiles_for(int(STACK_NRB))
+    if topo.nrb == 2 and topo.ntiles <= _cu_count(topo.device):
+        alt = topo.tiles_for(1)
+        if alt is not None and alt.ell_tiles is not None and alt.ellT_tiles is not None:
+            return alt
+    return topo
+
+
 def supported(blocks, topo) -> Optional[_lib.StackDims]:
     """The stack's dims when the whole-stack kernels cover it on this topology, else None."""
     if not STACK_KERNEL or topo.global_only:
         return None
     d = dims_of(blocks)
-    if d is None or topo.ell_tiles is None or topo.ellT_tiles is None or topo.ell_ent_tiles is None or topo.ellT_ent_tiles is None:
+    ts = tiles_of(topo) if d is not None else None
+    if ts is None or ts.ell_tiles is None or ts.ellT_tiles is None or ts.ell_ent_tiles is None or ts.ellT_ent_tiles is None:
         return None
     b0 = blocks[0]
     if len(blocks) >= DROP_STRIDE or b0.n_gnn_layers + 1 >= DROP_STRIDE:
         return None
-    ok = _lib.lib().dss2_stack_supported(C.byref(d), b0.dim_hid, b0.K + 1, b0.dim_featn, b0.dim_feate, topo.nrb, topo.ell, topo.ellT)
+    ok = _lib.lib().dss2_stack_supported(C.byref(d), b0.dim_hid, b0.K + 1, b0.dim_featn, b0.dim_feate, ts.nrb, ts.ell, ts.ellT)
     return d if ok else None
 
 
@@ -122,9 +141,10 @@ def _fill_common(a: "_lib.StackArgs", plan: _Plan, topo, x, ldx, ea, ldea, acts,
     a.dims = d
     a.x, a.ldx, a.ea, a.ldea = x.data_ptr(), ldx, ea.data_ptr(), ldea
     a.wpack = plan.wpack.data_ptr()
-    a.tile_start, a.ntiles, a.tm = topo.tile_start.data_ptr(), topo.ntiles, 32 * topo.nrb
-    a.ell_w, a.ell_e, a.ell_width = topo.ell_tiles.data_ptr(), topo.ell_ent_tiles.data_ptr(), topo.ell
-    a.ellT_w, a.ellT_e, a.ellT_width = topo.ellT_tiles.data_ptr(), topo.ellT_ent_tiles.data_ptr(), topo.ellT
+    ts = tiles_of(topo)
+    a.tile_start, a.ntiles, a.tm = ts.tile_start.data_ptr(), ts.ntiles, 32 * ts.nrb
+    a.ell_w, a.ell_e, a.ell_width = ts.ell_tiles.data_ptr(), ts.ell_ent_tiles.data_ptr(), ts.ell
+    a.ellT_w, a.ellT_e, a.ellT_width = ts.ellT_tiles.data_ptr(), ts.ellT_ent_tiles.data_ptr(), ts.ellT
     a.deg_pows = topo.deg_pows.data_ptr()
     a.acts = acts.data_ptr()
     a.xs = xs.data_ptr() if xs is not None else None
@@ -187,7 +207,7 @@ class _FusedStackFn(torch.autograd.Function):
         if plan.version != ver:           # another forward re-packed in between (weights are unchanged: autograd checks that)
             plan.pack(ps, None, 0, False)
         g = gout.contiguous()
-        n_wg = max(1, min(topo.ntiles, _cu_count(dev)))
+        n_wg = max(1, min(tiles_of(topo).ntiles, _cu_count(dev)))
         slab = torch.empty(n_wg, plan.stride, dtype=_F32, device=dev)
         flat = torch.empty(plan.total, dtype=_F32, device=dev)
         need_dx = bool(ctx.needs_input_grad[0])

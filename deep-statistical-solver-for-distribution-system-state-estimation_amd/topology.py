@@ -148,11 +148,30 @@ class Topology:
                 raise ValueError("TopologyHint.max_degree is smaller than a row of the batch")
         return self._stats
 
-    def _build_tiles(self) -> None:
+    def tiles_for(self, nrb: int):
+        """A second set of tiles / ELL slices with a FORCED tile height of 32 * nrb rows, beside the primary one (cached).
+        Used by the whole-stack kernels, which are latency-bound per tile: at small batches twice as many 32-row tiles
+        put twice as many CUs to work.  Returns a namespace with the tile attributes (nrb, ntiles, tile_start, ell, ellT,
+        ell_tiles, ell_ent_tiles, ellT_tiles, ellT_ent_tiles), or None when no whole-graph tiling of that height exists."""
+        import types
+        if not self.__dict__.get("_tiles_built", False):
+            self._build_tiles()
+        if self.global_only:
+            return None
+        if nrb == self.nrb:
+            return self
+        alt = self.__dict__.setdefault("_alt_tiles", {})
+        if nrb not in alt:
+            d = self._build_tiles(choices=(int(nrb),), store=False)
+            alt[nrb] = types.SimpleNamespace(**d) if d is not None and not d["global_only"] else None
+        return alt[nrb]
+
+    def _build_tiles(self, choices=None, store=True):
         L = _lib.lib()
         dev, N = self.device, self.N
         env = os.environ.get("DSS2_NRB")
-        choices = (int(self._nrb_forced),) if self._nrb_forced else ((int(env),) if env else _NRB_CHOICES)
+        if choices is None:
+            choices = (int(self._nrb_forced),) if self._nrb_forced else ((int(env),) if env else _NRB_CHOICES)
         st = _stream(dev)
         hint = self.hint
         if hint is not None and N % hint.nodes_per_graph == 0:
@@ -168,7 +187,7 @@ class Topology:
                 if best is None or util > best[0] + 0.03:
                     best = (util, cand, nt, per)
             if best is None:
-                return self._global_tiles(n)
+                return self._global_tiles(n) if store else None
             util, nrb, nt, per = best
             tile_start = torch.empty(nt + 1, dtype=torch.int32, device=dev)
             _lib.check(L.dss2_tiles_uniform(tile_start.data_ptr(), nt, per * n, N, st), "dss2_tiles_uniform")
@@ -196,7 +215,7 @@ class Topology:
                 if best is None or util > best[0] + 0.03:
                     best = (util, cand, nt, i)
             if best is None:
-                return self._global_tiles(max_segment)
+                return self._global_tiles(max_segment) if store else None
             util, nrb, nt, i = best
             tile_start = cands[i][:nt + 1].clone()
             nnz_bound, exact_nnz = 0, True
@@ -223,10 +242,13 @@ class Topology:
             max_nnz, max_nnzT = max_deg * tm, max_degT * tm
         else:
             max_nnz = max_nnzT = nnz_bound
-        self.__dict__.update(global_only=False, nrb=nrb, ntiles=nt, tile_start=tile_start, utilisation=util, max_segment=max_segment,
-                             max_nnz=max_nnz, max_nnzT=max_nnzT, ell=ell, ellT=ellT, ell_tiles=ell_tiles,
-                             ellT_tiles=ellT_tiles, ell_ent_tiles=ell_ent_tiles, ellT_ent_tiles=ellT_ent_tiles)
+        d = dict(global_only=False, nrb=nrb, ntiles=nt, tile_start=tile_start, utilisation=util, max_segment=max_segment,
+                 max_nnz=max_nnz, max_nnzT=max_nnzT, ell=ell, ellT=ellT, ell_tiles=ell_tiles,
+                 ellT_tiles=ellT_tiles, ell_ent_tiles=ell_ent_tiles, ellT_ent_tiles=ellT_ent_tiles)
         self._stats = None            # (the ELL build added the per-tile entry counts to the statistics)
+        if not store:
+            return d
+        self.__dict__.update(d)
         self._tiles_built = True
 
     def _global_tiles(self, max_segment: int) -> None:

@@ -44,6 +44,10 @@ def run(cls, args, grids, B, p_note=""):
         print(f"   {n:40s} {e:.2e} {'  <<<<' if e > 1e-4 else ''}")
 
 
-run("MPN", (8, 6, 2, 32, 2, 2, 0.0), ["cigre14"], 8)
-run("MPN", (8, 6, 2, 32, 3, 2, 0.0), ["cigre14"], 8)
-run("SkipPFN", (8, 6, 2, 32, 3, 2, 0.0, 2), ["cigre14"], 8)
+import sys
+if len(sys.argv) > 1 and sys.argv[1] == "driver":
+    run("SkipPFN", (8, 6, 2, 32, 8, 2, 0.3, 5), ["cigre14"], 64)
+else:
+    run("MPN", (8, 6, 2, 32, 2, 2, 0.0), ["cigre14"], 8)
+    run("MPN", (8, 6, 2, 32, 3, 2, 0.0), ["cigre14"], 8)
+    run("SkipPFN", (8, 6, 2, 32, 3, 2, 0.0, 2), ["cigre14"], 8)

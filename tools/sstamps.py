@@ -26,7 +26,10 @@ torch.cuda.synchronize()
 step(); torch.cuda.synchronize()
 lib = pkg._lib.lib()
 lib.dss2_debug_read_sstamps.argtypes = [C.c_void_p, C.c_int]
-nwg = min(64, (b["x"].shape[0] + 59) // 60)
+stack_mod = importlib.import_module("deep-statistical-solver-for-distribution-system-state-estimation_amd.stack")
+tset = stack_mod.tiles_of(pkg.topology.get_topology(ei, x.shape[0]))
+nwg = min(64, tset.ntiles)
+print(f"tiles: {tset.ntiles} of {32 * tset.nrb} rows")
 
 
 def read(which):
@@ -62,7 +65,7 @@ for i in range(n_hh + 1):
     if i:      # per-role MFMA phase time
         q0 = 3 * u
         d = g[:, :, base + 1] - g[:, :, base]
-        roles = {"wgrad": [(q0 + k) % 8 for k in range(3)], "dgrad": [(q0 + 3) % 8, (q0 + 4) % 8], "bias sums": [(q0 + 5) % 8, (q0 + 6) % 8]}
-        print("           " + "  ".join(f"{r}: {np.median(d[:, w]):.0f}" for r, w in roles.items()))
+        roles = {"wgrad": [(q0 + k) % 8 for k in range(3)], "dgrad": [(q0 + 3 + k) % 8 for k in range(4)], "bias sums": [(q0 + 7) % 8]}
+        print("           " + "  ".join(f"{r}: {np.median(d[:, w].max(axis=1)):.0f}" for r, w in roles.items()))
 e0 = 3 + 5 * (n_hh + 1)
 print(f"  edge passes {span(g, e0 - 1, e0):6.0f}   dx + barrier {span(g, e0, e0 + 1):6.0f}   tile total {span(g, 0, e0 + 1):8.0f}")
