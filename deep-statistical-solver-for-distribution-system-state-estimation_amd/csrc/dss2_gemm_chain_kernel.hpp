@@ -113,6 +113,12 @@ __global__ void __launch_bounds__(NW * 64, RS == 3 ? 3 : chain_waves_per_simd(NR
   CSTAMP(0);
   __syncthreads();
   CSTAMP(1);
+#ifdef DSS2_CHAIN_DEPHASE
+  // Diagnostic build only (-DDSS2_CHAIN_DEPHASE=n): the workgroups of every second dispatch round start n x 8 K cycles late, so
+  // the two workgroups that share a CU are out of phase (one's Horner / epilogue beside the other's MFMA phase).
+  if ((blockIdx.x >> 8) & 1)
+    for (int i = 0; i < DSS2_CHAIN_DEPHASE; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 
   const int c32 = lane & 31, half = lane >> 5;
   const int nkk = p.kpad >> 3;

@@ -132,7 +132,10 @@ def test_whole_stack_kernels_match_the_oracle(pkg, oracle, cls, args, grids, B):
     assert abs(loss.item() - l64.item()) <= 1e-5 * abs(l64.item())
     for (n, _), g, r in zip(model.named_parameters(), grads, ref.parameters()):
         assert rel_err(g, r.grad) < _tol(n, 1e-4), n           # conv gates pinned: tight
-    tol = max(1e-4, 16.0 / b["x"].shape[0])                     # the two GPU routes against each other: nothing pinned (a gate or two may differ)
+    # the two GPU routes against each other, nothing pinned: a razor-edge gate that differs between them toggles ONE node's
+    # contribution to a weight-gradient row, which weighs ~1 / sqrt(N_nodes) of that row's randomly-signed sum.  (The tight
+    # checks are the pinned referee above and the B = 4096 route-vs-route test below.)
+    tol = max(1e-4, 1.0 / b["x"].shape[0] ** 0.5)
     # bitwise reproducible: same torch seed -> same masks -> same bits, forward and backward
     torch.manual_seed(5)
     out2, loss2, grads2, _ = _train(pkg, oracle, model, b)
