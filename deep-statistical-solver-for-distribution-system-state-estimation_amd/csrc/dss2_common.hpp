@@ -35,6 +35,9 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // at 6 x 2 = 12 cycles per unit of k against 32 for v_mfma_f32_32x32x2_f32 (MI355X: the fp32 MFMA runs at 1/16 of bf16).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// Non-finite inputs: +-inf gives h = +-inf and the residual inf - inf = NaN, so a bf16x6 product with an infinite operand is
+// NaN where the fp32 MFMA would return +-inf (NaN stays NaN).  Non-finite in => non-finite out either way (tested:
+// tests/test_gpu_bf16x6.py::test_non_finite_inputs_stay_non_finite); a guard would cost two VALU ops per value in the hot loop.
 __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
   h = (__bf16)v;
   const float r1 = v - (float)h;

@@ -1,12 +1,15 @@
 // bf16x6 instantiations of the layer-chain kernel (dss2_gemm_chain_kernel.hpp, B16 = true).
 //
 // A translation unit of its own because it is compiled WITHOUT packed fp32 VALU ops (build.sh: -packed-fp32-ops for this
-// file only).  With them the compiler turns the epilogue's `v += prebias[m] * rowscale[row][m]` into v_pk_fma_f32 with
-// op_sel broadcasts, and those returned wrong values in lanes 48..63 -- run-to-run different -- whenever a second
-// workgroup's v_mfma_f32_32x32x16_bf16 stream shared the SIMD (two workgroups per CU, > 256 tiles); the same source with
-// v_fmac_f32 (or one workgroup per CU, or the fp32 MFMA instantiation) is bitwise reproducible and matches the fp32 path
-// to 5e-7 (tools/accuracy_bf16x6.py; DESIGN.md section 4.1a has the bisection).  Plain VALU ops are also the cheaper
-// fillers beside MFMAs (MI355X_MICROARCH.md).
+// file, dss2_wgrad16.hip and dss2_stack.hip; the build disassembles them and fails if one v_pk_*_f32 is left).
+// Root cause (round 3, profiles/r03_pk_fma_investigation.txt, tools/micro/pkfma_beside_mfma.hip): on MI355X a v_pk_fma_f32
+// / v_pk_add_f32 / v_pk_mul_f32 of one wave occasionally returns wrong values in lanes 48..63 -- the last 16-lane pass of the
+// op -- while ANOTHER wave of the same SIMD streams v_mfma_f32_32x32x16_bf16, with two or more workgroups per CU.  An 87-line
+// kernel without LDS whose failing wave executes no MFMA at all reproduces it (fp32 MFMAs or plain VALU work beside it: never;
+// one workgroup per CU: never), so it is neither an LDS race of this kernel nor a missed MFMA -> VALU hazard of the compiler.
+// Round 2 met it as run-to-run different values of the epilogue's `v += prebias[m] * rowscale[row][m]`; with today's paired
+// operand split (split3_pair -> v_pk_add_f32) a packed build returns garbage in every lane (tools/pk_stress.py).  Plain VALU
+// ops are also the cheaper fillers beside MFMAs (MI355X_MICROARCH.md).
 #include <stdlib.h>
 
 #include "dss2_gemm_chain_kernel.hpp"
