@@ -134,7 +134,7 @@ class StackArgs(C.Structure):
                 ("tile_start", C.c_void_p), ("ntiles", C.c_int32), ("tm", C.c_int32),
                 ("ell_w", C.c_void_p), ("ell_e", C.c_void_p), ("ell_width", C.c_int32),
                 ("ellT_w", C.c_void_p), ("ellT_e", C.c_void_p), ("ellT_width", C.c_int32),
-                ("deg_pows", C.c_void_p), ("xs", C.c_void_p), ("acts", C.c_void_p),
+                ("deg_pows", C.c_void_p), ("eacache", C.c_void_p), ("xs", C.c_void_p), ("acts", C.c_void_p),
                 ("out", C.c_void_p), ("ldo", C.c_int64), ("gout", C.c_void_p), ("ldg", C.c_int64),
                 ("dxbuf", C.c_void_p), ("dx_out", C.c_void_p),
                 ("slab", C.c_void_p), ("slab_stride", C.c_int64), ("n_wg", C.c_int32),
@@ -216,7 +216,7 @@ _SIGNATURES = {
     "dss2_stack_flat_floats": (C.c_int64, [C.POINTER(StackDims)]),
     "dss2_stack_supported": (C.c_int, [C.POINTER(StackDims), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_stack_pack": (C.c_int, [C.POINTER(StackDims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
-                                  C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "dss2_stack_forward": (C.c_int, [C.POINTER(StackArgs), C.c_void_p]),
     "dss2_stack_backward": (C.c_int, [C.POINTER(StackArgs), C.c_void_p]),
     "dss2_stack_reduce": (C.c_int, [C.POINTER(StackDims), C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

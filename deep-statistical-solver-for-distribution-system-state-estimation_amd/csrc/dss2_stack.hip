@@ -89,13 +89,40 @@ __device__ __forceinline__ void split8_store(const float (&v)[8], uint32_t* dst 
 // =====================================================================================================================
 // pack: fold + bf16x3 fragments + fp32 copies, one launch per step
 // =====================================================================================================================
+struct EaPrep {      // per-tile edge-feature cache: [ntiles][D + DT][64][8] floats, rows as stage_edges lays them out in LDS
+  const float* ea; int64_t ldea; const int32_t* ell_e; const int32_t* ellT_e; int D, DT, tm, ntiles; float* cache;
+};
+
 __global__ void __launch_bounds__(256) stack_pack_kernel(const dss2_stack_dims d, const float* const* __restrict__ params,
                                                          uint32_t* __restrict__ wpack, unsigned long long* rng_state,
                                                          unsigned long long* rng_snap, unsigned long long host_seed,
-                                                         int use_host_seed, float* tick) {
+                                                         int use_host_seed, float* tick, const EaPrep ep) {
   __shared__ float src[SH][SH + 1], wm[SH][SH + 1], w2s[SH][SH + 1];
   const int tid = threadIdx.x;
   const int per_block = d.n_hh * SNM + 2;
+  if ((int)blockIdx.x >= d.n_blocks * per_block) {
+    // ---- edge-feature cache of one tile: the gathered, sign-corrected edge_attr row of every (slot, row) of its two ELL slices,
+    // so that the forward / backward launches stage them with plain 16-byte copies instead of dependent gathers
+    const int tile = blockIdx.x - d.n_blocks * per_block;
+    float* out = ep.cache + (size_t)tile * (ep.D + ep.DT) * STM * 8;
+    for (int idx = tid; idx < (ep.D + ep.DT) * STM; idx += 256) {
+      const bool tr = idx >= ep.D * STM;
+      const int li = tr ? idx - ep.D * STM : idx, k = li >> 6, r = li & 63;
+      const int W = tr ? ep.DT : ep.D;
+      int2 en = make_int2(0, -1);
+      if (r < ep.tm) en = reinterpret_cast<const int2*>(tr ? ep.ellT_e : ep.ell_e)[((size_t)tile * W + k) * ep.tm + r];
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+      if (en.y != -1) {
+        const float* e = ep.ea + (int64_t)(en.y & 0x7fffffff) * ep.ldea;
+        const float sgn = en.y < 0 ? -1.f : 1.f;
+        a = f32x4{e[0] * sgn, e[1], e[2] * sgn, e[3]};
+        c = f32x4{e[4], e[5], 0.f, 0.f};
+      }
+      *reinterpret_cast<f32x4*>(out + idx * 8) = a;
+      *reinterpret_cast<f32x4*>(out + idx * 8 + 4) = c;
+    }
+    return;
+  }
   const int b = blockIdx.x / per_block, u = blockIdx.x - b * per_block;
   const float* const* P = params + (size_t)b * params_per_block(d.n_hh);
   uint32_t* wb = wpack + (size_t)b * wp_block_words(d.n_hh);
@@ -196,25 +223,18 @@ __device__ __forceinline__ float edge_z(const float (&w)[SW1LD], float b, f32x4 
   return (zt + zs) + ze;
 }
 
-// the tile's slice of an {other node, ent} ELL table -> other[D][64] (-1 = empty) and the sign-corrected edge_attr rows [D][64][8]
-__device__ __forceinline__ void stage_edges(const int32_t* __restrict__ ell_e, int tile, int D, int tm, const float* __restrict__ ea,
-                                            int64_t ldea, int* other, float* eaL, int tid, int nthreads) {
+// the tile's slice of an {other node, ent} ELL table -> other[D][64] (-1 = empty) and its edge_attr rows [D][64][8] from the
+// per-tile cache the pack launch has gathered (sign-corrected; independent 16-byte copies, no dependent gather)
+__device__ __forceinline__ void stage_edges(const int32_t* __restrict__ ell_e, int tile, int D, int tm, const float* __restrict__ cache,
+                                            int* other, float* eaL, int tid, int nthreads) {
   const int2* src = reinterpret_cast<const int2*>(ell_e) + (size_t)tile * D * tm;
   for (int idx = tid; idx < D * STM; idx += nthreads) {
     const int k = idx >> 6, r = idx & 63;
     int2 en = make_int2(0, -1);
     if (r < tm) en = src[k * tm + r];
-    const bool ok = en.y != -1;
-    other[idx] = ok ? en.x : -1;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
-    if (ok) {
-      const float* e = ea + (int64_t)(en.y & 0x7fffffff) * ldea;
-      const float sgn = en.y < 0 ? -1.f : 1.f;
-      a = f32x4{e[0] * sgn, e[1], e[2] * sgn, e[3]};
-      c = f32x4{e[4], e[5], 0.f, 0.f};
-    }
-    *reinterpret_cast<f32x4*>(eaL + idx * 8) = a;
-    *reinterpret_cast<f32x4*>(eaL + idx * 8 + 4) = c;
+    other[idx] = en.y != -1 ? en.x : -1;
+    *reinterpret_cast<f32x4*>(eaL + idx * 8) = *reinterpret_cast<const f32x4*>(cache + idx * 8);
+    *reinterpret_cast<f32x4*>(eaL + idx * 8 + 4) = *reinterpret_cast<const f32x4*>(cache + idx * 8 + 4);
   }
 }
 
@@ -297,7 +317,7 @@ __global__ void __launch_bounds__(512, 2) stack_fwd_kernel(const dss2_stack_args
     *reinterpret_cast<f32x4*>(dps + tid * 4) = v;
   }
   stage_ell_w(p.ell_w, tile, D, p.tm, ellw, tid, 512);
-  stage_edges(p.ell_e, tile, D, p.tm, p.ea, p.ldea, other, eaL, tid, 512);
+  stage_edges(p.ell_e, tile, D, p.tm, p.eacache + (size_t)tile * (D + p.ellT_width) * STM * 8, other, eaL, tid, 512);
   if (p.tm <= 32)      // rows 32..63 of the tile buffers are never produced: keep them zero (finite) for the pad-row hops
     for (int idx = tid; idx < 32 * SXLD * 4; idx += 512) { const int bsel = idx / (32 * SXLD); smem[bsel * STM * SXLD + 32 * SXLD + idx % (32 * SXLD)] = 0.f; }
 
@@ -487,35 +507,42 @@ static size_t stack_fwd_lds(int D) { return (size_t)(STM * SXLD * 4 + STM * SFN 
 constexpr int STLD = 68;      // row stride of the transposed fp32 copies [column][64 rows]: 16-byte rows of 4 consecutive tile
                               // rows, conflict-free ds_read_b128 for 32 lanes on 32 consecutive columns (68 c mod 64 = 4 c)
 
-// acc[j][i] += sum over the tile's 64 rows of Z[row][j] a[row][i]   (fp32 MFMA: k = row, two rows per instruction).  Both
-// operands come from the TRANSPOSED copies: lane (c32, half) reads four consecutive rows of its column per ds_read_b128,
-// 16 reads feed 32 MFMAs (the row-major form needed 64 scalar reads and ran at 2.5x the pipe time).
-__device__ __forceinline__ f32x16 wgrad_block(f32x16 acc, const float* zt /* ZT + (col block + c32) * STLD + 32 half */,
-                                              const float* at /* AT + c32 * STLD + 32 half */, bool short_t) {
-  // operands of the next eight MFMAs are requested before the current eight are issued (LDS latency behind 512 cycles of MFMA)
-  f32x4 a0 = *reinterpret_cast<const f32x4*>(zt), b0 = *reinterpret_cast<const f32x4*>(at);
-  f32x4 a1 = *reinterpret_cast<const f32x4*>(zt + 4), b1 = *reinterpret_cast<const f32x4*>(at + 4);
-#pragma unroll
-  for (int t = 0; t < 8; t += 2) {
-    f32x4 na0 = a0, nb0 = b0, na1 = a1, nb1 = b1;
-    if (t + 2 < 8) {
-      na0 = *reinterpret_cast<const f32x4*>(zt + 4 * (t + 2)); nb0 = *reinterpret_cast<const f32x4*>(at + 4 * (t + 2));
-      na1 = *reinterpret_cast<const f32x4*>(zt + 4 * (t + 3)); nb1 = *reinterpret_cast<const f32x4*>(at + 4 * (t + 3));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
-    if (short_t && t == 2) break;      // 32-row tiles: 16 rows per half
+// acc[j][i] += sum over the tile's rows of Z[row][j] a[row][i] as bf16x6 on the bf16 matrix pipe (fp32-accurate, dss2_common.hpp).
+// Both operands come from the TRANSPOSED fp32 copies, where the contraction index (the tile row) is the fast one: lane
+// (c32, half) reads rows 16 kg + 8 half .. + 7 of its column as two ds_read_b128 -- exactly an A / B fragment of
+// v_mfma_f32_32x32x16_bf16 -- and splits them in registers.  4 k-groups x 6 MFMAs = 768 cycles of matrix pipe per block (the
+// fp32 form, 32 x v_mfma_f32_32x32x2_f32, held the pipe for 2048 and starved the data-gradient waves of the same SIMD).
+__device__ __forceinline__ void split8(const float* src, bf16x8& h, bf16x8& m, bf16x8& l) {
+  const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+  uint32_t sh[4], sm[4], sl[4];
+  split3_pair(v0[0], v0[1], sh[0], sm[0], sl[0]);
+  split3_pair(v0[2], v0[3], sh[1], sm[1], sl[1]);
+  split3_pair(v1[0], v1[1], sh[2], sm[2], sl[2]);
+  split3_pair(v1[2], v1[3], sh[3], sm[3], sl[3]);
+  h = __builtin_bit_cast(bf16x8, u32x4{sh[0], sh[1], sh[2], sh[3]});
+  m = __builtin_bit_cast(bf16x8, u32x4{sm[0], sm[1], sm[2], sm[3]});
+  l = __builtin_bit_cast(bf16x8, u32x4{sl[0], sl[1], sl[2], sl[3]});
+}
+
+__device__ __forceinline__ f32x16 wgrad_block(f32x16 acc, const float* zt /* ZT + (col block + c32) * STLD + 8 half */,
+                                              const float* at /* AT + c32 * STLD + 8 half */, bool short_t) {
+#pragma unroll 1
+  for (int kg = 0; kg < (short_t ? 2 : 4); ++kg) {
+    bf16x8 ah, am, al, bh, bm, bl;
+    split8(zt + 16 * kg, ah, am, al);
+    split8(at + 16 * kg, bh, bm, bl);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);      // smallest terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
   }
   return acc;
 }
 
 // column sums of a [64][ld] fp32 tile, 32 columns, ONE wave: lane (r8 = lane >> 3, cq = 4 (lane & 7)) adds rows r8 + 8 i; the
-// eight row lanes meet through a wave-private LDS scratch [8][32] (one round trip: cross-lane shuffles are ds_bpermute, a
+// eight row lanes meet by one shuffle and a wave-private LDS scratch [4][32] (one round trip: cross-lane shuffles are ds_bpermute, a
 // dependent chain of three LDS latencies per value); lanes 0..31 return the sum of their column.  `scale`: optional per-row
 // factor [64][4], column m.
 __device__ __forceinline__ float colsum32(const float* tile, int ld, int lane, const float* scale, int m, float* scratch) {
@@ -527,12 +554,14 @@ __device__ __forceinline__ float colsum32(const float* tile, int ld, int lane, c
     const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * ld + cq);
     if (scale) s += v * scale[row * 4 + m]; else s += v;
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s[q] += __shfl_xor(s[q], 32);      // rows r8 and r8 + 4 (one cross-lane step, four values in flight)
   wave_lds_sync();      // (the previous call's readers are done)
-  *reinterpret_cast<f32x4*>(scratch + r8 * SH + cq) = s;
+  if (lane < 32) *reinterpret_cast<f32x4*>(scratch + r8 * SH + cq) = s;
   wave_lds_sync();
   float t = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) t += scratch[k * SH + (lane & 31)];
+  for (int k = 0; k < 4; ++k) t += scratch[k * SH + (lane & 31)];
   return t;
 }
 
@@ -554,8 +583,8 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
   float* w1T = w1L + SH * SW1LD;                      // [16][36]: W1[:, 0:16] transposed (dx)
   float* accS = w1T + 16 * SXLD;                      // bias sums: db[l][32] (l < 7) | dbf[3][32] | dbh[8] | dW1 [32][24] (col 22 = db1)
   constexpr int ACC_DBF = S_MAX_HH * SH, ACC_DBH = ACC_DBF + SNM * SH, ACC_W1 = ACC_DBH + 8, ACC_WORDS = ACC_W1 + SH * SW1LD;
-  float* csum = accS + ACC_WORDS;                     // [8][32] scratch of the bias-sum wave
-  bf16x8* wfrag = reinterpret_cast<bf16x8*>(csum + 8 * SH);         // [6 k-groups][3 planes][64 lanes]: the unit's data-gradient operand
+  float* csum = accS + ACC_WORDS;                     // [4][4][32] wave-private scratches of the bias sums
+  bf16x8* wfrag = reinterpret_cast<bf16x8*>(csum + 4 * 4 * SH);         // [6 k-groups][3 planes][64 lanes]: the unit's data-gradient operand
   float* eaL = reinterpret_cast<float*>(wfrag + 6 * 3 * 64);        // [D][64][8]
   float* eaT = eaL + D * STM * 8;                     // [DT][64][8]
   int2* ellTw = reinterpret_cast<int2*>(eaT + DT * STM * 8);    // [DT][64]
@@ -617,8 +646,9 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
           *reinterpret_cast<f32x4*>(dps + tid * 4) = v;
         }
         stage_ell_w(p.ellT_w, tile, DT, p.tm, ellTw, tid, 512);
-        stage_edges(p.ell_e, tile, D, p.tm, p.ea, p.ldea, other, eaL, tid, 512);
-        stage_edges(p.ellT_e, tile, DT, p.tm, p.ea, p.ldea, otherT, eaT, tid, 512);
+        const float* ec = p.eacache + (size_t)tile * (D + DT) * STM * 8;
+        stage_edges(p.ell_e, tile, D, p.tm, ec, other, eaL, tid, 512);
+        stage_edges(p.ellT_e, tile, DT, p.tm, ec + D * STM * 8, otherT, eaT, tid, 512);
         staged_tile = tile;
       }
       {   // the head's data-gradient operand fragments (2 k-groups)
@@ -706,13 +736,16 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
           for (int k = 0; k < nblk; ++k) {
             const int q = q0 + k;
             if (wave == (q & 7)) {
-              const int rbase = short_t ? 16 * half : 32 * half;      // 32-row tiles: k runs over rows 0..31 only
-              const float* zt = ZT + (k * SH + c32) * STLD + rbase;
-              const float* at = ATbuf[u & 1] + c32 * STLD + rbase;
+              const float* zt = ZT + (k * SH + c32) * STLD + 8 * half;      // (32-row tiles: k runs over rows 0..31 only)
+              const float* at = ATbuf[u & 1] + c32 * STLD + 8 * half;
               const int slot = q >> 3;
               if (slot == 0) acc0 = wgrad_block(acc0, zt, at, short_t);
               else if (slot == 1) acc1 = wgrad_block(acc1, zt, at, short_t);
               else acc2 = wgrad_block(acc2, zt, at, short_t);
+              if (u == 0) {      // folded conv 0: dbf_k[c] += sum_rows (A^k deg)[row] g[row][c]  (this wave's share of the bias sums)
+                const float sf = colsum32(Z, SZLD, lane, dps, k, csum + k * (4 * SH));
+                if (lane < 32) accS[ACC_DBF + k * SH + lane] += sf;
+              }
             }
           }
           if (dgrad_wave) {
@@ -735,15 +768,8 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
               s += __shfl_xor(s, 8); s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
               if (lane < 8 && lane < dout) accS[ACC_DBH + lane] += s;
             } else {         // db_u[c] += sum_rows g[row][c];  folded conv 0 also dbf_m[c] += sum_rows (A^m deg)[row] g[row][c]
-              float s = colsum32(Z, SZLD, lane, nullptr, 0, csum);
+              const float s = colsum32(Z, SZLD, lane, nullptr, 0, csum + 3 * (4 * SH));
               if (lane < 32) accS[u * SH + lane] += s;
-              if (u == 0) {
-#pragma unroll
-                for (int m = 0; m < SNM; ++m) {
-                  s = colsum32(Z, SZLD, lane, dps, m, csum);
-                  if (lane < 32) accS[ACC_DBF + m * SH + lane] += s;
-                }
-              }
             }
           }
         }
@@ -915,7 +941,7 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
 
 static size_t stack_bwd_lds(int D, int DT) {
   const size_t f = (size_t)STM * SZLD + 4 * STM * SXLD + 3 * SH * STLD + 2 * SH * STLD + 2 * STM * SFN + STM * 4 + SH * SW1LD + 16 * SXLD +
-                   (S_MAX_HH * SH + SNM * SH + 8 + SH * SW1LD + 8 * SH) + (size_t)(D + DT) * STM * 8;
+                   (S_MAX_HH * SH + SNM * SH + 8 + SH * SW1LD + 4 * 4 * SH) + (size_t)(D + DT) * STM * 8;
   return f * 4 + (size_t)6 * 3 * 64 * 16 + (size_t)DT * STM * 8 + (size_t)(D + DT) * STM * 4;
 }
 
@@ -1047,12 +1073,20 @@ extern "C" int dss2_stack_supported(const dss2_stack_dims* d, int hid, int nmat,
 }
 
 extern "C" int dss2_stack_pack(const dss2_stack_dims* d, const float* const* params, uint32_t* wpack, uint64_t* rng_state,
-                               uint64_t* rng_snapshot, uint64_t host_seed, int use_host_seed, float* tick, void* stream) {
+                               uint64_t* rng_snapshot, uint64_t host_seed, int use_host_seed, float* tick,
+                               const dss2_stack_args* tiles, void* stream) {
   if (!dims_ok(*d) || !params || !wpack) { set_error("stack_pack: bad arguments"); return 2; }
   if (rng_snapshot && !use_host_seed && !rng_state) { set_error("stack_pack: rng_state missing"); return 2; }
-  hipLaunchKernelGGL(stack_pack_kernel, dim3(d->n_blocks * (d->n_hh * SNM + 2)), dim3(256), 0, as_stream(stream), *d, params, wpack,
-                     reinterpret_cast<unsigned long long*>(rng_state), reinterpret_cast<unsigned long long*>(rng_snapshot),
-                     (unsigned long long)host_seed, use_host_seed, tick);
+  EaPrep ep = {};
+  if (tiles) {      // also gather the per-tile edge-feature cache of this forward call (args: ea, ELL slices, tiles, eacache)
+    const dss2_stack_args& a = *tiles;
+    if (!a.ea || !a.ell_e || !a.ellT_e || !a.eacache || a.ntiles < 1 || (a.tm != 32 && a.tm != 64) || a.ell_width < 1 ||
+        a.ell_width > S_MAX_ELL || a.ellT_width < 1 || a.ellT_width > S_MAX_ELL) { set_error("stack_pack: bad tile arguments"); return 2; }
+    ep = EaPrep{a.ea, a.ldea, a.ell_e, a.ellT_e, a.ell_width, a.ellT_width, a.tm, a.ntiles, a.eacache};
+  }
+  hipLaunchKernelGGL(stack_pack_kernel, dim3(d->n_blocks * (d->n_hh * SNM + 2) + ep.ntiles), dim3(256), 0, as_stream(stream), *d, params,
+                     wpack, reinterpret_cast<unsigned long long*>(rng_state), reinterpret_cast<unsigned long long*>(rng_snapshot),
+                     (unsigned long long)host_seed, use_host_seed, tick, ep);
   return check_launch("stack_pack");
 }
 
@@ -1060,7 +1094,7 @@ static int stack_args_ok(const dss2_stack_args& a, const char* what) {
   if (!dims_ok(a.dims)) { set_error("%s: unsupported dimensions", what); return 2; }
   if (a.tm != 32 && a.tm != 64) { set_error("%s: tiles of %d rows (needs 32 or 64)", what, a.tm); return 2; }
   if (a.ell_width < 1 || a.ell_width > S_MAX_ELL) { set_error("%s: ELL width %d", what, a.ell_width); return 2; }
-  if (!a.x || !a.ea || !a.wpack || !a.tile_start || !a.ell_w || !a.ell_e || !a.deg_pows || !a.acts || (a.dims.n_blocks > 1 && !a.xs)) {
+  if (!a.x || !a.ea || !a.wpack || !a.tile_start || !a.ell_w || !a.ell_e || !a.deg_pows || !a.acts || !a.eacache || (a.dims.n_blocks > 1 && !a.xs)) {
     set_error("%s: null argument", what); return 2;
   }
   return 0;
@@ -1071,6 +1105,7 @@ extern "C" int dss2_stack_forward(const dss2_stack_args* ap, void* stream) {
   if (a.ntiles <= 0) return 0;
   if (int rc = stack_args_ok(a, "stack_forward")) return rc;
   if (!a.out) { set_error("stack_forward: null output"); return 2; }
+  if (a.ellT_width < 1 || a.ellT_width > S_MAX_ELL) { set_error("stack_forward: ellT_width (the edge-feature cache's stride) missing"); return 2; }
   static std::atomic<uint32_t> done{0};
   if (ensure_max_lds(reinterpret_cast<const void*>(stack_fwd_kernel), done, "stack_forward")) return 1;
   hipLaunchKernelGGL(stack_fwd_kernel, dim3(a.ntiles), dim3(512), stack_fwd_lds(a.ell_width), as_stream(stream), a);

@@ -538,6 +538,8 @@ typedef struct dss2_stack_args {
   const int32_t* ell_w; const int32_t* ell_e; int32_t ell_width;        /* by target: {local col, weight} / {local col, ent} */
   const int32_t* ellT_w; const int32_t* ellT_e; int32_t ellT_width;     /* by source (backward only) */
   const float* deg_pows;                     /* [N, 4] column m = A^m deg */
+  float* eacache;                            /* [ntiles][ell_width + ellT_width][64][8]: per-tile gathered, sign-corrected edge_attr
+                                                rows; written by dss2_stack_pack (tiles != NULL), read by forward and backward */
   float* xs;                                 /* [n_blocks][N][8]: slot b = input of block b (slot 0 unused) */
   float* acts;                               /* [n_blocks][n_hh + 1][N][32]: slot 0 = aggregated hidden S, slot l = h_l */
   float* out; int64_t ldo;                   /* forward: [N, dout_last] */
@@ -558,7 +560,11 @@ int dss2_stack_supported(const dss2_stack_dims* dims, int hid, int nmat, int fn,
  * dropout state hand-over of dss2_rng_next done by the same launch.  tick (optional): *tick += 1 (the device-side step
  * count of a capturable optimizer). */
 int dss2_stack_pack(const dss2_stack_dims* dims, const float* const* params, uint32_t* wpack, uint64_t* rng_state,
-                    uint64_t* rng_snapshot, uint64_t host_seed, int use_host_seed, float* tick, void* stream);
+                    uint64_t* rng_snapshot, uint64_t host_seed, int use_host_seed, float* tick,
+                    const dss2_stack_args* tiles, void* stream);
+/* tiles (optional, the forward's argument struct): the same launch also gathers args->eacache from args->ea through the two
+ * ELL slices (edge_attr changes per batch, the weights per step: both are per-forward work).  NULL: weights only (a backward
+ * that has to re-pack because another forward ran in between). */
 int dss2_stack_forward(const dss2_stack_args* args, void* stream);
 int dss2_stack_backward(const dss2_stack_args* args, void* stream);
 /* flat[i] = sum over the n_slabs slabs (fixed order; slab_stride a multiple of 4), then the chain rule of the fold: conv 0's
