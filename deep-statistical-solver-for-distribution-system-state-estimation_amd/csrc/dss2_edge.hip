@@ -188,6 +188,7 @@ struct EdgeCombineArgs {
   const float* AB; int64_t ldab; const float* ea; int64_t ldea; const float* W1c; int64_t ldw; const float* b1;
   const float* dS; const int32_t* rowptr; const int32_t* col; const int32_t* ent;
   float* S; float* dAB; float* slab; int64_t n_nodes; int h, fe, by_source;
+  int hfull, c0;      // the launch covers hidden units c0 .. c0 + h - 1 of hfull (wider layers run as several launches of <= 256 units)
 };
 
 template <int FPL, bool BWD>
@@ -196,16 +197,16 @@ __global__ void __launch_bounds__(256) edge_combine_kernel(const EdgeCombineArgs
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wpb = blockDim.x >> 6;
-  const int h = p.h, fe = p.fe;
+  const int h = p.h, fe = p.fe, hf = p.hfull, c0 = p.c0;
   float w[FPL][EC_MAXFE], b[FPL], dw[BWD ? FPL : 1][EC_MAXFE], db[BWD ? FPL : 1];
 #pragma unroll
   for (int f = 0; f < FPL; ++f) {
     const int j = lane + 64 * f;
-    b[f] = j < h ? p.b1[j] : 0.f;
+    b[f] = j < h ? p.b1[c0 + j] : 0.f;
     if (BWD) db[f] = 0.f;
 #pragma unroll
     for (int k = 0; k < EC_MAXFE; ++k) {
-      w[f][k] = (j < h && k < fe) ? p.W1c[(size_t)j * p.ldw + k] : 0.f;
+      w[f][k] = (j < h && k < fe) ? p.W1c[(size_t)(c0 + j) * p.ldw + k] : 0.f;
       if (BWD) dw[f][k] = 0.f;
     }
   }
@@ -215,8 +216,8 @@ __global__ void __launch_bounds__(256) edge_combine_kernel(const EdgeCombineArgs
     for (int f = 0; f < FPL; ++f) {
       const int j = lane + 64 * f;
       // rows are targets (own = A part) or, in the by-source pass, sources (own = B part)
-      own[f] = j < h ? p.AB[i * p.ldab + (BWD && p.by_source ? h : 0) + j] : 0.f;
-      g[f] = (BWD && !p.by_source && j < h) ? p.dS[i * h + j] : 0.f;
+      own[f] = j < h ? p.AB[i * p.ldab + (BWD && p.by_source ? hf : 0) + c0 + j] : 0.f;
+      g[f] = (BWD && !p.by_source && j < h) ? p.dS[i * hf + c0 + j] : 0.f;
       acc[f] = 0.f;
     }
     const int e1 = p.rowptr[i + 1];
@@ -233,14 +234,14 @@ __global__ void __launch_bounds__(256) edge_combine_kernel(const EdgeCombineArgs
 #pragma unroll
       for (int f = 0; f < FPL; ++f) {
         const int j = lane + 64 * f;
-        const float oth = j < h ? p.AB[other * p.ldab + (BWD && p.by_source ? 0 : h) + j] : 0.f;
+        const float oth = j < h ? p.AB[other * p.ldab + (BWD && p.by_source ? 0 : hf) + c0 + j] : 0.f;
         float z = (own[f] + oth) + b[f];
 #pragma unroll
         for (int k = 0; k < EC_MAXFE; ++k) z = fmaf(w[f][k], a[k], z);
         if (!BWD) {
           acc[f] += fmaxf(z, 0.f);
         } else {
-          const float gg = p.by_source ? ((j < h) ? p.dS[other * h + j] : 0.f) : g[f];
+          const float gg = p.by_source ? ((j < h) ? p.dS[other * hf + c0 + j] : 0.f) : g[f];
           const float dz = z > 0.f ? gg : 0.f;
           acc[f] += dz;
           if (!p.by_source) {
@@ -255,14 +256,14 @@ __global__ void __launch_bounds__(256) edge_combine_kernel(const EdgeCombineArgs
     for (int f = 0; f < FPL; ++f) {
       const int j = lane + 64 * f;
       if (j < h) {
-        if (!BWD) p.S[i * h + j] = acc[f];
-        else p.dAB[i * p.ldab + (p.by_source ? h : 0) + j] = acc[f];
+        if (!BWD) p.S[i * hf + c0 + j] = acc[f];
+        else p.dAB[i * p.ldab + (p.by_source ? hf : 0) + c0 + j] = acc[f];
       }
     }
   }
   if (!BWD) return;
   if (p.by_source || !p.slab) return;
-  float* out = p.slab + (size_t)blockIdx.x * ((size_t)h * fe + h);      // [h][fe] dW1c, then [h] db1
+  float* out = p.slab + (size_t)blockIdx.x * ((size_t)hf * fe + hf) + (size_t)c0 * fe;      // [hfull][fe] dW1c, then [hfull] db1
   for (int wv = 0; wv < wpb; ++wv) {
     if (wave == wv) {
 #pragma unroll
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(256) edge_combine_kernel(const EdgeCombineArgs
     const int j = idx / fe, k = idx - j * fe;
     out[idx] = red[j * (EC_MAXFE + 1) + k];
   }
-  for (int j = threadIdx.x; j < h; j += blockDim.x) out[(size_t)h * fe + j] = red[j * (EC_MAXFE + 1) + EC_MAXFE];
+  for (int j = threadIdx.x; j < h; j += blockDim.x) out[(size_t)(hf - c0) * fe + c0 + j] = red[j * (EC_MAXFE + 1) + EC_MAXFE];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -971,15 +972,18 @@ extern "C" int dss2_edge_tile_bwd(const float* x, int64_t ldx, const float* ea, 
 extern "C" int dss2_edge_combine_fwd(const float* AB, int64_t ldab, const float* ea, int64_t ldea, const float* W1c, int64_t ldw,
                                      const float* b1, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* S,
                                      int64_t n_nodes, int h, int fe, void* stream) {
-  if (h <= 0 || h > 256 || fe < 0 || fe > EC_MAXFE) { set_error("edge_combine_fwd: h=%d (1..256) / fe=%d (0..8) unsupported", h, fe); return 2; }
+  if (h <= 0 || fe < 0 || fe > EC_MAXFE) { set_error("edge_combine_fwd: h=%d / fe=%d (0..8) unsupported", h, fe); return 2; }
   if (n_nodes <= 0) return 0;
-  EdgeCombineArgs a{AB, ldab, ea, ldea, W1c, ldw, b1, nullptr, rowptr, col, ent, S, nullptr, nullptr, n_nodes, h, fe, 0};
   int64_t blocks = (n_nodes + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  const int fpl = (h + 63) / 64;
+  for (int c0 = 0; c0 < h; c0 += 256) {      // hidden units are independent: wider layers run as launches of <= 256 units
+    const int hc = h - c0 < 256 ? h - c0 : 256;
+    EdgeCombineArgs a{AB, ldab, ea, ldea, W1c, ldw, b1, nullptr, rowptr, col, ent, S, nullptr, nullptr, n_nodes, hc, fe, 0, h, c0};
+    const int fpl = (hc + 63) / 64;
 #define L(FPL) hipLaunchKernelGGL((edge_combine_kernel<FPL, false>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a)
-  if (fpl == 1) L(1); else if (fpl == 2) L(2); else if (fpl == 3) L(3); else L(4);
+    if (fpl == 1) L(1); else if (fpl == 2) L(2); else if (fpl == 3) L(3); else L(4);
 #undef L
+  }
   return check_launch("edge_combine_fwd");
 }
 
@@ -987,16 +991,19 @@ extern "C" int dss2_edge_combine_bwd(const float* AB, int64_t ldab, const float*
                                      const float* b1, const float* dS, const int32_t* rowptr, const int32_t* col,
                                      const int32_t* ent, float* dAB, float* slab, int n_slabs, int64_t n_nodes, int h, int fe,
                                      int by_source, void* stream) {
-  if (h <= 0 || h > 256 || fe < 0 || fe > EC_MAXFE) { set_error("edge_combine_bwd: h=%d (1..256) / fe=%d (0..8) unsupported", h, fe); return 2; }
+  if (h <= 0 || fe < 0 || fe > EC_MAXFE) { set_error("edge_combine_bwd: h=%d / fe=%d (0..8) unsupported", h, fe); return 2; }
   if (!by_source && (!slab || n_slabs <= 0)) { set_error("edge_combine_bwd: slab missing"); return 2; }
   if (n_nodes <= 0) return 0;
-  EdgeCombineArgs a{AB, ldab, ea, ldea, W1c, ldw, b1, dS, rowptr, col, ent, nullptr, dAB, slab, n_nodes, h, fe, by_source};
   int64_t blocks = by_source ? (n_nodes + 3) / 4 : n_slabs;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  const int fpl = (h + 63) / 64;
+  for (int c0 = 0; c0 < h; c0 += 256) {
+    const int hc = h - c0 < 256 ? h - c0 : 256;
+    EdgeCombineArgs a{AB, ldab, ea, ldea, W1c, ldw, b1, dS, rowptr, col, ent, nullptr, dAB, slab, n_nodes, hc, fe, by_source, h, c0};
+    const int fpl = (hc + 63) / 64;
 #define L(FPL) hipLaunchKernelGGL((edge_combine_kernel<FPL, true>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a)
-  if (fpl == 1) L(1); else if (fpl == 2) L(2); else if (fpl == 3) L(3); else L(4);
+    if (fpl == 1) L(1); else if (fpl == 2) L(2); else if (fpl == 3) L(3); else L(4);
 #undef L
+  }
   return check_launch("edge_combine_bwd");
 }
 

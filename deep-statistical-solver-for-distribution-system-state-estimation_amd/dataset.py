@@ -180,10 +180,11 @@ class MixedDataset:
     TopologyHint.  Nothing is read back: a shuffled mixed-topology epoch has no host synchronisation at all."""
 
     def __init__(self, parts: Sequence[DeviceDataset], ids: Optional[np.ndarray] = None):
-        if len({p.n for p in parts}) != 1:
-            raise NotImplementedError("mixed datasets need the same bus count in every part")
         self.parts = list(parts)
-        self.n = parts[0].n
+        # n: the common bus count, or None when the parts differ (PyG's DataLoader, dss2_run.py:68-69, takes any data list):
+        # such batches are collated the same way (per-slot node offsets) but their structure is built without a TopologyHint
+        # (one 64-byte device-to-host copy of the build statistics per new batch)
+        self.n = parts[0].n if len({p.n for p in parts}) == 1 else None
         self.start = np.concatenate([[0], np.cumsum([p.S for p in parts])]).astype(np.int64)
         self.ids = np.arange(self.start[-1], dtype=np.int64) if ids is None else np.asarray(ids, dtype=np.int64)
 
@@ -204,14 +205,17 @@ class MixedDataset:
         return MixedDataset(self.parts, rng.permutation(self.ids))
 
     def collate(self, ids: np.ndarray) -> Batch:
-        B, n, dev = int(ids.size), self.n, self.device
+        B, dev = int(ids.size), self.device
         part = np.searchsorted(self.start, ids, side="right") - 1           # part of every slot
         e_slot = np.asarray([p.e for p in self.parts], dtype=np.int64)[part]
         edge_off = np.concatenate([[0], np.cumsum(e_slot)]).astype(np.int64)
         E = int(edge_off[-1])
+        n_slot = np.asarray([p.n for p in self.parts], dtype=np.int64)[part]
+        node_off = np.concatenate([[0], np.cumsum(n_slot)]).astype(np.int64)
+        Ntot = int(node_off[-1])
         p0 = self.parts[0]
-        x = torch.empty(B * n, p0.x.size(2), dtype=_F32, device=dev)
-        y = torch.empty(B * n, p0.y.size(2), dtype=_F32, device=dev)
+        x = torch.empty(Ntot, p0.x.size(2), dtype=_F32, device=dev)
+        y = torch.empty(Ntot, p0.y.size(2), dtype=_F32, device=dev)
         ea = torch.empty(E, p0.edge_attr.size(2), dtype=_F32, device=dev)
         ei = torch.empty(2, E, dtype=torch.int64, device=dev)
         L = _lib.lib()
@@ -220,7 +224,8 @@ class MixedDataset:
             slots = np.nonzero(part == k)[0]
             if slots.size == 0:
                 continue
-            tab = np.stack([ids[slots] - self.start[k], slots * n, edge_off[slots]]).astype(np.int64)
+            n = p.n
+            tab = np.stack([ids[slots] - self.start[k], node_off[slots], edge_off[slots]]).astype(np.int64)
             tab_d = torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)      # 3 x count int64, host -> device only
             descs = (_lib.CollateDesc * 4)()
             items = [(p.x, x, n * p.x.size(2), 0, 0, p.x.size(2)), (p.y, y, n * p.y.size(2), 0, 0, p.y.size(2)),
@@ -230,6 +235,10 @@ class MixedDataset:
                 d.src, d.dst, d.chunk, d.kind, d.shared, d.nodes_per_sample = src.data_ptr(), dst.data_ptr(), chunk, kind, shared, width
             _lib.check(L.dss2_collate_ragged(C.addressof(descs), 4, tab_d[0].data_ptr(), tab_d[1].data_ptr(), tab_d[2].data_ptr(),
                                              int(slots.size), E, st), "dss2_collate_ragged")
+        if self.n is None:       # different bus counts: no closed-form tiles, the general (statistics-reading) build
+            _topology.register_topology(ei, Ntot, _topology.Topology(ei, Ntot))
+            return Batch(x, ei, ea, y, B)
+        n = self.n
         first = self.parts[int(part[0])]
         hint = _topology.TopologyHint(
             directed=first.hint(int(ids[0] - self.start[part[0]])).directed, nodes_per_graph=n,

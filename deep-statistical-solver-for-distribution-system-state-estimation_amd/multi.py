@@ -29,7 +29,7 @@ import torch.nn as nn
 from . import _lib
 from .networks import (_F32, _DESC_DTYPE, _MPNFn, _PackPlan, _MatView, _ncg, _require_gpu, _round8, _rows, _stream,
                        MPN, TAGConv, dropout_snapshot, gemm_prop, is_narrow, wgrad, _reduce, _tagconv_forward,
-                       _tagconv_backward, _tagconv_forward_global, _tagconv_backward_global)
+                       _tagconv_backward, _tagconv_forward_global, _tagconv_backward_global, use_global_path)
 from .topology import Topology, get_topology
 
 
@@ -153,6 +153,12 @@ class _EdgeAggrGeneralFn(torch.autograd.Function):
         return dx, None, None, None, dW1, g1c[h * fe:], g2[:ho * h].view(ho, h), g2[ho * h:]
 
 
+def _check_general_dims(mod) -> None:
+    if mod.dim_feate > 8:
+        raise NotImplementedError("EdgeAggregation on HIP: dim_feate <= 8 (the per-edge kernel holds a unit's edge-feature "
+                                  "weights in registers)")
+
+
 class EdgeAggregationGeneral(nn.Module):
     """/root/reference/networks.py:159-209 for any ``dim_featn`` (MultiMPN applies it to the hidden activation) and
     ``dim_feate <= 8``; same parameters and state_dict keys as ``networks.EdgeAggregation``.  ``forward`` takes the graph
@@ -160,8 +166,8 @@ class EdgeAggregationGeneral(nn.Module):
 
     def __init__(self, dim_featn, dim_feate, dim_hid, dim_out):
         super().__init__()
-        if dim_feate > 8 or dim_hid > 256:
-            raise NotImplementedError("EdgeAggregation on HIP: dim_feate <= 8 and dim_hid <= 256")
+        if dim_feate > 8:
+            raise NotImplementedError("EdgeAggregation on HIP: dim_feate <= 8")
         self.dim_featn, self.dim_feate, self.dim_hid, self.dim_out = dim_featn, dim_feate, dim_hid, dim_out
         self.edge_aggr = nn.Sequential(nn.Linear(dim_featn * 2 + dim_feate, dim_hid), nn.ReLU(), nn.Linear(dim_hid, dim_out))
         self._gplan = None
@@ -182,32 +188,34 @@ class _TAGConvPostFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, topo, mod, bias, *ws):
         x = x.contiguous()
-        if mod._plan is None or mod._plan.device != x.device or mod._plan.stacked != topo.global_only:
-            mod._plan = _PackPlan([list(ws)], x.device, stacked=topo.global_only)
+        hin, hout, nmat = mod.in_channels, mod.out_channels, mod.K + 1
+        glob = use_global_path(topo, nmat)
+        if mod._plan is None or mod._plan.device != x.device or mod._plan.stacked != glob:
+            mod._plan = _PackPlan([list(ws)], x.device, stacked=glob)
         plan = mod._plan
         ctx.ver = plan.refresh()
-        hin, hout, nmat = mod.in_channels, mod.out_channels, mod.K + 1
-        topo.lds_check(nmat, _round8(hin), _ncg(hout))
+        if not glob:
+            topo.lds_check(nmat, _round8(hin), _ncg(hout))
         relu, snap, p = _post_spec(mod, x.device)
-        out = (_tagconv_forward_global if topo.global_only else _tagconv_forward)(topo, x, plan.fwd[0], bias, nmat, hin, hout, relu=relu,
+        out = (_tagconv_forward_global if glob else _tagconv_forward)(topo, x, plan.fwd[0], bias, nmat, hin, hout, relu=relu,
                                drop=((snap, p, 1) if snap is not None else None))
         ctx.save_for_backward(x, out)
-        ctx.meta = (topo, mod, relu, snap, p)
+        ctx.meta = (topo, mod, relu, snap, p, glob)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         x, y = ctx.saved_tensors
-        topo, mod, relu, snap, p = ctx.meta
+        topo, mod, relu, snap, p, glob = ctx.meta
         plan = mod._plan
         if plan.version != ctx.ver:
             plan.refresh()
         hin, hout, nmat = mod.in_channels, mod.out_channels, mod.K + 1
         g = _gate(gout, y, snap, p) if relu else gout.contiguous()
         flat = torch.empty(nmat * hout * hin + hout, dtype=_F32, device=g.device)
-        if plan.stacked != topo.global_only:
+        if plan.stacked != glob:
             raise RuntimeError("the module's weight layouts changed between forward and backward")
-        dh = (_tagconv_backward_global if topo.global_only else _tagconv_backward)(
+        dh = (_tagconv_backward_global if glob else _tagconv_backward)(
             topo, g, x, plan.bwd[0], nmat, hin, hout, flat, need_dh=ctx.needs_input_grad[0])
         gw = [flat[m * hout * hin:(m + 1) * hout * hin].view(hout, hin) for m in range(nmat)]
         return (dh, None, None, flat[nmat * hout * hin:], *gw)
@@ -293,8 +301,12 @@ class MaskEmbdMPN(MPN, _ReferenceHelpers):
 
     def __init__(self, dim_featn, dim_feate, dim_out, dim_hid, n_gnn_layers, K, dropout_rate):
         if n_gnn_layers < 2:
-            raise NotImplementedError("MaskEmbdMPN with n_gnn_layers == 1 builds two dim_hid -> dim_out convs in the reference "
-                                      "(networks.py:408-416), which only type-checks for dim_out == dim_hid")
+            # the reference builds TWO dim_hid -> dim_out convs for n_gnn_layers == 1 (networks.py:408-416), which only runs for
+            # dim_out == dim_hid (its forward fails on the second conv otherwise): that is a two-conv stack of equal widths
+            if dim_out != dim_hid:
+                raise ValueError("MaskEmbdMPN(n_gnn_layers=1) is two dim_hid -> dim_out TAGConvs in the reference (networks.py:408-416): "
+                                 "its forward only runs for dim_out == dim_hid")
+            n_gnn_layers = 2
         super().__init__(dim_featn, dim_feate, dim_out, dim_hid, n_gnn_layers, K, dropout_rate)
         self.mask_embd = nn.Sequential(nn.Linear(dim_featn, dim_hid), nn.ReLU(), nn.Linear(dim_hid, dim_featn))
         self._me_plan = None
@@ -306,6 +318,8 @@ class MaskEmbdMPN(MPN, _ReferenceHelpers):
         _require_gpu(data.x, data.edge_index, data.edge_attr)
         topo = get_topology(data.edge_index, data.x.size(0), flip=False)
         x = _mask_embd(self, data.x, topo)
+        if not self.edge_aggr.fused_dims():
+            return self._forward_general(x, data.edge_attr, topo)
         return _MPNFn.apply(x, data.edge_attr, topo, self, *self._params())
 
 

@@ -877,8 +877,10 @@ class TAGConv(nn.Module):
 
     def __init__(self, in_channels: int, out_channels: int, K: int = 3):
         super().__init__()
-        if not 0 <= K <= 3:
-            raise NotImplementedError("TAGConv on HIP supports K in 0..3")
+        if K < 0:
+            raise ValueError("TAGConv: K >= 0")
+        # K <= 3: the fused tile GEMM + Horner kernels (templated on K + 1 <= 4 matrices); K > 3: ONE plain tile GEMM
+        # X [W_0 | .. | W_K]^T and K propagation hops in global memory (the path of graphs beyond the LDS-resident tiles)
         self.in_channels, self.out_channels, self.K = in_channels, out_channels, K
         self.bias = nn.Parameter(torch.zeros(out_channels))
         self.lins = nn.ModuleList([nn.Linear(in_channels, out_channels, bias=False) for _ in range(K + 1)])
@@ -897,15 +899,17 @@ class _TAGConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, topo, mod, bias, *ws):
         x = x.contiguous()
-        if mod._plan is None or mod._plan.device != x.device or mod._plan.stacked != topo.global_only:
-            mod._plan = _PackPlan([list(ws)], x.device, stacked=topo.global_only)
+        hin, hout, nmat = mod.in_channels, mod.out_channels, mod.K + 1
+        glob = use_global_path(topo, nmat)
+        if mod._plan is None or mod._plan.device != x.device or mod._plan.stacked != glob:
+            mod._plan = _PackPlan([list(ws)], x.device, stacked=glob)
         plan = mod._plan
         ctx.ver = plan.refresh()
-        hin, hout, nmat = mod.in_channels, mod.out_channels, mod.K + 1
-        topo.lds_check(nmat, _round8(hin), _ncg(hout))
-        out = (_tagconv_forward_global if topo.global_only else _tagconv_forward)(topo, x, plan.fwd[0], bias, nmat, hin, hout)
+        if not glob:
+            topo.lds_check(nmat, _round8(hin), _ncg(hout))
+        out = (_tagconv_forward_global if glob else _tagconv_forward)(topo, x, plan.fwd[0], bias, nmat, hin, hout)
         ctx.save_for_backward(x)
-        ctx.topo, ctx.mod = topo, mod
+        ctx.topo, ctx.mod, ctx.glob = topo, mod, glob
         return out
 
     @staticmethod
@@ -917,9 +921,9 @@ class _TAGConvFn(torch.autograd.Function):
         hin, hout, nmat = mod.in_channels, mod.out_channels, mod.K + 1
         g = gout.contiguous()
         flat = torch.empty(nmat * hout * hin + hout, dtype=_F32, device=g.device)
-        if plan.stacked != topo.global_only:
+        if plan.stacked != ctx.glob:
             raise RuntimeError("the module's weight layouts changed between forward and backward")
-        dh = (_tagconv_backward_global if topo.global_only else _tagconv_backward)(
+        dh = (_tagconv_backward_global if ctx.glob else _tagconv_backward)(
             topo, g, x, plan.bwd[0], nmat, hin, hout, flat, need_dh=ctx.needs_input_grad[0])
         gw = [flat[m * hout * hin:(m + 1) * hout * hin].view(hout, hin) for m in range(nmat)]
         gb = flat[nmat * hout * hin:]
@@ -936,6 +940,13 @@ class EdgeAggregation(MessagePassing):
         self.edge_aggr = nn.Sequential(nn.Linear(dim_featn * 2 + dim_feate, dim_hid), nn.ReLU(),
                                        nn.Linear(dim_hid, dim_out))
         self._plan = None
+        self._gplan, self._post = None, None      # (state of the general path, multi._EdgeAggrGeneralFn)
+
+    def fused_dims(self) -> bool:
+        """The fused edge-MLP kernels are built for the reference's data (8 node / 6 edge features, networks.py:170) and
+        dim_hid <= 256; every other width runs the general path: AB = X [W1a; W1b]^T as one tile GEMM, then per edge
+        relu(A[i] + B[src] + W1c ea + b1) summed per target (dss2_edge_combine_*), then the second Linear."""
+        return self.dim_featn == 8 and self.dim_feate == 6 and self.dim_hid <= 256
 
     def message(self, x_i, x_j, edge_attr):
         """networks.py:176-181, the reference expression.  ``forward`` does not call it (the fused kernels evaluate the same
@@ -944,8 +955,13 @@ class EdgeAggregation(MessagePassing):
 
     def forward(self, x, edge_index, edge_attr):
         _require_gpu(x, edge_index, edge_attr)
+        _no_edge_attr_grad(edge_attr)
         topo = get_topology_asis(edge_index, x.size(0))
         lin1, lin2 = self.edge_aggr[0], self.edge_aggr[2]
+        if not self.fused_dims():
+            from .multi import _EdgeAggrGeneralFn, _check_general_dims
+            _check_general_dims(self)
+            return _EdgeAggrGeneralFn.apply(x, edge_attr, topo, self, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
         return _EdgeAggrFn.apply(x, edge_attr, topo, self, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
 
 
@@ -979,6 +995,20 @@ class _EdgeAggrFn(torch.autograd.Function):
         nc = 2 * fn + fe
         return (dx, None, None, None, g1[:hid * nc].view(hid, nc), g1[hid * nc:], g2[:hout * hid].view(hout, hid),
                 g2[hout * hid:])
+
+
+def _no_edge_attr_grad(edge_attr: torch.Tensor) -> None:
+    """The kernels produce gradients for the parameters and (when asked) for x, never for edge_attr (the reference's edge
+    features are data: dss2_run.py:138).  Asking for one must not silently return None."""
+    if edge_attr.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("the DSS2 HIP path does not differentiate with respect to edge_attr (edge features are inputs "
+                                  "of the reference's training loop, dss2_run.py:138); detach() it")
+
+
+def use_global_path(topo: Topology, nmat: int) -> bool:
+    """A TAGConv runs as ONE plain tile GEMM + K propagation hops in global memory when the graphs exceed the LDS-resident
+    tiles (> 192 nodes) or when K > 3 (the fused tile kernels are instantiated for K + 1 <= 4 matrices)."""
+    return bool(topo.global_only or nmat > 4)
 
 
 def get_topology_asis(edge_index: torch.Tensor, num_nodes: int) -> Topology:
@@ -1043,12 +1073,31 @@ class MPN(nn.Module):
 
     def forward(self, x, edge_index, edge_attr):
         _require_gpu(x, edge_index, edge_attr)
+        _no_edge_attr_grad(edge_attr)
         topo = get_topology(edge_index, x.size(0))
+        if not self.edge_aggr.fused_dims():
+            return self._forward_general(x, edge_attr, topo)
         from . import stack as _stack
         dims = _stack.route(self, [self], topo)
         if dims is not None:          # dim_hid 32, K 2: the whole-stack kernels (one launch forward, one backward)
             return _stack.run(self, [self], dims, topo, x, edge_attr)
         return _MPNFn.apply(x, edge_attr, topo, self, *self._params())
+
+    def _forward_general(self, x, edge_attr, topo):
+        """networks.py:260-273 for input widths other than (8, 6) (or dim_hid > 256): the same layer loop out of the
+        per-layer autograd nodes of multi.py -- general edge aggregation, TAGConv with the fused "dropout, then ReLU"
+        epilogue -- instead of the fused block.  Correct for every width the kernels take; not the tuned path."""
+        from .multi import _EdgeAggrGeneralFn, _check_general_dims, _run_tagconv
+        ea_mod = self.edge_aggr
+        _check_general_dims(ea_mod)
+        lin1, lin2 = ea_mod.edge_aggr[0], ea_mod.edge_aggr[2]
+        ea_mod._post = None
+        h = _EdgeAggrGeneralFn.apply(x, edge_attr, topo, ea_mod, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+        last = len(self.convs) - 1
+        for i, conv in enumerate(self.convs):
+            conv._post = None if i == last else (float(self.dropout_rate) if self.dropout_rate > 0 else True)
+            h = _run_tagconv(conv, h, topo)
+        return x + h if self.skip else h
 
 
 class SkipMPN(MPN):
@@ -1063,7 +1112,7 @@ def _ensure_plans(mod, topo, dev, ps):
     W1, b1, W2, b2 = ps[0:4]
     conv_ps = [ps[4 + l * (nmat + 1): 4 + (l + 1) * (nmat + 1)] for l in range(L)]   # (bias, W_0..W_K)
     hout0 = mod.dim_out if L == 1 else hid
-    glob = topo.global_only       # graphs beyond the LDS-resident tiles: plain GEMMs + propagation hops in global memory
+    glob = use_global_path(topo, nmat)       # graphs beyond the LDS-resident tiles, or K > 3: plain GEMMs + propagation hops in global memory
     fold_on = FOLD_W2 and not is_narrow(nmat, hout0) and not glob
     b16 = tuple(range(1, L)) if (CHAIN_BF16 and not glob and hid % 4 == 0 and hid <= 256 and not is_narrow(nmat, hid) and L >= 2
                                  and (L >= 3 or gemm16_supported(topo, nmat, hid, False))) else ()
@@ -1098,7 +1147,8 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
         ver = plan.refresh()
     else:
         ver = plan.version
-    topo.lds_check(nmat, _round8(hid), _ncg(hid))
+    if not glob:
+        topo.lds_check(nmat, _round8(hid), _ncg(hid))
     S, h = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, plan.fwd[0], hid, hid, mod.dim_featn, mod.dim_feate,
                               second_linear=fold is None)
     if fold is not None:
@@ -1447,7 +1497,8 @@ class PFN(nn.Module):
 
     def forward(self, x, edge_index, edge_attr):
         _require_gpu(x, edge_index, edge_attr)
-        if not STACK_NODE or self.n_gnn_layers + 1 >= _StackPlan.DROP_STRIDE:
+        _no_edge_attr_grad(edge_attr)
+        if not STACK_NODE or self.n_gnn_layers + 1 >= _StackPlan.DROP_STRIDE or not self.mpns[0].edge_aggr.fused_dims():
             for m in self.mpns:
                 x = m(x, edge_index, edge_attr)
             return x

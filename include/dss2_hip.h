@@ -160,7 +160,7 @@ int dss2_edge_hidden_bwd(const float* x, int64_t ldx, const float* ea, int64_t l
 
 /* EdgeAggregation with node features of any width (networks.py:159-209 as MultiMPN / MaskEmbdMultiMPN instantiate it on the
  * hidden activation, networks.py:486-498).  AB[N, 2h] = X [W1[:, :d] ; W1[:, d:2d]]^T (one dss2_gemm_prop); W1c = &W1[0][2d]
- * with row stride ldw = 2d + fe; fe <= 8; h <= 256.
+ * with row stride ldw = 2d + fe; fe <= 8; any h (hidden units are independent: more than 256 run as several launches).
  *   fwd: S[i,:] = sum_{e: tgt(e)=i} relu(AB[i, :h] + AB[src(e), h:] + W1c ea'(e) + b1)
  *   bwd: dz_e = dS[tgt(e)] (z_e > 0).  by_source = 0 (CSR by target): dAB[i, :h] = sum dz, slab[n_slabs][h*fe + h] =
  *        partial dW1c, db1 (finish with dss2_reduce_slabs); by_source = 1 (CSR by source): dAB[j, h:] = sum dz.
