@@ -103,60 +103,69 @@ class FusedAdamax(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for gi, group in enumerate(self.param_groups):
-            ps = [p for p in group["params"] if p.grad is not None]
-            if not ps:
-                continue
-            dev = ps[0].device
-            for p in ps:
-                if not p.is_cuda or p.dtype != torch.float32:
-                    raise RuntimeError("FusedAdamax needs fp32 GPU parameters (there is no CPU fallback)")
-            # one step tensor shared by every parameter of the group (torch keeps one per parameter with the same value):
-            # advanced ONCE per step -- on the host, or by the kernel itself when capturable
-            shared = group.get("_step")
-            if shared is None:
-                known = [self.state[p]["step"] for p in ps if "step" in self.state[p]]
-                first = float(known[0]) if known else 0.0
-                shared = group["_step"] = (torch.tensor(first, dtype=torch.float32, device=dev) if self.capturable
-                                           else torch.tensor(first))
-            for p in ps:
-                st = self.state[p]
-                if "exp_avg" not in st:
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_inf"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    self._table.pop(gi, None)
-                    self._flat_table.pop(gi, None)
-                if st.get("step") is not shared:
-                    st["step"] = shared
-            if not self.capturable:
-                shared += 1.0
-                step = int(shared)
-            if self._step_flat(gi, group, ps, shared, step if not self.capturable else 0, dev):
-                continue
-            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
-            # host-side descriptor table, passed to the kernels BY VALUE (no device copy to keep alive, capture-safe);
-            # parameter and state addresses are written once, the gradient addresses every step (the flat gradient
-            # buckets of the backward move)
-            cached = self._table.get(gi)
-            pkey = tuple(p.data_ptr() for p in ps)
-            if cached is None or cached[1] != pkey:
-                tab = (_lib.AdamaxDesc * len(ps))()
-                for d, p in zip(tab, ps):
-                    stp = self.state[p]
-                    d.param, d.exp_avg, d.exp_inf, d.n = p.data_ptr(), stp["exp_avg"].data_ptr(), stp["exp_inf"].data_ptr(), p.numel()
-                cached = self._table[gi] = (tab, pkey)
-                self.table_builds += 1
-            tab = cached[0]
-            for d, g in zip(tab, grads):
-                d.grad = g.data_ptr()
-            b1, b2 = group["betas"]
-            st = _lib.stream_ptr(dev)
-            if self.capturable:
-                _lib.check(_lib.lib().dss2_adamax_step_dev(C.addressof(tab), len(ps), float(group["lr"]), float(b1),
-                                                           float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                                           shared.data_ptr(), st), "dss2_adamax_step_dev")
-            else:
-                _lib.check(_lib.lib().dss2_adamax_step(C.addressof(tab), len(ps), float(group["lr"]), float(b1),
-                                                       float(b2), float(group["eps"]), float(group["weight_decay"]), step, st),
-                           "dss2_adamax_step")
+        for gi in range(len(self.param_groups)):
+            self._step_group(gi)
         return loss
+
+    @torch.no_grad()
+    def step_group(self, gi: int) -> None:
+        """Step ONE parameter group (parallel.step_overlapped: the groups follow the chunks of the gradient bucket)."""
+        self._step_group(gi)
+
+    def _step_group(self, gi: int) -> None:
+        group = self.param_groups[gi]
+        ps = [p for p in group["params"] if p.grad is not None]
+        if not ps:
+            return
+        dev = ps[0].device
+        for p in ps:
+            if not p.is_cuda or p.dtype != torch.float32:
+                raise RuntimeError("FusedAdamax needs fp32 GPU parameters (there is no CPU fallback)")
+        # one step tensor shared by every parameter of the group (torch keeps one per parameter with the same value):
+        # advanced ONCE per step -- on the host, or by the kernel itself when capturable
+        shared = group.get("_step")
+        if shared is None:
+            known = [self.state[p]["step"] for p in ps if "step" in self.state[p]]
+            first = float(known[0]) if known else 0.0
+            shared = group["_step"] = (torch.tensor(first, dtype=torch.float32, device=dev) if self.capturable
+                                       else torch.tensor(first))
+        for p in ps:
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_inf"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                self._table.pop(gi, None)
+                self._flat_table.pop(gi, None)
+            if st.get("step") is not shared:
+                st["step"] = shared
+        if not self.capturable:
+            shared += 1.0
+            step = int(shared)
+        if self._step_flat(gi, group, ps, shared, step if not self.capturable else 0, dev):
+            return
+        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+        # host-side descriptor table, passed to the kernels BY VALUE (no device copy to keep alive, capture-safe);
+        # parameter and state addresses are written once, the gradient addresses every step (the flat gradient
+        # buckets of the backward move)
+        cached = self._table.get(gi)
+        pkey = tuple(p.data_ptr() for p in ps)
+        if cached is None or cached[1] != pkey:
+            tab = (_lib.AdamaxDesc * len(ps))()
+            for d, p in zip(tab, ps):
+                stp = self.state[p]
+                d.param, d.exp_avg, d.exp_inf, d.n = p.data_ptr(), stp["exp_avg"].data_ptr(), stp["exp_inf"].data_ptr(), p.numel()
+            cached = self._table[gi] = (tab, pkey)
+            self.table_builds += 1
+        tab = cached[0]
+        for d, g in zip(tab, grads):
+            d.grad = g.data_ptr()
+        b1, b2 = group["betas"]
+        st = _lib.stream_ptr(dev)
+        if self.capturable:
+            _lib.check(_lib.lib().dss2_adamax_step_dev(C.addressof(tab), len(ps), float(group["lr"]), float(b1),
+                                                       float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                                       shared.data_ptr(), st), "dss2_adamax_step_dev")
+        else:
+            _lib.check(_lib.lib().dss2_adamax_step(C.addressof(tab), len(ps), float(group["lr"]), float(b1),
+                                                   float(b2), float(group["eps"]), float(group["weight_decay"]), step, st),
+                       "dss2_adamax_step")

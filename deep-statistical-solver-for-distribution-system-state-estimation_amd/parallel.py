@@ -77,9 +77,13 @@ def shard_batch(batch: Dict[str, object], rank: int, world: int) -> Dict[str, ob
 
 
 def allreduce_loss_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
-    """sums[0..4] = batch sums, sums[5] = node count, sums[6] = edge count -> global values."""
+    """sums[0..4] = batch sums, sums[5] = node count, sums[6] = edge count -> global values.  56 bytes: pure latency.  The
+    collective is posted asynchronously (it runs on the backend's own stream as soon as the partials kernel has finished) and
+    joined by a STREAM dependency, so the host goes on enqueueing; no kernel of the step is independent of these sums (the loss
+    value and every gradient need the global penalty means), so there is nothing to overlap it with on the device."""
     if dist.is_initialized():
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        work = dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        work.wait()          # current stream waits for the collective's stream; the host does not block (NCCL / RCCL)
     return sums
 
 
@@ -95,7 +99,61 @@ def allreduce_flat_grads(flat: torch.Tensor, group=None, pending: Optional[List]
     return flat
 
 
-def attach_grad_allreduce(model: torch.nn.Module, group=None, async_op: bool = False) -> int:
+def bucket_param_offsets(model: torch.nn.Module):
+    """[(parameter, element offset, numel)] of every parameter inside the model's flat gradient bucket, for models whose backward
+    produces ONE bucket: an MPN / SkipMPN block, or a PFN / SkipPFN stack (one autograd node).  Layout per block =
+    MPN._flat_offsets(): [W1 | b1] [W2 | b2] then per conv [W_0 .. W_K | bias]; a stack's blocks follow each other."""
+    blocks = list(model.mpns) if hasattr(model, "mpns") else [model]
+    out, base = [], 0
+    for m in blocks:
+        offs = m._flat_offsets()
+        hid, nmat = m.dim_hid, m.K + 1
+        lin1, lin2 = m.edge_aggr.edge_aggr[0], m.edge_aggr.edge_aggr[2]
+        out += [(lin1.weight, base + offs[0], lin1.weight.numel()), (lin1.bias, base + offs[0] + lin1.weight.numel(), hid),
+                (lin2.weight, base + offs[1], hid * hid), (lin2.bias, base + offs[1] + hid * hid, hid)]
+        for l, c in enumerate(m.convs):
+            hout = c.out_channels
+            for k, lin in enumerate(c.lins):
+                out.append((lin.weight, base + offs[2 + l] + k * hout * hid, hout * hid))
+            out.append((c.bias, base + offs[2 + l] + nmat * hout * hid, hout))
+        base += offs[-1]
+    return out
+
+
+def overlap_param_groups(model: torch.nn.Module, n_chunks: int = 2):
+    """Parameter groups for an optimizer that is stepped chunk by chunk while the later chunks of the gradient bucket are still
+    being all-reduced (``attach_grad_allreduce(..., async_op=True, n_chunks=n)`` + ``step_overlapped``).  The bucket is cut
+    at element n * total / n_chunks (rounded to 64 elements: collectives do not care about parameter boundaries); group i holds
+    the parameters that END inside chunk i, so a parameter straddling a cut is stepped with the later chunk."""
+    table = bucket_param_offsets(model)
+    total = max(off + n for _, off, n in table)
+    cuts = [min(total, (total * (i + 1) // n_chunks + 63) // 64 * 64) for i in range(n_chunks)]
+    cuts[-1] = total
+    groups = [[] for _ in range(n_chunks)]
+    for prm, off, n in table:
+        gi = next(i for i, c in enumerate(cuts) if off + n <= c)
+        groups[gi].append(prm)
+    model._dss2_bucket_cuts = cuts
+    return [{"params": g} for g in groups if g]
+
+
+def step_overlapped(model: torch.nn.Module, optimizer) -> None:
+    """Optimizer step overlapped with the tail of the gradient all-reduce: chunk i's collective is joined, then the parameter
+    group that lives in chunk i is stepped (one fused launch) while chunk i + 1 is still in flight on the collective stream.
+    Needs ``attach_grad_allreduce(async_op=True, n_chunks=n)`` and an optimizer built on ``overlap_param_groups(model, n)``
+    with a ``step_group(i)`` method (optim.FusedAdamax).  Without pending collectives it is a plain ``optimizer.step()``."""
+    pending = getattr(model, "_dss2_pending_allreduce", None)
+    if not pending or not hasattr(optimizer, "step_group") or len(pending) != len(optimizer.param_groups):
+        wait_grad_allreduce(model)
+        optimizer.step()
+        return
+    for gi, work in enumerate(pending):
+        work.wait()
+        optimizer.step_group(gi)
+    pending.clear()
+
+
+def attach_grad_allreduce(model: torch.nn.Module, group=None, async_op: bool = False, n_chunks: int = 1) -> int:
     """Install the flat-bucket all-reduce on every MPN block of `model` (MPN / SkipMPN themselves,
     or the blocks inside PFN / SkipPFN).  Returns the number of blocks hooked.  A PFN / SkipPFN stack runs as one
     autograd node with ONE gradient bucket (networks._PFNFn): it issues a single collective per step, through the hook
@@ -106,7 +164,9 @@ def attach_grad_allreduce(model: torch.nn.Module, group=None, async_op: bool = F
     instead of L serialised ones); call ``wait_grad_allreduce(model)`` after ``loss.backward()`` and before reading
     the gradients (the wait is a stream dependency, not a host block).  The asynchronous mode requires the ``.grad`` of
     every parameter to be None when backward runs (see ``hook`` below); a step that finds gradients in place reduces its
-    buckets with blocking collectives instead."""
+    buckets with blocking collectives instead.  ``n_chunks > 1`` (with ``async_op`` and ``overlap_param_groups``): the bucket
+    travels as n_chunks collectives so that ``step_overlapped`` can step the first chunks' parameters while the last ones are
+    still in flight ("optimizer overlapped with the all-reduce")."""
     n = 0
     pending = [] if async_op else None
     model._dss2_pending_allreduce = pending
@@ -120,6 +180,13 @@ def attach_grad_allreduce(model: torch.nn.Module, group=None, async_op: bool = F
         # the reduced values would never reach p.grad: such a step falls back to the blocking collective.
         if q is not None and any(p.grad is not None for p in params):
             q = None
+        cuts = getattr(model, "_dss2_bucket_cuts", None)
+        if q is not None and n_chunks > 1 and cuts is not None and len(cuts) == n_chunks and cuts[-1] == flat.numel():
+            a = 0
+            for c in cuts:            # one collective per chunk, issued in order: chunk i completes before chunk i + 1
+                allreduce_flat_grads(flat[a:c], g, q)
+                a = c
+            return flat
         return allreduce_flat_grads(flat, g, q)
 
     for m in model.modules():

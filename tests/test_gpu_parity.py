@@ -196,6 +196,7 @@ def _train_step_pair(pkg, oracle, grids, B, hid, L, K=2, seed=0, cls="MPN", dim_
     (["cigre14"], 4096, 128, 4),                                # C2 (the headline configuration)
     (["ober_sub"], 1024, 128, 4),                               # C3
     (["cigre14", "cigre14_reswitched"], 512, 256, 8),           # C5's model on a mixed-topology shard
+    (["cigre14", "cigre14_reswitched"], 4096, 256, 8),          # ... and on a full 4096-graph shard (un-pinned tolerance 1.3e-4)
     (["ober179"], 1024, 128, 4),                                # C3 read as "~180 buses": the synthetic 179-bus feeder, full size
 ])
 def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
@@ -295,6 +296,45 @@ def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
         dev = (p.grad.double().cpu() - q64.grad).abs()
         assert (dev <= bound + 1e-5 * q64.grad.abs().max()).all(), (n, e, (dev - bound).max().item())
         assert e < 1e-3, (n, e)
+
+
+def test_cache_busting_batch_is_deterministic_and_linear_in_gout(pkg, oracle):
+    """B = 32768 graphs on one GPU (N = 491 520 nodes: activations of 252 MB per layer, beyond the 256 MiB Infinity Cache --
+    the size bench.py times the scatter-add on): the size-independent properties of the path -- bitwise run-to-run
+    reproducibility and linearity of the backward in the incoming gradient -- plus block-diagonality: the batch is eight
+    copies of a 4096-graph batch, so every copy's outputs must equal the first copy's bit for bit."""
+    torch.manual_seed(0)
+    b = pkg.synthetic.make_batch(["cigre14"], 4096, seed=5)
+    m = pkg.MPN(8, 6, 2, 128, 4, 2, 0.0).to(DEV)
+    reps, n1 = 8, b["x"].shape[0]
+    x = b["x"].to(DEV).repeat(reps, 1)
+    ea = b["edge_attr"].to(DEV).repeat(reps, 1)
+    ei1 = b["edge_index"].to(DEV)
+    ei = torch.cat([ei1 + k * n1 for k in range(reps)], 1)
+    g = torch.randn(n1, 2, device=DEV).repeat(reps, 1)
+
+    def run(scale):
+        for p in m.parameters():
+            p.grad = None
+        out = m(x[:, :8], ei, ea[:, :6])
+        out.backward(g * scale)
+        return out.detach().clone(), [p.grad.clone() for p in m.parameters()]
+
+    o1, g1 = run(1.0)
+    o2, g2 = run(1.0)
+    assert torch.equal(o1, o2) and all(torch.equal(a, c) for a, c in zip(g1, g2))
+    assert all(torch.equal(o1[:n1], o1[k * n1:(k + 1) * n1]) for k in range(1, reps))
+    _, g3 = run(2.0)
+    for a, c in zip(g1, g3):
+        assert rel_err(c, 2 * a) < 1e-6
+    # against the 4096-graph batch itself: same outputs, gradients 8 x (to summation-order rounding)
+    for p in m.parameters():
+        p.grad = None
+    o_small = m(x[:n1, :8], ei1, ea[:ei1.shape[1], :6])
+    o_small.backward(g[:n1])
+    assert torch.equal(o_small.detach(), o1[:n1])
+    for p, a in zip(m.parameters(), g1):
+        assert rel_err(a, reps * p.grad) < 5e-6
 
 
 def test_full_size_is_deterministic_and_linear_in_gout(pkg, oracle):

@@ -162,3 +162,62 @@ def test_async_bucket_hook_with_gradients_already_in_place():
         ok1, j1, ok2, j2 = ret[r]
         assert ok1 and j1 == 1, ret[r]
         assert ok2 and j2 == 0, ret[r]
+
+
+class _ChunkOpt:
+    """Optimizer stub with FusedAdamax's step_group interface: plain SGD, records the order of group steps."""
+
+    def __init__(self, param_groups, lr):
+        self.param_groups, self.lr, self.order = param_groups, lr, []
+
+    def step_group(self, gi):
+        self.order.append(gi)
+        with torch.no_grad():
+            for p in self.param_groups[gi]["params"]:
+                p -= self.lr * p.grad
+
+    def step(self):
+        for gi in range(len(self.param_groups)):
+            self.step_group(gi)
+
+
+def _overlap_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    pkg = load_pkg()
+    torch.set_num_threads(1)
+    pkg.parallel.init_from_env("gloo")
+    torch.manual_seed(0)
+    model = pkg.SkipPFN(8, 6, 2, 16, 3, 2, 0.0, 2)            # CPU: only its structure and parameters are used
+    table = pkg.parallel.bucket_param_offsets(model)
+    total = max(o + n for _, o, n in table)
+    assert total == sum(p.numel() for p in model.parameters())
+    assert sorted(id(p) for p, _, _ in table) == sorted(id(p) for p in model.parameters())
+    groups = pkg.parallel.overlap_param_groups(model, 2)
+    assert len(groups) == 2 and sum(len(g["params"]) for g in groups) == len(list(model.parameters()))
+    assert pkg.parallel.attach_grad_allreduce(model, async_op=True, n_chunks=2) == 2
+    opt = _ChunkOpt(groups, 0.5)
+    before = [p.detach().clone() for p, _, _ in table]
+    # what the backward of the stack does: one flat bucket, the hook of the first block, views handed to autograd
+    flat = torch.arange(total, dtype=torch.float32) * (rank + 1)
+    model.mpns[0]._grad_bucket_hook(flat)
+    n_pending = len(model._dss2_pending_allreduce)
+    for prm, off, n in table:
+        prm.grad = flat[off:off + n].view_as(prm)
+    pkg.parallel.step_overlapped(model, opt)
+    expect = torch.arange(total, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    ok = all(torch.equal(prm.detach(), b0 - 0.5 * expect[off:off + n].view_as(prm)) for (prm, off, n), b0 in zip(table, before))
+    ret[rank] = (ok, n_pending, list(opt.order), len(model._dss2_pending_allreduce))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chunked_bucket_and_overlapped_optimizer_step():
+    """SURVEY 8f rank 2 / VERDICT r2 next #3: the gradient bucket travels as two collectives and the optimizer steps the first
+    half's parameters while the second half is still in flight; the result equals the plain all-reduce + step."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_overlap_worker, args=(world, 29880 + os.getpid() % 60, ret), nprocs=world, join=True)
+    for r in range(world):
+        ok, n_pending, order, left = ret[r]
+        assert ok and n_pending == 2 and order == [0, 1] and left == 0, ret[r]
