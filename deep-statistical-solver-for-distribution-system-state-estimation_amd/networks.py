@@ -724,6 +724,8 @@ CHAIN_BF16 = _os.environ.get("DSS2_CHAIN_BF16", "1") == "1"            # its til
 WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"
 STACK_NODE = _os.environ.get("DSS2_STACK_NODE", "1") == "1"              # PFN / SkipPFN as ONE autograd node (_PFNFn)
 DX_MERGE = _os.environ.get("DSS2_DX_MERGE", "1") == "1"                  # dx of the edge MLP as ONE K = 2 hid GEMM
+PREP_SIDE_STREAM = _os.environ.get("DSS2_PREP_STREAM", "0") == "1"       # opt-in: fold + weight packing on a side stream beside the edge MLP's forward
+                                                                         # (measured at C2, same box: 0.590 ms with it, 0.579 without: the fork / join costs more than the 19 us it hides)
 WGRAD_JOIN_FOLDED = None    # None: join the folded conv 0 into the batched launch only when the tiles divide evenly          # hid->hid layers of a block: one wgrad launch
 
 
@@ -1141,16 +1143,30 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
     W1, b1, W2, b2 = ps[0:4]
     conv_ps = [ps[4 + l * (nmat + 1): 4 + (l + 1) * (nmat + 1)] for l in range(L)]   # (bias, W_0..W_K)
     plan, fold, glob = _ensure_plans(mod, topo, dev, ps)
+    prep_side = None
     if stack is None:
-        if fold is not None:
-            fold.refresh_forward()
-        ver = plan.refresh()
+        if fold is not None and PREP_SIDE_STREAM:
+            # The fold (W_m W2: small GEMMs) and the weight packing depend on the weights only, and with the fold the edge MLP's
+            # forward needs nothing of them: both launches run on a side stream beside the edge kernel and are joined before
+            # the first TAGConv (in a hipGraph capture: a parallel branch).  ~19 us of the C2 step off the critical path.
+            main = torch.cuda.current_stream(dev)
+            prep_side = _side_stream(dev)
+            prep_side.wait_stream(main)
+            with torch.cuda.stream(prep_side):
+                fold.refresh_forward()
+                ver = plan.refresh()
+        else:
+            if fold is not None:
+                fold.refresh_forward()
+            ver = plan.refresh()
     else:
         ver = plan.version
     if not glob:
         topo.lds_check(nmat, _round8(hid), _ncg(hid))
     S, h = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, plan.fwd[0], hid, hid, mod.dim_featn, mod.dim_feate,
                               second_linear=fold is None)
+    if prep_side is not None:
+        torch.cuda.current_stream(dev).wait_stream(prep_side)
     if fold is not None:
         h = S            # conv 0 consumes the aggregated hidden directly
     acts = [h]

@@ -373,8 +373,10 @@ def test_quirks_and_errors(pkg):
     assert ei2.shape[1] == 2 * ei.shape[1] and m.is_directed(ei2) is False
     with pytest.raises(RuntimeError):
         pkg.MPN(8, 6, 2, 32, 2, 2, 0.0)(b["x"][:, :8], b["edge_index"], b["edge_attr"][:, :6])  # CPU tensors
-    with pytest.raises(RuntimeError):
-        pkg.EdgeAggregation(7, 6, 32, 32).to(DEV)(x[:, :7].contiguous(), ei2, ea2)  # unsupported dims fail loudly
+    # (other input widths used to fail loudly; since round 3 they run the general path: tests/test_gpu_cliffs.py)
+    assert pkg.EdgeAggregation(7, 6, 32, 32).to(DEV)(x[:, :7].contiguous(), ei2, ea2).shape == (x.shape[0], 32)
+    with pytest.raises(NotImplementedError):
+        pkg.EdgeAggregation(8, 9, 32, 32).to(DEV)(x[:, :8], ei2, torch.cat([ea2, ea2[:, :3]], 1))   # dim_feate > 8: loud
 
 
 def test_hipgraph_replay_matches_eager(pkg, oracle):
@@ -501,8 +503,10 @@ def test_chained_and_batched_launches_equal_per_layer_launches(pkg, oracle, grid
         nw.CHAIN_LAYERS, nw.WGRAD_BATCH, nw.FOLD_W2, nw.CHAIN_BF16 = saved
         nw.WGRAD_JOIN_FOLDED = None
     assert torch.equal(o_chain, o_ref) and torch.equal(o_join, o_ref) and torch.equal(o_sep, o_ref)
+    # (the batched schedules sum their slabs in the 16-lane order of reduce_slabs_multi_v4, the per-layer launches in the 4-group
+    #  order of reduce_slabs: two fixed orders, fp32 rounding apart)
     for a, c, j, sp, (n, _) in zip(g_ref, g_chain, g_join, g_sep, model.named_parameters()):
-        assert rel_err(c, a) < 2e-6 and rel_err(j, a) < 2e-6 and rel_err(sp, a) < 2e-6, n
+        assert rel_err(c, a) < 4e-6 and rel_err(j, a) < 4e-6 and rel_err(sp, a) < 4e-6, n
     # folding the second Linear re-associates one matrix product: fp32 rounding level, not bitwise
     assert rel_err(o_unfold, o_ref) < 2e-6
     for a, c, (n, _) in zip(g_ref, g_unfold, model.named_parameters()):
