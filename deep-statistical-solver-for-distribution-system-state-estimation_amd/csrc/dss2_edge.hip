@@ -1098,6 +1098,13 @@ extern "C" int dss2_gather_rows(const float* src, int64_t lds, const int32_t* id
 
 extern "C" int dss2_reduce_slabs(const float* slab, int n_slabs, int64_t stride, float* out, int64_t len, void* stream) {
   if (len <= 0) return 0;
+  if (stride % 4 == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && n_slabs > 0) {
+    // the same summation order as the batched form (dss2_reduce_slabs_multi): a reduction gives the same bits either way
+    ReduceTable tab = {};
+    tab.d[0].slab = slab; tab.d[0].out = out; tab.d[0].stride = stride; tab.d[0].len = len; tab.d[0].n_slabs = n_slabs;
+    hipLaunchKernelGGL(reduce_slabs_multi_v4_kernel, dim3((unsigned)((len + 63) / 64), 1), dim3(256), 0, as_stream(stream), tab);
+    return check_launch("reduce_slabs");
+  }
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 63) / 64)), dim3(64, 4), 0, as_stream(stream), slab,
                      n_slabs, stride, out, len);
   return check_launch("reduce_slabs");

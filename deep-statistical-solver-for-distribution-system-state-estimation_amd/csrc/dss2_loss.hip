@@ -225,16 +225,23 @@ __global__ void wls_value_kernel(const double* __restrict__ sums, float lam_reg,
 // 5 waves, wave c sums column c of the workgroup partials: lanes stride over the workgroups, then
 // a fixed-order butterfly.  Deterministic.
 __global__ void __launch_bounds__(320) wls_finish_kernel(const double* __restrict__ partials, int n_blocks,
-                                                         double* __restrict__ sums, double n_nodes, double n_edges) {
+                                                         double* __restrict__ sums, double n_nodes, double n_edges,
+                                                         float lam_reg, float* __restrict__ loss) {
+  __shared__ double tot[5];
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double s = 0;
   for (int b = lane; b < n_blocks; b += 64) s += partials[(size_t)b * 5 + c];
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0) sums[c] = s;
+  if (lane == 0) { sums[c] = s; tot[c] = s; }
+  __syncthreads();
   if (threadIdx.x == 0) {
     sums[5] = n_nodes;
     sums[6] = n_edges;
     sums[7] = 0;
+    if (loss) {      // the (local-batch) loss value, so that the gradient kernel can wait for the backward pass
+      const double lr = (double)lam_reg, mv = tot[2] / n_nodes, mt = tot[3] / n_edges, ml = tot[4] / n_edges;
+      loss[0] = (float)(tot[0] / n_nodes + tot[1] / n_edges + lr * mv * mv + lr * mt * mt + lr * ml * ml);
+    }
   }
 }
 
@@ -454,7 +461,7 @@ extern "C" int dss2_wls_loss_partials(const dss2_wls_args* ap, void* stream) {
   hipLaunchKernelGGL(wls_partials_kernel, dim3((unsigned)nb), dim3(LB), 0, s, a);
   if (!(a.flags & DSS2_WLS_FUSED_FINISH))
     hipLaunchKernelGGL(wls_finish_kernel, dim3(1), dim3(320), 0, s, a.partials, (int)nb, a.sums, (double)a.n_nodes,
-                       (double)a.n_edges);
+                       (double)a.n_edges, a.lam_reg, a.loss);
   return check_launch("wls_loss_partials");
 }
 

@@ -53,11 +53,12 @@ __global__ void __launch_bounds__(256) adamax_flat_kernel(const dss2_adamax_flat
     d.param[i] = p - clr * (m / u);
   }
   if (!step_dev) return;
-  // the last workgroup to finish advances the device-side count (every workgroup has read it by then)
+  // The last workgroup to arrive advances the device-side count.  Every workgroup has READ the count before it arrives: the
+  // barrier drains its loads (s_waitcnt vmcnt(0)), and only then is the arrival posted.  Nothing is published through memory, so
+  // a relaxed device-scope atomic is enough -- a release fence here would be an L2 write-back per workgroup on MI355X.
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();
-    if (atomicAdd(counter, 1u) == gridDim.x * gridDim.y - 1) {
+    if (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1) {
       step_dev[0] += 1.f;
       *counter = 0u;
     }

@@ -96,9 +96,9 @@ def _counter(dev) -> torch.Tensor:
 class _WlsFn(torch.autograd.Function):
     """loss, output = f(output): `output` is modified in place (theta masked) and marked dirty.
 
-    Forward = ONE launch (`dss2_wls_loss_partials`: flows, injections, residual coefficients, the five batch sums; its last
-    workgroup sums the partials in a fixed order and writes the loss); backward = ONE launch (`dss2_wls_loss_grad`, which
-    takes autograd's upstream gradient as a device scalar).  Data-parallel: the sums are all-reduced after the forward
+    Forward = `dss2_wls_loss_partials` (flows, injections, residual coefficients, the five batch sums; small batches: its
+    last workgroup sums the partials in a fixed order and writes the loss -- ONE launch; bigger ones: a one-workgroup finish
+    launch does); backward = ONE launch (`dss2_wls_loss_grad`, which takes autograd's upstream gradient as a device scalar).  Data-parallel: the sums are all-reduced after the forward
     launch and a one-thread launch re-evaluates the loss from the global sums."""
 
     @staticmethod
@@ -122,7 +122,9 @@ class _WlsFn(torch.autograd.Function):
         }
         a = _fill_args(topo, input, edge_input, (output, output.stride(0)), node_param, edge_param,
                        x_mean, x_std, edge_mean, edge_std, reg_coefs, bufs)
-        a.flags = _lib.WLS_FUSED_FINISH | (_lib.WLS_VMM_CACHED if vmm_valid else 0)
+        # (the in-kernel finish needs a device-scope fence per workgroup = an L2 write-back on MI355X: it only pays when the
+        #  grid is a handful of workgroups; bigger batches run the one-workgroup finish launch, which writes the loss too)
+        a.flags = (_lib.WLS_FUSED_FINISH if nb <= 16 else 0) | (_lib.WLS_VMM_CACHED if vmm_valid else 0)
         a.counter = _counter(dev).data_ptr()
         st = _stream(output)
         L = _lib.lib()
