@@ -1436,7 +1436,9 @@ class _StackRun:
 class _PFNFn(torch.autograd.Function):
     """All blocks of a PFN / SkipPFN as ONE autograd node: the per-block housekeeping launches (fold, pack, dropout state,
     slab reductions, chain rule of the folds, gradient all-reduce) run once per stack, and every gradient of the stack is
-    complete when the node returns (autograd may accumulate into existing .grad tensors right away)."""
+    complete when the node returns -- with blocking collectives.  (parallel.attach_grad_allreduce(async_op=True) returns views of
+    a bucket whose all-reduce is still in flight: sound only while every .grad is None, so its hook falls back to the blocking
+    collective when gradients are already in place.)"""
 
     @staticmethod
     def forward(ctx, x, ea, topo, pfn, n_per_block, *ps):

@@ -75,6 +75,68 @@ def train_epoch(model, opt, loader, stats, reg_coefs, group=None) -> float:
     return float(total / len(loader))                                # one host sync per epoch (:147)
 
 
+class GraphedTrainer:
+    """The training step of ``train_epoch`` -- zero_grad, forward, gsp_wls_edge, backward, optimizer step -- captured ONCE per
+    batch shape into a hipGraph (graphs.GraphedStep) and replayed on static input buffers: at the driver's batch size the eager
+    step is host-bound (~2.4 ms of Python / autograd dispatch around 0.33 ms of kernels for the SkipPFN line), the replay is
+    not.  Valid when every batch of a shape has the SAME graph structure (one topology per dataset, e.g. the reference's
+    cigre14 folder): the structure is part of the captured launches, so only x and edge_attr are copied per step.  In-kernel
+    dropout draws new masks on every replay; the optimizer must be ``FusedAdamax(capturable=True)``."""
+
+    def __init__(self, model, opt, stats, reg_coefs, group=None):
+        if not getattr(opt, "capturable", False):
+            raise ValueError("GraphedTrainer needs FusedAdamax(capturable=True): the step count must live on the device")
+        self.model, self.opt, self.stats, self.reg, self.group = model, opt, stats, reg_coefs, group
+        self.graphs = {}
+        self.params = list(model.parameters())
+
+    def _build(self, x, ei, ea):
+        from .graphs import GraphedStep
+        sx, sea, sei = x.clone(), ea.clone(), ei.clone()
+        st, reg, model, opt, params, group = self.stats, self.reg, self.model, self.opt, self.params, self.group
+        eager_losses = []
+
+        def step_fn():
+            for p in params:
+                p.grad = None
+            out = model(sx[:, :8], sei, sea[:, :6])
+            loss = dss2_data.gsp_wls_edge(input=sx[:, :8], edge_input=sea[:, :6], output=out, x_mean=st[0], x_std=st[1],
+                                          edge_mean=st[2], edge_std=st[3], edge_index=sei, reg_coefs=reg, num_samples=None,
+                                          node_param=sx[:, 8:], edge_param=sea[:, 6:], group=group)
+            loss.backward()
+            opt.step()
+            if not torch.cuda.is_current_stream_capturing():
+                eager_losses.append(loss.detach().clone())
+            return loss
+        # the warm-up step of the capture is a REAL training step on this batch (it advances the weights and the optimizer); the
+        # capture runs on the caller's current stream when that is not the default one (the autograd state of earlier eager
+        # steps belongs to it), else on a stream of its own
+        cur = torch.cuda.current_stream()
+        g = GraphedStep(step_fn, warmup=1, capture_error_mode=("thread_local" if group is not None else "global"),
+                        stream=(cur if cur != torch.cuda.default_stream() else None))
+        return g, sx, sea, eager_losses[-1]
+
+    def step(self, x, ei, ea) -> torch.Tensor:
+        key = (tuple(x.shape), tuple(ea.shape), tuple(ei.shape))
+        hit = self.graphs.get(key)
+        if hit is None:
+            g, sx, sea, first_loss = self._build(x, ei, ea)
+            self.graphs[key] = (g, sx, sea)
+            return first_loss           # (the capture's warm-up step has trained on this batch)
+        g, sx, sea = hit
+        sx.copy_(x)
+        sea.copy_(ea)
+        return g.replay().detach()
+
+
+def train_epoch_graphed(trainer: GraphedTrainer, loader) -> float:
+    total = torch.zeros((), device=trainer.stats[0].device)
+    for data in loader:
+        x, ei, ea, _, _ = _fields(data)
+        total += trainer.step(x, ei, ea)
+    return float(total / len(loader))
+
+
 @torch.no_grad()
 def evaluate(model, loader, stats) -> Dict[str, float]:
     """dss2_run.py:165-224: RMSE / MAE of V and theta and of the line / trafo loadings from get_pflow, and the
@@ -105,6 +167,8 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--save", default="")
     ap.add_argument("--data-folder", default="", help="folder with the reference's pickles (nodes, edges, labels, noise_param)")
+    ap.add_argument("--graph", type=int, default=-1, help="1: replay the training step as a hipGraph (GraphedTrainer; needs ONE graph "
+                    "structure per batch shape), 0: eager, -1 (default): graph when the data has a single topology")
     a = ap.parse_args(argv)
     hp = {k: getattr(a, k) for k in HYPER}
     if a.model == "SkipMPN":
@@ -126,11 +190,15 @@ def main(argv=None):
     else:
         train_loader, test_loader, stats = make_loaders(a.case, a.graphs, a.batch_size, dev, a.seed)
     model = build_model(a.model, hp).to(dev)
-    opt = FusedAdamax(model.parameters(), lr=a.lr)
-    print(f"device:{dev}  train batches {len(train_loader)}  test batches {len(test_loader)}  model {a.model} {hp}")
+    single_topology = (not a.data_folder) or bool(getattr(train_loader.dataset, "shared_topology", False))
+    use_graph = (a.graph == 1) or (a.graph == -1 and single_topology and hp["dim_out"] == 2)
+    opt = FusedAdamax(model.parameters(), lr=a.lr, capturable=use_graph)
+    trainer = GraphedTrainer(model, opt, stats, REG_COEFS) if use_graph else None
+    print(f"device:{dev}  train batches {len(train_loader)}  test batches {len(test_loader)}  model {a.model} {hp}  "
+          f"step: {'hipGraph replay' if use_graph else 'eager'}")
     for epoch in range(a.epochs):
         t0 = time.perf_counter()
-        tl = train_epoch(model, opt, train_loader, stats, REG_COEFS)
+        tl = train_epoch_graphed(trainer, train_loader) if use_graph else train_epoch(model, opt, train_loader, stats, REG_COEFS)
         m = evaluate(model, test_loader, stats) if hp["dim_out"] == 2 else {}
         torch.cuda.synchronize()
         print(f"epoch {epoch:4d}  train_loss {tl:.6g}  " + "  ".join(f"{k} {v:.4g}" for k, v in m.items()) +

@@ -245,3 +245,28 @@ def test_whole_stack_training_step_inside_a_hipgraph(pkg, oracle):
     assert all(l == l and l < 1e30 for l in losses)                   # finite
     assert min(losses[-5:]) < losses[0]                                # it trains
     assert len(set(losses)) > 25                                       # new masks every replay
+
+
+def test_graphed_trainer_equals_the_eager_training_loop(pkg, oracle):
+    """runner.GraphedTrainer (the training step captured once per batch shape, replayed on static buffers) against
+    runner.train_epoch (eager) on the same batches from the same initial weights, dropout 0: same losses, same weights."""
+    torch.manual_seed(0)
+    batches = [pkg.synthetic.make_batch(["cigre14"], 64, seed=20 + k) for k in range(3)]
+    batches.append(pkg.synthetic.make_batch(["cigre14"], 24, seed=99, stats=batches[0]["stats"]))      # a short last batch: second shape
+    st = tuple(s.to(DEV) for s in batches[0]["stats"])
+    dev_b = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items() if k != "stats"} for b in batches]
+    m_e = pkg.SkipPFN(8, 6, 2, 32, 4, 2, 0.0, 3).to(DEV)
+    m_g = pkg.SkipPFN(8, 6, 2, 32, 4, 2, 0.0, 3).to(DEV)
+    m_g.load_state_dict(m_e.state_dict())
+    o_e = pkg.FusedAdamax(m_e.parameters(), lr=3e-3)
+    o_g = pkg.FusedAdamax(m_g.parameters(), lr=3e-3, capturable=True)
+    trainer = pkg.runner.GraphedTrainer(m_g, o_g, st, pkg.runner.REG_COEFS)
+    for epoch in range(3):
+        l_e = pkg.runner.train_epoch(m_e, o_e, dev_b, st, pkg.runner.REG_COEFS)
+        l_g = pkg.runner.train_epoch_graphed(trainer, dev_b)
+        # (same kernels; the only difference is Adamax's bias correction 1 - beta1^t, evaluated by the host's powf in the eager
+        #  optimizer and by the device's in the capturable one: an ulp that twelve training steps amplify to ~1e-5)
+        assert abs(l_e - l_g) <= 1e-4 * abs(l_e), (epoch, l_e, l_g)
+    assert len(trainer.graphs) == 2
+    for (n, a), (_, c) in zip(m_e.named_parameters(), m_g.named_parameters()):
+        assert rel_err(c, a) < 1e-4, n

@@ -14,6 +14,8 @@ find /tmp/final_stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_benc
 cd $R
 bash tools/pmc_one.sh chain > $O/pmc_gemm_chain.txt 2>&1
 bash tools/pmc_one.sh wgrad2 > $O/pmc_wgrad_batched.txt 2>&1
+bash tools/pmc_one.sh stack4096 > $O/pmc_stack_B4096.txt 2>&1
+bash tools/pmc_one.sh stack64 > $O/pmc_stack_B64.txt 2>&1
 rm -rf $R/gpurun_out/pmc1_*
 # scatter-add, cache-busting working set: FETCH_SIZE and WRITE_SIZE in separate passes (no trace domains besides kernel-trace)
 cd /tmp
@@ -49,4 +51,13 @@ CHAINBENCH_BF16=0 CHAINBENCH_STEP=0 python3 tools/chainbench.py > $O/chainbench_
 python3 tools/accuracy_bf16x6.py > $O/accuracy_bf16x6.txt 2>&1
 bash tools/driverline_trace.sh 64 > /dev/null 2>&1; cp $R/gpurun_out/driverline_trace_B64.txt $O/ 2>/dev/null
 bash tools/driverline_trace.sh 4096 > /dev/null 2>&1; cp $R/gpurun_out/driverline_trace_B4096.txt $O/ 2>/dev/null
+# phase stamps of the whole-stack kernels (needs the diagnostic build <pkg>/libdss2_sstamps.so, see tools/sstamps.py)
+P=$R/deep-statistical-solver-for-distribution-system-state-estimation_amd
+if [ -f $P/libdss2_sstamps.so ]; then
+  DSS2_LIB=$P/libdss2_sstamps.so python3 tools/sstamps.py 64 2>&1 | grep -v amdgpu > $O/stack_stamps_B64.txt
+  DSS2_LIB=$P/libdss2_sstamps.so python3 tools/sstamps.py 4096 2>&1 | grep -v amdgpu > $O/stack_stamps_B4096.txt
+fi
+# the packed-fp32 reproducer (tools/micro/pkfma_beside_mfma.hip) and the 200-launch stress of the real kernel
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/pkfma_beside_mfma.hip -o /tmp/pkfma 2>/dev/null && /tmp/pkfma > $O/pkfma_micro.txt 2>&1
+python3 tools/pk_stress.py 200 2>&1 | grep -v amdgpu > $O/pk_stress_shipped.txt
 ls -la $O

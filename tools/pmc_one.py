@@ -15,6 +15,16 @@ plan = nw._PackPlan([Ws], dev, bf16_groups=((0,) if B16 else ())); plan.refresh(
 h = torch.randn(N, H, device=dev); g = torch.randn(N, H, device=dev); out = torch.empty(N, H, device=dev)
 bias = torch.randn(H, device=dev); flat = torch.empty(nmat * H * H + H, device=dev)
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+if which.startswith("stack"):      # the whole-stack kernels on the driver's model line: stack64 / stack4096 = graphs in the batch
+    Bs = int(which[5:] or 4096)
+    bs = pkg.synthetic.make_batch(["cigre14"], Bs, seed=1)
+    xs, eis, eas = bs["x"].to(dev), bs["edge_index"].to(dev), bs["edge_attr"].to(dev)
+    model = pkg.SkipPFN(8, 6, 2, 32, 8, 2, 0.3, 5).to(dev)
+    for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
+        for q in model.parameters(): q.grad = None
+        model(xs[:, :8], eis, eas[:, :6]).square().sum().backward()
+    torch.cuda.synchronize()
+    sys.exit(0)
 for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
     if which == "fwd":
         nw.gemm_prop(topo, h, H, H, plan.fwd[0], nmat, H, out, bias=bias, relu=True)
