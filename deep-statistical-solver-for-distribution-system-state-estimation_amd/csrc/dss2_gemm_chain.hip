@@ -66,6 +66,7 @@ extern "C" int dss2_gemm_prop_chain(const dss2_gemm_prop_args* ap, const dss2_ch
       set_error("gemm_prop_chain(bf16x6): unsupported shape (nrb=%d nmat=%d k=%d kpad=%d hout=%d)", a.nrb, a.nmat, a.kreal, a.kpad, a.hout);
       return 2;
     }
+    if (rsplit == 1 && chain_sp_supported(a)) return launch_chain_sp(a, ct, s);      // 64-row tiles, H >= 96: split-plane form
     return launch_chain16(a, ct, rsplit, s);
   }
   if (a.b_format != 0) { set_error("gemm_prop_chain: unknown b_format %d", a.b_format); return 2; }

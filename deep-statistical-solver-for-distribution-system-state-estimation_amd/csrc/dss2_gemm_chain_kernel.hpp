@@ -27,8 +27,18 @@ __device__ unsigned long long g_cstamps[2048 * 8 * 64];
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     if (lane == 0 && blockIdx.x < 2048 && (slot) < 64) g_cstamps[((size_t)blockIdx.x * 8 + wave) * 64 + (slot)] = t_; \
   } while (0)
+// the 100 MHz wall clock (s_memrealtime) into a slot: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+#define CSTAMP_RT(slot)                                                                                      \
+  do {                                                                                                       \
+    unsigned long long t_;                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (lane == 0 && blockIdx.x < 2048) g_cstamps[((size_t)blockIdx.x * 8 + wave) * 64 + (slot)] = t_;       \
+  } while (0)
 #else
 #define CSTAMP(slot) do {} while (0)
+#define CSTAMP_RT(slot) do {} while (0)
 #endif
 
 constexpr int CHAIN_MAX = 8;
@@ -450,5 +460,8 @@ inline int launch_chain(const dss2_gemm_prop_args& a, const ChainTable& ct, hipS
 
 // the bf16x6 instantiations live in their own translation unit (dss2_gemm_chain16.hip, compiled without packed fp32 ops)
 int launch_chain16(const dss2_gemm_prop_args& a, const ChainTable& ct, int rsplit, hipStream_t s);
+// 64-row tiles, one wave per column group: the tile kept in LDS as split bf16 planes (dss2_gemm_chain_sp.hip; DSS2_CHAIN_SP=0: off)
+bool chain_sp_supported(const dss2_gemm_prop_args& a);
+int launch_chain_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t s);
 
 }  // namespace dss2

@@ -1,0 +1,318 @@
+// Layer chain for 64-row tiles with one wave per 32-column group (C2: H = 128), "split planes" form of the bf16x6 chain.
+//
+// The bf16x6 chain of dss2_gemm_chain_kernel.hpp keeps the activation tile as fp32 in LDS and every wave splits the A
+// fragments it reads into their three bf16 pieces in registers: all four column-group waves split the same rows (4 x
+// redundant, ~770 of a wave's ~1950 VALU instructions per layer), and the Horner hops gather scalar by scalar in the MFMA
+// accumulator layout (512 LDS reads per wave and layer).  Round 2's PMC pass: matrix pipe busy 42 %, 6.8 VALU per MFMA.
+//
+// Here the tile lives in LDS already split: per 32-column stripe three bf16 planes [64 rows][32 k] (80-byte rows: the
+// ds_read_b128 lane groups of an A fragment fall on 16 distinct 16-byte slots).  An A fragment is three ds_read_b128, the
+// GEMM phase has no VALU work besides addresses; every element is split ONCE, by the wave that produces it in the epilogue.
+// The stripe of column group w is written only by wave w, and it aliases wave w's Horner slots (two [64][32] fp32 slots,
+// 16 KB per wave): after the barrier that ends the GEMM phase nobody reads the planes any more, the hops are wave-private
+// (a wave owns all 64 rows of its columns), and the epilogue puts the next layer's planes over its own slots.  Two barriers
+// per layer as before; LDS 64 KB + the ELL slice, two workgroups per CU.
+// The hops run on 16-byte row pieces (a lane owns 4 columns of 8 rows: one ELL entry + one ds_read_b128 per neighbour) and
+// end in the lanes and the row-major form the epilogue wants: 144 LDS reads per wave and layer instead of 520.
+// Same MFMA sequence per accumulator and same fma order per hop as the fp32-tile form: bitwise the same results.
+//
+// Compiled without packed fp32 ops like the other bf16x6 translation units (build.sh, dss2_gemm_chain16.hip).
+#include <stdlib.h>
+
+#include "dss2_gemm_chain_kernel.hpp"
+
+namespace dss2 {
+
+constexpr int SP_TM = 64;
+constexpr int SP_RS = 40;                      // bf16 per plane row: 32 k + 8 pad
+constexpr int SP_PLANE = SP_TM * SP_RS;        // bf16 per plane
+constexpr int SP_REGION = 4096;                // floats per column group: two [64][32] fp32 slots = 16 KB >= three planes (15 KB)
+constexpr int SP_SLOT = SP_TM * 32;
+
+__device__ __forceinline__ void sp_barrier() {      // LDS-only hand-off: the Y stores of the epilogue stay in flight
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// the three bf16 pieces of 4 consecutive values -> the three planes (8 bytes each)
+__device__ __forceinline__ void sp_store_split(__bf16* dst, const f32x4 v) {
+  uint32_t h0, m0, l0, h1, m1, l1;
+  split3_pair(v[0], v[1], h0, m0, l0);
+  split3_pair(v[2], v[3], h1, m1, l1);
+  *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+  *reinterpret_cast<u32x2*>(dst + SP_PLANE) = u32x2{m0, m1};
+  *reinterpret_cast<u32x2*>(dst + 2 * SP_PLANE) = u32x2{l0, l1};
+}
+
+template <int NMAT, int NW>
+__global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
+  constexpr int TM = SP_TM;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nthreads = blockDim.x;
+  const int ncg = nthreads >> 6;
+  const int tile = blockIdx.x;
+  const uint64_t drop_seed = p.drop_state ? p.drop_state[0] : 0, drop_off = p.drop_state ? p.drop_state[1] : 0;
+  __bf16* xpl = reinterpret_cast<__bf16*>(smem);               // stripe s: xpl + s * (2 * SP_REGION)
+  int2* ell = reinterpret_cast<int2*>(smem + ncg * SP_REGION);
+  const int D = p.ell_width;
+  const int ts = p.tile_start[tile];
+  const int R = p.tile_start[tile + 1] - ts;
+  const int kq = p.kpad >> 2;
+
+  // ---- stage the first layer's input tile as split planes (zero padded to 64 x kpad) and the tile's ELL slice
+  for (int idx = tid; idx < TM * kq; idx += nthreads) {
+    const int r = idx / kq, c = (idx - r * kq) << 2;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
+    sp_store_split(xpl + (c >> 5) * (2 * SP_REGION) + r * SP_RS + (c & 31), v);
+  }
+  {
+    const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
+    for (int idx = tid; idx < D * TM; idx += nthreads) ell[idx] = src[idx];
+  }
+  const int c32 = lane & 31, half = lane >> 5;
+  const int cg = wave;
+  const int nks = p.kpad >> 4;
+  const __bf16* xa = xpl + c32 * SP_RS + half * 8;
+  float* slot0 = smem + cg * SP_REGION;
+  __bf16* own_planes = xpl + cg * (2 * SP_REGION);
+  const int cq = (lane & 7) * 4, r8 = lane >> 3;
+  const int col0 = cg * 32 + cq;
+  const bool col_ok = col0 < p.hout;
+
+  bf16x8 b0[3][NMAT];
+  auto load_b = [&](const bf16x8* __restrict__ bp16, bf16x8 (&b)[3][NMAT], int ks) {
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[pl][m] = bp16[(((size_t)(m * ncg + cg) * nks + ks) * 3 + pl) * 64 + lane];
+  };
+  load_b(reinterpret_cast<const bf16x8*>(ct.l[0].Bp), b0, 0);
+  CSTAMP(0);
+  sp_barrier();
+  CSTAMP(1);
+  CSTAMP_RT(62);
+
+  for (int li = 0; li < ct.n; ++li) {
+    const dss2_chain_layer& L = ct.l[li];    // uniform: scalar loads from the kernel-argument segment
+    const bf16x8* __restrict__ bp16 = reinterpret_cast<const bf16x8*>(L.Bp);
+    f32x16 acc[2][NMAT];
+
+    // ---- tile GEMM, 16 k per step: B fragments (L2) ping-pong one step ahead, A fragments (LDS planes) one row block ahead
+    {
+      bf16x8 b1[3][NMAT], a[2][3];
+      auto load_a = [&](bf16x8 (&af)[3], int rb, int ks) {
+        const __bf16* src = xa + (ks >> 1) * (2 * SP_REGION) + rb * 32 * SP_RS + (ks & 1) * 16;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8*>(src + pl * SP_PLANE);
+      };
+      auto mma = [&](const bf16x8 (&af)[3], const bf16x8 (&b)[3][NMAT], f32x16 (&c)[NMAT], const bool first) {
+        // per accumulator the smallest terms first (same sequence as the fp32-tile form); the NMAT chains are independent
+        // (first step of a layer: the accumulator operand is the inline constant 0 -- no 96 v_mov per layer)
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0][m], first ? zero : c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1][m], c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2][m], c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0][m], c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[1][m], c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[0][m], c[m], 0, 0, 0);
+      };
+      // (no branches inside the k loop: the last step re-requests its own operands.  A conditional prefetch splits the loop
+      //  body into basic blocks, and the waitcnt pass then waits for the NEW requests at the join: one L2 latency per step)
+      auto step = [&](const bf16x8 (&bc)[3][NMAT], bf16x8 (&bn)[3][NMAT], int ks, const bool first) {
+        const int kn = ks + 1 < nks ? ks + 1 : ks;
+        load_a(a[1], 1, ks);
+        load_b(bp16, bn, kn);
+        mma(a[0], bc, acc[0], first);
+        load_a(a[0], 0, kn);
+        mma(a[1], bc, acc[1], first);
+        // one memory instruction per MFMA gap (a request issued in a cluster holds the SIMD's vector issue with the matrix pipe
+        // idle: 12.1 K cycles per 288 MFMAs with the 15 requests of a step clustered, 32 cycles per MFMA = 9.2 K is the floor):
+        // gaps 1-3 this step's second row block (LDS), 4-12 the next step's weight fragments (L2), 19-21 the next first row block
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#pragma unroll
+        for (int i = 0; i < 3 * NMAT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * NMAT - 3 - 3 * NMAT, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * NMAT - 3, 0);
+      };
+      // (b0 holds step 0's fragments: requested before the first barrier / at the start of the previous layer's epilogue)
+      load_a(a[0], 0, 0);
+#ifndef DSS2_SP_NOPRIO
+      __builtin_amdgcn_s_setprio(2);      // the matrix-pipe phase wins the SIMD's issue arbitration over the other workgroup's Horner / epilogue
+#endif
+      step(b0, b1, 0, true);
+      int ks = 1;
+      for (; ks + 2 <= nks; ks += 2) {
+        step(b1, b0, ks, false);
+        step(b0, b1, ks + 1, false);
+      }
+      if (ks < nks) step(b1, b0, ks, false);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    CSTAMP(2 + li * 6 + 0);      // GEMM phase done
+    // ---- everything the epilogue reads from HBM per row, requested before the hops
+    // (rowv: this lane's first row, made opaque once per layer so that the per-row 64-bit addresses of Y / relu_src / ... are
+    //  computed where they are used instead of being hoisted out of the layer loop into 60 spilled registers)
+    int rowv = r8;
+    asm volatile("" : "+v"(rowv));
+    const bool has_pre = L.prebias != nullptr, has_dm = L.dmask != nullptr, has_rs = L.relu_src != nullptr, has_add = L.add_src != nullptr;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (L.bias && col_ok) bias4 = *reinterpret_cast<const f32x4*>(L.bias + col0);
+    auto grow_of = [&](int i) { const int row = rowv + 8 * i; return (size_t)(ts + (row < R ? row : 0)); };      // (clamped: loads only)
+    f32x4 gate[8];
+    if (has_rs && col_ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) gate[i] = *reinterpret_cast<const f32x4*>(L.relu_src + grow_of(i) * p.ld_relu + col0);
+    }
+    // every wave is done with this layer's planes: the hops below overwrite the wave's own stripe
+    sp_barrier();
+    CSTAMP(2 + li * 6 + 1);
+
+    // ---- Horner on row pieces, wave-private: T in one slot, G_m in the other; U = G_m + P T replaces G_m
+    f32x4 U[8];
+    {
+      auto put = [&](float* slot, int m) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) slot[(rb * 32 + acc_row(r, half)) * 32 + c32] = acc[rb][m][r];
+      };
+      put(slot0, NMAT - 1);
+#pragma unroll
+      for (int m = NMAT - 2; m >= 0; --m) {
+        float* cur = slot0 + (((NMAT - 2 - m) & 1) ? SP_SLOT : 0);      // holds T
+        float* oth = slot0 + (((NMAT - 2 - m) & 1) ? 0 : SP_SLOT);      // receives G_m, then U
+        put(oth, m);
+        wave_lds_sync();
+        int2 en[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { en[i] = ell[r8 + 8 * i]; U[i] = *reinterpret_cast<const f32x4*>(oth + (r8 + 8 * i) * 32 + cq); }
+        for (int k = 0; k < D; ++k) {
+          const int kn = k + 1 < D ? k + 1 : k;
+          f32x4 z[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) z[i] = *reinterpret_cast<const f32x4*>(cur + en[i].x * 32 + cq);
+          int2 en_next[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) en_next[i] = ell[kn * TM + r8 + 8 * i];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float w = __int_as_float(en[i].y);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) U[i][q] = fmaf(w, z[i][q], U[i][q]);
+            en[i] = en_next[i];
+          }
+        }
+        if (m > 0) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(oth + (r8 + 8 * i) * 32 + cq) = U[i];
+        }
+        wave_lds_sync();      // the other lanes' gathers precede the next writes into `cur` (m > 0) / into the planes (m == 0)
+      }
+    }
+
+    CSTAMP(2 + li * 6 + 2);      // Horner done
+    CSTAMP(2 + li * 6 + 5);
+    // ---- epilogue: bias / folded bias / masks / dropout / ReLU / gate / residual -> HBM and, split, the next layer's planes
+    // (one uniform branch per feature around a loop over the lane's rows, not the other way round)
+    const bool keep = li + 1 < ct.n;
+    if (keep) load_b(reinterpret_cast<const bf16x8*>(ct.l[li + 1].Bp), b0, 0);      // the next layer's first fragments ride under the epilogue
+#pragma unroll
+    for (int i = 0; i < 8; ++i) U[i] += bias4;
+    if (col_ok) {
+      if (has_pre) {
+        f32x4 pb4[NMAT];
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) pb4[m] = *reinterpret_cast<const f32x4*>(L.prebias + (size_t)m * p.hout + col0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pre_rowscale + grow_of(i) * 4);
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m) U[i] += pb4[m] * ps[m];
+        }
+      }
+      if (has_dm) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) U[i] *= *reinterpret_cast<const f32x4*>(L.dmask + grow_of(i) * p.ld_dmask + col0);
+      }
+      if (L.drop_id) {
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i)
+          U[i] *= dropout_mult4(drop_seed, drop_off, (uint32_t)L.drop_id, (uint32_t)grow_of(i), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
+      }
+      if (L.relu & 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) U[i][q] = fmaxf(U[i][q], 0.f);
+      }
+      if (has_rs) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) U[i][q] = gate[i][q] > 0.f ? U[i][q] : 0.f;
+      }
+      if (has_add) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) U[i] += *reinterpret_cast<const f32x4*>(L.add_src + grow_of(i) * p.ld_add + col0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (rowv + 8 * i < R) *reinterpret_cast<f32x4*>(L.Y + (size_t)(ts + rowv + 8 * i) * p.ldy + col0) = U[i];
+    }
+    if (keep) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = rowv + 8 * i;
+        sp_store_split(own_planes + row * SP_RS + cq, (row < R && col_ok) ? U[i] : f32x4{0.f, 0.f, 0.f, 0.f});
+      }
+    }
+    CSTAMP(2 + li * 6 + 3);      // epilogue done
+    if (keep) sp_barrier();   // the next layer's planes are complete
+    CSTAMP(2 + li * 6 + 4);
+    if (!keep) CSTAMP_RT(63);
+  }
+}
+
+inline size_t chain_sp_lds_bytes(int ncg, int ell_width) { return (size_t)ncg * SP_REGION * 4 + (size_t)SP_TM * ell_width * 8; }
+
+bool chain_sp_supported(const dss2_gemm_prop_args& a) {
+  static const int on = [] { const char* e = getenv("DSS2_CHAIN_SP"); return e ? atoi(e) : 1; }();
+  return on && a.b_format == 1 && a.nrb == 2 && a.nmat >= 2 && a.nmat <= 3 && (a.kpad & 15) == 0 && a.kpad <= 32 * a.ncg &&
+         a.ncg >= 3 && a.ncg <= 8 && chain_sp_lds_bytes(a.ncg, a.ell_width) <= (size_t)kMaxLdsBytes;
+}
+
+template <int NMAT, int NW>
+static int launch_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t stream) {
+  static std::atomic<uint32_t> lds_done{0};
+  auto kern = gemm_chain_sp_kernel<NMAT, NW>;
+  if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop_chain(split planes)")) return 1;
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg), chain_sp_lds_bytes(a.ncg, a.ell_width), stream, a, ct);
+  return check_launch("gemm_prop_chain(split planes)");
+}
+
+int launch_chain_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t s) {
+  if (a.nmat == 2) return a.ncg <= 4 ? launch_sp<2, 4>(a, ct, s) : launch_sp<2, 8>(a, ct, s);
+  return a.ncg <= 4 ? launch_sp<3, 4>(a, ct, s) : launch_sp<3, 8>(a, ct, s);      // (K = 3 would spill: chain_sp_supported says no)
+}
+
+}  // namespace dss2
+
+#ifdef DSS2_CHAIN_STAMPS
+extern "C" int dss2_debug_read_cstamps_sp(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dss2::g_cstamps), sizeof(unsigned long long) * n);
+}
+#endif

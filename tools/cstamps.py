@@ -25,8 +25,10 @@ run(); torch.cuda.synchronize()
 nwg = min(topo.ntiles, 2048)
 buf = (C.c_ulonglong * (nwg * 8 * 64))()
 lib = pkg._lib.lib()
-lib.dss2_debug_read_cstamps.argtypes = [C.c_void_p, C.c_int]
-assert lib.dss2_debug_read_cstamps(buf, nwg * 8 * 64) == 0
+sp = H >= 96 and os.environ.get("DSS2_CHAIN_SP", "1") != "0"      # the split-plane kernel keeps its stamps in its own translation unit
+reader = lib.dss2_debug_read_cstamps_sp if sp else lib.dss2_debug_read_cstamps
+reader.argtypes = [C.c_void_p, C.c_int]
+assert reader(buf, nwg * 8 * 64) == 0
 ncg = (H + 31) // 32
 nwav = min(8, ncg * (2 if ncg <= 2 else 1))      # waves per workgroup (row split for narrow layers)
 st = np.frombuffer(buf, dtype=np.uint64).reshape(nwg, 8, 64)[:, :nwav, :].astype(np.int64)
@@ -40,5 +42,16 @@ for li in range(nl):
     gemm, bar1, horner, epi, bar2 = us(s(0) - prev), us(s(1) - s(0)), us(s(2) - s(1)), us(s(3) - s(2)), us(s(4) - s(3))
     epi_a = us(s(5) - s(2))
     print(f"  layer {li}: GEMM {gemm:7.0f}  barrier {bar1:5.0f}  Horner {horner:6.0f}  epilogue {epi:6.0f} (T -> stage {epi_a:5.0f}, rows -> HBM / X tile {epi - epi_a:5.0f})  barrier {bar2:5.0f}   sum {gemm + bar1 + horner + epi + bar2:7.0f} cycles")
+if sp:
+    dt, drt = st[:, :, 2 + (nl - 1) * 6 + 4] - st[:, :, 1], st[:, :, 63] - st[:, :, 62]
+    print(f"  in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz), median: {np.median(dt / np.maximum(drt, 1)) * 0.1:.2f} GHz")
+if sp:
+    # wall-clock picture (100 MHz s_memrealtime): when workgroups start their first layer and when they end
+    t0 = st[:, :, 62].min(); a = (st[:, :, 62].min(axis=1) - t0) / 100.0; e = (st[:, :, 63].max(axis=1) - t0) / 100.0
+    q = lambda v: " ".join(f"{x:6.1f}" for x in np.percentile(v, [0, 10, 50, 90, 100]))
+    n1 = min(nwg, 512)
+    print(f"  wall clock, us after the first workgroup's start (min p10 p50 p90 max):")
+    print(f"    workgroups 0..{n1 - 1}: start {q(a[:n1])} | end {q(e[:n1])} | duration {q(e[:n1] - a[:n1])}")
+    if nwg > n1: print(f"    workgroups {n1}..{nwg - 1}: start {q(a[n1:])} | end {q(e[n1:])} | duration {q(e[n1:] - a[n1:])}")
 wg = st[:, :, 2 + (nl - 1) * 6 + 3].max(axis=1) - st[:, :, 0].min(axis=1)
 print(f"  per workgroup, first stamp -> last epilogue: median {np.median(wg):.0f} cycles, max {wg.max():.0f}")
