@@ -142,7 +142,7 @@ def main():
         loss = pkg.gsp_wls_edge(input=xin, edge_input=ein, output=out, x_mean=stats[0], x_std=stats[1],
                                 edge_mean=stats[2], edge_std=stats[3], edge_index=ei, reg_coefs=REG,
                                 num_samples=None, node_param=npar, edge_param=epar, group=group)
-        loss.backward()
+        loss.backward(pkg.data.unit_grad(loss))      # (= loss.backward(); the root gradient is a cached scalar 1 instead of a fill kernel per step)
         return loss
 
     def sync():

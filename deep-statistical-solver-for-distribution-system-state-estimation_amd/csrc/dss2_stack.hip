@@ -52,14 +52,14 @@ __device__ unsigned long long g_sstamps[2][64 * 8 * 128];
 #define SSTAMP(which, on) do {} while (0)
 #endif
 
-constexpr int SH = 32, SNM = 3, SFN = 8, SFC = 22, SW1LD = 24, STM = 64, SXLD = 36, SZLD = 100;
+constexpr int SH = 32, SNM = 3, SFN = 8, SFC = 22, SW1LD = 24, STM = 64, SXLD = 36;
 constexpr int S_MAX_HH = 7, S_MAX_ELL = 4;      // (ELL width <= 4: the backward keeps a row's entries in registers and its LDS is full)
 
 // ---- wpack layout (32-bit words), per block -------------------------------------------------------------------------------
 constexpr int WP_W1 = 0, WP_B1 = SH * SW1LD, WP_CONV0 = WP_B1 + SH;
 constexpr int WP_FRAG = 3 * 64 * 4;                          // one k-group of 16: 3 planes x 64 lanes x 8 bf16
 constexpr int WP_CONV_FWD = 0;                               // [m][kg 0..1][plane][lane][4 words]
-constexpr int WP_CONV_BWD = SNM * 2 * WP_FRAG;               // [kg 0..5][plane][lane][4]   (k = 32 m + j)
+constexpr int WP_CONV_BWD = SNM * 2 * WP_FRAG;               // [ib 0..1][k-step 0..2][plane][lane][4]: 16x16x32 A fragments (k = 32 m + j)
 constexpr int WP_CONV_BIAS = WP_CONV_BWD + 6 * WP_FRAG;      // [32]
 constexpr int WP_CONV_PRE = WP_CONV_BIAS + SH;               // [3][32]  (conv 0: bf_m = W_m b2)
 constexpr int WP_CONV_STRIDE = WP_CONV_PRE + SNM * SH;
@@ -166,10 +166,11 @@ __global__ void __launch_bounds__(256) stack_pack_kernel(const dss2_stack_dims d
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = src[c32][16 * kg + 8 * half + q];
       split8_store(v, cw + WP_CONV_FWD + (m * 2 + kg) * WP_FRAG + lane * 4, 256);
-    } else {              // data-gradient operand: B[k = 32 m + j][i = in] = src[j][i]
+    } else {              // data-gradient operand (v_mfma_f32_16x16x32_bf16, A side): A[i = 16 ib + lane % 16][k = 32 m + 8 (lane / 16) + q]
+      const int ib = kg;  //   = W_m[j = 8 (lane / 16) + q][i]; fragment [ib][k-step m][plane][lane]
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = src[16 * kg + 8 * half + q][c32];
-      split8_store(v, cw + WP_CONV_BWD + (m * 2 + kg) * WP_FRAG + lane * 4, 256);
+      for (int q = 0; q < 8; ++q) v[q] = src[8 * (lane >> 4) + q][16 * ib + (lane & 15)];
+      split8_store(v, cw + WP_CONV_BWD + (ib * SNM + m) * WP_FRAG + lane * 4, 256);
     }
   } else if (u == d.n_hh * SNM) {
     // head: three [dout][32] matrices side by side in one 32-column group (forward) / stacked along k (data-gradient)
@@ -186,10 +187,11 @@ __global__ void __launch_bounds__(256) stack_pack_kernel(const dss2_stack_dims d
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = c32 < SNM * dout ? hs[c32 * (SH + 1) + 16 * kg + 8 * half + q] : 0.f;
       split8_store(v, hw + WP_HEAD_FWD + kg * WP_FRAG + lane * 4, 256);
-    } else {              // B[kk = m dout + o][i = c32] = W_m[o][i]
+    } else {              // A[i = 16 ib + lane % 16][kk = m dout + o] = W_m[o][i], kk = 8 (lane / 16) + q < 32 (one k-step, zero padded)
+      const int ib = kg;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { const int kk = 16 * kg + 8 * half + q; v[q] = kk < SNM * dout ? hs[kk * (SH + 1) + c32] : 0.f; }
-      split8_store(v, hw + WP_HEAD_BWD + kg * WP_FRAG + lane * 4, 256);
+      for (int q = 0; q < 8; ++q) { const int kk = 8 * (lane >> 4) + q; v[q] = kk < SNM * dout ? hs[kk * (SH + 1) + 16 * ib + (lane & 15)] : 0.f; }
+      split8_store(v, hw + WP_HEAD_BWD + ib * WP_FRAG + lane * 4, 256);
     }
     if (tid < 8) reinterpret_cast<float*>(hw + WP_HEAD_BIAS)[tid] = tid < dout ? P[4 + 4 * d.n_hh][tid] : 0.f;
   } else {
@@ -504,6 +506,7 @@ static size_t stack_fwd_lds(int D) { return (size_t)(STM * SXLD * 4 + STM * SFN 
 // =====================================================================================================================
 // backward
 // =====================================================================================================================
+constexpr int SZ2 = 68;       // row stride of [Z_1 | Z_2] (64 columns + 4: 16-byte aligned rows)
 constexpr int STLD = 68;      // row stride of the transposed fp32 copies [column][64 rows]: 16-byte rows of 4 consecutive tile
                               // rows, conflict-free ds_read_b128 for 32 lanes on 32 consecutive columns (68 c mod 64 = 4 c)
 
@@ -512,6 +515,16 @@ constexpr int STLD = 68;      // row stride of the transposed fp32 copies [colum
 // (c32, half) reads rows 16 kg + 8 half .. + 7 of its column as two ds_read_b128 -- exactly an A / B fragment of
 // v_mfma_f32_32x32x16_bf16 -- and splits them in registers.  4 k-groups x 6 MFMAs = 768 cycles of matrix pipe per block (the
 // fp32 form, 32 x v_mfma_f32_32x32x2_f32, held the pipe for 2048 and starved the data-gradient waves of the same SIMD).
+__device__ __forceinline__ void split8v(const f32x4 v0, const f32x4 v1, bf16x8& h, bf16x8& m, bf16x8& l) {
+  uint32_t sh[4], sm[4], sl[4];
+  split3_pair(v0[0], v0[1], sh[0], sm[0], sl[0]);
+  split3_pair(v0[2], v0[3], sh[1], sm[1], sl[1]);
+  split3_pair(v1[0], v1[1], sh[2], sm[2], sl[2]);
+  split3_pair(v1[2], v1[3], sh[3], sm[3], sl[3]);
+  h = __builtin_bit_cast(bf16x8, u32x4{sh[0], sh[1], sh[2], sh[3]});
+  m = __builtin_bit_cast(bf16x8, u32x4{sm[0], sm[1], sm[2], sm[3]});
+  l = __builtin_bit_cast(bf16x8, u32x4{sl[0], sl[1], sl[2], sl[3]});
+}
 __device__ __forceinline__ void split8(const float* src, bf16x8& h, bf16x8& m, bf16x8& l) {
   const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
   uint32_t sh[4], sm[4], sl[4];
@@ -568,13 +581,15 @@ __device__ __forceinline__ float colsum32(const float* tile, int ld, int lane, c
 __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int D = p.ell_width, DT = p.ellT_width;
-  float* Z = smem;                                    // [64][100]: Z_0 = g | Z_1 = A^T g | Z_2 = (A^T)^2 g
-  float* A0 = Z + STM * SZLD;                         // [64][36] x 2: the unit's saved input activation (ping-pong)
+  float* Z12 = smem;                                  // [64][68]: Z_1 = A^T g | Z_2 = (A^T)^2 g (columns 0..31 | 32..63); U0 | U1 in the edge phase
+  float* A0 = Z12 + STM * SZ2;                        // [64][36] x 2: the unit's saved input activation (ping-pong)
   float* A1 = A0 + STM * SXLD;
-  float* stg = A1 + STM * SXLD;                       // [64][36] x 2: data gradient before the gate, one per k half; U0 / U1 in the edge phase
-  float* stg2 = stg + STM * SXLD;
-  float* ZT = stg2 + STM * SXLD;                      // [96][68]: Z transposed (weight-gradient operand)
-  float* AT0 = ZT + 3 * SH * STLD;                    // [32][68] x 2: the activation transposed
+  float* Z0a = A1 + STM * SXLD;                       // [64][36] x 2: Z_0 = g of the unit (ping-pong: the data-gradient waves write the
+  float* Z0b = Z0a + STM * SXLD;                      //   gated gradient of the unit below while the others still read this unit's)
+  float* ZT12 = Z0b + STM * SXLD;                     // [64][68]: Z_1, Z_2 transposed (weight-gradient operands)
+  float* ZT0a = ZT12 + 2 * SH * STLD;                 // [32][68] x 2: Z_0 transposed (ping-pong like Z_0)
+  float* ZT0b = ZT0a + SH * STLD;
+  float* AT0 = ZT0b + SH * STLD;                      // [32][68] x 2: the activation transposed
   float* AT1 = AT0 + SH * STLD;
   float* x8 = AT1 + SH * STLD;                        // [64][8] block input
   float* gx = x8 + STM * SFN;                         // [64][8] gradient of the block output
@@ -598,10 +613,17 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
   const int blk_words = wp_block_words(n_hh);
   const int prow = tid >> 3, pcq = (tid & 7) * 4, ho = tid & 7;
   const int bsz_inner = fl_block(n_hh, p.dims.dout_inner);
-  float* Abuf[2] = {A0, A1};
-  float* ATbuf[2] = {AT0, AT1};
+  // (ping-pong buffers are addressed as base + parity * size: an ARRAY of LDS pointers indexed at run time lives in private memory
+  //  as generic pointers, and every access through one becomes a flat_load / flat_store that waits for vmcnt(0) AND lgkmcnt(0))
+  auto Abuf = [&](int par) { return A0 + (par & 1) * (STM * SXLD); };
+  auto ATbuf = [&](int par) { return AT0 + (par & 1) * (SH * STLD); };
+  auto Z0buf = [&](int par) { return Z0a + (par & 1) * (STM * SXLD); };
+  auto ZT0buf = [&](int par) { return ZT0a + (par & 1) * (SH * STLD); };
+  // (pad rows of the Z_0 buffers: 32-row tiles never write rows 32..63, the hops and column sums read them)
+  for (int idx = tid; idx < 2 * STM * SXLD; idx += 512) Z0a[idx] = 0.f;
   const bool short_t = p.tm <= 32;      // 32-row tiles: rows 32..63 are zero padding everywhere
   const int n_et = short_t ? 2 : STM / 16;
+  const bool one_tile = (int)gridDim.x >= p.ntiles;      // small batches: the dx hand-over between blocks stays in LDS (gx)
   int staged_tile = -1;      // the tile whose block-independent operands (ELL slices, edge features, row scales) are in LDS
 
   for (int b = NB - 1; b >= 0; --b) {
@@ -632,12 +654,14 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
       for (int idx = tid; idx < STM * SFN; idx += 512) {
         const int r = idx >> 3, c = idx & 7;
         x8[idx] = r < R ? xin[(int64_t)(ts + r) * ldxin + c] : 0.f;
-        float g = 0.f;
-        if (r < R) {
-          if (b == NB - 1) { if (c < dout) g = p.gout[(int64_t)(ts + r) * p.ldg + c]; }
-          else g = p.dxbuf[(int64_t)(ts + r) * SFN + c];
+        if (b == NB - 1 || !one_tile) {      // (one tile per workgroup: the block above has left its dx in gx)
+          float g = 0.f;
+          if (r < R) {
+            if (b == NB - 1) { if (c < dout) g = p.gout[(int64_t)(ts + r) * p.ldg + c]; }
+            else g = __hip_atomic_load(p.dxbuf + (int64_t)(ts + r) * SFN + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (from L2: see the block end)
+          }
+          gx[idx] = g;
         }
-        gx[idx] = g;
       }
       if (tile != staged_tile) {      // (a workgroup with ONE tile -- small batches -- stages these once for all blocks)
         if (tid < STM) {
@@ -646,10 +670,6 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
           *reinterpret_cast<f32x4*>(dps + tid * 4) = v;
         }
         stage_ell_w(p.ellT_w, tile, DT, p.tm, ellTw, tid, 512);
-        const float* ec = p.eacache + (size_t)tile * (D + DT) * STM * 8;
-        stage_edges(p.ell_e, tile, D, p.tm, ec, other, eaL, tid, 512);
-        stage_edges(p.ellT_e, tile, DT, p.tm, ec + D * STM * 8, otherT, eaT, tid, 512);
-        staged_tile = tile;
       }
       {   // the head's data-gradient operand fragments (2 k-groups)
         const bf16x8* bsrc = reinterpret_cast<const bf16x8*>(p.wpack + (size_t)b * blk_words + wp_head(n_hh) + WP_HEAD_BWD);
@@ -658,11 +678,28 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
       {   // the head's input activation h_{n_hh}, row-major (gate) and transposed (weight-gradient operand)
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (prow < R) v = *reinterpret_cast<const f32x4*>(act_b + ((size_t)n_hh * N + ts + prow) * SH + pcq);
-        *reinterpret_cast<f32x4*>(Abuf[n_hh & 1] + prow * SXLD + pcq) = v;
-        float* at = ATbuf[n_hh & 1] + pcq * STLD + prow;
+        *reinterpret_cast<f32x4*>(Abuf(n_hh & 1) + prow * SXLD + pcq) = v;
+        float* at = ATbuf(n_hh & 1) + pcq * STLD + prow;
 #pragma unroll
         for (int q = 0; q < 4; ++q) at[q * STLD] = v[q];
       }
+      // The tile's edge tables and edge features (20 KB, only the edge passes at the END of the tile read them): requested here,
+      // AFTER every load the staging barrier waits for (vector loads return in order),
+      // into registers, stored to LDS at the top of the second unit -- a global round trip off the staging barrier's critical path
+      // (threads 0..255: the by-target table, 256..511: the by-source table; D, DT <= 4: one item per thread).
+      asm volatile("" ::: "memory");      // (keeps the requests below behind the stores above)
+      const bool e_pend = tile != staged_tile;
+      int2 e_en = make_int2(0, -1);
+      f32x4 e_a = {0.f, 0.f, 0.f, 0.f}, e_c = {0.f, 0.f, 0.f, 0.f};
+      const int e_tr = tid >> 8, e_idx = tid & 255, e_W = e_tr ? DT : D;
+      if (e_pend && e_idx < e_W * STM) {
+        const int k = e_idx >> 6, r = e_idx & 63;
+        if (r < p.tm) e_en = (reinterpret_cast<const int2*>(e_tr ? p.ellT_e : p.ell_e) + (size_t)tile * e_W * p.tm)[k * p.tm + r];
+        const float* ec = p.eacache + ((size_t)tile * (D + DT) + (e_tr ? D : 0)) * STM * 8 + e_idx * 8;
+        e_a = *reinterpret_cast<const f32x4*>(ec);
+        e_c = *reinterpret_cast<const f32x4*>(ec + 4);
+      }
+      staged_tile = tile;
       SSTAMP(1, st_on);            // 1: staging issued
       wg_barrier();
       SSTAMP(1, st_on);            // 2: staged
@@ -672,92 +709,161 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
       for (int k = 0; k < 4; ++k) en4[k] = k < DT ? ellTw[k * STM + prow] : make_int2(prow, 0);
 
       // ---- units u = n_hh (head), n_hh - 1 .. 0 (H -> H layers; conv 0 folded)
+      // Per unit: two hops (Z_1, Z_2 and their transposed copies), then ONE phase in which three waves accumulate the weight
+      // gradients, one wave the bias sums, and four waves compute the data gradient AND gate it: D^T = Wcat^T Z^T on
+      // v_mfma_f32_16x16x32_bf16 (bf16x6), whose accumulator gives a lane 4 consecutive input features of ONE tile row -- the
+      // 16-byte row piece the gate (saved activation > 0, regenerated dropout mask) and the next unit's Z_0 want, so the
+      // gradient never visits LDS between the GEMM and the gate (round 3, first form: 32x32 blocks split over k halves,
+      // exchanged through LDS and gated in a phase of its own: 5.7 K of a unit's 7.6 K cycles).  Z_0 is double-buffered.
+      f32x4 apf = {0.f, 0.f, 0.f, 0.f};
+      bf16x8 wpf[3];
       for (int u = n_hh; u >= 0; --u) {
         const bool head = u == n_hh;
-        float* Acur = Abuf[u & 1];
-        // the input activation of the unit below, requested now, stored after the MFMA phase
-        f32x4 apf = {0.f, 0.f, 0.f, 0.f};
+        float* Z0 = Z0buf(u & 1);
+        float* ZT0 = ZT0buf(u & 1);
+        float* Acur = Abuf(u & 1);
+        if (!head) {
+          // this unit's operands, requested during the unit above: data-gradient fragments, input activation (both forms)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { const int f = tid + 512 * i; if (f < 6 * 3 * 64) wfrag[f] = wpf[i]; }
+          *reinterpret_cast<f32x4*>(Acur + prow * SXLD + pcq) = apf;
+          float* at = ATbuf(u & 1) + pcq * STLD + prow;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) at[q * STLD] = apf[q];
+          if (u == n_hh - 1 && e_pend && e_idx < e_W * STM) {      // the deferred edge staging (see above)
+            (e_tr ? otherT : other)[e_idx] = e_en.y != -1 ? e_en.x : -1;
+            float* dst = (e_tr ? eaT : eaL) + e_idx * 8;
+            *reinterpret_cast<f32x4*>(dst) = e_a;
+            *reinterpret_cast<f32x4*>(dst + 4) = e_c;
+          }
+        }
+        // the operands of the unit below: L2 -> registers now, -> LDS at the top of that unit (a whole unit of latency cover)
+        apf = f32x4{0.f, 0.f, 0.f, 0.f};
         if (u > 0 && prow < R) apf = *reinterpret_cast<const f32x4*>(act_b + ((size_t)(u - 1) * N + ts + prow) * SH + pcq);
-        // wave roles of this unit: weight gradient blocks q = 3 u + k on wave q mod 8 (slot q / 8); data gradient on the next
-        // four waves (row block x k half); bias sums on the last one
-        const int q0 = 3 * u;
-        const int di = (wave - (q0 + 3)) & 7;            // 0..3: data-gradient wave
-        const int drb = di & 1, dkh = di >> 1;
-        const bool dgrad_wave = di < 4 && (!head || di < 2) && !(short_t && drb);
-        const bool sum_wave = wave == ((q0 + 7) & 7);
-        // the data-gradient operand fragments of the unit BELOW: L2 -> registers now, -> LDS in this unit's gate phase (after
-        // its MFMA phase has read this unit's), so their L2 latency hides behind the hops and the MFMA phase
-        bf16x8 wpf[3];
         if (u > 0) {
           const bf16x8* bsrc = reinterpret_cast<const bf16x8*>(p.wpack + (size_t)b * blk_words + WP_CONV0 + (u - 1) * WP_CONV_STRIDE + WP_CONV_BWD);
 #pragma unroll
           for (int i = 0; i < 3; ++i) wpf[i] = bsrc[tid + 512 * i < 6 * 3 * 64 ? tid + 512 * i : 0];
         }
+        // wave roles of this unit: weight gradient blocks q = 3 u + k on wave q mod 8 (slot q / 8); data gradient + gate on the
+        // next four waves; bias sums on the last one
+        const int q0 = 3 * u;
+        const int di = (wave - (q0 + 3)) & 7;            // 0..3: data-gradient wave
+        const bool sum_wave = wave == ((q0 + 7) & 7);
         if (head) {
-          // Z[:, 0:dout] = g, then two dout-wide hops; columns 3 dout .. 31 zero (every value also into the transposed copy)
-          if (ho < dout) { const float g = gx[prow * SFN + ho]; Z[prow * SZLD + ho] = g; ZT[ho * STLD + prow] = g; }
-          for (int c = 3 * dout + ho; c < 32; c += 8) { Z[prow * SZLD + c] = 0.f; ZT[c * STLD + prow] = 0.f; }
+          // Z_0[:, 0:dout] = g, then two dout-wide hops inside the same 32 columns; columns 3 dout .. 31 zero (every value also
+          // into the transposed copy)
+          if (ho < dout) { const float g = gx[prow * SFN + ho]; Z0[prow * SXLD + ho] = g; ZT0[ho * STLD + prow] = g; }
+          for (int c = 3 * dout + ho; c < 32; c += 8) { Z0[prow * SXLD + c] = 0.f; ZT0[c * STLD + prow] = 0.f; }
           wg_barrier();
           if (ho < dout) {
             float t = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) t = fmaf(__int_as_float(en4[k].y), Z[en4[k].x * SZLD + ho], t);
-            Z[prow * SZLD + dout + ho] = t; ZT[(dout + ho) * STLD + prow] = t;
+            for (int k = 0; k < 4; ++k) t = fmaf(__int_as_float(en4[k].y), Z0[en4[k].x * SXLD + ho], t);
+            Z0[prow * SXLD + dout + ho] = t; ZT0[(dout + ho) * STLD + prow] = t;
           }
           wg_barrier();
           if (ho < dout) {
             float t = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) t = fmaf(__int_as_float(en4[k].y), Z[en4[k].x * SZLD + dout + ho], t);
-            Z[prow * SZLD + 2 * dout + ho] = t; ZT[(2 * dout + ho) * STLD + prow] = t;
+            for (int k = 0; k < 4; ++k) t = fmaf(__int_as_float(en4[k].y), Z0[en4[k].x * SXLD + dout + ho], t);
+            Z0[prow * SXLD + 2 * dout + ho] = t; ZT0[(2 * dout + ho) * STLD + prow] = t;
           }
           wg_barrier();
         } else {
 #pragma unroll
           for (int m = 1; m < SNM; ++m) {
-            const float* src = Z + (m - 1) * SH + pcq;
+            const float* src = (m == 1 ? Z0 : Z12) + pcq;
+            const int sld = m == 1 ? SXLD : SZ2;
             f32x4 zz[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) zz[k] = *reinterpret_cast<const f32x4*>(src + en4[k].x * SZLD);      // all four gathers in flight
+            for (int k = 0; k < 4; ++k) zz[k] = *reinterpret_cast<const f32x4*>(src + en4[k].x * sld);      // all four gathers in flight
             f32x4 U = zz[0] * __int_as_float(en4[0].y);
 #pragma unroll
             for (int k = 1; k < 4; ++k) U += zz[k] * __int_as_float(en4[k].y);
-            *reinterpret_cast<f32x4*>(Z + prow * SZLD + m * SH + pcq) = U;
-            float* zt = ZT + (m * SH + pcq) * STLD + prow;
+            *reinterpret_cast<f32x4*>(Z12 + prow * SZ2 + (m - 1) * SH + pcq) = U;
+            float* zt = ZT12 + ((m - 1) * SH + pcq) * STLD + prow;
 #pragma unroll
             for (int q = 0; q < 4; ++q) zt[q * STLD] = U[q];
             wg_barrier();
           }
         }
         SSTAMP(1, st_on);          // 3 + 5 i: hops done (i = n_hh - u)
-        // ---- ONE MFMA phase: weight gradients (3 waves), data gradient (4 waves), bias sums (1 wave)
+        // ---- ONE phase: weight gradients (3 waves), data gradient + gate (4 waves), bias sums (1 wave)
         {
           const int nblk = head ? 1 : SNM;
           for (int k = 0; k < nblk; ++k) {
             const int q = q0 + k;
             if (wave == (q & 7)) {
-              const float* zt = ZT + (k * SH + c32) * STLD + 8 * half;      // (32-row tiles: k runs over rows 0..31 only)
-              const float* at = ATbuf[u & 1] + c32 * STLD + 8 * half;
+              const float* zt = (k == 0 ? ZT0 : ZT12 + (k - 1) * SH * STLD) + c32 * STLD + 8 * half;      // (32-row tiles: k runs over rows 0..31 only)
+              const float* at = ATbuf(u & 1) + c32 * STLD + 8 * half;
               const int slot = q >> 3;
               if (slot == 0) acc0 = wgrad_block(acc0, zt, at, short_t);
               else if (slot == 1) acc1 = wgrad_block(acc1, zt, at, short_t);
               else acc2 = wgrad_block(acc2, zt, at, short_t);
               if (u == 0) {      // folded conv 0: dbf_k[c] += sum_rows (A^k deg)[row] g[row][c]  (this wave's share of the bias sums)
-                const float sf = colsum32(Z, SZLD, lane, dps, k, csum + k * (4 * SH));
+                const float sf = colsum32(Z0, SXLD, lane, dps, k, csum + k * (4 * SH));
                 if (lane < 32) accS[ACC_DBF + k * SH + lane] += sf;
               }
             }
           }
-          if (dgrad_wave) {
-            // rows drb * 32 .., k-groups 3 dkh .. 3 dkh + 2 (head: 0, 1): two independent accumulation chains
-            const float* arow = Z + (drb * 32 + c32) * SZLD + half * 8 + (head ? 0 : dkh * 48);
-            const bf16x8* bq = wfrag + (head ? 0 : 3 * dkh) * 3 * 64 + lane;      // [k-group][plane][lane]
-            f32x16 a0 = mma6(zero16(), arow, bq[0], bq[64], bq[128]);
-            f32x16 a1 = mma6(zero16(), arow + 16, bq[192], bq[256], bq[320]);
-            if (!head) a0 = mma6(a0, arow + 32, bq[384], bq[448], bq[512]);
-            float* g = (dkh ? stg2 : stg) + (drb * 32) * SXLD + c32;
+          if (di < 4) {
+            // 64-row tiles: wave di owns tile rows 16 di .. + 15, both 16-feature blocks (the Z fragment is split once for the
+            // two); 32-row tiles: (row block di & 1, feature block di >> 1)
+            const int l16 = lane & 15, kg = lane >> 4;
+            const int row = (short_t ? (di & 1) : di) * 16 + l16;
+            const int ib0 = short_t ? (di >> 1) : 0, nib = short_t ? 1 : 2;
+            const int nks = head ? 1 : SNM;
+            f32x4 d[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            // (requesting every Z fragment and the gate's inputs -- saved activation, dropout multipliers -- ahead of the k-steps
+            //  was tried: 30 more live registers spill, 0.309 -> 0.316 ms at B = 64)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g[acc_row(r, half) * SXLD] = a0[r] + a1[r];
+            for (int ks = 0; ks < SNM; ++ks) {
+              if (ks < nks) {
+                bf16x8 zh, zm, zl;
+                split8((ks == 0 ? Z0 + row * SXLD : Z12 + row * SZ2 + (ks - 1) * SH) + 8 * kg, zh, zm, zl);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                  if (j < nib) {
+                    const bf16x8* wq = wfrag + ((ib0 + j) * nks + ks) * 3 * 64 + lane;      // [feature block][k-step][plane][lane]
+                    const bf16x8 wh = wq[0], wm = wq[64], wl = wq[128];
+                    f32x4 c = d[j];      // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, zh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, zm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, zl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, zh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, zm, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, zh, c, 0, 0, 0);
+                    d[j] = c;
+                  }
+                }
+              }
+            }
+            // gate: gradient w.r.t. the pre-activation output of the unit below (u > 0); u == 0: dS, no gate.  Lane: row `row`,
+            // features 16 ib + 4 kg .. + 3
+            float* Zn = Z0buf((u + 1) & 1);
+            float* ZTn = ZT0buf((u + 1) & 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              if (j < nib) {
+                const int col = 16 * (ib0 + j) + 4 * kg;
+                f32x4 v = d[j];
+                if (u > 0) {
+                  const f32x4 a = *reinterpret_cast<const f32x4*>(Acur + row * SXLD + col);
+                  f32x4 mult = {1.f, 1.f, 1.f, 1.f};
+                  if (p.drop_state) mult = dropout_mult4(dseed, doff, (uint32_t)(b * p.drop_stride + u), (uint32_t)(ts + row), (uint32_t)(col >> 2), p.drop_thr, p.drop_scale);
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) v[q] = a[q] > 0.f ? v[q] * mult[q] : 0.f;
+                }
+                if (row >= R) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(Zn + row * SXLD + col) = v;
+                if (u > 0) {
+                  float* zt = ZTn + col * STLD + row;
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) zt[q * STLD] = v[q];
+                }
+              }
+            }
           }
           if (sum_wave) {
             if (head) {      // db_head[o] += sum_rows g[row][o]
@@ -767,45 +873,22 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
               for (int i = 0; i < 8; ++i) s += gx[(part * 8 + i) * SFN + o];
               s += __shfl_xor(s, 8); s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
               if (lane < 8 && lane < dout) accS[ACC_DBH + lane] += s;
-            } else {         // db_u[c] += sum_rows g[row][c];  folded conv 0 also dbf_m[c] += sum_rows (A^m deg)[row] g[row][c]
-              const float s = colsum32(Z, SZLD, lane, nullptr, 0, csum + 3 * (4 * SH));
+            } else {         // db_u[c] += sum_rows g[row][c]
+              const float s = colsum32(Z0, SXLD, lane, nullptr, 0, csum + 3 * (4 * SH));
               if (lane < 32) accS[u * SH + lane] += s;
             }
           }
         }
-        // the gate's dropout multipliers depend on (row, column, unit) only: issued here, they fill the MFMA waits
-        f32x4 mult = {1.f, 1.f, 1.f, 1.f};
-        if (u > 0 && p.drop_state) mult = dropout_mult4(dseed, doff, (uint32_t)(b * p.drop_stride + u), (uint32_t)(ts + prow), (uint32_t)(pcq >> 2), p.drop_thr, p.drop_scale);
-        SSTAMP(1, st_on);          // 4 + 5 i: this wave's MFMA-phase work done
+        SSTAMP(1, st_on);          // 4 + 5 i: this wave's work of the phase done
         wg_barrier();
         SSTAMP(1, st_on);          // 5 + 5 i
-        // ---- gate: gradient w.r.t. the pre-activation output of the unit below (u > 0); u == 0: dS, no gate
-        {
-          f32x4 v = *reinterpret_cast<const f32x4*>(stg + prow * SXLD + pcq);
-          if (!head) v += *reinterpret_cast<const f32x4*>(stg2 + prow * SXLD + pcq);
-          if (u > 0) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(Acur + prow * SXLD + pcq);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = a[q] > 0.f ? v[q] * mult[q] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { const int f = tid + 512 * i; if (f < 6 * 3 * 64) wfrag[f] = wpf[i]; }
-            *reinterpret_cast<f32x4*>(Abuf[(u - 1) & 1] + prow * SXLD + pcq) = apf;
-            float* at = ATbuf[(u - 1) & 1] + pcq * STLD + prow;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) at[q * STLD] = apf[q];
-          }
-          if (prow >= R) v = f32x4{0.f, 0.f, 0.f, 0.f};
-          *reinterpret_cast<f32x4*>(Z + prow * SZLD + pcq) = v;
-          if (u > 0) {
-            float* zt = ZT + pcq * STLD + prow;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) zt[q * STLD] = v[q];
-          }
-        }
-        SSTAMP(1, st_on);          // 6 + 5 i: gate done
-        wg_barrier();
+        SSTAMP(1, st_on);          // 6 + 5 i  (the separate gate phase is gone; the stamp layout of tools/sstamps.py is kept)
         SSTAMP(1, st_on);          // 7 + 5 i
       }
+      // the gradient w.r.t. the aggregated edge hidden (unit 0's output) sits in the Z_0 buffer of parity 1
+      const float* dS = Z0buf(1);
+      float* U0 = Z12;             // [64][SZ2]: columns 0..31 (free since the last unit's phase)
+      float* U1 = Z12 + SH;
 
       // ---- edge MLP backward: dS = Z[:, 0:32]
       {
@@ -824,7 +907,7 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
         for (int t = 0; t < n_et; ++t) {      // by target: dW1, db1, U0
           const int r = stream + 16 * t;
           const f32x4 ta = *reinterpret_cast<const f32x4*>(x8 + r * SFN), tb = *reinterpret_cast<const f32x4*>(x8 + r * SFN + 4);
-          const float gS = Z[r * SZLD + c32];
+          const float gS = dS[r * SXLD + c32];
           float u0 = 0.f;
           for (int k = 0; k < D; ++k) {
             const int o = other[k * STM + r];
@@ -842,7 +925,7 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
             }
             dw[20] = fmaf(dz, e1[0], dw[20]); dw[21] = fmaf(dz, e1[1], dw[21]);
           }
-          stg[r * SXLD + c32] = u0;
+          U0[r * SZ2 + c32] = u0;
         }
         if (need_dx) {
 #pragma unroll 1
@@ -855,9 +938,9 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
               if (o < 0) continue;
               const f32x4 ta = *reinterpret_cast<const f32x4*>(x8 + o * SFN), tb = *reinterpret_cast<const f32x4*>(x8 + o * SFN + 4);
               const f32x4 e0 = *reinterpret_cast<const f32x4*>(eaT + (k * STM + r) * 8), e1 = *reinterpret_cast<const f32x4*>(eaT + (k * STM + r) * 8 + 4);
-              u1 += edge_z(w, bb, ta, tb, sa, sb, e0, e1) > 0.f ? Z[o * SZLD + c32] : 0.f;
+              u1 += edge_z(w, bb, ta, tb, sa, sb, e0, e1) > 0.f ? dS[o * SXLD + c32] : 0.f;
             }
-            stg2[r * SXLD + c32] = u1;
+            U1[r * SZ2 + c32] = u1;
           }
         }
         // the streams' shares of dW1 / db1: the two halves of a wave meet by shuffle, the eight waves through scratch
@@ -866,7 +949,7 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
         for (int q = 0; q < SFC; ++q) dw[q] += __shfl_xor(dw[q], 32);
         db1 += __shfl_xor(db1, 32);
         if (half == 0) {
-          float* red = ZT + (wave * SH + c32) * SW1LD;      // [8 waves][32][24] = 6144 floats <= ZT
+          float* red = ZT12 + (wave * SH + c32) * SW1LD;    // [8 waves][32][24] = 6144 floats <= ZT12 | ZT0a | ZT0b (8704, contiguous)
 #pragma unroll
           for (int q = 0; q < SFC; ++q) red[q] = dw[q];
           red[SFC] = db1;
@@ -879,20 +962,21 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
         if (q > SFC) continue;
         float s = 0.f;
 #pragma unroll
-        for (int st = 0; st < 8; ++st) s += ZT[st * (SH * SW1LD) + idx];
+        for (int st = 0; st < 8; ++st) s += ZT12[st * (SH * SW1LD) + idx];
         accS[ACC_W1 + idx] += s;
       }
       if (need_dx) {      // dx[row][c] = U0[row] . W1[:, c] + U1[row] . W1[:, 8 + c] (+ residual): four partial sums, fixed order
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j4 = 0; j4 < SH / 4; ++j4) {
-          const f32x4 u0 = *reinterpret_cast<const f32x4*>(stg + prow * SXLD + 4 * j4), u1 = *reinterpret_cast<const f32x4*>(stg2 + prow * SXLD + 4 * j4);
+          const f32x4 u0 = *reinterpret_cast<const f32x4*>(U0 + prow * SZ2 + 4 * j4), u1 = *reinterpret_cast<const f32x4*>(U1 + prow * SZ2 + 4 * j4);
           const f32x4 wa = *reinterpret_cast<const f32x4*>(w1T + ho * SXLD + 4 * j4), wb = *reinterpret_cast<const f32x4*>(w1T + (SFN + ho) * SXLD + 4 * j4);
           s4 += u0 * wa;
           s4 += u1 * wb;
         }
         const float s = (skip ? gx[prow * SFN + ho] : 0.f) + ((s4[0] + s4[1]) + (s4[2] + s4[3]));
-        if (prow < R) {
+        if (b > 0 && one_tile) gx[prow * SFN + ho] = prow < R ? s : 0.f;      // (read above by this very thread only)
+        else if (prow < R) {
           if (b > 0) p.dxbuf[(int64_t)(ts + prow) * SFN + ho] = s;
           else p.dx_out[(int64_t)(ts + prow) * SFN + ho] = s;
         }
@@ -933,14 +1017,17 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
       if (t2 < SNM * SH) sl[FL_W2 + t2] = accS[ACC_DBF + t2];      // dbf_m travels in the W2 section (the reduce kernel knows)
       if (t2 < dout) sl[fl_head(n_hh) + SNM * dout * SH + t2] = accS[ACC_DBH + t2];
     }
-    // the block below reads the dx rows this workgroup has just written (global memory): make them visible
-    __threadfence();
+    // The block below reads the dx rows written above through global memory -- but always THIS workgroup's own rows (a workgroup
+    // walks the same tiles in every block), so a workgroup-scope hand-off is enough: the waves of a workgroup share their CU's L1.
+    // (The device-scope __threadfence() that stood here is an L2 write-back per block on MI355X: 350 us of a 1.44 ms step at
+    //  B = 4096.)  The stores are complete in L2 after __syncthreads()'s vmcnt(0); the loads of the next block's staging are
+    //  device-scope relaxed atomic loads, served by that L2, so nothing depends on what the CU's L1 holds.
     __syncthreads();
   }
 }
 
 static size_t stack_bwd_lds(int D, int DT) {
-  const size_t f = (size_t)STM * SZLD + 4 * STM * SXLD + 3 * SH * STLD + 2 * SH * STLD + 2 * STM * SFN + STM * 4 + SH * SW1LD + 16 * SXLD +
+  const size_t f = (size_t)STM * SZ2 + 4 * STM * SXLD + 4 * SH * STLD + 2 * SH * STLD + 2 * STM * SFN + STM * 4 + SH * SW1LD + 16 * SXLD +
                    (S_MAX_HH * SH + SNM * SH + 8 + SH * SW1LD + 4 * 4 * SH) + (size_t)(D + DT) * STM * 8;
   return f * 4 + (size_t)6 * 3 * 64 * 16 + (size_t)DT * STM * 8 + (size_t)(D + DT) * STM * 4;
 }

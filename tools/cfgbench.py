@@ -27,7 +27,7 @@ for name, grids, B, cls, args in CFG:
         out = model(x[:, :8], ei, ea[:, :6])
         loss = pkg.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2],
                                 edge_std=st[3], edge_index=ei, reg_coefs=REG, num_samples=None, node_param=x[:, 8:], edge_param=ea[:, 6:])
-        loss.backward(); return loss
+        loss.backward(pkg.data.unit_grad(loss)); return loss
     # ---- hipGraph replay of the whole step, captured first (fresh autograd state, side stream)
     dtg = float("nan"); n = 30
     if os.environ.get("CFG_GRAPH", "1") == "1":
@@ -83,7 +83,7 @@ if not sel or any("C5" in s_ for s_ in sel):
         loss = pkg.gsp_wls_edge(input=bt.x[:, :8], edge_input=bt.edge_attr[:, :6], output=out, x_mean=st[0], x_std=st[1],
                                 edge_mean=st[2], edge_std=st[3], edge_index=bt.edge_index, reg_coefs=REG, num_samples=None,
                                 node_param=bt.x[:, 8:], edge_param=bt.edge_attr[:, 6:])
-        loss.backward(); return loss
+        loss.backward(pkg.data.unit_grad(loss)); return loss
     bt0 = fresh()
     for _ in range(5): step(bt0)
     n = 20

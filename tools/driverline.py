@@ -22,7 +22,7 @@ for B in (64, 4096):
             out = model(x[:, :8], ei, ea[:, :6])
             loss = pkg.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2],
                                     edge_std=st[3], edge_index=ei, reg_coefs=REG, num_samples=None, node_param=x[:, 8:], edge_param=ea[:, 6:])
-            loss.backward()
+            loss.backward(pkg.data.unit_grad(loss))
             return loss
 
         opt_c = pkg.FusedAdamax(model.parameters(), lr=3e-3, capturable=True)

@@ -25,7 +25,7 @@ def run(B):
         out = model(x[:, :8], ei, ea[:, :6])
         loss = pkg.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2],
                                 edge_std=st[3], edge_index=ei, reg_coefs=REG, num_samples=None, node_param=x[:, 8:], edge_param=ea[:, 6:])
-        loss.backward()
+        loss.backward(pkg.data.unit_grad(loss))
         opt.step()
         return loss
     g = pkg.graphs.GraphedStep(train_step)
