@@ -39,6 +39,13 @@ class GemmPropArgs(C.Structure):
                 ("b_format", C.c_int32)]
 
 
+class ChainHead(C.Structure):
+    _fields_ = [("W", C.c_void_p * 4), ("bias", C.c_void_p), ("add_src", C.c_void_p), ("Y", C.c_void_p),
+                ("G", C.c_void_p), ("gate", C.c_void_p), ("Xout", C.c_void_p),
+                ("ld_add", C.c_int64), ("ldy", C.c_int64), ("ldg", C.c_int64), ("ld_gate", C.c_int64), ("ldxo", C.c_int64),
+                ("nout", C.c_int32), ("mode", C.c_int32), ("drop_id", C.c_int32), ("pad", C.c_int32)]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [("G", C.c_void_p), ("ldg", C.c_int64), ("hout", C.c_int32),
                 ("X", C.c_void_p), ("ldx", C.c_int64), ("hin", C.c_int32),
@@ -183,6 +190,8 @@ _SIGNATURES = {
                                      C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dss2_gemm_prop": (C.c_int, [C.POINTER(GemmPropArgs), C.c_void_p]),
     "dss2_gemm_prop_chain": (C.c_int, [C.POINTER(GemmPropArgs), C.c_void_p, C.c_int, C.c_void_p]),
+    "dss2_gemm_prop_chain_head": (C.c_int, [C.POINTER(GemmPropArgs), C.c_void_p, C.c_int, C.POINTER(ChainHead), C.c_void_p]),
+    "dss2_gemm_prop_chain_head_supported": (C.c_int, [C.c_int] * 6),
     "dss2_gemm_prop_chain_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_gemm_prop_chain16_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_gemm_prop16_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -31,7 +31,40 @@ extern "C" int dss2_gemm_prop_chain16_supported(int nrb, int nmat, int kreal, in
   return chain_lds_bytes(nrb, (kreal + 15) / 16 * 16, ncg, ell_width, chain_rm(nrb, rsplit, true, nmat) ? nmat : 0) <= (size_t)kMaxLdsBytes ? 1 : 0;
 }
 
+static int chain_impl(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, const dss2_chain_head* head, void* stream);
+
 extern "C" int dss2_gemm_prop_chain(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, void* stream) {
+  return chain_impl(ap, layers, n_layers, nullptr, stream);
+}
+
+extern "C" int dss2_gemm_prop_chain_head_supported(int nrb, int nmat, int kreal, int hout, int ell_width, int nout) {
+  using namespace dss2;
+  if (nout < 1 || nout > 4 || !dss2_gemm_prop_chain16_supported(nrb, nmat, kreal, hout, ell_width)) return 0;
+  dss2_gemm_prop_args a = {};
+  a.b_format = 1; a.nrb = nrb; a.nmat = nmat; a.kreal = kreal; a.kpad = (kreal + 15) / 16 * 16; a.hout = hout; a.ncg = (hout + 31) / 32; a.ell_width = ell_width;
+  return (chain_row_split(nrb, a.ncg) == 1 && chain_sp_supported(a)) ? 1 : 0;
+}
+
+extern "C" int dss2_gemm_prop_chain_head(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers,
+                                         const dss2_chain_head* head, void* stream) {
+  using namespace dss2;
+  if (!head || (head->mode != 1 && head->mode != 2)) { set_error("gemm_prop_chain_head: head.mode must be 1 or 2"); return 2; }
+  if (!dss2_gemm_prop_chain_head_supported(ap->nrb, ap->nmat, ap->kreal, ap->hout, ap->ell_width, head->nout) || ap->b_format != 1) {
+    set_error("gemm_prop_chain_head: unsupported shape (nrb=%d nmat=%d hid=%d nout=%d b_format=%d)", ap->nrb, ap->nmat, ap->hout, head->nout, ap->b_format);
+    return 2;
+  }
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  for (int m = 0; m < ap->nmat; ++m)
+    if (!head->W[m] || !al16(head->W[m])) { set_error("gemm_prop_chain_head: W[%d] missing or misaligned", m); return 2; }
+  if (head->mode == 1 && !head->Y) { set_error("gemm_prop_chain_head: forward head needs Y"); return 2; }
+  if (head->mode == 2 && (!head->G || !head->Xout || !al16(head->Xout) || !al16(head->gate) || (head->ldxo & 3) || (head->ld_gate & 3))) {
+    set_error("gemm_prop_chain_head: backward head needs G, a 16-byte aligned Xout (and gate)"); return 2;
+  }
+  if (head->drop_id && !ap->drop_state) { set_error("gemm_prop_chain_head: drop_id without drop_state"); return 2; }
+  return chain_impl(ap, layers, n_layers, head, stream);
+}
+
+static int chain_impl(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, const dss2_chain_head* head, void* stream) {
   using namespace dss2;
   const dss2_gemm_prop_args& a = *ap;
   if (n_layers < 1 || n_layers > CHAIN_MAX || !layers) { set_error("gemm_prop_chain: 1..%d layers, got %d", CHAIN_MAX, n_layers); return 2; }
@@ -43,7 +76,7 @@ extern "C" int dss2_gemm_prop_chain(const dss2_gemm_prop_args* ap, const dss2_ch
     return 2;
   }
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  if (!a.X || !al16(a.X) || (a.ldx & 3) || (a.ldy & 3) || (a.ld_relu & 3) || (a.ld_dmask & 3) || (a.ld_add & 3)) {
+  if (((!a.X || !al16(a.X)) && !(head && head->mode == 2)) || (a.ldx & 3) || (a.ldy & 3) || (a.ld_relu & 3) || (a.ld_dmask & 3) || (a.ld_add & 3)) {
     set_error("gemm_prop_chain: operands must be 16-byte aligned with leading dimensions divisible by 4"); return 2;
   }
   ChainTable ct = {};
@@ -66,7 +99,8 @@ extern "C" int dss2_gemm_prop_chain(const dss2_gemm_prop_args* ap, const dss2_ch
       set_error("gemm_prop_chain(bf16x6): unsupported shape (nrb=%d nmat=%d k=%d kpad=%d hout=%d)", a.nrb, a.nmat, a.kreal, a.kpad, a.hout);
       return 2;
     }
-    if (rsplit == 1 && chain_sp_supported(a)) return launch_chain_sp(a, ct, s);      // 64-row tiles, H >= 96: split-plane form
+    if (rsplit == 1 && chain_sp_supported(a)) return launch_chain_sp(a, ct, head, s);      // 64-row tiles, H >= 96: split-plane form
+    if (head) { set_error("gemm_prop_chain_head: the split-plane chain does not cover this shape"); return 2; }
     return launch_chain16(a, ct, rsplit, s);
   }
   if (a.b_format != 0) { set_error("gemm_prop_chain: unknown b_format %d", a.b_format); return 2; }

@@ -462,6 +462,6 @@ inline int launch_chain(const dss2_gemm_prop_args& a, const ChainTable& ct, hipS
 int launch_chain16(const dss2_gemm_prop_args& a, const ChainTable& ct, int rsplit, hipStream_t s);
 // 64-row tiles, one wave per column group: the tile kept in LDS as split bf16 planes (dss2_gemm_chain_sp.hip; DSS2_CHAIN_SP=0: off)
 bool chain_sp_supported(const dss2_gemm_prop_args& a);
-int launch_chain_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t s);
+int launch_chain_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head* head, hipStream_t s);
 
 }  // namespace dss2

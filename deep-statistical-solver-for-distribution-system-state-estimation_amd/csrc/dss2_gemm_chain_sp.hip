@@ -45,8 +45,15 @@ __device__ __forceinline__ void sp_store_split(__bf16* dst, const f32x4 v) {
   *reinterpret_cast<u32x2*>(dst + 2 * SP_PLANE) = u32x2{l0, l1};
 }
 
-template <int NMAT, int NW>
-__global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
+// HM (fused narrow head, dss2_gemm_prop_chain_head): 0 none; 1 forward -- after the last chained layer the tile is still in
+// the waves' registers: the head TAGConv (hid -> nout <= 4) is computed from them (per wave the partial products of its 32
+// columns, summed over the waves in LDS, two hops on nout-wide rows by wave 0) instead of a launch that re-reads [N, hid];
+// 2 backward -- the chain's input tile (the head's data gradient, gated by the head's input activation / dropout mask) is
+// computed in the staging from the nout-wide upstream gradient instead of being written and re-read by a launch of its own.
+constexpr int SP_HEAD_MAX = 4;      // nout
+
+template <int NMAT, int NW, int HM>
+__global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_gemm_prop_args p, const ChainTable ct, const dss2_chain_head hd) {
   constexpr int TM = SP_TM;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -63,17 +70,6 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
   const int R = p.tile_start[tile + 1] - ts;
   const int kq = p.kpad >> 2;
 
-  // ---- stage the first layer's input tile as split planes (zero padded to 64 x kpad) and the tile's ELL slice
-  for (int idx = tid; idx < TM * kq; idx += nthreads) {
-    const int r = idx / kq, c = (idx - r * kq) << 2;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
-    sp_store_split(xpl + (c >> 5) * (2 * SP_REGION) + r * SP_RS + (c & 31), v);
-  }
-  {
-    const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
-    for (int idx = tid; idx < D * TM; idx += nthreads) ell[idx] = src[idx];
-  }
   const int c32 = lane & 31, half = lane >> 5;
   const int cg = wave;
   const int nks = p.kpad >> 4;
@@ -83,6 +79,82 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
   const int cq = (lane & 7) * 4, r8 = lane >> 3;
   const int col0 = cg * 32 + cq;
   const bool col_ok = col0 < p.hout;
+
+  // ---- stage the tile's ELL slice and the first layer's input tile as split planes (zero padded to 64 x kpad)
+  {
+    const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
+    for (int idx = tid; idx < D * TM; idx += nthreads) ell[idx] = src[idx];
+  }
+  if constexpr (HM != 2) {
+    for (int idx = tid; idx < TM * kq; idx += nthreads) {
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
+      sp_store_split(xpl + (c >> 5) * (2 * SP_REGION) + r * SP_RS + (c & 31), v);
+    }
+  } else {
+    // X[row][c] = gate(row, c) * sum_{m, o} ((P^T)^m G)[row][o] W_m[o][c]: every wave builds its own 32-column stripe.
+    // Gate source rows (the head's input activation) requested first; the hops of G are nout wide and run once per WAVE
+    // (lane = row, wave-private scratch in the wave's own region, which the planes below overwrite at the very end).
+    const int nout = hd.nout;
+    f32x4 ga[8];
+    if (hd.gate && col_ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int row = r8 + 8 * i; ga[i] = *reinterpret_cast<const f32x4*>(hd.gate + (size_t)(ts + (row < R ? row : 0)) * hd.ld_gate + col0); }
+    }
+    f32x4 wl[NMAT][SP_HEAD_MAX];      // W_m[o][col0 .. col0 + 3]
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+      for (int o = 0; o < SP_HEAD_MAX; ++o)
+        wl[m][o] = (o < nout && col_ok) ? *reinterpret_cast<const f32x4*>(hd.W[m] + (size_t)o * p.hout + col0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float* zt = slot0;                       // [64][NMAT * 4]: ((P^T)^m G)[row][o]
+    float* hs = slot0 + TM * NMAT * 4;       // [64][4] hop scratch
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (lane < R) {
+#pragma unroll
+      for (int o = 0; o < SP_HEAD_MAX; ++o) if (o < nout) z[o] = hd.G[(size_t)(ts + lane) * hd.ldg + o];
+    }
+    *reinterpret_cast<f32x4*>(zt + lane * (NMAT * 4)) = z;
+    sp_barrier();                            // the ELL slice is staged
+#pragma unroll
+    for (int m = 1; m < NMAT; ++m) {
+      *reinterpret_cast<f32x4*>(hs + lane * 4) = z;
+      wave_lds_sync();
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < D; ++k) {
+        const int2 en = ell[k * TM + lane];
+        t += *reinterpret_cast<const f32x4*>(hs + en.x * 4) * __int_as_float(en.y);
+      }
+      wave_lds_sync();
+      z = t;
+      *reinterpret_cast<f32x4*>(zt + lane * (NMAT * 4) + m * 4) = z;
+    }
+    wave_lds_sync();
+    f32x4 xv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = r8 + 8 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) {
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(zt + row * (NMAT * 4) + m * 4);
+#pragma unroll
+        for (int o = 0; o < SP_HEAD_MAX; ++o) v += wl[m][o] * zz[o];
+      }
+      if (hd.gate) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ga[i][q] > 0.f ? v[q] : 0.f;
+      }
+      if (hd.drop_id) v *= dropout_mult4(drop_seed, drop_off, (uint32_t)hd.drop_id, (uint32_t)(ts + row), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
+      if (row >= R || !col_ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      else *reinterpret_cast<f32x4*>(hd.Xout + (size_t)(ts + row) * hd.ldxo + col0) = v;      // (the weight gradients read it)
+      xv[i] = v;
+    }
+    wave_lds_sync();                         // every lane is done with zt: the planes go over it
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sp_store_split(own_planes + (r8 + 8 * i) * SP_RS + cq, xv[i]);
+  }
 
   bf16x8 b0[3][NMAT];
   auto load_b = [&](const bf16x8* __restrict__ bp16, bf16x8 (&b)[3][NMAT], int ks) {
@@ -280,6 +352,87 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
         sp_store_split(own_planes + row * SP_RS + cq, (row < R && col_ok) ? U[i] : f32x4{0.f, 0.f, 0.f, 0.f});
       }
     }
+    if constexpr (HM == 1) {
+      if (!keep) {
+        // ---- fused head: Y = bias + sum_m P^m (h W_m^T) (+ residual), h = this tile's last activations (U, zero outside the tile)
+        const int nout = hd.nout, nmo = NMAT * nout;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));      // (opaque: the per-lane addresses of this block are formed here, not hoisted -- and spilled -- across the layer loop)
+        float* rowbuf = slot0;                           // [64][36]: the wave's 32 columns, row-major
+        float* part = slot0 + TM * 36;                   // [64][17]: this wave's partial products (m, o)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = rowv + 8 * i;
+          *reinterpret_cast<f32x4*>(rowbuf + row * 36 + cq) = (row < R && col_ok) ? U[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        wave_lds_sync();
+        const int kmax = p.hout - cg * 32;               // (columns beyond hout hold zeros; their weights are not read)
+        // W_m[o][this wave's 32 columns] -> LDS [m nout + o][32] (coalesced loads; uniform scalar reads of global memory compile to
+        // one waited-for load per weight: 25 us per launch), then broadcast ds_read_b128
+        float* wls = part + TM * 17;
+        for (int idx = ln; idx < nmo * 32; idx += 64) {
+          const int mo = idx >> 5, k = idx & 31, m = mo / nout, o = mo - m * nout;
+          const float* wp = m == 0 ? hd.W[0] : (m == 1 ? hd.W[1] : (m == 2 ? hd.W[2] : hd.W[3]));
+          wls[idx] = k < kmax ? wp[(size_t)o * p.hout + cg * 32 + k] : 0.f;
+        }
+        f32x4 hr[8];                                     // lane = row: its 32 values
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hr[j] = *reinterpret_cast<const f32x4*>(rowbuf + ln * 36 + 4 * j);
+        wave_lds_sync();
+#pragma unroll 1
+        for (int mo = 0; mo < nmo; ++mo) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wls + mo * 32 + 4 * j);      // same address in every lane
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sacc = fmaf(hr[j][q], wv[q], sacc);
+          }
+          part[ln * 17 + mo] = sacc;
+        }
+        sp_barrier();
+        if (wave == 0) {
+          float g[NMAT][SP_HEAD_MAX];
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+            for (int o = 0; o < SP_HEAD_MAX; ++o) {
+              float t = 0.f;
+              if (o < nout)
+                for (int w = 0; w < ncg; ++w) t += smem[w * SP_REGION + TM * 36 + ln * 17 + m * nout + o];
+              g[m][o] = t;
+            }
+          float* hs = rowbuf;                            // [64][4] hop scratch (the row buffer is done)
+          f32x4 t = {g[NMAT - 1][0], g[NMAT - 1][1], g[NMAT - 1][2], g[NMAT - 1][3]};
+#pragma unroll
+          for (int m = NMAT - 2; m >= 0; --m) {
+            wave_lds_sync();
+            *reinterpret_cast<f32x4*>(hs + ln * 4) = t;
+            wave_lds_sync();
+            f32x4 a = {g[m][0], g[m][1], g[m][2], g[m][3]};
+            for (int k = 0; k < D; ++k) {
+              const int2 en = ell[k * TM + ln];
+              const f32x4 zz = *reinterpret_cast<const f32x4*>(hs + en.x * 4);
+              const float w = __int_as_float(en.y);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) a[q] = fmaf(w, zz[q], a[q]);
+            }
+            t = a;
+          }
+          if (ln < R) {
+#pragma unroll
+            for (int o = 0; o < SP_HEAD_MAX; ++o) {
+              if (o < nout) {
+                float v = t[o];
+                if (hd.bias) v += hd.bias[o];
+                if (hd.add_src) v += hd.add_src[(size_t)(ts + ln) * hd.ld_add + o];
+                hd.Y[(size_t)(ts + ln) * hd.ldy + o] = v;
+              }
+            }
+          }
+        }
+      }
+    }
     CSTAMP(2 + li * 6 + 3);      // epilogue done
     if (keep) sp_barrier();   // the next layer's planes are complete
     CSTAMP(2 + li * 6 + 4);
@@ -295,18 +448,27 @@ bool chain_sp_supported(const dss2_gemm_prop_args& a) {
          a.ncg >= 3 && a.ncg <= 8 && chain_sp_lds_bytes(a.ncg, a.ell_width) <= (size_t)kMaxLdsBytes;
 }
 
-template <int NMAT, int NW>
-static int launch_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t stream) {
+template <int NMAT, int NW, int HM>
+static int launch_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head& hd, hipStream_t stream) {
   static std::atomic<uint32_t> lds_done{0};
-  auto kern = gemm_chain_sp_kernel<NMAT, NW>;
+  auto kern = gemm_chain_sp_kernel<NMAT, NW, HM>;
   if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop_chain(split planes)")) return 1;
-  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg), chain_sp_lds_bytes(a.ncg, a.ell_width), stream, a, ct);
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg), chain_sp_lds_bytes(a.ncg, a.ell_width), stream, a, ct, hd);
   return check_launch("gemm_prop_chain(split planes)");
 }
 
-int launch_chain_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t s) {
-  if (a.nmat == 2) return a.ncg <= 4 ? launch_sp<2, 4>(a, ct, s) : launch_sp<2, 8>(a, ct, s);
-  return a.ncg <= 4 ? launch_sp<3, 4>(a, ct, s) : launch_sp<3, 8>(a, ct, s);      // (K = 3 would spill: chain_sp_supported says no)
+template <int HM>
+static int launch_sp_hm(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head& hd, hipStream_t s) {
+  if (a.nmat == 2) return a.ncg <= 4 ? launch_sp<2, 4, HM>(a, ct, hd, s) : launch_sp<2, 8, HM>(a, ct, hd, s);
+  return a.ncg <= 4 ? launch_sp<3, 4, HM>(a, ct, hd, s) : launch_sp<3, 8, HM>(a, ct, hd, s);      // (K = 3 would spill: chain_sp_supported says no)
+}
+
+int launch_chain_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head* head, hipStream_t s) {
+  dss2_chain_head hd = {};
+  if (head) hd = *head;
+  if (hd.mode == 1) return launch_sp_hm<1>(a, ct, hd, s);
+  if (hd.mode == 2) return launch_sp_hm<2>(a, ct, hd, s);
+  return launch_sp_hm<0>(a, ct, hd, s);
 }
 
 }  // namespace dss2

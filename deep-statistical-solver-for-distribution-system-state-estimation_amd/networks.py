@@ -127,6 +127,15 @@ def chain16_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> 
     return CHAIN_BF16 and tiles is not None and bool(_lib.lib().dss2_gemm_prop_chain16_supported(topo.nrb, nmat, hid, hid, ell))
 
 
+def chain_head_supported(topo: Topology, nmat: int, hid: int, nout: int, transposed: bool) -> bool:
+    """True when the narrow head TAGConv (hid -> nout) can ride inside the chained launch of the hid -> hid layers
+    (dss2_gemm_prop_chain_head: forward = the head after the last chained layer, transposed = the chain's input computed from
+    the head's upstream gradient); DSS2_CHAIN_HEAD=0 switches it off."""
+    ell, tiles = (topo.ellT, topo.ellT_tiles) if transposed else (topo.ell, topo.ell_tiles)
+    return bool(CHAIN_HEAD) and CHAIN_BF16 and tiles is not None and bool(
+        _lib.lib().dss2_gemm_prop_chain_head_supported(topo.nrb, nmat, hid, hid, ell, nout))
+
+
 def gemm16_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bool:
     """True when a single hid -> hid layer (dss2_gemm_prop) can take bf16x3 weights: the tall tiles (128 / 192 rows) that
     run matrix-sequentially with K-halved staging and therefore have no layer chain."""
@@ -134,11 +143,13 @@ def gemm16_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> b
     return CHAIN_BF16 and tiles is not None and bool(_lib.lib().dss2_gemm_prop16_supported(topo.nrb, nmat, hid, hid, nnz, ell))
 
 
-def gemm_prop_chain(topo: Topology, X: torch.Tensor, hid: int, nmat: int, layers: Sequence[dict], transposed: bool = False,
-                    pre_rowscale=None, drop=None, b_format: int = 0) -> None:
+def gemm_prop_chain(topo: Topology, X: Optional[torch.Tensor], hid: int, nmat: int, layers: Sequence[dict], transposed: bool = False,
+                    pre_rowscale=None, drop=None, b_format: int = 0, head: Optional[dict] = None) -> None:
     """layers: dicts with Bp, Y and optionally bias, relu, relu_src, dmask, prebias; every tensor is [N, hid]
     contiguous.  Layer i reads layer i-1's output from LDS; every Y is written once.  The library chains at most
     CHAIN_MAX layers per launch; deeper stacks run as consecutive launches (the next one reads the previous one's last Y)."""
+    if head is not None and len(layers) > CHAIN_MAX:
+        raise ValueError("gemm_prop_chain: a fused head needs the whole chain in one launch")
     if len(layers) > CHAIN_MAX:
         for c0 in range(0, len(layers), CHAIN_MAX):
             gemm_prop_chain(topo, X if c0 == 0 else layers[c0 - 1]["Y"], hid, nmat, layers[c0:c0 + CHAIN_MAX],
@@ -149,7 +160,9 @@ def gemm_prop_chain(topo: Topology, X: torch.Tensor, hid: int, nmat: int, layers
     if drop is not None:            # (snapshot, p); the layers name their masks with "drop_id"
         a.drop_state = drop[0].data_ptr()
         a.drop_thr, a.drop_scale = _dropout_params(drop[1])
-    a.X, a.ldx, a.kreal, a.kpad = X.data_ptr(), X.stride(0), hid, (_round16(hid) if b_format == 1 else _round8(hid))
+    dev_t = X if X is not None else layers[0]["Y"]
+    a.X, a.ldx = (X.data_ptr(), X.stride(0)) if X is not None else (0, hid)
+    a.kreal, a.kpad = hid, (_round16(hid) if b_format == 1 else _round8(hid))
     a.hout, a.ncg, a.ldy, a.ld_relu, a.ld_dmask, a.ld_add = hid, _ncg(hid), hid, hid, hid, hid
     a.nmat, a.nrb, a.ntiles = nmat, topo.nrb, topo.ntiles
     a.tile_start = topo.tile_start.data_ptr()
@@ -169,7 +182,33 @@ def gemm_prop_chain(topo: Topology, X: torch.Tensor, hid: int, nmat: int, layers
         d.relu_src, d.dmask, d.prebias = _ptr(ly.get("relu_src")), _ptr(ly.get("dmask")), _ptr(ly.get("prebias"))
         d.relu = int(bool(ly.get("relu", False)))
         d.drop_id = int(ly.get("drop_id", 0)) if drop is not None else 0
-    _lib.check(_lib.lib().dss2_gemm_prop_chain(C.byref(a), C.addressof(tab), len(layers), _stream(X)), "dss2_gemm_prop_chain")
+    if head is None:
+        _lib.check(_lib.lib().dss2_gemm_prop_chain(C.byref(a), C.addressof(tab), len(layers), _stream(dev_t)), "dss2_gemm_prop_chain")
+        return
+    # head: dict(W=[W_0..W_K] ([nout, hid] contiguous), nout, and forward: Y, bias, add_src / backward: G, gate, Xout, drop_id)
+    hd = _lib.ChainHead()
+    for m, w_ in enumerate(head["W"]):
+        if w_.stride(0) != hid or w_.stride(1) != 1:
+            raise ValueError("gemm_prop_chain: head weights [nout, hid] contiguous expected")
+        hd.W[m] = w_.data_ptr()
+    hd.nout = int(head["nout"])
+    if not transposed:
+        hd.mode = 1
+        y_ = head["Y"]
+        hd.Y, hd.ldy, hd.bias = y_.data_ptr(), y_.stride(0), _ptr(head.get("bias"))
+        add_ = head.get("add_src")
+        if add_ is not None:
+            hd.add_src, hd.ld_add = add_.data_ptr(), int(head["add_ld"])
+    else:
+        hd.mode = 2
+        g_, xo_ = head["G"], head["Xout"]
+        hd.G, hd.ldg, hd.Xout, hd.ldxo = g_.data_ptr(), g_.stride(0), xo_.data_ptr(), xo_.stride(0)
+        gate_ = head.get("gate")
+        if gate_ is not None:
+            hd.gate, hd.ld_gate = gate_.data_ptr(), gate_.stride(0)
+        hd.drop_id = int(head.get("drop_id", 0)) if drop is not None else 0
+    _lib.check(_lib.lib().dss2_gemm_prop_chain_head(C.byref(a), C.addressof(tab), len(layers), C.byref(hd), _stream(dev_t)),
+               "dss2_gemm_prop_chain_head")
 
 
 def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int, nmat: int, out_flat: torch.Tensor,
@@ -721,6 +760,7 @@ WGRAD_SIDE_STREAM = _os.environ.get("DSS2_WGRAD_STREAM", "0") == "1"   # opt-in:
 CHAIN_LAYERS = _os.environ.get("DSS2_CHAIN", "1") == "1"               # hid->hid layers of a block: one chained launch
 WGRAD_BF16 = _os.environ.get("DSS2_WGRAD_BF16", "1") == "1"            # weight gradients as bf16x6 where the kernel covers the shape
 CHAIN_BF16 = _os.environ.get("DSS2_CHAIN_BF16", "1") == "1"            # its tile GEMM as bf16x6 on the bf16 matrix pipe (fp32-accurate)
+CHAIN_HEAD = _os.environ.get("DSS2_CHAIN_HEAD", "1") == "1"            # the narrow head TAGConv (and its data gradient) inside the chained launches
 WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"
 STACK_NODE = _os.environ.get("DSS2_STACK_NODE", "1") == "1"              # PFN / SkipPFN as ONE autograd node (_PFNFn)
 DX_MERGE = _os.environ.get("DSS2_DX_MERGE", "1") == "1"                  # dx of the edge MLP as ONE K = 2 hid GEMM
@@ -1194,9 +1234,19 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
             layers.append(dict(Bp=(plan.fwd16[1 + l] if use16 else plan.fwd[1 + l]), Y=out_l, bias=conv_ps[l][0], relu=True,
                                drop_id=drop_id(l), prebias=(fold.bf if (fold is not None and l == 0) else None)))
             acts.append(out_l)
+        # the narrow last layer inside the same launch (the tile is still in the waves' registers): dss2_gemm_prop_chain_head
+        head_fused = (use16 and n_chain == L - 1 and n_chain <= CHAIN_MAX and not glob and is_narrow(nmat, mod.dim_out)
+                      and chain_head_supported(topo, nmat, hid, mod.dim_out, False))
+        head = None
+        if head_fused:
+            y_head = torch.empty(topo.N, mod.dim_out, dtype=_F32, device=dev)
+            head = dict(W=list(conv_ps[L - 1][1:1 + nmat]), nout=mod.dim_out, Y=y_head, bias=conv_ps[L - 1][0],
+                        add_src=(x if mod.skip else None), add_ld=ldx)
         gemm_prop_chain(topo, h, hid, nmat, layers, pre_rowscale=(topo.deg_pows if fold is not None else None),
-                        drop=((snap, p) if snap is not None else None), b_format=int(use16))
+                        drop=((snap, p) if snap is not None else None), b_format=int(use16), head=head)
         h = acts[-1]
+        if head_fused:
+            h, n_chain = y_head, L
     for l in range(n_chain, L):
         last = l == L - 1
         hout = mod.dim_out if last else hid
@@ -1256,20 +1306,34 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         if pending is None:
             pending = []
         l = L - 1
-        g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, mod.dim_out, flat[offs[2 + l]:offs[3 + l]],
-                              relu_src=acts[l], drop=drop_of(l - 1), pending=pending)
+        use16 = bool(plan.bwd16) and chain16_supported(topo, nmat, hid, True)
+        # the head's data gradient inside the chained launch (its input tile is computed from the dim_out-wide upstream gradient):
+        # dss2_gemm_prop_chain_head, mode 2; only the head's weight gradient keeps a launch of its own
+        head_fused = (use16 and L - 1 <= CHAIN_MAX and is_narrow(nmat, mod.dim_out)
+                      and chain_head_supported(topo, nmat, hid, mod.dim_out, True))
+        head = None
+        if head_fused:
+            _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, mod.dim_out, flat[offs[2 + l]:offs[3 + l]],
+                              need_dh=False, pending=pending)
+            g_in = torch.empty(topo.N, hid, dtype=_F32, device=dev)
+            dr = drop_of(l - 1)
+            head = dict(W=list(ps[4 + l * (nmat + 1) + 1:4 + (l + 1) * (nmat + 1)]), nout=mod.dim_out, G=g, gate=acts[l], Xout=g_in,
+                        drop_id=(dr[2] if dr is not None else 0))
+            g = g_in
+        else:
+            g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, mod.dim_out, flat[offs[2 + l]:offs[3 + l]],
+                                  relu_src=acts[l], drop=drop_of(l - 1), pending=pending)
         gl = [None] * (L - 1)                   # gl[l]: gradient w.r.t. layer l's pre-activation output
         gl[L - 2] = g
         layers = []
-        use16 = bool(plan.bwd16) and chain16_supported(topo, nmat, hid, True)
         for l in range(L - 2, -1, -1):
             out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
             layers.append(dict(Bp=(plan.bwd16[1 + l] if use16 else plan.bwd[1 + l]), Y=out_l, relu_src=(acts[l] if l > 0 else None),
                                drop_id=(base + l if (l > 0 and snap is not None) else 0)))      # mask of conv l-1: id (l-1)+1
             if l > 0:
                 gl[l - 1] = out_l
-        gemm_prop_chain(topo, g, hid, nmat, layers, transposed=True, drop=((snap, p_drop) if snap is not None else None),
-                        b_format=int(use16))
+        gemm_prop_chain(topo, (None if head_fused else g), hid, nmat, layers, transposed=True,
+                        drop=((snap, p_drop) if snap is not None else None), b_format=int(use16), head=head)
         d_in = layers[-1]["Y"]                  # gradient w.r.t. conv 0's input: dS (folded) or dx0
         # (joining conv 0 pays only when the tiles still divide evenly over the workgroups the layers share:
         #  at C2 three layers x 85 workgroups leave a 13-vs-12-tile tail that costs more than the launch saves)

@@ -257,6 +257,24 @@ typedef struct dss2_chain_layer {
   const float* prebias; float* Y; int32_t relu; int32_t drop_id;   /* drop_id: as in dss2_gemm_prop_args, per layer */
 } dss2_chain_layer;
 int dss2_gemm_prop_chain(const dss2_gemm_prop_args* args_host, const dss2_chain_layer* layers_host, int n_layers, void* stream);
+/* The chain with the narrow head TAGConv fused in (replaces a dss2_gemm_prop launch next to the chain that re-reads [N, hid];
+ * /root/reference/networks.py:266-275 -- the last TAGConv(dim_hid, dim_out) of MPN / SkipMPN and its data gradient).
+ * mode 1 (forward chain): after the last chained layer, Y[N][nout] = bias + sum_m P^m (h W_m^T) (+ add_src), h = that layer's
+ *   output (still written to its own Y for the backward).  mode 2 (transposed chain = data gradients): the chain's input tile is
+ *   X = (gate > 0) * dropout(drop_id) * sum_m (P^T)^m G W_m with G[N][nout] the gradient w.r.t. the head's output, gate the
+ *   head's input activation; X is also written to Xout (the weight-gradient kernels read it); args.X is ignored.
+ * W[m]: the head's weights [nout][hid] row-major, m < nmat.  nout <= 4.  Same tiles / ELL slices as the chain. */
+typedef struct dss2_chain_head {
+  const float* W[4];
+  const float* bias; const float* add_src; float* Y;      /* mode 1 */
+  const float* G; const float* gate; float* Xout;         /* mode 2 */
+  int64_t ld_add, ldy, ldg, ld_gate, ldxo;
+  int32_t nout, mode, drop_id, pad;
+} dss2_chain_head;
+int dss2_gemm_prop_chain_head(const dss2_gemm_prop_args* args_host, const dss2_chain_layer* layers_host, int n_layers,
+                              const dss2_chain_head* head_host, void* stream);
+/* != 0: dss2_gemm_prop_chain_head runs this shape (the split-plane chain: 64-row tiles, hid >= 96, bf16x6 weights) */
+int dss2_gemm_prop_chain_head_supported(int nrb, int nmat, int kreal, int hout, int ell_width, int nout);
 int dss2_gemm_prop_chain_supported(int nrb, int nmat, int kreal, int hout, int ell_width);
 /* != 0: the chain can also run with args.b_format = 1 -- weights packed as bf16x3 fragments, the tile GEMM as six
  * v_mfma_f32_32x32x16_bf16 per fp32 product term set (h/m/l splits of both operands, fp32 accumulation): fp32-accurate

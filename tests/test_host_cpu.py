@@ -32,9 +32,9 @@ def test_struct_layouts_match_the_header_sizes():
     import subprocess
     import tempfile
     pkg = load_pkg()
-    src = ('#include <stdio.h>\n#include "dss2_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(dss2_pack_desc), '
+    src = ('#include <stdio.h>\n#include "dss2_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(dss2_pack_desc), '
            'sizeof(dss2_gemm_prop_args), sizeof(dss2_wgrad_args), sizeof(dss2_wls_args), sizeof(dss2_csr_build_args), '
-           'sizeof(dss2_ell_build_args), sizeof(dss2_csr_axpy_args), sizeof(dss2_stack_dims), sizeof(dss2_stack_args));return 0;}\n')
+           'sizeof(dss2_ell_build_args), sizeof(dss2_csr_axpy_args), sizeof(dss2_stack_dims), sizeof(dss2_stack_args), sizeof(dss2_chain_head));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "p.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "p.c"), "-o", os.path.join(d, "p")])
@@ -42,7 +42,7 @@ def test_struct_layouts_match_the_header_sizes():
     L = pkg._lib
     assert sizes == [ctypes.sizeof(L.PackDesc), ctypes.sizeof(L.GemmPropArgs), ctypes.sizeof(L.WgradArgs), ctypes.sizeof(L.WlsArgs),
                      ctypes.sizeof(L.CsrBuildArgs), ctypes.sizeof(L.EllBuildArgs), ctypes.sizeof(L.CsrAxpyArgs), ctypes.sizeof(L.StackDims),
-                     ctypes.sizeof(L.StackArgs)]
+                     ctypes.sizeof(L.StackArgs), ctypes.sizeof(L.ChainHead)]
     assert pkg.networks._DESC_DTYPE.itemsize == sizes[0]
 
 
