@@ -302,6 +302,21 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
     // (one uniform branch per feature around a loop over the lane's rows, not the other way round)
     const bool keep = li + 1 < ct.n;
     if (keep) load_b(reinterpret_cast<const bf16x8*>(ct.l[li + 1].Bp), b0, 0);      // the next layer's first fragments ride under the epilogue
+    // fused head: its weights (this lane's share of the wave's [m nout + o][32] block), bias and residual row, requested under the epilogue
+    [[maybe_unused]] float hw_pre[3] = {0.f, 0.f, 0.f};      // (nout <= 2: all of them; wider heads fetch the rest in the head block)
+    if constexpr (HM == 1) {
+      if (!keep) {
+        const int nout = hd.nout, kmax = p.hout - cg * 32;
+        int lp = lane;
+        asm volatile("" : "+v"(lp));      // (opaque: the three addresses are formed here, not hoisted out of the layer loop and spilled)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int idx = lp + 64 * i, mo = idx >> 5, k = idx & 31, m = mo / nout, o = mo - m * nout;
+          const float* wp = m == 0 ? hd.W[0] : (m == 1 ? hd.W[1] : (m == 2 ? hd.W[2] : hd.W[3]));
+          if (mo < NMAT * nout && k < kmax) hw_pre[i] = wp[(size_t)o * p.hout + cg * 32 + k];
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) U[i] += bias4;
     if (col_ok) {
@@ -358,6 +373,16 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
         const int nout = hd.nout, nmo = NMAT * nout;
         int ln = lane;
         asm volatile("" : "+v"(ln));      // (opaque: the per-lane addresses of this block are formed here, not hoisted -- and spilled -- across the layer loop)
+        f32x4 hb_pre = {0.f, 0.f, 0.f, 0.f}, ha_pre = {0.f, 0.f, 0.f, 0.f};      // bias and residual row: requested now, used by wave 0 at the very end
+        if (wave == 0) {
+#pragma unroll
+          for (int o = 0; o < SP_HEAD_MAX; ++o) {
+            if (o < nout) {
+              if (hd.bias) hb_pre[o] = hd.bias[o];
+              if (hd.add_src && ln < R) ha_pre[o] = hd.add_src[(size_t)(ts + ln) * hd.ld_add + o];
+            }
+          }
+        }
         float* rowbuf = slot0;                           // [64][36]: the wave's 32 columns, row-major
         float* part = slot0 + TM * 36;                   // [64][17]: this wave's partial products (m, o)
 #pragma unroll
@@ -366,14 +391,16 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
           *reinterpret_cast<f32x4*>(rowbuf + row * 36 + cq) = (row < R && col_ok) ? U[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         wave_lds_sync();
-        const int kmax = p.hout - cg * 32;               // (columns beyond hout hold zeros; their weights are not read)
-        // W_m[o][this wave's 32 columns] -> LDS [m nout + o][32] (coalesced loads; uniform scalar reads of global memory compile to
-        // one waited-for load per weight: 25 us per launch), then broadcast ds_read_b128
+        // W_m[o][this wave's 32 columns] -> LDS [m nout + o][32] (requested under the epilogue; uniform scalar reads of global memory
+        // in the loop below compile to one waited-for load per weight: 25 us per launch), then broadcast ds_read_b128
         float* wls = part + TM * 17;
-        for (int idx = ln; idx < nmo * 32; idx += 64) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          if (ln + 64 * i < nmo * 32) wls[ln + 64 * i] = hw_pre[i];
+        for (int idx = ln + 192; idx < nmo * 32; idx += 64) {
           const int mo = idx >> 5, k = idx & 31, m = mo / nout, o = mo - m * nout;
           const float* wp = m == 0 ? hd.W[0] : (m == 1 ? hd.W[1] : (m == 2 ? hd.W[2] : hd.W[3]));
-          wls[idx] = k < kmax ? wp[(size_t)o * p.hout + cg * 32 + k] : 0.f;
+          wls[idx] = k < p.hout - cg * 32 ? wp[(size_t)o * p.hout + cg * 32 + k] : 0.f;
         }
         f32x4 hr[8];                                     // lane = row: its 32 values
 #pragma unroll
@@ -423,10 +450,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
 #pragma unroll
             for (int o = 0; o < SP_HEAD_MAX; ++o) {
               if (o < nout) {
-                float v = t[o];
-                if (hd.bias) v += hd.bias[o];
-                if (hd.add_src) v += hd.add_src[(size_t)(ts + ln) * hd.ld_add + o];
-                hd.Y[(size_t)(ts + ln) * hd.ldy + o] = v;
+                hd.Y[(size_t)(ts + ln) * hd.ldy + o] = t[o] + hb_pre[o] + ha_pre[o];
               }
             }
           }
