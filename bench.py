@@ -262,6 +262,13 @@ def main():
         bf16x6 = bool(chained and pkg.networks.CHAIN_BF16 and pkg.networks.chain16_supported(
             pkg.topology.get_topology(ei, N), KHOPS + 1, HID, False))
         kname = ("gemm_chain_kernel<2,3,4,1,true>" if bf16x6 else "gemm_chain_kernel<2,3>") if chained else "gemm_prop_kernel<2,3,false>"
+        topo_ = pkg.topology.get_topology(ei, N)
+        if bf16x6 and os.environ.get("DSS2_CHAIN_SP", "1") != "0" and pkg._lib.lib().dss2_gemm_prop_chain_head_supported(
+                topo_.nrb, KHOPS + 1, HID, HID, topo_.ell, 2):
+            # 64-row tiles, one wave per column group: the split-plane form (csrc/dss2_gemm_chain_sp.hip); with DSS2_CHAIN_HEAD=1 the
+            # narrow head rides in the same launches (forward: <3,4,1>, data gradients: <3,4,2>) -- its time is inside the launch
+            # durations below, its FLOPs (0.1 GFLOP) are not in `achieved`
+            kname = "gemm_chain_sp_kernel<3,4>"
         traffic, traffic_source = None, None
         try:   # HBM bytes per launch from the committed PMC runs (FETCH_SIZE x2 on gfx950 + WRITE_SIZE): a pointer to
                # the rocprofv3 --pmc evidence under profiles/, NOT a counter read during this run

@@ -760,7 +760,10 @@ WGRAD_SIDE_STREAM = _os.environ.get("DSS2_WGRAD_STREAM", "0") == "1"   # opt-in:
 CHAIN_LAYERS = _os.environ.get("DSS2_CHAIN", "1") == "1"               # hid->hid layers of a block: one chained launch
 WGRAD_BF16 = _os.environ.get("DSS2_WGRAD_BF16", "1") == "1"            # weight gradients as bf16x6 where the kernel covers the shape
 CHAIN_BF16 = _os.environ.get("DSS2_CHAIN_BF16", "1") == "1"            # its tile GEMM as bf16x6 on the bf16 matrix pipe (fp32-accurate)
-CHAIN_HEAD = _os.environ.get("DSS2_CHAIN_HEAD", "1") == "1"            # the narrow head TAGConv (and its data gradient) inside the chained launches
+CHAIN_HEAD = _os.environ.get("DSS2_CHAIN_HEAD", "1") == "1"            # the narrow head TAGConv's data gradient inside the chained launch of the data gradients
+# ... and the head's forward inside the forward chain: measured break-even at C2 (chain + head 124.5 us against 110.7 + 14.1 us for the
+# two launches: the head's tail runs on one wave per workgroup), so it is off by default; tested under DSS2_CHAIN_HEAD_FWD=1
+CHAIN_HEAD_FWD = _os.environ.get("DSS2_CHAIN_HEAD_FWD", "0") == "1"
 WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"
 STACK_NODE = _os.environ.get("DSS2_STACK_NODE", "1") == "1"              # PFN / SkipPFN as ONE autograd node (_PFNFn)
 DX_MERGE = _os.environ.get("DSS2_DX_MERGE", "1") == "1"                  # dx of the edge MLP as ONE K = 2 hid GEMM
@@ -1235,7 +1238,7 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
                                drop_id=drop_id(l), prebias=(fold.bf if (fold is not None and l == 0) else None)))
             acts.append(out_l)
         # the narrow last layer inside the same launch (the tile is still in the waves' registers): dss2_gemm_prop_chain_head
-        head_fused = (use16 and n_chain == L - 1 and n_chain <= CHAIN_MAX and not glob and is_narrow(nmat, mod.dim_out)
+        head_fused = (CHAIN_HEAD_FWD and use16 and n_chain == L - 1 and n_chain <= CHAIN_MAX and not glob and is_narrow(nmat, mod.dim_out)
                       and chain_head_supported(topo, nmat, hid, mod.dim_out, False))
         head = None
         if head_fused:

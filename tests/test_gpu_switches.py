@@ -16,6 +16,10 @@ FALLBACKS = {
     # one weight-gradient launch per layer, un-folded second edge-MLP layer
     "unfused": dict(DSS2_STACK_NODE="0", DSS2_DX_MERGE="0", DSS2_WGRAD_KSPLIT="0", DSS2_CHAIN="0", DSS2_WGRAD_BATCH="0",
                     DSS2_FOLD_W2="0"),
+    # round-3 chain variants: the fp32-tile form of the bf16x6 chain instead of the split-plane form, the narrow head's data
+    # gradient as its own launch; and the head's FORWARD inside the chained launch (off by default)
+    "chain-variants-a": dict(DSS2_CHAIN_SP="0", DSS2_CHAIN_HEAD="0"),
+    "chain-variants-b": dict(DSS2_CHAIN_HEAD_FWD="1"),
     # the generic narrow kernels, scalar-VALU edge MLP, edges through the global CSR instead of tile-local lists
     "generic-narrow-edge": dict(DSS2_NARROW_STREAM="0", DSS2_EDGE_MFMA="0", DSS2_EDGE_TILE="0"),
 }

@@ -57,6 +57,11 @@ if [ -f $P/libdss2_sstamps.so ]; then
   DSS2_LIB=$P/libdss2_sstamps.so python3 tools/sstamps.py 64 2>&1 | grep -v amdgpu > $O/stack_stamps_B64.txt
   DSS2_LIB=$P/libdss2_sstamps.so python3 tools/sstamps.py 4096 2>&1 | grep -v amdgpu > $O/stack_stamps_B4096.txt
 fi
+# phase stamps of the split-plane layer chain (needs <pkg>/libdss2_cstamps.so, see tools/cstamps.py)
+if [ -f $P/libdss2_cstamps.so ]; then
+  DSS2_LIB=$P/libdss2_cstamps.so python3 tools/cstamps.py 1024 2>&1 | grep -v amdgpu > $O/chain_stamps_B1024.txt
+  DSS2_LIB=$P/libdss2_cstamps.so python3 tools/cstamps.py 4096 2>&1 | grep -v amdgpu > $O/chain_stamps_B4096.txt
+fi
 # the packed-fp32 reproducer (tools/micro/pkfma_beside_mfma.hip) and the 200-launch stress of the real kernel
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/pkfma_beside_mfma.hip -o /tmp/pkfma 2>/dev/null && /tmp/pkfma > $O/pkfma_micro.txt 2>&1
 python3 tools/pk_stress.py 200 2>&1 | grep -v amdgpu > $O/pk_stress_shipped.txt
