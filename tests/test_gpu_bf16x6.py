@@ -94,6 +94,10 @@ def test_shapes_outside_the_bf16x6_weight_gradient_fall_back(pkg):
     (["ober_sub"], 64, 128, 3, 3),               # 96-row tiles, one wave per SIMD
     (["cigre14"], 300, 256, 3, 2),               # H = 256: eight waves
     (["cigre14"], 200, 100, 3, 3),               # H = 100: k padded to 112
+    (["cigre14"], 300, 96, 3, 2),                # split-plane form, three column groups
+    (["cigre14"], 300, 128, 2, 3),               # split-plane form, K = 1
+    (["cigre14", "cigre14_reswitched"], 190, 160, 2, 2),   # split-plane form, five column groups (eight-wave instantiation), K = 1
+    (["cigre14"], 130, 72, 3, 2),                # 72 of 96 columns: the last stripe half empty (k padded to 80)
 ])
 def test_layer_chain_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat, nl):
     """Forward form with bias / ReLU / folded bias (prebias + row scales) in the first layer, backward form with ReLU gates:
@@ -263,3 +267,31 @@ def test_non_finite_inputs_stay_non_finite(pkg):
         assert not torch.isfinite(o16[:15]).all() and not torch.isfinite(o32[:15]).all()      # the graph of node 7
         assert torch.isfinite(o16[60:]).all() and torch.equal(o16[60:], clean[60:])           # other tiles: untouched
         assert (torch.isfinite(o16) <= torch.isfinite(o32)).all()                             # never finite where fp32 is not
+
+
+@pytest.mark.parametrize("H,nmat", [(128, 3), (96, 2), (256, 3)])
+def test_split_plane_chain_general_epilogue(pkg, H, nmat):
+    """The split-plane chain's general epilogue (mask tensor, residual, in-kernel dropout, folded bias) against the fp32 MFMA chain:
+    same Philox masks (same snapshot and ids), so the two forms agree to rounding."""
+    nw = pkg.networks
+    topo, N = _topo(pkg, ["cigre14"], 333)
+    torch.manual_seed(5)
+    Ws = [torch.randn(H, H, device=DEV) * (1.5 / H ** 0.5) for _ in range(nmat)]
+    plan = nw._PackPlan([Ws], DEV, bf16_groups=(0,))
+    plan.refresh()
+    h = torch.randn(N, H, device=DEV)
+    bias, pbias, prs = torch.randn(H, device=DEV), torch.randn(nmat, H, device=DEV), torch.rand(N, 4, device=DEV)
+    dmask = (torch.rand(N, H, device=DEV) > 0.4).float() * 1.6
+    snap = torch.tensor([1234567, 3], dtype=torch.int64, device=DEV)
+
+    def run(fmt):
+        outs = [torch.empty(N, H, device=DEV) for _ in range(3)]
+        layers = [dict(Bp=(plan.fwd16[0] if fmt else plan.fwd[0]), Y=outs[0], bias=bias, relu=True, prebias=pbias, drop_id=1),
+                  dict(Bp=(plan.fwd16[0] if fmt else plan.fwd[0]), Y=outs[1], bias=bias, relu=True, dmask=dmask, drop_id=2),
+                  dict(Bp=(plan.fwd16[0] if fmt else plan.fwd[0]), Y=outs[2], relu=False, drop_id=0)]
+        nw.gemm_prop_chain(topo, h, H, nmat, layers, pre_rowscale=prs, drop=(snap, 0.3), b_format=fmt)
+        return outs
+    ref, a, b_ = run(0), run(1), run(1)
+    for r, x, y in zip(ref, a, b_):
+        assert torch.equal(x, y)
+        assert rel_err(x, r) < 3e-6

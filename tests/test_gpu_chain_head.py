@@ -1,0 +1,86 @@
+"""GPU: the narrow head TAGConv fused into the chained launches (dss2_gemm_prop_chain_head, csrc/dss2_gemm_chain_sp.hip;
+/root/reference/networks.py:266-275: the last TAGConv(dim_hid, dim_out) of MPN / SkipMPN) against the same model with the head as
+launches of its own -- forward fusion (DSS2_CHAIN_HEAD_FWD, off by default), backward fusion (DSS2_CHAIN_HEAD, on by default) --
+and against the fp64 oracle."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(pkg, model, b, fwd, bwd, seed):
+    nw = pkg.networks
+    saved = nw.CHAIN_HEAD_FWD, nw.CHAIN_HEAD
+    nw.CHAIN_HEAD_FWD, nw.CHAIN_HEAD = fwd, bwd
+    try:
+        for p in model.parameters():
+            p.grad = None
+        torch.manual_seed(seed)          # (the dropout snapshot is drawn from torch's generator)
+        x = b["x"][:, :8].to(DEV).requires_grad_(True)
+        out = model(x, b["edge_index"].to(DEV), b["edge_attr"][:, :6].to(DEV))
+        w = torch.linspace(-1.0, 1.0, out.numel(), device=DEV).view_as(out)
+        (out * w).sum().backward()
+        return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in model.parameters()]
+    finally:
+        nw.CHAIN_HEAD_FWD, nw.CHAIN_HEAD = saved
+
+
+@pytest.mark.parametrize("cls,args,B", [
+    ("MPN", (8, 6, 2, 128, 4, 2, 0.0), 300),          # the C2 model
+    ("MPN", (8, 6, 3, 128, 4, 2, 0.3), 257),          # dim_out 3, dropout mask on the head's input, odd tile count
+    ("MPN", (8, 6, 4, 96, 3, 1, 0.3), 200),           # K = 1, dim_out 4, three column groups
+    ("MPN", (8, 6, 2, 256, 5, 2, 0.0), 70),           # eight-wave instantiation
+])
+def test_fused_head_equals_separate_launches(pkg, cls, args, B):
+    b = pkg.synthetic.make_batch(["cigre14"], B, seed=4)
+    torch.manual_seed(0)
+    model = getattr(pkg, cls)(*args).to(DEV)
+    topo = pkg.topology.get_topology(b["edge_index"].to(DEV), b["x"].shape[0])
+    nw = pkg.networks
+    assert nw.chain_head_supported(topo, args[5] + 1, args[3], args[2], False) and nw.chain_head_supported(topo, args[5] + 1, args[3], args[2], True)
+    ref = _run(pkg, model, b, False, False, 7)
+    for fwd, bwd in ((True, False), (False, True), (True, True)):
+        got = _run(pkg, model, b, fwd, bwd, 7)
+        again = _run(pkg, model, b, fwd, bwd, 7)
+        assert torch.equal(got[0], again[0]) and torch.equal(got[1], again[1])
+        assert rel_err(got[0], ref[0]) < 2e-6 and rel_err(got[1], ref[1]) < 1e-5, (fwd, bwd)
+        for g, r, (n, _) in zip(got[2], ref[2], model.named_parameters()):
+            assert rel_err(g, r) < 1e-5, (fwd, bwd, n)
+
+
+def test_fused_head_against_the_oracle(pkg, oracle):
+    """MPN(H = 128, L = 4) with both fusions on against the fp64 oracle, gates pinned by the output tolerance only (p = 0)."""
+    b = pkg.synthetic.make_batch(["cigre14"], 64, seed=9)
+    torch.manual_seed(0)
+    ref = oracle.MPN(8, 6, 2, 128, 4, 2, 0.0).double()
+    mine = pkg.MPN(8, 6, 2, 128, 4, 2, 0.0)
+    mine.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    mine = mine.to(DEV)
+    out64 = ref(b["x"][:, :8].double(), b["edge_index"], b["edge_attr"][:, :6].double())
+    nw = pkg.networks
+    saved = nw.CHAIN_HEAD_FWD, nw.CHAIN_HEAD
+    nw.CHAIN_HEAD_FWD, nw.CHAIN_HEAD = True, True
+    try:
+        out = mine(b["x"][:, :8].to(DEV), b["edge_index"].to(DEV), b["edge_attr"][:, :6].to(DEV))
+        w = torch.linspace(-1.0, 1.0, out64.numel(), dtype=torch.float64).view_as(out64)
+        (out * w.float().to(DEV)).sum().backward()
+        (out64 * w).sum().backward()
+    finally:
+        nw.CHAIN_HEAD_FWD, nw.CHAIN_HEAD = saved
+    assert rel_err(out, out64) < 1e-5
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad, q.grad) < max(1e-4, 8.0 / b["x"].shape[0]), n
+
+
+def test_wide_heads_keep_their_own_launches(pkg):
+    """SkipMPN's head is dim_featn = 8 wide (networks.py:336): beyond the fused head's 4 outputs, so the switch changes nothing."""
+    b = pkg.synthetic.make_batch(["cigre14"], 100, seed=4)
+    torch.manual_seed(0)
+    model = pkg.SkipMPN(8, 6, 8, 128, 4, 2, 0.3).to(DEV)
+    topo = pkg.topology.get_topology(b["edge_index"].to(DEV), b["x"].shape[0])
+    assert not pkg.networks.chain_head_supported(topo, 3, 128, 8, False)
+    ref, got = _run(pkg, model, b, False, False, 3), _run(pkg, model, b, True, True, 3)
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
