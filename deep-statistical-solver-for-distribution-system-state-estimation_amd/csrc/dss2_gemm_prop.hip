@@ -40,14 +40,25 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const dss2_pack_desc*
     const int cg = cg0 + (idx >> 6) / nkl;
     const int j = cg * 32 + (lane & 31) - d.joff;
     if (j < 0 || j >= J) return;
-    __bf16* dst = reinterpret_cast<__bf16*>(d.dst) + (((size_t)cg * nkk + kg) * 3 * 64 + lane) * 8;
+    // (pointers out of a descriptor are generic -- flat_load / flat_store -- unless told otherwise: global by contract; the eight
+    //  source values are requested together, then split)
+    typedef const __attribute__((address_space(1))) float* gsrc_t;
+    typedef __attribute__((address_space(1))) __bf16* gdst_t;
+    const gsrc_t src = (gsrc_t)d.src;
+    gdst_t dst = (gdst_t)(reinterpret_cast<__bf16*>(d.dst) + (((size_t)cg * nkk + kg) * 3 * 64 + lane) * 8);
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = kg * 16 + 8 * (lane >> 5) + q - d.koff;
+      const int kc = k < 0 ? 0 : (k >= K ? K - 1 : k);
+      v[q] = tr ? src[(size_t)j * d.ld + kc] : src[(size_t)kc * d.ld + j];
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int k = kg * 16 + 8 * (lane >> 5) + q - d.koff;
       if (k < 0 || k >= K) continue;
-      const float v = tr ? d.src[(size_t)j * d.ld + k] : d.src[(size_t)k * d.ld + j];
       __bf16 h, m, l;
-      split3(v, h, m, l);
+      split3(v[q], h, m, l);
       dst[q] = h; dst[64 * 8 + q] = m; dst[2 * 64 * 8 + q] = l;
     }
     return;

@@ -90,8 +90,11 @@ __device__ __forceinline__ void small_gemm_body(const dss2_sgemm_desc* __restric
   // unconditional loads from clamped addresses (one batch of 32 in flight), masked afterwards
   auto issue = [&](int c) {
     const int bidx = c / kchunks, k0 = (c - bidx * kchunks) * SG_KC;
-    const float* A = dp->A[bidx];   // uniform scalar loads from the descriptor
-    const float* B = dp->B[bidx];
+    // (pointers read from a descriptor in memory are generic: through them every access is a flat_load that waits for vmcnt AND
+    //  lgkmcnt; they are global by contract -- say so)
+    typedef const __attribute__((address_space(1))) float* gptr;
+    const gptr A = (gptr)dp->A[bidx];   // uniform scalar loads from the descriptor
+    const gptr B = (gptr)dp->B[bidx];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       // A(i,k): row-major [M,K] (k contiguous) or, transposed, stored [K,M] (i contiguous)
