@@ -83,6 +83,10 @@ class DeviceDataset:
         # host-side facts about the samples' edge lists, once per dataset: what lets a batch's graph structure be built
         # without any device-to-host copy (topology.TopologyHint)
         ei_h = (edge_index[0:1] if self.shared_topology else edge_index).cpu().numpy()
+        # the hinted structure build never copies its error flag back (topology.TopologyHint): node ids are checked here, once,
+        # on the host copy the degrees are counted from anyway (an id outside [0, n) would index HBM / LDS out of bounds later)
+        if ei_h.size and (int(ei_h.min()) < 0 or int(ei_h.max()) >= self.n):
+            raise ValueError(f"edge_index holds node ids outside [0, {self.n}) (min {int(ei_h.min())}, max {int(ei_h.max())})")
         first = ei_h[0]
         self.directed = not bool(((first[0] == first[1, 0]) & (first[1] == first[0, 0])).any())   # networks.py:236-238 on sample 0
         self._sample_directed = None if self.shared_topology else \

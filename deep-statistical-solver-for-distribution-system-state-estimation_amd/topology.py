@@ -193,6 +193,9 @@ class Topology:
             _lib.check(L.dss2_tiles_uniform(tile_start.data_ptr(), nt, per * n, N, st), "dss2_tiles_uniform")
             max_deg = max_degT = int(hint.max_degree)
             max_segment = n
+            if os.environ.get("DSS2_CHECK", "0") == "1":      # debugging aid: read the build's error flag after all (ONE host sync)
+                self._stats = None
+                self.stats()
             nnz_bound = per * hint.max_edges_per_graph * (2 if self.directed else 1)
             exact_nnz = False
         else:

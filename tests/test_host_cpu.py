@@ -195,3 +195,19 @@ def test_fused_adamax_checkpoint_has_one_step_tensor_per_parameter():
     assert [float(ref.state[p]["step"]) for p in ref.param_groups[0]["params"]] == [6.0, 6.0]
     # and the export did not detach the optimizer's own shared counter
     assert opt.state[ps[0]]["step"] is opt.state[ps[1]]["step"]
+
+
+def test_device_dataset_rejects_out_of_range_node_ids():
+    """the hinted structure build never reads its error flag back, so the dataset checks node ids once on the host."""
+    import pytest
+    import torch
+    pkg = load_pkg()
+    S, n, e = 3, 5, 4
+    x, ea, y = torch.zeros(S, n, 11), torch.zeros(S, e, 13), torch.zeros(S, n, 2)
+    ei = torch.tensor([[0, 1, 2, 3], [1, 2, 3, 4]]).expand(S, 2, e).clone()
+    ds = pkg.dataset.DeviceDataset(x, ea, y, ei)
+    assert ds.max_degree_asis == 1 and ds.hint().nodes_per_graph == n
+    bad = ei.clone()
+    bad[1, 1, 2] = n          # one endpoint of one sample outside [0, n)
+    with pytest.raises(ValueError, match="outside"):
+        pkg.dataset.DeviceDataset(x, ea, y, bad)
