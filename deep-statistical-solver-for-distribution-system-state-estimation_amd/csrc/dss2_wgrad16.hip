@@ -24,7 +24,7 @@
 
 namespace dss2 {
 
-constexpr int W16_TM = 64, W16_ZC = 64, W16_XW = 128, W16_NT = 512, W16_LDZF = 68, W16_DMAX = 8;
+constexpr int W16_TM = 64, W16_ZC = 64, W16_XW = 128, W16_NT = 512, W16_LDZF = 64, W16_DMAX = 8;      // (LDZF = 64: a row is one 256-byte bank row -- the b128 lane groups of the row-piece stores and gathers then cover all 16 slots whatever rows they touch; 68 cost a third of the LDS cycles in conflicts)
 
 // byte offset of (column, row) inside one plane of a transposed image: 128 B per column, 16-byte chunks of 8 rows swizzled
 // (the swizzle key ((col >> 1) ^ (col >> 4)) & 7 makes BOTH access patterns conflict-free: the transposed stores of a wave --
