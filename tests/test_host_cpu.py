@@ -166,7 +166,7 @@ def test_no_kernel_in_the_library_spills_registers():
     # ONE documented exception: the whole-stack backward (csrc/dss2_stack.hip).  Its three persistent weight-gradient
     # accumulator slots (48 VGPRs) live across the whole tile loop of a 256-register kernel (8 waves per workgroup); the
     # allocator saves ~50 loop-carried / invariant registers around the per-tile staging section (a few dozen scratch
-    # accesses per tile and block, none inside the unit loop's phases: DESIGN.md section 4.6).  Bounded here so it cannot grow.
+    # accesses per tile and block, none inside the unit loop's phases: DESIGN.md section 4.7).  Bounded here so it cannot grow.
     allowed = {"dss2::stack_bwd_kernel": 64}
     bad = [(fn, name, sp, scr) for fn, ks in results for name, sp, scr in ks
            if (sp or scr) and not (name.strip() in allowed and sp <= allowed[name.strip()])]
