@@ -376,11 +376,17 @@ __global__ void __launch_bounds__(256 * RSP, RSP > 1 ? 2 : gemm_waves_per_simd(N
             };
             load_b16(bq0, 0);
             int s = 0;
+            // (sched_barrier: without it the scheduler sinks the next step's requests below this step's MFMAs to share the
+            //  registers of the two buffers, and every step then waits for its own L2 round trip)
             for (; s + 2 <= nsh; s += 2) {
               load_b16(bq1, s + 1);
+              __builtin_amdgcn_sched_barrier(0);
               step16(bq0, s);
+              __builtin_amdgcn_sched_barrier(0);
               load_b16(bq0, s + 2);
+              __builtin_amdgcn_sched_barrier(0);
               step16(bq1, s + 1);
+              __builtin_amdgcn_sched_barrier(0);
             }
             if (s < nsh) step16(bq0, s);
           } else {
