@@ -11,7 +11,8 @@ dev = torch.device("cuda:0"); nmat = 3
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 nl = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-b = pkg.synthetic.make_batch(["cigre14"], B, seed=0)
+GRID = sys.argv[4] if len(sys.argv) > 4 else "cigre14"
+b = pkg.synthetic.make_batch([GRID], B, seed=0)
 ei = b["edge_index"].to(dev); N = b["x"].shape[0]
 topo = pkg.topology.get_topology(ei, N)
 Ws = [torch.randn(H, H, device=dev) * 0.1 for _ in range(nmat)]
@@ -26,11 +27,12 @@ nwg = min(topo.ntiles, 2048)
 buf = (C.c_ulonglong * (nwg * 8 * 64))()
 lib = pkg._lib.lib()
 sp = H >= 96 and os.environ.get("DSS2_CHAIN_SP", "1") != "0"      # the split-plane kernel keeps its stamps in its own translation unit
-reader = lib.dss2_debug_read_cstamps_sp if sp else lib.dss2_debug_read_cstamps
+sp3 = topo.nrb == 3 and H >= 64 and os.environ.get("DSS2_CHAIN_SP", "1") != "0"
+reader = lib.dss2_debug_read_cstamps_sp3 if sp3 else (lib.dss2_debug_read_cstamps_sp if sp else lib.dss2_debug_read_cstamps)
 reader.argtypes = [C.c_void_p, C.c_int]
 assert reader(buf, nwg * 8 * 64) == 0
 ncg = (H + 31) // 32
-nwav = min(8, ncg * (2 if ncg <= 2 else 1))      # waves per workgroup (row split for narrow layers)
+nwav = min(8, ncg * (2 if (ncg <= 2 and topo.nrb != 3) else 1))      # waves per workgroup (row split for narrow layers)
 st = np.frombuffer(buf, dtype=np.uint64).reshape(nwg, 8, 64)[:, :nwav, :].astype(np.int64)
 us = lambda d: float(np.median(d))      # s_memtime ticks = shader cycles
 print(f"B={B}: {topo.ntiles} tiles; shader cycles (median over workgroups x waves)")
@@ -42,10 +44,10 @@ for li in range(nl):
     gemm, bar1, horner, epi, bar2 = us(s(0) - prev), us(s(1) - s(0)), us(s(2) - s(1)), us(s(3) - s(2)), us(s(4) - s(3))
     epi_a = us(s(5) - s(2))
     print(f"  layer {li}: GEMM {gemm:7.0f}  barrier {bar1:5.0f}  Horner {horner:6.0f}  epilogue {epi:6.0f} (T -> stage {epi_a:5.0f}, rows -> HBM / X tile {epi - epi_a:5.0f})  barrier {bar2:5.0f}   sum {gemm + bar1 + horner + epi + bar2:7.0f} cycles")
-if sp:
+if sp and not sp3:
     dt, drt = st[:, :, 2 + (nl - 1) * 6 + 4] - st[:, :, 1], st[:, :, 63] - st[:, :, 62]
     print(f"  in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz), median: {np.median(dt / np.maximum(drt, 1)) * 0.1:.2f} GHz")
-if sp:
+if sp and not sp3:
     # wall-clock picture (100 MHz s_memrealtime): when workgroups start their first layer and when they end
     t0 = st[:, :, 62].min(); a = (st[:, :, 62].min(axis=1) - t0) / 100.0; e = (st[:, :, 63].max(axis=1) - t0) / 100.0
     q = lambda v: " ".join(f"{x:6.1f}" for x in np.percentile(v, [0, 10, 50, 90, 100]))
