@@ -23,6 +23,11 @@ extern "C" int dss2_gemm_prop_chain_supported(int nrb, int nmat, int kreal, int 
 
 extern "C" int dss2_gemm_prop_chain16_supported(int nrb, int nmat, int kreal, int hout, int ell_width) {
   using namespace dss2;
+  if (nrb == 6) {      // 192-row tiles: only the split-plane form exists (dss2_gemm_chain_sp6.hip)
+    dss2_gemm_prop_args a = {};
+    a.b_format = 1; a.nrb = nrb; a.nmat = nmat; a.kreal = kreal; a.kpad = (kreal + 15) / 16 * 16; a.hout = hout; a.ncg = (hout + 31) / 32; a.ell_width = ell_width;
+    return (kreal == hout && (hout & 3) == 0 && ell_width > 0 && chain_sp6_supported(a)) ? 1 : 0;
+  }
   // the shapes of the fp32 chain whose bf16x6 instantiation exists without register spills (dss2_gemm_chain16.hip)
   if (!dss2_gemm_prop_chain_supported(nrb, nmat, kreal, hout, ell_width)) return 0;
   const int ncg = (hout + 31) / 32, rsplit = chain_row_split(nrb, ncg);
@@ -69,7 +74,8 @@ static int chain_impl(const dss2_gemm_prop_args* ap, const dss2_chain_layer* lay
   const dss2_gemm_prop_args& a = *ap;
   if (n_layers < 1 || n_layers > CHAIN_MAX || !layers) { set_error("gemm_prop_chain: 1..%d layers, got %d", CHAIN_MAX, n_layers); return 2; }
   if (a.ntiles <= 0) return 0;
-  if (!dss2_gemm_prop_chain_supported(a.nrb, a.nmat, a.kreal, a.hout, a.ell_width) || !a.ell_tiles || a.prop_in || a.narrow_h ||
+  const bool tall16 = a.b_format == 1 && a.nrb == 6 && dss2_gemm_prop_chain16_supported(a.nrb, a.nmat, a.kreal, a.hout, a.ell_width);
+  if ((!tall16 && !dss2_gemm_prop_chain_supported(a.nrb, a.nmat, a.kreal, a.hout, a.ell_width)) || !a.ell_tiles || a.prop_in || a.narrow_h ||
       a.rowscale || a.kpad != (a.b_format == 1 ? (a.kreal + 15) / 16 * 16 : (a.kreal + 7) / 8 * 8) || a.ncg != (a.hout + 31) / 32) {
     set_error("gemm_prop_chain: unsupported shape (nrb=%d nmat=%d k=%d hout=%d ell=%d); use dss2_gemm_prop per layer",
               a.nrb, a.nmat, a.kreal, a.hout, a.ell_width);
@@ -101,6 +107,7 @@ static int chain_impl(const dss2_gemm_prop_args* ap, const dss2_chain_layer* lay
     }
     if (rsplit == 1 && chain_sp_supported(a)) return launch_chain_sp(a, ct, head, s);      // 64-row tiles, H >= 96: split-plane form
     if (head) { set_error("gemm_prop_chain_head: the split-plane chain does not cover this shape"); return 2; }
+    if (a.nrb == 6 && chain_sp6_supported(a)) return launch_chain_sp6(a, ct, s);      // 192-row tiles: split-plane form, six row blocks per wave
     if (rsplit == 1 && chain_sp3_supported(a)) return launch_chain_sp3(a, ct, s);      // 96-row tiles: split-plane form, three waves per column group
     return launch_chain16(a, ct, rsplit, s);
   }

@@ -466,5 +466,8 @@ int launch_chain_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, const ds
 // 96-row tiles, three waves per column group (dss2_gemm_chain_sp3.hip)
 bool chain_sp3_supported(const dss2_gemm_prop_args& a);
 int launch_chain_sp3(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t s);
+// 192-row tiles, six row blocks per wave (dss2_gemm_chain_sp6.hip)
+bool chain_sp6_supported(const dss2_gemm_prop_args& a);
+int launch_chain_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t s);
 
 }  // namespace dss2

@@ -1,0 +1,315 @@
+// Split-plane layer chain for 192-row tiles (graphs of 97..192 buses, one per tile: the 179-bus feeder): dss2_gemm_chain_sp3.hip
+// with six row blocks per wave.
+//
+// One wave per 32-column group owns all 192 rows of its columns: 288 accumulator registers (AGPRs; one wave per SIMD, 512-register
+// budget), the Horner hops wave-private, every weight fragment fetched once per column group, two barriers per layer.  What
+// differs from the 96-row form is the LDS budget -- the tile alone is 144 KB as split planes:
+//   * plane rows are UNPADDED (32 bf16 = 64 bytes) and XOR-swizzled by 16-byte chunk with key (row / 4) mod 4: the ds_read_b128
+//     lane groups of an A fragment still fall on 16 distinct slots;
+//   * ONE Horner slot per column group ([192][32] fp32 = 24 KB inside the group's 36 KB stripe): a hop gathers
+//     z = sum_k w T[nbr] from the slot into registers, then G_m takes the slot's place (accumulator layout -> rows) and
+//     U = G_m + z is read back from the lane's own rows -- instead of T and G_m side by side.  (The sums are therefore formed as
+//     G_m + (sum), not as an fma chain starting at G_m: results differ from the per-layer kernel by rounding.)
+// This configuration had no layer chain at all (gemm_prop_kernel<6,3,true,2> per layer: X tile re-read, in-register operand split,
+// accumulator-layout hops with workgroup barriers: 100 K cycles per layer and tile).  LDS 4 x 36 KB + ELL, one workgroup per CU.
+// Compiled without packed fp32 ops like the other bf16x6 translation units (build.sh, dss2_gemm_chain16.hip).
+#include <stdlib.h>
+
+#include "dss2_gemm_chain_kernel.hpp"
+
+namespace dss2 {
+
+#define S6STAMP(slot) CSTAMP(slot)
+constexpr int S6_TM = 192;
+constexpr int S6_RS = 32;                      // bf16 per plane row: unpadded, chunks swizzled
+constexpr int S6_PLANE = S6_TM * S6_RS;        // bf16 per plane
+constexpr int S6_REGION = 3 * S6_PLANE / 2;    // floats per column group: three planes = 36 KB >= the Horner slot ([192][32] fp32 = 24 KB)
+
+// bf16 offset of (row, k) inside a plane: 16-byte chunk (k / 8) XOR (row / 4) mod 4
+__device__ __forceinline__ int s6_off(int row, int k) { return row * S6_RS + ((((k >> 3) ^ (row >> 2)) & 3) << 3) + (k & 7); }
+
+__device__ __forceinline__ void s6_barrier() {      // LDS-only hand-off: the Y stores of the epilogue stay in flight
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+typedef uint32_t u32x2_s6 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void s6_store_split(__bf16* dst, const f32x4 v) {
+  uint32_t h0, m0, l0, h1, m1, l1;
+  split3_pair(v[0], v[1], h0, m0, l0);
+  split3_pair(v[2], v[3], h1, m1, l1);
+  *reinterpret_cast<u32x2_s6*>(dst) = u32x2_s6{h0, h1};
+  *reinterpret_cast<u32x2_s6*>(dst + S6_PLANE) = u32x2_s6{m0, m1};
+  *reinterpret_cast<u32x2_s6*>(dst + 2 * S6_PLANE) = u32x2_s6{l0, l1};
+}
+
+template <int NMAT>
+__global__ void __launch_bounds__(256) gemm_chain_sp6_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
+  constexpr int TM = S6_TM;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nthreads = blockDim.x;
+  const int ncg = nthreads >> 6;
+  const int cg = wave;
+  const int tile = blockIdx.x;
+  const uint64_t drop_seed = p.drop_state ? p.drop_state[0] : 0, drop_off = p.drop_state ? p.drop_state[1] : 0;
+  __bf16* xpl = reinterpret_cast<__bf16*>(smem);               // stripe s: xpl + s * (2 * S6_REGION)
+  int2* ell = reinterpret_cast<int2*>(smem + ncg * S6_REGION);
+  const int D = p.ell_width;
+  const int ts = p.tile_start[tile];
+  const int R = p.tile_start[tile + 1] - ts;
+  const int kq = p.kpad >> 2;
+  const int c32 = lane & 31, half = lane >> 5;
+  const int nks = p.kpad >> 4;
+  float* slot0 = smem + cg * S6_REGION;
+  __bf16* own_planes = xpl + cg * (2 * S6_REGION);
+  const int cq = (lane & 7) * 4, r8 = lane >> 3;
+  const int col0 = cg * 32 + cq;
+  const bool col_ok = col0 < p.hout;
+  constexpr int NRP = 24, HP = 12;              // row pieces per lane: rows r8 + 8 i; HP of them per gather pass
+
+  // ---- stage the tile's ELL slice and the first layer's input tile as split planes (zero padded to 96 x kpad)
+  {
+    const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
+    for (int idx = tid; idx < D * TM; idx += nthreads) ell[idx] = src[idx];
+  }
+  for (int idx = tid; idx < TM * kq; idx += nthreads) {
+    const int r = idx / kq, c = (idx - r * kq) << 2;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
+    s6_store_split(xpl + (c >> 5) * (2 * S6_REGION) + s6_off(r, c & 31), v);
+  }
+  bf16x8 b0[3][NMAT];
+  auto load_b = [&](const bf16x8* __restrict__ bp16, bf16x8 (&bb)[3][NMAT], int ks) {
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bb[pl][m] = bp16[(((size_t)(m * ncg + cg) * nks + ks) * 3 + pl) * 64 + lane];
+  };
+  load_b(reinterpret_cast<const bf16x8*>(ct.l[0].Bp), b0, 0);
+  S6STAMP(0);
+  s6_barrier();
+  S6STAMP(1);
+
+  for (int li = 0; li < ct.n; ++li) {
+    const dss2_chain_layer& L = ct.l[li];    // uniform: scalar loads from the kernel-argument segment
+    const bf16x8* __restrict__ bp16 = reinterpret_cast<const bf16x8*>(L.Bp);
+    f32x16 acc[6][NMAT];
+
+    // ---- tile GEMM, 16 k per step: B fragments (L2) ping-pong one step ahead, A fragments (LDS planes) one row block ahead;
+    // one memory request per MFMA gap (dss2_gemm_chain_sp.hip)
+    {
+      bf16x8 b1[3][NMAT], a[2][3];
+      auto load_a = [&](bf16x8 (&af)[3], int rb, int ks) {
+        const __bf16* src = xpl + (ks >> 1) * (2 * S6_REGION) + s6_off(rb * 32 + c32, (ks & 1) * 16 + half * 8);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8*>(src + pl * S6_PLANE);
+      };
+      auto mma = [&](const bf16x8 (&af)[3], const bf16x8 (&b)[3][NMAT], f32x16 (&c)[NMAT], const bool first) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0][m], first ? zero : c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1][m], c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2][m], c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0][m], c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[1][m], c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[0][m], c[m], 0, 0, 0);
+      };
+      // a[rb & 1] holds row block rb's fragment; right after its MFMAs the register set is re-requested for row block rb + 2
+      // (of this step, or of the next one; branch-free: the last step re-requests its own operands).  Two sets, not six:
+      // 6 x NMAT accumulator blocks already take 288 of the wave's 512 registers at NMAT = 3.
+      auto step = [&](const bf16x8 (&bc)[3][NMAT], bf16x8 (&bn)[3][NMAT], int ks, const bool first) {
+        const int kn = ks + 1 < nks ? ks + 1 : ks;
+        load_b(bp16, bn, kn);
+#pragma unroll
+        for (int rb = 0; rb < 6; ++rb) { mma(a[rb & 1], bc, acc[rb], first); load_a(a[rb & 1], rb < 4 ? rb + 2 : rb - 4, rb < 4 ? ks : kn); }
+        // gaps 1-9: the next step's weight fragments; after each row block's MFMAs: the re-request of its fragment
+#pragma unroll
+        for (int i = 0; i < 3 * NMAT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * NMAT - 3 * NMAT, 0);
+#pragma unroll
+        for (int rb = 1; rb < 6; ++rb) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+          __builtin_amdgcn_sched_group_barrier(0x008, 6 * NMAT - 3, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      };
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) load_a(a[rb], rb, 0);
+      step(b0, b1, 0, true);
+      int ks = 1;
+      for (; ks + 2 <= nks; ks += 2) {
+        step(b1, b0, ks, false);
+        step(b0, b1, ks + 1, false);
+      }
+      if (ks < nks) step(b1, b0, ks, false);
+    }
+    S6STAMP(2 + li * 6 + 0);      // GEMM phase done
+    // ---- what the epilogue reads from HBM per row, requested before the hops (rowv opaque: see dss2_gemm_chain_sp.hip)
+    int rowv = r8;
+    asm volatile("" : "+v"(rowv));
+    const bool has_pre = L.prebias != nullptr, has_dm = L.dmask != nullptr, has_rs = L.relu_src != nullptr, has_add = L.add_src != nullptr;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (L.bias && col_ok) bias4 = *reinterpret_cast<const f32x4*>(L.bias + col0);
+    auto grow_of = [&](int i) { const int row = rowv + 8 * i; return (size_t)(ts + (row < R ? row : 0)); };      // (clamped: loads only)
+    // The ReLU gate of the backward pass: requested at the start of the LAST hop.  With 6 x NMAT accumulator blocks alive the
+    // compiler parks most of these 96 registers in scratch memory until the epilogue (measured: requesting them later, or keeping
+    // one bit per element, is 1-2 % slower -- the scratch round trip is the cheaper prefetch).
+    f32x4 gate[NRP];
+    s6_barrier();      // every wave is done with this layer's planes: the slots below go over the wave's own stripe
+    S6STAMP(2 + li * 6 + 1);
+
+    // ---- Horner on row pieces, wave-private: T in one slot, G_m in the other; U = G_m + P T replaces G_m
+    f32x4 U[NRP];
+    {
+      auto put = [&](int m) {
+#pragma unroll
+        for (int rb = 0; rb < 6; ++rb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) slot0[(rb * 32 + acc_row(r, half)) * 32 + c32] = acc[rb][m][r];
+      };
+      put(NMAT - 1);
+      wave_lds_sync();
+#pragma unroll
+      for (int m = NMAT - 2; m >= 0; --m) {
+        if (m == 0 && has_rs && col_ok) {
+#pragma unroll
+          for (int i = 0; i < NRP; ++i) gate[i] = *reinterpret_cast<const f32x4*>(L.relu_src + grow_of(i) * p.ld_relu + col0);
+        }
+        // z = P T gathered from the slot (NRP / HP passes of HP row pieces), then G_m takes the slot and U = G_m + z
+#pragma unroll
+        for (int h12 = 0; h12 < NRP / HP; ++h12) {
+          int2 en[HP];
+#pragma unroll
+          for (int i = 0; i < HP; ++i) { en[i] = ell[r8 + 8 * (HP * h12 + i)]; U[HP * h12 + i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+          for (int k = 0; k < D; ++k) {
+            const int kn = k + 1 < D ? k + 1 : k;
+            f32x4 z[HP];
+#pragma unroll
+            for (int i = 0; i < HP; ++i) z[i] = *reinterpret_cast<const f32x4*>(slot0 + en[i].x * 32 + cq);
+            int2 en_next[HP];
+#pragma unroll
+            for (int i = 0; i < HP; ++i) en_next[i] = ell[kn * TM + r8 + 8 * (HP * h12 + i)];
+#pragma unroll
+            for (int i = 0; i < HP; ++i) {
+              const float w = __int_as_float(en[i].y);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) U[HP * h12 + i][q] = fmaf(w, z[i][q], U[HP * h12 + i][q]);
+              en[i] = en_next[i];
+            }
+          }
+        }
+        wave_lds_sync();      // every lane's gathers are done: G_m goes over T
+        put(m);
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < NRP; ++i) U[i] += *reinterpret_cast<const f32x4*>(slot0 + (r8 + 8 * i) * 32 + cq);
+        if (m > 0) {
+          wave_lds_sync();
+#pragma unroll
+          for (int i = 0; i < NRP; ++i) *reinterpret_cast<f32x4*>(slot0 + (r8 + 8 * i) * 32 + cq) = U[i];
+        }
+        wave_lds_sync();      // (m > 0: the new T is complete; m == 0: the planes may go over the slot)
+      }
+    }
+
+    S6STAMP(2 + li * 6 + 2);      // hops done
+    S6STAMP(2 + li * 6 + 5);
+    // ---- epilogue: bias / folded bias / masks / dropout / ReLU / gate / residual -> HBM and, split, the next layer's planes
+    const bool keep = li + 1 < ct.n;
+#pragma unroll
+    for (int i = 0; i < NRP; ++i) U[i] += bias4;
+    if (col_ok) {
+      if (has_pre) {
+        f32x4 pb4[NMAT];
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) pb4[m] = *reinterpret_cast<const f32x4*>(L.prebias + (size_t)m * p.hout + col0);
+#pragma unroll
+        for (int i = 0; i < NRP; ++i) {
+          const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pre_rowscale + grow_of(i) * 4);
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m) U[i] += pb4[m] * ps[m];
+        }
+      }
+      if (has_dm) {
+#pragma unroll
+        for (int i = 0; i < NRP; ++i) U[i] *= *reinterpret_cast<const f32x4*>(L.dmask + grow_of(i) * p.ld_dmask + col0);
+      }
+      if (L.drop_id) {
+#pragma unroll      // (fully unrolled: a rolled loop indexes U at run time and sends the whole array to scratch memory)
+        for (int i = 0; i < NRP; ++i)
+          U[i] *= dropout_mult4(drop_seed, drop_off, (uint32_t)L.drop_id, (uint32_t)grow_of(i), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
+      }
+      if (L.relu & 1) {
+#pragma unroll
+        for (int i = 0; i < NRP; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) U[i][q] = fmaxf(U[i][q], 0.f);
+      }
+      if (has_rs) {
+#pragma unroll
+        for (int i = 0; i < NRP; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) U[i][q] = gate[i][q] > 0.f ? U[i][q] : 0.f;
+      }
+      if (has_add) {
+#pragma unroll
+        for (int i = 0; i < NRP; ++i) U[i] += *reinterpret_cast<const f32x4*>(L.add_src + grow_of(i) * p.ld_add + col0);
+      }
+#pragma unroll
+      for (int i = 0; i < NRP; ++i)
+        if (rowv + 8 * i < R) *reinterpret_cast<f32x4*>(L.Y + (size_t)(ts + rowv + 8 * i) * p.ldy + col0) = U[i];
+    }
+    if (keep) {
+      load_b(reinterpret_cast<const bf16x8*>(ct.l[li + 1].Bp), b0, 0);      // the next layer's first fragments
+#pragma unroll
+      for (int i = 0; i < NRP; ++i) {
+        const int row = rowv + 8 * i;
+        s6_store_split(own_planes + s6_off(row, cq), (row < R && col_ok) ? U[i] : f32x4{0.f, 0.f, 0.f, 0.f});
+      }
+      S6STAMP(2 + li * 6 + 3);
+      s6_barrier();   // the next layer's planes are complete
+      S6STAMP(2 + li * 6 + 4);
+    } else {
+      S6STAMP(2 + li * 6 + 3);
+      S6STAMP(2 + li * 6 + 4);
+    }
+  }
+}
+
+static size_t chain_sp6_lds_bytes(int ncg, int ell_width) { return (size_t)ncg * S6_REGION * 4 + (size_t)S6_TM * ell_width * 8; }
+
+bool chain_sp6_supported(const dss2_gemm_prop_args& a) {
+  static const int on = [] { const char* e = getenv("DSS2_CHAIN_SP"); return e ? atoi(e) : 1; }();
+  return on && a.b_format == 1 && a.nrb == 6 && a.nmat >= 2 && a.nmat <= 3 && (a.kpad & 15) == 0 && a.kpad <= 32 * a.ncg &&
+         a.ncg >= 2 && a.ncg <= 4 && chain_sp6_lds_bytes(a.ncg, a.ell_width) <= (size_t)kMaxLdsBytes;
+}
+
+template <int NMAT>
+static int launch_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t stream) {
+  static std::atomic<uint32_t> lds_done{0};
+  auto kern = gemm_chain_sp6_kernel<NMAT>;
+  if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop_chain(split planes, 192 rows)")) return 1;
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg), chain_sp6_lds_bytes(a.ncg, a.ell_width), stream, a, ct);
+  return check_launch("gemm_prop_chain(split planes, 192 rows)");
+}
+
+int launch_chain_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t s) {
+  return a.nmat == 2 ? launch_sp6<2>(a, ct, s) : launch_sp6<3>(a, ct, s);
+}
+
+}  // namespace dss2
+
+#ifdef DSS2_CHAIN_STAMPS
+extern "C" int dss2_debug_read_cstamps_sp6(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dss2::g_cstamps), sizeof(unsigned long long) * n);
+}
+#endif

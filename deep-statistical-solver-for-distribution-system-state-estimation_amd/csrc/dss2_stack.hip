@@ -648,7 +648,11 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
     for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
       const int ts = p.tile_start[tile], R = p.tile_start[tile + 1] - ts;
       [[maybe_unused]] int sidx = 0;
+      #if defined(DSS2_SSTAMP_BLOCK_BACK) && defined(DSS2_SSTAMP_TILE)      // (steady state instead of the kernel's cold first tile)
+      [[maybe_unused]] const bool st_on = b == NB - 1 - DSS2_SSTAMP_BLOCK_BACK && tile == (int)(blockIdx.x + DSS2_SSTAMP_TILE * gridDim.x);
+#else
       [[maybe_unused]] const bool st_on = b == NB - 1 && tile == (int)blockIdx.x;
+#endif
       SSTAMP(1, st_on);            // 0
       // ---- stage the tile
       for (int idx = tid; idx < STM * SFN; idx += 512) {

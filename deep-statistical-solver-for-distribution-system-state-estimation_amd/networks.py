@@ -114,11 +114,14 @@ def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.T
 CHAIN_MAX = 8      # layers per dss2_gemm_prop_chain launch (csrc/dss2_gemm_chain.hip)
 
 
-def chain_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bool:
-    """True when n >= 2 consecutive hid -> hid layers can run as one chained launch (dss2_gemm_prop_chain)."""
+def chain_supported(topo: Topology, nmat: int, hid: int, transposed: bool, have16: bool = False) -> bool:
+    """True when n >= 2 consecutive hid -> hid layers can run as one chained launch (dss2_gemm_prop_chain).  ``have16``: the
+    caller holds bf16x6 weight packs, so shapes that only the split-plane form covers (192-row tiles) count too."""
     ell, tiles = (topo.ellT, topo.ellT_tiles) if transposed else (topo.ell, topo.ell_tiles)
-    return CHAIN_LAYERS and tiles is not None and bool(
-        _lib.lib().dss2_gemm_prop_chain_supported(topo.nrb, nmat, hid, hid, ell))
+    if not CHAIN_LAYERS or tiles is None:
+        return False
+    return bool(_lib.lib().dss2_gemm_prop_chain_supported(topo.nrb, nmat, hid, hid, ell)) or (
+        have16 and chain16_supported(topo, nmat, hid, transposed))
 
 
 def chain16_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bool:
@@ -1228,7 +1231,7 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
         return base + l + 1 if (snap is not None and l < L - 1) else 0
 
     # the hid -> hid layers 0 .. L-2 as ONE chained launch (activation tile stays in LDS between layers)
-    n_chain = L - 1 if (L - 1 >= 2 and chain_supported(topo, nmat, hid, False)) else 0
+    n_chain = L - 1 if (L - 1 >= 2 and chain_supported(topo, nmat, hid, False, bool(plan.fwd16))) else 0
     if n_chain:
         layers = []
         use16 = bool(plan.fwd16) and chain16_supported(topo, nmat, hid, False)
@@ -1304,7 +1307,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
     dS = None
     # slab reductions recorded in ``pending`` run in ONE launch at the end (chained path; always inside a stack)
     fold_late = False
-    if L >= 3 and not WGRAD_SIDE_STREAM and WGRAD_BATCH and chain_supported(topo, nmat, hid, True):
+    if L >= 3 and not WGRAD_SIDE_STREAM and WGRAD_BATCH and chain_supported(topo, nmat, hid, True, bool(plan.bwd16)):
         # last layer on its own; then the data-gradients of layers L-2 .. 0 as ONE chained launch
         if pending is None:
             pending = []

@@ -182,6 +182,80 @@ def test_tall_tile_layer_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat):
         assert rel_err(x, r) < 3e-6
 
 
+@pytest.mark.parametrize("B,H,nmat,nl", [
+    (40, 128, 3, 3),                             # the 179-bus configuration's shape: four column groups, K = 2
+    (700, 128, 3, 3),                            # every CU busy, several rounds of workgroups
+    (9, 64, 3, 2),                               # two column groups
+    (12, 96, 2, 4),                              # three column groups, K = 1
+])
+def test_tall_tile_layer_chain_equals_layer_by_layer(pkg, B, H, nmat, nl):
+    """192-row tiles (nrb = 6) have ONE chained form, the split-plane bf16x6 kernel of csrc/dss2_gemm_chain_sp6.hip: checked
+    against the fp32 MFMA kernel launched layer by layer with the same epilogues -- forward: bias / ReLU / folded bias / mask
+    tensor / in-kernel dropout (same Philox snapshot and ids); data-gradient form: ReLU gates -- and launched twice
+    (bitwise reproducible)."""
+    nw = pkg.networks
+    topo, N = _topo(pkg, ["ober179"], B)
+    assert topo.nrb == 6
+    saved16 = nw.CHAIN_BF16
+    nw.CHAIN_BF16 = True
+    try:
+        assert nw.chain16_supported(topo, nmat, H, False) and nw.chain16_supported(topo, nmat, H, True)
+        assert nw.chain_supported(topo, nmat, H, False, have16=True) and not nw.chain_supported(topo, nmat, H, False)
+    finally:
+        nw.CHAIN_BF16 = saved16
+    torch.manual_seed(7)
+    Ws = [torch.randn(H, H, device=DEV) * (1.5 / H ** 0.5) for _ in range(nmat)]
+    plan = nw._PackPlan([Ws], DEV, bf16_groups=(0,))
+    plan.refresh()
+    h, g = torch.randn(N, H, device=DEV), torch.randn(N, H, device=DEV)
+    bias, pbias, prs = torch.randn(H, device=DEV), torch.randn(nmat, H, device=DEV), torch.rand(N, 4, device=DEV)
+    dmask = (torch.rand(N, H, device=DEV) > 0.4).float() * 1.6
+    acts = [torch.randn(N, H, device=DEV) for _ in range(nl)]
+    snap = torch.tensor([7654321, 5], dtype=torch.int64, device=DEV)
+
+    def fwd_layers(outs, fmt):
+        Bp = plan.fwd16[0] if fmt else plan.fwd[0]
+        ls = [dict(Bp=Bp, Y=o, bias=bias, relu=True, drop_id=i + 1) for i, o in enumerate(outs)]
+        ls[0]["prebias"] = pbias
+        ls[1]["dmask"] = dmask
+        ls[-1].update(relu=False, drop_id=0)
+        return ls
+
+    def fwd_chain():
+        outs = [torch.empty(N, H, device=DEV) for _ in range(nl)]
+        nw.gemm_prop_chain(topo, h, H, nmat, fwd_layers(outs, 1), pre_rowscale=prs, drop=(snap, 0.3), b_format=1)
+        return outs
+
+    def fwd_ref():
+        outs = [torch.empty(N, H, device=DEV) for _ in range(nl)]
+        x = h
+        for L in fwd_layers(outs, 0):
+            nw.gemm_prop(topo, x, H, H, L["Bp"], nmat, H, L["Y"], bias=L["bias"], relu=L["relu"], prebias=L.get("prebias"),
+                         pre_rowscale=prs if "prebias" in L else None, dmask=L.get("dmask"),
+                         drop=(snap, 0.3, L["drop_id"]) if L["drop_id"] else None)
+            x = L["Y"]
+        return outs
+
+    def bwd_chain():
+        outs = [torch.empty(N, H, device=DEV) for _ in range(nl)]
+        nw.gemm_prop_chain(topo, g, H, nmat, [dict(Bp=plan.bwd16[0], Y=o, relu_src=a_) for o, a_ in zip(outs, acts)],
+                           transposed=True, b_format=1)
+        return outs
+
+    def bwd_ref():
+        outs = [torch.empty(N, H, device=DEV) for _ in range(nl)]
+        x = g
+        for o, a_ in zip(outs, acts):
+            nw.gemm_prop(topo, x, H, H, plan.bwd[0], nmat, H, o, relu_src=a_, transposed=True)
+            x = o
+        return outs
+    for chain, ref in ((fwd_chain, fwd_ref), (bwd_chain, bwd_ref)):
+        r, a, b_ = ref(), chain(), chain()
+        for li, (rr, x, y) in enumerate(zip(r, a, b_)):
+            assert torch.equal(x, y)
+            assert rel_err(x, rr) < 3e-6 * (li + 1), li      # (layer li's input already carries li layers of rounding differences)
+
+
 def _stress(fn, ref, n=200):
     """n launches of fn(): every result bitwise equal to the first, and within 5e-7 (max-normalised) of the fp32-MFMA form."""
     first = fn()

@@ -167,7 +167,10 @@ def test_no_kernel_in_the_library_spills_registers():
     # accumulator slots (48 VGPRs) live across the whole tile loop of a 256-register kernel (8 waves per workgroup); the
     # allocator saves ~50 loop-carried / invariant registers around the per-tile staging section (a few dozen scratch
     # accesses per tile and block, none inside the unit loop's phases: DESIGN.md section 4.7).  Bounded here so it cannot grow.
-    allowed = {"dss2::stack_bwd_kernel": 64}
+    # A second one: the 192-row split-plane chain (csrc/dss2_gemm_chain_sp6.hip).  Six row blocks x NMAT accumulator blocks take
+    # 192 / 288 of the wave's 512 registers; the backward form's 96 prefetched ReLU-gate registers are parked in scratch memory
+    # between the last hop and the epilogue, once per layer and outside the GEMM loop (the header of that file has the measurement).
+    allowed = {"dss2::stack_bwd_kernel": 64, "void dss2::gemm_chain_sp6_kernel<2>": 80, "void dss2::gemm_chain_sp6_kernel<3>": 128}
     bad = [(fn, name, sp, scr) for fn, ks in results for name, sp, scr in ks
            if (sp or scr) and not (name.strip() in allowed and sp <= allowed[name.strip()])]
     assert not bad, bad
