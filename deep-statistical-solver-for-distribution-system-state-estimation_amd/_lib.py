@@ -90,7 +90,8 @@ class ReduceDesc(C.Structure):
 
 class ChainLayer(C.Structure):
     _fields_ = [("Bp", C.c_void_p), ("bias", C.c_void_p), ("relu_src", C.c_void_p), ("dmask", C.c_void_p),
-                ("add_src", C.c_void_p), ("prebias", C.c_void_p), ("Y", C.c_void_p), ("relu", C.c_int32), ("drop_id", C.c_int32)]
+                ("add_src", C.c_void_p), ("prebias", C.c_void_p), ("Y", C.c_void_p), ("relu", C.c_int32), ("drop_id", C.c_int32),
+                ("gate_bits", C.c_void_p), ("y_bits", C.c_void_p)]
 
 
 class AdamaxDesc(C.Structure):
@@ -194,6 +195,7 @@ _SIGNATURES = {
     "dss2_gemm_prop_chain_head_supported": (C.c_int, [C.c_int] * 6),
     "dss2_gemm_prop_chain_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_gemm_prop_chain16_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dss2_gemm_prop_chain_gate_words": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_gemm_prop16_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p]),
     "dss2_wgrad_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),

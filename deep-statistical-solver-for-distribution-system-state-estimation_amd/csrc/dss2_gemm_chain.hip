@@ -21,6 +21,14 @@ extern "C" int dss2_gemm_prop_chain_supported(int nrb, int nmat, int kreal, int 
   return chain_lds_bytes(nrb, kpad, ncg, ell_width) <= (size_t)kMaxLdsBytes ? 1 : 0;
 }
 
+extern "C" int dss2_gemm_prop_chain_gate_words(int nrb, int nmat, int kreal, int hout, int ell_width) {
+  using namespace dss2;
+  dss2_gemm_prop_args a = {};
+  a.b_format = 1; a.nrb = nrb; a.nmat = nmat; a.kreal = kreal; a.kpad = (kreal + 15) / 16 * 16; a.hout = hout; a.ncg = (hout + 31) / 32; a.ell_width = ell_width;
+  if (!(kreal == hout && (hout & 3) == 0 && ell_width > 0 && (nrb == 6 || nrb == 3) && chain_sp6_supported(a))) return 0;
+  return a.ncg * (4 * nrb) * 4;      // per wave (column group): row pieces x 4 ballot words (dss2_gemm_chain_sp6.hip)
+}
+
 extern "C" int dss2_gemm_prop_chain16_supported(int nrb, int nmat, int kreal, int hout, int ell_width) {
   using namespace dss2;
   if (nrb == 6) {      // 192-row tiles: only the split-plane form exists (dss2_gemm_chain_sp6.hip)
@@ -107,7 +115,7 @@ static int chain_impl(const dss2_gemm_prop_args* ap, const dss2_chain_layer* lay
     }
     if (rsplit == 1 && chain_sp_supported(a)) return launch_chain_sp(a, ct, head, s);      // 64-row tiles, H >= 96: split-plane form
     if (head) { set_error("gemm_prop_chain_head: the split-plane chain does not cover this shape"); return 2; }
-    if (a.nrb == 6 && chain_sp6_supported(a)) return launch_chain_sp6(a, ct, s);      // 192-row tiles: split-plane form, six row blocks per wave
+    if ((a.nrb == 6 || a.nrb == 3) && chain_sp6_supported(a)) return launch_chain_sp6(a, ct, s);      // 192-row tiles: split-plane form, six row blocks per wave
     if (rsplit == 1 && chain_sp3_supported(a)) return launch_chain_sp3(a, ct, s);      // 96-row tiles: split-plane form, three waves per column group
     return launch_chain16(a, ct, rsplit, s);
   }

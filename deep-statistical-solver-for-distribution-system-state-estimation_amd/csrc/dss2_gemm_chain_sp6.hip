@@ -20,10 +20,9 @@
 namespace dss2 {
 
 #define S6STAMP(slot) CSTAMP(slot)
-constexpr int S6_TM = 192;
 constexpr int S6_RS = 32;                      // bf16 per plane row: unpadded, chunks swizzled
-constexpr int S6_PLANE = S6_TM * S6_RS;        // bf16 per plane
-constexpr int S6_REGION = 3 * S6_PLANE / 2;    // floats per column group: three planes = 36 KB >= the Horner slot ([192][32] fp32 = 24 KB)
+constexpr int s6_plane(int nrb) { return 32 * nrb * S6_RS; }           // bf16 per plane
+constexpr int s6_region(int nrb) { return 3 * s6_plane(nrb) / 2; }     // floats per column group: three planes (192 rows: 36 KB >= the Horner slot, [192][32] fp32 = 24 KB)
 
 // bf16 offset of (row, k) inside a plane: 16-byte chunk (k / 8) XOR (row / 4) mod 4
 __device__ __forceinline__ int s6_off(int row, int k) { return row * S6_RS + ((((k >> 3) ^ (row >> 2)) & 3) << 3) + (k & 7); }
@@ -34,6 +33,7 @@ __device__ __forceinline__ void s6_barrier() {      // LDS-only hand-off: the Y 
 
 typedef uint32_t u32x2_s6 __attribute__((ext_vector_type(2)));
 
+template <int S6_PLANE>
 __device__ __forceinline__ void s6_store_split(__bf16* dst, const f32x4 v) {
   uint32_t h0, m0, l0, h1, m1, l1;
   split3_pair(v[0], v[1], h0, m0, l0);
@@ -43,9 +43,9 @@ __device__ __forceinline__ void s6_store_split(__bf16* dst, const f32x4 v) {
   *reinterpret_cast<u32x2_s6*>(dst + 2 * S6_PLANE) = u32x2_s6{l0, l1};
 }
 
-template <int NMAT>
-__global__ void __launch_bounds__(256) gemm_chain_sp6_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
-  constexpr int TM = S6_TM;
+template <int NRB, int NMAT>
+__global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
+  constexpr int TM = 32 * NRB, S6_PLANE = s6_plane(NRB), S6_REGION = s6_region(NRB);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) gemm_chain_sp6_kernel(const dss2_gemm_pro
   const int cq = (lane & 7) * 4, r8 = lane >> 3;
   const int col0 = cg * 32 + cq;
   const bool col_ok = col0 < p.hout;
-  constexpr int NRP = 24, HP = 12;              // row pieces per lane: rows r8 + 8 i; HP of them per gather pass
+  constexpr int NRP = 4 * NRB, HP = NRP / 2;              // row pieces per lane: rows r8 + 8 i; HP of them per gather pass
 
   // ---- stage the tile's ELL slice and the first layer's input tile as split planes (zero padded to 96 x kpad)
   {
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) gemm_chain_sp6_kernel(const dss2_gemm_pro
     const int r = idx / kq, c = (idx - r * kq) << 2;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
-    s6_store_split(xpl + (c >> 5) * (2 * S6_REGION) + s6_off(r, c & 31), v);
+    s6_store_split<S6_PLANE>(xpl + (c >> 5) * (2 * S6_REGION) + s6_off(r, c & 31), v);
   }
   bf16x8 b0[3][NMAT];
   auto load_b = [&](const bf16x8* __restrict__ bp16, bf16x8 (&bb)[3][NMAT], int ks) {
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) gemm_chain_sp6_kernel(const dss2_gemm_pro
   for (int li = 0; li < ct.n; ++li) {
     const dss2_chain_layer& L = ct.l[li];    // uniform: scalar loads from the kernel-argument segment
     const bf16x8* __restrict__ bp16 = reinterpret_cast<const bf16x8*>(L.Bp);
-    f32x16 acc[6][NMAT];
+    f32x16 acc[NRB][NMAT];
 
     // ---- tile GEMM, 16 k per step: B fragments (L2) ping-pong one step ahead, A fragments (LDS planes) one row block ahead;
     // one memory request per MFMA gap (dss2_gemm_chain_sp.hip)
@@ -125,17 +125,17 @@ __global__ void __launch_bounds__(256) gemm_chain_sp6_kernel(const dss2_gemm_pro
       // a[rb & 1] holds row block rb's fragment; right after its MFMAs the register set is re-requested for row block rb + 2
       // (of this step, or of the next one; branch-free: the last step re-requests its own operands).  Two sets, not six:
       // 6 x NMAT accumulator blocks already take 288 of the wave's 512 registers at NMAT = 3.
-      auto step = [&](const bf16x8 (&bc)[3][NMAT], bf16x8 (&bn)[3][NMAT], int ks, const bool first) {
+      auto step = [&](const bf16x8 (&bc)[3][NMAT], bf16x8 (&bn)[3][NMAT], int ks, const bool first, const int par) {
         const int kn = ks + 1 < nks ? ks + 1 : ks;
         load_b(bp16, bn, kn);
 #pragma unroll
-        for (int rb = 0; rb < 6; ++rb) { mma(a[rb & 1], bc, acc[rb], first); load_a(a[rb & 1], rb < 4 ? rb + 2 : rb - 4, rb < 4 ? ks : kn); }
+        for (int rb = 0; rb < NRB; ++rb) { mma(a[(par + rb) & 1], bc, acc[rb], first); load_a(a[(par + rb) & 1], rb + 2 < NRB ? rb + 2 : rb + 2 - NRB, rb + 2 < NRB ? ks : kn); }
         // gaps 1-9: the next step's weight fragments; after each row block's MFMAs: the re-request of its fragment
 #pragma unroll
         for (int i = 0; i < 3 * NMAT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
         __builtin_amdgcn_sched_group_barrier(0x008, 6 * NMAT - 3 * NMAT, 0);
 #pragma unroll
-        for (int rb = 1; rb < 6; ++rb) {
+        for (int rb = 1; rb < NRB; ++rb) {
 #pragma unroll
           for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
           __builtin_amdgcn_sched_group_barrier(0x008, 6 * NMAT - 3, 0);
@@ -144,13 +144,14 @@ __global__ void __launch_bounds__(256) gemm_chain_sp6_kernel(const dss2_gemm_pro
       };
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) load_a(a[rb], rb, 0);
-      step(b0, b1, 0, true);
+      // (par: which A-fragment set row block 0 of the step finds its operands in -- with an odd NRB the sets swap roles every step)
+      step(b0, b1, 0, true, 0);
       int ks = 1;
       for (; ks + 2 <= nks; ks += 2) {
-        step(b1, b0, ks, false);
-        step(b0, b1, ks + 1, false);
+        step(b1, b0, ks, false, NRB & 1);
+        step(b0, b1, ks + 1, false, 0);
       }
-      if (ks < nks) step(b1, b0, ks, false);
+      if (ks < nks) step(b1, b0, ks, false, NRB & 1);
     }
     S6STAMP(2 + li * 6 + 0);      // GEMM phase done
     // ---- what the epilogue reads from HBM per row, requested before the hops (rowv opaque: see dss2_gemm_chain_sp.hip)
@@ -160,10 +161,19 @@ __global__ void __launch_bounds__(256) gemm_chain_sp6_kernel(const dss2_gemm_pro
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (L.bias && col_ok) bias4 = *reinterpret_cast<const f32x4*>(L.bias + col0);
     auto grow_of = [&](int i) { const int row = rowv + 8 * i; return (size_t)(ts + (row < R ? row : 0)); };      // (clamped: loads only)
-    // The ReLU gate of the backward pass: requested at the start of the LAST hop.  With 6 x NMAT accumulator blocks alive the
-    // compiler parks most of these 96 registers in scratch memory until the epilogue (measured: requesting them later, or keeping
-    // one bit per element, is 1-2 % slower -- the scratch round trip is the cheaper prefetch).
-    f32x4 gate[NRP];
+    // The ReLU gate of the backward form, ONE BIT per element.
+    //  * L.gate_bits (written by the forward chain of the same tiles through y_bits, see below): 4 x NRP ballot words per wave,
+    //    read in the epilogue with uniform (scalar) loads from the constant address space -- no vector registers, 1/32 of the bytes.
+    //  * otherwise from relu_src: each gather pass of the LAST hop requests the fp32 values of its own HP row pieces at its top
+    //    and folds them into bits at its end.  (Requested as one block of NRP vectors -- before the hops, as the 96-row kernel of
+    //    dss2_gemm_chain_sp3.hip does with 48 registers -- the register allocator has no room beside the accumulators and U and
+    //    spills every pair the moment it arrives: "load, load, wait, store, store" NRP / 2 times = as many SERIALISED global round
+    //    trips per layer.  With one wave per SIMD nothing hides those either way: backward chain 606 us against 426 us forward
+    //    on the 179-bus configuration, which is what the bit words remove.)
+    typedef const __attribute__((address_space(4))) uint64_t* cbits_t;
+    const cbits_t gbits = (cbits_t)(L.gate_bits ? L.gate_bits + ((size_t)tile * ncg + cg) * (NRP * 4) : nullptr);
+    const bool fp32_gate = has_rs && !L.gate_bits;
+    uint32_t gate_bits[(NRP + 7) / 8] = {};
     s6_barrier();      // every wave is done with this layer's planes: the slots below go over the wave's own stripe
     S6STAMP(2 + li * 6 + 1);
 
@@ -172,7 +182,7 @@ __global__ void __launch_bounds__(256) gemm_chain_sp6_kernel(const dss2_gemm_pro
     {
       auto put = [&](int m) {
 #pragma unroll
-        for (int rb = 0; rb < 6; ++rb)
+        for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) slot0[(rb * 32 + acc_row(r, half)) * 32 + c32] = acc[rb][m][r];
       };
@@ -180,14 +190,16 @@ __global__ void __launch_bounds__(256) gemm_chain_sp6_kernel(const dss2_gemm_pro
       wave_lds_sync();
 #pragma unroll
       for (int m = NMAT - 2; m >= 0; --m) {
-        if (m == 0 && has_rs && col_ok) {
-#pragma unroll
-          for (int i = 0; i < NRP; ++i) gate[i] = *reinterpret_cast<const f32x4*>(L.relu_src + grow_of(i) * p.ld_relu + col0);
-        }
+        const bool want_gate = m == 0 && fp32_gate && col_ok;
         // z = P T gathered from the slot (NRP / HP passes of HP row pieces), then G_m takes the slot and U = G_m + z
 #pragma unroll
         for (int h12 = 0; h12 < NRP / HP; ++h12) {
           int2 en[HP];
+          f32x4 gt[HP];
+          if (want_gate) {
+#pragma unroll
+            for (int i = 0; i < HP; ++i) gt[i] = *reinterpret_cast<const f32x4*>(L.relu_src + grow_of(HP * h12 + i) * p.ld_relu + col0);
+          }
 #pragma unroll
           for (int i = 0; i < HP; ++i) { en[i] = ell[r8 + 8 * (HP * h12 + i)]; U[HP * h12 + i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
           for (int k = 0; k < D; ++k) {
@@ -205,6 +217,12 @@ __global__ void __launch_bounds__(256) gemm_chain_sp6_kernel(const dss2_gemm_pro
               for (int q = 0; q < 4; ++q) U[HP * h12 + i][q] = fmaf(w, z[i][q], U[HP * h12 + i][q]);
               en[i] = en_next[i];
             }
+          }
+          if (want_gate) {
+#pragma unroll
+            for (int i = 0; i < HP; ++i)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) gate_bits[(HP * h12 + i) >> 3] |= (gt[i][q] > 0.f ? 1u : 0u) << (((HP * h12 + i) & 7) * 4 + q);
           }
         }
         wave_lds_sync();      // every lane's gathers are done: G_m goes over T
@@ -255,10 +273,17 @@ __global__ void __launch_bounds__(256) gemm_chain_sp6_kernel(const dss2_gemm_pro
           for (int q = 0; q < 4; ++q) U[i][q] = fmaxf(U[i][q], 0.f);
       }
       if (has_rs) {
+        if (gbits) {
 #pragma unroll
-        for (int i = 0; i < NRP; ++i)
+          for (int i = 0; i < NRP; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) U[i][q] = gate[i][q] > 0.f ? U[i][q] : 0.f;
+            for (int q = 0; q < 4; ++q) U[i][q] = ((gbits[i * 4 + q] >> lane) & 1ull) ? U[i][q] : 0.f;
+        } else {
+#pragma unroll
+          for (int i = 0; i < NRP; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) U[i][q] = ((gate_bits[i >> 3] >> ((i & 7) * 4 + q)) & 1u) ? U[i][q] : 0.f;
+        }
       }
       if (has_add) {
 #pragma unroll
@@ -268,12 +293,22 @@ __global__ void __launch_bounds__(256) gemm_chain_sp6_kernel(const dss2_gemm_pro
       for (int i = 0; i < NRP; ++i)
         if (rowv + 8 * i < R) *reinterpret_cast<f32x4*>(L.Y + (size_t)(ts + rowv + 8 * i) * p.ldy + col0) = U[i];
     }
+    if (L.y_bits) {      // (uniform) the sign bits of what went to Y: word (i, q) = ballot over the wave of Y[row piece i][q] > 0
+      uint64_t* yb = L.y_bits + ((size_t)tile * ncg + cg) * (NRP * 4);
+#pragma unroll
+      for (int i = 0; i < NRP; ++i) {
+        const bool in_y = col_ok && rowv + 8 * i < R;      // (pad rows and pad columns: zero bits)
+        const uint64_t m0 = __ballot(in_y && U[i][0] > 0.f), m1 = __ballot(in_y && U[i][1] > 0.f);
+        const uint64_t m2 = __ballot(in_y && U[i][2] > 0.f), m3 = __ballot(in_y && U[i][3] > 0.f);
+        if (lane < 4) yb[i * 4 + lane] = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
+      }
+    }
     if (keep) {
       load_b(reinterpret_cast<const bf16x8*>(ct.l[li + 1].Bp), b0, 0);      // the next layer's first fragments
 #pragma unroll
       for (int i = 0; i < NRP; ++i) {
         const int row = rowv + 8 * i;
-        s6_store_split(own_planes + s6_off(row, cq), (row < R && col_ok) ? U[i] : f32x4{0.f, 0.f, 0.f, 0.f});
+        s6_store_split<S6_PLANE>(own_planes + s6_off(row, cq), (row < R && col_ok) ? U[i] : f32x4{0.f, 0.f, 0.f, 0.f});
       }
       S6STAMP(2 + li * 6 + 3);
       s6_barrier();   // the next layer's planes are complete
@@ -285,25 +320,28 @@ __global__ void __launch_bounds__(256) gemm_chain_sp6_kernel(const dss2_gemm_pro
   }
 }
 
-static size_t chain_sp6_lds_bytes(int ncg, int ell_width) { return (size_t)ncg * S6_REGION * 4 + (size_t)S6_TM * ell_width * 8; }
+static size_t chain_sp6_lds_bytes(int nrb, int ncg, int ell_width) { return (size_t)ncg * s6_region(nrb) * 4 + (size_t)32 * nrb * ell_width * 8; }
 
 bool chain_sp6_supported(const dss2_gemm_prop_args& a) {
   static const int on = [] { const char* e = getenv("DSS2_CHAIN_SP"); return e ? atoi(e) : 1; }();
-  return on && a.b_format == 1 && a.nrb == 6 && a.nmat >= 2 && a.nmat <= 3 && (a.kpad & 15) == 0 && a.kpad <= 32 * a.ncg &&
-         a.ncg >= 2 && a.ncg <= 4 && chain_sp6_lds_bytes(a.ncg, a.ell_width) <= (size_t)kMaxLdsBytes;
+  static const int on3 = [] { const char* e = getenv("DSS2_CHAIN_SP3B"); return e ? atoi(e) : 1; }();      // 0: 96-row tiles run dss2_gemm_chain_sp3.hip
+  if (a.nrb == 3 && !on3) return false;
+  return on && a.b_format == 1 && (a.nrb == 6 || a.nrb == 3) && a.nmat >= 2 && a.nmat <= 3 && (a.kpad & 15) == 0 && a.kpad <= 32 * a.ncg &&
+         a.ncg >= 2 && a.ncg <= 4 && chain_sp6_lds_bytes(a.nrb, a.ncg, a.ell_width) <= (size_t)(a.nrb == 3 ? kMaxLdsBytes / 2 : kMaxLdsBytes);
 }
 
-template <int NMAT>
+template <int NRB, int NMAT>
 static int launch_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t stream) {
   static std::atomic<uint32_t> lds_done{0};
-  auto kern = gemm_chain_sp6_kernel<NMAT>;
+  auto kern = gemm_chain_sp6_kernel<NRB, NMAT>;
   if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop_chain(split planes, 192 rows)")) return 1;
-  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg), chain_sp6_lds_bytes(a.ncg, a.ell_width), stream, a, ct);
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg), chain_sp6_lds_bytes(NRB, a.ncg, a.ell_width), stream, a, ct);
   return check_launch("gemm_prop_chain(split planes, 192 rows)");
 }
 
 int launch_chain_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t s) {
-  return a.nmat == 2 ? launch_sp6<2>(a, ct, s) : launch_sp6<3>(a, ct, s);
+  if (a.nrb == 3) return a.nmat == 2 ? launch_sp6<3, 2>(a, ct, s) : launch_sp6<3, 3>(a, ct, s);
+  return a.nmat == 2 ? launch_sp6<6, 2>(a, ct, s) : launch_sp6<6, 3>(a, ct, s);
 }
 
 }  // namespace dss2

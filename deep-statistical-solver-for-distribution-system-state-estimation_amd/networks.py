@@ -124,6 +124,16 @@ def chain_supported(topo: Topology, nmat: int, hid: int, transposed: bool, have1
         have16 and chain16_supported(topo, nmat, hid, transposed))
 
 
+def chain_gate_words(topo: Topology, nmat: int, hid: int) -> int:
+    """64-bit words per tile of a layer's sign-bit buffer (``y_bits`` of a forward chain -> ``gate_bits`` of the data-gradient
+    chain over the same tiles); 0 where the chain kernel of this shape has no bit form (or either direction is not chained)."""
+    if not (CHAIN_LAYERS and CHAIN_BF16 and CHAIN_GATE_BITS) or topo.ell_tiles is None or topo.ellT_tiles is None:
+        return 0
+    L = _lib.lib()
+    return min(int(L.dss2_gemm_prop_chain_gate_words(topo.nrb, nmat, hid, hid, topo.ell)),
+               int(L.dss2_gemm_prop_chain_gate_words(topo.nrb, nmat, hid, hid, topo.ellT)))
+
+
 def chain16_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bool:
     """True when the chain can run its tile GEMM on the bf16 matrix pipe (bf16x6, fp32-accurate; dss2_gemm_chain16.hip)."""
     ell, tiles = (topo.ellT, topo.ellT_tiles) if transposed else (topo.ell, topo.ell_tiles)
@@ -183,6 +193,7 @@ def gemm_prop_chain(topo: Topology, X: Optional[torch.Tensor], hid: int, nmat: i
                 raise ValueError("gemm_prop_chain: [N, hid] contiguous tensors expected")
         d.Bp, d.Y, d.bias = ly["Bp"].data_ptr(), ly["Y"].data_ptr(), _ptr(ly.get("bias"))
         d.relu_src, d.dmask, d.prebias = _ptr(ly.get("relu_src")), _ptr(ly.get("dmask")), _ptr(ly.get("prebias"))
+        d.gate_bits, d.y_bits = _ptr(ly.get("gate_bits")), _ptr(ly.get("y_bits"))      # (only where chain_gate_words() > 0)
         d.relu = int(bool(ly.get("relu", False)))
         d.drop_id = int(ly.get("drop_id", 0)) if drop is not None else 0
     if head is None:
@@ -762,6 +773,7 @@ EDGE_TILE_KERNELS = _os.environ.get("DSS2_EDGE_TILE", "1") == "1"       # 0 = ro
 WGRAD_SIDE_STREAM = _os.environ.get("DSS2_WGRAD_STREAM", "0") == "1"   # opt-in: +3 % at C2 (kernels then overlap)
 CHAIN_LAYERS = _os.environ.get("DSS2_CHAIN", "1") == "1"               # hid->hid layers of a block: one chained launch
 WGRAD_BF16 = _os.environ.get("DSS2_WGRAD_BF16", "1") == "1"            # weight gradients as bf16x6 where the kernel covers the shape
+CHAIN_GATE_BITS = _os.environ.get("DSS2_CHAIN_GATE_BITS", "1") == "1"  # tall tiles: the backward chain's ReLU gates as bit words written by the forward chain
 CHAIN_BF16 = _os.environ.get("DSS2_CHAIN_BF16", "1") == "1"            # its tile GEMM as bf16x6 on the bf16 matrix pipe (fp32-accurate)
 CHAIN_HEAD = _os.environ.get("DSS2_CHAIN_HEAD", "1") == "1"            # the narrow head TAGConv's data gradient inside the chained launch of the data gradients
 # ... and the head's forward inside the forward chain: measured break-even at C2 (chain + head 124.5 us against 110.7 + 14.1 us for the
@@ -1216,6 +1228,7 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
     if fold is not None:
         h = S            # conv 0 consumes the aggregated hidden directly
     acts = [h]
+    act_bits = {}              # index into acts -> sign-bit words of that activation (chain_gate_words)
     p = float(mod.dropout_rate)
     # dropout is active regardless of .training (a fresh nn.Dropout is built inside forward, networks.py:268).  The
     # masks are not tensors: the epilogues regenerate them from (snapshot, layer id) in forward and backward.
@@ -1235,10 +1248,15 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
     if n_chain:
         layers = []
         use16 = bool(plan.fwd16) and chain16_supported(topo, nmat, hid, False)
+        # tall tiles: the chain also writes the sign bits of its outputs; the data-gradient chain reads those instead of the
+        # activations for its ReLU gates (dss2_chain_layer.y_bits / gate_bits)
+        gw = chain_gate_words(topo, nmat, hid) if use16 else 0      # (inside autograd.Function.forward grad mode is off: always written; 1/32 of a layer output)
         for l in range(n_chain):
             out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
             layers.append(dict(Bp=(plan.fwd16[1 + l] if use16 else plan.fwd[1 + l]), Y=out_l, bias=conv_ps[l][0], relu=True,
                                drop_id=drop_id(l), prebias=(fold.bf if (fold is not None and l == 0) else None)))
+            if gw:
+                act_bits[len(acts)] = layers[-1]["y_bits"] = torch.empty(topo.ntiles * gw, dtype=torch.int64, device=dev)
             acts.append(out_l)
         # the narrow last layer inside the same launch (the tile is still in the waves' registers): dss2_gemm_prop_chain_head
         head_fused = (CHAIN_HEAD_FWD and use16 and n_chain == L - 1 and n_chain <= CHAIN_MAX and not glob and is_narrow(nmat, mod.dim_out)
@@ -1271,7 +1289,7 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
                              drop=((snap, p, drop_id(l)) if snap is not None else None), b_format=int(g16))
         if not last:
             acts.append(h)
-    meta = (ldx, ldea, len(acts), (snap, p, base), fold is not None, glob, ver)
+    meta = (ldx, ldea, len(acts), (snap, p, base), fold is not None, glob, ver, act_bits)
     return h, [x, ea, S] + acts, meta
 
 
@@ -1280,7 +1298,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
     reductions and the fold's chain rule, calls the all-reduce hook.  Inside a stack: ``flat`` is the block's slice of the
     stack's buffer and every slab reduction is only recorded in ``pending``; the caller runs them (and the chain rule of
     all folds) in one launch each after the last block.  Returns (dx, parameter gradients as views into flat, fold_late)."""
-    ldx, ldea, n_acts, (snap, p_drop, base), folded, glob, ver = meta
+    ldx, ldea, n_acts, (snap, p_drop, base), folded, glob, ver, act_bits = meta
     x, ea, S = saved[0:3]
     acts = list(saved[3:3 + n_acts])
     in_stack = flat is not None
@@ -1335,6 +1353,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         for l in range(L - 2, -1, -1):
             out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
             layers.append(dict(Bp=(plan.bwd16[1 + l] if use16 else plan.bwd[1 + l]), Y=out_l, relu_src=(acts[l] if l > 0 else None),
+                               gate_bits=(act_bits.get(l) if (l > 0 and use16) else None),
                                drop_id=(base + l if (l > 0 and snap is not None) else 0)))      # mask of conv l-1: id (l-1)+1
             if l > 0:
                 gl[l - 1] = out_l

@@ -255,7 +255,14 @@ int dss2_gemm_prop(const dss2_gemm_prop_args* args_host, void* stream);
 typedef struct dss2_chain_layer {
   const float* Bp; const float* bias; const float* relu_src; const float* dmask; const float* add_src;
   const float* prebias; float* Y; int32_t relu; int32_t drop_id;   /* drop_id: as in dss2_gemm_prop_args, per layer */
+  /* Optional, only where dss2_gemm_prop_chain_gate_words(...) > 0 (else leave NULL: the kernels of other shapes ignore both).
+   * y_bits: the chain also writes one bit per stored element, Y > 0, as ntiles x gate_words 64-bit words in the kernel's own
+   * order.  gate_bits: such a buffer, written by a chain launch over the SAME tiles, hout and nmat, replaces the reads of
+   * relu_src (which must still be given: it defines the gate) -- 1/32 of the bytes and no latency-exposed vector loads. */
+  const uint64_t* gate_bits; uint64_t* y_bits;
 } dss2_chain_layer;
+/* 64-bit words per tile of y_bits / gate_bits for this shape; 0: the chain kernel of this shape has no bit form */
+int dss2_gemm_prop_chain_gate_words(int nrb, int nmat, int kreal, int hout, int ell_width);
 int dss2_gemm_prop_chain(const dss2_gemm_prop_args* args_host, const dss2_chain_layer* layers_host, int n_layers, void* stream);
 /* The chain with the narrow head TAGConv fused in (replaces a dss2_gemm_prop launch next to the chain that re-reads [N, hid];
  * /root/reference/networks.py:266-275 -- the last TAGConv(dim_hid, dim_out) of MPN / SkipMPN and its data gradient).

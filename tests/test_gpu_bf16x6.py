@@ -256,6 +256,42 @@ def test_tall_tile_layer_chain_equals_layer_by_layer(pkg, B, H, nmat, nl):
             assert rel_err(x, rr) < 3e-6 * (li + 1), li      # (layer li's input already carries li layers of rounding differences)
 
 
+@pytest.mark.parametrize("grid,B,H,nmat", [("ober179", 40, 128, 3), ("ober179", 700, 128, 3), ("ober179", 9, 64, 3), ("ober179", 12, 96, 2),
+                                            ("ober_sub", 64, 128, 3), ("ober_sub", 1024, 128, 3), ("ober_sub", 30, 64, 2)])
+def test_tall_tile_chain_gate_bits_equal_fp32_gate(pkg, grid, B, H, nmat):
+    """dss2_chain_layer.y_bits / gate_bits: the forward chain writes the sign bits of its outputs (with dropout zeros in them),
+    the data-gradient chain gates with those words instead of reading the activations -- bitwise the same result."""
+    nw = pkg.networks
+    topo, N = _topo(pkg, [grid], B)
+    gw = nw.chain_gate_words(topo, nmat, H)
+    assert gw == ((H + 31) // 32) * (4 * topo.nrb) * 4 and topo.nrb in (3, 6)
+    torch.manual_seed(11)
+    Ws = [torch.randn(H, H, device=DEV) * (1.5 / H ** 0.5) for _ in range(nmat)]
+    plan = nw._PackPlan([Ws], DEV, bf16_groups=(0,))
+    plan.refresh()
+    h, g, bias = torch.randn(N, H, device=DEV), torch.randn(N, H, device=DEV), torch.randn(H, device=DEV)
+    snap = torch.tensor([424242, 9], dtype=torch.int64, device=DEV)
+    nl = 3
+    acts = [torch.empty(N, H, device=DEV) for _ in range(nl)]
+    bits = [torch.zeros(topo.ntiles * gw, dtype=torch.int64, device=DEV) for _ in range(nl)]
+    nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=plan.fwd16[0], Y=a_, bias=bias, relu=True, drop_id=i + 1, y_bits=b_)
+                                           for i, (a_, b_) in enumerate(zip(acts, bits))], drop=(snap, 0.3), b_format=1)
+    frac = [(a_ > 0).float().mean().item() for a_ in acts]
+    assert all(0.05 < f < 0.6 for f in frac), frac
+    # every set bit belongs to a positive element: the populations match
+    for a_, b_ in zip(acts, bits):
+        pop = sum(int(((b_ >> k) & 1).sum()) for k in range(64))
+        assert pop == int((a_ > 0).sum())
+
+    def bwd(use_bits):
+        outs = [torch.empty(N, H, device=DEV) for _ in range(nl)]
+        nw.gemm_prop_chain(topo, g, H, nmat, [dict(Bp=plan.bwd16[0], Y=o, relu_src=a_, gate_bits=(b_ if use_bits else None))
+                                               for o, a_, b_ in zip(outs, acts, bits)], transposed=True, b_format=1)
+        return outs
+    for x, y in zip(bwd(True), bwd(False)):
+        assert torch.equal(x, y)
+
+
 def _stress(fn, ref, n=200):
     """n launches of fn(): every result bitwise equal to the first, and within 5e-7 (max-normalised) of the fp32-MFMA form."""
     first = fn()

@@ -19,7 +19,9 @@ FALLBACKS = {
     # round-3 chain variants: the fp32-tile form of the bf16x6 chain instead of the split-plane form, the narrow head's data
     # gradient as its own launch; and the head's FORWARD inside the chained launch (off by default)
     "chain-variants-a": dict(DSS2_CHAIN_SP="0", DSS2_CHAIN_HEAD="0"),
-    "chain-variants-b": dict(DSS2_CHAIN_HEAD_FWD="1"),
+    # ... plus: 96-row tiles on the one-workgroup-per-CU chain (dss2_gemm_chain_sp3.hip), tall-tile ReLU gates read from the
+    # activations instead of the forward chain's bit words
+    "chain-variants-b": dict(DSS2_CHAIN_HEAD_FWD="1", DSS2_CHAIN_SP3B="0", DSS2_CHAIN_GATE_BITS="0"),
     # the generic narrow kernels, scalar-VALU edge MLP, edges through the global CSR instead of tile-local lists
     "generic-narrow-edge": dict(DSS2_NARROW_STREAM="0", DSS2_EDGE_MFMA="0", DSS2_EDGE_TILE="0"),
 }

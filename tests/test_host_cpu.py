@@ -170,7 +170,10 @@ def test_no_kernel_in_the_library_spills_registers():
     # A second one: the 192-row split-plane chain (csrc/dss2_gemm_chain_sp6.hip).  Six row blocks x NMAT accumulator blocks take
     # 192 / 288 of the wave's 512 registers; the backward form's 96 prefetched ReLU-gate registers are parked in scratch memory
     # between the last hop and the epilogue, once per layer and outside the GEMM loop (the header of that file has the measurement).
-    allowed = {"dss2::stack_bwd_kernel": 64, "void dss2::gemm_chain_sp6_kernel<2>": 80, "void dss2::gemm_chain_sp6_kernel<3>": 128}
+    # (Its 96-row instantiation runs two workgroups per CU on 256 registers with 144 of them accumulators; what spills there are
+    # loop invariants around the layer loop and the fp32-gate fallback of the hop phase -- the model path gates with bit words.)
+    allowed = {"dss2::stack_bwd_kernel": 64, "void dss2::gemm_chain_sp6_kernel<6, 2>": 80, "void dss2::gemm_chain_sp6_kernel<6, 3>": 144,
+               "void dss2::gemm_chain_sp6_kernel<3, 2>": 16, "void dss2::gemm_chain_sp6_kernel<3, 3>": 96}
     bad = [(fn, name, sp, scr) for fn, ks in results for name, sp, scr in ks
            if (sp or scr) and not (name.strip() in allowed and sp <= allowed[name.strip()])]
     assert not bad, bad

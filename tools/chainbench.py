@@ -22,7 +22,12 @@ h = torch.randn(N, H, device=dev); g = torch.randn(N, H, device=dev); bias = tor
 outs = [torch.empty(N, H, device=dev) for _ in range(nl)]
 acts = [torch.randn(N, H, device=dev) for _ in range(nl)]
 fwd = lambda: nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=pf, Y=o, bias=bias, relu=True) for o in outs], b_format=int(B16))
-bwd = lambda: nw.gemm_prop_chain(topo, g, H, nmat, [dict(Bp=pb, Y=o, relu_src=a_) for o, a_ in zip(outs, acts)], transposed=True, b_format=int(B16))
+gw = nw.chain_gate_words(topo, nmat, H) if B16 else 0      # tall tiles: sign-bit words instead of the activations (needs real activations)
+bits = [torch.zeros(topo.ntiles * gw, dtype=torch.int64, device=dev) for _ in range(nl)] if gw else [None] * nl
+if gw:
+    nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=pf, Y=a_, bias=bias, relu=True, y_bits=b_) for a_, b_ in zip(acts, bits)], b_format=1)
+    print("backward gates: bit words written by a forward chain")
+bwd = lambda: nw.gemm_prop_chain(topo, g, H, nmat, [dict(Bp=pb, Y=o, relu_src=a_, gate_bits=b_) for o, a_, b_ in zip(outs, acts, bits)], transposed=True, b_format=int(B16))
 fl = nl * (2.0 * N * H * nmat * H + 2.0 * (nmat - 1) * topo.E2 * H)
 for _ in range(300):   # clock ramp
     fwd()
