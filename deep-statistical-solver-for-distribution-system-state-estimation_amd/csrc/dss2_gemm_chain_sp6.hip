@@ -20,6 +20,9 @@
 namespace dss2 {
 
 #define S6STAMP(slot) CSTAMP(slot)
+#ifndef DSS2_S6_PASSES
+#define DSS2_S6_PASSES 2      // gather passes per hop (NRP / passes row pieces in flight per lane).  Measured (chainbench, 192-row fwd / bwd): 1 pass 472 / 531 us, 2 passes 406 / 473, 4 passes 439 / 499
+#endif
 constexpr int S6_RS = 32;                      // bf16 per plane row: unpadded, chunks swizzled
 constexpr int s6_plane(int nrb) { return 32 * nrb * S6_RS; }           // bf16 per plane
 constexpr int s6_region(int nrb) { return 3 * s6_plane(nrb) / 2; }     // floats per column group: three planes (192 rows: 36 KB >= the Horner slot, [192][32] fp32 = 24 KB)
@@ -68,7 +71,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
   const int cq = (lane & 7) * 4, r8 = lane >> 3;
   const int col0 = cg * 32 + cq;
   const bool col_ok = col0 < p.hout;
-  constexpr int NRP = 4 * NRB, HP = NRP / 2;              // row pieces per lane: rows r8 + 8 i; HP of them per gather pass
+  constexpr int NRP = 4 * NRB, HP = NRP / DSS2_S6_PASSES;              // row pieces per lane: rows r8 + 8 i; HP of them per gather pass
 
   // ---- stage the tile's ELL slice and the first layer's input tile as split planes (zero padded to 96 x kpad)
   {
