@@ -129,9 +129,13 @@ def chain_gate_words(topo: Topology, nmat: int, hid: int) -> int:
     chain over the same tiles); 0 where the chain kernel of this shape has no bit form (or either direction is not chained)."""
     if not (CHAIN_LAYERS and CHAIN_BF16 and CHAIN_GATE_BITS) or topo.ell_tiles is None or topo.ellT_tiles is None:
         return 0
-    L = _lib.lib()
-    return min(int(L.dss2_gemm_prop_chain_gate_words(topo.nrb, nmat, hid, hid, topo.ell)),
-               int(L.dss2_gemm_prop_chain_gate_words(topo.nrb, nmat, hid, hid, topo.ellT)))
+    cache = topo.__dict__.setdefault("_gate_words", {})      # (asked once per forward: keep the two library calls off the step)
+    gw = cache.get((nmat, hid))
+    if gw is None:
+        L = _lib.lib()
+        gw = cache[(nmat, hid)] = min(int(L.dss2_gemm_prop_chain_gate_words(topo.nrb, nmat, hid, hid, topo.ell)),
+                                      int(L.dss2_gemm_prop_chain_gate_words(topo.nrb, nmat, hid, hid, topo.ellT)))
+    return gw
 
 
 def chain16_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bool:
