@@ -20,6 +20,10 @@
 namespace dss2 {
 
 #define S6STAMP(slot) CSTAMP(slot)
+#ifndef DSS2_S6_BWD_READLANE
+#define DSS2_S6_BWD_READLANE 1
+#endif
+constexpr bool S6_BWD_READLANE = DSS2_S6_BWD_READLANE != 0;
 #ifndef DSS2_S6_PASSES
 #define DSS2_S6_PASSES 2      // gather passes per hop (NRP / passes row pieces in flight per lane).  Measured (chainbench, 192-row fwd / bwd): 1 pass 472 / 531 us, 2 passes 406 / 473, 4 passes 439 / 499
 #endif
@@ -46,7 +50,11 @@ __device__ __forceinline__ void s6_store_split(__bf16* dst, const f32x4 v) {
   *reinterpret_cast<u32x2_s6*>(dst + 2 * S6_PLANE) = u32x2_s6{l0, l1};
 }
 
-template <int NRB, int NMAT>
+// DIR: which epilogue features the launch's layers use, so that each direction gets its own register allocation (one generic
+// kernel: 77 / 130 spilled VGPRs at K = 2 and a backward chain 8-17 % slower than the forward one; specialised: 10-13 / 12).
+//   1 = forward set (bias, folded bias, in-kernel dropout, ReLU, y_bits);  2 = data-gradient set (gate_bits, in-kernel dropout);
+//   0 = everything (mask tensor, residual, fp32 gates: tests and callers outside networks.py)
+template <int NRB, int NMAT, int DIR>
 __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
   constexpr int TM = 32 * NRB, S6_PLANE = s6_plane(NRB), S6_REGION = s6_region(NRB);
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -160,9 +168,9 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     // ---- what the epilogue reads from HBM per row, requested before the hops (rowv opaque: see dss2_gemm_chain_sp.hip)
     int rowv = r8;
     asm volatile("" : "+v"(rowv));
-    const bool has_pre = L.prebias != nullptr, has_dm = L.dmask != nullptr, has_rs = L.relu_src != nullptr, has_add = L.add_src != nullptr;
+    const bool has_pre = DIR != 2 && L.prebias != nullptr, has_dm = DIR == 0 && L.dmask != nullptr, has_rs = DIR != 1 && L.relu_src != nullptr, has_add = DIR == 0 && L.add_src != nullptr;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (L.bias && col_ok) bias4 = *reinterpret_cast<const f32x4*>(L.bias + col0);
+    if (DIR != 2 && L.bias && col_ok) bias4 = *reinterpret_cast<const f32x4*>(L.bias + col0);
     auto grow_of = [&](int i) { const int row = rowv + 8 * i; return (size_t)(ts + (row < R ? row : 0)); };      // (clamped: loads only)
     // The ReLU gate of the backward form, ONE BIT per element.
     //  * L.gate_bits (written by the forward chain of the same tiles through y_bits, see below): 4 x NRP ballot words per wave,
@@ -174,8 +182,17 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     //    trips per layer.  With one wave per SIMD nothing hides those either way: backward chain 606 us against 426 us forward
     //    on the 179-bus configuration, which is what the bit words remove.)
     typedef const __attribute__((address_space(4))) uint64_t* cbits_t;
-    const cbits_t gbits = (cbits_t)(L.gate_bits ? L.gate_bits + ((size_t)tile * ncg + cg) * (NRP * 4) : nullptr);
-    const bool fp32_gate = has_rs && !L.gate_bits;
+    const cbits_t gbits = (cbits_t)((DIR != 1 && L.gate_bits) ? L.gate_bits + ((size_t)tile * ncg + cg) * (NRP * 4) : nullptr);
+    // DIR == 2: the words are requested HERE, before the hops, one or two per lane, and handed out in the epilogue with v_readlane
+    // (as uniform loads inside the epilogue they are twelve s_load_dwordx16 in sequence, each waited for: 70 us of the 480 us
+    // 192-row backward chain; in the generic kernel the four extra registers cost the forward path 30 us instead)
+    uint64_t gw0 = 0, gw1 = 0;
+    if (DIR == 2 && S6_BWD_READLANE && gbits) {
+      const uint64_t* gb = L.gate_bits + ((size_t)tile * ncg + cg) * (NRP * 4);
+      if (lane < NRP * 4) gw0 = gb[lane];
+      if (NRP * 4 > 64 && lane + 64 < NRP * 4) gw1 = gb[lane + 64];
+    }
+    const bool fp32_gate = DIR == 0 && has_rs && !L.gate_bits;
     uint32_t gate_bits[(NRP + 7) / 8] = {};
     s6_barrier();      // every wave is done with this layer's planes: the slots below go over the wave's own stripe
     S6STAMP(2 + li * 6 + 1);
@@ -269,7 +286,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
         for (int i = 0; i < NRP; ++i)
           U[i] *= dropout_mult4(drop_seed, drop_off, (uint32_t)L.drop_id, (uint32_t)grow_of(i), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
       }
-      if (L.relu & 1) {
+      if (DIR != 2 && (L.relu & 1)) {
 #pragma unroll
         for (int i = 0; i < NRP; ++i)
 #pragma unroll
@@ -280,7 +297,18 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
 #pragma unroll
           for (int i = 0; i < NRP; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) U[i][q] = ((gbits[i * 4 + q] >> lane) & 1ull) ? U[i][q] : 0.f;
+            for (int q = 0; q < 4; ++q) {
+              uint64_t m;
+              if (DIR == 2 && S6_BWD_READLANE) {
+                const int w = i * 4 + q;
+                const uint64_t src = w < 64 ? gw0 : gw1;
+                m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(src >> 32), w & 63) << 32) |
+                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)src, w & 63);
+              } else {
+                m = gbits[i * 4 + q];
+              }
+              U[i][q] = ((m >> lane) & 1ull) ? U[i][q] : 0.f;
+            }
         } else {
 #pragma unroll
           for (int i = 0; i < NRP; ++i)
@@ -296,7 +324,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
       for (int i = 0; i < NRP; ++i)
         if (rowv + 8 * i < R) *reinterpret_cast<f32x4*>(L.Y + (size_t)(ts + rowv + 8 * i) * p.ldy + col0) = U[i];
     }
-    if (L.y_bits) {      // (uniform) the sign bits of what went to Y: word (i, q) = ballot over the wave of Y[row piece i][q] > 0
+    if (DIR != 2 && L.y_bits) {      // (uniform) the sign bits of what went to Y: word (i, q) = ballot over the wave of Y[row piece i][q] > 0
       uint64_t* yb = L.y_bits + ((size_t)tile * ncg + cg) * (NRP * 4);
 #pragma unroll
       for (int i = 0; i < NRP; ++i) {
@@ -333,18 +361,28 @@ bool chain_sp6_supported(const dss2_gemm_prop_args& a) {
          a.ncg >= 2 && a.ncg <= 4 && chain_sp6_lds_bytes(a.nrb, a.ncg, a.ell_width) <= (size_t)(a.nrb == 3 ? kMaxLdsBytes / 2 : kMaxLdsBytes);
 }
 
-template <int NRB, int NMAT>
+template <int NRB, int NMAT, int DIR>
 static int launch_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t stream) {
   static std::atomic<uint32_t> lds_done{0};
-  auto kern = gemm_chain_sp6_kernel<NRB, NMAT>;
+  auto kern = gemm_chain_sp6_kernel<NRB, NMAT, DIR>;
   if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop_chain(split planes, 192 rows)")) return 1;
   hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg), chain_sp6_lds_bytes(NRB, a.ncg, a.ell_width), stream, a, ct);
   return check_launch("gemm_prop_chain(split planes, 192 rows)");
 }
 
 int launch_chain_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t s) {
-  if (a.nrb == 3) return a.nmat == 2 ? launch_sp6<3, 2>(a, ct, s) : launch_sp6<3, 3>(a, ct, s);
-  return a.nmat == 2 ? launch_sp6<6, 2>(a, ct, s) : launch_sp6<6, 3>(a, ct, s);
+  bool fwd = true, bwd = true;
+  for (int i = 0; i < ct.n; ++i) {
+    const dss2_chain_layer& L = ct.l[i];
+    if (L.relu_src || L.gate_bits || L.dmask || L.add_src) fwd = false;
+    if (L.bias || L.prebias || L.dmask || L.add_src || L.y_bits || (L.relu & 1) || (L.relu_src && !L.gate_bits)) bwd = false;
+  }
+  static const int spec = [] { const char* e = getenv("DSS2_CHAIN_SP6_DIR"); return e ? atoi(e) : 1; }();      // 0: the generic kernel always
+  const int dir = !spec ? 0 : (fwd ? 1 : (bwd ? 2 : 0));
+#define DSS2_S6_LAUNCH(NRB, NMAT) (dir == 1 ? launch_sp6<NRB, NMAT, 1>(a, ct, s) : (dir == 2 ? launch_sp6<NRB, NMAT, 2>(a, ct, s) : launch_sp6<NRB, NMAT, 0>(a, ct, s)))
+  if (a.nrb == 3) return a.nmat == 2 ? DSS2_S6_LAUNCH(3, 2) : DSS2_S6_LAUNCH(3, 3);
+  return a.nmat == 2 ? DSS2_S6_LAUNCH(6, 2) : DSS2_S6_LAUNCH(6, 3);
+#undef DSS2_S6_LAUNCH
 }
 
 }  // namespace dss2

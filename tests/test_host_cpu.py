@@ -172,8 +172,11 @@ def test_no_kernel_in_the_library_spills_registers():
     # between the last hop and the epilogue, once per layer and outside the GEMM loop (the header of that file has the measurement).
     # (Its 96-row instantiation runs two workgroups per CU on 256 registers with 144 of them accumulators; what spills there are
     # loop invariants around the layer loop and the fp32-gate fallback of the hop phase -- the model path gates with bit words.)
-    allowed = {"dss2::stack_bwd_kernel": 64, "void dss2::gemm_chain_sp6_kernel<6, 2>": 80, "void dss2::gemm_chain_sp6_kernel<6, 3>": 144,
-               "void dss2::gemm_chain_sp6_kernel<3, 2>": 16, "void dss2::gemm_chain_sp6_kernel<3, 3>": 96}
+    allowed = {"dss2::stack_bwd_kernel": 64}
+    # (the direction-specialised instantiations <NRB, NMAT, 1 | 2> that the models run spill 0-16 registers at K = 2, none at K = 1;
+    #  the generic ones <., ., 0> -- mask tensor, residual, fp32 gates: tests and outside callers -- carry every feature at once)
+    for nrb, nmat, d, cap in ((3, 3, 1, 16), (3, 3, 2, 16), (6, 3, 1, 24), (6, 3, 2, 24), (3, 2, 0, 16), (3, 3, 0, 96), (6, 2, 0, 80), (6, 3, 0, 144)):
+        allowed[f"void dss2::gemm_chain_sp6_kernel<{nrb}, {nmat}, {d}>"] = cap
     bad = [(fn, name, sp, scr) for fn, ks in results for name, sp, scr in ks
            if (sp or scr) and not (name.strip() in allowed and sp <= allowed[name.strip()])]
     assert not bad, bad
