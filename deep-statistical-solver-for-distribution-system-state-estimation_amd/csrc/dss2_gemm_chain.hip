@@ -26,7 +26,7 @@ extern "C" int dss2_gemm_prop_chain_gate_words(int nrb, int nmat, int kreal, int
   dss2_gemm_prop_args a = {};
   a.b_format = 1; a.nrb = nrb; a.nmat = nmat; a.kreal = kreal; a.kpad = (kreal + 15) / 16 * 16; a.hout = hout; a.ncg = (hout + 31) / 32; a.ell_width = ell_width;
   if (!(kreal == hout && (hout & 3) == 0 && ell_width > 0 && (nrb == 6 || nrb == 3) && chain_sp6_supported(a))) return 0;
-  return a.ncg * (4 * nrb) * 4;      // per wave (column group): row pieces x 4 ballot words (dss2_gemm_chain_sp6.hip)
+  return a.ncg * 32 * ((4 * nrb + 7) / 8);      // per wave (column group): 64 lanes x ceil(row pieces / 8) 32-bit words (dss2_gemm_chain_sp6.hip)
 }
 
 extern "C" int dss2_gemm_prop_chain16_supported(int nrb, int nmat, int kreal, int hout, int ell_width) {

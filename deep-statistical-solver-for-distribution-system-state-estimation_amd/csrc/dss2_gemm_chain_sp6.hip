@@ -20,10 +20,6 @@
 namespace dss2 {
 
 #define S6STAMP(slot) CSTAMP(slot)
-#ifndef DSS2_S6_BWD_READLANE
-#define DSS2_S6_BWD_READLANE 1
-#endif
-constexpr bool S6_BWD_READLANE = DSS2_S6_BWD_READLANE != 0;
 #ifndef DSS2_S6_PASSES
 #define DSS2_S6_PASSES 2      // gather passes per hop (NRP / passes row pieces in flight per lane).  Measured (chainbench, 192-row fwd / bwd): 1 pass 472 / 531 us, 2 passes 406 / 473, 4 passes 439 / 499
 #endif
@@ -172,28 +168,27 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (DIR != 2 && L.bias && col_ok) bias4 = *reinterpret_cast<const f32x4*>(L.bias + col0);
     auto grow_of = [&](int i) { const int row = rowv + 8 * i; return (size_t)(ts + (row < R ? row : 0)); };      // (clamped: loads only)
-    // The ReLU gate of the backward form, ONE BIT per element.
-    //  * L.gate_bits (written by the forward chain of the same tiles through y_bits, see below): 4 x NRP ballot words per wave,
-    //    read in the epilogue with uniform (scalar) loads from the constant address space -- no vector registers, 1/32 of the bytes.
-    //  * otherwise from relu_src: each gather pass of the LAST hop requests the fp32 values of its own HP row pieces at its top
-    //    and folds them into bits at its end.  (Requested as one block of NRP vectors -- before the hops, as the 96-row kernel of
-    //    dss2_gemm_chain_sp3.hip does with 48 registers -- the register allocator has no room beside the accumulators and U and
-    //    spills every pair the moment it arrives: "load, load, wait, store, store" NRP / 2 times = as many SERIALISED global round
-    //    trips per layer.  With one wave per SIMD nothing hides those either way: backward chain 606 us against 426 us forward
-    //    on the 179-bus configuration, which is what the bit words remove.)
-    typedef const __attribute__((address_space(4))) uint64_t* cbits_t;
-    const cbits_t gbits = (cbits_t)((DIR != 1 && L.gate_bits) ? L.gate_bits + ((size_t)tile * ncg + cg) * (NRP * 4) : nullptr);
-    // DIR == 2: the words are requested HERE, before the hops, one or two per lane, and handed out in the epilogue with v_readlane
-    // (as uniform loads inside the epilogue they are twelve s_load_dwordx16 in sequence, each waited for: 70 us of the 480 us
-    // 192-row backward chain; in the generic kernel the four extra registers cost the forward path 30 us instead)
-    uint64_t gw0 = 0, gw1 = 0;
-    if (DIR == 2 && S6_BWD_READLANE && gbits) {
-      const uint64_t* gb = L.gate_bits + ((size_t)tile * ncg + cg) * (NRP * 4);
-      if (lane < NRP * 4) gw0 = gb[lane];
-      if (NRP * 4 > 64 && lane + 64 < NRP * 4) gw1 = gb[lane + 64];
+    // The ReLU gate of the backward form, ONE BIT per element, (NRP + 7) / 8 registers per lane: bit (i & 7) * 4 + q of word i / 8
+    // belongs to element q of the lane's row piece i.
+    //  * L.gate_bits (written by the forward chain of the same tiles through y_bits, see below; layout [tile][column group][word]
+    //    [lane]): the lane's own words, requested HERE, before the hops -- two or three registers, 1/32 of the bytes, no exposed
+    //    latency.  (First form: one ballot word per row piece and element -- 4 x NRP uniform words per wave.  Writing them cost the
+    //    192-row forward chain 50 us (96 ballots, selects and 24 four-lane stores per layer); reading them as uniform loads in the
+    //    epilogue -- twelve s_load_dwordx16 in sequence, each waited for -- 70 us of the backward chain, through v_readlane 38 us.)
+    //  * otherwise (generic kernel only) from relu_src: each gather pass of the LAST hop requests the fp32 values of its own HP row
+    //    pieces at its top and folds them into bits at its end.  (Requested as one block of NRP vectors -- before the hops, as the
+    //    96-row kernel of dss2_gemm_chain_sp3.hip does with 48 registers -- the register allocator has no room beside the
+    //    accumulators and U and spills every pair the moment it arrives: "load, load, wait, store, store" NRP / 2 times = as many
+    //    SERIALISED global round trips per layer: backward chain 606 us against 426 us forward on the 179-bus configuration.)
+    constexpr int NGW = (NRP + 7) / 8;
+    uint32_t gate_bits[NGW] = {};
+    const bool gbits = DIR != 1 && L.gate_bits != nullptr;
+    if (gbits) {
+      const uint32_t* gb = reinterpret_cast<const uint32_t*>(L.gate_bits) + ((size_t)tile * ncg + cg) * (NGW * 64) + lane;
+#pragma unroll
+      for (int w = 0; w < NGW; ++w) gate_bits[w] = gb[w * 64];
     }
     const bool fp32_gate = DIR == 0 && has_rs && !L.gate_bits;
-    uint32_t gate_bits[(NRP + 7) / 8] = {};
     s6_barrier();      // every wave is done with this layer's planes: the slots below go over the wave's own stripe
     S6STAMP(2 + li * 6 + 1);
 
@@ -293,28 +288,10 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
           for (int q = 0; q < 4; ++q) U[i][q] = fmaxf(U[i][q], 0.f);
       }
       if (has_rs) {
-        if (gbits) {
 #pragma unroll
-          for (int i = 0; i < NRP; ++i)
+        for (int i = 0; i < NRP; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              uint64_t m;
-              if (DIR == 2 && S6_BWD_READLANE) {
-                const int w = i * 4 + q;
-                const uint64_t src = w < 64 ? gw0 : gw1;
-                m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(src >> 32), w & 63) << 32) |
-                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)src, w & 63);
-              } else {
-                m = gbits[i * 4 + q];
-              }
-              U[i][q] = ((m >> lane) & 1ull) ? U[i][q] : 0.f;
-            }
-        } else {
-#pragma unroll
-          for (int i = 0; i < NRP; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) U[i][q] = ((gate_bits[i >> 3] >> ((i & 7) * 4 + q)) & 1u) ? U[i][q] : 0.f;
-        }
+          for (int q = 0; q < 4; ++q) U[i][q] = ((gate_bits[i >> 3] >> ((i & 7) * 4 + q)) & 1u) ? U[i][q] : 0.f;
       }
       if (has_add) {
 #pragma unroll
@@ -324,14 +301,18 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
       for (int i = 0; i < NRP; ++i)
         if (rowv + 8 * i < R) *reinterpret_cast<f32x4*>(L.Y + (size_t)(ts + rowv + 8 * i) * p.ldy + col0) = U[i];
     }
-    if (DIR != 2 && L.y_bits) {      // (uniform) the sign bits of what went to Y: word (i, q) = ballot over the wave of Y[row piece i][q] > 0
-      uint64_t* yb = L.y_bits + ((size_t)tile * ncg + cg) * (NRP * 4);
+    if (DIR != 2 && L.y_bits) {      // (uniform) the sign bits of what went to Y, in the layout the data-gradient form reads
+      uint32_t* yb = reinterpret_cast<uint32_t*>(L.y_bits) + ((size_t)tile * ncg + cg) * (NGW * 64) + lane;
 #pragma unroll
-      for (int i = 0; i < NRP; ++i) {
-        const bool in_y = col_ok && rowv + 8 * i < R;      // (pad rows and pad columns: zero bits)
-        const uint64_t m0 = __ballot(in_y && U[i][0] > 0.f), m1 = __ballot(in_y && U[i][1] > 0.f);
-        const uint64_t m2 = __ballot(in_y && U[i][2] > 0.f), m3 = __ballot(in_y && U[i][3] > 0.f);
-        if (lane < 4) yb[i * 4 + lane] = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
+      for (int w = 0; w < NGW; ++w) {
+        uint32_t word = 0u;
+#pragma unroll
+        for (int i = 8 * w; i < 8 * w + 8 && i < NRP; ++i) {
+          const bool in_y = col_ok && rowv + 8 * i < R;      // (pad rows and pad columns: zero bits)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) word |= ((in_y && U[i][q] > 0.f) ? 1u : 0u) << ((i & 7) * 4 + q);
+        }
+        yb[w * 64] = word;
       }
     }
     if (keep) {

@@ -257,7 +257,7 @@ typedef struct dss2_chain_layer {
   const float* prebias; float* Y; int32_t relu; int32_t drop_id;   /* drop_id: as in dss2_gemm_prop_args, per layer */
   /* Optional, only where dss2_gemm_prop_chain_gate_words(...) > 0 (else leave NULL: the kernels of other shapes ignore both).
    * y_bits: the chain also writes one bit per stored element, Y > 0, as ntiles x gate_words 64-bit words in the kernel's own
-   * order.  gate_bits: such a buffer, written by a chain launch over the SAME tiles, hout and nmat, replaces the reads of
+   * order (per lane of the wave that owns the element: opaque to the caller).  gate_bits: such a buffer, written by a chain launch over the SAME tiles, hout and nmat, replaces the reads of
    * relu_src (which must still be given: it defines the gate) -- 1/32 of the bytes and no latency-exposed vector loads. */
   const uint64_t* gate_bits; uint64_t* y_bits;
 } dss2_chain_layer;

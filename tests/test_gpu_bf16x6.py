@@ -264,7 +264,7 @@ def test_tall_tile_chain_gate_bits_equal_fp32_gate(pkg, grid, B, H, nmat):
     nw = pkg.networks
     topo, N = _topo(pkg, [grid], B)
     gw = nw.chain_gate_words(topo, nmat, H)
-    assert gw == ((H + 31) // 32) * (4 * topo.nrb) * 4 and topo.nrb in (3, 6)
+    assert gw == ((H + 31) // 32) * 32 * ((4 * topo.nrb + 7) // 8) and topo.nrb in (3, 6)
     torch.manual_seed(11)
     Ws = [torch.randn(H, H, device=DEV) * (1.5 / H ** 0.5) for _ in range(nmat)]
     plan = nw._PackPlan([Ws], DEV, bf16_groups=(0,))

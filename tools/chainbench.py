@@ -21,7 +21,28 @@ print("tile GEMM:", "bf16x6 (v_mfma_f32_32x32x16_bf16 x 6)" if B16 else "fp32 (v
 h = torch.randn(N, H, device=dev); g = torch.randn(N, H, device=dev); bias = torch.randn(H, device=dev)
 outs = [torch.empty(N, H, device=dev) for _ in range(nl)]
 acts = [torch.randn(N, H, device=dev) for _ in range(nl)]
-fwd = lambda: nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=pf, Y=o, bias=bias, relu=True) for o in outs], b_format=int(B16))
+# CHAINBENCH_FWD=pre,ybits,drop: the model's forward extras -- folded bias of layer 0 (prebias + row scales), sign-bit words, dropout
+_extras = set(filter(None, os.environ.get("CHAINBENCH_FWD", "").split(",")))
+_pb, _prs = torch.randn(nmat, H, device=dev), torch.rand(N, 4, device=dev)
+_snap = torch.tensor([12345, 3], dtype=torch.int64, device=dev)
+
+
+def fwd():
+    gwf = nw.chain_gate_words(topo, nmat, H) if ("ybits" in _extras and B16) else 0
+    ls = [dict(Bp=pf, Y=o, bias=bias, relu=True) for o in outs]
+    if "pre" in _extras:
+        ls[0]["prebias"] = _pb
+    if gwf:
+        for l_, b_ in zip(ls, fwd_bits):
+            l_["y_bits"] = b_
+    if "drop" in _extras:
+        for i_, l_ in enumerate(ls):
+            l_["drop_id"] = i_ + 1
+    nw.gemm_prop_chain(topo, h, H, nmat, ls, pre_rowscale=(_prs if "pre" in _extras else None),
+                       drop=((_snap, 0.3) if "drop" in _extras else None), b_format=int(B16))
+
+
+fwd_bits = [torch.zeros(topo.ntiles * max(1, nw.chain_gate_words(topo, nmat, H) if B16 else 1), dtype=torch.int64, device=dev) for _ in range(nl)]
 gw = nw.chain_gate_words(topo, nmat, H) if B16 else 0      # tall tiles: sign-bit words instead of the activations (needs real activations)
 bits = [torch.zeros(topo.ntiles * gw, dtype=torch.int64, device=dev) for _ in range(nl)] if gw else [None] * nl
 if gw:
