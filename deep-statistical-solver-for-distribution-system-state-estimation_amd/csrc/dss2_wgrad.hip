@@ -51,22 +51,26 @@ constexpr bool wgrad_prop4(int nrb, int nmat, int nb) {
   return !((nrb == 2 && nmat == 2 && (nb == 2 || nb == 4)) || (nrb == 3 && nmat == 2 && nb == 2) || (nrb == 4 && (nmat == 3 || nmat == 4) && nb == 2));
 }
 
-template <int NB> struct WgradGeom {
-  static constexpr int NW = NB >= 2 ? 8 : 4;
+// W8 (tall tiles, NB == 1): eight waves all the same -- the two halves split the k steps (rows) of every MFMA phase instead of the
+// output blocks, so that, as with NB >= 2, the propagation / staging of one wave of a SIMD sits under the MFMAs of the other.
+// The 4-wave form runs one wave per SIMD there: 18.4 K cycles of MFMAs per 192-row tile out of 28 K (tools/wstamps.py).
+template <int NB, bool W8 = false> struct WgradGeom {
+  static constexpr int NW = (NB >= 2 || W8) ? 8 : 4;
   static constexpr int NT = NW * 64;
   static constexpr int NBW = NB >= 2 ? NB / 2 : 1;   // output blocks per wave
 };
 
 
-template <int NRB, int NMAT, int NB>
-__global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgrad_args p, int nibg, const WgradBatch wb, int ksplit) {
+template <int NRB, int NMAT, int NB, bool W8 = false>
+__global__ void __launch_bounds__((WgradGeom<NB, W8>::NT)) wgrad_kernel(const dss2_wgrad_args p, int nibg, const WgradBatch wb, int ksplit) {
   const float* __restrict__ Gp = wb.n > 0 ? wb.G[blockIdx.z] : p.G;
   const float* __restrict__ Xp = wb.n > 0 ? wb.X[blockIdx.z] : p.X;
   float* __restrict__ slabp = wb.n > 0 ? wb.slab[blockIdx.z] : p.slab;
   const float* __restrict__ rs2 = wb.n > 0 ? wb.rowscale2[blockIdx.z] : p.rowscale2;
   constexpr int TM = NRB * 32;
   constexpr int LDZ = NB * 32;
-  constexpr int NW = WgradGeom<NB>::NW, NT = WgradGeom<NB>::NT, NBW = WgradGeom<NB>::NBW;
+  constexpr int NW = WgradGeom<NB, W8>::NW, NT = WgradGeom<NB, W8>::NT, NBW = WgradGeom<NB, W8>::NBW;
+  static_assert(!W8 || NB == 1, "W8 is the eight-wave form of the one-output-block kernel");
   constexpr int NG4 = TM * LDZ / 4 / NT;   // float4 of the G slab per thread
   constexpr int NX4 = TM * XW / 4 / NT;    // float4 of the X slab per thread
   static_assert(NG4 * NT * 4 == TM * LDZ && NX4 * NT * 4 == TM * XW, "slabs must tile the threads");
@@ -86,15 +90,17 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   const int xw = (NB == 1) ? min(XW, ((p.hin + 31) >> 5) << 5) : XW;
   f32x4* Dsc = reinterpret_cast<f32x4*>(Xs + TM * xw);   // [TM] row scales of the tile (rowscale2)
   f32x4* Bsum = reinterpret_cast<f32x4*>(Xs + TM * xw + TM * 4);   // [NT] running partial column sums (fast_bias)
-  int2* ell = reinterpret_cast<int2*>(Xs + TM * xw + TM * 4 + NT * 4);
-  int* lrow = reinterpret_cast<int*>(Xs + TM * xw + TM * 4 + NT * 4);
+  // (W8: no running bias partials -- the tall tile leaves no LDS for 512 more 16-byte slots; the per-tile pass runs instead)
+  int2* ell = reinterpret_cast<int2*>(Xs + TM * xw + TM * 4 + (W8 ? 0 : NT * 4));
+  int* lrow = reinterpret_cast<int*>(Xs + TM * xw + TM * 4 + (W8 ? 0 : NT * 4));
   int2* lent = reinterpret_cast<int2*>(lrow + TM + 2);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int c32 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int obh = wave >> 2;
+  const int role = wave >> 2;                 // which half of the workgroup (phase order, see phase())
+  const int obh = NB >= 2 ? role : 0;         // output-block half (NB >= 2)
   const int obg = blockIdx.y / nibg, ibg = blockIdx.y - obg * nibg;
   const int gcol0 = obg * LDZ;
   const int xcol0 = ibg * XW;
@@ -103,9 +109,10 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   // (k steps j = ks, ks + KS, ..) for the same output block instead; the partial accumulators meet once, after the last
   // tile, in a fixed order through LDS.
   const int nib_act = min(4, (p.hin - xcol0 + 31) >> 5);
-  const int KS = (NB == 1 && ksplit) ? (nib_act == 1 ? 4 : (nib_act == 2 ? 2 : 1)) : 1;
-  const int ibw = KS > 1 ? (wave & 3) % nib_act : (wave & 3);
-  const int ks = KS > 1 ? (wave & 3) / nib_act : 0;
+  constexpr int KSC = W8 ? 2 : 1;             // W8: the halves split the k steps, whatever the input width
+  const int KS = W8 ? 2 : ((NB == 1 && ksplit) ? (nib_act == 1 ? 4 : (nib_act == 2 ? 2 : 1)) : 1);
+  const int ibw = W8 ? (wave & 3) : (KS > 1 ? (wave & 3) % nib_act : (wave & 3));
+  const int ks = W8 ? role : (KS > 1 ? (wave & 3) / nib_act : 0);
   const bool wave_active = (xcol0 + ibw * 32) < p.hin;
 
   f32x16 acc[NMAT][NBW];
@@ -127,7 +134,8 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   // of those columns across ALL its tiles (in its own LDS slot: the register file is full); the partials meet
   // once, after the last tile.
   const bool fast_bias = gvec && !p.rowscale && !rs2 && ibg == 0 && (NT % (LDZ / 4) == 0);
-  if (fast_bias) Bsum[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum_reg = {0.f, 0.f, 0.f, 0.f};      // W8: the running partial sums in registers (no LDS left for 512 slots)
+  if (fast_bias && !W8) Bsum[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   constexpr bool FASTMMA = wgrad_fast_mma(NRB, NMAT, NB);
   auto mma = [&](const float* Z, f32x16 (&a)[NBW], int R) {
@@ -156,19 +164,19 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
       // immediate offsets, so a step is 2 ds_read_b32 + 1 MFMA instead of ~14 instructions of address arithmetic,
       // clamping and waits -- one wave per SIMD issues ~4 cycles per instruction and the rolled loop ran at ~120
       // cycles per 64-cycle MFMA (tools/wstamps.py ober179: 11.5 K cycles for the 96 MFMAs of a phase).
-      if (KS == 1 && xw == XW) {
-        constexpr int U = (NB == 1 && NRB >= 4) ? 8 : 4;      // (tall tiles: one wave per SIMD, registers to spare)
-        const float* zq = Z + half * LDZ + obh * NBW * 32 + c32;
-        const float* xq = Xs + half * XW + ibw * 32 + c32;
+      if (KS == KSC && xw == XW) {
+        constexpr int U = (NB == 1 && NRB >= 4 && !W8) ? 8 : 4;      // (tall tiles: one wave per SIMD, registers to spare)
+        const float* zq = Z + (half + 2 * ks) * LDZ + obh * NBW * 32 + c32;
+        const float* xq = Xs + (half + 2 * ks) * XW + ibw * 32 + c32;
         float bq[2][U], aq[2][U][NBW];
         auto ldg = [&](float (&b)[U], float (&av)[U][NBW], int g) {
-          const float* zg = zq + g * (U * 2 * LDZ);
-          const float* xg = xq + g * (U * 2 * XW);
+          const float* zg = zq + g * (U * 2 * KSC * LDZ);
+          const float* xg = xq + g * (U * 2 * KSC * XW);
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            b[u] = xg[u * 2 * XW];
+            b[u] = xg[u * 2 * KSC * XW];
 #pragma unroll
-            for (int ob = 0; ob < NBW; ++ob) av[u][ob] = zg[u * 2 * LDZ + ob * 32];
+            for (int ob = 0; ob < NBW; ++ob) av[u][ob] = zg[u * 2 * KSC * LDZ + ob * 32];
           }
         };
         auto mmg = [&](const float (&b)[U], const float (&av)[U][NBW]) {
@@ -325,7 +333,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
   bool stamp_on = false; (void)stamp_on;
   auto phase = [&](const float* Zs, float* Zd, f32x16 (&a)[NBW], int R, bool do_prop, bool do_bias, int ts, int s0) {
     (void)s0;
-    if (NW == 8 && obh == 1) {
+    if (NW == 8 && role == 1) {
       if (do_bias && !fast_bias) bias_sums(ts, R);
       WSTAMP(s0);
       if (do_prop) prop(Zs, Zd);
@@ -351,11 +359,15 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     const int ts = p.tile_start[tile];
     const int R = p.tile_start[tile + 1] - ts;
     constexpr int QG = LDZ / 4;
-    const int QX = xw >> 2;
+    const int QX = W8 ? XW / 4 : (xw >> 2);
+    // (W8, 256 registers: the per-load 64-bit addresses are loop invariants the compiler would carry -- spilled -- through the tile
+    //  loop, and a scratch reload inside this burst waits for every load issued before it: 8.7 K cycles instead of 2.2 K)
+    int tidl = tid;
+    if (W8) asm volatile("" : "+v"(tidl));
     if (gvec) {
 #pragma unroll
       for (int i = 0; i < NG4; ++i) {
-        const int idx = tid + i * NT;
+        const int idx = tidl + i * NT;
         const int r = idx / QG, c = (idx - r * QG) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (r < R && gcol0 + c < p.hout) v = *reinterpret_cast<const f32x4*>(Gp + (size_t)(ts + r) * p.ldg + gcol0 + c);
@@ -365,7 +377,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     if (xvec) {
 #pragma unroll
       for (int i = 0; i < NX4; ++i) {
-        const int idx = tid + i * NT;
+        const int idx = tidl + i * NT;
         const int r = idx / QX, c = (idx - r * QX) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (idx < TM * QX && r < R && xcol0 + c < p.hin) v = *reinterpret_cast<const f32x4*>(Xp + (size_t)(ts + r) * p.ldx + xcol0 + c);
@@ -387,7 +399,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
         f32x4 sp = pg[0];
 #pragma unroll
         for (int i = 1; i < NG4; ++i) sp += pg[i];
-        Bsum[tid] += sp;
+        if (W8) bsum_reg += sp; else Bsum[tid] += sp;
       }
     } else {
       for (int idx = tid; idx < TM * LDZ; idx += NT) {
@@ -445,6 +457,9 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
     // Next tile's slabs -> registers.  Issuing a wave's sixteen 16-byte loads blocks it for 2-5 K cycles (the CU's
     // vector-memory pipe moves 64 B/clk; tools/wstamps.py), so with PF it is done inside the MFMA phase, the two
     // halves at different points: while one wave of a SIMD feeds the memory pipe the other keeps the MFMA pipe busy.
+    // (W8: all eight waves at once, 4.4 K cycles with the MFMA pipe idle.  Issued inside the first phase instead, the halves at
+    //  different points, the burst takes 7.9 K cycles beside the partner's MFMAs -- rolled loop, no spills -- and the tile 34.6 K
+    //  instead of 32.0 K; as two inlined copies it spills 53 registers.)
     if (!PF && next < p.ntiles) issue_loads(next);
     WSTAMP(2);
     // ---- narrow mode: append P^m G as column blocks [m*hout, (m+1)*hout) of the same 32-wide slab
@@ -484,9 +499,9 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
       prop(Zb, Zc);
       __syncthreads();
       WSTAMP(5);
-      if (obh == 0 && next < p.ntiles) issue_loads(next);
+      if (role == 0 && next < p.ntiles) issue_loads(next);
       mma(Za, acc[0], R);
-      if (obh != 0 && next < p.ntiles) issue_loads(next);
+      if (role != 0 && next < p.ntiles) issue_loads(next);
       if (NW == 8 && !fast_bias) bias_sums(ts, R);
       mma(Zb, acc[1 % NMAT], R);
       mma(Zc, acc[2 % NMAT], R);
@@ -514,7 +529,7 @@ __global__ void __launch_bounds__(WgradGeom<NB>::NT) wgrad_kernel(const dss2_wgr
 
   if (fast_bias) {   // (uniform) partial column sums -> LDS [NT / (LDZ/4)][LDZ] -> the owner threads
     constexpr int QG = LDZ / 4;
-    *reinterpret_cast<f32x4*>(Za + (tid / QG) * LDZ + (tid % QG) * 4) = Bsum[tid];    // the slabs are dead: last tile done
+    *reinterpret_cast<f32x4*>(Za + (tid / QG) * LDZ + (tid % QG) * 4) = W8 ? bsum_reg : Bsum[tid];    // the slabs are dead: last tile done
     __syncthreads();
     const int t = tid - (NT - LDZ);
     if (t >= 0) {
@@ -677,11 +692,11 @@ static int launch_wgrad_narrow_stream(const dss2_wgrad_args& a, hipStream_t stre
 }
 
 // nmat here = number of MFMA matrix passes (1 in narrow mode); graph = a graph slice is staged
-static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz, int ell_width, bool graph, int hin = XW) {
+static size_t wgrad_lds(int nrb, int nmat, int nb, int max_nnz, int ell_width, bool graph, int hin = XW, bool w8 = false) {
   const size_t TM = (size_t)nrb * 32;
   const size_t xw = nb == 1 ? (size_t)((((hin + 31) >> 5) << 5) < XW ? (((hin + 31) >> 5) << 5) : XW) : (size_t)XW;
   size_t b = TM * (size_t)nb * 32 * 4 * (wgrad_pf(nrb, nmat) ? 3 : (nmat > 1 ? 2 : 1)) + TM * xw * 4 + TM * 16;
-  b += (size_t)(nb >= 2 ? 512 : 256) * 16;   // running bias partials, one 16-byte slot per thread
+  if (!w8) b += (size_t)(nb >= 2 ? 512 : 256) * 16;   // running bias partials, one 16-byte slot per thread
   if (graph) b += ell_width > 0 ? TM * (size_t)ell_width * 8 : (TM + 2) * 4 + (size_t)max_nnz * 8;
   if (nb == 1 && b < 3 * 16 * 64 * 4) b = 3 * 16 * 64 * 4;     // the K-split's final reduction: three partial accumulators
   return b;
@@ -711,16 +726,23 @@ static int pick_nb(int nrb, int nmat, int hout, int max_nnz, int ell_width) {
   return 0;
 }
 
-template <int NRB, int NMAT, int NB>
+// the eight-wave form of the one-output-block kernel: 192-row tiles with full 128-column input groups
+static bool wgrad_w8(const dss2_wgrad_args& a, int nb) {
+  static const int on = [] { const char* e = getenv("DSS2_WGRAD_W8"); return e ? atoi(e) : 1; }();
+  return on && a.nrb == 6 && nb == 1 && !a.narrow && a.nmat == 3 && (a.hin % 128) == 0 && a.ell_width > 0 &&      // (K = 1 spills 42 registers)
+         wgrad_lds(6, a.nmat, 1, a.max_nnz, a.ell_width, true, a.hin, true) <= (size_t)kMaxLdsBytes;
+}
+
+template <int NRB, int NMAT, int NB, bool W8 = false>
 static int launch_wgrad(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb) {
   static std::atomic<uint32_t> lds_done{0};
-  auto kern = wgrad_kernel<NRB, NMAT, NB>;
+  auto kern = wgrad_kernel<NRB, NMAT, NB, W8>;
   if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "wgrad")) return 1;
   const int nob = (a.hout + 31) / 32, nib = (a.hin + 31) / 32;
   const int nobg = (nob + NB - 1) / NB, nibg = (nib + 3) / 4;
-  const size_t lds = wgrad_lds(NRB, NMAT, NB, a.max_nnz, a.ell_width, NMAT > 1 || a.narrow, a.hin);
+  const size_t lds = wgrad_lds(NRB, NMAT, NB, a.max_nnz, a.ell_width, NMAT > 1 || a.narrow, a.hin, W8);
   static const int ksplit = [] { const char* e = getenv("DSS2_WGRAD_KSPLIT"); return e ? atoi(e) : 1; }();
-  hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg, wb.n > 0 ? wb.n : 1), dim3(WgradGeom<NB>::NT), lds, stream, a, nibg, wb, ksplit);
+  hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg, wb.n > 0 ? wb.n : 1), dim3(WgradGeom<NB, W8>::NT), lds, stream, a, nibg, wb, ksplit);
   return check_launch("wgrad");
 }
 
@@ -783,6 +805,7 @@ static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::Wg
   const int nb = pick_nb(a.nrb, a.nmat, a.hout, a.max_nnz, a.ell_width);
   if (!nb) { set_error("wgrad: tile of %d rows does not fit LDS (nmat=%d nnz=%d)", a.nrb * 32, a.nmat, a.max_nnz); return 3; }
   hipStream_t s = as_stream(stream);
+  if (wgrad_w8(a, nb)) return launch_wgrad<6, 3, 1, true>(a, s, wb);
 #define DSS2_CASE(NRB, NMAT, NB) \
   if constexpr (!wgrad_spills(NRB, NMAT, NB)) { if (a.nrb == NRB && a.nmat == NMAT && nb == NB) return launch_wgrad<NRB, NMAT, NB>(a, s, wb); }
 #define DSS2_NMATS(NRB, NB) DSS2_CASE(NRB, 1, NB) DSS2_CASE(NRB, 2, NB) DSS2_CASE(NRB, 3, NB) DSS2_CASE(NRB, 4, NB)

@@ -34,7 +34,7 @@ if os.environ.get("WSTAMP_PF", "1") == "1":     # propagate-first schedule (NMAT
     show("closing barrier", t[:, :, 14] - t[:, :, 6])
     show("tile total", t[:, :, 14] - t[:, :, 0])
     sys.exit(0)
-if topo.nrb >= 4:      # tall tiles: the 4-wave kernel (NB = 1): every wave runs MFMA -> bias sums -> propagation per phase
+if topo.nrb >= 4 and (topo.nrb != 6 or os.environ.get("DSS2_WGRAD_W8", "1") == "0"):      # tall tiles: the 4-wave kernel (NB = 1; 192-row tiles: DSS2_WGRAD_W8=0): every wave runs MFMA -> bias sums -> propagation per phase
     for ph, s0 in (("phase 0", 3), ("phase 1", 7), ("phase 2", 11)):
         start = t[:, :4, 2] if s0 == 3 else t[:, :4, s0 - 1]
         show(f"{ph}: MFMA", h0[:, :, s0] - start)
