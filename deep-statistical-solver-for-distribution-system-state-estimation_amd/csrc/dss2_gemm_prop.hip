@@ -941,7 +941,7 @@ __global__ void __launch_bounds__(256) gemm_narrow_stream_kernel(const dss2_gemm
 static bool narrow_stream_ok(const dss2_gemm_prop_args& a) {
   static const int enabled = [] { const char* e = getenv("DSS2_NARROW_STREAM"); return e ? atoi(e) : 1; }();
   return enabled && a.nmat * a.narrow_h <= NS_MAXO && (a.kpad & 15) == 0 && (a.kreal & 3) == 0 && (a.ldx & 3) == 0 &&
-         (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && a.nrb <= 4 && (a.nmat == 1 || (a.ell_width > 0 && a.ell_tiles));
+         (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && (a.nrb <= 4 || a.nrb == 6) && (a.nmat == 1 || (a.ell_width > 0 && a.ell_tiles));
 }
 
 template <int NRB>
@@ -1061,6 +1061,7 @@ extern "C" int dss2_gemm_prop(const dss2_gemm_prop_args* ap, void* stream) {
         case 1: return launch_narrow_stream<1>(a, sn);
         case 2: return launch_narrow_stream<2>(a, sn);
         case 3: return launch_narrow_stream<3>(a, sn);
+        case 6: return launch_narrow_stream<6>(a, sn);
         default: return launch_narrow_stream<4>(a, sn);
       }
     }

@@ -679,7 +679,7 @@ static bool wgrad_narrow_stream_ok(const dss2_wgrad_args& a) {
   static const int enabled = [] { const char* e = getenv("DSS2_NARROW_STREAM"); return e ? atoi(e) : 1; }();
   const int tpr = a.hin >> 2;
   return enabled && a.narrow && a.nmat * a.hout <= WN_MAXO && (a.hin & 3) == 0 && tpr > 0 && tpr <= 256 && (256 % tpr) == 0 &&
-         (a.ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && !a.rowscale && a.nrb <= 4 &&
+         (a.ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && !a.rowscale && (a.nrb <= 4 || a.nrb == 6) &&
          (a.nmat == 1 || (a.ell_width > 0 && a.ell_tiles));
 }
 
@@ -789,6 +789,7 @@ static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::Wg
         case 1: return launch_wgrad_narrow_stream<1>(a, sn);
         case 2: return launch_wgrad_narrow_stream<2>(a, sn);
         case 3: return launch_wgrad_narrow_stream<3>(a, sn);
+        case 6: return launch_wgrad_narrow_stream<6>(a, sn);
         default: return launch_wgrad_narrow_stream<4>(a, sn);
       }
     }
