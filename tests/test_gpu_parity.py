@@ -460,6 +460,8 @@ def test_runner_trains_and_tracks_the_oracle(pkg, oracle):
     (["cigre14", "cigre14_reswitched"], 96, 256, 5, "MPN", 0.0),  # 8-wave chain (H = 256), mixed topologies
     (["ober_sub"], 24, 64, 4, "SkipMPN", 0.0),                  # 96-row tiles, narrow H -> 8 last layer, residual
     (["cigre14"], 128, 32, 6, "MPN", 0.3),                      # dropout masks inside the chain, H = 32
+    (["ober_sub"], 16, 128, 4, "MPN", 0.3),                     # 96-row tiles: two-workgroup chain, sign-bit gates WITH dropout zeros in them
+    (["ober179"], 8, 128, 4, "MPN", 0.3),                       # 192-row tiles: the same, eight-wave weight gradient
 ])
 def test_chained_and_batched_launches_equal_per_layer_launches(pkg, oracle, grids, B, hid, L, cls, p):
     """The layer chain (dss2_gemm_prop_chain), the batched weight gradient (dss2_wgrad_batched) and the folded

@@ -19,7 +19,8 @@ FALLBACKS = {
     # round-3 chain variants: the fp32-tile form of the bf16x6 chain instead of the split-plane form, the narrow head's data
     # gradient as its own launch; and the head's FORWARD inside the chained launch (off by default)
     "chain-variants-a": dict(DSS2_CHAIN_SP="0", DSS2_CHAIN_HEAD="0"),
-    "chain-variants-c": dict(DSS2_CHAIN_SP6_DIR="0"),      # tall tiles: the generic chain kernel instead of the per-direction ones
+    # tall tiles: the generic chain kernel instead of the per-direction ones, the four-wave weight gradient at 192 rows
+    "chain-variants-c": dict(DSS2_CHAIN_SP6_DIR="0", DSS2_WGRAD_W8="0"),
     # ... plus: 96-row tiles on the one-workgroup-per-CU chain (dss2_gemm_chain_sp3.hip), tall-tile ReLU gates read from the
     # activations instead of the forward chain's bit words
     "chain-variants-b": dict(DSS2_CHAIN_HEAD_FWD="1", DSS2_CHAIN_SP3B="0", DSS2_CHAIN_GATE_BITS="0"),
