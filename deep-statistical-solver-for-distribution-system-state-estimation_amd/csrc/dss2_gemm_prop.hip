@@ -585,7 +585,8 @@ __global__ void __launch_bounds__(256 * RSP, RSP > 1 ? 2 : gemm_waves_per_simd(N
       // tested once, the LDS / gate reads of 4 rows per lane issued before the first use.  One wave per SIMD issues an
       // instruction every ~4 cycles, and the general loop below spends most of them on flag tests and short waits (the
       // epilogue is 64 of this kernel's 299 us at the 179-bus shape, tools/ablate.py).
-      const bool simple = SEQ && !p.prebias && !p.dmask && !p.add_src && !p.drop_id && !p.rowscale;
+      // (also the single-matrix GEMMs of tall tiles -- the narrow head's data gradient, K = 8: pure epilogue, 72 -> 60 us at 192 rows)
+      const bool simple = (SEQ || (NMAT == 1 && NRB >= 3)) && !p.prebias && !p.dmask && !p.add_src && !p.drop_id && !p.rowscale;
       if (col0 < p.hout && simple) {
         const bool has_rs = p.relu_src != nullptr, has_bias = p.bias != nullptr, do_relu = (p.relu & 1) != 0;
         constexpr int NP4 = 2;      // passes of 16 rows per batch (four spill 13 registers in the 192-row instantiations)
