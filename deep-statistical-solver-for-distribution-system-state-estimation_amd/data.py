@@ -64,8 +64,14 @@ def _vminmax_scratch(node_param: torch.Tensor):
     """(scratch [130], valid): the per-workgroup (min, max) pairs of ``node_param[:, 0]`` (vn_kv) are a constant of the
     batch tensor, so they are computed once per tensor and not once per step: the cache is keyed by the identity of the
     tensor that owns the storage (``x`` for the usual ``x[:, 8:]`` view), its version counter, address and layout, and an
-    entry dies with its tensor."""
+    entry dies with its tensor.  (The version counter sees torch's own writes; the library's collate kernels write through raw
+    pointers into tensors they have just allocated, which are new cache keys, and ``invalidate_vminmax`` is there for callers
+    that refill a tensor through the C ABI.)"""
     import weakref
+    if torch.cuda.is_current_stream_capturing():
+        # a capture executes nothing and its replays run on whatever the static input holds by then: the captured step
+        # always carries its own vminmax launch and never reads or fills the cache (ADVICE r3)
+        return torch.empty(130, dtype=_F32, device=node_param.device), False
     base = node_param._base if node_param._base is not None else node_param
     key = id(base)
     sig = (base._version, node_param.data_ptr(), tuple(node_param.shape), tuple(node_param.stride()))
@@ -73,8 +79,6 @@ def _vminmax_scratch(node_param: torch.Tensor):
     if hit is not None and hit[0]() is base and hit[1] == sig:
         return hit[2], True
     vmm = torch.empty(130, dtype=_F32, device=node_param.device)
-    if torch.cuda.is_current_stream_capturing():
-        return vmm, False       # computed by the captured launch on every replay; never cached (a capture executes nothing)
     if len(_VMM_CACHE) >= 64:
         _VMM_CACHE.pop(next(iter(_VMM_CACHE)))
 
@@ -84,6 +88,16 @@ def _vminmax_scratch(node_param: torch.Tensor):
             _VMM_CACHE.pop(key, None)
     _VMM_CACHE[key] = (weakref.ref(base, _drop), sig, vmm)
     return vmm, False
+
+
+def invalidate_vminmax(node_param: Optional[torch.Tensor] = None) -> None:
+    """Forget the cached V_hv / V_lv of one tensor (or of all): for callers that rewrite a batch tensor through raw pointers
+    (C-ABI kernels), which torch's version counter does not see."""
+    if node_param is None:
+        _VMM_CACHE.clear()
+        return
+    base = node_param._base if node_param._base is not None else node_param
+    _VMM_CACHE.pop(id(base), None)
 
 
 _UNIT: Dict[str, torch.Tensor] = {}

@@ -57,12 +57,11 @@ def shard_bounds(num_graphs: int, rank: int, world: int):
     return g0, g0 + base + (1 if rank < rem else 0)
 
 
-def shard_batch(batch: Dict[str, object], rank: int, world: int) -> Dict[str, object]:
-    """Cut a collated batch (synthetic.make_batch layout, with 'graph_ptr') into this rank's whole
-    graphs; node indices are re-based to the shard.  Edges are assumed grouped by graph in graph
-    order (what PyG collation and synthetic.make_batch produce)."""
+def cut_batch(batch: Dict[str, object], g0: int, g1: int) -> Dict[str, object]:
+    """Graphs [g0, g1) of a collated batch (synthetic.make_batch layout, with 'graph_ptr') as a batch of their own; node
+    indices are re-based to the cut.  Edges are assumed grouped by graph in graph order (what PyG collation and
+    synthetic.make_batch produce)."""
     gp = batch["graph_ptr"]
-    g0, g1 = shard_bounds(int(batch["num_graphs"]), rank, world)
     n0, n1 = int(gp[g0]), int(gp[g1])
     ei = batch["edge_index"]
     sel = (ei[0] >= n0) & (ei[0] < n1)
@@ -74,6 +73,12 @@ def shard_batch(batch: Dict[str, object], rank: int, world: int) -> Dict[str, ob
     out.update(x=batch["x"][n0:n1], y=batch["y"][n0:n1], edge_attr=batch["edge_attr"][e0:e1],
                edge_index=(ei[:, e0:e1] - n0), num_graphs=g1 - g0, graph_ptr=gp[g0:g1 + 1] - n0)
     return out
+
+
+def shard_batch(batch: Dict[str, object], rank: int, world: int) -> Dict[str, object]:
+    """This rank's contiguous share of whole graphs (``shard_bounds``) of a collated batch."""
+    g0, g1 = shard_bounds(int(batch["num_graphs"]), rank, world)
+    return cut_batch(batch, g0, g1)
 
 
 def allreduce_loss_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
@@ -166,33 +171,65 @@ def attach_grad_allreduce(model: torch.nn.Module, group=None, async_op: bool = F
     every parameter to be None when backward runs (see ``hook`` below); a step that finds gradients in place reduces its
     buckets with blocking collectives instead.  ``n_chunks > 1`` (with ``async_op`` and ``overlap_param_groups``): the bucket
     travels as n_chunks collectives so that ``step_overlapped`` can step the first chunks' parameters while the last ones are
-    still in flight ("optimizer overlapped with the all-reduce")."""
+    still in flight ("optimizer overlapped with the all-reduce").
+
+    Parameters whose gradients do not come in a bucket -- blocks on the general route (input widths other than (8, 6),
+    dim_hid > 256: per-layer autograd nodes), the mask-embedding MLP of MaskEmbd*, the MultiMPN family -- get a tensor hook
+    each: one blocking collective per parameter on the gradient of this backward, before autograd accumulates it."""
     n = 0
     pending = [] if async_op else None
     model._dss2_pending_allreduce = pending
+    for h in getattr(model, "_dss2_param_hook_handles", ()):       # a second attach replaces the first one's hooks
+        h.remove()
+    model._dss2_param_hook_handles = []
     params = [p for p in model.parameters()]
 
-    def hook(flat, g=group, q=pending):
-        # The asynchronous mode hands autograd VIEWS of a bucket whose collective is still in flight.  That is only
-        # sound while AccumulateGrad adopts those views as the .grad tensors, i.e. while every .grad is None
-        # (``zero_grad(set_to_none=True)``, torch's default).  With a .grad already in place (gradient accumulation,
-        # ``set_to_none=False``) autograd would run ``p.grad += view`` on the compute stream beside the collective and
-        # the reduced values would never reach p.grad: such a step falls back to the blocking collective.
-        if q is not None and any(p.grad is not None for p in params):
-            q = None
-        cuts = getattr(model, "_dss2_bucket_cuts", None)
-        if q is not None and n_chunks > 1 and cuts is not None and len(cuts) == n_chunks and cuts[-1] == flat.numel():
-            a = 0
-            for c in cuts:            # one collective per chunk, issued in order: chunk i completes before chunk i + 1
-                allreduce_flat_grads(flat[a:c], g, q)
-                a = c
-            return flat
-        return allreduce_flat_grads(flat, g, q)
+    def make_hook(own):
+        own_numel = sum(p.numel() for p in own)
 
+        def hook(flat, g=group, q=pending):
+            # The asynchronous mode hands autograd VIEWS of a bucket whose collective is still in flight.  That is only
+            # sound while AccumulateGrad adopts those views as the .grad tensors, i.e. while every .grad the bucket feeds is
+            # None (``zero_grad(set_to_none=True)``, torch's default).  With a .grad already in place (gradient accumulation,
+            # ``set_to_none=False``) autograd would run ``p.grad += view`` on the compute stream beside the collective and
+            # the reduced values would never reach p.grad: such a step falls back to the blocking collective.  Only the
+            # parameters THIS bucket feeds are looked at: the block itself, or (a PFN / SkipPFN stack as one autograd node:
+            # one bucket through its first block's hook) the whole model -- blocks that run as separate nodes have had the
+            # .grad of the blocks above them set by the time their own bucket is ready (ADVICE r3).
+            if q is not None and any(p.grad is not None for p in (own if flat.numel() == own_numel else params)):
+                q = None
+            cuts = getattr(model, "_dss2_bucket_cuts", None)
+            if q is not None and n_chunks > 1 and cuts is not None and len(cuts) == n_chunks and cuts[-1] == flat.numel():
+                a = 0
+                for c in cuts:            # one collective per chunk, issued in order: chunk i completes before chunk i + 1
+                    allreduce_flat_grads(flat[a:c], g, q)
+                    a = c
+                return flat
+            return allreduce_flat_grads(flat, g, q)
+        return hook
+
+    def param_hook(grad, g=group):
+        # parameters whose gradients are NOT produced in a flat bucket: one blocking collective per parameter on this
+        # backward's contribution, before autograd accumulates it (correct under gradient accumulation as well)
+        grad = grad.contiguous()
+        allreduce_flat_grads(grad, g, None)
+        return grad
+
+    bucketed = set()
     for m in model.modules():
         if hasattr(m, "convs") and hasattr(m, "edge_aggr") and hasattr(m, "_plan"):
-            m._grad_bucket_hook = hook
             n += 1
+            if m.edge_aggr.fused_dims() if hasattr(m.edge_aggr, "fused_dims") else True:
+                own = list(m._params()) if hasattr(m, "_params") else list(m.parameters())
+                m._grad_bucket_hook = make_hook(own)
+                bucketed.update(id(p) for p in own)
+            else:
+                m._grad_bucket_hook = None          # the general route (other input widths, dim_hid > 256): per-layer nodes
+    # everything the buckets do not carry -- the general route's blocks, MaskEmbd*'s embedding MLP, the MultiMPN family --
+    # is reduced parameter by parameter (not the tuned path: one small collective each)
+    for p in params:
+        if id(p) not in bucketed and p.requires_grad:
+            model._dss2_param_hook_handles.append(p.register_hook(param_hook))
     return n
 
 

@@ -136,16 +136,21 @@ class Topology:
             return self.__dict__[name]
         raise AttributeError(name)
 
+    @staticmethod
+    def _read_stats(meta: torch.Tensor) -> Dict[str, int]:
+        m = meta.tolist()
+        if m[5] == 1:
+            raise ValueError("edge_index holds node ids outside [0, num_nodes)")
+        if m[5] == 2:
+            raise ValueError("TopologyHint.max_degree is smaller than a row of the batch")
+        return dict(max_deg=m[0], max_degT=m[1], max_segment=m[2], n_segments=m[3], min_segment=m[4], error=m[5],
+                    max_nnz=m[6], max_nnzT=m[7], ntiles_cand=m[8:16])
+
     def stats(self) -> Dict[str, int]:
-        """Exact build statistics (one 64-byte device-to-host copy, cached): degrees, segments, error flag."""
+        """Exact build statistics of the PRIMARY tiling (one 64-byte device-to-host copy, cached): degrees, segments, error
+        flag.  An alternate tiling (``tiles_for``) is built on its own copy of these 16 words and never shows up here."""
         if self._stats is None:
-            m = self._meta.tolist()
-            self._stats = dict(max_deg=m[0], max_degT=m[1], max_segment=m[2], n_segments=m[3], min_segment=m[4], error=m[5],
-                               max_nnz=m[6], max_nnzT=m[7], ntiles_cand=m[8:16])
-            if m[5] == 1:
-                raise ValueError("edge_index holds node ids outside [0, num_nodes)")
-            if m[5] == 2:
-                raise ValueError("TopologyHint.max_degree is smaller than a row of the batch")
+            self._stats = self._read_stats(self._meta)
         return self._stats
 
     def tiles_for(self, nrb: int):
@@ -174,6 +179,15 @@ class Topology:
             choices = (int(self._nrb_forced),) if self._nrb_forced else ((int(env),) if env else _NRB_CHOICES)
         st = _stream(dev)
         hint = self.hint
+        # an alternate tiling works on a copy of the statistics words (the walk and the ELL build write per-tiling maxima
+        # into them): the primary tiling's statistics stay what they were
+        meta = self._meta if store else self._meta.clone()
+
+        def read_stats():
+            if store:
+                self._stats = None
+                return self.stats()
+            return self._read_stats(meta)
         if hint is not None and N % hint.nodes_per_graph == 0:
             # ---- no device-to-host copy: uniform graphs => closed-form tiles, degrees from the hint
             n, G = hint.nodes_per_graph, N // hint.nodes_per_graph
@@ -194,8 +208,7 @@ class Topology:
             max_deg = max_degT = int(hint.max_degree)
             max_segment = n
             if os.environ.get("DSS2_CHECK", "0") == "1":      # debugging aid: read the build's error flag after all (ONE host sync)
-                self._stats = None
-                self.stats()
+                read_stats()
             nnz_bound = per * hint.max_edges_per_graph * (2 if self.directed else 1)
             exact_nnz = False
         else:
@@ -205,9 +218,8 @@ class Topology:
             tm_host = (C.c_int32 * len(choices))(*[32 * c for c in choices])
             ptrs = (C.c_void_p * len(choices))(*[t.data_ptr() for t in cands])
             _lib.check(L.dss2_tiles_walk(self._lastcut.data_ptr(), N, tm_host, len(choices), ptrs, cap,
-                                         self._meta[8:].data_ptr(), st), "dss2_tiles_walk")
-            self._stats = None
-            s = self.stats()
+                                         meta[8:].data_ptr(), st), "dss2_tiles_walk")
+            s = read_stats()
             max_deg, max_degT, max_segment = s["max_deg"], s["max_degT"], s["max_segment"]
             best = None
             for i, cand in enumerate(choices):
@@ -235,11 +247,10 @@ class Topology:
         b.tile_start, b.ntiles, b.tm, b.ell_width, b.ellT_width = tile_start.data_ptr(), nt, tm, ell, ellT
         b.ell_tiles, b.ell_ent_tiles = (ell_tiles.data_ptr() if ell else None), (ell_ent_tiles.data_ptr() if ell else None)
         b.ellT_tiles, b.ellT_ent_tiles = (ellT_tiles.data_ptr() if ellT else None), (ellT_ent_tiles.data_ptr() if ellT else None)
-        b.meta = self._meta.data_ptr()
+        b.meta = meta.data_ptr()
         _lib.check(L.dss2_ell_tiles_build(C.byref(b), st), "dss2_ell_tiles_build")
         if exact_nnz and (ell == 0 or ellT == 0):      # CSR staging in the tile kernels (hub graphs): exact sizes needed
-            self._stats = None
-            s = self.stats()
+            s = read_stats()
             max_nnz, max_nnzT = s["max_nnz"], s["max_nnzT"]
         elif exact_nnz:                                 # ELL staging: the CSR size of a tile is not used by any kernel
             max_nnz, max_nnzT = max_deg * tm, max_degT * tm
@@ -248,9 +259,9 @@ class Topology:
         d = dict(global_only=False, nrb=nrb, ntiles=nt, tile_start=tile_start, utilisation=util, max_segment=max_segment,
                  max_nnz=max_nnz, max_nnzT=max_nnzT, ell=ell, ellT=ellT, ell_tiles=ell_tiles,
                  ellT_tiles=ellT_tiles, ell_ent_tiles=ell_ent_tiles, ellT_ent_tiles=ellT_ent_tiles)
-        self._stats = None            # (the ELL build added the per-tile entry counts to the statistics)
         if not store:
             return d
+        self._stats = None            # (the ELL build added the per-tile entry counts to the statistics)
         self.__dict__.update(d)
         self._tiles_built = True
 

@@ -221,3 +221,58 @@ def test_chunked_bucket_and_overlapped_optimizer_step():
     for r in range(world):
         ok, n_pending, order, left = ret[r]
         assert ok and n_pending == 2 and order == [0, 1] and left == 0, ret[r]
+
+
+class _TwoBlocksAndAHead(torch.nn.Module):
+    """Two bucket blocks run as SEPARATE autograd nodes plus a plain Linear whose gradients come in no bucket (what the
+    general route's per-layer nodes, MaskEmbd*'s embedding MLP and the MultiMPN family look like to parallel.py)."""
+
+    def __init__(self):
+        super().__init__()
+        self.a, self.b = _BucketBlock(), _BucketBlock()
+        self.head = torch.nn.Linear(1, 3)
+
+    def forward(self, scale):
+        return self.head((self.a(scale) + 2.0 * self.b(scale)).view(1, 1)).sum()
+
+
+def _param_hook_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    pkg = load_pkg()
+    torch.set_num_threads(1)
+    pkg.parallel.init_from_env("gloo")
+    torch.manual_seed(0)
+    m = _TwoBlocksAndAHead()
+    single = _TwoBlocksAndAHead()
+    single.load_state_dict(m.state_dict())
+    assert pkg.parallel.attach_grad_allreduce(m, async_op=True) == 2
+    assert len(m._dss2_param_hook_handles) == 2               # head.weight, head.bias: reduced parameter by parameter
+    m(torch.tensor(rank + 1.0)).backward()
+    # both blocks' buckets travelled asynchronously: block a's hook ran after block b's .grad was set (separate nodes) and
+    # must look at its OWN parameters only (ADVICE r3)
+    joined = pkg.parallel.wait_grad_allreduce(m)
+    # single-process reference: the sum over ranks of the per-rank losses
+    sum(single(torch.tensor(r + 1.0)) for r in range(world)).backward()
+    ok = all(torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-6) for p, q in zip(m.parameters(), single.parameters()))
+    # a second attach (blocking) replaces the tensor hooks instead of stacking a second collective on them
+    pkg.parallel.attach_grad_allreduce(m)
+    n_handles = len(m._dss2_param_hook_handles)
+    for p in m.parameters():
+        p.grad = None
+    m(torch.tensor(rank + 1.0)).backward()
+    ok2 = all(torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-6) for p, q in zip(m.parameters(), single.parameters()))
+    ret[rank] = (ok, joined, ok2, n_handles)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_parameters_outside_the_buckets_are_reduced_and_async_checks_only_the_own_block():
+    """ADVICE r3 (medium + low): gradients that do not come in a flat bucket must still be all-reduced (tensor hooks), and a
+    block's asynchronous collective must not be downgraded because the blocks above it already have their .grad."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_param_hook_worker, args=(world, 29800 + os.getpid() % 60, ret), nprocs=world, join=True)
+    for r in range(world):
+        ok, joined, ok2, n_handles = ret[r]
+        assert ok and joined == 2 and ok2 and n_handles == 2, ret[r]
