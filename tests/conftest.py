@@ -79,6 +79,10 @@ CASES = {
     "mpn_ober": ("MPN", (8, 6, 2, 32, 2, 2, 0.0), True),
     "mpn_mixed": ("MPN", (8, 6, 2, 64, 2, 2, 0.0), True),
     "mpn_undirected_input": ("MPN", (8, 6, 2, 32, 2, 2, 0.0), False),
+    # the C2 model at the three tile heights (64 / 96 / 192 rows): make_goldens.py flagship
+    "mpn_c2model": ("MPN", (8, 6, 2, 128, 4, 2, 0.0), True),
+    "mpn_ober_h128": ("MPN", (8, 6, 2, 128, 4, 2, 0.0), True),
+    "mpn_ober179_h128": ("MPN", (8, 6, 2, 128, 4, 2, 0.0), True),
 }
 LOSS_CASES = ["loss_real", "loss_violate_cigre", "loss_violate_ober"]
 

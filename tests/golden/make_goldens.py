@@ -17,6 +17,8 @@ Fixtures written:
     tests/golden/dataset64.npz          raw tables of 64 real CIGRE-14 samples, the standard-normal draws
                                         the reference consumed, and its data_from_pickles output on them
                                         (python tests/golden/make_goldens.py dataset64 writes only this one)
+    tests/golden/case_mpn_{c2model,ober_h128,ober179_h128}.npz   the C2 model at the three tile heights
+                                        (python tests/golden/make_goldens.py flagship)
 """
 import os
 import pickle
@@ -231,6 +233,22 @@ def extras():
         save(f"case_{name}.npz", **arr)
 
 
+def flagship():
+    """Reference-generated goldens at the flagship shapes (python make_goldens.py flagship): the C2 model
+    (dim_hid 128, 4 layers) on the 64 real CIGRE-14 graphs (64-row tiles: split-plane layer chain, bf16x6 weight gradient),
+    on ober_sub graphs (96-row tiles) and on the synthetic 179-bus feeder (192-row tiles)."""
+    N = ref_networks
+    z = np.load(os.path.join(HERE, "cigre14_real64.npz"))
+    real = dict(x=torch.from_numpy(z["x"]), edge_index=torch.from_numpy(z["edge_index"]), edge_attr=torch.from_numpy(z["edge_attr"]),
+                stats=tuple(torch.from_numpy(z[k]) for k in ("x_mean", "x_std", "edge_mean", "edge_std")))
+    torch.manual_seed(31)
+    run_case("mpn_c2model", N.MPN(8, 6, 2, 128, 4, 2, 0.0), real)
+    torch.manual_seed(32)
+    run_case("mpn_ober_h128", N.MPN(8, 6, 2, 128, 4, 2, 0.0), synthetic.make_batch(["ober_sub"], 6, seed=32))
+    torch.manual_seed(33)
+    run_case("mpn_ober179_h128", N.MPN(8, 6, 2, 128, 4, 2, 0.0), synthetic.make_batch(["ober179"], 4, seed=33))
+
+
 def main():
     grids()
     real = real_cigre()
@@ -291,5 +309,7 @@ if __name__ == "__main__":
         dataset64()
     elif len(sys.argv) > 1 and sys.argv[1] == "extras":
         extras()
+    elif len(sys.argv) > 1 and sys.argv[1] == "flagship":
+        flagship()
     else:
         main()
