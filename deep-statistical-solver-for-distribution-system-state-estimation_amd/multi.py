@@ -110,7 +110,9 @@ class _EdgeAggrGeneralFn(torch.autograd.Function):
         # second Linear after the (linear) aggregation: sum_e (W2 h_e + b2) = W2 S + deg b2, then dropout + ReLU if inside a stack
         gemm_prop(topo, S, h, h, p2.fwd[0], 1, ho, y, bias=b2, rowscale=topo.deg, relu=relu,
                   drop=((snap, p, 1) if snap is not None else None))
-        ctx.save_for_backward(x, ea, AB, S, y, W1, b1)
+        # (y is only needed for the gate; the last layer's output is not saved: gsp_wls_edge masks the model output IN PLACE,
+        #  data.py:413, and a saved tensor must not change under autograd)
+        ctx.save_for_backward(x, ea, AB, S, y if relu else None, W1, b1)
         ctx.meta = (topo, mod, ldx, ldea, relu, snap, p)
         return y
 
@@ -199,7 +201,7 @@ class _TAGConvPostFn(torch.autograd.Function):
         relu, snap, p = _post_spec(mod, x.device)
         out = (_tagconv_forward_global if glob else _tagconv_forward)(topo, x, plan.fwd[0], bias, nmat, hin, hout, relu=relu,
                                drop=((snap, p, 1) if snap is not None else None))
-        ctx.save_for_backward(x, out)
+        ctx.save_for_backward(x, out if relu else None)       # (see _EdgeAggrGeneralFn: an un-gated output may be modified in place)
         ctx.meta = (topo, mod, relu, snap, p, glob)
         return out
 

@@ -56,15 +56,23 @@ def tiles_of(topo):
     """The tile set the whole-stack kernels run on.  They are latency-bound per tile (one workgroup walks a tile through ~45
     dependent phases), so as long as 64-row tiles leave CUs idle, 32-row tiles -- twice as many workgroups, half the work
     per phase -- are faster (B = 64: 16 -> 32 workgroups); big batches keep the 64-row tiles (less overhead per graph)."""
-    if topo.global_only or topo.nrb > 2:
+    if topo.global_only:
         return None
     if STACK_NRB in ("1", "2"):
         return topo.tiles_for(int(STACK_NRB))
-    if topo.nrb == 2 and topo.ntiles <= _cu_count(topo.device):
+    base = topo
+    if topo.nrb > 2:
+        # small graphs the primary tiling happened to pack into taller tiles (ragged or tiny batches: 29 CIGRE graphs tile as
+        # well at 96 rows as at 64): the stack kernels run them on a 64-row tiling of their own, so that the route -- and
+        # with it every razor-edge ReLU gate -- does not depend on the batch size (tests/test_gpu_shard_emulation.py)
+        base = topo.tiles_for(2)
+        if base is None or base.ell_tiles is None or base.ellT_tiles is None:
+            return None
+    if base.nrb == 2 and base.ntiles <= _cu_count(topo.device):
         alt = topo.tiles_for(1)
         if alt is not None and alt.ell_tiles is not None and alt.ellT_tiles is not None:
             return alt
-    return topo
+    return base
 
 
 def supported(blocks, topo) -> Optional[_lib.StackDims]:

@@ -141,3 +141,36 @@ def test_mixed_dataset_with_different_bus_counts(pkg, oracle):
     out = mine(batch.x[:, :8], batch.edge_index, batch.edge_attr[:, :6])
     out64 = ref(batch.x[:, :8].double().cpu(), ei, batch.edge_attr[:, :6].double().cpu())
     _check(mine, ref, out, out64, tol=max(1e-4, 8.0 / batch.x.shape[0]))
+
+
+@pytest.mark.parametrize("cls,args", [("MultiMPN", (8, 6, 2, 32, 2, 2, 0.0)), ("MPN", (7, 5, 2, 32, 2, 2, 0.0))])
+def test_general_route_output_survives_the_in_place_mask_of_the_loss(pkg, oracle, cls, args):
+    """gsp_wls_edge zeroes theta at the slack buses IN PLACE on the model output (/root/reference/data.py:413).  The per-layer
+    autograd nodes of the general route used to save their un-gated last output for a gate they do not have, and autograd then
+    refused the backward ("modified by an inplace operation"): model -> loss -> backward must run on every route, and match
+    the fp64 oracle."""
+    ref, mine = _pair(pkg, oracle, cls, args)
+    b = pkg.synthetic.make_batch(["cigre14"], 8, seed=5)
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    st = tuple(s.to(DEV) for s in b["stats"])
+    fn, fe = args[0], args[1]
+    if cls == "MultiMPN":
+        out = mine(types.SimpleNamespace(x=x[:, :8].contiguous(), edge_index=ei, edge_attr=ea[:, :6].contiguous()))
+        out64 = ref(types.SimpleNamespace(x=b["x"][:, :8].double(), edge_index=b["edge_index"], edge_attr=b["edge_attr"][:, :6].double()))
+    else:
+        out = mine(x[:, :fn].contiguous(), ei, ea[:, :fe].contiguous())
+        out64 = ref(b["x"][:, :fn].double(), b["edge_index"], b["edge_attr"][:, :fe].double())
+    kw = dict(reg_coefs=oracle.DEFAULT_REG_COEFS, num_samples=None)
+    loss = pkg.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2],
+                            edge_std=st[3], edge_index=ei, node_param=x[:, 8:], edge_param=ea[:, 6:], **kw)
+    loss.backward()
+    x64, ea64 = b["x"].double(), b["edge_attr"].double()
+    st64 = tuple(s.double() for s in b["stats"])
+    loss64 = oracle.gsp_wls_edge(input=x64[:, :8], edge_input=ea64[:, :6], output=out64, x_mean=st64[0], x_std=st64[1],
+                                 edge_mean=st64[2], edge_std=st64[3], edge_index=b["edge_index"], node_param=x64[:, 8:],
+                                 edge_param=ea64[:, 6:], **kw)
+    loss64.backward()
+    assert abs(loss.item() - loss64.item()) <= 1e-5 * abs(loss64.item())
+    assert (out.detach()[x[:, 9] > 0, 1] == 0).all()
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and rel_err(p.grad, q.grad) < 1e-4, n

@@ -10,7 +10,10 @@ handed to ``parallel.allreduce_flat_grads`` -- with the two collectives replaced
 does over eight: pass 1 collects every shard's eight sums, pass 2 hands each shard the total and adds up the buckets.
 
 Bars: loss and every gradient equal the single-batch HIP step to 1e-6 and the fp64 oracle on the whole batch to 1e-5 (loss) /
-2e-5 (gradients, max-normalised; the bar test_tall_tiles_matrix_sequential uses against the fp64 oracle)."""
+2e-5 (gradients, max-normalised; the bar test_tall_tiles_matrix_sequential uses against the fp64 oracle; the edge MLP's first
+Linear 2e-3: its per-edge gates are un-pinnable).  The first bar needs every shard on the same kernels as the whole batch:
+found on the way, a 29-graph shard tiled at 96 rows and left the whole-stack kernels (stack.tiles_of now asks for its own
+64-row tiling), and the general route kept its un-gated last output alive across the loss's in-place mask (multi.py)."""
 import pytest
 import torch
 
@@ -18,6 +21,7 @@ from conftest import load_pkg, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+TOL_SHARD, TOL_ORACLE = 1e-6, 2e-5
 
 
 @pytest.fixture(scope="module")
@@ -154,10 +158,12 @@ def test_sharded_hip_step_equals_single_batch_step(pkg, oracle, monkeypatch, nam
     # every rank reports the loss of the GLOBAL batch
     for l in losses:
         assert abs(l.item() - loss_one.item()) <= 1e-6 * abs(loss_one.item()), (l.item(), loss_one.item())
+    names = [n for n, _ in model.named_parameters()]
+    errs = {n: rel_err(a, c) for n, a, c in zip(names, grads, grads_one)}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    assert all(e < TOL_SHARD for e in errs.values()), ("sharded vs single-batch HIP step", worst)
     for a, c in zip(flat_sum, buckets_one):
-        assert rel_err(a, c) < 1e-6
-    for (n, _), a, c in zip(model.named_parameters(), grads, grads_one):
-        assert rel_err(a, c) < 1e-6, (n, rel_err(a, c))
+        assert rel_err(a, c) < TOL_SHARD
 
     # ---- the fp64 oracle on the whole batch (the reference's single-process step)
     b64 = {"x": full["x"].double(), "edge_index": full["edge_index"], "edge_attr": full["edge_attr"].double()}
@@ -166,8 +172,14 @@ def test_sharded_hip_step_equals_single_batch_step(pkg, oracle, monkeypatch, nam
     else:
         _, loss64 = oracle.train_step(ref, b64, tuple(s.double() for s in full["stats"]))
     assert abs(losses[0].item() - loss64.item()) <= 1e-5 * abs(loss64.item())
-    for (n, _), a, q in zip(model.named_parameters(), grads, ref.parameters()):
-        assert rel_err(a, q.grad) < 2e-5, (n, rel_err(a, q.grad))
+    errs64 = {n: rel_err(a, q.grad) for n, a, q in zip(names, grads, ref.parameters())}
+    worst64 = sorted(errs64.items(), key=lambda kv: -kv[1])[:6]
+    # (the gates of the edge MLP are per edge and recomputed inside the kernels: they cannot be pinned from outside, and a
+    #  razor-edge one that falls the other way than in fp64 moves its block's first-Linear gradients by ~1/N_edges --
+    #  tests/test_gpu_stack.py gives those rows 2e-2 at this batch size; measured here: 3.4e-4 on one bias of the SkipPFN)
+    def tol(n):
+        return 2e-3 if ".edge_aggr.edge_aggr.0." in n or n.startswith("edge_aggr.edge_aggr.0.") else TOL_ORACLE
+    assert all(e < tol(n) for n, e in errs64.items()), ("sharded HIP step vs fp64 oracle", worst64)
 
 
 def _oracle_step_general(oracle, model, b, st, fn, fe):
