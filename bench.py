@@ -73,6 +73,90 @@ def dry_run(args) -> int:
     return 0
 
 
+def flops_per_graph(n, e, hid, layers, khops, fn=8, fe=6, fo=2, blocks=1, fo_inner=None):
+    """SURVEY.md 8(d): forward FLOPs of one graph = e2 (2 (2 Fn + Fe) H + 2 H^2) + sum over layers [n (K + 1) 2 H H_out + K e2 2 H];
+    forward + backward = 3 x forward.  ``blocks`` > 1: a PFN / SkipPFN stack (inner blocks end at ``fo_inner`` columns)."""
+    e2 = 2 * e
+    total = 0.0
+    for b in range(blocks):
+        out = fo if b == blocks - 1 else (fo_inner if fo_inner is not None else fo)
+        fin = fn if b == 0 else (fo_inner if fo_inner is not None else fo)
+        f = e2 * (2.0 * (2 * fin + fe) * hid + 2.0 * hid * hid)
+        for l in range(layers):
+            hout = out if l == layers - 1 else hid
+            f += n * (khops + 1) * 2.0 * hid * hout + khops * e2 * 2.0 * hid
+        total += f
+    return 3.0 * total
+
+
+# The other BASELINE.json configurations and the reference driver's own model line, timed on ONE GPU beside the headline
+# (VERDICT r3 #6: "make the driver see more than C2").  (tag, grids, graphs, class, ctor args, (n, e) per graph, blocks)
+OTHER_CONFIGS = [
+    ("C1 cigre14 B=64 H=32 L=1", ["cigre14"], 64, "MPN", (8, 6, 2, 32, 1, 2, 0.0), (15, 14), 1),
+    ("C3 ober_sub B=1024 H=128 L=4", ["ober_sub"], 1024, "MPN", (8, 6, 2, 128, 4, 2, 0.0), (70, 69), 1),
+    ("C3' ober179 (synthetic 179-bus feeder) B=1024 H=128 L=4", ["ober179"], 1024, "MPN", (8, 6, 2, 128, 4, 2, 0.0), (179, 178), 1),
+    ("C5 model, 4096-graph mixed-topology shard, H=256 L=8", ["cigre14", "cigre14_reswitched"], 4096, "MPN", (8, 6, 2, 256, 8, 2, 0.0), (15, 14.5), 1),
+    ("C2 shape, B=32768 on one GPU (cache-busting)", ["cigre14"], 32768, "MPN", (8, 6, 2, 128, 4, 2, 0.0), (15, 14), 1),
+    ("driver line: SkipPFN H=32 8 layers x 5 blocks, dropout 0.3, B=4096", ["cigre14"], 4096, "SkipPFN", (8, 6, 2, 32, 8, 2, 0.3, 5), (15, 14), 5),
+]
+
+
+def time_other_config(pkg, dev, stream, tag, grids, B, cls, cargs, ne, blocks, seconds):
+    """ms/step of forward + gsp_wls_edge + backward on a resident batch, eager and as a replayed hipGraph, each over
+    >= `seconds` of timed work; fractions from SURVEY 8(d)'s FLOP count."""
+    torch.manual_seed(0)
+    b = pkg.synthetic.make_batch(grids, B, seed=1)
+    x, ei, ea = b["x"].to(dev), b["edge_index"].to(dev), b["edge_attr"].to(dev)
+    st = tuple(s.to(dev) for s in b["stats"])
+    model = getattr(pkg, cls)(*cargs).to(dev)
+    params = list(model.parameters())
+    xin, ein, npar, epar = x[:, :8], ea[:, :6], x[:, 8:], ea[:, 6:]
+
+    def step():
+        for p in params:
+            p.grad = None
+        out = model(xin, ei, ein)
+        loss = pkg.gsp_wls_edge(input=xin, edge_input=ein, output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2], edge_std=st[3],
+                                edge_index=ei, reg_coefs=REG, num_samples=None, node_param=npar, edge_param=epar)
+        loss.backward(pkg.data.unit_grad(loss))
+        return loss
+
+    def timed(run):
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(10):
+                run()
+            torch.cuda.synchronize()
+            n += 10
+            el = time.perf_counter() - t0
+            if el >= seconds or n >= 20000:
+                return el / n * 1e3
+
+    ms_eager = timed(step)
+    rec = {"graphs": B, "ms_per_step_eager": ms_eager}
+    try:
+        g = pkg.graphs.GraphedStep(step, stream=stream, capture_error_mode="thread_local")
+        rec["ms_per_step_replay"] = timed(g.replay)
+    except Exception as exc:
+        rec["ms_per_step_replay"] = None
+        rec["replay_error"] = f"{type(exc).__name__}: {exc}"[:200]
+    best = min(v for v in (rec["ms_per_step_eager"], rec["ms_per_step_replay"]) if v is not None)
+    hid, layers, khops = cargs[3], cargs[4], cargs[5]
+    ne = (x.shape[0] / float(B), ei.shape[1] / float(B))      # nodes / stored edges per graph of THIS batch (mixed topologies: the mean)
+    fpg = flops_per_graph(ne[0], ne[1], hid, layers, khops, blocks=blocks, fo_inner=(8 if blocks > 1 else None))
+    tf = fpg * B / (best * 1e-3) / 1e12
+    topo = pkg.topology.get_topology(ei, x.shape[0])
+    rec.update(nodes_per_graph=ne[0], edges_per_graph=ne[1], ms_per_step=best, graphs_per_s=B / (best * 1e-3), flops_per_graph_fwd_bwd=fpg, tflops_fp32_equiv=tf,
+               frac_of_fp32_mfma_peak=tf / FP32_MFMA_PEAK_TF, frac_of_bf16_pipe_div6=tf / (BF16_MFMA_PEAK_TF / 6.0),
+               tile_rows=32 * int(topo.nrb), tile_utilisation=float(topo.utilisation), loss=float(step().item()))
+    del g, model, x, ei, ea
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,8 +170,12 @@ def main():
                     help="run the weight-gradient chain on a side stream beside the data-gradient chain (+3 %% at C2; "
                          "per-kernel durations then include the overlap)")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="CPU time budget per thread count of the cpu_baseline sweep")
-    ap.add_argument("--min-window-seconds", type=float, default=0.5,
-                    help="repeat the K-step timed window until this much timed work has accumulated; the median window is reported")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs block (C1, C3, C3', C5 shard, B=32768, driver line)")
+    ap.add_argument("--other-seconds", type=float, default=1.0, help="timed work per mode of every other_configs entry")
+    ap.add_argument("--min-window-seconds", type=float, default=5.0,
+                    help="repeat the K-step timed window until this much timed work has accumulated; the median window is "
+                         "reported (5 s per mode: the eager and the replay leg together keep the GPU busy >= 10 s in a row, so "
+                         "that an outside utilisation sampler sees the run)")
     ap.add_argument("--ramp-seconds", type=float, default=2.0,
                     help="untimed load before the W warm-up steps: a fresh MI355X needs ~1 s of sustained work to reach "
                          "its steady clocks (measured: the first ~100 steps of a process run 40 %% slower)")
@@ -183,7 +271,7 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dtw = float(tt.item())
             out.append(dtw)
-            go = sum(out) < args.min_window_seconds and len(out) < 200
+            go = sum(out) < args.min_window_seconds and len(out) < 2000
             if distributed:
                 flag = torch.tensor([int(go)], dtype=torch.int32, device=dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -386,6 +474,20 @@ def main():
         except Exception as exc:      # e.g. a box short of memory: report the cache-resident point only
             result["scatter_add"].update(cache_busting=f"skipped: {exc}", achieved=small["achieved"], frac=small["frac"])
         torch.cuda.empty_cache()
+
+        # ---- the other configurations on this GPU (not bench lines of their own: BASELINE.json's metric is quoted on C2)
+        if world == 1 and not args.no_other_configs:
+            others = {}
+            for tag, grids, B_, cls, cargs, ne, blocks in OTHER_CONFIGS:
+                try:
+                    others[tag] = time_other_config(pkg, dev, work_stream, tag, grids, B_, cls, cargs, ne, blocks, args.other_seconds)
+                except Exception as exc:      # e.g. a box short of memory at B = 32768
+                    others[tag] = {"skipped": f"{type(exc).__name__}: {exc}"[:200]}
+                    torch.cuda.empty_cache()
+            result["other_configs"] = others
+            result["other_configs_note"] = ("forward + gsp_wls_edge + backward on a resident synthetic batch, one GPU, eager and hipGraph "
+                                            "replay (>= %.1f s of timed work each), ms_per_step = the faster; TFLOP/s from SURVEY 8(d)'s "
+                                            "algorithmic FLOPs (3 x forward); the driver line excludes the optimizer" % args.other_seconds)
 
         # ---- CPU baseline (SURVEY 8d / BASELINE.md 3): the oracle -- a port of the reference's PyTorch-eager path --
         # on this box's host cores, same batch.  Thread sweep, best-of reported as `value`; plus the single-thread
