@@ -166,9 +166,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time the eager step only (default: eager and hipGraph replay, best reported)")
     ap.add_argument("--graph-timeout", type=float, default=90.0, help="seconds the hipGraph leg may take before the eager result is printed")
-    ap.add_argument("--overlap-wgrad", action="store_true",
-                    help="run the weight-gradient chain on a side stream beside the data-gradient chain (+3 %% at C2; "
-                         "per-kernel durations then include the overlap)")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="CPU time budget per thread count of the cpu_baseline sweep")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs block (C1, C3, C3', C5 shard, B=32768, driver line)")
     ap.add_argument("--other-seconds", type=float, default=1.0, help="timed work per mode of every other_configs entry")
@@ -194,7 +191,6 @@ def main():
 
     pkg = importlib.import_module(PKG)
     pkg._lib.lib()  # fail loudly without the HIP extension
-    pkg.networks.WGRAD_SIDE_STREAM = bool(args.overlap_wgrad)
     import torch.distributed as dist
     env = pkg.parallel.init_from_env("nccl")
     rank, world, local = env["rank"], env["world"], env["local"]
@@ -366,7 +362,7 @@ def main():
         except Exception:
             pass
         flops = flops_layer * layers_per_launch
-        # in situ, exactly as the timed region runs (single stream unless --overlap-wgrad): the average
+        # in situ, exactly as the timed region runs (single stream): the average
         # agrees with `rocprofv3 --kernel-trace --stats` of this same command (profiles/)
         result["roofline"] = {
             "kernel": f"dss2::{kname} (TAGConv H->H layers, forward and data-gradient"
@@ -377,7 +373,7 @@ def main():
             "launches_timed": n_l, "layers_per_launch": layers_per_launch, "avg_launch_us": avg_ms * 1e3,
             "median_launch_us": med_ms * 1e3, "algorithmic_flops_per_launch": flops,
             "algorithmic_bytes_per_launch": 4.0 * N * HID + bytes_layer * layers_per_launch,
-            "mode": "side-stream overlap on" if pkg.networks.WGRAD_SIDE_STREAM else "single stream",
+            "mode": "single stream",
         }
         if bf16x6:
             # The tile GEMM runs on the bf16 matrix pipe as six v_mfma_f32_32x32x16_bf16 per fp32 product group (operands split

@@ -115,8 +115,7 @@ static int chain_impl(const dss2_gemm_prop_args* ap, const dss2_chain_layer* lay
     }
     if (rsplit == 1 && chain_sp_supported(a)) return launch_chain_sp(a, ct, head, s);      // 64-row tiles, H >= 96: split-plane form
     if (head) { set_error("gemm_prop_chain_head: the split-plane chain does not cover this shape"); return 2; }
-    if ((a.nrb == 6 || a.nrb == 3) && chain_sp6_supported(a)) return launch_chain_sp6(a, ct, s);      // 192-row tiles: split-plane form, six row blocks per wave
-    if (rsplit == 1 && chain_sp3_supported(a)) return launch_chain_sp3(a, ct, s);      // 96-row tiles: split-plane form, three waves per column group
+    if ((a.nrb == 6 || a.nrb == 3) && chain_sp6_supported(a)) return launch_chain_sp6(a, ct, s);      // 96- / 192-row tiles: split-plane form, NRB row blocks per wave
     return launch_chain16(a, ct, rsplit, s);
   }
   if (a.b_format != 0) { set_error("gemm_prop_chain: unknown b_format %d", a.b_format); return 2; }

@@ -463,9 +463,6 @@ int launch_chain16(const dss2_gemm_prop_args& a, const ChainTable& ct, int rspli
 // 64-row tiles, one wave per column group: the tile kept in LDS as split bf16 planes (dss2_gemm_chain_sp.hip; DSS2_CHAIN_SP=0: off)
 bool chain_sp_supported(const dss2_gemm_prop_args& a);
 int launch_chain_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head* head, hipStream_t s);
-// 96-row tiles, three waves per column group (dss2_gemm_chain_sp3.hip)
-bool chain_sp3_supported(const dss2_gemm_prop_args& a);
-int launch_chain_sp3(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t s);
 // 192-row tiles, six row blocks per wave (dss2_gemm_chain_sp6.hip)
 bool chain_sp6_supported(const dss2_gemm_prop_args& a);
 int launch_chain_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t s);

@@ -1,5 +1,6 @@
-// Split-plane layer chain for 192-row tiles (graphs of 97..192 buses, one per tile: the 179-bus feeder): dss2_gemm_chain_sp3.hip
-// with six row blocks per wave.
+// Split-plane layer chain for tall tiles: 192 rows (graphs of 97..192 buses, one per tile: the 179-bus feeder) and 96 rows
+// (the 70-bus ober_sub graphs), NRB = 6 / 3 row blocks per wave.  (The round-3 one-workgroup-per-CU 96-row kernel it
+// replaced is kept as a record: profiles/experiments/r03_gemm_chain_sp3_one_workgroup_per_cu.hip.txt.)
 //
 // One wave per 32-column group owns all 192 rows of its columns: 288 accumulator registers (AGPRs; one wave per SIMD, 512-register
 // budget), the Horner hops wave-private, every weight fragment fetched once per column group, two barriers per layer.  What
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     //    epilogue -- twelve s_load_dwordx16 in sequence, each waited for -- 70 us of the backward chain, through v_readlane 38 us.)
     //  * otherwise (generic kernel only) from relu_src: each gather pass of the LAST hop requests the fp32 values of its own HP row
     //    pieces at its top and folds them into bits at its end.  (Requested as one block of NRP vectors -- before the hops, as the
-    //    96-row kernel of dss2_gemm_chain_sp3.hip does with 48 registers -- the register allocator has no room beside the
+    //    round-3 96-row kernel (profiles/experiments/) did with 48 registers -- the register allocator has no room beside the
     //    accumulators and U and spills every pair the moment it arrives: "load, load, wait, store, store" NRP / 2 times = as many
     //    SERIALISED global round trips per layer: backward chain 606 us against 426 us forward on the 179-bus configuration.)
     constexpr int NGW = (NRP + 7) / 8;
@@ -336,8 +337,6 @@ static size_t chain_sp6_lds_bytes(int nrb, int ncg, int ell_width) { return (siz
 
 bool chain_sp6_supported(const dss2_gemm_prop_args& a) {
   static const int on = [] { const char* e = getenv("DSS2_CHAIN_SP"); return e ? atoi(e) : 1; }();
-  static const int on3 = [] { const char* e = getenv("DSS2_CHAIN_SP3B"); return e ? atoi(e) : 1; }();      // 0: 96-row tiles run dss2_gemm_chain_sp3.hip
-  if (a.nrb == 3 && !on3) return false;
   return on && a.b_format == 1 && (a.nrb == 6 || a.nrb == 3) && a.nmat >= 2 && a.nmat <= 3 && (a.kpad & 15) == 0 && a.kpad <= 32 * a.ncg &&
          a.ncg >= 2 && a.ncg <= 4 && chain_sp6_lds_bytes(a.nrb, a.ncg, a.ell_width) <= (size_t)(a.nrb == 3 ? kMaxLdsBytes / 2 : kMaxLdsBytes);
 }
@@ -358,8 +357,7 @@ int launch_chain_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStre
     if (L.relu_src || L.gate_bits || L.dmask || L.add_src) fwd = false;
     if (L.bias || L.prebias || L.dmask || L.add_src || L.y_bits || (L.relu & 1) || (L.relu_src && !L.gate_bits)) bwd = false;
   }
-  static const int spec = [] { const char* e = getenv("DSS2_CHAIN_SP6_DIR"); return e ? atoi(e) : 1; }();      // 0: the generic kernel always
-  const int dir = !spec ? 0 : (fwd ? 1 : (bwd ? 2 : 0));
+  const int dir = fwd ? 1 : (bwd ? 2 : 0);      // (0: a layer table that mixes the feature sets runs the generic instantiation)
 #define DSS2_S6_LAUNCH(NRB, NMAT) (dir == 1 ? launch_sp6<NRB, NMAT, 1>(a, ct, s) : (dir == 2 ? launch_sp6<NRB, NMAT, 2>(a, ct, s) : launch_sp6<NRB, NMAT, 0>(a, ct, s)))
   if (a.nrb == 3) return a.nmat == 2 ? DSS2_S6_LAUNCH(3, 2) : DSS2_S6_LAUNCH(3, 3);
   return a.nmat == 2 ? DSS2_S6_LAUNCH(6, 2) : DSS2_S6_LAUNCH(6, 3);

@@ -728,8 +728,7 @@ static int pick_nb(int nrb, int nmat, int hout, int max_nnz, int ell_width) {
 
 // the eight-wave form of the one-output-block kernel: 192-row tiles with full 128-column input groups
 static bool wgrad_w8(const dss2_wgrad_args& a, int nb) {
-  static const int on = [] { const char* e = getenv("DSS2_WGRAD_W8"); return e ? atoi(e) : 1; }();
-  return on && a.nrb == 6 && nb == 1 && !a.narrow && a.nmat == 3 && (a.hin % 128) == 0 && a.ell_width > 0 &&      // (K = 1 spills 42 registers)
+  return a.nrb == 6 && nb == 1 && !a.narrow && a.nmat == 3 && (a.hin % 128) == 0 && a.ell_width > 0 &&      // (K = 1 spills 42 registers)
          wgrad_lds(6, a.nmat, 1, a.max_nnz, a.ell_width, true, a.hin, true) <= (size_t)kMaxLdsBytes;
 }
 

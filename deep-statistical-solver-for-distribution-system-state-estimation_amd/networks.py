@@ -772,9 +772,7 @@ def dropout_mask(snapshot: torch.Tensor, p: float, drop_id: int, n_rows: int, h:
     return out
 
 
-_SIDE_STREAMS = {}
 EDGE_TILE_KERNELS = _os.environ.get("DSS2_EDGE_TILE", "1") == "1"       # 0 = row-per-wave CSR kernels
-WGRAD_SIDE_STREAM = _os.environ.get("DSS2_WGRAD_STREAM", "0") == "1"   # opt-in: +3 % at C2 (kernels then overlap)
 CHAIN_LAYERS = _os.environ.get("DSS2_CHAIN", "1") == "1"               # hid->hid layers of a block: one chained launch
 WGRAD_BF16 = _os.environ.get("DSS2_WGRAD_BF16", "1") == "1"            # weight gradients as bf16x6 where the kernel covers the shape
 CHAIN_GATE_BITS = _os.environ.get("DSS2_CHAIN_GATE_BITS", "1") == "1"  # tall tiles: the backward chain's ReLU gates as bit words written by the forward chain
@@ -786,38 +784,14 @@ CHAIN_HEAD_FWD = _os.environ.get("DSS2_CHAIN_HEAD_FWD", "0") == "1"
 WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"
 STACK_NODE = _os.environ.get("DSS2_STACK_NODE", "1") == "1"              # PFN / SkipPFN as ONE autograd node (_PFNFn)
 DX_MERGE = _os.environ.get("DSS2_DX_MERGE", "1") == "1"                  # dx of the edge MLP as ONE K = 2 hid GEMM
-PREP_SIDE_STREAM = _os.environ.get("DSS2_PREP_STREAM", "0") == "1"       # opt-in: fold + weight packing on a side stream beside the edge MLP's forward
-                                                                         # (measured at C2, same box: 0.590 ms with it, 0.579 without: the fork / join costs more than the 19 us it hides)
 WGRAD_JOIN_FOLDED = None    # None: join the folded conv 0 into the batched launch only when the tiles divide evenly          # hid->hid layers of a block: one wgrad launch
-
-
-def _side_stream(device):
-    s = _SIDE_STREAMS.get(device)
-    if s is None:
-        s = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
-    return s
 
 
 def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=None, dmask=None, need_dh=True,
                       rowscale2=None, defer_wgrad=False, pending=None, drop=None, b_format=0):
     """g: gradient w.r.t. the conv's pre-activation output [N, hout] (already masked).
-    g_flat <- [dW_0..dW_K, db]; returns dh (masked by relu_src / dmask of the PREVIOUS layer).
-    The weight gradient only feeds the flat gradient buffer, so it may run on a side stream beside the
-    data-gradient chain (the caller joins the streams before it hands the buffer to autograd)."""
-    if defer_wgrad:      # the caller batches this layer's weight gradient with its siblings (wgrad_batched)
-        pass
-    elif WGRAD_SIDE_STREAM and need_dh:
-        main = torch.cuda.current_stream(g.device)
-        side = _side_stream(g.device)
-        side.wait_stream(main)                      # g (and h) are ready on the main stream
-        # g is released by the caller as soon as the data-gradient below has consumed it: tell the
-        # caching allocator that the side stream still reads it (and h, g_flat) until its work is done
-        g.record_stream(side)
-        h.record_stream(side)
-        g_flat.record_stream(side)
-        with torch.cuda.stream(side):
-            wgrad(topo, g, hout, h, hin, nmat, g_flat, rowscale2=rowscale2)
-    else:
+    g_flat <- [dW_0..dW_K, db]; returns dh (masked by relu_src / dmask of the PREVIOUS layer)."""
+    if not defer_wgrad:      # (deferred: the caller batches this layer's weight gradient with its siblings, wgrad_batched)
         wgrad(topo, g, hout, h, hin, nmat, g_flat, rowscale2=rowscale2, pending=pending)
     if not need_dh:
         return None
@@ -1205,30 +1179,16 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
     W1, b1, W2, b2 = ps[0:4]
     conv_ps = [ps[4 + l * (nmat + 1): 4 + (l + 1) * (nmat + 1)] for l in range(L)]   # (bias, W_0..W_K)
     plan, fold, glob = _ensure_plans(mod, topo, dev, ps)
-    prep_side = None
     if stack is None:
-        if fold is not None and PREP_SIDE_STREAM:
-            # The fold (W_m W2: small GEMMs) and the weight packing depend on the weights only, and with the fold the edge MLP's
-            # forward needs nothing of them: both launches run on a side stream beside the edge kernel and are joined before
-            # the first TAGConv (in a hipGraph capture: a parallel branch).  ~19 us of the C2 step off the critical path.
-            main = torch.cuda.current_stream(dev)
-            prep_side = _side_stream(dev)
-            prep_side.wait_stream(main)
-            with torch.cuda.stream(prep_side):
-                fold.refresh_forward()
-                ver = plan.refresh()
-        else:
-            if fold is not None:
-                fold.refresh_forward()
-            ver = plan.refresh()
+        if fold is not None:
+            fold.refresh_forward()
+        ver = plan.refresh()
     else:
         ver = plan.version
     if not glob:
         topo.lds_check(nmat, _round8(hid), _ncg(hid))
     S, h = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, plan.fwd[0], hid, hid, mod.dim_featn, mod.dim_feate,
                               second_linear=fold is None)
-    if prep_side is not None:
-        torch.cuda.current_stream(dev).wait_stream(prep_side)
     if fold is not None:
         h = S            # conv 0 consumes the aggregated hidden directly
     acts = [h]
@@ -1329,7 +1289,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
     dS = None
     # slab reductions recorded in ``pending`` run in ONE launch at the end (chained path; always inside a stack)
     fold_late = False
-    if L >= 3 and not WGRAD_SIDE_STREAM and WGRAD_BATCH and chain_supported(topo, nmat, hid, True, bool(plan.bwd16)):
+    if L >= 3 and WGRAD_BATCH and chain_supported(topo, nmat, hid, True, bool(plan.bwd16)):
         # last layer on its own; then the data-gradients of layers L-2 .. 0 as ONE chained launch
         if pending is None:
             pending = []
@@ -1405,7 +1365,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
                                          relu_src=(acts[l] if l > 0 else None),
                                          drop=(drop_of(l - 1) if l > 0 else None), pending=pending)
             continue
-        defer = WGRAD_BATCH and not WGRAD_SIDE_STREAM and hout == hid and not is_narrow(nmat, hout)
+        defer = WGRAD_BATCH and hout == hid and not is_narrow(nmat, hout)
         if defer:
             deferred.append((l, g, acts[l]))
         g16 = hout == hid and (1 + l) in plan.bwd16 and gemm16_supported(topo, nmat, hid, True)
@@ -1432,8 +1392,6 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
             reduce_pending(pending)     # all slab reductions of the block in one launch
         if fold_late:
             fold.backward(flat)
-        if WGRAD_SIDE_STREAM:
-            torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
         hook = getattr(mod, "_grad_bucket_hook", None)
         if hook is not None:      # data-parallel: all-reduce the flat bucket once (parallel.py)
             hook(flat)
@@ -1581,8 +1539,6 @@ class _PFNFn(torch.autograd.Function):
             if sp.fold_bwd is None:
                 raise RuntimeError("the stack's fold tables are missing")
             _small_gemm(sp.fold_bwd, flat.data_ptr(), dev)
-        if WGRAD_SIDE_STREAM:
-            torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
         hook = getattr(blocks[0], "_grad_bucket_hook", None)
         if hook is not None:      # data-parallel: ONE all-reduce for the whole stack's bucket
             hook(flat)

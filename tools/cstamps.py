@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU diagnostic (needs the -DDSS2_CHAIN_STAMPS build: DSS2_OUT=<pkg>/libdss2_cstamps.so DSS2_OBJ=/tmp/obj_cst bash csrc/build.sh -DDSS2_CHAIN_STAMPS; run with DSS2_LIB=<pkg>/libdss2_cstamps.so): s_memtime phase stamps of the bf16x6
+"""GPU diagnostic (needs the -DDSS2_CHAIN_STAMPS build: DSS2_OUT=tools/diag_lib/libdss2_cstamps.so DSS2_OBJ=/tmp/obj_cst bash csrc/build.sh -DDSS2_CHAIN_STAMPS; run with DSS2_LIB=tools/diag_lib/libdss2_cstamps.so): s_memtime phase stamps of the bf16x6
 layer chain (forward; argv: graphs, hidden width (128), layers (3): the C2 shape by default) -- per layer: GEMM phase, barrier wait, Horner, epilogue, barrier wait, as the
 median over workgroups and waves.  argv[1] = graphs in the batch (1024: one workgroup per CU; 4096: two per CU, two rounds)."""
 import ctypes as C, importlib, os, sys
@@ -28,7 +28,7 @@ buf = (C.c_ulonglong * (nwg * 8 * 64))()
 lib = pkg._lib.lib()
 sp = H >= 96 and os.environ.get("DSS2_CHAIN_SP", "1") != "0"      # the split-plane kernel keeps its stamps in its own translation unit
 sp3 = topo.nrb == 3 and H >= 64 and os.environ.get("DSS2_CHAIN_SP", "1") != "0"
-reader = lib.dss2_debug_read_cstamps_sp3 if sp3 else (lib.dss2_debug_read_cstamps_sp if sp else lib.dss2_debug_read_cstamps)
+reader = lib.dss2_debug_read_cstamps_sp6 if sp3 else (lib.dss2_debug_read_cstamps_sp if sp else lib.dss2_debug_read_cstamps)      # (96-row tiles: gemm_chain_sp6_kernel<3, .>)
 reader.argtypes = [C.c_void_p, C.c_int]
 assert reader(buf, nwg * 8 * 64) == 0
 ncg = (H + 31) // 32

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU diagnostic: s_memtime phase stamps of the whole-stack kernels (csrc/dss2_stack.hip).  Needs the stamps build:
-    DSS2_OUT=<pkg>/libdss2_sstamps.so DSS2_OBJ=/tmp/obj_sst bash <pkg>/csrc/build.sh -DDSS2_STACK_STAMPS
-    DSS2_LIB=<pkg>/libdss2_sstamps.so python tools/sstamps.py [graphs]
+    DSS2_OUT=tools/diag_lib/libdss2_sstamps.so DSS2_OBJ=/tmp/obj_sst bash <pkg>/csrc/build.sh -DDSS2_STACK_STAMPS
+    DSS2_LIB=tools/diag_lib/libdss2_sstamps.so python tools/sstamps.py [graphs]
 Prints, per phase, the median over workgroups of (max over waves) in shader cycles: forward block 0, backward last block."""
 import ctypes as C, importlib, os, sys
 import numpy as np, torch

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU diagnostic (needs the -DDSS2_STAMPS build: DSS2_LIB=<pkg>/libdss2_hip_stamps.so): per-wave phase durations of
+"""GPU diagnostic (needs the -DDSS2_STAMPS build: DSS2_LIB=tools/diag_lib/libdss2_hip_stamps.so): per-wave phase durations of
 wgrad_kernel<2,3,4> on the second tile of every workgroup (s_memtime ticks = 100 MHz constant clock)."""
 import ctypes as C, importlib, os, sys
 import numpy as np, torch
