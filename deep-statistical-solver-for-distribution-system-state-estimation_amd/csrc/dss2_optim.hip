@@ -86,9 +86,11 @@ __device__ __forceinline__ void small_gemm_body(const dss2_sgemm_desc* __restric
   const int t = threadIdx.x, lo = t & 31, hi = t >> 5;   // lo runs along the contiguous memory direction
   const int kchunks = (K + SG_KC - 1) / SG_KC;
   const int nchunks = nbatch * kchunks;
-  float ra[16], rb[16];
-  // unconditional loads from clamped addresses (one batch of 32 in flight), masked afterwards
-  auto issue = [&](int c) {
+  // THREE chunks of operands in flight (96 registers): the chain rule's dW2 = sum_m W_m^T dWf_m walks three K-chunks per tile,
+  // and with one chunk requested at a time every chunk paid its own round trip to L2 / HBM (17.9 us for that launch at C2)
+  float rab[3][16], rbb[3][16];
+  // unconditional loads from clamped addresses (one batch of 32 in flight per chunk), masked afterwards
+  auto issue = [&](int c, float (&ra)[16], float (&rb)[16]) {
     const int bidx = c / kchunks, k0 = (c - bidx * kchunks) * SG_KC;
     // (pointers read from a descriptor in memory are generic: through them every access is a flat_load that waits for vmcnt AND
     //  lgkmcnt; they are global by contract -- say so)
@@ -109,7 +111,7 @@ __device__ __forceinline__ void small_gemm_body(const dss2_sgemm_desc* __restric
       rb[q] = bv * (((j0 + j) < N && (k0 + kb) < K) ? 1.f : 0.f);
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](const float (&ra)[16], const float (&rb)[16]) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       if (tA) As[lo][hi + 8 * q] = ra[q]; else As[hi + 8 * (q >> 2)][lo + 32 * (q & 3)] = ra[q];
@@ -117,26 +119,33 @@ __device__ __forceinline__ void small_gemm_body(const dss2_sgemm_desc* __restric
     }
   };
   float s[4] = {0.f, 0.f, 0.f, 0.f};   // rows hi + 8 q, column lo
-  if (nchunks > 0) issue(0);
-  for (int c = 0; c < nchunks; ++c) {
-    __syncthreads();
-    stage();
-    __syncthreads();
-    if (c + 1 < nchunks) issue(c + 1);
-    for (int k = 0; k < SG_KC; k += 8) {
-      float bv[8];
-      f32x4 av[4][2];
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) bv[kk] = Bs[k + kk][lo];
+  for (int u3 = 0; u3 < 3; ++u3)
+    if (u3 < nchunks) issue(u3, rab[u3], rbb[u3]);
+  for (int c0 = 0; c0 < nchunks; c0 += 3) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        av[q][0] = *reinterpret_cast<const f32x4*>(&As[hi + 8 * q][k]);
-        av[q][1] = *reinterpret_cast<const f32x4*>(&As[hi + 8 * q][k + 4]);
+    for (int u3 = 0; u3 < 3; ++u3) {
+      const int c = c0 + u3;
+      if (c >= nchunks) break;          // (uniform)
+      __syncthreads();
+      stage(rab[u3], rbb[u3]);
+      __syncthreads();
+      if (c + 3 < nchunks) issue(c + 3, rab[u3], rbb[u3]);
+      for (int k = 0; k < SG_KC; k += 8) {
+        float bv[8];
+        f32x4 av[4][2];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) bv[kk] = Bs[k + kk][lo];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          av[q][0] = *reinterpret_cast<const f32x4*>(&As[hi + 8 * q][k]);
+          av[q][1] = *reinterpret_cast<const f32x4*>(&As[hi + 8 * q][k + 4]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s[q] = fmaf(av[q][kk >> 2][kk & 3], bv[kk], s[q]);
       }
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s[q] = fmaf(av[q][kk >> 2][kk & 3], bv[kk], s[q]);
     }
   }
   const int j = j0 + lo;

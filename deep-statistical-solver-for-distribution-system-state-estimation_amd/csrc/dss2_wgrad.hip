@@ -771,7 +771,7 @@ extern "C" int dss2_wgrad_y_slices(int nrb, int nmat, int hout, int hin, int ell
   const size_t b = dss2::wgrad16_lds_bytes(nrb, nmat, hout, hin, ell_width);
   if (b == 0 || b > (size_t)dss2::kMaxLdsBytes) return 1;
   (void)has_rowscale2;
-  return ((hout + 127) / 128) * ((hin + 127) / 128);          // a workgroup owns 128 output x 128 input columns
+  return dss2::wgrad16_y_slices(nrb, hout, hin);          // 64-row tiles: a workgroup owns 128 output x 128 input columns; 32-row tiles: 64 x 128
 }
 
 static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::WgradBatch& wb) {

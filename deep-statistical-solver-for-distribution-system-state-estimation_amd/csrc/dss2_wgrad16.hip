@@ -275,8 +275,252 @@ __global__ void __launch_bounds__(W16_NT) wgrad16_kernel(const dss2_wgrad_args p
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 32-row tiles, TWO workgroups per CU (round 4).  The 64-row kernel above is one 8-wave workgroup per CU whose phases --
+// staging, two hops, MFMA -- follow each other between barriers: the matrix pipe is busy 33 % of the time
+// (profiles/r03_final_pmc_wgrad_batched.txt).  Here a workgroup is four waves that own 64 output x 128 input columns of
+// every matrix on a 32-row tile; everything it keeps in LDS is half as tall:
+//     fp32 G / P G (propagation ping-pong)   2 x 32 x 64 x 4     16.0 KB
+//     transposed planes of G, P G, P^2 G     3 x 3 x 64 x 64 B   36.0 KB
+//     transposed planes of X (128 columns)   3 x 128 x 64 B      24.0 KB
+//     ELL slice (D <= 8)                                           2.0 KB
+// = 78 KB, so two workgroups share a CU and one's staging / hops run beside the other's MFMA phase.  The other 64 output
+// columns belong to the workgroup at blockIdx.y + 1, which stages the same X tile again (+25 % split work).  Wave w multiplies
+// input block w with both output blocks: 72 MFMAs per tile and wave, the X fragment read once for six accumulator blocks.
+// Transposed image: 64 bytes per column and plane (32 rows), 16-byte chunks of 8 rows XOR-swizzled with (column / 8) mod 4:
+// the b128 operand reads of a lane group (16 columns) cover all 64 banks.  The transposed b32 stores of one instruction come
+// from 16 column groups x 2 row pairs; a column is 16 banks wide, so an instruction reaches both halves of the 32 banks only if
+// its lanes write columns of both parities: odd column groups store their four columns in the order 1, 0, 3, 2 (2-way
+// conflicts, which a b32 store does not pay for; in column order they were 4-way, 8-way with a 32 x 1 lane shape).
+constexpr int W16B_TM = 32, W16B_ZC = 64, W16B_XW = 128, W16B_NT = 256, W16B_LDZF = 64;
+__device__ __forceinline__ int tpb_key(int col) { return (col >> 3) & 3; }
+__device__ __forceinline__ int tpb_off(int col, int row) { return col * 64 + ((((row >> 3) ^ tpb_key(col)) << 4) | ((row & 7) << 1)); }
+
+// rows (2 rp, 2 rp + 1) x columns (c0 .. c0+3), c0 a multiple of 4 (one key for the four columns): off0 = tpb_off(c0, 2 rp);
+// sw (0 / 1, the parity of the column group): the column order 1, 0, 3, 2
+template <int NCOLS>
+__device__ __forceinline__ void store_planes_b(char* img, int off0, int sw, const f32x4 v0, const f32x4 v1) {
+  char* base[2] = {img + off0 + sw * 64, img + off0 + (1 - sw) * 64};      // instruction 0, 2 / instruction 1, 3
+#pragma unroll
+  for (int qi = 0; qi < 4; ++qi) {
+    const float a = sw ? v0[qi ^ 1] : v0[qi], b = sw ? v1[qi ^ 1] : v1[qi];      // column qi ^ sw
+    uint32_t h, m, l;
+    split3_pair(a, b, h, m, l);
+    char* dst = base[qi & 1] + (qi >> 1) * 128;
+    *reinterpret_cast<uint32_t*>(dst) = h;
+    *reinterpret_cast<uint32_t*>(dst + NCOLS * 64) = m;
+    *reinterpret_cast<uint32_t*>(dst + 2 * NCOLS * 64) = l;
+  }
+}
+
+template <int NMAT, bool RS2>
+__global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_args p, int nibg, const WgradBatch wb) {
+  constexpr int TM = W16B_TM, ZC = W16B_ZC, XW = W16B_XW, NT = W16B_NT, LDZF = W16B_LDZF;
+  const float* __restrict__ Gp = wb.n > 0 ? wb.G[blockIdx.z] : p.G;
+  const float* __restrict__ Xp = wb.n > 0 ? wb.X[blockIdx.z] : p.X;
+  float* __restrict__ slabp = wb.n > 0 ? wb.slab[blockIdx.z] : p.slab;
+  const float* __restrict__ rs2 = RS2 ? (wb.n > 0 ? wb.rowscale2[blockIdx.z] : p.rowscale2) : nullptr;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Zf0 = smem;
+  float* Zf1 = Zf0 + TM * LDZF;
+  char* ZT = reinterpret_cast<char*>(Zf1 + TM * LDZF);          // [NMAT][3 planes][ZC columns][64 B]
+  char* XT = ZT + NMAT * 3 * ZC * 64;                             // [3 planes][XW columns][64 B]
+  int2* ell = reinterpret_cast<int2*>(XT + 3 * XW * 64);         // [D][TM]
+  const int D = p.ell_width;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, c32 = lane & 31, half = lane >> 5;
+  const int ibw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // (Placing the workgroups that walk the same tile-list slice 8 linear ids apart -- same XCD, shared L2 for the X tile they both
+  //  stage -- was 20 % SLOWER: such a pair lands on one CU and runs its phases in lockstep, MFMA beside MFMA and staging beside
+  //  staging; with the slices n_split ids apart a CU's two workgroups are unrelated and drift out of phase.)
+  const int slice = blockIdx.x, ysl = blockIdx.y;
+  const int obg = ysl / nibg, ibg = ysl - obg * nibg;
+  const int gcol0 = obg * ZC, xcol0 = ibg * XW;
+  const bool in_active = (xcol0 + ibw * 32) < p.hin;
+
+  // staging units: rows (2 rp, 2 rp + 1) of four columns; 16 column groups x 16 row pairs, one unit of G and two of X (columns
+  // 4 cg and 64 + 4 cg) per thread
+  const int cg = tid & 15, rp = tid >> 4, sw = cg & 1;
+  const int g_off0 = tpb_off(4 * cg, 2 * rp);
+  const int x_off0[2] = {tpb_off(4 * cg, 2 * rp), tpb_off(64 + 4 * cg, 2 * rp)};
+  const uint32_t g_goff = (uint32_t)((2 * rp) * p.ldg + 4 * cg) * 4u, x_goff = (uint32_t)((2 * rp) * p.ldx + 4 * cg) * 4u;
+
+  f32x16 acc[2][NMAT];
+#pragma unroll
+  for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ob][m][r] = 0.f;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bs2[RS2 ? NMAT : 1];
+#pragma unroll
+  for (int m = 0; m < (RS2 ? NMAT : 1); ++m) bs2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 pg[2], px[4];
+  auto load_tile = [&](int tile) {
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    const char* gb = reinterpret_cast<const char*>(Gp + (size_t)ts * p.ldg + gcol0);      // uniform
+    const char* xb = reinterpret_cast<const char*>(Xp + (size_t)ts * p.ldx + xcol0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = 2 * rp + u;
+      pg[u] = (r < R && gcol0 + 4 * cg < p.hout) ? *reinterpret_cast<const f32x4*>(gb + g_goff + (uint32_t)(u * p.ldg) * 4u) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        px[2 * i + u] = (r < R && xcol0 + 64 * i + 4 * cg < p.hin) ? *reinterpret_cast<const f32x4*>(xb + x_goff + (uint32_t)(u * p.ldx + 64 * i) * 4u)
+                                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto prop = [&](const float* Zs, float* Zd, char* img) {
+    f32x4 s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = 2 * rp + u;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      for (int k0 = 0; k0 < D; k0 += 4) {
+        int2 en[4];
+        f32x4 z[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) en[k] = k0 + k < D ? ell[(k0 + k) * TM + row] : make_int2(row, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[k] = *reinterpret_cast<const f32x4*>(Zs + en[k].x * LDZF + 4 * cg);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float w = __int_as_float(en[k].y);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a[q] = fmaf(w, z[k][q], a[q]);
+        }
+      }
+      s[u] = a;
+      if (Zd) *reinterpret_cast<f32x4*>(Zd + row * LDZF + 4 * cg) = a;
+    }
+    store_planes_b<ZC>(img, g_off0, sw, s[0], s[1]);
+  };
+
+  if (slice < p.ntiles) load_tile(slice);
+  for (int tile = slice; tile < p.ntiles; tile += p.n_split) {
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    const int next = tile + p.n_split;
+    // ---- planes of X and G, the fp32 G slab (first hop's input), the ELL slice, bias partial sums
+#pragma unroll
+    for (int i = 0; i < 2; ++i) store_planes_b<XW>(XT, x_off0[i], sw, px[2 * i], px[2 * i + 1]);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(Zf0 + (2 * rp + u) * LDZF + 4 * cg) = pg[u];
+    store_planes_b<ZC>(ZT, g_off0, sw, pg[0], pg[1]);
+    {
+      const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
+      if (tid < D * TM) ell[tid] = src[tid];          // (D <= 8: at most 256 entries)
+    }
+    bsum += pg[0] + pg[1];
+    if constexpr (RS2) {
+      if (rs2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int r = 2 * rp + u;
+          if (r < R) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(rs2 + (size_t)(ts + r) * 4);
+#pragma unroll
+            for (int m = 0; m < NMAT; ++m) bs2[m] += pg[u] * d[m];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (next < p.ntiles) load_tile(next);      // in flight across the hops and the MFMA phase
+    // ---- P G, P^2 G
+    if (NMAT > 1) {
+      prop(Zf0, NMAT > 2 ? Zf1 : nullptr, ZT + 3 * ZC * 64);
+      if (NMAT > 2) {
+        __syncthreads();
+        prop(Zf1, nullptr, ZT + 2 * 3 * ZC * 64);
+      }
+      __syncthreads();
+    }
+    // ---- MFMA phase: 2 steps of 16 rows; the X fragment of a step serves both output blocks and all matrices
+    if (in_active) {
+      const int nsteps = (R + 15) >> 4;
+      const int xc = ibw * 32 + c32;
+      const int xkey = tpb_key(xc), zkey0 = tpb_key(c32), zkey1 = tpb_key(32 + c32);
+      for (int ks = 0; ks < nsteps; ++ks) {
+        const int ch = 2 * ks + half;
+        const int choff = xc * 64 + ((ch ^ xkey) << 4);
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(XT + choff);
+        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(XT + XW * 64 + choff);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(XT + 2 * XW * 64 + choff);
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+          if (gcol0 + ob * 32 >= p.hout) continue;      // (uniform)
+          const int zoff = (ob * 32 + c32) * 64 + ((ch ^ (ob ? zkey1 : zkey0)) << 4);
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m) {
+            const char* zi = ZT + m * 3 * ZC * 64 + zoff;
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(zi);
+            const bf16x8 am = *reinterpret_cast<const bf16x8*>(zi + ZC * 64);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(zi + 2 * ZC * 64);
+            f32x16 c = acc[ob][m];        // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+            acc[ob][m] = c;
+          }
+        }
+      }
+    }
+    __syncthreads();          // planes and fp32 slabs are free for the next tile
+  }
+
+  // ---- one slab per tile-list slice blockIdx.x; the y-slices tile the [nmat*hout, hin] matrix
+  const size_t stride = (size_t)p.nmat * p.hout * p.hin + p.hout + (rs2 ? (size_t)p.nmat * p.hout : 0);
+  float* out = slabp + (size_t)slice * (wb.slab_stride > 0 ? (size_t)wb.slab_stride : stride);
+  if (in_active) {
+    const int i = xcol0 + ibw * 32 + c32;
+    if (i < p.hin) {
+#pragma unroll
+      for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int o = gcol0 + ob * 32 + acc_row(r, half);
+            if (o < p.hout) out[((size_t)m * p.hout + o) * p.hin + i] = acc[ob][m][r];
+          }
+    }
+  }
+  if (ibg == 0) {   // (uniform) column sums: the 16 threads that share a column group meet in LDS, fixed order
+    f32x4* red = reinterpret_cast<f32x4*>(smem);          // [1 + NMAT][NT]
+    const int nsum = rs2 ? 1 + NMAT : 1;
+    __syncthreads();
+    red[tid] = bsum;
+    if constexpr (RS2) {
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) red[(1 + m) * NT + tid] = bs2[m];
+    }
+    __syncthreads();
+    for (int j = tid; j < nsum * ZC; j += NT) {
+      const int which = j / ZC, col = j - which * ZC;
+      float s = 0.f;
+      for (int r16 = 0; r16 < 16; ++r16) s += red[which * NT + r16 * 16 + (col >> 2)][col & 3];
+      const int o = gcol0 + col;
+      if (o < p.hout) out[(size_t)p.nmat * p.hout * p.hin + (which == 0 ? 0 : p.hout + (size_t)(which - 1) * p.hout) + o] = s;
+    }
+  }
+}
+
 size_t wgrad16_lds_bytes(int nrb, int nmat, int hout, int hin, int ell_width) {
-  if (nrb != 2 || nmat < 2 || nmat > 3 || ell_width < 1 || ell_width > W16_DMAX || hout <= 32 || (hout & 3) || (hin & 3)) return 0;
+  if ((nrb != 1 && nrb != 2) || nmat < 2 || nmat > 3 || ell_width < 1 || ell_width > W16_DMAX || hout <= 32 || (hout & 3) || (hin & 3)) return 0;
+  if (nrb == 1) {      // wgrad16b_kernel: two workgroups per CU
+    const size_t b1 = 2 * (size_t)W16B_TM * W16B_LDZF * 4 + (size_t)nmat * 3 * W16B_ZC * 64 + 3 * (size_t)W16B_XW * 64 + (size_t)ell_width * W16B_TM * 8;
+    const size_t red1 = (size_t)(1 + nmat) * W16B_NT * 16;
+    return b1 > red1 ? b1 : red1;
+  }
   size_t b = 2 * (size_t)W16_TM * W16_LDZF * 4 + (size_t)nmat * 3 * W16_ZC * 128 + 3 * (size_t)W16_XW * 128 + (size_t)ell_width * W16_TM * 8;
   const size_t red = (size_t)(1 + nmat) * W16_NT * 16;          // the final column-sum exchange reuses the front of the buffer
   return b > red ? b : red;
@@ -287,6 +531,21 @@ bool wgrad16_covers(const dss2_wgrad_args& a) {
   return a.mfma_bf16 && !a.narrow && !a.rowscale && a.ell_tiles && al16(a.G) && al16(a.X) && (a.ldg & 3) == 0 && (a.ldx & 3) == 0 &&
          (!a.rowscale2 || al16(a.rowscale2)) && wgrad16_lds_bytes(a.nrb, a.nmat, a.hout, a.hin, a.ell_width) != 0 &&
          wgrad16_lds_bytes(a.nrb, a.nmat, a.hout, a.hin, a.ell_width) <= (size_t)kMaxLdsBytes;
+}
+
+int wgrad16_y_slices(int nrb, int hout, int hin) {
+  return nrb == 1 ? ((hout + W16B_ZC - 1) / W16B_ZC) * ((hin + W16B_XW - 1) / W16B_XW) : ((hout + 127) / 128) * ((hin + 127) / 128);
+}
+
+template <int NMAT, bool RS2>
+static int launch16b(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb) {
+  static std::atomic<uint32_t> lds_done{0};
+  auto kern = wgrad16b_kernel<NMAT, RS2>;
+  if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "wgrad(bf16x6, 32 rows)")) return 1;
+  const int nobg = (a.hout + W16B_ZC - 1) / W16B_ZC, nibg = (a.hin + W16B_XW - 1) / W16B_XW;
+  hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg, wb.n > 0 ? wb.n : 1), dim3(W16B_NT),
+                     wgrad16_lds_bytes(a.nrb, a.nmat, a.hout, a.hin, a.ell_width), stream, a, nibg, wb);
+  return check_launch("wgrad(bf16x6, 32 rows)");
 }
 
 template <int NMAT, int NP, bool RS2>
@@ -307,6 +566,10 @@ int launch_wgrad16(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatc
       set_error("wgrad(bf16x6): layer %d has a misaligned operand", l); return 2;
     }
     rs2 = rs2 || wb.rowscale2[l] != nullptr;
+  }
+  if (a.nrb == 1) {
+    if (a.nmat == 2) return rs2 ? launch16b<2, true>(a, stream, wb) : launch16b<2, false>(a, stream, wb);
+    if (a.nmat == 3) return rs2 ? launch16b<3, true>(a, stream, wb) : launch16b<3, false>(a, stream, wb);
   }
   if (a.nmat == 2) return rs2 ? launch16<2, 2, true>(a, stream, wb) : launch16<2, 2, false>(a, stream, wb);
   if (a.nmat == 3) return rs2 ? launch16<3, 2, true>(a, stream, wb) : launch16<3, 2, false>(a, stream, wb);

@@ -16,6 +16,7 @@ struct WgradBatch {
 // dss2_wgrad16.hip: the bf16x6 kernel.  wgrad16_lds_bytes: dynamic LDS of its launch (0: shape not covered)
 size_t wgrad16_lds_bytes(int nrb, int nmat, int hout, int hin, int ell_width);
 bool wgrad16_covers(const dss2_wgrad_args& a);
+int wgrad16_y_slices(int nrb, int hout, int hin);      // workgroups per tile-list slice (grid.y)
 int launch_wgrad16(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb);
 
 }  // namespace dss2

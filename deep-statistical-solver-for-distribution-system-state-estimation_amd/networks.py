@@ -229,6 +229,27 @@ def gemm_prop_chain(topo: Topology, X: Optional[torch.Tensor], hid: int, nmat: i
                "dss2_gemm_prop_chain_head")
 
 
+WGRAD_TM32 = _os.environ.get("DSS2_WGRAD_TM32", "1") == "1"      # bf16x6 weight gradient on 32-row tiles, two workgroups per CU (wgrad16b_kernel)
+
+
+WGRAD_TM32_MAX_BYTES = 64 << 20
+
+
+def _wgrad_tiles(topo: Topology, nmat: int, hout: int, hin: int, b16: int):
+    """The tile set a weight-gradient launch walks: the topology's own, or -- 64-row tilings under the bf16x6 kernel -- a
+    32-row tiling of the same graphs (Topology.tiles_for(1)), on which two 4-wave workgroups share a CU and overlap each
+    other's staging / propagation with their MFMA phases (csrc/dss2_wgrad16.hip)."""
+    # (each X tile is staged by the two workgroups that own its 64-column output halves, at unrelated times: beyond the
+    #  Infinity Cache that is a second trip to HBM -- B = 32768: 3.52 ms against 3.43 on the 64-row kernel -- so the 32-row
+    #  form is taken while one layer's input stays well inside it)
+    if (WGRAD_TM32 and b16 and topo.nrb == 2 and not topo.global_only and nmat in (2, 3) and hout > 32 and 1 <= topo.ellT <= 8
+            and topo.N * hin * 4 <= WGRAD_TM32_MAX_BYTES):
+        alt = topo.tiles_for(1)
+        if alt is not None and alt.ellT_tiles is not None and 1 <= alt.ellT <= 8:
+            return alt
+    return topo
+
+
 def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int, nmat: int, out_flat: torch.Tensor,
           rowscale=None, rowscale2=None, pending=None, out_len: Optional[int] = None) -> None:
     """out_flat[nmat*hout*hin + hout] <- [dW_0 .. dW_{nmat-1}, db] (deterministic two-pass sum); with
@@ -238,20 +259,21 @@ def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int,
         raise NotImplementedError("wgrad with propagation needs LDS-resident graph tiles (graphs of <= 192 nodes)")
     narrow = nmat > 1 and nmat * hout <= 32 and rowscale2 is None
     b16 = int(WGRAD_BF16 and rowscale is None and not narrow)
-    lds = _lib.lib().dss2_wgrad_lds_bytes_ex(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT, b16)
+    ts = _wgrad_tiles(topo, nmat, hout, hin, b16)
+    lds = _lib.lib().dss2_wgrad_lds_bytes_ex(ts.nrb, nmat, hout, hin, ts.max_nnzT, ts.ellT, b16)
     per_cu = _wgrad_per_cu(int(lds))
-    ys = _lib.lib().dss2_wgrad_y_slices(topo.nrb, nmat, hout, hin, topo.ellT, b16, int(rowscale2 is not None))
-    n_split = min(topo.ntiles, max(1, (256 * per_cu) // ys))
+    ys = _lib.lib().dss2_wgrad_y_slices(ts.nrb, nmat, hout, hin, ts.ellT, b16, int(rowscale2 is not None))
+    n_split = min(ts.ntiles, max(1, (256 * per_cu) // ys))
     stride = nmat * hout * hin + hout + (nmat * hout if rowscale2 is not None else 0)
     slab = torch.empty(n_split * stride, dtype=_F32, device=G.device)
     a = _lib.WgradArgs()
     a.G, a.ldg, a.hout = G.data_ptr(), G.stride(0), hout
     a.X, a.ldx, a.hin = X.data_ptr(), X.stride(0), hin
     a.rowscale, a.rowscale2 = _ptr(rowscale), _ptr(rowscale2)
-    a.slab, a.n_split, a.nmat, a.nrb, a.ntiles = slab.data_ptr(), n_split, nmat, topo.nrb, topo.ntiles
-    a.tile_start = topo.tile_start.data_ptr()
-    a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
-    a.ell_width, a.ell_tiles = topo.ellT, _ptr(topo.ellT_tiles)
+    a.slab, a.n_split, a.nmat, a.nrb, a.ntiles = slab.data_ptr(), n_split, nmat, ts.nrb, ts.ntiles
+    a.tile_start = ts.tile_start.data_ptr()
+    a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), ts.max_nnzT
+    a.ell_width, a.ell_tiles = ts.ellT, _ptr(ts.ellT_tiles)
     a.narrow, a.mfma_bf16 = int(narrow), b16
     st = _stream(G)
     _lib.check(_lib.lib().dss2_wgrad(C.byref(a), st), "dss2_wgrad")
@@ -265,10 +287,11 @@ def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Seq
     With ``first_rowscale2`` layer 0 is a folded layer (see ``wgrad``): its result, with the extra nmat*hout
     scaled sums, goes to ``first_out`` and the remaining layers to ``out_flat`` (two slab reductions)."""
     nl = len(Gs)
-    lds = _lib.lib().dss2_wgrad_lds_bytes_ex(topo.nrb, nmat, hout, hin, topo.max_nnzT, topo.ellT, int(WGRAD_BF16))
+    ts = _wgrad_tiles(topo, nmat, hout, hin, int(WGRAD_BF16))
+    lds = _lib.lib().dss2_wgrad_lds_bytes_ex(ts.nrb, nmat, hout, hin, ts.max_nnzT, ts.ellT, int(WGRAD_BF16))
     per_cu = _wgrad_per_cu(int(lds))
-    ys = _lib.lib().dss2_wgrad_y_slices(topo.nrb, nmat, hout, hin, topo.ellT, int(WGRAD_BF16), int(first_rowscale2 is not None))
-    n_split = min(topo.ntiles, max(1, (256 * per_cu) // (nl * ys)))       # the layers share the chip
+    ys = _lib.lib().dss2_wgrad_y_slices(ts.nrb, nmat, hout, hin, ts.ellT, int(WGRAD_BF16), int(first_rowscale2 is not None))
+    n_split = min(ts.ntiles, max(1, (256 * per_cu) // (nl * ys)))       # the layers share the chip
     stride = nmat * hout * hin + hout
     lens = [stride + (nmat * hout if (first_rowscale2 is not None and l == 0) else 0) for l in range(nl)]
     total = sum(lens)
@@ -278,11 +301,11 @@ def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Seq
     for g_, x_ in zip(Gs, Xs):
         if g_.stride(0) != a.ldg or x_.stride(0) != a.ldx or g_.shape != Gs[0].shape or x_.shape != Xs[0].shape:
             raise ValueError("wgrad_batched: layers must share shapes and leading dimensions")
-    a.n_split, a.nmat, a.nrb, a.ntiles = n_split, nmat, topo.nrb, topo.ntiles
+    a.n_split, a.nmat, a.nrb, a.ntiles = n_split, nmat, ts.nrb, ts.ntiles
     a.mfma_bf16 = int(WGRAD_BF16)
-    a.tile_start = topo.tile_start.data_ptr()
-    a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
-    a.ell_width, a.ell_tiles = topo.ellT, _ptr(topo.ellT_tiles)
+    a.tile_start = ts.tile_start.data_ptr()
+    a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), ts.max_nnzT
+    a.ell_width, a.ell_tiles = ts.ellT, _ptr(ts.ellT_tiles)
     PtrArr = C.c_void_p * nl
     gs, xs = PtrArr(*[g_.data_ptr() for g_ in Gs]), PtrArr(*[x_.data_ptr() for x_ in Xs])
     offs = [sum(lens[:l]) for l in range(nl)]
@@ -784,7 +807,7 @@ CHAIN_HEAD_FWD = _os.environ.get("DSS2_CHAIN_HEAD_FWD", "0") == "1"
 WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"
 STACK_NODE = _os.environ.get("DSS2_STACK_NODE", "1") == "1"              # PFN / SkipPFN as ONE autograd node (_PFNFn)
 DX_MERGE = _os.environ.get("DSS2_DX_MERGE", "1") == "1"                  # dx of the edge MLP as ONE K = 2 hid GEMM
-WGRAD_JOIN_FOLDED = None    # None: join the folded conv 0 into the batched launch only when the tiles divide evenly          # hid->hid layers of a block: one wgrad launch
+WGRAD_JOIN_FOLDED = None    # None / True: the folded conv 0 rides in the batched weight-gradient launch of the plain layers; False: its own launch
 
 
 def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=None, dmask=None, need_dh=True,
@@ -1324,14 +1347,12 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         gemm_prop_chain(topo, (None if head_fused else g), hid, nmat, layers, transposed=True,
                         drop=((snap, p_drop) if snap is not None else None), b_format=int(use16), head=head)
         d_in = layers[-1]["Y"]                  # gradient w.r.t. conv 0's input: dS (folded) or dx0
-        # (joining conv 0 pays only when the tiles still divide evenly over the workgroups the layers share:
-        #  at C2 three layers x 85 workgroups leave a 13-vs-12-tile tail that costs more than the launch saves)
-        ns3 = max(1, (256 * 2) // (L - 1))
-        even = -(-topo.ntiles // ns3) * ns3 <= 1.03 * topo.ntiles
-        if WGRAD_JOIN_FOLDED is not None:
-            even = bool(WGRAD_JOIN_FOLDED)
-        if fold is not None and L - 1 <= 8 and even and (WGRAD_JOIN_FOLDED is not None or not WGRAD_BF16):
-            # (bf16x6 weight gradient: the folded layer's extra sums only fit the one-pass kernel, so it runs on its own)
+        # The folded conv 0 joins the batched launch of the plain layers (round 4; WGRAD_JOIN_FOLDED=False: its own launch).
+        # Round 3 kept it apart because three layers x 85 workgroups leave a 13-vs-12-tile tail at C2; measured now, the
+        # joined launch is 141 us against 93 + 57, and -- what matters more -- the step writes and re-reads half the slabs
+        # (255 x 197 KB instead of 128 x 2 + 256): reduction 24.7 -> 17.8 us, C2 step 0.537 -> 0.509 ms on one box.
+        join = True if WGRAD_JOIN_FOLDED is None else bool(WGRAD_JOIN_FOLDED)
+        if fold is not None and L - 1 <= 8 and join:
             # the folded conv 0 (input S, extra scaled bias sums) and the plain layers 1 .. L-2 in ONE launch
             wgrad_batched(topo, gl, hid, [S] + acts[1:L - 1], hid, nmat, flat[offs[3]:offs[2 + L - 1]],
                           first_rowscale2=topo.deg_pows, first_out=fold.gfold, pending=pending)

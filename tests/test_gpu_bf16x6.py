@@ -41,10 +41,10 @@ def test_weight_gradient_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat, n_layer
     Xs = [torch.randn(N, H, device=DEV) for _ in range(n_layers)]
     rs2 = torch.rand(N, 4, device=DEV) if with_rs2 else None
     stride = nmat * H * H + H
-    saved = nw.WGRAD_BF16
+    saved = (nw.WGRAD_BF16, nw.WGRAD_TM32)
 
-    def run(bf16):
-        nw.WGRAD_BF16 = bf16
+    def run(bf16, tm32=True):
+        nw.WGRAD_BF16, nw.WGRAD_TM32 = bf16, tm32
         if n_layers == 1:
             out = torch.zeros(stride + (nmat * H if with_rs2 else 0), device=DEV)
             nw.wgrad(topo, Gs[0], H, Xs[0], H, nmat, out, rowscale2=rs2)
@@ -55,16 +55,19 @@ def test_weight_gradient_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat, n_layer
         return [out] + ([first] if with_rs2 else [])
     try:
         ref = run(False)
-        got = run(True)
+        got = run(True)                   # 32-row tiles, two workgroups per CU (wgrad16b_kernel, the default)
         got2 = run(True)
+        got64 = run(True, tm32=False)     # 64-row tiles, one workgroup per CU (wgrad16_kernel)
+        got64b = run(True, tm32=False)
     finally:
-        nw.WGRAD_BF16 = saved
+        nw.WGRAD_BF16, nw.WGRAD_TM32 = saved
     lds = pkg._lib.lib().dss2_wgrad_lds_bytes_ex
     covered = lds(2, nmat, H, H, topo.max_nnzT, topo.ellT, 1) != lds(2, nmat, H, H, topo.max_nnzT, topo.ellT, 0)
     assert covered                                                     # these shapes do run the bf16x6 kernel
-    for a, b_, c in zip(got, ref, got2):
-        assert torch.equal(a, c)                                       # fixed-order sums: bitwise reproducible
-        assert rel_err(a, b_) < 2e-6
+    assert pkg.networks._wgrad_tiles(topo, nmat, H, H, 1).nrb == 1       # ... and the default walks the 32-row tiling
+    for a, b_, c, d, e in zip(got, ref, got2, got64, got64b):
+        assert torch.equal(a, c) and torch.equal(d, e)                 # fixed-order sums: bitwise reproducible
+        assert rel_err(a, b_) < 2e-6 and rel_err(d, b_) < 2e-6
 
 
 def test_shapes_outside_the_bf16x6_weight_gradient_fall_back(pkg):

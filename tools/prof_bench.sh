@@ -4,7 +4,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 cd /tmp; rm -rf /tmp/prof_bench
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o s -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o s -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs --min-window-seconds 0.5 > $R/gpurun_out/prof_bench.log 2>&1
 find /tmp/prof_bench -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/prof_bench_kernel_stats.csv \;
 python3 - <<PY
 import csv
