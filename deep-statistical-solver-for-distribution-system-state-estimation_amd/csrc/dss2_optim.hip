@@ -67,8 +67,8 @@ __global__ void __launch_bounds__(256) adamax_flat_kernel(const dss2_adamax_flat
 
 // Batched small dense products in weight space (a few 128^3 products per step; one launch).
 // One 32 x 32 tile of C per workgroup.  The operands are tiny (<= a few hundred KB, L2-resident) and the
-// kernel is latency-bound: a whole K-chunk of 128 is requested at once (32 loads in flight per thread),
-// the next chunk's loads are issued before the current chunk is multiplied out of LDS.
+// kernel is latency-bound: a whole K-chunk of 128 is requested at once (32 loads in flight per thread), up to three
+// chunks ahead, and each chunk is multiplied out of LDS on the matrix pipe, a k quarter per wave.
 constexpr int SG_T = 32, SG_KC = 128, SG_LDA = SG_KC + 4;
 template <bool tA, bool tB>
 __device__ __forceinline__ void small_gemm_body(const dss2_sgemm_desc* __restrict__ dp, float* base_out,
@@ -118,7 +118,15 @@ __device__ __forceinline__ void small_gemm_body(const dss2_sgemm_desc* __restric
       if (tB) Bs[lo + 32 * (q & 3)][hi + 8 * (q >> 2)] = rb[q]; else Bs[hi + 8 * q][lo] = rb[q];
     }
   };
-  float s[4] = {0.f, 0.f, 0.f, 0.f};   // rows hi + 8 q, column lo
+  // The product itself on the matrix pipe (round 4): wave w multiplies the k quarter [32 w, 32 w + 32) of every chunk for the
+  // whole 32 x 32 tile -- 16 v_mfma_f32_32x32x2_f32 per chunk and wave (exact fp32 fma chains), operands from the LDS images:
+  // A as one ds_read_b128 per four k (row stride 132 floats: a 16-lane group covers all 64 banks), B as one ds_read_b32 per k
+  // -- and the four partial tiles meet once, after the last chunk, in LDS, summed in wave order.  The VALU form (one column
+  // and four rows per thread, 16 LDS reads per 32 fma) spent ~6 us per chunk; the chain rule's launch was 18-19 us at C2.
+  const int wave = t >> 6, lane = t & 63, c32 = lane & 31, half = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
   for (int u3 = 0; u3 < 3; ++u3)
     if (u3 < nchunks) issue(u3, rab[u3], rbb[u3]);
@@ -131,34 +139,38 @@ __device__ __forceinline__ void small_gemm_body(const dss2_sgemm_desc* __restric
       stage(rab[u3], rbb[u3]);
       __syncthreads();
       if (c + 3 < nchunks) issue(c + 3, rab[u3], rbb[u3]);
-      for (int k = 0; k < SG_KC; k += 8) {
-        float bv[8];
-        f32x4 av[4][2];
+      const int kw = wave * 32;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) bv[kk] = Bs[k + kk][lo];
+      for (int g = 0; g < 8; ++g) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(&As[c32][kw + 4 * g]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          av[q][0] = *reinterpret_cast<const f32x4*>(&As[hi + 8 * q][k]);
-          av[q][1] = *reinterpret_cast<const f32x4*>(&As[hi + 8 * q][k + 4]);
+        for (int tt = 0; tt < 2; ++tt) {
+          const float a = half ? av[2 * tt + 1] : av[2 * tt];                    // A[i = c32][k = kw + 4 g + 2 tt + half]
+          const float bvv = Bs[kw + 4 * g + 2 * tt + half][c32];               // B[k][j = c32]
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc, 0, 0, 0);
         }
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) s[q] = fmaf(av[q][kk >> 2][kk & 3], bv[kk], s[q]);
       }
     }
   }
-  const int j = j0 + lo;
+  // ---- the four k quarters meet in LDS (the operand images are free after the last barrier below), fixed order
+  __syncthreads();
+  float* red = &As[0][0];                     // [4 waves][16 registers][64 lanes] = 16 KB <= sizeof(As)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  // thread t finishes rows acc_row(r, half) for r = 4 wave .. 4 wave + 3 of column c32
+  const int j = j0 + c32;
   if (j < N) {
     const float vj = u ? v[j] : 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int i = i0 + hi + 8 * q;
+      const int r = 4 * wave + q;
+      const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (i >= M) continue;
-      float r = s[q];
-      if (u) r = fmaf(u[i], vj, r);
+      float sum = (red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + (red[(2 * 16 + r) * 64 + lane] + red[(3 * 16 + r) * 64 + lane]);
+      if (u) sum = fmaf(u[i], vj, sum);
       float* cp = C + (size_t)i * ldc + j;
-      *cp = accum ? *cp + r : r;
+      *cp = accum ? *cp + sum : sum;
     }
   }
 }
