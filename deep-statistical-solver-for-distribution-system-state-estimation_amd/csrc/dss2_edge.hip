@@ -6,10 +6,10 @@
 // live in registers.  Node / edge inputs of a row are wave-uniform, so they are fetched with
 // scalar loads and broadcast for free; the only vector memory traffic is the coalesced S row.
 #include "dss2_common.hpp"
+#include "dss2_edge_tile.hpp"
 
 namespace dss2 {
 
-constexpr int FN = 8, FE = 6, FC = 2 * FN + FE;  // feature dims of the reference's data (networks.py:170)
 
 template <int FPL>
 __global__ void __launch_bounds__(256) edge_hidden_fwd_kernel(
@@ -293,13 +293,6 @@ __global__ void __launch_bounds__(256) edge_combine_kernel(const EdgeCombineArgs
 // chains of dependent scalar global loads (the row-per-wave kernels above are latency bound on
 // rowptr -> col/ent -> x/ea).
 // ------------------------------------------------------------------------------------------
-struct EdgeTileArgs {
-  const float* x; int64_t ldx; const float* ea; int64_t ldea;
-  const float* W1; const float* b1; const float* dS;
-  const int32_t* tile_start; const int2* ell_ent;   // [ntiles][D][TM] {local other node, eid | flip<<31 ; -1 = empty}
-  float* S; float* slab; float* U; int64_t ldu;
-  int h, D, TM, by_source, ntiles;
-};
 
 template <int FPL, bool BWD>
 __global__ void __launch_bounds__(256) edge_tile_kernel(const EdgeTileArgs p) {
@@ -684,71 +677,6 @@ extern "C" int dss2_edge_hidden_bwd(const float* x, int64_t ldx, const float* ea
 // ones yields db1.  (The VALU kernels above need ~90 / ~200 vector instructions per edge and lane; this
 // path needs ~25 MFMAs per slot and row block.)
 // ------------------------------------------------------------------------------------------
-constexpr int EM_LDA = 36;   // A_k row stride: 24 inputs + 8 zero columns (B operand of the dW MFMA) + 4 pad
-
-struct EdgeStage {
-  float* xs; float* eaL; int* other; float* Ak; float* st;
-};
-
-template <int NRB>
-__device__ __forceinline__ EdgeStage edge_stage_ptrs(float* esm, int D, int nw, bool with_st) {
-  constexpr int TM = NRB * 32;
-  EdgeStage s;
-  s.xs = esm;
-  s.eaL = s.xs + TM * FN;
-  s.other = reinterpret_cast<int*>(s.eaL + D * TM * 8);
-  s.Ak = reinterpret_cast<float*>(s.other + D * TM);
-  s.st = with_st ? s.Ak + TM * EM_LDA : nullptr;
-  (void)nw;
-  return s;
-}
-
-template <int NRB>
-__device__ __forceinline__ void edge_stage_tile(const EdgeTileArgs& p, const EdgeStage& s, int tile, int ts, int R, int tid, int nthreads) {
-  constexpr int TM = NRB * 32;
-  const int D = p.D;
-  for (int idx = tid; idx < TM * FN; idx += nthreads) {
-    const int r = idx / FN, k = idx - r * FN;
-    s.xs[idx] = r < R ? p.x[(int64_t)(ts + r) * p.ldx + k] : 0.f;
-  }
-  for (int idx = tid; idx < D * TM; idx += nthreads) {
-    const int2 en = p.ell_ent[(size_t)tile * D * TM + idx];
-    const bool ok = en.y != -1;
-    s.other[idx] = ok ? en.x : -1;
-    float* d = s.eaL + idx * 8;
-    if (ok) {
-      const int eid = en.y & 0x7fffffff;
-      const float sgn = en.y < 0 ? -1.f : 1.f;
-      const float* e = p.ea + (int64_t)eid * p.ldea;
-      d[0] = e[0] * sgn; d[1] = e[1]; d[2] = e[2] * sgn; d[3] = e[3]; d[4] = e[4]; d[5] = e[5];
-    } else {
-      d[0] = 0.f; d[1] = 0.f; d[2] = 0.f; d[3] = 0.f; d[4] = 0.f; d[5] = 0.f;
-    }
-  }
-}
-
-// A_k for slot k: [x_i (8) | x_j (8) | ea (6) | one (1: valid slot, bias-gradient column) | 0 ...]
-template <int NRB>
-__device__ __forceinline__ void edge_build_ak(const EdgeStage& s, int k, int tid, int nthreads, float ones) {
-  constexpr int TM = NRB * 32;
-  for (int idx = tid; idx < TM * 4; idx += nthreads) {
-    const int r = idx >> 2, q = idx & 3;
-    const int o = s.other[k * TM + r];
-    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-    if (o >= 0) {
-      if (q == 0) { v0 = *reinterpret_cast<const f32x4*>(s.xs + r * FN); v1 = *reinterpret_cast<const f32x4*>(s.xs + r * FN + 4); }
-      else if (q == 1) { v0 = *reinterpret_cast<const f32x4*>(s.xs + o * FN); v1 = *reinterpret_cast<const f32x4*>(s.xs + o * FN + 4); }
-      else if (q == 2) {
-        v0 = *reinterpret_cast<const f32x4*>(s.eaL + (k * TM + r) * 8);
-        const f32x4 t = *reinterpret_cast<const f32x4*>(s.eaL + (k * TM + r) * 8 + 4);
-        v1 = f32x4{t[0], t[1], ones, 0.f};
-      }
-    }
-    *reinterpret_cast<f32x4*>(s.Ak + r * EM_LDA + q * 8) = v0;
-    *reinterpret_cast<f32x4*>(s.Ak + r * EM_LDA + q * 8 + 4) = v1;
-  }
-}
-
 template <int NRB>
 __global__ void __launch_bounds__(512) edge_mfma_fwd_kernel(const EdgeTileArgs p) {
   constexpr int TM = NRB * 32;
@@ -982,7 +910,11 @@ extern "C" int dss2_edge_tile_fwd(const float* x, int64_t ldx, const float* ea, 
   if (ntiles <= 0) return 0;
   EdgeTileArgs a{x, ldx, ea, ldea, W1, b1, nullptr, tile_start, reinterpret_cast<const int2*>(ell_ent), S, nullptr, nullptr, 0,
                  h, ell_width, nrb * 32, 0, ntiles};
-  if (edge_mfma_ok(h, nrb, ell_width)) return dispatch_edge_mfma(a, nrb, ntiles, false, as_stream(stream));
+  if (edge_mfma_ok(h, nrb, ell_width)) {
+    // first Linear as bf16x6 on the bf16 matrix pipe (dss2_edge16.hip; DSS2_EDGE_BF16=0: the fp32 MFMA form below)
+    if (edge16_ok(h, nrb, ell_width, false, false)) return launch_edge16(a, nrb, ntiles, false, as_stream(stream));
+    return dispatch_edge_mfma(a, nrb, ntiles, false, as_stream(stream));
+  }
   return launch_edge_tile<false>(a, ntiles, as_stream(stream));
 }
 
@@ -1001,8 +933,11 @@ extern "C" int dss2_edge_tile_bwd(const float* x, int64_t ldx, const float* ea, 
   // n_slabs workgroups walk the tiles (the slab buffer holds one partial per workgroup)
   // (96-row tiles WITH the per-row sums U, the PFN inner-block case: that instantiation misses its register budget, so it is
   //  not compiled -- the VALU tile kernel below serves it)
-  if (!by_source && edge_mfma_ok(h, nrb, ell_width, true) && !(nrb == 3 && U))
+  if (!by_source && edge_mfma_ok(h, nrb, ell_width, true) && !(nrb == 3 && U)) {
+    if (edge16_ok(h, nrb, ell_width, true, U != nullptr))      // (the recomputed gates come from the arithmetic of the bf16x6 forward)
+      return launch_edge16(a, nrb, n_slabs < ntiles ? n_slabs : ntiles, true, as_stream(stream));
     return dispatch_edge_mfma(a, nrb, n_slabs < ntiles ? n_slabs : ntiles, true, as_stream(stream));
+  }
   return launch_edge_tile<true>(a, n_slabs < ntiles ? n_slabs : ntiles, as_stream(stream));
 }
 

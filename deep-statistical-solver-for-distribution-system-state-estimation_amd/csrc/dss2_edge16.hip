@@ -1,0 +1,333 @@
+// Edge MLP, first Linear on the bf16 matrix pipe as bf16x6 (fp32-accurate, dss2_common.hpp: split3): forward, and the
+// recomputation of the pre-activation in the backward.  gfx950.  (/root/reference/networks.py:176-181: the per-edge
+// Linear(22 -> hid) + ReLU, summed per target.)
+//
+// dss2_edge.hip's matrix-pipe kernels run  Z_k = A_k W1^T,  A_k = [x_i | x_j | edge_attr],  as twelve v_mfma_f32_32x32x2_f32 per
+// ELL slot and row block (64 cycles each), between two workgroup barriers per slot (A_k is rebuilt in LDS for every slot), and
+// read the slot's validity word per accumulator element.  Here
+//   * the x_i term does not depend on the slot: C_i = X_i W1a^T once per tile and row block (K = 8, one k-step of 16);
+//   * a slot adds [x_j | edge_attr | 1 | invalid] W1bc^T: K = 8 + 6 + 2 = 16, ONE k-step -- six v_mfma_f32_32x32x16_bf16
+//     (32 cycles each) per slot and row block, started on the accumulator C_i;
+//   * the bias rides in the k = 14 column (a = 1 on valid slots, b = b1: exact, 1 is a bf16 number and b1 = h + m + l), and
+//     the k = 15 column carries a = 1 on EMPTY slots against b = -1e30: an empty slot's pre-activation is hugely negative, the
+//     ReLU removes it, and the epilogue is two vector instructions per element (max, add) with no validity lookups;
+//   * the split planes of every slot are built in ONE phase after the staging (each input element is split once per workgroup,
+//     16-byte row pieces: conflict-free b128 fragment reads without padding), so the slot loop of the forward has no barrier.
+// The backward recomputes the pre-activation with the very same planes, fragments and MFMA order -- its gates are bit for bit
+// the forward's -- and keeps dss2_edge.hip's fp32 form for dW1 += dZ_k^T A_k (a contraction over the tile's rows: bf16x6 there
+// needs transposed images of both operands).
+// Built without packed fp32 VALU ops like every translation unit that runs bf16 MFMAs beside other workgroups (csrc/build.sh).
+#include <stdlib.h>
+
+#include "dss2_edge_tile.hpp"
+
+namespace dss2 {
+
+constexpr float E16_KILL = -1e30f;
+
+// 8 consecutive k of one operand row -> the three bf16 planes (16 bytes each)
+__device__ __forceinline__ void e16_split8(const f32x4 v0, const f32x4 v1, uint4& h, uint4& m, uint4& l) {
+  split3_pair(v0[0], v0[1], h.x, m.x, l.x);
+  split3_pair(v0[2], v0[3], h.y, m.y, l.y);
+  split3_pair(v1[0], v1[1], h.z, m.z, l.z);
+  split3_pair(v1[2], v1[3], h.w, m.w, l.w);
+}
+__device__ __forceinline__ bf16x8 e16_frag(const uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+struct E16Lds {
+  EdgeStage s;
+  char* PI;      // [3 planes][TM][16 B]: x_i
+  char* PK;      // [D][3 planes][2 halves][TM][16 B]: half 0 = x_j, half 1 = edge_attr (6) | valid | empty
+};
+
+template <int NRB>
+__device__ __forceinline__ E16Lds e16_ptrs(float* esm, int D, int nw, bool bwd) {
+  constexpr int TM = NRB * 32;
+  E16Lds L;
+  L.s.xs = esm;
+  L.s.eaL = L.s.xs + TM * FN;
+  L.s.other = reinterpret_cast<int*>(L.s.eaL + D * TM * 8);
+  L.PI = reinterpret_cast<char*>(L.s.other + D * TM);
+  L.PK = L.PI + 3 * TM * 16;
+  float* tail = reinterpret_cast<float*>(L.PK + (size_t)D * 6 * TM * 16);
+  L.s.Ak = bwd ? tail : nullptr;
+  L.s.st = bwd ? tail + TM * EM_LDA : nullptr;
+  (void)nw;
+  return L;
+}
+
+static size_t e16_lds_bytes(int TM, int D, int nw, bool bwd) {
+  size_t b = ((size_t)TM * FN + (size_t)D * TM * 8) * 4 + (size_t)D * TM * 4 + 3 * (size_t)TM * 16 + (size_t)D * 6 * TM * 16;
+  if (bwd) b += (size_t)TM * EM_LDA * 4 + (size_t)nw * TM * 32 * 4;
+  return b;
+}
+
+// all slots' planes in one phase: unit = (image, row) of 8 elements; images: x_i, then (slot k, half) for k < D
+template <int NRB>
+__device__ __forceinline__ void e16_build(const E16Lds& L, int D, int tid, int nthreads) {
+  constexpr int TM = NRB * 32;
+  const EdgeStage& s = L.s;
+  for (int u = tid; u < TM * (1 + 2 * D); u += nthreads) {
+    const int img = u / TM, row = u - img * TM;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    char* dst;
+    int pstride;
+    if (img == 0) {
+      v0 = *reinterpret_cast<const f32x4*>(s.xs + row * FN);
+      v1 = *reinterpret_cast<const f32x4*>(s.xs + row * FN + 4);
+      dst = L.PI + row * 16;
+      pstride = TM * 16;
+    } else {
+      const int k = (img - 1) >> 1, hh = (img - 1) & 1;
+      const int o = s.other[k * TM + row];
+      if (hh == 0) {
+        if (o >= 0) { v0 = *reinterpret_cast<const f32x4*>(s.xs + o * FN); v1 = *reinterpret_cast<const f32x4*>(s.xs + o * FN + 4); }
+      } else if (o >= 0) {
+        v0 = *reinterpret_cast<const f32x4*>(s.eaL + (k * TM + row) * 8);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(s.eaL + (k * TM + row) * 8 + 4);
+        v1 = f32x4{t[0], t[1], 1.f, 0.f};
+      } else {
+        v1 = f32x4{0.f, 0.f, 0.f, 1.f};
+      }
+      dst = L.PK + ((size_t)(k * 3) * 2 + hh) * TM * 16 + row * 16;
+      pstride = 2 * TM * 16;
+    }
+    uint4 h, m, l;
+    e16_split8(v0, v1, h, m, l);
+    *reinterpret_cast<uint4*>(dst) = h;
+    *reinterpret_cast<uint4*>(dst + pstride) = m;
+    *reinterpret_cast<uint4*>(dst + 2 * pstride) = l;
+  }
+}
+
+// the wave's weight fragments: lane (c32 = hidden column of the wave's group, half) holds k = 8 half .. 8 half + 7
+struct E16W { bf16x8 ah, am, al, bh, bm, bl; };      // a*: W1a (x_i columns), b*: W1bc (x_j | edge_attr | b1 | kill)
+__device__ __forceinline__ E16W e16_weights(const float* __restrict__ W1, const float* __restrict__ b1, int j, int half) {
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0, b1v;
+  const float* w = W1 + (size_t)j * FC;
+  if (half == 0) {
+    a0 = f32x4{w[0], w[1], w[2], w[3]}; a1 = f32x4{w[4], w[5], w[6], w[7]};
+    b0 = f32x4{w[8], w[9], w[10], w[11]}; b1v = f32x4{w[12], w[13], w[14], w[15]};
+  } else {
+    b0 = f32x4{w[16], w[17], w[18], w[19]}; b1v = f32x4{w[20], w[21], b1[j], E16_KILL};
+  }
+  uint4 h, m, l;
+  E16W r;
+  e16_split8(a0, a1, h, m, l);
+  r.ah = e16_frag(h); r.am = e16_frag(m); r.al = e16_frag(l);
+  e16_split8(b0, b1v, h, m, l);
+  r.bh = e16_frag(h); r.bm = e16_frag(m); r.bl = e16_frag(l);
+  return r;
+}
+
+// six MFMAs, smallest terms first (the order of the other bf16x6 kernels)
+__device__ __forceinline__ f32x16 e16_mma6(const bf16x8 ah, const bf16x8 am, const bf16x8 al, const bf16x8 bh, const bf16x8 bm,
+                                           const bf16x8 bl, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+  return c;
+}
+
+// C_i of row block rb: x_i W1a^T (the k = 8 .. 15 half of the step is zero on both sides)
+template <int NRB>
+__device__ __forceinline__ f32x16 e16_xterm(const E16Lds& L, const E16W& w, int rb, int c32, int half) {
+  constexpr int TM = NRB * 32;
+  const uint4 z = {0u, 0u, 0u, 0u};
+  const char* pi = L.PI + (rb * 32 + c32) * 16;
+  const uint4 h = half ? z : *reinterpret_cast<const uint4*>(pi);
+  const uint4 m = half ? z : *reinterpret_cast<const uint4*>(pi + TM * 16);
+  const uint4 l = half ? z : *reinterpret_cast<const uint4*>(pi + 2 * TM * 16);
+  f32x16 c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  return e16_mma6(e16_frag(h), e16_frag(m), e16_frag(l), w.ah, w.am, w.al, c);
+}
+
+// pre-activation of slot k, row block rb (bias included; hugely negative on empty slots): THE definition, forward and backward
+template <int NRB>
+__device__ __forceinline__ f32x16 e16_z(const E16Lds& L, const E16W& w, int k, int rb, int c32, int half, const f32x16 ci) {
+  constexpr int TM = NRB * 32;
+  const char* pk = L.PK + ((size_t)(k * 3) * 2 + half) * TM * 16 + (rb * 32 + c32) * 16;
+  const uint4 h = *reinterpret_cast<const uint4*>(pk);
+  const uint4 m = *reinterpret_cast<const uint4*>(pk + 2 * TM * 16);
+  const uint4 l = *reinterpret_cast<const uint4*>(pk + 4 * TM * 16);
+  return e16_mma6(e16_frag(h), e16_frag(m), e16_frag(l), w.bh, w.bm, w.bl, ci);
+}
+
+template <int NRB>
+__global__ void __launch_bounds__(512) edge16_fwd_kernel(const EdgeTileArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float esm[];
+  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+  const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);      // one 32-column group of the hidden layer per wave
+  const int c32 = lane & 31, half = lane >> 5;
+  const int D = p.D;
+  const E16Lds L = e16_ptrs<NRB>(esm, D, nthreads >> 6, false);
+  const int j = cg * 32 + c32;
+  const E16W w = e16_weights(p.W1, p.b1, j, half);
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    edge_stage_tile<NRB>(p, L.s, tile, ts, R, tid, nthreads);
+    __syncthreads();
+    e16_build<NRB>(L, D, tid, nthreads);
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      const f32x16 ci = e16_xterm<NRB>(L, w, rb, c32, half);
+      f32x16 Sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Sacc[r] = 0.f;
+      for (int k = 0; k < D; ++k) {
+        const f32x16 c = e16_z<NRB>(L, w, k, rb, c32, half, ci);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Sacc[r] += fmaxf(c[r], 0.f);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rb * 32 + acc_row(r, half);
+        if (row < R) p.S[(int64_t)(ts + row) * p.h + j] = Sacc[r];
+      }
+    }
+    __syncthreads();      // (a workgroup that walks several tiles restages over the images)
+  }
+}
+
+// backward by target: dW1, db1 (slab per workgroup) and optionally U[row] = sum over incoming edges of dZ
+template <int NRB, bool WITH_U>
+__global__ void __launch_bounds__(512) edge16_bwd_kernel(const EdgeTileArgs p) {
+  constexpr int TM = NRB * 32;
+  extern __shared__ __attribute__((aligned(16))) float esm[];
+  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+  const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c32 = lane & 31, half = lane >> 5;
+  const int D = p.D;
+  const E16Lds L = e16_ptrs<NRB>(esm, D, nthreads >> 6, true);
+  const EdgeStage& s = L.s;
+  float* st = s.st + cg * (TM * 32);        // wave-private dZ tile [TM][32]
+  const int j = cg * 32 + c32;
+  const E16W w = e16_weights(p.W1, p.b1, j, half);
+  f32x16 dWacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dWacc[r] = 0.f;
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    edge_stage_tile<NRB>(p, s, tile, ts, R, tid, nthreads);
+    f32x16 gS[NRB], Uacc[WITH_U ? NRB : 1];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rb * 32 + acc_row(r, half);
+        gS[rb][r] = row < R ? p.dS[(int64_t)(ts + row) * p.h + j] : 0.f;
+        if (WITH_U) Uacc[rb][r] = 0.f;
+      }
+    __syncthreads();
+    e16_build<NRB>(L, D, tid, nthreads);      // (the first slot's fp32 A_k below is built in the same phase)
+    f32x16 ci[NRB];
+    for (int k = 0; k < D; ++k) {
+      edge_build_ak<NRB>(s, k, tid, nthreads, 1.f);
+      __syncthreads();
+      if (k == 0) {
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) ci[rb] = e16_xterm<NRB>(L, w, rb, c32, half);
+      }
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        const f32x16 c = e16_z<NRB>(L, w, k, rb, c32, half, ci[rb]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rb * 32 + acc_row(r, half);
+          const float dz = c[r] > 0.f ? gS[rb][r] : 0.f;
+          if (WITH_U) Uacc[rb][r] += dz;
+          st[row * 32 + c32] = dz;
+        }
+      }
+      wave_lds_sync();
+      // dW1[o][i] += sum_rows dZ[row][o] * A_k[row][i]   (column 22 of A_k is 1 on valid slots: db1)
+      const float* ap = st + half * 32 + c32;
+      const float* bp2 = s.Ak + half * EM_LDA + c32;
+      // a fresh accumulator per slot, added to the running total afterwards (dss2_edge.hip: short fp32 accumulation chains)
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        f32x16 part;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+        for (int n2 = rb * 16; n2 < rb * 16 + 16; ++n2)
+          part = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[n2 * 64], bp2[n2 * 2 * EM_LDA], part, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dWacc[r] += part[r];
+      }
+      __syncthreads();   // everyone is done with A_k (and this wave with its dZ tile)
+    }
+    if (WITH_U) {
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rb * 32 + acc_row(r, half);
+          if (row < R) p.U[(int64_t)(ts + row) * p.ldu + j] = Uacc[rb][r];
+        }
+    }
+  }
+  if (!p.slab) return;
+  float* out = p.slab + (size_t)blockIdx.x * ((size_t)p.h * FC + p.h);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = cg * 32 + acc_row(r, half);
+    if (c32 < FC) out[(size_t)o * FC + c32] = dWacc[r];
+    else if (c32 == FC) out[(size_t)p.h * FC + o] = dWacc[r];
+  }
+}
+
+bool edge16_ok(int h, int nrb, int D, bool bwd, bool with_u) {
+  // (read per call, like DSS2_EDGE_MFMA: lets a test switch forms inside one process; both passes must switch together,
+  //  the backward recomputes the forward's gates)
+  const char* env = getenv("DSS2_EDGE_BF16");
+  if (env && atoi(env) == 0) return false;
+  if ((h & 31) || h > 256 || !(nrb == 1 || nrb == 2 || nrb == 3) || D < 1 || D > 32) return false;
+  if (bwd && with_u && nrb == 3) return false;      // (that instantiation misses its register budget, as in dss2_edge.hip)
+  return e16_lds_bytes(nrb * 32, D, h >> 5, true) <= (size_t)kMaxLdsBytes;
+}
+
+template <int NRB>
+static int launch16(const EdgeTileArgs& a, int grid, bool bwd, hipStream_t s) {
+  const int nw = a.h >> 5;
+  const size_t lds = e16_lds_bytes(NRB * 32, a.D, nw, bwd);
+  if (bwd && a.U) {
+    if constexpr (NRB <= 2) {
+      static std::atomic<uint32_t> lds_done{0};
+      auto kern = edge16_bwd_kernel<NRB, true>;
+      if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "edge16_bwd")) return 1;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, s, a);
+    } else {
+      set_error("edge16_bwd with U: tiles above 64 rows are served by the VALU kernel"); return 2;
+    }
+  } else if (bwd) {
+    static std::atomic<uint32_t> lds_done{0};
+    auto kern = edge16_bwd_kernel<NRB, false>;
+    if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "edge16_bwd")) return 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, s, a);
+  } else {
+    static std::atomic<uint32_t> lds_done{0};
+    auto kern = edge16_fwd_kernel<NRB>;
+    if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "edge16_fwd")) return 1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, s, a);
+  }
+  return check_launch(bwd ? "edge16_bwd" : "edge16_fwd");
+}
+
+int launch_edge16(const EdgeTileArgs& a, int nrb, int grid, bool bwd, hipStream_t s) {
+  switch (nrb) {
+    case 1: return launch16<1>(a, grid, bwd, s);
+    case 2: return launch16<2>(a, grid, bwd, s);
+    default: return launch16<3>(a, grid, bwd, s);
+  }
+}
+
+}  // namespace dss2

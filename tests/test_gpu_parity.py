@@ -78,10 +78,11 @@ def test_tagconv_fwd_bwd(pkg, oracle, grid, hin, hout, K):
         assert rel_err(a.weight.grad, bb.weight.grad) < TOL_GRAD
 
 
-@pytest.mark.parametrize("mfma", ["1", "0"])     # matrix-pipe kernels (default) and the VALU tile kernels
+@pytest.mark.parametrize("mfma", ["bf16x6", "fp32-mfma", "valu"])     # first Linear as bf16x6 (default), on fp32 MFMAs, VALU tile kernels
 @pytest.mark.parametrize("grid,hid", [("cigre14", 128), ("ober_sub", 32), ("cigre14_reswitched", 256), ("cigre14", 64)])
 def test_edge_aggregation_fwd_bwd(pkg, oracle, grid, hid, mfma, monkeypatch):
-    monkeypatch.setenv("DSS2_EDGE_MFMA", mfma)      # read per call by the library
+    monkeypatch.setenv("DSS2_EDGE_MFMA", "0" if mfma == "valu" else "1")      # read per call by the library
+    monkeypatch.setenv("DSS2_EDGE_BF16", "1" if mfma == "bf16x6" else "0")
     torch.manual_seed(3)
     b = pkg.synthetic.make_batch([grid], 5, seed=4)
     x, ea = b["x"][:, :8], b["edge_attr"][:, :6]

@@ -15,8 +15,8 @@ C1, C2, C3, C5S = "grids0-64-32-1", "grids1-4096-128-4", "grids2-1024-128-4", "g
 
 # name -> (switches, [(test file, -k expression)])
 FALLBACKS = {
-    # fp32 MFMA kernels instead of the bf16x6 ones (tile GEMM of the layer chain, weight gradient)
-    "fp32-mfma": (dict(DSS2_CHAIN_BF16="0", DSS2_WGRAD_BF16="0"),
+    # fp32 MFMA kernels instead of the bf16x6 ones (tile GEMM of the layer chain, weight gradient, edge MLP)
+    "fp32-mfma": (dict(DSS2_CHAIN_BF16="0", DSS2_WGRAD_BF16="0", DSS2_EDGE_BF16="0"),
                   [(PARITY, f"golden or tagconv or {C1} or {C2} or {C3}")]),
     # one autograd node per block, separate dx GEMMs, no K split, one launch per layer instead of the layer chain,
     # one weight-gradient launch per layer, un-folded second edge-MLP layer
