@@ -9,11 +9,11 @@ export TMPDIR=/tmp
 cd $R
 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/final_stats -o s -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/final_stats -o s -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs --min-window-seconds 0.5 > $O/bench_under_rocprof.log 2>&1
 find /tmp/final_stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_bench_c2.csv \;
 cd $R
 bash tools/pmc_one.sh chain > $O/pmc_gemm_chain.txt 2>&1
-bash tools/pmc_one.sh wgrad2 > $O/pmc_wgrad_batched.txt 2>&1
+bash tools/pmc_one.sh wgrad3 > $O/pmc_wgrad_batched.txt 2>&1
 bash tools/pmc_one.sh stack4096 > $O/pmc_stack_B4096.txt 2>&1
 bash tools/pmc_one.sh stack64 > $O/pmc_stack_B64.txt 2>&1
 rm -rf $R/gpurun_out/pmc1_*
@@ -64,5 +64,6 @@ if [ -f tools/diag_lib/libdss2_cstamps.so ]; then
 fi
 # the packed-fp32 reproducer (tools/micro/pkfma_beside_mfma.hip) and the 200-launch stress of the real kernel
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/pkfma_beside_mfma.hip -o /tmp/pkfma 2>/dev/null && /tmp/pkfma > $O/pkfma_micro.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/work_beside_mfma.hip -o /tmp/wbm 2>/dev/null && /tmp/wbm > $O/work_beside_mfma.txt 2>&1
 python3 tools/pk_stress.py 200 2>&1 | grep -v amdgpu > $O/pk_stress_shipped.txt
 ls -la $O

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Launch ONLY one kernel shape repeatedly (for rocprofv3 --pmc): argv[1] in {fwd, dgrad, wgrad, chain, wgrad2}."""
+"""Launch ONLY one kernel shape repeatedly (for rocprofv3 --pmc): argv[1] in {fwd, dgrad, wgrad, chain, wgrad2, wgrad3, stack64, stack4096}."""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -34,9 +34,13 @@ for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
         outs = [torch.empty(N, H, device=dev) for _ in range(3)]
         nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=(plan.fwd16[0] if B16 else plan.fwd[0]), Y=o, bias=bias, relu=True) for o in outs],
                            b_format=int(B16))
-    elif which == "wgrad2":      # two layers batched in one launch (the C2 backward)
+    elif which == "wgrad2":      # two layers batched in one launch (the C2 backward of round 3)
         flat2 = torch.empty(2 * (nmat * H * H + H), device=dev)
         nw.wgrad_batched(topo, [g, g], H, [h, h], H, nmat, flat2)
+    elif which == "wgrad3":      # the C2 backward of round 4: the folded conv 0 (extra scaled bias sums) + two plain layers in ONE launch
+        flat2 = torch.empty(2 * (nmat * H * H + H), device=dev)
+        first = torch.empty(nmat * H * H + H + nmat * H, device=dev)
+        nw.wgrad_batched(topo, [g, g, g], H, [h, h, h], H, nmat, flat2, first_rowscale2=topo.deg_pows, first_out=first)
     else:
         nw.wgrad(topo, g, H, h, H, nmat, flat)
 torch.cuda.synchronize()
