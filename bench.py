@@ -343,7 +343,7 @@ def main():
         flops_layer = 2.0 * N * HID * (KHOPS + 1) * HID + 2.0 * KHOPS * E2 * HID
         bytes_layer = 4.0 * N * HID + 4.0 * (KHOPS + 1) * HID * HID          # write the output once + the weights
         chained = layers_per_launch > 1
-        bf16x6 = bool(chained and pkg.networks.CHAIN_BF16 and pkg.networks.chain16_supported(
+        bf16x6 = bool(chained and pkg.flags.CHAIN_BF16 and pkg.networks.chain16_supported(
             pkg.topology.get_topology(ei, N), KHOPS + 1, HID, False))
         kname = ("gemm_chain_kernel<2,3,4,1,true>" if bf16x6 else "gemm_chain_kernel<2,3>") if chained else "gemm_prop_kernel<2,3,false>"
         topo_ = pkg.topology.get_topology(ei, N)

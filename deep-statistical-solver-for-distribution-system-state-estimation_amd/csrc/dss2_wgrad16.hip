@@ -290,24 +290,23 @@ __global__ void __launch_bounds__(W16_NT) wgrad16_kernel(const dss2_wgrad_args p
 // input block w with both output blocks: 72 MFMAs per tile and wave, the X fragment read once for six accumulator blocks.
 // Transposed image: 64 bytes per column and plane (32 rows), 16-byte chunks of 8 rows XOR-swizzled with (column / 8) mod 4:
 // the b128 operand reads of a lane group (16 columns) cover all 64 banks.  The transposed b32 stores of one instruction come
-// from 16 column groups x 2 row pairs; a column is 16 banks wide, so an instruction reaches both halves of the 32 banks only if
-// its lanes write columns of both parities: odd column groups store their four columns in the order 1, 0, 3, 2 (2-way
-// conflicts, which a b32 store does not pay for; in column order they were 4-way, 8-way with a 32 x 1 lane shape).
+// from 16 column groups x 2 row pairs and all write the same column parity (= 16 of the 32 banks): the bank is
+// 16 parity + 4 (chunk ^ key) + (row pair mod 4), the key spreads column-group bits 1-2, and ODD column groups own the row pair
+// rp ^ 2, which spreads the last two bits: 16 distinct banks, 2-way conflicts (free for a b32 store; in thread order they
+// were 4-way -- 150.6 us instead of 132.9 --, 8-way with a 32 x 1 lane shape).  The two lanes that split a row between them
+// sit in the same wave, so a wave-wide load still covers whole rows.
 constexpr int W16B_TM = 32, W16B_ZC = 64, W16B_XW = 128, W16B_NT = 256, W16B_LDZF = 64;
 __device__ __forceinline__ int tpb_key(int col) { return (col >> 3) & 3; }
 __device__ __forceinline__ int tpb_off(int col, int row) { return col * 64 + ((((row >> 3) ^ tpb_key(col)) << 4) | ((row & 7) << 1)); }
 
-// rows (2 rp, 2 rp + 1) x columns (c0 .. c0+3), c0 a multiple of 4 (one key for the four columns): off0 = tpb_off(c0, 2 rp);
-// sw (0 / 1, the parity of the column group): the column order 1, 0, 3, 2
+// rows (2 rp, 2 rp + 1) x columns (c0 .. c0+3), c0 a multiple of 4 (one key for the four columns): off0 = tpb_off(c0, 2 rp)
 template <int NCOLS>
-__device__ __forceinline__ void store_planes_b(char* img, int off0, int sw, const f32x4 v0, const f32x4 v1) {
-  char* base[2] = {img + off0 + sw * 64, img + off0 + (1 - sw) * 64};      // instruction 0, 2 / instruction 1, 3
+__device__ __forceinline__ void store_planes_b(char* img, int off0, const f32x4 v0, const f32x4 v1) {
 #pragma unroll
-  for (int qi = 0; qi < 4; ++qi) {
-    const float a = sw ? v0[qi ^ 1] : v0[qi], b = sw ? v1[qi ^ 1] : v1[qi];      // column qi ^ sw
+  for (int q = 0; q < 4; ++q) {
     uint32_t h, m, l;
-    split3_pair(a, b, h, m, l);
-    char* dst = base[qi & 1] + (qi >> 1) * 128;
+    split3_pair(v0[q], v1[q], h, m, l);
+    char* dst = img + off0 + q * 64;
     *reinterpret_cast<uint32_t*>(dst) = h;
     *reinterpret_cast<uint32_t*>(dst + NCOLS * 64) = m;
     *reinterpret_cast<uint32_t*>(dst + 2 * NCOLS * 64) = l;
@@ -342,10 +341,10 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
 
   // staging units: rows (2 rp, 2 rp + 1) of four columns; 16 column groups x 16 row pairs, one unit of G and two of X (columns
   // 4 cg and 64 + 4 cg) per thread
-  const int cg = tid & 15, rp = tid >> 4, sw = cg & 1;
+  const int cg = tid & 15, rp = (tid >> 4) ^ ((tid & 1) << 1);      // (odd column groups: row pair ^ 2, see the layout note above)
   const int g_off0 = tpb_off(4 * cg, 2 * rp);
   const int x_off0[2] = {tpb_off(4 * cg, 2 * rp), tpb_off(64 + 4 * cg, 2 * rp)};
-  const uint32_t g_goff = (uint32_t)((2 * rp) * p.ldg + 4 * cg) * 4u, x_goff = (uint32_t)((2 * rp) * p.ldx + 4 * cg) * 4u;
+  const uint32_t g_goff = (uint32_t)((2 * rp) * p.ldg + 4 * cg) * 4u;
 
   f32x16 acc[2][NMAT];
 #pragma unroll
@@ -369,10 +368,12 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
     for (int u = 0; u < 2; ++u) {
       const int r = 2 * rp + u;
       pg[u] = (r < R && gcol0 + 4 * cg < p.hout) ? *reinterpret_cast<const f32x4*>(gb + g_goff + (uint32_t)(u * p.ldg) * 4u) : f32x4{0.f, 0.f, 0.f, 0.f};
+      // X rows beyond the tile's R rows are read from its LAST row instead of being zeroed (finite values; they only ever meet
+      // the zero rows of G / P G / P^2 G), columns beyond hin from column group 0 (their products are never stored)
+      const uint32_t xro = (uint32_t)((r < R ? r : R - 1) * p.ldx) * 4u;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        px[2 * i + u] = (r < R && xcol0 + 64 * i + 4 * cg < p.hin) ? *reinterpret_cast<const f32x4*>(xb + x_goff + (uint32_t)(u * p.ldx + 64 * i) * 4u)
-                                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+        px[2 * i + u] = *reinterpret_cast<const f32x4*>(xb + xro + ((xcol0 + 64 * i + 4 * cg < p.hin) ? (uint32_t)(64 * i + 4 * cg) * 4u : 0u));
     }
   };
   auto prop = [&](const float* Zs, float* Zd, char* img) {
@@ -381,11 +382,11 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
     for (int u = 0; u < 2; ++u) {
       const int row = 2 * rp + u;
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      for (int k0 = 0; k0 < D; k0 += 4) {
+      for (int k0 = 0; k0 < D; k0 += 4) {      // (the slice is padded to four entries per row: zero weight, own row)
         int2 en[4];
         f32x4 z[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) en[k] = k0 + k < D ? ell[(k0 + k) * TM + row] : make_int2(row, 0);
+        for (int k = 0; k < 4; ++k) en[k] = ell[(k0 + k) * TM + row];
 #pragma unroll
         for (int k = 0; k < 4; ++k) z[k] = *reinterpret_cast<const f32x4*>(Zs + en[k].x * LDZF + 4 * cg);
 #pragma unroll
@@ -398,7 +399,7 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
       s[u] = a;
       if (Zd) *reinterpret_cast<f32x4*>(Zd + row * LDZF + 4 * cg) = a;
     }
-    store_planes_b<ZC>(img, g_off0, sw, s[0], s[1]);
+    store_planes_b<ZC>(img, g_off0, s[0], s[1]);
   };
 
   if (slice < p.ntiles) load_tile(slice);
@@ -408,13 +409,14 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
     const int next = tile + p.n_split;
     // ---- planes of X and G, the fp32 G slab (first hop's input), the ELL slice, bias partial sums
 #pragma unroll
-    for (int i = 0; i < 2; ++i) store_planes_b<XW>(XT, x_off0[i], sw, px[2 * i], px[2 * i + 1]);
+    for (int i = 0; i < 2; ++i) store_planes_b<XW>(XT, x_off0[i], px[2 * i], px[2 * i + 1]);
 #pragma unroll
     for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(Zf0 + (2 * rp + u) * LDZF + 4 * cg) = pg[u];
-    store_planes_b<ZC>(ZT, g_off0, sw, pg[0], pg[1]);
+    store_planes_b<ZC>(ZT, g_off0, pg[0], pg[1]);
     {
       const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
-      if (tid < D * TM) ell[tid] = src[tid];          // (D <= 8: at most 256 entries)
+      const int Dp = (D + 3) & ~3;                    // (D <= 8: at most 256 entries)
+      if (tid < Dp * TM) ell[tid] = tid < D * TM ? src[tid] : make_int2(tid & (TM - 1), 0);
     }
     bsum += pg[0] + pg[1];
     if constexpr (RS2) {
@@ -517,7 +519,7 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
 size_t wgrad16_lds_bytes(int nrb, int nmat, int hout, int hin, int ell_width) {
   if ((nrb != 1 && nrb != 2) || nmat < 2 || nmat > 3 || ell_width < 1 || ell_width > W16_DMAX || hout <= 32 || (hout & 3) || (hin & 3)) return 0;
   if (nrb == 1) {      // wgrad16b_kernel: two workgroups per CU
-    const size_t b1 = 2 * (size_t)W16B_TM * W16B_LDZF * 4 + (size_t)nmat * 3 * W16B_ZC * 64 + 3 * (size_t)W16B_XW * 64 + (size_t)ell_width * W16B_TM * 8;
+    const size_t b1 = 2 * (size_t)W16B_TM * W16B_LDZF * 4 + (size_t)nmat * 3 * W16B_ZC * 64 + 3 * (size_t)W16B_XW * 64 + (size_t)((ell_width + 3) & ~3) * W16B_TM * 8;
     const size_t red1 = (size_t)(1 + nmat) * W16B_NT * 16;
     return b1 > red1 ? b1 : red1;
   }

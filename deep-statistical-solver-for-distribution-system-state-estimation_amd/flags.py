@@ -1,0 +1,24 @@
+"""Module-level switches of the hot path, in ONE place (environment defaults).
+
+``ops.py``, ``plans.py`` and ``networks.py`` read them at call time as ``flags.<NAME>``, so a test or a tool flips a code path
+inside one process with ``pkg.flags.<NAME> = value`` (and restores it afterwards)."""
+import os as _os
+
+EDGE_TILE_KERNELS = _os.environ.get("DSS2_EDGE_TILE", "1") == "1"       # 0 = row-per-wave CSR kernels
+CHAIN_LAYERS = _os.environ.get("DSS2_CHAIN", "1") == "1"               # hid->hid layers of a block: one chained launch
+WGRAD_BF16 = _os.environ.get("DSS2_WGRAD_BF16", "1") == "1"            # weight gradients as bf16x6 where the kernel covers the shape
+CHAIN_GATE_BITS = _os.environ.get("DSS2_CHAIN_GATE_BITS", "1") == "1"  # tall tiles: the backward chain's ReLU gates as bit words written by the forward chain
+CHAIN_BF16 = _os.environ.get("DSS2_CHAIN_BF16", "1") == "1"            # its tile GEMM as bf16x6 on the bf16 matrix pipe (fp32-accurate)
+CHAIN_HEAD = _os.environ.get("DSS2_CHAIN_HEAD", "1") == "1"            # the narrow head TAGConv's data gradient inside the chained launch of the data gradients
+# ... and the head's forward inside the forward chain: measured break-even at C2 (chain + head 124.5 us against 110.7 + 14.1 us for the
+# two launches: the head's tail runs on one wave per workgroup), so it is off by default; tested under DSS2_CHAIN_HEAD_FWD=1
+CHAIN_HEAD_FWD = _os.environ.get("DSS2_CHAIN_HEAD_FWD", "0") == "1"
+WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"
+STACK_NODE = _os.environ.get("DSS2_STACK_NODE", "1") == "1"              # PFN / SkipPFN as ONE autograd node (_PFNFn)
+DX_MERGE = _os.environ.get("DSS2_DX_MERGE", "1") == "1"                  # dx of the edge MLP as ONE K = 2 hid GEMM
+WGRAD_JOIN_FOLDED = None    # None / True: the folded conv 0 rides in the batched weight-gradient launch of the plain layers; False: its own launch
+FOLD_W2 = _os.environ.get("DSS2_FOLD_W2", "1") == "1"   # 0 = run the edge MLP's second Linear as its own GEMMs
+WGRAD_TM32 = _os.environ.get("DSS2_WGRAD_TM32", "1") == "1"      # bf16x6 weight gradient on 32-row tiles, two workgroups per CU (wgrad16b_kernel)
+WGRAD_TM32_MAX_BYTES = 64 << 20      # ... while one layer's input (N * hin * 4 bytes) stays well inside the Infinity Cache
+WGRAD_PER_CU = int(_os.environ.get("DSS2_WGRAD_PER_CU", "2"))   # cap on persistent wgrad workgroups per CU (= slabs / 256)
+CHAIN_MAX = 8      # layers per dss2_gemm_prop_chain launch (csrc/dss2_gemm_chain.hip)

@@ -32,555 +32,9 @@ from .topology import Topology, get_topology
 
 _F32 = torch.float32
 
-
-def _stream(t: torch.Tensor) -> int:
-    return _lib.stream_ptr(t.device)
-
-
-def _require_gpu(*tensors: torch.Tensor) -> None:
-    for t in tensors:
-        if t is None:
-            continue
-        if not t.is_cuda:
-            raise RuntimeError("DSS2 HIP path needs GPU tensors (gfx950); there is no CPU fallback")
-        if t.is_floating_point() and t.dtype != _F32:
-            raise TypeError("DSS2 HIP path computes in fp32; got " + str(t.dtype))
-
-
-def _rows(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
-    """A 2-D fp32 tensor usable with an explicit leading dimension (column slices of a row-major
-    matrix are fine); anything else is made contiguous."""
-    if t.dim() != 2:
-        raise ValueError("expected a 2-D tensor")
-    if t.stride(1) != 1 or (t.size(0) > 1 and t.stride(0) < t.size(1)):
-        t = t.contiguous()
-    return t, (t.stride(0) if t.size(0) > 1 else t.size(1))
-
-
-def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    return None if t is None else t.data_ptr()
-
-
-def _round8(k: int) -> int:
-    return (k + 7) // 8 * 8
-
-
-def _round16(k: int) -> int:
-    return (k + 15) // 16 * 16
-
-
-def _ncg(j: int) -> int:
-    return (j + 31) // 32
-
-
-# ------------------------------------------------------------------------------------------
-# thin op wrappers over the C ABI
-# ------------------------------------------------------------------------------------------
-def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.Tensor, nmat: int, hout: int,
-              Y: torch.Tensor, bias=None, rowscale=None, relu_src=None, dmask=None, add_src=None, add_ld=0,
-              relu: bool = False, transposed: bool = False, prop_in: int = 0, narrow_h: int = 0,
-              prebias=None, pre_rowscale=None, drop=None, b_format: int = 0) -> None:
-    """drop = (snapshot, p, drop_id): in-kernel dropout mask of layer drop_id (see dropout_snapshot).
-    b_format = 1: Bp holds bf16x3 fragments (_PackPlan.fwd16 / bwd16) and the tile GEMM runs as bf16x6 -- the tall-tile
-    shapes of gemm16_supported only."""
-    if topo.global_only and (nmat > 1 or prop_in > 0):
-        raise NotImplementedError(f"largest connected component has {topo.max_segment} nodes: the fused GEMM + propagation "
-                                  "kernels hold a whole graph in LDS (<= 192 nodes); use the MPN / TAGConv modules, which "
-                                  "switch to the global-memory propagation path")
-    a = _lib.GemmPropArgs()
-    if drop is not None and drop[2] > 0:
-        a.drop_state, a.drop_id = drop[0].data_ptr(), int(drop[2])
-        a.drop_thr, a.drop_scale = _dropout_params(drop[1])
-    a.prebias, a.pre_rowscale = _ptr(prebias), _ptr(pre_rowscale)
-    a.prop_in, a.narrow_h = prop_in, narrow_h
-    a.X, a.ldx, a.kreal, a.kpad = X.data_ptr(), ldx, kreal, (_round16(kreal) if b_format == 1 else _round8(kreal))
-    a.b_format = b_format
-    a.Bp, a.bias, a.rowscale = Bp.data_ptr(), _ptr(bias), _ptr(rowscale)
-    a.relu_src, a.ld_relu = _ptr(relu_src), (relu_src.stride(0) if relu_src is not None else 0)
-    a.dmask, a.ld_dmask = _ptr(dmask), (dmask.stride(0) if dmask is not None else 0)
-    a.add_src, a.ld_add = _ptr(add_src), add_ld
-    a.Y, a.ldy, a.hout, a.ncg = Y.data_ptr(), Y.stride(0), hout, (1 if narrow_h else _ncg(hout))
-    a.relu, a.nmat, a.nrb, a.ntiles = int(relu), nmat, topo.nrb, topo.ntiles
-    a.tile_start = topo.tile_start.data_ptr()
-    if transposed:
-        a.rowptr, a.col, a.w, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
-        a.ell_width, a.ell_tiles = topo.ellT, _ptr(topo.ellT_tiles)
-    else:
-        a.rowptr, a.col, a.w, a.max_nnz = topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.w.data_ptr(), topo.max_nnz
-        a.ell_width, a.ell_tiles = topo.ell, _ptr(topo.ell_tiles)
-    _lib.check(_lib.lib().dss2_gemm_prop(C.byref(a), _stream(Y)), "dss2_gemm_prop")
-
-
-CHAIN_MAX = 8      # layers per dss2_gemm_prop_chain launch (csrc/dss2_gemm_chain.hip)
-
-
-def chain_supported(topo: Topology, nmat: int, hid: int, transposed: bool, have16: bool = False) -> bool:
-    """True when n >= 2 consecutive hid -> hid layers can run as one chained launch (dss2_gemm_prop_chain).  ``have16``: the
-    caller holds bf16x6 weight packs, so shapes that only the split-plane form covers (192-row tiles) count too."""
-    ell, tiles = (topo.ellT, topo.ellT_tiles) if transposed else (topo.ell, topo.ell_tiles)
-    if not CHAIN_LAYERS or tiles is None:
-        return False
-    return bool(_lib.lib().dss2_gemm_prop_chain_supported(topo.nrb, nmat, hid, hid, ell)) or (
-        have16 and chain16_supported(topo, nmat, hid, transposed))
-
-
-def chain_gate_words(topo: Topology, nmat: int, hid: int) -> int:
-    """64-bit words per tile of a layer's sign-bit buffer (``y_bits`` of a forward chain -> ``gate_bits`` of the data-gradient
-    chain over the same tiles); 0 where the chain kernel of this shape has no bit form (or either direction is not chained)."""
-    if not (CHAIN_LAYERS and CHAIN_BF16 and CHAIN_GATE_BITS) or topo.ell_tiles is None or topo.ellT_tiles is None:
-        return 0
-    cache = topo.__dict__.setdefault("_gate_words", {})      # (asked once per forward: keep the two library calls off the step)
-    gw = cache.get((nmat, hid))
-    if gw is None:
-        L = _lib.lib()
-        gw = cache[(nmat, hid)] = min(int(L.dss2_gemm_prop_chain_gate_words(topo.nrb, nmat, hid, hid, topo.ell)),
-                                      int(L.dss2_gemm_prop_chain_gate_words(topo.nrb, nmat, hid, hid, topo.ellT)))
-    return gw
-
-
-def chain16_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bool:
-    """True when the chain can run its tile GEMM on the bf16 matrix pipe (bf16x6, fp32-accurate; dss2_gemm_chain16.hip)."""
-    ell, tiles = (topo.ellT, topo.ellT_tiles) if transposed else (topo.ell, topo.ell_tiles)
-    return CHAIN_BF16 and tiles is not None and bool(_lib.lib().dss2_gemm_prop_chain16_supported(topo.nrb, nmat, hid, hid, ell))
-
-
-def chain_head_supported(topo: Topology, nmat: int, hid: int, nout: int, transposed: bool) -> bool:
-    """True when the narrow head TAGConv (hid -> nout) can ride inside the chained launch of the hid -> hid layers
-    (dss2_gemm_prop_chain_head: forward = the head after the last chained layer, transposed = the chain's input computed from
-    the head's upstream gradient); DSS2_CHAIN_HEAD=0 switches it off."""
-    ell, tiles = (topo.ellT, topo.ellT_tiles) if transposed else (topo.ell, topo.ell_tiles)
-    return bool(CHAIN_HEAD) and CHAIN_BF16 and tiles is not None and bool(
-        _lib.lib().dss2_gemm_prop_chain_head_supported(topo.nrb, nmat, hid, hid, ell, nout))
-
-
-def gemm16_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bool:
-    """True when a single hid -> hid layer (dss2_gemm_prop) can take bf16x3 weights: the tall tiles (128 / 192 rows) that
-    run matrix-sequentially with K-halved staging and therefore have no layer chain."""
-    ell, tiles, nnz = (topo.ellT, topo.ellT_tiles, topo.max_nnzT) if transposed else (topo.ell, topo.ell_tiles, topo.max_nnz)
-    return CHAIN_BF16 and tiles is not None and bool(_lib.lib().dss2_gemm_prop16_supported(topo.nrb, nmat, hid, hid, nnz, ell))
-
-
-def gemm_prop_chain(topo: Topology, X: Optional[torch.Tensor], hid: int, nmat: int, layers: Sequence[dict], transposed: bool = False,
-                    pre_rowscale=None, drop=None, b_format: int = 0, head: Optional[dict] = None) -> None:
-    """layers: dicts with Bp, Y and optionally bias, relu, relu_src, dmask, prebias; every tensor is [N, hid]
-    contiguous.  Layer i reads layer i-1's output from LDS; every Y is written once.  The library chains at most
-    CHAIN_MAX layers per launch; deeper stacks run as consecutive launches (the next one reads the previous one's last Y)."""
-    if head is not None and len(layers) > CHAIN_MAX:
-        raise ValueError("gemm_prop_chain: a fused head needs the whole chain in one launch")
-    if len(layers) > CHAIN_MAX:
-        for c0 in range(0, len(layers), CHAIN_MAX):
-            gemm_prop_chain(topo, X if c0 == 0 else layers[c0 - 1]["Y"], hid, nmat, layers[c0:c0 + CHAIN_MAX],
-                            transposed=transposed, pre_rowscale=pre_rowscale, drop=drop, b_format=b_format)
-        return
-    a = _lib.GemmPropArgs()
-    a.b_format = b_format          # 1: every layer's Bp holds bf16x3 fragments (_PackPlan.fwd16 / bwd16)
-    if drop is not None:            # (snapshot, p); the layers name their masks with "drop_id"
-        a.drop_state = drop[0].data_ptr()
-        a.drop_thr, a.drop_scale = _dropout_params(drop[1])
-    dev_t = X if X is not None else layers[0]["Y"]
-    a.X, a.ldx = (X.data_ptr(), X.stride(0)) if X is not None else (0, hid)
-    a.kreal, a.kpad = hid, (_round16(hid) if b_format == 1 else _round8(hid))
-    a.hout, a.ncg, a.ldy, a.ld_relu, a.ld_dmask, a.ld_add = hid, _ncg(hid), hid, hid, hid, hid
-    a.nmat, a.nrb, a.ntiles = nmat, topo.nrb, topo.ntiles
-    a.tile_start = topo.tile_start.data_ptr()
-    a.pre_rowscale = _ptr(pre_rowscale)
-    if transposed:
-        a.rowptr, a.col, a.w, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
-        a.ell_width, a.ell_tiles = topo.ellT, _ptr(topo.ellT_tiles)
-    else:
-        a.rowptr, a.col, a.w, a.max_nnz = topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.w.data_ptr(), topo.max_nnz
-        a.ell_width, a.ell_tiles = topo.ell, _ptr(topo.ell_tiles)
-    tab = (_lib.ChainLayer * len(layers))()
-    for d, ly in zip(tab, layers):
-        for t_ in (ly["Y"], ly.get("relu_src"), ly.get("dmask")):
-            if t_ is not None and (t_.stride(0) != hid or t_.stride(1) != 1):
-                raise ValueError("gemm_prop_chain: [N, hid] contiguous tensors expected")
-        d.Bp, d.Y, d.bias = ly["Bp"].data_ptr(), ly["Y"].data_ptr(), _ptr(ly.get("bias"))
-        d.relu_src, d.dmask, d.prebias = _ptr(ly.get("relu_src")), _ptr(ly.get("dmask")), _ptr(ly.get("prebias"))
-        d.gate_bits, d.y_bits = _ptr(ly.get("gate_bits")), _ptr(ly.get("y_bits"))      # (only where chain_gate_words() > 0)
-        d.relu = int(bool(ly.get("relu", False)))
-        d.drop_id = int(ly.get("drop_id", 0)) if drop is not None else 0
-    if head is None:
-        _lib.check(_lib.lib().dss2_gemm_prop_chain(C.byref(a), C.addressof(tab), len(layers), _stream(dev_t)), "dss2_gemm_prop_chain")
-        return
-    # head: dict(W=[W_0..W_K] ([nout, hid] contiguous), nout, and forward: Y, bias, add_src / backward: G, gate, Xout, drop_id)
-    hd = _lib.ChainHead()
-    for m, w_ in enumerate(head["W"]):
-        if w_.stride(0) != hid or w_.stride(1) != 1:
-            raise ValueError("gemm_prop_chain: head weights [nout, hid] contiguous expected")
-        hd.W[m] = w_.data_ptr()
-    hd.nout = int(head["nout"])
-    if not transposed:
-        hd.mode = 1
-        y_ = head["Y"]
-        hd.Y, hd.ldy, hd.bias = y_.data_ptr(), y_.stride(0), _ptr(head.get("bias"))
-        add_ = head.get("add_src")
-        if add_ is not None:
-            hd.add_src, hd.ld_add = add_.data_ptr(), int(head["add_ld"])
-    else:
-        hd.mode = 2
-        g_, xo_ = head["G"], head["Xout"]
-        hd.G, hd.ldg, hd.Xout, hd.ldxo = g_.data_ptr(), g_.stride(0), xo_.data_ptr(), xo_.stride(0)
-        gate_ = head.get("gate")
-        if gate_ is not None:
-            hd.gate, hd.ld_gate = gate_.data_ptr(), gate_.stride(0)
-        hd.drop_id = int(head.get("drop_id", 0)) if drop is not None else 0
-    _lib.check(_lib.lib().dss2_gemm_prop_chain_head(C.byref(a), C.addressof(tab), len(layers), C.byref(hd), _stream(dev_t)),
-               "dss2_gemm_prop_chain_head")
-
-
-WGRAD_TM32 = _os.environ.get("DSS2_WGRAD_TM32", "1") == "1"      # bf16x6 weight gradient on 32-row tiles, two workgroups per CU (wgrad16b_kernel)
-
-
-WGRAD_TM32_MAX_BYTES = 64 << 20
-
-
-def _wgrad_tiles(topo: Topology, nmat: int, hout: int, hin: int, b16: int):
-    """The tile set a weight-gradient launch walks: the topology's own, or -- 64-row tilings under the bf16x6 kernel -- a
-    32-row tiling of the same graphs (Topology.tiles_for(1)), on which two 4-wave workgroups share a CU and overlap each
-    other's staging / propagation with their MFMA phases (csrc/dss2_wgrad16.hip)."""
-    # (each X tile is staged by the two workgroups that own its 64-column output halves, at unrelated times: beyond the
-    #  Infinity Cache that is a second trip to HBM -- B = 32768: 3.52 ms against 3.43 on the 64-row kernel -- so the 32-row
-    #  form is taken while one layer's input stays well inside it)
-    if (WGRAD_TM32 and b16 and topo.nrb == 2 and not topo.global_only and nmat in (2, 3) and hout > 32 and 1 <= topo.ellT <= 8
-            and topo.N * hin * 4 <= WGRAD_TM32_MAX_BYTES):
-        alt = topo.tiles_for(1)
-        if alt is not None and alt.ellT_tiles is not None and 1 <= alt.ellT <= 8:
-            return alt
-    return topo
-
-
-def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int, nmat: int, out_flat: torch.Tensor,
-          rowscale=None, rowscale2=None, pending=None, out_len: Optional[int] = None) -> None:
-    """out_flat[nmat*hout*hin + hout] <- [dW_0 .. dW_{nmat-1}, db] (deterministic two-pass sum); with
-    rowscale2 additionally [nmat*hout] scaled column sums of P^m G (one block per matrix).  ``out_len``: reduce only
-    the first out_len elements of the result."""
-    if topo.global_only and nmat > 1:
-        raise NotImplementedError("wgrad with propagation needs LDS-resident graph tiles (graphs of <= 192 nodes)")
-    narrow = nmat > 1 and nmat * hout <= 32 and rowscale2 is None
-    b16 = int(WGRAD_BF16 and rowscale is None and not narrow)
-    ts = _wgrad_tiles(topo, nmat, hout, hin, b16)
-    lds = _lib.lib().dss2_wgrad_lds_bytes_ex(ts.nrb, nmat, hout, hin, ts.max_nnzT, ts.ellT, b16)
-    per_cu = _wgrad_per_cu(int(lds))
-    ys = _lib.lib().dss2_wgrad_y_slices(ts.nrb, nmat, hout, hin, ts.ellT, b16, int(rowscale2 is not None))
-    n_split = min(ts.ntiles, max(1, (256 * per_cu) // ys))
-    stride = nmat * hout * hin + hout + (nmat * hout if rowscale2 is not None else 0)
-    slab = torch.empty(n_split * stride, dtype=_F32, device=G.device)
-    a = _lib.WgradArgs()
-    a.G, a.ldg, a.hout = G.data_ptr(), G.stride(0), hout
-    a.X, a.ldx, a.hin = X.data_ptr(), X.stride(0), hin
-    a.rowscale, a.rowscale2 = _ptr(rowscale), _ptr(rowscale2)
-    a.slab, a.n_split, a.nmat, a.nrb, a.ntiles = slab.data_ptr(), n_split, nmat, ts.nrb, ts.ntiles
-    a.tile_start = ts.tile_start.data_ptr()
-    a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), ts.max_nnzT
-    a.ell_width, a.ell_tiles = ts.ellT, _ptr(ts.ellT_tiles)
-    a.narrow, a.mfma_bf16 = int(narrow), b16
-    st = _stream(G)
-    _lib.check(_lib.lib().dss2_wgrad(C.byref(a), st), "dss2_wgrad")
-    _reduce(slab, 0, n_split, stride, out_flat, stride if out_len is None else out_len, pending)
-
-
-def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Sequence[torch.Tensor], hin: int, nmat: int,
-                  out_flat: torch.Tensor, first_rowscale2=None, first_out=None, pending=None) -> None:
-    """len(Gs) layers of identical shape in one launch:
-    out_flat[j * (nmat*hout*hin + hout) + ...] <- [dW_0 .. dW_{nmat-1}, db] of the plain layers, in order.
-    With ``first_rowscale2`` layer 0 is a folded layer (see ``wgrad``): its result, with the extra nmat*hout
-    scaled sums, goes to ``first_out`` and the remaining layers to ``out_flat`` (two slab reductions)."""
-    nl = len(Gs)
-    ts = _wgrad_tiles(topo, nmat, hout, hin, int(WGRAD_BF16))
-    lds = _lib.lib().dss2_wgrad_lds_bytes_ex(ts.nrb, nmat, hout, hin, ts.max_nnzT, ts.ellT, int(WGRAD_BF16))
-    per_cu = _wgrad_per_cu(int(lds))
-    ys = _lib.lib().dss2_wgrad_y_slices(ts.nrb, nmat, hout, hin, ts.ellT, int(WGRAD_BF16), int(first_rowscale2 is not None))
-    n_split = min(ts.ntiles, max(1, (256 * per_cu) // (nl * ys)))       # the layers share the chip
-    stride = nmat * hout * hin + hout
-    lens = [stride + (nmat * hout if (first_rowscale2 is not None and l == 0) else 0) for l in range(nl)]
-    total = sum(lens)
-    slab = torch.empty(n_split * total, dtype=_F32, device=Gs[0].device)
-    a = _lib.WgradArgs()
-    a.ldg, a.hout, a.ldx, a.hin = Gs[0].stride(0), hout, Xs[0].stride(0), hin
-    for g_, x_ in zip(Gs, Xs):
-        if g_.stride(0) != a.ldg or x_.stride(0) != a.ldx or g_.shape != Gs[0].shape or x_.shape != Xs[0].shape:
-            raise ValueError("wgrad_batched: layers must share shapes and leading dimensions")
-    a.n_split, a.nmat, a.nrb, a.ntiles = n_split, nmat, ts.nrb, ts.ntiles
-    a.mfma_bf16 = int(WGRAD_BF16)
-    a.tile_start = ts.tile_start.data_ptr()
-    a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), ts.max_nnzT
-    a.ell_width, a.ell_tiles = ts.ellT, _ptr(ts.ellT_tiles)
-    PtrArr = C.c_void_p * nl
-    gs, xs = PtrArr(*[g_.data_ptr() for g_ in Gs]), PtrArr(*[x_.data_ptr() for x_ in Xs])
-    offs = [sum(lens[:l]) for l in range(nl)]
-    sl = PtrArr(*[slab.data_ptr() + 4 * o for o in offs])
-    rs = PtrArr(*[(first_rowscale2.data_ptr() if (first_rowscale2 is not None and l == 0) else None) for l in range(nl)])
-    st = _stream(Gs[0])
-    L_ = _lib.lib()
-    _lib.check(L_.dss2_wgrad_batched(C.byref(a), gs, xs, sl, rs, total, nl, st), "dss2_wgrad_batched")
-    if first_rowscale2 is not None:
-        _reduce(slab, 0, n_split, total, first_out, lens[0], pending)
-        if nl > 1:
-            _reduce(slab, lens[0], n_split, total, out_flat, total - lens[0], pending)
-    else:
-        _reduce(slab, 0, n_split, total, out_flat, total, pending)
-
-
-def _reduce(slab: torch.Tensor, slab_off: int, n_slabs: int, stride: int, out: torch.Tensor, length: int, pending) -> None:
-    """out[:length] <- fixed-order sum of the slabs; with ``pending`` (a list) the reduction is only recorded, and
-    ``reduce_pending`` later runs all recorded ones in one launch (the slab tensors are kept alive by the list)."""
-    if pending is not None:
-        pending.append((slab, slab.data_ptr() + 4 * slab_off, n_slabs, stride, out, length))
-        return
-    _lib.check(_lib.lib().dss2_reduce_slabs(slab.data_ptr() + 4 * slab_off, n_slabs, stride, out.data_ptr(), length,
-                                            _stream(slab)), "dss2_reduce_slabs")
-
-
-def reduce_pending(pending) -> None:
-    for c0 in range(0, len(pending), 32):
-        chunk = pending[c0:c0 + 32]
-        descs = (_lib.ReduceDesc * len(chunk))()
-        for d, (slab, ptr, n_slabs, stride, out, length) in zip(descs, chunk):
-            d.slab, d.out, d.stride, d.len, d.n_slabs = ptr, out.data_ptr(), stride, length, n_slabs
-        _lib.check(_lib.lib().dss2_reduce_slabs_multi(C.addressof(descs), len(chunk), _stream(chunk[0][0])),
-                   "dss2_reduce_slabs_multi")
-    pending.clear()
-
-
-def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, ent: torch.Tensor, n_rows: int) -> torch.Tensor:
-    """K6: out[i] = sum of msg rows listed in CSR row i (the scatter-add of aggr='add')."""
-    _require_gpu(msg)
-    msg, ldm = _rows(msg)
-    if ent.dtype != torch.int32:
-        ent = ent.to(torch.int32)
-    out = torch.empty(n_rows, msg.size(1), dtype=_F32, device=msg.device)
-    _lib.check(_lib.lib().dss2_segment_sum(msg.data_ptr(), ldm, rowptr.data_ptr(), ent.data_ptr(), out.data_ptr(),
-                                           out.stride(0), n_rows, msg.size(1), _stream(msg)), "dss2_segment_sum")
-    return out
-
-
-# ------------------------------------------------------------------------------------------
-# weight packing plans
-# ------------------------------------------------------------------------------------------
-_DESC_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("ld", "<i4"),
-                        ("transpose", "<i4"), ("koff", "<i4"), ("kpad", "<i4"), ("ncg", "<i4"), ("joff", "<i4")])
-
-
-_SG_DTYPE = np.dtype([("A", "<u8", (4,)), ("B", "<u8", (4,)), ("C", "<u8"), ("u", "<u8"), ("v", "<u8"), ("c_off", "<i8"),
-                      ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"),
-                      ("transA", "<i4"), ("transB", "<i4"), ("nbatch", "<i4"), ("accumulate", "<i4")])
-
-
-def _sg(A, B, M, N, K, lda, ldb, ldc, C=0, c_off=-1, tA=0, tB=0, u=0, v=0):
-    A = list(A) + [0] * (4 - len(A))
-    B = list(B) + [0] * (4 - len(B))
-    nb = sum(1 for a in A if a)
-    return (A, B, C, u, v, c_off, M, N, K, lda, ldb, ldc, tA, tB, nb, 0)
-
-
-def _sg_table(recs, device):
-    """(device table, record count, largest output in 32x32 blocks) of a list of small-GEMM records."""
-    arr = np.zeros(len(recs), dtype=_SG_DTYPE)
-    for i, r in enumerate(recs):
-        arr[i] = tuple(r)
-    return (torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(recs),
-            max(((r[6] + 31) // 32) * ((r[7] + 31) // 32) for r in recs))
-
-
-def _small_gemm(tab, base, device) -> None:
-    t, cnt, mx = tab
-    _lib.check(_lib.lib().dss2_small_gemm(t.data_ptr(), cnt, mx, base, _lib.stream_ptr(device)), "dss2_small_gemm")
-
-
-class _FoldPlan:
-    """The edge MLP's second Linear folded into the first TAGConv (same mathematics):
-        conv0(S W2^T + deg b2^T) = sum_m A^m (S (W_m W2)^T) + sum_m (A^m deg) (W_m b2)^T + bias
-    so conv 0 runs directly on the aggregated hidden S with folded weights Wf_m = W_m W2 and a
-    rank-(K+1) bias term bf_m = W_m b2 scaled by the topology constants A^m deg in the epilogue: the
-    H x H GEMM of the Linear, its data-gradient and its weight-gradient (3 launches + a slab reduction
-    per step) disappear.  Chain rule back, in
-    weight space (one batched small-GEMM launch):
-        dW_m = dWf_m W2^T + dbf_m (x) b2 ;  dW2 = sum_m W_m^T dWf_m ;  db2 = sum_m W_m^T dbf_m."""
-
-    def __init__(self, W2, b2, ws, device, off_w2: int, off_conv0: int):
-        nm, (ho, hid) = len(ws), ws[0].shape
-        self.nm, self.ho, self.hid, self.device = nm, ho, hid, device
-        self.Wf = torch.zeros(nm, ho, hid, dtype=_F32, device=device)
-        self.bf = torch.zeros(nm, ho, dtype=_F32, device=device)
-        # wgrad of the folded conv writes here: [nm*ho*hid dWf][ho db][nm*ho dbf]
-        self.gfold = torch.zeros(nm * ho * hid + ho + nm * ho, dtype=_F32, device=device)
-        self.one = torch.ones(1, dtype=_F32, device=device)
-        self.params = (W2, b2, list(ws))
-        self.off_w2, self.off_conv0 = off_w2, off_conv0
-        self.ptrs = None
-
-    def records(self, base_off: int = 0):
-        """(forward, backward) small-GEMM records; backward outputs are element offsets from the flat gradient buffer
-        handed to the launch, shifted by ``base_off`` (a stack's blocks share ONE buffer and ONE launch)."""
-        W2, b2, ws = self.params
-        nm, ho, hid = self.nm, self.ho, self.hid
-        f4 = 4
-        fwd, bwd = [], []
-        off_conv0, off_w2 = self.off_conv0 + base_off, self.off_w2 + base_off
-        for m, w in enumerate(ws):
-            fwd.append(_sg([w.data_ptr()], [W2.data_ptr()], ho, hid, hid, hid, hid, hid, C=self.Wf[m].data_ptr()))
-            fwd.append(_sg([w.data_ptr()], [b2.data_ptr()], ho, 1, hid, hid, 1, 1, C=self.bf[m].data_ptr()))
-        g = self.gfold.data_ptr()
-        dWf = [g + f4 * m * ho * hid for m in range(nm)]
-        db = g + f4 * nm * ho * hid
-        dbf = [db + f4 * ho + f4 * m * ho for m in range(nm)]
-        for m, w in enumerate(ws):   # dW_m = dWf_m W2^T + dbf_m (x) b2
-            bwd.append(_sg([dWf[m]], [W2.data_ptr()], ho, hid, hid, hid, hid, hid, c_off=off_conv0 + m * ho * hid,
-                           tB=1, u=dbf[m], v=b2.data_ptr()))
-        # conv0.bias gradient: plain copy of the unscaled column sums (K = 0, rank-1 term with v = 1)
-        bwd.append(_sg([], [], ho, 1, 0, 1, 1, 1, c_off=off_conv0 + nm * ho * hid, u=db, v=self.one.data_ptr()))
-        # dW2 = sum_m W_m^T dWf_m ; db2 = sum_m W_m^T dbf_m
-        bwd.append(_sg([w.data_ptr() for w in ws], dWf, hid, hid, ho, hid, hid, hid, c_off=off_w2, tA=1))
-        bwd.append(_sg([w.data_ptr() for w in ws], dbf, hid, 1, ho, hid, 1, 1, c_off=off_w2 + hid * hid, tA=1))
-        return fwd, bwd
-
-    def _tables(self):
-        fwd, bwd = self.records()
-        self.fwd_tab, self.bwd_tab = _sg_table(fwd, self.device), _sg_table(bwd, self.device)
-
-    def pointers(self):
-        W2, b2, ws = self.params
-        return (W2.data_ptr(), b2.data_ptr()) + tuple(w.data_ptr() for w in ws)
-
-    def _check(self):
-        ptrs = self.pointers()
-        if ptrs != self.ptrs:
-            self._tables()
-            self.ptrs = ptrs
-
-    def refresh_forward(self):
-        self._check()
-        t, n, mx = self.fwd_tab
-        st = _lib.stream_ptr(self.device)
-        _lib.check(_lib.lib().dss2_small_gemm(t.data_ptr(), n, mx, None, st), "dss2_small_gemm")
-
-    def backward(self, flat: torch.Tensor):
-        self._check()
-        t, n, mx = self.bwd_tab
-        st = _lib.stream_ptr(self.device)
-        _lib.check(_lib.lib().dss2_small_gemm(t.data_ptr(), n, mx, flat.data_ptr(), st), "dss2_small_gemm")
-
-
-_WGRAD_PER_CU = int(_os.environ.get("DSS2_WGRAD_PER_CU", "2"))   # cap on persistent wgrad workgroups per CU (= slabs / 256)
-
-
-def _wgrad_per_cu(lds: int) -> int:
-    """Persistent weight-gradient workgroups per CU: what LDS allows, capped at 2 -- every extra workgroup is another
-    slab to write and reduce (measured at H = 32, where LDS would allow 4: caps 1 / 2 / 3 / 4 -> 2.73 / 2.15 / 2.32 /
-    2.27 ms per SkipPFN step)."""
-    return max(1, min(_WGRAD_PER_CU, (160 * 1024) // max(lds, 1)))
-FOLD_W2 = _os.environ.get("DSS2_FOLD_W2", "1") == "1"   # 0 = run the edge MLP's second Linear as its own GEMMs
-
-
-def is_narrow(nmat: int, hout: int) -> bool:
-    """Layers whose nmat*hout output columns fit one 32-wide MFMA block use the packed layouts:
-    forward = matrices side by side in one column group (output-side Horner across column blocks),
-    data-gradient = matrices stacked along k (input-side propagation)."""
-    return nmat > 1 and nmat * hout <= 32
-
-
-class _MatView:
-    """A [rows, cols] block of a row-major parameter tensor (leading dimension ld, element offset
-    off): lets the pack kernel read e.g. W1[:, :fn] in place, without a copy per step."""
-
-    def __init__(self, t: torch.Tensor, rows: int, cols: int, ld: int, off: int = 0):
-        self.t, self.shape, self.ld, self.off = t, (rows, cols), ld, off
-
-    def data_ptr(self) -> int:
-        return self.t.data_ptr() + 4 * self.off
-
-    def is_contiguous(self) -> bool:
-        return self.t.is_contiguous()
-
-
-def _as_view(w):
-    return w if isinstance(w, _MatView) else _MatView(w, w.shape[0], w.shape[1], w.shape[1], 0)
-
-
-class _PackPlan:
-    """Fragment-packed copies (forward and data-gradient layouts) of a list of weight matrices,
-    refreshed by ONE kernel launch per forward."""
-
-    def __init__(self, groups: Sequence[Sequence[torch.Tensor]], device, stacked: bool = False, stacked_groups=(),
-                 bf16_groups=()):
-        # groups[g] = the nmat matrices [hout, hin] of one fused GEMM (TAGConv lins, or one Linear);
-        # entries are Parameters or _MatView blocks of a Parameter.
-        # stacked: every group uses the narrow layouts whatever its width -- forward = matrices side by side along the
-        # output columns, data-gradient = stacked along k -- as ONE plain GEMM (the global-memory propagation path)
-        self.groups = groups = [[_as_view(w) for w in mats] for mats in groups]
-        self.device = device
-        self.stacked = stacked
-        self._stk = [bool(len(mats) > 1 and (stacked or g in stacked_groups)) for g, mats in enumerate(groups)]
-        self.fwd, self.bwd, self.meta = [], [], []
-        for g, mats in enumerate(groups):
-            hout, hin = mats[0].shape
-            nm = len(mats)
-            if is_narrow(nm, hout) or self._stk[g]:
-                kf, cf, kb, cb = _round8(hin), _ncg(nm * hout), _round8(nm * hout), _ncg(hin)
-                self.fwd.append(torch.zeros(cf * (kf // 8) * 256, dtype=_F32, device=device))
-                self.bwd.append(torch.zeros(cb * (kb // 8) * 256, dtype=_F32, device=device))
-            else:
-                kf, cf, kb, cb = _round8(hin), _ncg(hout), _round8(hout), _ncg(hin)
-                self.fwd.append(torch.zeros(nm * cf * (kf // 8) * 256, dtype=_F32, device=device))
-                self.bwd.append(torch.zeros(nm * cb * (kb // 8) * 256, dtype=_F32, device=device))
-            self.meta.append((nm, hout, hin, kf, cf, kb, cb))
-        # bf16_groups: additionally the bf16x3 fragment layout (fp32-accurate tile GEMM on the bf16 matrix pipe,
-        # csrc/dss2_gemm_chain16.hip): [matrix][col group][k/16][3 planes][64 lanes][8 bf16]
-        self.fwd16, self.bwd16 = {}, {}
-        for g in bf16_groups:
-            nm, hout, hin = self.meta[g][0:3]
-            if is_narrow(nm, hout) or self._stk[g]:
-                raise ValueError("bf16x3 packing is for plain per-matrix layouts")
-            kf, cf, kb, cb = _round16(hin), _ncg(hout), _round16(hout), _ncg(hin)
-            self.fwd16[g] = torch.zeros(nm * cf * (kf // 16) * 768, dtype=_F32, device=device)
-            self.bwd16[g] = torch.zeros(nm * cb * (kb // 16) * 768, dtype=_F32, device=device)
-        self.ptrs = None
-        self.table = None
-        self.max_elems = 0
-        self.version = 0
-
-    def pointers(self):
-        return tuple(w.data_ptr() for mats in self.groups for w in mats)
-
-    def records(self):
-        """The pack kernel's descriptor records of this plan (a stack concatenates those of its blocks into one launch)."""
-        recs = []
-        for g, mats in enumerate(self.groups):
-            nm, hout, hin, kf, cf, kb, cb = self.meta[g]
-            narrow = is_narrow(nm, hout) or self._stk[g]
-            for m, w in enumerate(mats):
-                if not w.is_contiguous():
-                    raise RuntimeError("weight matrices must be contiguous")
-                # record = (src, dst, rows, cols, ld, transpose, koff, kpad, ncg, joff)
-                if narrow:
-                    recs.append((w.data_ptr(), self.fwd[g].data_ptr(), hout, hin, w.ld, 1, 0, kf, cf, m * hout))
-                    recs.append((w.data_ptr(), self.bwd[g].data_ptr(), hout, hin, w.ld, 0, m * hout, kb, cb, 0))
-                else:
-                    recs.append((w.data_ptr(), self.fwd[g].data_ptr() + 4 * m * cf * (kf // 8) * 256, hout, hin, w.ld, 1, 0, kf, cf, 0))
-                    recs.append((w.data_ptr(), self.bwd[g].data_ptr() + 4 * m * cb * (kb // 8) * 256, hout, hin, w.ld, 0, 0, kb, cb, 0))
-                self.max_elems = max(self.max_elems, (cf + 1) * (kf // 8 + 1) * 64, (cb + 1) * (kb // 8 + 1) * 64)
-                if g in self.fwd16:      # transpose | 2: bf16x3 layout
-                    k16, b16 = _round16(hin), _round16(hout)
-                    recs.append((w.data_ptr(), self.fwd16[g].data_ptr() + 4 * m * cf * (k16 // 16) * 768, hout, hin, w.ld, 3, 0, k16, cf, 0))
-                    recs.append((w.data_ptr(), self.bwd16[g].data_ptr() + 4 * m * cb * (b16 // 16) * 768, hout, hin, w.ld, 2, 0, b16, cb, 0))
-        return recs
-
-    def _build_table(self):
-        recs = self.records()
-        arr = np.array(recs, dtype=_DESC_DTYPE)
-        self.n_desc = len(recs)
-        self.table = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
-
-    def refresh(self):
-        ptrs = self.pointers()
-        if ptrs != self.ptrs:
-            self._build_table()
-            self.ptrs = ptrs
-        st = _lib.stream_ptr(self.device)
-        _lib.check(_lib.lib().dss2_pack_weights(self.table.data_ptr(), self.n_desc, self.max_elems, st), "dss2_pack_weights")
-        self.version += 1
-        return self.version
+from . import flags as FL
+from .ops import (_DROP_PARAMS, _dropout_params, _ncg, _ptr, _reduce, _require_gpu, _round16, _round8, _rows, _stream, _wgrad_per_cu, _wgrad_tiles, chain16_supported, chain_gate_words, chain_head_supported, chain_supported, csr_axpy, dropout_mask, dropout_snapshot, gather_rows, gemm16_supported, gemm_prop, gemm_prop_chain, is_narrow, reduce_pending, segment_sum, wgrad, wgrad_batched)
+from .plans import (_DESC_DTYPE, _FoldPlan, _MatView, _PackPlan, _SG_DTYPE, _as_view, _sg, _sg_table, _small_gemm)
 
 
 # ------------------------------------------------------------------------------------------
@@ -589,7 +43,7 @@ class _PackPlan:
 def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hout, fn, fe, second_linear=True):
     N = topo.N
     S = torch.empty(N, hid, dtype=_F32, device=W1.device)
-    if topo.ell_ent_tiles is not None and EDGE_TILE_KERNELS:
+    if topo.ell_ent_tiles is not None and FL.EDGE_TILE_KERNELS:
         _lib.check(_lib.lib().dss2_edge_tile_fwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(),
                                                  topo.tile_start.data_ptr(), topo.ell_ent_tiles.data_ptr(), topo.ell,
                                                  topo.nrb, topo.ntiles, S.data_ptr(), hid, fn, fe, _stream(S)),
@@ -620,13 +74,13 @@ def _edge_aggr_backward(topo, gx0, x, ldx, ea, ldea, W1, b1, S, pack_w2_bwd, hid
     gx0 = dS
     dev = dS.device
     stride = hid * (2 * fn + fe) + hid
-    tiled = topo.ell_ent_tiles is not None and topo.ellT_ent_tiles is not None and EDGE_TILE_KERNELS
+    tiled = topo.ell_ent_tiles is not None and topo.ellT_ent_tiles is not None and FL.EDGE_TILE_KERNELS
     n_slabs = min(topo.ntiles, 512) if tiled else int(min(512, max(1, (N + 15) // 16)))
     slab = torch.empty(n_slabs * stride, dtype=_F32, device=dev)
     L = _lib.lib()
     # U0 = sum of dz over incoming edges (x enters as x_i), U1 over outgoing edges (as x_j).  Side by side in one [N, 2 hid]
     # buffer when the K = 2 hid tile fits LDS: dx is then ONE GEMM [U0 | U1] [W1[:, :fn] ; W1[:, fn:2fn]]
-    merged = bool(need_dx and pack_dx is not None and len(pack_dx) > 2 and pack_dx[2] is not None and DX_MERGE and
+    merged = bool(need_dx and pack_dx is not None and len(pack_dx) > 2 and pack_dx[2] is not None and FL.DX_MERGE and
                   L.dss2_gemm_prop_lds_bytes(topo.nrb, 1, _round8(2 * hid), 1, 0, 0) <= 160 * 1024)
     if not need_dx:
         U = u0 = u1 = None
@@ -690,27 +144,6 @@ def _tagconv_forward(topo, h, pack_fwd, bias, nmat, hin, hout, dmask=None, relu=
     return out
 
 
-def csr_axpy(topo: Topology, T: torch.Tensor, out: torch.Tensor, h: int, add=None, transposed: bool = False, bias=None,
-             relu: bool = False, relu_src=None, add_src=None, add_ld: int = 0, drop=None) -> None:
-    """out[:, :h] = epi(add[:, :h] + A_hat T[:, :h]) -- one propagation hop in global memory (dss2_csr_axpy); T, add and
-    out may be column blocks of wider row-major buffers (their stride(0) is the leading dimension)."""
-    a = _lib.CsrAxpyArgs()
-    if transposed:
-        a.rowptr, a.col, a.w = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr()
-    else:
-        a.rowptr, a.col, a.w = topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.w.data_ptr()
-    a.T, a.ldt, a.out, a.ldo = T.data_ptr(), T.stride(0), out.data_ptr(), out.stride(0)
-    a.add, a.ld_add = _ptr(add), (add.stride(0) if add is not None else 0)
-    a.bias, a.relu = _ptr(bias), int(relu)
-    a.relu_src, a.ld_relu = _ptr(relu_src), (relu_src.stride(0) if relu_src is not None else 0)
-    a.add_src, a.ld_src = _ptr(add_src), add_ld
-    if drop is not None and drop[2] > 0:
-        a.drop_state, a.drop_id = drop[0].data_ptr(), int(drop[2])
-        a.drop_thr, a.drop_scale = _dropout_params(drop[1])
-    a.n_rows, a.h = topo.N, h
-    _lib.check(_lib.lib().dss2_csr_axpy(C.byref(a), _stream(out)), "dss2_csr_axpy")
-
-
 def _tagconv_forward_global(topo, h, pack_fwd, bias, nmat, hin, hout, relu=False, add_src=None, add_ld=0, drop=None):
     """TAGConv for graphs beyond the LDS-resident tiles (> 192 nodes): ONE plain tile GEMM X [W_0|..|W_K]^T, then K
     propagation hops in global memory in Horner order, the last one carrying the epilogue.  ``pack_fwd`` is the stacked
@@ -756,60 +189,6 @@ def _tagconv_backward_global(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu
     return dh
 
 
-_DROP_PARAMS = {}
-
-
-def _dropout_params(p: float):
-    """(threshold, scale) of a dropout rate: keep iff Philox uint32 >= threshold (dss2_dropout_params)."""
-    v = _DROP_PARAMS.get(p)
-    if v is None:
-        thr, sc = C.c_uint32(), C.c_float()
-        _lib.lib().dss2_dropout_params(float(p), C.byref(thr), C.byref(sc))
-        v = _DROP_PARAMS[p] = (thr.value, sc.value)
-    return v
-
-
-def dropout_snapshot(mod: nn.Module, device) -> torch.Tensor:
-    """The {seed, offset} pair (device int64[2]) the kernels of ONE forward call and its backward read to regenerate
-    their dropout masks (nn.Dropout, networks.py:268, without storing [N, H] masks).  Eager: the seed is drawn from
-    torch's CPU generator (as nn.Dropout consumes torch's generator in the reference), so ``torch.manual_seed``
-    reproduces a run.  Inside a hipGraph capture a by-value seed would be frozen into the graph, so the module's
-    device-side state is used and advanced by the captured kernel itself: every replay sees fresh masks."""
-    host_seed = int(torch.empty((), dtype=torch.int64).random_().item())       # exactly ONE generator draw per forward call
-    st = getattr(mod, "_rng_state", None)
-    if st is None or st.device != device:
-        st = mod._rng_state = torch.tensor([host_seed ^ 0x5DEECE66D, 0], dtype=torch.int64).to(device)
-    snap = torch.empty(2, dtype=torch.int64, device=device)
-    capturing = torch.cuda.is_current_stream_capturing()
-    _lib.check(_lib.lib().dss2_rng_next(st.data_ptr(), snap.data_ptr(), host_seed, int(not capturing),
-                                        _lib.stream_ptr(device)), "dss2_rng_next")
-    return snap
-
-
-def dropout_mask(snapshot: torch.Tensor, p: float, drop_id: int, n_rows: int, h: int) -> torch.Tensor:
-    """The [n_rows, h] multipliers (0 or 1/(1-p)) the kernels apply for layer mask ``drop_id`` of that forward call
-    (dss2_dropout_mask): lets a test hand the very same masks to the CPU oracle."""
-    out = torch.empty(n_rows, h, dtype=_F32, device=snapshot.device)
-    _lib.check(_lib.lib().dss2_dropout_mask(snapshot.data_ptr(), drop_id, float(p), n_rows, h, out.data_ptr(), h,
-                                            _lib.stream_ptr(snapshot.device)), "dss2_dropout_mask")
-    return out
-
-
-EDGE_TILE_KERNELS = _os.environ.get("DSS2_EDGE_TILE", "1") == "1"       # 0 = row-per-wave CSR kernels
-CHAIN_LAYERS = _os.environ.get("DSS2_CHAIN", "1") == "1"               # hid->hid layers of a block: one chained launch
-WGRAD_BF16 = _os.environ.get("DSS2_WGRAD_BF16", "1") == "1"            # weight gradients as bf16x6 where the kernel covers the shape
-CHAIN_GATE_BITS = _os.environ.get("DSS2_CHAIN_GATE_BITS", "1") == "1"  # tall tiles: the backward chain's ReLU gates as bit words written by the forward chain
-CHAIN_BF16 = _os.environ.get("DSS2_CHAIN_BF16", "1") == "1"            # its tile GEMM as bf16x6 on the bf16 matrix pipe (fp32-accurate)
-CHAIN_HEAD = _os.environ.get("DSS2_CHAIN_HEAD", "1") == "1"            # the narrow head TAGConv's data gradient inside the chained launch of the data gradients
-# ... and the head's forward inside the forward chain: measured break-even at C2 (chain + head 124.5 us against 110.7 + 14.1 us for the
-# two launches: the head's tail runs on one wave per workgroup), so it is off by default; tested under DSS2_CHAIN_HEAD_FWD=1
-CHAIN_HEAD_FWD = _os.environ.get("DSS2_CHAIN_HEAD_FWD", "0") == "1"
-WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"
-STACK_NODE = _os.environ.get("DSS2_STACK_NODE", "1") == "1"              # PFN / SkipPFN as ONE autograd node (_PFNFn)
-DX_MERGE = _os.environ.get("DSS2_DX_MERGE", "1") == "1"                  # dx of the edge MLP as ONE K = 2 hid GEMM
-WGRAD_JOIN_FOLDED = None    # None / True: the folded conv 0 rides in the batched weight-gradient launch of the plain layers; False: its own launch
-
-
 def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=None, dmask=None, need_dh=True,
                       rowscale2=None, defer_wgrad=False, pending=None, drop=None, b_format=0):
     """g: gradient w.r.t. the conv's pre-activation output [N, hout] (already masked).
@@ -831,15 +210,6 @@ def _tagconv_backward(topo, g, h, pack_bwd, nmat, hin, hout, g_flat, relu_src=No
 # ------------------------------------------------------------------------------------------
 # modules
 # ------------------------------------------------------------------------------------------
-def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-    """out[r] = src[idx[r]] (idx: int32 device tensor): dss2_gather_rows."""
-    src, lds = _rows(src)
-    out = torch.empty(idx.numel(), src.size(1), dtype=_F32, device=src.device)
-    _lib.check(_lib.lib().dss2_gather_rows(src.data_ptr(), lds, idx.data_ptr(), out.data_ptr(), out.stride(0) if out.size(0) > 1 else out.size(1),
-                                           idx.numel(), src.size(1), _stream(src)), "dss2_gather_rows")
-    return out
-
-
 class _GatherFn(torch.autograd.Function):
     """x_j = x[edge_index[0]] (by_source) / x_i = x[edge_index[1]] of PyG's propagate; the backward of a gather is the
     segmented sum over the CSR grouped by that end."""
@@ -1174,8 +544,8 @@ def _ensure_plans(mod, topo, dev, ps):
     conv_ps = [ps[4 + l * (nmat + 1): 4 + (l + 1) * (nmat + 1)] for l in range(L)]   # (bias, W_0..W_K)
     hout0 = mod.dim_out if L == 1 else hid
     glob = use_global_path(topo, nmat)       # graphs beyond the LDS-resident tiles, or K > 3: plain GEMMs + propagation hops in global memory
-    fold_on = FOLD_W2 and not is_narrow(nmat, hout0) and not glob
-    b16 = tuple(range(1, L)) if (CHAIN_BF16 and not glob and hid % 4 == 0 and hid <= 256 and not is_narrow(nmat, hid) and L >= 2
+    fold_on = FL.FOLD_W2 and not is_narrow(nmat, hout0) and not glob
+    b16 = tuple(range(1, L)) if (FL.CHAIN_BF16 and not glob and hid % 4 == 0 and hid <= 256 and not is_narrow(nmat, hid) and L >= 2
                                  and (L >= 3 or gemm16_supported(topo, nmat, hid, False))) else ()
     if (mod._plan is None or mod._plan.device != dev or (mod._fold is not None) != fold_on or mod._plan.stacked != glob
             or tuple(sorted(mod._plan.fwd16)) != b16):
@@ -1246,7 +616,7 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
                 act_bits[len(acts)] = layers[-1]["y_bits"] = torch.empty(topo.ntiles * gw, dtype=torch.int64, device=dev)
             acts.append(out_l)
         # the narrow last layer inside the same launch (the tile is still in the waves' registers): dss2_gemm_prop_chain_head
-        head_fused = (CHAIN_HEAD_FWD and use16 and n_chain == L - 1 and n_chain <= CHAIN_MAX and not glob and is_narrow(nmat, mod.dim_out)
+        head_fused = (FL.CHAIN_HEAD_FWD and use16 and n_chain == L - 1 and n_chain <= FL.CHAIN_MAX and not glob and is_narrow(nmat, mod.dim_out)
                       and chain_head_supported(topo, nmat, hid, mod.dim_out, False))
         head = None
         if head_fused:
@@ -1312,7 +682,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
     dS = None
     # slab reductions recorded in ``pending`` run in ONE launch at the end (chained path; always inside a stack)
     fold_late = False
-    if L >= 3 and WGRAD_BATCH and chain_supported(topo, nmat, hid, True, bool(plan.bwd16)):
+    if L >= 3 and FL.WGRAD_BATCH and chain_supported(topo, nmat, hid, True, bool(plan.bwd16)):
         # last layer on its own; then the data-gradients of layers L-2 .. 0 as ONE chained launch
         if pending is None:
             pending = []
@@ -1320,7 +690,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         use16 = bool(plan.bwd16) and chain16_supported(topo, nmat, hid, True)
         # the head's data gradient inside the chained launch (its input tile is computed from the dim_out-wide upstream gradient):
         # dss2_gemm_prop_chain_head, mode 2; only the head's weight gradient keeps a launch of its own
-        head_fused = (use16 and L - 1 <= CHAIN_MAX and is_narrow(nmat, mod.dim_out)
+        head_fused = (use16 and L - 1 <= FL.CHAIN_MAX and is_narrow(nmat, mod.dim_out)
                       and chain_head_supported(topo, nmat, hid, mod.dim_out, True))
         head = None
         if head_fused:
@@ -1347,11 +717,11 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         gemm_prop_chain(topo, (None if head_fused else g), hid, nmat, layers, transposed=True,
                         drop=((snap, p_drop) if snap is not None else None), b_format=int(use16), head=head)
         d_in = layers[-1]["Y"]                  # gradient w.r.t. conv 0's input: dS (folded) or dx0
-        # The folded conv 0 joins the batched launch of the plain layers (round 4; WGRAD_JOIN_FOLDED=False: its own launch).
+        # The folded conv 0 joins the batched launch of the plain layers (round 4; FL.WGRAD_JOIN_FOLDED=False: its own launch).
         # Round 3 kept it apart because three layers x 85 workgroups leave a 13-vs-12-tile tail at C2; measured now, the
         # joined launch is 141 us against 93 + 57, and -- what matters more -- the step writes and re-reads half the slabs
         # (255 x 197 KB instead of 128 x 2 + 256): reduction 24.7 -> 17.8 us, C2 step 0.537 -> 0.509 ms on one box.
-        join = True if WGRAD_JOIN_FOLDED is None else bool(WGRAD_JOIN_FOLDED)
+        join = True if FL.WGRAD_JOIN_FOLDED is None else bool(FL.WGRAD_JOIN_FOLDED)
         if fold is not None and L - 1 <= 8 and join:
             # the folded conv 0 (input S, extra scaled bias sums) and the plain layers 1 .. L-2 in ONE launch
             wgrad_batched(topo, gl, hid, [S] + acts[1:L - 1], hid, nmat, flat[offs[3]:offs[2 + L - 1]],
@@ -1386,7 +756,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
                                          relu_src=(acts[l] if l > 0 else None),
                                          drop=(drop_of(l - 1) if l > 0 else None), pending=pending)
             continue
-        defer = WGRAD_BATCH and hout == hid and not is_narrow(nmat, hout)
+        defer = FL.WGRAD_BATCH and hout == hid and not is_narrow(nmat, hout)
         if defer:
             deferred.append((l, g, acts[l]))
         g16 = hout == hid and (1 + l) in plan.bwd16 and gemm16_supported(topo, nmat, hid, True)
@@ -1586,7 +956,7 @@ class PFN(nn.Module):
     def forward(self, x, edge_index, edge_attr):
         _require_gpu(x, edge_index, edge_attr)
         _no_edge_attr_grad(edge_attr)
-        if not STACK_NODE or self.n_gnn_layers + 1 >= _StackPlan.DROP_STRIDE or not self.mpns[0].edge_aggr.fused_dims():
+        if not FL.STACK_NODE or self.n_gnn_layers + 1 >= _StackPlan.DROP_STRIDE or not self.mpns[0].edge_aggr.fused_dims():
             for m in self.mpns:
                 x = m(x, edge_index, edge_attr)
             return x

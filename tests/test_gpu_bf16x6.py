@@ -41,10 +41,10 @@ def test_weight_gradient_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat, n_layer
     Xs = [torch.randn(N, H, device=DEV) for _ in range(n_layers)]
     rs2 = torch.rand(N, 4, device=DEV) if with_rs2 else None
     stride = nmat * H * H + H
-    saved = (nw.WGRAD_BF16, nw.WGRAD_TM32)
+    saved = (pkg.flags.WGRAD_BF16, pkg.flags.WGRAD_TM32)
 
     def run(bf16, tm32=True):
-        nw.WGRAD_BF16, nw.WGRAD_TM32 = bf16, tm32
+        pkg.flags.WGRAD_BF16, pkg.flags.WGRAD_TM32 = bf16, tm32
         if n_layers == 1:
             out = torch.zeros(stride + (nmat * H if with_rs2 else 0), device=DEV)
             nw.wgrad(topo, Gs[0], H, Xs[0], H, nmat, out, rowscale2=rs2)
@@ -60,7 +60,7 @@ def test_weight_gradient_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat, n_layer
         got64 = run(True, tm32=False)     # 64-row tiles, one workgroup per CU (wgrad16_kernel)
         got64b = run(True, tm32=False)
     finally:
-        nw.WGRAD_BF16, nw.WGRAD_TM32 = saved
+        pkg.flags.WGRAD_BF16, pkg.flags.WGRAD_TM32 = saved
     lds = pkg._lib.lib().dss2_wgrad_lds_bytes_ex
     covered = lds(2, nmat, H, H, topo.max_nnzT, topo.ellT, 1) != lds(2, nmat, H, H, topo.max_nnzT, topo.ellT, 0)
     assert covered                                                     # these shapes do run the bf16x6 kernel
@@ -73,7 +73,7 @@ def test_weight_gradient_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat, n_layer
 def test_shapes_outside_the_bf16x6_weight_gradient_fall_back(pkg):
     """H <= 32 (the K-split 4-wave kernel), K = 3, tall tiles: the fp32 kernel runs, results unchanged by the switch."""
     nw = pkg.networks
-    saved = nw.WGRAD_BF16
+    saved = pkg.flags.WGRAD_BF16
     try:
         for grids, B, H, nmat in ((["cigre14"], 64, 32, 3), (["cigre14"], 64, 64, 4), (["ober_sub"], 12, 64, 3)):
             topo, N = _topo(pkg, grids, B)
@@ -81,13 +81,13 @@ def test_shapes_outside_the_bf16x6_weight_gradient_fall_back(pkg):
             G, X = torch.randn(N, H, device=DEV), torch.randn(N, H, device=DEV)
             outs = []
             for mode in (False, True):
-                nw.WGRAD_BF16 = mode
+                pkg.flags.WGRAD_BF16 = mode
                 o = torch.zeros(nmat * H * H + H, device=DEV)
                 nw.wgrad(topo, G, H, X, H, nmat, o)
                 outs.append(o)
             assert torch.equal(outs[0], outs[1])
     finally:
-        nw.WGRAD_BF16 = saved
+        pkg.flags.WGRAD_BF16 = saved
 
 
 @pytest.mark.parametrize("grids,B,H,nmat,nl", [
@@ -107,12 +107,12 @@ def test_layer_chain_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat, nl):
     bf16x6 against the fp32 MFMA chain, twice (bitwise reproducible)."""
     nw = pkg.networks
     topo, N = _topo(pkg, grids, B)
-    saved16 = nw.CHAIN_BF16
-    nw.CHAIN_BF16 = True                     # (the environment may have switched the default off: these shapes are covered)
+    saved16 = pkg.flags.CHAIN_BF16
+    pkg.flags.CHAIN_BF16 = True                     # (the environment may have switched the default off: these shapes are covered)
     try:
         assert nw.chain16_supported(topo, nmat, H, False) and nw.chain16_supported(topo, nmat, H, True)
     finally:
-        nw.CHAIN_BF16 = saved16
+        pkg.flags.CHAIN_BF16 = saved16
     torch.manual_seed(3)
     Ws = [torch.randn(H, H, device=DEV) * (1.5 / H ** 0.5) for _ in range(nmat)]
     plan = nw._PackPlan([Ws], DEV, bf16_groups=(0,))
@@ -151,12 +151,12 @@ def test_tall_tile_layer_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat):
     data-gradient form with a ReLU gate, against the fp32 MFMA kernel, twice (bitwise reproducible)."""
     nw = pkg.networks
     topo, N = _topo(pkg, grids, B)
-    saved16 = nw.CHAIN_BF16
-    nw.CHAIN_BF16 = True
+    saved16 = pkg.flags.CHAIN_BF16
+    pkg.flags.CHAIN_BF16 = True
     try:
         ok = nw.gemm16_supported(topo, nmat, H, False) and nw.gemm16_supported(topo, nmat, H, True)
     finally:
-        nw.CHAIN_BF16 = saved16
+        pkg.flags.CHAIN_BF16 = saved16
     assert topo.nrb == 6
     if H == 96:
         assert not ok      # (bf16x6 exists for the K-halved configuration only; the model code then keeps the fp32 weights)
@@ -199,13 +199,13 @@ def test_tall_tile_layer_chain_equals_layer_by_layer(pkg, B, H, nmat, nl):
     nw = pkg.networks
     topo, N = _topo(pkg, ["ober179"], B)
     assert topo.nrb == 6
-    saved16 = nw.CHAIN_BF16
-    nw.CHAIN_BF16 = True
+    saved16 = pkg.flags.CHAIN_BF16
+    pkg.flags.CHAIN_BF16 = True
     try:
         assert nw.chain16_supported(topo, nmat, H, False) and nw.chain16_supported(topo, nmat, H, True)
         assert nw.chain_supported(topo, nmat, H, False, have16=True) and not nw.chain_supported(topo, nmat, H, False)
     finally:
-        nw.CHAIN_BF16 = saved16
+        pkg.flags.CHAIN_BF16 = saved16
     torch.manual_seed(7)
     Ws = [torch.randn(H, H, device=DEV) * (1.5 / H ** 0.5) for _ in range(nmat)]
     plan = nw._PackPlan([Ws], DEV, bf16_groups=(0,))

@@ -13,8 +13,8 @@ DEV = "cuda:0"
 
 def _run(pkg, model, b, fwd, bwd, seed):
     nw = pkg.networks
-    saved = nw.CHAIN_HEAD_FWD, nw.CHAIN_HEAD
-    nw.CHAIN_HEAD_FWD, nw.CHAIN_HEAD = fwd, bwd
+    saved = pkg.flags.CHAIN_HEAD_FWD, pkg.flags.CHAIN_HEAD
+    pkg.flags.CHAIN_HEAD_FWD, pkg.flags.CHAIN_HEAD = fwd, bwd
     try:
         for p in model.parameters():
             p.grad = None
@@ -25,7 +25,7 @@ def _run(pkg, model, b, fwd, bwd, seed):
         (out * w).sum().backward()
         return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in model.parameters()]
     finally:
-        nw.CHAIN_HEAD_FWD, nw.CHAIN_HEAD = saved
+        pkg.flags.CHAIN_HEAD_FWD, pkg.flags.CHAIN_HEAD = saved
 
 
 @pytest.mark.parametrize("cls,args,B", [
@@ -61,15 +61,15 @@ def test_fused_head_against_the_oracle(pkg, oracle):
     mine = mine.to(DEV)
     out64 = ref(b["x"][:, :8].double(), b["edge_index"], b["edge_attr"][:, :6].double())
     nw = pkg.networks
-    saved = nw.CHAIN_HEAD_FWD, nw.CHAIN_HEAD
-    nw.CHAIN_HEAD_FWD, nw.CHAIN_HEAD = True, True
+    saved = pkg.flags.CHAIN_HEAD_FWD, pkg.flags.CHAIN_HEAD
+    pkg.flags.CHAIN_HEAD_FWD, pkg.flags.CHAIN_HEAD = True, True
     try:
         out = mine(b["x"][:, :8].to(DEV), b["edge_index"].to(DEV), b["edge_attr"][:, :6].to(DEV))
         w = torch.linspace(-1.0, 1.0, out64.numel(), dtype=torch.float64).view_as(out64)
         (out * w.float().to(DEV)).sum().backward()
         (out64 * w).sum().backward()
     finally:
-        nw.CHAIN_HEAD_FWD, nw.CHAIN_HEAD = saved
+        pkg.flags.CHAIN_HEAD_FWD, pkg.flags.CHAIN_HEAD = saved
     assert rel_err(out, out64) < 1e-5
     for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
         assert rel_err(p.grad, q.grad) < max(1e-4, 8.0 / b["x"].shape[0]), n

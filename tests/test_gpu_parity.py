@@ -476,10 +476,10 @@ def test_chained_and_batched_launches_equal_per_layer_launches(pkg, oracle, grid
     dim_out = 8 if cls == "SkipMPN" else 2
     torch.manual_seed(11)
     model = getattr(pkg, cls)(8, 6, dim_out, hid, L, 2, p).to(DEV)
-    saved = (nw.CHAIN_LAYERS, nw.WGRAD_BATCH, nw.FOLD_W2, nw.CHAIN_BF16)
+    saved = (pkg.flags.CHAIN_LAYERS, pkg.flags.WGRAD_BATCH, pkg.flags.FOLD_W2, pkg.flags.CHAIN_BF16)
 
     def run(chain, batch, fold, bf16=False):
-        nw.CHAIN_LAYERS, nw.WGRAD_BATCH, nw.FOLD_W2, nw.CHAIN_BF16 = chain, batch, fold, bf16
+        pkg.flags.CHAIN_LAYERS, pkg.flags.WGRAD_BATCH, pkg.flags.FOLD_W2, pkg.flags.CHAIN_BF16 = chain, batch, fold, bf16
         for q in model.parameters():
             q.grad = None
         torch.manual_seed(5)                       # same dropout masks
@@ -495,16 +495,16 @@ def test_chained_and_batched_launches_equal_per_layer_launches(pkg, oracle, grid
     try:
         o_ref, g_ref = run(False, False, True)     # per-layer launches (fold on: same forward arithmetic)
         o_chain, g_chain = run(True, True, True)
-        nw.WGRAD_JOIN_FOLDED = True                # folded conv 0 in the same batched launch as the plain layers
+        pkg.flags.WGRAD_JOIN_FOLDED = True                # folded conv 0 in the same batched launch as the plain layers
         o_join, g_join = run(True, True, True)
-        nw.WGRAD_JOIN_FOLDED = False
+        pkg.flags.WGRAD_JOIN_FOLDED = False
         o_sep, g_sep = run(True, True, True)
         o_unfold, g_unfold = run(False, False, False)
-        nw.WGRAD_JOIN_FOLDED = None
+        pkg.flags.WGRAD_JOIN_FOLDED = None
         o_16, g_16 = run(True, True, True, bf16=True)     # the chain's tile GEMM as bf16x6 (the default): fp32 rounding level
     finally:
-        nw.CHAIN_LAYERS, nw.WGRAD_BATCH, nw.FOLD_W2, nw.CHAIN_BF16 = saved
-        nw.WGRAD_JOIN_FOLDED = None
+        pkg.flags.CHAIN_LAYERS, pkg.flags.WGRAD_BATCH, pkg.flags.FOLD_W2, pkg.flags.CHAIN_BF16 = saved
+        pkg.flags.WGRAD_JOIN_FOLDED = None
     assert torch.equal(o_chain, o_ref) and torch.equal(o_join, o_ref) and torch.equal(o_sep, o_ref)
     # (the batched schedules sum their slabs in the 16-lane order of reduce_slabs_multi_v4, the per-layer launches in the 4-group
     #  order of reduce_slabs: two fixed orders, fp32 rounding apart)

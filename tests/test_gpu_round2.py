@@ -73,10 +73,10 @@ def test_deep_stacks_chunk_the_layer_chain(pkg, oracle, L, hid):
     st = tuple(s.to(DEV) for s in b["stats"])
     real_chain = pkg.networks.gemm_prop_chain
     def counting(topo, X, h, nmat, layers, **kw):
-        if len(layers) <= pkg.networks.CHAIN_MAX:
+        if len(layers) <= pkg.flags.CHAIN_MAX:
             launches.append(len(layers))
         return real_chain(topo, X, h, nmat, layers, **kw)
-    pkg.networks.gemm_prop_chain = counting
+    pkg.networks.gemm_prop_chain = pkg.ops.gemm_prop_chain = counting      # (ops: the chunks of a deep stack are its own recursive calls)
     try:
         out = mine(x[:, :8], ei, ea[:, :6])
         loss = pkg.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2],
@@ -84,8 +84,8 @@ def test_deep_stacks_chunk_the_layer_chain(pkg, oracle, L, hid):
                                 node_param=x[:, 8:], edge_param=ea[:, 6:])
         loss.backward()
     finally:
-        pkg.networks.gemm_prop_chain = real_chain
-    if pkg.networks.CHAIN_LAYERS:      # (DSS2_CHAIN=0: one launch per layer, nothing to count)
+        pkg.networks.gemm_prop_chain = pkg.ops.gemm_prop_chain = real_chain
+    if pkg.flags.CHAIN_LAYERS:      # (DSS2_CHAIN=0: one launch per layer, nothing to count)
         assert max(launches) <= 8 and sum(launches) == 2 * (L - 1), launches      # forward + data-gradient chains
     assert rel_err(out, out64) < 1e-5
     assert abs(loss.item() - l64.item()) <= 1e-5 * abs(l64.item())

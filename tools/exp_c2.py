@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU: the C2 step (or another cfgbench-style configuration) under module-flag settings, eager and replayed.
-    python tools/exp_c2.py [B=4096] [grid=cigre14] [H=128] [L=4] [FLAG=value ...]      (FLAG: an attribute of <pkg>.networks)
+    python tools/exp_c2.py [B=4096] [grid=cigre14] [H=128] [L=4] [FLAG=value ...]      (FLAG: an attribute of <pkg>.flags)
 Several settings in one call: separate them with '--'."""
 import importlib, os, sys, time
 import torch
@@ -15,8 +15,8 @@ def run(setting):
     B, grid, H, L = int(kv.pop("B", 4096)), kv.pop("grid", "cigre14"), int(kv.pop("H", 128)), int(kv.pop("L", 4))
     saved = {}
     for k, v in kv.items():
-        saved[k] = getattr(pkg.networks, k)
-        setattr(pkg.networks, k, {"True": True, "False": False, "None": None}.get(v, v if not v.lstrip("-").isdigit() else int(v)))
+        saved[k] = getattr(pkg.flags, k)
+        setattr(pkg.flags, k, {"True": True, "False": False, "None": None}.get(v, v if not v.lstrip("-").isdigit() else int(v)))
     torch.manual_seed(0)
     b = pkg.synthetic.make_batch(grid.split("+"), B, seed=1)
     x, ei, ea = b["x"].to(dev), b["edge_index"].to(dev), b["edge_attr"].to(dev)
@@ -55,7 +55,7 @@ def run(setting):
         gsum = sum(float(p.grad.double().abs().sum()) for p in params)
     print(f"{' '.join(setting) or '(defaults)':60s} eager {e:.4f} ms  replay {r:.4f} ms  loss {l:.9g}  sum|grad| {gsum:.9g}", flush=True)
     for k, v in saved.items():
-        setattr(pkg.networks, k, v)
+        setattr(pkg.flags, k, v)
 
 
 args, cur = [], []
