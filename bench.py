@@ -325,13 +325,24 @@ def main():
             e1.record()
             events.append((e0, e1, 1))
 
+    wg_events = []
+    orig_wgb = nw_mod.wgrad_batched
+
+    def timed_wgrad_batched(topo, Gs, hout, Xs, hin, nmat, out_flat, **kw):   # the block's H -> H weight gradients (one launch)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig_wgb(topo, Gs, hout, Xs, hin, nmat, out_flat, **kw)
+        e1.record()
+        wg_events.append((e0, e1, len(Gs), hout, hin, nmat))
+
     def timed_pass(n_steps):
         events.clear()
-        nw_mod.gemm_prop_chain, nw_mod.gemm_prop = timed_chain, timed_single
+        wg_events.clear()
+        nw_mod.gemm_prop_chain, nw_mod.gemm_prop, nw_mod.wgrad_batched = timed_chain, timed_single, timed_wgrad_batched
         for _ in range(n_steps):
             step()
         torch.cuda.synchronize()
-        nw_mod.gemm_prop_chain, nw_mod.gemm_prop = orig_chain, orig_single
+        nw_mod.gemm_prop_chain, nw_mod.gemm_prop, nw_mod.wgrad_batched = orig_chain, orig_single, orig_wgb
         durs = sorted(a.elapsed_time(b) for a, b, _ in events)
         layers = sum(n for _, _, n in events)
         return sum(durs) / len(durs), durs[len(durs) // 2], len(durs), layers / len(durs)
@@ -375,6 +386,19 @@ def main():
             "algorithmic_bytes_per_launch": 4.0 * N * HID + bytes_layer * layers_per_launch,
             "mode": "single stream",
         }
+        if wg_events:       # the second-largest kernel of the step, same reading: algorithmic FLOPs / in-situ launch time
+            nl, ho, hi, nm = wg_events[0][2:]
+            wflops = nl * 2.0 * N * nm * ho * hi
+            wus = sum(a.elapsed_time(b) for a, b, *_ in wg_events) / len(wg_events) * 1e3
+            wbf16 = bool(pkg.flags.WGRAD_BF16)
+            wpeak = BF16_MFMA_PEAK_TF / 6.0 if wbf16 else FP32_MFMA_PEAK_TF
+            result["roofline_wgrad"] = {
+                "kernel": f"the block's {nl} H->H weight gradients dW_k = ((A^T)^k g)^T h in one launch "
+                          + ("(dss2::wgrad16b_kernel / wgrad16_kernel, bf16x6)" if wbf16 else "(dss2::wgrad_kernel, fp32 MFMA)"),
+                "bound": "mfma", "achieved": wflops / (wus * 1e-6) / 1e12, "peak": wpeak, "unit": "TFLOP/s",
+                "frac": wflops / (wus * 1e-6) / 1e12 / wpeak, "avg_launch_us": wus, "launches_timed": len(wg_events),
+                "algorithmic_flops_per_launch": wflops, "traffic": None,
+            }
         if bf16x6:
             # The tile GEMM runs on the bf16 matrix pipe as six v_mfma_f32_32x32x16_bf16 per fp32 product group (operands split
             # into three bf16 pieces, fp32 accumulation: fp32-accurate, tools/accuracy_bf16x6.py).  The bound of the pipe the
