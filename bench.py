@@ -115,7 +115,6 @@ def time_other_config(pkg, dev, stream, tag, grids, B, cls, cargs, ne, blocks, s
     def step():
         for p in params:
             p.grad = None
-        pkg.data.prefetch_vminmax(npar)
         out = model(xin, ei, ein)
         loss = pkg.gsp_wls_edge(input=xin, edge_input=ein, output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2], edge_std=st[3],
                                 edge_index=ei, reg_coefs=REG, num_samples=None, node_param=npar, edge_param=epar)
@@ -223,7 +222,6 @@ def main():
     def step():
         for p in params:
             p.grad = None
-        pkg.data.prefetch_vminmax(npar)      # (inside a hipGraph capture: the batch's V_hv / V_lv launch on a side branch; eager: no-op)
         out = model(xin, ei, ein)
         loss = pkg.gsp_wls_edge(input=xin, edge_input=ein, output=out, x_mean=stats[0], x_std=stats[1],
                                 edge_mean=stats[2], edge_std=stats[3], edge_index=ei, reg_coefs=REG,

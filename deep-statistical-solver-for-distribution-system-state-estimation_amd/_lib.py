@@ -204,7 +204,6 @@ _SIGNATURES = {
     "dss2_wls_loss_partials": (C.c_int, [C.POINTER(WlsArgs), C.c_void_p]),
     "dss2_wls_loss_grad": (C.c_int, [C.POINTER(WlsArgs), C.c_void_p]),
     "dss2_wls_loss_value": (C.c_int, [C.POINTER(WlsArgs), C.c_void_p]),
-    "dss2_vminmax": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "dss2_get_pflow": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                  C.c_int, C.c_void_p]),

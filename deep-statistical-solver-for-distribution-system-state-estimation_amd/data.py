@@ -70,13 +70,7 @@ def _vminmax_scratch(node_param: torch.Tensor):
     import weakref
     if torch.cuda.is_current_stream_capturing():
         # a capture executes nothing and its replays run on whatever the static input holds by then: the captured step
-        # always carries its own vminmax launch and never reads or fills the cache -- either the one
-        # ``prefetch_vminmax`` put on a side branch at the start of the step (joined here), or one in front of the partials
-        pend = _VMM_PENDING.pop((id(node_param._base if node_param._base is not None else node_param), node_param.data_ptr()), None)
-        if pend is not None:
-            vmm, side = pend
-            torch.cuda.current_stream(node_param.device).wait_stream(side)
-            return vmm, True
+        # always carries its own vminmax launch and never reads or fills the cache
         return torch.empty(130, dtype=_F32, device=node_param.device), False
     base = node_param._base if node_param._base is not None else node_param
     key = id(base)
@@ -94,28 +88,6 @@ def _vminmax_scratch(node_param: torch.Tensor):
             _VMM_CACHE.pop(key, None)
     _VMM_CACHE[key] = (weakref.ref(base, _drop), sig, vmm)
     return vmm, False
-
-
-_VMM_PENDING = {}       # (id(base tensor), data_ptr) -> (vminmax scratch, side stream) of a capture in progress
-_VMM_SIDE = {}          # device -> side stream
-
-
-def prefetch_vminmax(node_param: torch.Tensor) -> None:
-    """Call at the START of a training step that may be captured into a hipGraph, with the ``node_param`` tensor the loss
-    will get (``x[:, 8:]``).  During a capture the batch-global V_hv / V_lv launch goes on a side branch of the graph -- it
-    depends on the batch only -- instead of between the model forward and the loss (4.7 us of a 0.5 ms C2 step); the loss
-    joins the branch.  Outside a capture this does nothing: the eager path keeps V_hv / V_lv cached per tensor."""
-    if not node_param.is_cuda or not torch.cuda.is_current_stream_capturing():
-        return
-    npar, ld_np = _rows(node_param)
-    dev = node_param.device
-    side = _VMM_SIDE.get(dev)
-    if side is None:
-        side = _VMM_SIDE[dev] = torch.cuda.Stream(device=dev)
-    vmm = torch.empty(130, dtype=_F32, device=dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
-    _lib.check(_lib.lib().dss2_vminmax(npar.data_ptr(), ld_np, npar.size(0), vmm.data_ptr(), side.cuda_stream), "dss2_vminmax")
-    _VMM_PENDING[(id(node_param._base if node_param._base is not None else node_param), node_param.data_ptr())] = (vmm, side)
 
 
 def invalidate_vminmax(node_param: Optional[torch.Tensor] = None) -> None:

@@ -99,12 +99,10 @@ class GraphedTrainer:
         def step_fn():
             for p in params:
                 p.grad = None
-            npar = sx[:, 8:]
-            dss2_data.prefetch_vminmax(npar)      # (capture: V_hv / V_lv of the batch on a side branch of the graph)
             out = model(sx[:, :8], sei, sea[:, :6])
             loss = dss2_data.gsp_wls_edge(input=sx[:, :8], edge_input=sea[:, :6], output=out, x_mean=st[0], x_std=st[1],
                                           edge_mean=st[2], edge_std=st[3], edge_index=sei, reg_coefs=reg, num_samples=None,
-                                          node_param=npar, edge_param=sea[:, 6:], group=group)
+                                          node_param=sx[:, 8:], edge_param=sea[:, 6:], group=group)
             loss.backward(dss2_data.unit_grad(loss))
             opt.step()
             if not torch.cuda.is_current_stream_capturing():

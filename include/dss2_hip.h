@@ -430,12 +430,6 @@ int dss2_wls_loss_grad(const dss2_wls_args* args_host, void* stream);
 /* loss[0] <- the loss of the batch sums[0..6] describe (after a data-parallel caller has all-reduced them) */
 int dss2_wls_loss_value(const dss2_wls_args* args_host, void* stream);
 
-/* The batch-global V_hv / V_lv of get_pflow (data.py:335-336: max / min of node_param[:, 0]) on their own: fills the
- * vminmax[130] scratch dss2_wls_loss_partials reads when DSS2_WLS_VMM_CACHED is set.  A caller whose step is captured
- * into a hipGraph launches it on a side branch at the start of the step (it depends on the batch only, not on the model),
- * so that it leaves the critical path between the model forward and the loss. */
-int dss2_vminmax(const float* node_param, int64_t ld_np, int64_t n_nodes, float* vminmax, void* stream);
-
 /* get_pflow alone (data.py:328-390; evaluation path dss2_run.py:193-194): y[N,2] = (v, theta)
  * in physical units; writes pflow[E,8] = loading_lines, loading_trafo, P_from, Q_from, P_to,
  * Q_to, I_from, I_to.  vminmax[130] is device scratch.  apply_shift != 0: the angle difference is

@@ -27,7 +27,6 @@ def run(setting):
     def step():
         for p in params:
             p.grad = None
-        pkg.data.prefetch_vminmax(x[:, 8:])
         out = model(x[:, :8], ei, ea[:, :6])
         loss = pkg.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2],
                                 edge_std=st[3], edge_index=ei, reg_coefs=REG, num_samples=None, node_param=x[:, 8:], edge_param=ea[:, 6:])
