@@ -296,7 +296,10 @@ __global__ void __launch_bounds__(W16_NT) wgrad16_kernel(const dss2_wgrad_args p
 // were 4-way -- 150.6 us instead of 132.9 --, 8-way with a 32 x 1 lane shape).  The two lanes that split a row between them
 // sit in the same wave, so a wave-wide load still covers whole rows.
 constexpr int W16B_TM = 32, W16B_ZC = 64, W16B_XW = 128, W16B_NT = 256, W16B_LDZF = 64;
-__device__ __forceinline__ int tpb_key(int col) { return (col >> 3) & 3; }
+// (bits 3 and 4 of the column, swapped: the transposed stores of a half wave -- 16 column groups x 2 row pairs here, 4 x 8 in the
+//  pipelined experiment profiles/experiments/r04_wgrad16c_pipelined.hip.txt -- then reach 16 banks; with the plain (col >> 3) & 3
+//  this kernel took 124.6 us for the three C2 layers, with the swapped bits 120.6)
+__device__ __forceinline__ int tpb_key(int col) { return (((col >> 3) & 1) << 1) | ((col >> 4) & 1); }
 __device__ __forceinline__ int tpb_off(int col, int row) { return col * 64 + ((((row >> 3) ^ tpb_key(col)) << 4) | ((row & 7) << 1)); }
 
 // rows (2 rp, 2 rp + 1) x columns (c0 .. c0+3), c0 a multiple of 4 (one key for the four columns): off0 = tpb_off(c0, 2 rp)
@@ -515,6 +518,7 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
     }
   }
 }
+
 
 size_t wgrad16_lds_bytes(int nrb, int nmat, int hout, int hin, int ell_width) {
   if ((nrb != 1 && nrb != 2) || nmat < 2 || nmat > 3 || ell_width < 1 || ell_width > W16_DMAX || hout <= 32 || (hout & 3) || (hin & 3)) return 0;
