@@ -361,7 +361,8 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
 #pragma unroll
   for (int m = 0; m < (RS2 ? NMAT : 1); ++m) bs2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  f32x4 pg[2], px[4];
+  f32x4 pg[2], px[4], prs[RS2 ? 2 : 1];
+  int2 pel;                                      // the tile's ELL entry of this thread (D <= 8: at most 256 entries), one tile ahead like its rows
   auto load_tile = [&](int tile) {
     const int ts = p.tile_start[tile];
     const int R = p.tile_start[tile + 1] - ts;
@@ -377,7 +378,9 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         px[2 * i + u] = *reinterpret_cast<const f32x4*>(xb + xro + ((xcol0 + 64 * i + 4 * cg < p.hin) ? (uint32_t)(64 * i + 4 * cg) * 4u : 0u));
+      if constexpr (RS2) prs[u] = (rs2 && r < R) ? *reinterpret_cast<const f32x4*>(rs2 + (size_t)(ts + r) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    pel = tid < D * TM ? (reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM)[tid] : make_int2(tid & (TM - 1), 0);
   };
   auto prop = [&](const float* Zs, float* Zd, char* img) {
     f32x4 s[2];
@@ -416,23 +419,14 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
 #pragma unroll
     for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(Zf0 + (2 * rp + u) * LDZF + 4 * cg) = pg[u];
     store_planes_b<ZC>(ZT, g_off0, pg[0], pg[1]);
-    {
-      const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
-      const int Dp = (D + 3) & ~3;                    // (D <= 8: at most 256 entries)
-      if (tid < Dp * TM) ell[tid] = tid < D * TM ? src[tid] : make_int2(tid & (TM - 1), 0);
-    }
+    if (tid < ((D + 3) & ~3) * TM) ell[tid] = pel;
     bsum += pg[0] + pg[1];
     if constexpr (RS2) {
       if (rs2) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int r = 2 * rp + u;
-          if (r < R) {
-            const f32x4 d = *reinterpret_cast<const f32x4*>(rs2 + (size_t)(ts + r) * 4);
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int m = 0; m < NMAT; ++m) bs2[m] += pg[u] * d[m];
-          }
-        }
+          for (int m = 0; m < NMAT; ++m) bs2[m] += pg[u] * prs[u][m];
       }
     }
     __syncthreads();
@@ -520,8 +514,279 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Tall tiles (96 / 128 / 160 / 192 rows: graphs of 65 .. 192 nodes), round 4.  The contraction over rows can be cut anywhere;
+// only the propagation needs a whole graph.  So P G of the WHOLE tile is kept in fp32 (one hop, gathered from the staged fp32
+// G), and everything the MFMAs read is made per CHUNK of 32 rows exactly as in wgrad16b_kernel: transposed planes of G (read
+// again from global memory -- L2 --, not from the fp32 image, so that image's space can be the planes' space), of P G (the
+// chunk's rows of the fp32 image) and of P^2 G (one more hop, gathered from the P G image, never stored in fp32), and of the
+// chunk's X rows.
+//     fp32 P G of the tile                    32 NRB x 64 x 4              24 / 48 KB  (96 / 192 rows)
+//     fp32 G of the tile, then the planes     max(32 NRB x 64 x 4, 60 KB)  60 KB
+//     ELL slice (padded to 4 or 8 entries)    32 NRB x 8 x 8               6 / 12 KB
+// One 8-wave workgroup per CU.  Waves 0-3 split the chunk's G and P G rows and the X columns 0..63, waves 4-7 gather and split
+// P^2 G and split the X columns 64..127 (about the same instruction count); in the MFMA phase wave w multiplies input block
+// w & 3 with output block w >> 2 of every matrix (18 MFMAs per 16 rows).  Chunks beyond the tile's last real row are skipped,
+// the last chunk runs one k-step if that covers it (70-node graphs: 5 k-steps instead of 6).
+constexpr int W16T_NT = 512;
+
+template <int NRB, int NMAT, bool RS2, bool DB>
+__global__ void __launch_bounds__(W16T_NT) wgrad16t_kernel(const dss2_wgrad_args p, int nibg, const WgradBatch wb) {
+  constexpr int TR = 32 * NRB, ZC = W16B_ZC, XW = W16B_XW, NT = W16T_NT, LDZF = W16B_LDZF;
+  constexpr int PLANES = NMAT * 3 * ZC * 64 + 3 * XW * 64;
+  constexpr int PBUF = TR * LDZF * 4 > PLANES ? TR * LDZF * 4 : PLANES;      // one set of planes; the tile's fp32 G fits in it
+  constexpr int UBYTES = DB ? 2 * PBUF : PBUF;
+  const float* __restrict__ Gp = wb.n > 0 ? wb.G[blockIdx.z] : p.G;
+  const float* __restrict__ Xp = wb.n > 0 ? wb.X[blockIdx.z] : p.X;
+  float* __restrict__ slabp = wb.n > 0 ? wb.slab[blockIdx.z] : p.slab;
+  const float* __restrict__ rs2 = RS2 ? (wb.n > 0 ? wb.rowscale2[blockIdx.z] : p.rowscale2) : nullptr;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Zf1 = smem;                                              // [TR][LDZF]  P G
+  char* const U = reinterpret_cast<char*>(Zf1 + TR * LDZF);       // one or (DB) two sets of planes [NMAT][3 planes][ZC columns][64 B] + [3 planes][XW columns][64 B];
+                                                                  // the tile's fp32 G [TR][LDZF] lives in the set the next chunk writes (dead after the first hop)
+  int2* ell = reinterpret_cast<int2*>(U + UBYTES);                // [Dp][TR]
+  int pb = 0;                                                     // (DB) the set the next chunk writes
+  const int D = p.ell_width, Dp = (D + 3) & ~3;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, c32 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ibw = wave & 3, obh = wave >> 2, role = wave >> 2;
+  const int slice = blockIdx.x, ysl = blockIdx.y;
+  const int obg = ysl / nibg, ibg = ysl - obg * nibg;
+  const int gcol0 = obg * ZC, xcol0 = ibg * XW;
+  const bool in_active = (xcol0 + ibw * 32) < p.hin && (gcol0 + obh * 32) < p.hout;
+
+  // whole-tile units: one row of four columns per row block (a wave covers four whole rows of the fp32 image)
+  const int q16 = tid & 15, r32 = tid >> 4;
+  const bool gcol_ok = gcol0 + 4 * q16 < p.hout;
+  // chunk units: rows (2 rp, 2 rp + 1) of four columns, the thread map of wgrad16b_kernel within each half of the workgroup
+  const int t8 = tid & 255, cg = t8 & 15, rp = (t8 >> 4) ^ ((t8 & 1) << 1);
+  const int z_off = tpb_off(4 * cg, 2 * rp), x_off = tpb_off(64 * role + 4 * cg, 2 * rp);
+  const uint32_t xcb = (xcol0 + 64 * role + 4 * cg < p.hin) ? (uint32_t)(64 * role + 4 * cg) * 4u : 0u;      // (columns beyond hin: group 0, never stored)
+  const bool zcol_ok = gcol0 + 4 * cg < p.hout;
+
+  f32x16 acc[NMAT];
+#pragma unroll
+  for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bs2[RS2 ? NMAT : 1];
+#pragma unroll
+  for (int m = 0; m < (RS2 ? NMAT : 1); ++m) bs2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Everything a tile's prologue reads from global memory is requested one tile ahead (one workgroup per CU: nobody else
+  // would cover the latency): its G rows, its ELL slice, the folded layer's row scales.
+  constexpr int NEL = (W16_DMAX * TR + NT - 1) / NT;
+  f32x4 pgw[NRB], prs[RS2 ? NRB : 1], px[2], pgc[2];
+  int2 pel[NEL];
+  auto load_tile_g = [&](int tile) {
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    const char* gb = reinterpret_cast<const char*>(Gp + (size_t)ts * p.ldg + gcol0 + 4 * q16);
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      const int r = r32 + 32 * rb;
+      pgw[rb] = (r < R && gcol_ok) ? *reinterpret_cast<const f32x4*>(gb + (uint32_t)(r * p.ldg) * 4u) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (RS2) prs[rb] = (rs2 && r < R) ? *reinterpret_cast<const f32x4*>(rs2 + (size_t)(ts + r) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TR;
+#pragma unroll
+    for (int j = 0; j < NEL; ++j) {
+      const int idx = tid + j * NT;
+      pel[j] = idx < D * TR ? src[idx] : make_int2(idx % TR, 0);      // (padding entries: own row, zero weight)
+    }
+  };
+  auto load_chunk = [&](int tile, int c) {
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    const char* xb = reinterpret_cast<const char*>(Xp + (size_t)ts * p.ldx + xcol0);
+    const char* gb = reinterpret_cast<const char*>(Gp + (size_t)ts * p.ldg + gcol0 + 4 * cg);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = 32 * c + 2 * rp + u;
+      // X rows beyond the tile's R rows are read from its last row (finite; they only meet zero rows of G / P G / P^2 G)
+      px[u] = *reinterpret_cast<const f32x4*>(xb + (uint32_t)((r < R ? r : R - 1) * p.ldx) * 4u + xcb);
+      if (role == 0) pgc[u] = (r < R && zcol_ok) ? *reinterpret_cast<const f32x4*>(gb + (uint32_t)(r * p.ldg) * 4u) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  // one row of P Zs (four columns at c4) for a real row; the slice is padded to four entries per row (zero weight, own row)
+  auto hop_row = [&](const float* Zs, int row, int c4) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < Dp; k0 += 4) {
+      int2 en[4];
+      f32x4 z[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) en[k] = ell[(k0 + k) * TR + row];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) z[k] = *reinterpret_cast<const f32x4*>(Zs + en[k].x * LDZF + c4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float w = __int_as_float(en[k].y);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = fmaf(w, z[k][q], a[q]);
+      }
+    }
+    return a;
+  };
+
+  if (slice < p.ntiles) { load_tile_g(slice); load_chunk(slice, 0); }
+  for (int tile = slice; tile < p.ntiles; tile += p.n_split) {
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    const int nch = (R + 31) >> 5;
+    const int next = tile + p.n_split;
+    // ---- fp32 G of the tile (first hop's input), the ELL slice, bias partial sums
+    float* Zf0 = reinterpret_cast<float*>(U + pb * PBUF);
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      if (rb < nch) *reinterpret_cast<f32x4*>(Zf0 + (r32 + 32 * rb) * LDZF + 4 * q16) = pgw[rb];
+      bsum += pgw[rb];
+    }
+    if constexpr (RS2) {
+      if (rs2) {
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m) bs2[m] += pgw[rb] * prs[rb][m];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NEL; ++j)
+      if (tid + j * NT < Dp * TR) ell[tid + j * NT] = pel[j];
+    __syncthreads();
+    if (next < p.ntiles) load_tile_g(next);      // in flight for the whole tile
+    // ---- P G of the tile
+    if (NMAT > 1) {
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) {
+        if (rb < nch) {
+          const int row = r32 + 32 * rb;
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+          if (row < R) a = hop_row(Zf0, row, 4 * q16);
+          *reinterpret_cast<f32x4*>(Zf1 + row * LDZF + 4 * q16) = a;
+        }
+      }
+      __syncthreads();          // Zf0 is dead: the planes take its place
+    }
+    for (int c = 0; c < nch; ++c) {
+      // ---- planes of the chunk
+      char* ZT = U + pb * PBUF;
+      char* XT = ZT + NMAT * 3 * ZC * 64;
+      if (32 * c + 8 * (wave & 3) < ((R + 15) & ~15)) {      // (a wave's units are eight rows; rows beyond the last k-step are not read)
+        store_planes_b<XW>(XT, x_off, px[0], px[1]);
+        if (role == 0) {
+          store_planes_b<ZC>(ZT, z_off, pgc[0], pgc[1]);
+          if (NMAT > 1) {
+            const float* src = Zf1 + (32 * c + 2 * rp) * LDZF + 4 * cg;
+            store_planes_b<ZC>(ZT + 3 * ZC * 64, z_off, *reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + LDZF));
+          }
+        } else if (NMAT > 2) {
+          f32x4 s[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int row = 32 * c + 2 * rp + u;
+            s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < R) s[u] = hop_row(Zf1, row, 4 * cg);
+          }
+          store_planes_b<ZC>(ZT + 2 * 3 * ZC * 64, z_off, s[0], s[1]);
+        }
+      }
+      __syncthreads();
+      if (c + 1 < nch) load_chunk(tile, c + 1);
+      else if (next < p.ntiles) load_chunk(next, 0);
+      // ---- MFMA phase: up to 2 steps of 16 rows
+      if (in_active) {
+        const int left = R - 32 * c;
+        const int nsteps = left > 16 ? 2 : 1;
+        const int xc = ibw * 32 + c32, zc = obh * 32 + c32;
+        const int xkey = tpb_key(xc), zkey = tpb_key(zc);
+        for (int ks = 0; ks < nsteps; ++ks) {
+          const int ch = 2 * ks + half;
+          const int choff = xc * 64 + ((ch ^ xkey) << 4);
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(XT + choff);
+          const bf16x8 bm = *reinterpret_cast<const bf16x8*>(XT + XW * 64 + choff);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(XT + 2 * XW * 64 + choff);
+          const int zoff = zc * 64 + ((ch ^ zkey) << 4);
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m) {
+            const char* zi = ZT + m * 3 * ZC * 64 + zoff;
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(zi);
+            const bf16x8 am = *reinterpret_cast<const bf16x8*>(zi + ZC * 64);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(zi + 2 * ZC * 64);
+            f32x16 cc = acc[m];        // smallest terms first
+            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, cc, 0, 0, 0);
+            cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, cc, 0, 0, 0);
+            acc[m] = cc;
+          }
+        }
+      }
+      if constexpr (DB) pb ^= 1;          // the next chunk (or the next tile's fp32 G) writes the other set: no barrier here
+      else __syncthreads();               // the planes are free for the next chunk / the next tile's fp32 G
+    }
+  }
+
+  // ---- one slab per tile-list slice blockIdx.x; the y-slices tile the [nmat*hout, hin] matrix
+  const size_t stride = (size_t)p.nmat * p.hout * p.hin + p.hout + (rs2 ? (size_t)p.nmat * p.hout : 0);
+  float* out = slabp + (size_t)slice * (wb.slab_stride > 0 ? (size_t)wb.slab_stride : stride);
+  if (in_active) {
+    const int i = xcol0 + ibw * 32 + c32;
+    if (i < p.hin) {
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = gcol0 + obh * 32 + acc_row(r, half);
+          if (o < p.hout) out[((size_t)m * p.hout + o) * p.hin + i] = acc[m][r];
+        }
+    }
+  }
+  if (ibg == 0) {   // (uniform) column sums: the 32 threads that share a column group meet in LDS, fixed order
+    f32x4* red = reinterpret_cast<f32x4*>(smem);          // [1 + NMAT][NT]
+    const int nsum = rs2 ? 1 + NMAT : 1;
+    __syncthreads();
+    red[tid] = bsum;
+    if constexpr (RS2) {
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) red[(1 + m) * NT + tid] = bs2[m];
+    }
+    __syncthreads();
+    for (int j = tid; j < nsum * ZC; j += NT) {
+      const int which = j / ZC, col = j - which * ZC;
+      float s = 0.f;
+      for (int r = 0; r < 32; ++r) s += red[which * NT + r * 16 + (col >> 2)][col & 3];
+      const int o = gcol0 + col;
+      if (o < p.hout) out[(size_t)p.nmat * p.hout * p.hin + (which == 0 ? 0 : p.hout + (size_t)(which - 1) * p.hout) + o] = s;
+    }
+  }
+}
+
+// two sets of planes (one barrier per chunk instead of two) wherever they fit
+static bool wgrad16t_double(int nrb, int nmat, int ell_width) {
+  static const int on = [] { const char* e = getenv("DSS2_WGRAD_TALL_DB"); return e ? atoi(e) : 1; }();
+  const size_t fimg = (size_t)32 * nrb * W16B_LDZF * 4, planes = (size_t)nmat * 3 * W16B_ZC * 64 + 3 * (size_t)W16B_XW * 64;
+  return on && fimg + 2 * (fimg > planes ? fimg : planes) + (size_t)((ell_width + 3) & ~3) * 32 * nrb * 8 <= (size_t)kMaxLdsBytes;
+}
+
+static size_t wgrad16t_lds_bytes(int nrb, int nmat, int ell_width) {
+  const size_t fimg = (size_t)32 * nrb * W16B_LDZF * 4, planes = (size_t)nmat * 3 * W16B_ZC * 64 + 3 * (size_t)W16B_XW * 64;
+  const size_t b = fimg + (wgrad16t_double(nrb, nmat, ell_width) ? 2 : 1) * (fimg > planes ? fimg : planes) + (size_t)((ell_width + 3) & ~3) * 32 * nrb * 8;
+  const size_t red = (size_t)(1 + nmat) * W16T_NT * 16;
+  return b > red ? b : red;
+}
+
+
 size_t wgrad16_lds_bytes(int nrb, int nmat, int hout, int hin, int ell_width) {
-  if ((nrb != 1 && nrb != 2) || nmat < 2 || nmat > 3 || ell_width < 1 || ell_width > W16_DMAX || hout <= 32 || (hout & 3) || (hin & 3)) return 0;
+  if (nrb < 1 || nrb > 6 || nmat < 2 || nmat > 3 || ell_width < 1 || ell_width > W16_DMAX || hout <= 32 || (hout & 3) || (hin & 3)) return 0;
+  if (nrb >= 3) {      // wgrad16t_kernel: tall tiles, chunks of 32 rows
+    static const int tall = [] { const char* e = getenv("DSS2_WGRAD_TALL16"); return e ? atoi(e) : 1; }();
+    return tall ? wgrad16t_lds_bytes(nrb, nmat, ell_width) : 0;
+  }
   if (nrb == 1) {      // wgrad16b_kernel: two workgroups per CU
     const size_t b1 = 2 * (size_t)W16B_TM * W16B_LDZF * 4 + (size_t)nmat * 3 * W16B_ZC * 64 + 3 * (size_t)W16B_XW * 64 + (size_t)((ell_width + 3) & ~3) * W16B_TM * 8;
     const size_t red1 = (size_t)(1 + nmat) * W16B_NT * 16;
@@ -540,7 +805,7 @@ bool wgrad16_covers(const dss2_wgrad_args& a) {
 }
 
 int wgrad16_y_slices(int nrb, int hout, int hin) {
-  return nrb == 1 ? ((hout + W16B_ZC - 1) / W16B_ZC) * ((hin + W16B_XW - 1) / W16B_XW) : ((hout + 127) / 128) * ((hin + 127) / 128);
+  return nrb != 2 ? ((hout + W16B_ZC - 1) / W16B_ZC) * ((hin + W16B_XW - 1) / W16B_XW) : ((hout + 127) / 128) * ((hin + 127) / 128);
 }
 
 template <int NMAT, bool RS2>
@@ -552,6 +817,17 @@ static int launch16b(const dss2_wgrad_args& a, hipStream_t stream, const WgradBa
   hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg, wb.n > 0 ? wb.n : 1), dim3(W16B_NT),
                      wgrad16_lds_bytes(a.nrb, a.nmat, a.hout, a.hin, a.ell_width), stream, a, nibg, wb);
   return check_launch("wgrad(bf16x6, 32 rows)");
+}
+
+template <int NRB, int NMAT, bool RS2, bool DB>
+static int launch16t(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb) {
+  static std::atomic<uint32_t> lds_done{0};
+  auto kern = wgrad16t_kernel<NRB, NMAT, RS2, DB>;
+  if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "wgrad(bf16x6, tall tiles)")) return 1;
+  const int nobg = (a.hout + W16B_ZC - 1) / W16B_ZC, nibg = (a.hin + W16B_XW - 1) / W16B_XW;
+  hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg, wb.n > 0 ? wb.n : 1), dim3(W16T_NT),
+                     wgrad16_lds_bytes(a.nrb, a.nmat, a.hout, a.hin, a.ell_width), stream, a, nibg, wb);
+  return check_launch("wgrad(bf16x6, tall tiles)");
 }
 
 template <int NMAT, int NP, bool RS2>
@@ -577,6 +853,14 @@ int launch_wgrad16(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatc
     if (a.nmat == 2) return rs2 ? launch16b<2, true>(a, stream, wb) : launch16b<2, false>(a, stream, wb);
     if (a.nmat == 3) return rs2 ? launch16b<3, true>(a, stream, wb) : launch16b<3, false>(a, stream, wb);
   }
+#define DSS2_TALL(NRB, DB) \
+  if (a.nrb == NRB && wgrad16t_double(a.nrb, a.nmat, a.ell_width) == DB) { \
+    if (a.nmat == 2) return rs2 ? launch16t<NRB, 2, true, DB>(a, stream, wb) : launch16t<NRB, 2, false, DB>(a, stream, wb); \
+    if (a.nmat == 3) return rs2 ? launch16t<NRB, 3, true, DB>(a, stream, wb) : launch16t<NRB, 3, false, DB>(a, stream, wb); \
+  }
+  DSS2_TALL(3, true) DSS2_TALL(4, true) DSS2_TALL(5, true) DSS2_TALL(6, true) DSS2_TALL(3, false) DSS2_TALL(4, false) DSS2_TALL(5, false) DSS2_TALL(6, false)
+#undef DSS2_TALL
+  if (a.nrb != 2) { set_error("wgrad(bf16x6): no kernel for nrb=%d nmat=%d", a.nrb, a.nmat); return 2; }
   if (a.nmat == 2) return rs2 ? launch16<2, 2, true>(a, stream, wb) : launch16<2, 2, false>(a, stream, wb);
   if (a.nmat == 3) return rs2 ? launch16<3, 2, true>(a, stream, wb) : launch16<3, 2, false>(a, stream, wb);
   set_error("wgrad(bf16x6): unsupported nmat=%d", a.nmat);

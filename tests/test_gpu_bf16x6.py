@@ -70,12 +70,61 @@ def test_weight_gradient_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat, n_layer
         assert rel_err(a, b_) < 2e-6 and rel_err(d, b_) < 2e-6
 
 
+@pytest.mark.parametrize("grids,B,H,nmat,n_layers,with_rs2,nrb", [
+    (["ober_sub"], 40, 128, 3, 1, False, None),       # 96-row tiles, 70 real rows: the last chunk runs one k-step
+    (["ober_sub"], 300, 128, 3, 3, True, None),       # the C3 block: three layers in one launch, folded first layer
+    (["ober_sub"], 41, 128, 3, 2, False, 5),          # two graphs per 160-row tile, odd graph count
+    (["ober_sub"], 30, 100, 3, 1, False, 4),          # 128-row tiles, H = 100 (partial column groups)
+    (["ober179"], 40, 128, 3, 1, True, None),         # 192-row tiles
+    (["ober179"], 9, 64, 2, 1, False, None),          # K = 1
+    (["ober179"], 12, 256, 3, 2, False, None),        # H = 256: two output x two input groups over grid.y
+    (["cigre14", "ober_sub"], 60, 128, 3, 1, False, 3),   # mixed graph sizes in 96-row tiles
+])
+def test_tall_tile_weight_gradient_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nmat, n_layers, with_rs2, nrb):
+    """wgrad16t_kernel (96 .. 192-row tiles, chunks of 32 rows) against the fp32-MFMA kernel on the topology's own tiling."""
+    nw = pkg.networks
+    b = pkg.synthetic.make_batch(grids, B, seed=0)
+    ei, N = b["edge_index"].to(DEV), b["x"].shape[0]
+    ref_topo = pkg.topology.get_topology(ei, N)
+    topo = ref_topo if nrb is None else pkg.topology.Topology(ei, N, nrb=nrb)
+    assert topo.nrb >= 3 and (nrb is None or topo.nrb == nrb)
+    torch.manual_seed(1)
+    Gs = [torch.randn(N, H, device=DEV) for _ in range(n_layers)]
+    Xs = [torch.randn(N, H, device=DEV) for _ in range(n_layers)]
+    rs2 = torch.rand(N, 4, device=DEV) if with_rs2 else None
+    stride = nmat * H * H + H
+    saved = pkg.flags.WGRAD_BF16
+
+    def run(bf16, tp):
+        pkg.flags.WGRAD_BF16 = bf16
+        if n_layers == 1:
+            out = torch.zeros(stride + (nmat * H if with_rs2 else 0), device=DEV)
+            nw.wgrad(tp, Gs[0], H, Xs[0], H, nmat, out, rowscale2=rs2)
+            return [out]
+        out = torch.zeros((n_layers - (1 if with_rs2 else 0)) * stride, device=DEV)
+        first = torch.zeros(stride + nmat * H, device=DEV) if with_rs2 else None
+        nw.wgrad_batched(tp, Gs, H, Xs, H, nmat, out, first_rowscale2=rs2, first_out=first)
+        return [out] + ([first] if with_rs2 else [])
+    try:
+        ref = run(False, ref_topo)
+        got = run(True, topo)
+        got2 = run(True, topo)
+    finally:
+        pkg.flags.WGRAD_BF16 = saved
+    lds = pkg._lib.lib().dss2_wgrad_lds_bytes_ex
+    if topo.nrb != 5:                                                  # (the fp32 kernel has no 160-row instantiation)
+        assert lds(topo.nrb, nmat, H, H, topo.max_nnzT, topo.ellT, 1) != lds(topo.nrb, nmat, H, H, topo.max_nnzT, topo.ellT, 0)
+    for a, b_, c in zip(got, ref, got2):
+        assert torch.equal(a, c)                                        # fixed-order sums: bitwise reproducible
+        assert rel_err(a, b_) < 2e-6
+
+
 def test_shapes_outside_the_bf16x6_weight_gradient_fall_back(pkg):
-    """H <= 32 (the K-split 4-wave kernel), K = 3, tall tiles: the fp32 kernel runs, results unchanged by the switch."""
+    """H <= 32 (the K-split 4-wave kernel), K = 3, ELL slices wider than 8: the fp32 kernel runs, results unchanged by the switch."""
     nw = pkg.networks
     saved = pkg.flags.WGRAD_BF16
     try:
-        for grids, B, H, nmat in ((["cigre14"], 64, 32, 3), (["cigre14"], 64, 64, 4), (["ober_sub"], 12, 64, 3)):
+        for grids, B, H, nmat in ((["cigre14"], 64, 32, 3), (["cigre14"], 64, 64, 4), (["ober_sub"], 12, 32, 3)):
             topo, N = _topo(pkg, grids, B)
             torch.manual_seed(2)
             G, X = torch.randn(N, H, device=DEV), torch.randn(N, H, device=DEV)

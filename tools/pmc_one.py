@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 pkg = importlib.import_module("deep-statistical-solver-for-distribution-system-state-estimation_amd")
 nw = pkg.networks
 dev = torch.device("cuda:0"); H, nmat = 128, 3
-b = pkg.synthetic.make_batch(["cigre14"], 4096, seed=0)
+b = pkg.synthetic.make_batch([os.environ.get("PMC_GRID", "cigre14")], int(os.environ.get("PMC_B", "4096")), seed=0)      # (PMC_GRID=ober_sub PMC_B=1024: the C3 shape)
 ei = b["edge_index"].to(dev); N = b["x"].shape[0]
 topo = pkg.topology.get_topology(ei, N)
 Ws = [torch.randn(H, H, device=dev) * 0.1 for _ in range(nmat)]
@@ -25,7 +25,11 @@ if which.startswith("stack"):      # the whole-stack kernels on the driver's mod
         model(xs[:, :8], eis, eas[:, :6]).square().sum().backward()
     torch.cuda.synchronize()
     sys.exit(0)
-for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
+NREP = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+T0, T1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for it in range(NREP):
+    if it == NREP // 5:
+        T0.record()
     if which == "fwd":
         nw.gemm_prop(topo, h, H, H, plan.fwd[0], nmat, H, out, bias=bias, relu=True)
     elif which == "dgrad":
@@ -43,4 +47,7 @@ for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 10):
         nw.wgrad_batched(topo, [g, g, g], H, [h, h, h], H, nmat, flat2, first_rowscale2=topo.deg_pows, first_out=first)
     else:
         nw.wgrad(topo, g, H, h, H, nmat, flat)
+T1.record()
 torch.cuda.synchronize()
+if os.environ.get("PMC_TIME"):      # (launch + its slab reduction, back to back)
+    print(f"{which} {os.environ.get('DSS2_LIB', 'product library')}: {1e3 * T0.elapsed_time(T1) / (NREP - NREP // 5):.1f} us per call")
