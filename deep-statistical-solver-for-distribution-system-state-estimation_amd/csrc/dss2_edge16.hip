@@ -152,8 +152,11 @@ __device__ __forceinline__ f32x16 e16_z(const E16Lds& L, const E16W& w, int k, i
   return e16_mma6(e16_frag(h), e16_frag(m), e16_frag(l), w.bh, w.bm, w.bl, ci);
 }
 
+// (four waves per SIMD: the kernel waits on its staging chain tile_start -> ELL entry -> edge_attr row, and a fourth resident
+//  workgroup covers more of it than the 3-8 spilled registers cost: 18.5 -> 15.6 us at C2; the backward, whose vector and matrix
+//  work are balanced, lost 3 us when squeezed from two to three waves)
 template <int NRB>
-__global__ void __launch_bounds__(512) edge16_fwd_kernel(const EdgeTileArgs p) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) edge16_fwd_kernel(const EdgeTileArgs p) {
   extern __shared__ __attribute__((aligned(16))) float esm[];
   const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
   const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);      // one 32-column group of the hidden layer per wave
