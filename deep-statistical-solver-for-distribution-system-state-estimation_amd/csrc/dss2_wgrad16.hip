@@ -579,7 +579,8 @@ __global__ void __launch_bounds__(W16T_NT) wgrad16t_kernel(const dss2_wgrad_args
   // Everything a tile's prologue reads from global memory is requested one tile ahead (one workgroup per CU: nobody else
   // would cover the latency): its G rows, its ELL slice, the folded layer's row scales.
   constexpr int NEL = (W16_DMAX * TR + NT - 1) / NT;
-  f32x4 pgw[NRB], prs[RS2 ? NRB : 1], px[2], pgc[2];
+  constexpr bool PRS = RS2 && NRB <= 4;      // (160- / 192-row tiles have no registers left for the row scales: read in place)
+  f32x4 pgw[NRB], prs[PRS ? NRB : 1], px[2], pgc[2];
   int2 pel[NEL];
   auto load_tile_g = [&](int tile) {
     const int ts = p.tile_start[tile];
@@ -589,7 +590,7 @@ __global__ void __launch_bounds__(W16T_NT) wgrad16t_kernel(const dss2_wgrad_args
     for (int rb = 0; rb < NRB; ++rb) {
       const int r = r32 + 32 * rb;
       pgw[rb] = (r < R && gcol_ok) ? *reinterpret_cast<const f32x4*>(gb + (uint32_t)(r * p.ldg) * 4u) : f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (RS2) prs[rb] = (rs2 && r < R) ? *reinterpret_cast<const f32x4*>(rs2 + (size_t)(ts + r) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (PRS) prs[rb] = (rs2 && r < R) ? *reinterpret_cast<const f32x4*>(rs2 + (size_t)(ts + r) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TR;
 #pragma unroll
@@ -647,9 +648,13 @@ __global__ void __launch_bounds__(W16T_NT) wgrad16t_kernel(const dss2_wgrad_args
     if constexpr (RS2) {
       if (rs2) {
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
+        for (int rb = 0; rb < NRB; ++rb) {
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (PRS) d = prs[rb];
+          else if (r32 + 32 * rb < R) d = *reinterpret_cast<const f32x4*>(rs2 + (size_t)(ts + r32 + 32 * rb) * 4);
 #pragma unroll
-          for (int m = 0; m < NMAT; ++m) bs2[m] += pgw[rb] * prs[rb][m];
+          for (int m = 0; m < NMAT; ++m) bs2[m] += pgw[rb] * d[m];
+        }
       }
     }
 #pragma unroll

@@ -177,6 +177,11 @@ def test_no_kernel_in_the_library_spills_registers():
     #  the generic ones <., ., 0> -- mask tensor, residual, fp32 gates: tests and outside callers -- carry every feature at once)
     for nrb, nmat, d, cap in ((3, 3, 1, 16), (3, 3, 2, 16), (6, 3, 1, 24), (6, 3, 2, 24), (3, 2, 0, 16), (3, 3, 0, 96), (6, 2, 0, 80), (6, 3, 0, 144)):
         allowed[f"void dss2::gemm_chain_sp6_kernel<{nrb}, {nmat}, {d}>"] = cap
+    # A third, chosen: the edge MLP's bf16x6 forward (csrc/dss2_edge16.hip) is held to 128 registers (four waves per SIMD,
+    # amdgpu_waves_per_eu) because it waits on a dependent staging chain; the 2 / 7 registers that costs at 64- / 96-row tiles
+    # are spilled once per tile outside the slot loop (C2: 18.5 -> 15.6 us with them).
+    allowed["void dss2::edge16_fwd_kernel<2>"] = 4
+    allowed["void dss2::edge16_fwd_kernel<3>"] = 8
     bad = [(fn, name, sp, scr) for fn, ks in results for name, sp, scr in ks
            if (sp or scr) and not (name.strip() in allowed and sp <= allowed[name.strip()])]
     assert not bad, bad
