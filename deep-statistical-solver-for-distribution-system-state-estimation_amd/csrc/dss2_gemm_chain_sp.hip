@@ -245,9 +245,21 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
     if (L.bias && col_ok) bias4 = *reinterpret_cast<const f32x4*>(L.bias + col0);
     auto grow_of = [&](int i) { const int row = rowv + 8 * i; return (size_t)(ts + (row < R ? row : 0)); };      // (clamped: loads only)
     f32x4 gate[8];
-    if (has_rs && col_ok) {
+    if (has_rs) {      // (uniform; the row addresses hang on a value defined inside the branch, or they are formed -- 80 vector
+                       //  instructions per layer -- whether or not the layer has a gate: the forward chain has none)
+      int rowg = rowv;
+      asm volatile("" : "+v"(rowg));
+      if (col_ok) {
+        // one 64-bit product for the lane's first row, a uniform stride for the others; rows beyond the tile read its first row
+        const char* g0 = reinterpret_cast<const char*>(L.relu_src + (size_t)ts * p.ld_relu + col0);
+        const char* gp = g0 + (size_t)rowg * p.ld_relu * 4;
+        const size_t gstep = (size_t)p.ld_relu * 32;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) gate[i] = *reinterpret_cast<const f32x4*>(L.relu_src + grow_of(i) * p.ld_relu + col0);
+        for (int i = 0; i < 8; ++i) {
+          gate[i] = *reinterpret_cast<const f32x4*>(rowg + 8 * i < R ? gp : g0);
+          gp += gstep;
+        }
+      }
     }
     // every wave is done with this layer's planes: the hops below overwrite the wave's own stripe
     sp_barrier();
@@ -269,24 +281,27 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
         float* oth = slot0 + (((NMAT - 2 - m) & 1) ? 0 : SP_SLOT);      // receives G_m, then U
         put(oth, m);
         wave_lds_sync();
-        int2 en[8];
+        int2 ea[8], eb[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { en[i] = ell[r8 + 8 * i]; U[i] = *reinterpret_cast<const f32x4*>(oth + (r8 + 8 * i) * 32 + cq); }
-        for (int k = 0; k < D; ++k) {
-          const int kn = k + 1 < D ? k + 1 : k;
+        for (int i = 0; i < 8; ++i) { ea[i] = ell[r8 + 8 * i]; U[i] = *reinterpret_cast<const f32x4*>(oth + (r8 + 8 * i) * 32 + cq); }
+        // one hop entry: gather with `e`, request the entry after next into `nx`, accumulate.  Two entries per trip with the two
+        // register sets swapping roles: the one-entry loop copied the next entries over the current ones (16 v_mov per entry)
+        auto hop1 = [&](const int2 (&e)[8], int2 (&nx)[8], int kn) {
           f32x4 z[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) z[i] = *reinterpret_cast<const f32x4*>(cur + en[i].x * 32 + cq);
-          int2 en_next[8];
+          for (int i = 0; i < 8; ++i) z[i] = *reinterpret_cast<const f32x4*>(cur + e[i].x * 32 + cq);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) en_next[i] = ell[kn * TM + r8 + 8 * i];
+          for (int i = 0; i < 8; ++i) nx[i] = ell[kn * TM + r8 + 8 * i];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const float w = __int_as_float(en[i].y);
+            const float w = __int_as_float(e[i].y);
 #pragma unroll
             for (int q = 0; q < 4; ++q) U[i][q] = fmaf(w, z[i][q], U[i][q]);
-            en[i] = en_next[i];
           }
+        };
+        for (int k = 0; k < D; k += 2) {
+          hop1(ea, eb, k + 1 < D ? k + 1 : k);
+          if (k + 1 < D) hop1(eb, ea, k + 2 < D ? k + 2 : k + 1);      // (uniform)
         }
         if (m > 0) {
 #pragma unroll
@@ -340,11 +355,11 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
         for (int i = 0; i < 8; ++i)
           U[i] *= dropout_mult4(drop_seed, drop_off, (uint32_t)L.drop_id, (uint32_t)grow_of(i), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
       }
-      if (L.relu & 1) {
+      if (L.relu & 1) {      // (one v_max_f32 per value: fmaxf() first quiets its operand with a second one)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) U[i][q] = fmaxf(U[i][q], 0.f);
+          for (int q = 0; q < 4; ++q) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(U[i][q])); U[i][q] = r; }
       }
       if (has_rs) {
 #pragma unroll
@@ -356,16 +371,23 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
 #pragma unroll
         for (int i = 0; i < 8; ++i) U[i] += *reinterpret_cast<const f32x4*>(L.add_src + grow_of(i) * p.ld_add + col0);
       }
+      {
+        char* yp = reinterpret_cast<char*>(L.Y + (size_t)(ts + rowv) * p.ldy + col0);      // one 64-bit product per layer, then a uniform stride
+        const size_t ystep = (size_t)p.ldy * 32;                                           // 8 rows
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (rowv + 8 * i < R) *reinterpret_cast<f32x4*>(L.Y + (size_t)(ts + rowv + 8 * i) * p.ldy + col0) = U[i];
+        for (int i = 0; i < 8; ++i) {
+          if (rowv + 8 * i < R) *reinterpret_cast<f32x4*>(yp) = U[i];
+          yp += ystep;
+        }
+      }
     }
     if (keep) {
+      // (rows beyond the tile's R rows are NOT zeroed -- 32 selects per layer: their values are finite (bias-driven like any
+      //  activation), no real row ever gathers from them (ELL neighbours are real rows; a padding row's own entries carry weight 0),
+      //  nothing of them is stored, the fused head below masks its own copy.  Columns beyond hout are zero by construction:
+      //  zero weight columns, no bias.)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = rowv + 8 * i;
-        sp_store_split(own_planes + row * SP_RS + cq, (row < R && col_ok) ? U[i] : f32x4{0.f, 0.f, 0.f, 0.f});
-      }
+      for (int i = 0; i < 8; ++i) sp_store_split(own_planes + (rowv + 8 * i) * SP_RS + cq, U[i]);
     }
     if constexpr (HM == 1) {
       if (!keep) {
