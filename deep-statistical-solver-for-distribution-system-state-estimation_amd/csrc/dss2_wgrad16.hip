@@ -333,14 +333,18 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, c32 = lane & 31, half = lane >> 5;
-  const int ibw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // wave w multiplies the input blocks 2 (w & 1), 2 (w & 1) + 1 with the output block w >> 1 of every matrix: 6 + 9 operand
+  // fragments per k-step for its 36 MFMAs (one input block x both output blocks took 3 + 18: 29 % more LDS read bytes)
+  const int xb0 = 2 * (wv & 1), obw = wv >> 1;
   // (Placing the workgroups that walk the same tile-list slice 8 linear ids apart -- same XCD, shared L2 for the X tile they both
   //  stage -- was 20 % SLOWER: such a pair lands on one CU and runs its phases in lockstep, MFMA beside MFMA and staging beside
   //  staging; with the slices n_split ids apart a CU's two workgroups are unrelated and drift out of phase.)
   const int slice = blockIdx.x, ysl = blockIdx.y;
   const int obg = ysl / nibg, ibg = ysl - obg * nibg;
   const int gcol0 = obg * ZC, xcol0 = ibg * XW;
-  const bool in_active = (xcol0 + ibw * 32) < p.hin;
+  const bool x_on[2] = {(xcol0 + xb0 * 32) < p.hin, (xcol0 + (xb0 + 1) * 32) < p.hin};
+  const bool in_active = x_on[0] && (gcol0 + obw * 32) < p.hout;
 
   // staging units: rows (2 rp, 2 rp + 1) of four columns; 16 column groups x 16 row pairs, one unit of G and two of X (columns
   // 4 cg and 64 + 4 cg) per thread
@@ -349,13 +353,13 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
   const int x_off0[2] = {tpb_off(4 * cg, 2 * rp), tpb_off(64 + 4 * cg, 2 * rp)};
   const uint32_t g_goff = (uint32_t)((2 * rp) * p.ldg + 4 * cg) * 4u;
 
-  f32x16 acc[2][NMAT];
+  f32x16 acc[2][NMAT];      // [input block of the wave][matrix]
 #pragma unroll
-  for (int ob = 0; ob < 2; ++ob)
+  for (int xb = 0; xb < 2; ++xb)
 #pragma unroll
     for (int m = 0; m < NMAT; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ob][m][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[xb][m][r] = 0.f;
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   f32x4 bs2[RS2 ? NMAT : 1];
 #pragma unroll
@@ -440,35 +444,41 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
       }
       __syncthreads();
     }
-    // ---- MFMA phase: 2 steps of 16 rows; the X fragment of a step serves both output blocks and all matrices
+    // ---- MFMA phase: 2 steps of 16 rows; a step's Z fragments (three per matrix) serve both input blocks of the wave
     if (in_active) {
       const int nsteps = (R + 15) >> 4;
-      const int xc = ibw * 32 + c32;
-      const int xkey = tpb_key(xc), zkey0 = tpb_key(c32), zkey1 = tpb_key(32 + c32);
+      const int zc = obw * 32 + c32;
+      const int zkey = tpb_key(zc);
+      const int xc0 = xb0 * 32 + c32, xc1 = xc0 + 32;
+      const int xkey0 = tpb_key(xc0), xkey1 = tpb_key(xc1);
       for (int ks = 0; ks < nsteps; ++ks) {
         const int ch = 2 * ks + half;
-        const int choff = xc * 64 + ((ch ^ xkey) << 4);
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(XT + choff);
-        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(XT + XW * 64 + choff);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(XT + 2 * XW * 64 + choff);
+        bf16x8 bh[2], bm[2], bl[2];
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob) {
-          if (gcol0 + ob * 32 >= p.hout) continue;      // (uniform)
-          const int zoff = (ob * 32 + c32) * 64 + ((ch ^ (ob ? zkey1 : zkey0)) << 4);
+        for (int xb = 0; xb < 2; ++xb) {
+          const int choff = (xb ? xc1 : xc0) * 64 + ((ch ^ (xb ? xkey1 : xkey0)) << 4);
+          bh[xb] = *reinterpret_cast<const bf16x8*>(XT + choff);
+          bm[xb] = *reinterpret_cast<const bf16x8*>(XT + XW * 64 + choff);
+          bl[xb] = *reinterpret_cast<const bf16x8*>(XT + 2 * XW * 64 + choff);
+        }
+        const int zoff = zc * 64 + ((ch ^ zkey) << 4);
 #pragma unroll
-          for (int m = 0; m < NMAT; ++m) {
-            const char* zi = ZT + m * 3 * ZC * 64 + zoff;
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(zi);
-            const bf16x8 am = *reinterpret_cast<const bf16x8*>(zi + ZC * 64);
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(zi + 2 * ZC * 64);
-            f32x16 c = acc[ob][m];        // smallest terms first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-            acc[ob][m] = c;
+        for (int m = 0; m < NMAT; ++m) {
+          const char* zi = ZT + m * 3 * ZC * 64 + zoff;
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(zi);
+          const bf16x8 am = *reinterpret_cast<const bf16x8*>(zi + ZC * 64);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(zi + 2 * ZC * 64);
+#pragma unroll
+          for (int xb = 0; xb < 2; ++xb) {
+            if (xb == 1 && !x_on[1]) continue;      // (uniform)
+            f32x16 c = acc[xb][m];        // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[xb], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[xb], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[xb], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[xb], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[xb], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[xb], c, 0, 0, 0);
+            acc[xb][m] = c;
           }
         }
       }
@@ -480,17 +490,18 @@ __global__ void __launch_bounds__(W16B_NT, 2) wgrad16b_kernel(const dss2_wgrad_a
   const size_t stride = (size_t)p.nmat * p.hout * p.hin + p.hout + (rs2 ? (size_t)p.nmat * p.hout : 0);
   float* out = slabp + (size_t)slice * (wb.slab_stride > 0 ? (size_t)wb.slab_stride : stride);
   if (in_active) {
-    const int i = xcol0 + ibw * 32 + c32;
-    if (i < p.hin) {
 #pragma unroll
-      for (int ob = 0; ob < 2; ++ob)
+    for (int xb = 0; xb < 2; ++xb) {
+      const int i = xcol0 + (xb0 + xb) * 32 + c32;
+      if (i < p.hin) {
 #pragma unroll
         for (int m = 0; m < NMAT; ++m)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int o = gcol0 + ob * 32 + acc_row(r, half);
-            if (o < p.hout) out[((size_t)m * p.hout + o) * p.hin + i] = acc[ob][m][r];
+            const int o = gcol0 + obw * 32 + acc_row(r, half);
+            if (o < p.hout) out[((size_t)m * p.hout + o) * p.hin + i] = acc[xb][m][r];
           }
+      }
     }
   }
   if (ibg == 0) {   // (uniform) column sums: the 16 threads that share a column group meet in LDS, fixed order
