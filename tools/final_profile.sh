@@ -44,6 +44,11 @@ print(f"HBM bytes per launch (2 x FETCH + WRITE) = {(2*f + w)*1e3/1e6:.1f} MB vs
 PY
 cd $R
 python3 tools/cfgbench.py > $O/cfgbench.txt 2>&1
+# kernel stats of the tall-tile configurations (eager mode) and the counters of their weight-gradient launch
+bash tools/prof_cfg.sh c3 "C3 ober_sub" > /dev/null 2>&1; cp $R/gpurun_out/prof_c3_kernel_stats.csv $O/kernel_stats_c3_ober_sub.csv 2>/dev/null
+bash tools/prof_cfg.sh c3p "ober179" > /dev/null 2>&1; cp $R/gpurun_out/prof_c3p_kernel_stats.csv $O/kernel_stats_c3_ober179.csv 2>/dev/null
+PMC_GRID=ober_sub PMC_B=1024 bash tools/pmc_one.sh wgrad3 > $O/pmc_wgrad_tall_c3.txt 2>&1
+rm -rf $R/gpurun_out/pmc1_*
 python3 tools/driverline.py > $O/driverline.txt 2>&1
 python3 tools/collate_bench.py > $O/collate_bench.txt 2>&1
 python3 tools/chainbench.py > $O/chainbench.txt 2>&1
@@ -65,5 +70,6 @@ fi
 # the packed-fp32 reproducer (tools/micro/pkfma_beside_mfma.hip) and the 200-launch stress of the real kernel
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/pkfma_beside_mfma.hip -o /tmp/pkfma 2>/dev/null && /tmp/pkfma > $O/pkfma_micro.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/work_beside_mfma.hip -o /tmp/wbm 2>/dev/null && /tmp/wbm > $O/work_beside_mfma.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result tools/micro/mfma_shape_clock.hip -o /tmp/msc 2>/dev/null && /tmp/msc > $O/mfma_shape_clock.txt 2>&1
 python3 tools/pk_stress.py 200 2>&1 | grep -v amdgpu > $O/pk_stress_shipped.txt
 ls -la $O
