@@ -78,6 +78,32 @@ def test_tagconv_fwd_bwd(pkg, oracle, grid, hin, hout, K):
         assert rel_err(a.weight.grad, bb.weight.grad) < TOL_GRAD
 
 
+@pytest.mark.parametrize("grid,hid,nrb", [("ober_sub", 128, None), ("ober_sub", 64, "4"), ("ober179", 128, None), ("ober179", 32, None)])
+def test_edge_aggregation_tall_tiles_without_input_gradient(pkg, oracle, grid, hid, nrb, monkeypatch):
+    """The first block of a model: x needs no gradient, so the backward is the weight-gradient-only form: edge16_bwd_kernel
+    without the per-row sums on 96-row tiles; 128- (forced) and 192-row tiles run the VALU tile kernels (an edge16 form for
+    them measured 132 + 68 us against 150 + 51 at the 179-bus shape: no gain, not kept)."""
+    if nrb is not None:
+        monkeypatch.setenv("DSS2_NRB", nrb)
+    torch.manual_seed(5)
+    b = pkg.synthetic.make_batch([grid], 7 if nrb is None else 9, seed=6)      # (another batch for the forced height: the structure cache is keyed by content)
+    x, ea = b["x"][:, :8], b["edge_attr"][:, :6]
+    ei2, ea2 = oracle.undirect_graph(b["edge_index"], ea)
+    ref = oracle.EdgeAggregation(8, 6, hid, hid).double()
+    mine = pkg.EdgeAggregation(8, 6, hid, hid).to(DEV)
+    mine.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    outr = ref(x.double(), ei2, ea2.double())
+    g = torch.randn(outr.shape)
+    outr.backward(g.double())
+    ei_dev = ei2.to(DEV)
+    outm = mine(x.to(DEV).contiguous(), ei_dev, ea2.to(DEV).contiguous())
+    outm.backward(g.to(DEV))
+    assert pkg.topology.get_topology(ei_dev, x.shape[0], double=False).nrb == (int(nrb) if nrb else (3 if grid == "ober_sub" else 6))
+    assert rel_err(outm, outr) < TOL_OUT
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad, q.grad) < TOL_GRAD, n
+
+
 @pytest.mark.parametrize("mfma", ["bf16x6", "fp32-mfma", "valu"])     # first Linear as bf16x6 (default), on fp32 MFMAs, VALU tile kernels
 @pytest.mark.parametrize("grid,hid", [("cigre14", 128), ("ober_sub", 32), ("cigre14_reswitched", 256), ("cigre14", 64)])
 def test_edge_aggregation_fwd_bwd(pkg, oracle, grid, hid, mfma, monkeypatch):
