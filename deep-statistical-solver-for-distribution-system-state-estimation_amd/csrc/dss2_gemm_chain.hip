@@ -55,14 +55,16 @@ extern "C" int dss2_gemm_prop_chain_head_supported(int nrb, int nmat, int kreal,
   if (nout < 1 || nout > 4 || !dss2_gemm_prop_chain16_supported(nrb, nmat, kreal, hout, ell_width)) return 0;
   dss2_gemm_prop_args a = {};
   a.b_format = 1; a.nrb = nrb; a.nmat = nmat; a.kreal = kreal; a.kpad = (kreal + 15) / 16 * 16; a.hout = hout; a.ncg = (hout + 31) / 32; a.ell_width = ell_width;
-  return (chain_row_split(nrb, a.ncg) == 1 && chain_sp_supported(a)) ? 1 : 0;
+  if (chain_row_split(nrb, a.ncg) == 1 && chain_sp_supported(a)) return 3;      // 64-row tiles: forward (bit 0) and backward (bit 1) head
+  if ((nrb == 3 || nrb == 6) && chain_sp6_supported(a)) return 2;               // 96- / 192-row tiles: the backward head only
+  return 0;
 }
 
 extern "C" int dss2_gemm_prop_chain_head(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers,
                                          const dss2_chain_head* head, void* stream) {
   using namespace dss2;
   if (!head || (head->mode != 1 && head->mode != 2)) { set_error("gemm_prop_chain_head: head.mode must be 1 or 2"); return 2; }
-  if (!dss2_gemm_prop_chain_head_supported(ap->nrb, ap->nmat, ap->kreal, ap->hout, ap->ell_width, head->nout) || ap->b_format != 1) {
+  if (!(dss2_gemm_prop_chain_head_supported(ap->nrb, ap->nmat, ap->kreal, ap->hout, ap->ell_width, head->nout) & head->mode) || ap->b_format != 1) {
     set_error("gemm_prop_chain_head: unsupported shape (nrb=%d nmat=%d hid=%d nout=%d b_format=%d)", ap->nrb, ap->nmat, ap->hout, head->nout, ap->b_format);
     return 2;
   }
@@ -114,8 +116,8 @@ static int chain_impl(const dss2_gemm_prop_args* ap, const dss2_chain_layer* lay
       return 2;
     }
     if (rsplit == 1 && chain_sp_supported(a)) return launch_chain_sp(a, ct, head, s);      // 64-row tiles, H >= 96: split-plane form
+    if ((a.nrb == 6 || a.nrb == 3) && chain_sp6_supported(a)) return launch_chain_sp6(a, ct, head, s);      // 96- / 192-row tiles: split-plane form, NRB row blocks per wave
     if (head) { set_error("gemm_prop_chain_head: the split-plane chain does not cover this shape"); return 2; }
-    if ((a.nrb == 6 || a.nrb == 3) && chain_sp6_supported(a)) return launch_chain_sp6(a, ct, s);      // 96- / 192-row tiles: split-plane form, NRB row blocks per wave
     return launch_chain16(a, ct, rsplit, s);
   }
   if (a.b_format != 0) { set_error("gemm_prop_chain: unknown b_format %d", a.b_format); return 2; }

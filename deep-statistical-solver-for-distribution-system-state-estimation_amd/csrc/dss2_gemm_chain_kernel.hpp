@@ -465,6 +465,6 @@ bool chain_sp_supported(const dss2_gemm_prop_args& a);
 int launch_chain_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head* head, hipStream_t s);
 // 192-row tiles, six row blocks per wave (dss2_gemm_chain_sp6.hip)
 bool chain_sp6_supported(const dss2_gemm_prop_args& a);
-int launch_chain_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t s);
+int launch_chain_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head* head, hipStream_t s);
 
 }  // namespace dss2

@@ -51,8 +51,11 @@ __device__ __forceinline__ void s6_store_split(__bf16* dst, const f32x4 v) {
 // kernel: 77 / 130 spilled VGPRs at K = 2 and a backward chain 8-17 % slower than the forward one; specialised: 10-13 / 12).
 //   1 = forward set (bias, folded bias, in-kernel dropout, ReLU, y_bits);  2 = data-gradient set (gate_bits, in-kernel dropout);
 //   0 = everything (mask tensor, residual, fp32 gates: tests and callers outside networks.py)
-template <int NRB, int NMAT, int DIR>
-__global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(const dss2_gemm_prop_args p, const ChainTable ct) {
+// HM = 2 (backward launches only, DIR = 2): the chain's input tile is the narrow head's data gradient, computed in the staging
+// from the nout-wide upstream gradient (dss2_gemm_chain_sp.hip, dss2_gemm_prop_chain_head) instead of by a launch of its own
+// that writes [N, hid] and is re-read here (C3: 22.6 us, 179-bus: 60 us).
+template <int NRB, int NMAT, int DIR, int HM = 0>
+__global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(const dss2_gemm_prop_args p, const ChainTable ct, const dss2_chain_head hd) {
   constexpr int TM = 32 * NRB, S6_PLANE = s6_plane(NRB), S6_REGION = s6_region(NRB);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -83,11 +86,89 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
     for (int idx = tid; idx < D * TM; idx += nthreads) ell[idx] = src[idx];
   }
-  for (int idx = tid; idx < TM * kq; idx += nthreads) {
-    const int r = idx / kq, c = (idx - r * kq) << 2;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
-    s6_store_split<S6_PLANE>(xpl + (c >> 5) * (2 * S6_REGION) + s6_off(r, c & 31), v);
+  if constexpr (HM != 2) {
+    for (int idx = tid; idx < TM * kq; idx += nthreads) {
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
+      s6_store_split<S6_PLANE>(xpl + (c >> 5) * (2 * S6_REGION) + s6_off(r, c & 31), v);
+    }
+  } else {
+    // X[row][c] = gate(row, c) * sum_{m, o} ((P^T)^m G)[row][o] W_m[o][c]: every wave builds its own 32-column stripe.  The hops of
+    // G are nout wide and run once per WAVE (a lane owns rows lane, lane + 64, ..; wave-private scratch at the start of the wave's
+    // own region, which the planes overwrite at the very end).
+    constexpr int RPL = (TM + 63) / 64;      // rows per lane in the hop phase
+    const int nout = hd.nout;
+    f32x4 ga[NRP];
+    if (hd.gate && col_ok) {
+#pragma unroll
+      for (int i = 0; i < NRP; ++i) { const int row = r8 + 8 * i; ga[i] = *reinterpret_cast<const f32x4*>(hd.gate + (size_t)(ts + (row < R ? row : 0)) * hd.ld_gate + col0); }
+    }
+    f32x4 wl[NMAT][4];      // W_m[o][col0 .. col0 + 3]
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        wl[m][o] = (o < nout && col_ok) ? *reinterpret_cast<const f32x4*>(hd.W[m] + (size_t)o * p.hout + col0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float* zt = slot0;                       // [TM][NMAT * 4]: ((P^T)^m G)[row][o]
+    float* hs = slot0 + TM * NMAT * 4;       // [TM][4] hop scratch
+    f32x4 z[RPL];
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+      const int row = lane + 64 * j;
+      z[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < R) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) if (o < nout) z[j][o] = hd.G[(size_t)(ts + row) * hd.ldg + o];
+      }
+      if (row < TM) *reinterpret_cast<f32x4*>(zt + row * (NMAT * 4)) = z[j];
+    }
+    s6_barrier();                            // the ELL slice is staged
+#pragma unroll
+    for (int m = 1; m < NMAT; ++m) {
+#pragma unroll
+      for (int j = 0; j < RPL; ++j) if (lane + 64 * j < TM) *reinterpret_cast<f32x4*>(hs + (lane + 64 * j) * 4) = z[j];
+      wave_lds_sync();
+#pragma unroll
+      for (int j = 0; j < RPL; ++j) {
+        const int row = lane + 64 * j;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (row < TM) {
+          for (int k = 0; k < D; ++k) {
+            const int2 en = ell[k * TM + row];
+            t += *reinterpret_cast<const f32x4*>(hs + en.x * 4) * __int_as_float(en.y);
+          }
+        }
+        z[j] = t;
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int j = 0; j < RPL; ++j) if (lane + 64 * j < TM) *reinterpret_cast<f32x4*>(zt + (lane + 64 * j) * (NMAT * 4) + m * 4) = z[j];
+    }
+    wave_lds_sync();
+    f32x4 xv[NRP];
+#pragma unroll
+    for (int i = 0; i < NRP; ++i) {
+      const int row = r8 + 8 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) {
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(zt + row * (NMAT * 4) + m * 4);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) v += wl[m][o] * zz[o];
+      }
+      if (hd.gate) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ga[i][q] > 0.f ? v[q] : 0.f;
+      }
+      if (hd.drop_id) v *= dropout_mult4(drop_seed, drop_off, (uint32_t)hd.drop_id, (uint32_t)(ts + row), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
+      if (row >= R || !col_ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      else *reinterpret_cast<f32x4*>(hd.Xout + (size_t)(ts + row) * hd.ldxo + col0) = v;      // (the weight gradients read it)
+      xv[i] = v;
+    }
+    wave_lds_sync();                         // every lane is done with zt: the planes go over it
+#pragma unroll
+    for (int i = 0; i < NRP; ++i) s6_store_split<S6_PLANE>(own_planes + s6_off(r8 + 8 * i, cq), xv[i]);
   }
   bf16x8 b0[3][NMAT];
   auto load_b = [&](const bf16x8* __restrict__ bp16, bf16x8 (&bb)[3][NMAT], int ks) {
@@ -341,24 +422,31 @@ bool chain_sp6_supported(const dss2_gemm_prop_args& a) {
          a.ncg >= 2 && a.ncg <= 4 && chain_sp6_lds_bytes(a.nrb, a.ncg, a.ell_width) <= (size_t)(a.nrb == 3 ? kMaxLdsBytes / 2 : kMaxLdsBytes);
 }
 
-template <int NRB, int NMAT, int DIR>
-static int launch_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t stream) {
+template <int NRB, int NMAT, int DIR, int HM = 0>
+static int launch_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head& hd, hipStream_t stream) {
   static std::atomic<uint32_t> lds_done{0};
-  auto kern = gemm_chain_sp6_kernel<NRB, NMAT, DIR>;
+  auto kern = gemm_chain_sp6_kernel<NRB, NMAT, DIR, HM>;
   if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop_chain(split planes, 192 rows)")) return 1;
-  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg), chain_sp6_lds_bytes(NRB, a.ncg, a.ell_width), stream, a, ct);
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg), chain_sp6_lds_bytes(NRB, a.ncg, a.ell_width), stream, a, ct, hd);
   return check_launch("gemm_prop_chain(split planes, 192 rows)");
 }
 
-int launch_chain_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, hipStream_t s) {
+int launch_chain_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head* head, hipStream_t s) {
   bool fwd = true, bwd = true;
   for (int i = 0; i < ct.n; ++i) {
     const dss2_chain_layer& L = ct.l[i];
     if (L.relu_src || L.gate_bits || L.dmask || L.add_src) fwd = false;
     if (L.bias || L.prebias || L.dmask || L.add_src || L.y_bits || (L.relu & 1) || (L.relu_src && !L.gate_bits)) bwd = false;
   }
+  dss2_chain_head hd = {};
+  if (head) {      // the backward head (mode 2) rides in the staging of the data-gradient launch; nothing else is built here
+    if (head->mode != 2 || !bwd) { set_error("gemm_prop_chain_head: tall tiles take the backward head (mode 2) on a data-gradient chain only"); return 2; }
+    hd = *head;
+    if (a.nrb == 3) return a.nmat == 2 ? launch_sp6<3, 2, 2, 2>(a, ct, hd, s) : launch_sp6<3, 3, 2, 2>(a, ct, hd, s);
+    return a.nmat == 2 ? launch_sp6<6, 2, 2, 2>(a, ct, hd, s) : launch_sp6<6, 3, 2, 2>(a, ct, hd, s);
+  }
   const int dir = fwd ? 1 : (bwd ? 2 : 0);      // (0: a layer table that mixes the feature sets runs the generic instantiation)
-#define DSS2_S6_LAUNCH(NRB, NMAT) (dir == 1 ? launch_sp6<NRB, NMAT, 1>(a, ct, s) : (dir == 2 ? launch_sp6<NRB, NMAT, 2>(a, ct, s) : launch_sp6<NRB, NMAT, 0>(a, ct, s)))
+#define DSS2_S6_LAUNCH(NRB, NMAT) (dir == 1 ? launch_sp6<NRB, NMAT, 1>(a, ct, hd, s) : (dir == 2 ? launch_sp6<NRB, NMAT, 2>(a, ct, hd, s) : launch_sp6<NRB, NMAT, 0>(a, ct, hd, s)))
   if (a.nrb == 3) return a.nmat == 2 ? DSS2_S6_LAUNCH(3, 2) : DSS2_S6_LAUNCH(3, 3);
   return a.nmat == 2 ? DSS2_S6_LAUNCH(6, 2) : DSS2_S6_LAUNCH(6, 3);
 #undef DSS2_S6_LAUNCH

@@ -690,8 +690,10 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         use16 = bool(plan.bwd16) and chain16_supported(topo, nmat, hid, True)
         # the head's data gradient inside the chained launch (its input tile is computed from the dim_out-wide upstream gradient):
         # dss2_gemm_prop_chain_head, mode 2; only the head's weight gradient keeps a launch of its own
+        # (tall tiles: only the direction-specialised data-gradient chain has the head form -- its layers gate with bit words)
         head_fused = (use16 and L - 1 <= FL.CHAIN_MAX and is_narrow(nmat, mod.dim_out)
-                      and chain_head_supported(topo, nmat, hid, mod.dim_out, True))
+                      and chain_head_supported(topo, nmat, hid, mod.dim_out, True)
+                      and (topo.nrb <= 2 or all(act_bits.get(l_) is not None for l_ in range(1, L - 1))))
         head = None
         if head_fused:
             _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, mod.dim_out, flat[offs[2 + l]:offs[3 + l]],

@@ -131,8 +131,8 @@ def chain_head_supported(topo: Topology, nmat: int, hid: int, nout: int, transpo
     (dss2_gemm_prop_chain_head: forward = the head after the last chained layer, transposed = the chain's input computed from
     the head's upstream gradient); DSS2_CHAIN_HEAD=0 switches it off."""
     ell, tiles = (topo.ellT, topo.ellT_tiles) if transposed else (topo.ell, topo.ell_tiles)
-    return bool(FL.CHAIN_HEAD) and FL.CHAIN_BF16 and tiles is not None and bool(
-        _lib.lib().dss2_gemm_prop_chain_head_supported(topo.nrb, nmat, hid, hid, ell, nout))
+    return bool(FL.CHAIN_HEAD) and FL.CHAIN_BF16 and tiles is not None and bool(      # (a mask of modes: bit 0 forward, bit 1 backward)
+        _lib.lib().dss2_gemm_prop_chain_head_supported(topo.nrb, nmat, hid, hid, ell, nout) & (2 if transposed else 1))
 
 
 def gemm16_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bool:

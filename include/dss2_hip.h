@@ -280,7 +280,8 @@ typedef struct dss2_chain_head {
 } dss2_chain_head;
 int dss2_gemm_prop_chain_head(const dss2_gemm_prop_args* args_host, const dss2_chain_layer* layers_host, int n_layers,
                               const dss2_chain_head* head_host, void* stream);
-/* != 0: dss2_gemm_prop_chain_head runs this shape (the split-plane chain: 64-row tiles, hid >= 96, bf16x6 weights) */
+/* mask of the head modes dss2_gemm_prop_chain_head runs for this shape: bit 0 = mode 1 (forward), bit 1 = mode 2 (backward).
+ * 3 on the split-plane chain of 64-row tiles (hid >= 96, bf16x6 weights), 2 on its 96- / 192-row form, 0 otherwise. */
 int dss2_gemm_prop_chain_head_supported(int nrb, int nmat, int kreal, int hout, int ell_width, int nout);
 int dss2_gemm_prop_chain_supported(int nrb, int nmat, int kreal, int hout, int ell_width);
 /* != 0: the chain can also run with args.b_format = 1 -- weights packed as bf16x3 fragments, the tile GEMM as six

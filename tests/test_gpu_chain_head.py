@@ -51,6 +51,32 @@ def test_fused_head_equals_separate_launches(pkg, cls, args, B):
             assert rel_err(g, r) < 1e-5, (fwd, bwd, n)
 
 
+@pytest.mark.parametrize("grid,args,B", [
+    ("ober_sub", (8, 6, 2, 128, 4, 2, 0.0), 41),        # the C3 model on 96-row tiles, odd tile count
+    ("ober_sub", (8, 6, 3, 128, 4, 2, 0.3), 20),        # dim_out 3, dropout mask on the head's input
+    ("ober179", (8, 6, 2, 128, 4, 2, 0.0), 12),         # 192-row tiles (three rows per lane in the head's hop phase)
+    ("ober179", (8, 6, 4, 96, 3, 1, 0.3), 9),           # K = 1, dim_out 4, three column groups
+])
+def test_tall_tile_backward_head_equals_separate_launches(pkg, grid, args, B):
+    """96- / 192-row tiles: only the BACKWARD head rides in the chain (gemm_chain_sp6_kernel<NRB, NMAT, 2, 2>: the data-gradient
+    chain's input tile built in its staging); the forward head keeps its launch whatever the switch says."""
+    b = pkg.synthetic.make_batch([grid], B, seed=4)
+    torch.manual_seed(0)
+    model = pkg.MPN(*args).to(DEV)
+    topo = pkg.topology.get_topology(b["edge_index"].to(DEV), b["x"].shape[0])
+    nw = pkg.networks
+    assert topo.nrb in (3, 6)
+    assert nw.chain_head_supported(topo, args[5] + 1, args[3], args[2], True) and not nw.chain_head_supported(topo, args[5] + 1, args[3], args[2], False)
+    ref = _run(pkg, model, b, False, False, 7)
+    got = _run(pkg, model, b, True, True, 7)
+    again = _run(pkg, model, b, True, True, 7)
+    assert torch.equal(got[0], ref[0])                                   # the forward is the same launches
+    assert torch.equal(got[1], again[1])
+    assert rel_err(got[1], ref[1]) < 1e-5
+    for g, r, (n, _) in zip(got[2], ref[2], model.named_parameters()):
+        assert rel_err(g, r) < 1e-5, n
+
+
 def test_fused_head_against_the_oracle(pkg, oracle):
     """MPN(H = 128, L = 4) with both fusions on against the fp64 oracle, gates pinned by the output tolerance only (p = 0)."""
     b = pkg.synthetic.make_batch(["cigre14"], 64, seed=9)
