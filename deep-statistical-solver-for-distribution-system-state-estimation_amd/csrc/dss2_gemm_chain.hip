@@ -25,8 +25,11 @@ extern "C" int dss2_gemm_prop_chain_gate_words(int nrb, int nmat, int kreal, int
   using namespace dss2;
   dss2_gemm_prop_args a = {};
   a.b_format = 1; a.nrb = nrb; a.nmat = nmat; a.kreal = kreal; a.kpad = (kreal + 15) / 16 * 16; a.hout = hout; a.ncg = (hout + 31) / 32; a.ell_width = ell_width;
-  if (!(kreal == hout && (hout & 3) == 0 && ell_width > 0 && (nrb == 6 || nrb == 3) && chain_sp6_supported(a))) return 0;
-  return a.ncg * 32 * ((4 * nrb + 7) / 8);      // per wave (column group): 64 lanes x ceil(row pieces / 8) 32-bit words (dss2_gemm_chain_sp6.hip)
+  if (!(kreal == hout && (hout & 3) == 0 && ell_width > 0)) return 0;
+  const bool tall = (nrb == 6 || nrb == 3) && chain_sp6_supported(a);
+  const bool sp64 = nrb == 2 && chain_row_split(nrb, a.ncg) == 1 && chain_sp_supported(a);      // (round 4: the 64-row split-plane chain too)
+  if (!tall && !sp64) return 0;
+  return a.ncg * 32 * ((4 * nrb + 7) / 8);      // per wave (column group): 64 lanes x ceil(row pieces / 8) 32-bit words (dss2_gemm_chain_sp6.hip, _sp.hip)
 }
 
 extern "C" int dss2_gemm_prop_chain16_supported(int nrb, int nmat, int kreal, int hout, int ell_width) {

@@ -52,7 +52,15 @@ __device__ __forceinline__ void sp_store_split(__bf16* dst, const f32x4 v) {
 // computed in the staging from the nout-wide upstream gradient instead of being written and re-read by a launch of its own.
 constexpr int SP_HEAD_MAX = 4;      // nout
 
-template <int NMAT, int NW, int HM>
+// MS: the tile GEMM's MFMA shape.  0: v_mfma_f32_32x32x16_bf16, two 32-row blocks x NMAT accumulator blocks per wave (six dependent MFMAs
+// per block and k-step).  1: v_mfma_f32_16x16x32_bf16 (round 4), four 16-row x two 16-column blocks per matrix -- 24 independent
+// accumulator chains of NMAT interleaved: in the chain's GEMM regime in isolation the 16x16 shape keeps the pipe at 92 % with two
+// waves per SIMD, the 32x32 shape at 73 % (tools/micro/mfma_shape_clock.hip).  Same operands: the A fragment of a 16-row block is
+// rows x 8 k at k = 32 kb + 8 (lane >> 4) of the same planes, the B fragment is read out of the SAME packed weights (fragment order of
+// the 32x32x16 form: k-group 2 kb + (lane >> 5), source lane ((lane >> 4) & 1) * 32 + 16 nb + (lane & 15)).  Only the GEMM phase and the
+// accumulator hand-off (put) differ; sums are formed in another order, so results differ from MS = 0 by rounding.  K a multiple of 32.
+typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+template <int NMAT, int NW, int HM, int MS>
 __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_gemm_prop_args p, const ChainTable ct, const dss2_chain_head hd) {
   constexpr int TM = SP_TM;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -163,7 +171,16 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) b[pl][m] = bp16[(((size_t)(m * ncg + cg) * nks + ks) * 3 + pl) * 64 + lane];
   };
-  load_b(reinterpret_cast<const bf16x8*>(ct.l[0].Bp), b0, 0);
+  // MS = 1: the fragments of k-step kb (32 k) and 16-column block nb, out of the 32x32x16 fragment order
+  auto load_b16 = [&](const bf16x8* __restrict__ bp16, bf16x8 (&b)[3][NMAT], int kb, int nb) {
+    const int ks = 2 * kb + (lane >> 5), sl = ((lane >> 4) & 1) * 32 + nb * 16 + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[pl][m] = bp16[(((size_t)(m * ncg + cg) * nks + ks) * 3 + pl) * 64 + sl];
+  };
+  if constexpr (MS == 0) load_b(reinterpret_cast<const bf16x8*>(ct.l[0].Bp), b0, 0);
+  else load_b16(reinterpret_cast<const bf16x8*>(ct.l[0].Bp), b0, 0, 0);
   CSTAMP(0);
   sp_barrier();
   CSTAMP(1);
@@ -172,10 +189,62 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
   for (int li = 0; li < ct.n; ++li) {
     const dss2_chain_layer& L = ct.l[li];    // uniform: scalar loads from the kernel-argument segment
     const bf16x8* __restrict__ bp16 = reinterpret_cast<const bf16x8*>(L.Bp);
-    f32x16 acc[2][NMAT];
+    f32x16 acc[MS == 0 ? 2 : 1][NMAT];
+    f32x4_acc c16[MS == 1 ? 4 : 1][2][NMAT];
 
+    if constexpr (MS == 1) {
+      // ---- tile GEMM on 16x16x32 MFMAs: a k-step (32 k) is two half-steps, one per 16-column block; the four row blocks' A fragments
+      // live for the whole k-step and are re-requested for the next one right after their last use; B fragments ping-pong one half-step ahead
+      const int nkb = p.kpad >> 5;
+      bf16x8 b1[3][NMAT], a[4][3];
+      auto load_a16 = [&](bf16x8 (&af)[3], int mb, int kb) {
+        const __bf16* src = xpl + kb * (2 * SP_REGION) + (mb * 16 + (lane & 15)) * SP_RS + (lane >> 4) * 8;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8*>(src + pl * SP_PLANE);
+      };
+      auto mma16 = [&](const bf16x8 (&af)[3], const bf16x8 (&b)[3][NMAT], f32x4_acc (&c)[NMAT], const bool first) {
+        const f32x4_acc zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], b[0][m], first ? zero : c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], b[1][m], c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], b[2][m], c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], b[0][m], c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], b[1][m], c[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], b[0][m], c[m], 0, 0, 0);
+      };
+      // one k-step: b0 holds (kb, column block 0); branch-free (the last step re-requests its own operands)
+      auto kstep = [&](int kb, const bool first) {
+        const int kn = kb + 1 < nkb ? kb + 1 : kb;
+        load_b16(bp16, b1, kb, 1);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) mma16(a[mb], b0, c16[mb][0], first);
+        load_b16(bp16, b0, kn, 0);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) { mma16(a[mb], b1, c16[mb][1], first); load_a16(a[mb], mb, kn); }
+        // one memory request per few MFMAs: half-step 0 carries the 3 NMAT weight fragments of half-step 1, half-step 1 those of the next
+        // k-step and, behind each row block's MFMAs, that block's three plane fragments
+#pragma unroll
+        for (int i = 0; i < 3 * NMAT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 24 * NMAT - 6 * NMAT, 0);
+#pragma unroll
+        for (int i = 0; i < 3 * NMAT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+      };
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) load_a16(a[mb], mb, 0);
+#ifndef DSS2_SP_NOPRIO
+      __builtin_amdgcn_s_setprio(2);
+#endif
+      kstep(0, true);
+      for (int kb = 1; kb < nkb; ++kb) kstep(kb, false);
+      __builtin_amdgcn_s_setprio(0);
+    }
     // ---- tile GEMM, 16 k per step: B fragments (L2) ping-pong one step ahead, A fragments (LDS planes) one row block ahead
-    {
+    if constexpr (MS == 0) {
       bf16x8 b1[3][NMAT], a[2][3];
       auto load_a = [&](bf16x8 (&af)[3], int rb, int ks) {
         const __bf16* src = xa + (ks >> 1) * (2 * SP_REGION) + rb * 32 * SP_RS + (ks & 1) * 16;
@@ -245,34 +314,55 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
     if (L.bias && col_ok) bias4 = *reinterpret_cast<const f32x4*>(L.bias + col0);
     auto grow_of = [&](int i) { const int row = rowv + 8 * i; return (size_t)(ts + (row < R ? row : 0)); };      // (clamped: loads only)
     f32x4 gate[8];
-    if (has_rs) {      // (uniform; the row addresses hang on a value defined inside the branch, or they are formed -- 80 vector
-                       //  instructions per layer -- whether or not the layer has a gate: the forward chain has none)
-      int rowg = rowv;
-      asm volatile("" : "+v"(rowg));
-      if (col_ok) {
-        // one 64-bit product for the lane's first row, a uniform stride for the others; rows beyond the tile read its first row
-        const char* g0 = reinterpret_cast<const char*>(L.relu_src + (size_t)ts * p.ld_relu + col0);
-        const char* gp = g0 + (size_t)rowg * p.ld_relu * 4;
-        const size_t gstep = (size_t)p.ld_relu * 32;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          gate[i] = *reinterpret_cast<const f32x4*>(rowg + 8 * i < R ? gp : g0);
-          gp += gstep;
-        }
-      }
-    }
+    // The ReLU gate of a data-gradient layer as ONE BIT per element where the forward chain of the same tiles left the sign bits of
+    // its output (L.gate_bits <- that layer's y_bits; layout [tile][column group][lane], bit 4 i + q = element q of the lane's row
+    // piece i, as in dss2_gemm_chain_sp6.hip): one register instead of eight row pieces, 1/32 of the bytes, no exposed latency.
+    uint32_t gate_word = 0u;
+    const bool gbits = L.gate_bits != nullptr;
+    if (gbits) gate_word = reinterpret_cast<const uint32_t*>(L.gate_bits)[((size_t)tile * ncg + cg) * 64 + lane];
     // every wave is done with this layer's planes: the hops below overwrite the wave's own stripe
     sp_barrier();
     CSTAMP(2 + li * 6 + 1);
 
+    // (the gate rows are requested inside the Horner phase, after the first two accumulator hand-offs: before the barrier above they
+    //  were live beside all 96 accumulator registers and, in the 16x16x32 form, went to scratch memory straight after their loads --
+    //  a full memory latency in front of every layer's hops: 131 us instead of 111 for the backward chain)
+    auto request_gates = [&]() {
+      if (has_rs) {      // (uniform; the row addresses hang on a value defined inside the branch, or they are formed -- 80 vector
+                         //  instructions per layer -- whether or not the layer has a gate: the forward chain has none)
+        int rowg = rowv;
+        asm volatile("" : "+v"(rowg));
+        if (col_ok) {
+          // one 64-bit product for the lane's first row, a uniform stride for the others; rows beyond the tile read its first row
+          const char* g0 = reinterpret_cast<const char*>(L.relu_src + (size_t)ts * p.ld_relu + col0);
+          const char* gp = g0 + (size_t)rowg * p.ld_relu * 4;
+          const size_t gstep = (size_t)p.ld_relu * 32;
+  #pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            gate[i] = *reinterpret_cast<const f32x4*>(rowg + 8 * i < R ? gp : g0);
+            gp += gstep;
+          }
+        }
+      }
+    };
     // ---- Horner on row pieces, wave-private: T in one slot, G_m in the other; U = G_m + P T replaces G_m
     f32x4 U[8];
     {
       auto put = [&](float* slot, int m) {
+        if constexpr (MS == 0) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+          for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) slot[(rb * 32 + acc_row(r, half)) * 32 + c32] = acc[rb][m][r];
+            for (int r = 0; r < 16; ++r) slot[(rb * 32 + acc_row(r, half)) * 32 + c32] = acc[rb][m][r];
+        } else {      // lane (n = lane & 15, row group lane >> 4) holds rows 16 mb + 4 (lane >> 4) + r of column 16 nb + n
+          float* dst = slot + (4 * (lane >> 4)) * 32 + (lane & 15);
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) dst[(mb * 16 + r) * 32 + nb * 16] = c16[mb][nb][m][r];
+        }
       };
       put(slot0, NMAT - 1);
 #pragma unroll
@@ -280,6 +370,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
         float* cur = slot0 + (((NMAT - 2 - m) & 1) ? SP_SLOT : 0);      // holds T
         float* oth = slot0 + (((NMAT - 2 - m) & 1) ? 0 : SP_SLOT);      // receives G_m, then U
         put(oth, m);
+        if (m == NMAT - 2 && !gbits) request_gates();
         wave_lds_sync();
         int2 ea[8], eb[8];
 #pragma unroll
@@ -316,7 +407,10 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
     // ---- epilogue: bias / folded bias / masks / dropout / ReLU / gate / residual -> HBM and, split, the next layer's planes
     // (one uniform branch per feature around a loop over the lane's rows, not the other way round)
     const bool keep = li + 1 < ct.n;
-    if (keep) load_b(reinterpret_cast<const bf16x8*>(ct.l[li + 1].Bp), b0, 0);      // the next layer's first fragments ride under the epilogue
+    if (keep) {      // the next layer's first fragments ride under the epilogue
+      if constexpr (MS == 0) load_b(reinterpret_cast<const bf16x8*>(ct.l[li + 1].Bp), b0, 0);
+      else load_b16(reinterpret_cast<const bf16x8*>(ct.l[li + 1].Bp), b0, 0, 0);
+    }
     // fused head: its weights (this lane's share of the wave's [m nout + o][32] block), bias and residual row, requested under the epilogue
     [[maybe_unused]] float hw_pre[3] = {0.f, 0.f, 0.f};      // (nout <= 2: all of them; wider heads fetch the rest in the head block)
     if constexpr (HM == 1) {
@@ -361,7 +455,12 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
 #pragma unroll
           for (int q = 0; q < 4; ++q) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(U[i][q])); U[i][q] = r; }
       }
-      if (has_rs) {
+      if (gbits) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) U[i][q] = ((gate_word >> (4 * i + q)) & 1u) ? U[i][q] : 0.f;
+      } else if (has_rs) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -380,6 +479,16 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
           yp += ystep;
         }
       }
+    }
+    if (L.y_bits) {      // (uniform) the sign bits of what went to Y, in the layout the data-gradient form reads (pad rows / columns: zero bits)
+      uint32_t word = 0u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool in_y = col_ok && rowv + 8 * i < R;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) word |= ((in_y && U[i][q] > 0.f) ? 1u : 0u) << (4 * i + q);
+      }
+      reinterpret_cast<uint32_t*>(L.y_bits)[((size_t)tile * ncg + cg) * 64 + lane] = word;
     }
     if (keep) {
       // (rows beyond the tile's R rows are NOT zeroed -- 32 selects per layer: their values are finite (bias-driven like any
@@ -494,10 +603,10 @@ bool chain_sp_supported(const dss2_gemm_prop_args& a) {
          a.ncg >= 3 && a.ncg <= 8 && chain_sp_lds_bytes(a.ncg, a.ell_width) <= (size_t)kMaxLdsBytes;
 }
 
-template <int NMAT, int NW, int HM>
+template <int NMAT, int NW, int HM, int MS>
 static int launch_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head& hd, hipStream_t stream) {
   static std::atomic<uint32_t> lds_done{0};
-  auto kern = gemm_chain_sp_kernel<NMAT, NW, HM>;
+  auto kern = gemm_chain_sp_kernel<NMAT, NW, HM, MS>;
   if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop_chain(split planes)")) return 1;
   hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg), chain_sp_lds_bytes(a.ncg, a.ell_width), stream, a, ct, hd);
   return check_launch("gemm_prop_chain(split planes)");
@@ -505,8 +614,17 @@ static int launch_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, const d
 
 template <int HM>
 static int launch_sp_hm(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head& hd, hipStream_t s) {
-  if (a.nmat == 2) return a.ncg <= 4 ? launch_sp<2, 4, HM>(a, ct, hd, s) : launch_sp<2, 8, HM>(a, ct, hd, s);
-  return a.ncg <= 4 ? launch_sp<3, 4, HM>(a, ct, hd, s) : launch_sp<3, 8, HM>(a, ct, hd, s);      // (K = 3 would spill: chain_sp_supported says no)
+  static const int ms16 = [] { const char* e = getenv("DSS2_CHAIN_MFMA16"); return e ? atoi(e) : 1; }();      // 0: the 32x32x16 form
+  // (a layer gated by fp32 activations instead of bit words keeps eight row pieces of gate values beside the accumulators: the 16x16
+  //  form has 24 registers less room, spills them on arrival and waits a memory latency per layer -- 124 us against 107)
+  bool fp32_gates = false;
+  for (int i = 0; i < ct.n; ++i) fp32_gates = fp32_gates || (ct.l[i].relu_src && !ct.l[i].gate_bits);
+  if (ms16 && (a.kpad & 31) == 0 && !fp32_gates) {
+    if (a.nmat == 2) return a.ncg <= 4 ? launch_sp<2, 4, HM, 1>(a, ct, hd, s) : launch_sp<2, 8, HM, 1>(a, ct, hd, s);
+    return a.ncg <= 4 ? launch_sp<3, 4, HM, 1>(a, ct, hd, s) : launch_sp<3, 8, HM, 1>(a, ct, hd, s);
+  }
+  if (a.nmat == 2) return a.ncg <= 4 ? launch_sp<2, 4, HM, 0>(a, ct, hd, s) : launch_sp<2, 8, HM, 0>(a, ct, hd, s);
+  return a.ncg <= 4 ? launch_sp<3, 4, HM, 0>(a, ct, hd, s) : launch_sp<3, 8, HM, 0>(a, ct, hd, s);      // (K = 3 would spill: chain_sp_supported says no)
 }
 
 int launch_chain_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head* head, hipStream_t s) {

@@ -24,6 +24,16 @@ DEV = "cuda:0"
 TOL_SHARD, TOL_ORACLE = 1e-6, 2e-5
 
 
+@pytest.fixture(autouse=True)
+def same_tile_height_for_every_shard(monkeypatch):
+    """The 1e-6 bar compares a sharded step with the single-batch step, so every shard must run the kernels the whole batch runs.
+    A 5-graph shard tiles best at 32 or 96 rows and then takes another form of the layer chain; until round 4 all forms summed in
+    the same order (bitwise equal results), since the 64-row chain's tile GEMM moved to 16x16x32 MFMAs they differ by rounding --
+    nothing a data-parallel run cares about, but 1e-6 is below it.  So the tile height is pinned for this file (read per structure
+    build, topology.py)."""
+    monkeypatch.setenv("DSS2_NRB", "2")
+
+
 @pytest.fixture(scope="module")
 def pkg():
     p = load_pkg()

@@ -30,8 +30,9 @@ FALLBACKS = {
     # of the forward chain's bit words
     "chain-variants-b": (dict(DSS2_CHAIN_HEAD_FWD="1", DSS2_CHAIN_GATE_BITS="0"),
                          [(PARITY, f"golden or {C2} or {C3} or tall_tiles")]),
-    # the generic narrow kernels, scalar-VALU edge MLP, edges through the global CSR instead of tile-local lists
-    "generic-narrow-edge": (dict(DSS2_NARROW_STREAM="0", DSS2_EDGE_MFMA="0", DSS2_EDGE_TILE="0"),
+    # the generic narrow kernels, scalar-VALU edge MLP, edges through the global CSR instead of tile-local lists; the 64-row chain's tile
+    # GEMM on 32x32x16 MFMAs instead of 16x16x32
+    "generic-narrow-edge": (dict(DSS2_NARROW_STREAM="0", DSS2_EDGE_MFMA="0", DSS2_EDGE_TILE="0", DSS2_CHAIN_MFMA16="0"),
                             [(PARITY, f"golden or edge_aggregation or tagconv or {C2}"), (ROUND2, "propagate or message or known_answers")]),
 }
 
