@@ -172,12 +172,16 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
       for (int pl = 0; pl < 3; ++pl) b[pl][m] = bp16[(((size_t)(m * ncg + cg) * nks + ks) * 3 + pl) * 64 + lane];
   };
   // MS = 1: the fragments of k-step kb (32 k) and 16-column block nb, out of the 32x32x16 fragment order
+  // (a uniform 64-bit base per matrix -- scalar registers -- plus ONE 32-bit lane offset: with per-matrix 64-bit lane pointers the
+  //  16x16 form kept three pointer pairs in scratch memory and reloaded them, each behind an s_waitcnt vmcnt(0), at the top of every k-step)
+  const uint32_t b16_lane = (uint32_t)(((lane >> 5) * 3 * 64 + ((lane >> 4) & 1) * 32 + (lane & 15)) * 16);
   auto load_b16 = [&](const bf16x8* __restrict__ bp16, bf16x8 (&b)[3][NMAT], int kb, int nb) {
-    const int ks = 2 * kb + (lane >> 5), sl = ((lane >> 4) & 1) * 32 + nb * 16 + (lane & 15);
 #pragma unroll
-    for (int m = 0; m < NMAT; ++m)
+    for (int m = 0; m < NMAT; ++m) {
+      const char* mbase = reinterpret_cast<const char*>(bp16) + (size_t)(uint32_t)(((m * ncg + cg) * nks + 2 * kb) * 3072 + nb * 256);      // uniform
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) b[pl][m] = bp16[(((size_t)(m * ncg + cg) * nks + ks) * 3 + pl) * 64 + sl];
+      for (int pl = 0; pl < 3; ++pl) b[pl][m] = *reinterpret_cast<const bf16x8*>(mbase + (size_t)(b16_lane + (uint32_t)(pl * 1024)));
+    }
   };
   if constexpr (MS == 0) load_b(reinterpret_cast<const bf16x8*>(ct.l[0].Bp), b0, 0);
   else load_b16(reinterpret_cast<const bf16x8*>(ct.l[0].Bp), b0, 0, 0);
@@ -228,11 +232,19 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
         for (int mb = 0; mb < 4; ++mb) { mma16(a[mb], b1, c16[mb][1], first); load_a16(a[mb], mb, kn); }
         // one memory request per few MFMAs: half-step 0 carries the 3 NMAT weight fragments of half-step 1, half-step 1 those of the next
         // k-step and, behind each row block's MFMAs, that block's three plane fragments
+        // half-step 0 (24 NMAT MFMAs): its 3 NMAT weight requests, one per two MFMAs, then the rest
 #pragma unroll
         for (int i = 0; i < 3 * NMAT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
         __builtin_amdgcn_sched_group_barrier(0x008, 24 * NMAT - 6 * NMAT, 0);
+        // half-step 1: row block 0's 6 NMAT MFMAs carry the next weight requests; behind them row block 0's plane registers are free and
+        // row block j's MFMAs carry the three plane reads of row block j - 1; the last three reads close the step (needed 18 NMAT MFMAs later)
 #pragma unroll
-        for (int i = 0; i < 3 * NMAT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        for (int i = 0; i < 3 * NMAT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, (6 * NMAT) / (3 * NMAT), 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2 * NMAT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
       };
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) load_a16(a[mb], mb, 0);

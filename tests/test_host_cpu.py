@@ -185,12 +185,12 @@ def test_no_kernel_in_the_library_spills_registers():
     allowed["void dss2::edge16_fwd_kernel<2>"] = 4
     allowed["void dss2::edge16_fwd_kernel<3>"] = 8
     # A fourth, chosen: the 64-row split-plane chain on 16x16x32 MFMAs at K = 2 (csrc/dss2_gemm_chain_sp.hip, MS = 1).  96 accumulator
-    # registers + the four row blocks' plane fragments (48) + two sets of weight fragments (72) leave 40 for everything else; ~50 loop
-    # invariants live in scratch memory around the layer loop, four accesses per k-step of 144 MFMAs inside it.  Measured with them:
-    # forward / backward chain 109.4 / 108.9 -> 100.7 / 101.7 us at C2 (the 32x32x16 form, MS = 0, does not spill).
+    # registers + the four row blocks' plane fragments (48) + two sets of weight fragments (72) leave 40 for everything else; 20-24 loop
+    # invariants live in scratch memory around the layer loop, none inside the k-step loop.  Measured with them: forward / backward chain
+    # 109.4 / 108.9 -> 100.7 / 101.7 us at C2 (the 32x32x16 form, MS = 0, does not spill).
     for nw in (4, 8):
         for hm in (0, 1, 2):
-            allowed[f"void dss2::gemm_chain_sp_kernel<3, {nw}, {hm}, 1>"] = 56
+            allowed[f"void dss2::gemm_chain_sp_kernel<3, {nw}, {hm}, 1>"] = 32
     bad = [(fn, name, sp, scr) for fn, ks in results for name, sp, scr in ks
            if (sp or scr) and not (name.strip() in allowed and sp <= allowed[name.strip()])]
     assert not bad, bad
