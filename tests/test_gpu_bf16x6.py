@@ -309,14 +309,17 @@ def test_tall_tile_layer_chain_equals_layer_by_layer(pkg, B, H, nmat, nl):
 
 
 @pytest.mark.parametrize("grid,B,H,nmat", [("ober179", 40, 128, 3), ("ober179", 700, 128, 3), ("ober179", 9, 64, 3), ("ober179", 12, 96, 2),
-                                            ("ober_sub", 64, 128, 3), ("ober_sub", 1024, 128, 3), ("ober_sub", 30, 64, 2)])
+                                            ("ober_sub", 64, 128, 3), ("ober_sub", 1024, 128, 3), ("ober_sub", 30, 64, 2),
+                                            ("cigre14", 300, 128, 3), ("cigre14", 4096, 128, 3), ("cigre14", 70, 100, 3), ("cigre14", 41, 96, 2)])
 def test_tall_tile_chain_gate_bits_equal_fp32_gate(pkg, grid, B, H, nmat):
     """dss2_chain_layer.y_bits / gate_bits: the forward chain writes the sign bits of its outputs (with dropout zeros in them),
-    the data-gradient chain gates with those words instead of reading the activations -- bitwise the same result."""
+    the data-gradient chain gates with those words instead of reading the activations -- bitwise the same result.  (Round 4: the
+    64-row split-plane chain too; there a chain gated by fp32 activations runs its tile GEMM on 32x32x16 MFMAs and one gated by
+    bit words on 16x16x32 when K is a multiple of 32 -- same gates, sums in another order: equal to rounding, bitwise at H = 100.)"""
     nw = pkg.networks
     topo, N = _topo(pkg, [grid], B)
     gw = nw.chain_gate_words(topo, nmat, H)
-    assert gw == ((H + 31) // 32) * 32 * ((4 * topo.nrb + 7) // 8) and topo.nrb in (3, 6)
+    assert gw == ((H + 31) // 32) * 32 * ((4 * topo.nrb + 7) // 8) and topo.nrb in (2, 3, 6)
     torch.manual_seed(11)
     Ws = [torch.randn(H, H, device=DEV) * (1.5 / H ** 0.5) for _ in range(nmat)]
     plan = nw._PackPlan([Ws], DEV, bf16_groups=(0,))
@@ -340,8 +343,11 @@ def test_tall_tile_chain_gate_bits_equal_fp32_gate(pkg, grid, B, H, nmat):
         nw.gemm_prop_chain(topo, g, H, nmat, [dict(Bp=plan.bwd16[0], Y=o, relu_src=a_, gate_bits=(b_ if use_bits else None))
                                                for o, a_, b_ in zip(outs, acts, bits)], transposed=True, b_format=1)
         return outs
-    for x, y in zip(bwd(True), bwd(False)):
-        assert torch.equal(x, y)
+    for li, (x, y) in enumerate(zip(bwd(True), bwd(False))):
+        if topo.nrb == 2 and H % 32 == 0:
+            assert rel_err(x, y) < 3e-6 * (li + 1), li
+        else:
+            assert torch.equal(x, y)
 
 
 def _stress(fn, ref, n=200):
