@@ -11,7 +11,9 @@ CHAIN_GATE_BITS = _os.environ.get("DSS2_CHAIN_GATE_BITS", "1") == "1"  # split-p
 CHAIN_BF16 = _os.environ.get("DSS2_CHAIN_BF16", "1") == "1"            # its tile GEMM as bf16x6 on the bf16 matrix pipe (fp32-accurate)
 CHAIN_HEAD = _os.environ.get("DSS2_CHAIN_HEAD", "1") == "1"            # the narrow head TAGConv's data gradient inside the chained launch of the data gradients
 # ... and the head's forward inside the forward chain: measured break-even at C2 (chain + head 124.5 us against 110.7 + 14.1 us for the
-# two launches: the head's tail runs on one wave per workgroup), so it is off by default; tested under DSS2_CHAIN_HEAD_FWD=1
+# two launches: the head's tail runs on one wave per workgroup), so it is off by default; tested under DSS2_CHAIN_HEAD_FWD=1.
+# (With the 16x16x32 chain of round 4 the fused step measures 4 us shorter -- 0.4716-0.4739 against 0.4760 ms eager -- but the head's
+#  ~10 us then sit inside the launch bench.py prices against the H -> H layers' FLOPs; left off.)
 CHAIN_HEAD_FWD = _os.environ.get("DSS2_CHAIN_HEAD_FWD", "0") == "1"
 WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"
 STACK_NODE = _os.environ.get("DSS2_STACK_NODE", "1") == "1"              # PFN / SkipPFN as ONE autograd node (_PFNFn)
