@@ -196,6 +196,27 @@ def test_no_kernel_in_the_library_spills_registers():
     assert not bad, bad
 
 
+def test_shape_queries_route_the_round_4_kernels():
+    """Host-side shape queries of the C ABI (no GPU needed): which tile heights get the bf16x6 weight gradient, how many workgroups it
+    puts on a tile-list slice, which head modes and gate-bit words the layer chains offer.  The Python layer routes on these answers."""
+    from conftest import load_pkg
+    L = load_pkg()._lib.lib()
+    # weight gradient: 32-row form (two workgroups per CU), 64-row form, tall tiles (one 8-wave workgroup per CU); K = 3 and H <= 32 fall back
+    lds = lambda nrb, nmat, h, ell, b16: int(L.dss2_wgrad_lds_bytes_ex(nrb, nmat, h, h, 8 * 32 * nrb, ell, b16))
+    assert lds(1, 3, 128, 3, 1) <= 80 * 1024 < lds(2, 3, 128, 3, 1) <= 160 * 1024
+    for nrb in (3, 4, 5, 6):
+        assert 80 * 1024 < lds(nrb, 3, 128, 3, 1) <= 160 * 1024 and (nrb == 5 or lds(nrb, 3, 128, 3, 1) != lds(nrb, 3, 128, 3, 0))
+    assert lds(3, 4, 128, 3, 1) == lds(3, 4, 128, 3, 0) and lds(3, 3, 32, 3, 1) == lds(3, 3, 32, 3, 0) and lds(3, 3, 128, 9, 1) == lds(3, 3, 128, 9, 0)
+    ys = lambda nrb, h: int(L.dss2_wgrad_y_slices(nrb, 3, h, h, 3, 1, 0))
+    assert (ys(1, 128), ys(2, 128), ys(3, 128), ys(6, 256), ys(2, 256)) == (2, 1, 2, 8, 4)
+    # fused narrow head: 64-row split-plane chain both directions (mask 3), its tall forms the backward only (2), wide heads none
+    head = lambda nrb, h, nout: int(L.dss2_gemm_prop_chain_head_supported(nrb, 3, h, h, 3, nout))
+    assert (head(2, 128, 2), head(3, 128, 2), head(6, 128, 4), head(2, 128, 8), head(2, 64, 2), head(4, 128, 2)) == (3, 2, 2, 0, 0, 0)
+    # ReLU gates as bit words: one 32-bit word per lane and eight row pieces, in 64-bit words per tile
+    gw = lambda nrb, h: int(L.dss2_gemm_prop_chain_gate_words(nrb, 3, h, h, 3))
+    assert (gw(2, 128), gw(3, 128), gw(6, 128), gw(2, 256), gw(2, 64), gw(1, 128)) == (128, 256, 384, 256, 0, 0)
+
+
 def test_fused_adamax_checkpoint_has_one_step_tensor_per_parameter():
     """internally the parameters of a group share one step tensor; a checkpoint must not export that aliasing
     (torch.optim.Adamax would then advance the count once per PARAMETER per iteration)."""
