@@ -179,10 +179,10 @@ __global__ void __launch_bounds__(256) edge_hidden_bwd_kernel(
 //     z_e = W1a x_i + W1b x_j + W1c ea_e + b1,
 // so the two node products are ONE tile GEMM per node, AB = X [W1a; W1b]^T  ([N, 2 hid], dss2_gemm_prop), and only the
 // per-edge combination lives here: S[i] = sum_{e -> i} relu(A[i] + B[src(e)] + W1c ea'_e + b1)   (row per wave, lanes over
-// the hidden features, W1c and b1 in registers; fe <= 8).  Backward: dz_e = dS[i] (z_e > 0); by target it writes
+// the hidden features, W1c and b1 in registers; fe <= 8 with up to 256 hidden units per launch, <= 16 with 128, <= 32 with 64).  Backward: dz_e = dS[i] (z_e > 0); by target it writes
 // dAB[i, :hid] = sum dz and the slabs of dW1c / db1, by source dAB[j, hid:] = sum over the edges leaving j.
 // ------------------------------------------------------------------------------------------
-constexpr int EC_MAXFE = 8;
+constexpr int EC_MAXFE = 32;      // widest edge feature vector (template MAXFE = 8 / 16 / 32 holds a unit's edge-feature weights in registers)
 
 struct EdgeCombineArgs {
   const float* AB; int64_t ldab; const float* ea; int64_t ldea; const float* W1c; int64_t ldw; const float* b1;
@@ -191,9 +191,10 @@ struct EdgeCombineArgs {
   int hfull, c0;      // the launch covers hidden units c0 .. c0 + h - 1 of hfull (wider layers run as several launches of <= 256 units)
 };
 
-template <int FPL, bool BWD>
+template <int FPL, bool BWD, int MAXFE>
 __global__ void __launch_bounds__(256) edge_combine_kernel(const EdgeCombineArgs p) {
-  __shared__ float red[BWD ? 256 * (EC_MAXFE + 1) : 1];
+  constexpr int EC_MAXFE = MAXFE;      // (shadows the file-scope bound: this instantiation's register / LDS width)
+  __shared__ float red[BWD ? 64 * FPL * (EC_MAXFE + 1) : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wpb = blockDim.x >> 6;
@@ -944,16 +945,19 @@ extern "C" int dss2_edge_tile_bwd(const float* x, int64_t ldx, const float* ea, 
 extern "C" int dss2_edge_combine_fwd(const float* AB, int64_t ldab, const float* ea, int64_t ldea, const float* W1c, int64_t ldw,
                                      const float* b1, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* S,
                                      int64_t n_nodes, int h, int fe, void* stream) {
-  if (h <= 0 || fe < 0 || fe > EC_MAXFE) { set_error("edge_combine_fwd: h=%d / fe=%d (0..8) unsupported", h, fe); return 2; }
+  if (h <= 0 || fe < 0 || fe > EC_MAXFE) { set_error("edge_combine_fwd: h=%d / fe=%d (0..32) unsupported", h, fe); return 2; }
   if (n_nodes <= 0) return 0;
   int64_t blocks = (n_nodes + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  for (int c0 = 0; c0 < h; c0 += 256) {      // hidden units are independent: wider layers run as launches of <= 256 units
-    const int hc = h - c0 < 256 ? h - c0 : 256;
+  const int cw = fe <= 8 ? 256 : (fe <= 16 ? 128 : 64);      // hidden units per launch: 64 FPL lanes x (FPL x MAXFE <= 32 weight registers)
+  for (int c0 = 0; c0 < h; c0 += cw) {      // hidden units are independent: wider layers run as several launches
+    const int hc = h - c0 < cw ? h - c0 : cw;
     EdgeCombineArgs a{AB, ldab, ea, ldea, W1c, ldw, b1, nullptr, rowptr, col, ent, S, nullptr, nullptr, n_nodes, hc, fe, 0, h, c0};
     const int fpl = (hc + 63) / 64;
-#define L(FPL) hipLaunchKernelGGL((edge_combine_kernel<FPL, false>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a)
-    if (fpl == 1) L(1); else if (fpl == 2) L(2); else if (fpl == 3) L(3); else L(4);
+#define L(FPL, MFE) hipLaunchKernelGGL((edge_combine_kernel<FPL, false, MFE>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a)
+    if (fe <= 8) { if (fpl == 1) L(1, 8); else if (fpl == 2) L(2, 8); else if (fpl == 3) L(3, 8); else L(4, 8); }
+    else if (fe <= 16) { if (fpl == 1) L(1, 16); else L(2, 16); }
+    else L(1, 32);
 #undef L
   }
   return check_launch("edge_combine_fwd");
@@ -963,17 +967,20 @@ extern "C" int dss2_edge_combine_bwd(const float* AB, int64_t ldab, const float*
                                      const float* b1, const float* dS, const int32_t* rowptr, const int32_t* col,
                                      const int32_t* ent, float* dAB, float* slab, int n_slabs, int64_t n_nodes, int h, int fe,
                                      int by_source, void* stream) {
-  if (h <= 0 || fe < 0 || fe > EC_MAXFE) { set_error("edge_combine_bwd: h=%d / fe=%d (0..8) unsupported", h, fe); return 2; }
+  if (h <= 0 || fe < 0 || fe > EC_MAXFE) { set_error("edge_combine_bwd: h=%d / fe=%d (0..32) unsupported", h, fe); return 2; }
   if (!by_source && (!slab || n_slabs <= 0)) { set_error("edge_combine_bwd: slab missing"); return 2; }
   if (n_nodes <= 0) return 0;
   int64_t blocks = by_source ? (n_nodes + 3) / 4 : n_slabs;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  for (int c0 = 0; c0 < h; c0 += 256) {
-    const int hc = h - c0 < 256 ? h - c0 : 256;
+  const int cw = fe <= 8 ? 256 : (fe <= 16 ? 128 : 64);
+  for (int c0 = 0; c0 < h; c0 += cw) {
+    const int hc = h - c0 < cw ? h - c0 : cw;
     EdgeCombineArgs a{AB, ldab, ea, ldea, W1c, ldw, b1, dS, rowptr, col, ent, nullptr, dAB, slab, n_nodes, hc, fe, by_source, h, c0};
     const int fpl = (hc + 63) / 64;
-#define L(FPL) hipLaunchKernelGGL((edge_combine_kernel<FPL, true>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a)
-    if (fpl == 1) L(1); else if (fpl == 2) L(2); else if (fpl == 3) L(3); else L(4);
+#define L(FPL, MFE) hipLaunchKernelGGL((edge_combine_kernel<FPL, true, MFE>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a)
+    if (fe <= 8) { if (fpl == 1) L(1, 8); else if (fpl == 2) L(2, 8); else if (fpl == 3) L(3, 8); else L(4, 8); }
+    else if (fe <= 16) { if (fpl == 1) L(1, 16); else L(2, 16); }
+    else L(1, 32);
 #undef L
   }
   return check_launch("edge_combine_bwd");

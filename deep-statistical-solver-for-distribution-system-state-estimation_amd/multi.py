@@ -156,20 +156,20 @@ class _EdgeAggrGeneralFn(torch.autograd.Function):
 
 
 def _check_general_dims(mod) -> None:
-    if mod.dim_feate > 8:
-        raise NotImplementedError("EdgeAggregation on HIP: dim_feate <= 8 (the per-edge kernel holds a unit's edge-feature "
-                                  "weights in registers)")
+    if mod.dim_feate > 32:
+        raise NotImplementedError("EdgeAggregation on HIP: dim_feate <= 32 (the per-edge kernel holds a unit's edge-feature "
+                                  "weights in registers: 8 / 16 / 32 wide instantiations)")
 
 
 class EdgeAggregationGeneral(nn.Module):
     """/root/reference/networks.py:159-209 for any ``dim_featn`` (MultiMPN applies it to the hidden activation) and
-    ``dim_feate <= 8``; same parameters and state_dict keys as ``networks.EdgeAggregation``.  ``forward`` takes the graph
+    ``dim_feate <= 32``; same parameters and state_dict keys as ``networks.EdgeAggregation``.  ``forward`` takes the graph
     structure of the caller (the Multi* stacks double the graph once for all their layers)."""
 
     def __init__(self, dim_featn, dim_feate, dim_hid, dim_out):
         super().__init__()
-        if dim_feate > 8:
-            raise NotImplementedError("EdgeAggregation on HIP: dim_feate <= 8")
+        if dim_feate > 32:
+            raise NotImplementedError("EdgeAggregation on HIP: dim_feate <= 32")
         self.dim_featn, self.dim_feate, self.dim_hid, self.dim_out = dim_featn, dim_feate, dim_hid, dim_out
         self.edge_aggr = nn.Sequential(nn.Linear(dim_featn * 2 + dim_feate, dim_hid), nn.ReLU(), nn.Linear(dim_hid, dim_out))
         self._gplan = None

@@ -36,7 +36,8 @@ def _check(mine, ref, out, out64, tol=1e-4):
         assert rel_err(p.grad, q.grad) < tol, n
 
 
-@pytest.mark.parametrize("fn,fe,hid,dout", [(5, 4, 32, 16), (11, 3, 64, 64), (8, 6, 320, 40), (3, 0, 16, 8)])
+@pytest.mark.parametrize("fn,fe,hid,dout", [(5, 4, 32, 16), (11, 3, 64, 64), (8, 6, 320, 40), (3, 0, 16, 8),
+                                            (8, 9, 64, 32), (6, 16, 200, 16), (8, 17, 96, 8), (4, 32, 70, 24)])      # edge features wider than 8 (round 4: up to 32)
 def test_edge_aggregation_with_other_input_widths(pkg, oracle, fn, fe, hid, dout):
     """EdgeAggregation(dim_featn, dim_feate, ...) for widths other than the reference data's (8, 6), and a hidden width above
     256 on the reference's own widths: forward, parameter gradients and the gradient of x."""
@@ -62,6 +63,8 @@ def test_edge_aggregation_with_other_input_widths(pkg, oracle, fn, fe, hid, dout
     ("MPN", (8, 6, 2, 320, 3, 2, 0.0)),           # dim_hid > 256
     ("MPN", (8, 6, 2, 32, 3, 4, 0.0)),            # K = 4: one plain GEMM + four propagation hops per layer
     ("MPN", (8, 6, 2, 64, 2, 5, 0.0)),            # K = 5
+    ("MPN", (8, 12, 2, 64, 3, 2, 0.0)),           # twelve edge features (the reference is width-agnostic, networks.py:163-174)
+    ("SkipPFN", (8, 20, 2, 32, 2, 2, 0.0, 2)),    # twenty, in a stack
 ])
 def test_mpn_family_beyond_the_reference_data_shapes(pkg, oracle, cls, args):
     b = pkg.synthetic.make_batch(["cigre14", "cigre14_reswitched"], 10, seed=5)

@@ -402,8 +402,8 @@ def test_quirks_and_errors(pkg):
         pkg.MPN(8, 6, 2, 32, 2, 2, 0.0)(b["x"][:, :8], b["edge_index"], b["edge_attr"][:, :6])  # CPU tensors
     # (other input widths used to fail loudly; since round 3 they run the general path: tests/test_gpu_cliffs.py)
     assert pkg.EdgeAggregation(7, 6, 32, 32).to(DEV)(x[:, :7].contiguous(), ei2, ea2).shape == (x.shape[0], 32)
-    with pytest.raises(NotImplementedError):
-        pkg.EdgeAggregation(8, 9, 32, 32).to(DEV)(x[:, :8], ei2, torch.cat([ea2, ea2[:, :3]], 1))   # dim_feate > 8: loud
+    with pytest.raises(NotImplementedError):      # dim_feate > 32: loud (9 .. 32 run since round 4: tests/test_gpu_cliffs.py)
+        pkg.EdgeAggregation(8, 33, 32, 32).to(DEV)(x[:, :8], ei2, torch.cat([ea2] * 6, 1)[:, :33])
 
 
 def test_hipgraph_replay_matches_eager(pkg, oracle):
