@@ -50,8 +50,35 @@ def spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def capture_watchdog(result: dict, rank: int, world: int, timeout: float, eager_line_printed: bool):
+    """The hipGraph leg's dead-man timer (every rank runs one).  If the capture or a replay hangs -- e.g. a collective that
+    never completes inside a capture -- the process leaves `timeout` seconds later WITH the eager measurement on stdout:
+    * world == 1: the eager line has not been printed yet; print it now, exit code 0.
+    * world  > 1: rank 0 printed (and flushed) the eager line BEFORE the leg started, so it already is the last JSON line
+      of the run; every rank's own timer ends its process with exit code 0 -- the launcher then reports success and the
+      driver reads a valid (eager) measurement.  The hang itself is recorded on stderr.
+    Returns the started threading.Timer (cancel() it when the leg finishes)."""
+    import threading
+
+    def bail():
+        msg = f"hipGraph leg: no answer within {timeout:.0f} s; the eager measurement stands"
+        print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+        if rank == 0 and not eager_line_printed:
+            result["config"]["hipgraph"] = msg
+            result["partial"] = "hipGraph leg hung and was abandoned; value / ms_per_step are the eager measurement"
+            print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os._exit(0)
+    t = threading.Timer(timeout, bail)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def dry_run(args) -> int:
-    """The launch path without a GPU: gloo process group from the launcher's environment, one all-reduce, one JSON line."""
+    """The launch path without a GPU: gloo process group from the launcher's environment, one all-reduce, one JSON line.
+    --simulate-hung-capture: after the eager line, every rank starts the hipGraph leg's watchdog and then blocks forever
+    (what a capture with a never-completing collective looks like): the run must end with rc 0 and the eager line last."""
     import torch.distributed as dist
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world != args.gpus:
@@ -65,11 +92,20 @@ def dry_run(args) -> int:
         dist.all_reduce(t)
         total = int(t.item())
         dist.barrier()
-        dist.destroy_process_group()
     if total != world * (world + 1) // 2:
         return 3
+    res = {"dry_run": True, "n_gpus": world, "ranks_seen": total, "steps": args.steps, "warmup": args.warmup}
+    if args.simulate_hung_capture:
+        res["config"] = {"mode": "eager"}
+        if rank == 0 and world > 1:
+            print(json.dumps(res), flush=True)
+        capture_watchdog(res, rank, world, args.graph_timeout, eager_line_printed=(world > 1))
+        import threading
+        threading.Event().wait()          # never returns: the watchdog ends the process
+    if world > 1:
+        dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": total, "steps": args.steps, "warmup": args.warmup}), flush=True)
+        print(json.dumps(res), flush=True)
     return 0
 
 
@@ -137,6 +173,7 @@ def time_other_config(pkg, dev, stream, tag, grids, B, cls, cargs, ne, blocks, s
 
     ms_eager = timed(step)
     rec = {"graphs": B, "ms_per_step_eager": ms_eager}
+    g = None          # (a failed capture must not lose the eager measurement: `del g` below)
     try:
         g = pkg.graphs.GraphedStep(step, stream=stream, capture_error_mode="thread_local")
         rec["ms_per_step_replay"] = timed(g.replay)
@@ -176,6 +213,7 @@ def main():
     ap.add_argument("--ramp-seconds", type=float, default=2.0,
                     help="untimed load before the W warm-up steps: a fresh MI355X needs ~1 s of sustained work to reach "
                          "its steady clocks (measured: the first ~100 steps of a process run 40 %% slower)")
+    ap.add_argument("--simulate-hung-capture", action="store_true", help="with --dry-run: block after the eager line as a hung capture would (tests/test_bench_launch_cpu.py)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous path only (gloo on CPU, no GPU call): every rank joins the process group, one "
                          "all-reduce checks it, rank 0 prints a JSON line marked dry_run (tests/test_bench_launch_cpu.py)")
@@ -415,19 +453,19 @@ def main():
     # but up to 0.8 ms on a loaded host -- and two collectives more per step when distributed -- which then bounds the step.
     # Replay has no host work.  Distributed steps are captured WITH their RCCL collectives (capture_error_mode =
     # "thread_local": the process-group watchdog may touch HIP during the capture; tests/test_gpu_rccl.py).  A watchdog
-    # timer prints the eager result and exits 0 if a capture or a replay ever hangs.
-    if not args.no_graph:
-        import threading
-
-        def bail():
-            result["config"]["hipgraph"] = f"no answer within {args.graph_timeout:.0f} s: eager result reported"
-            result["partial"] = "hipGraph leg hung and was abandoned; value / ms_per_step are the eager measurement"
-            if rank == 0:
-                print(json.dumps(result), flush=True)
-            os._exit(0 if world == 1 else 4)      # distributed: the other ranks are stuck in a collective -- make the launcher fail loudly
-        timer = threading.Timer(args.graph_timeout, bail)
-        timer.daemon = True
-        timer.start()
+    # timer (capture_watchdog) leaves with the eager result and exit code 0 if a capture or a replay ever hangs.
+    # At world > 1 rank 0 prints (and flushes) the EAGER line before the leg starts: whatever happens to a capture that
+    # contains RCCL collectives on more than one rank (it has never run on hardware), the run has a valid
+    # measurement on stdout.  If the leg completes, the final line follows and supersedes it.  DSS2_BENCH_DIST_GRAPH=0 skips
+    # the leg at world > 1.
+    dist_graph = os.environ.get("DSS2_BENCH_DIST_GRAPH", "1") != "0"
+    run_graph_leg = not args.no_graph and (world == 1 or dist_graph)
+    if world > 1 and rank == 0 and run_graph_leg:
+        early = dict(result)
+        early["partial"] = "eager measurement, printed before the hipGraph leg; a later line (if any) supersedes it"
+        print(json.dumps(early), flush=True)
+    if run_graph_leg:
+        timer = capture_watchdog(result, rank, world, args.graph_timeout, eager_line_printed=(world > 1))
         try:
             graphed = pkg.graphs.GraphedStep(step, stream=work_stream, capture_error_mode="thread_local")
             for _ in range(max(args.warmup, 5)):
@@ -444,6 +482,8 @@ def main():
         except Exception as exc:          # capture not possible on this stack: the eager numbers stand
             result["config"]["hipgraph"] = f"failed: {type(exc).__name__}: {exc}"[:300]
         timer.cancel()
+    elif not args.no_graph:
+        result["config"]["hipgraph"] = "skipped at world > 1 (DSS2_BENCH_DIST_GRAPH=0)"
 
     if rank == 0:
         # ---- standalone scatter-add (K6) against the HBM roofline (north_star asks for it separately), at two sizes:

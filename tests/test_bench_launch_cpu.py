@@ -34,3 +34,23 @@ def test_bench_dry_run_single_process():
 def test_bench_under_a_launcher_with_the_wrong_world_size_fails():
     p = _run(["--gpus", "2", "--dry-run"], env_extra={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert p.returncode != 0
+
+
+def test_a_hung_capture_leg_at_world_2_leaves_the_eager_line_last_and_exits_0():
+    """at world > 1 rank 0 prints the eager line BEFORE the hipGraph leg; if that leg hangs (a collective
+    that never completes inside a capture) every rank's watchdog ends its process with rc 0 -- the first 8-GPU run cannot
+    lose its measurement.  --simulate-hung-capture blocks every rank exactly there."""
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--simulate-hung-capture", "--graph-timeout", "3"])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[-1])
+    assert res["n_gpus"] == 2 and res["config"]["mode"] == "eager" and "partial" not in res
+    assert "no answer within 3 s" in p.stderr
+
+
+def test_a_hung_capture_leg_at_world_1_prints_the_eager_line_from_the_watchdog():
+    p = _run(["--dry-run", "--simulate-hung-capture", "--graph-timeout", "2"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and "hung" in res["partial"] and "no answer" in res["config"]["hipgraph"]
