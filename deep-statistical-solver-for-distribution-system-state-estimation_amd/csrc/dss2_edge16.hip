@@ -188,6 +188,24 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))
         const int row = rb * 32 + acc_row(r, half);
         if (row < R) p.S[(int64_t)(ts + row) * p.h + j] = Sacc[r];
       }
+      if constexpr (NRB == 2) {
+        if (p.xplanes) {      // (uniform) S as an X plane image for the weight gradient of the layer that consumes it (dss2_wgrad16p.hip)
+          // register r of this lane = tile row r8 + 8 i with r8 = (r & 3) + 4 half, i = (r >> 2) + 4 rb: for each r & 3 the lane holds
+          // half (4 consecutive i) of a 16-byte piece of column j; lane slot of column c32: n = (c32 & 3) * 8 + (c32 >> 2)
+          char* xb = reinterpret_cast<char*>(p.xplanes) + ((size_t)tile * (p.h >> 5) + cg) * 12288 + (2 * half) * 3072 +
+                     (((c32 & 3) << 3) | (c32 >> 2)) * 16 + 8 * rb;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            uint32_t h0, m0, l0, h1, m1, l1;
+            split3_pair(Sacc[a], Sacc[a + 4], h0, m0, l0);
+            split3_pair(Sacc[a + 8], Sacc[a + 12], h1, m1, l1);
+            char* dst = xb + (a >> 1) * 3072 + (a & 1) * 512;      // k-step (r8 >> 1), k half (r8 & 1)
+            *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(dst + 1024) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(dst + 2048) = make_uint2(l0, l1);
+          }
+        }
+      }
     }
     __syncthreads();      // (a workgroup that walks several tiles restages over the images)
   }

@@ -10,11 +10,9 @@ WGRAD_BF16 = _os.environ.get("DSS2_WGRAD_BF16", "1") == "1"            # weight 
 CHAIN_GATE_BITS = _os.environ.get("DSS2_CHAIN_GATE_BITS", "1") == "1"  # split-plane chains (64-, 96-, 192-row tiles): the backward chain's ReLU gates as bit words written by the forward chain
 CHAIN_BF16 = _os.environ.get("DSS2_CHAIN_BF16", "1") == "1"            # its tile GEMM as bf16x6 on the bf16 matrix pipe (fp32-accurate)
 CHAIN_HEAD = _os.environ.get("DSS2_CHAIN_HEAD", "1") == "1"            # the narrow head TAGConv's data gradient inside the chained launch of the data gradients
-# ... and the head's forward inside the forward chain: measured break-even at C2 (chain + head 124.5 us against 110.7 + 14.1 us for the
-# two launches: the head's tail runs on one wave per workgroup), so it is off by default; tested under DSS2_CHAIN_HEAD_FWD=1.
-# (With the 16x16x32 chain of round 4 the fused step measures 4 us shorter -- 0.4716-0.4739 against 0.4760 ms eager -- but the head's
-#  ~10 us then sit inside the launch bench.py prices against the H -> H layers' FLOPs; left off.)
-CHAIN_HEAD_FWD = _os.environ.get("DSS2_CHAIN_HEAD_FWD", "0") == "1"
+# ... and the head's forward inside the forward chain (round 2: break-even, off; with the 16x16x32 chain of round 4 the fused step is
+# 4 us shorter; round 5: on, and bench.py counts the head's FLOPs in the launch it rides in).  DSS2_CHAIN_HEAD_FWD=0: its own launch.
+CHAIN_HEAD_FWD = _os.environ.get("DSS2_CHAIN_HEAD_FWD", "1") == "1"
 WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"
 STACK_NODE = _os.environ.get("DSS2_STACK_NODE", "1") == "1"              # PFN / SkipPFN as ONE autograd node (_PFNFn)
 DX_MERGE = _os.environ.get("DSS2_DX_MERGE", "1") == "1"                  # dx of the edge MLP as ONE K = 2 hid GEMM
@@ -22,5 +20,10 @@ WGRAD_JOIN_FOLDED = None    # None / True: the folded conv 0 rides in the batche
 FOLD_W2 = _os.environ.get("DSS2_FOLD_W2", "1") == "1"   # 0 = run the edge MLP's second Linear as its own GEMMs
 WGRAD_TM32 = _os.environ.get("DSS2_WGRAD_TM32", "1") == "1"      # bf16x6 weight gradient on 32-row tiles, two workgroups per CU (wgrad16b_kernel)
 WGRAD_TM32_MAX_BYTES = 64 << 20      # ... while one layer's input (N * hin * 4 bytes) stays well inside the Infinity Cache
+# The H -> H layers' inputs as X plane images written by their producers (edge MLP, forward chain) and the weight-gradient kernel that
+# reads them (csrc/dss2_wgrad16p.hip, round 5); 0 = wgrad16b / wgrad16 split X themselves.  XP_DROP_FP32: the forward chain then does not
+# write the fp32 copies of h_1 .. h_{L-2} at all (nobody reads them: the backward chain gates with bit words, the weight gradient reads planes)
+WGRAD_XP = _os.environ.get("DSS2_WGRAD_XP", "0") == "1"
+XP_DROP_FP32 = _os.environ.get("DSS2_XP_DROP_FP32", "1") == "1"
 WGRAD_PER_CU = int(_os.environ.get("DSS2_WGRAD_PER_CU", "2"))   # cap on persistent wgrad workgroups per CU (= slabs / 256)
 CHAIN_MAX = 8      # layers per dss2_gemm_prop_chain launch (csrc/dss2_gemm_chain.hip)

@@ -33,21 +33,22 @@ from .topology import Topology, get_topology
 _F32 = torch.float32
 
 from . import flags as FL
-from .ops import (_DROP_PARAMS, _dropout_params, _ncg, _ptr, _reduce, _require_gpu, _round16, _round8, _rows, _stream, _wgrad_per_cu, _wgrad_tiles, chain16_supported, chain_gate_words, chain_head_supported, chain_supported, csr_axpy, dropout_mask, dropout_snapshot, gather_rows, gemm16_supported, gemm_prop, gemm_prop_chain, is_narrow, reduce_pending, segment_sum, wgrad, wgrad_batched)
+from .ops import (new_xplanes, wgrad_batched_xp, xplanes_supported, _DROP_PARAMS, _dropout_params, _ncg, _ptr, _reduce, _require_gpu, _round16, _round8, _rows, _stream, _wgrad_per_cu, _wgrad_tiles, chain16_supported, chain_gate_words, chain_head_supported, chain_supported, csr_axpy, dropout_mask, dropout_snapshot, gather_rows, gemm16_supported, gemm_prop, gemm_prop_chain, is_narrow, reduce_pending, segment_sum, wgrad, wgrad_batched)
 from .plans import (_DESC_DTYPE, _FoldPlan, _MatView, _PackPlan, _SG_DTYPE, _as_view, _sg, _sg_table, _small_gemm)
 
 
 # ------------------------------------------------------------------------------------------
 # functional pieces (raw tensors in, raw tensors out); used by the autograd Functions below
 # ------------------------------------------------------------------------------------------
-def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hout, fn, fe, second_linear=True):
+def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hout, fn, fe, second_linear=True, xp=None):
+    """xp: an X plane image (ops.new_xplanes) that receives S as well (its consumer's weight gradient reads it)."""
     N = topo.N
     S = torch.empty(N, hid, dtype=_F32, device=W1.device)
     if topo.ell_ent_tiles is not None and FL.EDGE_TILE_KERNELS:
-        _lib.check(_lib.lib().dss2_edge_tile_fwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(),
-                                                 topo.tile_start.data_ptr(), topo.ell_ent_tiles.data_ptr(), topo.ell,
-                                                 topo.nrb, topo.ntiles, S.data_ptr(), hid, fn, fe, _stream(S)),
-                   "dss2_edge_tile_fwd")
+        _lib.check(_lib.lib().dss2_edge_tile_fwd_xp(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(),
+                                                    topo.tile_start.data_ptr(), topo.ell_ent_tiles.data_ptr(), topo.ell,
+                                                    topo.nrb, topo.ntiles, S.data_ptr(), hid, fn, fe, _ptr(xp), _stream(S)),
+                   "dss2_edge_tile_fwd_xp")
     else:   # general graphs (hub nodes beyond the ELL width): row-per-wave kernel on the CSR
         _lib.check(_lib.lib().dss2_edge_hidden_fwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(),
                                                    topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(),
@@ -512,6 +513,7 @@ class MPN(nn.Module):
         dims = _stack.route(self, [self], topo)
         if dims is not None:          # dim_hid 32, K 2: the whole-stack kernels (one launch forward, one backward)
             return _stack.run(self, [self], dims, topo, x, edge_attr)
+        self.__dict__["_grad_mode"] = torch.is_grad_enabled()      # (inside autograd.Function.forward it reads False: what only a backward needs is decided here)
         return _MPNFn.apply(x, edge_attr, topo, self, *self._params())
 
     def _forward_general(self, x, edge_attr, topo):
@@ -580,8 +582,19 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
         ver = plan.version
     if not glob:
         topo.lds_check(nmat, _round8(hid), _ncg(hid))
+    # the hid -> hid layers 0 .. L-2 as ONE chained launch (activation tile stays in LDS between layers)
+    n_chain = L - 1 if (L - 1 >= 2 and chain_supported(topo, nmat, hid, False, bool(plan.fwd16))) else 0
+    use16 = bool(n_chain) and bool(plan.fwd16) and chain16_supported(topo, nmat, hid, False)
+    # X plane images (round 5): the inputs of the chained layers -- S and the chain's outputs but the last -- are ALSO written, by their
+    # producers, as the bf16x3 pieces the batched weight gradient's MFMA operand wants (csrc/dss2_wgrad16p.hip).  Only where the
+    # backward will take exactly that launch: folded conv 0 + chained data gradients + batched weight gradients, grad mode on.
+    gw = chain_gate_words(topo, nmat, hid) if use16 else 0      # (inside autograd.Function.forward grad mode is off: always written; 1/32 of a layer output)
+    use_xp = bool(use16 and gw and fold is not None and n_chain == L - 1 and 3 <= L <= 9 and not glob and xplanes_supported(topo, nmat, hid)
+                  and FL.WGRAD_JOIN_FOLDED is not False and mod.__dict__.get("_grad_mode", True)
+                  and chain_supported(topo, nmat, hid, True, True) and chain16_supported(topo, nmat, hid, True))
+    xps = [new_xplanes(topo, hid, dev) for _ in range(n_chain)] if use_xp else []
     S, h = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, plan.fwd[0], hid, hid, mod.dim_featn, mod.dim_feate,
-                              second_linear=fold is None)
+                              second_linear=fold is None, xp=(xps[0] if use_xp else None))
     if fold is not None:
         h = S            # conv 0 consumes the aggregated hidden directly
     acts = [h]
@@ -600,21 +613,21 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
     def drop_id(l):            # mask applied to conv l's output (none after the last conv)
         return base + l + 1 if (snap is not None and l < L - 1) else 0
 
-    # the hid -> hid layers 0 .. L-2 as ONE chained launch (activation tile stays in LDS between layers)
-    n_chain = L - 1 if (L - 1 >= 2 and chain_supported(topo, nmat, hid, False, bool(plan.fwd16))) else 0
     if n_chain:
         layers = []
-        use16 = bool(plan.fwd16) and chain16_supported(topo, nmat, hid, False)
-        # tall tiles: the chain also writes the sign bits of its outputs; the data-gradient chain reads those instead of the
+        # the chain also writes the sign bits of its outputs; the data-gradient chain reads those instead of the
         # activations for its ReLU gates (dss2_chain_layer.y_bits / gate_bits)
-        gw = chain_gate_words(topo, nmat, hid) if use16 else 0      # (inside autograd.Function.forward grad mode is off: always written; 1/32 of a layer output)
         for l in range(n_chain):
-            out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
+            # with X planes the fp32 copy of an inner chain output has no reader (the data-gradient chain gates with the bit words, the
+            # weight gradient reads the planes): it is not written at all; acts keeps a placeholder
+            planes_l = xps[l + 1] if (use_xp and l + 1 < n_chain) else None
+            no_fp32 = planes_l is not None and FL.XP_DROP_FP32
+            out_l = None if no_fp32 else torch.empty(topo.N, hid, dtype=_F32, device=dev)
             layers.append(dict(Bp=(plan.fwd16[1 + l] if use16 else plan.fwd[1 + l]), Y=out_l, bias=conv_ps[l][0], relu=True,
-                               drop_id=drop_id(l), prebias=(fold.bf if (fold is not None and l == 0) else None)))
+                               drop_id=drop_id(l), prebias=(fold.bf if (fold is not None and l == 0) else None), x_planes=planes_l))
             if gw:
                 act_bits[len(acts)] = layers[-1]["y_bits"] = torch.empty(topo.ntiles * gw, dtype=torch.int64, device=dev)
-            acts.append(out_l)
+            acts.append(out_l if out_l is not None else S.new_empty(0))
         # the narrow last layer inside the same launch (the tile is still in the waves' registers): dss2_gemm_prop_chain_head
         head_fused = (FL.CHAIN_HEAD_FWD and use16 and n_chain == L - 1 and n_chain <= FL.CHAIN_MAX and not glob and is_narrow(nmat, mod.dim_out)
                       and chain_head_supported(topo, nmat, hid, mod.dim_out, False))
@@ -646,8 +659,8 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
                              drop=((snap, p, drop_id(l)) if snap is not None else None), b_format=int(g16))
         if not last:
             acts.append(h)
-    meta = (ldx, ldea, len(acts), (snap, p, base), fold is not None, glob, ver, act_bits)
-    return h, [x, ea, S] + acts, meta
+    meta = (ldx, ldea, len(acts), (snap, p, base), fold is not None, glob, ver, act_bits, len(xps))
+    return h, [x, ea, S] + acts + xps, meta
 
 
 def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=None):
@@ -655,9 +668,10 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
     reductions and the fold's chain rule, calls the all-reduce hook.  Inside a stack: ``flat`` is the block's slice of the
     stack's buffer and every slab reduction is only recorded in ``pending``; the caller runs them (and the chain rule of
     all folds) in one launch each after the last block.  Returns (dx, parameter gradients as views into flat, fold_late)."""
-    ldx, ldea, n_acts, (snap, p_drop, base), folded, glob, ver, act_bits = meta
+    ldx, ldea, n_acts, (snap, p_drop, base), folded, glob, ver, act_bits, n_xp = meta
     x, ea, S = saved[0:3]
     acts = list(saved[3:3 + n_acts])
+    xps = list(saved[3 + n_acts:3 + n_acts + n_xp])      # X plane images of S, h_1 .. h_{L-2} (or none)
     in_stack = flat is not None
 
     def drop_of(l):            # the mask that was applied to conv l's output: (snapshot, p, id) or None
@@ -711,7 +725,8 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         layers = []
         for l in range(L - 2, -1, -1):
             out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
-            layers.append(dict(Bp=(plan.bwd16[1 + l] if use16 else plan.bwd[1 + l]), Y=out_l, relu_src=(acts[l] if l > 0 else None),
+            # (an inner activation whose fp32 copy was never written -- X planes, XP_DROP_FP32 -- is a placeholder: its gate is the bit words)
+            layers.append(dict(Bp=(plan.bwd16[1 + l] if use16 else plan.bwd[1 + l]), Y=out_l, relu_src=(acts[l] if (l > 0 and acts[l].numel()) else None),
                                gate_bits=(act_bits.get(l) if (l > 0 and use16) else None),
                                drop_id=(base + l if (l > 0 and snap is not None) else 0)))      # mask of conv l-1: id (l-1)+1
             if l > 0:
@@ -724,7 +739,15 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         # joined launch is 141 us against 93 + 57, and -- what matters more -- the step writes and re-reads half the slabs
         # (255 x 197 KB instead of 128 x 2 + 256): reduction 24.7 -> 17.8 us, C2 step 0.537 -> 0.509 ms on one box.
         join = True if FL.WGRAD_JOIN_FOLDED is None else bool(FL.WGRAD_JOIN_FOLDED)
-        if fold is not None and L - 1 <= 8 and join:
+        if xps and not (fold is not None and L - 1 <= 8 and join and use16 and len(xps) == L - 1):
+            raise RuntimeError("the forward wrote X plane images for a backward route that is not taken (flags changed in between?)")
+        if xps:
+            # ... with the layers' inputs as the X plane images their producers wrote (csrc/dss2_wgrad16p.hip)
+            wgrad_batched_xp(topo, gl, hid, xps, hid, nmat, flat[offs[3]:offs[2 + L - 1]],
+                             first_rowscale2=topo.deg_pows, first_out=fold.gfold, pending=pending)
+            fold_late = True
+            dS, g = d_in, None
+        elif fold is not None and L - 1 <= 8 and join:
             # the folded conv 0 (input S, extra scaled bias sums) and the plain layers 1 .. L-2 in ONE launch
             wgrad_batched(topo, gl, hid, [S] + acts[1:L - 1], hid, nmat, flat[offs[3]:offs[2 + L - 1]],
                           first_rowscale2=topo.deg_pows, first_out=fold.gfold, pending=pending)

@@ -1,6 +1,6 @@
 """GPU: the narrow head TAGConv fused into the chained launches (dss2_gemm_prop_chain_head, csrc/dss2_gemm_chain_sp.hip;
 /root/reference/networks.py:266-275: the last TAGConv(dim_hid, dim_out) of MPN / SkipMPN) against the same model with the head as
-launches of its own -- forward fusion (DSS2_CHAIN_HEAD_FWD, off by default), backward fusion (DSS2_CHAIN_HEAD, on by default) --
+launches of its own -- forward fusion (DSS2_CHAIN_HEAD_FWD), backward fusion (DSS2_CHAIN_HEAD), both on by default since round 5 --
 and against the fp64 oracle."""
 import pytest
 import torch
