@@ -207,6 +207,7 @@ _SIGNATURES = {
     "dss2_xplanes_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "dss2_wgrad_xp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad_xp_y_slices": (C.c_int, [C.c_int, C.c_int]),
+    "dss2_wgrad_xp_per_cu": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad_batched_xp": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
                                         C.c_void_p]),
     "dss2_reduce_slabs_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

@@ -414,6 +414,10 @@ extern "C" int dss2_wgrad_xp_supported(int nrb, int nmat, int hout, int hin, int
   return on && dss2::wgrad16p_covers(nrb, nmat, hout, hin, ell_width) ? 1 : 0;
 }
 
+extern "C" int dss2_wgrad_xp_per_cu(int nrb, int nmat, int hout, int hin, int ell_width) {
+  return dss2::wgrad16q_covers(nrb, nmat, hout, hin, ell_width) ? 1 : 2;      // the pipelined kernel takes the CU's whole LDS
+}
+
 extern "C" int dss2_wgrad_xp_y_slices(int hout, int hin) {
   return ((hout + dss2::W16P_ZC - 1) / dss2::W16P_ZC) * ((hin + dss2::W16P_XW - 1) / dss2::W16P_XW);
 }
@@ -449,5 +453,6 @@ extern "C" int dss2_wgrad_batched_xp(const dss2_wgrad_args* ap, const float* con
     }
     if (slab_len < need + (wp.rowscale2[l] ? (long long)a.nmat * a.hout : 0)) { set_error("wgrad_batched_xp: slab_len too small"); return 2; }
   }
+  if (wgrad16q_covers(a.nrb, a.nmat, a.hout, a.hin, a.ell_width)) return launch_wgrad16q(a, wp, n_wg, as_stream(stream));
   return launch_wgrad16p(a, wp, n_wg, as_stream(stream));
 }

@@ -1,0 +1,513 @@
+// Weight gradient of the H -> H TAGConv layers from X plane images, SOFTWARE-PIPELINED (round 5):  dW_m = (P^m G)^T X, bf16x6.
+//
+// Same contract, images, slab layout and (layer, tile) ranges as wgrad16p_kernel (dss2_wgrad16p.hip).  What changes is who hides
+// whose latency.  On this hardware a wave that issues vector work beside ANOTHER wave's dense MFMA stream is starved
+// (tools/micro/work_beside_mfma.hip: a dependent fma chain 9x slower, the MFMA stream not at all), so the phase-structured kernels
+// -- hops and splits between barriers, then MFMAs, two workgroups per CU to "overlap" them -- pay matrix-pipe time PLUS vector time
+// (wgrad16b 126 us, wgrad16p 147 us against 52 us of MFMAs).  A wave's OWN vector instructions placed between its MFMAs do issue
+// (tools/micro/fillers_two_waves.hip: two waves per SIMD, six fillers per MFMA: pipe 88 % busy).  So here every wave carries both
+// streams, interleaved in program order: while it multiplies chunk c, it builds the planes of chunk c + 1 (or stages / propagates the
+// next tile).  Everything is double-buffered, which takes the whole CU's LDS -- one workgroup of eight waves per CU:
+//     fp32 G of the tile            2 x 64 x 64 x 4       32 KB      (hop input, Z_0 source, bias sums)
+//     fp32 P G of the tile          2 x 64 x 64 x 4       32 KB      (second hop's input, Z_1 source)
+//     planes of G, P G, P^2 G       2 x 3 x 3 x 64 x 64 B 72 KB      (one chunk of 32 positions per buffer)
+//     ELL slice, row scales         2 x (2..4 + 1) KB      6-10 KB
+// Wave w multiplies input block w & 3 with output block w >> 2 of every matrix (48 accumulator registers); a chunk is 36 MFMAs per
+// wave.  Slots of a tile t (each ends with one workgroup barrier):
+//     A :  MFMA (t, chunk 0), all matrices        ||  planes of (t, chunk 1); bias sums of t; request X of (t, 1), touch X of t + 1
+//     B0:  MFMA (t, chunk 1), matrix 0            ||  stage G / ELL / row scales of tile t + 1 from registers; request X of (t + 1, 0)
+//     B1:  MFMA (t, chunk 1), matrix 1            ||  first hop of tile t + 1; request G / ELL of tile t + 2
+//     B2:  MFMA (t, chunk 1), matrix 2            ||  planes of (t + 1, chunk 0)
+// Plane building is split by wave role: waves 0-3 split the chunk's G and P G rows, waves 4-7 gather and split P^2 G (as
+// wgrad16t_kernel).  The last tile of a range "stages" itself again instead of branching (every slot is one basic block).
+// Covered: 64-row tiles, hout % 64 == 0, hin % 128 == 0, K <= 2, ELL slices <= 8 wide; everything else: wgrad16p_kernel.
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+
+#include "dss2_wgrad_batch.hpp"
+
+namespace dss2 {
+
+template <int I> using IC = std::integral_constant<int, I>;
+template <class F, int... I>
+__device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
+#define W16Q_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+#ifdef DSS2_STAMPS
+__device__ unsigned long long g_qstamps[256 * 8 * 16];
+#define QSTAMP(slot)                                                                                   \
+  do {                                                                                                 \
+    if (stamp_on) {                                                                                    \
+      unsigned long long t_;                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+      __builtin_amdgcn_sched_barrier(0);                                                               \
+      if (lane == 0 && blockIdx.x < 128) g_qstamps[((blockIdx.x * 2 + (blockIdx.y & 1)) * 8 + wv) * 16 + (slot)] = t_; \
+    }                                                                                                  \
+  } while (0)
+#else
+#define QSTAMP(slot) do {} while (0)
+#endif
+
+#ifndef W16Q_TOUCH
+#define W16Q_TOUCH 0      // (an L2 touch of the tile after next, through a consumed register: measured 139 us against 128 without)
+#endif
+#ifndef W16Q_B1
+#define W16Q_B1 14      // MFMAs of chunk 1 that run beside the first hop (slot B1); the rest beside the planes of the next chunk 0 (slot B2)
+#endif
+constexpr int W16Q_TR = 64, W16Q_ZC = 64, W16Q_XW = 128, W16Q_NT = 512, W16Q_LDZF = 64;
+constexpr int W16Q_ZTB = 3 * 3 * W16Q_ZC * 64;      // bytes of one plane buffer (three matrices)
+
+__device__ __forceinline__ int tpq_key(int col) { return (((col >> 3) & 1) << 1) | ((col >> 4) & 1); }
+__device__ __forceinline__ int tpq_off(int col, int pos) { return col * 64 + ((((pos >> 3) ^ tpq_key(col)) << 4) | ((pos & 7) << 1)); }
+
+__device__ __forceinline__ void store_planes_q(char* img, int off0, const f32x4 v0, const f32x4 v1) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t h, m, l;
+    split3_pair(v0[q], v1[q], h, m, l);
+    char* dst = img + off0 + q * 64;
+    *reinterpret_cast<uint32_t*>(dst) = h;
+    *reinterpret_cast<uint32_t*>(dst + W16Q_ZC * 64) = m;
+    *reinterpret_cast<uint32_t*>(dst + 2 * W16Q_ZC * 64) = l;
+  }
+}
+
+// DP: ELL entries per row as staged (4 or 8: the slice padded with {own row, 0})
+template <int NMAT, bool RS2, int DP>
+__global__ void __launch_bounds__(W16Q_NT, 1) wgrad16q_kernel(const dss2_wgrad_args p, int nibg, const WgradPlanes wp) {
+  constexpr int TR = W16Q_TR, ZC = W16Q_ZC, XW = W16Q_XW, NT = W16Q_NT, LDZF = W16Q_LDZF, ZTB = W16Q_ZTB;
+  static_assert(NMAT == 3, "the slots are written for K = 2");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const Zf0 = smem;                                              // [2][TR][LDZF]
+  float* const Zf1 = Zf0 + 2 * TR * LDZF;                               // [2][TR][LDZF]
+  char* const ZT = reinterpret_cast<char*>(Zf1 + 2 * TR * LDZF);        // [2][NMAT][3][ZC][64 B]
+  constexpr int ELLN = DP * TR > NT ? DP * TR : NT;                     // entries per ELL buffer (every thread writes one: no branch)
+  static_assert(DP * TR <= NT, "one ELL entry per thread");
+  int2* const ell = reinterpret_cast<int2*>(ZT + 2 * ZTB);              // [2][ELLN]
+  f32x4* const rsl = reinterpret_cast<f32x4*>(ell + 2 * ELLN);          // [2][TR]
+  const int D = p.ell_width;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, c32 = lane & 31, half = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ibw = wv & 3, obw = wv >> 2, role = wv >> 2;
+  const int ysl = blockIdx.y;
+  const int obg = ysl / nibg, ibg = ysl - obg * nibg;
+  const int gcol0 = obg * ZC, xcol0 = ibg * XW;
+  const int wg = blockIdx.x;
+
+  // whole-tile units (staging, first hop): rows r32, r32 + 32 of four columns 4 q16
+  const int q16 = tid & 15, r32 = tid >> 4;
+  // chunk units (planes): unit u = tid & 255: positions (2 pp, 2 pp + 1) of four columns 4 q16 = tile rows rA, rA + 8
+  const int u8 = tid & 255;
+  const int pp = (u8 >> 4) ^ ((u8 & 1) << 1);
+  const int z_off = tpq_off(4 * q16, 2 * pp);
+  const int rA0 = (pp >> 2) + 16 * (pp & 3);
+  // MFMA operand addresses
+  const int zc = obw * 32 + c32;
+  const int zfrag0 = zc * 64 + (((0 + half) ^ tpq_key(zc)) << 4), zfrag1 = zc * 64 + (((2 + half) ^ tpq_key(zc)) << 4);
+
+  const long long total = (long long)wp.n_layers * p.ntiles;
+  const long long it0 = (long long)wg * wp.ipw, it1 = (it0 + wp.ipw < total) ? it0 + wp.ipw : total;
+  if (it0 >= it1) return;
+
+  // ---- prefetch state
+  f32x4 pg[2], prs = {0.f, 0.f, 0.f, 0.f};
+  int2 pel = make_int2(0, 0);
+  bf16x8 xfA[2][3], xfB[2][3];      // X fragments of chunk 0 / chunk 1: [k-step of the chunk][piece]
+  [[maybe_unused]] uint32_t tch = 0u, tsink = 0u;
+
+  // (layer, tile) of the current item and of the two after it, advanced with scalar adds (a 64-bit division per address -- four per
+  // tile -- was a 100-instruction scalar chain in front of every request)
+  struct It { int L, tile; };
+  auto it_next = [&](It a, long long idx_of_a) {      // the item after a (idx_of_a: a's index in the list); beyond the range: a itself
+    It n = a;
+    if (idx_of_a + 1 < it1) { n.tile = a.tile + 1; if (n.tile == p.ntiles) { n.tile = 0; n.L = a.L + 1; } }
+    return n;
+  };
+  auto load_g = [&](It it) {      // G rows, ELL entry, row scales of a tile -> registers
+    const int L = it.L, tile = it.tile;
+    const int ts = p.tile_start[tile];
+    const int R = p.tile_start[tile + 1] - ts;
+    const char* gb = reinterpret_cast<const char*>(wp.G[L] + (size_t)ts * p.ldg + gcol0 + 4 * q16);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = r32 + 32 * j;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(gb + (uint32_t)((r < R ? r : 0) * p.ldg) * 4u);      // (clamped, then zeroed: no branch)
+      pg[j] = r < R ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TR;
+    const int2 e = src[tid < D * TR ? tid : 0];
+    pel = tid < D * TR ? e : make_int2(tid & (TR - 1), 0);      // (padding entries: own row, zero weight)
+    if constexpr (RS2) {
+      const float* rs2n = wp.rowscale2[L];
+      const int rr = lane < R ? lane : 0;
+      const f32x4 d = *reinterpret_cast<const f32x4*>((rs2n ? rs2n : wp.G[L]) + (size_t)(ts + rr) * 4);      // (a plain layer reads G instead and keeps zeros)
+      prs = (rs2n && lane < R) ? d : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto load_xk = [&](bf16x8 (&xf)[3], It it, int c, int ksl) {      // one k-step's three pieces of chunk c
+    const char* q = reinterpret_cast<const char*>(wp.XP[it.L]) + ((size_t)it.tile * wp.ncb + (size_t)(ibg * 4 + ibw)) * 12288 + (size_t)(2 * c + ksl) * 3072 + lane * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) xf[pl] = *reinterpret_cast<const bf16x8*>(q + pl * 1024);
+  };
+  [[maybe_unused]] auto load_x = [&](bf16x8 (&xf)[2][3], It it, int c) { load_xk(xf[0], it, c, 0); load_xk(xf[1], it, c, 1); };
+  // L2 touch of a tile's X plane lines (48 KB = 384 lines for this workgroup's 128 input columns), one tile ahead; the register is
+  // consumed when the slot is used again (see wgrad16p_kernel)
+  auto touch = [&](It it) {
+    const char* q = reinterpret_cast<const char*>(wp.XP[it.L]) + ((size_t)it.tile * wp.ncb + (size_t)ibg * 4) * 12288 + (size_t)(tid < 384 ? tid : 0) * 128;
+    tsink += tch;
+    tch = *reinterpret_cast<const volatile uint32_t*>(q);
+  };
+  auto hop_row = [&](const float* Zs, const int2* el, int row, int c4) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k0 = 0; k0 < DP; k0 += 4) {
+      int2 en[4];
+      f32x4 z[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) en[k] = el[(k0 + k) * TR + row];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) z[k] = *reinterpret_cast<const f32x4*>(Zs + en[k].x * LDZF + c4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float w = __int_as_float(en[k].y);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = fmaf(w, z[k][q], a[q]);
+      }
+    }
+    return a;
+  };
+  // ---- the pieces of a tile's vector work
+  auto stage = [&](int b) {      // registers -> fp32 G image, ELL slice, row scales of buffer b
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(Zf0 + b * TR * LDZF + (r32 + 32 * j) * LDZF + 4 * q16) = pg[j];
+    ell[b * ELLN + tid] = pel;                                   // (entries beyond DP * TR: never read)
+    if constexpr (RS2) rsl[b * TR + lane] = prs;                 // (every wave holds the same 64 rows: identical writes)
+  };
+  auto hop1 = [&](int b) {
+    const float* zs = Zf0 + b * TR * LDZF;
+    const int2* el = ell + b * ELLN;
+    const f32x4 a0 = hop_row(zs, el, r32, 4 * q16), a1 = hop_row(zs, el, r32 + 32, 4 * q16);
+    *reinterpret_cast<f32x4*>(Zf1 + b * TR * LDZF + r32 * LDZF + 4 * q16) = a0;
+    *reinterpret_cast<f32x4*>(Zf1 + b * TR * LDZF + (r32 + 32) * LDZF + 4 * q16) = a1;
+  };
+  auto build = [&](auto RC, int b, int c, int zb) {      // planes of chunk c of the tile in buffer b -> plane buffer zb (RC: the wave's role)
+    char* zt = ZT + zb * ZTB;
+    const int rA = 4 * c + rA0;
+    if constexpr (decltype(RC)::value == 0) {
+      const float* s0 = Zf0 + b * TR * LDZF + rA * LDZF + 4 * q16;
+      const float* s1 = Zf1 + b * TR * LDZF + rA * LDZF + 4 * q16;
+      store_planes_q(zt, z_off, *reinterpret_cast<const f32x4*>(s0), *reinterpret_cast<const f32x4*>(s0 + 8 * LDZF));
+      store_planes_q(zt + 3 * ZC * 64, z_off, *reinterpret_cast<const f32x4*>(s1), *reinterpret_cast<const f32x4*>(s1 + 8 * LDZF));
+    } else {
+      const float* zs = Zf1 + b * TR * LDZF;
+      const int2* el = ell + b * ELLN;
+      const f32x4 u0 = hop_row(zs, el, rA, 4 * q16), u1 = hop_row(zs, el, rA + 8, 4 * q16);
+      store_planes_q(zt + 2 * 3 * ZC * 64, z_off, u0, u1);
+    }
+  };
+  f32x16 acc[NMAT];
+  // Column sums of G: db, and (RS2 kernels) the folded layer's three scaled sums.  RS2: ONE accumulator per thread -- thread (q16,
+  // r32) sums, for its four columns, the eight rows 4 (r32 >> 2) + {0..3} (+ 32) weighted with column r32 & 3 of the row scales
+  // (r32 & 3 == 3: weight 1, the plain sum) -- three accumulators per thread for its own two rows cost 16 more live registers,
+  // which this kernel does not have (33 spilled into the interleaved stream: 195 us instead of 130).
+  f32x4 bsum;
+  // ---- the same work as micro-pieces of 4-8 instructions, issued one per MFMA gap in PROGRAM order between scheduling fences (the
+  // machine scheduler's own interleave -- sched_group_barrier -- is reverted at this register pressure: the fallback is source order)
+  bf16x8 zr[2][3];      // Z fragments of the current / next (matrix, k-step) step
+  auto zload = [&](int zb, int s_, bf16x8 (&z)[3]) {      // step s_ = 3 k-step + m of the chunk (k-step major: a k-step's X fragments die after its three matrices)
+    const char* zi = ZT + zb * ZTB + (s_ % 3) * 3 * ZC * 64 + ((s_ >= 3) ? zfrag1 : zfrag0);
+    z[0] = *reinterpret_cast<const bf16x8*>(zi);
+    z[1] = *reinterpret_cast<const bf16x8*>(zi + ZC * 64);
+    z[2] = *reinterpret_cast<const bf16x8*>(zi + 2 * ZC * 64);
+  };
+  // MFMA k (0..35) of the chunk in plane buffer zb: step k / 6 = 3 k-step + matrix, product k % 6 (smallest terms first); the next
+  // step's fragments are requested behind product 2
+  auto mfma_k = [&](auto KC, int zb, const bf16x8 (&xf)[2][3]) {
+    constexpr int k = decltype(KC)::value, st = k / 6, m = st % 3, ksl = st / 3, j = k % 6;
+    constexpr int za = (j == 0 || j == 3) ? 2 : ((j == 1 || j == 4 - 1 + 0) ? 1 : 0);      // al, am, ah, am, ah, ah
+    constexpr int zsel = j == 0 ? 2 : (j == 1 ? 1 : (j == 2 ? 0 : (j == 3 ? 1 : 0)));
+    constexpr int xsel = j == 0 ? 0 : (j == 1 ? 1 : (j == 2 ? 2 : (j == 3 ? 0 : (j == 4 ? 1 : 0))));
+    (void)za;
+    if constexpr (j == 2 && st < 5) zload(zb, st + 1, zr[(st + 1) & 1]);
+    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zr[st & 1][zsel], xf[ksl][xsel], acc[m], 0, 0, 0);
+  };
+  // split of one column pair in three pieces: h + residuals | m, l | the three stores
+  uint32_t sh = 0, sm = 0, sl = 0;
+  float sra = 0.f, srb = 0.f;
+  auto split_piece = [&](int part, float va, float vb, char* dst) {
+    if (part == 0) {
+      sh = cvt_pk_bf16(va, vb);
+      sra = va - __uint_as_float(sh << 16); srb = vb - __uint_as_float(sh & 0xffff0000u);
+    } else if (part == 1) {
+      sm = cvt_pk_bf16(sra, srb);
+      sl = cvt_pk_bf16(sra - __uint_as_float(sm << 16), srb - __uint_as_float(sm & 0xffff0000u));
+    } else {
+      *reinterpret_cast<uint32_t*>(dst) = sh;
+      *reinterpret_cast<uint32_t*>(dst + ZC * 64) = sm;
+      *reinterpret_cast<uint32_t*>(dst + 2 * ZC * 64) = sl;
+    }
+  };
+  // gather state of a two-row hop (first hop: rows r32, r32 + 32 of Zf0; P^2 G: rows rA, rA + 8 of Zf1)
+  int2 enA[4], enB[4];
+  f32x4 zg[4], aA, aB, s0a, s0b, s1a, s1b;      // (one set of gathered rows: row A's are consumed before row B's are requested)
+  constexpr int NH = DP / 4;                  // rounds of four ELL entries
+  constexpr int HOP_OPS = 10 * NH;            // pieces of a two-row hop
+  auto hop_piece = [&](auto KC, const float* zs, const int2* el, int rowA, int rowB) {
+    constexpr int k = decltype(KC)::value, rnd = k / 10, o = k % 10;
+    if constexpr (k == 0) { aA = f32x4{0.f, 0.f, 0.f, 0.f}; aB = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if constexpr (o == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) enA[e] = el[(4 * rnd + e) * TR + rowA];
+    } else if constexpr (o == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) enB[e] = el[(4 * rnd + e) * TR + rowB];
+    } else if constexpr (o == 2 || o == 3 || o == 6 || o == 7) {      // gathers: row A in pieces 2, 3, row B in 6, 7
+      constexpr int e0 = 2 * (o & 1);
+      const int2* en = o < 4 ? enA : enB;
+      zg[e0] = *reinterpret_cast<const f32x4*>(zs + en[e0].x * LDZF + 4 * q16);
+      zg[e0 + 1] = *reinterpret_cast<const f32x4*>(zs + en[e0 + 1].x * LDZF + 4 * q16);
+    } else {                                                           // fma: row A in pieces 4, 5, row B in 8, 9
+      constexpr int e0 = 2 * (o & 1);
+#pragma unroll
+      for (int e = e0; e < e0 + 2; ++e)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if constexpr (o < 6) aA[q] = fmaf(__int_as_float(enA[e].y), zg[e][q], aA[q]);
+          else aB[q] = fmaf(__int_as_float(enB[e].y), zg[e][q], aB[q]);
+        }
+    }
+  };
+  // pieces of a chunk's planes (role 0: G and P G rows -> matrices 0, 1; role 1: P^2 G rows -> matrix 2)
+  constexpr int BUILD_OPS0 = 2 + 24, BUILD_OPS1 = HOP_OPS + 12;
+  constexpr int H0 = BUILD_OPS0 / 2 - 2, H1 = BUILD_OPS1 / 2 - 2;      // build pieces in the first half of slot A (behind the bias sums and the staging)
+  auto build_piece = [&](auto RC, auto KC, int b_, int c_, int zb) {
+    constexpr int k = decltype(KC)::value;
+    char* zt = ZT + zb * ZTB;
+    const int rA = 4 * c_ + rA0;
+    if constexpr (decltype(RC)::value == 0) {
+      if constexpr (k == 0) {
+        const float* q0 = Zf0 + b_ * TR * LDZF + rA * LDZF + 4 * q16;
+        s0a = *reinterpret_cast<const f32x4*>(q0); s0b = *reinterpret_cast<const f32x4*>(q0 + 8 * LDZF);
+      } else if constexpr (k == 1) {
+        const float* q1 = Zf1 + b_ * TR * LDZF + rA * LDZF + 4 * q16;
+        s1a = *reinterpret_cast<const f32x4*>(q1); s1b = *reinterpret_cast<const f32x4*>(q1 + 8 * LDZF);
+      } else if constexpr (k < BUILD_OPS0) {
+        constexpr int mz = (k - 2) / 12, q = ((k - 2) / 3) & 3, part = (k - 2) % 3;
+        split_piece(part, mz ? s1a[q] : s0a[q], mz ? s1b[q] : s0b[q], zt + mz * 3 * ZC * 64 + z_off + q * 64);
+      }
+    } else {
+      if constexpr (k < HOP_OPS) hop_piece(KC, Zf1 + b_ * TR * LDZF, ell + b_ * ELLN, rA, rA + 8);
+      else if constexpr (k < BUILD_OPS1) {
+        constexpr int q = ((k - HOP_OPS) / 3) & 3, part = (k - HOP_OPS) % 3;
+        split_piece(part, aA[q], aB[q], zt + 2 * 3 * ZC * 64 + z_off + q * 64);
+      }
+    }
+  };
+  // bias sums of the current tile (slot A): the thread's own staging rows read back from the fp32 image
+  constexpr int BS_OPS = RS2 ? 9 : 2;
+  f32x4 ga, gb;
+  float wa = 0.f, wb = 0.f;
+  const int bm = r32 & 3, bg = 4 * (r32 >> 2);
+  auto bsum_piece = [&](auto KC, int b_) {
+    constexpr int k = decltype(KC)::value;
+    if constexpr (!RS2) {
+      if constexpr (k == 0) {
+        const float* g0 = Zf0 + b_ * TR * LDZF + r32 * LDZF + 4 * q16;
+        ga = *reinterpret_cast<const f32x4*>(g0); gb = *reinterpret_cast<const f32x4*>(g0 + 32 * LDZF);
+      } else {
+        bsum += ga + gb;
+      }
+    } else {
+      // piece k: request rows of pair k (rows bg + (k & 3) + 32 (k >> 2), two pieces ahead of their use), accumulate pair k - 1
+      auto req = [&](int j, f32x4& g, float& w) {
+        const int row = bg + (j & 3) + 32 * (j >> 2);
+        g = *reinterpret_cast<const f32x4*>(Zf0 + b_ * TR * LDZF + row * LDZF + 4 * q16);
+        w = reinterpret_cast<const float*>(rsl + b_ * TR + row)[bm];
+      };
+      if constexpr (k >= 1) {
+        if constexpr ((k - 1) & 1) bsum += gb * (bm == 3 ? 1.0f : wb); else bsum += ga * (bm == 3 ? 1.0f : wa);
+      }
+      if constexpr (k < 8) { if constexpr (k & 1) req(k, gb, wb); else req(k, ga, wa); }
+    }
+  };
+  // one interleaved run: MFMAs K0 .. K0 + NM - 1 of the chunk in plane buffer zb, pieces 0 .. NP - 1 spread over the gaps
+#define W16Q_RUN(K0, NM, NP, ZB, XF, PIECE)                                                             \
+  for_seq([&](auto GC) {                                                                                \
+    constexpr int g = decltype(GC)::value;                                                              \
+    mfma_k(IC<(K0) + g>{}, (ZB), (XF));                                                                 \
+    W16Q_FENCE();                                                                                       \
+    for_seq([&](auto JC) {                                                                              \
+      constexpr int pk = (g * (NP)) / (NM) + decltype(JC)::value;                                       \
+      auto KC = IC<pk>{};                                                                               \
+      PIECE;                                                                                            \
+    }, std::make_integer_sequence<int, ((g + 1) * (NP)) / (NM) - (g * (NP)) / (NM)>{});                \
+    W16Q_FENCE();                                                                                       \
+  }, std::make_integer_sequence<int, (NM)>{})
+
+  // ---- prologue: the range's first tile staged, propagated, its chunk 0 built
+  long long item = it0;
+  It it0c, it1c, it2;      // the current item, the next, the one after
+  it0c.L = (int)(it0 / p.ntiles); it0c.tile = (int)(it0 - (long long)it0c.L * p.ntiles);
+  it1c = it_next(it0c, it0);
+  it2 = it_next(it1c, it0 + 1);
+  load_g(it0c);
+  load_x(xfA, it0c, 0);
+  stage(0);
+  __syncthreads();
+  load_g(it1c);
+  hop1(0);
+  __syncthreads();
+  if (role == 0) build(std::integral_constant<int, 0>{}, 0, 0, 0); else build(std::integral_constant<int, 1>{}, 0, 0, 0);
+  touch(it1c);
+  __syncthreads();
+
+  int b = 0;      // buffer of the current tile
+  while (item < it1) {
+    const int L = (int)(item / p.ntiles);
+    const long long seg_end = ((long long)(L + 1) * p.ntiles < it1) ? (long long)(L + 1) * p.ntiles : it1;
+    [[maybe_unused]] const float* rs2 = RS2 ? wp.rowscale2[L] : nullptr;
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (; item < seg_end; ++item, b ^= 1, it0c = it1c, it1c = it2, it2 = it_next(it2, item + 1)) {
+      [[maybe_unused]] const bool stamp_on = item == it0 + 2;
+      QSTAMP(0);
+      // ---- slot A: chunk 0 of the tile (MFMAs 0..35) || planes of its chunk 1, its bias sums, the next tile's rows -> LDS
+      // X: k-step 0 of chunk 1 is requested when k-step 0 of chunk 0 has been multiplied (the same registers)
+#if W16Q_TOUCH
+      touch(it2);
+#endif
+      zload(0, 0, zr[0]);
+      W16Q_FENCE();
+      if (role == 0) {
+        W16Q_RUN(0, 18, BS_OPS + 1 + H0, 0, xfA,
+                 if constexpr (pk < BS_OPS) bsum_piece(KC, b); else if constexpr (pk == BS_OPS) stage(b ^ 1); else build_piece(IC<0>{}, IC<pk - BS_OPS - 1>{}, b, 1, 1));
+        load_xk(xfB[0], it0c, 1, 0);
+        W16Q_FENCE();
+        W16Q_RUN(18, 18, BUILD_OPS0 - H0, 0, xfA, build_piece(IC<0>{}, IC<pk + H0>{}, b, 1, 1));
+      } else {
+        W16Q_RUN(0, 18, BS_OPS + 1 + H1, 0, xfA,
+                 if constexpr (pk < BS_OPS) bsum_piece(KC, b); else if constexpr (pk == BS_OPS) stage(b ^ 1); else build_piece(IC<1>{}, IC<pk - BS_OPS - 1>{}, b, 1, 1));
+        load_xk(xfB[0], it0c, 1, 0);
+        W16Q_FENCE();
+        W16Q_RUN(18, 18, BUILD_OPS1 - H1, 0, xfA, build_piece(IC<1>{}, IC<pk + H1>{}, b, 1, 1));
+      }
+      QSTAMP(1);
+      __syncthreads();
+      QSTAMP(2);
+      // ---- slot B1: chunk 1, MFMAs 0..W16Q_B1-1 || first hop of the next tile; its X (chunk 0, k-step 0), the tile after it requested
+      load_xk(xfB[1], it0c, 1, 1);
+      load_xk(xfA[0], it1c, 0, 0);
+      load_g(it2);
+      zload(1, 0, zr[0]);
+      W16Q_FENCE();
+      W16Q_RUN(0, W16Q_B1, HOP_OPS, 1, xfB, hop_piece(KC, Zf0 + (b ^ 1) * TR * LDZF, ell + (b ^ 1) * ELLN, r32, r32 + 32));
+      *reinterpret_cast<f32x4*>(Zf1 + (b ^ 1) * TR * LDZF + r32 * LDZF + 4 * q16) = aA;
+      *reinterpret_cast<f32x4*>(Zf1 + (b ^ 1) * TR * LDZF + (r32 + 32) * LDZF + 4 * q16) = aB;
+      QSTAMP(5);
+      __syncthreads();
+      QSTAMP(6);
+      // ---- slot B2: chunk 1, MFMAs W16Q_B1..35 || planes of the next tile's chunk 0; its X (chunk 0, k-step 1) requested behind MFMA 17
+      if (role == 0) {
+        W16Q_RUN(W16Q_B1, 18 - W16Q_B1, (BUILD_OPS0 * (18 - W16Q_B1)) / (36 - W16Q_B1), 1, xfB, build_piece(IC<0>{}, KC, b ^ 1, 0, 0));
+        load_xk(xfA[1], it1c, 0, 1);
+        W16Q_FENCE();
+        W16Q_RUN(18, 18, BUILD_OPS0 - (BUILD_OPS0 * (18 - W16Q_B1)) / (36 - W16Q_B1), 1, xfB,
+                 build_piece(IC<0>{}, IC<pk + (BUILD_OPS0 * (18 - W16Q_B1)) / (36 - W16Q_B1)>{}, b ^ 1, 0, 0));
+      } else {
+        W16Q_RUN(W16Q_B1, 18 - W16Q_B1, (BUILD_OPS1 * (18 - W16Q_B1)) / (36 - W16Q_B1), 1, xfB, build_piece(IC<1>{}, KC, b ^ 1, 0, 0));
+        load_xk(xfA[1], it1c, 0, 1);
+        W16Q_FENCE();
+        W16Q_RUN(18, 18, BUILD_OPS1 - (BUILD_OPS1 * (18 - W16Q_B1)) / (36 - W16Q_B1), 1, xfB,
+                 build_piece(IC<1>{}, IC<pk + (BUILD_OPS1 * (18 - W16Q_B1)) / (36 - W16Q_B1)>{}, b ^ 1, 0, 0));
+      }
+      QSTAMP(7);
+      __syncthreads();
+      QSTAMP(8);
+    }
+
+    // ---- the segment's slab: id = workgroup + layer
+    float* out = wp.slab + (size_t)(wg + L) * (size_t)wp.slab_len;
+    {
+      int cl = c32, hl = half, hin_l = p.hin, hout_l = p.hout;
+      asm volatile("" : "+v"(cl), "+v"(hl), "+s"(hin_l), "+s"(hout_l));      // (addresses formed here, per segment)
+      const int ncol = ((cl & 7) << 2) | (cl >> 3);      // accumulator column n -> input column of the block (the image's lane order)
+      const int o0 = gcol0 + obw * 32 + 4 * hl;
+      const int i = xcol0 + ibw * 32 + ncol;
+      float* ob = out + (size_t)o0 * hin_l + i;
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          ob[((size_t)m * hout_l + dr) * hin_l] = acc[m][r];
+        }
+    }
+    if (ibg == 0) {   // (uniform) column sums: the threads that share a column group meet in LDS (plane buffer 1: idle between the slots), fixed order
+      f32x4* red = reinterpret_cast<f32x4*>(ZT + ZTB);          // [NT] = 8 KB of its 36
+      red[tid] = bsum;
+      __syncthreads();
+      if constexpr (!RS2) {
+        for (int j = tid; j < ZC; j += NT) {
+          float s_ = 0.f;
+          for (int r = 0; r < 32; ++r) s_ += red[r * 16 + (j >> 2)][j & 3];
+          out[(size_t)p.nmat * p.hout * p.hin + gcol0 + j] = s_;
+        }
+      } else {
+        // which = 0: db (threads with r32 & 3 == 3); 1 + m: the scaled sums of matrix m (r32 & 3 == m), written only for the folded layer
+        for (int j = tid; j < (rs2 ? 1 + NMAT : 1) * ZC; j += NT) {
+          const int which = j / ZC, col = j - which * ZC, mm = which == 0 ? 3 : which - 1;
+          float s_ = 0.f;
+          for (int g = 0; g < 8; ++g) s_ += red[(4 * g + mm) * 16 + (col >> 2)][col & 3];
+          out[(size_t)p.nmat * p.hout * p.hin + (which == 0 ? 0 : p.hout + (size_t)(which - 1) * p.hout) + gcol0 + col] = s_;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tsink + tch == 0x9e3779b9u && p.ntiles < 0) wp.slab[0] = 0.f;      // (never true: keeps the touch register's consumption alive)
+#undef W16Q_RUN
+}
+
+size_t wgrad16q_lds_bytes(int nmat, int ell_width) {
+  (void)nmat; (void)ell_width;
+  return 4 * (size_t)W16Q_TR * W16Q_LDZF * 4 + 2 * (size_t)W16Q_ZTB + 2 * (size_t)W16Q_NT * 8 + 2 * (size_t)W16Q_TR * 16;
+}
+
+bool wgrad16q_covers(int nrb, int nmat, int hout, int hin, int ell_width) {
+  static const int on = [] { const char* e = getenv("DSS2_WGRAD_XQ"); return e ? atoi(e) : 1; }();
+  return on && nrb == 2 && nmat == 3 && ell_width >= 1 && ell_width <= 8 && hout >= 64 && (hout & 63) == 0 && hin >= 128 && (hin & 127) == 0 &&
+         wgrad16q_lds_bytes(nmat, ell_width) <= (size_t)kMaxLdsBytes;
+}
+
+template <bool RS2, int DP>
+static int launch16q(const dss2_wgrad_args& a, const WgradPlanes& wp, int n_wg, hipStream_t stream) {
+  static std::atomic<uint32_t> lds_done{0};
+  auto kern = wgrad16q_kernel<3, RS2, DP>;
+  if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "wgrad(bf16x6, X planes, pipelined)")) return 1;
+  const int nobg = a.hout / W16Q_ZC, nibg = a.hin / W16Q_XW;
+  hipLaunchKernelGGL(kern, dim3(n_wg, nobg * nibg), dim3(W16Q_NT), wgrad16q_lds_bytes(a.nmat, a.ell_width), stream, a, nibg, wp);
+  return check_launch("wgrad(bf16x6, X planes, pipelined)");
+}
+
+int launch_wgrad16q(const dss2_wgrad_args& a, const WgradPlanes& wp, int n_wg, hipStream_t stream) {
+  bool rs2 = false;
+  for (int l = 0; l < wp.n_layers; ++l) rs2 = rs2 || wp.rowscale2[l] != nullptr;
+  if (a.ell_width <= 4) return rs2 ? launch16q<true, 4>(a, wp, n_wg, stream) : launch16q<false, 4>(a, wp, n_wg, stream);
+  return rs2 ? launch16q<true, 8>(a, wp, n_wg, stream) : launch16q<false, 8>(a, wp, n_wg, stream);
+}
+
+}  // namespace dss2
+
+#ifdef DSS2_STAMPS
+extern "C" int dss2_debug_read_qstamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dss2::g_qstamps), sizeof(unsigned long long) * n);
+}
+#endif

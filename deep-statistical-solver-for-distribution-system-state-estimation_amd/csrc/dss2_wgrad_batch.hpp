@@ -24,6 +24,9 @@ struct WgradPlanes {
 size_t wgrad16p_lds_bytes(int nmat, int ell_width);
 bool wgrad16p_covers(int nrb, int nmat, int hout, int hin, int ell_width);
 int launch_wgrad16p(const dss2_wgrad_args& a, const WgradPlanes& wp, int n_wg, hipStream_t stream);
+// dss2_wgrad16q.hip: the software-pipelined form (one 8-wave workgroup per CU)
+bool wgrad16q_covers(int nrb, int nmat, int hout, int hin, int ell_width);
+int launch_wgrad16q(const dss2_wgrad_args& a, const WgradPlanes& wp, int n_wg, hipStream_t stream);
 
 // dss2_wgrad16.hip: the bf16x6 kernel.  wgrad16_lds_bytes: dynamic LDS of its launch (0: shape not covered)
 size_t wgrad16_lds_bytes(int nrb, int nmat, int hout, int hin, int ell_width);

@@ -321,11 +321,11 @@ def new_xplanes(topo: Topology, ncols: int, device) -> torch.Tensor:
     return torch.empty(int(_lib.lib().dss2_xplanes_bytes(topo.ntiles, ncols)), dtype=torch.uint8, device=device)
 
 
-def wgrad_xp_plan(ntiles: int, n_layers: int, ys: int):
-    """(n_wg, ipw, [(first slab id, n_slabs) per layer]) of a dss2_wgrad_batched_xp launch: two workgroups per CU, the list of
-    (layer, tile) pairs cut into equal ranges; the slab of (range w, layer l) has id w + l."""
+def wgrad_xp_plan(ntiles: int, n_layers: int, ys: int, per_cu: int = 2):
+    """(n_wg, ipw, [(first slab id, n_slabs) per layer]) of a dss2_wgrad_batched_xp launch: ``per_cu`` workgroups per CU, the list
+    of (layer, tile) pairs cut into equal ranges; the slab of (range w, layer l) has id w + l."""
     total = n_layers * ntiles
-    n_wg = max(1, min(total, (256 * 2) // ys))
+    n_wg = max(1, min(total, (256 * per_cu) // ys))
     ipw = (total + n_wg - 1) // n_wg
     n_wg = (total + ipw - 1) // ipw          # ranges that actually hold pairs
     spans = []
@@ -343,7 +343,7 @@ def wgrad_batched_xp(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xps:
     nl = len(Gs)
     L_ = _lib.lib()
     ys = int(L_.dss2_wgrad_xp_y_slices(hout, hin))
-    n_wg, ipw, spans = wgrad_xp_plan(topo.ntiles, nl, ys)
+    n_wg, ipw, spans = wgrad_xp_plan(topo.ntiles, nl, ys, int(L_.dss2_wgrad_xp_per_cu(topo.nrb, nmat, hout, hin, topo.ellT)))
     stride = nmat * hout * hin + hout
     slab_len = stride + (nmat * hout if first_rowscale2 is not None else 0)
     slab = torch.empty((n_wg + nl - 1) * slab_len, dtype=_F32, device=Gs[0].device)

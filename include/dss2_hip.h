@@ -398,8 +398,10 @@ int dss2_wgrad_batched(const dss2_wgrad_args* args_host, const float* const* Gs,
 size_t dss2_xplanes_bytes(int64_t ntiles, int32_t ncols);
 /* != 0: dss2_wgrad_batched_xp covers the shape (64-row tiles, K <= 2, ELL slices <= 8 wide, hin % 32 == 0, hout % 4 == 0, hout > 32) */
 int dss2_wgrad_xp_supported(int nrb, int nmat, int hout, int hin, int ell_width);
-/* workgroups per range of the (layer, tile) list (grid.y): a caller that wants two workgroups per CU asks for n_wg = 512 / this */
+/* workgroups per range of the (layer, tile) list (grid.y), and how many workgroups of the launch fit a CU (1: the software-pipelined
+ * kernel, which takes the CU's whole LDS; 2 otherwise): a caller that wants the chip filled once asks for n_wg = 256 * per_cu / y_slices */
 int dss2_wgrad_xp_y_slices(int hout, int hin);
+int dss2_wgrad_xp_per_cu(int nrb, int nmat, int hout, int hin, int ell_width);
 /* n_layers (<= 8) layers of identical shape in ONE launch.  Gs[l]: fp32 [N, hout] (leading dimension args->ldg); Xps[l]: the X     *
  * plane image of layer l's input; args->X / ldx / slab / n_split are ignored.  The launch cuts the list of (layer, tile) pairs     *
  * into n_wg equal contiguous ranges of ipw = ceil(n_layers * ntiles / n_wg) pairs; the workgroup of range w writes its partial     *

@@ -12,6 +12,7 @@ ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--grid", default="cigre14")
 ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--only-wgrad", action="store_true")
+ap.add_argument("--no-rs2", action="store_true", help="plain layers only (no folded layer with its scaled bias sums)")
 args = ap.parse_args()
 DEV = "cuda:0"
 nw, ops = pkg.networks, pkg.ops
@@ -65,15 +66,19 @@ stride = nmat * H * H + H
 out = torch.empty(nl * stride, device=DEV); first = torch.empty(stride + nmat * H, device=DEV)
 
 
+KW = {} if args.no_rs2 else dict(first_rowscale2=topo.deg_pows, first_out=first)
+NOUT = nl if args.no_rs2 else nl - 1
+
+
 def w_old():
     pend = []
-    ops.wgrad_batched(topo, Gs, H, Ys, H, nmat, out[:(nl - 1) * stride], first_rowscale2=topo.deg_pows, first_out=first, pending=pend)
+    ops.wgrad_batched(topo, Gs, H, Ys, H, nmat, out[:NOUT * stride], pending=pend, **KW)
     return pend
 
 
 def w_new():
     pend = []
-    ops.wgrad_batched_xp(topo, Gs, H, xps, H, nmat, out[:(nl - 1) * stride], first_rowscale2=topo.deg_pows, first_out=first, pending=pend)
+    ops.wgrad_batched_xp(topo, Gs, H, xps, H, nmat, out[:NOUT * stride], pending=pend, **KW)
     return pend
 
 
