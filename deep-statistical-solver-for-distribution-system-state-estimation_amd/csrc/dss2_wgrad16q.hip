@@ -121,17 +121,26 @@ __global__ void __launch_bounds__(W16Q_NT, 1) wgrad16q_kernel(const dss2_wgrad_a
 
   // (layer, tile) of the current item and of the two after it, advanced with scalar adds (a 64-bit division per address -- four per
   // tile -- was a 100-instruction scalar chain in front of every request)
-  struct It { int L, tile; };
-  auto it_next = [&](It a, long long idx_of_a) {      // the item after a (idx_of_a: a's index in the list); beyond the range: a itself
+  // ... and everything an address of the item needs as SCALARS resolved once per tile (resolve): a request inside an interleaved slot
+  // that starts with s_load tile_start / s_load pointer table waits lgkmcnt(0) -- the LDS queue drained, the loads' latency exposed
+  // (slot B1 spent ~900 of its 2700 cycles in four such dependent scalar loads before its first MFMA)
+  struct It { int L, tile, ts, R; const float* G; const char* XP; const float* RS; };
+  auto resolve = [&](It& a) {
+    a.ts = p.tile_start[a.tile];
+    a.R = p.tile_start[a.tile + 1] - a.ts;
+    a.G = wp.G[a.L];
+    a.XP = reinterpret_cast<const char*>(wp.XP[a.L]);
+    a.RS = RS2 ? wp.rowscale2[a.L] : nullptr;
+  };
+  auto it_next = [&](const It& a, long long idx_of_a) {      // the item after a (idx_of_a: a's index in the list), resolved; beyond the range: a itself
     It n = a;
     if (idx_of_a + 1 < it1) { n.tile = a.tile + 1; if (n.tile == p.ntiles) { n.tile = 0; n.L = a.L + 1; } }
+    resolve(n);
     return n;
   };
-  auto load_g = [&](It it) {      // G rows, ELL entry, row scales of a tile -> registers
-    const int L = it.L, tile = it.tile;
-    const int ts = p.tile_start[tile];
-    const int R = p.tile_start[tile + 1] - ts;
-    const char* gb = reinterpret_cast<const char*>(wp.G[L] + (size_t)ts * p.ldg + gcol0 + 4 * q16);
+  auto load_g = [&](const It& it) {      // G rows, ELL entry, row scales of a tile -> registers
+    const int tile = it.tile, ts = it.ts, R = it.R;
+    const char* gb = reinterpret_cast<const char*>(it.G + (size_t)ts * p.ldg + gcol0 + 4 * q16);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = r32 + 32 * j;
@@ -142,22 +151,22 @@ __global__ void __launch_bounds__(W16Q_NT, 1) wgrad16q_kernel(const dss2_wgrad_a
     const int2 e = src[tid < D * TR ? tid : 0];
     pel = tid < D * TR ? e : make_int2(tid & (TR - 1), 0);      // (padding entries: own row, zero weight)
     if constexpr (RS2) {
-      const float* rs2n = wp.rowscale2[L];
+      const float* rs2n = it.RS;
       const int rr = lane < R ? lane : 0;
-      const f32x4 d = *reinterpret_cast<const f32x4*>((rs2n ? rs2n : wp.G[L]) + (size_t)(ts + rr) * 4);      // (a plain layer reads G instead and keeps zeros)
+      const f32x4 d = *reinterpret_cast<const f32x4*>((rs2n ? rs2n : it.G) + (size_t)(ts + rr) * 4);      // (a plain layer reads G instead and keeps zeros)
       prs = (rs2n && lane < R) ? d : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto load_xk = [&](bf16x8 (&xf)[3], It it, int c, int ksl) {      // one k-step's three pieces of chunk c
-    const char* q = reinterpret_cast<const char*>(wp.XP[it.L]) + ((size_t)it.tile * wp.ncb + (size_t)(ibg * 4 + ibw)) * 12288 + (size_t)(2 * c + ksl) * 3072 + lane * 16;
+  auto load_xk = [&](bf16x8 (&xf)[3], const It& it, int c, int ksl) {      // one k-step's three pieces of chunk c
+    const char* q = it.XP + ((size_t)it.tile * wp.ncb + (size_t)(ibg * 4 + ibw)) * 12288 + (size_t)(2 * c + ksl) * 3072 + lane * 16;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) xf[pl] = *reinterpret_cast<const bf16x8*>(q + pl * 1024);
   };
-  [[maybe_unused]] auto load_x = [&](bf16x8 (&xf)[2][3], It it, int c) { load_xk(xf[0], it, c, 0); load_xk(xf[1], it, c, 1); };
+  [[maybe_unused]] auto load_x = [&](bf16x8 (&xf)[2][3], const It& it, int c) { load_xk(xf[0], it, c, 0); load_xk(xf[1], it, c, 1); };
   // L2 touch of a tile's X plane lines (48 KB = 384 lines for this workgroup's 128 input columns), one tile ahead; the register is
   // consumed when the slot is used again (see wgrad16p_kernel)
-  auto touch = [&](It it) {
-    const char* q = reinterpret_cast<const char*>(wp.XP[it.L]) + ((size_t)it.tile * wp.ncb + (size_t)ibg * 4) * 12288 + (size_t)(tid < 384 ? tid : 0) * 128;
+  [[maybe_unused]] auto touch = [&](const It& it) {
+    const char* q = it.XP + ((size_t)it.tile * wp.ncb + (size_t)ibg * 4) * 12288 + (size_t)(tid < 384 ? tid : 0) * 128;
     tsink += tch;
     tch = *reinterpret_cast<const volatile uint32_t*>(q);
   };
@@ -350,8 +359,9 @@ __global__ void __launch_bounds__(W16Q_NT, 1) wgrad16q_kernel(const dss2_wgrad_a
 
   // ---- prologue: the range's first tile staged, propagated, its chunk 0 built
   long long item = it0;
-  It it0c, it1c, it2;      // the current item, the next, the one after
+  It it0c, it1c, it2, it3;      // the current item, the next, the one after, and (inside a tile) the one after that
   it0c.L = (int)(it0 / p.ntiles); it0c.tile = (int)(it0 - (long long)it0c.L * p.ntiles);
+  resolve(it0c);
   it1c = it_next(it0c, it0);
   it2 = it_next(it1c, it0 + 1);
   load_g(it0c);
@@ -362,7 +372,6 @@ __global__ void __launch_bounds__(W16Q_NT, 1) wgrad16q_kernel(const dss2_wgrad_a
   hop1(0);
   __syncthreads();
   if (role == 0) build(std::integral_constant<int, 0>{}, 0, 0, 0); else build(std::integral_constant<int, 1>{}, 0, 0, 0);
-  touch(it1c);
   __syncthreads();
 
   int b = 0;      // buffer of the current tile
@@ -376,9 +385,10 @@ __global__ void __launch_bounds__(W16Q_NT, 1) wgrad16q_kernel(const dss2_wgrad_a
       for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
     bsum = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (; item < seg_end; ++item, b ^= 1, it0c = it1c, it1c = it2, it2 = it_next(it2, item + 1)) {
+    for (; item < seg_end; ++item, b ^= 1, it0c = it1c, it1c = it2, it2 = it3) {
       [[maybe_unused]] const bool stamp_on = item == it0 + 2;
       QSTAMP(0);
+      it3 = it_next(it2, item + 2);      // (its scalar loads are issued here, behind the barrier; first used a tile later)
       // ---- slot A: chunk 0 of the tile (MFMAs 0..35) || planes of its chunk 1, its bias sums, the next tile's rows -> LDS
       // X: k-step 0 of chunk 1 is requested when k-step 0 of chunk 0 has been multiplied (the same registers)
 #if W16Q_TOUCH
