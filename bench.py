@@ -180,6 +180,15 @@ def time_other_config(pkg, dev, stream, tag, grids, B, cls, cargs, ne, blocks, s
     except Exception as exc:
         rec["ms_per_step_replay"] = None
         rec["replay_error"] = f"{type(exc).__name__}: {exc}"[:200]
+    # ... and as a launch plan (graphs.PlannedStep: the library's own record of the step's launches, re-issued from ONE C call): what an
+    # eager step costs without the Python around every launch -- for steps that cannot be captured into a hipGraph
+    if B <= 4096:
+        try:
+            pl = pkg.graphs.PlannedStep(step, stream=stream)
+            rec["ms_per_step_plan"], rec["plan_launches"] = timed(pl.replay), pl.n_launches
+            del pl
+        except Exception as exc:
+            rec["ms_per_step_plan"], rec["plan_error"] = None, f"{type(exc).__name__}: {exc}"[:200]
     best = min(v for v in (rec["ms_per_step_eager"], rec["ms_per_step_replay"]) if v is not None)
     hid, layers, khops = cargs[3], cargs[4], cargs[5]
     ne = (x.shape[0] / float(B), ei.shape[1] / float(B))      # nodes / stored edges per graph of THIS batch (mixed topologies: the mean)
@@ -495,6 +504,27 @@ def main():
         timer.cancel()
     elif not args.no_graph:
         result["config"]["hipgraph"] = "skipped at world > 1 (DSS2_BENCH_DIST_GRAPH=0)"
+    # ---- and as a launch plan (graphs.PlannedStep, include/dss2_hip.h "launch plans"): the library's own record of the step's launches
+    # re-issued from ONE C call per step -- real launches of the same kernels on the same stream, no Python between them, and like the
+    # hipGraph replay it carries the step's vminmax launch (no cached batch constants).  Single process only (a collective is not a
+    # launch of this library).
+    if world == 1 and not args.no_graph:
+        try:
+            planned = pkg.graphs.PlannedStep(step, stream=work_stream)
+            for _ in range(max(args.warmup, 5)):
+                planned.replay()
+            pw, _ = timed_windows(planned.replay)
+            pdt = sorted(pw)[len(pw) // 2]
+            result["config"]["ms_per_step_by_mode"]["launch plan"] = pdt / args.steps * 1e3
+            result["config"]["plan_launches"] = planned.n_launches
+            if pdt < dt:
+                dt, ms, windows, mode = pdt, pdt / args.steps * 1e3, pw, "launch plan (dss2_plan_run)"
+                value = args.batch * world / (dt / args.steps)
+                result.update(value=value, ms_per_step=ms)
+                result["config"].update(mode=mode, timed_windows=len(pw),
+                                        window_ms_min_median_max=[min(pw) * 1e3, pdt * 1e3, max(pw) * 1e3])
+        except Exception as exc:
+            result["config"]["launch_plan"] = f"failed: {type(exc).__name__}: {exc}"[:300]
 
     if rank == 0:
         # ---- standalone scatter-add (K6) against the HBM roofline (north_star asks for it separately), at two sizes:
@@ -556,8 +586,9 @@ def main():
                     others[tag] = {"skipped": f"{type(exc).__name__}: {exc}"[:200]}
                     torch.cuda.empty_cache()
             result["other_configs"] = others
-            result["other_configs_note"] = ("forward + gsp_wls_edge + backward on a resident synthetic batch, one GPU, eager and hipGraph "
-                                            "replay (>= %.1f s of timed work each), ms_per_step = the faster; TFLOP/s from SURVEY 8(d)'s "
+            result["other_configs_note"] = ("forward + gsp_wls_edge + backward on a resident synthetic batch, one GPU, eager, as a hipGraph "
+                                            "replay and as a launch plan (one C call per step, dss2_plan_run), >= %.1f s of timed work each; "
+                                            "ms_per_step = the faster of eager / replay; TFLOP/s from SURVEY 8(d)'s "
                                             "algorithmic FLOPs (3 x forward); the driver line excludes the optimizer" % args.other_seconds)
 
         # ---- CPU baseline (SURVEY 8d / BASELINE.md 3): the oracle -- a port of the reference's PyTorch-eager path --

@@ -154,6 +154,11 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "dss2_last_error": (C.c_char_p, []),
     "dss2_version": (C.c_int, []),
+    "dss2_plan_begin": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "dss2_plan_end": (C.c_int, [C.c_void_p]),
+    "dss2_plan_size": (C.c_int, [C.c_void_p]),
+    "dss2_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dss2_plan_destroy": (None, [C.c_void_p]),
     "dss2_topology_probe": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "dss2_csr_build": (C.c_int, [C.POINTER(CsrBuildArgs), C.c_void_p]),
     "dss2_csr_build_work_ints": (C.c_int64, [C.c_int64, C.c_int64, C.c_int]),

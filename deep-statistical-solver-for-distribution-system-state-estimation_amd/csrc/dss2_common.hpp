@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <functional>
+#include <vector>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -25,6 +27,15 @@ inline int check_launch(const char* what) {
 }
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- launch plans (dss2_plan_*, dss2_api.hip): while a plan records, every launch entry point of the library appends a closure --
+// its own launch function bound to COPIES of its host-side arguments -- and dss2_plan_run re-issues the closures in order from ONE C
+// call.  DSS2_RECORD sits in the extern "C" wrapper of an entry point, in front of the call of its *_launch body.
+bool plan_recording();
+void plan_record(std::function<int(void*)> op);
+template <class T> inline std::vector<T> plan_keep(const T* p, size_t n) { return p ? std::vector<T>(p, p + n) : std::vector<T>(); }
+template <class T> inline const T* plan_ptr(const std::vector<T>& v) { return v.empty() ? nullptr : v.data(); }
+#define DSS2_RECORD(...) do { if (dss2::plan_recording()) dss2::plan_record(__VA_ARGS__); } while (0)
 
 // 32x32 MFMA accumulator register r of lane -> row inside the 32-row block
 // (col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); CDNA4 C/D layout.

@@ -635,9 +635,12 @@ __global__ void __launch_bounds__(256) reduce_slabs_multi_v4_kernel(const Reduce
 
 using namespace dss2;
 
-extern "C" int dss2_edge_hidden_fwd(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1,
-                                    const float* b1, const int32_t* rowptr, const int32_t* col, const int32_t* ent,
-                                    float* S, int64_t n_nodes, int h, int fn, int fe, void* stream) {
+static int dss2_edge_hidden_fwd_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* S, int64_t n_nodes, int h, int fn, int fe, void* stream);
+extern "C" int dss2_edge_hidden_fwd(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* S, int64_t n_nodes, int h, int fn, int fe, void* stream) {
+  DSS2_RECORD([x, ldx, ea, ldea, W1, b1, rowptr, col, ent, S, n_nodes, h, fn, fe](void* s_) { return dss2_edge_hidden_fwd_launch(x, ldx, ea, ldea, W1, b1, rowptr, col, ent, S, n_nodes, h, fn, fe, s_); });
+  return dss2_edge_hidden_fwd_launch(x, ldx, ea, ldea, W1, b1, rowptr, col, ent, S, n_nodes, h, fn, fe, stream);
+}
+static int dss2_edge_hidden_fwd_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* S, int64_t n_nodes, int h, int fn, int fe, void* stream) {
   if (fn != FN || fe != FE) { set_error("edge_hidden_fwd: only dim_featn=8, dim_feate=6 are built (got %d, %d)", fn, fe); return 2; }
   if (h <= 0 || h > 256) { set_error("edge_hidden_fwd: h=%d unsupported (1..256)", h); return 2; }
   if (n_nodes <= 0) return 0;
@@ -652,10 +655,12 @@ extern "C" int dss2_edge_hidden_fwd(const float* x, int64_t ldx, const float* ea
   return check_launch("edge_hidden_fwd");
 }
 
-extern "C" int dss2_edge_hidden_bwd(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1,
-                                    const float* b1, const float* dS, const int32_t* rowptr, const int32_t* col,
-                                    const int32_t* ent, float* slab, int n_slabs, float* U, int64_t ldu,
-                                    int64_t n_nodes, int h, int fn, int fe, int by_source, void* stream) {
+static int dss2_edge_hidden_bwd_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const float* dS, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* slab, int n_slabs, float* U, int64_t ldu, int64_t n_nodes, int h, int fn, int fe, int by_source, void* stream);
+extern "C" int dss2_edge_hidden_bwd(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const float* dS, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* slab, int n_slabs, float* U, int64_t ldu, int64_t n_nodes, int h, int fn, int fe, int by_source, void* stream) {
+  DSS2_RECORD([x, ldx, ea, ldea, W1, b1, dS, rowptr, col, ent, slab, n_slabs, U, ldu, n_nodes, h, fn, fe, by_source](void* s_) { return dss2_edge_hidden_bwd_launch(x, ldx, ea, ldea, W1, b1, dS, rowptr, col, ent, slab, n_slabs, U, ldu, n_nodes, h, fn, fe, by_source, s_); });
+  return dss2_edge_hidden_bwd_launch(x, ldx, ea, ldea, W1, b1, dS, rowptr, col, ent, slab, n_slabs, U, ldu, n_nodes, h, fn, fe, by_source, stream);
+}
+static int dss2_edge_hidden_bwd_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const float* dS, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* slab, int n_slabs, float* U, int64_t ldu, int64_t n_nodes, int h, int fn, int fe, int by_source, void* stream) {
   if (fn != FN || fe != FE) { set_error("edge_hidden_bwd: only dim_featn=8, dim_feate=6 are built (got %d, %d)", fn, fe); return 2; }
   if (h <= 0 || h > 256) { set_error("edge_hidden_bwd: h=%d unsupported (1..256)", h); return 2; }
   if (n_slabs <= 0) { set_error("edge_hidden_bwd: n_slabs must be > 0"); return 2; }
@@ -913,9 +918,12 @@ extern "C" int dss2_edge_tile_fwd(const float* x, int64_t ldx, const float* ea, 
   return dss2_edge_tile_fwd_xp(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, nullptr, stream);
 }
 
-extern "C" int dss2_edge_tile_fwd_xp(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1,
-                                     const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width,
-                                     int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, void* stream) {
+static int dss2_edge_tile_fwd_xp_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, void* stream);
+extern "C" int dss2_edge_tile_fwd_xp(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, void* stream) {
+  DSS2_RECORD([x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, x_planes](void* s_) { return dss2_edge_tile_fwd_xp_launch(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, x_planes, s_); });
+  return dss2_edge_tile_fwd_xp_launch(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, x_planes, stream);
+}
+static int dss2_edge_tile_fwd_xp_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, void* stream) {
   if (fn != FN || fe != FE) { set_error("edge_tile_fwd: only dim_featn=8, dim_feate=6 are built (got %d, %d)", fn, fe); return 2; }
   if (h <= 0 || h > 256 || ell_width <= 0 || ell_width > 32) { set_error("edge_tile_fwd: bad h=%d or ell_width=%d", h, ell_width); return 2; }
   if (x_planes && !dss2_edge_tile_fwd_xp_supported(nrb, h, ell_width)) {
@@ -932,10 +940,12 @@ extern "C" int dss2_edge_tile_fwd_xp(const float* x, int64_t ldx, const float* e
   return launch_edge_tile<false>(a, ntiles, as_stream(stream));
 }
 
-extern "C" int dss2_edge_tile_bwd(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1,
-                                  const float* b1, const float* dS, const int32_t* tile_start, const void* ell_ent,
-                                  int ell_width, int nrb, int ntiles, float* slab, int n_slabs, float* U, int64_t ldu,
-                                  int h, int fn, int fe, int by_source, void* stream) {
+static int dss2_edge_tile_bwd_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const float* dS, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* slab, int n_slabs, float* U, int64_t ldu, int h, int fn, int fe, int by_source, void* stream);
+extern "C" int dss2_edge_tile_bwd(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const float* dS, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* slab, int n_slabs, float* U, int64_t ldu, int h, int fn, int fe, int by_source, void* stream) {
+  DSS2_RECORD([x, ldx, ea, ldea, W1, b1, dS, tile_start, ell_ent, ell_width, nrb, ntiles, slab, n_slabs, U, ldu, h, fn, fe, by_source](void* s_) { return dss2_edge_tile_bwd_launch(x, ldx, ea, ldea, W1, b1, dS, tile_start, ell_ent, ell_width, nrb, ntiles, slab, n_slabs, U, ldu, h, fn, fe, by_source, s_); });
+  return dss2_edge_tile_bwd_launch(x, ldx, ea, ldea, W1, b1, dS, tile_start, ell_ent, ell_width, nrb, ntiles, slab, n_slabs, U, ldu, h, fn, fe, by_source, stream);
+}
+static int dss2_edge_tile_bwd_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const float* dS, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* slab, int n_slabs, float* U, int64_t ldu, int h, int fn, int fe, int by_source, void* stream) {
   if (fn != FN || fe != FE) { set_error("edge_tile_bwd: only dim_featn=8, dim_feate=6 are built (got %d, %d)", fn, fe); return 2; }
   if (h <= 0 || h > 256 || ell_width <= 0 || ell_width > 32) { set_error("edge_tile_bwd: bad h=%d or ell_width=%d", h, ell_width); return 2; }
   if (!by_source && !slab) { set_error("edge_tile_bwd: slab is NULL"); return 2; }
@@ -955,9 +965,12 @@ extern "C" int dss2_edge_tile_bwd(const float* x, int64_t ldx, const float* ea, 
   return launch_edge_tile<true>(a, n_slabs < ntiles ? n_slabs : ntiles, as_stream(stream));
 }
 
-extern "C" int dss2_edge_combine_fwd(const float* AB, int64_t ldab, const float* ea, int64_t ldea, const float* W1c, int64_t ldw,
-                                     const float* b1, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* S,
-                                     int64_t n_nodes, int h, int fe, void* stream) {
+static int dss2_edge_combine_fwd_launch(const float* AB, int64_t ldab, const float* ea, int64_t ldea, const float* W1c, int64_t ldw, const float* b1, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* S, int64_t n_nodes, int h, int fe, void* stream);
+extern "C" int dss2_edge_combine_fwd(const float* AB, int64_t ldab, const float* ea, int64_t ldea, const float* W1c, int64_t ldw, const float* b1, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* S, int64_t n_nodes, int h, int fe, void* stream) {
+  DSS2_RECORD([AB, ldab, ea, ldea, W1c, ldw, b1, rowptr, col, ent, S, n_nodes, h, fe](void* s_) { return dss2_edge_combine_fwd_launch(AB, ldab, ea, ldea, W1c, ldw, b1, rowptr, col, ent, S, n_nodes, h, fe, s_); });
+  return dss2_edge_combine_fwd_launch(AB, ldab, ea, ldea, W1c, ldw, b1, rowptr, col, ent, S, n_nodes, h, fe, stream);
+}
+static int dss2_edge_combine_fwd_launch(const float* AB, int64_t ldab, const float* ea, int64_t ldea, const float* W1c, int64_t ldw, const float* b1, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* S, int64_t n_nodes, int h, int fe, void* stream) {
   if (h <= 0 || fe < 0 || fe > EC_MAXFE) { set_error("edge_combine_fwd: h=%d / fe=%d (0..32) unsupported", h, fe); return 2; }
   if (n_nodes <= 0) return 0;
   int64_t blocks = (n_nodes + 3) / 4;
@@ -976,10 +989,12 @@ extern "C" int dss2_edge_combine_fwd(const float* AB, int64_t ldab, const float*
   return check_launch("edge_combine_fwd");
 }
 
-extern "C" int dss2_edge_combine_bwd(const float* AB, int64_t ldab, const float* ea, int64_t ldea, const float* W1c, int64_t ldw,
-                                     const float* b1, const float* dS, const int32_t* rowptr, const int32_t* col,
-                                     const int32_t* ent, float* dAB, float* slab, int n_slabs, int64_t n_nodes, int h, int fe,
-                                     int by_source, void* stream) {
+static int dss2_edge_combine_bwd_launch(const float* AB, int64_t ldab, const float* ea, int64_t ldea, const float* W1c, int64_t ldw, const float* b1, const float* dS, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* dAB, float* slab, int n_slabs, int64_t n_nodes, int h, int fe, int by_source, void* stream);
+extern "C" int dss2_edge_combine_bwd(const float* AB, int64_t ldab, const float* ea, int64_t ldea, const float* W1c, int64_t ldw, const float* b1, const float* dS, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* dAB, float* slab, int n_slabs, int64_t n_nodes, int h, int fe, int by_source, void* stream) {
+  DSS2_RECORD([AB, ldab, ea, ldea, W1c, ldw, b1, dS, rowptr, col, ent, dAB, slab, n_slabs, n_nodes, h, fe, by_source](void* s_) { return dss2_edge_combine_bwd_launch(AB, ldab, ea, ldea, W1c, ldw, b1, dS, rowptr, col, ent, dAB, slab, n_slabs, n_nodes, h, fe, by_source, s_); });
+  return dss2_edge_combine_bwd_launch(AB, ldab, ea, ldea, W1c, ldw, b1, dS, rowptr, col, ent, dAB, slab, n_slabs, n_nodes, h, fe, by_source, stream);
+}
+static int dss2_edge_combine_bwd_launch(const float* AB, int64_t ldab, const float* ea, int64_t ldea, const float* W1c, int64_t ldw, const float* b1, const float* dS, const int32_t* rowptr, const int32_t* col, const int32_t* ent, float* dAB, float* slab, int n_slabs, int64_t n_nodes, int h, int fe, int by_source, void* stream) {
   if (h <= 0 || fe < 0 || fe > EC_MAXFE) { set_error("edge_combine_bwd: h=%d / fe=%d (0..32) unsupported", h, fe); return 2; }
   if (!by_source && (!slab || n_slabs <= 0)) { set_error("edge_combine_bwd: slab missing"); return 2; }
   if (n_nodes <= 0) return 0;
@@ -999,7 +1014,13 @@ extern "C" int dss2_edge_combine_bwd(const float* AB, int64_t ldab, const float*
   return check_launch("edge_combine_bwd");
 }
 
+static int dss2_csr_axpy_launch(const dss2_csr_axpy_args* ap, void* stream);
 extern "C" int dss2_csr_axpy(const dss2_csr_axpy_args* ap, void* stream) {
+  if (!ap) { dss2::set_error("dss2_csr_axpy: null argument"); return 2; }
+  DSS2_RECORD([a = *ap](void* s_) { return dss2_csr_axpy_launch(&a, s_); });
+  return dss2_csr_axpy_launch(ap, stream);
+}
+static int dss2_csr_axpy_launch(const dss2_csr_axpy_args* ap, void* stream) {
   const dss2_csr_axpy_args& a = *ap;
   if (a.n_rows <= 0) return 0;
   if (!a.rowptr || !a.col || !a.w || !a.T || !a.out || a.h <= 0) { set_error("csr_axpy: bad arguments"); return 2; }
@@ -1017,8 +1038,12 @@ extern "C" int dss2_csr_axpy(const dss2_csr_axpy_args* ap, void* stream) {
   return check_launch("csr_axpy");
 }
 
-extern "C" int dss2_segment_sum(const float* msg, int64_t ldm, const int32_t* rowptr, const int32_t* ent, float* out,
-                                int64_t ldo, int64_t n_rows, int h, void* stream) {
+static int dss2_segment_sum_launch(const float* msg, int64_t ldm, const int32_t* rowptr, const int32_t* ent, float* out, int64_t ldo, int64_t n_rows, int h, void* stream);
+extern "C" int dss2_segment_sum(const float* msg, int64_t ldm, const int32_t* rowptr, const int32_t* ent, float* out, int64_t ldo, int64_t n_rows, int h, void* stream) {
+  DSS2_RECORD([msg, ldm, rowptr, ent, out, ldo, n_rows, h](void* s_) { return dss2_segment_sum_launch(msg, ldm, rowptr, ent, out, ldo, n_rows, h, s_); });
+  return dss2_segment_sum_launch(msg, ldm, rowptr, ent, out, ldo, n_rows, h, stream);
+}
+static int dss2_segment_sum_launch(const float* msg, int64_t ldm, const int32_t* rowptr, const int32_t* ent, float* out, int64_t ldo, int64_t n_rows, int h, void* stream) {
   if (h <= 0) { set_error("segment_sum: h=%d", h); return 2; }
   if (n_rows <= 0) return 0;
   const bool fast = (h == 32 || h == 64 || h == 128 || h == 256) && !(ldm & 3) && !(ldo & 3) &&
@@ -1038,8 +1063,12 @@ extern "C" int dss2_segment_sum(const float* msg, int64_t ldm, const int32_t* ro
   return check_launch("segment_sum");
 }
 
-extern "C" int dss2_gather_rows(const float* src, int64_t lds, const int32_t* idx, float* out, int64_t ldo, int64_t n_rows,
-                                int h, void* stream) {
+static int dss2_gather_rows_launch(const float* src, int64_t lds, const int32_t* idx, float* out, int64_t ldo, int64_t n_rows, int h, void* stream);
+extern "C" int dss2_gather_rows(const float* src, int64_t lds, const int32_t* idx, float* out, int64_t ldo, int64_t n_rows, int h, void* stream) {
+  DSS2_RECORD([src, lds, idx, out, ldo, n_rows, h](void* s_) { return dss2_gather_rows_launch(src, lds, idx, out, ldo, n_rows, h, s_); });
+  return dss2_gather_rows_launch(src, lds, idx, out, ldo, n_rows, h, stream);
+}
+static int dss2_gather_rows_launch(const float* src, int64_t lds, const int32_t* idx, float* out, int64_t ldo, int64_t n_rows, int h, void* stream) {
   if (h <= 0) { set_error("gather_rows: h=%d", h); return 2; }
   if (n_rows <= 0) return 0;
   const bool vec = !(h & 3) && !(lds & 3) && !(ldo & 3) && !(reinterpret_cast<uintptr_t>(src) & 15) &&
@@ -1051,7 +1080,12 @@ extern "C" int dss2_gather_rows(const float* src, int64_t lds, const int32_t* id
   return check_launch("gather_rows");
 }
 
+static int dss2_reduce_slabs_launch(const float* slab, int n_slabs, int64_t stride, float* out, int64_t len, void* stream);
 extern "C" int dss2_reduce_slabs(const float* slab, int n_slabs, int64_t stride, float* out, int64_t len, void* stream) {
+  DSS2_RECORD([slab, n_slabs, stride, out, len](void* s_) { return dss2_reduce_slabs_launch(slab, n_slabs, stride, out, len, s_); });
+  return dss2_reduce_slabs_launch(slab, n_slabs, stride, out, len, stream);
+}
+static int dss2_reduce_slabs_launch(const float* slab, int n_slabs, int64_t stride, float* out, int64_t len, void* stream) {
   if (len <= 0) return 0;
   if (stride % 4 == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && n_slabs > 0) {
     // the same summation order as the batched form (dss2_reduce_slabs_multi): a reduction gives the same bits either way
@@ -1065,7 +1099,12 @@ extern "C" int dss2_reduce_slabs(const float* slab, int n_slabs, int64_t stride,
   return check_launch("reduce_slabs");
 }
 
+static int dss2_reduce_slabs_multi_launch(const dss2_reduce_desc* descs_host, int n_desc, void* stream);
 extern "C" int dss2_reduce_slabs_multi(const dss2_reduce_desc* descs_host, int n_desc, void* stream) {
+  DSS2_RECORD([d = dss2::plan_keep(descs_host, (size_t)(n_desc > 0 ? n_desc : 0)), n_desc](void* s_) { return dss2_reduce_slabs_multi_launch(dss2::plan_ptr(d), n_desc, s_); });
+  return dss2_reduce_slabs_multi_launch(descs_host, n_desc, stream);
+}
+static int dss2_reduce_slabs_multi_launch(const dss2_reduce_desc* descs_host, int n_desc, void* stream) {
   if (n_desc <= 0) return 0;
   if (!descs_host || n_desc > REDUCE_MAX_DESC) { set_error("reduce_slabs_multi: 1..%d descriptors, got %d", REDUCE_MAX_DESC, n_desc); return 2; }
   ReduceTable tab = {};

@@ -57,7 +57,13 @@ extern "C" int dss2_gemm_prop_chain_xplanes_supported(int nrb, int nmat, int kre
   return chain_row_split(nrb, a.ncg) == 1 && chain_sp_supported(a) ? 1 : 0;
 }
 
+static int dss2_gemm_prop_chain_launch(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, void* stream);
 extern "C" int dss2_gemm_prop_chain(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, void* stream) {
+  if (!ap) { dss2::set_error("dss2_gemm_prop_chain: null argument"); return 2; }
+  DSS2_RECORD([a = *ap, l = dss2::plan_keep(layers, (size_t)(n_layers > 0 ? n_layers : 0)), n_layers](void* s_) { return dss2_gemm_prop_chain_launch(&a, dss2::plan_ptr(l), n_layers, s_); });
+  return dss2_gemm_prop_chain_launch(ap, layers, n_layers, stream);
+}
+static int dss2_gemm_prop_chain_launch(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, void* stream) {
   return chain_impl(ap, layers, n_layers, nullptr, stream);
 }
 
@@ -71,8 +77,14 @@ extern "C" int dss2_gemm_prop_chain_head_supported(int nrb, int nmat, int kreal,
   return 0;
 }
 
-extern "C" int dss2_gemm_prop_chain_head(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers,
-                                         const dss2_chain_head* head, void* stream) {
+static int dss2_gemm_prop_chain_head_launch(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, const dss2_chain_head* head, void* stream);
+extern "C" int dss2_gemm_prop_chain_head(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, const dss2_chain_head* head, void* stream) {
+  if (!ap) { dss2::set_error("dss2_gemm_prop_chain_head: null argument"); return 2; }
+  if (!head) { dss2::set_error("dss2_gemm_prop_chain_head: head is NULL"); return 2; }
+  DSS2_RECORD([a = *ap, l = dss2::plan_keep(layers, (size_t)(n_layers > 0 ? n_layers : 0)), n_layers, h = *head](void* s_) { return dss2_gemm_prop_chain_head_launch(&a, dss2::plan_ptr(l), n_layers, &h, s_); });
+  return dss2_gemm_prop_chain_head_launch(ap, layers, n_layers, head, stream);
+}
+static int dss2_gemm_prop_chain_head_launch(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, const dss2_chain_head* head, void* stream) {
   using namespace dss2;
   if (!head || (head->mode != 1 && head->mode != 2)) { set_error("gemm_prop_chain_head: head.mode must be 1 or 2"); return 2; }
   if (!(dss2_gemm_prop_chain_head_supported(ap->nrb, ap->nmat, ap->kreal, ap->hout, ap->ell_width, head->nout) & head->mode) || ap->b_format != 1) {

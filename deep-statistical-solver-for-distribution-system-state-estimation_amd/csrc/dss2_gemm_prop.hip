@@ -1036,14 +1036,25 @@ extern "C" int dss2_gemm_prop16_supported(int nrb, int nmat, int kreal, int hout
   return dss2::gemm16_shape_ok(nrb, nmat, kreal, hout, max_nnz, ell_width) ? 1 : 0;
 }
 
+static int dss2_pack_weights_launch(const dss2_pack_desc* descs, int n_desc, int max_elems, void* stream);
 extern "C" int dss2_pack_weights(const dss2_pack_desc* descs, int n_desc, int max_elems, void* stream) {
+  DSS2_RECORD([descs, n_desc, max_elems](void* s_) { return dss2_pack_weights_launch(descs, n_desc, max_elems, s_); });
+  return dss2_pack_weights_launch(descs, n_desc, max_elems, stream);
+}
+static int dss2_pack_weights_launch(const dss2_pack_desc* descs, int n_desc, int max_elems, void* stream) {
   if (n_desc <= 0) return 0;
   dim3 grid((max_elems + 255) / 256, n_desc);
   hipLaunchKernelGGL(dss2::pack_weights_kernel, grid, dim3(256), 0, dss2::as_stream(stream), descs);
   return dss2::check_launch("pack_weights");
 }
 
+static int dss2_gemm_prop_launch(const dss2_gemm_prop_args* ap, void* stream);
 extern "C" int dss2_gemm_prop(const dss2_gemm_prop_args* ap, void* stream) {
+  if (!ap) { dss2::set_error("dss2_gemm_prop: null argument"); return 2; }
+  DSS2_RECORD([a = *ap](void* s_) { return dss2_gemm_prop_launch(&a, s_); });
+  return dss2_gemm_prop_launch(ap, stream);
+}
+static int dss2_gemm_prop_launch(const dss2_gemm_prop_args* ap, void* stream) {
   using namespace dss2;
   const dss2_gemm_prop_args& a = *ap;
   if (a.ntiles <= 0) return 0;

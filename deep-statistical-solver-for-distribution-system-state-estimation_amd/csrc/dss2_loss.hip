@@ -450,7 +450,13 @@ __global__ void eval_finish_kernel(const double* __restrict__ partials, int nb, 
 
 using namespace dss2;
 
+static int dss2_wls_loss_partials_launch(const dss2_wls_args* ap, void* stream);
 extern "C" int dss2_wls_loss_partials(const dss2_wls_args* ap, void* stream) {
+  if (!ap) { dss2::set_error("dss2_wls_loss_partials: null argument"); return 2; }
+  DSS2_RECORD([a = *ap](void* s_) { return dss2_wls_loss_partials_launch(&a, s_); });
+  return dss2_wls_loss_partials_launch(ap, stream);
+}
+static int dss2_wls_loss_partials_launch(const dss2_wls_args* ap, void* stream) {
   const dss2_wls_args& a = *ap;
   if (a.n_nodes <= 0 || a.n_edges <= 0) { set_error("wls_loss: empty batch"); return 2; }
   const int64_t nb = (a.n_nodes + LB - 1) / LB;
@@ -465,13 +471,25 @@ extern "C" int dss2_wls_loss_partials(const dss2_wls_args* ap, void* stream) {
   return check_launch("wls_loss_partials");
 }
 
+static int dss2_wls_loss_value_launch(const dss2_wls_args* ap, void* stream);
 extern "C" int dss2_wls_loss_value(const dss2_wls_args* ap, void* stream) {
+  if (!ap) { dss2::set_error("dss2_wls_loss_value: null argument"); return 2; }
+  DSS2_RECORD([a = *ap](void* s_) { return dss2_wls_loss_value_launch(&a, s_); });
+  return dss2_wls_loss_value_launch(ap, stream);
+}
+static int dss2_wls_loss_value_launch(const dss2_wls_args* ap, void* stream) {
   if (!ap->sums || !ap->loss) { set_error("wls_loss_value: null argument"); return 2; }
   hipLaunchKernelGGL(wls_value_kernel, dim3(1), dim3(64), 0, as_stream(stream), ap->sums, ap->lam_reg, ap->loss);
   return check_launch("wls_loss_value");
 }
 
+static int dss2_wls_loss_grad_launch(const dss2_wls_args* ap, void* stream);
 extern "C" int dss2_wls_loss_grad(const dss2_wls_args* ap, void* stream) {
+  if (!ap) { dss2::set_error("dss2_wls_loss_grad: null argument"); return 2; }
+  DSS2_RECORD([a = *ap](void* s_) { return dss2_wls_loss_grad_launch(&a, s_); });
+  return dss2_wls_loss_grad_launch(ap, stream);
+}
+static int dss2_wls_loss_grad_launch(const dss2_wls_args* ap, void* stream) {
   const dss2_wls_args& a = *ap;
   if (a.n_nodes <= 0) { set_error("wls_loss: empty batch"); return 2; }
   const int64_t nb = (a.n_nodes + LB - 1) / LB;

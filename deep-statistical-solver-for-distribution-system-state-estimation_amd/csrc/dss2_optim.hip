@@ -186,7 +186,12 @@ __global__ void __launch_bounds__(256) small_gemm_kernel(const dss2_sgemm_desc* 
 
 }  // namespace dss2
 
+static int dss2_small_gemm_launch(const dss2_sgemm_desc* descs, int n_desc, int max_tiles, float* base_out, void* stream);
 extern "C" int dss2_small_gemm(const dss2_sgemm_desc* descs, int n_desc, int max_tiles, float* base_out, void* stream) {
+  DSS2_RECORD([descs, n_desc, max_tiles, base_out](void* s_) { return dss2_small_gemm_launch(descs, n_desc, max_tiles, base_out, s_); });
+  return dss2_small_gemm_launch(descs, n_desc, max_tiles, base_out, stream);
+}
+static int dss2_small_gemm_launch(const dss2_sgemm_desc* descs, int n_desc, int max_tiles, float* base_out, void* stream) {
   if (n_desc <= 0) return 0;
   if (max_tiles <= 0) { dss2::set_error("small_gemm: max_tiles must be positive"); return 2; }
   hipLaunchKernelGGL(dss2::small_gemm_kernel, dim3(max_tiles, n_desc), dim3(256), 0, dss2::as_stream(stream),
@@ -213,17 +218,24 @@ static int adamax_launch(const dss2_adamax_desc* descs_host, int n_desc, float l
   return dss2::check_launch("adamax_step");
 }
 
-extern "C" int dss2_adamax_step(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1,
-                                float beta2, float eps, float weight_decay, int step, void* stream) {
+static int dss2_adamax_step_launch(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+extern "C" int dss2_adamax_step(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+  DSS2_RECORD([d = dss2::plan_keep(descs_host, (size_t)(n_desc > 0 ? n_desc : 0)), n_desc, lr, beta1, beta2, eps, weight_decay, step](void* s_) { return dss2_adamax_step_launch(dss2::plan_ptr(d), n_desc, lr, beta1, beta2, eps, weight_decay, step, s_); });
+  return dss2_adamax_step_launch(descs_host, n_desc, lr, beta1, beta2, eps, weight_decay, step, stream);
+}
+static int dss2_adamax_step_launch(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
   if (n_desc <= 0) return 0;
   if (!descs_host) { dss2::set_error("adamax_step: null descriptor table"); return 2; }
   if (step < 1) { dss2::set_error("adamax_step: step must be >= 1"); return 2; }
   return adamax_launch(descs_host, n_desc, lr, beta1, beta2, eps, weight_decay, 1.f - powf(beta1, (float)step), nullptr, dss2::as_stream(stream));
 }
 
-extern "C" int dss2_adamax_step_flat(const dss2_adamax_flat_desc* descs_dev, int n_desc, int64_t max_n, const float* grad_base,
-                                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* step_dev,
-                                     uint32_t* counter, void* stream) {
+static int dss2_adamax_step_flat_launch(const dss2_adamax_flat_desc* descs_dev, int n_desc, int64_t max_n, const float* grad_base, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* step_dev, uint32_t* counter, void* stream);
+extern "C" int dss2_adamax_step_flat(const dss2_adamax_flat_desc* descs_dev, int n_desc, int64_t max_n, const float* grad_base, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* step_dev, uint32_t* counter, void* stream) {
+  DSS2_RECORD([descs_dev, n_desc, max_n, grad_base, lr, beta1, beta2, eps, weight_decay, step, step_dev, counter](void* s_) { return dss2_adamax_step_flat_launch(descs_dev, n_desc, max_n, grad_base, lr, beta1, beta2, eps, weight_decay, step, step_dev, counter, s_); });
+  return dss2_adamax_step_flat_launch(descs_dev, n_desc, max_n, grad_base, lr, beta1, beta2, eps, weight_decay, step, step_dev, counter, stream);
+}
+static int dss2_adamax_step_flat_launch(const dss2_adamax_flat_desc* descs_dev, int n_desc, int64_t max_n, const float* grad_base, float lr, float beta1, float beta2, float eps, float weight_decay, int step, float* step_dev, uint32_t* counter, void* stream) {
   if (n_desc <= 0) return 0;
   if (!descs_dev || !grad_base || n_desc > 65535) { dss2::set_error("adamax_step_flat: bad arguments"); return 2; }
   if (step < 0 || (step == 0 && (!step_dev || !counter))) { dss2::set_error("adamax_step_flat: step >= 1, or step == 0 with step_dev and counter"); return 2; }
@@ -236,8 +248,12 @@ extern "C" int dss2_adamax_step_flat(const dss2_adamax_flat_desc* descs_dev, int
   return dss2::check_launch("adamax_step_flat");
 }
 
-extern "C" int dss2_adamax_step_dev(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1,
-                                    float beta2, float eps, float weight_decay, float* step_dev, void* stream) {
+static int dss2_adamax_step_dev_launch(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1, float beta2, float eps, float weight_decay, float* step_dev, void* stream);
+extern "C" int dss2_adamax_step_dev(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1, float beta2, float eps, float weight_decay, float* step_dev, void* stream) {
+  DSS2_RECORD([d = dss2::plan_keep(descs_host, (size_t)(n_desc > 0 ? n_desc : 0)), n_desc, lr, beta1, beta2, eps, weight_decay, step_dev](void* s_) { return dss2_adamax_step_dev_launch(dss2::plan_ptr(d), n_desc, lr, beta1, beta2, eps, weight_decay, step_dev, s_); });
+  return dss2_adamax_step_dev_launch(descs_host, n_desc, lr, beta1, beta2, eps, weight_decay, step_dev, stream);
+}
+static int dss2_adamax_step_dev_launch(const dss2_adamax_desc* descs_host, int n_desc, float lr, float beta1, float beta2, float eps, float weight_decay, float* step_dev, void* stream) {
   if (n_desc <= 0) return 0;
   if (!descs_host || !step_dev) { dss2::set_error("adamax_step_dev: null argument"); return 2; }
   hipLaunchKernelGGL(dss2::adamax_tick_kernel, dim3(1), dim3(64), 0, dss2::as_stream(stream), step_dev);
@@ -268,7 +284,12 @@ __global__ void __launch_bounds__(256) dropout_mask_kernel(const uint64_t* __res
 }
 }  // namespace dss2
 
+static int dss2_rng_next_launch(uint64_t* state, uint64_t* snapshot, uint64_t host_seed, int use_host_seed, void* stream);
 extern "C" int dss2_rng_next(uint64_t* state, uint64_t* snapshot, uint64_t host_seed, int use_host_seed, void* stream) {
+  DSS2_RECORD([state, snapshot, host_seed, use_host_seed](void* s_) { return dss2_rng_next_launch(state, snapshot, host_seed, use_host_seed, s_); });
+  return dss2_rng_next_launch(state, snapshot, host_seed, use_host_seed, stream);
+}
+static int dss2_rng_next_launch(uint64_t* state, uint64_t* snapshot, uint64_t host_seed, int use_host_seed, void* stream) {
   if (!snapshot || (!use_host_seed && !state)) { dss2::set_error("rng_next: null argument"); return 2; }
   hipLaunchKernelGGL(dss2::rng_next_kernel, dim3(1), dim3(64), 0, dss2::as_stream(stream),
                      reinterpret_cast<unsigned long long*>(state), reinterpret_cast<unsigned long long*>(snapshot),
@@ -325,8 +346,12 @@ __global__ void __launch_bounds__(256) gate_grad_kernel(const float* __restrict_
 }
 }  // namespace dss2
 
-extern "C" int dss2_gate_grad(const float* g, const float* y, float* out, int64_t n_rows, int h, const uint64_t* snapshot,
-                              int32_t drop_id, float p, int relu, void* stream) {
+static int dss2_gate_grad_launch(const float* g, const float* y, float* out, int64_t n_rows, int h, const uint64_t* snapshot, int32_t drop_id, float p, int relu, void* stream);
+extern "C" int dss2_gate_grad(const float* g, const float* y, float* out, int64_t n_rows, int h, const uint64_t* snapshot, int32_t drop_id, float p, int relu, void* stream) {
+  DSS2_RECORD([g, y, out, n_rows, h, snapshot, drop_id, p, relu](void* s_) { return dss2_gate_grad_launch(g, y, out, n_rows, h, snapshot, drop_id, p, relu, s_); });
+  return dss2_gate_grad_launch(g, y, out, n_rows, h, snapshot, drop_id, p, relu, stream);
+}
+static int dss2_gate_grad_launch(const float* g, const float* y, float* out, int64_t n_rows, int h, const uint64_t* snapshot, int32_t drop_id, float p, int relu, void* stream) {
   if (!g || !out || (relu && !y) || h <= 0) { dss2::set_error("gate_grad: bad arguments"); return 2; }
   if (n_rows <= 0) return 0;
   uint32_t thr = 0; float scale = 1.f;

@@ -1163,9 +1163,13 @@ extern "C" int dss2_stack_supported(const dss2_stack_dims* d, int hid, int nmat,
           ell_width <= S_MAX_ELL && ellT_width >= 1 && ellT_width <= S_MAX_ELL) ? 1 : 0;
 }
 
-extern "C" int dss2_stack_pack(const dss2_stack_dims* d, const float* const* params, uint32_t* wpack, uint64_t* rng_state,
-                               uint64_t* rng_snapshot, uint64_t host_seed, int use_host_seed, float* tick,
-                               const dss2_stack_args* tiles, void* stream) {
+static int dss2_stack_pack_launch(const dss2_stack_dims* d, const float* const* params, uint32_t* wpack, uint64_t* rng_state, uint64_t* rng_snapshot, uint64_t host_seed, int use_host_seed, float* tick, const dss2_stack_args* tiles, void* stream);
+extern "C" int dss2_stack_pack(const dss2_stack_dims* d, const float* const* params, uint32_t* wpack, uint64_t* rng_state, uint64_t* rng_snapshot, uint64_t host_seed, int use_host_seed, float* tick, const dss2_stack_args* tiles, void* stream) {
+  if (!d) { dss2::set_error("dss2_stack_pack: null argument"); return 2; }
+  DSS2_RECORD([dd = *d, params, wpack, rng_state, rng_snapshot, host_seed, use_host_seed, tick, has_t = tiles != nullptr, tt = tiles ? *tiles : dss2_stack_args{}](void* s_) { return dss2_stack_pack_launch(&dd, params, wpack,      /* (params: a DEVICE table of pointers) */ rng_state, rng_snapshot, host_seed, use_host_seed, tick, has_t ? &tt : nullptr, s_); });
+  return dss2_stack_pack_launch(d, params, wpack, rng_state, rng_snapshot, host_seed, use_host_seed, tick, tiles, stream);
+}
+static int dss2_stack_pack_launch(const dss2_stack_dims* d, const float* const* params, uint32_t* wpack, uint64_t* rng_state, uint64_t* rng_snapshot, uint64_t host_seed, int use_host_seed, float* tick, const dss2_stack_args* tiles, void* stream) {
   if (!dims_ok(*d) || !params || !wpack) { set_error("stack_pack: bad arguments"); return 2; }
   if (rng_snapshot && !use_host_seed && !rng_state) { set_error("stack_pack: rng_state missing"); return 2; }
   EaPrep ep = {};
@@ -1191,7 +1195,13 @@ static int stack_args_ok(const dss2_stack_args& a, const char* what) {
   return 0;
 }
 
+static int dss2_stack_forward_launch(const dss2_stack_args* ap, void* stream);
 extern "C" int dss2_stack_forward(const dss2_stack_args* ap, void* stream) {
+  if (!ap) { dss2::set_error("dss2_stack_forward: null argument"); return 2; }
+  DSS2_RECORD([a = *ap](void* s_) { return dss2_stack_forward_launch(&a, s_); });
+  return dss2_stack_forward_launch(ap, stream);
+}
+static int dss2_stack_forward_launch(const dss2_stack_args* ap, void* stream) {
   const dss2_stack_args& a = *ap;
   if (a.ntiles <= 0) return 0;
   if (int rc = stack_args_ok(a, "stack_forward")) return rc;
@@ -1203,7 +1213,13 @@ extern "C" int dss2_stack_forward(const dss2_stack_args* ap, void* stream) {
   return check_launch("stack_forward");
 }
 
+static int dss2_stack_backward_launch(const dss2_stack_args* ap, void* stream);
 extern "C" int dss2_stack_backward(const dss2_stack_args* ap, void* stream) {
+  if (!ap) { dss2::set_error("dss2_stack_backward: null argument"); return 2; }
+  DSS2_RECORD([a = *ap](void* s_) { return dss2_stack_backward_launch(&a, s_); });
+  return dss2_stack_backward_launch(ap, stream);
+}
+static int dss2_stack_backward_launch(const dss2_stack_args* ap, void* stream) {
   const dss2_stack_args& a = *ap;
   if (a.ntiles <= 0) return 0;
   if (int rc = stack_args_ok(a, "stack_backward")) return rc;
@@ -1216,8 +1232,13 @@ extern "C" int dss2_stack_backward(const dss2_stack_args* ap, void* stream) {
   return check_launch("stack_backward");
 }
 
-extern "C" int dss2_stack_reduce(const dss2_stack_dims* d, const float* slab, int32_t n_slabs, int64_t slab_stride,
-                                 const float* const* params, float* flat, float* fold_scratch, void* stream) {
+static int dss2_stack_reduce_launch(const dss2_stack_dims* d, const float* slab, int32_t n_slabs, int64_t slab_stride, const float* const* params, float* flat, float* fold_scratch, void* stream);
+extern "C" int dss2_stack_reduce(const dss2_stack_dims* d, const float* slab, int32_t n_slabs, int64_t slab_stride, const float* const* params, float* flat, float* fold_scratch, void* stream) {
+  if (!d) { dss2::set_error("dss2_stack_reduce: null argument"); return 2; }
+  DSS2_RECORD([dd = *d, slab, n_slabs, slab_stride, params, flat, fold_scratch](void* s_) { return dss2_stack_reduce_launch(&dd, slab, n_slabs, slab_stride, params, flat, fold_scratch, s_); });
+  return dss2_stack_reduce_launch(d, slab, n_slabs, slab_stride, params, flat, fold_scratch, stream);
+}
+static int dss2_stack_reduce_launch(const dss2_stack_dims* d, const float* slab, int32_t n_slabs, int64_t slab_stride, const float* const* params, float* flat, float* fold_scratch, void* stream) {
   if (!dims_ok(*d) || !slab || !params || !flat || !fold_scratch || n_slabs < 1 || (slab_stride & 3)) { set_error("stack_reduce: bad arguments"); return 2; }
   const int64_t total = dss2_stack_flat_floats(d);
   hipStream_t s = as_stream(stream);

@@ -820,13 +820,24 @@ static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::Wg
   return 2;
 }
 
+static int dss2_wgrad_launch(const dss2_wgrad_args* ap, void* stream);
 extern "C" int dss2_wgrad(const dss2_wgrad_args* ap, void* stream) {
+  if (!ap) { dss2::set_error("dss2_wgrad: null argument"); return 2; }
+  DSS2_RECORD([a = *ap](void* s_) { return dss2_wgrad_launch(&a, s_); });
+  return dss2_wgrad_launch(ap, stream);
+}
+static int dss2_wgrad_launch(const dss2_wgrad_args* ap, void* stream) {
   dss2::WgradBatch wb = {};
   return wgrad_dispatch(*ap, stream, wb);
 }
 
-extern "C" int dss2_wgrad_batched(const dss2_wgrad_args* ap, const float* const* Gs, const float* const* Xs, float* const* slabs,
-                                  const float* const* rowscale2s, int64_t slab_stride, int n_layers, void* stream) {
+static int dss2_wgrad_batched_launch(const dss2_wgrad_args* ap, const float* const* Gs, const float* const* Xs, float* const* slabs, const float* const* rowscale2s, int64_t slab_stride, int n_layers, void* stream);
+extern "C" int dss2_wgrad_batched(const dss2_wgrad_args* ap, const float* const* Gs, const float* const* Xs, float* const* slabs, const float* const* rowscale2s, int64_t slab_stride, int n_layers, void* stream) {
+  if (!ap) { dss2::set_error("dss2_wgrad_batched: null argument"); return 2; }
+  DSS2_RECORD([a = *ap, g = dss2::plan_keep(Gs, (size_t)(n_layers > 0 ? n_layers : 0)), x = dss2::plan_keep(Xs, (size_t)(n_layers > 0 ? n_layers : 0)), sl = dss2::plan_keep(slabs, (size_t)(n_layers > 0 ? n_layers : 0)), r = dss2::plan_keep(rowscale2s, (size_t)(rowscale2s && n_layers > 0 ? n_layers : 0)), slab_stride, n_layers](void* s_) { return dss2_wgrad_batched_launch(&a, dss2::plan_ptr(g), dss2::plan_ptr(x), dss2::plan_ptr(sl), dss2::plan_ptr(r), slab_stride, n_layers, s_); });
+  return dss2_wgrad_batched_launch(ap, Gs, Xs, slabs, rowscale2s, slab_stride, n_layers, stream);
+}
+static int dss2_wgrad_batched_launch(const dss2_wgrad_args* ap, const float* const* Gs, const float* const* Xs, float* const* slabs, const float* const* rowscale2s, int64_t slab_stride, int n_layers, void* stream) {
   if (n_layers < 1 || n_layers > dss2::WGRAD_MAX_BATCH) { dss2::set_error("wgrad_batched: 1..%d layers, got %d", dss2::WGRAD_MAX_BATCH, n_layers); return 2; }
   if (!Gs || !Xs || !slabs) { dss2::set_error("wgrad_batched: null pointer table"); return 2; }
   dss2::WgradBatch wb = {};

@@ -422,8 +422,13 @@ extern "C" int dss2_wgrad_xp_y_slices(int hout, int hin) {
   return ((hout + dss2::W16P_ZC - 1) / dss2::W16P_ZC) * ((hin + dss2::W16P_XW - 1) / dss2::W16P_XW);
 }
 
-extern "C" int dss2_wgrad_batched_xp(const dss2_wgrad_args* ap, const float* const* Gs, const void* const* Xps, float* slab,
-                                     int64_t slab_len, const float* const* rowscale2s, int n_layers, int n_wg, void* stream) {
+static int dss2_wgrad_batched_xp_launch(const dss2_wgrad_args* ap, const float* const* Gs, const void* const* Xps, float* slab, int64_t slab_len, const float* const* rowscale2s, int n_layers, int n_wg, void* stream);
+extern "C" int dss2_wgrad_batched_xp(const dss2_wgrad_args* ap, const float* const* Gs, const void* const* Xps, float* slab, int64_t slab_len, const float* const* rowscale2s, int n_layers, int n_wg, void* stream) {
+  if (!ap) { dss2::set_error("dss2_wgrad_batched_xp: null argument"); return 2; }
+  DSS2_RECORD([a = *ap, g = dss2::plan_keep(Gs, (size_t)(n_layers > 0 ? n_layers : 0)), x = dss2::plan_keep(Xps, (size_t)(n_layers > 0 ? n_layers : 0)), slab, slab_len, r = dss2::plan_keep(rowscale2s, (size_t)(rowscale2s && n_layers > 0 ? n_layers : 0)), n_layers, n_wg](void* s_) { return dss2_wgrad_batched_xp_launch(&a, dss2::plan_ptr(g), dss2::plan_ptr(x), slab, slab_len, dss2::plan_ptr(r), n_layers, n_wg, s_); });
+  return dss2_wgrad_batched_xp_launch(ap, Gs, Xps, slab, slab_len, rowscale2s, n_layers, n_wg, stream);
+}
+static int dss2_wgrad_batched_xp_launch(const dss2_wgrad_args* ap, const float* const* Gs, const void* const* Xps, float* slab, int64_t slab_len, const float* const* rowscale2s, int n_layers, int n_wg, void* stream) {
   using namespace dss2;
   if (n_layers < 1 || n_layers > WGRAD_MAX_BATCH) { set_error("wgrad_batched_xp: 1..%d layers, got %d", WGRAD_MAX_BATCH, n_layers); return 2; }
   if (!ap || !Gs || !Xps || !slab || n_wg < 1) { set_error("wgrad_batched_xp: null pointer / no workgroups"); return 2; }

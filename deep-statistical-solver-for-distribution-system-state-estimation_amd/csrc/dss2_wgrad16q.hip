@@ -20,7 +20,7 @@
 //     B2:  MFMA (t, chunk 1), matrix 2            ||  planes of (t + 1, chunk 0)
 // Plane building is split by wave role: waves 0-3 split the chunk's G and P G rows, waves 4-7 gather and split P^2 G (as
 // wgrad16t_kernel).  The last tile of a range "stages" itself again instead of branching (every slot is one basic block).
-// Covered: 64-row tiles, hout % 64 == 0, hin % 128 == 0, K <= 2, ELL slices <= 8 wide; everything else: wgrad16p_kernel.
+// Covered: 64-row tiles, hout % 64 == 0, hin % 128 == 0, K = 2, ELL slices <= 4 wide; everything else: wgrad16p_kernel.
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
@@ -493,7 +493,7 @@ size_t wgrad16q_lds_bytes(int nmat, int ell_width) {
 
 bool wgrad16q_covers(int nrb, int nmat, int hout, int hin, int ell_width) {
   static const int on = [] { const char* e = getenv("DSS2_WGRAD_XQ"); return e ? atoi(e) : 1; }();
-  return on && nrb == 2 && nmat == 3 && ell_width >= 1 && ell_width <= 8 && hout >= 64 && (hout & 63) == 0 && hin >= 128 && (hin & 127) == 0 &&
+  return on && nrb == 2 && nmat == 3 && ell_width >= 1 && ell_width <= 4 && hout >= 64 && (hout & 63) == 0 && hin >= 128 && (hin & 127) == 0 &&
          wgrad16q_lds_bytes(nmat, ell_width) <= (size_t)kMaxLdsBytes;
 }
 
@@ -510,8 +510,8 @@ static int launch16q(const dss2_wgrad_args& a, const WgradPlanes& wp, int n_wg, 
 int launch_wgrad16q(const dss2_wgrad_args& a, const WgradPlanes& wp, int n_wg, hipStream_t stream) {
   bool rs2 = false;
   for (int l = 0; l < wp.n_layers; ++l) rs2 = rs2 || wp.rowscale2[l] != nullptr;
-  if (a.ell_width <= 4) return rs2 ? launch16q<true, 4>(a, wp, n_wg, stream) : launch16q<false, 4>(a, wp, n_wg, stream);
-  return rs2 ? launch16q<true, 8>(a, wp, n_wg, stream) : launch16q<false, 8>(a, wp, n_wg, stream);
+  // (ELL slices of 5..8 entries -- DP = 8 -- compile, but with 15-48 spilled registers in the interleaved stream: wgrad16p_kernel serves them)
+  return rs2 ? launch16q<true, 4>(a, wp, n_wg, stream) : launch16q<false, 4>(a, wp, n_wg, stream);
 }
 
 }  // namespace dss2

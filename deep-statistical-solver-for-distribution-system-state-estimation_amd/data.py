@@ -22,9 +22,18 @@ from typing import Dict, Optional
 
 import torch
 
+
 from . import _lib
 from .networks import _F32, _require_gpu, _rows, _stream
 from .topology import Topology, get_topology
+
+
+def _static_replay() -> bool:
+    """True while the step is being captured into a hipGraph or recorded into a launch plan (graphs.PlannedStep): by-value seeds /
+    cached batch constants must not be baked in -- the device-side state is used instead."""
+    from .graphs import plan_recording
+    return plan_recording() or torch.cuda.is_current_stream_capturing()
+
 
 _N_PARTIAL_BLOCKS = 5
 
@@ -68,7 +77,7 @@ def _vminmax_scratch(node_param: torch.Tensor):
     pointers into tensors they have just allocated, which are new cache keys, and ``invalidate_vminmax`` is there for callers
     that refill a tensor through the C ABI.)"""
     import weakref
-    if torch.cuda.is_current_stream_capturing():
+    if _static_replay():
         # a capture executes nothing and its replays run on whatever the static input holds by then: the captured step
         # always carries its own vminmax launch and never reads or fills the cache (ADVICE r3)
         return torch.empty(130, dtype=_F32, device=node_param.device), False

@@ -13,6 +13,14 @@ from . import _lib
 from . import flags as FL
 from .topology import Topology
 
+
+def _static_replay() -> bool:
+    """True while the step is being captured into a hipGraph or recorded into a launch plan (graphs.PlannedStep): by-value seeds /
+    cached batch constants must not be baked in -- the device-side state is used instead."""
+    from .graphs import plan_recording
+    return plan_recording() or torch.cuda.is_current_stream_capturing()
+
+
 _F32 = torch.float32
 
 
@@ -462,7 +470,7 @@ def dropout_snapshot(mod: nn.Module, device) -> torch.Tensor:
     if st is None or st.device != device:
         st = mod._rng_state = torch.tensor([host_seed ^ 0x5DEECE66D, 0], dtype=torch.int64).to(device)
     snap = torch.empty(2, dtype=torch.int64, device=device)
-    capturing = torch.cuda.is_current_stream_capturing()
+    capturing = _static_replay()
     _lib.check(_lib.lib().dss2_rng_next(st.data_ptr(), snap.data_ptr(), host_seed, int(not capturing),
                                         _lib.stream_ptr(device)), "dss2_rng_next")
     return snap

@@ -15,7 +15,16 @@ from typing import List, Optional, Sequence
 import numpy as np
 import torch
 
+
 from . import _lib
+
+
+def _static_replay() -> bool:
+    """True while the step is being captured into a hipGraph or recorded into a launch plan (graphs.PlannedStep): by-value seeds /
+    cached batch constants must not be baked in -- the device-side state is used instead."""
+    from .graphs import plan_recording
+    return plan_recording() or torch.cuda.is_current_stream_capturing()
+
 
 _F32 = torch.float32
 STACK_KERNEL = _os.environ.get("DSS2_STACK_KERNEL", "1") == "1"
@@ -187,7 +196,7 @@ class _FusedStackFn(torch.autograd.Function):
             if plan.rng_state is None:
                 plan.rng_state = torch.tensor([host_seed ^ 0x5DEECE66D, 0], dtype=torch.int64).to(dev)
             snap = torch.empty(2, dtype=torch.int64, device=dev)
-            capturing = torch.cuda.is_current_stream_capturing()
+            capturing = _static_replay()
         acts = torch.empty(NB, n_hh + 1, N, 32, dtype=_F32, device=dev)
         xs = torch.empty(NB, N, 8, dtype=_F32, device=dev) if NB > 1 else None
         out = torch.empty(N, dims.dout_last, dtype=_F32, device=dev)

@@ -50,6 +50,24 @@ int dss2_version(void);
  * out3 must be zeroed by the caller; one 24-byte device-to-host copy replaces the reference's per-forward sync. */
 int dss2_topology_probe(const int64_t* edge_index, int64_t n_edges, uint64_t* out3, void* stream);
 
+/* ---- launch plans (round 5): one C call per step where a step cannot be captured into a hipGraph ----------------------------- *
+ * The reference's training loop runs its step from Python batch after batch (/root/reference/dss2_run.py:134-144).  Here a step is *
+ * ~14-60 launches through this C ABI, and the Python around every launch (argument structs, tensor bookkeeping, autograd) costs     *
+ * ~20 us of host time: small configurations are host-bound (C1: 0.29 ms eager against 0.10 ms as a hipGraph replay).  A plan is the *
+ * library's own record of a step: between dss2_plan_begin and dss2_plan_end EVERY launch entry point of this header (all threads:    *
+ * autograd runs the backward on its own) still launches, and also appends itself -- bound to copies of its host-side argument        *
+ * structs and tables -- to the plan; dss2_plan_run(plan, stream) then re-issues the same launches, in order, on `stream`, from ONE  *
+ * C call.  Same contract as a hipGraph replay: the recorded device pointers must stay valid (record the step on tensors that        *
+ * live as long as the plan, e.g. inside a private memory pool), by-value scalars are frozen (use the device-side step counter of    *
+ * dss2_adamax_step_flat / _dev and use_host_seed = 0 of dss2_rng_next, as under capture).  Only launches of this library are         *
+ * recorded.  One plan records at a time (process-wide).                                                                              */
+typedef struct dss2_plan dss2_plan;
+int dss2_plan_begin(dss2_plan** out);
+int dss2_plan_end(dss2_plan* plan);
+int dss2_plan_size(const dss2_plan* plan);                /* recorded launches */
+int dss2_plan_run(const dss2_plan* plan, void* stream);
+void dss2_plan_destroy(dss2_plan* plan);
+
 /* ---- dss2_csr_build: the whole per-topology structure on the device, no host round trip.
  * Replaces MPN.undirect_graph's concatenations (networks.py:240-258), PyG gcn_norm / degree (per TAGConv call) and the
  * index handling of PyG's scatter: counting sort of the directed edge list by target, by source, and of the stored

@@ -1,11 +1,11 @@
-mkdir -p gpurun_out/r05n
-python -m pytest tests/test_gpu_bf16x6.py tests/test_gpu_xplanes.py tests/test_gpu_rccl.py -x -q -m gpu > gpurun_out/r05n/gpu_part.log 2>&1; tail -3 gpurun_out/r05n/gpu_part.log
-B="--no-cpu-baseline --no-other-configs --min-window-seconds 2 --ramp-seconds 1.5"
-for v in 0 1 0 1; do DSS2_WGRAD_RANGES=$v python bench.py $B > gpurun_out/r05n/bench_rg${v}_$RANDOM.json 2>/dev/null; done
+mkdir -p gpurun_out/r05q
+python -m pytest tests/test_gpu_plan.py -x -q -m gpu > gpurun_out/r05q/plan.log 2>&1; tail -25 gpurun_out/r05q/plan.log | cut -c1-220
+python bench.py --no-cpu-baseline --min-window-seconds 1.5 --ramp-seconds 1 --other-seconds 0.7 > gpurun_out/r05q/bench.json 2> gpurun_out/r05q/bench.err
 python - <<'PY'
-import json,glob
-for f in sorted(glob.glob('gpurun_out/r05n/bench_*.json')):
-    try:
-        d=json.load(open(f)); print(f, round(d['ms_per_step'],4), d['config']['ms_per_step_by_mode'], 'chain', round(d['roofline']['avg_launch_us'],1), 'wgrad', d.get('roofline_wgrad',{}).get('avg_launch_us'))
-    except Exception as e: print(f, 'ERR', e)
+import json
+d=json.load(open('gpurun_out/r05q/bench.json'))
+print(d['ms_per_step'], d['config']['ms_per_step_by_mode'])
+for k,v in d.get('other_configs',{}).items():
+    print(k[:40], {kk: (round(vv,4) if isinstance(vv,float) else vv) for kk,vv in v.items() if kk.startswith('ms_per') or kk in ('plan_launches','plan_error','skipped','replay_error')})
 PY
+tail -3 gpurun_out/r05q/bench.err
