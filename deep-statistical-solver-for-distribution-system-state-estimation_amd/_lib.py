@@ -193,7 +193,7 @@ _SIGNATURES = {
                                      C.c_void_p]),
     "dss2_edge_tile_fwd_xp": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                        C.c_void_p, C.c_void_p]),
+                                        C.c_void_p, C.c_int, C.c_void_p]),
     "dss2_edge_tile_fwd_xp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "dss2_edge_tile_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

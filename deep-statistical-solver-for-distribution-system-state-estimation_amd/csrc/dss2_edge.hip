@@ -915,15 +915,15 @@ extern "C" int dss2_edge_tile_fwd_xp_supported(int nrb, int h, int ell_width) {
 extern "C" int dss2_edge_tile_fwd(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1,
                                   const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width,
                                   int nrb, int ntiles, float* S, int h, int fn, int fe, void* stream) {
-  return dss2_edge_tile_fwd_xp(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, nullptr, stream);
+  return dss2_edge_tile_fwd_xp(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, nullptr, 0, stream);
 }
 
-static int dss2_edge_tile_fwd_xp_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, void* stream);
-extern "C" int dss2_edge_tile_fwd_xp(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, void* stream) {
-  DSS2_RECORD([x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, x_planes](void* s_) { return dss2_edge_tile_fwd_xp_launch(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, x_planes, s_); });
-  return dss2_edge_tile_fwd_xp_launch(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, x_planes, stream);
+static int dss2_edge_tile_fwd_xp_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, int bwd_with_u, void* stream);
+extern "C" int dss2_edge_tile_fwd_xp(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, int bwd_with_u, void* stream) {
+  DSS2_RECORD([x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, x_planes, bwd_with_u](void* s_) { return dss2_edge_tile_fwd_xp_launch(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, x_planes, bwd_with_u, s_); });
+  return dss2_edge_tile_fwd_xp_launch(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, x_planes, bwd_with_u, stream);
 }
-static int dss2_edge_tile_fwd_xp_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, void* stream) {
+static int dss2_edge_tile_fwd_xp_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, int bwd_with_u, void* stream) {
   if (fn != FN || fe != FE) { set_error("edge_tile_fwd: only dim_featn=8, dim_feate=6 are built (got %d, %d)", fn, fe); return 2; }
   if (h <= 0 || h > 256 || ell_width <= 0 || ell_width > 32) { set_error("edge_tile_fwd: bad h=%d or ell_width=%d", h, ell_width); return 2; }
   if (x_planes && !dss2_edge_tile_fwd_xp_supported(nrb, h, ell_width)) {
@@ -932,7 +932,12 @@ static int dss2_edge_tile_fwd_xp_launch(const float* x, int64_t ldx, const float
   if (ntiles <= 0) return 0;
   EdgeTileArgs a{x, ldx, ea, ldea, W1, b1, nullptr, tile_start, reinterpret_cast<const int2*>(ell_ent), S, nullptr, nullptr, 0,
                  h, ell_width, nrb * 32, 0, ntiles, x_planes};
-  if (edge_mfma_ok(h, nrb, ell_width)) {
+  // The backward recomputes the ReLU gates, so forward and backward must run the same arithmetic.  dss2_edge_tile_bwd with U on 96-row
+  // tiles runs the VALU tile kernel (neither matrix-pipe backward is built for it): a caller that announces such a backward gets the
+  // VALU tile forward.
+  const bool valu_pair = bwd_with_u && nrb == 3;
+  if (x_planes && valu_pair) { set_error("edge_tile_fwd_xp: x_planes with a backward that needs U on 96-row tiles is not built"); return 2; }
+  if (edge_mfma_ok(h, nrb, ell_width) && !valu_pair) {
     // first Linear as bf16x6 on the bf16 matrix pipe (dss2_edge16.hip; DSS2_EDGE_BF16=0: the fp32 MFMA form below)
     if (edge16_ok(h, nrb, ell_width, false, false)) return launch_edge16(a, nrb, ntiles, false, as_stream(stream));
     return dispatch_edge_mfma(a, nrb, ntiles, false, as_stream(stream));

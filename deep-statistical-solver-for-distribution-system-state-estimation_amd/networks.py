@@ -40,14 +40,15 @@ from .plans import (_DESC_DTYPE, _FoldPlan, _MatView, _PackPlan, _SG_DTYPE, _as_
 # ------------------------------------------------------------------------------------------
 # functional pieces (raw tensors in, raw tensors out); used by the autograd Functions below
 # ------------------------------------------------------------------------------------------
-def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hout, fn, fe, second_linear=True, xp=None):
-    """xp: an X plane image (ops.new_xplanes) that receives S as well (its consumer's weight gradient reads it)."""
+def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hout, fn, fe, second_linear=True, xp=None, need_dx=False):
+    """xp: an X plane image (ops.new_xplanes) that receives S as well (its consumer's weight gradient reads it).  need_dx: the backward
+    will be asked for the gradient w.r.t. x (the library then picks the forward whose gates that backward recomputes exactly)."""
     N = topo.N
     S = torch.empty(N, hid, dtype=_F32, device=W1.device)
     if topo.ell_ent_tiles is not None and FL.EDGE_TILE_KERNELS:
         _lib.check(_lib.lib().dss2_edge_tile_fwd_xp(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(),
                                                     topo.tile_start.data_ptr(), topo.ell_ent_tiles.data_ptr(), topo.ell,
-                                                    topo.nrb, topo.ntiles, S.data_ptr(), hid, fn, fe, _ptr(xp), _stream(S)),
+                                                    topo.nrb, topo.ntiles, S.data_ptr(), hid, fn, fe, _ptr(xp), int(bool(need_dx)), _stream(S)),
                    "dss2_edge_tile_fwd_xp")
     else:   # general graphs (hub nodes beyond the ELL width): row-per-wave kernel on the CSR
         _lib.check(_lib.lib().dss2_edge_hidden_fwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(),
@@ -407,7 +408,7 @@ class _EdgeAggrFn(torch.autograd.Function):
         ctx.ver = mod._plan.refresh()
         topo.lds_check(1, _round8(mod.dim_hid), _ncg(mod.dim_out))
         S, x0 = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, mod._plan.fwd[0], mod.dim_hid, mod.dim_out,
-                                   mod.dim_featn, mod.dim_feate)
+                                   mod.dim_featn, mod.dim_feate, need_dx=ctx.needs_input_grad[0])
         ctx.save_for_backward(x, ea, S, W1, b1)
         ctx.topo, ctx.mod, ctx.ld = topo, mod, (ldx, ldea)
         return x0
@@ -563,7 +564,7 @@ def _ensure_plans(mod, topo, dev, ps):
     return mod._plan, mod._fold, glob
 
 
-def _mpn_forward(mod, topo, x, ea, ps, stack=None):
+def _mpn_forward(mod, topo, x, ea, ps, stack=None, need_dx=False):
     """One MPN block forward on raw tensors.  ``stack`` (a _StackRun, PFN / SkipPFN): the weight packing, the fold and the
     dropout snapshot were already done for all blocks of the stack in one launch each.
     Returns (out, tensors to keep for backward, meta)."""
@@ -594,7 +595,7 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None):
                   and chain_supported(topo, nmat, hid, True, True) and chain16_supported(topo, nmat, hid, True))
     xps = [new_xplanes(topo, hid, dev) for _ in range(n_chain)] if use_xp else []
     S, h = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, plan.fwd[0], hid, hid, mod.dim_featn, mod.dim_feate,
-                              second_linear=fold is None, xp=(xps[0] if use_xp else None))
+                              second_linear=fold is None, xp=(xps[0] if use_xp else None), need_dx=need_dx)
     if fold is not None:
         h = S            # conv 0 consumes the aggregated hidden directly
     acts = [h]
@@ -831,7 +832,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
 class _MPNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ea, topo, mod, *ps):
-        out, saved, meta = _mpn_forward(mod, topo, x, ea, ps)
+        out, saved, meta = _mpn_forward(mod, topo, x, ea, ps, need_dx=ctx.needs_input_grad[0])
         ctx.save_for_backward(*saved, *ps)
         ctx.meta = (topo, mod, meta, len(saved))
         return out
@@ -920,8 +921,8 @@ class _PFNFn(torch.autograd.Function):
         snap = dropout_snapshot(pfn, dev) if float(pfn.dropout_rate) > 0.0 else None
         run = _StackRun(sp, snap)
         saved, metas, counts = [], [], []
-        for m, bp in zip(blocks, params):
-            x, sv, meta = _mpn_forward(m, topo, x, ea, bp, stack=run)
+        for bi, (m, bp) in enumerate(zip(blocks, params)):
+            x, sv, meta = _mpn_forward(m, topo, x, ea, bp, stack=run, need_dx=(bi > 0 or ctx.needs_input_grad[0]))
             saved += sv
             metas.append(meta)
             counts.append(len(sv))

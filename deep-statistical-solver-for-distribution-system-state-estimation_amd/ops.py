@@ -230,8 +230,13 @@ def _wgrad_tiles(topo: Topology, nmat: int, hout: int, hin: int, b16: int):
     if (FL.WGRAD_TM32 and b16 and topo.nrb == 2 and not topo.global_only and nmat in (2, 3) and hout > 32 and 1 <= topo.ellT <= 8
             and topo.N * hin * 4 <= FL.WGRAD_TM32_MAX_BYTES):
         alt = topo.tiles_for(1)
+        # ... and only where the library's bf16x6 kernel covers the shape on that tiling (its LDS query answers with the fp32 kernel's
+        # size when it does not: hout % 4, hin % 4, hout > 32, K <= 2 -- the conditions live in ONE place, wgrad16_covers)
         if alt is not None and alt.ellT_tiles is not None and 1 <= alt.ellT <= 8:
-            return alt
+            L_ = _lib.lib()
+            if (L_.dss2_wgrad_lds_bytes_ex(1, nmat, hout, hin, alt.max_nnzT, alt.ellT, 1)
+                    != L_.dss2_wgrad_lds_bytes_ex(1, nmat, hout, hin, alt.max_nnzT, alt.ellT, 0)):
+                return alt
     return topo
 
 

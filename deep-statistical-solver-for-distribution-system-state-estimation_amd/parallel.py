@@ -211,7 +211,9 @@ def attach_grad_allreduce(model: torch.nn.Module, group=None, async_op: bool = F
     def param_hook(grad, g=group):
         # parameters whose gradients are NOT produced in a flat bucket: one blocking collective per parameter on this
         # backward's contribution, before autograd accumulates it (correct under gradient accumulation as well)
-        grad = grad.contiguous()
+        # (a reduced COPY is returned: the hook's input may be shared with other consumers of the same autograd edge, ADVICE r4.  These
+        #  are the parameters off the tuned path -- a few small blocking collectives per step, not coalesced)
+        grad = grad.clone(memory_format=torch.contiguous_format)
         allreduce_flat_grads(grad, g, None)
         return grad
 

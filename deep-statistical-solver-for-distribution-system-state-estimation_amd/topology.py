@@ -182,6 +182,8 @@ class Topology:
         # an alternate tiling works on a copy of the statistics words (the walk and the ELL build write per-tiling maxima
         # into them): the primary tiling's statistics stay what they were
         meta = self._meta if store else self._meta.clone()
+        if not store:
+            meta[5:8].zero_()      # (error flag and per-tile maxima are THIS tiling's own: not the primary's carried over)
 
         def read_stats():
             if store:
@@ -249,6 +251,8 @@ class Topology:
         b.ellT_tiles, b.ellT_ent_tiles = (ellT_tiles.data_ptr() if ellT else None), (ellT_ent_tiles.data_ptr() if ellT else None)
         b.meta = meta.data_ptr()
         _lib.check(L.dss2_ell_tiles_build(C.byref(b), st), "dss2_ell_tiles_build")
+        if not store and hint is not None and os.environ.get("DSS2_CHECK", "0") == "1":
+            read_stats()      # (the hint path reads nothing back: with DSS2_CHECK the alternate build's error flag is read too)
         if exact_nnz and (ell == 0 or ellT == 0):      # CSR staging in the tile kernels (hub graphs): exact sizes needed
             s = read_stats()
             max_nnz, max_nnzT = s["max_nnz"], s["max_nnzT"]

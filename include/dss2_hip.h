@@ -202,10 +202,12 @@ int dss2_edge_tile_fwd(const float* x, int64_t ldx, const float* ea, int64_t lde
                        int nrb, int ntiles, float* S, int h, int fn, int fe, void* stream);
 /* dss2_edge_tile_fwd that additionally writes S as an X plane image (see dss2_xplanes_bytes; the weight gradient of the layer that
  * consumes S reads it).  x_planes == NULL: exactly dss2_edge_tile_fwd.  Non-NULL needs 64-row tiles, h % 32 == 0 and the bf16x6
- * form (dss2_edge_tile_fwd_xp_supported). */
+ * form (dss2_edge_tile_fwd_xp_supported).  bwd_with_u != 0: the caller's dss2_edge_tile_bwd will be asked for U (the gradient
+ * w.r.t. x): the forward then takes the arithmetic that backward recomputes its ReLU gates with (on 96-row tiles the fp32 MFMA form:
+ * the bf16x6 backward with U is not built there). */
 int dss2_edge_tile_fwd_xp(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1,
                           const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width,
-                          int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, void* stream);
+                          int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, int bwd_with_u, void* stream);
 int dss2_edge_tile_fwd_xp_supported(int nrb, int h, int ell_width);
 int dss2_edge_tile_bwd(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1,
                        const float* b1, const float* dS, const int32_t* tile_start, const void* ell_ent,
