@@ -355,6 +355,7 @@ def main():
     nw_mod = pkg.networks
     orig_chain, orig_single = nw_mod.gemm_prop_chain, nw_mod.gemm_prop
 
+    by_dir = {}                 # average launch time (us) of the forward chain / of the data-gradient chain
     head_launches = [0, 0]      # chained launches that carry the narrow head (forward: its TAGConv; backward: its data gradient), all launches
 
     def timed_chain(topo, X, hid, nmat, layers, **kw):
@@ -362,7 +363,7 @@ def main():
         e0.record()
         orig_chain(topo, X, hid, nmat, layers, **kw)
         e1.record()
-        events.append((e0, e1, len(layers)))
+        events.append((e0, e1, len(layers), bool(kw.get("transposed", False))))
         head_launches[0] += int(kw.get("head") is not None)
         head_launches[1] += 1
 
@@ -374,7 +375,7 @@ def main():
         orig_single(topo, X, ldx, kreal, Bp, nmat, hout, Y, **kw)
         if dominant:
             e1.record()
-            events.append((e0, e1, 1))
+            events.append((e0, e1, 1, bool(kw.get("transposed", False))))
 
     wg_events = []
     orig_wgb = nw_mod.wgrad_batched
@@ -394,11 +395,26 @@ def main():
             step()
         torch.cuda.synchronize()
         nw_mod.gemm_prop_chain, nw_mod.gemm_prop, nw_mod.wgrad_batched = orig_chain, orig_single, orig_wgb
-        durs = sorted(a.elapsed_time(b) for a, b, _ in events)
-        layers = sum(n for _, _, n in events)
+        durs = sorted(a.elapsed_time(b) for a, b, _, _ in events)
+        layers = sum(n for _, _, n, _ in events)
+        by_dir.clear()
+        for tr in (False, True):
+            d = [a.elapsed_time(b) for a, b, _, t in events if t == tr]
+            if d:
+                by_dir["data-gradient chain" if tr else "forward chain"] = sum(d) / len(d) * 1e3
         return sum(durs) / len(durs), durs[len(durs) // 2], len(durs), layers / len(durs)
 
-    avg_ms, med_ms, n_l, layers_per_launch = timed_pass(min(args.steps, 20))
+    # the clock the chip HOLDS under the dominant kernel: the split-plane chain leaves {s_memtime, s_memrealtime} at the
+    # start and the end of four of its workgroups (dss2_debug_chain_clock_probe; off outside this pass): shader cycles per 100 MHz tick
+    probe = torch.zeros(16, dtype=torch.int64, device=dev)
+    pkg._lib.lib().dss2_debug_chain_clock_probe(probe.data_ptr())
+    try:
+        avg_ms, med_ms, n_l, layers_per_launch = timed_pass(min(args.steps, 20))
+    finally:
+        pkg._lib.lib().dss2_debug_chain_clock_probe(None)
+    pr = probe.cpu().view(4, 4).tolist()
+    clocks = [(q[2] - q[0]) / float(q[3] - q[1]) * 0.1 for q in pr if q[3] > q[1] and q[2] > q[0]]
+    held_clock_ghz = (sum(clocks) / len(clocks)) if clocks else None
 
 
     if rank == 0:
@@ -441,6 +457,7 @@ def main():
             "launches_timed": n_l, "layers_per_launch": layers_per_launch, "avg_launch_us": avg_ms * 1e3,
             "median_launch_us": med_ms * 1e3, "algorithmic_flops_per_launch": flops,
             "head_flops_per_launch_included": head_flops, "launches_with_fused_head": head_frac,
+            "avg_launch_us_by_direction": dict(by_dir),
             "algorithmic_bytes_per_launch": 4.0 * N * HID + bytes_layer * layers_per_launch,
             "mode": "single stream",
         }
@@ -468,6 +485,13 @@ def main():
             r["frac"] = r["achieved"] / r["peak"]
             r["peak_pipe"] = "bf16 MFMA dense peak (2500 TF) / 6 instructions per fp32 product group (bf16x6)"
             r["frac_bf16_pipe"] = r["frac"]
+            if held_clock_ghz:
+                # the matrix pipe's bound scales with the clock: 2.5 PF is the figure at 2.4 GHz.  Under this kernel the chip holds less
+                # (DVFS: a cycle saved inside the kernel comes back partly as a lower clock), so two fractions are reported:
+                # `frac` against the headline peak, frac_at_held_clock against the pipe's bound at the clock the kernel actually ran at
+                r["held_clock_ghz"] = held_clock_ghz
+                r["frac_at_held_clock"] = r["frac"] * 2.4 / held_clock_ghz
+                r["held_clock_source"] = "s_memtime / s_memrealtime (100 MHz) over the life of workgroups 0, 256, 512, 768 of the last chain launch of the instrumented pass"
     # ---- the SAME step replayed as a hipGraph (graphs.GraphedStep), timed the same way; the faster mode is reported.
     # Eager: 19 launches through the C ABI per step, ~0.41 ms of host work on a quiet box (hidden by the 0.58 ms of GPU work)
     # but up to 0.8 ms on a loaded host -- and two collectives more per step when distributed -- which then bounds the step.

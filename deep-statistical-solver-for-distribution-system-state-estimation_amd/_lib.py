@@ -154,6 +154,7 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "dss2_last_error": (C.c_char_p, []),
     "dss2_version": (C.c_int, []),
+    "dss2_debug_chain_clock_probe": (None, [C.c_void_p]),
     "dss2_plan_begin": (C.c_int, [C.POINTER(C.c_void_p)]),
     "dss2_plan_end": (C.c_int, [C.c_void_p]),
     "dss2_plan_size": (C.c_int, [C.c_void_p]),

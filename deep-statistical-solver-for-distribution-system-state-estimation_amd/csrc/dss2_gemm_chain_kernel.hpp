@@ -42,7 +42,12 @@ __device__ unsigned long long g_cstamps[2048 * 8 * 64];
 #endif
 
 constexpr int CHAIN_MAX = 8;
-struct ChainTable { dss2_chain_layer l[CHAIN_MAX]; int n; };
+struct ChainTable {
+  dss2_chain_layer l[CHAIN_MAX]; int n;
+  // diagnostic, NULL in normal runs (dss2_debug_chain_clock_probe): workgroups 0, 256, 512, 768 of a split-plane chain launch leave
+  // {s_memtime, s_memrealtime} at their start and end -- shader cycles over 100 MHz ticks = the clock the chip HELD under the kernel
+  unsigned long long* clock_probe;
+};
 
 constexpr int chain_waves_per_simd(int nrb, int nmat) { return nrb * nmat * 16 <= 128 ? 2 : 1; }
 constexpr bool chain_rm(int nrb, int rs, bool b16, int nmat) { return b16 && rs == 2 && nrb == 2 && nmat <= 3; }      // (K = 3 would spill)

@@ -71,6 +71,11 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
   const int ncg = nthreads >> 6;
   const int tile = blockIdx.x;
   const uint64_t drop_seed = p.drop_state ? p.drop_state[0] : 0, drop_off = p.drop_state ? p.drop_state[1] : 0;
+  const bool probe = ct.clock_probe != nullptr && (tile & 255) == 0 && tile < 1024;      // (uniform; diagnostic, see ChainTable)
+  if (probe && tid == 0) {      // (written at once: nothing of the probe stays live across the kernel)
+    unsigned long long* q = ct.clock_probe + (tile >> 8) * 4;
+    q[0] = __builtin_amdgcn_s_memtime(); q[1] = __builtin_amdgcn_s_memrealtime();
+  }
   __bf16* xpl = reinterpret_cast<__bf16*>(smem);               // stripe s: xpl + s * (2 * SP_REGION)
   int2* ell = reinterpret_cast<int2*>(smem + ncg * SP_REGION);
   const int D = p.ell_width;
@@ -638,6 +643,10 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
     CSTAMP(2 + li * 6 + 4);
     if (!keep) CSTAMP_RT(63);
   }
+  if (probe && tid == 0) {
+    unsigned long long* q = ct.clock_probe + (tile >> 8) * 4;
+    q[2] = __builtin_amdgcn_s_memtime(); q[3] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 inline size_t chain_sp_lds_bytes(int ncg, int ell_width) { return (size_t)ncg * SP_REGION * 4 + (size_t)SP_TM * ell_width * 8; }
@@ -672,15 +681,24 @@ static int launch_sp_hm(const dss2_gemm_prop_args& a, const ChainTable& ct, cons
   return a.ncg <= 4 ? launch_sp<3, 4, HM, 0>(a, ct, hd, s) : launch_sp<3, 8, HM, 0>(a, ct, hd, s);      // (K = 3 would spill: chain_sp_supported says no)
 }
 
-int launch_chain_sp(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head* head, hipStream_t s) {
+static std::atomic<unsigned long long*> g_chain_clock_probe{nullptr};
+
+int launch_chain_sp(const dss2_gemm_prop_args& a, const ChainTable& ct_in, const dss2_chain_head* head, hipStream_t s) {
   dss2_chain_head hd = {};
   if (head) hd = *head;
+  ChainTable ct = ct_in;
+  ct.clock_probe = g_chain_clock_probe.load(std::memory_order_relaxed);
   if (hd.mode == 1) return launch_sp_hm<1>(a, ct, hd, s);
   if (hd.mode == 2) return launch_sp_hm<2>(a, ct, hd, s);
   return launch_sp_hm<0>(a, ct, hd, s);
 }
 
 }  // namespace dss2
+
+// Diagnostic (bench.py's held_clock_ghz): probe != NULL -> every later split-plane chain launch of 64-row tiles writes four records of
+// {s_memtime at start, s_memrealtime at start, s_memtime at end, s_memrealtime at end} (16 uint64, device memory) -- workgroups 0, 256,
+// 512 and 768; NULL switches it off again.  The records of the LAST launch stay in the buffer.
+extern "C" void dss2_debug_chain_clock_probe(unsigned long long* probe) { dss2::g_chain_clock_probe.store(probe, std::memory_order_relaxed); }
 
 #ifdef DSS2_CHAIN_STAMPS
 extern "C" int dss2_debug_read_cstamps_sp(unsigned long long* host_out, int n) {

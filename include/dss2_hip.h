@@ -325,6 +325,11 @@ int dss2_gemm_prop_chain16_supported(int nrb, int nmat, int kreal, int hout, int
  * matrix-sequentially with the X tile staged in two K halves; same bf16x6 arithmetic as the chain. */
 int dss2_gemm_prop16_supported(int nrb, int nmat, int kreal, int hout, int max_nnz, int ell_width);
 
+/* Diagnostic: the clock the chip holds under the dominant kernel.  probe != NULL (16 uint64 of device memory): every later split-plane
+ * chain launch on 64-row tiles leaves {s_memtime, s_memrealtime} at the start and at the end of its workgroups 0, 256, 512, 768;
+ * shader cycles over 100 MHz ticks = the in-kernel clock (bench.py: roofline.held_clock_ghz).  NULL: off (the default). */
+void dss2_debug_chain_clock_probe(unsigned long long* probe);
+
 /* ---- dropout random state.  state[2] = persistent device {seed, offset}; snapshot[2] <- the pair this forward call's
  * kernels (forward AND backward) read.  use_host_seed != 0: snapshot = {host_seed, 0} (eager mode: the host draws the seed
  * from torch's generator, so torch.manual_seed reproduces); 0: snapshot = {state.seed, state.offset++} (inside a hipGraph

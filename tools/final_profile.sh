@@ -56,16 +56,16 @@ CHAINBENCH_BF16=0 CHAINBENCH_STEP=0 python3 tools/chainbench.py > $O/chainbench_
 python3 tools/accuracy_bf16x6.py > $O/accuracy_bf16x6.txt 2>&1
 bash tools/driverline_trace.sh 64 > /dev/null 2>&1; cp $R/gpurun_out/driverline_trace_B64.txt $O/ 2>/dev/null
 bash tools/driverline_trace.sh 4096 > /dev/null 2>&1; cp $R/gpurun_out/driverline_trace_B4096.txt $O/ 2>/dev/null
-# phase stamps of the whole-stack kernels (needs the diagnostic build tools/diag_lib/libdss2_sstamps.so, see tools/sstamps.py)
+# phase stamps of the whole-stack kernels (needs the diagnostic build tools/diag_lib/libdss2_sstamps.so, see tools/stamps.py)
 P=$R/deep-statistical-solver-for-distribution-system-state-estimation_amd
 if [ -f tools/diag_lib/libdss2_sstamps.so ]; then
-  DSS2_LIB=tools/diag_lib/libdss2_sstamps.so python3 tools/sstamps.py 64 2>&1 | grep -v amdgpu > $O/stack_stamps_B64.txt
-  DSS2_LIB=tools/diag_lib/libdss2_sstamps.so python3 tools/sstamps.py 4096 2>&1 | grep -v amdgpu > $O/stack_stamps_B4096.txt
+  DSS2_LIB=tools/diag_lib/libdss2_sstamps.so python3 tools/stamps.py stack 64 2>&1 | grep -v amdgpu > $O/stack_stamps_B64.txt
+  DSS2_LIB=tools/diag_lib/libdss2_sstamps.so python3 tools/stamps.py stack 4096 2>&1 | grep -v amdgpu > $O/stack_stamps_B4096.txt
 fi
-# phase stamps of the split-plane layer chain (needs tools/diag_lib/libdss2_cstamps.so, see tools/cstamps.py)
+# phase stamps of the split-plane layer chain (needs tools/diag_lib/libdss2_cstamps.so, see tools/stamps.py)
 if [ -f tools/diag_lib/libdss2_cstamps.so ]; then
-  DSS2_LIB=tools/diag_lib/libdss2_cstamps.so python3 tools/cstamps.py 1024 2>&1 | grep -v amdgpu > $O/chain_stamps_B1024.txt
-  DSS2_LIB=tools/diag_lib/libdss2_cstamps.so python3 tools/cstamps.py 4096 2>&1 | grep -v amdgpu > $O/chain_stamps_B4096.txt
+  DSS2_LIB=tools/diag_lib/libdss2_cstamps.so python3 tools/stamps.py chain 1024 2>&1 | grep -v amdgpu > $O/chain_stamps_B1024.txt
+  DSS2_LIB=tools/diag_lib/libdss2_cstamps.so python3 tools/stamps.py chain 4096 2>&1 | grep -v amdgpu > $O/chain_stamps_B4096.txt
 fi
 # the packed-fp32 reproducer (tools/micro/pkfma_beside_mfma.hip) and the 200-launch stress of the real kernel
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/pkfma_beside_mfma.hip -o /tmp/pkfma 2>/dev/null && /tmp/pkfma > $O/pkfma_micro.txt 2>&1

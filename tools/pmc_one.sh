@@ -28,5 +28,7 @@ for k,d in agg.items():
     g=d.get("GRBM_GUI_ACTIVE"); m=d.get("SQ_VALU_MFMA_BUSY_CYCLES")
     if g and m:
         cyc=sum(g)/len(g)/8
-        print(f"   -> kernel active cycles (GUI_ACTIVE/8) {cyc:.0f}; MFMA pipe busy {100*sum(m)/len(m)/(1024*cyc):.1f}% of SIMD-cycles; clock ~{cyc/ (dd[len(dd)//2]*1e-6)/1e9:.2f} GHz (profiled)")
+        # (GRBM_GUI_ACTIVE / 8 over the launch's wall time is NOT a clock on dispatches this short -- it read 2.7-7.9 "GHz" in round 4;
+        #  the in-kernel clock is s_memtime over wall time: bench.py's held_clock_ghz, tools/stamps.py chain)
+        print(f"   -> kernel active cycles (GUI_ACTIVE/8) {cyc:.0f}; MFMA pipe busy {100*sum(m)/len(m)/(1024*cyc):.1f}% of SIMD-cycles")
 PY
