@@ -7,6 +7,7 @@
 // scalar loads and broadcast for free; the only vector memory traffic is the coalesced S row.
 #include "dss2_common.hpp"
 #include "dss2_edge_tile.hpp"
+#include "dss2_weightspace.hpp"
 
 namespace dss2 {
 
@@ -566,69 +567,10 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restri
   if (q == 0 && j < len) out[j] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
-// several reductions in one launch (blockIdx.y = reduction): the small ones are launch/latency-bound on their own
-constexpr int REDUCE_MAX_DESC = 32;      // by-value table: 32 x 40 B of the 4 KiB kernel-argument space
-struct ReduceTable { dss2_reduce_desc d[REDUCE_MAX_DESC]; uint32_t scalar_mask; };      // bit i: reduction i lacks the alignment of the 16-byte form
-// The same reductions with 16-byte lanes: a workgroup owns 64 consecutive floats of one reduction, its 256 threads are 16 slab
-// lanes x 16 float4 columns; lane s sums slabs s, s + 16, .. (four independent loads in flight per pass), the sixteen partial
-// sums meet in LDS and are added in lane order: fixed order, bitwise reproducible.  ~2x the bytes per second of the scalar form
-// (measured on the whole-stack slabs: 124 MB in 30 us).  Needs 16-byte aligned slabs / outputs and strides divisible by 4.
-// Reductions whose slabs / outputs are not 16-byte aligned (bit in scalar_mask: e.g. what follows a 2-wide bias in a flat
-// gradient) run the scalar form inside the same launch -- one misaligned descriptor no longer sends all of them there.
+// (ReduceTable, reduce_slabs_body: dss2_weightspace.hpp)
 __global__ void __launch_bounds__(256) reduce_slabs_multi_v4_kernel(const ReduceTable tab) {
   __shared__ f32x4 part[16][16];
-  const dss2_reduce_desc& d = tab.d[blockIdx.y];
-  if ((int64_t)blockIdx.x * 64 >= d.len) return;          // uniform per workgroup
-  const int tid = threadIdx.x, cl = tid & 15, sl = tid >> 4;
-  if ((tab.scalar_mask >> blockIdx.y) & 1u) {              // (uniform) 64 columns x 4 slab quarters, as reduce_slabs_multi_kernel
-    float* sp = reinterpret_cast<float*>(part);
-    const int x = tid & 63, q = tid >> 6;
-    const int64_t j = (int64_t)blockIdx.x * 64 + x;
-    const int per = (d.n_slabs + 3) >> 2;
-    const int k0 = q * per, k1 = min(d.n_slabs, k0 + per);
-    float s = 0.f;
-    if (j < d.len) {      // (the summation order of reduce_slabs_kernel)
-      const float* p = d.slab + j;
-      int k = k0;
-      for (; k + 8 <= k1; k += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * d.stride];
-        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-      }
-      for (; k < k1; ++k) s += p[(size_t)k * d.stride];
-    }
-    sp[q * 64 + x] = s;
-    __syncthreads();
-    if (q == 0 && j < d.len) d.out[j] = (sp[x] + sp[64 + x]) + (sp[128 + x] + sp[192 + x]);
-    return;
-  }
-  const int64_t i4 = (int64_t)blockIdx.x * 64 + cl * 4;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (i4 + 4 <= d.len) {
-    int k = sl;
-#pragma unroll 1
-    for (; k + 48 < d.n_slabs; k += 64) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(d.slab + (size_t)k * d.stride + i4);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(d.slab + (size_t)(k + 16) * d.stride + i4);
-      const f32x4 c = *reinterpret_cast<const f32x4*>(d.slab + (size_t)(k + 32) * d.stride + i4);
-      const f32x4 e = *reinterpret_cast<const f32x4*>(d.slab + (size_t)(k + 48) * d.stride + i4);
-      s += a; s += b; s += c; s += e;
-    }
-    for (; k < d.n_slabs; k += 16) s += *reinterpret_cast<const f32x4*>(d.slab + (size_t)k * d.stride + i4);
-  } else if (i4 < d.len) {
-    for (int k = sl; k < d.n_slabs; k += 16)
-      for (int q = 0; i4 + q < d.len; ++q) s[q] += d.slab[(size_t)k * d.stride + i4 + q];
-  }
-  part[sl][cl] = s;
-  __syncthreads();
-  if (sl == 0 && i4 < d.len) {
-    f32x4 t = part[0][cl];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) t += part[k][cl];
-    if (i4 + 4 <= d.len) *reinterpret_cast<f32x4*>(d.out + i4) = t;
-    else for (int q = 0; i4 + q < d.len; ++q) d.out[i4 + q] = t[q];
-  }
+  reduce_slabs_body(tab.d[blockIdx.y], ((tab.scalar_mask >> blockIdx.y) & 1u) != 0, (int)blockIdx.x, part);
 }
 
 }  // namespace dss2

@@ -14,7 +14,7 @@
 //   4. bias / dropout mask / ReLU / ReLU-mask / residual, one 128-B row segment per half wave.
 #include <stdlib.h>
 
-#include "dss2_common.hpp"
+#include "dss2_weightspace.hpp"
 
 namespace dss2 {
 
@@ -22,66 +22,7 @@ namespace dss2 {
 // weight packing
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) pack_weights_kernel(const dss2_pack_desc* __restrict__ descs) {
-  const dss2_pack_desc d = descs[blockIdx.y];
-  const bool tr = d.transpose & 1;
-  const int K = tr ? d.cols : d.rows;
-  const int J = tr ? d.rows : d.cols;
-  if (d.transpose & 2) {
-    // bf16x3 layout (dss2_common.hpp: split3): [col group][kpad/16][plane 0..2][64 lanes][8 bf16]; lane (half, c32) holds
-    // B[k = 16 kg + 8 half + 0..7][j = 32 cg + c32] -- the B operand of v_mfma_f32_32x32x16_bf16, one plane per term
-    const int kg0 = d.koff >> 4, kg1 = (d.koff + K + 15) >> 4;
-    const int cg0 = d.joff >> 5, cg1 = (d.joff + J + 31) >> 5;
-    const int nkl = kg1 - kg0, nkk = d.kpad >> 4;
-    const int total = (cg1 - cg0) * nkl * 64;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int lane = idx & 63;
-    const int kg = kg0 + (idx >> 6) % nkl;
-    const int cg = cg0 + (idx >> 6) / nkl;
-    const int j = cg * 32 + (lane & 31) - d.joff;
-    if (j < 0 || j >= J) return;
-    // (pointers out of a descriptor are generic -- flat_load / flat_store -- unless told otherwise: global by contract; the eight
-    //  source values are requested together, then split)
-    typedef const __attribute__((address_space(1))) float* gsrc_t;
-    typedef __attribute__((address_space(1))) __bf16* gdst_t;
-    const gsrc_t src = (gsrc_t)d.src;
-    gdst_t dst = (gdst_t)(reinterpret_cast<__bf16*>(d.dst) + (((size_t)cg * nkk + kg) * 3 * 64 + lane) * 8);
-    float v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int k = kg * 16 + 8 * (lane >> 5) + q - d.koff;
-      const int kc = k < 0 ? 0 : (k >= K ? K - 1 : k);
-      v[q] = tr ? src[(size_t)j * d.ld + kc] : src[(size_t)kc * d.ld + j];
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int k = kg * 16 + 8 * (lane >> 5) + q - d.koff;
-      if (k < 0 || k >= K) continue;
-      __bf16 h, m, l;
-      split3(v[q], h, m, l);
-      dst[q] = h; dst[64 * 8 + q] = m; dst[2 * 64 * 8 + q] = l;
-    }
-    return;
-  }
-  // destination k-groups / column groups this block touches
-  const int kg0 = d.koff >> 3, kg1 = (d.koff + K + 7) >> 3;
-  const int cg0 = d.joff >> 5, cg1 = (d.joff + J + 31) >> 5;
-  const int nkl = kg1 - kg0;
-  const int nkk = d.kpad >> 3;
-  const int total = (cg1 - cg0) * nkl * 64;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int lane = idx & 63;
-  const int kg = kg0 + (idx >> 6) % nkl;
-  const int cg = cg0 + (idx >> 6) / nkl;
-  const int j = cg * 32 + (lane & 31) - d.joff;     // source column
-  if (j < 0 || j >= J) return;
-  float* dst = d.dst + (((size_t)cg * nkk + kg) * 64 + lane) * 4;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int k = kg * 8 + 4 * (lane >> 5) + s - d.koff;   // source k
-    if (k >= 0 && k < K) dst[s] = tr ? d.src[(size_t)j * d.ld + k] : d.src[(size_t)k * d.ld + j];
-  }
+  pack_weights_body(descs[blockIdx.y], (int)blockIdx.x);      // (dss2_weightspace.hpp)
 }
 
 // ------------------------------------------------------------------------------------------

@@ -2,7 +2,7 @@
 // /root/reference/dss2_run.py:91-92,143): one launch updates every parameter tensor of the model.
 //   exp_avg = b1*exp_avg + (1-b1)*g ;  exp_inf = max(b2*exp_inf, |g| + eps) ;
 //   p -= lr / (1 - b1^t) * exp_avg / exp_inf           (weight_decay: g += wd * p first)
-#include "dss2_common.hpp"
+#include "dss2_weightspace.hpp"
 
 namespace dss2 {
 
@@ -65,123 +65,11 @@ __global__ void __launch_bounds__(256) adamax_flat_kernel(const dss2_adamax_flat
   }
 }
 
-// Batched small dense products in weight space (a few 128^3 products per step; one launch).
-// One 32 x 32 tile of C per workgroup.  The operands are tiny (<= a few hundred KB, L2-resident) and the
-// kernel is latency-bound: a whole K-chunk of 128 is requested at once (32 loads in flight per thread), up to three
-// chunks ahead, and each chunk is multiplied out of LDS on the matrix pipe, a k quarter per wave.
-constexpr int SG_T = 32, SG_KC = 128, SG_LDA = SG_KC + 4;
-template <bool tA, bool tB>
-__device__ __forceinline__ void small_gemm_body(const dss2_sgemm_desc* __restrict__ dp, float* base_out,
-                                                float (&As)[SG_T][SG_LDA], float (&Bs)[SG_KC][SG_T + 1]) {
-  // every field once, into scalars (the descriptor itself stays in global memory)
-  const int M = dp->M, N = dp->N, K = dp->K, lda = dp->lda, ldb = dp->ldb, ldc = dp->ldc;
-  const bool accum = dp->accumulate != 0;
-  const int nbatch = dp->nbatch;
-  const float* u = dp->u;
-  const float* v = dp->v;
-  float* C = dp->c_off >= 0 ? base_out + dp->c_off : dp->C;
-  const int tn = (N + SG_T - 1) / SG_T, tm = (M + SG_T - 1) / SG_T;
-  if ((int)blockIdx.x >= tm * tn) return;
-  const int i0 = ((int)blockIdx.x / tn) * SG_T, j0 = ((int)blockIdx.x % tn) * SG_T;
-  const int t = threadIdx.x, lo = t & 31, hi = t >> 5;   // lo runs along the contiguous memory direction
-  const int kchunks = (K + SG_KC - 1) / SG_KC;
-  const int nchunks = nbatch * kchunks;
-  // THREE chunks of operands in flight (96 registers): the chain rule's dW2 = sum_m W_m^T dWf_m walks three K-chunks per tile,
-  // and with one chunk requested at a time every chunk paid its own round trip to L2 / HBM (17.9 us for that launch at C2)
-  float rab[3][16], rbb[3][16];
-  // unconditional loads from clamped addresses (one batch of 32 in flight per chunk), masked afterwards
-  auto issue = [&](int c, float (&ra)[16], float (&rb)[16]) {
-    const int bidx = c / kchunks, k0 = (c - bidx * kchunks) * SG_KC;
-    // (pointers read from a descriptor in memory are generic: through them every access is a flat_load that waits for vmcnt AND
-    //  lgkmcnt; they are global by contract -- say so)
-    typedef const __attribute__((address_space(1))) float* gptr;
-    const gptr A = (gptr)dp->A[bidx];   // uniform scalar loads from the descriptor
-    const gptr B = (gptr)dp->B[bidx];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      // A(i,k): row-major [M,K] (k contiguous) or, transposed, stored [K,M] (i contiguous)
-      const int i = tA ? lo : hi + 8 * (q >> 2), k = tA ? hi + 8 * q : lo + 32 * (q & 3);
-      const int gi = min(i0 + i, M - 1), gk = min(k0 + k, K - 1);
-      const float av = tA ? A[(size_t)gk * lda + gi] : A[(size_t)gi * lda + gk];
-      ra[q] = av * (((i0 + i) < M && (k0 + k) < K) ? 1.f : 0.f);   // (a select would let the compiler branch around the load)
-      // B(k,j): row-major [K,N] (j contiguous) or, transposed, stored [N,K] (k contiguous)
-      const int kb = tB ? lo + 32 * (q & 3) : hi + 8 * q, j = tB ? hi + 8 * (q >> 2) : lo;
-      const int gj = min(j0 + j, N - 1), gkb = min(k0 + kb, K - 1);
-      const float bv = tB ? B[(size_t)gj * ldb + gkb] : B[(size_t)gkb * ldb + gj];
-      rb[q] = bv * (((j0 + j) < N && (k0 + kb) < K) ? 1.f : 0.f);
-    }
-  };
-  auto stage = [&](const float (&ra)[16], const float (&rb)[16]) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      if (tA) As[lo][hi + 8 * q] = ra[q]; else As[hi + 8 * (q >> 2)][lo + 32 * (q & 3)] = ra[q];
-      if (tB) Bs[lo + 32 * (q & 3)][hi + 8 * (q >> 2)] = rb[q]; else Bs[hi + 8 * q][lo] = rb[q];
-    }
-  };
-  // The product itself on the matrix pipe (round 4): wave w multiplies the k quarter [32 w, 32 w + 32) of every chunk for the
-  // whole 32 x 32 tile -- 16 v_mfma_f32_32x32x2_f32 per chunk and wave (exact fp32 fma chains), operands from the LDS images:
-  // A as one ds_read_b128 per four k (row stride 132 floats: a 16-lane group covers all 64 banks), B as one ds_read_b32 per k
-  // -- and the four partial tiles meet once, after the last chunk, in LDS, summed in wave order.  The VALU form (one column
-  // and four rows per thread, 16 LDS reads per 32 fma) spent ~6 us per chunk; the chain rule's launch was 18-19 us at C2.
-  const int wave = t >> 6, lane = t & 63, c32 = lane & 31, half = lane >> 5;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-  for (int u3 = 0; u3 < 3; ++u3)
-    if (u3 < nchunks) issue(u3, rab[u3], rbb[u3]);
-  for (int c0 = 0; c0 < nchunks; c0 += 3) {
-#pragma unroll
-    for (int u3 = 0; u3 < 3; ++u3) {
-      const int c = c0 + u3;
-      if (c >= nchunks) break;          // (uniform)
-      __syncthreads();
-      stage(rab[u3], rbb[u3]);
-      __syncthreads();
-      if (c + 3 < nchunks) issue(c + 3, rab[u3], rbb[u3]);
-      const int kw = wave * 32;
-#pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(&As[c32][kw + 4 * g]);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const float a = half ? av[2 * tt + 1] : av[2 * tt];                    // A[i = c32][k = kw + 4 g + 2 tt + half]
-          const float bvv = Bs[kw + 4 * g + 2 * tt + half][c32];               // B[k][j = c32]
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc, 0, 0, 0);
-        }
-      }
-    }
-  }
-  // ---- the four k quarters meet in LDS (the operand images are free after the last barrier below), fixed order
-  __syncthreads();
-  float* red = &As[0][0];                     // [4 waves][16 registers][64 lanes] = 16 KB <= sizeof(As)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
-  __syncthreads();
-  // thread t finishes rows acc_row(r, half) for r = 4 wave .. 4 wave + 3 of column c32
-  const int j = j0 + c32;
-  if (j < N) {
-    const float vj = u ? v[j] : 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = 4 * wave + q;
-      const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (i >= M) continue;
-      float sum = (red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + (red[(2 * 16 + r) * 64 + lane] + red[(3 * 16 + r) * 64 + lane]);
-      if (u) sum = fmaf(u[i], vj, sum);
-      float* cp = C + (size_t)i * ldc + j;
-      *cp = accum ? *cp + sum : sum;
-    }
-  }
-}
-
+// (small_gemm_body / small_gemm_tile: dss2_weightspace.hpp)
 __global__ void __launch_bounds__(256) small_gemm_kernel(const dss2_sgemm_desc* __restrict__ descs, float* base_out) {
   __shared__ __attribute__((aligned(16))) float As[SG_T][SG_LDA];   // As[i][k]
   __shared__ float Bs[SG_KC][SG_T + 1];                             // Bs[k][j]
-  const dss2_sgemm_desc* dp = descs + blockIdx.y;
-  const bool ta = dp->transA != 0, tb = dp->transB != 0;
-  if (ta) { if (tb) small_gemm_body<true, true>(dp, base_out, As, Bs); else small_gemm_body<true, false>(dp, base_out, As, Bs); }
-  else    { if (tb) small_gemm_body<false, true>(dp, base_out, As, Bs); else small_gemm_body<false, false>(dp, base_out, As, Bs); }
+  small_gemm_tile(descs + blockIdx.y, base_out, As, Bs, (int)blockIdx.x);
 }
 
 }  // namespace dss2

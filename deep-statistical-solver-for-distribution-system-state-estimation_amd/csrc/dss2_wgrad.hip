@@ -597,7 +597,7 @@ __global__ void __launch_bounds__((WgradGeom<NB, W8>::NT)) wgrad_kernel(const ds
 // ------------------------------------------------------------------------------------------
 constexpr int WN_MAXO = 8;
 template <int NRB>
-__global__ void __launch_bounds__(256) wgrad_narrow_stream_kernel(const dss2_wgrad_args p) {
+__global__ void __launch_bounds__(256) wgrad_narrow_stream_kernel(const dss2_wgrad_args p) {      // (198 registers = two workgroups per CU; bounded to 170 / 128 the allocator spills 7 / 27)
   constexpr int TM = NRB * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -613,9 +613,18 @@ __global__ void __launch_bounds__(256) wgrad_narrow_stream_kernel(const dss2_wgr
 #pragma unroll
   for (int j = 0; j < WN_MAXO; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dbv = 0.f;                            // thread tid < hout: column sum of G[:, tid]
+  // (TM <= 8 * nrg rows: one batch of eight 16-byte loads per thread covers the tile -- 64-row tiles at hin = 128 -- and is requested
+  //  BEFORE the tile's G rows are staged and propagated, so the HBM latency of the only large operand runs under that work; round 5:
+  //  13.7 -> ... us at C2.  Taller tiles request their remaining batches after the hops, as before.)
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const int ts = p.tile_start[tile];
     const int R = p.tile_start[tile + 1] - ts;
+    f32x4 xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int row = rg + u * nrg;
+      xv[u] = (row < R) ? *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + row) * p.ldx + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int idx = tid; idx < TM * WN_MAXO; idx += 256) {
       const int row = idx / WN_MAXO, j = idx - row * WN_MAXO;
       Gp[idx] = (row < R && j < h) ? p.G[(size_t)(ts + row) * p.ldg + j] : 0.f;
@@ -643,11 +652,12 @@ __global__ void __launch_bounds__(256) wgrad_narrow_stream_kernel(const dss2_wgr
       dbv += s;
     }
     for (int r0 = rg; r0 < TM; r0 += 8 * nrg) {   // eight rows (16-byte loads) in flight per thread
-      f32x4 xv[8];
+      if (r0 != rg) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int row = r0 + u * nrg;
-        xv[u] = (row < R) ? *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + row) * p.ldx + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 8; ++u) {
+          const int row = r0 + u * nrg;
+          xv[u] = (row < R) ? *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + row) * p.ldx + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {

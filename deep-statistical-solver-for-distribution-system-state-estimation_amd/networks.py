@@ -33,8 +33,8 @@ from .topology import Topology, get_topology
 _F32 = torch.float32
 
 from . import flags as FL
-from .ops import (new_xplanes, wgrad_batched_xp, xplanes_supported, _DROP_PARAMS, _dropout_params, _ncg, _ptr, _reduce, _require_gpu, _round16, _round8, _rows, _stream, _wgrad_per_cu, _wgrad_tiles, chain16_supported, chain_gate_words, chain_head_supported, chain_supported, csr_axpy, dropout_mask, dropout_snapshot, gather_rows, gemm16_supported, gemm_prop, gemm_prop_chain, is_narrow, reduce_pending, segment_sum, wgrad, wgrad_batched)
-from .plans import (_DESC_DTYPE, _FoldPlan, _MatView, _PackPlan, _SG_DTYPE, _as_view, _sg, _sg_table, _small_gemm)
+from .ops import (new_xplanes, wgrad_batched_xp, xplanes_supported, _DROP_PARAMS, _dropout_params, _ncg, _ptr, _reduce, _require_gpu, _round16, _round8, _rows, _stream, _wgrad_per_cu, _wgrad_tiles, chain16_supported, chain_gate_words, chain_head_supported, chain_supported, csr_axpy, dropout_mask, dropout_snapshot, gather_rows, gemm16_supported, gemm_prop, gemm_prop_chain, is_narrow, finish_weights, prep_weights, reduce_pending, segment_sum, wgrad, wgrad_batched)
+from .plans import (_DESC_DTYPE, _FoldPlan, _MatView, _PackPlan, _SG_DTYPE, _as_view, _pack_table, _sg, _sg_table, _small_gemm)
 
 
 # ------------------------------------------------------------------------------------------
@@ -556,7 +556,7 @@ def _ensure_plans(mod, topo, dev, ps):
         mod._fold = _FoldPlan(W2, b2, conv_ps[0][1:], dev, int(offs[1]), int(offs[2])) if fold_on else None
         conv_groups = [list(cp[1:]) for cp in conv_ps]
         if fold_on:   # conv 0 is packed from the folded weights
-            conv_groups[0] = [mod._fold.Wf[m] for m in range(nmat)]
+            conv_groups[0] = [_MatView(mod._fold.Wf[m], hout0, hid, hid, 0, dep=True) for m in range(nmat)]
         mod._plan = _PackPlan([[W2]] + conv_groups + _dx_views(W1, hid, mod.dim_featn, mod.dim_feate), dev, stacked=glob,
                               stacked_groups=(L + 3,), bf16_groups=b16)
     if mod._fold is not None:
@@ -576,9 +576,7 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None, need_dx=False):
     conv_ps = [ps[4 + l * (nmat + 1): 4 + (l + 1) * (nmat + 1)] for l in range(L)]   # (bias, W_0..W_K)
     plan, fold, glob = _ensure_plans(mod, topo, dev, ps)
     if stack is None:
-        if fold is not None:
-            fold.refresh_forward()
-        ver = plan.refresh()
+        ver = plan.refresh(fold)      # (fold + packing: one launch)
     else:
         ver = plan.version
     if not glob:
@@ -681,9 +679,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
     if folded != (fold is not None) or plan.stacked != glob:
         raise RuntimeError("DSS2_FOLD_W2 / the module's plan changed between forward and backward")
     if plan.version != ver:
-        if fold is not None:
-            fold.refresh_forward()
-        plan.refresh()   # weights are checked unchanged by autograd's saved-tensor versioning
+        plan.refresh(fold)   # weights are checked unchanged by autograd's saved-tensor versioning
     dev = gout.device
     L, nmat, hid, fn, fe = mod.n_gnn_layers, mod.K + 1, mod.dim_hid, mod.dim_featn, mod.dim_feate
     W1, b1 = ps[0], ps[1]
@@ -805,10 +801,11 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
                              pack_dx=tuple(plan.bwd[1 + L:4 + L]), dS=(dS if fold is not None else None),
                              pending=pending, dx_add=(gout if (need_dx and mod.skip) else None))
     if not in_stack:
-        if pending:
-            reduce_pending(pending)     # all slab reductions of the block in one launch
+        # all slab reductions of the block and the chain rule of the fold (it needs the reduced gfold only): one launch
         if fold_late:
-            fold.backward(flat)
+            fold._check()
+        finish_weights(pending if pending is not None else [], (fold.bwd_tab if fold_late else None), flat,
+                       ({fold.gfold.data_ptr()} if fold_late else ()), dev)
         hook = getattr(mod, "_grad_bucket_hook", None)
         if hook is not None:      # data-parallel: all-reduce the flat bucket once (parallel.py)
             hook(flat)
@@ -878,15 +875,12 @@ class _StackPlan:
                 max_elems = max(max_elems, p.max_elems)
             self.fold_fwd = _sg_table(fwd, self.device) if fwd else None
             self.fold_bwd = _sg_table(bwd, self.device) if bwd else None
-            arr = np.array(recs, dtype=_DESC_DTYPE)
-            self.pack_tab = (torch.from_numpy(arr.view(np.uint8).copy()).to(self.device), len(recs), max_elems)
+            t, cnt, n_dep = _pack_table(recs, self.device)
+            self.pack_tab = (t, cnt, max_elems, n_dep)
             self.key = key
             self.table_builds += 1
-        if self.fold_fwd is not None:
-            _small_gemm(self.fold_fwd, None, self.device)
-        t, cnt, mx = self.pack_tab
-        _lib.check(_lib.lib().dss2_pack_weights(t.data_ptr(), cnt, mx, _lib.stream_ptr(self.device)),
-                   "dss2_pack_weights")
+        self.gfolds = {f.gfold.data_ptr() for _, f, _ in plans if f is not None}
+        prep_weights(self.fold_fwd, self.pack_tab, self.device)      # every block's fold + every block's packing: one launch
         for p, _, _ in plans:
             p.version += 1
 
@@ -950,12 +944,9 @@ class _PFNFn(torch.autograd.Function):
                                                 g, need_dx, flat=flat[sp.base[b]:sp.base[b + 1]],
                                                 pending=pending)
             any_fold = any_fold or fl
-        if pending:
-            reduce_pending(pending)
-        if any_fold:
-            if sp.fold_bwd is None:
-                raise RuntimeError("the stack's fold tables are missing")
-            _small_gemm(sp.fold_bwd, flat.data_ptr(), dev)
+        if any_fold and sp.fold_bwd is None:
+            raise RuntimeError("the stack's fold tables are missing")
+        finish_weights(pending, (sp.fold_bwd if any_fold else None), flat, (sp.gfolds if any_fold else ()), dev)
         hook = getattr(blocks[0], "_grad_bucket_hook", None)
         if hook is not None:      # data-parallel: ONE all-reduce for the whole stack's bucket
             hook(flat)

@@ -392,15 +392,77 @@ def _reduce(slab: torch.Tensor, slab_off: int, n_slabs: int, stride: int, out: t
                                             _stream(slab)), "dss2_reduce_slabs")
 
 
+def _reduce_descs(chunk):
+    descs = (_lib.ReduceDesc * len(chunk))()
+    for d, (slab, ptr, n_slabs, stride, out, length) in zip(descs, chunk):
+        d.slab, d.out, d.stride, d.len, d.n_slabs = ptr, out.data_ptr(), stride, length, n_slabs
+    return descs
+
+
 def reduce_pending(pending) -> None:
     for c0 in range(0, len(pending), 32):
         chunk = pending[c0:c0 + 32]
-        descs = (_lib.ReduceDesc * len(chunk))()
-        for d, (slab, ptr, n_slabs, stride, out, length) in zip(descs, chunk):
-            d.slab, d.out, d.stride, d.len, d.n_slabs = ptr, out.data_ptr(), stride, length, n_slabs
+        descs = _reduce_descs(chunk)
         _lib.check(_lib.lib().dss2_reduce_slabs_multi(C.addressof(descs), len(chunk), _stream(chunk[0][0])),
                    "dss2_reduce_slabs_multi")
     pending.clear()
+
+
+_COUNTERS = {}
+
+
+def weight_counters(device) -> torch.Tensor:
+    """The counter words of dss2_prep_weights / dss2_finish_weights on this device: words 0..511 for the step-start launch, 512..1023
+    for the step-end launch (DSS2_WEIGHT_COUNTER_WORDS = 288 each; zero between launches; launches of one device are ordered on its stream)."""
+    device = torch.device(device)
+    t = _COUNTERS.get(device)
+    if t is None:
+        t = _COUNTERS[device] = torch.zeros(1024, dtype=torch.int32, device=device)
+    return t
+
+
+def prep_weights(fold_tab, pack_tab, device) -> None:
+    """Start of a step in weight space: the fold of the edge MLP's second Linear (``fold_tab``: small-GEMM table or None) and the
+    packing of every weight (``pack_tab`` = (device table, descriptors, max elements, leading descriptors that read folded weights)) -- ONE launch (flags.WEIGHTS_MERGED) or two."""
+    t, cnt, mx, n_dep = pack_tab
+    st = _lib.stream_ptr(device)
+    if fold_tab is not None and FL.WEIGHTS_MERGED:
+        ft, fcnt, fmx = fold_tab
+        _lib.check(_lib.lib().dss2_prep_weights(ft.data_ptr(), fcnt, fmx, t.data_ptr(), cnt, n_dep, mx, weight_counters(device).data_ptr(), st),
+                   "dss2_prep_weights")
+        return
+    if fold_tab is not None:
+        ft, fcnt, fmx = fold_tab
+        _lib.check(_lib.lib().dss2_small_gemm(ft.data_ptr(), fcnt, fmx, None, st), "dss2_small_gemm")
+    _lib.check(_lib.lib().dss2_pack_weights(t.data_ptr(), cnt, mx, st), "dss2_pack_weights")
+
+
+def finish_weights(pending, rule_tab, base: Optional[torch.Tensor], dep_outs, device) -> None:
+    """End of a step in weight space: the recorded slab reductions and, with ``rule_tab`` (small-GEMM table writing into ``base``), the
+    chain rule of the fold, which reads the reductions whose outputs are in ``dep_outs`` (data pointers) -- ONE launch
+    (flags.WEIGHTS_MERGED: the chain rule starts as soon as ITS reductions are done and runs beside the others) or two."""
+    if rule_tab is None:
+        if pending:
+            reduce_pending(pending)
+        return
+    rt, rcnt, rmx = rule_tab
+    st = _lib.stream_ptr(device)
+    dep = [p for p in pending if p[4].data_ptr() in dep_outs]
+    if FL.WEIGHTS_MERGED and 1 <= len(dep) <= 32 and len(dep) == len(dep_outs):
+        rest = [p for p in pending if p[4].data_ptr() not in dep_outs]
+        room = 32 - len(dep)
+        over = rest[room:]
+        if over:
+            reduce_pending(over)
+        chunk = dep + rest[:room]
+        descs = _reduce_descs(chunk)
+        _lib.check(_lib.lib().dss2_finish_weights(C.addressof(descs), len(chunk), len(dep), rt.data_ptr(), rcnt, rmx, base.data_ptr(),
+                                                  weight_counters(device).data_ptr() + 2048, st), "dss2_finish_weights")
+        pending.clear()
+        return
+    if pending:
+        reduce_pending(pending)
+    _lib.check(_lib.lib().dss2_small_gemm(rt.data_ptr(), rcnt, rmx, base.data_ptr(), st), "dss2_small_gemm")
 
 
 def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, ent: torch.Tensor, n_rows: int) -> torch.Tensor:

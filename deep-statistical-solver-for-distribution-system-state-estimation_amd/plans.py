@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from . import flags as FL
-from .ops import _F32, _ncg, _round8, _round16, is_narrow
+from .ops import _F32, _ncg, _round8, _round16, is_narrow, prep_weights
 
 # ------------------------------------------------------------------------------------------
 # weight packing plans
@@ -38,6 +38,14 @@ def _sg_table(recs, device):
         arr[i] = tuple(r)
     return (torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(recs),
             max(((r[6] + 31) // 32) * ((r[7] + 31) // 32) for r in recs))
+
+
+def _pack_table(recs, device):
+    """(device table, descriptors, leading descriptors whose source the fold of the same step writes) of packing records: the
+    dependent ones (transpose bit 2, _MatView.dep) first -- dss2_prep_weights makes exactly those wait for the fold."""
+    recs = sorted(recs, key=lambda r: 0 if (r[5] & 4) else 1)      # (stable)
+    arr = np.array(recs, dtype=_DESC_DTYPE)
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(recs), sum(1 for r in recs if r[5] & 4)
 
 
 def _small_gemm(tab, base, device) -> None:
@@ -123,8 +131,9 @@ class _MatView:
     """A [rows, cols] block of a row-major parameter tensor (leading dimension ld, element offset
     off): lets the pack kernel read e.g. W1[:, :fn] in place, without a copy per step."""
 
-    def __init__(self, t: torch.Tensor, rows: int, cols: int, ld: int, off: int = 0):
+    def __init__(self, t: torch.Tensor, rows: int, cols: int, ld: int, off: int = 0, dep: bool = False):
         self.t, self.shape, self.ld, self.off = t, (rows, cols), ld, off
+        self.dep = dep      # written by the fold of the same step: its packing waits for the fold inside dss2_prep_weights (transpose bit 2)
 
     def data_ptr(self) -> int:
         return self.t.data_ptr() + 4 * self.off
@@ -192,32 +201,34 @@ class _PackPlan:
                 if not w.is_contiguous():
                     raise RuntimeError("weight matrices must be contiguous")
                 # record = (src, dst, rows, cols, ld, transpose, koff, kpad, ncg, joff)
+                dp = 4 if w.dep else 0
                 if narrow:
-                    recs.append((w.data_ptr(), self.fwd[g].data_ptr(), hout, hin, w.ld, 1, 0, kf, cf, m * hout))
-                    recs.append((w.data_ptr(), self.bwd[g].data_ptr(), hout, hin, w.ld, 0, m * hout, kb, cb, 0))
+                    recs.append((w.data_ptr(), self.fwd[g].data_ptr(), hout, hin, w.ld, 1 | dp, 0, kf, cf, m * hout))
+                    recs.append((w.data_ptr(), self.bwd[g].data_ptr(), hout, hin, w.ld, 0 | dp, m * hout, kb, cb, 0))
                 else:
-                    recs.append((w.data_ptr(), self.fwd[g].data_ptr() + 4 * m * cf * (kf // 8) * 256, hout, hin, w.ld, 1, 0, kf, cf, 0))
-                    recs.append((w.data_ptr(), self.bwd[g].data_ptr() + 4 * m * cb * (kb // 8) * 256, hout, hin, w.ld, 0, 0, kb, cb, 0))
+                    recs.append((w.data_ptr(), self.fwd[g].data_ptr() + 4 * m * cf * (kf // 8) * 256, hout, hin, w.ld, 1 | dp, 0, kf, cf, 0))
+                    recs.append((w.data_ptr(), self.bwd[g].data_ptr() + 4 * m * cb * (kb // 8) * 256, hout, hin, w.ld, 0 | dp, 0, kb, cb, 0))
                 self.max_elems = max(self.max_elems, (cf + 1) * (kf // 8 + 1) * 64, (cb + 1) * (kb // 8 + 1) * 64)
                 if g in self.fwd16:      # transpose | 2: bf16x3 layout
                     k16, b16 = _round16(hin), _round16(hout)
-                    recs.append((w.data_ptr(), self.fwd16[g].data_ptr() + 4 * m * cf * (k16 // 16) * 768, hout, hin, w.ld, 3, 0, k16, cf, 0))
-                    recs.append((w.data_ptr(), self.bwd16[g].data_ptr() + 4 * m * cb * (b16 // 16) * 768, hout, hin, w.ld, 2, 0, b16, cb, 0))
+                    recs.append((w.data_ptr(), self.fwd16[g].data_ptr() + 4 * m * cf * (k16 // 16) * 768, hout, hin, w.ld, 3 | dp, 0, k16, cf, 0))
+                    recs.append((w.data_ptr(), self.bwd16[g].data_ptr() + 4 * m * cb * (b16 // 16) * 768, hout, hin, w.ld, 2 | dp, 0, b16, cb, 0))
         return recs
 
     def _build_table(self):
-        recs = self.records()
-        arr = np.array(recs, dtype=_DESC_DTYPE)
-        self.n_desc = len(recs)
-        self.table = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
+        self.table, self.n_desc, self.n_dep = _pack_table(self.records(), self.device)
 
-    def refresh(self):
+    def refresh(self, fold: Optional["_FoldPlan"] = None):
+        """Packs every matrix of the plan; with ``fold`` the fold's small GEMMs run first -- inside the same launch
+        (ops.prep_weights)."""
         ptrs = self.pointers()
         if ptrs != self.ptrs:
             self._build_table()
             self.ptrs = ptrs
-        st = _lib.stream_ptr(self.device)
-        _lib.check(_lib.lib().dss2_pack_weights(self.table.data_ptr(), self.n_desc, self.max_elems, st), "dss2_pack_weights")
+        fold_tab = None
+        if fold is not None:
+            fold._check()
+            fold_tab = fold.fwd_tab
+        prep_weights(fold_tab, (self.table, self.n_desc, self.max_elems, self.n_dep), self.device)
         self.version += 1
         return self.version
-

@@ -139,7 +139,8 @@ typedef struct dss2_pack_desc {
   int32_t rows, cols, ld;
   int32_t transpose;  /* bit 0: 1: B[k][j] = W[j][k] (forward, K=cols); 0: B[k][j] = W[k][j].
                        * bit 1: write the bf16x3 layout [ncg][kpad/16][3 planes][64 lanes][8 bf16] (kpad a multiple of 16):
-                       * every weight split into three bf16 pieces h + m + l for the fp32-accurate bf16 MFMA path        */
+                       * every weight split into three bf16 pieces h + m + l for the fp32-accurate bf16 MFMA path
+                       * bit 2: ignored by the kernels (the host side marks descriptors whose src the fold of the same step writes) */
   int32_t koff;       /* k offset of this block inside the packed matrix (any value)   */
   int32_t kpad;       /* padded K of the packed matrix (multiple of 8)                  */
   int32_t ncg;        /* number of 32-column groups of the packed matrix                */
@@ -532,6 +533,26 @@ typedef struct dss2_sgemm_desc {
 
 /* max_tiles = max over the descriptors of ceil(M/32) * ceil(N/32); descs is a DEVICE array */
 int dss2_small_gemm(const dss2_sgemm_desc* descs, int n_desc, int max_tiles, float* base_out, void* stream);
+
+/* ---- the weight-space work of a training step in two launches (round 5; csrc/dss2_weights.hip).  Host-side glue the reference
+ *      does not have (its autograd keeps nn.Linear weights as they are: /root/reference/networks.py:159-209, 211-264): the fold and
+ *      the packing are this library's own preparation of those weights, the reductions / chain rule its own gradient assembly.
+ *      Bitwise the same results as the separate launches (same device code, dss2_weightspace.hpp).
+ * dss2_prep_weights   = dss2_small_gemm(fold, n_fold, fold_tiles, NULL) then dss2_pack_weights(pack, n_pack, max_elems), as ONE
+ *      launch: the FIRST n_dep packing descriptors (the ones whose src the fold writes; 0 <= n_dep <= n_pack) wait inside the kernel
+ *      for the fold, the others run beside it.  fold / pack: DEVICE arrays.  n_fold = 0 (then n_dep = 0): plain packing.
+ * dss2_finish_weights = dss2_reduce_slabs_multi(descs_host, n_red) then dss2_small_gemm(rule, n_rule, rule_tiles, base_out), as ONE
+ *      launch: the chain rule waits for the FIRST n_dep reductions only (1 <= n_dep <= n_red <= 32: the caller lists the ones whose
+ *      outputs `rule` reads first) and runs beside the others.  descs_host: HOST array (copied into the kernel arguments); rule:
+ *      DEVICE array.
+ * counters: DSS2_WEIGHT_COUNTER_WORDS zero-initialised uint32 words of device memory, 128-byte aligned, per launch in flight
+ *      (launches ordered on one stream may share them); every launch leaves them zero.  Both launches rely on workgroups being
+ *      dispatched in id order (the producers take the lowest ids). */
+#define DSS2_WEIGHT_COUNTER_WORDS 288
+int dss2_prep_weights(const dss2_sgemm_desc* fold, int n_fold, int fold_tiles, const dss2_pack_desc* pack, int n_pack, int n_dep,
+                      int max_elems, uint32_t* counters, void* stream);
+int dss2_finish_weights(const dss2_reduce_desc* descs_host, int n_red, int n_dep, const dss2_sgemm_desc* rule, int n_rule,
+                        int rule_tiles, float* base_out, uint32_t* counters, void* stream);
 
 /* ---- dataset side: what sits in front of the path in every training step.
  *      Replaces the arithmetic of data_from_pickles (/root/reference/data.py:119-190) and the

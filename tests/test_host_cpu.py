@@ -193,6 +193,9 @@ def test_no_kernel_in_the_library_spills_registers():
     allowed["void dss2::wgrad16p_kernel<3, true>"] = 20
     allowed["void dss2::wgrad16p_kernel<3, false>"] = 8
     allowed["void dss2::wgrad16q_kernel<3, true, 4>"] = 16
+    # The step-end launch of round 5 (csrc/dss2_weights.hip): the chain rule's small GEMM with two operand chunks in flight (64 registers)
+    # compiled for four workgroups per CU -- the slab reductions it runs beside want the occupancy -- parks two values around its chunk loop.
+    allowed["dss2::finish_weights_kernel"] = 4
     # A fourth, chosen: the 64-row split-plane chain on 16x16x32 MFMAs at K = 2 (csrc/dss2_gemm_chain_sp.hip, MS = 1).  96 accumulator
     # registers + the four row blocks' plane fragments (48) + two sets of weight fragments (72) leave 40 for everything else; 20-24 loop
     # invariants live in scratch memory around the layer loop, none inside the k-step loop.  Measured with them: forward / backward chain
