@@ -34,4 +34,8 @@ bool wgrad16_covers(const dss2_wgrad_args& a);
 int wgrad16_y_slices(int nrb, int hout, int hin);      // workgroups per tile-list slice (grid.y)
 int launch_wgrad16(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb);
 
+// dss2_wgrad16h.hip: the f16x3 kernel (32-row tiles; args.mfma_bf16 = 2 | headroom bits << 8)
+bool wgrad16h_covers(const dss2_wgrad_args& a);
+int launch_wgrad16h(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb);
+
 }  // namespace dss2

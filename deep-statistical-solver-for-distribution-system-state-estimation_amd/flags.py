@@ -23,6 +23,9 @@ FOLD_W2 = _os.environ.get("DSS2_FOLD_W2", "1") == "1"   # 0 = run the edge MLP's
 # merged against 4.6 + 5.6 (10.8 back to back), step end 20.8 against 13.8 + 8.0 (22.9 back to back) at C2, C2 step unchanged within
 # +-2 us (profiles/experiments/r05_weights_merged.txt)
 WEIGHTS_MERGED = _os.environ.get("DSS2_WEIGHTS_MERGED", "0") == "1"
+# ... and on 32-row tiles as f16x3: two fp16 pieces per operand after a power-of-two scale, three MFMAs per product instead of six
+# (csrc/dss2_wgrad16h.hip, round 5; errors of the size of fp32 arithmetic itself).  0 = bf16x6 there too.
+WGRAD_F16 = _os.environ.get("DSS2_WGRAD_F16", "1") == "1"
 WGRAD_TM32 = _os.environ.get("DSS2_WGRAD_TM32", "1") == "1"      # bf16x6 weight gradient on 32-row tiles, two workgroups per CU (wgrad16b_kernel)
 WGRAD_TM32_MAX_BYTES = 64 << 20      # ... while one layer's input (N * hin * 4 bytes) stays well inside the Infinity Cache
 # The H -> H layers' inputs as X plane images written by their producers (edge MLP, forward chain) and the weight-gradient kernel that

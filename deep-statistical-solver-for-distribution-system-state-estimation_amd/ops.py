@@ -4,6 +4,7 @@ memory, dropout state.  No autograd, no modules: ``networks.py`` builds the refe
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -240,6 +241,23 @@ def _wgrad_tiles(topo: Topology, nmat: int, hout: int, hin: int, b16: int):
     return topo
 
 
+def _wgrad_mode(ts, nmat: int, b16: int) -> int:
+    """args.mfma_bf16 of a weight-gradient launch on the tile set ``ts``: 0 fp32 MFMA, 1 bf16x6, or -- flags.WGRAD_F16 on 32-row tiles
+    with ELL slices -- 2 | hb << 8: the f16x3 kernel (csrc/dss2_wgrad16h.hip) with hb headroom bits for the gain of the propagation
+    hops, ceil(log2(max row sum of |P^T| ^ K)), read from the ELL slices once per tile set (one device-to-host copy, cached)."""
+    if not (b16 and FL.WGRAD_F16 and ts.nrb == 1 and nmat in (2, 3) and ts.ellT_tiles is not None and 1 <= ts.ellT <= 8):
+        return b16
+    cache = ts.__dict__.setdefault("_f16_gain_bits", {})
+    hb = cache.get(nmat)
+    if hb is None:
+        if torch.cuda.is_current_stream_capturing():
+            return b16            # (first met inside a capture: no copy to the host there; the warm-up steps normally fill the cache)
+        w = ts.ellT_tiles[..., 1].contiguous().view(torch.float32)      # [tiles][width][rows]: the entries' weights
+        gain = max(float(w.abs().sum(dim=1).max()), 1.0)
+        hb = cache[nmat] = max(0, int(math.ceil(math.log2(gain) * (nmat - 1) - 1e-6)))
+    return (2 | (hb << 8)) if hb <= 10 else b16
+
+
 def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int, nmat: int, out_flat: torch.Tensor,
           rowscale=None, rowscale2=None, pending=None, out_len: Optional[int] = None) -> None:
     """out_flat[nmat*hout*hin + hout] <- [dW_0 .. dW_{nmat-1}, db] (deterministic two-pass sum); with
@@ -264,7 +282,7 @@ def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int,
     a.tile_start = ts.tile_start.data_ptr()
     a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), ts.max_nnzT
     a.ell_width, a.ell_tiles = ts.ellT, _ptr(ts.ellT_tiles)
-    a.narrow, a.mfma_bf16 = int(narrow), b16
+    a.narrow, a.mfma_bf16 = int(narrow), (_wgrad_mode(ts, nmat, b16) if (not narrow and rowscale is None) else b16)
     st = _stream(G)
     _lib.check(_lib.lib().dss2_wgrad(C.byref(a), st), "dss2_wgrad")
     _reduce(slab, 0, n_split, stride, out_flat, stride if out_len is None else out_len, pending)
@@ -292,7 +310,7 @@ def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Seq
         if g_.stride(0) != a.ldg or x_.stride(0) != a.ldx or g_.shape != Gs[0].shape or x_.shape != Xs[0].shape:
             raise ValueError("wgrad_batched: layers must share shapes and leading dimensions")
     a.n_split, a.nmat, a.nrb, a.ntiles = n_split, nmat, ts.nrb, ts.ntiles
-    a.mfma_bf16 = int(FL.WGRAD_BF16)
+    a.mfma_bf16 = _wgrad_mode(ts, nmat, int(FL.WGRAD_BF16))
     a.tile_start = ts.tile_start.data_ptr()
     a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), ts.max_nnzT
     a.ell_width, a.ell_tiles = ts.ellT, _ptr(ts.ellT_tiles)

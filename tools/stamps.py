@@ -12,6 +12,7 @@ stamp scripts folded into one).  Each needs a diagnostic build of the library wi
     wgrad     DSS2_STAMPS         wgrad_kernel<2,3,4> (args: grid, graphs, hidden width)
     wgradxp   DSS2_STAMPS         wgrad16p_kernel (X plane images; args: grid, graphs)
     wgradxq   DSS2_STAMPS         wgrad16q_kernel (X plane images, software-pipelined)
+    wgradh    DSS2_STAMPS         wgrad16h_kernel (f16x3, 32-row tiles; args: grid, graphs)
 """
 import ctypes as C, importlib, os, sys
 import numpy as np, torch
@@ -353,7 +354,50 @@ wgrad16q_kernel on the third tile of every workgroup's range (s_memtime ticks), 
         show("  tile total (72 MFMAs = 2304 cycles of matrix pipe per wave)", tt[:, :, 8] - tt[:, :, 0])
 
 
-COMMANDS = {"gemm": cmd_gemm, "teams": cmd_teams, "chain": cmd_chain, "stack": cmd_stack, "wgrad": cmd_wgrad, "wgradxp": cmd_wgradxp, "wgradxq": cmd_wgradxq}
+def cmd_wgradh(argv):
+    """GPU diagnostic (needs a -DDSS2_STAMPS build of csrc/dss2_wgrad16h.hip: DSS2_LIB=<that library>): per-wave phase durations of
+wgrad16h_kernel on the third tile of every workgroup's walk (layer 1 of three; s_memtime ticks = 10 ns), C2 by default."""
+    sys_argv = [""] + list(argv)
+    ops = pkg.ops
+    DEV = "cuda:0"; H, nmat, nl = 128, 3, 3
+    GRID = sys_argv[1] if len(sys_argv) > 1 else "cigre14"; B = int(sys_argv[2]) if len(sys_argv) > 2 else 4096
+    b = pkg.synthetic.make_batch([GRID], B, seed=0)
+    ei = b["edge_index"].to(DEV); N = b["x"].shape[0]
+    topo = pkg.topology.get_topology(ei, N)
+    torch.manual_seed(0)
+    Xs = [torch.relu(torch.randn(N, H, device=DEV)) for _ in range(nl)]
+    Gs = [torch.randn(N, H, device=DEV) for _ in range(nl)]
+    stride = nmat * H * H + H
+    out = torch.empty(nl * stride, device=DEV); first = torch.empty(stride + nmat * H, device=DEV)
+    big = torch.empty(300 << 20, dtype=torch.uint8, device=DEV)
+    for _ in range(5):
+        big.fill_(1)      # (cold caches, as inside the step)
+        ops.wgrad_batched(topo, Gs, H, Xs, H, nmat, out[:(nl - 1) * stride], first_rowscale2=topo.deg_pows, first_out=first, pending=[])
+    torch.cuda.synchronize()
+    lib = C.CDLL(pkg._lib.LIB_PATH)
+    n = 512 * 4 * 16
+    buf = (C.c_ulonglong * n)()
+    assert lib.dss2_debug_read_hstamps(buf, n) == 0
+    t = np.frombuffer(buf, dtype=np.uint64).reshape(512, 4, 16).astype(np.int64)
+    t = t[(t[:, :, 11] > 0).all(axis=1)]
+    def show(name, v):
+        print(f"{name:58s} mean {v.mean():8.0f}  median {np.median(v):8.0f}  p90 {np.percentile(v, 90):8.0f} ticks")
+    print(f"{t.shape[0]} workgroups stamped")
+    show("scales (LDS maxima, running exponents)", t[:, :, 1] - t[:, :, 0])
+    show("staging: splits of X and G -> planes, fp32 G, ELL", t[:, :, 2] - t[:, :, 1])
+    show("barrier", t[:, :, 3] - t[:, :, 2])
+    show("next tile's loads issued", t[:, :, 4] - t[:, :, 3])
+    show("hop 1 (gathers, fma, split -> planes)", t[:, :, 5] - t[:, :, 4])
+    show("barrier", t[:, :, 6] - t[:, :, 5])
+    show("hop 2", t[:, :, 7] - t[:, :, 6])
+    show("barrier", t[:, :, 8] - t[:, :, 7])
+    show("MFMA phase (36 MFMAs = 1152 cycles of matrix pipe)", t[:, :, 9] - t[:, :, 8])
+    show("next tile's maxima (waits for its rows)", t[:, :, 10] - t[:, :, 9])
+    show("closing barrier", t[:, :, 11] - t[:, :, 10])
+    show("tile total", t[:, :, 11] - t[:, :, 0])
+
+
+COMMANDS = {"wgradh": cmd_wgradh, "gemm": cmd_gemm, "teams": cmd_teams, "chain": cmd_chain, "stack": cmd_stack, "wgrad": cmd_wgrad, "wgradxp": cmd_wgradxp, "wgradxq": cmd_wgradxq}
 
 if __name__ == "__main__":
     if len(sys.argv) < 2 or sys.argv[1] not in COMMANDS:
