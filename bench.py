@@ -378,6 +378,7 @@ def main():
             events.append((e0, e1, 1, bool(kw.get("transposed", False))))
 
     wg_events = []
+    wg_topo = [None]
     orig_wgb = nw_mod.wgrad_batched
 
     def timed_wgrad_batched(topo, Gs, hout, Xs, hin, nmat, out_flat, **kw):   # the block's H -> H weight gradients (one launch)
@@ -386,6 +387,7 @@ def main():
         orig_wgb(topo, Gs, hout, Xs, hin, nmat, out_flat, **kw)
         e1.record()
         wg_events.append((e0, e1, len(Gs), hout, hin, nmat))
+        wg_topo[0] = topo
 
     def timed_pass(n_steps):
         events.clear()
@@ -466,24 +468,38 @@ def main():
             wflops = nl * 2.0 * N * nm * ho * hi
             wus = sum(a.elapsed_time(b) for a, b, *_ in wg_events) / len(wg_events) * 1e3
             wbf16 = bool(pkg.flags.WGRAD_BF16)
-            wpeak = BF16_MFMA_PEAK_TF / 6.0 if wbf16 else FP32_MFMA_PEAK_TF
+            # which kernel took the launch: f16x3 (two fp16 pieces per operand, THREE matrix instructions per fp32 product; 32-row tiles) or
+            # bf16x6 (three bf16 pieces, SIX).  The bound is the pipe's dense peak (2500 TF for fp16 and bf16 alike) over that count, so a
+            # kernel that needs half the instructions has twice the bound: `frac` says how busy the pipe is, ms/step what the work costs.
+            wts = pkg.ops._wgrad_tiles(wg_topo[0], nm, ho, hi, int(wbf16))
+            wf16 = bool(wbf16 and (pkg.ops._wgrad_mode(wts, nm, 1) & 255) == 2)
+            wprod = 3.0 if wf16 else 6.0
+            wpeak = BF16_MFMA_PEAK_TF / wprod if wbf16 else FP32_MFMA_PEAK_TF
+            wname = ("(dss2::wgrad16h_kernel, f16x3)" if wf16 else "(dss2::wgrad16b_kernel / wgrad16_kernel, bf16x6)") if wbf16 else "(dss2::wgrad_kernel, fp32 MFMA)"
             result["roofline_wgrad"] = {
-                "kernel": f"the block's {nl} H->H weight gradients dW_k = ((A^T)^k g)^T h in one launch "
-                          + ("(dss2::wgrad16b_kernel / wgrad16_kernel, bf16x6)" if wbf16 else "(dss2::wgrad_kernel, fp32 MFMA)"),
+                "kernel": f"the block's {nl} H->H weight gradients dW_k = ((A^T)^k g)^T h in one launch " + wname,
                 "bound": "mfma", "achieved": wflops / (wus * 1e-6) / 1e12, "peak": wpeak, "unit": "TFLOP/s",
                 "frac": wflops / (wus * 1e-6) / 1e12 / wpeak, "avg_launch_us": wus, "launches_timed": len(wg_events),
                 "algorithmic_flops_per_launch": wflops, "traffic": None,
+                "peak_pipe": (f"fp16 / bf16 MFMA dense peak (2500 TF) / {int(wprod)} instructions per fp32 product" if wbf16 else "fp32 MFMA"),
             }
         if bf16x6:
-            # The tile GEMM runs on the bf16 matrix pipe as six v_mfma_f32_32x32x16_bf16 per fp32 product group (operands split
-            # into three bf16 pieces, fp32 accumulation: fp32-accurate, tools/accuracy_bf16x6.py).  The bound of the pipe the
-            # kernel executes on is the dense bf16 peak / 6 executed flops per algorithmic flop: THAT is `peak` and `frac`.
-            # The ratio to the fp32 MFMA peak (which this kernel can exceed) is kept as a secondary field only.
+            # The tile GEMM runs on the 16-bit matrix pipe: as f16x3 (round 5: operands as TWO fp16 pieces after an exact power-of-two
+            # scale, THREE v_mfma_f32_16x16x32_f16 per fp32 product group; csrc/dss2_gemm_chain_sp.hip MS = 2) where the chain has the
+            # form, else as bf16x6 (three bf16 pieces, SIX instructions).  fp32 accumulation, errors of fp32 arithmetic's own size
+            # (tests/test_gpu_f16x3.py, tools/accuracy_bf16x6.py).  The bound of the pipe the kernel executes on is its dense peak
+            # (2500 TF for fp16 and bf16 alike) / executed flops per algorithmic flop: THAT is `peak` and `frac` -- a kernel that needs
+            # half the instructions has twice the bound; what the work costs is ms_per_step.  The ratio to the fp32 MFMA peak (which
+            # this kernel exceeds) is kept as a secondary field only.
+            f16x3 = bool(pkg.flags.CHAIN_F16 and pkg.ops.chain_f16_supported(topo_, KHOPS + 1, HID) and kname.startswith("gemm_chain_sp"))
+            nprod = 3.0 if f16x3 else 6.0
             r = result["roofline"]
             r["frac_of_fp32_mfma_peak"] = r["achieved"] / FP32_MFMA_PEAK_TF
-            r["peak"] = BF16_MFMA_PEAK_TF / 6.0
+            r["peak"] = BF16_MFMA_PEAK_TF / nprod
             r["frac"] = r["achieved"] / r["peak"]
-            r["peak_pipe"] = "bf16 MFMA dense peak (2500 TF) / 6 instructions per fp32 product group (bf16x6)"
+            r["peak_pipe"] = (f"fp16 MFMA dense peak (2500 TF) / 3 instructions per fp32 product group (f16x3)" if f16x3 else
+                              "bf16 MFMA dense peak (2500 TF) / 6 instructions per fp32 product group (bf16x6)")
+            r["mfma_instructions_per_fp32_product"] = int(nprod)
             r["frac_bf16_pipe"] = r["frac"]
             if held_clock_ghz:
                 # the matrix pipe's bound scales with the clock: 2.5 PF is the figure at 2.4 GHz.  Under this kernel the chip holds less

@@ -78,6 +78,41 @@ __device__ __forceinline__ void split3x4(const f32x4 v, bf16x4& h, bf16x4& m, bf
   }
 }
 
+// ---- f16x3 (round 5): an fp32 operand as TWO fp16 pieces, hi = fp16(x), lo = fp16(x - hi), after an exact power-of-two scale that
+// puts the operand's maximum into [2^14, 2^15); a product is three fp16 MFMAs (lo hi + hi lo + hi hi).  See dss2_wgrad16h.hip.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// the two pieces of (a, b), each packed {a, b}
+__device__ __forceinline__ void split2_pair(float a, float b, uint32_t& h, uint32_t& l) {
+  const f16x2 hh = __builtin_convertvector(f32x2{a, b}, f16x2);
+  const float ra = a - (float)hh[0], rb = b - (float)hh[1];
+  h = __builtin_bit_cast(uint32_t, hh);
+  l = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ra, rb}, f16x2));
+}
+__device__ __forceinline__ float absmax4(float m, const f32x4 v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+// max over the wave of non-negative values, in every lane (DPP row shifts and broadcasts: six VALU instructions; six ds_bpermute
+// round trips cost the weight-gradient kernel ~1000 cycles per tile).  v_max_f32 ignores NaN operands.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_max(float v) {
+  return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, true)));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = dpp_max<0x111, 0xf>(v);      // row_shr:1
+  v = dpp_max<0x112, 0xf>(v);      // row_shr:2
+  v = dpp_max<0x114, 0xf>(v);      // row_shr:4
+  v = dpp_max<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row of 16: the row's maximum
+  v = dpp_max<0x142, 0xa>(v);      // row_bcast:15 into rows 1, 3
+  v = dpp_max<0x143, 0xc>(v);      // row_bcast:31 into rows 2, 3 -> lane 63: the wave's maximum
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// floor(log2 m) for a finite positive fp32, clamped to [-100, 127] (0, subnormals -> -100; Inf / NaN -> 128: the scaled values stay Inf / NaN)
+__device__ __forceinline__ int exp_of(float m) {
+  const int e = (int)((__float_as_uint(m) >> 23) & 255u) - 127;
+  return e < -100 ? -100 : e;
+}
+
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 // Orders LDS traffic between lanes of ONE wave (DS ops of a wave execute in order; this keeps

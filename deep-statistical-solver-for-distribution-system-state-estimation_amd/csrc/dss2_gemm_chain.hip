@@ -49,6 +49,15 @@ extern "C" int dss2_gemm_prop_chain16_supported(int nrb, int nmat, int kreal, in
 
 static int chain_impl(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, const dss2_chain_head* head, void* stream);
 
+// b_format 2 (weights as two fp16 planes + scale exponents, tile GEMM as f16x3): the split-plane chain of 64-row tiles on 16x16x32 MFMAs
+extern "C" int dss2_gemm_prop_chain_f16_supported(int nrb, int nmat, int kreal, int hout, int ell_width) {
+  using namespace dss2;
+  if (nrb != 2 || (hout & 31) != 0 || kreal != hout || ell_width <= 0 || !dss2_gemm_prop_chain16_supported(nrb, nmat, kreal, hout, ell_width)) return 0;
+  dss2_gemm_prop_args a = {};
+  a.b_format = 2; a.nrb = nrb; a.nmat = nmat; a.kreal = kreal; a.kpad = (kreal + 15) / 16 * 16; a.hout = hout; a.ncg = (hout + 31) / 32; a.ell_width = ell_width;
+  return chain_row_split(nrb, a.ncg) == 1 && chain_sp_supported(a) ? 1 : 0;
+}
+
 extern "C" int dss2_gemm_prop_chain_xplanes_supported(int nrb, int nmat, int kreal, int hout, int ell_width) {
   using namespace dss2;
   if (nrb != 2 || (hout & 31) != 0 || !dss2_gemm_prop_chain16_supported(nrb, nmat, kreal, hout, ell_width)) return 0;
@@ -87,7 +96,8 @@ extern "C" int dss2_gemm_prop_chain_head(const dss2_gemm_prop_args* ap, const ds
 static int dss2_gemm_prop_chain_head_launch(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, const dss2_chain_head* head, void* stream) {
   using namespace dss2;
   if (!head || (head->mode != 1 && head->mode != 2)) { set_error("gemm_prop_chain_head: head.mode must be 1 or 2"); return 2; }
-  if (!(dss2_gemm_prop_chain_head_supported(ap->nrb, ap->nmat, ap->kreal, ap->hout, ap->ell_width, head->nout) & head->mode) || ap->b_format != 1) {
+  if (!(dss2_gemm_prop_chain_head_supported(ap->nrb, ap->nmat, ap->kreal, ap->hout, ap->ell_width, head->nout) & head->mode) || (ap->b_format != 1 && ap->b_format != 2) ||
+      (ap->b_format == 2 && !dss2_gemm_prop_chain_f16_supported(ap->nrb, ap->nmat, ap->kreal, ap->hout, ap->ell_width))) {
     set_error("gemm_prop_chain_head: unsupported shape (nrb=%d nmat=%d hid=%d nout=%d b_format=%d)", ap->nrb, ap->nmat, ap->hout, head->nout, ap->b_format);
     return 2;
   }
@@ -109,7 +119,7 @@ static int chain_impl(const dss2_gemm_prop_args* ap, const dss2_chain_layer* lay
   if (a.ntiles <= 0) return 0;
   const bool tall16 = a.b_format == 1 && a.nrb == 6 && dss2_gemm_prop_chain16_supported(a.nrb, a.nmat, a.kreal, a.hout, a.ell_width);
   if ((!tall16 && !dss2_gemm_prop_chain_supported(a.nrb, a.nmat, a.kreal, a.hout, a.ell_width)) || !a.ell_tiles || a.prop_in || a.narrow_h ||
-      a.rowscale || a.kpad != (a.b_format == 1 ? (a.kreal + 15) / 16 * 16 : (a.kreal + 7) / 8 * 8) || a.ncg != (a.hout + 31) / 32) {
+      a.rowscale || a.kpad != (a.b_format >= 1 ? (a.kreal + 15) / 16 * 16 : (a.kreal + 7) / 8 * 8) || a.ncg != (a.hout + 31) / 32) {
     set_error("gemm_prop_chain: unsupported shape (nrb=%d nmat=%d k=%d hout=%d ell=%d); use dss2_gemm_prop per layer",
               a.nrb, a.nmat, a.kreal, a.hout, a.ell_width);
     return 2;
@@ -137,6 +147,13 @@ static int chain_impl(const dss2_gemm_prop_args* ap, const dss2_chain_layer* lay
   if (any_pre && !a.pre_rowscale) { set_error("gemm_prop_chain: prebias needs pre_rowscale"); return 2; }
   hipStream_t s = as_stream(stream);
   const int rsplit = chain_row_split(a.nrb, a.ncg);
+  if (a.b_format == 2) {     // weights packed as two fp16 planes with scale exponents, tile GEMM as f16x3
+    if (!dss2_gemm_prop_chain_f16_supported(a.nrb, a.nmat, a.kreal, a.hout, a.ell_width)) {
+      set_error("gemm_prop_chain(f16x3): unsupported shape (nrb=%d nmat=%d k=%d hout=%d): 64-row tiles, hout a multiple of 32", a.nrb, a.nmat, a.kreal, a.hout);
+      return 2;
+    }
+    return launch_chain_sp(a, ct, head, s);
+  }
   if (a.b_format == 1) {     // weights packed as bf16x3 fragments, tile GEMM as bf16x6
     if (!dss2_gemm_prop_chain16_supported(a.nrb, a.nmat, a.kreal, a.hout, a.ell_width) || (a.kpad & 15)) {
       set_error("gemm_prop_chain(bf16x6): unsupported shape (nrb=%d nmat=%d k=%d kpad=%d hout=%d)", a.nrb, a.nmat, a.kreal, a.kpad, a.hout);

@@ -45,6 +45,15 @@ __device__ __forceinline__ void sp_store_split(__bf16* dst, const f32x4 v) {
   *reinterpret_cast<u32x2*>(dst + 2 * SP_PLANE) = u32x2{l0, l1};
 }
 
+// f16x3 form (MS = 2): the two fp16 pieces of 4 consecutive values scaled by 2^e -> planes 0, 1
+__device__ __forceinline__ void sp_store_split_h(__bf16* dst, const f32x4 v, int e) {
+  uint32_t h0, l0, h1, l1;
+  split2_pair(ldexpf(v[0], e), ldexpf(v[1], e), h0, l0);
+  split2_pair(ldexpf(v[2], e), ldexpf(v[3], e), h1, l1);
+  *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+  *reinterpret_cast<u32x2*>(dst + SP_PLANE) = u32x2{l0, l1};
+}
+
 // HM (fused narrow head, dss2_gemm_prop_chain_head): 0 none; 1 forward -- after the last chained layer the tile is still in
 // the waves' registers: the head TAGConv (hid -> nout <= 4) is computed from them (per wave the partial products of its 32
 // columns, summed over the waves in LDS, two hops on nout-wide rows by wave 0) instead of a launch that re-reads [N, hid];
@@ -59,6 +68,13 @@ constexpr int SP_HEAD_MAX = 4;      // nout
 // rows x 8 k at k = 32 kb + 8 (lane >> 4) of the same planes, the B fragment is read out of the SAME packed weights (fragment order of
 // the 32x32x16 form: k-group 2 kb + (lane >> 5), source lane ((lane >> 4) & 1) * 32 + 16 nb + (lane & 15)).  Only the GEMM phase and the
 // accumulator hand-off (put) differ; sums are formed in another order, so results differ from MS = 0 by rounding.  K a multiple of 32.
+// MS = 2 (round 5): MS = 1's structure as f16x3 -- the tile lives in LDS as TWO fp16 planes per stripe, scaled by 2^ea (ea: a per-tile,
+// per-layer exponent that puts the tile's largest |value| into [2^14, 2^15)); the weights come as two fp16 planes scaled by 2^ew[m] per
+// matrix (dss2_pack_desc, transpose bit 3: the exponents follow the planes); three v_mfma_f32_16x16x32_f16 per product group (lo hi +
+// hi lo + hi hi) instead of six; the accumulators leave the GEMM phase multiplied by 2^-(ea + ew[m]) (v_ldexp in the hand-off: exact),
+// so the hops and the epilogue are those of the bf16x6 form.  The tile maximum: every wave's maximum over its stripe of the finished
+// layer output (DPP), four LDS words, ONE more barrier per layer.  Errors of the size of fp32 arithmetic's own (dss2_wgrad16h.hip).
+// Layers gated by fp32 activations and X plane images: not in this form (the host routes them to MS = 1).
 typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 template <int NMAT, int NW, int HM, int MS>
 __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_gemm_prop_args p, const ChainTable ct, const dss2_chain_head hd) {
@@ -70,6 +86,8 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
   const int nthreads = blockDim.x;
   const int ncg = nthreads >> 6;
   const int tile = blockIdx.x;
+  constexpr bool F16 = MS == 2;
+  constexpr int NP = F16 ? 2 : 3;      // planes per stripe / per weight fragment group
   const uint64_t drop_seed = p.drop_state ? p.drop_state[0] : 0, drop_off = p.drop_state ? p.drop_state[1] : 0;
   const bool probe = ct.clock_probe != nullptr && (tile & 255) == 0 && tile < 1024;      // (uniform; diagnostic, see ChainTable)
   if (probe && tid == 0) {      // (written at once: nothing of the probe stays live across the kernel)
@@ -79,6 +97,13 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
   __bf16* xpl = reinterpret_cast<__bf16*>(smem);               // stripe s: xpl + s * (2 * SP_REGION)
   int2* ell = reinterpret_cast<int2*>(smem + ncg * SP_REGION);
   const int D = p.ell_width;
+  float* mxw = reinterpret_cast<float*>(ell + D * TM);      // (MS = 2) [ncg]: every wave's maximum over its part of the tile
+  int ea = 0;                                                // (MS = 2) the planes in LDS hold 2^ea x
+  auto tile_exponent = [&]() {      // after a barrier behind the waves' writes of mxw
+    float m = 0.f;
+    for (int w = 0; w < ncg; ++w) m = fmaxf(m, mxw[w]);
+    return 14 - __builtin_amdgcn_readfirstlane(exp_of(m));
+  };
   const int ts = p.tile_start[tile];
   const int R = p.tile_start[tile + 1] - ts;
   const int kq = p.kpad >> 2;
@@ -98,12 +123,35 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
     const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
     for (int idx = tid; idx < D * TM; idx += nthreads) ell[idx] = src[idx];
   }
-  if constexpr (HM != 2) {
+  if constexpr (HM != 2 && !F16) {
     for (int idx = tid; idx < TM * kq; idx += nthreads) {
       const int r = idx / kq, c = (idx - r * kq) << 2;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
       sp_store_split(xpl + (c >> 5) * (2 * SP_REGION) + r * SP_RS + (c & 31), v);
+    }
+  } else if constexpr (HM != 2) {
+    // the input tile waits in registers (TM kq / threads = kpad / (4 ncg) <= 8 row pieces per thread) while its maximum is formed
+    f32x4 xin[8];
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx = tid + j * nthreads;
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      const bool on = idx < TM * kq && r < R && c < p.kreal;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + (on ? r : 0)) * p.ldx + (on ? c : 0));      // (unconditional, masked)
+      xin[j] = on ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      mx = absmax4(mx, xin[j]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) mxw[wave] = mx;
+    sp_barrier();
+    ea = tile_exponent();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx = tid + j * nthreads;
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      if (idx < TM * kq) sp_store_split_h(xpl + (c >> 5) * (2 * SP_REGION) + r * SP_RS + (c & 31), xin[j], ea);
     }
   } else {
     // X[row][c] = gate(row, c) * sum_{m, o} ((P^T)^m G)[row][o] W_m[o][c]: every wave builds its own 32-column stripe.
@@ -164,28 +212,40 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
       else *reinterpret_cast<f32x4*>(hd.Xout + (size_t)(ts + row) * hd.ldxo + col0) = v;      // (the weight gradients read it)
       xv[i] = v;
     }
+    if constexpr (F16) {
+      float mx = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mx = absmax4(mx, xv[i]);
+      mx = wave_max(mx);
+      if (lane == 0) mxw[wave] = mx;
+      sp_barrier();
+      ea = tile_exponent();
+    }
     wave_lds_sync();                         // every lane is done with zt: the planes go over it
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sp_store_split(own_planes + (r8 + 8 * i) * SP_RS + cq, xv[i]);
+    for (int i = 0; i < 8; ++i) {
+      if constexpr (F16) sp_store_split_h(own_planes + (r8 + 8 * i) * SP_RS + cq, xv[i], ea);
+      else sp_store_split(own_planes + (r8 + 8 * i) * SP_RS + cq, xv[i]);
+    }
   }
 
-  bf16x8 b0[3][NMAT];
-  auto load_b = [&](const bf16x8* __restrict__ bp16, bf16x8 (&b)[3][NMAT], int ks) {
+  bf16x8 b0[NP][NMAT];
+  auto load_b = [&](const bf16x8* __restrict__ bp16, bf16x8 (&b)[NP][NMAT], int ks) {
 #pragma unroll
     for (int m = 0; m < NMAT; ++m)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) b[pl][m] = bp16[(((size_t)(m * ncg + cg) * nks + ks) * 3 + pl) * 64 + lane];
+      for (int pl = 0; pl < NP; ++pl) b[pl][m] = bp16[(((size_t)(m * ncg + cg) * nks + ks) * NP + pl) * 64 + lane];
   };
   // MS = 1: the fragments of k-step kb (32 k) and 16-column block nb, out of the 32x32x16 fragment order
   // (a uniform 64-bit base per matrix -- scalar registers -- plus ONE 32-bit lane offset: with per-matrix 64-bit lane pointers the
   //  16x16 form kept three pointer pairs in scratch memory and reloaded them, each behind an s_waitcnt vmcnt(0), at the top of every k-step)
-  const uint32_t b16_lane = (uint32_t)(((lane >> 5) * 3 * 64 + ((lane >> 4) & 1) * 32 + (lane & 15)) * 16);
-  auto load_b16 = [&](const bf16x8* __restrict__ bp16, bf16x8 (&b)[3][NMAT], int kb, int nb) {
+  const uint32_t b16_lane = (uint32_t)(((lane >> 5) * NP * 64 + ((lane >> 4) & 1) * 32 + (lane & 15)) * 16);
+  auto load_b16 = [&](const bf16x8* __restrict__ bp16, bf16x8 (&b)[NP][NMAT], int kb, int nb) {
 #pragma unroll
     for (int m = 0; m < NMAT; ++m) {
-      const char* mbase = reinterpret_cast<const char*>(bp16) + (size_t)(uint32_t)(((m * ncg + cg) * nks + 2 * kb) * 3072 + nb * 256);      // uniform
+      const char* mbase = reinterpret_cast<const char*>(bp16) + (size_t)(uint32_t)(((m * ncg + cg) * nks + 2 * kb) * (NP * 1024) + nb * 256);      // uniform
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) b[pl][m] = *reinterpret_cast<const bf16x8*>(mbase + (size_t)(b16_lane + (uint32_t)(pl * 1024)));
+      for (int pl = 0; pl < NP; ++pl) b[pl][m] = *reinterpret_cast<const bf16x8*>(mbase + (size_t)(b16_lane + (uint32_t)(pl * 1024)));
     }
   };
   if constexpr (MS == 0) load_b(reinterpret_cast<const bf16x8*>(ct.l[0].Bp), b0, 0);
@@ -199,26 +259,42 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
     const dss2_chain_layer& L = ct.l[li];    // uniform: scalar loads from the kernel-argument segment
     const bf16x8* __restrict__ bp16 = reinterpret_cast<const bf16x8*>(L.Bp);
     f32x16 acc[MS == 0 ? 2 : 1][NMAT];
-    f32x4_acc c16[MS == 1 ? 4 : 1][2][NMAT];
+    f32x4_acc c16[MS >= 1 ? 4 : 1][2][NMAT];
+    [[maybe_unused]] int ue[NMAT];      // (MS = 2) what takes the scales out of matrix m's accumulators: -(ea + ew[m])
+    if constexpr (F16) {
+      const int* whdr = reinterpret_cast<const int*>(reinterpret_cast<const char*>(L.Bp) + (size_t)NMAT * ncg * nks * 2048);      // uniform: scalar loads
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) ue[m] = -(ea + whdr[m]);
+    }
 
-    if constexpr (MS == 1) {
+    if constexpr (MS >= 1) {
       // ---- tile GEMM on 16x16x32 MFMAs: a k-step (32 k) is two half-steps, one per 16-column block; the four row blocks' A fragments
       // live for the whole k-step and are re-requested for the next one right after their last use; B fragments ping-pong one half-step ahead
       const int nkb = p.kpad >> 5;
-      bf16x8 b1[3][NMAT], a[4][3];
-      auto load_a16 = [&](bf16x8 (&af)[3], int mb, int kb) {
+      bf16x8 b1[NP][NMAT], a[4][NP];
+      auto load_a16 = [&](bf16x8 (&af)[NP], int mb, int kb) {
         const __bf16* src = xpl + kb * (2 * SP_REGION) + (mb * 16 + (lane & 15)) * SP_RS + (lane >> 4) * 8;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8*>(src + pl * SP_PLANE);
+        for (int pl = 0; pl < NP; ++pl) af[pl] = *reinterpret_cast<const bf16x8*>(src + pl * SP_PLANE);
       };
-      auto mma16 = [&](const bf16x8 (&af)[3], const bf16x8 (&b)[3][NMAT], f32x4_acc (&c)[NMAT], const bool first) {
+      auto mma16 = [&](const bf16x8 (&af)[NP], const bf16x8 (&b)[NP][NMAT], f32x4_acc (&c)[NMAT], const bool first) {
         const f32x4_acc zero = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (F16) {      // lo hi + hi lo + hi hi, smallest terms first
+          auto h8 = [](const bf16x8 v) { return __builtin_bit_cast(f16x8, v); };
 #pragma unroll
-        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], b[0][m], first ? zero : c[m], 0, 0, 0);
+          for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h8(af[1]), h8(b[0][m]), first ? zero : c[m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h8(af[0]), h8(b[1][m]), c[m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h8(af[0]), h8(b[0][m]), c[m], 0, 0, 0);
+          return;
+        }
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NP - 1], b[0][m], first ? zero : c[m], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], b[1][m], c[m], 0, 0, 0);
 #pragma unroll
-        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], b[2][m], c[m], 0, 0, 0);
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], b[NP - 1][m], c[m], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], b[0][m], c[m], 0, 0, 0);
 #pragma unroll
@@ -235,21 +311,31 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
         load_b16(bp16, b0, kn, 0);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) { mma16(a[mb], b1, c16[mb][1], first); load_a16(a[mb], mb, kn); }
-        // one memory request per few MFMAs: half-step 0 carries the 3 NMAT weight fragments of half-step 1, half-step 1 those of the next
-        // k-step and, behind each row block's MFMAs, that block's three plane fragments
-        // half-step 0 (24 NMAT MFMAs): its 3 NMAT weight requests, one per two MFMAs, then the rest
+        // one memory request per few MFMAs: half-step 0 carries the NP NMAT weight fragments of half-step 1, half-step 1 those of the next
+        // k-step and, behind each row block's MFMAs, that block's NP plane fragments
+        constexpr int NPR = F16 ? 3 : 6;              // MFMAs per product group
+        constexpr int NQ = NP * NMAT;                 // weight requests per half-step
+        constexpr int RBM = NPR * NMAT;               // MFMAs per row block and half-step
+        // half-step 0 (4 RBM MFMAs): its NQ weight requests, one per two MFMAs, then the rest
 #pragma unroll
-        for (int i = 0; i < 3 * NMAT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-        __builtin_amdgcn_sched_group_barrier(0x008, 24 * NMAT - 6 * NMAT, 0);
-        // half-step 1: row block 0's 6 NMAT MFMAs carry the next weight requests; behind them row block 0's plane registers are free and
-        // row block j's MFMAs carry the three plane reads of row block j - 1; the last three reads close the step (needed 18 NMAT MFMAs later)
+        for (int i = 0; i < NQ; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * RBM - 2 * NQ, 0);
+        // half-step 1: row block 0's RBM MFMAs carry the next weight requests; behind them row block 0's plane registers are free and
+        // row block j's MFMAs carry the NP plane reads of row block j - 1; the last NP reads close the step
 #pragma unroll
-        for (int i = 0; i < 3 * NMAT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, (6 * NMAT) / (3 * NMAT), 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        for (int i = 0; i < NQ; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, F16 ? 1 : 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        if constexpr (RBM - (F16 ? 1 : 2) * NQ > 0) __builtin_amdgcn_sched_group_barrier(0x008, RBM - (F16 ? 1 : 2) * NQ, 0);
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 3; ++j) {
+          if constexpr (F16) {
+            __builtin_amdgcn_sched_group_barrier(0x008, (RBM + 1) / 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, RBM / 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          } else {
 #pragma unroll
-          for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2 * NMAT, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, RBM / 3, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+          }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
       };
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) load_a16(a[mb], mb, 0);
@@ -378,7 +464,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) dst[(mb * 16 + r) * 32 + nb * 16] = c16[mb][nb][m][r];
+              for (int r = 0; r < 4; ++r) dst[(mb * 16 + r) * 32 + nb * 16] = F16 ? ldexpf(c16[mb][nb][m][r], ue[m]) : c16[mb][nb][m][r];
         }
       };
       put(slot0, NMAT - 1);
@@ -507,7 +593,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
       }
       reinterpret_cast<uint32_t*>(L.y_bits)[((size_t)tile * ncg + cg) * 64 + lane] = word;
     }
-    if (L.x_planes) {      // (uniform)
+    if (!F16 && L.x_planes) {      // (uniform; not in the f16x3 form)
       // The layer's output as an X plane image for its consumer's weight gradient (dss2_wgrad16p.hip): this lane owns rows r8 + 8 i,
       // i = 0..7, of four columns -- per column and piece exactly one 16-byte entry of the image (k-step r8 >> 1, k half r8 & 1, lane
       // slot q * 8 + (lane & 7) of column cq + q).  The split is made ONCE, in ROW pairs (the image's order); the next layer's LDS
@@ -545,8 +631,21 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
       //  activation), no real row ever gathers from them (ELL neighbours are real rows; a padding row's own entries carry weight 0),
       //  nothing of them is stored, the fused head below masks its own copy.  Columns beyond hout are zero by construction:
       //  zero weight columns, no bias.)
+      if constexpr (F16) {
+        // the next layer's scale: the tile's maximum over all stripes (one more barrier per layer; the planes then go over the slots)
+        float mx = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sp_store_split(own_planes + (rowv + 8 * i) * SP_RS + cq, U[i]);
+        for (int i = 0; i < 8; ++i) mx = absmax4(mx, U[i]);
+        mx = wave_max(mx);
+        if (lane == 0) mxw[wave] = mx;
+        sp_barrier();
+        ea = tile_exponent();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sp_store_split_h(own_planes + (rowv + 8 * i) * SP_RS + cq, U[i], ea);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sp_store_split(own_planes + (rowv + 8 * i) * SP_RS + cq, U[i]);
+      }
     }
     if constexpr (HM == 1) {
       if (!keep) {
@@ -649,11 +748,13 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
   }
 }
 
-inline size_t chain_sp_lds_bytes(int ncg, int ell_width) { return (size_t)ncg * SP_REGION * 4 + (size_t)SP_TM * ell_width * 8; }
+inline size_t chain_sp_lds_bytes(int ncg, int ell_width) { return (size_t)ncg * SP_REGION * 4 + (size_t)SP_TM * ell_width * 8 + 64; }      // (+ the f16x3 form's maxima)
 
 bool chain_sp_supported(const dss2_gemm_prop_args& a) {
   static const int on = [] { const char* e = getenv("DSS2_CHAIN_SP"); return e ? atoi(e) : 1; }();
-  return on && a.b_format == 1 && a.nrb == 2 && a.nmat >= 2 && a.nmat <= 3 && (a.kpad & 15) == 0 && a.kpad <= 32 * a.ncg &&
+  static const int f16on = [] { const char* e = getenv("DSS2_CHAIN_SP_F16"); return e ? atoi(e) : 1; }();
+  if (a.b_format == 2 && (!f16on || (a.kpad & 31) != 0)) return false;      // the f16x3 form: 16x16x32 MFMAs only
+  return on && (a.b_format == 1 || a.b_format == 2) && a.nrb == 2 && a.nmat >= 2 && a.nmat <= 3 && (a.kpad & 15) == 0 && a.kpad <= 32 * a.ncg &&
          a.ncg >= 3 && a.ncg <= 8 && chain_sp_lds_bytes(a.ncg, a.ell_width) <= (size_t)kMaxLdsBytes;
 }
 
@@ -673,6 +774,13 @@ static int launch_sp_hm(const dss2_gemm_prop_args& a, const ChainTable& ct, cons
   //  form has 24 registers less room, spills them on arrival and waits a memory latency per layer -- 124 us against 107)
   bool fp32_gates = false;
   for (int i = 0; i < ct.n; ++i) fp32_gates = fp32_gates || (ct.l[i].relu_src && !ct.l[i].gate_bits);
+  if (a.b_format == 2) {      // weights as two fp16 planes: the f16x3 form
+    bool xp = false;
+    for (int i = 0; i < ct.n; ++i) xp = xp || ct.l[i].x_planes;
+    if (fp32_gates || xp) { set_error("gemm_prop_chain(f16x3): layers gated by fp32 activations / X plane images need bf16x3 weights (b_format 1)"); return 2; }
+    if (a.nmat == 2) return a.ncg <= 4 ? launch_sp<2, 4, HM, 2>(a, ct, hd, s) : launch_sp<2, 8, HM, 2>(a, ct, hd, s);
+    return a.ncg <= 4 ? launch_sp<3, 4, HM, 2>(a, ct, hd, s) : launch_sp<3, 8, HM, 2>(a, ct, hd, s);
+  }
   if (ms16 && (a.kpad & 31) == 0 && !fp32_gates) {
     if (a.nmat == 2) return a.ncg <= 4 ? launch_sp<2, 4, HM, 1>(a, ct, hd, s) : launch_sp<2, 8, HM, 1>(a, ct, hd, s);
     return a.ncg <= 4 ? launch_sp<3, 4, HM, 1>(a, ct, hd, s) : launch_sp<3, 8, HM, 1>(a, ct, hd, s);

@@ -42,20 +42,9 @@ __device__ unsigned long long g_hstamps[512 * 4 * 16];
 #endif
 
 constexpr int W16H_TM = 32, W16H_ZC = 64, W16H_XW = 128, W16H_NT = 256, W16H_LDZF = 64, W16H_DMAX = 8;
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
 // (the transposed image of wgrad16b_kernel: 64 bytes per column and plane, 16-byte chunks of 8 rows swizzled)
 __device__ __forceinline__ int tph_key(int col) { return (((col >> 3) & 1) << 1) | ((col >> 4) & 1); }
 __device__ __forceinline__ int tph_off(int col, int row) { return col * 64 + ((((row >> 3) ^ tph_key(col)) << 4) | ((row & 7) << 1)); }
-
-// the two fp16 pieces of (a, b), packed {a, b}
-__device__ __forceinline__ void split2_pair(float a, float b, uint32_t& h, uint32_t& l) {
-  const f16x2 hh = __builtin_convertvector(f32x2{a, b}, f16x2);
-  const float ra = a - (float)hh[0], rb = b - (float)hh[1];
-  h = __builtin_bit_cast(uint32_t, hh);
-  l = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ra, rb}, f16x2));
-}
 
 // rows (2 rp, 2 rp + 1) x columns (c0 .. c0+3) scaled by 2^e -> the two planes of a transposed image with NCOLS columns
 template <int NCOLS>
@@ -68,30 +57,6 @@ __device__ __forceinline__ void store_planes_h(char* img, int off0, const f32x4 
     *reinterpret_cast<uint32_t*>(dst) = h;
     *reinterpret_cast<uint32_t*>(dst + NCOLS * 64) = l;
   }
-}
-
-__device__ __forceinline__ float absmax4(float m, const f32x4 v) {
-  return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-}
-// max over the wave of non-negative values, in every lane's copy of lane 63 (DPP row shifts and broadcasts: six VALU instructions;
-// six ds_bpermute round trips cost this kernel ~1000 cycles per tile).  v_max_f32 ignores NaN operands.
-template <int CTRL, int ROWS>
-__device__ __forceinline__ float dpp_max(float v) {
-  return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, true)));
-}
-__device__ __forceinline__ float wave_max(float v) {
-  v = dpp_max<0x111, 0xf>(v);      // row_shr:1
-  v = dpp_max<0x112, 0xf>(v);      // row_shr:2
-  v = dpp_max<0x114, 0xf>(v);      // row_shr:4
-  v = dpp_max<0x118, 0xf>(v);      // row_shr:8   -> lane 15 of every row of 16: the row's maximum
-  v = dpp_max<0x142, 0xa>(v);      // row_bcast:15 into rows 1, 3
-  v = dpp_max<0x143, 0xc>(v);      // row_bcast:31 into rows 2, 3 -> lane 63: the wave's maximum
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-// floor(log2 m) for a finite positive fp32, clamped to [-100, 127] (0, subnormals -> -100; Inf / NaN -> 128: the scaled values stay Inf / NaN)
-__device__ __forceinline__ int exp_of(float m) {
-  const int e = (int)((__float_as_uint(m) >> 23) & 255u) - 127;
-  return e < -100 ? -100 : e;
 }
 
 template <int NMAT, bool RS2>

@@ -9,6 +9,9 @@ CHAIN_LAYERS = _os.environ.get("DSS2_CHAIN", "1") == "1"               # hid->hi
 WGRAD_BF16 = _os.environ.get("DSS2_WGRAD_BF16", "1") == "1"            # weight gradients as bf16x6 where the kernel covers the shape
 CHAIN_GATE_BITS = _os.environ.get("DSS2_CHAIN_GATE_BITS", "1") == "1"  # split-plane chains (64-, 96-, 192-row tiles): the backward chain's ReLU gates as bit words written by the forward chain
 CHAIN_BF16 = _os.environ.get("DSS2_CHAIN_BF16", "1") == "1"            # its tile GEMM as bf16x6 on the bf16 matrix pipe (fp32-accurate)
+# ... as f16x3 where the split-plane chain of 64-row tiles has the form (round 5: two fp16 pieces per operand after an exact power-of-two
+# scale, three MFMAs per product instead of six; csrc/dss2_gemm_chain_sp.hip MS = 2).  0 = bf16x6.
+CHAIN_F16 = _os.environ.get("DSS2_CHAIN_F16", "1") == "1"
 CHAIN_HEAD = _os.environ.get("DSS2_CHAIN_HEAD", "1") == "1"            # the narrow head TAGConv's data gradient inside the chained launch of the data gradients
 # ... and the head's forward inside the forward chain (round 2: break-even, off; with the 16x16x32 chain of round 4 the fused step is
 # 4 us shorter; round 5: on, and bench.py counts the head's FLOPs in the launch it rides in).  DSS2_CHAIN_HEAD_FWD=0: its own launch.

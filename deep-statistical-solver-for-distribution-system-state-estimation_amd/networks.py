@@ -33,7 +33,7 @@ from .topology import Topology, get_topology
 _F32 = torch.float32
 
 from . import flags as FL
-from .ops import (new_xplanes, wgrad_batched_xp, xplanes_supported, _DROP_PARAMS, _dropout_params, _ncg, _ptr, _reduce, _require_gpu, _round16, _round8, _rows, _stream, _wgrad_per_cu, _wgrad_tiles, chain16_supported, chain_gate_words, chain_head_supported, chain_supported, csr_axpy, dropout_mask, dropout_snapshot, gather_rows, gemm16_supported, gemm_prop, gemm_prop_chain, is_narrow, finish_weights, prep_weights, reduce_pending, segment_sum, wgrad, wgrad_batched)
+from .ops import (new_xplanes, wgrad_batched_xp, xplanes_supported, _DROP_PARAMS, _dropout_params, _ncg, _ptr, _reduce, _require_gpu, _round16, _round8, _rows, _stream, _wgrad_per_cu, _wgrad_tiles, chain16_supported, chain_f16_supported, chain_gate_words, chain_head_supported, chain_supported, csr_axpy, dropout_mask, dropout_snapshot, gather_rows, gemm16_supported, gemm_prop, gemm_prop_chain, is_narrow, finish_weights, prep_weights, reduce_pending, segment_sum, wgrad, wgrad_batched)
 from .plans import (_DESC_DTYPE, _FoldPlan, _MatView, _PackPlan, _SG_DTYPE, _as_view, _pack_table, _sg, _sg_table, _small_gemm)
 
 
@@ -550,15 +550,18 @@ def _ensure_plans(mod, topo, dev, ps):
     fold_on = FL.FOLD_W2 and not is_narrow(nmat, hout0) and not glob
     b16 = tuple(range(1, L)) if (FL.CHAIN_BF16 and not glob and hid % 4 == 0 and hid <= 256 and not is_narrow(nmat, hid) and L >= 2
                                  and (L >= 3 or gemm16_supported(topo, nmat, hid, False))) else ()
+    # ... as f16x3 where both chains of the block have the form (64-row tiles; csrc/dss2_gemm_chain_sp.hip MS = 2) and the backward takes
+    # the chained route; X plane images (the optional DSS2_WGRAD_XP route) want bf16x3 pieces
+    f16 = bool(b16 and L >= 3 and FL.WGRAD_BATCH and not FL.WGRAD_XP and chain_f16_supported(topo, nmat, hid))
     if (mod._plan is None or mod._plan.device != dev or (mod._fold is not None) != fold_on or mod._plan.stacked != glob
-            or tuple(sorted(mod._plan.fwd16)) != b16):
+            or tuple(sorted(mod._plan.fwd16)) != b16 or mod._plan.f16 != f16):
         offs = mod._flat_offsets()
         mod._fold = _FoldPlan(W2, b2, conv_ps[0][1:], dev, int(offs[1]), int(offs[2])) if fold_on else None
         conv_groups = [list(cp[1:]) for cp in conv_ps]
         if fold_on:   # conv 0 is packed from the folded weights
             conv_groups[0] = [_MatView(mod._fold.Wf[m], hout0, hid, hid, 0, dep=True) for m in range(nmat)]
         mod._plan = _PackPlan([[W2]] + conv_groups + _dx_views(W1, hid, mod.dim_featn, mod.dim_feate), dev, stacked=glob,
-                              stacked_groups=(L + 3,), bf16_groups=b16)
+                              stacked_groups=(L + 3,), bf16_groups=b16, f16=f16)
     if mod._fold is not None:
         mod._fold.params = (W2, b2, list(conv_ps[0][1:]))
     return mod._plan, mod._fold, glob
@@ -588,7 +591,7 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None, need_dx=False):
     # producers, as the bf16x3 pieces the batched weight gradient's MFMA operand wants (csrc/dss2_wgrad16p.hip).  Only where the
     # backward will take exactly that launch: folded conv 0 + chained data gradients + batched weight gradients, grad mode on.
     gw = chain_gate_words(topo, nmat, hid) if use16 else 0      # (inside autograd.Function.forward grad mode is off: always written; 1/32 of a layer output)
-    use_xp = bool(use16 and gw and fold is not None and n_chain == L - 1 and 3 <= L <= 9 and not glob and xplanes_supported(topo, nmat, hid)
+    use_xp = bool(use16 and not plan.f16 and gw and fold is not None and n_chain == L - 1 and 3 <= L <= 9 and not glob and xplanes_supported(topo, nmat, hid)
                   and FL.WGRAD_JOIN_FOLDED is not False and mod.__dict__.get("_grad_mode", True)
                   and chain_supported(topo, nmat, hid, True, True) and chain16_supported(topo, nmat, hid, True))
     xps = [new_xplanes(topo, hid, dev) for _ in range(n_chain)] if use_xp else []
@@ -636,7 +639,7 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None, need_dx=False):
             head = dict(W=list(conv_ps[L - 1][1:1 + nmat]), nout=mod.dim_out, Y=y_head, bias=conv_ps[L - 1][0],
                         add_src=(x if mod.skip else None), add_ld=ldx)
         gemm_prop_chain(topo, h, hid, nmat, layers, pre_rowscale=(topo.deg_pows if fold is not None else None),
-                        drop=((snap, p) if snap is not None else None), b_format=int(use16), head=head)
+                        drop=((snap, p) if snap is not None else None), b_format=(2 if (use16 and plan.f16) else int(use16)), head=head)
         h = acts[-1]
         if head_fused:
             h, n_chain = y_head, L
@@ -651,7 +654,7 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None, need_dx=False):
                 acts.append(h)
             continue
         pre = (fold.bf, topo.deg_pows) if (fold is not None and l == 0) else (None, None)
-        g16 = (not last) and (1 + l) in plan.fwd16 and gemm16_supported(topo, nmat, hid, False)      # tall tiles: bf16x6 per layer
+        g16 = (not last) and (1 + l) in plan.fwd16 and not plan.f16 and gemm16_supported(topo, nmat, hid, False)      # tall tiles: bf16x6 per layer
         h = _tagconv_forward(topo, h, (plan.fwd16[1 + l] if g16 else plan.fwd[1 + l]), conv_ps[l][0], nmat, hid, hout, relu=not last,
                              add_src=(x if (last and mod.skip) else None), add_ld=ldx,
                              prebias=pre[0], pre_rowscale=pre[1],
@@ -729,7 +732,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
             if l > 0:
                 gl[l - 1] = out_l
         gemm_prop_chain(topo, (None if head_fused else g), hid, nmat, layers, transposed=True,
-                        drop=((snap, p_drop) if snap is not None else None), b_format=int(use16), head=head)
+                        drop=((snap, p_drop) if snap is not None else None), b_format=(2 if (use16 and plan.f16) else int(use16)), head=head)
         d_in = layers[-1]["Y"]                  # gradient w.r.t. conv 0's input: dS (folded) or dx0
         # The folded conv 0 joins the batched launch of the plain layers (round 4; FL.WGRAD_JOIN_FOLDED=False: its own launch).
         # Round 3 kept it apart because three layers x 85 workgroups leave a 13-vs-12-tile tail at C2; measured now, the
@@ -767,7 +770,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
             # one small-GEMM launch then writes dW_m, conv0.bias, dW2, db2 into the flat buffer
             wgrad(topo, g, hout, S, hid, nmat, fold.gfold, rowscale2=topo.deg_pows, pending=pending)
             dS = torch.empty(topo.N, hid, dtype=_F32, device=dev)
-            g16 = hout == hid and 1 in plan.bwd16 and gemm16_supported(topo, nmat, hid, True)
+            g16 = hout == hid and 1 in plan.bwd16 and not plan.f16 and gemm16_supported(topo, nmat, hid, True)
             gemm_prop(topo, g, g.stride(0), hout, (plan.bwd16[1] if g16 else plan.bwd[1]), nmat, hid, dS, transposed=True, b_format=int(g16))
             fold_late = True
             g = None
@@ -781,7 +784,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         defer = FL.WGRAD_BATCH and hout == hid and not is_narrow(nmat, hout)
         if defer:
             deferred.append((l, g, acts[l]))
-        g16 = hout == hid and (1 + l) in plan.bwd16 and gemm16_supported(topo, nmat, hid, True)
+        g16 = hout == hid and (1 + l) in plan.bwd16 and not plan.f16 and gemm16_supported(topo, nmat, hid, True)
         g = _tagconv_backward(topo, g, acts[l], (plan.bwd16[1 + l] if g16 else plan.bwd[1 + l]), nmat, hid, hout, seg,
                               relu_src=(acts[l] if l > 0 else None), drop=(drop_of(l - 1) if l > 0 else None),
                               defer_wgrad=defer, pending=pending, b_format=int(g16))

@@ -73,6 +73,7 @@ def gemm_prop(topo: Topology, X: torch.Tensor, ldx: int, kreal: int, Bp: torch.T
               relu: bool = False, transposed: bool = False, prop_in: int = 0, narrow_h: int = 0,
               prebias=None, pre_rowscale=None, drop=None, b_format: int = 0) -> None:
     """drop = (snapshot, p, drop_id): in-kernel dropout mask of layer drop_id (see dropout_snapshot).
+    b_format = 2: Bp holds the f16x2 group buffers of _PackPlan(f16_groups=...) and the tile GEMM runs as f16x3 (chain_f16_supported);
     b_format = 1: Bp holds bf16x3 fragments (_PackPlan.fwd16 / bwd16) and the tile GEMM runs as bf16x6 -- the tall-tile
     shapes of gemm16_supported only."""
     if topo.global_only and (nmat > 1 or prop_in > 0):
@@ -135,6 +136,16 @@ def chain16_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> 
     return FL.CHAIN_BF16 and tiles is not None and bool(_lib.lib().dss2_gemm_prop_chain16_supported(topo.nrb, nmat, hid, hid, ell))
 
 
+def chain_f16_supported(topo: Topology, nmat: int, hid: int) -> bool:
+    """True when BOTH chains of a block (forward, data gradients) can run their tile GEMM as f16x3 (b_format 2: weights as two fp16
+    planes with scale exponents, _PackPlan f16_groups): the split-plane chain of 64-row tiles with bit-word ReLU gates
+    (csrc/dss2_gemm_chain_sp.hip, MS = 2).  flags.CHAIN_F16 = False: bf16x6."""
+    if not (FL.CHAIN_F16 and FL.CHAIN_BF16 and topo.ell_tiles is not None and topo.ellT_tiles is not None and chain_gate_words(topo, nmat, hid) > 0):
+        return False
+    L = _lib.lib()
+    return bool(L.dss2_gemm_prop_chain_f16_supported(topo.nrb, nmat, hid, hid, topo.ell)) and bool(L.dss2_gemm_prop_chain_f16_supported(topo.nrb, nmat, hid, hid, topo.ellT))
+
+
 def chain_head_supported(topo: Topology, nmat: int, hid: int, nout: int, transposed: bool) -> bool:
     """True when the narrow head TAGConv (hid -> nout) can ride inside the chained launch of the hid -> hid layers
     (dss2_gemm_prop_chain_head: forward = the head after the last chained layer, transposed = the chain's input computed from
@@ -170,7 +181,7 @@ def gemm_prop_chain(topo: Topology, X: Optional[torch.Tensor], hid: int, nmat: i
         a.drop_thr, a.drop_scale = _dropout_params(drop[1])
     dev_t = X if X is not None else layers[-1]["Y"]
     a.X, a.ldx = (X.data_ptr(), X.stride(0)) if X is not None else (0, hid)
-    a.kreal, a.kpad = hid, (_round16(hid) if b_format == 1 else _round8(hid))
+    a.kreal, a.kpad = hid, (_round16(hid) if b_format >= 1 else _round8(hid))
     a.hout, a.ncg, a.ldy, a.ld_relu, a.ld_dmask, a.ld_add = hid, _ncg(hid), hid, hid, hid, hid
     a.nmat, a.nrb, a.ntiles = nmat, topo.nrb, topo.ntiles
     a.tile_start = topo.tile_start.data_ptr()

@@ -151,7 +151,7 @@ class _PackPlan:
     refreshed by ONE kernel launch per forward."""
 
     def __init__(self, groups: Sequence[Sequence[torch.Tensor]], device, stacked: bool = False, stacked_groups=(),
-                 bf16_groups=()):
+                 bf16_groups=(), f16: bool = False):
         # groups[g] = the nmat matrices [hout, hin] of one fused GEMM (TAGConv lins, or one Linear);
         # entries are Parameters or _MatView blocks of a Parameter.
         # stacked: every group uses the narrow layouts whatever its width -- forward = matrices side by side along the
@@ -175,14 +175,18 @@ class _PackPlan:
             self.meta.append((nm, hout, hin, kf, cf, kb, cb))
         # bf16_groups: additionally the bf16x3 fragment layout (fp32-accurate tile GEMM on the bf16 matrix pipe,
         # csrc/dss2_gemm_chain16.hip): [matrix][col group][k/16][3 planes][64 lanes][8 bf16]
-        self.fwd16, self.bwd16 = {}, {}
+        # f16: those groups in the f16x2 layout instead (f16x3 chains, b_format 2): [matrix][col group][k/16][2 planes][64 lanes][8 fp16],
+        # then one int32 scale exponent per matrix (written by the pack kernel, which forms each matrix's maximum)
+        self.fwd16, self.bwd16, self.f16 = {}, {}, bool(f16)
         for g in bf16_groups:
             nm, hout, hin = self.meta[g][0:3]
             if is_narrow(nm, hout) or self._stk[g]:
                 raise ValueError("bf16x3 packing is for plain per-matrix layouts")
             kf, cf, kb, cb = _round16(hin), _ncg(hout), _round16(hout), _ncg(hin)
-            self.fwd16[g] = torch.zeros(nm * cf * (kf // 16) * 768, dtype=_F32, device=device)
-            self.bwd16[g] = torch.zeros(nm * cb * (kb // 16) * 768, dtype=_F32, device=device)
+            per = 512 if self.f16 else 768      # floats per (column group, k-step of 16)
+            tail = 4 if self.f16 else 0         # (nm <= 4 exponents, 16 bytes)
+            self.fwd16[g] = torch.zeros(nm * cf * (kf // 16) * per + tail, dtype=_F32, device=device)
+            self.bwd16[g] = torch.zeros(nm * cb * (kb // 16) * per + tail, dtype=_F32, device=device)
         self.ptrs = None
         self.table = None
         self.max_elems = 0
@@ -209,7 +213,11 @@ class _PackPlan:
                     recs.append((w.data_ptr(), self.fwd[g].data_ptr() + 4 * m * cf * (kf // 8) * 256, hout, hin, w.ld, 1 | dp, 0, kf, cf, 0))
                     recs.append((w.data_ptr(), self.bwd[g].data_ptr() + 4 * m * cb * (kb // 8) * 256, hout, hin, w.ld, 0 | dp, 0, kb, cb, 0))
                 self.max_elems = max(self.max_elems, (cf + 1) * (kf // 8 + 1) * 64, (cb + 1) * (kb // 8 + 1) * 64)
-                if g in self.fwd16:      # transpose | 2: bf16x3 layout
+                if g in self.fwd16 and self.f16:      # transpose | 8: f16x2 layout (dst = the group's buffer, koff = matrices, joff = this one)
+                    k16, b16 = _round16(hin), _round16(hout)
+                    recs.append((w.data_ptr(), self.fwd16[g].data_ptr(), hout, hin, w.ld, 9 | dp, nm, k16, cf, m))
+                    recs.append((w.data_ptr(), self.bwd16[g].data_ptr(), hout, hin, w.ld, 8 | dp, nm, b16, cb, m))
+                elif g in self.fwd16:      # transpose | 2: bf16x3 layout
                     k16, b16 = _round16(hin), _round16(hout)
                     recs.append((w.data_ptr(), self.fwd16[g].data_ptr() + 4 * m * cf * (k16 // 16) * 768, hout, hin, w.ld, 3 | dp, 0, k16, cf, 0))
                     recs.append((w.data_ptr(), self.bwd16[g].data_ptr() + 4 * m * cb * (b16 // 16) * 768, hout, hin, w.ld, 2 | dp, 0, b16, cb, 0))

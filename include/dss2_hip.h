@@ -140,7 +140,11 @@ typedef struct dss2_pack_desc {
   int32_t transpose;  /* bit 0: 1: B[k][j] = W[j][k] (forward, K=cols); 0: B[k][j] = W[k][j].
                        * bit 1: write the bf16x3 layout [ncg][kpad/16][3 planes][64 lanes][8 bf16] (kpad a multiple of 16):
                        * every weight split into three bf16 pieces h + m + l for the fp32-accurate bf16 MFMA path
-                       * bit 2: ignored by the kernels (the host side marks descriptors whose src the fold of the same step writes) */
+                       * bit 2: ignored by the kernels (the host side marks descriptors whose src the fold of the same step writes)
+                       * bit 3: the f16x2 layout of the f16x3 chains (round 5): dst = the GROUP's buffer [matrix][ncg][kpad/16][2 planes]
+                       * [64 lanes][8 fp16] + one int32 per matrix (the exponent s of the power-of-two scale applied before the split:
+                       * 2^s max |W| in [2^14, 2^15)); koff = matrices in the group, joff = this matrix's index (not offsets); the
+                       * matrix is written whole, padding included                                                                  */
   int32_t koff;       /* k offset of this block inside the packed matrix (any value)   */
   int32_t kpad;       /* padded K of the packed matrix (multiple of 8)                  */
   int32_t ncg;        /* number of 32-column groups of the packed matrix                */
@@ -322,6 +326,12 @@ int dss2_gemm_prop_chain_supported(int nrb, int nmat, int kreal, int hout, int e
  * v_mfma_f32_32x32x16_bf16 per fp32 product term set (h/m/l splits of both operands, fp32 accumulation): fp32-accurate
  * results at 12 instead of 32 MFMA cycles per unit of k.  Two-row-block tiles, H <= 128. */
 int dss2_gemm_prop_chain16_supported(int nrb, int nmat, int kreal, int hout, int ell_width);
+/* ... and with args.b_format = 2 as f16x3 (round 5): every layer's Bp = a group buffer in the f16x2 layout (dss2_pack_desc, transpose
+ * bit 3: two fp16 planes per matrix + scale exponents), three fp16 MFMAs per product, the activation tile scaled per tile and layer by
+ * an exact power of two (csrc/dss2_gemm_chain_sp.hip, MS = 2).  64-row tiles, hout = kreal a multiple of 32; layers gated by fp32
+ * activations (relu_src without gate_bits) and x_planes are refused -- callers keep bf16x3 weights for those.  Also through
+ * dss2_gemm_prop_chain_head.  Errors of the size of fp32 arithmetic's own rounding. */
+int dss2_gemm_prop_chain_f16_supported(int nrb, int nmat, int kreal, int hout, int ell_width);
 /* != 0: dss2_gemm_prop (one layer) accepts args.b_format = 1 for this shape -- the tall tiles (128 / 192 rows) that run
  * matrix-sequentially with the X tile staged in two K halves; same bf16x6 arithmetic as the chain. */
 int dss2_gemm_prop16_supported(int nrb, int nmat, int kreal, int hout, int max_nnz, int ell_width);

@@ -177,3 +177,162 @@ def test_f16x3_is_reproducible(pkg):
     b = _run(pkg, topo, Gs, Xs, H, nmat, True, True)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the layer chains as f16x3 (csrc/dss2_gemm_chain_sp.hip, MS = 2): the C2 model's three H -> H TAGConv layers forward and backward.
+# The oracle comparison of this route is tests/test_gpu_parity.py (default flags take it: goldens, the full-size C2 step); here:
+# the route is the one that runs, it agrees with the bf16x6 route far inside the north-star tolerance on adversarial magnitudes,
+# the weight packing is exact to 2^-22, NaN stays where it belongs, same inputs give the same bits.
+# ---------------------------------------------------------------------------------------------------------------------------------
+REG = {"mu_v": 1e-1, "mu_theta": 1e-1, "lam_v": 1e-4, "lam_p": 1e-8, "lam_pf": 1e-6, "lam_reg": 1e2}
+
+
+def _model_step(pkg, cls, cargs, grids, B, seed=0, xscale=None, wscale=None):
+    torch.manual_seed(seed)
+    b = pkg.synthetic.make_batch(grids, B, seed=seed, violate=0.3)
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    if xscale is not None:
+        x = x.clone(); x[:, :8] *= xscale(x.shape[0]).to(DEV)[:, None]
+    st = tuple(s.to(DEV) for s in b["stats"])
+    model = getattr(pkg, cls)(*cargs).to(DEV)
+    if wscale is not None:
+        with torch.no_grad():
+            for i, p in enumerate(model.parameters()):
+                p.mul_(wscale(i, p))
+    params = list(model.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        out = model(x[:, :8], ei, ea[:, :6])
+        loss = pkg.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2], edge_std=st[3],
+                                edge_index=ei, reg_coefs=REG, num_samples=None, node_param=x[:, 8:], edge_param=ea[:, 6:])
+        loss.backward(pkg.data.unit_grad(loss))
+        torch.cuda.synchronize()
+        return out.detach().clone(), loss.detach().clone(), [p.grad.detach().clone() for p in params]
+    return model, step
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-300)).item()
+
+
+def _ab(pkg, step):
+    old = pkg.flags.CHAIN_F16
+    try:
+        pkg.flags.CHAIN_F16 = False
+        ref = step()
+        pkg.flags.CHAIN_F16 = True
+        got = step()
+        again = step()
+    finally:
+        pkg.flags.CHAIN_F16 = old
+    return ref, got, again
+
+
+@pytest.mark.parametrize("cls,cargs,grids,B", [
+    ("MPN", (8, 6, 2, 128, 4, 2, 0.0), ["cigre14"], 512),                          # the C2 model
+    ("MPN", (8, 6, 2, 128, 4, 2, 0.0), ["cigre14", "cigre14_reswitched"], 100),    # mixed topologies, ragged last tile
+    ("MPN", (8, 6, 2, 64, 5, 2, 0.0), ["cigre14"], 256),                           # H = 64 (two stripes: below the split-plane chain -> bf16x6 either way)
+    ("MPN", (8, 6, 2, 256, 4, 1, 0.0), ["cigre14"], 128),                          # H = 256 (eight waves), K = 1
+    ("SkipPFN", (8, 6, 2, 128, 3, 2, 0.2, 2), ["cigre14"], 200),                   # a stack with in-kernel dropout
+])
+def test_f16x3_chains_agree_with_the_bf16x6_chains(pkg, cls, cargs, grids, B):
+    model, step = _model_step(pkg, cls, cargs, grids, B, seed=21)
+    (o0, l0, g0), (o1, l1, g1), (o2, l2, g2) = _ab(pkg, step)
+    mods = [m for m in model.modules() if m.__class__.__name__ in ("MPN", "SkipMPN") and getattr(m, "_plan", None) is not None]
+    took = any(m._plan.f16 for m in mods)
+    if cargs[3] in (128, 256):
+        assert took, "the f16x3 route was expected for 64-row tiles with H a multiple of 32 >= 96"
+    if cls != "SkipPFN":      # (dropout draws a new mask per call: only the dropout-free models compare call to call)
+        assert _rel(o1, o0) < 2e-6 and abs(l1.item() - l0.item()) <= 2e-6 * abs(l0.item())
+        for a, b_ in zip(g1, g0):
+            assert _rel(a, b_) < 5e-6
+        assert torch.equal(o1, o2) and torch.equal(l1, l2) and all(torch.equal(a, b_) for a, b_ in zip(g1, g2))      # same inputs, same bits
+    else:
+        assert torch.isfinite(o1).all() and all(torch.isfinite(g).all() for g in g1)
+
+
+def test_f16x3_chains_follow_the_scale_of_the_data(pkg):
+    # node features over eight decades from graph to graph (the activation tiles' exponents differ tile by tile and layer by layer),
+    # conv weights of one layer x 64, of another x 1/256 (the per-matrix weight exponents differ).  The WLS loss of such a batch is a
+    # difference of 1e17-sized terms: its gradients move by PERCENT between any two correct evaluation orders (bf16x6 against the fp32
+    # MFMA route: 4 %), so the yardstick is the third route: f16x3 must sit as close to the fp32-MFMA chains as bf16x6 does.
+    n_per = 15
+    def xscale(n):
+        g = torch.Generator(device="cpu").manual_seed(5)
+        dec = torch.rand((n + n_per - 1) // n_per, generator=g) * 8 - 4
+        return (10.0 ** dec).repeat_interleave(n_per)[:n]
+    def wscale(i, p):
+        return 64.0 if i == 6 else (1.0 / 256.0 if i == 10 else 1.0)
+    model, step = _model_step(pkg, "MPN", (8, 6, 2, 128, 4, 2, 0.0), ["cigre14"], 300, seed=22, xscale=xscale, wscale=wscale)
+    FL = pkg.flags
+    old = (FL.CHAIN_BF16, FL.CHAIN_F16)
+    try:
+        FL.CHAIN_BF16, FL.CHAIN_F16 = False, False
+        o32, _, g32 = step()
+        FL.CHAIN_BF16 = True
+        ob, _, gb = step()
+        FL.CHAIN_F16 = True
+        oh, _, gh = step()
+        assert model._plan.f16
+    finally:
+        FL.CHAIN_BF16, FL.CHAIN_F16 = old
+    assert torch.isfinite(oh).all()
+    assert _rel(oh, o32) < 2e-6 and _rel(ob, o32) < 2e-6
+    for a, b_, c in zip(gh, gb, g32):
+        assert _rel(a, c) <= 3.0 * _rel(b_, c) + 3e-6, (_rel(a, c), _rel(b_, c))
+
+
+def test_f16x3_chain_keeps_a_bad_value_in_its_graph(pkg):
+    # (a NaN among a tile's activations must not move the tile's scale: v_max_f32 ignores it.  What the NaN does to its OWN graph is the
+    #  library's ReLU, a v_max_f32 with 0, in every route: it is quenched there -- torch.relu would carry it -- so only the other graphs
+    #  of the tile are checked here)
+    torch.manual_seed(23)
+    b = pkg.synthetic.make_batch(["cigre14"], 64, seed=23)
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    model = pkg.MPN(8, 6, 2, 128, 4, 2, 0.0).to(DEV)
+    n_per = x.shape[0] // 64
+    with torch.no_grad():
+        clean = model(x[:, :8], ei, ea[:, :6]).clone()
+        xb = x.clone(); xb[5 * n_per + 3, 2] = float("nan")      # one node of graph 5
+        dirty = model(xb[:, :8], ei, ea[:, :6])
+    assert model._plan.f16
+    rows = torch.arange(x.shape[0], device=DEV)
+    in_g5 = (rows >= 5 * n_per) & (rows < 6 * n_per)
+    assert torch.isfinite(dirty[~in_g5]).all()
+    assert _rel(dirty[~in_g5], clean[~in_g5]) < 1e-6
+
+
+@pytest.mark.parametrize("nm,ho,hi,scales", [(3, 128, 128, (1.0, 1e-3, 300.0)), (2, 96, 96, (0.09, 0.09)), (3, 256, 256, (1.0, 0.0, 1e-20))])
+def test_f16x2_weight_packing_is_exact_to_22_bits(pkg, nm, ho, hi, scales):
+    pl = importlib.import_module(PKG_NAME + ".plans")
+    g = torch.Generator(device="cpu").manual_seed(nm * 7 + ho)
+    Ws = [(torch.randn(ho, hi, generator=g) * sc).to(DEV) for sc in scales]
+    plan = pl._PackPlan([Ws], DEV, bf16_groups=(0,), f16=True)
+    plan.refresh()
+    torch.cuda.synchronize()
+    for buf, transposed in ((plan.fwd16[0], True), (plan.bwd16[0], False)):      # forward: B[k][j] = W[j][k]; data gradient: B[k][j] = W[k][j]
+        K, J = (hi, ho) if transposed else (ho, hi)
+        nkk, ncg = (K + 15) // 16, (J + 31) // 32
+        words = nm * ncg * nkk * 512
+        raw = buf[:words].view(torch.int32).cpu()
+        exps = buf[words:words + nm].view(torch.int32).cpu().tolist()
+        halves = raw.view(torch.int16).view(torch.float16).view(nm, ncg, nkk, 2, 64, 8).float().double()
+        for m in range(nm):
+            W = Ws[m].cpu().double()
+            mx = W.abs().max().item()
+            if mx > 0:
+                assert 2.0 ** 14 <= mx * 2.0 ** exps[m] < 2.0 ** 15, (mx, exps[m])
+            val = (halves[m, :, :, 0] + halves[m, :, :, 1]) * 2.0 ** (-exps[m])      # [ncg][nkk][64 lanes][8]
+            B = torch.zeros(nkk * 16, ncg * 32, dtype=torch.float64)
+            lane = torch.arange(64)
+            for q in range(8):
+                kk = (torch.arange(nkk)[:, None] * 16 + 8 * (lane[None, :] >> 5) + q)          # [nkk][64]
+                jj = (torch.arange(ncg)[:, None, None] * 32 + (lane[None, None, :] & 31))        # [ncg][1][64]
+                B[kk[None].expand(ncg, -1, -1), jj.expand(-1, nkk, -1)] = val[:, :, :, q]
+            want = (W.t() if transposed else W)
+            got = B[:K, :J]
+            assert (got - want).abs().max().item() <= 2.0 ** -22 * max(mx, 1e-300) * 1.01, m
+            assert B[K:].abs().max().item() == 0 if K < nkk * 16 else True

@@ -239,8 +239,9 @@ def test_whole_step_with_and_without_images(pkg, grids, B, L):
     b = pkg.synthetic.make_batch(grids, B, seed=5)
     torch.manual_seed(6)
     model = pkg.MPN(8, 6, 2, 128, L, 2, 0.0).to(DEV)
-    old = (FL.WGRAD_XP, FL.XP_DROP_FP32)
+    old = (FL.WGRAD_XP, FL.XP_DROP_FP32, FL.CHAIN_F16)
     try:
+        FL.CHAIN_F16 = False      # (like with like: the image route is a bf16x6 route; without images the chains would run as f16x3)
         FL.WGRAD_XP, FL.XP_DROP_FP32 = True, True
         topo = pkg.topology.get_topology(b["edge_index"].to(DEV), b["x"].shape[0])
         topo.__dict__.pop("_xp_ok", None)
@@ -253,7 +254,7 @@ def test_whole_step_with_and_without_images(pkg, grids, B, L):
         topo.__dict__.pop("_xp_ok", None)
         o3, l3, g3 = _step(pkg, model, b)
     finally:
-        FL.WGRAD_XP, FL.XP_DROP_FP32 = old
+        FL.WGRAD_XP, FL.XP_DROP_FP32, FL.CHAIN_F16 = old
         topo.__dict__.pop("_xp_ok", None)
     assert torch.equal(o1, o2) and torch.equal(o1, o3) and torch.equal(l1, l2) and torch.equal(l1, l3)
     for a, c, d in zip(g1, g2, g3):
