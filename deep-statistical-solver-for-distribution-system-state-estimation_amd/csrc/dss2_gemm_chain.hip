@@ -52,9 +52,11 @@ static int chain_impl(const dss2_gemm_prop_args* ap, const dss2_chain_layer* lay
 // b_format 2 (weights as two fp16 planes + scale exponents, tile GEMM as f16x3): the split-plane chain of 64-row tiles on 16x16x32 MFMAs
 extern "C" int dss2_gemm_prop_chain_f16_supported(int nrb, int nmat, int kreal, int hout, int ell_width) {
   using namespace dss2;
-  if (nrb != 2 || (hout & 31) != 0 || kreal != hout || ell_width <= 0 || !dss2_gemm_prop_chain16_supported(nrb, nmat, kreal, hout, ell_width)) return 0;
+  if (kreal != hout || ell_width <= 0 || (hout & 3) != 0) return 0;
   dss2_gemm_prop_args a = {};
   a.b_format = 2; a.nrb = nrb; a.nmat = nmat; a.kreal = kreal; a.kpad = (kreal + 15) / 16 * 16; a.hout = hout; a.ncg = (hout + 31) / 32; a.ell_width = ell_width;
+  if (nrb == 3 || nrb == 6) return chain_sp6_supported(a) ? 1 : 0;      // 96- / 192-row tiles (dss2_gemm_chain_sp6.hip)
+  if (nrb != 2 || (hout & 31) != 0 || !dss2_gemm_prop_chain16_supported(nrb, nmat, kreal, hout, ell_width)) return 0;
   return chain_row_split(nrb, a.ncg) == 1 && chain_sp_supported(a) ? 1 : 0;
 }
 
@@ -117,7 +119,7 @@ static int chain_impl(const dss2_gemm_prop_args* ap, const dss2_chain_layer* lay
   const dss2_gemm_prop_args& a = *ap;
   if (n_layers < 1 || n_layers > CHAIN_MAX || !layers) { set_error("gemm_prop_chain: 1..%d layers, got %d", CHAIN_MAX, n_layers); return 2; }
   if (a.ntiles <= 0) return 0;
-  const bool tall16 = a.b_format == 1 && a.nrb == 6 && dss2_gemm_prop_chain16_supported(a.nrb, a.nmat, a.kreal, a.hout, a.ell_width);
+  const bool tall16 = (a.b_format == 1 || a.b_format == 2) && a.nrb == 6 && dss2_gemm_prop_chain16_supported(a.nrb, a.nmat, a.kreal, a.hout, a.ell_width);
   if ((!tall16 && !dss2_gemm_prop_chain_supported(a.nrb, a.nmat, a.kreal, a.hout, a.ell_width)) || !a.ell_tiles || a.prop_in || a.narrow_h ||
       a.rowscale || a.kpad != (a.b_format >= 1 ? (a.kreal + 15) / 16 * 16 : (a.kreal + 7) / 8 * 8) || a.ncg != (a.hout + 31) / 32) {
     set_error("gemm_prop_chain: unsupported shape (nrb=%d nmat=%d k=%d hout=%d ell=%d); use dss2_gemm_prop per layer",
@@ -149,9 +151,10 @@ static int chain_impl(const dss2_gemm_prop_args* ap, const dss2_chain_layer* lay
   const int rsplit = chain_row_split(a.nrb, a.ncg);
   if (a.b_format == 2) {     // weights packed as two fp16 planes with scale exponents, tile GEMM as f16x3
     if (!dss2_gemm_prop_chain_f16_supported(a.nrb, a.nmat, a.kreal, a.hout, a.ell_width)) {
-      set_error("gemm_prop_chain(f16x3): unsupported shape (nrb=%d nmat=%d k=%d hout=%d): 64-row tiles, hout a multiple of 32", a.nrb, a.nmat, a.kreal, a.hout);
+      set_error("gemm_prop_chain(f16x3): unsupported shape (nrb=%d nmat=%d k=%d hout=%d)", a.nrb, a.nmat, a.kreal, a.hout);
       return 2;
     }
+    if (a.nrb == 3 || a.nrb == 6) return launch_chain_sp6(a, ct, head, s);
     return launch_chain_sp(a, ct, head, s);
   }
   if (a.b_format == 1) {     // weights packed as bf16x3 fragments, tile GEMM as bf16x6

@@ -47,6 +47,16 @@ __device__ __forceinline__ void s6_store_split(__bf16* dst, const f32x4 v) {
   *reinterpret_cast<u32x2_s6*>(dst + 2 * S6_PLANE) = u32x2_s6{l0, l1};
 }
 
+// f16x3 form (F16): the two fp16 pieces of 4 consecutive values scaled by 2^e -> planes 0, 1 (dss2_gemm_chain_sp.hip, MS = 2)
+template <int S6_PLANE>
+__device__ __forceinline__ void s6_store_split_h(__bf16* dst, const f32x4 v, int e) {
+  uint32_t h0, l0, h1, l1;
+  split2_pair(ldexpf(v[0], e), ldexpf(v[1], e), h0, l0);
+  split2_pair(ldexpf(v[2], e), ldexpf(v[3], e), h1, l1);
+  *reinterpret_cast<u32x2_s6*>(dst) = u32x2_s6{h0, h1};
+  *reinterpret_cast<u32x2_s6*>(dst + S6_PLANE) = u32x2_s6{l0, l1};
+}
+
 // DIR: which epilogue features the launch's layers use, so that each direction gets its own register allocation (one generic
 // kernel: 77 / 130 spilled VGPRs at K = 2 and a backward chain 8-17 % slower than the forward one; specialised: 10-13 / 12).
 //   1 = forward set (bias, folded bias, in-kernel dropout, ReLU, y_bits);  2 = data-gradient set (gate_bits, in-kernel dropout);
@@ -54,7 +64,10 @@ __device__ __forceinline__ void s6_store_split(__bf16* dst, const f32x4 v) {
 // HM = 2 (backward launches only, DIR = 2): the chain's input tile is the narrow head's data gradient, computed in the staging
 // from the nout-wide upstream gradient (dss2_gemm_chain_sp.hip, dss2_gemm_prop_chain_head) instead of by a launch of its own
 // that writes [N, hid] and is re-read here (C3: 22.6 us, 179-bus: 60 us).
-template <int NRB, int NMAT, int DIR, int HM = 0>
+// F16 (round 5; DIR 1 and 2): the tile GEMM as f16x3 -- two fp16 planes per stripe scaled by 2^ea per tile and layer, the weights as two
+// fp16 planes with per-matrix exponents (b_format 2), three v_mfma_f32_32x32x16_f16 per product; the accumulators are handed to the hops
+// with the scales taken out.  One more barrier per layer (the tile's maximum).  See dss2_gemm_chain_sp.hip, MS = 2.
+template <int NRB, int NMAT, int DIR, int HM = 0, bool F16 = false>
 __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(const dss2_gemm_prop_args p, const ChainTable ct, const dss2_chain_head hd) {
   constexpr int TM = 32 * NRB, S6_PLANE = s6_plane(NRB), S6_REGION = s6_region(NRB);
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -69,6 +82,14 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
   __bf16* xpl = reinterpret_cast<__bf16*>(smem);               // stripe s: xpl + s * (2 * S6_REGION)
   int2* ell = reinterpret_cast<int2*>(smem + ncg * S6_REGION);
   const int D = p.ell_width;
+  constexpr int NP = F16 ? 2 : 3;
+  float* mxw = reinterpret_cast<float*>(ell + D * TM);      // (F16) [ncg]: every wave's maximum over its part of the tile
+  int ea = 0;                                                // (F16) the planes in LDS hold 2^ea x
+  auto tile_exponent = [&]() {
+    float m = 0.f;
+    for (int w = 0; w < ncg; ++w) m = fmaxf(m, mxw[w]);
+    return 14 - __builtin_amdgcn_readfirstlane(exp_of(m));
+  };
   const int ts = p.tile_start[tile];
   const int R = p.tile_start[tile + 1] - ts;
   const int kq = p.kpad >> 2;
@@ -86,12 +107,35 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM;
     for (int idx = tid; idx < D * TM; idx += nthreads) ell[idx] = src[idx];
   }
-  if constexpr (HM != 2) {
+  if constexpr (HM != 2 && !F16) {
     for (int idx = tid; idx < TM * kq; idx += nthreads) {
       const int r = idx / kq, c = (idx - r * kq) << 2;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (r < R && c < p.kreal) v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + r) * p.ldx + c);
       s6_store_split<S6_PLANE>(xpl + (c >> 5) * (2 * S6_REGION) + s6_off(r, c & 31), v);
+    }
+  } else if constexpr (HM != 2) {
+    // the input tile waits in registers (TM kq / threads <= TM / 8 row pieces per thread) while its maximum is formed
+    f32x4 xin[NRP];
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < NRP; ++j) {
+      const int idx = tid + j * nthreads;
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      const bool on = idx < TM * kq && r < R && c < p.kreal;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.X + (size_t)(ts + (on ? r : 0)) * p.ldx + (on ? c : 0));      // (unconditional, masked)
+      xin[j] = on ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      mx = absmax4(mx, xin[j]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) mxw[wave] = mx;
+    s6_barrier();
+    ea = tile_exponent();
+#pragma unroll
+    for (int j = 0; j < NRP; ++j) {
+      const int idx = tid + j * nthreads;
+      const int r = idx / kq, c = (idx - r * kq) << 2;
+      if (idx < TM * kq) s6_store_split_h<S6_PLANE>(xpl + (c >> 5) * (2 * S6_REGION) + s6_off(r, c & 31), xin[j], ea);
     }
   } else {
     // X[row][c] = gate(row, c) * sum_{m, o} ((P^T)^m G)[row][o] W_m[o][c]: every wave builds its own 32-column stripe.  The hops of
@@ -166,16 +210,28 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
       else *reinterpret_cast<f32x4*>(hd.Xout + (size_t)(ts + row) * hd.ldxo + col0) = v;      // (the weight gradients read it)
       xv[i] = v;
     }
+    if constexpr (F16) {
+      float mx = 0.f;
+#pragma unroll
+      for (int i = 0; i < NRP; ++i) mx = absmax4(mx, xv[i]);
+      mx = wave_max(mx);
+      if (lane == 0) mxw[wave] = mx;
+      s6_barrier();
+      ea = tile_exponent();
+    }
     wave_lds_sync();                         // every lane is done with zt: the planes go over it
 #pragma unroll
-    for (int i = 0; i < NRP; ++i) s6_store_split<S6_PLANE>(own_planes + s6_off(r8 + 8 * i, cq), xv[i]);
+    for (int i = 0; i < NRP; ++i) {
+      if constexpr (F16) s6_store_split_h<S6_PLANE>(own_planes + s6_off(r8 + 8 * i, cq), xv[i], ea);
+      else s6_store_split<S6_PLANE>(own_planes + s6_off(r8 + 8 * i, cq), xv[i]);
+    }
   }
-  bf16x8 b0[3][NMAT];
-  auto load_b = [&](const bf16x8* __restrict__ bp16, bf16x8 (&bb)[3][NMAT], int ks) {
+  bf16x8 b0[NP][NMAT];
+  auto load_b = [&](const bf16x8* __restrict__ bp16, bf16x8 (&bb)[NP][NMAT], int ks) {
 #pragma unroll
     for (int m = 0; m < NMAT; ++m)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) bb[pl][m] = bp16[(((size_t)(m * ncg + cg) * nks + ks) * 3 + pl) * 64 + lane];
+      for (int pl = 0; pl < NP; ++pl) bb[pl][m] = bp16[(((size_t)(m * ncg + cg) * nks + ks) * NP + pl) * 64 + lane];
   };
   load_b(reinterpret_cast<const bf16x8*>(ct.l[0].Bp), b0, 0);
   S6STAMP(0);
@@ -186,24 +242,40 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     const dss2_chain_layer& L = ct.l[li];    // uniform: scalar loads from the kernel-argument segment
     const bf16x8* __restrict__ bp16 = reinterpret_cast<const bf16x8*>(L.Bp);
     f32x16 acc[NRB][NMAT];
+    [[maybe_unused]] int ue[NMAT];      // (F16) what takes the scales out of matrix m's accumulators: -(ea + ew[m])
+    if constexpr (F16) {
+      const int* whdr = reinterpret_cast<const int*>(reinterpret_cast<const char*>(L.Bp) + (size_t)NMAT * ncg * nks * 2048);      // uniform: scalar loads
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) ue[m] = -(ea + whdr[m]);
+    }
 
     // ---- tile GEMM, 16 k per step: B fragments (L2) ping-pong one step ahead, A fragments (LDS planes) one row block ahead;
     // one memory request per MFMA gap (dss2_gemm_chain_sp.hip)
     {
-      bf16x8 b1[3][NMAT], a[2][3];
-      auto load_a = [&](bf16x8 (&af)[3], int rb, int ks) {
+      bf16x8 b1[NP][NMAT], a[2][NP];
+      auto load_a = [&](bf16x8 (&af)[NP], int rb, int ks) {
         const __bf16* src = xpl + (ks >> 1) * (2 * S6_REGION) + s6_off(rb * 32 + c32, (ks & 1) * 16 + half * 8);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8*>(src + pl * S6_PLANE);
+        for (int pl = 0; pl < NP; ++pl) af[pl] = *reinterpret_cast<const bf16x8*>(src + pl * S6_PLANE);
       };
-      auto mma = [&](const bf16x8 (&af)[3], const bf16x8 (&b)[3][NMAT], f32x16 (&c)[NMAT], const bool first) {
+      auto mma = [&](const bf16x8 (&af)[NP], const bf16x8 (&b)[NP][NMAT], f32x16 (&c)[NMAT], const bool first) {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (F16) {      // lo hi + hi lo + hi hi, smallest terms first
+          auto h8 = [](const bf16x8 v) { return __builtin_bit_cast(f16x8, v); };
 #pragma unroll
-        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], b[0][m], first ? zero : c[m], 0, 0, 0);
+          for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(af[1]), h8(b[0][m]), first ? zero : c[m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(af[0]), h8(b[1][m]), c[m], 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h8(af[0]), h8(b[0][m]), c[m], 0, 0, 0);
+          return;
+        }
+#pragma unroll
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NP - 1], b[0][m], first ? zero : c[m], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[1][m], c[m], 0, 0, 0);
 #pragma unroll
-        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[2][m], c[m], 0, 0, 0);
+        for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], b[NP - 1][m], c[m], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < NMAT; ++m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], b[0][m], c[m], 0, 0, 0);
 #pragma unroll
@@ -214,22 +286,23 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
       // a[rb & 1] holds row block rb's fragment; right after its MFMAs the register set is re-requested for row block rb + 2
       // (of this step, or of the next one; branch-free: the last step re-requests its own operands).  Two sets, not six:
       // 6 x NMAT accumulator blocks already take 288 of the wave's 512 registers at NMAT = 3.
-      auto step = [&](const bf16x8 (&bc)[3][NMAT], bf16x8 (&bn)[3][NMAT], int ks, const bool first, const int par) {
+      auto step = [&](const bf16x8 (&bc)[NP][NMAT], bf16x8 (&bn)[NP][NMAT], int ks, const bool first, const int par) {
         const int kn = ks + 1 < nks ? ks + 1 : ks;
         load_b(bp16, bn, kn);
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) { mma(a[(par + rb) & 1], bc, acc[rb], first); load_a(a[(par + rb) & 1], rb + 2 < NRB ? rb + 2 : rb + 2 - NRB, rb + 2 < NRB ? ks : kn); }
         // gaps 1-9: the next step's weight fragments; after each row block's MFMAs: the re-request of its fragment
+        constexpr int RBM = (F16 ? 3 : 6) * NMAT;      // MFMAs per row block
 #pragma unroll
-        for (int i = 0; i < 3 * NMAT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
-        __builtin_amdgcn_sched_group_barrier(0x008, 6 * NMAT - 3 * NMAT, 0);
+        for (int i = 0; i < NP * NMAT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        if constexpr (RBM - NP * NMAT > 0) __builtin_amdgcn_sched_group_barrier(0x008, RBM - NP * NMAT, 0);
 #pragma unroll
         for (int rb = 1; rb < NRB; ++rb) {
 #pragma unroll
-          for (int i = 0; i < 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-          __builtin_amdgcn_sched_group_barrier(0x008, 6 * NMAT - 3, 0);
+          for (int i = 0; i < NP; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+          __builtin_amdgcn_sched_group_barrier(0x008, RBM - NP, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
       };
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) load_a(a[rb], rb, 0);
@@ -281,7 +354,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) slot0[(rb * 32 + acc_row(r, half)) * 32 + c32] = acc[rb][m][r];
+          for (int r = 0; r < 16; ++r) slot0[(rb * 32 + acc_row(r, half)) * 32 + c32] = F16 ? ldexpf(acc[rb][m][r], ue[m]) : acc[rb][m][r];
       };
       put(NMAT - 1);
       wave_lds_sync();
@@ -399,10 +472,26 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     }
     if (keep) {
       load_b(reinterpret_cast<const bf16x8*>(ct.l[li + 1].Bp), b0, 0);      // the next layer's first fragments
+      if constexpr (F16) {
+        // the next layer's scale: the tile's maximum over all stripes (one more barrier per layer; the planes then go over the slots)
+        float mx = 0.f;
 #pragma unroll
-      for (int i = 0; i < NRP; ++i) {
-        const int row = rowv + 8 * i;
-        s6_store_split<S6_PLANE>(own_planes + s6_off(row, cq), (row < R && col_ok) ? U[i] : f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int i = 0; i < NRP; ++i) {
+          if (!(rowv + 8 * i < R && col_ok)) U[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          mx = absmax4(mx, U[i]);
+        }
+        mx = wave_max(mx);
+        if (lane == 0) mxw[wave] = mx;
+        s6_barrier();
+        ea = tile_exponent();
+#pragma unroll
+        for (int i = 0; i < NRP; ++i) s6_store_split_h<S6_PLANE>(own_planes + s6_off(rowv + 8 * i, cq), U[i], ea);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NRP; ++i) {
+          const int row = rowv + 8 * i;
+          s6_store_split<S6_PLANE>(own_planes + s6_off(row, cq), (row < R && col_ok) ? U[i] : f32x4{0.f, 0.f, 0.f, 0.f});
+        }
       }
       S6STAMP(2 + li * 6 + 3);
       s6_barrier();   // the next layer's planes are complete
@@ -414,18 +503,20 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
   }
 }
 
-static size_t chain_sp6_lds_bytes(int nrb, int ncg, int ell_width) { return (size_t)ncg * s6_region(nrb) * 4 + (size_t)32 * nrb * ell_width * 8; }
+static size_t chain_sp6_lds_bytes(int nrb, int ncg, int ell_width) { return (size_t)ncg * s6_region(nrb) * 4 + (size_t)32 * nrb * ell_width * 8 + 64; }      // (+ the f16x3 form's maxima)
 
 bool chain_sp6_supported(const dss2_gemm_prop_args& a) {
   static const int on = [] { const char* e = getenv("DSS2_CHAIN_SP"); return e ? atoi(e) : 1; }();
-  return on && a.b_format == 1 && (a.nrb == 6 || a.nrb == 3) && a.nmat >= 2 && a.nmat <= 3 && (a.kpad & 15) == 0 && a.kpad <= 32 * a.ncg &&
+  static const int f16on = [] { const char* e = getenv("DSS2_CHAIN_SP_F16"); return e ? atoi(e) : 1; }();
+  if (a.b_format == 2 && !f16on) return false;
+  return on && (a.b_format == 1 || a.b_format == 2) && (a.nrb == 6 || a.nrb == 3) && a.nmat >= 2 && a.nmat <= 3 && (a.kpad & 15) == 0 && a.kpad <= 32 * a.ncg &&
          a.ncg >= 2 && a.ncg <= 4 && chain_sp6_lds_bytes(a.nrb, a.ncg, a.ell_width) <= (size_t)(a.nrb == 3 ? kMaxLdsBytes / 2 : kMaxLdsBytes);
 }
 
-template <int NRB, int NMAT, int DIR, int HM = 0>
+template <int NRB, int NMAT, int DIR, int HM = 0, bool F16 = false>
 static int launch_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head& hd, hipStream_t stream) {
   static std::atomic<uint32_t> lds_done{0};
-  auto kern = gemm_chain_sp6_kernel<NRB, NMAT, DIR, HM>;
+  auto kern = gemm_chain_sp6_kernel<NRB, NMAT, DIR, HM, F16>;
   if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop_chain(split planes, 192 rows)")) return 1;
   hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg), chain_sp6_lds_bytes(NRB, a.ncg, a.ell_width), stream, a, ct, hd);
   return check_launch("gemm_prop_chain(split planes, 192 rows)");
@@ -442,10 +533,21 @@ int launch_chain_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, const d
   if (head) {      // the backward head (mode 2) rides in the staging of the data-gradient launch; nothing else is built here
     if (head->mode != 2 || !bwd) { set_error("gemm_prop_chain_head: tall tiles take the backward head (mode 2) on a data-gradient chain only"); return 2; }
     hd = *head;
+    if (a.b_format == 2) {
+      if (a.nrb == 3) return a.nmat == 2 ? launch_sp6<3, 2, 2, 2, true>(a, ct, hd, s) : launch_sp6<3, 3, 2, 2, true>(a, ct, hd, s);
+      return a.nmat == 2 ? launch_sp6<6, 2, 2, 2, true>(a, ct, hd, s) : launch_sp6<6, 3, 2, 2, true>(a, ct, hd, s);
+    }
     if (a.nrb == 3) return a.nmat == 2 ? launch_sp6<3, 2, 2, 2>(a, ct, hd, s) : launch_sp6<3, 3, 2, 2>(a, ct, hd, s);
     return a.nmat == 2 ? launch_sp6<6, 2, 2, 2>(a, ct, hd, s) : launch_sp6<6, 3, 2, 2>(a, ct, hd, s);
   }
   const int dir = fwd ? 1 : (bwd ? 2 : 0);      // (0: a layer table that mixes the feature sets runs the generic instantiation)
+  if (a.b_format == 2) {      // f16x3: the direction-specialised forms only
+    if (dir == 0) { set_error("gemm_prop_chain(f16x3): a layer table that mixes forward and data-gradient features needs bf16x3 weights (b_format 1)"); return 2; }
+#define DSS2_S6_LAUNCH_H(NRB, NMAT) (dir == 1 ? launch_sp6<NRB, NMAT, 1, 0, true>(a, ct, hd, s) : launch_sp6<NRB, NMAT, 2, 0, true>(a, ct, hd, s))
+    if (a.nrb == 3) return a.nmat == 2 ? DSS2_S6_LAUNCH_H(3, 2) : DSS2_S6_LAUNCH_H(3, 3);
+    return a.nmat == 2 ? DSS2_S6_LAUNCH_H(6, 2) : DSS2_S6_LAUNCH_H(6, 3);
+#undef DSS2_S6_LAUNCH_H
+  }
 #define DSS2_S6_LAUNCH(NRB, NMAT) (dir == 1 ? launch_sp6<NRB, NMAT, 1>(a, ct, hd, s) : (dir == 2 ? launch_sp6<NRB, NMAT, 2>(a, ct, hd, s) : launch_sp6<NRB, NMAT, 0>(a, ct, hd, s)))
   if (a.nrb == 3) return a.nmat == 2 ? DSS2_S6_LAUNCH(3, 2) : DSS2_S6_LAUNCH(3, 3);
   return a.nmat == 2 ? DSS2_S6_LAUNCH(6, 2) : DSS2_S6_LAUNCH(6, 3);

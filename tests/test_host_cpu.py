@@ -176,9 +176,14 @@ def test_no_kernel_in_the_library_spills_registers():
     # (the direction-specialised instantiations <NRB, NMAT, 1 | 2> that the models run spill 0-16 registers at K = 2, none at K = 1;
     #  the generic ones <., ., 0> -- mask tensor, residual, fp32 gates: tests and outside callers -- carry every feature at once)
     for nrb, nmat, d, cap in ((3, 3, 1, 16), (3, 3, 2, 16), (6, 3, 1, 24), (6, 3, 2, 24), (3, 2, 0, 16), (3, 3, 0, 96), (6, 2, 0, 80), (6, 3, 0, 144)):
-        allowed[f"void dss2::gemm_chain_sp6_kernel<{nrb}, {nmat}, {d}, 0>"] = cap
+        allowed[f"void dss2::gemm_chain_sp6_kernel<{nrb}, {nmat}, {d}, 0, false>"] = cap
     for nrb, cap in ((3, 16), (6, 24)):      # <., 3, 2, 2>: the data-gradient chain with the head's gradient built in its staging (same body)
-        allowed[f"void dss2::gemm_chain_sp6_kernel<{nrb}, 3, 2, 2>"] = cap
+        allowed[f"void dss2::gemm_chain_sp6_kernel<{nrb}, 3, 2, 2, false>"] = cap
+    # ... and their f16x3 forms (round 5: <., ., ., ., true>; two planes instead of three: fewer at 96 rows).  <6, 3, 2, 0, true> -- the
+    # 192-row data-gradient chain WITHOUT the fused head, which the models do not run -- keeps its 24 input row pieces in registers while
+    # the tile's maximum is formed and parks most of them in scratch memory once per tile, before the first layer.
+    for nrb, d, hm, cap in ((3, 1, 0, 8), (3, 2, 0, 8), (3, 2, 2, 8), (6, 1, 0, 32), (6, 2, 2, 32), (6, 2, 0, 96)):
+        allowed[f"void dss2::gemm_chain_sp6_kernel<{nrb}, 3, {d}, {hm}, true>"] = cap
     # A third, chosen: the edge MLP's bf16x6 forward (csrc/dss2_edge16.hip) is held to 128 registers (four waves per SIMD,
     # amdgpu_waves_per_eu) because it waits on a dependent staging chain; the 2 / 7 registers that costs at 64- / 96-row tiles
     # are spilled once per tile outside the slot loop (C2: 18.5 -> 15.6 us with them).
