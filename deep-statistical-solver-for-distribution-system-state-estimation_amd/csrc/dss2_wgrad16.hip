@@ -591,36 +591,42 @@ __global__ void __launch_bounds__(W16T_NT) wgrad16t_kernel(const dss2_wgrad_args
   // would cover the latency): its G rows, its ELL slice, the folded layer's row scales.
   constexpr int NEL = (W16_DMAX * TR + NT - 1) / NT;
   constexpr bool PRS = RS2 && NRB <= 4;      // (160- / 192-row tiles have no registers left for the row scales: read in place)
-  f32x4 pgw[NRB], prs[PRS ? NRB : 1], px[2], pgc[2];
+  // (round 5: every prefetch load is UNCONDITIONAL, from clamped rows / columns / entries, and masked where it is consumed -- the
+  //  `cond ? load : zero` forms made the compiler join the two values right behind the load, an s_waitcnt vmcnt inside the prefetch;
+  //  the row scales are 12-byte loads -- the dead fourth component's register was reused while the load was in flight -- and
+  //  tile_start is read one tile ahead of the loads it addresses: profiles/experiments/r05_wgrad16h_phase_stamps.txt)
+  typedef float f32x3_t __attribute__((ext_vector_type(3)));
+  f32x4 pgw[NRB], px[2], pgc[2];
+  f32x3_t prs[PRS ? NRB : 1];
   int2 pel[NEL];
-  auto load_tile_g = [&](int tile) {
-    const int ts = p.tile_start[tile];
-    const int R = p.tile_start[tile + 1] - ts;
-    const char* gb = reinterpret_cast<const char*>(Gp + (size_t)ts * p.ldg + gcol0 + 4 * q16);
+  const uint32_t gw_col = gcol_ok ? (uint32_t)(4 * q16) * 4u : 0u, gc_col = zcol_ok ? (uint32_t)(4 * cg) * 4u : 0u;
+  const float* __restrict__ rsb = RS2 ? (rs2 ? rs2 : Gp) : nullptr;      // (layers without row scales: any readable rows; never used)
+  auto load_tile_g = [&](int tile, int ts, int R) {
+    const char* gb = reinterpret_cast<const char*>(Gp + (size_t)ts * p.ldg + gcol0);
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
       const int r = r32 + 32 * rb;
-      pgw[rb] = (r < R && gcol_ok) ? *reinterpret_cast<const f32x4*>(gb + (uint32_t)(r * p.ldg) * 4u) : f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (PRS) prs[rb] = (rs2 && r < R) ? *reinterpret_cast<const f32x4*>(rs2 + (size_t)(ts + r) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int rr = r < R ? r : R - 1;
+      pgw[rb] = *reinterpret_cast<const f32x4*>(gb + (uint32_t)(rr * p.ldg) * 4u + gw_col);
+      if constexpr (PRS) prs[rb] = *reinterpret_cast<const f32x3_t*>(rsb + (size_t)(ts + rr) * 4);
     }
     const int2* src = reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TR;
 #pragma unroll
     for (int j = 0; j < NEL; ++j) {
       const int idx = tid + j * NT;
-      pel[j] = idx < D * TR ? src[idx] : make_int2(idx % TR, 0);      // (padding entries: own row, zero weight)
+      pel[j] = src[idx < D * TR ? idx : 0];      // (entries beyond the slice: replaced by padding where they are stored)
     }
   };
-  auto load_chunk = [&](int tile, int c) {
-    const int ts = p.tile_start[tile];
-    const int R = p.tile_start[tile + 1] - ts;
+  auto load_chunk = [&](int ts, int R, int c) {
     const char* xb = reinterpret_cast<const char*>(Xp + (size_t)ts * p.ldx + xcol0);
-    const char* gb = reinterpret_cast<const char*>(Gp + (size_t)ts * p.ldg + gcol0 + 4 * cg);
+    const char* gb = reinterpret_cast<const char*>(Gp + (size_t)ts * p.ldg + gcol0);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int r = 32 * c + 2 * rp + u;
+      const int rr = r < R ? r : R - 1;
       // X rows beyond the tile's R rows are read from its last row (finite; they only meet zero rows of G / P G / P^2 G)
-      px[u] = *reinterpret_cast<const f32x4*>(xb + (uint32_t)((r < R ? r : R - 1) * p.ldx) * 4u + xcb);
-      if (role == 0) pgc[u] = (r < R && zcol_ok) ? *reinterpret_cast<const f32x4*>(gb + (uint32_t)(r * p.ldg) * 4u) : f32x4{0.f, 0.f, 0.f, 0.f};
+      px[u] = *reinterpret_cast<const f32x4*>(xb + (uint32_t)(rr * p.ldx) * 4u + xcb);
+      if (role == 0) pgc[u] = *reinterpret_cast<const f32x4*>(gb + (uint32_t)(rr * p.ldg) * 4u + gc_col);
     }
   };
   // one row of P Zs (four columns at c4) for a real row; the slice is padded to four entries per row (zero weight, own row)
@@ -643,12 +649,18 @@ __global__ void __launch_bounds__(W16T_NT) wgrad16t_kernel(const dss2_wgrad_args
     return a;
   };
 
-  if (slice < p.ntiles) { load_tile_g(slice); load_chunk(slice, 0); }
+  int ts = 0, R = 0, ts_n = 0, R_n = 0;      // the current tile's rows and the next one's (read a tile ahead)
+  if (slice < p.ntiles) {
+    ts = p.tile_start[slice]; R = p.tile_start[slice + 1] - ts;
+    load_tile_g(slice, ts, R); load_chunk(ts, R, 0);
+    if (slice + p.n_split < p.ntiles) { ts_n = p.tile_start[slice + p.n_split]; R_n = p.tile_start[slice + p.n_split + 1] - ts_n; }
+  }
   for (int tile = slice; tile < p.ntiles; tile += p.n_split) {
-    const int ts = p.tile_start[tile];
-    const int R = p.tile_start[tile + 1] - ts;
     const int nch = (R + 31) >> 5;
     const int next = tile + p.n_split;
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+      if (!(gcol_ok && r32 + 32 * rb < R)) pgw[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
     // ---- fp32 G of the tile (first hop's input), the ELL slice, bias partial sums
     float* Zf0 = reinterpret_cast<float*>(U + pb * PBUF);
 #pragma unroll
@@ -661,7 +673,7 @@ __global__ void __launch_bounds__(W16T_NT) wgrad16t_kernel(const dss2_wgrad_args
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
           f32x4 d = {0.f, 0.f, 0.f, 0.f};
-          if constexpr (PRS) d = prs[rb];
+          if constexpr (PRS) d = f32x4{prs[rb][0], prs[rb][1], prs[rb][2], 0.f};
           else if (r32 + 32 * rb < R) d = *reinterpret_cast<const f32x4*>(rs2 + (size_t)(ts + r32 + 32 * rb) * 4);
 #pragma unroll
           for (int m = 0; m < NMAT; ++m) bs2[m] += pgw[rb] * d[m];
@@ -669,10 +681,12 @@ __global__ void __launch_bounds__(W16T_NT) wgrad16t_kernel(const dss2_wgrad_args
       }
     }
 #pragma unroll
-    for (int j = 0; j < NEL; ++j)
-      if (tid + j * NT < Dp * TR) ell[tid + j * NT] = pel[j];
+    for (int j = 0; j < NEL; ++j) {
+      const int idx = tid + j * NT;
+      if (idx < Dp * TR) ell[idx] = idx < D * TR ? pel[j] : make_int2(idx % TR, 0);      // (padding entries: own row, zero weight)
+    }
     __syncthreads();
-    if (next < p.ntiles) load_tile_g(next);      // in flight for the whole tile
+    if (next < p.ntiles) load_tile_g(next, ts_n, R_n);      // in flight for the whole tile
     // ---- P G of the tile
     if (NMAT > 1) {
 #pragma unroll
@@ -693,6 +707,9 @@ __global__ void __launch_bounds__(W16T_NT) wgrad16t_kernel(const dss2_wgrad_args
       if (32 * c + 8 * (wave & 3) < ((R + 15) & ~15)) {      // (a wave's units are eight rows; rows beyond the last k-step are not read)
         store_planes_b<XW>(XT, x_off, px[0], px[1]);
         if (role == 0) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            if (!(zcol_ok && 32 * c + 2 * rp + u < R)) pgc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
           store_planes_b<ZC>(ZT, z_off, pgc[0], pgc[1]);
           if (NMAT > 1) {
             const float* src = Zf1 + (32 * c + 2 * rp) * LDZF + 4 * cg;
@@ -710,8 +727,10 @@ __global__ void __launch_bounds__(W16T_NT) wgrad16t_kernel(const dss2_wgrad_args
         }
       }
       __syncthreads();
-      if (c + 1 < nch) load_chunk(tile, c + 1);
-      else if (next < p.ntiles) load_chunk(next, 0);
+      {      // ONE call site (two made the compiler load into temporaries and join them behind an s_waitcnt vmcnt(0))
+        const bool same = c + 1 < nch;
+        if (same || next < p.ntiles) load_chunk(same ? ts : ts_n, same ? R : R_n, same ? c + 1 : 0);
+      }
       // ---- MFMA phase: up to 2 steps of 16 rows
       if (in_active) {
         const int left = R - 32 * c;
@@ -745,6 +764,8 @@ __global__ void __launch_bounds__(W16T_NT) wgrad16t_kernel(const dss2_wgrad_args
       if constexpr (DB) pb ^= 1;          // the next chunk (or the next tile's fp32 G) writes the other set: no barrier here
       else __syncthreads();               // the planes are free for the next chunk / the next tile's fp32 G
     }
+    ts = ts_n; R = R_n;
+    if (next + p.n_split < p.ntiles) { ts_n = p.tile_start[next + p.n_split]; R_n = p.tile_start[next + p.n_split + 1] - ts_n; }
   }
 
   // ---- one slab per tile-list slice blockIdx.x; the y-slices tile the [nmat*hout, hin] matrix
