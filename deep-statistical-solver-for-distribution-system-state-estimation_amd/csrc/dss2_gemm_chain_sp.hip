@@ -529,6 +529,15 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
         }
       }
     }
+    // (the folded layer's row scales: all eight rows requested TOGETHER, before anything uses one -- inside the loop below each load
+    //  sat right in front of its use, eight L2 round trips in sequence: tools/isa_waits.py)
+    typedef float f32x3_e __attribute__((ext_vector_type(3)));
+    f32x3_e psr[8];
+    if (has_pre && col_ok) {
+      const char* pr0 = reinterpret_cast<const char*>(p.pre_rowscale + (size_t)ts * 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int row = rowv + 8 * i; psr[i] = *reinterpret_cast<const f32x3_e*>(pr0 + (size_t)(uint32_t)((row < R ? row : 0) * 16)); }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) U[i] += bias4;
     if (col_ok) {
@@ -538,9 +547,8 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
         for (int m = 0; m < NMAT; ++m) pb4[m] = *reinterpret_cast<const f32x4*>(L.prebias + (size_t)m * p.hout + col0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pre_rowscale + grow_of(i) * 4);
 #pragma unroll
-          for (int m = 0; m < NMAT; ++m) U[i] += pb4[m] * ps[m];
+          for (int m = 0; m < NMAT; ++m) U[i] += pb4[m] * psr[i][m];
         }
       }
       if (has_dm) {
