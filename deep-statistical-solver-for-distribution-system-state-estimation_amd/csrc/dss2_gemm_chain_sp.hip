@@ -69,9 +69,9 @@ constexpr int SP_HEAD_MAX = 4;      // nout
 // the 32x32x16 form: k-group 2 kb + (lane >> 5), source lane ((lane >> 4) & 1) * 32 + 16 nb + (lane & 15)).  Only the GEMM phase and the
 // accumulator hand-off (put) differ; sums are formed in another order, so results differ from MS = 0 by rounding.  K a multiple of 32.
 // MS = 2 (round 5): MS = 1's structure as f16x3 -- the tile lives in LDS as TWO fp16 planes per stripe, scaled by 2^ea (ea: a per-tile,
-// per-layer exponent that puts the tile's largest |value| into [2^14, 2^15)); the weights come as two fp16 planes scaled by 2^ew[m] per
-// matrix (dss2_pack_desc, transpose bit 3: the exponents follow the planes); three v_mfma_f32_16x16x32_f16 per product group (lo hi +
-// hi lo + hi hi) instead of six; the accumulators leave the GEMM phase multiplied by 2^-(ea + ew[m]) (v_ldexp in the hand-off: exact),
+// per-layer exponent that puts the tile's largest |value| into [2^14, 2^15)); the weights come as two fp16 planes scaled by 2^ew[m][j] per
+// matrix and output column (dss2_pack_desc, transpose bit 3: the exponents follow the planes); three v_mfma_f32_16x16x32_f16 per product
+// group (lo hi + hi lo + hi hi) instead of six; the accumulators leave the GEMM phase multiplied by 2^-(ea + ew[m][j]) (v_ldexp in the hand-off: exact),
 // so the hops and the epilogue are those of the bf16x6 form.  The tile maximum: every wave's maximum over its stripe of the finished
 // layer output (DPP), four LDS words, ONE more barrier per layer.  Errors of the size of fp32 arithmetic's own (dss2_wgrad16h.hip).
 // Layers gated by fp32 activations and X plane images: not in this form (the host routes them to MS = 1).
@@ -260,12 +260,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
     const bf16x8* __restrict__ bp16 = reinterpret_cast<const bf16x8*>(L.Bp);
     f32x16 acc[MS == 0 ? 2 : 1][NMAT];
     f32x4_acc c16[MS >= 1 ? 4 : 1][2][NMAT];
-    [[maybe_unused]] int ue[NMAT];      // (MS = 2) what takes the scales out of matrix m's accumulators: -(ea + ew[m])
-    if constexpr (F16) {
-      const int* whdr = reinterpret_cast<const int*>(reinterpret_cast<const char*>(L.Bp) + (size_t)NMAT * ncg * nks * 2048);      // uniform: scalar loads
-#pragma unroll
-      for (int m = 0; m < NMAT; ++m) ue[m] = -(ea + whdr[m]);
-    }
+    [[maybe_unused]] int ue[NMAT][2];      // (MS = 2) what takes the scales out of matrix m's accumulators, per output column of the lane
 
     if constexpr (MS >= 1) {
       // ---- tile GEMM on 16x16x32 MFMAs: a k-step (32 k) is two half-steps, one per 16-column block; the four row blocks' A fragments
@@ -412,6 +407,14 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
     //  computed where they are used instead of being hoisted out of the layer loop into 60 spilled registers)
     int rowv = r8;
     asm volatile("" : "+v"(rowv));
+    if constexpr (F16) {      // -(ea + ew[m][column]), column 16 nb + (lane & 15) of the wave's stripe: requested here (the fragment registers are free
+                              // now; at the top of the layer the six values were spilled across the GEMM phase), used in the hand-off behind the barrier
+      const int* whdr = reinterpret_cast<const int*>(reinterpret_cast<const char*>(L.Bp) + (size_t)NMAT * ncg * nks * 2048) + cg * 32 + (lane & 15);
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) ue[m][nb] = -(ea + whdr[m * ncg * 32 + nb * 16]);
+    }
     const bool has_pre = L.prebias != nullptr, has_dm = L.dmask != nullptr, has_rs = L.relu_src != nullptr, has_add = L.add_src != nullptr;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (L.bias && col_ok) bias4 = *reinterpret_cast<const f32x4*>(L.bias + col0);
@@ -464,7 +467,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) dst[(mb * 16 + r) * 32 + nb * 16] = F16 ? ldexpf(c16[mb][nb][m][r], ue[m]) : c16[mb][nb][m][r];
+              for (int r = 0; r < 4; ++r) dst[(mb * 16 + r) * 32 + nb * 16] = F16 ? ldexpf(c16[mb][nb][m][r], ue[m][nb]) : c16[mb][nb][m][r];
         }
       };
       put(slot0, NMAT - 1);
@@ -531,12 +534,13 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
     }
     // (the folded layer's row scales: all eight rows requested TOGETHER, before anything uses one -- inside the loop below each load
     //  sat right in front of its use, eight L2 round trips in sequence: tools/isa_waits.py)
+    // (MS = 2 only: the bf16x6 forms have 40 fragment registers more and would spill these 24)
     typedef float f32x3_e __attribute__((ext_vector_type(3)));
-    f32x3_e psr[8];
-    if (has_pre && col_ok) {
+    f32x3_e psr[F16 ? 8 : 1];
+    if (F16 && has_pre && col_ok) {
       const char* pr0 = reinterpret_cast<const char*>(p.pre_rowscale + (size_t)ts * 4);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int row = rowv + 8 * i; psr[i] = *reinterpret_cast<const f32x3_e*>(pr0 + (size_t)(uint32_t)((row < R ? row : 0) * 16)); }
+      for (int i = 0; i < (F16 ? 8 : 1); ++i) { const int row = rowv + 8 * i; psr[i] = *reinterpret_cast<const f32x3_e*>(pr0 + (size_t)(uint32_t)((row < R ? row : 0) * 16)); }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) U[i] += bias4;
@@ -547,8 +551,11 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
         for (int m = 0; m < NMAT; ++m) pb4[m] = *reinterpret_cast<const f32x4*>(L.prebias + (size_t)m * p.hout + col0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+          f32x3_e ps;
+          if constexpr (F16) ps = psr[i];
+          else ps = *reinterpret_cast<const f32x3_e*>(p.pre_rowscale + grow_of(i) * 4);
 #pragma unroll
-          for (int m = 0; m < NMAT; ++m) U[i] += pb4[m] * psr[i][m];
+          for (int m = 0; m < NMAT; ++m) U[i] += pb4[m] * ps[m];
         }
       }
       if (has_dm) {

@@ -242,12 +242,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     const dss2_chain_layer& L = ct.l[li];    // uniform: scalar loads from the kernel-argument segment
     const bf16x8* __restrict__ bp16 = reinterpret_cast<const bf16x8*>(L.Bp);
     f32x16 acc[NRB][NMAT];
-    [[maybe_unused]] int ue[NMAT];      // (F16) what takes the scales out of matrix m's accumulators: -(ea + ew[m])
-    if constexpr (F16) {
-      const int* whdr = reinterpret_cast<const int*>(reinterpret_cast<const char*>(L.Bp) + (size_t)NMAT * ncg * nks * 2048);      // uniform: scalar loads
-#pragma unroll
-      for (int m = 0; m < NMAT; ++m) ue[m] = -(ea + whdr[m]);
-    }
+    [[maybe_unused]] int ue[NMAT];      // (F16) what takes the scales out of matrix m's accumulators for the lane's output column: -(ea + ew[m][column])
 
     // ---- tile GEMM, 16 k per step: B fragments (L2) ping-pong one step ahead, A fragments (LDS planes) one row block ahead;
     // one memory request per MFMA gap (dss2_gemm_chain_sp.hip)
@@ -319,6 +314,11 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     // ---- what the epilogue reads from HBM per row, requested before the hops (rowv opaque: see dss2_gemm_chain_sp.hip)
     int rowv = r8;
     asm volatile("" : "+v"(rowv));
+    if constexpr (F16) {      // (requested here, behind the GEMM phase: its fragment registers are free; used in the hand-off behind the barrier)
+      const int* whdr = reinterpret_cast<const int*>(reinterpret_cast<const char*>(L.Bp) + (size_t)NMAT * ncg * nks * 2048) + cg * 32 + c32;
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) ue[m] = -(ea + whdr[m * ncg * 32]);
+    }
     const bool has_pre = DIR != 2 && L.prebias != nullptr, has_dm = DIR == 0 && L.dmask != nullptr, has_rs = DIR != 1 && L.relu_src != nullptr, has_add = DIR == 0 && L.add_src != nullptr;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (DIR != 2 && L.bias && col_ok) bias4 = *reinterpret_cast<const f32x4*>(L.bias + col0);

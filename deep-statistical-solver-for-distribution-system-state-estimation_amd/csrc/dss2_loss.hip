@@ -97,9 +97,12 @@ struct NodeMeas { float Z[4], R[4]; };
 
 __device__ __forceinline__ NodeMeas node_meas(const float* in, const float* xm, const float* xs) {
   NodeMeas m;
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = in[c];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const float z = in[2 * c], r = in[2 * c + 1];
+    const float z = v[2 * c], r = v[2 * c + 1];
     m.Z[c] = (z != 0.f) ? (z * xs[2 * c] + xm[2 * c]) : 0.f;
     m.R[c] = (r != 0.f) ? (r * xs[2 * c + 1] + xm[2 * c + 1]) : 0.f;
   }
@@ -108,12 +111,64 @@ __device__ __forceinline__ NodeMeas node_meas(const float* in, const float* xm, 
 
 constexpr int LB = 256;  // loss kernels' block size
 
+// Everything a bus needs of up to four of its incident branches, requested in three ROUNDS (entries -> other ends -> values) instead of
+// three dependent round trips PER branch: the loss kernels are one 4-wave workgroup per CU at C2, pure latency (round 5; the per-branch
+// loop cost wls_partials 11 us and wls_grad 9 us for 61 K buses).  Entries beyond the bus's list repeat its last one (loaded, not used).
+constexpr int WLS_GB = 4;
+struct BranchIn {
+  int en;                      // incidence entry: stored edge id, sign bit = this bus is the edge's to-end
+  int other;                   // the other end's bus
+  float o0, o1, slack_o;       // the other end's outputs and slack flag
+  float ep[7];                 // edge_param row (G, B, Gs, Bs, closed, shift, imax)
+  float ei[4];                 // edge_input row (z_p, r_p, z_q, r_q)
+  float apq_o[2];              // (gradient kernel) the other end's dL/dP, dL/dQ
+};
+template <bool GRAD>
+__device__ __forceinline__ void gather_branches(const dss2_wls_args& p, int k0, int k1, BranchIn (&b)[WLS_GB]) {
+#pragma unroll
+  for (int j = 0; j < WLS_GB; ++j) b[j].en = p.inc_ent[k0 + j < k1 ? k0 + j : k1 - 1];
+#pragma unroll
+  for (int j = 0; j < WLS_GB; ++j) {
+    const int e = b[j].en & 0x7fffffff;
+    const int32_t* ends = b[j].en < 0 ? p.efrom : p.eto;
+    b[j].other = ends[e];
+  }
+#pragma unroll
+  for (int j = 0; j < WLS_GB; ++j) {
+    const int e = b[j].en & 0x7fffffff;
+    const float* oo = p.output + (int64_t)b[j].other * p.ld_out;
+    b[j].o0 = oo[0]; b[j].o1 = oo[1];
+    b[j].slack_o = p.node_param[(int64_t)b[j].other * p.ld_np + 1];
+    const float* ep = p.edge_param + (int64_t)e * p.ld_ep;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) b[j].ep[c] = (c == 4) ? 0.f : ep[c];
+    const float* ei = p.edge_input + (int64_t)e * p.ld_ein;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[j].ei[c] = ei[c];
+    if constexpr (GRAD) { b[j].apq_o[0] = p.apq[2 * (int64_t)b[j].other]; b[j].apq_o[1] = p.apq[2 * (int64_t)b[j].other + 1]; }
+  }
+}
+__device__ __forceinline__ EdgeP edge_param_of(const BranchIn& b) {
+  EdgeP e;
+  e.G = b.ep[0]; e.B = b.ep[1]; e.Gs = b.ep[2]; e.Bs = b.ep[3];
+  e.tp = ceilf(b.ep[5]);
+  e.imax = b.ep[6];
+  return e;
+}
+
 __global__ void __launch_bounds__(LB) wls_partials_kernel(const dss2_wls_args p) {
   __shared__ double red[LB / 64][5];
   const int64_t i = (int64_t)blockIdx.x * LB + threadIdx.x;
   float vlv, vhv;
   vminmax_fold(p.vminmax, vlv, vhv);
-  const float xs0 = p.x_std[0], xm0 = p.x_mean[0];
+  // (the 8 + 8 + 4 + 4 normalisation constants: read ONCE, unconditionally -- inside `z != 0 ? z * std[c] + mean[c] : 0` every one of
+  //  them was a load behind a branch behind the load of z, a memory round trip each)
+  float xmv[8], xsv[8], emv[4], esv[4];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { xmv[c] = p.x_mean[c]; xsv[c] = p.x_std[c]; }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { emv[c] = p.edge_mean[c]; esv[c] = p.edge_std[c]; }
+  const float xs0 = xsv[0], xm0 = xmv[0];
   double acc[5] = {0, 0, 0, 0, 0};
   if (i < p.n_nodes) {
     float* o = p.output + i * p.ld_out;
@@ -121,19 +176,22 @@ __global__ void __launch_bounds__(LB) wls_partials_kernel(const dss2_wls_args p)
     const float th_i = o[1] * mi;
     o[1] = th_i;  // theta_i *= (1 - slack), in place on the model output (data.py:413)
     const float v_i = o[0] * xs0 + xm0;
-    const NodeMeas nm = node_meas(p.input + i * p.ld_in, p.x_mean, p.x_std);
+    const NodeMeas nm = node_meas(p.input + i * p.ld_in, xmv, xsv);
     float p_i = 0.f, q_i = 0.f, s_edge = 0.f, s_t = 0.f, s_l = 0.f;
     const int k1 = p.inc_rowptr[i + 1];
-    for (int k = p.inc_rowptr[i]; k < k1; ++k) {
-      const int en = p.inc_ent[k];
-      const int e = en & 0x7fffffff;
-      const bool to_end = en < 0;
-      const int64_t other = to_end ? p.efrom[e] : p.eto[e];
-      const float* oo = p.output + other * p.ld_out;
-      const float v_o = oo[0] * xs0 + xm0;
+    for (int k0 = p.inc_rowptr[i]; k0 < k1; k0 += WLS_GB) {
+     BranchIn bin[WLS_GB];
+     gather_branches<false>(p, k0, k1, bin);
+#pragma unroll
+     for (int j = 0; j < WLS_GB; ++j) {
+      if (k0 + j >= k1) break;
+      const BranchIn& bi = bin[j];
+      const int e = bi.en & 0x7fffffff;
+      const bool to_end = bi.en < 0;
+      const float v_o = bi.o0 * xs0 + xm0;
       // mask is 0/1, so re-applying it to a possibly already-masked value is idempotent
-      const float th_o = oo[1] * (1.f - p.node_param[other * p.ld_np + 1]);
-      const EdgeP ep = load_edge_param(p.edge_param + (int64_t)e * p.ld_ep);
+      const float th_o = bi.o1 * (1.f - bi.slack_o);
+      const EdgeP ep = edge_param_of(bi);
       const Flow f = to_end ? branch_flow(v_o, v_i, th_o, th_i, ep, vlv, vhv)
                             : branch_flow(v_i, v_o, th_i, th_o, ep, vlv, vhv);
       if (to_end) {
@@ -143,12 +201,11 @@ __global__ void __launch_bounds__(LB) wls_partials_kernel(const dss2_wls_args p)
         p_i -= f.pf;
         q_i -= f.qf;
         // each stored edge is accounted once, at its from-end
-        const float* ei = p.edge_input + (int64_t)e * p.ld_ein;
-        const float zp = ei[0], rp = ei[1], zq = ei[2], rq = ei[3];
-        const float Zp = (zp != 0.f) ? (zp * p.edge_std[0] + p.edge_mean[0]) : 0.f;
-        const float Rp = (rp != 0.f) ? (rp * p.edge_std[1] + p.edge_mean[1]) : 0.f;
-        const float Zq = (zq != 0.f) ? (zq * p.edge_std[2] + p.edge_mean[2]) : 0.f;
-        const float Rq = (rq != 0.f) ? (rq * p.edge_std[3] + p.edge_mean[3]) : 0.f;
+        const float zp = bi.ei[0], rp = bi.ei[1], zq = bi.ei[2], rq = bi.ei[3];
+        const float Zp = (zp != 0.f) ? (zp * esv[0] + emv[0]) : 0.f;
+        const float Rp = (rp != 0.f) ? (rp * esv[1] + emv[1]) : 0.f;
+        const float Zq = (zq != 0.f) ? (zq * esv[2] + emv[2]) : 0.f;
+        const float Rq = (rq != 0.f) ? (rq * esv[3] + emv[3]) : 0.f;
         const float dp = Zp - f.pf, dq = Zq - f.qf;
         s_edge += dp * dp * Rp * p.lam_pf + dq * dq * Rq * p.lam_pf;
         s_t += fmaxf(fabsf(f.d) - 0.5f, 0.f);
@@ -159,6 +216,7 @@ __global__ void __launch_bounds__(LB) wls_partials_kernel(const dss2_wls_args p)
           pf[4] = f.pt; pf[5] = f.qt; pf[6] = f.i_f; pf[7] = f.i_t;
         }
       }
+     }
     }
     const float h[4] = {v_i, th_i, p_i, q_i};
     const float lam[4] = {p.lam_v, p.lam_v, p.lam_p, p.lam_p};
@@ -262,7 +320,12 @@ __global__ void __launch_bounds__(LB) wls_grad_kernel(const dss2_wls_args p) {
   const float m_t = (float)(2.0 * p.lam_reg * mean_t / Ee);
   const float m_l = (float)(2.0 * p.lam_reg * mean_l / Ee);
   
-  const float xs0 = p.x_std[0], xm0 = p.x_mean[0];
+  float xmv[8], xsv[8], emv[4], esv[4];      // (read once, unconditionally: see wls_partials_kernel)
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { xmv[c] = p.x_mean[c]; xsv[c] = p.x_std[c]; }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { emv[c] = p.edge_mean[c]; esv[c] = p.edge_std[c]; }
+  const float xs0 = xsv[0], xm0 = xmv[0];
   const float kk = vlv * vlv;
   const float sqrt3 = 1.7320508075688772f;
   const float ratio = vhv / vlv;
@@ -271,35 +334,36 @@ __global__ void __launch_bounds__(LB) wls_grad_kernel(const dss2_wls_args p) {
   const float mi = 1.f - p.node_param[i * p.ld_np + 1];
   const float th_i = o[1] * mi;
   const float v_i = o[0] * xs0 + xm0;
-  const NodeMeas nm = node_meas(p.input + i * p.ld_in, p.x_mean, p.x_std);
+  const NodeMeas nm = node_meas(p.input + i * p.ld_in, xmv, xsv);
   float gv = invN * (-2.f * (nm.Z[0] - v_i) * nm.R[0] * p.lam_v);
   gv += m_v * ((v_i > 1.1f ? 1.f : 0.f) - (v_i < 0.9f ? 1.f : 0.f));
   float gth = invN * (-2.f * (nm.Z[1] - th_i) * nm.R[1] * p.lam_v);
   const float ap_i = p.apq[2 * i] * invN, aq_i = p.apq[2 * i + 1] * invN;
 
   const int k1 = p.inc_rowptr[i + 1];
-  for (int k = p.inc_rowptr[i]; k < k1; ++k) {
-    const int en = p.inc_ent[k];
-    const int e = en & 0x7fffffff;
-    const bool to_end = en < 0;
-    const int64_t other = to_end ? p.efrom[e] : p.eto[e];
-    const float* oo = p.output + other * p.ld_out;
-    const float v_o = oo[0] * xs0 + xm0;
-    const float th_o = oo[1] * (1.f - p.node_param[other * p.ld_np + 1]);
-    const float ap_o = p.apq[2 * other] * invN, aq_o = p.apq[2 * other + 1] * invN;
-    const EdgeP ep = load_edge_param(p.edge_param + (int64_t)e * p.ld_ep);
+  for (int k0 = p.inc_rowptr[i]; k0 < k1; k0 += WLS_GB) {
+   BranchIn bin[WLS_GB];
+   gather_branches<true>(p, k0, k1, bin);
+#pragma unroll
+   for (int j = 0; j < WLS_GB; ++j) {
+    if (k0 + j >= k1) break;
+    const BranchIn& bi = bin[j];
+    const bool to_end = bi.en < 0;
+    const float v_o = bi.o0 * xs0 + xm0;
+    const float th_o = bi.o1 * (1.f - bi.slack_o);
+    const float ap_o = bi.apq_o[0] * invN, aq_o = bi.apq_o[1] * invN;
+    const EdgeP ep = edge_param_of(bi);
     const float vf = to_end ? v_o : v_i, vt = to_end ? v_i : v_o;
     const float thf = to_end ? th_o : th_i, tht = to_end ? th_i : th_o;
     const float ap_f = to_end ? ap_o : ap_i, aq_f = to_end ? aq_o : aq_i;
     const float ap_t = to_end ? ap_i : ap_o, aq_t = to_end ? aq_i : aq_o;
     const Flow f = branch_flow(vf, vt, thf, tht, ep, vlv, vhv);
     // upstream gradients w.r.t. the four flows
-    const float* ei = p.edge_input + (int64_t)e * p.ld_ein;
-    const float zp = ei[0], rp = ei[1], zq = ei[2], rq = ei[3];
-    const float Zp = (zp != 0.f) ? (zp * p.edge_std[0] + p.edge_mean[0]) : 0.f;
-    const float Rp = (rp != 0.f) ? (rp * p.edge_std[1] + p.edge_mean[1]) : 0.f;
-    const float Zq = (zq != 0.f) ? (zq * p.edge_std[2] + p.edge_mean[2]) : 0.f;
-    const float Rq = (rq != 0.f) ? (rq * p.edge_std[3] + p.edge_mean[3]) : 0.f;
+    const float zp = bi.ei[0], rp = bi.ei[1], zq = bi.ei[2], rq = bi.ei[3];
+    const float Zp = (zp != 0.f) ? (zp * esv[0] + emv[0]) : 0.f;
+    const float Rp = (rp != 0.f) ? (rp * esv[1] + emv[1]) : 0.f;
+    const float Zq = (zq != 0.f) ? (zq * esv[2] + emv[2]) : 0.f;
+    const float Rq = (rq != 0.f) ? (rq * esv[3] + emv[3]) : 0.f;
     float uPf = invE * (-2.f * (Zp - f.pf) * Rp * p.lam_pf) - ap_f;
     float uQf = invE * (-2.f * (Zq - f.qf) * Rq * p.lam_pf) - aq_f;
     float uPt = -ap_t, uQt = -aq_t;
@@ -348,6 +412,7 @@ __global__ void __launch_bounds__(LB) wls_grad_kernel(const dss2_wls_args p) {
     // d/dd: d a1 = a2, d a2 = -a1, d a3 = -a4, d a4 = a3
     const float dd = (uPf * (-vv * a2) + uQf * (vv * (-a1)) + uPt * (-vv * (-a4)) + uQt * (vv * a3)) * kk + gd;
     gth += to_end ? -dd : dd;
+   }
   }
   const float gs = p.gscale ? p.gscale[0] : 1.f;      // upstream gradient of the loss (1 for loss.backward())
   p.grad_output[2 * i + 0] = gv * xs0 * gs;

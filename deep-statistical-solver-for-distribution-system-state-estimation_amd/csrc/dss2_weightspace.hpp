@@ -146,48 +146,46 @@ __device__ __forceinline__ void pack_weights_body(const dss2_pack_desc d, const 
   const int J = tr ? d.rows : d.cols;
   if (d.transpose & 8) {
     // f16x2 layout (f16x3 products, dss2_common.hpp: split2_pair): the GROUP's buffer d.dst = [matrix][col group][kpad/16][plane 0..1]
-    // [64 lanes][8 fp16] followed by one int32 per matrix, the exponent s of the power-of-two scale its elements were multiplied with
-    // before the split: 2^s max |W| in [2^14, 2^15).  d.koff = matrices in the group, d.joff = this matrix (no offsets in this layout).
-    // Every workgroup of the descriptor forms the matrix's maximum itself (64 KB of L2-resident reads at H = 128).
+    // [64 lanes][8 fp16] followed by one int32 per matrix and packed COLUMN j (ncg * 32 each): the exponent s of the power-of-two scale
+    // that column's elements were multiplied with before the split, 2^s max_k |B[k][j]| in [2^14, 2^15) (a scale must be uniform along
+    // k only; per column it is local to a workgroup -- a per-matrix maximum had every workgroup read the whole matrix again: 144 x 64
+    // KB at C2, pack_weights_kernel 5.7 -> 9.8 us).  d.koff = matrices in the group, d.joff = this matrix (no offsets in this layout).
+    // A workgroup owns 256 / U columns, U = the units of 8 k per column rounded up to a power of two.
     const int nkk = d.kpad >> 4, ncg = d.ncg;
-    const int total = ncg * nkk * 64;
-    if (bx * 256 >= total) return;      // (uniform)
-    __shared__ float wmx[4];
+    const int units = 2 * nkk;                         // per column: (k-step, half)
+    int U = 2; while (U < units) U <<= 1;
+    if (U > 256) return;                               // (kpad <= 2048)
+    const int cpb = 256 / U;
+    const int jpad = ncg * 32;
+    if (bx * cpb >= jpad) return;                      // (uniform)
+    __shared__ float cmx[256];
     typedef const __attribute__((address_space(1))) float* gsrc_t;
     const gsrc_t src = (gsrc_t)d.src;
-    float mx = 0.f;
-    if (((d.cols | d.ld) & 3) == 0 && (reinterpret_cast<uintptr_t>(d.src) & 15) == 0) {
-      const int c4 = d.cols >> 2, n4 = d.rows * c4;
-      for (int i = threadIdx.x; i < n4; i += 256) {
-        const int r = i / c4, c = i - r * c4;
-        mx = absmax4(mx, *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(src + (size_t)r * d.ld + 4 * c));
-      }
-    } else {
-      for (int i = threadIdx.x; i < d.rows * d.cols; i += 256) { const int r = i / d.cols, c = i - r * d.cols; mx = fmaxf(mx, fabsf(src[(size_t)r * d.ld + c])); }
-    }
-    mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    const int s = 14 - exp_of(fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3])));
-    const size_t mat_bytes = (size_t)ncg * nkk * 2048;
-    char* gb = reinterpret_cast<char*>(d.dst);
-    if (bx == 0 && threadIdx.x == 0) reinterpret_cast<int*>(gb + (size_t)d.koff * mat_bytes)[d.joff] = s;
-    const int idx = bx * 256 + (int)threadIdx.x;
-    if (idx >= total) return;
-    const int lane = idx & 63;
-    const int kg = (idx >> 6) % nkk;
-    const int cg = (idx >> 6) / nkk;
-    const int j = cg * 32 + (lane & 31);
-    typedef __attribute__((address_space(1))) uint32_t* gdst_t;
-    gdst_t dst = (gdst_t)(gb + (size_t)d.joff * mat_bytes + (((size_t)cg * nkk + kg) * 2 * 64 + lane) * 16);
+    const int t = threadIdx.x, u = t & (U - 1), cj = t / U;
+    const int j = bx * cpb + cj, kg = u >> 1, hf = u & 1;
+    const bool active = u < units && j < jpad;
     float v[8];
+    float mx = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int k = kg * 16 + 8 * (lane >> 5) + q;
+      const int k = kg * 16 + 8 * hf + q;
       const int kc = k >= K ? K - 1 : k, jc = j >= J ? J - 1 : j;
       const float x = tr ? src[(size_t)jc * d.ld + kc] : src[(size_t)kc * d.ld + jc];
-      v[q] = (k < K && j < J) ? x : 0.f;      // (padding: zero pieces -- this layout is written whole)
+      v[q] = (active && k < K && j < J) ? x : 0.f;      // (padding: zero pieces -- this layout is written whole)
+      mx = fmaxf(mx, fabsf(v[q]));
     }
+    cmx[t] = mx;
+    __syncthreads();
+    float cm = 0.f;
+    for (int w = 0; w < U; ++w) cm = fmaxf(cm, cmx[cj * U + w]);      // (the column's U partial maxima: broadcast reads)
+    const int s = cm > 0.f ? 14 - exp_of(cm) : 0;
+    const size_t mat_bytes = (size_t)ncg * nkk * 2048;
+    char* gb = reinterpret_cast<char*>(d.dst);
+    if (u == 0 && j < jpad) reinterpret_cast<int*>(gb + (size_t)d.koff * mat_bytes)[(size_t)d.joff * jpad + j] = s;
+    if (!active) return;
+    const int cg = j >> 5, lane = hf * 32 + (j & 31);
+    typedef __attribute__((address_space(1))) uint32_t* gdst_t;
+    gdst_t dst = (gdst_t)(gb + (size_t)d.joff * mat_bytes + (((size_t)cg * nkk + kg) * 2 * 64 + lane) * 16);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       uint32_t h, l;

@@ -176,7 +176,7 @@ class _PackPlan:
         # bf16_groups: additionally the bf16x3 fragment layout (fp32-accurate tile GEMM on the bf16 matrix pipe,
         # csrc/dss2_gemm_chain16.hip): [matrix][col group][k/16][3 planes][64 lanes][8 bf16]
         # f16: those groups in the f16x2 layout instead (f16x3 chains, b_format 2): [matrix][col group][k/16][2 planes][64 lanes][8 fp16],
-        # then one int32 scale exponent per matrix (written by the pack kernel, which forms each matrix's maximum)
+        # then one int32 scale exponent per matrix and packed column (written by the pack kernel, which forms each column's maximum)
         self.fwd16, self.bwd16, self.f16 = {}, {}, bool(f16)
         for g in bf16_groups:
             nm, hout, hin = self.meta[g][0:3]
@@ -184,9 +184,8 @@ class _PackPlan:
                 raise ValueError("bf16x3 packing is for plain per-matrix layouts")
             kf, cf, kb, cb = _round16(hin), _ncg(hout), _round16(hout), _ncg(hin)
             per = 512 if self.f16 else 768      # floats per (column group, k-step of 16)
-            tail = 4 if self.f16 else 0         # (nm <= 4 exponents, 16 bytes)
-            self.fwd16[g] = torch.zeros(nm * cf * (kf // 16) * per + tail, dtype=_F32, device=device)
-            self.bwd16[g] = torch.zeros(nm * cb * (kb // 16) * per + tail, dtype=_F32, device=device)
+            self.fwd16[g] = torch.zeros(nm * cf * (kf // 16) * per + (nm * cf * 32 if self.f16 else 0), dtype=_F32, device=device)      # (+ one exponent
+            self.bwd16[g] = torch.zeros(nm * cb * (kb // 16) * per + (nm * cb * 32 if self.f16 else 0), dtype=_F32, device=device)      #  per matrix and packed column)
         self.ptrs = None
         self.table = None
         self.max_elems = 0

@@ -142,9 +142,9 @@ typedef struct dss2_pack_desc {
                        * every weight split into three bf16 pieces h + m + l for the fp32-accurate bf16 MFMA path
                        * bit 2: ignored by the kernels (the host side marks descriptors whose src the fold of the same step writes)
                        * bit 3: the f16x2 layout of the f16x3 chains (round 5): dst = the GROUP's buffer [matrix][ncg][kpad/16][2 planes]
-                       * [64 lanes][8 fp16] + one int32 per matrix (the exponent s of the power-of-two scale applied before the split:
-                       * 2^s max |W| in [2^14, 2^15)); koff = matrices in the group, joff = this matrix's index (not offsets); the
-                       * matrix is written whole, padding included                                                                  */
+                       * [64 lanes][8 fp16] + one int32 per matrix and packed column ([matrix][ncg * 32]: the exponent s of the power-
+                       * of-two scale applied to that column before the split, 2^s max_k |B[k][j]| in [2^14, 2^15)); koff = matrices in
+                       * the group, joff = this matrix's index (not offsets); the matrix is written whole, padding included          */
   int32_t koff;       /* k offset of this block inside the packed matrix (any value)   */
   int32_t kpad;       /* padded K of the packed matrix (multiple of 8)                  */
   int32_t ncg;        /* number of 32-column groups of the packed matrix                */

@@ -182,7 +182,9 @@ def test_no_kernel_in_the_library_spills_registers():
     # ... and their f16x3 forms (round 5: <., ., ., ., true>; two planes instead of three: fewer at 96 rows).  <6, 3, 2, 0, true> -- the
     # 192-row data-gradient chain WITHOUT the fused head, which the models do not run -- keeps its 24 input row pieces in registers while
     # the tile's maximum is formed and parks most of them in scratch memory once per tile, before the first layer.
-    for nrb, d, hm, cap in ((3, 1, 0, 8), (3, 2, 0, 8), (3, 2, 2, 8), (6, 1, 0, 32), (6, 2, 2, 32), (6, 2, 0, 96)):
+    # (per-column weight exponents are per-lane values: three more registers across the hops; the 192-row forms, at 512 of 512 registers
+    #  with K = 2, pay for them in parked loop invariants -- cfgbench: 179-bus step 1.504 -> 1.506 ms with them)
+    for nrb, d, hm, cap in ((3, 1, 0, 16), (3, 2, 0, 8), (3, 2, 2, 8), (6, 1, 0, 64), (6, 2, 2, 32), (6, 2, 0, 128)):
         allowed[f"void dss2::gemm_chain_sp6_kernel<{nrb}, 3, {d}, {hm}, true>"] = cap
     # A third, chosen: the edge MLP's bf16x6 forward (csrc/dss2_edge16.hip) is held to 128 registers (four waves per SIMD,
     # amdgpu_waves_per_eu) because it waits on a dependent staging chain; the 2 / 7 registers that costs at 64- / 96-row tiles
@@ -208,6 +210,9 @@ def test_no_kernel_in_the_library_spills_registers():
     for nw in (4, 8):
         for hm in (0, 1, 2):
             allowed[f"void dss2::gemm_chain_sp_kernel<3, {nw}, {hm}, 1>"] = 32
+            # (its f16x3 form, MS = 2, has 40 fragment registers fewer: 8-12 values parked around the layer loop -- the folded layer's
+            #  eight row-scale vectors requested together at the top of the epilogue and the per-column weight exponents)
+            allowed[f"void dss2::gemm_chain_sp_kernel<3, {nw}, {hm}, 2>"] = 16
     bad = [(fn, name, sp, scr) for fn, ks in results for name, sp, scr in ks
            if (sp or scr) and not (name.strip() in allowed and sp <= allowed[name.strip()])]
     assert not bad, bad
