@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""GPU: accuracy of the bf16x6 kernels (DSS2_CHAIN_BF16=1 DSS2_WGRAD_BF16=1, default) against the fp32-MFMA path (both =0), both measured against
+"""GPU: accuracy of the three arithmetic routes of the H -> H layers -- f16x3 (default where the kernels have the form: DSS2_CHAIN_F16=1
+DSS2_WGRAD_F16=1), bf16x6 (both =0) and the fp32-MFMA path (DSS2_CHAIN_BF16=0 DSS2_WGRAD_BF16=0) --, each measured against
 the fp64 CPU oracle on the same weights and batch: max-normalised error of the output, relative error of the loss, worst
 max-normalised error over the parameter gradients.  Runs both settings in child processes."""
 import importlib, json, os, subprocess, sys
@@ -41,15 +42,19 @@ if __name__ == "__main__":
         child()
     else:
         rows = {}
-        for mode in ("1", "0"):
-            env = dict(os.environ, DSS2_CHAIN_BF16=mode, DSS2_WGRAD_BF16=mode)
+        MODES = {"f16x3": dict(DSS2_CHAIN_BF16="1", DSS2_WGRAD_BF16="1", DSS2_CHAIN_F16="1", DSS2_WGRAD_F16="1"),
+                 "bf16x6": dict(DSS2_CHAIN_BF16="1", DSS2_WGRAD_BF16="1", DSS2_CHAIN_F16="0", DSS2_WGRAD_F16="0"),
+                 "fp32": dict(DSS2_CHAIN_BF16="0", DSS2_WGRAD_BF16="0", DSS2_CHAIN_F16="0", DSS2_WGRAD_F16="0")}
+        for mode, envs in MODES.items():
+            env = dict(os.environ, **envs)
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
             if not line:
                 print(p.stdout[-2000:], p.stderr[-3000:]); sys.exit(1)
             rows[mode] = json.loads(line[-1])
         print(f"{'configuration':36s} {'path':8s} {'output':>10s} {'loss':>10s} {'worst grad':>10s}   (errors against the fp64 oracle)")
-        for name in rows["1"]:
-            for mode, label in (("1", "bf16x6"), ("0", "fp32")):
+        for name in rows["fp32"]:
+            for mode in MODES:
+                label = mode
                 r = rows[mode][name]
                 print(f"{name:36s} {label:8s} {r['out']:10.2e} {r['loss']:10.2e} {r['grad']:10.2e}")

@@ -15,9 +15,11 @@ N = x.shape[0]
 topo = pkg.topology.get_topology(ei, N)
 Ws = [torch.randn(H, H, device=dev) * 0.1 for _ in range(nmat)]
 B16 = os.environ.get("CHAINBENCH_BF16", "1") == "1" and nw.chain16_supported(topo, nmat, H, False)
-plan = nw._PackPlan([Ws], dev, bf16_groups=((0,) if B16 else ())); plan.refresh()
+F16 = bool(B16 and os.environ.get("CHAINBENCH_F16", "1") == "1" and pkg.ops.chain_f16_supported(topo, nmat, H))      # (CHAINBENCH_F16=0: bf16x6)
+BF = 2 if F16 else int(B16)
+plan = nw._PackPlan([Ws], dev, bf16_groups=((0,) if B16 else ()), f16=F16); plan.refresh()
 pf, pb = (plan.fwd16[0], plan.bwd16[0]) if B16 else (plan.fwd[0], plan.bwd[0])
-print("tile GEMM:", "bf16x6 (v_mfma_f32_32x32x16_bf16 x 6)" if B16 else "fp32 (v_mfma_f32_32x32x2_f32)")
+print("tile GEMM:", "f16x3 (three fp16 MFMAs per product)" if F16 else ("bf16x6 (six bf16 MFMAs per product)" if B16 else "fp32 (v_mfma_f32_32x32x2_f32)"))
 h = torch.randn(N, H, device=dev); g = torch.randn(N, H, device=dev); bias = torch.randn(H, device=dev)
 outs = [torch.empty(N, H, device=dev) for _ in range(nl)]
 acts = [torch.randn(N, H, device=dev) for _ in range(nl)]
@@ -39,16 +41,16 @@ def fwd():
         for i_, l_ in enumerate(ls):
             l_["drop_id"] = i_ + 1
     nw.gemm_prop_chain(topo, h, H, nmat, ls, pre_rowscale=(_prs if "pre" in _extras else None),
-                       drop=((_snap, 0.3) if "drop" in _extras else None), b_format=int(B16))
+                       drop=((_snap, 0.3) if "drop" in _extras else None), b_format=BF)
 
 
 fwd_bits = [torch.zeros(topo.ntiles * max(1, nw.chain_gate_words(topo, nmat, H) if B16 else 1), dtype=torch.int64, device=dev) for _ in range(nl)]
 gw = nw.chain_gate_words(topo, nmat, H) if B16 else 0      # tall tiles: sign-bit words instead of the activations (needs real activations)
 bits = [torch.zeros(topo.ntiles * gw, dtype=torch.int64, device=dev) for _ in range(nl)] if gw else [None] * nl
 if gw:
-    nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=pf, Y=a_, bias=bias, relu=True, y_bits=b_) for a_, b_ in zip(acts, bits)], b_format=1)
+    nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=pf, Y=a_, bias=bias, relu=True, y_bits=b_) for a_, b_ in zip(acts, bits)], b_format=BF)
     print("backward gates: bit words written by a forward chain")
-bwd = lambda: nw.gemm_prop_chain(topo, g, H, nmat, [dict(Bp=pb, Y=o, relu_src=a_, gate_bits=b_) for o, a_, b_ in zip(outs, acts, bits)], transposed=True, b_format=int(B16))
+bwd = lambda: nw.gemm_prop_chain(topo, g, H, nmat, [dict(Bp=pb, Y=o, relu_src=a_, gate_bits=b_) for o, a_, b_ in zip(outs, acts, bits)], transposed=True, b_format=BF)
 fl = nl * (2.0 * N * H * nmat * H + 2.0 * (nmat - 1) * topo.E2 * H)
 for _ in range(300):   # clock ramp
     fwd()

@@ -11,7 +11,8 @@ ei = b["edge_index"].to(dev); N = b["x"].shape[0]
 topo = pkg.topology.get_topology(ei, N)
 Ws = [torch.randn(H, H, device=dev) * 0.1 for _ in range(nmat)]
 B16 = nw.chain16_supported(topo, nmat, H, False)          # the product path: tile GEMM of the chain as bf16x6
-plan = nw._PackPlan([Ws], dev, bf16_groups=((0,) if B16 else ())); plan.refresh()
+F16 = bool(B16 and os.environ.get("PMC_F16", "1") == "1" and pkg.ops.chain_f16_supported(topo, nmat, H))      # ... as f16x3 where the chain has the form (PMC_F16=0: bf16x6)
+plan = nw._PackPlan([Ws], dev, bf16_groups=((0,) if B16 else ()), f16=F16); plan.refresh()
 h = torch.randn(N, H, device=dev); g = torch.randn(N, H, device=dev); out = torch.empty(N, H, device=dev)
 bias = torch.randn(H, device=dev); flat = torch.empty(nmat * H * H + H, device=dev)
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
@@ -37,7 +38,7 @@ for it in range(NREP):
     elif which == "chain":       # 3 chained H -> H layers (the C2 forward chain)
         outs = [torch.empty(N, H, device=dev) for _ in range(3)]
         nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=(plan.fwd16[0] if B16 else plan.fwd[0]), Y=o, bias=bias, relu=True) for o in outs],
-                           b_format=int(B16))
+                           b_format=(2 if F16 else int(B16)))
     elif which == "wgrad2":      # two layers batched in one launch (the C2 backward of round 3)
         flat2 = torch.empty(2 * (nmat * H * H + H), device=dev)
         nw.wgrad_batched(topo, [g, g], H, [h, h], H, nmat, flat2)

@@ -15,7 +15,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list)); dur=collecti
 for f in glob.glob(R+f"/gpurun_out/pmc1_{W}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"].split("(")[0]
-        if "gemm_prop_kernel" in k or "gemm_chain_kernel" in k or "gemm_chain_sp_kernel" in k or "wgrad_kernel" in k or "wgrad16_kernel" in k or "wgrad16b_kernel" in k or "wgrad16t_kernel" in k or "wgrad16p_kernel" in k or "wgrad16q_kernel" in k or "gemm_chain_sp6_kernel" in k or "reduce_slabs" in k or "stack_fwd_kernel" in k or "stack_bwd_kernel" in k:
+        if "gemm_prop_kernel" in k or "gemm_chain_kernel" in k or "gemm_chain_sp_kernel" in k or "wgrad_kernel" in k or "wgrad16_kernel" in k or "wgrad16b_kernel" in k or "wgrad16t_kernel" in k or "wgrad16p_kernel" in k or "wgrad16q_kernel" in k or "wgrad16h_kernel" in k or "gemm_chain_sp6_kernel" in k or "reduce_slabs" in k or "stack_fwd_kernel" in k or "stack_bwd_kernel" in k:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob(R+f"/gpurun_out/pmc1_{W}_*/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):

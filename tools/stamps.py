@@ -101,10 +101,12 @@ median over workgroups and waves.  argv[1] = graphs in the batch (1024: one work
     ei = b["edge_index"].to(dev); N = b["x"].shape[0]
     topo = pkg.topology.get_topology(ei, N)
     Ws = [torch.randn(H, H, device=dev) * 0.1 for _ in range(nmat)]
-    plan = nw._PackPlan([Ws], dev, bf16_groups=(0,)); plan.refresh()
+    f16 = os.environ.get("STAMPS_F16", "1") == "1" and pkg.ops.chain_f16_supported(topo, nmat, H)      # (STAMPS_F16=0: the bf16x6 form)
+    plan = nw._PackPlan([Ws], dev, bf16_groups=(0,), f16=f16); plan.refresh()
     h = torch.randn(N, H, device=dev); bias = torch.randn(H, device=dev)
     outs = [torch.empty(N, H, device=dev) for _ in range(nl)]
-    run = lambda: nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=plan.fwd16[0], Y=o, bias=bias, relu=True) for o in outs], b_format=1)
+    print("tile GEMM as", "f16x3" if f16 else "bf16x6")
+    run = lambda: nw.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=plan.fwd16[0], Y=o, bias=bias, relu=True) for o in outs], b_format=(2 if f16 else 1))
     for _ in range(200): run()
     torch.cuda.synchronize()
     run(); torch.cuda.synchronize()
