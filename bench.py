@@ -546,9 +546,17 @@ def main():
         result["config"]["hipgraph"] = "skipped at world > 1 (DSS2_BENCH_DIST_GRAPH=0)"
     # ---- and as a launch plan (graphs.PlannedStep, include/dss2_hip.h "launch plans"): the library's own record of the step's launches
     # re-issued from ONE C call per step -- real launches of the same kernels on the same stream, no Python between them, and like the
-    # hipGraph replay it carries the step's vminmax launch (no cached batch constants).  Single process only (a collective is not a
-    # launch of this library).
-    if world == 1 and not args.no_graph:
+    # hipGraph replay it carries the step's vminmax launch (no cached batch constants).  At world > 1 the step's collectives (loss
+    # sums, gradient bucket) cut the plan into segments: one C call per segment, the collectives between them (graphs.plan_collective)
+    # -- no Python around the launches and no RCCL inside a capture.  Behind the same watchdog as the hipGraph leg; rank 0 first
+    # prints what it has (the hipGraph result, if that leg completed), so a hang here costs nothing.
+    dist_plan = os.environ.get("DSS2_BENCH_DIST_PLAN", "1") != "0"
+    if not args.no_graph and (world == 1 or dist_plan):
+        if world > 1 and rank == 0:
+            early = dict(result)
+            early["partial"] = "printed before the launch-plan leg; a later line (if any) supersedes it"
+            print(json.dumps(early), flush=True)
+        ptimer = capture_watchdog(result, rank, world, args.graph_timeout, eager_line_printed=(world > 1)) if world > 1 else None
         try:
             planned = pkg.graphs.PlannedStep(step, stream=work_stream)
             for _ in range(max(args.warmup, 5)):
@@ -563,8 +571,12 @@ def main():
                 result.update(value=value, ms_per_step=ms)
                 result["config"].update(mode=mode, timed_windows=len(pw),
                                         window_ms_min_median_max=[min(pw) * 1e3, pdt * 1e3, max(pw) * 1e3])
+            if world > 1:
+                result["config"]["plan_segments"] = len(planned.segments)
         except Exception as exc:
             result["config"]["launch_plan"] = f"failed: {type(exc).__name__}: {exc}"[:300]
+        if ptimer is not None:
+            ptimer.cancel()
 
     if rank == 0:
         # ---- standalone scatter-add (K6) against the HBM roofline (north_star asks for it separately), at two sizes:

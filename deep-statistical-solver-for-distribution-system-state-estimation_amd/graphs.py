@@ -50,46 +50,109 @@ def plan_recording() -> bool:
     return _PLAN_RECORDING[0]
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _all_threads_to_pool(pool, device):
+    """Route EVERY thread's allocations on ``device`` to ``pool`` while a step is recorded.  torch.cuda.use_mem_pool routes the
+    calling thread only, and backward() allocates from the autograd engine's device thread: weight-gradient slabs and intermediate
+    gradients would then live in the general allocator, be handed to the next tensor anybody allocates after the recording, and
+    every replay would write into that tensor (found by cloning gradients between two replays: tests/test_gpu_rccl.py, round 5)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    torch._C._cuda_beginAllocateToPool(idx, pool.id)
+    try:
+        yield
+    finally:
+        torch._C._cuda_endAllocateToPool(idx, pool.id)
+        torch._C._cuda_releasePool(idx, pool.id)
+
+
+_PLAN_RECORDER = [None]      # the PlannedStep that is recording (its collectives cut the record into segments), or None
+
+
+def plan_collective(fn: Callable[[], object]):
+    """The product's collective call sites (parallel.py: loss sums, gradient buckets, their joins) run ``fn`` through here.  Outside
+    a recording it is just ``fn()``.  While a PlannedStep records, the collective ENDS the current plan segment, runs, and the next
+    segment begins behind it: a replay then issues segment, collective, segment, ... -- the collectives are not launches of this
+    library, so they are called again (same static tensors), from Python, between two ``dss2_plan_run`` calls."""
+    rec = _PLAN_RECORDER[0]
+    if rec is None:
+        return fn()
+    return rec._collective(fn)
+
+
 class PlannedStep:
     """``step_fn()`` recorded ONCE as the library's own launch list (include/dss2_hip.h, "launch plans") and re-issued from one C
     call: for steps that cannot be captured into a hipGraph (or as a check of one that can).  Same contract as GraphedStep: static
     inputs; the step's tensors -- activations, gradient buffers, the ``.grad`` tensors created during the recording -- live in a
     private memory pool for the plan's lifetime; only launches of this library are replayed (a step with a torch kernel in it is not
-    a candidate: compare ``replay()`` with an eager step once, as tests/test_gpu_plan.py does)."""
+    a candidate: compare ``replay()`` with an eager step once, as tests/test_gpu_plan.py does).  A data-parallel step's collectives
+    (``plan_collective``) cut the record into segments: one C call per segment, the collectives between them."""
 
     def __init__(self, step_fn: Callable[[], torch.Tensor], warmup: int = 2, stream=None):
         from . import _lib
         import ctypes as C
-        self._lib = _lib
+        self._lib, self._C = _lib, C
         self.stream = stream if stream is not None else torch.cuda.current_stream()
+        self.segments = []           # [(plan handle, collective or None)]: run the plan, then the collective
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 step_fn()
             torch.cuda.synchronize()
             self.pool = torch.cuda.MemPool()
-            handle = C.c_void_p()
             _PLAN_RECORDING[0] = True
+            _PLAN_RECORDER[0] = self
             try:
-                with torch.cuda.use_mem_pool(self.pool):
-                    _lib.check(_lib.lib().dss2_plan_begin(C.byref(handle)), "dss2_plan_begin")
+                with _all_threads_to_pool(self.pool, self.stream.device):
+                    self._cur = self._begin()
                     try:
                         self.loss = step_fn()
                     finally:
-                        _lib.check(_lib.lib().dss2_plan_end(handle), "dss2_plan_end")
+                        self._end(None)
             finally:
                 _PLAN_RECORDING[0] = False
+                _PLAN_RECORDER[0] = None
             torch.cuda.synchronize()
-        self.handle = handle
-        self.n_launches = int(_lib.lib().dss2_plan_size(handle))
+        self.handle = self.segments[0][0]      # (single-segment plans: the handle itself, as before)
+        self.n_launches = sum(int(_lib.lib().dss2_plan_size(h)) for h, _ in self.segments)
+        self.n_collectives = sum(1 for _, fn in self.segments if fn is not None)
+
+    def _begin(self):
+        h = self._C.c_void_p()
+        self._lib.check(self._lib.lib().dss2_plan_begin(self._C.byref(h)), "dss2_plan_begin")
+        return h
+
+    def _end(self, fn):
+        self._lib.check(self._lib.lib().dss2_plan_end(self._cur), "dss2_plan_end")
+        self.segments.append((self._cur, fn))
+        self._cur = None
+
+    def _collective(self, fn):
+        self._end(fn)
+        try:
+            return fn()
+        finally:
+            self._cur = self._begin()
 
     def replay(self) -> torch.Tensor:
-        self._lib.check(self._lib.lib().dss2_plan_run(self.handle, self.stream.cuda_stream), "dss2_plan_run")
+        lib, sp = self._lib.lib(), self.stream.cuda_stream
+        if len(self.segments) == 1:
+            self._lib.check(lib.dss2_plan_run(self.segments[0][0], sp), "dss2_plan_run")
+            return self.loss
+        with torch.cuda.stream(self.stream):
+            for h, fn in self.segments:
+                self._lib.check(lib.dss2_plan_run(h, sp), "dss2_plan_run")
+                if fn is not None:
+                    fn()
         return self.loss
 
     def __del__(self):
         try:
-            if getattr(self, "handle", None):
-                self._lib.lib().dss2_plan_destroy(self.handle)
-                self.handle = None
+            for h, _ in getattr(self, "segments", []):
+                if h:
+                    self._lib.lib().dss2_plan_destroy(h)
+            self.segments = []
+            self.handle = None
         except Exception:
             pass

@@ -24,6 +24,8 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
+from . import graphs as _graphs
+
 
 def init_from_env(backend: Optional[str] = None) -> Dict[str, int]:
     """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and initialise."""
@@ -87,8 +89,10 @@ def allreduce_loss_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
     joined by a STREAM dependency, so the host goes on enqueueing; no kernel of the step is independent of these sums (the loss
     value and every gradient need the global penalty means), so there is nothing to overlap it with on the device."""
     if dist.is_initialized():
-        work = dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        work.wait()          # current stream waits for the collective's stream; the host does not block (NCCL / RCCL)
+        def coll():
+            work = dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            work.wait()          # current stream waits for the collective's stream; the host does not block (NCCL / RCCL)
+        _graphs.plan_collective(coll)      # (under a recording launch plan: a segment boundary, graphs.PlannedStep)
     return sums
 
 
@@ -98,9 +102,9 @@ def allreduce_flat_grads(flat: torch.Tensor, group=None, pending: Optional[List]
     below) and its work handle is appended; ``wait_grad_allreduce`` joins all of them before the optimizer."""
     if dist.is_initialized():
         if pending is not None:
-            pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
+            _graphs.plan_collective(lambda: pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)))
         else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            _graphs.plan_collective(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group))
     return flat
 
 
@@ -241,11 +245,14 @@ def wait_grad_allreduce(model: torch.nn.Module) -> int:
     pending = getattr(model, "_dss2_pending_allreduce", None)
     if not pending:
         return 0
-    n = len(pending)
-    for w in pending:
-        w.wait()          # current stream waits for the collective; bounded by the process group's timeout
-    pending.clear()
-    return n
+
+    def join():
+        n_ = len(pending)
+        for w in pending:
+            w.wait()          # current stream waits for the collective; bounded by the process group's timeout
+        pending.clear()
+        return n_
+    return _graphs.plan_collective(join)      # (a recording launch plan joins again at this point of every replay)
 
 
 def broadcast_parameters(model: torch.nn.Module, src: int = 0, group=None) -> None:

@@ -12,6 +12,7 @@ At world size 1 a SUM all-reduce is the identity, so loss and every gradient mus
 non-distributed step.  Prints one JSON object on the last line of stdout.
 
     python _rccl_child.py eager     blocking and asynchronous collectives
+    python _rccl_child.py plan      the step as a segmented launch plan (graphs.PlannedStep: one C call per segment, collectives between)
     python _rccl_child.py graph     the step with its collectives inside a hipGraph capture (a separate process: a
                                     failing capture can take the process down, which must not take the eager result
                                     with it)
@@ -81,6 +82,31 @@ def main():
                 l0, g0 = snapshot(step(None))
             c["graph_capture"] = "ok"
             c["graph_bitwise"] = bool(torch.equal(l0, l3) and all(torch.equal(a, q) for a, q in zip(g0, g3)))
+            res["cases"][name] = c
+            continue
+        if mode == "plan":
+            # the data-parallel step as a SEGMENTED launch plan (graphs.PlannedStep): the collectives cut the record, a replay issues
+            # segment, collective, segment, ...; asynchronous bucket collectives joined by wait_grad_allreduce inside the step
+            l0, g0 = snapshot(step(None))
+            pkg.parallel.attach_grad_allreduce(model, group, async_op=(name == "MPN_C2_model" and os.environ.get("PLAN_ASYNC", "1") == "1"))
+
+            def dstep():
+                loss = step(group if os.environ.get("PLAN_GROUP", "1") == "1" else None)
+                pkg.parallel.wait_grad_allreduce(model)
+                return loss
+            plan = pkg.graphs.PlannedStep(dstep)
+            for p in model.parameters():
+                p.grad.fill_(float("nan"))
+            l4, g4 = snapshot(plan.replay())
+            l5, g5 = snapshot(plan.replay())
+            c["segments"], c["collectives"], c["launches"] = len(plan.segments), plan.n_collectives, plan.n_launches
+            c["loss_equal"] = bool(torch.equal(l0, l4))
+            c["grads_unequal"] = [i for i, (a, q) in enumerate(zip(g0, g4)) if not torch.equal(a, q)]
+            c["worst_rel"] = max([float((a - q).abs().max() / q.abs().max().clamp_min(1e-30)) for a, q in zip(g0, g4)] + [0.0])
+            c["nan_left"] = int(sum(int(torch.isnan(q).sum()) for q in g4))
+            c["plan_bitwise"] = bool(torch.equal(l0, l4) and all(torch.equal(a, q) for a, q in zip(g0, g4))
+                                     and torch.equal(l0, l5) and all(torch.equal(a, q) for a, q in zip(g0, g5)))
+            del plan
             res["cases"][name] = c
             continue
         l0, g0 = snapshot(step(None))                                     # non-distributed reference

@@ -5,7 +5,8 @@ every launch; the reference runs its loop from Python, /root/reference/dss2_run.
 * replaying the plan gives bit for bit the eager step: loss, outputs, every parameter gradient -- MPN on the chained kernels (the C2
   model), the C1 configuration on the whole-stack kernels, a SkipPFN with in-kernel dropout (device-side random state);
 * N planned training steps with the fused Adamax (capturable: device-side step count) = N eager steps, bit for bit in every parameter;
-* a plan that is still recording cannot be run; recording twice at once is refused.
+* a plan that is still recording cannot be run; recording twice at once is refused;
+* tensors allocated between two replays are not written by the second one (every thread's allocations of the recorded step stay in the plan's pool).
 """
 import ctypes as C
 import importlib
@@ -67,8 +68,15 @@ def test_plan_replay_is_bitwise_the_eager_step(pkg, cls, cargs, grids, B):
     assert torch.equal(loss_p, loss_e), (loss_p.item(), loss_e.item())
     for p, g in zip(params, grads_e):
         assert torch.equal(p.grad, g)
-    # ... again (the plan is reusable) and against a fresh eager step
+    # ... again (the plan is reusable), with tensors allocated in between: nothing the recorded step allocated -- its backward runs on the
+    # autograd engine's thread -- may have gone back to the general allocator, or this replay writes its slabs into the clones
+    clones = [p.grad.clone() for p in params] + [torch.full((1 << 20,), 7.0, device=DEV) for _ in range(24)]
     plan.replay()
+    torch.cuda.synchronize()
+    for c, g in zip(clones, grads_e):
+        assert torch.equal(c, g)
+    assert all(bool((c == 7.0).all()) for c in clones[len(params):])
+    # ... and against a fresh eager step
     loss_e2 = step().detach().clone()
     torch.cuda.synchronize()
     assert torch.equal(loss_e2, loss_e)

@@ -48,6 +48,22 @@ def test_rccl_world1_step_is_bitwise_the_non_distributed_step():
     print("RCCL world-1 eager:", json.dumps(res))
 
 
+def test_rccl_world1_step_as_a_segmented_launch_plan():
+    """The data-parallel step recorded as a launch plan (graphs.PlannedStep): its collectives -- loss sums, gradient bucket(s), the
+    join of asynchronous ones -- cut the record into segments; a replay issues one dss2_plan_run per segment with the collectives
+    between them (what bench.py times at world > 1 beside eager and hipGraph: no Python around the launches, no capture of RCCL).
+    Bitwise the non-distributed eager step at world size 1, twice."""
+    p = _child("plan")
+    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-4000:]
+    res = _result(p)
+    mpn, pfn = res["cases"]["MPN_C2_model"], res["cases"]["SkipPFN_5_blocks"]
+    assert mpn["plan_bitwise"] and pfn["plan_bitwise"], res
+    assert mpn["collectives"] == 3 and mpn["segments"] == 4, mpn          # loss sums, one asynchronous bucket, its join
+    assert pfn["collectives"] >= 2 and pfn["segments"] == pfn["collectives"] + 1, pfn
+    assert mpn["launches"] >= 10
+    print("RCCL world-1 segmented plan:", json.dumps(res))
+
+
 def test_rccl_collectives_inside_hipgraph_capture():
     """A step WITH its RCCL collectives (loss sums, gradient bucket) captured into a hipGraph and replayed: must be bitwise
     the eager step.  The capture needs capture_error_mode="thread_local" (graphs.GraphedStep): in the default global mode
