@@ -500,6 +500,7 @@ def main():
             r["peak_pipe"] = (f"fp16 MFMA dense peak (2500 TF) / 3 instructions per fp32 product group (f16x3)" if f16x3 else
                               "bf16 MFMA dense peak (2500 TF) / 6 instructions per fp32 product group (bf16x6)")
             r["mfma_instructions_per_fp32_product"] = int(nprod)
+            r["frac_vs_bf16x6_bound"] = r["achieved"] / (BF16_MFMA_PEAK_TF / 6.0)      # (round 4's yardstick, for comparison across rounds)
             r["frac_bf16_pipe"] = r["frac"]
             if held_clock_ghz:
                 # the matrix pipe's bound scales with the clock: 2.5 PF is the figure at 2.4 GHz.  Under this kernel the chip holds less
