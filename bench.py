@@ -394,6 +394,11 @@ def main():
         wg_events.clear()
         nw_mod.gemm_prop_chain, nw_mod.gemm_prop, nw_mod.wgrad_batched = timed_chain, timed_single, timed_wgrad_batched
         for _ in range(n_steps):
+            # the GPU waits ~0.8 ms (a spin kernel) while the host enqueues the whole instrumented step behind it: the step's launches then
+            # run back to back and the event pairs bracket KERNEL time.  Without it the eager step is host-bound by now (0.39 ms of GPU work
+            # under ~0.4 ms of Python), the GPU idles between an event record and the launch that follows it, and the "launch duration"
+            # read 101.7 us where rocprofv3's kernel average says 82-86.
+            torch.cuda._sleep(1_600_000)
             step()
         torch.cuda.synchronize()
         nw_mod.gemm_prop_chain, nw_mod.gemm_prop, nw_mod.wgrad_batched = orig_chain, orig_single, orig_wgb
