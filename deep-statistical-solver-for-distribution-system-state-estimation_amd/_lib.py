@@ -43,7 +43,7 @@ class ChainHead(C.Structure):
     _fields_ = [("W", C.c_void_p * 4), ("bias", C.c_void_p), ("add_src", C.c_void_p), ("Y", C.c_void_p),
                 ("G", C.c_void_p), ("gate", C.c_void_p), ("Xout", C.c_void_p),
                 ("ld_add", C.c_int64), ("ldy", C.c_int64), ("ldg", C.c_int64), ("ld_gate", C.c_int64), ("ldxo", C.c_int64),
-                ("nout", C.c_int32), ("mode", C.c_int32), ("drop_id", C.c_int32), ("pad", C.c_int32)]
+                ("nout", C.c_int32), ("mode", C.c_int32), ("drop_id", C.c_int32), ("pad", C.c_int32), ("wg_slab", C.c_void_p)]
 
 
 class WgradArgs(C.Structure):
@@ -203,6 +203,7 @@ _SIGNATURES = {
     "dss2_gemm_prop_chain": (C.c_int, [C.POINTER(GemmPropArgs), C.c_void_p, C.c_int, C.c_void_p]),
     "dss2_gemm_prop_chain_head": (C.c_int, [C.POINTER(GemmPropArgs), C.c_void_p, C.c_int, C.POINTER(ChainHead), C.c_void_p]),
     "dss2_gemm_prop_chain_head_supported": (C.c_int, [C.c_int] * 6),
+    "dss2_gemm_prop_chain_head_wgrad_supported": (C.c_int, [C.c_int] * 6),
     "dss2_gemm_prop_chain_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_gemm_prop_chain16_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_gemm_prop_chain_f16_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -1038,7 +1038,7 @@ static int dss2_reduce_slabs_launch(const float* slab, int n_slabs, int64_t stri
     // the same summation order as the batched form (dss2_reduce_slabs_multi): a reduction gives the same bits either way
     ReduceTable tab = {};
     tab.d[0].slab = slab; tab.d[0].out = out; tab.d[0].stride = stride; tab.d[0].len = len; tab.d[0].n_slabs = n_slabs;
-    hipLaunchKernelGGL(reduce_slabs_multi_v4_kernel, dim3((unsigned)((len + 63) / 64), 1), dim3(256), 0, as_stream(stream), tab);
+    hipLaunchKernelGGL(reduce_slabs_multi_v4_kernel, dim3((unsigned)reduce_blocks(tab.d[0], false), 1), dim3(256), 0, as_stream(stream), tab);      // (many short slabs: 16 floats per workgroup)
     return check_launch("reduce_slabs");
   }
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((len + 63) / 64)), dim3(64, 4), 0, as_stream(stream), slab,
@@ -1062,10 +1062,14 @@ static int dss2_reduce_slabs_multi_launch(const dss2_reduce_desc* descs_host, in
     if (tab.d[i].len > max_len) max_len = tab.d[i].len;
   }
   if (max_len == 0) return 0;
-  for (int i = 0; i < n_desc; ++i)      // 16-byte lanes per reduction that allows them
+  int64_t blocks = 0;
+  for (int i = 0; i < n_desc; ++i) {     // 16-byte lanes per reduction that allows them
     if ((tab.d[i].stride % 4 != 0) || (reinterpret_cast<uintptr_t>(tab.d[i].slab) & 15) || (reinterpret_cast<uintptr_t>(tab.d[i].out) & 15))
       tab.scalar_mask |= 1u << i;
-  hipLaunchKernelGGL(reduce_slabs_multi_v4_kernel, dim3((unsigned)((max_len + 63) / 64), (unsigned)n_desc), dim3(256), 0,
+    const int64_t b = reduce_blocks(tab.d[i], ((tab.scalar_mask >> i) & 1u) != 0);      // (many short slabs: 16 floats per workgroup)
+    if (b > blocks) blocks = b;
+  }
+  hipLaunchKernelGGL(reduce_slabs_multi_v4_kernel, dim3((unsigned)blocks, (unsigned)n_desc), dim3(256), 0,
                      as_stream(stream), tab);
   return check_launch("reduce_slabs_multi");
 }

@@ -88,6 +88,14 @@ extern "C" int dss2_gemm_prop_chain_head_supported(int nrb, int nmat, int kreal,
   return 0;
 }
 
+extern "C" int dss2_gemm_prop_chain_head_wgrad_supported(int nrb, int nmat, int kreal, int hout, int ell_width, int nout) {
+  using namespace dss2;
+  if (nrb != 2 || nout < 1 || nout > 2 || !(dss2_gemm_prop_chain_head_supported(nrb, nmat, kreal, hout, ell_width, nout) & 2)) return 0;
+  dss2_gemm_prop_args a = {};
+  a.b_format = 1; a.nrb = nrb; a.nmat = nmat; a.kreal = kreal; a.kpad = (kreal + 15) / 16 * 16; a.hout = hout; a.ncg = (hout + 31) / 32; a.ell_width = ell_width;
+  return chain_row_split(nrb, a.ncg) == 1 && chain_sp_supported(a) ? 1 : 0;      // the 64-row split-plane chain (dss2_gemm_chain_sp.hip)
+}
+
 static int dss2_gemm_prop_chain_head_launch(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, const dss2_chain_head* head, void* stream);
 extern "C" int dss2_gemm_prop_chain_head(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, const dss2_chain_head* head, void* stream) {
   if (!ap) { dss2::set_error("dss2_gemm_prop_chain_head: null argument"); return 2; }
@@ -111,6 +119,9 @@ static int dss2_gemm_prop_chain_head_launch(const dss2_gemm_prop_args* ap, const
     set_error("gemm_prop_chain_head: backward head needs G, a 16-byte aligned Xout (and gate)"); return 2;
   }
   if (head->drop_id && !ap->drop_state) { set_error("gemm_prop_chain_head: drop_id without drop_state"); return 2; }
+  if (head->wg_slab && (head->mode != 2 || !head->gate || !dss2_gemm_prop_chain_head_wgrad_supported(ap->nrb, ap->nmat, ap->kreal, ap->hout, ap->ell_width, head->nout))) {
+    set_error("gemm_prop_chain_head: wg_slab needs mode 2, gate and a shape dss2_gemm_prop_chain_head_wgrad_supported accepts"); return 2;
+  }
   return chain_impl(ap, layers, n_layers, head, stream);
 }
 

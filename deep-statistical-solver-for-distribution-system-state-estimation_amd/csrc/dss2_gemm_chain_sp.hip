@@ -177,6 +177,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
       for (int o = 0; o < SP_HEAD_MAX; ++o) if (o < nout) z[o] = hd.G[(size_t)(ts + lane) * hd.ldg + o];
     }
     *reinterpret_cast<f32x4*>(zt + lane * (NMAT * 4)) = z;
+    const float zg0 = z[0], zg1 = z[1];      // (the upstream gradient of this lane's row: the head's bias sums below)
     sp_barrier();                            // the ELL slice is staged
 #pragma unroll
     for (int m = 1; m < NMAT; ++m) {
@@ -192,6 +193,15 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
       *reinterpret_cast<f32x4*>(zt + lane * (NMAT * 4) + m * 4) = z;
     }
     wave_lds_sync();
+    // The head's WEIGHT gradient rides here too (round 5; hd.wg_slab, nout <= 2): dW_m[o][c] = sum_rows ((P^T)^m G)[row][o] h[row][c] needs
+    // exactly what this block holds -- the hop results zt and the head's input rows h (= the gate rows ga) -- so the launch that
+    // re-read the [N, hid] activation for it (wgrad_narrow_stream_kernel, 15 us at C2) is gone.  Per lane: its 8 rows x 4 columns x
+    // NMAT x nout partial sums, summed over the 8 lanes that share the columns through wave-private LDS in row order: one slab per
+    // tile, [NMAT nout][hid] + nout bias sums, reduced with the step's other slabs (fixed order: reproducible).
+    const bool wg = hd.wg_slab != nullptr && hd.gate != nullptr;
+    f32x4 hw[NMAT][2];
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m) { hw[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; hw[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     f32x4 xv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -202,6 +212,10 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
         const f32x4 zz = *reinterpret_cast<const f32x4*>(zt + row * (NMAT * 4) + m * 4);
 #pragma unroll
         for (int o = 0; o < SP_HEAD_MAX; ++o) v += wl[m][o] * zz[o];
+        if (wg && col_ok) {      // (rows beyond the tile: zz = 0; ga was read from a clamped row)
+          hw[m][0] += ga[i] * zz[0];
+          hw[m][1] += ga[i] * zz[1];
+        }
       }
       if (hd.gate) {
 #pragma unroll
@@ -212,6 +226,34 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
       else *reinterpret_cast<f32x4*>(hd.Xout + (size_t)(ts + row) * hd.ldxo + col0) = v;      // (the weight gradients read it)
       xv[i] = v;
     }
+    if (wg) {      // (uniform)
+      float* scr = slot0 + 2048;             // [64 lanes][NMAT 2][4]: behind zt / hs inside the wave's own region, before the planes go over it
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) {
+        *reinterpret_cast<f32x4*>(scr + (lane * (NMAT * 2) + 2 * m) * 4) = hw[m][0];
+        *reinterpret_cast<f32x4*>(scr + (lane * (NMAT * 2) + 2 * m + 1) * 4) = hw[m][1];
+      }
+      wave_lds_sync();
+      const int per = NMAT * 2 * 4;          // values per (row group, column group)
+      float* slab = hd.wg_slab + (size_t)tile * (hd.pad > 0 ? (size_t)hd.pad : (size_t)NMAT * nout * p.hout + nout);      // (pad: the slabs' stride in floats)
+      for (int idx = lane; idx < 8 * per; idx += 64) {
+        const int cqi = idx / per, rem = idx - cqi * per, mo = rem >> 2, q = rem & 3, m = mo >> 1, o = mo & 1;
+        float sum = 0.f;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) sum += scr[((g8 * 8 + cqi) * (NMAT * 2) + mo) * 4 + q];      // rows r8 = 0 .. 7 in order
+        const int col = cg * 32 + cqi * 4 + q;
+        if (o < nout && col < p.hout) slab[(size_t)(m * nout + o) * p.hout + col] = sum;
+      }
+      if (wave == 0) {                       // bias sums: the upstream gradient's column sums over the tile's rows, a butterfly over the
+        float sb0 = zg0, sb1 = zg1;          // 64 lanes (= rows): pairwise, fixed order
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { sb0 += __shfl_xor(sb0, d); sb1 += __shfl_xor(sb1, d); }
+        if (lane == 0) {
+          slab[(size_t)NMAT * nout * p.hout] = sb0;
+          if (nout > 1) slab[(size_t)NMAT * nout * p.hout + 1] = sb1;
+        }
+      }
+    }
     if constexpr (F16) {
       float mx = 0.f;
 #pragma unroll
@@ -221,7 +263,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
       sp_barrier();
       ea = tile_exponent();
     }
-    wave_lds_sync();                         // every lane is done with zt: the planes go over it
+    wave_lds_sync();                         // every lane is done with zt (and the scratch behind it): the planes go over it
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if constexpr (F16) sp_store_split_h(own_planes + (r8 + 8 * i) * SP_RS + cq, xv[i], ea);

@@ -144,7 +144,8 @@ static int dss2_finish_weights_launch(const dss2_reduce_desc* descs_host, int n_
     if (tab.d[i].len > max_len) max_len = tab.d[i].len;
     if ((tab.d[i].stride % 4 != 0) || (reinterpret_cast<uintptr_t>(tab.d[i].slab) & 15) || (reinterpret_cast<uintptr_t>(tab.d[i].out) & 15)) tab.scalar_mask |= 1u << i;
   }
-  const int red_x = (int)((max_len + 63) / 64);
+  int red_x = (int)((max_len + 63) / 64);
+  for (int i = 0; i < n_red; ++i) { const int64_t b = reduce_blocks(tab.d[i], ((tab.scalar_mask >> i) & 1u) != 0); if (b > red_x) red_x = (int)b; }
   if (red_x <= 0) { set_error("finish_weights: empty reductions"); return 2; }
   const long long total = (long long)n_red * red_x + (long long)n_rule * rule_tiles;
   hipLaunchKernelGGL(finish_weights_kernel, dim3((unsigned)total), dim3(256), 0, as_stream(stream), tab, n_red, n_dep, red_x, rule, rule_tiles, n_rule, base_out,

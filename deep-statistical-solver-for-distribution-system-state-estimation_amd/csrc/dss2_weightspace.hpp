@@ -264,8 +264,52 @@ struct ReduceTable { dss2_reduce_desc d[REDUCE_MAX_DESC]; uint32_t scalar_mask; 
 // Reductions whose slabs / outputs are not 16-byte aligned (bit in scalar_mask: e.g. what follows a 2-wide bias in a flat
 // gradient) run the scalar form inside the same launch -- one misaligned descriptor no longer sends all of them there.
 // one workgroup (256 threads) of reduction d: its 64 output floats bx * 64 .. bx * 64 + 63 (scalar: the form without 16-byte lanes)
+// MANY short slabs (the per-tile slabs of the narrow head's weight gradient: 1024 x 770 floats at C2): 16 slab lanes leave every lane
+// 64 slabs deep behind one another; the "tall" form gives a workgroup 16 output floats and 64 slab lanes instead (round 5).
+__host__ __device__ __forceinline__ bool reduce_tall(const dss2_reduce_desc& d) { return d.n_slabs >= 256 && d.len <= 8192; }
+__host__ __device__ __forceinline__ int64_t reduce_blocks(const dss2_reduce_desc& d, bool scalar) {
+  return (!scalar && reduce_tall(d)) ? (d.len + 15) / 16 : (d.len + 63) / 64;
+}
 template <bool COH = false>
 __device__ __forceinline__ void reduce_slabs_body(const dss2_reduce_desc& d, const bool scalar, const int bx, f32x4 (&part)[16][16]) {
+  if (!scalar && reduce_tall(d)) {                // (uniform per descriptor)
+    if ((int64_t)bx * 16 >= d.len) return;
+    const int tid = threadIdx.x, cl = tid & 3, sl = tid >> 2;      // 4 float4 columns x 64 slab lanes
+    const int64_t i4 = (int64_t)bx * 16 + cl * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    f32x4* pt = &part[0][0];
+    if (i4 + 4 <= d.len) {
+#pragma unroll 1
+      for (int k0 = sl; k0 < d.n_slabs; k0 += 256) {
+        f32x4 r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kk = k0 + 64 * j;
+          r[j] = *reinterpret_cast<const f32x4*>(d.slab + (size_t)(kk < d.n_slabs ? kk : k0) * d.stride + i4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k0 + 64 * j < d.n_slabs) s += r[j];
+      }
+    } else if (i4 < d.len) {
+      for (int k = sl; k < d.n_slabs; k += 64)
+        for (int q = 0; i4 + q < d.len; ++q) s[q] += d.slab[(size_t)k * d.stride + i4 + q];
+    }
+    pt[sl * 4 + cl] = s;
+    __syncthreads();
+    if (sl == 0 && i4 < d.len) {
+      f32x4 t4[4];      // four interleaved chains, then pairwise: fixed order
+#pragma unroll
+      for (int c = 0; c < 4; ++c) t4[c] = pt[c * 4 + cl];
+      for (int k = 4; k < 64; k += 4)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t4[c] += pt[(k + c) * 4 + cl];
+      const f32x4 t = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+      if (i4 + 4 <= d.len) ws_store4<COH>(d.out + i4, t);
+      else for (int q = 0; i4 + q < d.len; ++q) ws_store<COH>(d.out + i4 + q, t[q]);
+    }
+    return;
+  }
   if ((int64_t)bx * 64 >= d.len) return;          // uniform per workgroup
   const int tid = threadIdx.x, cl = tid & 15, sl = tid >> 4;
   if (scalar) {              // (uniform) 64 columns x 4 slab quarters, as reduce_slabs_multi_kernel

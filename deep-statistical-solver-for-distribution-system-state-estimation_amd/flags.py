@@ -15,6 +15,7 @@ CHAIN_F16 = _os.environ.get("DSS2_CHAIN_F16", "1") == "1"
 CHAIN_HEAD = _os.environ.get("DSS2_CHAIN_HEAD", "1") == "1"            # the narrow head TAGConv's data gradient inside the chained launch of the data gradients
 # ... and the head's forward inside the forward chain (round 2: break-even, off; with the 16x16x32 chain of round 4 the fused step is
 # 4 us shorter; round 5: on, and bench.py counts the head's FLOPs in the launch it rides in).  DSS2_CHAIN_HEAD_FWD=0: its own launch.
+CHAIN_HEAD_WGRAD = _os.environ.get("DSS2_CHAIN_HEAD_WGRAD", "1") == "1"   # ... and the head's weight gradient in the same staging (round 5; 0 = its own launch)
 CHAIN_HEAD_FWD = _os.environ.get("DSS2_CHAIN_HEAD_FWD", "1") == "1"
 WGRAD_BATCH = _os.environ.get("DSS2_WGRAD_BATCH", "1") == "1"
 STACK_NODE = _os.environ.get("DSS2_STACK_NODE", "1") == "1"              # PFN / SkipPFN as ONE autograd node (_PFNFn)

@@ -33,7 +33,7 @@ from .topology import Topology, get_topology
 _F32 = torch.float32
 
 from . import flags as FL
-from .ops import (new_xplanes, wgrad_batched_xp, xplanes_supported, _DROP_PARAMS, _dropout_params, _ncg, _ptr, _reduce, _require_gpu, _round16, _round8, _rows, _stream, _wgrad_per_cu, _wgrad_tiles, chain16_supported, chain_f16_supported, chain_gate_words, chain_head_supported, chain_supported, csr_axpy, dropout_mask, dropout_snapshot, gather_rows, gemm16_supported, gemm_prop, gemm_prop_chain, is_narrow, finish_weights, prep_weights, reduce_pending, segment_sum, wgrad, wgrad_batched)
+from .ops import (new_xplanes, wgrad_batched_xp, xplanes_supported, _DROP_PARAMS, _dropout_params, _ncg, _ptr, _reduce, _require_gpu, _round16, _round8, _rows, _stream, _wgrad_per_cu, _wgrad_tiles, chain16_supported, chain_f16_supported, chain_gate_words, chain_head_supported, chain_head_wgrad_supported, chain_supported, csr_axpy, dropout_mask, dropout_snapshot, gather_rows, gemm16_supported, gemm_prop, gemm_prop_chain, is_narrow, finish_weights, prep_weights, reduce_pending, segment_sum, wgrad, wgrad_batched)
 from .plans import (_DESC_DTYPE, _FoldPlan, _MatView, _PackPlan, _SG_DTYPE, _as_view, _pack_table, _sg, _sg_table, _small_gemm)
 
 
@@ -709,13 +709,23 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
                       and chain_head_supported(topo, nmat, hid, mod.dim_out, True)
                       and (topo.nrb <= 2 or all(act_bits.get(l_) is not None for l_ in range(1, L - 1))))
         head = None
+        head_wg = None
         if head_fused:
-            _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, mod.dim_out, flat[offs[2 + l]:offs[3 + l]],
-                              need_dh=False, pending=pending)
+            # ... and the head's weight gradient from the same staging (it holds the hop results and the head's input rows): one slab
+            # per tile, summed with the step's other slabs; elsewhere the narrow weight-gradient launch re-reads the activation
+            hw_fused = chain_head_wgrad_supported(topo, nmat, hid, mod.dim_out) and acts[l].numel() > 0
+            if hw_fused:
+                hw_len = nmat * mod.dim_out * hid + mod.dim_out
+                hw_stride = (hw_len + 3) & ~3      # (16-byte lanes in the reduction)
+                head_wg = (torch.empty(topo.ntiles * hw_stride, dtype=_F32, device=dev), hw_len, flat[offs[2 + l]:offs[3 + l]], hw_stride)
+            else:
+                _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, mod.dim_out, flat[offs[2 + l]:offs[3 + l]],
+                                  need_dh=False, pending=pending)
             g_in = torch.empty(topo.N, hid, dtype=_F32, device=dev)
             dr = drop_of(l - 1)
             head = dict(W=list(ps[4 + l * (nmat + 1) + 1:4 + (l + 1) * (nmat + 1)]), nout=mod.dim_out, G=g, gate=acts[l], Xout=g_in,
-                        drop_id=(dr[2] if dr is not None else 0))
+                        drop_id=(dr[2] if dr is not None else 0), wg_slab=(head_wg[0] if head_wg is not None else None),
+                        wg_stride=(head_wg[3] if head_wg is not None else 0))
             g = g_in
         else:
             g = _tagconv_backward(topo, g, acts[l], plan.bwd[1 + l], nmat, hid, mod.dim_out, flat[offs[2 + l]:offs[3 + l]],
@@ -733,6 +743,8 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
                 gl[l - 1] = out_l
         gemm_prop_chain(topo, (None if head_fused else g), hid, nmat, layers, transposed=True,
                         drop=((snap, p_drop) if snap is not None else None), b_format=(2 if (use16 and plan.f16) else int(use16)), head=head)
+        if head_wg is not None:
+            _reduce(head_wg[0], 0, topo.ntiles, head_wg[3], head_wg[2], head_wg[1], pending)
         d_in = layers[-1]["Y"]                  # gradient w.r.t. conv 0's input: dS (folded) or dx0
         # The folded conv 0 joins the batched launch of the plain layers (round 4; FL.WGRAD_JOIN_FOLDED=False: its own launch).
         # Round 3 kept it apart because three layers x 85 workgroups leave a 13-vs-12-tile tail at C2; measured now, the

@@ -155,6 +155,13 @@ def chain_head_supported(topo: Topology, nmat: int, hid: int, nout: int, transpo
         _lib.lib().dss2_gemm_prop_chain_head_supported(topo.nrb, nmat, hid, hid, ell, nout) & (2 if transposed else 1))
 
 
+def chain_head_wgrad_supported(topo: Topology, nmat: int, hid: int, nout: int) -> bool:
+    """True when the data-gradient chain with the fused head (mode 2) can also form the head's weight gradient in its staging
+    (dss2_chain_head.wg_slab, round 5): 64-row tiles, nout <= 2.  flags.CHAIN_HEAD_WGRAD = False: the narrow weight-gradient launch."""
+    return bool(FL.CHAIN_HEAD_WGRAD) and topo.ellT_tiles is not None and bool(
+        _lib.lib().dss2_gemm_prop_chain_head_wgrad_supported(topo.nrb, nmat, hid, hid, topo.ellT, nout))
+
+
 def gemm16_supported(topo: Topology, nmat: int, hid: int, transposed: bool) -> bool:
     """True when a single hid -> hid layer (dss2_gemm_prop) can take bf16x3 weights: the tall tiles (128 / 192 rows) that
     run matrix-sequentially with K-halved staging and therefore have no layer chain."""
@@ -228,6 +235,8 @@ def gemm_prop_chain(topo: Topology, X: Optional[torch.Tensor], hid: int, nmat: i
         if gate_ is not None:
             hd.gate, hd.ld_gate = gate_.data_ptr(), gate_.stride(0)
         hd.drop_id = int(head.get("drop_id", 0)) if drop is not None else 0
+        hd.wg_slab = _ptr(head.get("wg_slab"))      # (optional: the head's weight gradient, one slab per tile; chain_head_wgrad_supported)
+        hd.pad = int(head.get("wg_stride", 0))      # (stride of those slabs in floats)
     _lib.check(_lib.lib().dss2_gemm_prop_chain_head(C.byref(a), C.addressof(tab), len(layers), C.byref(hd), _stream(dev_t)),
                "dss2_gemm_prop_chain_head")
 

@@ -315,12 +315,19 @@ typedef struct dss2_chain_head {
   const float* G; const float* gate; float* Xout;         /* mode 2 */
   int64_t ld_add, ldy, ldg, ld_gate, ldxo;
   int32_t nout, mode, drop_id, pad;
+  float* wg_slab;   /* mode 2, optional (round 5): the head's WEIGHT gradient from the same staging -- one slab per tile,
+                     * [ntiles][nmat * nout * hid + nout] floats = [dW_0 .. dW_{nmat-1} ([nout][hid] each) | db], to be summed over the tiles
+                     * (dss2_reduce_slabs*); `pad` > 0: the stride between the tiles' slabs in floats (a multiple of 4 lets the reduction use
+                     * 16-byte lanes).  Needs gate (the head's input rows) and nout <= 2 on 64-row tiles
+                     * (dss2_gemm_prop_chain_head_wgrad_supported); NULL: not computed */
 } dss2_chain_head;
 int dss2_gemm_prop_chain_head(const dss2_gemm_prop_args* args_host, const dss2_chain_layer* layers_host, int n_layers,
                               const dss2_chain_head* head_host, void* stream);
 /* mask of the head modes dss2_gemm_prop_chain_head runs for this shape: bit 0 = mode 1 (forward), bit 1 = mode 2 (backward).
  * 3 on the split-plane chain of 64-row tiles (hid >= 96, bf16x6 weights), 2 on its 96- / 192-row form, 0 otherwise. */
 int dss2_gemm_prop_chain_head_supported(int nrb, int nmat, int kreal, int hout, int ell_width, int nout);
+/* != 0: a mode-2 launch of this shape also forms the head's weight gradient (dss2_chain_head.wg_slab) */
+int dss2_gemm_prop_chain_head_wgrad_supported(int nrb, int nmat, int kreal, int hout, int ell_width, int nout);
 int dss2_gemm_prop_chain_supported(int nrb, int nmat, int kreal, int hout, int ell_width);
 /* != 0: the chain can also run with args.b_format = 1 -- weights packed as bf16x3 fragments, the tile GEMM as six
  * v_mfma_f32_32x32x16_bf16 per fp32 product term set (h/m/l splits of both operands, fp32 accumulation): fp32-accurate

@@ -47,7 +47,14 @@ def test_fused_head_equals_separate_launches(pkg, cls, args, B):
         again = _run(pkg, model, b, fwd, bwd, 7)
         assert torch.equal(got[0], again[0]) and torch.equal(got[1], again[1])
         assert rel_err(got[0], ref[0]) < 2e-6 and rel_err(got[1], ref[1]) < 1e-5, (fwd, bwd)
+        head_bias = f"convs.{args[4] - 1}.bias"
         for g, r, (n, _) in zip(got[2], ref[2], model.named_parameters()):
+            if n == head_bias and bwd:
+                # the head's bias gradient is the column sum of the upstream gradient -- here linspace(-1, 1), which cancels to +-0.5 out of a
+                # sum of magnitudes of N / 2: two fp32 summation orders (the narrow weight-gradient launch / the fused per-tile sums of round 5)
+                # agree to eps x that sum of magnitudes, not to 1e-5 of the result
+                assert (g - r).abs().max().item() <= 1e-7 * b["x"].shape[0] / 2, (fwd, bwd, n)
+                continue
             assert rel_err(g, r) < 1e-5, (fwd, bwd, n)
 
 

@@ -182,3 +182,30 @@ def test_merged_weight_launches_save_two_launches_of_the_c2_step(pkg):
     finally:
         pkg.flags.WEIGHTS_MERGED = old
     assert counts[True] == counts[False] - 2, counts
+
+
+@pytest.mark.parametrize("n_slabs,length,stride", [(1024, 770, 772), (512, 2944, 2944), (300, 13, 16), (256, 8192, 8192), (255, 770, 772), (1024, 770, 770)])
+def test_slab_reduction_of_many_short_slabs(pkg, n_slabs, length, stride):
+    """The "tall" form of the fixed-order slab reduction (csrc/dss2_weightspace.hpp, round 5: n_slabs >= 256, len <= 8192 -- the per-tile
+    slabs of the narrow head's weight gradient): 16 output floats and 64 slab lanes per workgroup.  Both entry points (they size their
+    grids themselves), ragged lengths, a stride that is not a multiple of 4 (scalar form), one slab short of the threshold; against fp64."""
+    ops = pkg.ops
+    g = torch.Generator(device="cpu").manual_seed(n_slabs + length)
+    slab = torch.randn(n_slabs, stride, generator=g).to(DEV)
+    want = slab[:, :length].double().sum(0)
+    scale = slab[:, :length].abs().double().sum(0).max().item()
+    out1 = torch.full((length + 3,), float("nan"), device=DEV)
+    ops._reduce(slab, 0, n_slabs, stride, out1[:length], length, None)                  # dss2_reduce_slabs
+    out2 = torch.full((length + 3,), float("nan"), device=DEV)
+    other = torch.randn(85, 49664, generator=g).to(DEV)
+    o_other = torch.empty(49664, device=DEV)
+    pend = []
+    ops._reduce(other, 0, 85, 49664, o_other, 49664, pend)
+    ops._reduce(slab, 0, n_slabs, stride, out2[:length], length, pend)
+    ops.reduce_pending(pend)                                                             # dss2_reduce_slabs_multi, beside a long reduction
+    torch.cuda.synchronize()
+    for o in (out1, out2):
+        assert torch.isnan(o[length:]).all()                                             # nothing written past the end
+        assert (o[:length].double() - want).abs().max().item() <= 1e-6 * scale
+    assert torch.equal(out1[:length], out2[:length])                                     # the same bits through either entry point
+    assert (o_other.double() - other.double().sum(0)).abs().max().item() <= 1e-5 * other.abs().double().sum(0).max().item()
