@@ -91,7 +91,7 @@ class ReduceDesc(C.Structure):
 class ChainLayer(C.Structure):
     _fields_ = [("Bp", C.c_void_p), ("bias", C.c_void_p), ("relu_src", C.c_void_p), ("dmask", C.c_void_p),
                 ("add_src", C.c_void_p), ("prebias", C.c_void_p), ("Y", C.c_void_p), ("relu", C.c_int32), ("drop_id", C.c_int32),
-                ("gate_bits", C.c_void_p), ("y_bits", C.c_void_p), ("x_planes", C.c_void_p)]
+                ("gate_bits", C.c_void_p), ("y_bits", C.c_void_p)]
 
 
 class AdamaxDesc(C.Structure):
@@ -192,10 +192,9 @@ _SIGNATURES = {
     "dss2_edge_tile_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p]),
-    "dss2_edge_tile_fwd_xp": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                        C.c_void_p, C.c_int, C.c_void_p]),
-    "dss2_edge_tile_fwd_xp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "dss2_edge_tile_fwd_paired": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_void_p]),
     "dss2_edge_tile_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -207,17 +206,10 @@ _SIGNATURES = {
     "dss2_gemm_prop_chain_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_gemm_prop_chain16_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_gemm_prop_chain_f16_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "dss2_gemm_prop_chain_xplanes_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_gemm_prop_chain_gate_words": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_gemm_prop16_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p]),
     "dss2_wgrad_batched": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
-    "dss2_xplanes_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
-    "dss2_wgrad_xp_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "dss2_wgrad_xp_y_slices": (C.c_int, [C.c_int, C.c_int]),
-    "dss2_wgrad_xp_per_cu": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "dss2_wgrad_batched_xp": (C.c_int, [C.POINTER(WgradArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
-                                        C.c_void_p]),
     "dss2_reduce_slabs_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "dss2_reduce_slabs": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "dss2_wls_loss_partials": (C.c_int, [C.POINTER(WlsArgs), C.c_void_p]),
@@ -231,8 +223,6 @@ _SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dss2_eval_scratch_doubles": (C.c_int64, []),
     "dss2_small_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "dss2_prep_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "dss2_finish_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dss2_measure_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                      C.c_double, C.c_void_p, C.c_int64, C.c_void_p]),
     "dss2_measure_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_void_p, C.c_int64,

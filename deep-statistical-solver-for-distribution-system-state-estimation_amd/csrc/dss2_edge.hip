@@ -850,35 +850,27 @@ static int launch_edge_tile(const EdgeTileArgs& a, int grid, hipStream_t s) {
   return check_launch(BWD ? "edge_tile_bwd" : "edge_tile_fwd");
 }
 
-extern "C" int dss2_edge_tile_fwd_xp_supported(int nrb, int h, int ell_width) {
-  return nrb == 2 && h > 0 && (h & 31) == 0 && edge_mfma_ok(h, nrb, ell_width) && edge16_ok(h, nrb, ell_width, false, false) ? 1 : 0;
-}
-
 extern "C" int dss2_edge_tile_fwd(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1,
                                   const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width,
                                   int nrb, int ntiles, float* S, int h, int fn, int fe, void* stream) {
-  return dss2_edge_tile_fwd_xp(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, nullptr, 0, stream);
+  return dss2_edge_tile_fwd_paired(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, 0, stream);
 }
 
-static int dss2_edge_tile_fwd_xp_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, int bwd_with_u, void* stream);
-extern "C" int dss2_edge_tile_fwd_xp(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, int bwd_with_u, void* stream) {
-  DSS2_RECORD([x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, x_planes, bwd_with_u](void* s_) { return dss2_edge_tile_fwd_xp_launch(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, x_planes, bwd_with_u, s_); });
-  return dss2_edge_tile_fwd_xp_launch(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, x_planes, bwd_with_u, stream);
+static int dss2_edge_tile_fwd_paired_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, int bwd_with_u, void* stream);
+extern "C" int dss2_edge_tile_fwd_paired(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, int bwd_with_u, void* stream) {
+  DSS2_RECORD([x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, bwd_with_u](void* s_) { return dss2_edge_tile_fwd_paired_launch(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, bwd_with_u, s_); });
+  return dss2_edge_tile_fwd_paired_launch(x, ldx, ea, ldea, W1, b1, tile_start, ell_ent, ell_width, nrb, ntiles, S, h, fn, fe, bwd_with_u, stream);
 }
-static int dss2_edge_tile_fwd_xp_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, int bwd_with_u, void* stream) {
+static int dss2_edge_tile_fwd_paired_launch(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1, const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width, int nrb, int ntiles, float* S, int h, int fn, int fe, int bwd_with_u, void* stream) {
   if (fn != FN || fe != FE) { set_error("edge_tile_fwd: only dim_featn=8, dim_feate=6 are built (got %d, %d)", fn, fe); return 2; }
   if (h <= 0 || h > 256 || ell_width <= 0 || ell_width > 32) { set_error("edge_tile_fwd: bad h=%d or ell_width=%d", h, ell_width); return 2; }
-  if (x_planes && !dss2_edge_tile_fwd_xp_supported(nrb, h, ell_width)) {
-    set_error("edge_tile_fwd_xp: x_planes needs 64-row tiles, h %% 32 == 0 and the bf16x6 form (nrb=%d h=%d ell=%d)", nrb, h, ell_width); return 2;
-  }
   if (ntiles <= 0) return 0;
   EdgeTileArgs a{x, ldx, ea, ldea, W1, b1, nullptr, tile_start, reinterpret_cast<const int2*>(ell_ent), S, nullptr, nullptr, 0,
-                 h, ell_width, nrb * 32, 0, ntiles, x_planes};
+                 h, ell_width, nrb * 32, 0, ntiles};
   // The backward recomputes the ReLU gates, so forward and backward must run the same arithmetic.  dss2_edge_tile_bwd with U on 96-row
   // tiles runs the VALU tile kernel (neither matrix-pipe backward is built for it): a caller that announces such a backward gets the
   // VALU tile forward.
   const bool valu_pair = bwd_with_u && nrb == 3;
-  if (x_planes && valu_pair) { set_error("edge_tile_fwd_xp: x_planes with a backward that needs U on 96-row tiles is not built"); return 2; }
   if (edge_mfma_ok(h, nrb, ell_width) && !valu_pair) {
     // first Linear as bf16x6 on the bf16 matrix pipe (dss2_edge16.hip; DSS2_EDGE_BF16=0: the fp32 MFMA form below)
     if (edge16_ok(h, nrb, ell_width, false, false)) return launch_edge16(a, nrb, ntiles, false, as_stream(stream));
@@ -900,7 +892,7 @@ static int dss2_edge_tile_bwd_launch(const float* x, int64_t ldx, const float* e
   if (n_slabs <= 0) { set_error("edge_tile_bwd: n_slabs must be > 0"); return 2; }
   if (ntiles <= 0) return 0;
   EdgeTileArgs a{x, ldx, ea, ldea, W1, b1, dS, tile_start, reinterpret_cast<const int2*>(ell_ent), nullptr, slab, U, ldu,
-                 h, ell_width, nrb * 32, by_source, ntiles, nullptr};
+                 h, ell_width, nrb * 32, by_source, ntiles};
   // n_slabs workgroups walk the tiles (the slab buffer holds one partial per workgroup)
   // (96-row tiles WITH the per-row sums U, the PFN inner-block case: that instantiation misses its register budget, so it is
   //  not compiled -- the VALU tile kernel below serves it)

@@ -155,9 +155,7 @@ __device__ __forceinline__ f32x16 e16_z(const E16Lds& L, const E16W& w, int k, i
 // (four waves per SIMD: the kernel waits on its staging chain tile_start -> ELL entry -> edge_attr row, and a fourth resident
 //  workgroup covers more of it than the 3-8 spilled registers cost: 18.5 -> 15.6 us at C2; the backward, whose vector and matrix
 //  work are balanced, lost 3 us when squeezed from two to three waves)
-// XP: S additionally as an X plane image (EdgeTileArgs::xplanes; 64-row tiles) -- its own instantiation, so that the 128-register fit
-// of the plain forward is not touched by the 24 split / store groups of the image
-template <int NRB, bool XP = false>
+template <int NRB>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) edge16_fwd_kernel(const EdgeTileArgs p) {
   extern __shared__ __attribute__((aligned(16))) float esm[];
   const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
@@ -189,24 +187,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))
       for (int r = 0; r < 16; ++r) {
         const int row = rb * 32 + acc_row(r, half);
         if (row < R) p.S[(int64_t)(ts + row) * p.h + j] = Sacc[r];
-      }
-      if constexpr (NRB == 2 && XP) {
-        {      // S as an X plane image for the weight gradient of the layer that consumes it (dss2_wgrad16p.hip)
-          // register r of this lane = tile row r8 + 8 i with r8 = (r & 3) + 4 half, i = (r >> 2) + 4 rb: for each r & 3 the lane holds
-          // half (4 consecutive i) of a 16-byte piece of column j; lane slot of column c32: n = (c32 & 3) * 8 + (c32 >> 2)
-          char* xb = reinterpret_cast<char*>(p.xplanes) + ((size_t)tile * (p.h >> 5) + cg) * 12288 + (2 * half) * 3072 +
-                     (((c32 & 3) << 3) | (c32 >> 2)) * 16 + 8 * rb;
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            uint32_t h0, m0, l0, h1, m1, l1;
-            split3_pair(Sacc[a], Sacc[a + 4], h0, m0, l0);
-            split3_pair(Sacc[a + 8], Sacc[a + 12], h1, m1, l1);
-            char* dst = xb + (a >> 1) * 3072 + (a & 1) * 512;      // k-step (r8 >> 1), k half (r8 & 1)
-            *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(dst + 1024) = make_uint2(m0, m1);
-            *reinterpret_cast<uint2*>(dst + 2048) = make_uint2(l0, l1);
-          }
-        }
       }
     }
     __syncthreads();      // (a workgroup that walks several tiles restages over the images)
@@ -456,15 +436,6 @@ static int launch16(const EdgeTileArgs& a, int grid, bool bwd, hipStream_t s) {
     auto kern = edge16_bwd_kernel<NRB, false>;
     if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "edge16_bwd")) return 1;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, s, a);
-  } else if (a.xplanes) {
-    if constexpr (NRB == 2) {
-      static std::atomic<uint32_t> lds_done{0};
-      auto kern = edge16_fwd_kernel<2, true>;
-      if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "edge16_fwd(+image)")) return 1;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, s, a);
-    } else {
-      set_error("edge16_fwd: the X plane image needs 64-row tiles"); return 2;
-    }
   } else {
     static std::atomic<uint32_t> lds_done{0};
     auto kern = edge16_fwd_kernel<NRB>;

@@ -12,7 +12,6 @@ struct EdgeTileArgs {
   const int32_t* tile_start; const int2* ell_ent;   // [ntiles][D][TM] {local other node, eid | flip<<31 ; -1 = empty}
   float* S; float* slab; float* U; int64_t ldu;
   int h, D, TM, by_source, ntiles;
-  void* xplanes;      // forward, edge16 on 64-row tiles: S additionally as an X plane image (dss2_wgrad16p.hip), or NULL
 };
 
 constexpr int EM_LDA = 36;   // A_k row stride: 24 inputs + 8 zero columns (B operand of the dW MFMA) + 4 pad

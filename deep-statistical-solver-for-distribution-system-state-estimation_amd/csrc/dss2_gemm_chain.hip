@@ -60,14 +60,6 @@ extern "C" int dss2_gemm_prop_chain_f16_supported(int nrb, int nmat, int kreal, 
   return chain_row_split(nrb, a.ncg) == 1 && chain_sp_supported(a) ? 1 : 0;
 }
 
-extern "C" int dss2_gemm_prop_chain_xplanes_supported(int nrb, int nmat, int kreal, int hout, int ell_width) {
-  using namespace dss2;
-  if (nrb != 2 || (hout & 31) != 0 || !dss2_gemm_prop_chain16_supported(nrb, nmat, kreal, hout, ell_width)) return 0;
-  dss2_gemm_prop_args a = {};
-  a.b_format = 1; a.nrb = nrb; a.nmat = nmat; a.kreal = kreal; a.kpad = (kreal + 15) / 16 * 16; a.hout = hout; a.ncg = (hout + 31) / 32; a.ell_width = ell_width;
-  return chain_row_split(nrb, a.ncg) == 1 && chain_sp_supported(a) ? 1 : 0;
-}
-
 static int dss2_gemm_prop_chain_launch(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, void* stream);
 extern "C" int dss2_gemm_prop_chain(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, void* stream) {
   if (!ap) { dss2::set_error("dss2_gemm_prop_chain: null argument"); return 2; }
@@ -144,13 +136,9 @@ static int chain_impl(const dss2_gemm_prop_args* ap, const dss2_chain_layer* lay
   ChainTable ct = {};
   ct.n = n_layers;
   bool any_pre = false;
-  const bool xp_ok = a.b_format == 1 && dss2_gemm_prop_chain_xplanes_supported(a.nrb, a.nmat, a.kreal, a.hout, a.ell_width);
   for (int i = 0; i < n_layers; ++i) {
     const dss2_chain_layer& L = layers[i];
-    if (L.x_planes && (!xp_ok || !al16(L.x_planes))) {
-      set_error("gemm_prop_chain: layer %d asks for x_planes, which only the split-plane chain of 64-row tiles with hout %% 32 == 0 writes", i); return 2;
-    }
-    if (!L.Bp || (!L.Y && !L.x_planes) || !al16(L.Y) || !al16(L.bias) || !al16(L.relu_src) || !al16(L.dmask) || !al16(L.add_src) || !al16(L.prebias)) {
+    if (!L.Bp || !L.Y || !al16(L.Y) || !al16(L.bias) || !al16(L.relu_src) || !al16(L.dmask) || !al16(L.add_src) || !al16(L.prebias)) {
       set_error("gemm_prop_chain: layer %d has a missing or misaligned operand", i); return 2;
     }
     any_pre = any_pre || L.prebias;

@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
 #pragma unroll
         for (int i = 0; i < 8; ++i) U[i] += *reinterpret_cast<const f32x4*>(L.add_src + grow_of(i) * p.ld_add + col0);
       }
-      if (L.Y) {      // (uniform; NULL only beside x_planes: nobody reads the fp32 copy)
+      {
         char* yp = reinterpret_cast<char*>(L.Y + (size_t)(ts + rowv) * p.ldy + col0);      // one 64-bit product per layer, then a uniform stride
         const size_t ystep = (size_t)p.ldy * 32;                                           // 8 rows
 #pragma unroll
@@ -650,40 +650,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
       }
       reinterpret_cast<uint32_t*>(L.y_bits)[((size_t)tile * ncg + cg) * 64 + lane] = word;
     }
-    if (!F16 && L.x_planes) {      // (uniform; not in the f16x3 form)
-      // The layer's output as an X plane image for its consumer's weight gradient (dss2_wgrad16p.hip): this lane owns rows r8 + 8 i,
-      // i = 0..7, of four columns -- per column and piece exactly one 16-byte entry of the image (k-step r8 >> 1, k half r8 & 1, lane
-      // slot q * 8 + (lane & 7) of column cq + q).  The split is made ONCE, in ROW pairs (the image's order); the next layer's LDS
-      // planes want the same pieces in COLUMN pairs: one v_perm_b32 per dword instead of a second split.  Every element's pieces are
-      // those of sp_store_split (split3_pair splits its two values independently): the LDS planes are bit for bit the same.
-      // Rows beyond the tile's R rows are stored too (finite, see below; they only ever meet zero rows of P^m G).
-      uint32_t hp[4][4], mp[4][4], lp[4][4];      // [row pair (U[2 j], U[2 j + 1])][column q]
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) split3_pair(U[2 * j][q], U[2 * j + 1][q], hp[j][q], mp[j][q], lp[j][q]);
-      int ln = lane;
-      asm volatile("" : "+v"(ln));      // (opaque: the address is formed here, once per layer)
-      char* xb = reinterpret_cast<char*>(L.x_planes) + ((size_t)tile * ncg + cg) * 12288 + (size_t)((ln >> 4) * 3072 + ((ln >> 3) & 1) * 512 + (ln & 7) * 16);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<uint4*>(xb + q * 128) = make_uint4(hp[0][q], hp[1][q], hp[2][q], hp[3][q]);
-        *reinterpret_cast<uint4*>(xb + q * 128 + 1024) = make_uint4(mp[0][q], mp[1][q], mp[2][q], mp[3][q]);
-        *reinterpret_cast<uint4*>(xb + q * 128 + 2048) = make_uint4(lp[0][q], lp[1][q], lp[2][q], lp[3][q]);
-      }
-      if (keep) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const uint32_t sel = e ? 0x07060302u : 0x05040100u;      // the high / low halves of (column q + 1, column q)
-            __bf16* dst = own_planes + (rowv + 8 * (2 * j + e)) * SP_RS + cq;
-            *reinterpret_cast<u32x2*>(dst) = u32x2{__builtin_amdgcn_perm(hp[j][1], hp[j][0], sel), __builtin_amdgcn_perm(hp[j][3], hp[j][2], sel)};
-            *reinterpret_cast<u32x2*>(dst + SP_PLANE) = u32x2{__builtin_amdgcn_perm(mp[j][1], mp[j][0], sel), __builtin_amdgcn_perm(mp[j][3], mp[j][2], sel)};
-            *reinterpret_cast<u32x2*>(dst + 2 * SP_PLANE) = u32x2{__builtin_amdgcn_perm(lp[j][1], lp[j][0], sel), __builtin_amdgcn_perm(lp[j][3], lp[j][2], sel)};
-          }
-      }
-    } else if (keep) {
+    if (keep) {
       // (rows beyond the tile's R rows are NOT zeroed -- 32 selects per layer: their values are finite (bias-driven like any
       //  activation), no real row ever gathers from them (ELL neighbours are real rows; a padding row's own entries carry weight 0),
       //  nothing of them is stored, the fused head below masks its own copy.  Columns beyond hout are zero by construction:
@@ -832,9 +799,7 @@ static int launch_sp_hm(const dss2_gemm_prop_args& a, const ChainTable& ct, cons
   bool fp32_gates = false;
   for (int i = 0; i < ct.n; ++i) fp32_gates = fp32_gates || (ct.l[i].relu_src && !ct.l[i].gate_bits);
   if (a.b_format == 2) {      // weights as two fp16 planes: the f16x3 form
-    bool xp = false;
-    for (int i = 0; i < ct.n; ++i) xp = xp || ct.l[i].x_planes;
-    if (fp32_gates || xp) { set_error("gemm_prop_chain(f16x3): layers gated by fp32 activations / X plane images need bf16x3 weights (b_format 1)"); return 2; }
+    if (fp32_gates) { set_error("gemm_prop_chain(f16x3): layers gated by fp32 activations need bf16x3 weights (b_format 1)"); return 2; }
     if (a.nmat == 2) return a.ncg <= 4 ? launch_sp<2, 4, HM, 2>(a, ct, hd, s) : launch_sp<2, 8, HM, 2>(a, ct, hd, s);
     return a.ncg <= 4 ? launch_sp<3, 4, HM, 2>(a, ct, hd, s) : launch_sp<3, 8, HM, 2>(a, ct, hd, s);
   }

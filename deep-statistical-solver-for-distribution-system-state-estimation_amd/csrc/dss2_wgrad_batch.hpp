@@ -13,21 +13,6 @@ struct WgradBatch {
   int n; long long slab_stride;
 };
 
-// dss2_wgrad16p.hip: the layers' inputs as transposed bf16x3 plane images (dss2_xplanes_bytes), one (layer, tile) list cut into
-// equal ranges of ipw items per workgroup; slab id = workgroup + layer
-struct WgradPlanes {
-  const float* G[WGRAD_MAX_BATCH]; const void* XP[WGRAD_MAX_BATCH]; const float* rowscale2[WGRAD_MAX_BATCH];
-  float* slab; long long slab_len;
-  int n_layers, ipw, ncb;      // ncb: 32-column blocks of the image (hin / 32)
-  int pair;                    // which range of the list the other output halves walk (dss2_wgrad16p.hip)
-};
-size_t wgrad16p_lds_bytes(int nmat, int ell_width);
-bool wgrad16p_covers(int nrb, int nmat, int hout, int hin, int ell_width);
-int launch_wgrad16p(const dss2_wgrad_args& a, const WgradPlanes& wp, int n_wg, hipStream_t stream);
-// dss2_wgrad16q.hip: the software-pipelined form (one 8-wave workgroup per CU)
-bool wgrad16q_covers(int nrb, int nmat, int hout, int hin, int ell_width);
-int launch_wgrad16q(const dss2_wgrad_args& a, const WgradPlanes& wp, int n_wg, hipStream_t stream);
-
 // dss2_wgrad16.hip: the bf16x6 kernel.  wgrad16_lds_bytes: dynamic LDS of its launch (0: shape not covered)
 size_t wgrad16_lds_bytes(int nrb, int nmat, int hout, int hin, int ell_width);
 bool wgrad16_covers(const dss2_wgrad_args& a);

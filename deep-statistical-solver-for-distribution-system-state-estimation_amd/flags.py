@@ -22,20 +22,10 @@ STACK_NODE = _os.environ.get("DSS2_STACK_NODE", "1") == "1"              # PFN /
 DX_MERGE = _os.environ.get("DSS2_DX_MERGE", "1") == "1"                  # dx of the edge MLP as ONE K = 2 hid GEMM
 WGRAD_JOIN_FOLDED = None    # None / True: the folded conv 0 rides in the batched weight-gradient launch of the plain layers; False: its own launch
 FOLD_W2 = _os.environ.get("DSS2_FOLD_W2", "1") == "1"   # 0 = run the edge MLP's second Linear as its own GEMMs
-# 1 = fold + packing as ONE launch at the start of a step, slab reductions + chain rule of the fold as ONE at its end (csrc/dss2_weights.hip,
-# round 5; bitwise the same results).  Off: the in-launch hand-off costs more than the kernel boundary it replaces -- step start 15.4 us
-# merged against 4.6 + 5.6 (10.8 back to back), step end 20.8 against 13.8 + 8.0 (22.9 back to back) at C2, C2 step unchanged within
-# +-2 us (profiles/experiments/r05_weights_merged.txt)
-WEIGHTS_MERGED = _os.environ.get("DSS2_WEIGHTS_MERGED", "0") == "1"
 # ... and on 32-row tiles as f16x3: two fp16 pieces per operand after a power-of-two scale, three MFMAs per product instead of six
 # (csrc/dss2_wgrad16h.hip, round 5; errors of the size of fp32 arithmetic itself).  0 = bf16x6 there too.
 WGRAD_F16 = _os.environ.get("DSS2_WGRAD_F16", "1") == "1"
 WGRAD_TM32 = _os.environ.get("DSS2_WGRAD_TM32", "1") == "1"      # bf16x6 weight gradient on 32-row tiles, two workgroups per CU (wgrad16b_kernel)
 WGRAD_TM32_MAX_BYTES = 64 << 20      # ... while one layer's input (N * hin * 4 bytes) stays well inside the Infinity Cache
-# The H -> H layers' inputs as X plane images written by their producers (edge MLP, forward chain) and the weight-gradient kernel that
-# reads them (csrc/dss2_wgrad16p.hip, round 5); 0 = wgrad16b / wgrad16 split X themselves.  XP_DROP_FP32: the forward chain then does not
-# write the fp32 copies of h_1 .. h_{L-2} at all (nobody reads them: the backward chain gates with bit words, the weight gradient reads planes)
-WGRAD_XP = _os.environ.get("DSS2_WGRAD_XP", "0") == "1"
-XP_DROP_FP32 = _os.environ.get("DSS2_XP_DROP_FP32", "1") == "1"
 WGRAD_PER_CU = int(_os.environ.get("DSS2_WGRAD_PER_CU", "2"))   # cap on persistent wgrad workgroups per CU (= slabs / 256)
 CHAIN_MAX = 8      # layers per dss2_gemm_prop_chain launch (csrc/dss2_gemm_chain.hip)

@@ -33,23 +33,22 @@ from .topology import Topology, get_topology
 _F32 = torch.float32
 
 from . import flags as FL
-from .ops import (new_xplanes, wgrad_batched_xp, xplanes_supported, _DROP_PARAMS, _dropout_params, _ncg, _ptr, _reduce, _require_gpu, _round16, _round8, _rows, _stream, _wgrad_per_cu, _wgrad_tiles, chain16_supported, chain_f16_supported, chain_gate_words, chain_head_supported, chain_head_wgrad_supported, chain_supported, csr_axpy, dropout_mask, dropout_snapshot, gather_rows, gemm16_supported, gemm_prop, gemm_prop_chain, is_narrow, finish_weights, prep_weights, reduce_pending, segment_sum, wgrad, wgrad_batched)
+from .ops import (_DROP_PARAMS, _dropout_params, _ncg, _ptr, _reduce, _require_gpu, _round16, _round8, _rows, _stream, _wgrad_per_cu, _wgrad_tiles, chain16_supported, chain_f16_supported, chain_gate_words, chain_head_supported, chain_head_wgrad_supported, chain_supported, csr_axpy, dropout_mask, dropout_snapshot, gather_rows, gemm16_supported, gemm_prop, gemm_prop_chain, is_narrow, finish_weights, prep_weights, reduce_pending, segment_sum, wgrad, wgrad_batched)
 from .plans import (_DESC_DTYPE, _FoldPlan, _MatView, _PackPlan, _SG_DTYPE, _as_view, _pack_table, _sg, _sg_table, _small_gemm)
 
 
 # ------------------------------------------------------------------------------------------
 # functional pieces (raw tensors in, raw tensors out); used by the autograd Functions below
 # ------------------------------------------------------------------------------------------
-def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hout, fn, fe, second_linear=True, xp=None, need_dx=False):
-    """xp: an X plane image (ops.new_xplanes) that receives S as well (its consumer's weight gradient reads it).  need_dx: the backward
-    will be asked for the gradient w.r.t. x (the library then picks the forward whose gates that backward recomputes exactly)."""
+def _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, pack_w2_fwd, hid, hout, fn, fe, second_linear=True, need_dx=False):
+    """need_dx: the backward will be asked for the gradient w.r.t. x (the library then picks the forward whose gates that backward recomputes exactly)."""
     N = topo.N
     S = torch.empty(N, hid, dtype=_F32, device=W1.device)
     if topo.ell_ent_tiles is not None and FL.EDGE_TILE_KERNELS:
-        _lib.check(_lib.lib().dss2_edge_tile_fwd_xp(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(),
-                                                    topo.tile_start.data_ptr(), topo.ell_ent_tiles.data_ptr(), topo.ell,
-                                                    topo.nrb, topo.ntiles, S.data_ptr(), hid, fn, fe, _ptr(xp), int(bool(need_dx)), _stream(S)),
-                   "dss2_edge_tile_fwd_xp")
+        _lib.check(_lib.lib().dss2_edge_tile_fwd_paired(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(),
+                                                        topo.tile_start.data_ptr(), topo.ell_ent_tiles.data_ptr(), topo.ell,
+                                                        topo.nrb, topo.ntiles, S.data_ptr(), hid, fn, fe, int(bool(need_dx)), _stream(S)),
+                   "dss2_edge_tile_fwd_paired")
     else:   # general graphs (hub nodes beyond the ELL width): row-per-wave kernel on the CSR
         _lib.check(_lib.lib().dss2_edge_hidden_fwd(x.data_ptr(), ldx, ea.data_ptr(), ldea, W1.data_ptr(), b1.data_ptr(),
                                                    topo.rowptr.data_ptr(), topo.col.data_ptr(), topo.ent.data_ptr(),
@@ -514,7 +513,6 @@ class MPN(nn.Module):
         dims = _stack.route(self, [self], topo)
         if dims is not None:          # dim_hid 32, K 2: the whole-stack kernels (one launch forward, one backward)
             return _stack.run(self, [self], dims, topo, x, edge_attr)
-        self.__dict__["_grad_mode"] = torch.is_grad_enabled()      # (inside autograd.Function.forward it reads False: what only a backward needs is decided here)
         return _MPNFn.apply(x, edge_attr, topo, self, *self._params())
 
     def _forward_general(self, x, edge_attr, topo):
@@ -551,8 +549,8 @@ def _ensure_plans(mod, topo, dev, ps):
     b16 = tuple(range(1, L)) if (FL.CHAIN_BF16 and not glob and hid % 4 == 0 and hid <= 256 and not is_narrow(nmat, hid) and L >= 2
                                  and (L >= 3 or gemm16_supported(topo, nmat, hid, False))) else ()
     # ... as f16x3 where both chains of the block have the form (64-row tiles; csrc/dss2_gemm_chain_sp.hip MS = 2) and the backward takes
-    # the chained route; X plane images (the optional DSS2_WGRAD_XP route) want bf16x3 pieces
-    f16 = bool(b16 and L >= 3 and FL.WGRAD_BATCH and not FL.WGRAD_XP and chain_f16_supported(topo, nmat, hid))
+    # the chained route
+    f16 = bool(b16 and L >= 3 and FL.WGRAD_BATCH and chain_f16_supported(topo, nmat, hid))
     if (mod._plan is None or mod._plan.device != dev or (mod._fold is not None) != fold_on or mod._plan.stacked != glob
             or tuple(sorted(mod._plan.fwd16)) != b16 or mod._plan.f16 != f16):
         offs = mod._flat_offsets()
@@ -587,16 +585,9 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None, need_dx=False):
     # the hid -> hid layers 0 .. L-2 as ONE chained launch (activation tile stays in LDS between layers)
     n_chain = L - 1 if (L - 1 >= 2 and chain_supported(topo, nmat, hid, False, bool(plan.fwd16))) else 0
     use16 = bool(n_chain) and bool(plan.fwd16) and chain16_supported(topo, nmat, hid, False)
-    # X plane images (round 5): the inputs of the chained layers -- S and the chain's outputs but the last -- are ALSO written, by their
-    # producers, as the bf16x3 pieces the batched weight gradient's MFMA operand wants (csrc/dss2_wgrad16p.hip).  Only where the
-    # backward will take exactly that launch: folded conv 0 + chained data gradients + batched weight gradients, grad mode on.
     gw = chain_gate_words(topo, nmat, hid) if use16 else 0      # (inside autograd.Function.forward grad mode is off: always written; 1/32 of a layer output)
-    use_xp = bool(use16 and not plan.f16 and gw and fold is not None and n_chain == L - 1 and 3 <= L <= 9 and not glob and xplanes_supported(topo, nmat, hid)
-                  and FL.WGRAD_JOIN_FOLDED is not False and mod.__dict__.get("_grad_mode", True)
-                  and chain_supported(topo, nmat, hid, True, True) and chain16_supported(topo, nmat, hid, True))
-    xps = [new_xplanes(topo, hid, dev) for _ in range(n_chain)] if use_xp else []
     S, h = _edge_aggr_forward(topo, x, ldx, ea, ldea, W1, b1, b2, plan.fwd[0], hid, hid, mod.dim_featn, mod.dim_feate,
-                              second_linear=fold is None, xp=(xps[0] if use_xp else None), need_dx=need_dx)
+                              second_linear=fold is None, need_dx=need_dx)
     if fold is not None:
         h = S            # conv 0 consumes the aggregated hidden directly
     acts = [h]
@@ -620,16 +611,12 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None, need_dx=False):
         # the chain also writes the sign bits of its outputs; the data-gradient chain reads those instead of the
         # activations for its ReLU gates (dss2_chain_layer.y_bits / gate_bits)
         for l in range(n_chain):
-            # with X planes the fp32 copy of an inner chain output has no reader (the data-gradient chain gates with the bit words, the
-            # weight gradient reads the planes): it is not written at all; acts keeps a placeholder
-            planes_l = xps[l + 1] if (use_xp and l + 1 < n_chain) else None
-            no_fp32 = planes_l is not None and FL.XP_DROP_FP32
-            out_l = None if no_fp32 else torch.empty(topo.N, hid, dtype=_F32, device=dev)
+            out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
             layers.append(dict(Bp=(plan.fwd16[1 + l] if use16 else plan.fwd[1 + l]), Y=out_l, bias=conv_ps[l][0], relu=True,
-                               drop_id=drop_id(l), prebias=(fold.bf if (fold is not None and l == 0) else None), x_planes=planes_l))
+                               drop_id=drop_id(l), prebias=(fold.bf if (fold is not None and l == 0) else None)))
             if gw:
                 act_bits[len(acts)] = layers[-1]["y_bits"] = torch.empty(topo.ntiles * gw, dtype=torch.int64, device=dev)
-            acts.append(out_l if out_l is not None else S.new_empty(0))
+            acts.append(out_l)
         # the narrow last layer inside the same launch (the tile is still in the waves' registers): dss2_gemm_prop_chain_head
         head_fused = (FL.CHAIN_HEAD_FWD and use16 and n_chain == L - 1 and n_chain <= FL.CHAIN_MAX and not glob and is_narrow(nmat, mod.dim_out)
                       and chain_head_supported(topo, nmat, hid, mod.dim_out, False))
@@ -661,8 +648,8 @@ def _mpn_forward(mod, topo, x, ea, ps, stack=None, need_dx=False):
                              drop=((snap, p, drop_id(l)) if snap is not None else None), b_format=int(g16))
         if not last:
             acts.append(h)
-    meta = (ldx, ldea, len(acts), (snap, p, base), fold is not None, glob, ver, act_bits, len(xps))
-    return h, [x, ea, S] + acts + xps, meta
+    meta = (ldx, ldea, len(acts), (snap, p, base), fold is not None, glob, ver, act_bits)
+    return h, [x, ea, S] + acts, meta
 
 
 def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=None):
@@ -670,10 +657,9 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
     reductions and the fold's chain rule, calls the all-reduce hook.  Inside a stack: ``flat`` is the block's slice of the
     stack's buffer and every slab reduction is only recorded in ``pending``; the caller runs them (and the chain rule of
     all folds) in one launch each after the last block.  Returns (dx, parameter gradients as views into flat, fold_late)."""
-    ldx, ldea, n_acts, (snap, p_drop, base), folded, glob, ver, act_bits, n_xp = meta
+    ldx, ldea, n_acts, (snap, p_drop, base), folded, glob, ver, act_bits = meta
     x, ea, S = saved[0:3]
     acts = list(saved[3:3 + n_acts])
-    xps = list(saved[3 + n_acts:3 + n_acts + n_xp])      # X plane images of S, h_1 .. h_{L-2} (or none)
     in_stack = flat is not None
 
     def drop_of(l):            # the mask that was applied to conv l's output: (snapshot, p, id) or None
@@ -735,8 +721,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         layers = []
         for l in range(L - 2, -1, -1):
             out_l = torch.empty(topo.N, hid, dtype=_F32, device=dev)
-            # (an inner activation whose fp32 copy was never written -- X planes, XP_DROP_FP32 -- is a placeholder: its gate is the bit words)
-            layers.append(dict(Bp=(plan.bwd16[1 + l] if use16 else plan.bwd[1 + l]), Y=out_l, relu_src=(acts[l] if (l > 0 and acts[l].numel()) else None),
+            layers.append(dict(Bp=(plan.bwd16[1 + l] if use16 else plan.bwd[1 + l]), Y=out_l, relu_src=(acts[l] if l > 0 else None),
                                gate_bits=(act_bits.get(l) if (l > 0 and use16) else None),
                                drop_id=(base + l if (l > 0 and snap is not None) else 0)))      # mask of conv l-1: id (l-1)+1
             if l > 0:
@@ -751,15 +736,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         # joined launch is 141 us against 93 + 57, and -- what matters more -- the step writes and re-reads half the slabs
         # (255 x 197 KB instead of 128 x 2 + 256): reduction 24.7 -> 17.8 us, C2 step 0.537 -> 0.509 ms on one box.
         join = True if FL.WGRAD_JOIN_FOLDED is None else bool(FL.WGRAD_JOIN_FOLDED)
-        if xps and not (fold is not None and L - 1 <= 8 and join and use16 and len(xps) == L - 1):
-            raise RuntimeError("the forward wrote X plane images for a backward route that is not taken (flags changed in between?)")
-        if xps:
-            # ... with the layers' inputs as the X plane images their producers wrote (csrc/dss2_wgrad16p.hip)
-            wgrad_batched_xp(topo, gl, hid, xps, hid, nmat, flat[offs[3]:offs[2 + L - 1]],
-                             first_rowscale2=topo.deg_pows, first_out=fold.gfold, pending=pending)
-            fold_late = True
-            dS, g = d_in, None
-        elif fold is not None and L - 1 <= 8 and join:
+        if fold is not None and L - 1 <= 8 and join:
             # the folded conv 0 (input S, extra scaled bias sums) and the plain layers 1 .. L-2 in ONE launch
             wgrad_batched(topo, gl, hid, [S] + acts[1:L - 1], hid, nmat, flat[offs[3]:offs[2 + L - 1]],
                           first_rowscale2=topo.deg_pows, first_out=fold.gfold, pending=pending)
@@ -816,11 +793,10 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
                              pack_dx=tuple(plan.bwd[1 + L:4 + L]), dS=(dS if fold is not None else None),
                              pending=pending, dx_add=(gout if (need_dx and mod.skip) else None))
     if not in_stack:
-        # all slab reductions of the block and the chain rule of the fold (it needs the reduced gfold only): one launch
+        # all slab reductions of the block in one launch, then the chain rule of the fold (it needs the reduced gfold)
         if fold_late:
             fold._check()
-        finish_weights(pending if pending is not None else [], (fold.bwd_tab if fold_late else None), flat,
-                       ({fold.gfold.data_ptr()} if fold_late else ()), dev)
+        finish_weights(pending if pending is not None else [], (fold.bwd_tab if fold_late else None), flat, dev)
         hook = getattr(mod, "_grad_bucket_hook", None)
         if hook is not None:      # data-parallel: all-reduce the flat bucket once (parallel.py)
             hook(flat)
@@ -894,8 +870,7 @@ class _StackPlan:
             self.pack_tab = (t, cnt, max_elems, n_dep)
             self.key = key
             self.table_builds += 1
-        self.gfolds = {f.gfold.data_ptr() for _, f, _ in plans if f is not None}
-        prep_weights(self.fold_fwd, self.pack_tab, self.device)      # every block's fold + every block's packing: one launch
+        prep_weights(self.fold_fwd, self.pack_tab, self.device)      # every block's fold, then every block's packing: one launch each
         for p, _, _ in plans:
             p.version += 1
 
@@ -961,7 +936,7 @@ class _PFNFn(torch.autograd.Function):
             any_fold = any_fold or fl
         if any_fold and sp.fold_bwd is None:
             raise RuntimeError("the stack's fold tables are missing")
-        finish_weights(pending, (sp.fold_bwd if any_fold else None), flat, (sp.gfolds if any_fold else ()), dev)
+        finish_weights(pending, (sp.fold_bwd if any_fold else None), flat, dev)
         hook = getattr(blocks[0], "_grad_bucket_hook", None)
         if hook is not None:      # data-parallel: ONE all-reduce for the whole stack's bucket
             hook(flat)

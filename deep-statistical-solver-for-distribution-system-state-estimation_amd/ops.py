@@ -204,10 +204,9 @@ def gemm_prop_chain(topo: Topology, X: Optional[torch.Tensor], hid: int, nmat: i
         for t_ in (ly.get("Y"), ly.get("relu_src"), ly.get("dmask")):
             if t_ is not None and (t_.stride(0) != hid or t_.stride(1) != 1):
                 raise ValueError("gemm_prop_chain: [N, hid] contiguous tensors expected")
-        d.Bp, d.Y, d.bias = ly["Bp"].data_ptr(), _ptr(ly.get("Y")), _ptr(ly.get("bias"))      # (Y None: only beside x_planes)
+        d.Bp, d.Y, d.bias = ly["Bp"].data_ptr(), _ptr(ly.get("Y")), _ptr(ly.get("bias"))
         d.relu_src, d.dmask, d.prebias = _ptr(ly.get("relu_src")), _ptr(ly.get("dmask")), _ptr(ly.get("prebias"))
         d.gate_bits, d.y_bits = _ptr(ly.get("gate_bits")), _ptr(ly.get("y_bits"))      # (only where chain_gate_words() > 0)
-        d.x_planes = _ptr(ly.get("x_planes"))                                           # (only where xplanes_supported())
         d.relu = int(bool(ly.get("relu", False)))
         d.drop_id = int(ly.get("drop_id", 0)) if drop is not None else 0
     if head is None:
@@ -350,76 +349,6 @@ def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Seq
         _reduce(slab, 0, n_split, total, out_flat, total, pending)
 
 
-def xplanes_supported(topo: Topology, nmat: int, hid: int) -> bool:
-    """True when this block's H -> H weight gradients can read their inputs as X plane images (csrc/dss2_wgrad16p.hip): the
-    edge MLP and the forward chain can write them for this shape and dss2_wgrad_batched_xp covers it."""
-    if not (FL.WGRAD_XP and FL.WGRAD_BF16 and FL.WGRAD_BATCH and FL.CHAIN_BF16 and FL.EDGE_TILE_KERNELS) or topo.global_only or topo.nrb != 2:
-        return False
-    if topo.ell_tiles is None or topo.ellT_tiles is None or topo.ell_ent_tiles is None:
-        return False
-    cache = topo.__dict__.setdefault("_xp_ok", {})
-    ok = cache.get((nmat, hid))
-    if ok is None:
-        L = _lib.lib()
-        ok = cache[(nmat, hid)] = bool(L.dss2_wgrad_xp_supported(topo.nrb, nmat, hid, hid, topo.ellT)
-                                       and L.dss2_gemm_prop_chain_xplanes_supported(topo.nrb, nmat, hid, hid, topo.ell)
-                                       and L.dss2_edge_tile_fwd_xp_supported(topo.nrb, hid, topo.ell))
-    return ok
-
-
-def new_xplanes(topo: Topology, ncols: int, device) -> torch.Tensor:
-    """An (uninitialised) X plane image of an [N, ncols] activation on the topology's 64-row tiles (its producer writes all of it)."""
-    return torch.empty(int(_lib.lib().dss2_xplanes_bytes(topo.ntiles, ncols)), dtype=torch.uint8, device=device)
-
-
-def wgrad_xp_plan(ntiles: int, n_layers: int, ys: int, per_cu: int = 2):
-    """(n_wg, ipw, [(first slab id, n_slabs) per layer]) of a dss2_wgrad_batched_xp launch: ``per_cu`` workgroups per CU, the list
-    of (layer, tile) pairs cut into equal ranges; the slab of (range w, layer l) has id w + l."""
-    total = n_layers * ntiles
-    n_wg = max(1, min(total, (256 * per_cu) // ys))
-    ipw = (total + n_wg - 1) // n_wg
-    n_wg = (total + ipw - 1) // ipw          # ranges that actually hold pairs
-    spans = []
-    for l in range(n_layers):
-        first, last = (l * ntiles) // ipw, ((l + 1) * ntiles - 1) // ipw
-        spans.append((first + l, last - first + 1))
-    return n_wg, ipw, spans
-
-
-def wgrad_batched_xp(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xps: Sequence[torch.Tensor], hin: int, nmat: int,
-                     out_flat: torch.Tensor, first_rowscale2=None, first_out=None, pending=None) -> None:
-    """wgrad_batched with the layers' inputs given as X plane images (new_xplanes, written by the edge MLP / the forward chain):
-    same results layout -- out_flat <- [dW_0 .. dW_{nmat-1}, db] of the plain layers in order, the folded layer 0 (with
-    ``first_rowscale2``) to ``first_out`` with its extra nmat*hout scaled sums."""
-    nl = len(Gs)
-    L_ = _lib.lib()
-    ys = int(L_.dss2_wgrad_xp_y_slices(hout, hin))
-    n_wg, ipw, spans = wgrad_xp_plan(topo.ntiles, nl, ys, int(L_.dss2_wgrad_xp_per_cu(topo.nrb, nmat, hout, hin, topo.ellT)))
-    stride = nmat * hout * hin + hout
-    slab_len = stride + (nmat * hout if first_rowscale2 is not None else 0)
-    slab = torch.empty((n_wg + nl - 1) * slab_len, dtype=_F32, device=Gs[0].device)
-    a = _lib.WgradArgs()
-    a.ldg, a.hout, a.ldx, a.hin = Gs[0].stride(0), hout, hin, hin
-    for g_ in Gs:
-        if g_.stride(0) != a.ldg or g_.shape != Gs[0].shape:
-            raise ValueError("wgrad_batched_xp: layers must share shapes and leading dimensions")
-    a.n_split, a.nmat, a.nrb, a.ntiles = n_wg, nmat, topo.nrb, topo.ntiles
-    a.mfma_bf16 = 1
-    a.tile_start = topo.tile_start.data_ptr()
-    a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), topo.max_nnzT
-    a.ell_width, a.ell_tiles = topo.ellT, _ptr(topo.ellT_tiles)
-    PtrArr = C.c_void_p * nl
-    gs, xs = PtrArr(*[g_.data_ptr() for g_ in Gs]), PtrArr(*[x_.data_ptr() for x_ in Xps])
-    rs = PtrArr(*[(first_rowscale2.data_ptr() if (first_rowscale2 is not None and l == 0) else None) for l in range(nl)])
-    _lib.check(L_.dss2_wgrad_batched_xp(C.byref(a), gs, xs, slab.data_ptr(), slab_len, rs, nl, n_wg, _stream(Gs[0])), "dss2_wgrad_batched_xp")
-    for l, (sid, ns) in enumerate(spans):
-        if first_rowscale2 is not None and l == 0:
-            _reduce(slab, sid * slab_len, ns, slab_len, first_out, slab_len, pending)
-        else:
-            j = l - (1 if first_rowscale2 is not None else 0)
-            _reduce(slab, sid * slab_len, ns, slab_len, out_flat[j * stride:(j + 1) * stride], stride, pending)
-
-
 def _reduce(slab: torch.Tensor, slab_off: int, n_slabs: int, stride: int, out: torch.Tensor, length: int, pending) -> None:
     """out[:length] <- fixed-order sum of the slabs; with ``pending`` (a list) the reduction is only recorded, and
     ``reduce_pending`` later runs all recorded ones in one launch (the slab tensors are kept alive by the list)."""
@@ -446,61 +375,27 @@ def reduce_pending(pending) -> None:
     pending.clear()
 
 
-_COUNTERS = {}
-
-
-def weight_counters(device) -> torch.Tensor:
-    """The counter words of dss2_prep_weights / dss2_finish_weights on this device: words 0..511 for the step-start launch, 512..1023
-    for the step-end launch (DSS2_WEIGHT_COUNTER_WORDS = 288 each; zero between launches; launches of one device are ordered on its stream)."""
-    device = torch.device(device)
-    t = _COUNTERS.get(device)
-    if t is None:
-        t = _COUNTERS[device] = torch.zeros(1024, dtype=torch.int32, device=device)
-    return t
-
-
 def prep_weights(fold_tab, pack_tab, device) -> None:
-    """Start of a step in weight space: the fold of the edge MLP's second Linear (``fold_tab``: small-GEMM table or None) and the
-    packing of every weight (``pack_tab`` = (device table, descriptors, max elements, leading descriptors that read folded weights)) -- ONE launch (flags.WEIGHTS_MERGED) or two."""
-    t, cnt, mx, n_dep = pack_tab
+    """Start of a step in weight space: the fold of the edge MLP's second Linear (``fold_tab``: small-GEMM table or None), then the
+    packing of every weight (``pack_tab`` = (device table, descriptors, max elements, leading descriptors that read folded weights)):
+    two launches (one launch with in-kernel hand-offs measured slower: HISTORY round 5)."""
+    t, cnt, mx, _n_dep = pack_tab
     st = _lib.stream_ptr(device)
-    if fold_tab is not None and FL.WEIGHTS_MERGED:
-        ft, fcnt, fmx = fold_tab
-        _lib.check(_lib.lib().dss2_prep_weights(ft.data_ptr(), fcnt, fmx, t.data_ptr(), cnt, n_dep, mx, weight_counters(device).data_ptr(), st),
-                   "dss2_prep_weights")
-        return
     if fold_tab is not None:
         ft, fcnt, fmx = fold_tab
         _lib.check(_lib.lib().dss2_small_gemm(ft.data_ptr(), fcnt, fmx, None, st), "dss2_small_gemm")
     _lib.check(_lib.lib().dss2_pack_weights(t.data_ptr(), cnt, mx, st), "dss2_pack_weights")
 
 
-def finish_weights(pending, rule_tab, base: Optional[torch.Tensor], dep_outs, device) -> None:
-    """End of a step in weight space: the recorded slab reductions and, with ``rule_tab`` (small-GEMM table writing into ``base``), the
-    chain rule of the fold, which reads the reductions whose outputs are in ``dep_outs`` (data pointers) -- ONE launch
-    (flags.WEIGHTS_MERGED: the chain rule starts as soon as ITS reductions are done and runs beside the others) or two."""
-    if rule_tab is None:
-        if pending:
-            reduce_pending(pending)
-        return
-    rt, rcnt, rmx = rule_tab
-    st = _lib.stream_ptr(device)
-    dep = [p for p in pending if p[4].data_ptr() in dep_outs]
-    if FL.WEIGHTS_MERGED and 1 <= len(dep) <= 32 and len(dep) == len(dep_outs):
-        rest = [p for p in pending if p[4].data_ptr() not in dep_outs]
-        room = 32 - len(dep)
-        over = rest[room:]
-        if over:
-            reduce_pending(over)
-        chunk = dep + rest[:room]
-        descs = _reduce_descs(chunk)
-        _lib.check(_lib.lib().dss2_finish_weights(C.addressof(descs), len(chunk), len(dep), rt.data_ptr(), rcnt, rmx, base.data_ptr(),
-                                                  weight_counters(device).data_ptr() + 2048, st), "dss2_finish_weights")
-        pending.clear()
-        return
+def finish_weights(pending, rule_tab, base: Optional[torch.Tensor], device) -> None:
+    """End of a step in weight space: the recorded slab reductions in one launch and, with ``rule_tab`` (small-GEMM table writing
+    into ``base``), the chain rule of the fold behind them."""
     if pending:
         reduce_pending(pending)
-    _lib.check(_lib.lib().dss2_small_gemm(rt.data_ptr(), rcnt, rmx, base.data_ptr(), st), "dss2_small_gemm")
+    if rule_tab is None:
+        return
+    rt, rcnt, rmx = rule_tab
+    _lib.check(_lib.lib().dss2_small_gemm(rt.data_ptr(), rcnt, rmx, base.data_ptr(), _lib.stream_ptr(device)), "dss2_small_gemm")
 
 
 def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, ent: torch.Tensor, n_rows: int) -> torch.Tensor:

@@ -42,7 +42,7 @@ def _sg_table(recs, device):
 
 def _pack_table(recs, device):
     """(device table, descriptors, leading descriptors whose source the fold of the same step writes) of packing records: the
-    dependent ones (transpose bit 2, _MatView.dep) first -- dss2_prep_weights makes exactly those wait for the fold."""
+    dependent ones (transpose bit 2, _MatView.dep) first."""
     recs = sorted(recs, key=lambda r: 0 if (r[5] & 4) else 1)      # (stable)
     arr = np.array(recs, dtype=_DESC_DTYPE)
     return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(recs), sum(1 for r in recs if r[5] & 4)
@@ -133,7 +133,7 @@ class _MatView:
 
     def __init__(self, t: torch.Tensor, rows: int, cols: int, ld: int, off: int = 0, dep: bool = False):
         self.t, self.shape, self.ld, self.off = t, (rows, cols), ld, off
-        self.dep = dep      # written by the fold of the same step: its packing waits for the fold inside dss2_prep_weights (transpose bit 2)
+        self.dep = dep      # written by the fold of the same step (transpose bit 2; the packing launch runs behind the fold's)
 
     def data_ptr(self) -> int:
         return self.t.data_ptr() + 4 * self.off

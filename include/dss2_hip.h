@@ -205,15 +205,12 @@ int dss2_edge_combine_bwd(const float* AB, int64_t ldab, const float* ea, int64_
 int dss2_edge_tile_fwd(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1,
                        const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width,
                        int nrb, int ntiles, float* S, int h, int fn, int fe, void* stream);
-/* dss2_edge_tile_fwd that additionally writes S as an X plane image (see dss2_xplanes_bytes; the weight gradient of the layer that
- * consumes S reads it).  x_planes == NULL: exactly dss2_edge_tile_fwd.  Non-NULL needs 64-row tiles, h % 32 == 0 and the bf16x6
- * form (dss2_edge_tile_fwd_xp_supported).  bwd_with_u != 0: the caller's dss2_edge_tile_bwd will be asked for U (the gradient
- * w.r.t. x): the forward then takes the arithmetic that backward recomputes its ReLU gates with (on 96-row tiles the fp32 MFMA form:
- * the bf16x6 backward with U is not built there). */
-int dss2_edge_tile_fwd_xp(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1,
-                          const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width,
-                          int nrb, int ntiles, float* S, int h, int fn, int fe, void* x_planes, int bwd_with_u, void* stream);
-int dss2_edge_tile_fwd_xp_supported(int nrb, int h, int ell_width);
+/* dss2_edge_tile_fwd for a caller that announces its backward.  bwd_with_u != 0: the caller's dss2_edge_tile_bwd will be asked for U
+ * (the gradient w.r.t. x): the forward then takes the arithmetic that backward recomputes its ReLU gates with (on 96-row tiles the
+ * fp32 form: the bf16x6 backward with U is not built there).  bwd_with_u == 0: exactly dss2_edge_tile_fwd. */
+int dss2_edge_tile_fwd_paired(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1,
+                              const float* b1, const int32_t* tile_start, const void* ell_ent, int ell_width,
+                              int nrb, int ntiles, float* S, int h, int fn, int fe, int bwd_with_u, void* stream);
 int dss2_edge_tile_bwd(const float* x, int64_t ldx, const float* ea, int64_t ldea, const float* W1,
                        const float* b1, const float* dS, const int32_t* tile_start, const void* ell_ent,
                        int ell_width, int nrb, int ntiles, float* slab, int n_slabs, float* U, int64_t ldu,
@@ -292,13 +289,7 @@ typedef struct dss2_chain_layer {
    * order (per lane of the wave that owns the element: opaque to the caller).  gate_bits: such a buffer, written by a chain launch over the SAME tiles, hout and nmat, replaces the reads of
    * relu_src (which must still be given: it defines the gate) -- 1/32 of the bytes and no latency-exposed vector loads. */
   const uint64_t* gate_bits; uint64_t* y_bits;
-  /* Optional (split-plane chain of 64-row tiles with hout % 32 == 0 only: dss2_gemm_prop_chain_xplanes_supported; other kernels
-   * REJECT a non-NULL value): the layer's output additionally as an X plane image (dss2_xplanes_bytes(ntiles, hout) bytes) for
-   * dss2_wgrad_batched_xp.  Y may then be NULL (nobody needs the fp32 copy). */
-  void* x_planes;
 } dss2_chain_layer;
-/* != 0: chain layers of this shape can write x_planes */
-int dss2_gemm_prop_chain_xplanes_supported(int nrb, int nmat, int kreal, int hout, int ell_width);
 /* 64-bit words per tile of y_bits / gate_bits for this shape; 0: the chain kernel of this shape has no bit form */
 int dss2_gemm_prop_chain_gate_words(int nrb, int nmat, int kreal, int hout, int ell_width);
 int dss2_gemm_prop_chain(const dss2_gemm_prop_args* args_host, const dss2_chain_layer* layers_host, int n_layers, void* stream);
@@ -336,7 +327,7 @@ int dss2_gemm_prop_chain16_supported(int nrb, int nmat, int kreal, int hout, int
 /* ... and with args.b_format = 2 as f16x3 (round 5): every layer's Bp = a group buffer in the f16x2 layout (dss2_pack_desc, transpose
  * bit 3: two fp16 planes per matrix + scale exponents), three fp16 MFMAs per product, the activation tile scaled per tile and layer by
  * an exact power of two (csrc/dss2_gemm_chain_sp.hip, MS = 2).  64-row tiles, hout = kreal a multiple of 32; layers gated by fp32
- * activations (relu_src without gate_bits) and x_planes are refused -- callers keep bf16x3 weights for those.  Also through
+ * activations (relu_src without gate_bits) are refused -- callers keep bf16x3 weights for those.  Also through
  * dss2_gemm_prop_chain_head.  Errors of the size of fp32 arithmetic's own rounding. */
 int dss2_gemm_prop_chain_f16_supported(int nrb, int nmat, int kreal, int hout, int ell_width);
 /* != 0: dss2_gemm_prop (one layer) accepts args.b_format = 1 for this shape -- the tall tiles (128 / 192 rows) that run
@@ -426,34 +417,6 @@ int dss2_wgrad_y_slices(int nrb, int nmat, int hout, int hin, int ell_width, int
 int dss2_wgrad_batched(const dss2_wgrad_args* args_host, const float* const* Gs, const float* const* Xs,
                        float* const* slabs, const float* const* rowscale2s, int64_t slab_stride, int n_layers,
                        void* stream);
-
-/* ---- X plane images (round 5): the weight gradient's input operand, split once where it is produced ------------------------ *
- * dW_m = (P^m G)^T X runs on the bf16 matrix pipe as bf16x6 (three bf16 pieces per operand, six MFMAs: fp32-accurate).  The        *
- * kernels that PRODUCE an activation X split it anyway (the next layer's tile GEMM reads the pieces), so they can also store the   *
- * pieces in the order the weight-gradient kernel's MFMA operand wants; dss2_wgrad_batched_xp then spends no vector instruction on  *
- * X (dss2_wgrad_batched splits X in every workgroup that owns a part of the output).  Replaces autograd's dW of                    *
- * /root/reference/networks.py:266-271 (TAGConv.lins[k].weight.grad, dss2_run.py:142) like dss2_wgrad_batched.                       *
- * Image of an [N, ncols] activation on 64-row tiles (nrb = 2), opaque to the caller:                                               *
- *   [tile][32-column block][k-step 0..3][piece h, m, l][1 KB = the B fragment of v_mfma_f32_32x32x16_bf16 in lane order];         *
- *   lane (n, kh) holds tile rows (2 kstep + kh) + 8 i, i = 0..7, of column 32 block + ((n & 7) << 2 | n >> 3).                    *
- * Producers: dss2_gemm_prop_chain layers with x_planes != NULL (split-plane chain of 64-row tiles, hout % 32 == 0) and            *
- * dss2_edge_tile_fwd_xp.  Every position of every tile is written (rows beyond a tile's rows with finite values).                 */
-size_t dss2_xplanes_bytes(int64_t ntiles, int32_t ncols);
-/* != 0: dss2_wgrad_batched_xp covers the shape (64-row tiles, K <= 2, ELL slices <= 8 wide, hin % 32 == 0, hout % 4 == 0, hout > 32) */
-int dss2_wgrad_xp_supported(int nrb, int nmat, int hout, int hin, int ell_width);
-/* workgroups per range of the (layer, tile) list (grid.y), and how many workgroups of the launch fit a CU (1: the software-pipelined
- * kernel, which takes the CU's whole LDS; 2 otherwise): a caller that wants the chip filled once asks for n_wg = 256 * per_cu / y_slices */
-int dss2_wgrad_xp_y_slices(int hout, int hin);
-int dss2_wgrad_xp_per_cu(int nrb, int nmat, int hout, int hin, int ell_width);
-/* n_layers (<= 8) layers of identical shape in ONE launch.  Gs[l]: fp32 [N, hout] (leading dimension args->ldg); Xps[l]: the X     *
- * plane image of layer l's input; args->X / ldx / slab / n_split are ignored.  The launch cuts the list of (layer, tile) pairs     *
- * into n_wg equal contiguous ranges of ipw = ceil(n_layers * ntiles / n_wg) pairs; the workgroup of range w writes its partial     *
- * result of layer l to slab + (w + l) * slab_len (layout of dss2_wgrad: [nmat*hout*hin][hout][nmat*hout if rowscale2s[l]]).        *
- * Layer l's slabs are the contiguous ids first_w(l) + l .. last_w(l) + l with first_w(l) = (l * ntiles) / ipw, last_w(l) =         *
- * ((l + 1) * ntiles - 1) / ipw: finish each layer with dss2_reduce_slabs(_multi) over exactly those.  slab must hold               *
- * n_wg + n_layers - 1 slabs.  Deterministic (no atomics).                                                                          */
-int dss2_wgrad_batched_xp(const dss2_wgrad_args* args_host, const float* const* Gs, const void* const* Xps, float* slab,
-                          int64_t slab_len, const float* const* rowscale2s, int n_layers, int n_wg, void* stream);
 
 /* out[j] = sum_{s < n_slabs} slab[s*stride + j], j < len, fixed order. */
 int dss2_reduce_slabs(const float* slab, int n_slabs, int64_t stride, float* out, int64_t len, void* stream);
@@ -550,26 +513,6 @@ typedef struct dss2_sgemm_desc {
 
 /* max_tiles = max over the descriptors of ceil(M/32) * ceil(N/32); descs is a DEVICE array */
 int dss2_small_gemm(const dss2_sgemm_desc* descs, int n_desc, int max_tiles, float* base_out, void* stream);
-
-/* ---- the weight-space work of a training step in two launches (round 5; csrc/dss2_weights.hip).  Host-side glue the reference
- *      does not have (its autograd keeps nn.Linear weights as they are: /root/reference/networks.py:159-209, 211-264): the fold and
- *      the packing are this library's own preparation of those weights, the reductions / chain rule its own gradient assembly.
- *      Bitwise the same results as the separate launches (same device code, dss2_weightspace.hpp).
- * dss2_prep_weights   = dss2_small_gemm(fold, n_fold, fold_tiles, NULL) then dss2_pack_weights(pack, n_pack, max_elems), as ONE
- *      launch: the FIRST n_dep packing descriptors (the ones whose src the fold writes; 0 <= n_dep <= n_pack) wait inside the kernel
- *      for the fold, the others run beside it.  fold / pack: DEVICE arrays.  n_fold = 0 (then n_dep = 0): plain packing.
- * dss2_finish_weights = dss2_reduce_slabs_multi(descs_host, n_red) then dss2_small_gemm(rule, n_rule, rule_tiles, base_out), as ONE
- *      launch: the chain rule waits for the FIRST n_dep reductions only (1 <= n_dep <= n_red <= 32: the caller lists the ones whose
- *      outputs `rule` reads first) and runs beside the others.  descs_host: HOST array (copied into the kernel arguments); rule:
- *      DEVICE array.
- * counters: DSS2_WEIGHT_COUNTER_WORDS zero-initialised uint32 words of device memory, 128-byte aligned, per launch in flight
- *      (launches ordered on one stream may share them); every launch leaves them zero.  Both launches rely on workgroups being
- *      dispatched in id order (the producers take the lowest ids). */
-#define DSS2_WEIGHT_COUNTER_WORDS 288
-int dss2_prep_weights(const dss2_sgemm_desc* fold, int n_fold, int fold_tiles, const dss2_pack_desc* pack, int n_pack, int n_dep,
-                      int max_elems, uint32_t* counters, void* stream);
-int dss2_finish_weights(const dss2_reduce_desc* descs_host, int n_red, int n_dep, const dss2_sgemm_desc* rule, int n_rule,
-                        int rule_tiles, float* base_out, uint32_t* counters, void* stream);
 
 /* ---- dataset side: what sits in front of the path in every training step.
  *      Replaces the arithmetic of data_from_pickles (/root/reference/data.py:119-190) and the

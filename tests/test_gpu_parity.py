@@ -247,16 +247,9 @@ def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
     x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
     # the gates the kernels themselves applied: sign of the activations the forward pass kept for its backward (the same
     # launches as the step above -- the forward is bitwise reproducible), not of a re-evaluation by other kernels
-    # (with X plane images the step above never wrote the fp32 copies of the inner activations -- pkg.flags.XP_DROP_FP32; this
-    #  re-run asks for them: the forward arithmetic is the same either way, tests/test_gpu_xplanes.py holds that bit for bit)
-    keep_fp32 = pkg.flags.XP_DROP_FP32
-    pkg.flags.XP_DROP_FP32 = False
-    try:
-        with torch.no_grad():
-            topo = pkg.topology.get_topology(ei, x.shape[0])
-            _, kept, _ = pkg.networks._mpn_forward(mine, topo, x[:, :8], ea[:, :6], mine._params())
-    finally:
-        pkg.flags.XP_DROP_FP32 = keep_fp32
+    with torch.no_grad():
+        topo = pkg.topology.get_topology(ei, x.shape[0])
+        _, kept, _ = pkg.networks._mpn_forward(mine, topo, x[:, :8], ea[:, :6], mine._params())
     gates = [(a_ > 0).cpu() for a_ in kept[4:4 + L - 1]]        # kept = [x, edge_attr, S, conv-0 input, act_1 .. act_{L-1}]
     ref64 = type(ref)(8, 6, 2, hid, L, 2, 0.0).double()
     ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})

@@ -27,8 +27,8 @@ FALLBACKS = {
     "chain-variants-a": (dict(DSS2_CHAIN_SP="0", DSS2_CHAIN_HEAD="0"),
                          [(PARITY, f"golden or {C2} or {C3} or {C5S}")]),
     # the head's FORWARD as a launch of its own (inside the chained launch since round 5); ReLU gates read from the activations instead
-    # of the forward chain's bit words; the weight gradient splitting its input itself instead of reading X plane images
-    "chain-variants-b": (dict(DSS2_CHAIN_HEAD_FWD="0", DSS2_CHAIN_GATE_BITS="0", DSS2_WGRAD_XP="0"),
+    # of the forward chain's bit words
+    "chain-variants-b": (dict(DSS2_CHAIN_HEAD_FWD="0", DSS2_CHAIN_GATE_BITS="0"),
                          [(PARITY, f"golden or {C2} or {C3} or tall_tiles")]),
     # the generic narrow kernels, scalar-VALU edge MLP, edges through the global CSR instead of tile-local lists; the 64-row chain's tile
     # GEMM on 32x32x16 MFMAs instead of 16x16x32

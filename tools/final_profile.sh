@@ -72,7 +72,6 @@ fi
 if [ -f tools/diag_lib/libdss2_hstamps.so ]; then
   DSS2_LIB=tools/diag_lib/libdss2_hstamps.so python3 tools/stamps.py wgradh 2>&1 | grep -v amdgpu > $O/wgrad16h_stamps_C2.txt
 fi
-python3 tools/weights_bench.py 2>&1 | grep -v amdgpu > $O/weights_bench.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result tools/micro/f16x3_probe.hip -o /tmp/f16x3 2>/dev/null && /tmp/f16x3 > $O/f16x3_probe.txt 2>&1
 # the packed-fp32 reproducer (tools/micro/pkfma_beside_mfma.hip) and the 200-launch stress of the real kernel
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/pkfma_beside_mfma.hip -o /tmp/pkfma 2>/dev/null && /tmp/pkfma > $O/pkfma_micro.txt 2>&1

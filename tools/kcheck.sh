@@ -1,6 +1,6 @@
 #!/bin/bash
 # Compile ONE csrc/*.hip translation unit for gfx950 into /tmp and print every kernel's register / spill / LDS / scratch notes.
-#   tools/kcheck.sh dss2_wgrad16p [extra hipcc flags]
+#   tools/kcheck.sh dss2_wgrad16h [extra hipcc flags]
 set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 CS="$ROOT/deep-statistical-solver-for-distribution-system-state-estimation_amd/csrc"

@@ -46,20 +46,6 @@ for it in range(NREP):
         flat2 = torch.empty(2 * (nmat * H * H + H), device=dev)
         first = torch.empty(nmat * H * H + H + nmat * H, device=dev)
         nw.wgrad_batched(topo, [g, g, g], H, [h, h, h], H, nmat, flat2, first_rowscale2=topo.deg_pows, first_out=first)
-    elif which in ("wgradxp", "wgradxp_nors2"):      # round 5: the three layers' weight gradients from X plane images (dss2_wgrad_batched_xp)
-        if it == 0:
-            ops = pkg.ops
-            Ws3 = [[torch.randn(H, H, device=dev) * 0.1 for _ in range(nmat)] for _ in range(3)]
-            plan3 = nw._PackPlan(Ws3, dev, bf16_groups=(0, 1, 2)); plan3.refresh()
-            xps = [ops.new_xplanes(topo, H, dev) for _ in range(3)]
-            ops.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=plan3.fwd16[i], Y=torch.empty(N, H, device=dev), relu=True, x_planes=xps[i]) for i in range(3)], b_format=1)
-            gs3 = [torch.randn(N, H, device=dev) for _ in range(3)]
-            flat3 = torch.empty(3 * (nmat * H * H + H), device=dev)
-            first = torch.empty(nmat * H * H + H + nmat * H, device=dev)
-        if which == "wgradxp":
-            ops.wgrad_batched_xp(topo, gs3, H, xps, H, nmat, flat3[:2 * (nmat * H * H + H)], first_rowscale2=topo.deg_pows, first_out=first, pending=[])
-        else:
-            ops.wgrad_batched_xp(topo, gs3, H, xps, H, nmat, flat3, pending=[])
     else:
         nw.wgrad(topo, g, H, h, H, nmat, flat)
 T1.record()

@@ -10,8 +10,6 @@ stamp scripts folded into one).  Each needs a diagnostic build of the library wi
     chain     DSS2_CHAIN_STAMPS   the bf16x6 layer chains (args: graphs, hidden width, layers)
     stack     DSS2_STACK_STAMPS   the whole-stack kernels (args: graphs, dropout p)
     wgrad     DSS2_STAMPS         wgrad_kernel<2,3,4> (args: grid, graphs, hidden width)
-    wgradxp   DSS2_STAMPS         wgrad16p_kernel (X plane images; args: grid, graphs)
-    wgradxq   DSS2_STAMPS         wgrad16q_kernel (X plane images, software-pipelined)
     wgradh    DSS2_STAMPS         wgrad16h_kernel (f16x3, 32-row tiles; args: grid, graphs)
 """
 import ctypes as C, importlib, os, sys
@@ -271,91 +269,6 @@ wgrad_kernel<2,3,4> on the second tile of every workgroup (s_memtime ticks = 100
     show("tile total", t[:, :, 14] - t[:, :, 0])
 
 
-def cmd_wgradxp(argv):
-    """GPU diagnostic (needs a -DDSS2_STAMPS build of csrc/dss2_wgrad16p.hip: DSS2_LIB=<that library>): per-wave phase durations of
-wgrad16p_kernel on the third tile of every workgroup's range (s_memtime ticks), C2 by default."""
-    sys_argv = [""] + list(argv)
-    nw, ops = pkg.networks, pkg.ops
-    DEV = "cuda:0"; H, nmat, nl = 128, 3, 3
-    GRID = sys_argv[1] if len(sys_argv) > 1 else "cigre14"; B = int(sys_argv[2]) if len(sys_argv) > 2 else 4096
-    b = pkg.synthetic.make_batch([GRID], B, seed=0)
-    ei = b["edge_index"].to(DEV); N = b["x"].shape[0]
-    topo = pkg.topology.get_topology(ei, N)
-    torch.manual_seed(0)
-    Ws = [[torch.randn(H, H, device=DEV) * (1.2 / H ** 0.5) for _ in range(nmat)] for _ in range(nl)]
-    plan = nw._PackPlan(Ws, DEV, bf16_groups=tuple(range(nl))); plan.refresh()
-    h = torch.randn(N, H, device=DEV)
-    Ys = [torch.empty(N, H, device=DEV) for _ in range(nl)]
-    xps = [ops.new_xplanes(topo, H, DEV) for _ in range(nl)]
-    ops.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=plan.fwd16[i], Y=Ys[i], relu=True, x_planes=xps[i]) for i in range(nl)], b_format=1)
-    Gs = [torch.randn(N, H, device=DEV) for _ in range(nl)]
-    stride = nmat * H * H + H
-    out = torch.empty(nl * stride, device=DEV); first = torch.empty(stride + nmat * H, device=DEV)
-    big = torch.empty(300 << 20, dtype=torch.uint8, device=DEV)
-    for _ in range(5):
-        big.fill_(1)      # (cold caches, as inside the step)
-        ops.wgrad_batched_xp(topo, Gs, H, xps, H, nmat, out[:(nl - 1) * stride], first_rowscale2=topo.deg_pows, first_out=first, pending=[])
-    torch.cuda.synchronize()
-    lib = C.CDLL(pkg._lib.LIB_PATH)
-    n = 512 * 4 * 16
-    buf = (C.c_ulonglong * n)()
-    assert lib.dss2_debug_read_pstamps(buf, n) == 0
-    t = np.frombuffer(buf, dtype=np.uint64).reshape(512, 4, 16).astype(np.int64)
-    def show(name, v):
-        print(f"{name:58s} mean {v.mean():8.0f}  median {np.median(v):8.0f}  p90 {np.percentile(v, 90):8.0f} ticks")
-    show("staging (G -> LDS, ELL) + barrier", t[:, :, 1] - t[:, :, 0])
-    show("next item's loads issued + hop 1", t[:, :, 11] - t[:, :, 1])
-    show("hop-1 barrier", t[:, :, 2] - t[:, :, 11])
-    for c in (0, 1):
-        show(f"chunk {c}: X loads issued + planes (splits, hop 2)", t[:, :, 3 + 4 * c] - (t[:, :, 2] if c == 0 else t[:, :, 6]))
-        show(f"chunk {c}: barrier", t[:, :, 4 + 4 * c] - t[:, :, 3 + 4 * c])
-        show(f"chunk {c}: MFMA phase (72 MFMAs, waits for X)", t[:, :, 5 + 4 * c] - t[:, :, 4 + 4 * c])
-        show(f"chunk {c}: closing barrier", t[:, :, 6 + 4 * c] - t[:, :, 5 + 4 * c])
-    show("tile total", t[:, :, 10] - t[:, :, 0])
-
-
-def cmd_wgradxq(argv):
-    """GPU diagnostic (needs a -DDSS2_STAMPS build of csrc/dss2_wgrad16q.hip: DSS2_LIB=<that library>): per-wave slot durations of
-wgrad16q_kernel on the third tile of every workgroup's range (s_memtime ticks), C2."""
-    sys_argv = [""] + list(argv)
-    nw, ops = pkg.networks, pkg.ops
-    DEV = "cuda:0"; H, nmat, nl = 128, 3, 3
-    b = pkg.synthetic.make_batch(["cigre14"], 4096, seed=0)
-    ei = b["edge_index"].to(DEV); N = b["x"].shape[0]
-    topo = pkg.topology.get_topology(ei, N)
-    torch.manual_seed(0)
-    Ws = [[torch.randn(H, H, device=DEV) * (1.2 / H ** 0.5) for _ in range(nmat)] for _ in range(nl)]
-    plan = nw._PackPlan(Ws, DEV, bf16_groups=tuple(range(nl))); plan.refresh()
-    h = torch.randn(N, H, device=DEV)
-    xps = [ops.new_xplanes(topo, H, DEV) for _ in range(nl)]
-    ops.gemm_prop_chain(topo, h, H, nmat, [dict(Bp=plan.fwd16[i], Y=torch.empty(N, H, device=DEV), relu=True, x_planes=xps[i]) for i in range(nl)], b_format=1)
-    Gs = [torch.randn(N, H, device=DEV) for _ in range(nl)]
-    stride = nmat * H * H + H
-    out = torch.empty(nl * stride, device=DEV)
-    for _ in range(5):
-        ops.wgrad_batched_xp(topo, Gs, H, xps, H, nmat, out, pending=[])
-    torch.cuda.synchronize()
-    lib = C.CDLL(pkg._lib.LIB_PATH)
-    n = 256 * 8 * 16
-    buf = (C.c_ulonglong * n)()
-    assert lib.dss2_debug_read_qstamps(buf, n) == 0
-    t = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8, 16).astype(np.int64)
-    def show(name, v):
-        print(f"{name:62s} mean {v.mean():8.0f}  median {np.median(v):8.0f}  p90 {np.percentile(v, 90):8.0f} ticks")
-    for role, sl in (("waves 0-3 (G, P G planes)", slice(0, 4)), ("waves 4-7 (P^2 G planes)", slice(4, 8))):
-        print(role)
-        tt = t[:, sl, :]
-        show("  slot A : 36 MFMAs || planes of chunk 1, bias sums", tt[:, :, 1] - tt[:, :, 0])
-        show("  barrier", tt[:, :, 2] - tt[:, :, 1])
-        show("  slot B0:  4 MFMAs || next tile's rows -> LDS", tt[:, :, 3] - tt[:, :, 2])
-        show("  barrier", tt[:, :, 4] - tt[:, :, 3])
-        show("  slot B1: 12 MFMAs || first hop of the next tile", tt[:, :, 5] - tt[:, :, 4])
-        show("  barrier", tt[:, :, 6] - tt[:, :, 5])
-        show("  slot B2: 20 MFMAs || planes of the next tile's chunk 0", tt[:, :, 7] - tt[:, :, 6])
-        show("  barrier", tt[:, :, 8] - tt[:, :, 7])
-        show("  tile total (72 MFMAs = 2304 cycles of matrix pipe per wave)", tt[:, :, 8] - tt[:, :, 0])
-
-
 def cmd_wgradh(argv):
     """GPU diagnostic (needs a -DDSS2_STAMPS build of csrc/dss2_wgrad16h.hip: DSS2_LIB=<that library>): per-wave phase durations of
 wgrad16h_kernel on the third tile of every workgroup's walk (layer 1 of three; s_memtime ticks = 10 ns), C2 by default."""
@@ -399,7 +312,7 @@ wgrad16h_kernel on the third tile of every workgroup's walk (layer 1 of three; s
     show("tile total", t[:, :, 11] - t[:, :, 0])
 
 
-COMMANDS = {"wgradh": cmd_wgradh, "gemm": cmd_gemm, "teams": cmd_teams, "chain": cmd_chain, "stack": cmd_stack, "wgrad": cmd_wgrad, "wgradxp": cmd_wgradxp, "wgradxq": cmd_wgradxq}
+COMMANDS = {"wgradh": cmd_wgradh, "gemm": cmd_gemm, "teams": cmd_teams, "chain": cmd_chain, "stack": cmd_stack, "wgrad": cmd_wgrad}
 
 if __name__ == "__main__":
     if len(sys.argv) < 2 or sys.argv[1] not in COMMANDS:
