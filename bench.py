@@ -134,6 +134,11 @@ OTHER_CONFIGS = [
     ("C5 model, 4096-graph mixed-topology shard, H=256 L=8", ["cigre14", "cigre14_reswitched"], 4096, "MPN", (8, 6, 2, 256, 8, 2, 0.0), (15, 14.5), 1),
     ("C2 shape, B=32768 on one GPU (cache-busting)", ["cigre14"], 32768, "MPN", (8, 6, 2, 128, 4, 2, 0.0), (15, 14), 1),
     ("driver line: SkipPFN H=32 8 layers x 5 blocks, dropout 0.3, B=4096", ["cigre14"], 4096, "SkipPFN", (8, 6, 2, 32, 8, 2, 0.3, 5), (15, 14), 5),
+    # the reference driver's other branch (dss2_run.py:51-53: Oberrhein; 70 buses => 96-row tiles).  The whole-stack kernels cover <= 64-row
+    # tiles only (their backward takes 130 KB of LDS at 64 rows; 96 rows would need ~226 KB: DESIGN section 9), so these run the per-block
+    # kernels -- timed here so that the gap is a number
+    ("driver line on ober_sub: SkipPFN H=32 8 layers x 5 blocks, dropout 0.3, B=64", ["ober_sub"], 64, "SkipPFN", (8, 6, 2, 32, 8, 2, 0.3, 5), (70, 69), 5),
+    ("driver line on ober_sub: SkipPFN H=32 8 layers x 5 blocks, dropout 0.3, B=1024", ["ober_sub"], 1024, "SkipPFN", (8, 6, 2, 32, 8, 2, 0.3, 5), (70, 69), 5),
 ]
 
 
@@ -189,7 +194,7 @@ def time_other_config(pkg, dev, stream, tag, grids, B, cls, cargs, ne, blocks, s
             del pl
         except Exception as exc:
             rec["ms_per_step_plan"], rec["plan_error"] = None, f"{type(exc).__name__}: {exc}"[:200]
-    best = min(v for v in (rec["ms_per_step_eager"], rec["ms_per_step_replay"]) if v is not None)
+    best = min(v for v in (rec["ms_per_step_eager"], rec["ms_per_step_replay"], rec.get("ms_per_step_plan")) if v is not None)
     hid, layers, khops = cargs[3], cargs[4], cargs[5]
     ne = (x.shape[0] / float(B), ei.shape[1] / float(B))      # nodes / stored edges per graph of THIS batch (mixed topologies: the mean)
     fpg = flops_per_graph(ne[0], ne[1], hid, layers, khops, blocks=blocks, fo_inner=(8 if blocks > 1 else None))
@@ -646,7 +651,7 @@ def main():
             result["other_configs"] = others
             result["other_configs_note"] = ("forward + gsp_wls_edge + backward on a resident synthetic batch, one GPU, eager, as a hipGraph "
                                             "replay and as a launch plan (one C call per step, dss2_plan_run), >= %.1f s of timed work each; "
-                                            "ms_per_step = the faster of eager / replay; TFLOP/s from SURVEY 8(d)'s "
+                                            "ms_per_step = the fastest of eager / replay / plan; TFLOP/s from SURVEY 8(d)'s "
                                             "algorithmic FLOPs (3 x forward); the driver line excludes the optimizer" % args.other_seconds)
 
         # ---- CPU baseline (SURVEY 8d / BASELINE.md 3): the oracle -- a port of the reference's PyTorch-eager path --

@@ -82,10 +82,11 @@ extern "C" int dss2_gemm_prop_chain_head_supported(int nrb, int nmat, int kreal,
 
 extern "C" int dss2_gemm_prop_chain_head_wgrad_supported(int nrb, int nmat, int kreal, int hout, int ell_width, int nout) {
   using namespace dss2;
-  if (nrb != 2 || nout < 1 || nout > 2 || !(dss2_gemm_prop_chain_head_supported(nrb, nmat, kreal, hout, ell_width, nout) & 2)) return 0;
+  if (nout < 1 || nout > 2 || !(dss2_gemm_prop_chain_head_supported(nrb, nmat, kreal, hout, ell_width, nout) & 2)) return 0;
+  if (nrb == 3 || nrb == 6) return 1;      // the split-plane chains of 96- / 192-row tiles (dss2_gemm_chain_sp6.hip)
   dss2_gemm_prop_args a = {};
   a.b_format = 1; a.nrb = nrb; a.nmat = nmat; a.kreal = kreal; a.kpad = (kreal + 15) / 16 * 16; a.hout = hout; a.ncg = (hout + 31) / 32; a.ell_width = ell_width;
-  return chain_row_split(nrb, a.ncg) == 1 && chain_sp_supported(a) ? 1 : 0;      // the 64-row split-plane chain (dss2_gemm_chain_sp.hip)
+  return nrb == 2 && chain_row_split(nrb, a.ncg) == 1 && chain_sp_supported(a) ? 1 : 0;      // the 64-row split-plane chain (dss2_gemm_chain_sp.hip)
 }
 
 static int dss2_gemm_prop_chain_head_launch(const dss2_gemm_prop_args* ap, const dss2_chain_layer* layers, int n_layers, const dss2_chain_head* head, void* stream);

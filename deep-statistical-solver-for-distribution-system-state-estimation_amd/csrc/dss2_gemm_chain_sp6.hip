@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     // G are nout wide and run once per WAVE (a lane owns rows lane, lane + 64, ..; wave-private scratch at the start of the wave's
     // own region, which the planes overwrite at the very end).
     constexpr int RPL = (TM + 63) / 64;      // rows per lane in the hop phase
+    static_assert(TM * NMAT * 4 + TM * 4 + 64 * NMAT * 2 * 4 <= S6_REGION, "the head's scratches must fit the wave's own region");
     const int nout = hd.nout;
     f32x4 ga[NRP];
     if (hd.gate && col_ok) {
@@ -167,6 +168,9 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
       }
       if (row < TM) *reinterpret_cast<f32x4*>(zt + row * (NMAT * 4)) = z[j];
     }
+    float zg0 = 0.f, zg1 = 0.f;              // (this lane's rows of the upstream gradient, summed: the head's bias sums below)
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) { zg0 += z[j][0]; zg1 += z[j][1]; }
     s6_barrier();                            // the ELL slice is staged
 #pragma unroll
     for (int m = 1; m < NMAT; ++m) {
@@ -190,6 +194,15 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
       for (int j = 0; j < RPL; ++j) if (lane + 64 * j < TM) *reinterpret_cast<f32x4*>(zt + (lane + 64 * j) * (NMAT * 4) + m * 4) = z[j];
     }
     wave_lds_sync();
+    // The head's WEIGHT gradient rides here too (hd.wg_slab, nout <= 2; as in the 64-row chain, dss2_gemm_chain_sp.hip): dW_m[o][c] =
+    // sum_rows ((P^T)^m G)[row][o] h[row][c] needs what this block holds -- the hop results zt and the head's input rows h (= the gate
+    // rows ga) -- so the launch that re-read the [N, hid] activation for it (wgrad_narrow_stream_kernel: 18 us at C3) is not needed.
+    // Per lane: its NRP rows x 4 columns x NMAT x nout partial sums, then the 8 lanes that share the columns meet in wave-private LDS
+    // in row order: one slab per tile, [NMAT nout][hid] + nout bias sums, reduced with the step's other slabs (fixed order).
+    const bool wg = hd.wg_slab != nullptr && hd.gate != nullptr;
+    f32x4 hw[NMAT][2];
+#pragma unroll
+    for (int m = 0; m < NMAT; ++m) { hw[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; hw[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     f32x4 xv[NRP];
 #pragma unroll
     for (int i = 0; i < NRP; ++i) {
@@ -200,6 +213,10 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
         const f32x4 zz = *reinterpret_cast<const f32x4*>(zt + row * (NMAT * 4) + m * 4);
 #pragma unroll
         for (int o = 0; o < 4; ++o) v += wl[m][o] * zz[o];
+        if (wg && col_ok) {      // (rows beyond the tile: zz = 0; ga was read from a clamped row)
+          hw[m][0] += ga[i] * zz[0];
+          hw[m][1] += ga[i] * zz[1];
+        }
       }
       if (hd.gate) {
 #pragma unroll
@@ -210,6 +227,34 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
       else *reinterpret_cast<f32x4*>(hd.Xout + (size_t)(ts + row) * hd.ldxo + col0) = v;      // (the weight gradients read it)
       xv[i] = v;
     }
+    if (wg) {      // (uniform)
+      float* scr = hs + TM * 4;              // [64 lanes][NMAT 2][4]: behind zt / hs inside the wave's own region, before the planes go over it
+#pragma unroll
+      for (int m = 0; m < NMAT; ++m) {
+        *reinterpret_cast<f32x4*>(scr + (lane * (NMAT * 2) + 2 * m) * 4) = hw[m][0];
+        *reinterpret_cast<f32x4*>(scr + (lane * (NMAT * 2) + 2 * m + 1) * 4) = hw[m][1];
+      }
+      wave_lds_sync();
+      const int per = NMAT * 2 * 4;          // values per (row group, column group)
+      float* slab = hd.wg_slab + (size_t)tile * (hd.pad > 0 ? (size_t)hd.pad : (size_t)NMAT * nout * p.hout + nout);      // (pad: the slabs' stride in floats)
+      for (int idx = lane; idx < 8 * per; idx += 64) {
+        const int cqi = idx / per, rem = idx - cqi * per, mo = rem >> 2, q = rem & 3, m = mo >> 1, o = mo & 1;
+        float sum = 0.f;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) sum += scr[((g8 * 8 + cqi) * (NMAT * 2) + mo) * 4 + q];      // row groups r8 = 0 .. 7 in order
+        const int col = cg * 32 + cqi * 4 + q;
+        if (o < nout && col < p.hout) slab[(size_t)(m * nout + o) * p.hout + col] = sum;
+      }
+      if (wave == 0) {                       // bias sums: the upstream gradient's column sums over the tile's rows (a lane's rows first,
+        float sb0 = zg0, sb1 = zg1;          // then a butterfly over the 64 lanes: pairwise, fixed order)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { sb0 += __shfl_xor(sb0, d); sb1 += __shfl_xor(sb1, d); }
+        if (lane == 0) {
+          slab[(size_t)NMAT * nout * p.hout] = sb0;
+          if (nout > 1) slab[(size_t)NMAT * nout * p.hout + 1] = sb1;
+        }
+      }
+    }
     if constexpr (F16) {
       float mx = 0.f;
 #pragma unroll
@@ -219,7 +264,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
       s6_barrier();
       ea = tile_exponent();
     }
-    wave_lds_sync();                         // every lane is done with zt: the planes go over it
+    wave_lds_sync();                         // every lane is done with zt (and the scratch behind it): the planes go over it
 #pragma unroll
     for (int i = 0; i < NRP; ++i) {
       if constexpr (F16) s6_store_split_h<S6_PLANE>(own_planes + s6_off(r8 + 8 * i, cq), xv[i], ea);

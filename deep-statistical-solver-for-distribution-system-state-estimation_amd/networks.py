@@ -699,7 +699,7 @@ def _mpn_backward(mod, topo, saved, ps, meta, gout, need_dx, flat=None, pending=
         if head_fused:
             # ... and the head's weight gradient from the same staging (it holds the hop results and the head's input rows): one slab
             # per tile, summed with the step's other slabs; elsewhere the narrow weight-gradient launch re-reads the activation
-            hw_fused = chain_head_wgrad_supported(topo, nmat, hid, mod.dim_out) and acts[l].numel() > 0
+            hw_fused = chain_head_wgrad_supported(topo, nmat, hid, mod.dim_out)
             if hw_fused:
                 hw_len = nmat * mod.dim_out * hid + mod.dim_out
                 hw_stride = (hw_len + 3) & ~3      # (16-byte lanes in the reduction)

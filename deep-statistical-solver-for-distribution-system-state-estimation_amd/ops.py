@@ -157,7 +157,7 @@ def chain_head_supported(topo: Topology, nmat: int, hid: int, nout: int, transpo
 
 def chain_head_wgrad_supported(topo: Topology, nmat: int, hid: int, nout: int) -> bool:
     """True when the data-gradient chain with the fused head (mode 2) can also form the head's weight gradient in its staging
-    (dss2_chain_head.wg_slab, round 5): 64-row tiles, nout <= 2.  flags.CHAIN_HEAD_WGRAD = False: the narrow weight-gradient launch."""
+    (dss2_chain_head.wg_slab, round 5): 64-, 96- and 192-row tiles, nout <= 2.  flags.CHAIN_HEAD_WGRAD = False: the narrow weight-gradient launch."""
     return bool(FL.CHAIN_HEAD_WGRAD) and topo.ellT_tiles is not None and bool(
         _lib.lib().dss2_gemm_prop_chain_head_wgrad_supported(topo.nrb, nmat, hid, hid, topo.ellT, nout))
 

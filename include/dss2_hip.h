@@ -309,7 +309,7 @@ typedef struct dss2_chain_head {
   float* wg_slab;   /* mode 2, optional (round 5): the head's WEIGHT gradient from the same staging -- one slab per tile,
                      * [ntiles][nmat * nout * hid + nout] floats = [dW_0 .. dW_{nmat-1} ([nout][hid] each) | db], to be summed over the tiles
                      * (dss2_reduce_slabs*); `pad` > 0: the stride between the tiles' slabs in floats (a multiple of 4 lets the reduction use
-                     * 16-byte lanes).  Needs gate (the head's input rows) and nout <= 2 on 64-row tiles
+                     * 16-byte lanes).  Needs gate (the head's input rows) and nout <= 2 on 64-, 96- or 192-row tiles
                      * (dss2_gemm_prop_chain_head_wgrad_supported); NULL: not computed */
 } dss2_chain_head;
 int dss2_gemm_prop_chain_head(const dss2_gemm_prop_args* args_host, const dss2_chain_layer* layers_host, int n_layers,

@@ -61,12 +61,15 @@ def test_fused_head_equals_separate_launches(pkg, cls, args, B):
 @pytest.mark.parametrize("grid,args,B", [
     ("ober_sub", (8, 6, 2, 128, 4, 2, 0.0), 41),        # the C3 model on 96-row tiles, odd tile count
     ("ober_sub", (8, 6, 3, 128, 4, 2, 0.3), 20),        # dim_out 3, dropout mask on the head's input
+    ("ober_sub", (8, 6, 2, 128, 4, 2, 0.3), 23),        # dim_out 2 with dropout: the head's weight gradient reads the masked rows
+    ("ober179", (8, 6, 1, 128, 3, 2, 0.3), 7),          # dim_out 1 on 192-row tiles
     ("ober179", (8, 6, 2, 128, 4, 2, 0.0), 12),         # 192-row tiles (three rows per lane in the head's hop phase)
     ("ober179", (8, 6, 4, 96, 3, 1, 0.3), 9),           # K = 1, dim_out 4, three column groups
 ])
 def test_tall_tile_backward_head_equals_separate_launches(pkg, grid, args, B):
     """96- / 192-row tiles: only the BACKWARD head rides in the chain (gemm_chain_sp6_kernel<NRB, NMAT, 2, 2>: the data-gradient
-    chain's input tile built in its staging); the forward head keeps its launch whatever the switch says."""
+    chain's input tile built in its staging, and with it the head's weight gradient for nout <= 2); the forward head keeps its
+    launch whatever the switch says."""
     b = pkg.synthetic.make_batch([grid], B, seed=4)
     torch.manual_seed(0)
     model = pkg.MPN(*args).to(DEV)
@@ -80,7 +83,19 @@ def test_tall_tile_backward_head_equals_separate_launches(pkg, grid, args, B):
     assert torch.equal(got[0], ref[0])                                   # the forward is the same launches
     assert torch.equal(got[1], again[1])
     assert rel_err(got[1], ref[1]) < 1e-5
+    # ... and, for heads up to 2 wide, the head's WEIGHT gradient from the same staging (one slab per tile) instead of the narrow launch
+    assert bool(pkg.ops.chain_head_wgrad_supported(topo, args[5] + 1, args[3], args[2])) == (args[2] <= 2)
+    head_bias = f"convs.{args[4] - 1}.bias"
     for g, r, (n, _) in zip(got[2], ref[2], model.named_parameters()):
+        if n == head_bias and args[2] <= 2:
+            # cancelling column sums of linspace(-1, 1) (see test_fused_head_equals_separate_launches): +-0.5001 out of a sum of magnitudes of
+            # N / 2; the two launches' fp32 summation orders each carry a few eps of THAT sum (observed: 1.8e-4 apart at N = 2148, the exact
+            # value 0.500116 between them)
+            assert (g - r).abs().max().item() <= 4e-7 * b["x"].shape[0] / 2, n
+            exact = b["x"].shape[0] / (2.0 * b["x"].shape[0] - 1.0) if args[2] == 2 else None      # column 1 of linspace(-1, 1, 2 N) laid out [N, 2]
+            if exact is not None:
+                assert abs(abs(g[1].item()) - exact) <= 4e-7 * b["x"].shape[0] / 2, (g, exact)
+            continue
         assert rel_err(g, r) < 1e-5, n
 
 
