@@ -135,7 +135,7 @@ OTHER_CONFIGS = [
     ("C2 shape, B=32768 on one GPU (cache-busting)", ["cigre14"], 32768, "MPN", (8, 6, 2, 128, 4, 2, 0.0), (15, 14), 1),
     ("driver line: SkipPFN H=32 8 layers x 5 blocks, dropout 0.3, B=4096", ["cigre14"], 4096, "SkipPFN", (8, 6, 2, 32, 8, 2, 0.3, 5), (15, 14), 5),
     # the reference driver's other branch (dss2_run.py:51-53: Oberrhein; 70 buses => 96-row tiles).  The whole-stack kernels cover <= 64-row
-    # tiles only (their backward takes 130 KB of LDS at 64 rows; 96 rows would need ~226 KB: DESIGN section 9), so these run the per-block
+    # tiles only (their backward takes 158 of the CU's 160 KB of LDS at 64 rows; 96 rows would need ~226 KB: DESIGN section 9), so these run the per-block
     # kernels -- timed here so that the gap is a number
     ("driver line on ober_sub: SkipPFN H=32 8 layers x 5 blocks, dropout 0.3, B=64", ["ober_sub"], 64, "SkipPFN", (8, 6, 2, 32, 8, 2, 0.3, 5), (70, 69), 5),
     ("driver line on ober_sub: SkipPFN H=32 8 layers x 5 blocks, dropout 0.3, B=1024", ["ober_sub"], 1024, "SkipPFN", (8, 6, 2, 32, 8, 2, 0.3, 5), (70, 69), 5),

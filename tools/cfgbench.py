@@ -13,7 +13,7 @@ CFG = [("C1 cigre14 B=64 H=32 L=1", ["cigre14"], 64, "MPN", (8, 6, 2, 32, 1, 2, 
        ("C5 shard mixed B=4096 H=256 L=8", ["cigre14", "cigre14_reswitched"], 4096, "MPN", (8, 6, 2, 256, 8, 2, 0.0)),
        ("C2-size cache-busting B=32768", ["cigre14"], 32768, "MPN", (8, 6, 2, 128, 4, 2, 0.0)),
        ("SkipPFN driver line B=4096 H=32 gnn=8 L=5", ["cigre14"], 4096, "SkipPFN", (8, 6, 2, 32, 8, 2, 0.0, 5)),
-       ("SkipPFN driver line on ober_sub B=1024 H=32 gnn=8 L=5", ["ober_sub"], 1024, "SkipPFN", (8, 6, 2, 32, 8, 2, 0.3, 5))]
+       ("SkipPFN driver line on ober_sub B=1024 H=32 gnn=8 L=5", ["ober_sub"], 1024, "SkipPFN", (8, 6, 2, 32, 8, 2, 0.0, 5))]
 sel = sys.argv[1:] 
 for name, grids, B, cls, args in CFG:
     if sel and not any(s in name for s in sel):
