@@ -493,6 +493,14 @@ def main():
                 "algorithmic_flops_per_launch": wflops, "traffic": None,
                 "peak_pipe": (f"fp16 / bf16 MFMA dense peak (2500 TF) / {int(wprod)} instructions per fp32 product" if wbf16 else "fp32 MFMA"),
             }
+            try:   # (a pointer to the committed rocprofv3 --pmc passes, as for the chain above; the f16x3 kernel of the C2 shape only)
+                if wf16 and nl == 3:
+                    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                        wrec = json.load(fh)["wgrad16h_kernel<3,true> (3 layers in one launch)"]
+                    result["roofline_wgrad"].update(traffic=wrec["hbm_bytes_per_launch"], traffic_source=wrec.get("source"),
+                                                    algorithmic_bytes_per_launch=wrec.get("algorithmic_bytes_per_launch"))
+            except Exception:
+                pass
         if bf16x6:
             # The tile GEMM runs on the 16-bit matrix pipe: as f16x3 (round 5: operands as TWO fp16 pieces after an exact power-of-two
             # scale, THREE v_mfma_f32_16x16x32_f16 per fp32 product group; csrc/dss2_gemm_chain_sp.hip MS = 2) where the chain has the
