@@ -241,25 +241,36 @@ __global__ void __launch_bounds__(LB) wls_partials_kernel(const dss2_wls_args p)
   if ((threadIdx.x & 63) == 0)
     for (int c = 0; c < 5; ++c) red[w][c] = acc[c];
   __syncthreads();
+  const bool fused = (p.flags & DSS2_WLS_FUSED_FINISH) != 0;
+  typedef __attribute__((address_space(1))) unsigned long long gu64;
+  typedef __attribute__((address_space(1))) unsigned gu32;
   if (threadIdx.x < 5) {
     double s = 0;
     for (int k = 0; k < LB / 64; ++k) s += red[k][threadIdx.x];
-    p.partials[(size_t)blockIdx.x * 5 + threadIdx.x] = s;
+    // fused finish: the partial is PUBLISHED -- stored write-through at agent scope, so that it is in memory (not in this XCD's L2,
+    // which the other XCDs do not see) when the arrival below is counted
+    if (fused) __hip_atomic_store((gu64*)(p.partials + (size_t)blockIdx.x * 5 + threadIdx.x), (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else p.partials[(size_t)blockIdx.x * 5 + threadIdx.x] = s;
   }
-  if (!(p.flags & DSS2_WLS_FUSED_FINISH)) return;
-  // ---- the last workgroup to arrive finishes: fixed-order sum over the workgroups (independent of WHICH one is last)
+  if (!fused) return;
+  // ---- the last workgroup to arrive finishes: fixed-order sum over the workgroups (independent of WHICH one is last).
+  // No release fence: a device-scope fence per workgroup writes back its XCD's whole L2 on MI355X (the first form of this path:
+  // 28 us at N = 61 440 against 10 + 4.7 us for two launches).  Here nothing but the five partials is handed over, and those go
+  // through memory on both sides: write-through stores, drained (s_waitcnt vmcnt(0)) before the workgroup's arrival is counted by
+  // a RELAXED agent-scope atomic; the last workgroup reads them with agent-scope atomic loads (no stale line of an earlier step in
+  // its own L2 / L1 can answer).  The hand-off scheme of round 5's merged weight-space launches (HISTORY), without anybody polling.
   __shared__ unsigned last_flag;
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) last_flag = atomicAdd(p.counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+  if (threadIdx.x == 0) last_flag = __hip_atomic_fetch_add((gu32*)p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
   if (!last_flag) return;
-  __threadfence();
   __shared__ double tot[5];
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;      // LB = 256: waves 0..3 take columns 0..3, wave 0 also column 4
   for (int col = c; col < 5; col += LB / 64) {
     double s = 0;
-    for (int b = lane; b < (int)gridDim.x; b += 64) s += __builtin_nontemporal_load(p.partials + (size_t)b * 5 + col);
+    for (int b = lane; b < (int)gridDim.x; b += 64)
+      s += __longlong_as_double((long long)__hip_atomic_load((const gu64*)(p.partials + (size_t)b * 5 + col), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) { p.sums[col] = s; tot[col] = s; }
   }
@@ -269,7 +280,7 @@ __global__ void __launch_bounds__(LB) wls_partials_kernel(const dss2_wls_args p)
     p.sums[5] = Nn; p.sums[6] = Ee; p.sums[7] = 0;
     const double mv = tot[2] / Nn, mt = tot[3] / Ee, ml = tot[4] / Ee;
     p.loss[0] = (float)(tot[0] / Nn + tot[1] / Ee + lr * mv * mv + lr * mt * mt + lr * ml * ml);
-    *p.counter = 0u;      // ready for the next launch (a hipGraph replay included)
+    __hip_atomic_store((gu32*)p.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch (a hipGraph replay included)
   }
 }
 

@@ -24,6 +24,7 @@ import torch
 
 
 from . import _lib
+from . import flags as FL
 from .networks import _F32, _require_gpu, _rows, _stream
 from .topology import Topology, get_topology
 
@@ -158,9 +159,9 @@ class _WlsFn(torch.autograd.Function):
         }
         a = _fill_args(topo, input, edge_input, (output, output.stride(0)), node_param, edge_param,
                        x_mean, x_std, edge_mean, edge_std, reg_coefs, bufs)
-        # (the in-kernel finish needs a device-scope fence per workgroup = an L2 write-back on MI355X: it only pays when the
-        #  grid is a handful of workgroups; bigger batches run the one-workgroup finish launch, which writes the loss too)
-        a.flags = (_lib.WLS_FUSED_FINISH if nb <= 16 else 0) | (_lib.WLS_VMM_CACHED if vmm_valid else 0)
+        # (up to 16 workgroups the last one of the partials launch finishes the sums and writes the loss; bigger batches run the
+        #  one-workgroup finish launch, which costs what 240 arrivals on one counter word cost -- FL.WLS_FUSED_FINISH: fused at any size)
+        a.flags = (_lib.WLS_FUSED_FINISH if (nb <= 16 or FL.WLS_FUSED_FINISH) else 0) | (_lib.WLS_VMM_CACHED if vmm_valid else 0)
         a.counter = _counter(dev).data_ptr()
         st = _stream(output)
         L = _lib.lib()

@@ -25,6 +25,10 @@ FOLD_W2 = _os.environ.get("DSS2_FOLD_W2", "1") == "1"   # 0 = run the edge MLP's
 # ... and on 32-row tiles as f16x3: two fp16 pieces per operand after a power-of-two scale, three MFMAs per product instead of six
 # (csrc/dss2_wgrad16h.hip, round 5; errors of the size of fp32 arithmetic itself).  0 = bf16x6 there too.
 WGRAD_F16 = _os.environ.get("DSS2_WGRAD_F16", "1") == "1"
+# 1 = the loss's batch sums are finished by the last workgroup of the partials launch at every batch size (no finish launch; bitwise the
+# same sums).  Off above 16 workgroups: at C2 the 240 arrivals on one counter word (~12 ns each) and the last workgroup's round trip cost
+# what the 4.65 us finish launch costs -- A/B on one box 0.4047 / 0.4017 ms fused against 0.4022 / 0.3979 (end of round 5)
+WLS_FUSED_FINISH = _os.environ.get("DSS2_WLS_FUSED_FINISH", "0") == "1"
 WGRAD_TM32 = _os.environ.get("DSS2_WGRAD_TM32", "1") == "1"      # bf16x6 weight gradient on 32-row tiles, two workgroups per CU (wgrad16b_kernel)
 WGRAD_TM32_MAX_BYTES = 64 << 20      # ... while one layer's input (N * hin * 4 bytes) stays well inside the Infinity Cache
 WGRAD_PER_CU = int(_os.environ.get("DSS2_WGRAD_PER_CU", "2"))   # cap on persistent wgrad workgroups per CU (= slabs / 256)

@@ -466,11 +466,11 @@ typedef struct dss2_wls_args {
 } dss2_wls_args;
 #define DSS2_WLS_VMM_CACHED 1     /* vminmax[] already holds this node_param's partial (min, max) pairs: no vminmax launch */
 #define DSS2_WLS_FUSED_FINISH 2   /* the LAST workgroup of the partials kernel to finish sums the workgroup partials in a
-                                     fixed order into sums[0..7] and writes the (local-batch) loss: no finish launch.  Pays
-                                     only for small batches: every workgroup needs a device-scope release fence, which on
-                                     MI355X writes back its XCD's L2 (measured at N = 61 440: 28 us against 10 + 4.7 us for
-                                     the two-launch form, which also writes sums[] and loss[0]; the Python side uses this
-                                     flag below 16 workgroups only) */
+                                     fixed order into sums[0..7] and writes the (local-batch) loss: no finish launch (same
+                                     summation order, same bits).  The partials are handed over through memory (write-through
+                                     stores, a relaxed agent-scope arrival count, agent-scope loads in the last workgroup): no
+                                     release fence -- on MI355X that would write back an XCD's whole L2 per workgroup (the
+                                     first form of this path: 28 us at N = 61 440 against 10 + 4.7 us for two launches) */
 #define DSS2_WLS_NO_LOSS_WRITE 4  /* dss2_wls_loss_grad leaves loss[0] alone */
 
 int dss2_wls_loss_partials(const dss2_wls_args* args_host, void* stream);

@@ -567,3 +567,34 @@ def test_tall_tiles_matrix_sequential(pkg, oracle, hid, L, K):
     assert abs(loss.item() - l64.item()) <= TOL_LOSS * abs(l64.item())
     for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
         assert rel_err(p.grad, q.grad) < 2e-5, n
+
+
+def test_fused_loss_finish_is_bitwise_the_two_launch_form_under_repetition(pkg, oracle):
+    """data.py:443-459's five batch sums: the LAST workgroup of the partials launch sums the workgroups' partials (DSS2_WLS_FUSED_FINISH;
+    handed over through memory without a release fence, csrc/dss2_loss.hip).  Same summation order as the one-workgroup finish launch,
+    so the loss and its gradient must agree bit for bit -- on every one of many repetitions with changing outputs (a stale partial of
+    an earlier launch in some L2, or an arrival counted before its partial has landed, would show as a wrong sum now and then)."""
+    b = pkg.synthetic.make_batch(["cigre14"], 4096, seed=2)        # 240 workgroups in the partials launch
+    x, ei, ea = b["x"].to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    st = tuple(s.to(DEV) for s in b["stats"])
+    torch.manual_seed(1)
+    outs = [torch.randn(x.shape[0], 2, device=DEV) * (0.1 + 0.05 * i) for i in range(8)]
+
+    def run(o):
+        o_leaf = o.clone().requires_grad_(True)
+        loss = _loss(pkg.data, x, ei, ea, st, o_leaf * 1.0, oracle.DEFAULT_REG_COEFS)
+        loss.backward()
+        return loss.detach().clone(), o_leaf.grad.clone()
+    old = pkg.flags.WLS_FUSED_FINISH
+    try:
+        pkg.flags.WLS_FUSED_FINISH = False
+        want = [run(o) for o in outs]
+        pkg.flags.WLS_FUSED_FINISH = True
+        for rep in range(150):
+            i = rep % len(outs)
+            got = run(outs[i])
+            assert torch.equal(got[0], want[i][0]) and torch.equal(got[1], want[i][1]), (rep, got[0].item(), want[i][0].item())
+    finally:
+        pkg.flags.WLS_FUSED_FINISH = old
+    ref = _referee_loss(oracle, b["x"].double(), b["edge_attr"].double(), outs[0].double().cpu(), tuple(s.double() for s in b["stats"]), b["edge_index"])
+    assert abs(want[0][0].item() - ref.item()) <= 1e-5 * abs(ref.item())
