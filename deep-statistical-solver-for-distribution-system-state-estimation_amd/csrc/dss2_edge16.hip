@@ -352,6 +352,19 @@ __global__ void __launch_bounds__(512) edge16_bwd_kernel(const EdgeTileArgs p) {
         gS[rb][r] = row < R ? p.dS[(int64_t)(ts + row) * p.h + j] : 0.f;
         if (WITH_U) Uacc[rb][r] = 0.f;
       }
+    // dS is split into its three bf16 planes ONCE per tile (pairs of consecutive registers, the pairing of the weight-gradient product's
+    // A fragments below); a slot then gates the PLANES with 16-bit masks -- 4 vector instructions per element and slot instead of the
+    // 7.5 of selecting the gated value and splitting it again.  split3(gate ? g : 0) = gate ? split3(g) : 0 plane by plane: same bits.
+    // (where the planes fit beside everything else: not with U -- the fp32 values stay live for it -- and not at 96 rows: 26 / 8 spilled
+    //  registers otherwise)
+    constexpr bool PRE = !WITH_U && NRB <= 2;
+    uint32_t gh[PRE ? NRB : 1][8], gm[PRE ? NRB : 1][8], gl[PRE ? NRB : 1][8];
+    if constexpr (PRE) {
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split3_pair(gS[rb][2 * j], gS[rb][2 * j + 1], gh[rb][j], gm[rb][j], gl[rb][j]);
+    }
     __syncthreads();
     e16_bwd_build_tile<NRB>(B, tid, nthreads);
     f32x16 ci[NRB];
@@ -365,19 +378,31 @@ __global__ void __launch_bounds__(512) edge16_bwd_kernel(const EdgeTileArgs p) {
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb) {
         const f32x16 c = e16_z<NRB>(L, w, 0, rb, c32, half, ci[rb]);
-        f32x16 dz;
+        [[maybe_unused]] uint32_t mk[8];      // (PRE) the gates of registers (2 j, 2 j + 1) as a mask over the two bf16 halves of a plane word
+        [[maybe_unused]] f32x16 dz;
+        if constexpr (PRE) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          dz[r] = c[r] > 0.f ? gS[rb][r] : 0.f;
-          if (WITH_U) Uacc[rb][r] += dz[r];
+          for (int j = 0; j < 8; ++j) mk[j] = (c[2 * j] > 0.f ? 0x0000ffffu : 0u) | (c[2 * j + 1] > 0.f ? 0xffff0000u : 0u);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            dz[r] = c[r] > 0.f ? gS[rb][r] : 0.f;
+            if (WITH_U) Uacc[rb][r] += dz[r];
+          }
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
           uint4 ah, am, al;
-          split3_pair(dz[8 * st + 0], dz[8 * st + 1], ah.x, am.x, al.x);
-          split3_pair(dz[8 * st + 2], dz[8 * st + 3], ah.y, am.y, al.y);
-          split3_pair(dz[8 * st + 4], dz[8 * st + 5], ah.z, am.z, al.z);
-          split3_pair(dz[8 * st + 6], dz[8 * st + 7], ah.w, am.w, al.w);
+          if constexpr (PRE) {
+            ah = uint4{gh[rb][4 * st] & mk[4 * st], gh[rb][4 * st + 1] & mk[4 * st + 1], gh[rb][4 * st + 2] & mk[4 * st + 2], gh[rb][4 * st + 3] & mk[4 * st + 3]};
+            am = uint4{gm[rb][4 * st] & mk[4 * st], gm[rb][4 * st + 1] & mk[4 * st + 1], gm[rb][4 * st + 2] & mk[4 * st + 2], gm[rb][4 * st + 3] & mk[4 * st + 3]};
+            al = uint4{gl[rb][4 * st] & mk[4 * st], gl[rb][4 * st + 1] & mk[4 * st + 1], gl[rb][4 * st + 2] & mk[4 * st + 2], gl[rb][4 * st + 3] & mk[4 * st + 3]};
+          } else {
+            split3_pair(dz[8 * st + 0], dz[8 * st + 1], ah.x, am.x, al.x);
+            split3_pair(dz[8 * st + 2], dz[8 * st + 3], ah.y, am.y, al.y);
+            split3_pair(dz[8 * st + 4], dz[8 * st + 5], ah.z, am.z, al.z);
+            split3_pair(dz[8 * st + 6], dz[8 * st + 7], ah.w, am.w, al.w);
+          }
           const char* bp = bcol + rb * 64 + 32 * st + 16 * half;
           const uint4 z4 = {0u, 0u, 0u, 0u};
           const uint4 bh = bcol_ok ? *reinterpret_cast<const uint4*>(bp) : z4;
