@@ -11,10 +11,10 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # the feature and says so; that line is filtered.
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
 NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"
-NOPK_SRCS="${DSS2_NOPK_SRCS-dss2_gemm_chain16 dss2_gemm_chain_sp dss2_gemm_chain_sp6 dss2_wgrad16 dss2_wgrad16h dss2_stack dss2_edge16}"      # (DSS2_NOPK_SRCS="" builds the diagnostic library WITH packed ops everywhere)
+NOPK_SRCS="${DSS2_NOPK_SRCS-dss2_gemm_chain16 dss2_gemm_chain_sp dss2_gemm_chain_sp6 dss2_wgrad16 dss2_wgrad16h dss2_wgrad16th dss2_stack dss2_edge16}"      # (DSS2_NOPK_SRCS="" builds the diagnostic library WITH packed ops everywhere)
 mkdir -p "$OBJ"
 pids=()
-for src in dss2_api dss2_stack dss2_gemm_prop dss2_gemm_chain dss2_gemm_chain16 dss2_gemm_chain_sp dss2_gemm_chain_sp6 dss2_edge dss2_edge16 dss2_wgrad dss2_wgrad16 dss2_wgrad16h dss2_loss dss2_optim dss2_dataset dss2_topology; do
+for src in dss2_api dss2_stack dss2_gemm_prop dss2_gemm_chain dss2_gemm_chain16 dss2_gemm_chain_sp dss2_gemm_chain_sp6 dss2_edge dss2_edge16 dss2_wgrad dss2_wgrad16 dss2_wgrad16h dss2_wgrad16th dss2_loss dss2_optim dss2_dataset dss2_topology; do
   if [ ! -f "$OBJ/$src.o" ] || [ "$HERE/$src.hip" -nt "$OBJ/$src.o" ] || [ "$HERE/dss2_common.hpp" -nt "$OBJ/$src.o" ] || [ "$HERE/dss2_gemm_chain_kernel.hpp" -nt "$OBJ/$src.o" ] || [ "$HERE/dss2_weightspace.hpp" -nt "$OBJ/$src.o" ] || [ "$HERE/dss2_wgrad_batch.hpp" -nt "$OBJ/$src.o" ] || [ "$HERE/dss2_edge_tile.hpp" -nt "$OBJ/$src.o" ] || [ "$ROOT/include/dss2_hip.h" -nt "$OBJ/$src.o" ]; then
     extra=""; case " $NOPK_SRCS " in *" $src "*) extra="$NOPK";; esac
     $HIPCC $FLAGS $extra "$@" -c "$HERE/$src.hip" -o "$OBJ/$src.o" 2> >(grep -v "is not a recognized feature for this target" >&2) &

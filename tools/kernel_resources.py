@@ -8,7 +8,7 @@ import tempfile
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", f"-I{ROOT}/include",
        f"-I{os.path.dirname(os.path.abspath(src))}", "-c", src, "-o", tempfile.mktemp(suffix=".o", prefix="_kr"),
        "-Rpass-analysis=kernel-resource-usage"] + sys.argv[2:]
-if os.path.basename(src) in ("dss2_gemm_chain16.hip", "dss2_gemm_chain_sp.hip", "dss2_gemm_chain_sp6.hip", "dss2_wgrad16.hip", "dss2_wgrad16h.hip", "dss2_stack.hip", "dss2_edge16.hip"):      # as csrc/build.sh compiles it
+if os.path.basename(src) in ("dss2_gemm_chain16.hip", "dss2_gemm_chain_sp.hip", "dss2_gemm_chain_sp6.hip", "dss2_wgrad16.hip", "dss2_wgrad16h.hip", "dss2_wgrad16th.hip", "dss2_stack.hip", "dss2_edge16.hip"):      # as csrc/build.sh compiles it
     cmd += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
