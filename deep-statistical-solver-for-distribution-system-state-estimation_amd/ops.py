@@ -260,20 +260,24 @@ def _wgrad_tiles(topo: Topology, nmat: int, hout: int, hin: int, b16: int):
     return topo
 
 
-def _wgrad_mode(ts, nmat: int, b16: int) -> int:
+def _wgrad_mode(ts, nmat: int, b16: int, hinted: bool = False) -> int:
     """args.mfma_bf16 of a weight-gradient launch on the tile set ``ts``: 0 fp32 MFMA, 1 bf16x6, or -- flags.WGRAD_F16 on 32-row tiles
     (csrc/dss2_wgrad16h.hip) and on 96-row tiles (csrc/dss2_wgrad16th.hip) with ELL slices -- 2 | hb << 8: the f16x3 kernels
     with hb headroom bits for the gain of the propagation hops, ceil(log2(max row sum of |P^T| ^ K)), read from the ELL slices once per
-    tile set (one device-to-host copy, cached).  Shapes the f16x3 kernels do not cover run bf16x6 on the same value (the library decides)."""
+    tile set (one device-to-host copy, cached; ``hinted``: from the ELL width alone, no copy).  Shapes the f16x3 kernels do not cover run bf16x6 on the same value (the library decides)."""
     if not (b16 and FL.WGRAD_F16 and ts.nrb in (1, 3) and nmat in (2, 3) and ts.ellT_tiles is not None and 1 <= ts.ellT <= 8):
         return b16
     cache = ts.__dict__.setdefault("_f16_gain_bits", {})
     hb = cache.get(nmat)
     if hb is None:
-        if torch.cuda.is_current_stream_capturing():
-            return b16            # (first met inside a capture: no copy to the host there; the warm-up steps normally fill the cache)
-        w = ts.ellT_tiles[..., 1].contiguous().view(torch.float32)      # [tiles][width][rows]: the entries' weights
-        gain = max(float(w.abs().sum(dim=1).max()), 1.0)
+        if hinted or torch.cuda.is_current_stream_capturing():
+            # no copy to the host here (a topology built from a TopologyHint never reads anything back; neither may a capture): the
+            # bound that needs no data -- gcn_norm weights are <= 1, a row of P^T has at most ellT entries -- costs the smallest
+            # elements a bit or two of their 22 and is kept for the life of the tile set (same bits every step)
+            gain = float(max(int(ts.ellT), 1))
+        else:
+            w = ts.ellT_tiles[..., 1].contiguous().view(torch.float32)      # [tiles][width][rows]: the entries' weights
+            gain = max(float(w.abs().sum(dim=1).max()), 1.0)
         hb = cache[nmat] = max(0, int(math.ceil(math.log2(gain) * (nmat - 1) - 1e-6)))
     return (2 | (hb << 8)) if hb <= 10 else b16
 
@@ -302,7 +306,7 @@ def wgrad(topo: Topology, G: torch.Tensor, hout: int, X: torch.Tensor, hin: int,
     a.tile_start = ts.tile_start.data_ptr()
     a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), ts.max_nnzT
     a.ell_width, a.ell_tiles = ts.ellT, _ptr(ts.ellT_tiles)
-    a.narrow, a.mfma_bf16 = int(narrow), (_wgrad_mode(ts, nmat, b16) if (not narrow and rowscale is None) else b16)
+    a.narrow, a.mfma_bf16 = int(narrow), (_wgrad_mode(ts, nmat, b16, getattr(topo, "hint", None) is not None) if (not narrow and rowscale is None) else b16)
     st = _stream(G)
     _lib.check(_lib.lib().dss2_wgrad(C.byref(a), st), "dss2_wgrad")
     _reduce(slab, 0, n_split, stride, out_flat, stride if out_len is None else out_len, pending)
@@ -330,7 +334,7 @@ def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Seq
         if g_.stride(0) != a.ldg or x_.stride(0) != a.ldx or g_.shape != Gs[0].shape or x_.shape != Xs[0].shape:
             raise ValueError("wgrad_batched: layers must share shapes and leading dimensions")
     a.n_split, a.nmat, a.nrb, a.ntiles = n_split, nmat, ts.nrb, ts.ntiles
-    a.mfma_bf16 = _wgrad_mode(ts, nmat, int(FL.WGRAD_BF16))
+    a.mfma_bf16 = _wgrad_mode(ts, nmat, int(FL.WGRAD_BF16), getattr(topo, "hint", None) is not None)
     a.tile_start = ts.tile_start.data_ptr()
     a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), ts.max_nnzT
     a.ell_width, a.ell_tiles = ts.ellT, _ptr(ts.ellT_tiles)

@@ -131,8 +131,10 @@ def test_hinted_build_needs_no_host_sync_and_equals_the_oracle(pkg, grids, B):
                                      max_edges_per_graph=max(g.e for g in (pkg.synthetic.load_grid(n) for n in grids)))
     ei_d = ei.to(DEV)
     x, ea = b["x"].to(DEV), b["edge_attr"].to(DEV)
-    model = pkg.MPN(8, 6, 2, 32, 3, 2, 0.0).to(DEV)
-    model(x[:, :8], ei_d, ea[:, :6]).sum().backward()             # warm-up: plans, allocator
+    # (dim_hid 32: the whole-stack kernels / the fp32 fallbacks; 128: the f16x3 routes, whose headroom bits must come without a copy too)
+    models = [pkg.MPN(8, 6, 2, 32, 3, 2, 0.0).to(DEV), pkg.MPN(8, 6, 2, 128, 4, 2, 0.0).to(DEV)]
+    for model in models:
+        model(x[:, :8], ei_d, ea[:, :6]).sum().backward()         # warm-up: plans, allocator
     pkg.topology.clear_cache()
     torch.cuda.synchronize()
     torch.cuda.set_sync_debug_mode("error")
@@ -140,8 +142,9 @@ def test_hinted_build_needs_no_host_sync_and_equals_the_oracle(pkg, grids, B):
         topo = pkg.topology.Topology(ei_d, N, hint=hint)
         pkg.topology.register_topology(ei_d, N, topo)
         topo.nrb                                                   # builds the tile part
-        out = model(x[:, :8], ei_d, ea[:, :6])
-        out.sum().backward()
+        for model in models:
+            out = model(x[:, :8], ei_d, ea[:, :6])
+            out.sum().backward()
     finally:
         torch.cuda.set_sync_debug_mode("default")
     torch.cuda.synchronize()
