@@ -812,7 +812,7 @@ static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::Wg
     }
   }
   if (wgrad16h_covers(a)) return launch_wgrad16h(a, as_stream(stream), wb);        // f16x3 kernel (dss2_wgrad16h.hip): args.mfma_bf16 & 255 == 2, 32-row tiles
-  if (wgrad16th_covers(a)) return launch_wgrad16th(a, as_stream(stream), wb);      // f16x3 kernel of 96-row tiles (dss2_wgrad16th.hip)
+  if (wgrad16th_covers(a)) return launch_wgrad16th(a, as_stream(stream), wb);      // f16x3 kernel of 96- / 192-row tiles (dss2_wgrad16th.hip)
   if (wgrad16_covers(a)) return launch_wgrad16(a, as_stream(stream), wb);          // bf16x6 kernel (dss2_wgrad16.hip)
   const int nb = pick_nb(a.nrb, a.nmat, a.hout, a.max_nnz, a.ell_width);
   if (!nb) { set_error("wgrad: tile of %d rows does not fit LDS (nmat=%d nnz=%d)", a.nrb * 32, a.nmat, a.max_nnz); return 3; }

@@ -1,4 +1,4 @@
-// Weight gradient of TAGConv on 96-row tiles (graphs of 65 .. 96 nodes: C3) as f16x3 (end of round 5).
+// Weight gradient of TAGConv on 96- and 192-row tiles (graphs of 65 .. 96 / 161 .. 192 nodes: C3, the 179-bus feeder) as f16x3 (end of round 5).
 //   dW_m = (P^m G)^T X,  db = colsum(G)   -- contract, slab layout, thread maps and phases of wgrad16t_kernel (dss2_wgrad16.hip): the
 //   propagation needs the whole graph, so P G of the WHOLE tile is kept in fp32; the contraction over rows is cut into chunks of 32
 //   rows, whose transposed planes (G, P G, P^2 G, X) feed the matrix pipe.
@@ -12,8 +12,11 @@
 //     ELL slice; when a running exponent grows the accumulators are rescaled (v_ldexp, exact); G, P G, P^2 G carry hb headroom
 //     bits for the gain of the hops (args.mfma_bf16 bits 8..15, from the host: ops._wgrad_mode);
 //   * the slab is written with the scales taken out.
-// C3 (ober_sub, B = 1024): 210.4 -> 173.8 us for the three layers (rocprofv3, one box).  At 192 rows the same kernel holds 12 row pieces
-// of X per thread, spills 19 registers and measures 463 us against 457 for bf16x6: taller tiles keep dss2_wgrad16.hip's kernel.
+// C3 (ober_sub, B = 1024): 210.4 -> 173.8 us for the three layers (rocprofv3, one box).
+//   * 192 rows (PC): twelve row pieces of X per thread do not fit (19 spilled registers, 463 us against 457 for bf16x6), so there the X
+//     rows stay one CHUNK ahead and X gets an exponent per chunk -- one partial per wave at the top of the chunk, one more barrier
+//     (A) between building the G-side planes and splitting X; with two sets of planes that is two barriers per chunk, what the
+//     bf16x6 kernel pays at this height with one set.  179-bus feeder, B = 1024: 462.8 -> 384.7 us, step 1.478 -> 1.408 ms.
 // Errors of the size of fp32 arithmetic's own rounding (tests/test_gpu_f16x3.py).  Same inputs, same bits.
 // Built without packed fp32 VALU ops like the other MFMA-beside-VALU translation units (build.sh).
 #include <stdlib.h>
@@ -40,7 +43,7 @@ __device__ __forceinline__ void store_planes_h2(char* img, int off0, const f32x4
   }
 }
 
-template <int NRB, int NMAT, bool RS2>
+template <int NRB, int NMAT, bool RS2, bool PC>
 __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_args p, int nibg, const WgradBatch wb, int hb) {
   constexpr int TR = 32 * NRB, ZC = W16TH_ZC, XW = W16TH_XW, NT = W16TH_NT, LDZF = W16TH_LDZF;
   constexpr int PLANES = NMAT * 2 * ZC * 64 + 2 * XW * 64;
@@ -57,7 +60,7 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
   int2* ell = reinterpret_cast<int2*>(U + UBYTES);                // [Dp][TR]
   int pb = 0;                                                     // the set the next chunk writes
   const int D = p.ell_width, Dp = (D + 3) & ~3;
-  float* mxp = reinterpret_cast<float*>(ell + Dp * TR);           // [2][8 waves]: max |X|, max |G| of the tile whose rows wait in registers
+  float* mxp = reinterpret_cast<float*>(ell + Dp * TR);           // [2][8 waves]: max |X|, max |G| of the tile whose rows wait in registers (PC: max |X| of the chunk)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, c32 = lane & 31, half = lane >> 5;
@@ -97,7 +100,10 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
   //  the row scales are 12-byte loads -- the dead fourth component's register was reused while the load was in flight -- and
   //  tile_start is read one tile ahead of the loads it addresses: profiles/experiments/r05_wgrad16h_phase_stamps.txt)
   typedef float f32x3_t __attribute__((ext_vector_type(3)));
-  f32x4 pgw[NRB], px[NRB][2], pgc[2];      // px: the X rows of ALL the tile's chunks (requested a whole tile ahead: the tile's maximum needs them)
+  // px: the X rows of ALL the tile's chunks, requested a whole tile ahead (the tile's maximum needs them) -- or (PC, 192 rows: twelve
+  // row pieces per thread do not fit) of ONE chunk, requested a chunk ahead, with a maximum and one more barrier per chunk
+  constexpr int NPX = PC ? 1 : NRB;
+  f32x4 pgw[NRB], px[NPX][2], pgc[2];
   f32x3_t prs[PRS ? NRB : 1];
   int2 pel[NEL];
   const uint32_t gw_col = gcol_ok ? (uint32_t)(4 * q16) * 4u : 0u, gc_col = zcol_ok ? (uint32_t)(4 * cg) * 4u : 0u;
@@ -142,12 +148,14 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
   // the maxima of the tile whose rows wait in px / pgw: one partial per wave, read by everybody behind the next barrier
   auto publish_max = [&]() {
     float mx = 0.f, mg = 0.f;
+    if constexpr (!PC) {
 #pragma unroll
-    for (int c = 0; c < NRB; ++c) { mx = absmax4(mx, px[c][0]); mx = absmax4(mx, px[c][1]); }
+      for (int c = 0; c < NPX; ++c) { mx = absmax4(mx, px[c][0]); mx = absmax4(mx, px[c][1]); }
+    }
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) mg = absmax4(mg, pgw[rb]);
     mx = wave_max(mx); mg = wave_max(mg);
-    if (lane == 0) { mxp[wave] = mx; mxp[8 + wave] = mg; }
+    if (lane == 0) { if (!PC) mxp[wave] = mx; mxp[8 + wave] = mg; }
   };
   // one row of P Zs (four columns at c4) for a real row; the slice is padded to four entries per row (zero weight, own row)
   auto hop_row = [&](const float* Zs, int row, int c4) {
@@ -174,7 +182,7 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
     ts = p.tile_start[slice]; R = p.tile_start[slice + 1] - ts;
     load_tile_g(slice, ts, R);
 #pragma unroll
-    for (int c = 0; c < NRB; ++c) load_x(ts, R, px[c], c);
+    for (int c = 0; c < NPX; ++c) load_x(ts, R, px[c], c);
     load_gc(ts, R, 0);
     if (slice + p.n_split < p.ntiles) { ts_n = p.tile_start[slice + p.n_split]; R_n = p.tile_start[slice + p.n_split + 1] - ts_n; }
   }
@@ -214,8 +222,8 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
     {
       float mx = 0.f, mg = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) { mx = fmaxf(mx, mxp[w]); mg = fmaxf(mg, mxp[8 + w]); }
-      const int ex = __builtin_amdgcn_readfirstlane(exp_of(mx)), eg = __builtin_amdgcn_readfirstlane(exp_of(mg));
+      for (int w = 0; w < 8; ++w) { if (!PC) mx = fmaxf(mx, mxp[w]); mg = fmaxf(mg, mxp[8 + w]); }
+      const int ex = PC ? Ex : __builtin_amdgcn_readfirstlane(exp_of(mx)), eg = __builtin_amdgcn_readfirstlane(exp_of(mg));
       const int nx = ex > Ex ? ex : Ex, ng = eg > Eg ? eg : Eg;
       const int d = (nx - Ex) + (ng - Eg);
       if (d != 0) {      // (uniform)
@@ -226,7 +234,8 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
       }
       Ex = nx; Eg = ng;
     }
-    const int sxe = 14 - Ex, sze = 14 - hb - Eg;
+    int sxe = 14 - Ex;      // (PC: set per chunk)
+    const int sze = 14 - hb - Eg;
     if (next < p.ntiles) load_tile_g(next, ts_n, R_n);      // in flight for the whole tile
     // ---- P G of the tile
     if (NMAT > 1) {
@@ -247,8 +256,17 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
       // ---- planes of the chunk
       char* ZT = U + pb * PBUF;
       char* XT = ZT + NMAT * 2 * ZC * 64;
-      if (on && 32 * c + 8 * (wave & 3) < ((R + 15) & ~15)) {      // (a wave's units are eight rows; rows beyond the last k-step are not read)
-        store_planes_h2<XW>(XT, x_off, px[c][0], px[c][1], sxe);
+      f32x4 (&pxc)[2] = px[PC ? 0 : c];
+      if constexpr (PC) {
+        if (on) {      // the chunk's maximum of X: one partial per wave, read behind barrier A below
+          float mx = absmax4(absmax4(0.f, pxc[0]), pxc[1]);
+          mx = wave_max(mx);
+          if (lane == 0) mxp[wave] = mx;
+        }
+      }
+      const bool rows_on = on && 32 * c + 8 * (wave & 3) < ((R + 15) & ~15);      // (a wave's units are eight rows; rows beyond the last k-step are not read)
+      if constexpr (!PC) { if (rows_on) store_planes_h2<XW>(XT, x_off, pxc[0], pxc[1], sxe); }
+      if (rows_on) {
         if (role == 0) {
 #pragma unroll
           for (int u = 0; u < 2; ++u)
@@ -269,12 +287,38 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
           store_planes_h2<ZC>(ZT + 2 * 2 * ZC * 64, z_off, s[0], s[1], sze);
         }
       }
+      if constexpr (PC) {
+        if (on) {
+          __syncthreads();      // barrier A: the maxima are in
+          float mx = 0.f;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) mx = fmaxf(mx, mxp[w]);
+          const int ex = __builtin_amdgcn_readfirstlane(exp_of(mx));
+          if (ex > Ex) {      // (uniform)
+            const int d = ex - Ex;
+#pragma unroll
+            for (int m = 0; m < NMAT; ++m)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[m][r] = ldexpf(acc[m][r], -d);
+            Ex = ex;
+          }
+          sxe = 14 - Ex;
+          if (rows_on) store_planes_h2<XW>(XT, x_off, pxc[0], pxc[1], sxe);
+        }
+      }
       if (on) __syncthreads();
-      // the NEXT TILE's rows of this chunk take the registers this chunk's rows have just left (one call site per chunk)
-      if (next < p.ntiles) load_x(ts_n, R_n, px[c], c);
-      if (on) {      // ONE call site (two made the compiler load into temporaries and join them behind an s_waitcnt vmcnt(0))
-        const bool same = c + 1 < nch;
-        if (same || next < p.ntiles) load_gc(same ? ts : ts_n, same ? R : R_n, same ? c + 1 : 0);
+      if constexpr (PC) {
+        if (on) {      // ONE call site each
+          const bool same = c + 1 < nch;
+          if (same || next < p.ntiles) { load_x(same ? ts : ts_n, same ? R : R_n, pxc, same ? c + 1 : 0); load_gc(same ? ts : ts_n, same ? R : R_n, same ? c + 1 : 0); }
+        }
+      } else {
+        // the NEXT TILE's rows of this chunk take the registers this chunk's rows have just left (one call site per chunk)
+        if (next < p.ntiles) load_x(ts_n, R_n, pxc, c);
+        if (on) {      // ONE call site (two made the compiler load into temporaries and join them behind an s_waitcnt vmcnt(0))
+          const bool same = c + 1 < nch;
+          if (same || next < p.ntiles) load_gc(same ? ts : ts_n, same ? R : R_n, same ? c + 1 : 0);
+        }
       }
       // ---- MFMA phase: up to 2 steps of 16 rows; lo hi + hi lo + hi hi, smallest terms first
       if (on && in_active) {
@@ -351,20 +395,20 @@ size_t wgrad16th_lds_bytes(int nrb, int nmat, int ell_width) {
   return b > red ? b : red;
 }
 
-// args.mfma_bf16 & 255 == 2 on 96-row tiles (the other tall heights keep bf16x6: dss2_wgrad16.hip)
+// args.mfma_bf16 & 255 == 2 on 96- and 192-row tiles (128 / 160 rows keep bf16x6: dss2_wgrad16.hip)
 bool wgrad16th_covers(const dss2_wgrad_args& a) {
   static const int on = [] { const char* e = getenv("DSS2_WGRAD_TALL_F16"); return e ? atoi(e) : 1; }();
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  return on && (a.mfma_bf16 & 255) == 2 && a.nrb == 3 && (a.nmat == 2 || a.nmat == 3) && !a.narrow && !a.rowscale && a.ell_tiles &&
+  return on && (a.mfma_bf16 & 255) == 2 && (a.nrb == 3 || a.nrb == 6) && (a.nmat == 2 || a.nmat == 3) && !a.narrow && !a.rowscale && a.ell_tiles &&
          al16(a.G) && al16(a.X) && (a.ldg & 3) == 0 && (a.ldx & 3) == 0 && (!a.rowscale2 || al16(a.rowscale2)) && a.ell_width >= 1 &&
          a.ell_width <= W16TH_DMAX && a.hout > 32 && (a.hout & 3) == 0 && (a.hin & 3) == 0 &&
          wgrad16th_lds_bytes(a.nrb, a.nmat, a.ell_width) <= (size_t)kMaxLdsBytes;
 }
 
-template <int NRB, int NMAT, bool RS2>
+template <int NRB, int NMAT, bool RS2, bool PC>
 static int launch16th(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb) {
   static std::atomic<uint32_t> lds_done{0};
-  auto kern = wgrad16th_kernel<NRB, NMAT, RS2>;
+  auto kern = wgrad16th_kernel<NRB, NMAT, RS2, PC>;
   if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "wgrad(f16x3, tall tiles)")) return 1;
   const int nobg = (a.hout + W16TH_ZC - 1) / W16TH_ZC, nibg = (a.hin + W16TH_XW - 1) / W16TH_XW;
   const int hb = (a.mfma_bf16 >> 8) & 255;
@@ -380,12 +424,12 @@ int launch_wgrad16th(const dss2_wgrad_args& a, hipStream_t stream, const WgradBa
     }
     rs2 = rs2 || wb.rowscale2[l] != nullptr;
   }
-#define DSS2_TALLH(NRB) \
+#define DSS2_TALLH(NRB, PC) \
   if (a.nrb == NRB) { \
-    if (a.nmat == 2) return rs2 ? launch16th<NRB, 2, true>(a, stream, wb) : launch16th<NRB, 2, false>(a, stream, wb); \
-    return rs2 ? launch16th<NRB, 3, true>(a, stream, wb) : launch16th<NRB, 3, false>(a, stream, wb); \
+    if (a.nmat == 2) return rs2 ? launch16th<NRB, 2, true, PC>(a, stream, wb) : launch16th<NRB, 2, false, PC>(a, stream, wb); \
+    return rs2 ? launch16th<NRB, 3, true, PC>(a, stream, wb) : launch16th<NRB, 3, false, PC>(a, stream, wb); \
   }
-  DSS2_TALLH(3)
+  DSS2_TALLH(3, false) DSS2_TALLH(6, true)
 #undef DSS2_TALLH
   set_error("wgrad(f16x3, tall tiles): no kernel for nrb=%d", a.nrb);
   return 2;

@@ -23,7 +23,7 @@ int launch_wgrad16(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatc
 bool wgrad16h_covers(const dss2_wgrad_args& a);
 int launch_wgrad16h(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb);
 
-// dss2_wgrad16th.hip: the f16x3 kernel of 96-row tiles (same args.mfma_bf16 convention)
+// dss2_wgrad16th.hip: the f16x3 kernel of 96- / 192-row tiles (same args.mfma_bf16 convention)
 bool wgrad16th_covers(const dss2_wgrad_args& a);
 int launch_wgrad16th(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb);
 

@@ -262,10 +262,10 @@ def _wgrad_tiles(topo: Topology, nmat: int, hout: int, hin: int, b16: int):
 
 def _wgrad_mode(ts, nmat: int, b16: int, hinted: bool = False) -> int:
     """args.mfma_bf16 of a weight-gradient launch on the tile set ``ts``: 0 fp32 MFMA, 1 bf16x6, or -- flags.WGRAD_F16 on 32-row tiles
-    (csrc/dss2_wgrad16h.hip) and on 96-row tiles (csrc/dss2_wgrad16th.hip) with ELL slices -- 2 | hb << 8: the f16x3 kernels
+    (csrc/dss2_wgrad16h.hip) and on 96- / 192-row tiles (csrc/dss2_wgrad16th.hip) with ELL slices -- 2 | hb << 8: the f16x3 kernels
     with hb headroom bits for the gain of the propagation hops, ceil(log2(max row sum of |P^T| ^ K)), read from the ELL slices once per
     tile set (one device-to-host copy, cached; ``hinted``: from the ELL width alone, no copy).  Shapes the f16x3 kernels do not cover run bf16x6 on the same value (the library decides)."""
-    if not (b16 and FL.WGRAD_F16 and ts.nrb in (1, 3) and nmat in (2, 3) and ts.ellT_tiles is not None and 1 <= ts.ellT <= 8):
+    if not (b16 and FL.WGRAD_F16 and ts.nrb in (1, 3, 6) and nmat in (2, 3) and ts.ellT_tiles is not None and 1 <= ts.ellT <= 8):
         return b16
     cache = ts.__dict__.setdefault("_f16_gain_bits", {})
     hb = cache.get(nmat)

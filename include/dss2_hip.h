@@ -398,7 +398,7 @@ typedef struct dss2_wgrad_args {
                                          * 32-wide block instead of nmat separate blocks; same  *
                                          * slab layout [nmat*hout*hin + hout].                  *
                                          * (mfma_bf16 & 255) == 2: as f16x3 where that kernel    *
-                                         * covers the shape (32-row and 96-row tiles with ELL    *
+                                         * covers the shape (32-, 96- and 192-row tiles with ELL *
                                          * slices), bits 8..15 = headroom bits for the gain of   *
                                          * the propagation hops, ceil(log2(max row sum of        *
                                          * |P^T|^K)); elsewhere the bf16x6 / fp32 kernels        */

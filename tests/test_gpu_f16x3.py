@@ -116,6 +116,8 @@ def _check(pkg, topo, Gs, Xs, H, nmat, rs2, tol=2e-6, against_bf16=True):
     (["ober_sub"], 41, 2, False, 128, 3),
     (["ober_sub"], 30, 2, True, 128, 2),                           # K = 1
     (["ober_sub"], 9, 1, False, 96, 3),                            # the single-layer entry point, three column groups
+    (["ober179"], 12, 3, True, 128, 3),                            # 192-row tiles: six chunks, an exponent of X per chunk
+    (["ober179"], 9, 2, False, 128, 2),
     (["ober_sub"], 700, 3, True, 256, 3),                          # H = 256: four (output, input) slices per tile-list slice
 ])
 def test_f16x3_weight_gradient_matches_fp64_and_bf16x6(pkg, grids, B, nl, rs2, H, nmat):
