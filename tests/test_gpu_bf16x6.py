@@ -120,7 +120,8 @@ def test_tall_tile_weight_gradient_bf16x6_equals_fp32_mfma(pkg, grids, B, H, nma
 
 
 def test_shapes_outside_the_bf16x6_weight_gradient_fall_back(pkg):
-    """H <= 32 (the K-split 4-wave kernel), K = 3, ELL slices wider than 8: the fp32 kernel runs, results unchanged by the switch."""
+    """H <= 32 (the K-split 4-wave kernel), K = 3, ELL slices wider than 8: the fp32 kernel runs, results unchanged by the switch.
+    (H = 32 on 96-row tiles left this list at the end of round 5: the f16x3 tall-tile kernel takes it -- same numbers to fp32 rounding.)"""
     nw = pkg.networks
     saved = pkg.flags.WGRAD_BF16
     try:
@@ -134,7 +135,10 @@ def test_shapes_outside_the_bf16x6_weight_gradient_fall_back(pkg):
                 o = torch.zeros(nmat * H * H + H, device=DEV)
                 nw.wgrad(topo, G, H, X, H, nmat, o)
                 outs.append(o)
-            assert torch.equal(outs[0], outs[1])
+            if grids == ["ober_sub"] and H == 32 and pkg.flags.WGRAD_F16:
+                assert rel_err(outs[1], outs[0]) < 2e-6 and not torch.equal(outs[0], outs[1])      # (another kernel: csrc/dss2_wgrad16th.hip)
+            else:
+                assert torch.equal(outs[0], outs[1])
     finally:
         pkg.flags.WGRAD_BF16 = saved
 
