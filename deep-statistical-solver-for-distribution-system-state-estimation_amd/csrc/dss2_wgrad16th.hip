@@ -1,4 +1,4 @@
-// Weight gradient of TAGConv on 96- and 192-row tiles (graphs of 65 .. 96 / 161 .. 192 nodes: C3, the 179-bus feeder) as f16x3 (end of round 5).
+// Weight gradient of TAGConv on 96- .. 192-row tiles (graphs of 65 .. 192 nodes: C3, the 179-bus feeder) as f16x3 (end of round 5).
 //   dW_m = (P^m G)^T X,  db = colsum(G)   -- contract, slab layout, thread maps and phases of wgrad16t_kernel (dss2_wgrad16.hip): the
 //   propagation needs the whole graph, so P G of the WHOLE tile is kept in fp32; the contraction over rows is cut into chunks of 32
 //   rows, whose transposed planes (G, P G, P^2 G, X) feed the matrix pipe.
@@ -13,7 +13,7 @@
 //     bits for the gain of the hops (args.mfma_bf16 bits 8..15, from the host: ops._wgrad_mode);
 //   * the slab is written with the scales taken out.
 // C3 (ober_sub, B = 1024): 210.4 -> 173.8 us for the three layers (rocprofv3, one box).
-//   * 192 rows (PC): twelve row pieces of X per thread do not fit (19 spilled registers, 463 us against 457 for bf16x6), so there the X
+//   * 128 .. 192 rows (PC; measured at 192): twelve row pieces of X per thread do not fit (19 spilled registers, 463 us against 457 for bf16x6), so there the X
 //     rows stay one CHUNK ahead and X gets an exponent per chunk -- one partial per wave at the top of the chunk, one more barrier
 //     (A) between building the G-side planes and splitting X; with two sets of planes that is two barriers per chunk, what the
 //     bf16x6 kernel pays at this height with one set.  179-bus feeder, B = 1024: 462.8 -> 384.7 us, step 1.478 -> 1.408 ms.
@@ -395,14 +395,14 @@ size_t wgrad16th_lds_bytes(int nrb, int nmat, int ell_width) {
   return b > red ? b : red;
 }
 
-// args.mfma_bf16 & 255 == 2 on 96- and 192-row tiles (128 / 160 rows keep bf16x6: dss2_wgrad16.hip).  hout = 32 is covered HERE (the
+// args.mfma_bf16 & 255 == 2 on 96- .. 192-row tiles (96 rows: X a tile ahead; 128 .. 192 rows: the per-chunk form).  hout = 32 is covered HERE (the
 // bf16x6 kernels start above 32): one wave of eight multiplies, but the propagation, the splits and the prefetch are what a tile costs at
 // that width -- the driver's model on ober_sub (dim_hid 32, 7 layers per launch): 206 -> ~150 us per launch against the fp32 kernel,
 // replayed step 2.63 -> 2.37 ms
 bool wgrad16th_covers(const dss2_wgrad_args& a) {
   static const int on = [] { const char* e = getenv("DSS2_WGRAD_TALL_F16"); return e ? atoi(e) : 1; }();
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  return on && (a.mfma_bf16 & 255) == 2 && (a.nrb == 3 || a.nrb == 6) && (a.nmat == 2 || a.nmat == 3) && !a.narrow && !a.rowscale && a.ell_tiles &&
+  return on && (a.mfma_bf16 & 255) == 2 && a.nrb >= 3 && a.nrb <= 6 && (a.nmat == 2 || a.nmat == 3) && !a.narrow && !a.rowscale && a.ell_tiles &&
          al16(a.G) && al16(a.X) && (a.ldg & 3) == 0 && (a.ldx & 3) == 0 && (!a.rowscale2 || al16(a.rowscale2)) && a.ell_width >= 1 &&
          a.ell_width <= W16TH_DMAX && a.hout >= 32 && (a.hout & 3) == 0 && (a.hin & 3) == 0 &&
          wgrad16th_lds_bytes(a.nrb, a.nmat, a.ell_width) <= (size_t)kMaxLdsBytes;
@@ -432,7 +432,7 @@ int launch_wgrad16th(const dss2_wgrad_args& a, hipStream_t stream, const WgradBa
     if (a.nmat == 2) return rs2 ? launch16th<NRB, 2, true, PC>(a, stream, wb) : launch16th<NRB, 2, false, PC>(a, stream, wb); \
     return rs2 ? launch16th<NRB, 3, true, PC>(a, stream, wb) : launch16th<NRB, 3, false, PC>(a, stream, wb); \
   }
-  DSS2_TALLH(3, false) DSS2_TALLH(6, true)
+  DSS2_TALLH(3, false) DSS2_TALLH(4, true) DSS2_TALLH(5, true) DSS2_TALLH(6, true)
 #undef DSS2_TALLH
   set_error("wgrad(f16x3, tall tiles): no kernel for nrb=%d", a.nrb);
   return 2;

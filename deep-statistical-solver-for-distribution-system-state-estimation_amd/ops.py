@@ -245,10 +245,11 @@ def _wgrad_tiles(topo: Topology, nmat: int, hout: int, hin: int, b16: int):
     32-row tiling of the same graphs (Topology.tiles_for(1)), on which two 4-wave workgroups share a CU and overlap each
     other's staging / propagation with their MFMA phases (csrc/dss2_wgrad16.hip)."""
     # (each X tile is staged by the two workgroups that own its 64-column output halves, at unrelated times: beyond the
-    #  Infinity Cache that is a second trip to HBM -- B = 32768: 3.52 ms against 3.43 on the 64-row kernel -- so the 32-row
-    #  form is taken while one layer's input stays well inside it)
+    #  Infinity Cache that is a second trip to HBM.  As bf16x6 that lost to the 64-row kernel -- B = 32768: 3.52 ms against 3.43 --, so
+    #  that route takes the 32-row form only while one layer's input stays well inside the cache; as f16x3 (round 5) the 32-row kernel
+    #  wins at every size: B = 32768 2.75 -> 2.45 ms, B = 16384 1.44 -> 1.28 ms)
     if (FL.WGRAD_TM32 and b16 and topo.nrb == 2 and not topo.global_only and nmat in (2, 3) and hout > 32 and 1 <= topo.ellT <= 8
-            and topo.N * hin * 4 <= FL.WGRAD_TM32_MAX_BYTES):
+            and (FL.WGRAD_F16 or topo.N * hin * 4 <= FL.WGRAD_TM32_MAX_BYTES)):
         alt = topo.tiles_for(1)
         # ... and only where the library's bf16x6 kernel covers the shape on that tiling (its LDS query answers with the fp32 kernel's
         # size when it does not: hout % 4, hin % 4, hout > 32, K <= 2 -- the conditions live in ONE place, wgrad16_covers; ADVICE r4)
@@ -262,10 +263,10 @@ def _wgrad_tiles(topo: Topology, nmat: int, hout: int, hin: int, b16: int):
 
 def _wgrad_mode(ts, nmat: int, b16: int, hinted: bool = False) -> int:
     """args.mfma_bf16 of a weight-gradient launch on the tile set ``ts``: 0 fp32 MFMA, 1 bf16x6, or -- flags.WGRAD_F16 on 32-row tiles
-    (csrc/dss2_wgrad16h.hip) and on 96- / 192-row tiles (csrc/dss2_wgrad16th.hip) with ELL slices -- 2 | hb << 8: the f16x3 kernels
+    (csrc/dss2_wgrad16h.hip) and on 96- .. 192-row tiles (csrc/dss2_wgrad16th.hip) with ELL slices -- 2 | hb << 8: the f16x3 kernels
     with hb headroom bits for the gain of the propagation hops, ceil(log2(max row sum of |P^T| ^ K)), read from the ELL slices once per
     tile set (one device-to-host copy, cached; ``hinted``: from the ELL width alone, no copy).  Shapes the f16x3 kernels do not cover run bf16x6 on the same value (the library decides)."""
-    if not (b16 and FL.WGRAD_F16 and ts.nrb in (1, 3, 6) and nmat in (2, 3) and ts.ellT_tiles is not None and 1 <= ts.ellT <= 8):
+    if not (b16 and FL.WGRAD_F16 and ts.nrb in (1, 3, 4, 5, 6) and nmat in (2, 3) and ts.ellT_tiles is not None and 1 <= ts.ellT <= 8):
         return b16
     cache = ts.__dict__.setdefault("_f16_gain_bits", {})
     hb = cache.get(nmat)
