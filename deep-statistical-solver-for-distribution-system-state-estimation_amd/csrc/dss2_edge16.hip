@@ -12,7 +12,9 @@
 //     the k = 15 column carries a = 1 on EMPTY slots against b = -1e30: an empty slot's pre-activation is hugely negative, the
 //     ReLU removes it, and the epilogue is two vector instructions per element (max, add) with no validity lookups;
 //   * the split planes of every slot are built in ONE phase after the staging (each input element is split once per workgroup,
-//     16-byte row pieces: conflict-free b128 fragment reads without padding), so the slot loop of the forward has no barrier.
+//     16-byte row pieces: conflict-free b128 fragment reads without padding), so the slot loop of the forward has no barrier;
+//   * 192-row tiles (end of round 5) are walked as two PARTS of 96 rows by the 96-row instantiations: the whole tile's x rows are staged
+//     for each part (x_j may be any of them), everything else is the part's own (EdgeTileArgs::parts / xtm, edge_stage_part).
 // The backward recomputes the pre-activation with the very same plane values, fragments and MFMA order -- its gates are bit for
 // bit the forward's -- and forms dW1 += dZ_k^T A_k, a contraction over the tile's rows, as bf16x6 too (see edge16_bwd_kernel).
 // Built without packed fp32 VALU ops like every translation unit that runs bf16 MFMAs beside other workgroups (csrc/build.sh).
@@ -35,16 +37,18 @@ __device__ __forceinline__ bf16x8 e16_frag(const uint4 v) { return __builtin_bit
 
 struct E16Lds {
   EdgeStage s;
+  const float* xi;      // the x rows of this part's own rows (s.xs + r0 * FN)
   char* PI;      // [3 planes][TM][16 B]: x_i
   char* PK;      // [D][3 planes][2 halves][TM][16 B]: half 0 = x_j, half 1 = edge_attr (6) | valid | empty
 };
 
 template <int NRB>
-__device__ __forceinline__ E16Lds e16_ptrs(float* esm, int D) {
+__device__ __forceinline__ E16Lds e16_ptrs(float* esm, int D, int XT) {
   constexpr int TM = NRB * 32;
   E16Lds L;
   L.s.xs = esm;
-  L.s.eaL = L.s.xs + TM * FN;
+  L.xi = esm;
+  L.s.eaL = L.s.xs + XT * FN;
   L.s.other = reinterpret_cast<int*>(L.s.eaL + D * TM * 8);
   L.PI = reinterpret_cast<char*>(L.s.other + D * TM);
   L.PK = L.PI + 3 * TM * 16;
@@ -52,8 +56,8 @@ __device__ __forceinline__ E16Lds e16_ptrs(float* esm, int D) {
   return L;
 }
 
-static size_t e16_lds_bytes(int TM, int D) {      // forward: all slots' planes at once
-  return ((size_t)TM * FN + (size_t)D * TM * 8) * 4 + (size_t)D * TM * 4 + 3 * (size_t)TM * 16 + (size_t)D * 6 * TM * 16;
+static size_t e16_lds_bytes(int TM, int D, int XT) {      // forward: all slots' planes at once (XT: rows of the whole tile, whose x rows are staged)
+  return ((size_t)XT * FN + (size_t)D * TM * 8) * 4 + (size_t)D * TM * 4 + 3 * (size_t)TM * 16 + (size_t)D * 6 * TM * 16;
 }
 
 // all slots' planes in one phase: unit = (image, row) of 8 elements; images: x_i, then (slot k, half) for k < D
@@ -67,8 +71,8 @@ __device__ __forceinline__ void e16_build(const E16Lds& L, int D, int tid, int n
     char* dst;
     int pstride;
     if (img == 0) {
-      v0 = *reinterpret_cast<const f32x4*>(s.xs + row * FN);
-      v1 = *reinterpret_cast<const f32x4*>(s.xs + row * FN + 4);
+      v0 = *reinterpret_cast<const f32x4*>(L.xi + row * FN);
+      v1 = *reinterpret_cast<const f32x4*>(L.xi + row * FN + 4);
       dst = L.PI + row * 16;
       pstride = TM * 16;
     } else {
@@ -162,13 +166,18 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))
   const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);      // one 32-column group of the hidden layer per wave
   const int c32 = lane & 31, half = lane >> 5;
   const int D = p.D;
-  const E16Lds L = e16_ptrs<NRB>(esm, D);
+  const int parts = p.parts > 1 ? p.parts : 1, XT = p.xtm > 0 ? p.xtm : NRB * 32;      // (192-row tiles: two parts of 96 rows)
+  E16Lds L = e16_ptrs<NRB>(esm, D, XT);
   const int j = cg * 32 + c32;
   const E16W w = e16_weights(p.W1, p.b1, j, half);
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    const int ts = p.tile_start[tile];
-    const int R = p.tile_start[tile + 1] - ts;
-    edge_stage_tile<NRB>(p, L.s, tile, ts, R, tid, nthreads);
+  for (int vt = blockIdx.x; vt < p.ntiles * parts; vt += gridDim.x) {
+    const int tile = vt / parts, r0 = (vt - tile * parts) * (NRB * 32);
+    const int ts_full = p.tile_start[tile], R_full = p.tile_start[tile + 1] - ts_full;
+    const int ts = ts_full + r0;
+    const int R = R_full - r0 < NRB * 32 ? R_full - r0 : NRB * 32;
+    if (R <= 0) continue;      // (uniform: a part beyond the tile's rows)
+    L.xi = L.s.xs + r0 * FN;
+    edge_stage_part<NRB>(p, L.s, tile, XT, r0, ts_full, R_full, tid, nthreads);
     __syncthreads();
     e16_build<NRB>(L, D, tid, nthreads);
     __syncthreads();
@@ -215,6 +224,7 @@ __device__ __forceinline__ int e16_qpos(int row) {            // position of a r
 
 struct E16Bwd {
   EdgeStage s;      // xs, eaL, other (Ak / st unused)
+  const float* xi;  // the x rows of this part's own rows
   char* PI;         // [3 planes][TM][16 B]: x_i, the recomputation's row operand
   char* PK;         // [3 planes][2 halves][TM][16 B]: ONE slot
   char* ATI;        // [3 planes][8 columns][CS]: x_i transposed
@@ -222,11 +232,12 @@ struct E16Bwd {
 };
 
 template <int NRB>
-__device__ __forceinline__ E16Bwd e16_bwd_ptrs(float* esm, int D) {
+__device__ __forceinline__ E16Bwd e16_bwd_ptrs(float* esm, int D, int XT) {
   constexpr int TM = NRB * 32, CS = e16_cs(TM);
   E16Bwd L;
   L.s.xs = esm;
-  L.s.eaL = L.s.xs + TM * FN;
+  L.xi = esm;
+  L.s.eaL = L.s.xs + XT * FN;
   L.s.other = reinterpret_cast<int*>(L.s.eaL + D * TM * 8);
   L.s.Ak = nullptr; L.s.st = nullptr;
   L.PI = reinterpret_cast<char*>(L.s.other + D * TM);
@@ -236,8 +247,8 @@ __device__ __forceinline__ E16Bwd e16_bwd_ptrs(float* esm, int D) {
   return L;
 }
 
-static size_t e16_bwd_lds_bytes(int TM, int D) {
-  return ((size_t)TM * FN + (size_t)D * TM * 8) * 4 + (size_t)D * TM * 4 + 3 * (size_t)TM * 16 + 6 * (size_t)TM * 16 +
+static size_t e16_bwd_lds_bytes(int TM, int D, int XT) {
+  return ((size_t)XT * FN + (size_t)D * TM * 8) * 4 + (size_t)D * TM * 4 + 3 * (size_t)TM * 16 + 6 * (size_t)TM * 16 +
          3 * (size_t)(FN + E16_ATN) * e16_cs(TM);
 }
 
@@ -263,7 +274,7 @@ __device__ __forceinline__ void e16_bwd_build_tile(const E16Bwd& L, int tid, int
   constexpr int TM = NRB * 32;
   for (int row = tid; row < TM; row += nthreads) {
     uint4 h, m, l;
-    e16_split8(*reinterpret_cast<const f32x4*>(L.s.xs + row * FN), *reinterpret_cast<const f32x4*>(L.s.xs + row * FN + 4), h, m, l);
+    e16_split8(*reinterpret_cast<const f32x4*>(L.xi + row * FN), *reinterpret_cast<const f32x4*>(L.xi + row * FN + 4), h, m, l);
     char* dst = L.PI + row * 16;
     *reinterpret_cast<uint4*>(dst) = h;
     *reinterpret_cast<uint4*>(dst + TM * 16) = m;
@@ -271,7 +282,7 @@ __device__ __forceinline__ void e16_bwd_build_tile(const E16Bwd& L, int tid, int
   }
   for (int u = tid; u < (TM / 2) * 2; u += nthreads) {
     const int rp = u >> 1, q4 = u & 1;
-    const float* src = L.s.xs + (2 * rp) * FN + 4 * q4;
+    const float* src = L.xi + (2 * rp) * FN + 4 * q4;
     e16_store_t<NRB>(L.ATI, FN, 4 * q4, rp, *reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + FN));
   }
 }
@@ -327,9 +338,10 @@ __global__ void __launch_bounds__(512) edge16_bwd_kernel(const EdgeTileArgs p) {
   const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c32 = lane & 31, half = lane >> 5;
   const int D = p.D;
-  const E16Bwd B = e16_bwd_ptrs<NRB>(esm, D);
+  const int parts = p.parts > 1 ? p.parts : 1, XT = p.xtm > 0 ? p.xtm : NRB * 32;      // (192-row tiles: two parts of 96 rows)
+  E16Bwd B = e16_bwd_ptrs<NRB>(esm, D, XT);
   E16Lds L;                           // the view e16_xterm / e16_z read: the one-slot planes are "slot 0"
-  L.s = B.s; L.PI = B.PI; L.PK = B.PK;
+  L.s = B.s; L.xi = B.xi; L.PI = B.PI; L.PK = B.PK;
   const int j = cg * 32 + c32;
   const E16W w = e16_weights(p.W1, p.b1, j, half);
   // this lane's B-operand column of the weight-gradient product: input column c32 -> x_i (0..7), the slot's columns (8..23), none
@@ -339,10 +351,14 @@ __global__ void __launch_bounds__(512) edge16_bwd_kernel(const EdgeTileArgs p) {
   f32x16 dWacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dWacc[r] = 0.f;
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    const int ts = p.tile_start[tile];
-    const int R = p.tile_start[tile + 1] - ts;
-    edge_stage_tile<NRB>(p, B.s, tile, ts, R, tid, nthreads);
+  for (int vt = blockIdx.x; vt < p.ntiles * parts; vt += gridDim.x) {
+    const int tile = vt / parts, r0 = (vt - tile * parts) * (NRB * 32);
+    const int ts_full = p.tile_start[tile], R_full = p.tile_start[tile + 1] - ts_full;
+    const int ts = ts_full + r0;
+    const int R = R_full - r0 < NRB * 32 ? R_full - r0 : NRB * 32;
+    if (R <= 0) continue;      // (uniform: a part beyond the tile's rows)
+    B.xi = B.s.xs + r0 * FN;
+    edge_stage_part<NRB>(p, B.s, tile, XT, r0, ts_full, R_full, tid, nthreads);
     f32x16 gS[NRB], Uacc[WITH_U ? NRB : 1];
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb)
@@ -438,15 +454,17 @@ bool edge16_ok(int h, int nrb, int D, bool bwd, bool with_u) {
   //  the backward recomputes the forward's gates)
   const char* env = getenv("DSS2_EDGE_BF16");
   if (env && atoi(env) == 0) return false;
-  if ((h & 31) || h > 256 || !(nrb == 1 || nrb == 2 || nrb == 3) || D < 1 || D > 32) return false;
-  if (bwd && with_u && nrb == 3) return false;      // (that instantiation misses its register budget, as in dss2_edge.hip)
-  return (bwd ? e16_bwd_lds_bytes(nrb * 32, D) : e16_lds_bytes(nrb * 32, D)) <= (size_t)kMaxLdsBytes;
+  if ((h & 31) || h > 256 || !(nrb == 1 || nrb == 2 || nrb == 3 || nrb == 6) || D < 1 || D > 32) return false;
+  if (bwd && with_u && nrb >= 3) return false;      // (that instantiation misses its register budget, as in dss2_edge.hip)
+  const int tm = nrb == 6 ? 96 : nrb * 32;          // (192-row tiles: two parts of 96 rows, the whole tile's x rows staged for each)
+  return (bwd ? e16_bwd_lds_bytes(tm, D, nrb * 32) : e16_lds_bytes(tm, D, nrb * 32)) <= (size_t)kMaxLdsBytes;
 }
 
 template <int NRB>
 static int launch16(const EdgeTileArgs& a, int grid, bool bwd, hipStream_t s) {
   const int nw = a.h >> 5;
-  const size_t lds = bwd ? e16_bwd_lds_bytes(NRB * 32, a.D) : e16_lds_bytes(NRB * 32, a.D);
+  const int xt = a.xtm > 0 ? a.xtm : NRB * 32;
+  const size_t lds = bwd ? e16_bwd_lds_bytes(NRB * 32, a.D, xt) : e16_lds_bytes(NRB * 32, a.D, xt);
   if (bwd && a.U) {
     if constexpr (NRB <= 2) {
       static std::atomic<uint32_t> lds_done{0};
@@ -474,6 +492,11 @@ int launch_edge16(const EdgeTileArgs& a, int nrb, int grid, bool bwd, hipStream_
   switch (nrb) {
     case 1: return launch16<1>(a, grid, bwd, s);
     case 2: return launch16<2>(a, grid, bwd, s);
+    case 6: {      // 192-row tiles as two parts of 96 rows each (the forward: one workgroup per part)
+      EdgeTileArgs b = a;
+      b.xtm = 192; b.parts = 2;
+      return launch16<3>(b, bwd ? grid : 2 * grid, bwd, s);
+    }
     default: return launch16<3>(a, grid, bwd, s);
   }
 }

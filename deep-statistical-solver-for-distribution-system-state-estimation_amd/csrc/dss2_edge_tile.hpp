@@ -12,6 +12,9 @@ struct EdgeTileArgs {
   const int32_t* tile_start; const int2* ell_ent;   // [ntiles][D][TM] {local other node, eid | flip<<31 ; -1 = empty}
   float* S; float* slab; float* U; int64_t ldu;
   int h, D, TM, by_source, ntiles;
+  // dss2_edge16.hip on 192-row tiles: a tile is walked as `parts` parts of 96 rows; xtm = rows of the whole tile (the stride of the ELL
+  // table, and what x_j may point into).  0 / 1: whole tiles.
+  int xtm = 0, parts = 1;
 };
 
 constexpr int EM_LDA = 36;   // A_k row stride: 24 inputs + 8 zero columns (B operand of the dW MFMA) + 4 pad
@@ -43,6 +46,35 @@ __device__ __forceinline__ void edge_stage_tile(const EdgeTileArgs& p, const Edg
   }
   for (int idx = tid; idx < D * TM; idx += nthreads) {
     const int2 en = p.ell_ent[(size_t)tile * D * TM + idx];
+    const bool ok = en.y != -1;
+    s.other[idx] = ok ? en.x : -1;
+    float* d = s.eaL + idx * 8;
+    if (ok) {
+      const int eid = en.y & 0x7fffffff;
+      const float sgn = en.y < 0 ? -1.f : 1.f;
+      const float* e = p.ea + (int64_t)eid * p.ldea;
+      d[0] = e[0] * sgn; d[1] = e[1]; d[2] = e[2] * sgn; d[3] = e[3]; d[4] = e[4]; d[5] = e[5];
+    } else {
+      d[0] = 0.f; d[1] = 0.f; d[2] = 0.f; d[3] = 0.f; d[4] = 0.f; d[5] = 0.f;
+    }
+  }
+}
+
+// One PART of a tile (rows r0 .. r0 + TM - 1 of a tile of XT rows): the x rows of the WHOLE tile (a neighbour may be any of them), the
+// part's slice of the ELL table and its edge features.  XT = TM, r0 = 0: edge_stage_tile.
+template <int NRB>
+__device__ __forceinline__ void edge_stage_part(const EdgeTileArgs& p, const EdgeStage& s, int tile, int XT, int r0, int ts_full, int R_full,
+                                                int tid, int nthreads) {
+  constexpr int TM = NRB * 32;
+  const int D = p.D;
+  for (int idx = tid; idx < XT * FN; idx += nthreads) {
+    const int r = idx / FN, k = idx - r * FN;
+    s.xs[idx] = r < R_full ? p.x[(int64_t)(ts_full + r) * p.ldx + k] : 0.f;
+  }
+  for (int idx = tid; idx < D * TM; idx += nthreads) {
+    const int k = idx / TM, r = idx - k * TM;
+    int2 en = make_int2(0, -1);
+    if (r0 + r < XT) en = p.ell_ent[((size_t)tile * D + k) * XT + r0 + r];
     const bool ok = en.y != -1;
     s.other[idx] = ok ? en.x : -1;
     float* d = s.eaL + idx * 8;
