@@ -12,7 +12,8 @@
 //     ELL slice; when a running exponent grows the accumulators are rescaled (v_ldexp, exact); G, P G, P^2 G carry hb headroom
 //     bits for the gain of the hops (args.mfma_bf16 bits 8..15, from the host: ops._wgrad_mode);
 //   * the slab is written with the scales taken out.
-// C3 (ober_sub, B = 1024): 210.4 -> 173.8 us for the three layers (rocprofv3, one box).
+// C3 (ober_sub, B = 1024): 210.4 -> 173.8 us for the three layers (rocprofv3, one box); the per-chunk form below at 96 rows: replayed
+// step 0.587-0.589 ms against 0.567-0.570 for this one.
 //   * 128 .. 192 rows (PC; measured at 192): twelve row pieces of X per thread do not fit (19 spilled registers, 463 us against 457 for bf16x6), so there the X
 //     rows stay one CHUNK ahead and X gets an exponent per chunk -- one partial per wave at the top of the chunk, one more barrier
 //     (A) between building the G-side planes and splitting X; with two sets of planes that is two barriers per chunk, what the
