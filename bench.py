@@ -35,6 +35,32 @@ BF16_MFMA_PEAK_TF = 2500.0     # same table: Peak BF16 MFMA, dense
 HBM_PEAK_GBS = 8000.0
 
 
+# The arithmetic routes of the H -> H layers' products: all accumulate in fp32 and are fp32-accurate against fp64
+# (cpu_baseline.accuracy_vs_fp64_oracle); they differ in how a product of two fp32 operands reaches the matrix pipe.
+ROUTES = {
+    "f16x3": dict(CHAIN_BF16=True, WGRAD_BF16=True, CHAIN_F16=True, WGRAD_F16=True),
+    "bf16x6": dict(CHAIN_BF16=True, WGRAD_BF16=True, CHAIN_F16=False, WGRAD_F16=False),
+    "fp32-mfma": dict(CHAIN_BF16=False, WGRAD_BF16=False, CHAIN_F16=False, WGRAD_F16=False),
+}
+DTYPE_BY_ROUTE = {
+    "f16x3": "f32 (H->H products as f16x3: two fp16 pieces per operand, 3 fp16 MFMAs per fp32 product, f32 accumulate; edge MLP bf16x6; everything else f32/f64)",
+    "bf16x6": "f32 (H->H products as bf16x6: three bf16 pieces per operand, 6 bf16 MFMAs per fp32 product, f32 accumulate)",
+    "fp32-mfma": "f32 (H->H products on fp32 MFMAs; edge MLP bf16x6)",
+    "mixed": "f32 (mixed f16x3 / bf16x6 / fp32-MFMA routes: see config.arithmetic_route_flags)",
+}
+
+
+def route_name(pkg) -> str:
+    f = pkg.flags
+    cur = {k: bool(getattr(f, k)) for k in ("CHAIN_BF16", "WGRAD_BF16", "CHAIN_F16", "WGRAD_F16")}
+    if not cur["CHAIN_BF16"] and not cur["WGRAD_BF16"]:
+        return "fp32-mfma"
+    for name, setting in ROUTES.items():
+        if cur == setting:
+            return name
+    return "mixed"
+
+
 def spawn_ranks(n: int) -> int:
     """One child per GPU via `python -m torch.distributed.run` on a free loopback port; stdout / stderr pass through."""
     import socket
@@ -50,25 +76,29 @@ def spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-def capture_watchdog(result: dict, rank: int, world: int, timeout: float, eager_line_printed: bool):
-    """The hipGraph leg's dead-man timer (every rank runs one).  If the capture or a replay hangs -- e.g. a collective that
-    never completes inside a capture -- the process leaves `timeout` seconds later WITH the eager measurement on stdout:
-    * world == 1: the eager line has not been printed yet; print it now, exit code 0.
-    * world  > 1: rank 0 printed (and flushed) the eager line BEFORE the leg started, so it already is the last JSON line
-      of the run; every rank's own timer ends its process with exit code 0 -- the launcher then reports success and the
-      driver reads a valid (eager) measurement.  The hang itself is recorded on stderr.
-    Returns the started threading.Timer (cancel() it when the leg finishes)."""
+HANG_RC = int(os.environ.get("DSS2_BENCH_HANG_RC", "3"))      # exit status of a run one of whose legs hung
+
+
+def capture_watchdog(result: dict, rank: int, world: int, timeout: float, leg: str = "hipGraph replay"):
+    """Dead-man timer of a replay leg (hipGraph capture / launch plan; every rank runs one).  If the leg does not answer within
+    `timeout` seconds -- e.g. a collective that never completes inside a capture -- the process cannot be recovered (a hung HIP call
+    holds the GPU), so it ends here, VISIBLY: rank 0 prints the run's FINAL JSON line = everything measured so far (value /
+    ms_per_step: the best leg that completed) + `"hang": {"leg", "timeout_s", "exit_status"}` and `legs[leg] = "hung"`, and every rank
+    leaves with exit status HANG_RC (3; DSS2_BENCH_HANG_RC) -- the measurement survives on stdout, the launcher reports the failure.
+    Never a re-exec of this process (it has initialised the GPU).  Returns the started threading.Timer (cancel() it when the leg
+    finishes)."""
     import threading
 
     def bail():
-        msg = f"hipGraph leg: no answer within {timeout:.0f} s; the eager measurement stands"
+        msg = f"{leg} leg: no answer within {timeout:.0f} s; the measurements of the legs that completed stand"
         print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
-        if rank == 0 and not eager_line_printed:
-            result["config"]["hipgraph"] = msg
-            result["partial"] = "hipGraph leg hung and was abandoned; value / ms_per_step are the eager measurement"
+        if rank == 0:
+            result.pop("partial", None)
+            result["hang"] = {"leg": leg, "timeout_s": timeout, "exit_status": HANG_RC, "note": msg}
+            result.setdefault("legs", {})[leg] = "hung"
             print(json.dumps(result), flush=True)
         sys.stdout.flush()
-        os._exit(0)
+        os._exit(HANG_RC)
     t = threading.Timer(timeout, bail)
     t.daemon = True
     t.start()
@@ -77,8 +107,9 @@ def capture_watchdog(result: dict, rank: int, world: int, timeout: float, eager_
 
 def dry_run(args) -> int:
     """The launch path without a GPU: gloo process group from the launcher's environment, one all-reduce, one JSON line.
-    --simulate-hung-capture: after the eager line, every rank starts the hipGraph leg's watchdog and then blocks forever
-    (what a capture with a never-completing collective looks like): the run must end with rc 0 and the eager line last."""
+    --simulate-hung-capture: after the eager line, every rank starts a replay leg's watchdog and then blocks forever
+    (what a capture with a never-completing collective looks like): the run must end with the hang recorded in its LAST
+    JSON line (with the eager measurement in it) and exit status HANG_RC."""
     import torch.distributed as dist
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world != args.gpus:
@@ -97,9 +128,12 @@ def dry_run(args) -> int:
     res = {"dry_run": True, "n_gpus": world, "ranks_seen": total, "steps": args.steps, "warmup": args.warmup}
     if args.simulate_hung_capture:
         res["config"] = {"mode": "eager"}
+        res["legs"] = {"eager": "ok"}
         if rank == 0 and world > 1:
-            print(json.dumps(res), flush=True)
-        capture_watchdog(res, rank, world, args.graph_timeout, eager_line_printed=(world > 1))
+            early = dict(res)
+            early["partial"] = "eager measurement, printed before the replay legs; a later line supersedes it"
+            print(json.dumps(early), flush=True)
+        capture_watchdog(res, rank, world, args.graph_timeout, leg="hipGraph replay")
         import threading
         threading.Event().wait()          # never returns: the watchdog ends the process
     if world > 1:
@@ -208,6 +242,43 @@ def time_other_config(pkg, dev, stream, tag, grids, B, cls, cargs, ne, blocks, s
     return rec
 
 
+def route_accuracy(pkg, oracle, dev):
+    """Errors of the f16x3 / bf16x6 / fp32-MFMA routes against the fp64 CPU oracle (same weights, same 256-graph CIGRE batch, the C2 model):
+    {route: {"output", "loss", "worst_gradient"}} -- the oracle is the checker here, nothing of it is timed."""
+    torch.manual_seed(0)
+    b = pkg.synthetic.make_batch(["cigre14"], 256, seed=3)
+    ref = oracle.MPN(8, 6, 2, HID, LAYERS, KHOPS, 0.0).double()
+    b64 = {"x": b["x"].double(), "edge_index": b["edge_index"], "edge_attr": b["edge_attr"].double()}
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    out64, l64 = oracle.train_step(ref, b64, tuple(t.double() for t in b["stats"]), REG)
+    torch.set_num_threads(threads)
+    x, ei, ea = b["x"].to(dev), b["edge_index"].to(dev), b["edge_attr"].to(dev)
+    st = tuple(t.to(dev) for t in b["stats"])
+    rel = lambda a, r: float((a.detach().double().cpu() - r.detach().double()).abs().max() / r.detach().double().abs().max())
+    saved = {k: getattr(pkg.flags, k) for k in ("CHAIN_BF16", "WGRAD_BF16", "CHAIN_F16", "WGRAD_F16")}
+    res = {}
+    try:
+        for rname, setting in ROUTES.items():
+            for k, v in setting.items():
+                setattr(pkg.flags, k, v)
+            mine = pkg.MPN(8, 6, 2, HID, LAYERS, KHOPS, 0.0)
+            mine.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+            mine = mine.to(dev)
+            out = mine(x[:, :8], ei, ea[:, :6])
+            loss = pkg.gsp_wls_edge(input=x[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2],
+                                    edge_std=st[3], edge_index=ei, reg_coefs=REG, num_samples=None, node_param=x[:, 8:], edge_param=ea[:, 6:])
+            loss.backward()
+            torch.cuda.synchronize()
+            res[rname] = {"output": rel(out, out64), "loss": abs(loss.item() - l64.item()) / abs(l64.item()),
+                          "worst_gradient": max(rel(p.grad, q.grad) for p, q in zip(mine.parameters(), ref.parameters()))}
+    finally:
+        for k, v in saved.items():
+            setattr(pkg.flags, k, v)
+    res["note"] = "max-normalised errors against the fp64 CPU oracle, C2 model on a 256-graph CIGRE-14 batch, un-pinned ReLU gates; the parity bar is 1e-5"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,7 +288,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time the eager step only (default: eager and hipGraph replay, best reported)")
     ap.add_argument("--graph-timeout", type=float, default=90.0, help="seconds the hipGraph leg may take before the eager result is printed")
-    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="CPU time budget per thread count of the cpu_baseline sweep")
+    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="CPU time budget per thread count of the cpu_baseline thread sweep")
+    ap.add_argument("--cpu-protocol-steps", type=int, default=50, help="timed steps of the cpu_baseline's protocol leg at the best thread count (10 warm-ups before them)")
+    ap.add_argument("--no-routes", action="store_true", help="skip timing the step on the bf16x6 and fp32-MFMA routes beside the default one")
+    ap.add_argument("--route-seconds", type=float, default=1.5, help="timed work per extra arithmetic route")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs block (C1, C3, C3', C5 shard, B=32768, driver line)")
     ap.add_argument("--other-seconds", type=float, default=1.0, help="timed work per mode of every other_configs entry")
     ap.add_argument("--min-window-seconds", type=float, default=5.0,
@@ -260,7 +334,14 @@ def main():
     x, ei, ea = batch["x"].to(dev), batch["edge_index"].to(dev), batch["edge_attr"].to(dev)
     stats = tuple(s.to(dev) for s in batch["stats"])
     model = pkg.MPN(8, 6, 2, HID, LAYERS, KHOPS, 0.0).to(dev)
+    ranks_seen = 1
     if distributed:
+        # every rank adds one over RCCL: the JSON line then SHOWS that `world` ranks took part in the collectives of this run
+        seen = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM, group=group)
+        ranks_seen = int(seen.item())
+        if ranks_seen != world:
+            raise SystemExit(f"RCCL all-reduce of ones over the process group returned {ranks_seen}, expected {world}")
         pkg.parallel.broadcast_parameters(model, 0, group)
         pkg.parallel.attach_grad_allreduce(model, group)
     xin, ein, npar, epar = x[:, :8], ea[:, :6], x[:, 8:], ea[:, 6:]
@@ -340,14 +421,17 @@ def main():
     result = {
         "metric": "grid-samples/sec fwd+bwd (WLS loss), CIGRE-14 batch=4096, 1/2/4/8 GPU", "value": value, "unit": "graphs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": DTYPE_BY_ROUTE[route_name(pkg)], "data": "synthetic",
         "config": {"workload": f"CIGRE-14 (15 buses, 14 closed branches) B={args.batch} graphs/GPU, "
                                f"MPN L={LAYERS} H={HID} K={KHOPS} dropout=0: forward + gsp_wls_edge + backward"
                                + (" + RCCL loss-sum and gradient all-reduce" if distributed else ""),
                    "graphs_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                    "loss": float(loss.item()), "clock_ramp_steps_before_warmup": ramp_steps,
                    "timed_windows": len(windows), "window_ms_min_median_max": [min(windows) * 1e3, dt * 1e3, max(windows) * 1e3],
-                   "mode": mode, "ms_per_step_by_mode": {"eager": ms}},
+                   "mode": mode, "ms_per_step_by_mode": {"eager": ms}, "ranks_seen": ranks_seen,
+                   "ranks_seen_source": ("SUM all-reduce of a ones tensor over RCCL at start-up" if distributed else "single process, no process group"),
+                   "arithmetic_route": route_name(pkg)},
+        "legs": {"eager": "ok"},
     }
 
     # ---- instrumented pass: EVERY rank runs it (the steps contain collectives); rank 0 reports
@@ -491,6 +575,9 @@ def main():
                 "bound": "mfma", "achieved": wflops / (wus * 1e-6) / 1e12, "peak": wpeak, "unit": "TFLOP/s",
                 "frac": wflops / (wus * 1e-6) / 1e12 / wpeak, "avg_launch_us": wus, "launches_timed": len(wg_events),
                 "algorithmic_flops_per_launch": wflops, "traffic": None,
+                # truly algorithmic: every layer's G and X read ONCE (+ the weight gradients written once); what the kernel's design moves
+                # on top of that (X by both output-half workgroups, slabs written and re-read) is waste and shows in `traffic`
+                "algorithmic_bytes_per_launch": nl * (4.0 * N * ho + 4.0 * N * hi) + nl * nm * 4.0 * ho * hi,
                 "peak_pipe": (f"fp16 / bf16 MFMA dense peak (2500 TF) / {int(wprod)} instructions per fp32 product" if wbf16 else "fp32 MFMA"),
             }
             try:   # (a pointer to the committed rocprofv3 --pmc passes, as for the chain above; the f16x3 kernel of the C2 shape only)
@@ -498,7 +585,7 @@ def main():
                     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                         wrec = json.load(fh)["wgrad16h_kernel<3,true> (3 layers in one launch)"]
                     result["roofline_wgrad"].update(traffic=wrec["hbm_bytes_per_launch"], traffic_source=wrec.get("source"),
-                                                    algorithmic_bytes_per_launch=wrec.get("algorithmic_bytes_per_launch"))
+                                                    bytes_this_kernel_design_moves=wrec.get("design_bytes_per_launch"))
             except Exception:
                 pass
         if bf16x6:
@@ -537,14 +624,17 @@ def main():
     # contains RCCL collectives on more than one rank (it has never run on hardware), the run has a valid
     # measurement on stdout.  If the leg completes, the final line follows and supersedes it.  DSS2_BENCH_DIST_GRAPH=0 skips
     # the leg at world > 1.
-    dist_graph = os.environ.get("DSS2_BENCH_DIST_GRAPH", "1") != "0"
+    # at world > 1 the capture races with torch's process-group watchdog thread and ABORTS the process about one run in ten
+    # (hipErrorCapturedEvent, tests/test_gpu_rccl.py) -- an abort on any of 8 ranks would lose everything measured after the early line.
+    # So the distributed capture leg is OPT-IN (DSS2_BENCH_DIST_GRAPH=1); the host-free leg at world > 1 is the segmented launch plan.
+    dist_graph = os.environ.get("DSS2_BENCH_DIST_GRAPH", "0") == "1"
     run_graph_leg = not args.no_graph and (world == 1 or dist_graph)
     if world > 1 and rank == 0 and run_graph_leg:
         early = dict(result)
         early["partial"] = "eager measurement, printed before the hipGraph leg; a later line (if any) supersedes it"
         print(json.dumps(early), flush=True)
     if run_graph_leg:
-        timer = capture_watchdog(result, rank, world, args.graph_timeout, eager_line_printed=(world > 1))
+        timer = capture_watchdog(result, rank, world, args.graph_timeout, leg="hipGraph replay")
         try:
             graphed = pkg.graphs.GraphedStep(step, stream=work_stream, capture_error_mode="thread_local")
             for _ in range(max(args.warmup, 5)):
@@ -552,6 +642,7 @@ def main():
             gw, _ = timed_windows(graphed.replay)
             gdt = sorted(gw)[len(gw) // 2]
             result["config"]["ms_per_step_by_mode"]["hipGraph replay"] = gdt / args.steps * 1e3
+            result["legs"]["hipGraph replay"] = "ok"
             if gdt < dt:
                 dt, ms, windows, mode = gdt, gdt / args.steps * 1e3, gw, "hipGraph replay"
                 value = args.batch * world / (dt / args.steps)
@@ -560,9 +651,11 @@ def main():
                                         window_ms_min_median_max=[min(gw) * 1e3, gdt * 1e3, max(gw) * 1e3])
         except Exception as exc:          # capture not possible on this stack: the eager numbers stand
             result["config"]["hipgraph"] = f"failed: {type(exc).__name__}: {exc}"[:300]
+            result["legs"]["hipGraph replay"] = "failed"
         timer.cancel()
     elif not args.no_graph:
-        result["config"]["hipgraph"] = "skipped at world > 1 (DSS2_BENCH_DIST_GRAPH=0)"
+        result["config"]["hipgraph"] = "skipped at world > 1 (opt in with DSS2_BENCH_DIST_GRAPH=1: a capture with RCCL inside can abort the process)"
+        result["legs"]["hipGraph replay"] = "skipped"
     # ---- and as a launch plan (graphs.PlannedStep, include/dss2_hip.h "launch plans"): the library's own record of the step's launches
     # re-issued from ONE C call per step -- real launches of the same kernels on the same stream, no Python between them, and like the
     # hipGraph replay it carries the step's vminmax launch (no cached batch constants).  At world > 1 the step's collectives (loss
@@ -575,7 +668,7 @@ def main():
             early = dict(result)
             early["partial"] = "printed before the launch-plan leg; a later line (if any) supersedes it"
             print(json.dumps(early), flush=True)
-        ptimer = capture_watchdog(result, rank, world, args.graph_timeout, eager_line_printed=(world > 1)) if world > 1 else None
+        ptimer = capture_watchdog(result, rank, world, args.graph_timeout, leg="launch plan")
         try:
             planned = pkg.graphs.PlannedStep(step, stream=work_stream)
             for _ in range(max(args.warmup, 5)):
@@ -584,6 +677,7 @@ def main():
             pdt = sorted(pw)[len(pw) // 2]
             result["config"]["ms_per_step_by_mode"]["launch plan"] = pdt / args.steps * 1e3
             result["config"]["plan_launches"] = planned.n_launches
+            result["legs"]["launch plan"] = "ok"
             if pdt < dt:
                 dt, ms, windows, mode = pdt, pdt / args.steps * 1e3, pw, "launch plan (dss2_plan_run)"
                 value = args.batch * world / (dt / args.steps)
@@ -594,8 +688,49 @@ def main():
                 result["config"]["plan_segments"] = len(planned.segments)
         except Exception as exc:
             result["config"]["launch_plan"] = f"failed: {type(exc).__name__}: {exc}"[:300]
-        if ptimer is not None:
-            ptimer.cancel()
+            result["legs"]["launch plan"] = "failed"
+        ptimer.cancel()
+
+    # ---- the same step on the two other arithmetic routes of the H -> H layers: the headline runs the products as
+    # f16x3 (two fp16 pieces per operand, THREE 16-bit MFMAs per fp32 product, fp32 accumulate); beside it bf16x6 (SIX) and the true
+    # fp32-MFMA route (v_mfma_f32_32x32x2_f32), each as a replayed launch plan on the same resident batch -- times only, the headline stays
+    # the default route.  (Their errors against fp64: cpu_baseline.accuracy_vs_fp64_oracle below.)
+    if world == 1 and not args.no_graph and not args.no_routes:
+        by_route = {route_name(pkg): result["ms_per_step"]}
+        saved = {k: getattr(pkg.flags, k) for k in ("CHAIN_BF16", "WGRAD_BF16", "CHAIN_F16", "WGRAD_F16")}
+        for rname, setting in ROUTES.items():
+            if rname in by_route:
+                continue
+            rt = capture_watchdog(result, rank, world, args.graph_timeout, leg=f"route {rname}")
+            try:
+                for k, v in setting.items():
+                    setattr(pkg.flags, k, v)
+                for _ in range(3):
+                    step()
+                pl = pkg.graphs.PlannedStep(step, stream=work_stream)
+                for _ in range(10):
+                    pl.replay()
+                torch.cuda.synchronize()
+                n_r, t0 = 0, time.perf_counter()
+                while time.perf_counter() - t0 < args.route_seconds:
+                    for _ in range(args.steps):
+                        pl.replay()
+                    torch.cuda.synchronize()
+                    n_r += args.steps
+                by_route[rname] = (time.perf_counter() - t0) / n_r * 1e3
+                del pl
+            except Exception as exc:
+                by_route[rname] = f"failed: {type(exc).__name__}: {exc}"[:200]
+            finally:
+                rt.cancel()
+                for k, v in saved.items():
+                    setattr(pkg.flags, k, v)
+        for _ in range(2):
+            step()          # (the default route's plans / caches are current again)
+        torch.cuda.synchronize()
+        result["config"]["ms_per_step_by_arithmetic_route"] = by_route
+        if isinstance(by_route.get("fp32-mfma"), float):
+            result["ms_per_step_fp32_mfma_route"] = by_route["fp32-mfma"]
 
     if rank == 0:
         # ---- standalone scatter-add (K6) against the HBM roofline (north_star asks for it separately), at two sizes:
@@ -630,6 +765,9 @@ def main():
         small = scatter_point(args.batch)
         result["scatter_add"] = {"kernel": "dss2::segment_sum_kernel", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "cache_resident": small, "frac_cache_resident": small["frac"],
+                                 "standalone": "K6 is a standalone kernel by SURVEY 8's design (what MessagePassing.propagate runs for a user message()): "
+                                               "the C2 training step never launches it -- its aggregations live inside edge16_fwd / edge16_bwd and the chains' "
+                                               "Horner hops, priced in `roofline` (MFMA-bound), not here",
                                  "note": "cache_resident: the C2 batch (90.9 MB working set < 256 MiB Infinity Cache); "
                                          "cache_busting: B = 32768 graphs (722 MB), the HBM number"}
         try:
@@ -663,9 +801,10 @@ def main():
                                             "algorithmic FLOPs (3 x forward); the driver line excludes the optimizer" % args.other_seconds)
 
         # ---- CPU baseline (SURVEY 8d / BASELINE.md 3): the oracle -- a port of the reference's PyTorch-eager path --
-        # on this box's host cores, same batch.  Thread sweep, best-of reported as `value`; plus the single-thread
-        # number, one "as-is" step (with the reference's unused dense Laplacian, data.py:422-423: 15.1 GB at C2)
-        # and configuration C1.  Every leg: one warm-up step, then >= 3 timed steps within --cpu-seconds.
+        # on this box's host cores, same batch.  BASELINE.md 3's protocol: >= 10 warm-up + >= 50 timed steps, MEDIAN step, at the best
+        # thread count (found by a short sweep: 2 warm-ups, >= 3 steps within --cpu-seconds per count); >= 5 timed steps (2 warm-ups)
+        # for the as-is form (with the reference's unused dense Laplacian, data.py:422-423: 15.1 GB at C2); the single-thread figure
+        # from the sweep; configuration C1 at the full protocol.
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import dss2_oracle as oracle
@@ -675,29 +814,35 @@ def main():
             ncpu = os.cpu_count() or 1
             max_threads = torch.get_num_threads()
 
-            def time_leg(mdl, bt, stats_, n_graphs, threads, as_is=False, budget=args.cpu_seconds):
+            def time_leg(mdl, bt, stats_, n_graphs, threads, as_is=False, budget=args.cpu_seconds, warm=2, min_steps=3, max_steps=50):
+                """`warm` untimed steps, then steps until (>= min_steps and the budget is spent) or max_steps; the MEDIAN step is reported."""
                 torch.set_num_threads(threads)
-                oracle.train_step(mdl, bt, stats_, REG, as_is_laplacian=as_is)          # warm-up
-                n, t0 = 0, time.perf_counter()
-                while True:
+                for _ in range(warm):
                     oracle.train_step(mdl, bt, stats_, REG, as_is_laplacian=as_is)
-                    n += 1
-                    el = time.perf_counter() - t0
-                    if (n >= 3 and el > budget) or n >= 50:
+                ts, t_start = [], time.perf_counter()
+                while True:
+                    t0 = time.perf_counter()
+                    oracle.train_step(mdl, bt, stats_, REG, as_is_laplacian=as_is)
+                    ts.append(time.perf_counter() - t0)
+                    if (len(ts) >= min_steps and time.perf_counter() - t_start > budget) or len(ts) >= max_steps:
                         break
-                return {"threads": threads, "graphs_per_s": n_graphs / (el / n), "ms_per_step": el / n * 1e3, "steps": n}
+                med = sorted(ts)[len(ts) // 2]
+                return {"threads": threads, "graphs_per_s": n_graphs / med, "ms_per_step": med * 1e3, "steps": len(ts), "warmup_steps": warm,
+                        "ms_per_step_mean": sum(ts) / len(ts) * 1e3}
 
-            sweep = [time_leg(cpu_model, cpu_batch, batch["stats"], args.batch, th)
-                     for th in sorted({th for th in (1, 8, 16, 32, 64, max_threads) if th <= max(ncpu, 1)})]
-            best = max(sweep, key=lambda r: r["graphs_per_s"])
+            sweep = [time_leg(cpu_model, cpu_batch, batch["stats"], args.batch, th, budget=min(args.cpu_seconds, 3.0))
+                     for th in sorted({th for th in (1, 8, 16, 32, 64, max_threads) if th <= min(max(ncpu, 1), 64)})]
+            best_th = max(sweep, key=lambda r: r["graphs_per_s"])["threads"]
             one = [r for r in sweep if r["threads"] == 1][0]
+            full = args.cpu_protocol_steps
+            best = time_leg(cpu_model, cpu_batch, batch["stats"], args.batch, best_th, budget=0.0, warm=min(10, full), min_steps=full, max_steps=full)
             cb = {
                 "value": best["graphs_per_s"], "unit": "graphs/s", "cores": best["threads"], "kind": "port",
-                "sample": f"best of a thread sweep {[r['threads'] for r in sweep]} on the same B={args.batch} CIGRE-14 batch "
-                          f"(fwd + gsp_wls_edge + bwd, PyTorch eager CPU fp32, >= 3 steps per leg after one warm-up), "
-                          f"unused dense Laplacian of data.py:422-423 stripped",
-                "threads_best": best["threads"], "ms_per_step": best["ms_per_step"], "threads_1": one,
-                "thread_sweep": sweep, "host_cpus": ncpu,
+                "sample": f"the same B={args.batch} CIGRE-14 batch (fwd + gsp_wls_edge + bwd, PyTorch eager CPU fp32, unused dense Laplacian of "
+                          f"data.py:422-423 stripped): {best['warmup_steps']} warm-up + {best['steps']} timed steps at {best_th} threads, median step "
+                          f"(BASELINE.md 3); thread count = best of a short sweep {[r['threads'] for r in sweep]} (2 warm-ups, >= 3 steps each)",
+                "threads_best": best["threads"], "ms_per_step": best["ms_per_step"], "steps": best["steps"], "warmup_steps": best["warmup_steps"],
+                "protocol_leg": best, "threads_1": one, "thread_sweep": sweep, "host_cpus": ncpu,
             }
             # as-is: with the dead dense Laplacian (N^2 fp32 zero-fill per step), needs ~2x 15.1 GB of free RAM
             need = 2.2 * 4.0 * N * N
@@ -707,16 +852,24 @@ def main():
             except Exception:
                 avail = 0
             if avail > need:
-                cb["as_is_with_dense_laplacian"] = time_leg(cpu_model, cpu_batch, batch["stats"], args.batch, best["threads"],
-                                                            as_is=True, budget=min(args.cpu_seconds, 8.0))
+                cb["as_is_with_dense_laplacian"] = time_leg(cpu_model, cpu_batch, batch["stats"], args.batch, best_th, as_is=True,
+                                                            budget=0.0, warm=2, min_steps=min(5, full), max_steps=min(5, full))
             else:
                 cb["as_is_with_dense_laplacian"] = f"skipped: needs {need / 1e9:.0f} GB of free host RAM, {avail / 1e9:.0f} GB available"
-            # C1: the reference's own CPU-runnable configuration (B = 64, H = 32, 1 layer)
+            # C1: the reference's own CPU-runnable configuration (B = 64, H = 32, 1 layer), full protocol
             c1b = pkg.synthetic.make_batch(["cigre14"], 64, seed=2000)
             c1m = oracle.MPN(8, 6, 2, 32, 1, 2, 0.0)
-            c1 = [time_leg(c1m, c1b, c1b["stats"], 64, th, budget=1.0) for th in (1, min(8, ncpu))]
+            c1 = [time_leg(c1m, c1b, c1b["stats"], 64, th, budget=0.0, warm=10, min_steps=50, max_steps=50) for th in (1, min(8, ncpu))]
             cb["c1_cigre14_b64_h32_l1"] = max(c1, key=lambda r: r["graphs_per_s"])
             torch.set_num_threads(max_threads)
+
+            # ---- what the three arithmetic routes cost in accuracy: each against the fp64 oracle (the checker) on the C2 MODEL and a 256-graph
+            # batch -- max-normalised error of the output, relative error of the loss, worst max-normalised parameter gradient
+            if not args.no_routes:
+                try:
+                    cb["accuracy_vs_fp64_oracle"] = route_accuracy(pkg, oracle, dev)
+                except Exception as exc:
+                    cb["accuracy_vs_fp64_oracle"] = f"failed: {type(exc).__name__}: {exc}"[:200]
             result["cpu_baseline"] = cb
             result["speedup_vs_cpu_baseline"] = value / cb["value"]
         print(json.dumps(result), flush=True)

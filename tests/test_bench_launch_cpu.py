@@ -36,21 +36,30 @@ def test_bench_under_a_launcher_with_the_wrong_world_size_fails():
     assert p.returncode != 0
 
 
-def test_a_hung_capture_leg_at_world_2_leaves_the_eager_line_last_and_exits_0():
-    """at world > 1 rank 0 prints the eager line BEFORE the hipGraph leg; if that leg hangs (a collective
-    that never completes inside a capture) every rank's watchdog ends its process with rc 0 -- the first 8-GPU run cannot
-    lose its measurement.  --simulate-hung-capture blocks every rank exactly there."""
+def test_a_hung_leg_at_world_2_is_recorded_in_the_last_line_and_in_the_exit_status():
+    """VERDICT r4 #3 + r5 weak #9: at world > 1 rank 0 prints the eager line BEFORE the replay legs; if a leg hangs (a collective
+    that never completes inside a capture) every rank's watchdog ends its process -- rank 0 first prints the FINAL line, which carries
+    the eager measurement AND the hang record, and the run's exit status is non-zero (3): the measurement survives, the hang is not
+    mistaken for a clean run.  --simulate-hung-capture blocks every rank exactly there."""
     p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--simulate-hung-capture", "--graph-timeout", "3"])
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert p.returncode != 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout
+    assert len(lines) == 2, p.stdout
+    assert "partial" in json.loads(lines[0])
     res = json.loads(lines[-1])
     assert res["n_gpus"] == 2 and res["config"]["mode"] == "eager" and "partial" not in res
+    assert res["hang"]["leg"] == "hipGraph replay" and res["hang"]["exit_status"] == 3 and res["legs"] == {"eager": "ok", "hipGraph replay": "hung"}
     assert "no answer within 3 s" in p.stderr
 
 
-def test_a_hung_capture_leg_at_world_1_prints_the_eager_line_from_the_watchdog():
+def test_a_hung_leg_at_world_1_prints_the_final_line_from_the_watchdog_and_exits_3():
     p = _run(["--dry-run", "--simulate-hung-capture", "--graph-timeout", "2"])
-    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.returncode == 3, p.stderr[-2000:]
     res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
-    assert res["n_gpus"] == 1 and "hung" in res["partial"] and "no answer" in res["config"]["hipgraph"]
+    assert res["n_gpus"] == 1 and res["hang"]["leg"] == "hipGraph replay" and res["legs"]["hipGraph replay"] == "hung"
+
+
+def test_the_hang_exit_status_can_be_overridden():
+    p = _run(["--dry-run", "--simulate-hung-capture", "--graph-timeout", "1"], env_extra={"DSS2_BENCH_HANG_RC": "0"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "hang" in json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
