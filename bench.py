@@ -223,7 +223,7 @@ def time_other_config(pkg, dev, stream, tag, grids, B, cls, cargs, ne, blocks, s
     # eager step costs without the Python around every launch -- for steps that cannot be captured into a hipGraph
     if B <= 4096:
         try:
-            pl = pkg.graphs.PlannedStep(step, stream=stream)
+            pl = pkg.graphs.PlannedStep(step, stream=stream, verify=(None if cargs[6] > 0 else (lambda: [p.grad for p in params])))
             rec["ms_per_step_plan"], rec["plan_launches"] = timed(pl.replay), pl.n_launches
             del pl
         except Exception as exc:
@@ -240,6 +240,134 @@ def time_other_config(pkg, dev, stream, tag, grids, B, cls, cargs, ne, blocks, s
     del g, model, x, ei, ea
     torch.cuda.empty_cache()
     return rec
+
+
+# End-to-end training epochs (the reference's loop is dss2_run.py:131-147 with the loader of :68-69): device-resident dataset ->
+# shuffle on the device -> collation straight into the recorded step's static buffers -> forward + gsp_wls_edge + backward -> fused Adamax,
+# an epoch = N replays of one recorded step (runner.EpochTrainer).  (tag, grid, graphs per batch, class, ctor args, batches per epoch)
+TRAIN_EPOCHS = [
+    ("train epoch C2: cigre14 B=4096 H=128 L=4, 64 batches/epoch", "cigre14", 4096, "MPN", (8, 6, 2, 128, 4, 2, 0.0), 64),
+    ("train epoch SkipPFN driver line: cigre14 B=64 H=32 8 layers x 5 blocks dropout 0.3, 64 batches/epoch", "cigre14", 64, "SkipPFN", (8, 6, 2, 32, 8, 2, 0.3, 5), 64),
+]
+
+
+def time_train_epoch(pkg, dev, stream, tag, grid, B, cls, cargs, n_batches, epochs=3):
+    """ms per training step END TO END over `epochs` shuffled epochs of `n_batches` batches, beside the same training step (with the optimizer)
+    replayed on ONE resident batch, and the host's wall time per batch (how long the loop needs to hand a batch to the GPU)."""
+    torch.manual_seed(0)
+    base = pkg.synthetic.make_batch([grid], min(B, 4096), seed=7)
+    ds0 = pkg.dataset.DeviceDataset.from_batch(base, device=dev)
+    reps = -(-B * n_batches // ds0.S)
+    ds = pkg.dataset.DeviceDataset(ds0.x.repeat(reps, 1, 1)[:B * n_batches].contiguous(), ds0.edge_attr.repeat(reps, 1, 1)[:B * n_batches].contiguous(),
+                                   ds0.y.repeat(reps, 1, 1)[:B * n_batches].contiguous(), ds0.edge_index.repeat(reps, 1, 1)[:B * n_batches].contiguous())
+    st = tuple(t_.to(dev) for t_ in base["stats"])
+    rec = {"graphs_per_batch": B, "batches_per_epoch": n_batches, "epochs_timed": epochs, "samples_resident": ds.S}
+    for mode in ("plan", "graph"):
+        model = getattr(pkg, cls)(*cargs).to(dev)
+        opt = pkg.optim.FusedAdamax(model.parameters(), lr=3e-3, capturable=True)
+        try:
+            tr = pkg.runner.EpochTrainer(model, opt, st, REG, ds, B, shuffle=True, mode=mode)
+            tr.train_epoch()                                 # warm-up epoch
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(epochs):
+                tr.train_epoch()
+            t_host = time.perf_counter() - t0                # the host has handed over every batch of every epoch
+            loss = tr.mean_loss()                            # (the epochs' only synchronisation)
+            t_all = time.perf_counter() - t0
+            rec[f"ms_per_step_end_to_end_{mode}"] = t_all / (epochs * n_batches) * 1e3
+            rec[f"loader_and_launch_host_us_per_batch_{mode}"] = t_host / (epochs * n_batches) * 1e6
+            rec[f"launches_per_step_{mode}"] = getattr(tr.steps[B][0], "n_launches", None)
+            rec["last_epoch_mean_loss"] = loss
+            # the same recorded step WITHOUT the loader in front of it: one resident batch, replayed
+            sx = tr.steps[B][1]
+            del tr
+            m2 = getattr(pkg, cls)(*cargs).to(dev)
+            o2 = pkg.optim.FusedAdamax(m2.parameters(), lr=3e-3, capturable=True)
+            ei, _ = ds.batch_structure(B)
+            bt = ds.collate(ds.ids[:B].contiguous())
+            p2 = list(m2.parameters())
+
+            def resident():
+                for p in p2:
+                    p.grad = None
+                out = m2(bt.x[:, :8], ei, bt.edge_attr[:, :6])
+                l_ = pkg.gsp_wls_edge(input=bt.x[:, :8], edge_input=bt.edge_attr[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2],
+                                      edge_std=st[3], edge_index=ei, reg_coefs=REG, num_samples=None, node_param=bt.x[:, 8:], edge_param=bt.edge_attr[:, 6:])
+                l_.backward(pkg.data.unit_grad(l_))
+                o2.step()
+                return l_
+            g = pkg.graphs.PlannedStep(resident, stream=stream) if mode == "plan" else pkg.graphs.GraphedStep(resident, stream=stream)
+            for _ in range(10):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(epochs * n_batches):
+                g.replay()
+            torch.cuda.synchronize()
+            rec[f"ms_per_step_resident_batch_{mode}"] = (time.perf_counter() - t0) / (epochs * n_batches) * 1e3
+            del g, m2, o2, sx
+        except Exception as exc:
+            rec[f"error_{mode}"] = f"{type(exc).__name__}: {exc}"[:300]
+        torch.cuda.empty_cache()
+    e2e = [rec[k] for k in ("ms_per_step_end_to_end_plan", "ms_per_step_end_to_end_graph") if k in rec]
+    res = [rec[k] for k in ("ms_per_step_resident_batch_plan", "ms_per_step_resident_batch_graph") if k in rec]
+    if e2e and res:
+        rec.update(ms_per_step=min(e2e), ms_per_step_resident_batch=min(res), end_to_end_over_resident=min(e2e) / min(res),
+                   graphs_per_s=B / (min(e2e) * 1e-3))
+    rec["what"] = ("shuffled epochs from a device-resident dataset: permutation drawn on the device per epoch; per step ONE C call (plan) / one "
+                   "hipGraph launch (graph) whose first launch gathers the batch into the step's static buffers (dss2_collate_cursor) and whose last "
+                   "ones are the fused Adamax and the loss accumulation; one host synchronisation per timed run")
+    return rec
+
+
+def time_c5_fresh_batches(pkg, dev, seconds=1.5, B=4096, S=8192):
+    """BASELINE config C5 as it words it ("variable edge_index per sample"): a NEW Bernoulli(0.5) mix of cigre14 / cigre14_reswitched graphs
+    every step -- ragged collation + the batch's graph structure (CSR, tiles, ELL) built on the device per step.  ms/step on a resident batch,
+    with a fresh batch per step assembled in line (dataset.DataLoader), and assembled one batch ahead on a side stream (dataset.PrefetchLoader)."""
+    import numpy as np
+    full = pkg.synthetic.make_batch(["cigre14", "cigre14_reswitched"], 256, seed=1)
+    parts = [pkg.dataset.DeviceDataset.from_batch(pkg.synthetic.make_batch([g], S, seed=2 + k, stats=full["stats"]), device=dev)
+             for k, g in enumerate(["cigre14", "cigre14_reswitched"])]
+    ds = pkg.dataset.MixedDataset(parts)
+    st = tuple(s_.to(dev) for s_ in full["stats"])
+    model = pkg.MPN(8, 6, 2, 256, 8, 2, 0.0).to(dev)
+    params = list(model.parameters())
+
+    def step(bt):
+        for p in params:
+            p.grad = None
+        out = model(bt.x[:, :8], bt.edge_index, bt.edge_attr[:, :6])
+        loss = pkg.gsp_wls_edge(input=bt.x[:, :8], edge_input=bt.edge_attr[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2],
+                                edge_std=st[3], edge_index=bt.edge_index, reg_coefs=REG, num_samples=None, node_param=bt.x[:, 8:],
+                                edge_param=bt.edge_attr[:, 6:])
+        loss.backward(pkg.data.unit_grad(loss))
+        return loss
+
+    def run(loader_factory):
+        n, t0 = 0, None
+        while True:
+            for bt in loader_factory():
+                step(bt)
+                n += 1
+                if t0 is None and n == 4:          # (warm-up batches)
+                    torch.cuda.synchronize()
+                    t0, n0 = time.perf_counter(), n
+            torch.cuda.synchronize()
+            if time.perf_counter() - t0 >= seconds:
+                return (time.perf_counter() - t0) / (n - n0) * 1e3
+    gen = torch.Generator()
+    gen.manual_seed(0)
+    plain = lambda: pkg.dataset.DataLoader(ds, batch_size=B, shuffle=True, generator=gen)
+    bt0 = next(iter(plain()))
+    t_res = run(lambda: [bt0] * 8)
+    t_inline = run(plain)
+    t_pref = run(lambda: pkg.dataset.PrefetchLoader(plain()))
+    return {"graphs": B, "ms_per_step_resident_batch": t_res, "ms_per_step_fresh_batch_inline": t_inline, "ms_per_step_fresh_batch_prefetched": t_pref,
+            "fresh_batch_overhead_inline": t_inline / t_res - 1.0, "fresh_batch_overhead_prefetched": t_pref / t_res - 1.0,
+            "ms_per_step": t_pref, "graphs_per_s": B / (t_pref * 1e-3),
+            "what": "MPN H=256 L=8, eager steps; every step a new mix of the two topologies: ragged collation + device CSR / tile / ELL build, "
+                    "in line on the step's stream vs one batch ahead on a side stream (PrefetchLoader)"}
 
 
 def route_accuracy(pkg, oracle, dev):
@@ -293,6 +421,7 @@ def main():
     ap.add_argument("--no-routes", action="store_true", help="skip timing the step on the bf16x6 and fp32-MFMA routes beside the default one")
     ap.add_argument("--route-seconds", type=float, default=1.5, help="timed work per extra arithmetic route")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs block (C1, C3, C3', C5 shard, B=32768, driver line)")
+    ap.add_argument("--no-train-epochs", action="store_true", help="skip the end-to-end training epochs in other_configs")
     ap.add_argument("--other-seconds", type=float, default=1.0, help="timed work per mode of every other_configs entry")
     ap.add_argument("--min-window-seconds", type=float, default=5.0,
                     help="repeat the K-step timed window until this much timed work has accumulated; the median window is "
@@ -670,7 +799,8 @@ def main():
             print(json.dumps(early), flush=True)
         ptimer = capture_watchdog(result, rank, world, args.graph_timeout, leg="launch plan")
         try:
-            planned = pkg.graphs.PlannedStep(step, stream=work_stream)
+            # (verify: one replay must reproduce the recorded step's gradients bit for bit -- a launch the plan does not carry would show here)
+            planned = pkg.graphs.PlannedStep(step, stream=work_stream, verify=(lambda: [p.grad for p in params]) if world == 1 else None)
             for _ in range(max(args.warmup, 5)):
                 planned.replay()
             pw, _ = timed_windows(planned.replay)
@@ -794,6 +924,18 @@ def main():
                 except Exception as exc:      # e.g. a box short of memory at B = 32768
                     others[tag] = {"skipped": f"{type(exc).__name__}: {exc}"[:200]}
                     torch.cuda.empty_cache()
+            if not args.no_train_epochs:
+                try:
+                    others["C5 shuffled: a new topology mix every step, B=4096 H=256 L=8"] = time_c5_fresh_batches(pkg, dev)
+                except Exception as exc:
+                    others["C5 shuffled: a new topology mix every step, B=4096 H=256 L=8"] = {"skipped": f"{type(exc).__name__}: {exc}"[:200]}
+                    torch.cuda.empty_cache()
+                for tag, grid, B_, cls, cargs, nbat in TRAIN_EPOCHS:
+                    try:
+                        others[tag] = time_train_epoch(pkg, dev, work_stream, tag, grid, B_, cls, cargs, nbat)
+                    except Exception as exc:
+                        others[tag] = {"skipped": f"{type(exc).__name__}: {exc}"[:200]}
+                        torch.cuda.empty_cache()
             result["other_configs"] = others
             result["other_configs_note"] = ("forward + gsp_wls_edge + backward on a resident synthetic batch, one GPU, eager, as a hipGraph "
                                             "replay and as a launch plan (one C call per step, dss2_plan_run), >= %.1f s of timed work each; "

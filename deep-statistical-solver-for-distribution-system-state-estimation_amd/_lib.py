@@ -231,6 +231,8 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "dss2_masked_zscore_scratch_doubles": (C.c_int64, [C.c_int64]),
     "dss2_collate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dss2_collate_cursor": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "dss2_accum_scalar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dss2_collate_ragged": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "dss2_adamax_step": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "dss2_adamax_step_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),

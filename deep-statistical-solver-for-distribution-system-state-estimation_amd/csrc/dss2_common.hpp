@@ -36,6 +36,9 @@ void plan_record(std::function<int(void*)> op);
 template <class T> inline std::vector<T> plan_keep(const T* p, size_t n) { return p ? std::vector<T>(p, p + n) : std::vector<T>(); }
 template <class T> inline const T* plan_ptr(const std::vector<T>& v) { return v.empty() ? nullptr : v.data(); }
 #define DSS2_RECORD(...) do { if (dss2::plan_recording()) dss2::plan_record(__VA_ARGS__); } while (0)
+// Entry points that are NOT part of a step (structure build, measurement model, z-score: they size their outputs from host-side
+// facts of the batch) refuse to run while a plan records: a plan that silently skipped them would replay on stale structure.
+#define DSS2_NOT_IN_PLAN(name) do { if (dss2::plan_recording()) { dss2::set_error(name ": not available while a launch plan records (it is not a launch of a training step; build it before dss2_plan_begin)"); return 3; } } while (0)
 
 // 32x32 MFMA accumulator register r of lane -> row inside the 32-row block
 // (col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); CDNA4 C/D layout.

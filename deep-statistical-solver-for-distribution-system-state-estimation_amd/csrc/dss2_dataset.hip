@@ -147,10 +147,15 @@ __global__ void __launch_bounds__(256) masked_normalize_kernel(const float* __re
 // One workgroup per (selected sample, array): a contiguous chunk copy; edge_index chunks get the node
 // offset of the sample's slot in the batch added (PyG Batch semantics).
 struct CollateTable { dss2_collate_desc d[4]; };   // by value in the kernel arguments: no descriptor copy to the device
-__global__ void __launch_bounds__(256) collate_kernel(const CollateTable tab, const long long* __restrict__ ids, long long B) {
+__global__ void __launch_bounds__(256) collate_kernel(const CollateTable tab, const long long* __restrict__ ids, long long B,
+                                                      const long long* __restrict__ cursor) {
   const dss2_collate_desc& d = tab.d[blockIdx.y];
   const long long b = blockIdx.x;
-  const long long s = ids ? ids[b] : b;
+  // cursor (dss2_collate_cursor): the batch's ids start at element cursor[0] of `ids`, wrapped into [0, cursor[1]) -- the position
+  // lives on the device, so the launch is the same every step and can be replayed (hipGraph / launch plan)
+  long long pos = b;
+  if (cursor) { pos += cursor[0]; const long long n = cursor[1]; if (n > 0) pos %= n; }
+  const long long s = ids ? ids[pos] : pos;
   if (d.kind == 0) {
     const float* src = static_cast<const float*>(d.src) + s * d.chunk;
     float* dst = static_cast<float*>(d.dst) + b * d.chunk;
@@ -195,6 +200,20 @@ __global__ void __launch_bounds__(256) collate_ragged_kernel(const RaggedArgs a)
   }
 }
 
+// advances a collation cursor by one batch (stream-ordered behind the collation that read it) and wraps it at the epoch's end
+__global__ void cursor_advance_kernel(long long* cursor, long long B) {
+  long long p = cursor[0] + B;
+  const long long n = cursor[1];
+  if (n > 0 && p >= n) p -= n;
+  cursor[0] = p;
+}
+
+// acc[0] += *value, acc[1] += 1: the per-epoch mean of the step losses (dss2_run.py:146-147) without a torch kernel in the step
+__global__ void accum_scalar_kernel(double* acc, const float* value) {
+  acc[0] += (double)value[0];
+  acc[1] += 1.0;
+}
+
 }  // namespace dss2
 
 using namespace dss2;
@@ -202,6 +221,7 @@ using namespace dss2;
 extern "C" int dss2_measure_nodes(const double* nodes, const uint8_t* meas_v_mask, int32_t n_per_sample, const double* z,
                                   double v_noise, double pm_noise, double p_noise, double zero_inj_coef, float* x,
                                   int64_t rows, void* stream) {
+  DSS2_NOT_IN_PLAN("dss2_measure_nodes");
   if (rows <= 0) return 0;
   if (!nodes || !meas_v_mask || !z || !x || n_per_sample <= 0) { set_error("measure_nodes: null argument"); return 2; }
   hipLaunchKernelGGL(measure_nodes_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), nodes,
@@ -211,6 +231,7 @@ extern "C" int dss2_measure_nodes(const double* nodes, const uint8_t* meas_v_mas
 
 extern "C" int dss2_measure_edges(const double* edges, const uint8_t* meas_pflow_mask, int32_t e_per_sample, const double* z,
                                   double p_noise, float* edge_attr, int64_t rows, void* stream) {
+  DSS2_NOT_IN_PLAN("dss2_measure_edges");
   if (rows <= 0) return 0;
   if (!edges || !meas_pflow_mask || !z || !edge_attr || e_per_sample <= 0) { set_error("measure_edges: null argument"); return 2; }
   hipLaunchKernelGGL(measure_edges_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), edges,
@@ -220,6 +241,7 @@ extern "C" int dss2_measure_edges(const double* edges, const uint8_t* meas_pflow
 
 extern "C" int dss2_masked_zscore(const float* t, int64_t rows, int32_t ld, int32_t num_feat, float* out, int32_t ld_out,
                                   float* mean, float* stdv, double* scratch, void* stream) {
+  DSS2_NOT_IN_PLAN("dss2_masked_zscore");
   if (rows <= 0) return 0;
   if (num_feat <= 0 || num_feat > ZS_MAXC || num_feat > ld) { set_error("masked_zscore: num_feat %d out of range 1..%d", num_feat, ZS_MAXC); return 2; }
   if (!t || !out || !mean || !stdv || !scratch) { set_error("masked_zscore: null argument"); return 2; }
@@ -244,25 +266,61 @@ extern "C" int64_t dss2_masked_zscore_scratch_doubles(int64_t rows) {
   return ZS_MAXC + nb * 2 * ZS_MAXC;
 }
 
+static int collate_launch(const CollateTable& tab, int32_t n_desc, const int64_t* sample_ids, int64_t batch, int64_t* cursor, int advance,
+                          void* stream) {
+  static_assert(sizeof(long long) == sizeof(int64_t), "int64");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(collate_kernel, dim3((unsigned)batch, (unsigned)n_desc), dim3(256), 0, s, tab,
+                     reinterpret_cast<const long long*>(sample_ids), (long long)batch, reinterpret_cast<const long long*>(cursor));
+  if (cursor && advance)
+    hipLaunchKernelGGL(cursor_advance_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<long long*>(cursor), (long long)batch);
+  return check_launch("collate");
+}
+
+static int collate_table(const dss2_collate_desc* descs_host, int32_t n_desc, CollateTable* tab) {
+  if (!descs_host || n_desc < 1 || n_desc > 4) { set_error("collate: 1..4 descriptors expected, got %d", n_desc); return 2; }
+  *tab = CollateTable{};
+  for (int i = 0; i < n_desc; ++i) {
+    tab->d[i] = descs_host[i];
+    if (!tab->d[i].src || !tab->d[i].dst || tab->d[i].chunk <= 0) { set_error("collate: descriptor %d is incomplete", i); return 2; }
+  }
+  return 0;
+}
+
 extern "C" int dss2_collate(const dss2_collate_desc* descs_host, int32_t n_desc, const int64_t* sample_ids, int64_t batch,
                             void* stream) {
   if (batch <= 0 || n_desc <= 0) return 0;
-  if (!descs_host || n_desc > 4) { set_error("collate: 1..4 descriptors expected, got %d", n_desc); return 2; }
-  static_assert(sizeof(long long) == sizeof(int64_t), "int64");
-  CollateTable tab = {};
-  for (int i = 0; i < n_desc; ++i) {
-    tab.d[i] = descs_host[i];
-    if (!tab.d[i].src || !tab.d[i].dst || tab.d[i].chunk <= 0) { set_error("collate: descriptor %d is incomplete", i); return 2; }
-  }
-  hipLaunchKernelGGL(collate_kernel, dim3((unsigned)batch, (unsigned)n_desc), dim3(256), 0, as_stream(stream), tab,
-                     reinterpret_cast<const long long*>(sample_ids), (long long)batch);
-  return check_launch("collate");
+  CollateTable tab;
+  if (int rc = collate_table(descs_host, n_desc, &tab)) return rc;
+  DSS2_RECORD([tab, n_desc, sample_ids, batch](void* s_) { return collate_launch(tab, n_desc, sample_ids, batch, nullptr, 0, s_); });
+  return collate_launch(tab, n_desc, sample_ids, batch, nullptr, 0, stream);
+}
+
+extern "C" int dss2_collate_cursor(const dss2_collate_desc* descs_host, int32_t n_desc, const int64_t* sample_ids, int64_t* cursor,
+                                   int64_t batch, int advance, void* stream) {
+  if (batch <= 0 || n_desc <= 0) return 0;
+  if (!sample_ids || !cursor) { set_error("collate_cursor: null argument"); return 2; }
+  CollateTable tab;
+  if (int rc = collate_table(descs_host, n_desc, &tab)) return rc;
+  DSS2_RECORD([tab, n_desc, sample_ids, batch, cursor, advance](void* s_) { return collate_launch(tab, n_desc, sample_ids, batch, cursor, advance, s_); });
+  return collate_launch(tab, n_desc, sample_ids, batch, cursor, advance, stream);
+}
+
+static int accum_scalar_launch(double* acc, const float* value, void* stream) {
+  hipLaunchKernelGGL(accum_scalar_kernel, dim3(1), dim3(1), 0, as_stream(stream), acc, value);
+  return check_launch("accum_scalar");
+}
+extern "C" int dss2_accum_scalar(double* acc, const float* value, void* stream) {
+  if (!acc || !value) { set_error("accum_scalar: null argument"); return 2; }
+  DSS2_RECORD([acc, value](void* s_) { return accum_scalar_launch(acc, value, s_); });
+  return accum_scalar_launch(acc, value, stream);
 }
 
 extern "C" int dss2_collate_ragged(const dss2_collate_desc* descs_host, int32_t n_desc, const int64_t* samp,
                                    const int64_t* node_off, const int64_t* edge_off, int64_t count, int64_t e_total,
                                    void* stream) {
   using namespace dss2;
+  DSS2_NOT_IN_PLAN("dss2_collate_ragged");      // (a mixed-topology batch changes the graph structure: such a step is not replayable)
   if (count <= 0) return 0;
   if (!descs_host || n_desc < 1 || n_desc > 4 || !samp || !node_off || !edge_off) { set_error("collate_ragged: bad arguments"); return 2; }
   RaggedArgs a = {};

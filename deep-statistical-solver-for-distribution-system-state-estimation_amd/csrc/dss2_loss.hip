@@ -259,12 +259,23 @@ __global__ void __launch_bounds__(LB) wls_partials_kernel(const dss2_wls_args p)
   // through memory on both sides: write-through stores, drained (s_waitcnt vmcnt(0)) before the workgroup's arrival is counted by
   // a RELAXED agent-scope atomic; the last workgroup reads them with agent-scope atomic loads (no stale line of an earlier step in
   // its own L2 / L1 can answer).  The hand-off scheme of round 5's merged weight-space launches (HISTORY), without anybody polling.
+  // That form rests on gfx950's sc1 write-through behaviour, not on the HIP memory model: it is kept for the opt-in
+  // large grids only (DSS2_WLS_FUSED_FINISH=1 above 16 workgroups).  Up to 16 workgroups -- the DEFAULT use of this path, small
+  // batches, where an XCD's L2 holds next to nothing to write back -- the arrival is a RELEASE fetch_add at agent scope and the last
+  // workgroup ACQUIRES before it reads: a happens-before edge from every partial store to the loads below, by the book.
   __shared__ unsigned last_flag;
+  const bool by_the_book = gridDim.x <= 16;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) last_flag = __hip_atomic_fetch_add((gu32*)p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+  if (threadIdx.x == 0) {
+    const unsigned prev = by_the_book ? __hip_atomic_fetch_add((gu32*)p.counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
+                                      : __hip_atomic_fetch_add((gu32*)p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = prev == gridDim.x - 1 ? 1u : 0u;
+    if (by_the_book && last_flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (pairs with the other workgroups' release arrivals)
+  }
   __syncthreads();
   if (!last_flag) return;
+  if (by_the_book) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   __shared__ double tot[5];
   const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;      // LB = 256: waves 0..3 take columns 0..3, wave 0 also column 4
   for (int col = c; col < 5; col += LB / 64) {
@@ -573,11 +584,21 @@ static int dss2_wls_loss_grad_launch(const dss2_wls_args* ap, void* stream) {
   return check_launch("wls_loss_grad");
 }
 
+static int dss2_get_pflow_launch(const float* y, int64_t ldy, const float* node_param, int64_t ld_np,
+                                 const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
+                                 int64_t n_nodes, int64_t n_edges, float* vminmax, float* pflow, int apply_shift, void* stream);
 extern "C" int dss2_get_pflow(const float* y, int64_t ldy, const float* node_param, int64_t ld_np,
                               const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
                               int64_t n_nodes, int64_t n_edges, float* vminmax, float* pflow, int apply_shift,
                               void* stream) {
+  DSS2_RECORD([=](void* s_) { return dss2_get_pflow_launch(y, ldy, node_param, ld_np, edge_param, ld_ep, efrom, eto, n_nodes, n_edges, vminmax, pflow, apply_shift, s_); });
+  return dss2_get_pflow_launch(y, ldy, node_param, ld_np, edge_param, ld_ep, efrom, eto, n_nodes, n_edges, vminmax, pflow, apply_shift, stream);
+}
+static int dss2_get_pflow_launch(const float* y, int64_t ldy, const float* node_param, int64_t ld_np,
+                                 const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
+                                 int64_t n_nodes, int64_t n_edges, float* vminmax, float* pflow, int apply_shift, void* stream) {
   if (n_nodes <= 0 || n_edges <= 0) { set_error("get_pflow: empty batch"); return 2; }
+  if (!y || !node_param || !edge_param || !efrom || !eto || !vminmax || !pflow) { set_error("get_pflow: null argument"); return 2; }
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(vminmax_kernel, dim3(VMM_BLOCKS), dim3(256), 0, s, node_param, ld_np, n_nodes, vminmax);
   hipLaunchKernelGGL(pflow_kernel, dim3((unsigned)((n_edges + LB - 1) / LB)), dim3(LB), 0, s, y, ldy, edge_param, ld_ep,
@@ -587,10 +608,23 @@ extern "C" int dss2_get_pflow(const float* y, int64_t ldy, const float* node_par
 
 extern "C" int64_t dss2_eval_scratch_doubles(void) { return 256 * dss2::EV_SUMS; }
 
+static int dss2_eval_batch_launch(const float* out, int64_t ldo, const float* y, int64_t ldy, const float* node_param, int64_t ld_np,
+                                  const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
+                                  int64_t n_nodes, int64_t n_edges, const float* x_mean, const float* x_std, float* yhat,
+                                  float* pf_true, float* pf_out, float* vminmax, double* scratch, double* acc, void* stream);
 extern "C" int dss2_eval_batch(const float* out, int64_t ldo, const float* y, int64_t ldy, const float* node_param, int64_t ld_np,
                                const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
                                int64_t n_nodes, int64_t n_edges, const float* x_mean, const float* x_std, float* yhat,
                                float* pf_true, float* pf_out, float* vminmax, double* scratch, double* acc, void* stream) {
+  DSS2_RECORD([=](void* s_) { return dss2_eval_batch_launch(out, ldo, y, ldy, node_param, ld_np, edge_param, ld_ep, efrom, eto, n_nodes, n_edges,
+                                                            x_mean, x_std, yhat, pf_true, pf_out, vminmax, scratch, acc, s_); });
+  return dss2_eval_batch_launch(out, ldo, y, ldy, node_param, ld_np, edge_param, ld_ep, efrom, eto, n_nodes, n_edges, x_mean, x_std, yhat,
+                                pf_true, pf_out, vminmax, scratch, acc, stream);
+}
+static int dss2_eval_batch_launch(const float* out, int64_t ldo, const float* y, int64_t ldy, const float* node_param, int64_t ld_np,
+                                  const float* edge_param, int64_t ld_ep, const int32_t* efrom, const int32_t* eto,
+                                  int64_t n_nodes, int64_t n_edges, const float* x_mean, const float* x_std, float* yhat,
+                                  float* pf_true, float* pf_out, float* vminmax, double* scratch, double* acc, void* stream) {
   if (n_nodes <= 1 || n_edges <= 0) { set_error("eval_batch: needs at least 2 nodes and 1 edge"); return 2; }
   if (!out || !y || !node_param || !edge_param || !efrom || !eto || !x_mean || !x_std || !yhat || !pf_true || !pf_out ||
       !vminmax || !scratch || !acc) { set_error("eval_batch: null argument"); return 2; }

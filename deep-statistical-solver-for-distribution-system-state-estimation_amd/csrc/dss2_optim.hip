@@ -196,8 +196,13 @@ extern "C" void dss2_dropout_params(float p, uint32_t* thr, float* scale) {
   }
 }
 
+static int dss2_dropout_mask_launch(const uint64_t* snapshot, int32_t drop_id, float p, int64_t n_rows, int h, float* out, int64_t ldo, void* stream);
 extern "C" int dss2_dropout_mask(const uint64_t* snapshot, int32_t drop_id, float p, int64_t n_rows, int h, float* out,
                                  int64_t ldo, void* stream) {
+  DSS2_RECORD([=](void* s_) { return dss2_dropout_mask_launch(snapshot, drop_id, p, n_rows, h, out, ldo, s_); });
+  return dss2_dropout_mask_launch(snapshot, drop_id, p, n_rows, h, out, ldo, stream);
+}
+static int dss2_dropout_mask_launch(const uint64_t* snapshot, int32_t drop_id, float p, int64_t n_rows, int h, float* out, int64_t ldo, void* stream) {
   if (!snapshot || !out || drop_id <= 0 || h <= 0) { dss2::set_error("dropout_mask: bad arguments"); return 2; }
   if (n_rows <= 0) return 0;
   uint32_t thr; float scale;

@@ -399,6 +399,7 @@ static inline unsigned grid_for(int64_t n, int per_block = 256, int cap = 2048) 
 using namespace dss2;
 
 extern "C" int dss2_topology_probe(const int64_t* edge_index, int64_t n_edges, uint64_t* out3, void* stream) {
+  DSS2_NOT_IN_PLAN("dss2_topology_probe");
   if (n_edges <= 0) { set_error("topology_probe: empty edge list"); return 2; }
   hipLaunchKernelGGL(topo_probe_kernel, dim3(grid_for(2 * n_edges, 256, 1024)), dim3(256), 0, as_stream(stream), edge_index,
                      n_edges, reinterpret_cast<unsigned long long*>(out3));
@@ -414,6 +415,7 @@ extern "C" int64_t dss2_csr_build_work_ints(int64_t n_nodes, int64_t n_edges, in
 }
 
 extern "C" int dss2_csr_build(const dss2_csr_build_args* ap, void* stream) {
+  DSS2_NOT_IN_PLAN("dss2_csr_build");
   const dss2_csr_build_args& a = *ap;
   if (a.n_edges <= 0 || a.n_nodes <= 0) { set_error("csr_build: empty graph batch"); return 2; }
   if (a.n_nodes >= (1ll << 31) - 4 || 2 * a.n_edges >= (1ll << 31) - 4) { set_error("csr_build: graph too large for the int32 CSR"); return 2; }
@@ -475,6 +477,7 @@ extern "C" int dss2_csr_build(const dss2_csr_build_args* ap, void* stream) {
 }
 
 extern "C" int dss2_tiles_uniform(int32_t* tile_start, int32_t ntiles, int32_t rows_per_tile, int64_t n_nodes, void* stream) {
+  DSS2_NOT_IN_PLAN("dss2_tiles_uniform");
   if (ntiles <= 0 || rows_per_tile <= 0) { set_error("tiles_uniform: bad arguments"); return 2; }
   hipLaunchKernelGGL(tiles_uniform_kernel, dim3(grid_for(ntiles + 1)), dim3(256), 0, as_stream(stream), tile_start, ntiles,
                      rows_per_tile, (int)n_nodes);
@@ -483,6 +486,7 @@ extern "C" int dss2_tiles_uniform(int32_t* tile_start, int32_t ntiles, int32_t r
 
 extern "C" int dss2_tiles_walk(const int32_t* lastcut, int64_t n_nodes, const int32_t* tm_host, int32_t n_cand,
                                int32_t* const* tile_starts_host, int32_t cap, int32_t* ntiles_dev, void* stream) {
+  DSS2_NOT_IN_PLAN("dss2_tiles_walk");
   if (n_cand <= 0 || n_cand > 8) { set_error("tiles_walk: 1..8 candidates"); return 2; }
   WalkArgs w = {};
   w.lastcut = lastcut; w.N = (int)n_nodes; w.ncand = n_cand; w.ntiles = ntiles_dev; w.cap = cap;
@@ -492,6 +496,7 @@ extern "C" int dss2_tiles_walk(const int32_t* lastcut, int64_t n_nodes, const in
 }
 
 extern "C" int dss2_ell_tiles_build(const dss2_ell_build_args* ap, void* stream) {
+  DSS2_NOT_IN_PLAN("dss2_ell_tiles_build");
   const dss2_ell_build_args& b = *ap;
   if (b.ntiles <= 0 || b.tm <= 0) { set_error("ell_tiles_build: bad arguments"); return 2; }
   EllArgs a = {};
@@ -508,6 +513,7 @@ extern "C" int dss2_ell_tiles_build(const dss2_ell_build_args* ap, void* stream)
 
 extern "C" int dss2_deg_pows(const int32_t* rowptr, const int32_t* col, const float* w, const float* deg, int64_t n_nodes,
                              float* out, double* work, void* stream) {
+  DSS2_NOT_IN_PLAN("dss2_deg_pows");
   if (n_nodes <= 0) return 0;
   hipStream_t s = as_stream(stream);
   double *v0 = work, *v1 = work + n_nodes;

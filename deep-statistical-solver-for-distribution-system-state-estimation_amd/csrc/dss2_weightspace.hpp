@@ -1,11 +1,13 @@
 // Device-side bodies of the weight-space kernels (small GEMMs, weight packing, slab reductions), shared by their own launches
-// (dss2_optim.hip, dss2_gemm_prop.hip, dss2_edge.hip) and by the merged step-start / step-end launches (dss2_weights.hip).
+// (dss2_optim.hip, dss2_gemm_prop.hip, dss2_edge.hip).  Round 5's merged step-start / step-end launches, which also instantiated
+// these bodies with COH = true, measured slower and left the library (record: profiles/experiments/r05_weights_merged_launches.hip.txt);
+// the COH / NBUF template arguments remain as the hook that form would need and are instantiated with their defaults only.
 #pragma once
 #include "dss2_common.hpp"
 
 namespace dss2 {
 
-// Stores of results that ANOTHER workgroup of the same launch reads (dss2_weights.hip): write-through (sc1) global stores, so that the
+// Stores of results that ANOTHER workgroup of the same launch reads (COH = true; no launch of the library does today): write-through (sc1) global stores, so that the
 // producer needs no L2 write-back before it signals (MI355X: per-XCD L2s are not coherent with each other).  COH = false: plain stores.
 template <bool COH>
 __device__ __forceinline__ void ws_store(float* p, float v) {
@@ -41,7 +43,7 @@ __device__ __forceinline__ void small_gemm_body(const dss2_sgemm_desc* __restric
   const int nchunks = nbatch * kchunks;
   // THREE chunks of operands in flight (96 registers): the chain rule's dW2 = sum_m W_m^T dWf_m walks three K-chunks per tile,
   // and with one chunk requested at a time every chunk paid its own round trip to L2 / HBM (17.9 us for that launch at C2)
-  // (NBUF: chunks in flight; the merged launches of dss2_weights.hip trade them for registers -- same summation order, same results)
+  // (NBUF: chunks in flight; a merged launch would trade them for registers -- same summation order, same results)
   float rab[NBUF][16], rbb[NBUF][16];
   // unconditional loads from clamped addresses (one batch of 32 in flight per chunk), masked afterwards
   auto issue = [&](int c, float (&ra)[16], float (&rb)[16]) {

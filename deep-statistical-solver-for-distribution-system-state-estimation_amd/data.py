@@ -161,7 +161,7 @@ class _WlsFn(torch.autograd.Function):
                        x_mean, x_std, edge_mean, edge_std, reg_coefs, bufs)
         # (up to 16 workgroups the last one of the partials launch finishes the sums and writes the loss; bigger batches run the
         #  one-workgroup finish launch, which costs what 240 arrivals on one counter word cost -- FL.WLS_FUSED_FINISH: fused at any size)
-        a.flags = (_lib.WLS_FUSED_FINISH if (nb <= 16 or FL.WLS_FUSED_FINISH) else 0) | (_lib.WLS_VMM_CACHED if vmm_valid else 0)
+        a.flags = (_lib.WLS_FUSED_FINISH if ((nb <= 16 and FL.WLS_FUSED_FINISH_SMALL) or FL.WLS_FUSED_FINISH) else 0) | (_lib.WLS_VMM_CACHED if vmm_valid else 0)
         a.counter = _counter(dev).data_ptr()
         st = _stream(output)
         L = _lib.lib()

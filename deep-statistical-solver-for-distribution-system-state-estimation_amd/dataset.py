@@ -161,6 +161,42 @@ class DeviceDataset:
         #  would have to read back; those batches take the cached / probed path of topology.get_topology)
         return Batch(x, ei, ea, y, B)
 
+    # ---- collation into caller-owned (static) buffers: what a replayed training step reads (runner.EpochTrainer)
+    def collate_descs(self, x: torch.Tensor, edge_attr: torch.Tensor, y: Optional[torch.Tensor] = None):
+        """The descriptor table of ``collate_into`` for these destination buffers, built once (x [B*n, 11], edge_attr [B*e, 13],
+        optionally y [B*n, 2]; fp32, contiguous).  Keep the returned object alive as long as it is used."""
+        items = [(self.x, x, self.n * self.x.size(2)), (self.edge_attr, edge_attr, self.e * self.edge_attr.size(2))]
+        if y is not None:
+            items.append((self.y, y, self.n * self.y.size(2)))
+        descs = (_lib.CollateDesc * len(items))()
+        for d, (src, dst, chunk) in zip(descs, items):
+            if dst.dtype != _F32 or not dst.is_contiguous() or dst.numel() % chunk:
+                raise ValueError("collate_into: destination buffers must be contiguous fp32 of B whole samples")
+            d.src, d.dst, d.chunk, d.kind = src.data_ptr(), dst.data_ptr(), chunk, 0
+            d.shared, d.nodes_per_sample = int(self.shared_topology), self.n
+        return descs
+
+    def collate_into(self, descs, ids: torch.Tensor, B: int, cursor: Optional[torch.Tensor] = None, advance: bool = True) -> None:
+        """Gather B samples straight into the buffers of ``descs`` -- no allocation, no second copy.  Without ``cursor``: samples
+        ``ids[0:B]``.  With ``cursor`` (device int64[2] = {position, epoch length}): samples ``ids[(position + b) mod length]``, and
+        (``advance``) the position moves forward by B on the device behind the gather -- the SAME two launches every step, so a
+        recorded step (hipGraph / launch plan) that starts with this call walks an epoch by being replayed (dss2_collate_cursor)."""
+        st = _lib.stream_ptr(self.device)
+        if cursor is None:
+            _lib.check(_lib.lib().dss2_collate(C.addressof(descs), len(descs), ids.data_ptr(), B, st), "dss2_collate")
+        else:
+            _lib.check(_lib.lib().dss2_collate_cursor(C.addressof(descs), len(descs), ids.data_ptr(), cursor.data_ptr(), B, int(advance), st),
+                       "dss2_collate_cursor")
+
+    def batch_structure(self, B: int):
+        """(edge_index, Topology) of a B-sample batch of a single-topology dataset: built once per B, attached to the cached tensor."""
+        if not self.shared_topology:
+            raise ValueError("batch_structure: the samples have individual edge lists (use DataLoader / PrefetchLoader)")
+        ei = self.batch_edge_index(B, self.ids[:1])
+        if _topology._last.get((id(ei), "ref")) is None:
+            _topology.register_topology(ei, B * self.n, _topology.Topology(ei, B * self.n, hint=self.hint()))
+        return ei, _topology.get_topology(ei, B * self.n)
+
     @classmethod
     def from_batch(cls, batch: Dict[str, object], device=None) -> "DeviceDataset":
         """Per-sample store from a collated single-topology batch in the synthetic.make_batch layout."""
@@ -288,6 +324,58 @@ class DataLoader:
             if self.drop_last and b - a < self.batch_size:
                 break
             yield ds.collate(ids[a:b].contiguous())
+
+
+class PrefetchLoader:
+    """Iterates ``loader`` one batch AHEAD on a side stream: batch k + 1 is collated and its graph structure (CSR, tiles, ELL slices,
+    the 32-row tiling of the weight gradient, the folded bias scales) is built while step k runs on the caller's stream.  For data whose
+    structure changes per batch (BASELINE config C5: a new cigre14 / reswitched mix every step) the ~0.3 ms of small launch-bound
+    kernels of the assembly leave the step's critical path (15.6 % of the C5 step before).  Hand-over is by stream events only -- no host
+    synchronisation.  Memory safety: the side stream allocates batch k + 1 only after it has waited for everything the caller's stream
+    had been given when batch k was handed out (the caller dropped batch k - 1 at that point at the latest), so a block the caching
+    allocator recycles on the side stream is never still being read by a step.
+
+    ``prepare(batch)``: extra work to run on the side stream (default: build every lazily built part of the batch's structure)."""
+
+    def __init__(self, loader, prepare=None):
+        self.loader, self.prepare = loader, prepare
+        self.side = None
+
+    def __len__(self):
+        return len(self.loader)
+
+    @staticmethod
+    def _build_structure(batch: "Batch") -> None:
+        topo = _topology.get_topology(batch.edge_index, batch.x.size(0))
+        if not topo.global_only:          # (touching nrb builds tiles + ELL slices)
+            topo.tiles_for(1)
+            topo.tiles_for(2)
+        topo.deg_pows
+
+    def __iter__(self):
+        dev = self.loader.dataset.device
+        main = torch.cuda.current_stream(dev)
+        side = self.side = self.side or torch.cuda.Stream(device=dev)
+        it = iter(self.loader)
+        prep = self.prepare or self._build_structure
+
+        def fetch():
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                try:
+                    b = next(it)
+                except StopIteration:
+                    return None
+                prep(b)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return b, ev
+        nxt = fetch()
+        while nxt is not None:
+            cur, ev = nxt
+            main.wait_event(ev)
+            nxt = fetch()
+            yield cur
 
 
 def data_from_tables(nodes: np.ndarray, edges: np.ndarray, labels: np.ndarray, noise: Dict[str, float], num_nfeat: int,

@@ -29,6 +29,8 @@ WGRAD_F16 = _os.environ.get("DSS2_WGRAD_F16", "1") == "1"
 # same sums).  Off above 16 workgroups: at C2 the 240 arrivals on one counter word (~12 ns each) and the last workgroup's round trip cost
 # what the 4.65 us finish launch costs -- A/B on one box 0.4047 / 0.4017 ms fused against 0.4022 / 0.3979 (end of round 5)
 WLS_FUSED_FINISH = _os.environ.get("DSS2_WLS_FUSED_FINISH", "0") == "1"
+# 0 = the two-launch finish also up to 16 workgroups (where the fused finish is the default; tests compare the two)
+WLS_FUSED_FINISH_SMALL = _os.environ.get("DSS2_WLS_FUSED_FINISH_SMALL", "1") == "1"
 WGRAD_TM32 = _os.environ.get("DSS2_WGRAD_TM32", "1") == "1"      # bf16x6 weight gradient on 32-row tiles, two workgroups per CU (wgrad16b_kernel)
 WGRAD_TM32_MAX_BYTES = 64 << 20      # ... as bf16x6 (DSS2_WGRAD_F16=0) only while one layer's input (N * hin * 4 bytes) stays well inside the Infinity Cache; the f16x3 kernel has no such limit
 WGRAD_PER_CU = int(_os.environ.get("DSS2_WGRAD_PER_CU", "2"))   # cap on persistent wgrad workgroups per CU (= slabs / 256)

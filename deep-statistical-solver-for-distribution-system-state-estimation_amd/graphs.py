@@ -90,7 +90,11 @@ class PlannedStep:
     a candidate: compare ``replay()`` with an eager step once, as tests/test_gpu_plan.py does).  A data-parallel step's collectives
     (``plan_collective``) cut the record into segments: one C call per segment, the collectives between them."""
 
-    def __init__(self, step_fn: Callable[[], torch.Tensor], warmup: int = 2, stream=None):
+    def __init__(self, step_fn: Callable[[], torch.Tensor], warmup: int = 2, stream=None, verify: Callable[[], list] = None):
+        """``verify``: a callable returning tensors the step produces (the loss, parameter gradients).  After the recording they are
+        cloned, the plan is replayed ONCE and every one must come out bit for bit the same -- a step that contains a launch the plan
+        does not carry (a torch kernel: a fill, an add, ``.to()``) is caught at construction instead of replaying silently without it.
+        Only for steps that are functions of their static inputs (no optimizer step, no dropout inside): the check replays the step."""
         from . import _lib
         import ctypes as C
         self._lib, self._C = _lib, C
@@ -114,9 +118,33 @@ class PlannedStep:
                 _PLAN_RECORDING[0] = False
                 _PLAN_RECORDER[0] = None
             torch.cuda.synchronize()
+        # The tensors of the recorded step that no recorded launch rewrites (the root gradient autograd hands to the loss node, anything a
+        # torch kernel produced) stay valid only while the autograd graph of the recording keeps them alive: a step_fn that returns a
+        # DETACHED loss lets them go back to the pool during the recording, where a later allocation of the same step may reuse them and
+        # every replay would read overwritten memory.  So the attached loss is part of the contract.
+        if torch.is_tensor(self.loss) and torch.is_grad_enabled() and self.loss.grad_fn is None and any(
+                int(_lib.lib().dss2_plan_size(h)) for h, _ in self.segments):
+            for h, _ in self.segments:
+                _lib.lib().dss2_plan_destroy(h)
+            self.segments = []
+            raise ValueError("PlannedStep: step_fn must return the ATTACHED loss tensor (its autograd graph keeps the recorded step's "
+                             "tensors alive in the plan's pool); it returned a tensor without grad_fn")
         self.handle = self.segments[0][0]      # (single-segment plans: the handle itself, as before)
         self.n_launches = sum(int(_lib.lib().dss2_plan_size(h)) for h, _ in self.segments)
         self.n_collectives = sum(1 for _, fn in self.segments if fn is not None)
+        if verify is not None:
+            with torch.cuda.stream(self.stream):
+                outs = list(verify())
+                want = [t.detach().clone() for t in outs]
+                for t in outs:
+                    if t.is_floating_point():
+                        t.detach().fill_(float("nan"))      # (poisoned: the replay must rewrite every one)
+                self.replay()
+                torch.cuda.synchronize()
+                bad = [i for i, (t, w) in enumerate(zip(verify(), want)) if not torch.equal(t.detach(), w)]
+            if bad:
+                raise RuntimeError(f"PlannedStep: a replay does not reproduce the recorded step (outputs {bad} of verify() differ): the step "
+                                   "contains work the plan does not carry (only launches of libdss2_hip are recorded)")
 
     def _begin(self):
         h = self._C.c_void_p()

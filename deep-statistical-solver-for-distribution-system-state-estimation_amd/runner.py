@@ -137,6 +137,124 @@ def train_epoch_graphed(trainer: GraphedTrainer, loader) -> float:
     return float(total / len(loader))
 
 
+class EpochTrainer:
+    """The training loop of dss2_run.py:131-147 -- ``for data in loader: zero_grad; forward; gsp_wls_edge; backward; step`` -- with NO host
+    work per batch beyond one C call: the loader's collation writes straight into the step's static input buffers as the FIRST launch of
+    the recorded step (``dss2_collate_cursor``: the batch's position in the epoch's sample permutation lives on the device and is moved
+    forward by the launch behind the gather), the optimizer step and the running loss sum (``dss2_accum_scalar``) are its last ones.  An
+    epoch is ``len(dataset) // batch_size`` replays of one recorded step (+ one replay of a second, smaller step for the last
+    batch, ``drop_last=False`` as torch_geometric's loader at dss2_run.py:68-69); the only per-epoch host work is drawing the
+    permutation (on the device) and resetting two words.  Nothing is read back until the caller asks for the epoch's mean loss.
+
+    ``mode``: "plan" (graphs.PlannedStep: the library's own launch list, one ``dss2_plan_run`` per step; also at world > 1, where the
+    step's collectives cut it into segments) or "graph" (graphs.GraphedStep: a hipGraph).  Needs a single-topology ``DeviceDataset``
+    (the graph structure is part of the recorded launches) and ``FusedAdamax(capturable=True)``.  Recording a step runs it (plans:
+    three times, graphs: once), so the model, the optimizer state and the epoch position are saved before and restored after: the first
+    ``train_epoch()`` starts from exactly the state the trainer was given."""
+
+    def __init__(self, model, opt, stats, reg_coefs, dataset, batch_size: int, shuffle: bool = True, mode: str = "plan", group=None,
+                 generator=None):
+        from . import _lib
+        from . import dataset as dss2_dataset
+        if not isinstance(dataset, dss2_dataset.DeviceDataset) or not dataset.shared_topology:
+            raise ValueError("EpochTrainer needs a single-topology DeviceDataset (per-batch structures: DataLoader / PrefetchLoader + train_epoch)")
+        if not getattr(opt, "capturable", False):
+            raise ValueError("EpochTrainer needs FusedAdamax(capturable=True): the step count must live on the device")
+        if mode not in ("plan", "graph"):
+            raise ValueError("mode: 'plan' or 'graph'")
+        self._lib = _lib
+        self.model, self.opt, self.stats, self.reg, self.group = model, opt, stats, reg_coefs, group
+        self.ds, self.B, self.shuffle, self.mode, self.generator = dataset, int(batch_size), bool(shuffle), mode, generator
+        self.params = list(model.parameters())
+        dev = dataset.device
+        n = len(dataset)
+        if n < 1 or self.B < 1:
+            raise ValueError("empty dataset / batch")
+        self.n_full, self.rem = divmod(n, self.B)
+        self.base_ids = dataset.ids.contiguous()
+        self.ids = self.base_ids.clone()                                   # this epoch's order (static: the recorded steps read it)
+        self.cursor = torch.tensor([0, n], dtype=torch.int64, device=dev)  # {position, epoch length}
+        self._cursor0 = self.cursor.clone()
+        self.acc = torch.zeros(2, dtype=torch.float64, device=dev)         # {sum of the step losses, steps}
+        self.steps = {}
+        opt.init_state()
+        saved = self._snapshot()
+        for nb in ([self.B] if self.n_full else []) + ([self.rem] if self.rem else []):
+            self.steps[nb] = self._record(nb)
+        self._restore(saved)
+
+    # ---- state that recording a step consumes
+    def _state_tensors(self):
+        ts = list(self.params)
+        for g in self.opt.param_groups:
+            if torch.is_tensor(g.get("_step")):
+                ts.append(g["_step"])
+            for p in g["params"]:
+                st = self.opt.state.get(p, {})
+                ts += [st[k] for k in ("exp_avg", "exp_inf") if k in st]
+        return ts
+
+    def _snapshot(self):
+        return [t.detach().clone() for t in self._state_tensors()]
+
+    @torch.no_grad()
+    def _restore(self, saved):
+        for t, s in zip(self._state_tensors(), saved):
+            t.copy_(s)
+        self.cursor.copy_(self._cursor0)
+        self.acc.zero_()
+
+    def _record(self, nb: int):
+        from . import graphs
+        ds, st, reg, model, opt, params, group = self.ds, self.stats, self.reg, self.model, self.opt, self.params, self.group
+        dev = ds.device
+        sx = torch.empty(nb * ds.n, ds.x.size(2), dtype=torch.float32, device=dev)
+        sea = torch.empty(nb * ds.e, ds.edge_attr.size(2), dtype=torch.float32, device=dev)
+        ei, _ = ds.batch_structure(nb)
+        descs = ds.collate_descs(sx, sea)
+        ids, cursor, acc, L = self.ids, self.cursor, self.acc, self._lib
+
+        def step_fn():
+            ds.collate_into(descs, ids, nb, cursor=cursor, advance=True)
+            for p in params:
+                p.grad = None
+            out = model(sx[:, :8], ei, sea[:, :6])
+            loss = dss2_data.gsp_wls_edge(input=sx[:, :8], edge_input=sea[:, :6], output=out, x_mean=st[0], x_std=st[1],
+                                          edge_mean=st[2], edge_std=st[3], edge_index=ei, reg_coefs=reg, num_samples=None,
+                                          node_param=sx[:, 8:], edge_param=sea[:, 6:], group=group)
+            loss.backward(dss2_data.unit_grad(loss))
+            opt.step()
+            L.check(L.lib().dss2_accum_scalar(acc.data_ptr(), loss.data_ptr(), L.stream_ptr(dev)), "dss2_accum_scalar")
+            return loss
+        cur = torch.cuda.current_stream(dev)
+        if self.mode == "plan":
+            rec = graphs.PlannedStep(step_fn, stream=cur)
+        else:
+            rec = graphs.GraphedStep(step_fn, warmup=1, capture_error_mode=("thread_local" if group is not None else "global"),
+                                     stream=(cur if cur != torch.cuda.default_stream(dev) else None))
+        return rec, sx, sea, descs
+
+    def train_epoch(self) -> torch.Tensor:
+        """One pass over the dataset.  Returns the DEVICE tensor {sum of the step losses, steps} of this epoch (``mean_loss()`` reads
+        it: the epoch's single host synchronisation, dss2_run.py:147)."""
+        if self.shuffle:
+            perm = torch.randperm(self.base_ids.numel(), device=self.base_ids.device, generator=self.generator)
+            torch.index_select(self.base_ids, 0, perm, out=self.ids)
+        self.cursor.copy_(self._cursor0)
+        self.acc.zero_()
+        if self.n_full:
+            replay = self.steps[self.B][0].replay
+            for _ in range(self.n_full):
+                replay()
+        if self.rem:
+            self.steps[self.rem][0].replay()
+        return self.acc
+
+    def mean_loss(self) -> float:
+        s, k = self.acc.tolist()
+        return s / max(k, 1.0)
+
+
 @torch.no_grad()
 def evaluate(model, loader, stats) -> Dict[str, float]:
     """dss2_run.py:165-224: RMSE / MAE of V and theta and of the line / trafo loadings from get_pflow, and the

@@ -60,7 +60,11 @@ int dss2_topology_probe(const int64_t* edge_index, int64_t n_edges, uint64_t* ou
  * C call.  Same contract as a hipGraph replay: the recorded device pointers must stay valid (record the step on tensors that        *
  * live as long as the plan, e.g. inside a private memory pool), by-value scalars are frozen (use the device-side step counter of    *
  * dss2_adamax_step_flat / _dev and use_host_seed = 0 of dss2_rng_next, as under capture).  Only launches of this library are         *
- * recorded.  One plan records at a time (process-wide).                                                                              */
+ * recorded.  One plan records at a time (process-wide).  Every entry point that launches a STEP's work records itself (model, loss, *
+ * dss2_get_pflow / dss2_eval_batch, dropout masks, optimizer, dss2_collate / dss2_collate_cursor, dss2_accum_scalar); the entry     *
+ * points that are not launches of a step -- structure build (dss2_topology_probe, dss2_csr_build, dss2_tiles_*,                      *
+ * dss2_ell_tiles_build, dss2_deg_pows), measurement model, z-score, ragged collation -- return 3 while a plan records instead of     *
+ * being silently left out of it.                                                                                                     */
 typedef struct dss2_plan dss2_plan;
 int dss2_plan_begin(dss2_plan** out);
 int dss2_plan_end(dss2_plan* plan);
@@ -558,6 +562,18 @@ typedef struct dss2_collate_desc {
   int64_t nodes_per_sample;
 } dss2_collate_desc;
 int dss2_collate(const dss2_collate_desc* descs_host, int32_t n_desc, const int64_t* sample_ids, int64_t batch, void* stream);
+/* The same collation with the batch's position on the DEVICE (host-free epochs: dss2_run.py:131-147's loop as N replays of one
+ * recorded step).  cursor: DEVICE int64[2] = {position, epoch length}; slot b reads sample_ids[(cursor[0] + b) mod cursor[1]]
+ * (cursor[1] <= 0: no wrap).  advance != 0: a one-thread launch behind the collation moves cursor[0] forward by `batch` (wrapping
+ * at cursor[1]), so the identical pair of launches, replayed, walks the epoch -- which is why this entry point is recorded into
+ * launch plans and captured into hipGraphs like every other launch of a step.  The caller re-draws sample_ids (a device
+ * permutation) and zeroes cursor[0] between epochs; nothing is read back. */
+int dss2_collate_cursor(const dss2_collate_desc* descs_host, int32_t n_desc, const int64_t* sample_ids, int64_t* cursor,
+                        int64_t batch, int advance, void* stream);
+/* acc[0] += value[0]; acc[1] += 1 (DEVICE double[2], DEVICE float): the running sum of the step losses of an epoch
+ * (dss2_run.py:146-147: `total_loss += loss.item()`, without the host read) as a launch of this library, so that a recorded step
+ * carries it. */
+int dss2_accum_scalar(double* acc, const float* value, void* stream);
 
 /* Ragged collation for batches that mix cases with different closed-branch counts per sample (BASELINE config C5):
  * one call per case; item j < count is the j-th sample of that case in the batch: sample samp[j] of the case's store,
