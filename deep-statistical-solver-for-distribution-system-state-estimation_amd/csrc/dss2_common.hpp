@@ -92,6 +92,14 @@ __device__ __forceinline__ void split2_pair(float a, float b, uint32_t& h, uint3
   h = __builtin_bit_cast(uint32_t, hh);
   l = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ra, rb}, f16x2));
 }
+// ReLU with torch's non-finite semantics (nn.ReLU, /root/reference/networks.py:269: a NaN stays a NaN): `!(v <= 0) ? v : 0` is one
+// v_cmp_nle_f32 + one v_cndmask_b32 -- what fmaxf(v, 0.f) costs too (the compiler quiets fmaxf's operand with a second v_max_f32), but
+// v_max_f32 returns the OTHER operand for a NaN: max(NaN, 0) = 0 turned a NaN weight into a dead column and a FINITE loss where the
+// reference's loss is NaN (round 6, tools/nonfinite_probe.py; hardware NaNs are 0xFFC00000 on gfx950, so an integer max does not do either).
+__device__ __forceinline__ float relu_nan(float v) { return !(v <= 0.f) ? v : 0.f; }
+// The gate of ReLU's backward with torch's semantics (threshold_backward: `self <= 0 ? 0 : grad`): a NaN activation lets the gradient
+// through (it is NaN there anyway: the loss is), where `y > 0` would zero it and leave a FINITE parameter gradient beside a NaN loss.
+__device__ __forceinline__ bool relu_open(float y) { return !(y <= 0.f); }
 __device__ __forceinline__ float absmax4(float m, const f32x4 v) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }

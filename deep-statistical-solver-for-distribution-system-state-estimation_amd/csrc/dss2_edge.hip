@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) edge_hidden_fwd_kernel(
         for (int k = 0; k < FN; ++k) z = fmaf(w[f][FN + k], xs[k], z);
 #pragma unroll
         for (int k = 0; k < FE; ++k) z = fmaf(w[f][2 * FN + k], a[k], z);
-        acc[f] += fmaxf(z, 0.f);
+        acc[f] += relu_nan(z);
       }
     }
 #pragma unroll
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) edge_hidden_bwd_kernel(
 #pragma unroll
         for (int k = 0; k < FC; ++k) z = fmaf(w[f][k], c[k], z);
         const float g = (j < h) ? dS[tgt * h + j] : 0.f;
-        const float dz = z > 0.f ? g : 0.f;
+        const float dz = relu_open(z) ? g : 0.f;
         u[f] += dz;
         if (!by_source) {
           db[f] += dz;
@@ -241,10 +241,10 @@ __global__ void __launch_bounds__(256) edge_combine_kernel(const EdgeCombineArgs
 #pragma unroll
         for (int k = 0; k < EC_MAXFE; ++k) z = fmaf(w[f][k], a[k], z);
         if (!BWD) {
-          acc[f] += fmaxf(z, 0.f);
+          acc[f] += relu_nan(z);
         } else {
           const float gg = p.by_source ? ((j < h) ? p.dS[other * hf + c0 + j] : 0.f) : g[f];
-          const float dz = z > 0.f ? gg : 0.f;
+          const float dz = relu_open(z) ? gg : 0.f;
           acc[f] += dz;
           if (!p.by_source) {
             db[f] += dz;
@@ -383,10 +383,10 @@ __global__ void __launch_bounds__(256) edge_tile_kernel(const EdgeTileArgs p) {
 #pragma unroll
         for (int q = 0; q < FC; ++q) z = fmaf(w[f][q], c[q], z);
         if (!BWD) {
-          accv[f] += fmaxf(z, 0.f);
+          accv[f] += relu_nan(z);
         } else {
           const float g = p.by_source ? ((j < p.h) ? p.dS[tg * p.h + j] : 0.f) : grow[f];
-          const float dz = z > 0.f ? g : 0.f;
+          const float dz = relu_open(z) ? g : 0.f;
           accv[f] += dz;
           if (!p.by_source) {
             db[f] += dz;
@@ -528,12 +528,12 @@ __global__ void __launch_bounds__(256) csr_axpy_kernel(const CsrAxpyArgs p) {
     }
     if (p.relu) {
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) s[q] = fmaxf(s[q], 0.f);
+      for (int q = 0; q < VEC; ++q) s[q] = relu_nan(s[q]);
     }
     if (p.relu_src) {
       const V r = *reinterpret_cast<const V*>(p.relu_src + i * p.ld_relu + c);
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) s[q] = r[q] > 0.f ? s[q] : 0.f;
+      for (int q = 0; q < VEC; ++q) s[q] = relu_open(r[q]) ? s[q] : 0.f;
     }
     if (p.add_src) s += *reinterpret_cast<const V*>(p.add_src + i * p.ld_src + c);
     *reinterpret_cast<V*>(p.out + i * p.ldo + c) = s;
@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(512) edge_mfma_fwd_kernel(const EdgeTileArgs p
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const bool valid = s.other[k * TM + rb * 32 + acc_row(r, half)] >= 0;
-          Sacc[rb][r] += valid ? fmaxf(acc[r] + b1v, 0.f) : 0.f;
+          Sacc[rb][r] += valid ? relu_nan(acc[r] + b1v) : 0.f;
         }
       }
       __syncthreads();
@@ -742,7 +742,7 @@ __global__ void __launch_bounds__(512) edge_mfma_bwd_kernel(const EdgeTileArgs p
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rb * 32 + acc_row(r, half);
-          const bool on = s.other[k * TM + row] >= 0 && (acc[r] + b1v) > 0.f;
+          const bool on = s.other[k * TM + row] >= 0 && relu_open(acc[r] + b1v);
           const float dz = on ? gS[rb][r] : 0.f;
           if (WITH_U) Uacc[rb][r] += dz;
           st[row * 32 + c32] = dz;

@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))
       for (int k = 0; k < D; ++k) {
         const f32x16 c = e16_z<NRB>(L, w, k, rb, c32, half, ci);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Sacc[r] += fmaxf(c[r], 0.f);
+        for (int r = 0; r < 16; ++r) Sacc[r] += relu_nan(c[r]);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -398,11 +398,11 @@ __global__ void __launch_bounds__(512) edge16_bwd_kernel(const EdgeTileArgs p) {
         [[maybe_unused]] f32x16 dz;
         if constexpr (PRE) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) mk[j] = (c[2 * j] > 0.f ? 0x0000ffffu : 0u) | (c[2 * j + 1] > 0.f ? 0xffff0000u : 0u);
+          for (int j = 0; j < 8; ++j) mk[j] = (relu_open(c[2 * j]) ? 0x0000ffffu : 0u) | (relu_open(c[2 * j + 1]) ? 0xffff0000u : 0u);
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            dz[r] = c[r] > 0.f ? gS[rb][r] : 0.f;
+            dz[r] = relu_open(c[r]) ? gS[rb][r] : 0.f;
             if (WITH_U) Uacc[rb][r] += dz[r];
           }
         }

@@ -390,11 +390,11 @@ __global__ void __launch_bounds__(NW * 64, RS == 3 ? 3 : chain_waves_per_simd(NR
             if (has_bias) v += bias4;
             if (do_relu) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+              for (int q = 0; q < 4; ++q) v[q] = relu_nan(v[q]);
             }
             if (has_rs) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = gate[it][u][q] > 0.f ? v[q] : 0.f;
+              for (int q = 0; q < 4; ++q) v[q] = relu_open(gate[it][u][q]) ? v[q] : 0.f;
             }
             *reinterpret_cast<f32x4*>(L.Y + (size_t)(ts + row) * p.ldy + col0) = v;
             if (keep) *reinterpret_cast<f32x4*>(Xs + row * LDX + col0) = v;
@@ -429,11 +429,11 @@ __global__ void __launch_bounds__(NW * 64, RS == 3 ? 3 : chain_waves_per_simd(NR
           if (L.drop_id) v *= dropout_mult4(drop_seed, drop_off, (uint32_t)L.drop_id, (uint32_t)(ts + row), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
           if (L.relu & 1) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            for (int q = 0; q < 4; ++q) v[q] = relu_nan(v[q]);
           }
           if (L.relu_src) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = rs[u][q] > 0.f ? v[q] : 0.f;
+            for (int q = 0; q < 4; ++q) v[q] = relu_open(rs[u][q]) ? v[q] : 0.f;
           }
           if (L.add_src) v += ad[u];
           *reinterpret_cast<f32x4*>(L.Y + (size_t)(ts + row) * p.ldy + col0) = v;

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
       }
       if (hd.gate) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = ga[i][q] > 0.f ? v[q] : 0.f;
+        for (int q = 0; q < 4; ++q) v[q] = relu_open(ga[i][q]) ? v[q] : 0.f;
       }
       if (hd.drop_id) v *= dropout_mult4(drop_seed, drop_off, (uint32_t)hd.drop_id, (uint32_t)(ts + row), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
       if (row >= R || !col_ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -609,11 +609,12 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
         for (int i = 0; i < 8; ++i)
           U[i] *= dropout_mult4(drop_seed, drop_off, (uint32_t)L.drop_id, (uint32_t)grow_of(i), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
       }
-      if (L.relu & 1) {      // (one v_max_f32 per value: fmaxf() first quiets its operand with a second one)
+      if (L.relu & 1) {      // (v_cmp_nle + v_cndmask per value: a NaN stays a NaN as under nn.ReLU -- v_max_f32(NaN, 0) is 0; round 5's
+                             //  one-instruction `v_max_f32 0, x` turned a NaN weight into a finite loss, dss2_common.hpp relu_nan)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(U[i][q])); U[i][q] = r; }
+          for (int q = 0; q < 4; ++q) U[i][q] = relu_nan(U[i][q]);
       }
       if (gbits) {
 #pragma unroll
@@ -624,7 +625,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) U[i][q] = gate[i][q] > 0.f ? U[i][q] : 0.f;
+          for (int q = 0; q < 4; ++q) U[i][q] = relu_open(gate[i][q]) ? U[i][q] : 0.f;
       }
       if (has_add) {
 #pragma unroll
@@ -646,7 +647,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
       for (int i = 0; i < 8; ++i) {
         const bool in_y = col_ok && rowv + 8 * i < R;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) word |= ((in_y && U[i][q] > 0.f) ? 1u : 0u) << (4 * i + q);
+        for (int q = 0; q < 4; ++q) word |= ((in_y && relu_open(U[i][q])) ? 1u : 0u) << (4 * i + q);
       }
       reinterpret_cast<uint32_t*>(L.y_bits)[((size_t)tile * ncg + cg) * 64 + lane] = word;
     }

@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
       }
       if (hd.gate) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = ga[i][q] > 0.f ? v[q] : 0.f;
+        for (int q = 0; q < 4; ++q) v[q] = relu_open(ga[i][q]) ? v[q] : 0.f;
       }
       if (hd.drop_id) v *= dropout_mult4(drop_seed, drop_off, (uint32_t)hd.drop_id, (uint32_t)(ts + row), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
       if (row >= R || !col_ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
 #pragma unroll
             for (int i = 0; i < HP; ++i)
 #pragma unroll
-              for (int q = 0; q < 4; ++q) gate_bits[(HP * h12 + i) >> 3] |= (gt[i][q] > 0.f ? 1u : 0u) << (((HP * h12 + i) & 7) * 4 + q);
+              for (int q = 0; q < 4; ++q) gate_bits[(HP * h12 + i) >> 3] |= (relu_open(gt[i][q]) ? 1u : 0u) << (((HP * h12 + i) & 7) * 4 + q);
           }
         }
         wave_lds_sync();      // every lane's gathers are done: G_m goes over T
@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
 #pragma unroll
         for (int i = 0; i < NRP; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) U[i][q] = fmaxf(U[i][q], 0.f);
+          for (int q = 0; q < 4; ++q) U[i][q] = relu_nan(U[i][q]);
       }
       if (has_rs) {
 #pragma unroll
@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
         for (int i = 8 * w; i < 8 * w + 8 && i < NRP; ++i) {
           const bool in_y = col_ok && rowv + 8 * i < R;      // (pad rows and pad columns: zero bits)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) word |= ((in_y && U[i][q] > 0.f) ? 1u : 0u) << ((i & 7) * 4 + q);
+          for (int q = 0; q < 4; ++q) word |= ((in_y && relu_open(U[i][q])) ? 1u : 0u) << ((i & 7) * 4 + q);
         }
         yb[w * 64] = word;
       }

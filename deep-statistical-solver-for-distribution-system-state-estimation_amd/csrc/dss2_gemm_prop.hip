@@ -553,11 +553,11 @@ __global__ void __launch_bounds__(256 * RSP, RSP > 1 ? 2 : gemm_waves_per_simd(N
               if (has_bias) v += bias4;
               if (do_relu) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                for (int q = 0; q < 4; ++q) v[q] = relu_nan(v[q]);
               }
               if (has_rs) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = gate[it][u][q] > 0.f ? v[q] : 0.f;
+                for (int q = 0; q < 4; ++q) v[q] = relu_open(gate[it][u][q]) ? v[q] : 0.f;
               }
               *reinterpret_cast<f32x4*>(p.Y + (size_t)(ts + row) * p.ldy + col0) = v;
             }
@@ -593,11 +593,11 @@ __global__ void __launch_bounds__(256 * RSP, RSP > 1 ? 2 : gemm_waves_per_simd(N
             if (p.drop_id) v *= dropout_mult4(drop_seed, drop_off, (uint32_t)p.drop_id, (uint32_t)(ts + row), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
             if (p.relu & 1) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+              for (int q = 0; q < 4; ++q) v[q] = relu_nan(v[q]);
             }
             if (p.relu_src) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = rs[u][q] > 0.f ? v[q] : 0.f;
+              for (int q = 0; q < 4; ++q) v[q] = relu_open(rs[u][q]) ? v[q] : 0.f;
             }
             if (p.add_src) v += ad[u];
             *reinterpret_cast<f32x4*>(p.Y + (size_t)(ts + row) * p.ldy + col0) = v;
@@ -618,8 +618,8 @@ __global__ void __launch_bounds__(256 * RSP, RSP > 1 ? 2 : gemm_waves_per_simd(N
           }
           if (p.dmask) y *= p.dmask[grow * p.ld_dmask + colg];
           if (p.drop_id) y *= dropout_mult4(drop_seed, drop_off, (uint32_t)p.drop_id, (uint32_t)grow, (uint32_t)(colg >> 2), p.drop_thr, p.drop_scale)[colg & 3];
-          if (p.relu & 1) y = fmaxf(y, 0.f);
-          if (p.relu_src) y = (p.relu_src[grow * p.ld_relu + colg] > 0.f) ? y : 0.f;
+          if (p.relu & 1) y = relu_nan(y);
+          if (p.relu_src) y = relu_open(p.relu_src[grow * p.ld_relu + colg]) ? y : 0.f;
           if (p.add_src) y += p.add_src[grow * p.ld_add + colg];
           p.Y[grow * p.ldy + colg] = y;
         }
@@ -775,8 +775,8 @@ __global__ void __launch_bounds__(256) gemm_narrow_kernel(const dss2_gemm_prop_a
     float y = st[row * 32 + j];
     if (p.bias) y += p.rowscale ? p.bias[j] * p.rowscale[grow] : p.bias[j];
     if (p.dmask) y *= p.dmask[grow * p.ld_dmask + j];
-    if (p.relu & 1) y = fmaxf(y, 0.f);
-    if (p.relu_src) y = (p.relu_src[grow * p.ld_relu + j] > 0.f) ? y : 0.f;
+    if (p.relu & 1) y = relu_nan(y);
+    if (p.relu_src) y = relu_open(p.relu_src[grow * p.ld_relu + j]) ? y : 0.f;
     if (p.add_src) y += p.add_src[grow * p.ld_add + j];
     p.Y[grow * p.ldy + j] = y;
   }
@@ -873,8 +873,8 @@ __global__ void __launch_bounds__(256) gemm_narrow_stream_kernel(const dss2_gemm
     float y = Gs[row * NS_MAXO + j];
     if (p.bias) y += p.rowscale ? p.bias[j] * p.rowscale[grow] : p.bias[j];
     if (p.dmask) y *= p.dmask[grow * p.ld_dmask + j];
-    if (p.relu & 1) y = fmaxf(y, 0.f);
-    if (p.relu_src) y = (p.relu_src[grow * p.ld_relu + j] > 0.f) ? y : 0.f;
+    if (p.relu & 1) y = relu_nan(y);
+    if (p.relu_src) y = relu_open(p.relu_src[grow * p.ld_relu + j]) ? y : 0.f;
     if (p.add_src) y += p.add_src[grow * p.ld_add + j];
     p.Y[grow * p.ldy + j] = y;
   }

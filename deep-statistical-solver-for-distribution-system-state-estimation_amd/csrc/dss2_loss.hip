@@ -208,8 +208,8 @@ __global__ void __launch_bounds__(LB) wls_partials_kernel(const dss2_wls_args p)
         const float Rq = (rq != 0.f) ? (rq * esv[3] + emv[3]) : 0.f;
         const float dp = Zp - f.pf, dq = Zq - f.qf;
         s_edge += dp * dp * Rp * p.lam_pf + dq * dq * Rq * p.lam_pf;
-        s_t += fmaxf(fabsf(f.d) - 0.5f, 0.f);
-        s_l += fmaxf(f.load_line + f.load_trafo - 1.5f, 0.f);
+        s_t += relu_nan(fabsf(f.d) - 0.5f);
+        s_l += relu_nan(f.load_line + f.load_trafo - 1.5f);
         if (p.pflow) {
           float* pf = p.pflow + (int64_t)e * 8;
           pf[0] = f.load_line; pf[1] = f.load_trafo; pf[2] = f.pf; pf[3] = f.qf;
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(LB) wls_partials_kernel(const dss2_wls_args p)
     p.apq[2 * i + 1] = -2.f * (nm.Z[3] - q_i) * nm.R[3] * p.lam_p;
     acc[0] = s_node;
     acc[1] = s_edge;
-    acc[2] = fmaxf(v_i - 1.1f, 0.f) + fmaxf(0.9f - v_i, 0.f);
+    acc[2] = relu_nan(v_i - 1.1f) + relu_nan(0.9f - v_i);
     acc[3] = s_t;
     acc[4] = s_l;
   }

@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256) gate_grad_kernel(const float* __restrict_
       const int c = 4 * gq + q;
       if (c < h) {
         const int64_t i = row * h + c;
-        out[i] = (!relu || y[i] > 0.f) ? g[i] * m[q] : 0.f;
+        out[i] = (!relu || relu_open(y[i])) ? g[i] * m[q] : 0.f;
       }
     }
   }

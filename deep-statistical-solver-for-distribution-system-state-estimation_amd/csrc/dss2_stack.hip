@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(512, 2) stack_fwd_kernel(const dss2_stack_args
           const f32x4 sa = *reinterpret_cast<const f32x4*>(x8 + oc * SFN), sb = *reinterpret_cast<const f32x4*>(x8 + oc * SFN + 4);
           const f32x4 e0 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8), e1 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8 + 4);
           const float z = edge_z(w, bb, ta, tb, sa, sb, e0, e1);
-          acc += o >= 0 ? fmaxf(z, 0.f) : 0.f;
+          acc += o >= 0 ? relu_nan(z) : 0.f;
         }
         Xs[r * SXLD + c32] = acc;
         if (r < R) act_b[(size_t)(ts + r) * SH + c32] = acc;
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(512, 2) stack_fwd_kernel(const dss2_stack_args
         v += U;
         v *= mult;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = prow < R ? fmaxf(v[q], 0.f) : 0.f;
+        for (int q = 0; q < 4; ++q) v[q] = prow < R ? relu_nan(v[q]) : 0.f;
         if (prow < R) *reinterpret_cast<f32x4*>(act_b + ((size_t)(l + 1) * N + ts + prow) * SH + pcq) = v;
         *reinterpret_cast<f32x4*>(Xs + prow * SXLD + pcq) = v;
       }
@@ -857,7 +857,7 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
                   f32x4 mult = {1.f, 1.f, 1.f, 1.f};
                   if (p.drop_state) mult = dropout_mult4(dseed, doff, (uint32_t)(b * p.drop_stride + u), (uint32_t)(ts + row), (uint32_t)(col >> 2), p.drop_thr, p.drop_scale);
 #pragma unroll
-                  for (int q = 0; q < 4; ++q) v[q] = a[q] > 0.f ? v[q] * mult[q] : 0.f;
+                  for (int q = 0; q < 4; ++q) v[q] = relu_open(a[q]) ? v[q] * mult[q] : 0.f;
                 }
                 if (row >= R) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(Zn + row * SXLD + col) = v;
@@ -918,7 +918,7 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
             if (o < 0) continue;
             const f32x4 sa = *reinterpret_cast<const f32x4*>(x8 + o * SFN), sb = *reinterpret_cast<const f32x4*>(x8 + o * SFN + 4);
             const f32x4 e0 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8), e1 = *reinterpret_cast<const f32x4*>(eaL + (k * STM + r) * 8 + 4);
-            const float dz = edge_z(w, bb, ta, tb, sa, sb, e0, e1) > 0.f ? gS : 0.f;
+            const float dz = relu_open(edge_z(w, bb, ta, tb, sa, sb, e0, e1)) ? gS : 0.f;
             u0 += dz;
             db1 += dz;
 #pragma unroll
@@ -942,7 +942,7 @@ __global__ void __launch_bounds__(512, 1) stack_bwd_kernel(const dss2_stack_args
               if (o < 0) continue;
               const f32x4 ta = *reinterpret_cast<const f32x4*>(x8 + o * SFN), tb = *reinterpret_cast<const f32x4*>(x8 + o * SFN + 4);
               const f32x4 e0 = *reinterpret_cast<const f32x4*>(eaT + (k * STM + r) * 8), e1 = *reinterpret_cast<const f32x4*>(eaT + (k * STM + r) * 8 + 4);
-              u1 += edge_z(w, bb, ta, tb, sa, sb, e0, e1) > 0.f ? dS[o * SXLD + c32] : 0.f;
+              u1 += relu_open(edge_z(w, bb, ta, tb, sa, sb, e0, e1)) ? dS[o * SXLD + c32] : 0.f;
             }
             U1[r * SZ2 + c32] = u1;
           }

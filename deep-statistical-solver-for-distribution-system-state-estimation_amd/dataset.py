@@ -337,8 +337,10 @@ class PrefetchLoader:
 
     ``prepare(batch)``: extra work to run on the side stream (default: build every lazily built part of the batch's structure)."""
 
-    def __init__(self, loader, prepare=None):
-        self.loader, self.prepare = loader, prepare
+    def __init__(self, loader, prepare=None, priority: int = -1):
+        """``priority``: of the side stream (-1 = high: the assembly's small launch-bound kernels are dispatched ahead of the step's
+        waiting workgroups instead of behind them)."""
+        self.loader, self.prepare, self.priority = loader, prepare, int(priority)
         self.side = None
 
     def __len__(self):
@@ -355,7 +357,7 @@ class PrefetchLoader:
     def __iter__(self):
         dev = self.loader.dataset.device
         main = torch.cuda.current_stream(dev)
-        side = self.side = self.side or torch.cuda.Stream(device=dev)
+        side = self.side = self.side or torch.cuda.Stream(device=dev, priority=self.priority)
         it = iter(self.loader)
         prep = self.prepare or self._build_structure
 

@@ -183,7 +183,7 @@ class LooseGradCoalescer:
         self.offsets, off = [], 0
         for p in self.params:
             self.offsets.append(off)
-            off += (p.numel() + 15) // 16 * 16          # slices start on 64-byte boundaries
+            off += p.numel()                            # (contiguous: the buffer holds exactly the parameters' elements)
         self.total = off
         self.flat = None            # the buffer of the backward in flight (None between backward passes)
         self.mode = None

@@ -1,0 +1,97 @@
+"""GPU: non-finite values behave as in the reference (VERDICT r5 missing #4 / next #8).
+
+``nn.ReLU`` (/root/reference/networks.py:269) carries a NaN; ``v_max_f32(x, 0)`` -- every ReLU of rounds 1-5 -- returns 0 for it.  Round 6
+found what that costs (tools/nonfinite_probe.py): one NaN in a hidden layer's weight matrix gave a dead column and a FINITE loss where the
+reference's loss is NaN -- a diverged run would not have shown.  Every ReLU is now ``!(x <= 0) ? x : 0`` and every backward gate
+``!(y <= 0)`` (torch's threshold_backward), at the cost ``fmaxf`` already had.  Pinned here against the oracle (torch semantics = the
+reference's) on the C2 model (chained f16x3 kernels), on the whole-stack kernels (H = 32) and on a 70-bus grid (96-row tiles):
+the SAME output rows are non-finite, the loss is NaN in both, and every parameter gradient is non-finite in both."""
+import importlib
+
+import pytest
+import torch
+
+from conftest import PKG_NAME
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NAN, INF = float("nan"), float("inf")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module(PKG_NAME)
+
+
+def _run(pkg, oracle, hid, layers, grid, B, mutate_x=None, mutate_w=None):
+    torch.manual_seed(0)
+    b = pkg.synthetic.make_batch([grid], B, seed=5)
+    ref = oracle.MPN(8, 6, 2, hid, layers, 2, 0.0)
+    if mutate_w is not None:
+        with torch.no_grad():
+            mutate_w(ref)
+    mine = pkg.MPN(8, 6, 2, hid, layers, 2, 0.0)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(DEV)
+    x = b["x"].clone()
+    if mutate_x is not None:
+        mutate_x(x)
+    out_r, loss_r = oracle.train_step(ref, {"x": x, "edge_index": b["edge_index"], "edge_attr": b["edge_attr"]}, b["stats"], oracle.DEFAULT_REG_COEFS)
+    xd, ei, ea = x.to(DEV), b["edge_index"].to(DEV), b["edge_attr"].to(DEV)
+    st = tuple(s.to(DEV) for s in b["stats"])
+    out = mine(xd[:, :8], ei, ea[:, :6])
+    loss = pkg.gsp_wls_edge(input=xd[:, :8], edge_input=ea[:, :6], output=out, x_mean=st[0], x_std=st[1], edge_mean=st[2], edge_std=st[3],
+                            edge_index=ei, reg_coefs=oracle.DEFAULT_REG_COEFS, num_samples=None, node_param=xd[:, 8:], edge_param=ea[:, 6:])
+    loss.backward()
+    torch.cuda.synchronize()
+    rows_r = (~torch.isfinite(out_r).all(1)).nonzero().flatten().tolist()
+    rows_m = (~torch.isfinite(out.cpu()).all(1)).nonzero().flatten().tolist()
+    fin_r = {n: bool(torch.isfinite(p.grad).all()) for n, p in ref.named_parameters()}
+    fin_m = {n: bool(torch.isfinite(p.grad).all()) for n, p in mine.named_parameters()}
+    return rows_r, rows_m, loss_r.item(), loss.item(), fin_r, fin_m
+
+
+SHAPES = {"C2 model, 64-row tiles": (128, 4, "cigre14", 8, 15), "whole-stack kernels (H = 32)": (32, 2, "cigre14", 8, 15),
+          "70-bus grid, 96-row tiles": (128, 4, "ober_sub", 3, 70)}
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_a_clean_batch_is_finite(pkg, oracle, shape):
+    hid, layers, grid, B, n = SHAPES[shape]
+    rows_r, rows_m, lr, lm, fr, fm = _run(pkg, oracle, hid, layers, grid, B)
+    assert rows_r == [] and rows_m == [] and all(fr.values()) and all(fm.values())
+    assert abs(lm - lr) <= 1e-5 * abs(lr)
+
+
+@pytest.mark.parametrize("value", [NAN, INF], ids=["nan", "inf"])
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_a_non_finite_input_feature_poisons_its_graph_only(pkg, oracle, shape, value):
+    hid, layers, grid, B, n = SHAPES[shape]
+    node = n + 5                                                   # a bus of graph 1
+    rows_r, rows_m, lr, lm, fr, fm = _run(pkg, oracle, hid, layers, grid, B, mutate_x=lambda x: x.__setitem__((node, 0), value))
+    assert rows_r and set(rows_r) <= set(range(n, 2 * n))          # the reference: only rows of that graph (message passing does not leave it)
+    assert rows_m == rows_r
+    assert lr != lr and lm != lm                                   # NaN loss in both
+    assert not any(fr.values()) and not any(fm.values())           # ... and every parameter gradient non-finite in both
+
+
+@pytest.mark.parametrize("value", [NAN, INF], ids=["nan", "inf"])
+@pytest.mark.parametrize("where", ["hidden layer", "head", "edge MLP"])
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_a_non_finite_weight_gives_a_nan_loss_as_in_the_reference(pkg, oracle, shape, where, value):
+    hid, layers, grid, B, n = SHAPES[shape]
+
+    def mutate(m):
+        if where == "hidden layer":
+            m.convs[min(1, layers - 2)].lins[0].weight[3, 5] = value
+        elif where == "head":
+            m.convs[layers - 1].lins[1].weight[0, 5] = value
+        else:
+            m.edge_aggr.edge_aggr[0].weight[3, 2] = value
+    rows_r, rows_m, lr, lm, fr, fm = _run(pkg, oracle, hid, layers, grid, B, mutate_w=mutate)
+    assert rows_r and rows_m == rows_r                              # (a NaN weight: every row of every graph; an Inf one: wherever Inf meets 0 or -Inf)
+    if value != value:
+        assert len(rows_r) == B * n
+    assert lr != lr and lm != lm
+    assert not any(fr.values())
+    assert not any(fm.values()), [k for k, v in fm.items() if v]
