@@ -36,7 +36,7 @@ class GemmPropArgs(C.Structure):
                 ("prop_in", C.c_int32), ("narrow_h", C.c_int32),
                 ("prebias", C.c_void_p), ("pre_rowscale", C.c_void_p), ("ell_tiles", C.c_void_p),
                 ("drop_state", C.c_void_p), ("drop_thr", C.c_uint32), ("drop_scale", C.c_float), ("drop_id", C.c_int32),
-                ("b_format", C.c_int32)]
+                ("b_format", C.c_int32), ("max_tile_rows", C.c_int32)]
 
 
 class ChainHead(C.Structure):

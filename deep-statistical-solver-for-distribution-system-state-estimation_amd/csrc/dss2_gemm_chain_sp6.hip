@@ -67,7 +67,11 @@ __device__ __forceinline__ void s6_store_split_h(__bf16* dst, const f32x4 v, int
 // F16 (round 5; DIR 1 and 2): the tile GEMM as f16x3 -- two fp16 planes per stripe scaled by 2^ea per tile and layer, the weights as two
 // fp16 planes with per-matrix exponents (b_format 2), three v_mfma_f32_32x32x16_f16 per product; the accumulators are handed to the hops
 // with the scales taken out.  One more barrier per layer (the tile's maximum).  See dss2_gemm_chain_sp.hip, MS = 2.
-template <int NRB, int NMAT, int DIR, int HM = 0, bool F16 = false>
+// RPA (round 6): ACTIVE row pieces per lane, <= 4 NRB.  Where every tile of the launch holds at most 8 RPA rows (args.max_tile_rows: 70-bus
+// graphs in 96-row tiles -> 9 of 12 pieces) the accumulator hand-off, the hops, the epilogue and the split of the next layer's planes leave
+// out the pieces that are padding in every tile -- a quarter of a layer's vector and LDS work at C3.  The planes of those rows are never
+// rewritten (they hold whatever the Horner slot left there: only the accumulators of the same padding rows see it, and those are never read).
+template <int NRB, int NMAT, int DIR, int HM = 0, bool F16 = false, int RPA = 4 * NRB>
 __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(const dss2_gemm_prop_args p, const ChainTable ct, const dss2_chain_head hd) {
   constexpr int TM = 32 * NRB, S6_PLANE = s6_plane(NRB), S6_REGION = s6_region(NRB);
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -100,7 +104,9 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
   const int cq = (lane & 7) * 4, r8 = lane >> 3;
   const int col0 = cg * 32 + cq;
   const bool col_ok = col0 < p.hout;
-  constexpr int NRP = 4 * NRB, HP = NRP / DSS2_S6_PASSES;              // row pieces per lane: rows r8 + 8 i; HP of them per gather pass
+  constexpr int NRP = 4 * NRB, HP = (RPA + DSS2_S6_PASSES - 1) / DSS2_S6_PASSES;      // row pieces per lane: rows r8 + 8 i (RPA of them active in the layer loop); HP of them per gather pass
+  constexpr int NPASS = (RPA + HP - 1) / HP;
+  static_assert(RPA >= 1 && RPA <= NRP, "active row pieces");
 
   // ---- stage the tile's ELL slice and the first layer's input tile as split planes (zero padded to 96 x kpad)
   {
@@ -393,13 +399,14 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     S6STAMP(2 + li * 6 + 1);
 
     // ---- Horner on row pieces, wave-private: T in one slot, G_m in the other; U = G_m + P T replaces G_m
-    f32x4 U[NRP];
+    f32x4 U[RPA];
     {
-      auto put = [&](int m) {
+      auto put = [&](int m) {      // (accumulator registers of rows beyond the active pieces stay where they are)
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) slot0[(rb * 32 + acc_row(r, half)) * 32 + c32] = F16 ? ldexpf(acc[rb][m][r], ue[m]) : acc[rb][m][r];
+          for (int r = 0; r < 16; ++r)
+            if (rb * 32 + 8 * (r >> 2) < 8 * RPA) slot0[(rb * 32 + acc_row(r, half)) * 32 + c32] = F16 ? ldexpf(acc[rb][m][r], ue[m]) : acc[rb][m][r];
       };
       put(NMAT - 1);
       wave_lds_sync();
@@ -408,25 +415,27 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
         const bool want_gate = m == 0 && fp32_gate && col_ok;
         // z = P T gathered from the slot (NRP / HP passes of HP row pieces), then G_m takes the slot and U = G_m + z
 #pragma unroll
-        for (int h12 = 0; h12 < NRP / HP; ++h12) {
+        for (int h12 = 0; h12 < NPASS; ++h12) {
           int2 en[HP];
           f32x4 gt[HP];
+          auto on = [&](int i) { return HP * h12 + i < RPA; };      // (compile-time after unrolling: the last pass may be shorter)
           if (want_gate) {
 #pragma unroll
-            for (int i = 0; i < HP; ++i) gt[i] = *reinterpret_cast<const f32x4*>(L.relu_src + grow_of(HP * h12 + i) * p.ld_relu + col0);
+            for (int i = 0; i < HP; ++i) if (on(i)) gt[i] = *reinterpret_cast<const f32x4*>(L.relu_src + grow_of(HP * h12 + i) * p.ld_relu + col0);
           }
 #pragma unroll
-          for (int i = 0; i < HP; ++i) { en[i] = ell[r8 + 8 * (HP * h12 + i)]; U[HP * h12 + i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+          for (int i = 0; i < HP; ++i) if (on(i)) { en[i] = ell[r8 + 8 * (HP * h12 + i)]; U[HP * h12 + i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
           for (int k = 0; k < D; ++k) {
             const int kn = k + 1 < D ? k + 1 : k;
             f32x4 z[HP];
 #pragma unroll
-            for (int i = 0; i < HP; ++i) z[i] = *reinterpret_cast<const f32x4*>(slot0 + en[i].x * 32 + cq);
+            for (int i = 0; i < HP; ++i) if (on(i)) z[i] = *reinterpret_cast<const f32x4*>(slot0 + en[i].x * 32 + cq);
             int2 en_next[HP];
 #pragma unroll
-            for (int i = 0; i < HP; ++i) en_next[i] = ell[kn * TM + r8 + 8 * (HP * h12 + i)];
+            for (int i = 0; i < HP; ++i) if (on(i)) en_next[i] = ell[kn * TM + r8 + 8 * (HP * h12 + i)];
 #pragma unroll
             for (int i = 0; i < HP; ++i) {
+              if (!on(i)) continue;
               const float w = __int_as_float(en[i].y);
 #pragma unroll
               for (int q = 0; q < 4; ++q) U[HP * h12 + i][q] = fmaf(w, z[i][q], U[HP * h12 + i][q]);
@@ -437,18 +446,18 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
 #pragma unroll
             for (int i = 0; i < HP; ++i)
 #pragma unroll
-              for (int q = 0; q < 4; ++q) gate_bits[(HP * h12 + i) >> 3] |= (relu_open(gt[i][q]) ? 1u : 0u) << (((HP * h12 + i) & 7) * 4 + q);
+              for (int q = 0; q < 4; ++q) if (on(i)) gate_bits[(HP * h12 + i) >> 3] |= (relu_open(gt[i][q]) ? 1u : 0u) << (((HP * h12 + i) & 7) * 4 + q);
           }
         }
         wave_lds_sync();      // every lane's gathers are done: G_m goes over T
         put(m);
         wave_lds_sync();
 #pragma unroll
-        for (int i = 0; i < NRP; ++i) U[i] += *reinterpret_cast<const f32x4*>(slot0 + (r8 + 8 * i) * 32 + cq);
+        for (int i = 0; i < RPA; ++i) U[i] += *reinterpret_cast<const f32x4*>(slot0 + (r8 + 8 * i) * 32 + cq);
         if (m > 0) {
           wave_lds_sync();
 #pragma unroll
-          for (int i = 0; i < NRP; ++i) *reinterpret_cast<f32x4*>(slot0 + (r8 + 8 * i) * 32 + cq) = U[i];
+          for (int i = 0; i < RPA; ++i) *reinterpret_cast<f32x4*>(slot0 + (r8 + 8 * i) * 32 + cq) = U[i];
         }
         wave_lds_sync();      // (m > 0: the new T is complete; m == 0: the planes may go over the slot)
       }
@@ -459,14 +468,14 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     // ---- epilogue: bias / folded bias / masks / dropout / ReLU / gate / residual -> HBM and, split, the next layer's planes
     const bool keep = li + 1 < ct.n;
 #pragma unroll
-    for (int i = 0; i < NRP; ++i) U[i] += bias4;
+    for (int i = 0; i < RPA; ++i) U[i] += bias4;
     if (col_ok) {
       if (has_pre) {
         f32x4 pb4[NMAT];
 #pragma unroll
         for (int m = 0; m < NMAT; ++m) pb4[m] = *reinterpret_cast<const f32x4*>(L.prebias + (size_t)m * p.hout + col0);
 #pragma unroll
-        for (int i = 0; i < NRP; ++i) {
+        for (int i = 0; i < RPA; ++i) {
           const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pre_rowscale + grow_of(i) * 4);
 #pragma unroll
           for (int m = 0; m < NMAT; ++m) U[i] += pb4[m] * ps[m];
@@ -474,31 +483,31 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
       }
       if (has_dm) {
 #pragma unroll
-        for (int i = 0; i < NRP; ++i) U[i] *= *reinterpret_cast<const f32x4*>(L.dmask + grow_of(i) * p.ld_dmask + col0);
+        for (int i = 0; i < RPA; ++i) U[i] *= *reinterpret_cast<const f32x4*>(L.dmask + grow_of(i) * p.ld_dmask + col0);
       }
       if (L.drop_id) {
 #pragma unroll      // (fully unrolled: a rolled loop indexes U at run time and sends the whole array to scratch memory)
-        for (int i = 0; i < NRP; ++i)
+        for (int i = 0; i < RPA; ++i)
           U[i] *= dropout_mult4(drop_seed, drop_off, (uint32_t)L.drop_id, (uint32_t)grow_of(i), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
       }
       if (DIR != 2 && (L.relu & 1)) {
 #pragma unroll
-        for (int i = 0; i < NRP; ++i)
+        for (int i = 0; i < RPA; ++i)
 #pragma unroll
           for (int q = 0; q < 4; ++q) U[i][q] = relu_nan(U[i][q]);
       }
       if (has_rs) {
 #pragma unroll
-        for (int i = 0; i < NRP; ++i)
+        for (int i = 0; i < RPA; ++i)
 #pragma unroll
           for (int q = 0; q < 4; ++q) U[i][q] = ((gate_bits[i >> 3] >> ((i & 7) * 4 + q)) & 1u) ? U[i][q] : 0.f;
       }
       if (has_add) {
 #pragma unroll
-        for (int i = 0; i < NRP; ++i) U[i] += *reinterpret_cast<const f32x4*>(L.add_src + grow_of(i) * p.ld_add + col0);
+        for (int i = 0; i < RPA; ++i) U[i] += *reinterpret_cast<const f32x4*>(L.add_src + grow_of(i) * p.ld_add + col0);
       }
 #pragma unroll
-      for (int i = 0; i < NRP; ++i)
+      for (int i = 0; i < RPA; ++i)
         if (rowv + 8 * i < R) *reinterpret_cast<f32x4*>(L.Y + (size_t)(ts + rowv + 8 * i) * p.ldy + col0) = U[i];
     }
     if (DIR != 2 && L.y_bits) {      // (uniform) the sign bits of what went to Y, in the layout the data-gradient form reads
@@ -507,7 +516,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
       for (int w = 0; w < NGW; ++w) {
         uint32_t word = 0u;
 #pragma unroll
-        for (int i = 8 * w; i < 8 * w + 8 && i < NRP; ++i) {
+        for (int i = 8 * w; i < 8 * w + 8 && i < RPA; ++i) {
           const bool in_y = col_ok && rowv + 8 * i < R;      // (pad rows and pad columns: zero bits)
 #pragma unroll
           for (int q = 0; q < 4; ++q) word |= ((in_y && relu_open(U[i][q])) ? 1u : 0u) << ((i & 7) * 4 + q);
@@ -521,7 +530,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
         // the next layer's scale: the tile's maximum over all stripes (one more barrier per layer; the planes then go over the slots)
         float mx = 0.f;
 #pragma unroll
-        for (int i = 0; i < NRP; ++i) {
+        for (int i = 0; i < RPA; ++i) {
           if (!(rowv + 8 * i < R && col_ok)) U[i] = f32x4{0.f, 0.f, 0.f, 0.f};
           mx = absmax4(mx, U[i]);
         }
@@ -530,10 +539,10 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
         s6_barrier();
         ea = tile_exponent();
 #pragma unroll
-        for (int i = 0; i < NRP; ++i) s6_store_split_h<S6_PLANE>(own_planes + s6_off(rowv + 8 * i, cq), U[i], ea);
+        for (int i = 0; i < RPA; ++i) s6_store_split_h<S6_PLANE>(own_planes + s6_off(rowv + 8 * i, cq), U[i], ea);
       } else {
 #pragma unroll
-        for (int i = 0; i < NRP; ++i) {
+        for (int i = 0; i < RPA; ++i) {
           const int row = rowv + 8 * i;
           s6_store_split<S6_PLANE>(own_planes + s6_off(row, cq), (row < R && col_ok) ? U[i] : f32x4{0.f, 0.f, 0.f, 0.f});
         }
@@ -558,10 +567,10 @@ bool chain_sp6_supported(const dss2_gemm_prop_args& a) {
          a.ncg >= 2 && a.ncg <= 4 && chain_sp6_lds_bytes(a.nrb, a.ncg, a.ell_width) <= (size_t)(a.nrb == 3 ? kMaxLdsBytes / 2 : kMaxLdsBytes);
 }
 
-template <int NRB, int NMAT, int DIR, int HM = 0, bool F16 = false>
+template <int NRB, int NMAT, int DIR, int HM = 0, bool F16 = false, int RPA = 4 * NRB>
 static int launch_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, const dss2_chain_head& hd, hipStream_t stream) {
   static std::atomic<uint32_t> lds_done{0};
-  auto kern = gemm_chain_sp6_kernel<NRB, NMAT, DIR, HM, F16>;
+  auto kern = gemm_chain_sp6_kernel<NRB, NMAT, DIR, HM, F16, RPA>;
   if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "gemm_prop_chain(split planes, 192 rows)")) return 1;
   hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(64 * a.ncg), chain_sp6_lds_bytes(NRB, a.ncg, a.ell_width), stream, a, ct, hd);
   return check_launch("gemm_prop_chain(split planes, 192 rows)");
@@ -575,9 +584,14 @@ int launch_chain_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, const d
     if (L.bias || L.prebias || L.dmask || L.add_src || L.y_bits || (L.relu & 1) || (L.relu_src && !L.gate_bits)) bwd = false;
   }
   dss2_chain_head hd = {};
+  // 96-row tiles none of which holds more than 72 rows (70-bus graphs, one per tile): 9 of the 12 row pieces per lane are active (RPA, round 6;
+  // the f16x3 K = 2 forms of the C3 path; DSS2_CHAIN_RPA=0: all 12)
+  static const int rpa_on = [] { const char* e = getenv("DSS2_CHAIN_RPA"); return e ? atoi(e) : 1; }();
+  const bool rpa9 = rpa_on && a.b_format == 2 && a.nrb == 3 && a.nmat == 3 && a.max_tile_rows > 0 && a.max_tile_rows <= 72;
   if (head) {      // the backward head (mode 2) rides in the staging of the data-gradient launch; nothing else is built here
     if (head->mode != 2 || !bwd) { set_error("gemm_prop_chain_head: tall tiles take the backward head (mode 2) on a data-gradient chain only"); return 2; }
     hd = *head;
+    if (rpa9) return launch_sp6<3, 3, 2, 2, true, 9>(a, ct, hd, s);
     if (a.b_format == 2) {
       if (a.nrb == 3) return a.nmat == 2 ? launch_sp6<3, 2, 2, 2, true>(a, ct, hd, s) : launch_sp6<3, 3, 2, 2, true>(a, ct, hd, s);
       return a.nmat == 2 ? launch_sp6<6, 2, 2, 2, true>(a, ct, hd, s) : launch_sp6<6, 3, 2, 2, true>(a, ct, hd, s);
@@ -588,6 +602,7 @@ int launch_chain_sp6(const dss2_gemm_prop_args& a, const ChainTable& ct, const d
   const int dir = fwd ? 1 : (bwd ? 2 : 0);      // (0: a layer table that mixes the feature sets runs the generic instantiation)
   if (a.b_format == 2) {      // f16x3: the direction-specialised forms only
     if (dir == 0) { set_error("gemm_prop_chain(f16x3): a layer table that mixes forward and data-gradient features needs bf16x3 weights (b_format 1)"); return 2; }
+    if (rpa9) return dir == 1 ? launch_sp6<3, 3, 1, 0, true, 9>(a, ct, hd, s) : launch_sp6<3, 3, 2, 0, true, 9>(a, ct, hd, s);
 #define DSS2_S6_LAUNCH_H(NRB, NMAT) (dir == 1 ? launch_sp6<NRB, NMAT, 1, 0, true>(a, ct, hd, s) : launch_sp6<NRB, NMAT, 2, 0, true>(a, ct, hd, s))
     if (a.nrb == 3) return a.nmat == 2 ? DSS2_S6_LAUNCH_H(3, 2) : DSS2_S6_LAUNCH_H(3, 3);
     return a.nmat == 2 ? DSS2_S6_LAUNCH_H(6, 2) : DSS2_S6_LAUNCH_H(6, 3);

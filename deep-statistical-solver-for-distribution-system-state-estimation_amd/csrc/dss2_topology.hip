@@ -256,10 +256,15 @@ __global__ void __launch_bounds__(256) topo_finalize_kernel(const BuildPtrs p, c
       smin = min(smin, __shfl_xor(smin, o));
       scnt += __shfl_xor(scnt, o);
     }
-    if ((threadIdx.x & 63) == 0) {
-      atomicMax(p.meta + 0, mdeg);
-      atomicMax(p.meta + 1, mdegT);
-      if (scnt) { atomicMax(p.meta + 2, smax); atomicAdd(p.meta + 3, scnt); atomicMin(p.meta + 4, smin); }
+    if ((threadIdx.x & 63) == 0) {      // (running extrema: read first, post an atomic only when it would change the word)
+      auto cur = [&](int i) { return __hip_atomic_load(p.meta + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+      if (mdeg > cur(0)) atomicMax(p.meta + 0, mdeg);
+      if (mdegT > cur(1)) atomicMax(p.meta + 1, mdegT);
+      if (scnt) {
+        if (smax > cur(2)) atomicMax(p.meta + 2, smax);
+        atomicAdd(p.meta + 3, scnt);
+        if (smin < cur(4)) atomicMin(p.meta + 4, smin);
+      }
     }
     return;
   }
@@ -345,7 +350,11 @@ __global__ void __launch_bounds__(256) ell_tiles_kernel(const EllArgs a) {
   const int D = a.D[which];
   const int ts = a.tile_start[tile], R = a.tile_start[tile + 1] - ts;
   const int32_t* rp = a.rowptr[which];
-  if (threadIdx.x == 0) atomicMax(a.meta + 6 + which, rp[ts + R] - rp[ts]);
+  if (threadIdx.x == 0) {      // (a running maximum: read first -- thousands of tiles hammering one word with atomics cost this launch 38 us at C5;
+                               //  a stale read only costs a redundant atomic)
+    const int nnz = rp[ts + R] - rp[ts];
+    if (nnz > __hip_atomic_load(a.meta + 6 + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.meta + 6 + which, nnz);
+  }
   if (D <= 0) return;
   int2* ow = a.ell_w[which] + (size_t)tile * D * a.TM;
   int2* oe = a.ell_e[which] + (size_t)tile * D * a.TM;

@@ -244,6 +244,31 @@ class MixedDataset:
         rng = rng or np.random.default_rng()
         return MixedDataset(self.parts, rng.permutation(self.ids))
 
+    _RING = 8
+
+    def _upload(self, tab: np.ndarray, dev) -> torch.Tensor:
+        """Host -> device copy of a small index table through a RING of pinned staging buffers owned by the dataset.  (``pin_memory()``
+        per batch asks torch's pinned allocator for a block whose previous copy has completed; one batch ahead on a side stream
+        (PrefetchLoader) that copy is still queued behind a whole step, so every batch paid a fresh hipHostMalloc -- ~1.4 ms of host
+        time, round 6.)  A slot is reused _RING uploads later; its event is waited for only if that copy has still not run."""
+        ring = self.__dict__.setdefault("_ring", {"slots": [], "next": 0})
+        if not ring["slots"]:
+            ring["slots"] = [[None, None] for _ in range(self._RING)]
+        i = ring["next"]
+        ring["next"] = (i + 1) % self._RING
+        buf, ev = ring["slots"][i]
+        if buf is None or buf.numel() < tab.size:
+            buf = torch.empty(max(tab.size, 3 * 4096), dtype=torch.int64).pin_memory()
+            ev = torch.cuda.Event()
+        elif not ev.query():
+            ev.synchronize()
+        stage = buf[:tab.size].view(tab.shape)
+        stage.copy_(torch.from_numpy(tab))
+        out = stage.to(dev, non_blocking=True)
+        ev.record(torch.cuda.current_stream(dev))
+        ring["slots"][i] = [buf, ev]
+        return out
+
     def collate(self, ids: np.ndarray) -> Batch:
         B, dev = int(ids.size), self.device
         part = np.searchsorted(self.start, ids, side="right") - 1           # part of every slot
@@ -266,7 +291,7 @@ class MixedDataset:
                 continue
             n = p.n
             tab = np.stack([ids[slots] - self.start[k], node_off[slots], edge_off[slots]]).astype(np.int64)
-            tab_d = torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)      # 3 x count int64, host -> device only
+            tab_d = self._upload(tab, dev)                                             # 3 x count int64, host -> device only
             descs = (_lib.CollateDesc * 4)()
             items = [(p.x, x, n * p.x.size(2), 0, 0, p.x.size(2)), (p.y, y, n * p.y.size(2), 0, 0, p.y.size(2)),
                      (p.edge_attr, ea, p.e * p.edge_attr.size(2), 0, 1, p.edge_attr.size(2)),

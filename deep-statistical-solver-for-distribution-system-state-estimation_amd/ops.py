@@ -191,6 +191,7 @@ def gemm_prop_chain(topo: Topology, X: Optional[torch.Tensor], hid: int, nmat: i
     a.kreal, a.kpad = hid, (_round16(hid) if b_format >= 1 else _round8(hid))
     a.hout, a.ncg, a.ldy, a.ld_relu, a.ld_dmask, a.ld_add = hid, _ncg(hid), hid, hid, hid, hid
     a.nmat, a.nrb, a.ntiles = nmat, topo.nrb, topo.ntiles
+    a.max_tile_rows = int(getattr(topo, "max_tile_rows", 0) or 0)
     a.tile_start = topo.tile_start.data_ptr()
     a.pre_rowscale = _ptr(pre_rowscale)
     if transposed:

@@ -35,7 +35,7 @@ _FLIP = 1 << 31
 _NRB_CHOICES = (2, 4, 3, 1, 6)   # preference order on utilisation ties (32*nrb rows per tile)
 _LDS_LIMIT = 160 * 1024
 _ELL_MAX = 8
-_TILE_ATTRS = frozenset(["global_only", "nrb", "ntiles", "tile_start", "utilisation", "max_segment", "max_nnz", "max_nnzT", "ell", "ellT",
+_TILE_ATTRS = frozenset(["global_only", "nrb", "ntiles", "tile_start", "utilisation", "max_segment", "max_nnz", "max_nnzT", "ell", "ellT", "max_tile_rows",
                          "ell_tiles", "ellT_tiles", "ell_ent_tiles", "ellT_ent_tiles"])
 
 
@@ -209,6 +209,7 @@ class Topology:
             _lib.check(L.dss2_tiles_uniform(tile_start.data_ptr(), nt, per * n, N, st), "dss2_tiles_uniform")
             max_deg = max_degT = int(hint.max_degree)
             max_segment = n
+            max_tile_rows = per * n
             if os.environ.get("DSS2_CHECK", "0") == "1":      # debugging aid: read the build's error flag after all (ONE host sync)
                 read_stats()
             nnz_bound = per * hint.max_edges_per_graph * (2 if self.directed else 1)
@@ -236,6 +237,8 @@ class Topology:
             util, nrb, nt, i = best
             tile_start = cands[i][:nt + 1].clone()
             nnz_bound, exact_nnz = 0, True
+            # (known without another copy only where every graph has the same size: whole graphs per tile)
+            max_tile_rows = ((32 * nrb) // max_segment) * max_segment if s["min_segment"] == max_segment else 0
         ell = max_deg if max_deg <= _ELL_MAX else 0
         ellT = max_degT if max_degT <= _ELL_MAX else 0
         tm = 32 * nrb
@@ -260,7 +263,7 @@ class Topology:
             max_nnz, max_nnzT = max_deg * tm, max_degT * tm
         else:
             max_nnz = max_nnzT = nnz_bound
-        d = dict(global_only=False, nrb=nrb, ntiles=nt, tile_start=tile_start, utilisation=util, max_segment=max_segment,
+        d = dict(global_only=False, nrb=nrb, ntiles=nt, tile_start=tile_start, utilisation=util, max_segment=max_segment, max_tile_rows=max_tile_rows,
                  max_nnz=max_nnz, max_nnzT=max_nnzT, ell=ell, ellT=ellT, ell_tiles=ell_tiles,
                  ellT_tiles=ellT_tiles, ell_ent_tiles=ell_ent_tiles, ellT_ent_tiles=ellT_ent_tiles)
         if not store:
@@ -276,7 +279,7 @@ class Topology:
         nt = -(-self.N // 64)
         tile_start = torch.empty(nt + 1, dtype=torch.int32, device=self.device)
         _lib.check(_lib.lib().dss2_tiles_uniform(tile_start.data_ptr(), nt, 64, self.N, _stream(self.device)), "dss2_tiles_uniform")
-        self.__dict__.update(global_only=True, nrb=2, ntiles=nt, tile_start=tile_start, utilisation=self.N / float(nt * 64),
+        self.__dict__.update(global_only=True, nrb=2, ntiles=nt, tile_start=tile_start, utilisation=self.N / float(nt * 64), max_tile_rows=0,
                              max_segment=max_segment, max_nnz=0, max_nnzT=0, ell=0, ellT=0, ell_tiles=None, ellT_tiles=None,
                              ell_ent_tiles=None, ellT_ent_tiles=None)
         self._tiles_built = True

@@ -272,6 +272,9 @@ typedef struct dss2_gemm_prop_args {
   const uint64_t* drop_state; uint32_t drop_thr; float drop_scale; int32_t drop_id;
   int32_t b_format;   /* layout of the packed weights: 0 = fp32 fragments; 1 = bf16x3 fragments (dss2_gemm_prop_chain, and
                          dss2_gemm_prop where dss2_gemm_prop16_supported(...) != 0; kpad is then a multiple of 16) */
+  int32_t max_tile_rows;   /* 0: unknown (any tile may hold up to 32 * nrb rows); > 0: an upper bound of EVERY tile's row count --
+                              the tall-tile chains then leave out the row pieces that are padding in every tile (70-bus graphs in
+                              96-row tiles: rows 72..95, a quarter of the hops and of the epilogue) */
 } dss2_gemm_prop_args;
 
 int dss2_gemm_prop(const dss2_gemm_prop_args* args_host, void* stream);
