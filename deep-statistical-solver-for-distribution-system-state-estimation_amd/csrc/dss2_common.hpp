@@ -100,6 +100,16 @@ __device__ __forceinline__ float relu_nan(float v) { return !(v <= 0.f) ? v : 0.
 // The gate of ReLU's backward with torch's semantics (threshold_backward: `self <= 0 ? 0 : grad`): a NaN activation lets the gradient
 // through (it is NaN there anyway: the loss is), where `y > 0` would zero it and leave a FINITE parameter gradient beside a NaN loss.
 __device__ __forceinline__ bool relu_open(float y) { return !(y <= 0.f); }
+// relu_nan on four values with the compares and the selects interleaved by hand: the lane masks go to four SGPR pairs and every select
+// follows its compare by three instructions (the VALU-writes-SGPR -> VALU-reads-it-as-a-mask wait the compiler otherwise pads with s_nop 1).
+__device__ __forceinline__ void relu_nan4(f32x4& v) {
+  float a = v[0], b = v[1], c = v[2], d = v[3];
+  unsigned long long m0, m1, m2, m3;
+  asm("v_cmp_nge_f32_e64 %4, 0, %0\n\tv_cmp_nge_f32_e64 %5, 0, %1\n\tv_cmp_nge_f32_e64 %6, 0, %2\n\tv_cmp_nge_f32_e64 %7, 0, %3\n\t"
+      "v_cndmask_b32_e64 %0, 0, %0, %4\n\tv_cndmask_b32_e64 %1, 0, %1, %5\n\tv_cndmask_b32_e64 %2, 0, %2, %6\n\tv_cndmask_b32_e64 %3, 0, %3, %7"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3));
+  v = f32x4{a, b, c, d};
+}
 __device__ __forceinline__ float absmax4(float m, const f32x4 v) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }

@@ -609,12 +609,12 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
         for (int i = 0; i < 8; ++i)
           U[i] *= dropout_mult4(drop_seed, drop_off, (uint32_t)L.drop_id, (uint32_t)grow_of(i), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
       }
-      if (L.relu & 1) {      // (v_cmp_nle + v_cndmask per value: a NaN stays a NaN as under nn.ReLU -- v_max_f32(NaN, 0) is 0; round 5's
-                             //  one-instruction `v_max_f32 0, x` turned a NaN weight into a finite loss, dss2_common.hpp relu_nan)
+      if (L.relu & 1) {      // (v_cmp_nge + v_cndmask per value: a NaN stays a NaN as under nn.ReLU -- v_max_f32(NaN, 0) is 0; round 5's
+                             //  one-instruction `v_max_f32 0, x` turned a NaN weight into a finite loss, dss2_common.hpp relu_nan.
+                             //  Four compares, then their four selects: left to itself the compiler pairs every v_cmp (VCC) with its
+                             //  v_cndmask behind an `s_nop 1` -- a third issue slot per value, 32 per layer and wave)
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) U[i][q] = relu_nan(U[i][q]);
+        for (int i = 0; i < 8; ++i) relu_nan4(U[i]);
       }
       if (gbits) {
 #pragma unroll
@@ -643,11 +643,28 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
     }
     if (L.y_bits) {      // (uniform) the sign bits of what went to Y, in the layout the data-gradient form reads (pad rows / columns: zero bits)
       uint32_t word = 0u;
+      if ((L.relu & 1) && !has_add) {
+        // behind a ReLU (and no residual) a stored value is +0, positive or NaN: "open" = its bit pattern is not zero -- v_min_u32 +
+        // v_lshl_or_b32 per value instead of compare, select and or; NaN counts as open, as in relu_open (torch's threshold_backward)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const bool in_y = col_ok && rowv + 8 * i < R;
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) word |= ((in_y && relu_open(U[i][q])) ? 1u : 0u) << (4 * i + q);
+          for (int q = 0; q < 4; ++q) {      // (asm: the compiler rewrites umin(x, 1) as x != 0 -- compare, s_nop, select -- again)
+            uint32_t t;
+            asm("v_min_u32 %0, 1, %1" : "=v"(t) : "v"(__float_as_uint(U[i][q])));
+            word |= t << (4 * i + q);
+          }
+        uint32_t valid = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) valid |= (col_ok && rowv + 8 * i < R) ? (0xFu << (4 * i)) : 0u;
+        word &= valid;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool in_y = col_ok && rowv + 8 * i < R;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) word |= ((in_y && relu_open(U[i][q])) ? 1u : 0u) << (4 * i + q);
+        }
       }
       reinterpret_cast<uint32_t*>(L.y_bits)[((size_t)tile * ncg + cg) * 64 + lane] = word;
     }

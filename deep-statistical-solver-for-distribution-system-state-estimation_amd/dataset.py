@@ -244,29 +244,32 @@ class MixedDataset:
         rng = rng or np.random.default_rng()
         return MixedDataset(self.parts, rng.permutation(self.ids))
 
-    _RING = 8
+    _RING_MAX = 64
 
     def _upload(self, tab: np.ndarray, dev) -> torch.Tensor:
         """Host -> device copy of a small index table through a RING of pinned staging buffers owned by the dataset.  (``pin_memory()``
-        per batch asks torch's pinned allocator for a block whose previous copy has completed; one batch ahead on a side stream
-        (PrefetchLoader) that copy is still queued behind a whole step, so every batch paid a fresh hipHostMalloc -- ~1.4 ms of host
-        time, round 6.)  A slot is reused _RING uploads later; its event is waited for only if that copy has still not run."""
-        ring = self.__dict__.setdefault("_ring", {"slots": [], "next": 0})
-        if not ring["slots"]:
-            ring["slots"] = [[None, None] for _ in range(self._RING)]
-        i = ring["next"]
-        ring["next"] = (i + 1) % self._RING
-        buf, ev = ring["slots"][i]
-        if buf is None or buf.numel() < tab.size:
-            buf = torch.empty(max(tab.size, 3 * 4096), dtype=torch.int64).pin_memory()
-            ev = torch.cuda.Event()
-        elif not ev.query():
-            ev.synchronize()
+        per batch asks torch's pinned allocator for a block whose previous copy has completed; when the host runs a step or more ahead
+        of the GPU -- always, one batch ahead on a side stream -- that copy is still queued and every batch paid a fresh hipHostMalloc:
+        ~1.4 ms of host time, round 6.)  The oldest slot is reused if its copy has run; otherwise the ring grows by one slot (the host
+        never waits for the GPU here; the ring stops growing once it is as deep as the host's lead, _RING_MAX at most)."""
+        ring = self.__dict__.setdefault("_ring", [])
+        need = max(tab.size, 3 * 4096)
+        slot = None
+        if ring and ring[0][1].query() and ring[0][0].numel() >= tab.size:
+            slot = ring.pop(0)
+        elif len(ring) >= self._RING_MAX:
+            slot = ring.pop(0)
+            slot[1].synchronize()
+            if slot[0].numel() < tab.size:
+                slot = None
+        if slot is None:
+            slot = [torch.empty(need, dtype=torch.int64).pin_memory(), torch.cuda.Event()]
+        buf, ev = slot
         stage = buf[:tab.size].view(tab.shape)
         stage.copy_(torch.from_numpy(tab))
         out = stage.to(dev, non_blocking=True)
         ev.record(torch.cuda.current_stream(dev))
-        ring["slots"][i] = [buf, ev]
+        ring.append(slot)
         return out
 
     def collate(self, ids: np.ndarray) -> Batch:

@@ -3,11 +3,14 @@
   (b) the CPU oracle on the same seeded inputs (fp32, plus an fp64 referee where noted).
 Tolerances (max-normalised relative error, BASELINE.json north_star: 1e-5 on node states and loss):
   outputs 1e-5, loss 1e-5; gradients 1e-4 (the reference's own fp32-vs-fp64 gradient noise is 2e-5)."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import CASES, LOSS_CASES, case_batch, case_grads, case_state_dict, golden, load_pkg, rel_err, t
+from conftest import ROOT, CASES, LOSS_CASES, case_batch, case_grads, case_state_dict, golden, load_pkg, rel_err, t
 
 pytestmark = pytest.mark.gpu
 TOL_OUT, TOL_LOSS, TOL_GRAD = 1e-5, 1e-5, 1e-4
@@ -310,6 +313,26 @@ def test_baseline_configs_against_oracle(pkg, oracle, grids, B, hid, L):
     assert n_flip <= max(2, 1e-5 * n_gate), (n_flip, n_gate)
     assert rel_err(out_m, out64) < TOL_OUT
     assert abs(loss_m.item() - loss64.item()) <= TOL_LOSS * abs(loss64.item())
+    # ---- the plain numbers, for a reader who does not want to audit the referee above: the fp64 oracle with
+    # NOTHING pinned, and the worst parameter gradient against each of the three references -- logged per configuration
+    # (gpurun_out/parity_errors.jsonl; the committed copy: profiles/r06_parity_errors.jsonl) and held to the un-pinned tolerance
+    ref64u = type(ref)(8, 6, 2, hid, L, 2, 0.0).double()
+    ref64u.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+    out64u, loss64u = oracle.train_step(ref64u, {"x": x64, "edge_index": b["edge_index"], "edge_attr": ea64}, st64)
+    worst = {"fp32_oracle_unpinned": max((rel_err(p.grad, q.grad), n) for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters())),
+             "fp64_oracle_unpinned": max((rel_err(p.grad, q.grad), n) for (n, p), (_, q) in zip(mine.named_parameters(), ref64u.named_parameters())),
+             "fp64_referee_on_the_kernels_own_gates": max((rel_err(p.grad, q.grad), n) for (n, p), (_, q) in zip(mine.named_parameters(), ref64.named_parameters()))}
+    rec = {"config": f"{'+'.join(grids)} B={B} H={hid} L={L}", "nodes": int(out_m.shape[0]), "output_vs_fp64": rel_err(out_m, out64u),
+           "loss_vs_fp64": abs(loss_m.item() - loss64u.item()) / abs(loss64u.item()), "flipped_conv_gates": [n_flip, n_gate],
+           "worst_gradient": {k: {"error": v[0], "parameter": v[1]} for k, v in worst.items()}, "tol_unpinned": tol_unpinned}
+    print("[parity]", json.dumps(rec))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_errors.jsonl"), "a") as fh:
+            fh.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    assert worst["fp64_oracle_unpinned"][0] < tol_unpinned, worst["fp64_oracle_unpinned"]
     for (n, p), (_, q64) in zip(mine.named_parameters(), ref64.named_parameters()):
         e = rel_err(p.grad, q64.grad)
         if e < 1e-5:

@@ -12,6 +12,26 @@ stamp scripts folded into one).  Each needs a diagnostic build of the library wi
     wgrad     DSS2_STAMPS         wgrad_kernel<2,3,4> (args: grid, graphs, hidden width)
     wgradh    DSS2_STAMPS         wgrad16h_kernel (f16x3, 32-row tiles; args: grid, graphs)
 """
+
+def _refuse_a_stale_diagnostic_library():
+    """The stamp profiles must describe HEAD: tools/build_diag_libs.sh leaves the hash of every source it compiled beside the diagnostic
+    libraries (tools/diag_lib/SOURCES.sha256); a library (DSS2_LIB) under tools/diag_lib/ whose sources have changed since is refused."""
+    import glob, hashlib, os, sys
+    lib = os.environ.get("DSS2_LIB")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not lib or os.path.dirname(os.path.abspath(lib)) != os.path.join(root, "tools", "diag_lib"):
+        return
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "deep-*", "csrc", "*.h*")) + glob.glob(os.path.join(root, "include", "*.h"))):
+        h.update(open(f, "rb").read())
+    stamp = os.path.join(root, "tools", "diag_lib", "SOURCES.sha256")
+    have = open(stamp).read().strip() if os.path.exists(stamp) else "(none)"
+    if have != h.hexdigest():
+        sys.exit(f"tools/stamps.py: {lib} was not built from the sources as they are now: run tools/build_diag_libs.sh")
+
+
+_refuse_a_stale_diagnostic_library()
+
 import ctypes as C, importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
