@@ -870,9 +870,10 @@ static int dss2_edge_tile_fwd_paired_launch(const float* x, int64_t ldx, const f
   // The backward recomputes the ReLU gates, so forward and backward must run the same arithmetic.  dss2_edge_tile_bwd with U on 96-row
   // tiles runs the VALU tile kernel (neither matrix-pipe backward is built for it): a caller that announces such a backward gets the
   // VALU tile forward.
-  const bool valu_pair = bwd_with_u && (nrb == 3 || nrb == 6);
-  if (nrb == 6 && !valu_pair && edge_mfma_ok(h, 3, ell_width) && edge16_ok(h, 6, ell_width, false, false) && edge16_ok(h, 6, ell_width, true, false))
-    return launch_edge16(a, 6, ntiles, false, as_stream(stream));      // 192-row tiles: the bf16x6 kernels on two 96-row parts (both passes or neither)
+  const bool valu_pair = bwd_with_u && nrb >= 3;
+  const int part_nrb = nrb == 4 ? 2 : 3;      // 128- / 192-row tiles: the bf16x6 kernels on two parts of 64 / 96 rows (both passes or neither)
+  if ((nrb == 4 || nrb == 6) && !valu_pair && edge_mfma_ok(h, part_nrb, ell_width) && edge16_ok(h, nrb, ell_width, false, false) && edge16_ok(h, nrb, ell_width, true, false))
+    return launch_edge16(a, nrb, ntiles, false, as_stream(stream));
   if (edge_mfma_ok(h, nrb, ell_width) && !valu_pair) {
     // first Linear as bf16x6 on the bf16 matrix pipe (dss2_edge16.hip; DSS2_EDGE_BF16=0: the fp32 MFMA form below)
     if (edge16_ok(h, nrb, ell_width, false, false)) return launch_edge16(a, nrb, ntiles, false, as_stream(stream));
@@ -898,8 +899,9 @@ static int dss2_edge_tile_bwd_launch(const float* x, int64_t ldx, const float* e
   // n_slabs workgroups walk the tiles (the slab buffer holds one partial per workgroup)
   // (96-row tiles WITH the per-row sums U, the PFN inner-block case: that instantiation misses its register budget, so it is
   //  not compiled -- the VALU tile kernel below serves it)
-  if (!by_source && nrb == 6 && !U && edge_mfma_ok(h, 3, ell_width, true) && edge_mfma_ok(h, 3, ell_width) && edge16_ok(h, 6, ell_width, false, false) && edge16_ok(h, 6, ell_width, true, false))
-    return launch_edge16(a, 6, n_slabs < ntiles ? n_slabs : ntiles, true, as_stream(stream));
+  const int part_nrb = nrb == 4 ? 2 : 3;
+  if (!by_source && (nrb == 4 || nrb == 6) && !U && edge_mfma_ok(h, part_nrb, ell_width, true) && edge_mfma_ok(h, part_nrb, ell_width) && edge16_ok(h, nrb, ell_width, false, false) && edge16_ok(h, nrb, ell_width, true, false))
+    return launch_edge16(a, nrb, n_slabs < ntiles ? n_slabs : ntiles, true, as_stream(stream));
   if (!by_source && edge_mfma_ok(h, nrb, ell_width, true) && !(nrb == 3 && U)) {
     if (edge16_ok(h, nrb, ell_width, true, U != nullptr))      // (the recomputed gates come from the arithmetic of the bf16x6 forward)
       return launch_edge16(a, nrb, n_slabs < ntiles ? n_slabs : ntiles, true, as_stream(stream));

@@ -13,7 +13,7 @@
 //     ReLU removes it, and the epilogue is two vector instructions per element (max, add) with no validity lookups;
 //   * the split planes of every slot are built in ONE phase after the staging (each input element is split once per workgroup,
 //     16-byte row pieces: conflict-free b128 fragment reads without padding), so the slot loop of the forward has no barrier;
-//   * 192-row tiles (end of round 5) are walked as two PARTS of 96 rows by the 96-row instantiations: the whole tile's x rows are staged
+//   * 192-row tiles (end of round 5; round 6: 128-row tiles as two parts of 64 rows) are walked as two PARTS of 96 rows by the 96-row instantiations: the whole tile's x rows are staged
 //     for each part (x_j may be any of them), everything else is the part's own (EdgeTileArgs::parts / xtm, edge_stage_part).
 // The backward recomputes the pre-activation with the very same plane values, fragments and MFMA order -- its gates are bit for
 // bit the forward's -- and forms dW1 += dZ_k^T A_k, a contraction over the tile's rows, as bf16x6 too (see edge16_bwd_kernel).
@@ -454,9 +454,10 @@ bool edge16_ok(int h, int nrb, int D, bool bwd, bool with_u) {
   //  the backward recomputes the forward's gates)
   const char* env = getenv("DSS2_EDGE_BF16");
   if (env && atoi(env) == 0) return false;
-  if ((h & 31) || h > 256 || !(nrb == 1 || nrb == 2 || nrb == 3 || nrb == 6) || D < 1 || D > 32) return false;
+  if ((h & 31) || h > 256 || !(nrb == 1 || nrb == 2 || nrb == 3 || nrb == 4 || nrb == 6) || D < 1 || D > 32) return false;      // (no kernel of the library tiles at 160 rows)
   if (bwd && with_u && nrb >= 3) return false;      // (that instantiation misses its register budget, as in dss2_edge.hip)
-  const int tm = nrb == 6 ? 96 : nrb * 32;          // (192-row tiles: two parts of 96 rows, the whole tile's x rows staged for each)
+  // (128- / 192-row tiles: two parts of 64 / 96 rows, the whole tile's x rows staged for each)
+  const int tm = nrb == 4 ? 64 : (nrb == 6 ? 96 : nrb * 32);
   return (bwd ? e16_bwd_lds_bytes(tm, D, nrb * 32) : e16_lds_bytes(tm, D, nrb * 32)) <= (size_t)kMaxLdsBytes;
 }
 
@@ -492,9 +493,14 @@ int launch_edge16(const EdgeTileArgs& a, int nrb, int grid, bool bwd, hipStream_
   switch (nrb) {
     case 1: return launch16<1>(a, grid, bwd, s);
     case 2: return launch16<2>(a, grid, bwd, s);
+    case 4: {      // 128-row tiles as two parts of 64 rows (round 6; the VALU tile kernels before)
+      EdgeTileArgs b = a;
+      b.xtm = 128; b.parts = 2;
+      return launch16<2>(b, bwd ? grid : 2 * grid, bwd, s);
+    }
     case 6: {      // 192-row tiles as two parts of 96 rows each (the forward: one workgroup per part)
       EdgeTileArgs b = a;
-      b.xtm = 192; b.parts = 2;
+      b.xtm = 32 * nrb; b.parts = 2;
       return launch16<3>(b, bwd ? grid : 2 * grid, bwd, s);
     }
     default: return launch16<3>(a, grid, bwd, s);

@@ -81,18 +81,19 @@ def test_tagconv_fwd_bwd(pkg, oracle, grid, hin, hout, K):
         assert rel_err(a.weight.grad, bb.weight.grad) < TOL_GRAD
 
 
-@pytest.mark.parametrize("grid,hid,nrb", [("ober_sub", 128, None), ("ober_sub", 64, "4"), ("ober179", 128, None), ("ober179", 32, None),
-                                          ("cigre14+ober179", 128, "6")])
+@pytest.mark.parametrize("grid,hid,nrb", [("ober_sub", 128, None), ("ober_sub", 64, "4"), ("cigre14+ober_sub", 128, "4"), ("ober179", 128, None),
+                                          ("ober179", 32, None), ("cigre14+ober179", 128, "6")])
 def test_edge_aggregation_tall_tiles_without_input_gradient(pkg, oracle, grid, hid, nrb, monkeypatch):
     """The first block of a model: x needs no gradient, so the backward is the weight-gradient-only form: edge16_bwd_kernel
     without the per-row sums on 96-row tiles and -- as two PARTS of 96 rows each, end of round 5 -- on 192-row tiles (a 192-row
     instantiation had measured 132 + 68 us against 150 + 51 for the VALU tile kernels at the 179-bus shape; the parts: 81 + 45);
-    128-row tiles (forced) run the VALU tile kernels.  The mixed batch has tiles of CIGRE graphs only whose rows end inside the first
+    128-row tiles (forced: a 70-bus graph straddles the two parts of 64 rows) run as parts since round 6 (the VALU tile kernels before).  The mixed batch has tiles of CIGRE graphs only whose rows end inside the first
     part (the second part of such a tile is skipped) beside 179-bus tiles that fill both."""
     if nrb is not None:
         monkeypatch.setenv("DSS2_NRB", nrb)
     torch.manual_seed(5)
-    b = pkg.synthetic.make_batch(grid.split("+"), 7 if nrb is None else 9, seed=6)      # (another batch for the forced height: the structure cache is keyed by content)
+    # (another batch for every forced height: the structure cache is keyed by content)
+    b = pkg.synthetic.make_batch(grid.split("+"), 7 if nrb is None else {"4": 9, "6": 9}[nrb] + (1 if "+" in grid and nrb == "4" else 0), seed=6)
     x, ea = b["x"][:, :8], b["edge_attr"][:, :6]
     ei2, ea2 = oracle.undirect_graph(b["edge_index"], ea)
     ref = oracle.EdgeAggregation(8, 6, hid, hid).double()
@@ -106,7 +107,7 @@ def test_edge_aggregation_tall_tiles_without_input_gradient(pkg, oracle, grid, h
     outm.backward(g.to(DEV))
     topo_ = pkg.topology.get_topology(ei_dev, x.shape[0], double=False)
     assert topo_.nrb == (int(nrb) if nrb else (3 if grid == "ober_sub" else 6))
-    if "+" in grid:      # some tile ends inside its first 96 rows, some tile needs both parts
+    if "+" in grid and topo_.nrb == 6:      # some tile ends inside its first part, some tile needs both parts
         rows = (topo_.tile_start[1:] - topo_.tile_start[:-1]).cpu()
         assert int(rows.min()) <= 96 < int(rows.max()), rows.tolist()
     assert rel_err(outm, outr) < TOL_OUT

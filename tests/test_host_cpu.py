@@ -201,6 +201,12 @@ def test_no_kernel_in_the_library_spills_registers():
             # (its f16x3 form, MS = 2, has 40 fragment registers fewer: 8-12 values parked around the layer loop -- the folded layer's
             #  eight row-scale vectors requested together at the top of the epilogue and the per-column weight exponents)
             allowed[f"void dss2::gemm_chain_sp_kernel<3, {nw}, {hm}, 2>"] = 16
+    # (round 6: the tall-tile chain carries a sixth template argument, the number of ACTIVE row pieces per lane; the full-height
+    #  instantiations <.., 4 NRB> are the kernels named above, the reduced one -- <3, 3, ., ., true, 9> -- does not spill at all)
+    import re as _re
+    for key in [k for k in allowed if "gemm_chain_sp6_kernel<" in k]:
+        nrb_ = int(_re.search(r"kernel<(\d+),", key).group(1))
+        allowed[key[:-1] + f", {4 * nrb_}>"] = allowed[key]
     bad = [(fn, name, sp, scr) for fn, ks in results for name, sp, scr in ks
            if (sp or scr) and not (name.strip() in allowed and sp <= allowed[name.strip()])]
     assert not bad, bad
