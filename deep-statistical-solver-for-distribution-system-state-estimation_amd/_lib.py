@@ -199,6 +199,7 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dss2_gemm_prop": (C.c_int, [C.POINTER(GemmPropArgs), C.c_void_p]),
+    "dss2_chain_sp6_single_group_min_tiles": (C.c_int, []),
     "dss2_gemm_prop_chain": (C.c_int, [C.POINTER(GemmPropArgs), C.c_void_p, C.c_int, C.c_void_p]),
     "dss2_gemm_prop_chain_head": (C.c_int, [C.POINTER(GemmPropArgs), C.c_void_p, C.c_int, C.POINTER(ChainHead), C.c_void_p]),
     "dss2_gemm_prop_chain_head_supported": (C.c_int, [C.c_int] * 6),

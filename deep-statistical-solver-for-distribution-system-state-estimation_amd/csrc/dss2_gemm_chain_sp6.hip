@@ -559,12 +559,26 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
 
 static size_t chain_sp6_lds_bytes(int nrb, int ncg, int ell_width) { return (size_t)ncg * s6_region(nrb) * 4 + (size_t)32 * nrb * ell_width * 8 + 64; }      // (+ the f16x3 form's maxima)
 
+}  // namespace dss2
+extern "C" int dss2_chain_sp6_single_group_min_tiles(void) {
+  static const int v = [] { const char* e = getenv("DSS2_CHAIN_SP6_NCG1"); return (e ? atoi(e) : 1) ? 768 : -1; }();
+  return v;
+}
+namespace dss2 {
+
 bool chain_sp6_supported(const dss2_gemm_prop_args& a) {
   static const int on = [] { const char* e = getenv("DSS2_CHAIN_SP"); return e ? atoi(e) : 1; }();
   static const int f16on = [] { const char* e = getenv("DSS2_CHAIN_SP_F16"); return e ? atoi(e) : 1; }();
   if (a.b_format == 2 && !f16on) return false;
+  // (round 6: ONE column group -- dim_hid 32, the reference driver's model on 70-bus grids -- runs this form too, as single-wave
+  //  workgroups, seven of them per CU, where there are enough tiles to fill the chip that way: measured on the driver's model line,
+  //  2.47 -> 2.33 ms per step at 1024 tiles against the three-waves-per-column-group bf16x6 chain, but 1.55 -> 1.63 at 512 and 1.06 -> 1.15 ms at 64 tiles, where
+  //  a tile's latency is what counts.  A query (ntiles = 0) answers for the capability; the launch and the host's policy
+  //  (ops.py, dss2_chain_sp6_single_group_min_tiles) apply the tile count.  DSS2_CHAIN_SP6_NCG1=0: never)
+  if (a.ncg == 1 && (dss2_chain_sp6_single_group_min_tiles() < 0 || (a.ntiles > 0 && a.ntiles < dss2_chain_sp6_single_group_min_tiles()))) return false;
+  const int min_ncg = 1;
   return on && (a.b_format == 1 || a.b_format == 2) && (a.nrb == 6 || a.nrb == 3) && a.nmat >= 2 && a.nmat <= 3 && (a.kpad & 15) == 0 && a.kpad <= 32 * a.ncg &&
-         a.ncg >= 2 && a.ncg <= 4 && chain_sp6_lds_bytes(a.nrb, a.ncg, a.ell_width) <= (size_t)(a.nrb == 3 ? kMaxLdsBytes / 2 : kMaxLdsBytes);
+         a.ncg >= min_ncg && a.ncg <= 4 && chain_sp6_lds_bytes(a.nrb, a.ncg, a.ell_width) <= (size_t)(a.nrb == 3 ? kMaxLdsBytes / 2 : kMaxLdsBytes);
 }
 
 template <int NRB, int NMAT, int DIR, int HM = 0, bool F16 = false, int RPA = 4 * NRB>

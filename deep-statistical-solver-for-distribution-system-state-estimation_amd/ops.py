@@ -116,10 +116,22 @@ def chain_supported(topo: Topology, nmat: int, hid: int, transposed: bool, have1
         have16 and chain16_supported(topo, nmat, hid, transposed))
 
 
+def _single_group_tall_veto(topo: Topology, hid: int) -> bool:
+    """96- / 192-row tiles with ONE column group (hid <= 32): the split-plane chain runs them as single-wave workgroups, which pays from
+    dss2_chain_sp6_single_group_min_tiles() tiles on (the library applies the same count at launch); below it the block keeps the
+    multi-wave chain of that shape with its bf16x3 weights and fp32 gates, i.e. every sp6-only capability is declined here."""
+    if hid > 32 or topo.nrb not in (3, 6):
+        return False
+    m = int(_lib.lib().dss2_chain_sp6_single_group_min_tiles())
+    return m < 0 or topo.ntiles < m
+
+
 def chain_gate_words(topo: Topology, nmat: int, hid: int) -> int:
     """64-bit words per tile of a layer's sign-bit buffer (``y_bits`` of a forward chain -> ``gate_bits`` of the data-gradient
     chain over the same tiles); 0 where the chain kernel of this shape has no bit form (or either direction is not chained)."""
     if not (FL.CHAIN_LAYERS and FL.CHAIN_BF16 and FL.CHAIN_GATE_BITS) or topo.ell_tiles is None or topo.ellT_tiles is None:
+        return 0
+    if _single_group_tall_veto(topo, hid):
         return 0
     cache = topo.__dict__.setdefault("_gate_words", {})      # (asked once per forward: keep the two library calls off the step)
     gw = cache.get((nmat, hid))
@@ -151,6 +163,8 @@ def chain_head_supported(topo: Topology, nmat: int, hid: int, nout: int, transpo
     (dss2_gemm_prop_chain_head: forward = the head after the last chained layer, transposed = the chain's input computed from
     the head's upstream gradient); DSS2_CHAIN_HEAD=0 switches it off."""
     ell, tiles = (topo.ellT, topo.ellT_tiles) if transposed else (topo.ell, topo.ell_tiles)
+    if _single_group_tall_veto(topo, hid):
+        return False
     return bool(FL.CHAIN_HEAD) and FL.CHAIN_BF16 and tiles is not None and bool(      # (a mask of modes: bit 0 forward, bit 1 backward)
         _lib.lib().dss2_gemm_prop_chain_head_supported(topo.nrb, nmat, hid, hid, ell, nout) & (2 if transposed else 1))
 

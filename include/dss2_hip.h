@@ -278,6 +278,10 @@ typedef struct dss2_gemm_prop_args {
 } dss2_gemm_prop_args;
 
 int dss2_gemm_prop(const dss2_gemm_prop_args* args_host, void* stream);
+/* Policy constant shared with the host: 96- / 192-row tiles with ONE column group (hout <= 32) take the split-plane chain -- single-wave
+ * workgroups -- only from this many tiles on (a launch with fewer runs the multi-wave chain of that shape); -1: never
+ * (DSS2_CHAIN_SP6_NCG1=0).  The *_supported queries below answer for the capability, without a tile count. */
+int dss2_chain_sp6_single_group_min_tiles(void);
 
 /* ---- layer chain: n_layers (<= 8) H -> H layers of dss2_gemm_prop in ONE launch, the activation
  *      tile staying in LDS from layer to layer (tiles hold whole graphs, so a tile's next layer depends on that tile

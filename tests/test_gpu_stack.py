@@ -200,14 +200,16 @@ def test_whole_stack_full_batch_against_the_per_block_kernels(pkg, oracle):
         assert rel_err(g, g3) < 2e-4, n
 
 
-def test_driver_line_on_ober_sub_matches_the_oracle_on_the_per_block_kernels(pkg, oracle):
+@pytest.mark.parametrize("n_graphs", [64, 800])      # 800 tiles: the single-wave split-plane chain (f16x3) of one column group, round 6
+def test_driver_line_on_ober_sub_matches_the_oracle_on_the_per_block_kernels(pkg, oracle, n_graphs):
     """The reference driver's OTHER branch (/root/reference/dss2_run.py:51-53: Oberrhein, 70 buses) with the driver's model
     (dss2_run.py:72-88: SkipPFN dim_hid 32, 8 layers, K 2, dropout 0.3, L 5).  70-bus graphs need 96-row tiles, which the
     whole-stack kernels do not cover: the stack must run block by block -- one autograd node, in-kernel
     dropout, the layer chains of 96-row tiles -- and agree with the fp64 oracle on the very masks the kernels applied."""
     args = (8, 6, 2, 32, 8, 2, 0.3, 5)
     torch.manual_seed(0)
-    b = pkg.synthetic.make_batch(["ober_sub"], 64, seed=3)
+    b = pkg.synthetic.make_batch(["ober_sub"], n_graphs, seed=3)
+    single_wave = n_graphs >= int(pkg._lib.lib().dss2_chain_sp6_single_group_min_tiles()) > 0
     model = pkg.SkipPFN(*args).to(DEV)
     with torch.no_grad():
         for q in model.parameters():
@@ -216,11 +218,13 @@ def test_driver_line_on_ober_sub_matches_the_oracle_on_the_per_block_kernels(pkg
     torch.manual_seed(5)
     out, loss, grads, _ = _train(pkg, oracle, model, b)
     assert _train.gates is None and model.__dict__.get("_fused_plan") is None, "96-row tiles took the whole-stack kernels?"
+    assert bool(model.mpns[0]._plan.f16) == single_wave      # (from 768 tiles on the blocks' chains run as f16x3 on single-wave workgroups)
     ref, out64, l64, _ = _oracle_run(pkg, oracle, "SkipPFN", args, model, b)
     assert rel_err(out, out64) < 1e-5
     assert abs(loss.item() - l64.item()) <= 1e-5 * abs(l64.item())
     # conv gates NOT pinned here (40 gated layers deep): a razor-edge gate that falls the other way moves a gradient by ~1 / N_nodes
-    tol = max(2e-4, 8.0 / b["x"].shape[0])
+    # (the number of razor-edge gates grows with the batch as fast as one gate's weight shrinks: 72 M gates at 800 graphs, 2.1e-4 measured)
+    tol = max(2e-4 if n_graphs <= 64 else 4e-4, 8.0 / b["x"].shape[0])
     for (n, _), g, r in zip(model.named_parameters(), grads, ref.parameters()):
         assert rel_err(g, r.grad) < _tol(n, tol), (n, rel_err(g, r.grad))
     torch.manual_seed(5)      # bitwise reproducible on this route too
