@@ -51,6 +51,13 @@ PMC_GRID=ober_sub PMC_B=1024 bash tools/pmc_one.sh wgrad3 > $O/pmc_wgrad_tall_c3
 rm -rf $R/gpurun_out/pmc1_*
 python3 tools/driverline.py > $O/driverline.txt 2>&1
 python3 tools/collate_bench.py > $O/collate_bench.txt 2>&1
+# round 6: fresh mixed-topology batches (C5), non-finite semantics, power / clock under the step, the driver line on ober_sub, NaN bit patterns
+python3 tools/c5_fresh_probe.py 2>&1 | grep -v amdgpu > $O/c5_fresh_probe.txt
+python3 tools/nonfinite_probe.py 2>&1 | grep -v amdgpu > $O/nonfinite_probe.txt
+python3 tools/power_probe.py 2>&1 | grep -v amdgpu > $O/power_probe.txt
+python3 tools/ober_driverline.py 64 256 512 1024 2>&1 | grep "SkipPFN driver" > $O/ober_driverline.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-unused-result tools/micro/nan_bits.hip -o /tmp/nan_bits 2>/dev/null && /tmp/nan_bits > $O/nan_bits.txt 2>&1
+cp $R/gpurun_out/parity_errors.jsonl $O/ 2>/dev/null
 python3 tools/chainbench.py > $O/chainbench.txt 2>&1
 CHAINBENCH_BF16=0 CHAINBENCH_STEP=0 python3 tools/chainbench.py > $O/chainbench_fp32_mfma.txt 2>&1
 python3 tools/accuracy_bf16x6.py > $O/accuracy_bf16x6.txt 2>&1
