@@ -72,7 +72,7 @@ class EllBuildArgs(C.Structure):
                 ("tile_start", C.c_void_p), ("ntiles", C.c_int32), ("tm", C.c_int32), ("ell_width", C.c_int32),
                 ("ellT_width", C.c_int32),
                 ("ell_tiles", C.c_void_p), ("ell_ent_tiles", C.c_void_p), ("ellT_tiles", C.c_void_p),
-                ("ellT_ent_tiles", C.c_void_p), ("meta", C.c_void_p)]
+                ("ellT_ent_tiles", C.c_void_p), ("meta", C.c_void_p), ("uniform_rows", C.c_int32), ("n_nodes", C.c_int64)]
 
 
 class CsrAxpyArgs(C.Structure):
@@ -232,6 +232,8 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "dss2_masked_zscore_scratch_doubles": (C.c_int64, [C.c_int64]),
     "dss2_collate": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dss2_csr_build_graphs": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dss2_csr_build_graphs_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "dss2_collate_cursor": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "dss2_accum_scalar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dss2_collate_ragged": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),

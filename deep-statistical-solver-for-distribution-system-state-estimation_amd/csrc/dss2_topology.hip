@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256) topo_finalize_kernel(const BuildPtrs p, c
       scnt += __shfl_xor(scnt, o);
     }
     if ((threadIdx.x & 63) == 0) {      // (running extrema: read first, post an atomic only when it would change the word)
-      auto cur = [&](int i) { return __hip_atomic_load(p.meta + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+      auto cur = [&](int i) { return p.meta[i]; };
       if (mdeg > cur(0)) atomicMax(p.meta + 0, mdeg);
       if (mdegT > cur(1)) atomicMax(p.meta + 1, mdegT);
       if (scnt) {
@@ -344,16 +344,22 @@ struct EllArgs {
   const int32_t *rowptr[2], *col[2], *ent[2]; const float* w[2];
   int2 *ell_w[2], *ell_e[2]; int D[2];
   const int32_t* tile_start; int ntiles, TM; int32_t* meta;
+  int uniform_rows; long long N; int32_t* tile_start_w;      // (uniform_rows > 0: tile t = rows [t * uniform_rows, ..) and tile_start is WRITTEN here)
 };
 __global__ void __launch_bounds__(256) ell_tiles_kernel(const EllArgs a) {
   const int which = blockIdx.y, tile = blockIdx.x;
   const int D = a.D[which];
-  const int ts = a.tile_start[tile], R = a.tile_start[tile + 1] - ts;
+  int ts, R;
+  if (a.uniform_rows > 0) {      // tiles of equal-size graphs: closed form, and this launch also writes tile_start (dss2_tiles_uniform folded in)
+    const long long t0 = (long long)tile * a.uniform_rows, t1 = t0 + a.uniform_rows;
+    ts = (int)(t0 < a.N ? t0 : a.N); R = (int)(t1 < a.N ? t1 : a.N) - ts;
+    if (which == 0 && threadIdx.x == 0) { a.tile_start_w[tile] = ts; if (tile == a.ntiles - 1) a.tile_start_w[a.ntiles] = (int)a.N; }
+  } else { ts = a.tile_start[tile]; R = a.tile_start[tile + 1] - ts; }
   const int32_t* rp = a.rowptr[which];
-  if (threadIdx.x == 0) {      // (a running maximum: read first -- thousands of tiles hammering one word with atomics cost this launch 38 us at C5;
+  if (threadIdx.x == 0 && a.uniform_rows == 0) {      // (closed-form tilings take their entry bound from the hint: no statistic.  A running maximum: read first -- thousands of tiles hammering one word with atomics cost this launch 38 us at C5;
                                //  a stale read only costs a redundant atomic)
     const int nnz = rp[ts + R] - rp[ts];
-    if (nnz > __hip_atomic_load(a.meta + 6 + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.meta + 6 + which, nnz);
+    if (nnz > a.meta[6 + which]) atomicMax(a.meta + 6 + which, nnz);
   }
   if (D <= 0) return;
   int2* ow = a.ell_w[which] + (size_t)tile * D * a.TM;
@@ -393,6 +399,213 @@ __global__ void __launch_bounds__(256) deg_pows_init_kernel(const float* __restr
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
     v[r] = (double)deg[r];
     out[r * 4] = deg[r];
+  }
+}
+
+// ---- the whole CSR part in ONE launch for batches of equal-size graphs whose edge ranges are known (round 6) --------------------------
+// What dss2_csr_build does in 14 launches (count, three scans of the whole batch, cut positions, their running maximum, fill, finalize)
+// and dss2_deg_pows in 4 more is LOCAL to a graph once the graph's edge range [e0, e1) in the stored list is known: every global offset is
+// (1 or 2) * e0 plus a prefix sum over the graph's own <= 192 nodes.  The device loader knows that range (uniform samples: g * e; a mixed
+// batch: the prefix sum the host formed to lay the batch out), so a fresh batch -- BASELINE config C5: a new structure every step -- builds
+// its structure with ONE wave per graph: counts, prefix sums, slot claims, per-row order, gcn_norm weights, incidence lists, legal cuts,
+// statistics and the folded-bias row scales, all in LDS, same definitions and therefore the same bits as the general build.
+// (Assembly of a C5 batch: ~26 launches, 0.19 ms of kernels + their gaps -> 5; tests/test_gpu_topology.py compares the two builds.)
+struct GraphBuildArgs {
+  BuildPtrs p; FinalPtrs f; int32_t* efrom_w; int32_t* eto_w;      // (efrom / eto written here, read through f)
+  int32_t *rowptr, *rowptrT, *inc_rowptr, *lastcut;
+  const long long* edge_ptr; int n, e_uniform, emax; long long G;
+  float* deg_pows;      // [N][4] or NULL
+};
+
+// scans over a GROUP of W consecutive lanes (W = 16, 32 or 64: one graph per group)
+template <int W>
+__device__ __forceinline__ int group_excl_scan_add(int v, int sl) {
+  int s = v;
+#pragma unroll
+  for (int o = 1; o < W; o <<= 1) { const int t = __shfl_up(s, o, W); if (sl >= o) s += t; }
+  return s - v;
+}
+template <int W>
+__device__ __forceinline__ int group_incl_scan_max(int v, int sl) {
+#pragma unroll
+  for (int o = 1; o < W; o <<= 1) { const int t = __shfl_up(v, o, W); if (sl >= o) v = v > t ? v : t; }
+  return v;
+}
+
+// W lanes per graph: small graphs share a wave (15-bus graphs: four per wave -- with one graph per wave 15 of 64 lanes worked and the launch
+// was bound by instruction issue: 80 us for 4 096 graphs)
+template <int W>
+__global__ void __launch_bounds__(256) topo_build_graphs_kernel(const GraphBuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int32_t gsm[];
+  constexpr int GPW = 64 / W;                       // graphs per wave
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int sl = lane & (W - 1), gi = lane / W;     // lane inside its group, group inside the wave
+  const long long g = ((long long)blockIdx.x * 4 + wv) * GPW + gi;
+  const bool live = g < a.G;                        // (groups beyond the batch idle through the wave's steps: no early return, the syncs are wave-wide)
+  const int n = a.n, emax = a.emax;
+  const BuildPtrs& p = a.p;
+  const long long gg = live ? g : 0;
+  const long long e0 = a.edge_ptr ? a.edge_ptr[gg] : gg * a.e_uniform, e1 = a.edge_ptr ? a.edge_ptr[gg + 1] : (gg + 1) * (long long)a.e_uniform;
+  int ne = live ? (int)(e1 - e0) : 0;
+  const long long nb = gg * n;
+  const int dbl = p.doubled ? 2 : 1;
+  // per-group LDS: 11 arrays of n + 2 ints, three key arrays, the local endpoints, two double vectors
+  const int per_group = 11 * (n + 2) + 2 * (2 * emax) + 2 * emax + 2 * emax + 4 * (n + 2) + 2;
+  int32_t* w = gsm + (size_t)(wv * GPW + gi) * per_group;
+  int32_t *cnt = w, *cntT = cnt + (n + 2), *cntI = cntT + (n + 2), *cover = cntI + (n + 2), *cur = cover + (n + 2), *curT = cur + (n + 2),
+          *curI = curT + (n + 2), *rp = curI + (n + 2), *rpT = rp + (n + 2), *rpI = rpT + (n + 2), *cut = rpI + (n + 2);
+  int32_t *keys = cut + (n + 2), *keysT = keys + 2 * emax, *keysI = keysT + 2 * emax;
+  int32_t *ela = keysI + 2 * emax, *elb = ela + emax;      // the graph's stored edges, local endpoints: everything after the counting pass reads these
+  double* v0 = reinterpret_cast<double*>(elb + emax + ((size_t)(elb + emax) & 4 ? 1 : 0));      // (8-byte aligned)
+  double* v1 = v0 + n;
+  if (ne < 0 || ne > emax) { if (sl == 0) p.meta[5] = 1; ne = 0; }
+  for (int i = sl; i < 7 * (n + 2); i += W) cnt[i] = 0;      // cnt .. curI
+  wave_lds_sync();
+  // ---- counts (dss2_csr_build: topo_count_kernel)
+  for (int j = sl; j < ne; j += W) {
+    const long long A = p.ei[e0 + j], B = p.ei[p.E + e0 + j];
+    long long la = A - nb, lb = B - nb;
+    if (la < 0 || la >= n || lb < 0 || lb >= n) { p.meta[5] = 1; la = lb = 0; }      // an endpoint outside this graph's rows: the error flag (the arrays are then meaningless, not out of bounds)
+    a.efrom_w[e0 + j] = (int32_t)A;
+    a.eto_w[e0 + j] = (int32_t)B;
+    ela[j] = (int)la; elb[j] = (int)lb;
+    atomicAdd(cnt + lb, 1); atomicAdd(cntT + la, 1);
+    if (p.doubled) { atomicAdd(cnt + la, 1); atomicAdd(cntT + lb, 1); }
+    atomicAdd(cntI + la, 1); atomicAdd(cntI + lb, 1);
+    const int lo = (int)(la < lb ? la : lb), hi = (int)(la < lb ? lb : la);
+    atomicAdd(cover + lo + 1, 1); atomicAdd(cover + hi + 1, -1);
+  }
+  wave_lds_sync();
+  // ---- exclusive sums over the graph's nodes (chunks of W with running carries), global offsets added where they are stored
+  {
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int base = 0; base <= n + 1; base += W) {      // (uniform trip count: n is the same for every group)
+      const int i = base + sl;
+      const int x0 = i <= n ? cnt[i] : 0, x1 = i <= n ? cntT[i] : 0, x2 = i <= n ? cntI[i] : 0, x3 = i <= n + 1 ? cover[i] : 0;
+      const int s0 = group_excl_scan_add<W>(x0, sl) + c0, s1 = group_excl_scan_add<W>(x1, sl) + c1, s2 = group_excl_scan_add<W>(x2, sl) + c2,
+                s3 = group_excl_scan_add<W>(x3, sl) + c3;
+      // sum of cover[0 .. q] = number of edges with lo < q <= hi; a cut before local row q is legal iff that is 0 (or q = 0 / q = n)
+      if (i <= n) { rp[i] = s0; rpT[i] = s1; rpI[i] = s2; cut[i] = (i == 0 || i == n || s3 + x3 == 0) ? i : -1; }
+      c0 = __shfl(s0 + x0, W - 1, W); c1 = __shfl(s1 + x1, W - 1, W); c2 = __shfl(s2 + x2, W - 1, W); c3 = __shfl(s3 + x3, W - 1, W);
+    }
+  }
+  wave_lds_sync();
+  if (live) {
+    const int32_t b2 = (int32_t)(dbl * e0), bI = (int32_t)(2 * e0);
+    for (int i = sl; i <= n; i += W) { a.rowptr[nb + i] = b2 + rp[i]; a.rowptrT[nb + i] = b2 + rpT[i]; a.inc_rowptr[nb + i] = bI + rpI[i]; }
+  }
+  // ---- legal cuts: running maximum inside the graph (its first row is always one)
+  {
+    int carry = 0;
+    for (int base = 0; base <= n; base += W) {
+      const int q = base + sl;
+      int v = q <= n ? cut[q] : -1;
+      v = group_incl_scan_max<W>(v, sl);
+      v = v > carry ? v : carry;
+      if (q <= n) { if (live) a.lastcut[nb + q] = (int32_t)(nb + v); cut[q] = v; }
+      carry = __shfl(v, W - 1, W);
+    }
+  }
+  // ---- slot claims (topo_fill_kernel): keys hold GLOBAL directed edge ids
+  for (int j = sl; j < ne; j += W) {
+    const int la = ela[j], lb = elb[j];
+    const int32_t d = (int32_t)(e0 + j);
+    keys[rp[lb] + atomicAdd(cur + lb, 1)] = d;
+    keysT[rpT[la] + atomicAdd(curT + la, 1)] = d;
+    if (p.doubled) {
+      keys[rp[la] + atomicAdd(cur + la, 1)] = (int32_t)(p.E + d);
+      keysT[rpT[lb] + atomicAdd(curT + lb, 1)] = (int32_t)(p.E + d);
+    }
+    keysI[rpI[la] + atomicAdd(curI + la, 1)] = d;
+    keysI[rpI[lb] + atomicAdd(curI + lb, 1)] = (int32_t)((uint32_t)d | kFlip);
+  }
+  wave_lds_sync();
+  // 1 / sqrt(in-degree) of every node of the graph, once (two correctly rounded operations each; the slot counters are dead: their space)
+  float* isd = reinterpret_cast<float*>(cur);
+  for (int r = sl; r < n; r += W) isd[r] = inv_sqrt_deg(rp[r + 1] - rp[r]);
+  wave_lds_sync();
+  // ---- per-row order and the final arrays (topo_finalize_kernel)
+  int mdeg = 0, mdegT = 0, smax = 0, smin = 0x7fffffff, scnt = 0;
+  const FinalPtrs& f = a.f;
+  if (live) {
+    for (int r = sl; r < n; r += W) {
+      const int32_t b2 = (int32_t)(dbl * e0);
+#pragma unroll 1
+      for (int which = 0; which < 2; ++which) {
+        const int32_t* rpp = which == 0 ? rp : rpT;
+        int32_t* kk = which == 0 ? keys : keysT;
+        const int l0 = rpp[r], cntr = rpp[r + 1] - l0;
+        sort_row(kk + l0, cntr);
+        for (int k = 0; k < cntr; ++k) {
+          const int d = kk[l0 + k];
+          const bool flip = d >= p.E;
+          const int e = flip ? d - (int)p.E : d;
+          const int A = ela[e - (int)e0], B = elb[e - (int)e0];
+          const int ls = flip ? B : A, lt = flip ? A : B;
+          const int src = (int)nb + ls, tgt = (int)nb + lt;
+          // gcn_norm(add_self_loops=False): in-degree on the (doubled) directed list, both CSRs carry the same weight
+          const float wv_ = __fmul_rn(isd[ls], isd[lt]);
+          const int en = (int)((uint32_t)e | ((flip && !p.no_flip) ? kFlip : 0u));
+          const int o = b2 + l0 + k;
+          if (which == 0) { f.col[o] = src; f.ent[o] = en; f.perm[o] = d; f.w[o] = wv_; }
+          else { f.colT[o] = tgt; f.entT[o] = en; f.permT[o] = d; f.wT[o] = wv_; }
+        }
+      }
+      const int i0 = rpI[r], ni = rpI[r + 1] - i0;
+      sort_row(keysI + i0, ni);
+      for (int k = 0; k < ni; ++k) f.inc_ent[2 * e0 + i0 + k] = keysI[i0 + k];
+      const int dg = rp[r + 1] - rp[r];
+      f.deg[nb + r] = (float)dg;
+      mdeg = max(mdeg, dg);
+      mdegT = max(mdegT, rpT[r + 1] - rpT[r]);
+      const int q = r + 1;                         // a legal cut at q closes the segment [lastcut[q - 1], q)
+      if (cut[q] == q) { const int len = q - cut[q - 1]; smax = max(smax, len); smin = min(smin, len); ++scnt; }
+    }
+  }
+  int nlive = live && sl == 0 ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) {
+    mdeg = max(mdeg, __shfl_xor(mdeg, o)); mdegT = max(mdegT, __shfl_xor(mdegT, o));
+    smax = max(smax, __shfl_xor(smax, o)); smin = min(smin, __shfl_xor(smin, o)); scnt += __shfl_xor(scnt, o); nlive += __shfl_xor(nlive, o);
+  }
+  if (lane == 0) {
+    // (PLAIN loads: an agent-scope atomic load of one word from thousands of waves is served as slowly as an atomic -- 36 us for 4 096
+    //  of them in ell_tiles_kernel, round 6; a stale value only costs a redundant atomic)
+    auto curm = [&](int i) { return p.meta[i]; };
+    if (mdeg > curm(0)) atomicMax(p.meta + 0, mdeg);
+    if (mdegT > curm(1)) atomicMax(p.meta + 1, mdegT);
+    if (scnt) {
+      if (smax > curm(2)) atomicMax(p.meta + 2, smax);
+      if (smin < curm(4)) atomicMin(p.meta + 4, smin);
+    }
+    // the number of segments: every graph has at least one (its rows end at a legal cut), so the wave of graph 0 posts G for all of them and a
+    // wave posts only what its graphs have beyond one each -- thousands of same-address atomic adds, one per graph, cost this launch 200 us
+    if (blockIdx.x == 0 && wv == 0) atomicAdd(p.meta + 3, (int)a.G);
+    if (scnt > nlive) atomicAdd(p.meta + 3, scnt - nlive);
+  }
+  // ---- [deg, A deg, A^2 deg, A^3 deg] in float64 (dss2_deg_pows), CSR by target, in the order just written
+  if (a.deg_pows) {
+    wave_lds_sync();      // (the sorted keys of every row are in LDS)
+    for (int r = sl; r < n; r += W) { const float dg = (float)(rp[r + 1] - rp[r]); v0[r] = (double)dg; if (live) a.deg_pows[(nb + r) * 4] = dg; }
+    wave_lds_sync();
+    for (int m = 1; m < 4; ++m) {
+      for (int r = sl; r < n; r += W) {
+        double sacc = 0.0;
+        const int l0 = rp[r], cntr = rp[r + 1] - l0;
+        for (int k = 0; k < cntr; ++k) {
+          const int d = keys[l0 + k];
+          const bool flip = d >= p.E;
+          const int e = flip ? d - (int)p.E : d;
+          const int A = ela[e - (int)e0], B = elb[e - (int)e0];
+          const int ls = flip ? B : A, lt = flip ? A : B;
+          const float wv_ = __fmul_rn(isd[ls], isd[lt]);
+          sacc = __dadd_rn(sacc, __dmul_rn((double)wv_, v0[ls]));
+        }
+        v1[r] = sacc;
+        if (live) a.deg_pows[(nb + r) * 4 + m] = (float)sacc;
+      }
+      wave_lds_sync();
+      double* t = v0; v0 = v1; v1 = t;
+    }
   }
 }
 
@@ -485,6 +698,48 @@ extern "C" int dss2_csr_build(const dss2_csr_build_args* ap, void* stream) {
   return check_launch("csr_build");
 }
 
+static int graphs_group_width(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : 64); }
+static size_t graphs_lds_bytes(int n, int emax) {
+  const int gpw = 64 / graphs_group_width(n);
+  return ((size_t)4 * gpw * (11 * (n + 2) + 2 * (2 * emax) + 2 * emax + 2 * emax + 4 * (n + 2) + 2) + 8) * 4;
+}
+
+extern "C" int dss2_csr_build_graphs_supported(int32_t nodes_per_graph, int32_t max_edges_per_graph) {
+  return nodes_per_graph >= 1 && nodes_per_graph <= 192 && max_edges_per_graph >= 1 && max_edges_per_graph <= 1024 &&
+         graphs_lds_bytes(nodes_per_graph, max_edges_per_graph) <= (size_t)kMaxLdsBytes / 2;
+}
+
+extern "C" int dss2_csr_build_graphs(const dss2_csr_build_args* ap, int32_t nodes_per_graph, const int64_t* edge_ptr, int32_t edges_per_graph,
+                                     int32_t max_edges_per_graph, float* deg_pows, void* stream) {
+  DSS2_NOT_IN_PLAN("dss2_csr_build_graphs");
+  if (!ap) { set_error("csr_build_graphs: null argument"); return 2; }
+  const dss2_csr_build_args& a = *ap;
+  if (a.n_edges <= 0 || a.n_nodes <= 0 || nodes_per_graph <= 0 || a.n_nodes % nodes_per_graph) { set_error("csr_build_graphs: a batch of whole graphs of nodes_per_graph rows expected"); return 2; }
+  if (!dss2_csr_build_graphs_supported(nodes_per_graph, max_edges_per_graph)) { set_error("csr_build_graphs: graphs of %d nodes / %d edges are beyond this build (use dss2_csr_build)", nodes_per_graph, max_edges_per_graph); return 2; }
+  if (!edge_ptr && (edges_per_graph <= 0 || (int64_t)edges_per_graph * (a.n_nodes / nodes_per_graph) != a.n_edges)) { set_error("csr_build_graphs: uniform edges_per_graph does not match n_edges"); return 2; }
+  if (!a.edge_index || !a.rowptr || !a.col || !a.ent || !a.perm || !a.w || !a.rowptrT || !a.colT || !a.entT || !a.permT || !a.wT ||
+      !a.inc_rowptr || !a.inc_ent || !a.efrom || !a.eto || !a.deg || !a.lastcut || !a.meta) { set_error("csr_build_graphs: null argument"); return 2; }
+  hipStream_t s = as_stream(stream);
+  GraphBuildArgs g = {};
+  g.p.ei = a.edge_index; g.p.E = a.n_edges; g.p.N = a.n_nodes; g.p.E2 = a.doubled ? 2 * a.n_edges : a.n_edges; g.p.doubled = a.doubled ? 1 : 0;
+  g.p.no_flip = a.no_flip ? 1 : 0; g.p.meta = a.meta;
+  g.f.col = a.col; g.f.ent = a.ent; g.f.perm = a.perm; g.f.w = a.w; g.f.colT = a.colT; g.f.entT = a.entT; g.f.permT = a.permT; g.f.wT = a.wT;
+  g.f.inc_ent = a.inc_ent; g.f.deg = a.deg;
+  g.efrom_w = a.efrom; g.eto_w = a.eto; g.rowptr = a.rowptr; g.rowptrT = a.rowptrT; g.inc_rowptr = a.inc_rowptr; g.lastcut = a.lastcut;
+  g.edge_ptr = reinterpret_cast<const long long*>(edge_ptr); g.n = nodes_per_graph; g.e_uniform = edges_per_graph; g.emax = max_edges_per_graph;
+  g.G = a.n_nodes / nodes_per_graph; g.deg_pows = deg_pows;
+  hipLaunchKernelGGL(meta_init_kernel, dim3(1), dim3(64), 0, s, a.meta);
+  const int W = graphs_group_width(nodes_per_graph), per_wg = 4 * (64 / W);
+  const unsigned grid = (unsigned)((g.G + per_wg - 1) / per_wg);
+  const size_t lds = graphs_lds_bytes(nodes_per_graph, max_edges_per_graph);
+#define DSS2_GRAPHS(WW) { static std::atomic<uint32_t> lds_done{0}; \
+    if (ensure_max_lds(reinterpret_cast<const void*>(topo_build_graphs_kernel<WW>), lds_done, "csr_build_graphs")) return 1; \
+    hipLaunchKernelGGL(topo_build_graphs_kernel<WW>, dim3(grid), dim3(256), lds, s, g); }
+  if (W == 16) DSS2_GRAPHS(16) else if (W == 32) DSS2_GRAPHS(32) else DSS2_GRAPHS(64)
+#undef DSS2_GRAPHS
+  return check_launch("csr_build_graphs");
+}
+
 extern "C" int dss2_tiles_uniform(int32_t* tile_start, int32_t ntiles, int32_t rows_per_tile, int64_t n_nodes, void* stream) {
   DSS2_NOT_IN_PLAN("dss2_tiles_uniform");
   if (ntiles <= 0 || rows_per_tile <= 0) { set_error("tiles_uniform: bad arguments"); return 2; }
@@ -515,6 +770,10 @@ extern "C" int dss2_ell_tiles_build(const dss2_ell_build_args* ap, void* stream)
   a.ell_w[1] = reinterpret_cast<int2*>(b.ellT_tiles); a.ell_e[1] = reinterpret_cast<int2*>(b.ellT_ent_tiles);
   a.D[0] = b.ell_width; a.D[1] = b.ellT_width;
   a.tile_start = b.tile_start; a.ntiles = b.ntiles; a.TM = b.tm; a.meta = b.meta;
+  a.uniform_rows = b.uniform_rows; a.N = b.n_nodes; a.tile_start_w = const_cast<int32_t*>(b.tile_start);
+  if (b.uniform_rows < 0 || (b.uniform_rows > 0 && (b.n_nodes <= 0 || b.uniform_rows > b.tm || (int64_t)b.uniform_rows * b.ntiles < b.n_nodes))) {
+    set_error("ell_tiles_build: uniform_rows / n_nodes do not describe ntiles tiles of <= tm rows"); return 2;
+  }
   if ((a.D[0] > 0 && (!a.ell_w[0] || !a.ell_e[0])) || (a.D[1] > 0 && (!a.ell_w[1] || !a.ell_e[1]))) { set_error("ell_tiles_build: null output"); return 2; }
   hipLaunchKernelGGL(ell_tiles_kernel, dim3(b.ntiles, 2), dim3(256), 0, as_stream(stream), a);
   return check_launch("ell_tiles_build");

@@ -100,7 +100,7 @@ class DeviceDataset:
         d = self.directed if (self._sample_directed is None or first_sample is None) else bool(self._sample_directed[first_sample])
         return _topology.TopologyHint(directed=d, nodes_per_graph=self.n,
                                       max_degree=self.max_degree_doubled if d else self.max_degree_asis,
-                                      max_edges_per_graph=self.e)
+                                      max_edges_per_graph=self.e, edges_per_graph=self.e)
 
     @property
     def device(self):
@@ -308,11 +308,13 @@ class MixedDataset:
             return Batch(x, ei, ea, y, B)
         n = self.n
         first = self.parts[int(part[0])]
+        # (the batch's own prefix sum of the graphs' edge counts: with it the structure is one launch, a wave per graph)
+        edge_ptr = self._upload(edge_off.reshape(1, -1), dev).reshape(-1)
+        directed = first.hint(int(ids[0] - self.start[part[0]])).directed
         hint = _topology.TopologyHint(
-            directed=first.hint(int(ids[0] - self.start[part[0]])).directed, nodes_per_graph=n,
-            max_degree=max(p.max_degree_doubled for p in self.parts), max_edges_per_graph=max(p.e for p in self.parts))
-        if not hint.directed:
-            hint = _topology.TopologyHint(False, n, max(p.max_degree_asis for p in self.parts), hint.max_edges_per_graph)
+            directed=directed, nodes_per_graph=n,
+            max_degree=max((p.max_degree_doubled if directed else p.max_degree_asis) for p in self.parts),
+            max_edges_per_graph=max(p.e for p in self.parts), edge_ptr=edge_ptr)
         _topology.register_topology(ei, B * n, _topology.Topology(ei, B * n, hint=hint))
         return Batch(x, ei, ea, y, B)
 

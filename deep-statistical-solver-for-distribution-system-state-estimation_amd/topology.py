@@ -47,6 +47,11 @@ class TopologyHint:
     nodes_per_graph: int         # every graph of the batch has this many nodes, in consecutive rows
     max_degree: int              # upper bound of the in- and out-degree on the directed (doubled) list
     max_edges_per_graph: int     # upper bound of the stored edges of one graph
+    # round 6: where the graphs' ranges in the stored edge list are known too, the whole CSR part (and the folded-bias row scales) is ONE
+    # launch, a wave per graph (dss2_csr_build_graphs): edges_per_graph (every graph has this many, in graph order) or edge_ptr (device int64
+    # [G + 1], the batch's own prefix sum of the graphs' edge counts); neither: the general build (global scans)
+    edges_per_graph: int = 0
+    edge_ptr: Optional[torch.Tensor] = None
 
 
 def _stream(dev) -> int:
@@ -113,7 +118,10 @@ class Topology:
             d[name] = chunk[:n] if n != chunk.numel() else chunk
         for name in ("w", "wT", "deg"):
             d[name] = d[name].view(torch.float32)
-        work = torch.empty(int(L.dss2_csr_build_work_ints(N, E, int(self.directed))), dtype=torch.int32, device=dev)
+        graphs = (hint is not None and (hint.edges_per_graph > 0 or hint.edge_ptr is not None) and N % hint.nodes_per_graph == 0
+                  and os.environ.get("DSS2_TOPO_GRAPHS", "1") != "0"
+                  and bool(L.dss2_csr_build_graphs_supported(hint.nodes_per_graph, hint.max_edges_per_graph)))
+        work = None if graphs else torch.empty(int(L.dss2_csr_build_work_ints(N, E, int(self.directed))), dtype=torch.int32, device=dev)
         a = _lib.CsrBuildArgs()
         a.edge_index, a.n_edges, a.n_nodes, a.doubled = ei.data_ptr(), E, N, int(self.directed)
         a.no_flip = int(not flip)
@@ -122,10 +130,20 @@ class Topology:
         for (name, _), pn in zip(sizes, padded):
             setattr(a, name.lstrip("_"), base + 4 * off)
             off += pn
-        a.work = work.data_ptr()
-        _lib.check(L.dss2_csr_build(C.byref(a), _stream(dev)), "dss2_csr_build")
-        self._keep = (ei,)            # the build reads edge_index asynchronously
         self._deg_pows = None
+        if graphs:
+            # one wave per graph: every array above AND the [N, 4] folded-bias row scales (deg_pows) in one launch
+            dp = torch.empty(N, 4, dtype=torch.float32, device=dev)
+            ep = hint.edge_ptr
+            _lib.check(L.dss2_csr_build_graphs(C.byref(a), hint.nodes_per_graph, (ep.data_ptr() if ep is not None else None),
+                                               int(hint.edges_per_graph), int(hint.max_edges_per_graph), dp.data_ptr(), _stream(dev)),
+                       "dss2_csr_build_graphs")
+            self._deg_pows = dp
+            self._keep = (ei, ep)
+        else:
+            a.work = work.data_ptr()
+            _lib.check(L.dss2_csr_build(C.byref(a), _stream(dev)), "dss2_csr_build")
+            self._keep = (ei,)            # the build reads edge_index asynchronously
         self._stats = None
         self._tiles_built = False
 
@@ -181,8 +199,11 @@ class Topology:
         hint = self.hint
         # an alternate tiling works on a copy of the statistics words (the walk and the ELL build write per-tiling maxima
         # into them): the primary tiling's statistics stay what they were
-        meta = self._meta if store else self._meta.clone()
-        if not store:
+        # (closed-form tilings -- a hint with uniform graphs -- write no statistics: the ELL launch only raises the error flag, which may as
+        #  well be the primary's; no copy, no fill: two launches less per alternate tiling of a fresh batch, round 6)
+        closed_form = hint is not None and N % hint.nodes_per_graph == 0
+        meta = self._meta if (store or closed_form) else self._meta.clone()
+        if not store and not closed_form:
             meta[5:8].zero_()      # (error flag and per-tile maxima are THIS tiling's own: not the primary's carried over)
 
         def read_stats():
@@ -206,7 +227,7 @@ class Topology:
                 return self._global_tiles(n) if store else None
             util, nrb, nt, per = best
             tile_start = torch.empty(nt + 1, dtype=torch.int32, device=dev)
-            _lib.check(L.dss2_tiles_uniform(tile_start.data_ptr(), nt, per * n, N, st), "dss2_tiles_uniform")
+            uniform_rows = per * n          # (written by the ELL build below: dss2_tiles_uniform folded in, round 6)
             max_deg = max_degT = int(hint.max_degree)
             max_segment = n
             max_tile_rows = per * n
@@ -236,6 +257,7 @@ class Topology:
                 return self._global_tiles(max_segment) if store else None
             util, nrb, nt, i = best
             tile_start = cands[i][:nt + 1].clone()
+            uniform_rows = 0
             nnz_bound, exact_nnz = 0, True
             # (known without another copy only where every graph has the same size: whole graphs per tile)
             max_tile_rows = ((32 * nrb) // max_segment) * max_segment if s["min_segment"] == max_segment else 0
@@ -253,6 +275,10 @@ class Topology:
         b.ell_tiles, b.ell_ent_tiles = (ell_tiles.data_ptr() if ell else None), (ell_ent_tiles.data_ptr() if ell else None)
         b.ellT_tiles, b.ellT_ent_tiles = (ellT_tiles.data_ptr() if ellT else None), (ellT_ent_tiles.data_ptr() if ellT else None)
         b.meta = meta.data_ptr()
+        b.uniform_rows, b.n_nodes = uniform_rows, N
+        if uniform_rows and not (ell or ellT):      # (hub graphs: no ELL launch to fold the tile starts into)
+            _lib.check(L.dss2_tiles_uniform(tile_start.data_ptr(), nt, uniform_rows, N, st), "dss2_tiles_uniform")
+            b.uniform_rows = 0
         _lib.check(L.dss2_ell_tiles_build(C.byref(b), st), "dss2_ell_tiles_build")
         if not store and hint is not None and os.environ.get("DSS2_CHECK", "0") == "1":
             read_stats()      # (the hint path reads nothing back: with DSS2_CHECK the alternate build's error flag is read too)

@@ -96,6 +96,17 @@ typedef struct dss2_csr_build_args {
 } dss2_csr_build_args;
 int dss2_csr_build(const dss2_csr_build_args* args_host, void* stream);
 int64_t dss2_csr_build_work_ints(int64_t n_nodes, int64_t n_edges, int doubled);
+/* The same arrays (args.work unused) in ONE launch for a batch of equal-size graphs whose ranges in the stored edge list are known (round 6):
+ * graph g = rows [g * nodes_per_graph, ..) and stored edges [edge_ptr[g], edge_ptr[g + 1]) (DEVICE int64 [G + 1]; NULL: edges_per_graph
+ * each).  Every global offset is then a graph-local prefix sum plus (1 or 2) * edge_ptr[g], so one wave per graph builds counts, row
+ * pointers, slot claims, per-row order, gcn_norm weights, incidence lists, legal cuts and statistics in LDS -- and, if deg_pows != NULL,
+ * the [N][4] folded-bias row scales of dss2_deg_pows -- with the definitions, and therefore the bits, of dss2_csr_build (an edge that leaves
+ * its graph's rows sets meta[5] = 1).  What the device loader uses for every batch it assembles: a batch with a NEW structure per step
+ * (BASELINE config C5) goes from ~26 launches to 5.  dss2_csr_build_graphs_supported: nodes_per_graph <= 192, max_edges_per_graph <= 1024
+ * and the per-wave scratch within LDS. */
+int dss2_csr_build_graphs(const dss2_csr_build_args* args_host, int32_t nodes_per_graph, const int64_t* edge_ptr, int32_t edges_per_graph,
+                          int32_t max_edges_per_graph, float* deg_pows, void* stream);
+int dss2_csr_build_graphs_supported(int32_t nodes_per_graph, int32_t max_edges_per_graph);
 
 /* tile_start[ntiles+1] for batches of equal-size graphs (closed form): tile t starts at min(t * rows_per_tile, N). */
 int dss2_tiles_uniform(int32_t* tile_start, int32_t ntiles, int32_t rows_per_tile, int64_t n_nodes, void* stream);
@@ -114,6 +125,9 @@ typedef struct dss2_ell_build_args {
   const int32_t* rowptrT; const int32_t* colT; const int32_t* entT; const float* wT;
   const int32_t* tile_start; int32_t ntiles; int32_t tm; int32_t ell_width; int32_t ellT_width;
   void* ell_tiles; void* ell_ent_tiles; void* ellT_tiles; void* ellT_ent_tiles; int32_t* meta;
+  int32_t uniform_rows;   /* round 6.  > 0 (with n_nodes): tiles of equal-size graphs, tile t = rows [t * uniform_rows, (t + 1) * uniform_rows) cut at
+                           * n_nodes -- tile_start is then an OUTPUT of this launch (dss2_tiles_uniform folded in); 0: tile_start is read */
+  int64_t n_nodes;
 } dss2_ell_build_args;
 int dss2_ell_tiles_build(const dss2_ell_build_args* args_host, void* stream);
 

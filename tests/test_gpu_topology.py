@@ -154,3 +154,55 @@ def test_hinted_build_needs_no_host_sync_and_equals_the_oracle(pkg, grids, B):
     assert (topo.nrb, topo.ntiles, topo.ell, topo.ellT) == (ref.nrb, ref.ntiles, ref.ell, ref.ellT)
     assert topo.max_nnz >= ref.max_nnz and topo.max_nnzT >= ref.max_nnzT       # upper bounds (unused with ELL slices)
     assert topo.stats()["error"] == 0
+
+
+@pytest.mark.parametrize("grids,B,mode", [(["cigre14"], 4096, "uniform"), (["cigre14", "cigre14_reswitched"], 515, "edge_ptr"), (["ober_sub"], 37, "uniform"),
+                                          (["ober179"], 5, "edge_ptr"), (["cigre14"], 3, "uniform-asis"), (["cigre14_reswitched"], 9, "uniform-noflip")])
+def test_one_launch_build_of_equal_size_graphs_equals_the_oracle(pkg, grids, B, mode, monkeypatch):
+    """Round 6: with the graphs' ranges in the stored edge list known (uniform edges_per_graph, or the batch's own edge_ptr) the whole CSR
+    part AND the folded-bias row scales are ONE launch, a wave per graph (dss2_csr_build_graphs) -- every array bit for bit what the
+    oracle (and the general 18-launch build) gives: row pointers, per-row order, gcn_norm weights, incidence lists, degrees, legal cuts,
+    statistics, deg_pows; then tiles + ELL slices with the tile starts written by the ELL launch itself."""
+    b = pkg.synthetic.make_batch(grids, B, seed=5)
+    ei, N = b["edge_index"], b["x"].shape[0]
+    n = N // B
+    asis, noflip = mode.endswith("asis"), mode.endswith("noflip")
+    if asis:      # an edge list used as given (already doubled by the caller)
+        ei = torch.cat([ei, ei.flip(0)], 1)
+        # (graph order must be kept: interleave per graph)
+        gid = (ei[0] // n)
+        ei = ei[:, torch.argsort(gid, stable=True)]
+    ref = topo_oracle.TopologyOracle(ei, N, double=(False if asis else None))      # (the oracle flags reverse edges: `noflip` is compared with the general build only)
+    counts = torch.bincount(ei[0] // n, minlength=B)
+    assert bool((ei[1] // n == ei[0] // n).all())
+    kw = dict(directed=not asis, nodes_per_graph=n, max_degree=max(ref.max_deg, ref.max_degT), max_edges_per_graph=int(counts.max()))
+    if mode.startswith("uniform"):
+        assert int(counts.min()) == int(counts.max())
+        hint = pkg.topology.TopologyHint(edges_per_graph=int(counts[0]), **kw)
+    else:
+        ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts, 0)]).to(DEV)
+        hint = pkg.topology.TopologyHint(edge_ptr=ptr, **kw)
+    topo = pkg.topology.Topology(ei.to(DEV), N, hint=hint, double=(False if asis else None), flip=not noflip)
+    assert topo._deg_pows is not None, "the one-launch build was not taken"
+    topo.nrb
+    if not noflip:
+        for f in CSR_FIELDS + TILE_FIELDS:
+            _same(getattr(topo, f), getattr(ref, f), f)
+    _same(topo.deg_pows, ref.deg_pows, "deg_pows")
+    s = topo.stats()
+    assert (s["max_deg"], s["max_degT"], s["error"]) == (ref.max_deg, ref.max_degT, 0)
+    assert s["n_segments"] == len(ref.bounds) - 1 and s["min_segment"] == int(np.diff(ref.bounds).min()) and s["max_segment"] == ref.max_segment
+    # ... and the general build of the same batch (DSS2_TOPO_GRAPHS=0) gives the same legal cuts
+    monkeypatch.setenv("DSS2_TOPO_GRAPHS", "0")
+    gen = pkg.topology.Topology(ei.to(DEV), N, hint=hint, double=(False if asis else None), flip=not noflip)
+    assert gen._deg_pows is None
+    gen.nrb
+    for f in CSR_FIELDS + TILE_FIELDS + ["_lastcut", "deg_pows"]:
+        _same(getattr(topo, f), (getattr(gen, f).cpu() if getattr(gen, f) is not None else None), f)
+    # an edge that leaves its graph's rows is an error, not a silent wrong structure
+    bad = ei.clone()
+    bad[1, 0] = (bad[1, 0] + n) % N
+    monkeypatch.setenv("DSS2_TOPO_GRAPHS", "1")
+    t_bad = pkg.topology.Topology(bad.to(DEV), N, hint=hint, double=(False if asis else None), flip=not noflip)
+    with pytest.raises(ValueError):
+        t_bad.stats()
