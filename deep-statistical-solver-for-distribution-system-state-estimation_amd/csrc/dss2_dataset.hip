@@ -214,6 +214,31 @@ __global__ void accum_scalar_kernel(double* acc, const float* value) {
   acc[1] += 1.0;
 }
 
+// several cases in ONE launch (blockIdx.z = case): a mixed batch is assembled by a single launch from a single uploaded table
+struct RaggedMulti { RaggedArgs a[4]; long long count[4]; };
+__global__ void __launch_bounds__(256) collate_ragged_multi_kernel(const RaggedMulti m) {
+  const RaggedArgs& a = m.a[blockIdx.z];
+  if ((long long)blockIdx.x >= m.count[blockIdx.z]) return;
+  const dss2_collate_desc& d = a.d[blockIdx.y];
+  const long long j = blockIdx.x;
+  const long long s = a.samp[j];
+  if (d.kind == 0) {
+    const long long row = d.shared ? a.edge_off[j] : a.node_off[j];
+    const float* src = static_cast<const float*>(d.src) + s * d.chunk;
+    float* dst = static_cast<float*>(d.dst) + row * d.nodes_per_sample;
+    for (int k = threadIdx.x; k < d.chunk; k += blockDim.x) dst[k] = src[k];
+  } else {
+    const int e = d.chunk;
+    const long long* src = static_cast<const long long*>(d.src) + (d.shared ? 0 : s * 2 * e);
+    long long* dst = static_cast<long long*>(d.dst);
+    const long long noff = a.node_off[j], eoff = a.edge_off[j];
+    for (int k = threadIdx.x; k < 2 * e; k += blockDim.x) {
+      const int row = k / e, i = k - row * e;
+      dst[(long long)row * a.e_total + eoff + i] = src[k] + noff;
+    }
+  }
+}
+
 }  // namespace dss2
 
 using namespace dss2;
@@ -304,6 +329,32 @@ extern "C" int dss2_collate_cursor(const dss2_collate_desc* descs_host, int32_t 
   if (int rc = collate_table(descs_host, n_desc, &tab)) return rc;
   DSS2_RECORD([tab, n_desc, sample_ids, batch, cursor, advance](void* s_) { return collate_launch(tab, n_desc, sample_ids, batch, cursor, advance, s_); });
   return collate_launch(tab, n_desc, sample_ids, batch, cursor, advance, stream);
+}
+
+extern "C" int dss2_collate_ragged_multi(const dss2_collate_desc* descs_host, int32_t n_cases, int32_t n_desc, const int64_t* const* samp,
+                                         const int64_t* const* node_off, const int64_t* const* edge_off, const int64_t* count, int64_t e_total,
+                                         void* stream) {
+  using namespace dss2;
+  DSS2_NOT_IN_PLAN("dss2_collate_ragged_multi");
+  if (!descs_host || n_cases < 1 || n_cases > 4 || n_desc < 1 || n_desc > 4 || !samp || !node_off || !edge_off || !count) { set_error("collate_ragged_multi: bad arguments"); return 2; }
+  RaggedMulti m = {};
+  long long cmax = 0;
+  for (int c = 0; c < n_cases; ++c) {
+    for (int i = 0; i < n_desc; ++i) {
+      m.a[c].d[i] = descs_host[c * n_desc + i];
+      if (count[c] > 0 && (!m.a[c].d[i].src || !m.a[c].d[i].dst || m.a[c].d[i].chunk <= 0)) { set_error("collate_ragged_multi: descriptor %d of case %d is incomplete", i, c); return 2; }
+    }
+    if (count[c] > 0 && (!samp[c] || !node_off[c] || !edge_off[c])) { set_error("collate_ragged_multi: case %d has no tables", c); return 2; }
+    m.a[c].samp = reinterpret_cast<const long long*>(samp[c]);
+    m.a[c].node_off = reinterpret_cast<const long long*>(node_off[c]);
+    m.a[c].edge_off = reinterpret_cast<const long long*>(edge_off[c]);
+    m.a[c].e_total = e_total;
+    m.count[c] = count[c];
+    if (count[c] > cmax) cmax = count[c];
+  }
+  if (cmax <= 0) return 0;
+  hipLaunchKernelGGL(collate_ragged_multi_kernel, dim3((unsigned)cmax, (unsigned)n_desc, (unsigned)n_cases), dim3(256), 0, as_stream(stream), m);
+  return check_launch("collate_ragged_multi");
 }
 
 static int accum_scalar_launch(double* acc, const float* value, void* stream) {

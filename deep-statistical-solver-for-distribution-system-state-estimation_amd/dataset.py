@@ -253,7 +253,7 @@ class MixedDataset:
         ~1.4 ms of host time, round 6.)  The oldest slot is reused if its copy has run; otherwise the ring grows by one slot (the host
         never waits for the GPU here; the ring stops growing once it is as deep as the host's lead, _RING_MAX at most)."""
         ring = self.__dict__.setdefault("_ring", [])
-        need = max(tab.size, 3 * 4096)
+        need = max(tab.size, 4 * 4096 + 8)
         slot = None
         if ring and ring[0][1].query() and ring[0][0].numel() >= tab.size:
             slot = ring.pop(0)
@@ -288,28 +288,57 @@ class MixedDataset:
         ei = torch.empty(2, E, dtype=torch.int64, device=dev)
         L = _lib.lib()
         st = _lib.stream_ptr(dev)
-        for k, p in enumerate(self.parts):
-            slots = np.nonzero(part == k)[0]
-            if slots.size == 0:
-                continue
-            n = p.n
-            tab = np.stack([ids[slots] - self.start[k], node_off[slots], edge_off[slots]]).astype(np.int64)
-            tab_d = self._upload(tab, dev)                                             # 3 x count int64, host -> device only
-            descs = (_lib.CollateDesc * 4)()
-            items = [(p.x, x, n * p.x.size(2), 0, 0, p.x.size(2)), (p.y, y, n * p.y.size(2), 0, 0, p.y.size(2)),
-                     (p.edge_attr, ea, p.e * p.edge_attr.size(2), 0, 1, p.edge_attr.size(2)),
-                     (p.edge_index, ei, p.e, 1, int(p.shared_topology), 0)]
-            for d, (src, dst, chunk, kind, shared, width) in zip(descs, items):
-                d.src, d.dst, d.chunk, d.kind, d.shared, d.nodes_per_sample = src.data_ptr(), dst.data_ptr(), chunk, kind, shared, width
-            _lib.check(L.dss2_collate_ragged(C.addressof(descs), 4, tab_d[0].data_ptr(), tab_d[1].data_ptr(), tab_d[2].data_ptr(),
-                                             int(slots.size), E, st), "dss2_collate_ragged")
+        # ONE table for the whole batch -- per case {sample, node offset, edge offset} of its slots, then the batch's edge_ptr -- through
+        # one pinned staging buffer and one host-to-device copy; ONE launch gathers every case (round 6: was a copy and a launch per case)
+        n_parts = len(self.parts)
+        slots_of = [np.nonzero(part == k)[0] for k in range(n_parts)]
+        pieces, base, where = [], 0, []
+        for k, sl in enumerate(slots_of):
+            tab = np.stack([ids[sl] - self.start[k], node_off[sl], edge_off[sl]]).astype(np.int64).reshape(-1)
+            where.append(base)
+            pieces.append(tab)
+            base += tab.size
+        ptr_at = base
+        pieces.append(edge_off)
+        table = self._upload(np.concatenate(pieces).reshape(1, -1), dev).reshape(-1)
+        edge_ptr = table[ptr_at:ptr_at + B + 1]
+        if n_parts <= 4:
+            descs = (_lib.CollateDesc * (4 * n_parts))()
+            samp, noff, eoff, cnt = ((C.c_void_p * n_parts)() for _ in range(3)), None, None, (C.c_int64 * n_parts)()
+            samp, noff, eoff = samp
+            for k, p in enumerate(self.parts):
+                n, c = p.n, int(slots_of[k].size)
+                items = [(p.x, x, n * p.x.size(2), 0, 0, p.x.size(2)), (p.y, y, n * p.y.size(2), 0, 0, p.y.size(2)),
+                         (p.edge_attr, ea, p.e * p.edge_attr.size(2), 0, 1, p.edge_attr.size(2)),
+                         (p.edge_index, ei, p.e, 1, int(p.shared_topology), 0)]
+                for i, (src, dst, chunk, kind, shared, width) in enumerate(items):
+                    d = descs[4 * k + i]
+                    d.src, d.dst, d.chunk, d.kind, d.shared, d.nodes_per_sample = src.data_ptr(), dst.data_ptr(), chunk, kind, shared, width
+                t0 = table.data_ptr() + 8 * where[k]
+                samp[k], noff[k], eoff[k], cnt[k] = t0, t0 + 8 * c, t0 + 16 * c, c
+            _lib.check(L.dss2_collate_ragged_multi(C.addressof(descs), n_parts, 4, C.addressof(samp), C.addressof(noff), C.addressof(eoff),
+                                                   C.addressof(cnt), E, st), "dss2_collate_ragged_multi")
+        else:      # (more than four cases: a launch per case)
+            for k, p in enumerate(self.parts):
+                c = int(slots_of[k].size)
+                if c == 0:
+                    continue
+                n = p.n
+                descs = (_lib.CollateDesc * 4)()
+                items = [(p.x, x, n * p.x.size(2), 0, 0, p.x.size(2)), (p.y, y, n * p.y.size(2), 0, 0, p.y.size(2)),
+                         (p.edge_attr, ea, p.e * p.edge_attr.size(2), 0, 1, p.edge_attr.size(2)),
+                         (p.edge_index, ei, p.e, 1, int(p.shared_topology), 0)]
+                for d, (src, dst, chunk, kind, shared, width) in zip(descs, items):
+                    d.src, d.dst, d.chunk, d.kind, d.shared, d.nodes_per_sample = src.data_ptr(), dst.data_ptr(), chunk, kind, shared, width
+                t0 = table.data_ptr() + 8 * where[k]
+                _lib.check(L.dss2_collate_ragged(C.addressof(descs), 4, t0, t0 + 8 * c, t0 + 16 * c, c, E, st), "dss2_collate_ragged")
         if self.n is None:       # different bus counts: no closed-form tiles, the general (statistics-reading) build
             _topology.register_topology(ei, Ntot, _topology.Topology(ei, Ntot))
             return Batch(x, ei, ea, y, B)
         n = self.n
         first = self.parts[int(part[0])]
-        # (the batch's own prefix sum of the graphs' edge counts: with it the structure is one launch, a wave per graph)
-        edge_ptr = self._upload(edge_off.reshape(1, -1), dev).reshape(-1)
+        # (edge_ptr: the batch's own prefix sum of the graphs' edge counts, uploaded with the tables above: with it the structure is one
+        #  launch, a wave per graph)
         directed = first.hint(int(ids[0] - self.start[part[0]])).directed
         hint = _topology.TopologyHint(
             directed=directed, nodes_per_graph=n,

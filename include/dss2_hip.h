@@ -606,6 +606,11 @@ int dss2_accum_scalar(double* acc, const float* value, void* stream);
  *           stride e_total (shared != 0: one [2][e] list for every sample). */
 int dss2_collate_ragged(const dss2_collate_desc* descs_host, int32_t n_desc, const int64_t* samp, const int64_t* node_off,
                         const int64_t* edge_off, int64_t count, int64_t e_total, void* stream);
+/* The same for up to 4 cases in ONE launch (round 6): descs_host[n_cases][n_desc], per case its three DEVICE tables and its item count
+ * (HOST arrays of pointers / counts).  A mixed batch is then one upload and one launch. */
+int dss2_collate_ragged_multi(const dss2_collate_desc* descs_host, int32_t n_cases, int32_t n_desc, const int64_t* const* samp,
+                              const int64_t* const* node_off, const int64_t* const* edge_off, const int64_t* count, int64_t e_total,
+                              void* stream);
 
 /* ---- optimizer step (/root/reference/dss2_run.py:91-92,143: Adamax, lr 3e-3) ---
  * torch.optim.Adamax semantics on n_desc tensors, 96 tensors per launch.  descs_host: HOST array, passed to the kernels by
