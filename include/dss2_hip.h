@@ -62,9 +62,9 @@ int dss2_topology_probe(const int64_t* edge_index, int64_t n_edges, uint64_t* ou
  * dss2_adamax_step_flat / _dev and use_host_seed = 0 of dss2_rng_next, as under capture).  Only launches of this library are         *
  * recorded.  One plan records at a time (process-wide).  Every entry point that launches a STEP's work records itself (model, loss, *
  * dss2_get_pflow / dss2_eval_batch, dropout masks, optimizer, dss2_collate / dss2_collate_cursor, dss2_accum_scalar); the entry     *
- * points that are not launches of a step -- structure build (dss2_topology_probe, dss2_csr_build, dss2_tiles_*,                      *
- * dss2_ell_tiles_build, dss2_deg_pows), measurement model, z-score, ragged collation -- return 3 while a plan records instead of     *
- * being silently left out of it.                                                                                                     */
+ * points that are not launches of a step -- structure build (dss2_topology_probe, dss2_csr_build, dss2_csr_build_graphs,             *
+ * dss2_tiles_*, dss2_ell_tiles_build, dss2_deg_pows), measurement model, z-score, ragged collations -- return 3 while a plan records *
+ * instead of being silently left out of it.                                                                                         */
 typedef struct dss2_plan dss2_plan;
 int dss2_plan_begin(dss2_plan** out);
 int dss2_plan_end(dss2_plan* plan);
