@@ -125,8 +125,14 @@ __global__ void __launch_bounds__(W16H_NT, 2) wgrad16h_kernel(const dss2_wgrad_a
       const int rr = r < R ? r : R - 1;      // rows beyond the tile's R rows: its last row (finite values; G's are zeroed at consumption)
       pg[u] = *reinterpret_cast<const f32x4*>(gb + (uint32_t)(rr * p.ldg) * 4u + g_col);
       const uint32_t xro = (uint32_t)(rr * p.ldx) * 4u;
+#ifdef DSS2_ABLATE_XLOAD      // (diagnostic: X is never read)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) px[2 * i + u] = f32x4{1.f, 1.f, 1.f, 1.f};
+      (void)xro; (void)xb;
+#else
 #pragma unroll
       for (int i = 0; i < 2; ++i) px[2 * i + u] = *reinterpret_cast<const f32x4*>(xb + xro + x_col[i]);
+#endif
       if constexpr (RS2) prs[u] = *reinterpret_cast<const f32x3*>(rsb + (size_t)(ts + rr) * 4);
     }
     pel = tid < D * TM ? (reinterpret_cast<const int2*>(p.ell_tiles) + (size_t)tile * D * TM)[tid] : make_int2(tid & (TM - 1), 0);
@@ -205,8 +211,10 @@ __global__ void __launch_bounds__(W16H_NT, 2) wgrad16h_kernel(const dss2_wgrad_a
 #pragma unroll
     for (int u = 0; u < 2; ++u)
       if (!(g_ok && 2 * rp + u < R)) pg[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef DSS2_ABLATE_XSPLIT      // (diagnostic builds, tools/wgrad_ablations.sh: what the split of X costs -- the planes then hold whatever LDS held)
 #pragma unroll
     for (int i = 0; i < 2; ++i) store_planes_h<XW>(XT, x_off0[i], px[2 * i], px[2 * i + 1], sxe);
+#endif
 #pragma unroll
     for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4*>(Zf0 + (2 * rp + u) * LDZF + 4 * cg) = pg[u];
     store_planes_h<ZC>(ZT, g_off0, pg[0], pg[1], sze);
@@ -226,7 +234,11 @@ __global__ void __launch_bounds__(W16H_NT, 2) wgrad16h_kernel(const dss2_wgrad_a
     if (next < p.ntiles) load_tile(next, ts_n, R_n);      // in flight across the hops and the MFMA phase
     HSTAMP(4);
     // ---- P G, P^2 G
+#ifdef DSS2_ABLATE_HOPS      // (diagnostic: no propagation hops -- their planes hold whatever LDS held)
+    if (false) {
+#else
     if (NMAT > 1) {
+#endif
       prop(Zf0, NMAT > 2 ? Zf1 : nullptr, ZT + 2 * ZC * 64, sze);
       HSTAMP(5);
       if (NMAT > 2) {
@@ -239,7 +251,11 @@ __global__ void __launch_bounds__(W16H_NT, 2) wgrad16h_kernel(const dss2_wgrad_a
       HSTAMP(8);
     }
     // ---- MFMA phase: 2 steps of 16 rows; lo hi + hi lo + hi hi, smallest terms first
+#ifdef DSS2_ABLATE_MFMA      // (diagnostic: no matrix instructions)
+    if (false) {
+#else
     if (in_active) {
+#endif
       const int nsteps = (R + 15) >> 4;
       const int zc = obw * 32 + c32;
       const int zkey = tph_key(zc);

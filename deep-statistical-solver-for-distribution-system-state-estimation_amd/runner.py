@@ -311,12 +311,21 @@ def main(argv=None):
     single_topology = (not a.data_folder) or bool(getattr(train_loader.dataset, "shared_topology", False))
     use_graph = (a.graph == 1) or (a.graph == -1 and single_topology and hp["dim_out"] == 2)
     opt = FusedAdamax(model.parameters(), lr=a.lr, capturable=use_graph)
-    trainer = GraphedTrainer(model, opt, stats, REG_COEFS) if use_graph else None
-    print(f"device:{dev}  train batches {len(train_loader)}  test batches {len(test_loader)}  model {a.model} {hp}  "
-          f"step: {'hipGraph replay' if use_graph else 'eager'}")
+    # a device-resident data folder with ONE graph structure: whole epochs without the interpreter (EpochTrainer: the loader's collation is the
+    # first launch of the recorded step); pre-collated synthetic batches: the step replayed on copied inputs (GraphedTrainer); else eager
+    epoch_trainer = None
+    if use_graph and a.data_folder and single_topology:
+        epoch_trainer = EpochTrainer(model, opt, stats, REG_COEFS, train_loader.dataset, a.batch_size, shuffle=True, mode="graph")
+    trainer = GraphedTrainer(model, opt, stats, REG_COEFS) if (use_graph and epoch_trainer is None) else None
+    how = "whole epochs as replays of one recorded step (EpochTrainer)" if epoch_trainer is not None else ("hipGraph replay" if use_graph else "eager")
+    print(f"device:{dev}  train batches {len(train_loader)}  test batches {len(test_loader)}  model {a.model} {hp}  step: {how}")
     for epoch in range(a.epochs):
         t0 = time.perf_counter()
-        tl = train_epoch_graphed(trainer, train_loader) if use_graph else train_epoch(model, opt, train_loader, stats, REG_COEFS)
+        if epoch_trainer is not None:
+            epoch_trainer.train_epoch()
+            tl = epoch_trainer.mean_loss()
+        else:
+            tl = train_epoch_graphed(trainer, train_loader) if use_graph else train_epoch(model, opt, train_loader, stats, REG_COEFS)
         m = evaluate(model, test_loader, stats) if hp["dim_out"] == 2 else {}
         torch.cuda.synchronize()
         print(f"epoch {epoch:4d}  train_loss {tl:.6g}  " + "  ".join(f"{k} {v:.4g}" for k, v in m.items()) +

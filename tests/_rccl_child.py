@@ -13,6 +13,8 @@ non-distributed step.  Prints one JSON object on the last line of stdout.
 
     python _rccl_child.py eager     blocking and asynchronous collectives
     python _rccl_child.py plan      the step as a segmented launch plan (graphs.PlannedStep: one C call per segment, collectives between)
+    python _rccl_child.py epoch     runner.EpochTrainer over the process group (segmented plan) against the same epochs without one
+    python _rccl_child.py loose     the coalesced "loose" gradients (MultiMPN) over RCCL
     python _rccl_child.py graph     the step with its collectives inside a hipGraph capture (a separate process: a
                                     failing capture can take the process down, which must not take the eager result
                                     with it)
@@ -39,6 +41,63 @@ def main():
     dev = torch.device("cuda", env["local"])
     group = dist.group.WORLD
     res = {"backend": dist.get_backend(), "world": dist.get_world_size(), "cases": {}}
+
+    if mode == "epoch":
+        # a data-parallel TRAINING epoch without the interpreter (runner.EpochTrainer, mode "plan": the step's collectives cut the recorded
+        # step into segments) against the same epoch without a process group: every parameter bitwise (SUM over one rank = identity)
+        full = pkg.synthetic.make_batch(["cigre14"], 200, seed=4, violate=0.3)
+        ds = pkg.dataset.DeviceDataset.from_batch(full, device=dev)
+        stats = tuple(t_.to(dev) for t_ in full["stats"])
+        out = {}
+        finals = []
+        for grp in (None, group):
+            torch.manual_seed(1)
+            m = pkg.MPN(8, 6, 2, 64, 3, 2, 0.0).to(dev)
+            o = pkg.optim.FusedAdamax(m.parameters(), lr=3e-3, capturable=True)
+            if grp is not None:
+                pkg.parallel.attach_grad_allreduce(m, grp)
+            tr = pkg.runner.EpochTrainer(m, o, stats, REG, ds, 64, shuffle=False, mode="plan", group=grp)
+            for _ in range(2):
+                tr.train_epoch()
+            torch.cuda.synchronize()
+            finals.append(([p.detach().clone() for p in m.parameters()], tr.mean_loss()))
+            out["segments" if grp is not None else "segments_local"] = len(tr.steps[64][0].segments)
+        out["bitwise"] = bool(all(torch.equal(a, b_) for a, b_ in zip(finals[0][0], finals[1][0])) and finals[0][1] == finals[1][1])
+        res["cases"]["EpochTrainer"] = out
+        dist.barrier(); dist.destroy_process_group()
+        print(json.dumps(res), flush=True)
+        return
+    if mode == "loose":
+        # gradients that come in no flat bucket (the MultiMPN family): ONE collective per backward (parallel.LooseGradCoalescer) over RCCL,
+        # bitwise the non-distributed gradients; a backward on top of gradients already in place falls back to one collective per parameter
+        import types
+        b = pkg.synthetic.make_batch(["cigre14"], 64, seed=2)
+        data = types.SimpleNamespace(x=b["x"].to(dev), edge_index=b["edge_index"].to(dev), edge_attr=b["edge_attr"].to(dev))
+        data.x = data.x[:, :8].contiguous(); data.edge_attr = data.edge_attr[:, :6].contiguous()
+        torch.manual_seed(0)
+        m = pkg.MultiMPN(8, 6, 2, 32, 3, 2, 0.0).to(dev)
+        gout = torch.randn(data.x.shape[0], 2, device=dev)
+
+        def run():
+            m(data).backward(gout)
+            torch.cuda.synchronize()
+            return [p.grad.detach().clone() for p in m.parameters()]
+        g0 = run()
+        for p in m.parameters():
+            p.grad = None
+        pkg.parallel.attach_grad_allreduce(m, group)
+        co = m._dss2_loose_grads
+        g1 = run()
+        c = {"loose_parameters": len(co.params) if co is not None else 0, "collectives": co.collectives if co is not None else -1,
+             "fallback": co.fallback_collectives if co is not None else -1,
+             "bitwise": bool(all(torch.equal(a, q) for a, q in zip(g0, g1)))}
+        g2 = run()          # (gradients in place: accumulation)
+        c["accumulated_bitwise"] = bool(all(torch.equal(2 * a, q) for a, q in zip(g0, g2)))
+        c["fallback_after_accumulation"] = co.fallback_collectives if co is not None else -1
+        res["cases"]["MultiMPN"] = c
+        dist.barrier(); dist.destroy_process_group()
+        print(json.dumps(res), flush=True)
+        return
 
     models = {
         "MPN_C2_model": lambda: pkg.MPN(8, 6, 2, 128, 4, 2, 0.0),          # BASELINE config C2's model

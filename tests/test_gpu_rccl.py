@@ -64,6 +64,24 @@ def test_rccl_world1_step_as_a_segmented_launch_plan():
     print("RCCL world-1 segmented plan:", json.dumps(res))
 
 
+def test_rccl_world1_training_epochs_as_segmented_plans():
+    """Round 6: whole training epochs as replays of ONE recorded step (runner.EpochTrainer) with the data-parallel collectives inside: the
+    loss-sum all-reduce and the gradient bucket cut the plan into segments; two epochs over RCCL at world size 1 leave every parameter
+    bitwise where the same epochs without a process group leave it."""
+    p = _child("epoch")
+    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-4000:]
+    c = _result(p)["cases"]["EpochTrainer"]
+    assert c["bitwise"] and c["segments_local"] == 1 and c["segments"] >= 3, c
+
+
+def test_rccl_world1_loose_gradients_travel_in_one_collective():
+    p = _child("loose")
+    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-4000:]
+    c = _result(p)["cases"]["MultiMPN"]
+    assert c["loose_parameters"] > 4 and c["collectives"] == 1 and c["fallback"] == 0 and c["bitwise"], c
+    assert c["accumulated_bitwise"] and c["fallback_after_accumulation"] == c["loose_parameters"], c
+
+
 def test_rccl_collectives_inside_hipgraph_capture():
     """A step WITH its RCCL collectives (loss sums, gradient bucket) captured into a hipGraph and replayed: must be bitwise
     the eager step.  The capture needs capture_error_mode="thread_local" (graphs.GraphedStep): in the default global mode
