@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 cd $R
 python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/final_stats -o s -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs --min-window-seconds 0.5 > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/final_stats -o s -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs --no-routes --min-window-seconds 0.5 > $O/bench_under_rocprof.log 2>&1
 find /tmp/final_stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_bench_c2.csv \;
 cd $R
 bash tools/pmc_one.sh chain > $O/pmc_gemm_chain.txt 2>&1
