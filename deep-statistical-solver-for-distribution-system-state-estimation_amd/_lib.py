@@ -252,6 +252,7 @@ _SIGNATURES = {
     "dss2_adamax_step_flat": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
                                         C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dss2_gemm_prop_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dss2_wgrad_batched_groups": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad_y_slices": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad_lds_bytes_ex": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dss2_wgrad_lds_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

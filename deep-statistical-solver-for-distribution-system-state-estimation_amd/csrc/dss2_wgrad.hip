@@ -784,6 +784,15 @@ extern "C" int dss2_wgrad_y_slices(int nrb, int nmat, int hout, int hin, int ell
   return dss2::wgrad16_y_slices(nrb, hout, hin);          // 64-row tiles: a workgroup owns 128 output x 128 input columns; 32-row tiles: 64 x 128
 }
 
+// workgroup groups along grid.z of a batched launch of n_layers layers: one per layer, except where the f16x3 tall-tile kernel walks TWO
+// 32-column layers per workgroup (dss2_wgrad16th.hip, PAIR) -- the host sizes n_split (slabs per layer) with it so that the launch fills the chip
+extern "C" int dss2_wgrad_batched_groups(int nrb, int hout, int hin, int mfma_bf16, int n_layers) {
+  static const int pair_on = [] { const char* e = getenv("DSS2_WGRAD_TALL_PAIR"); return e ? atoi(e) : 1; }();
+  static const int tall_on = [] { const char* e = getenv("DSS2_WGRAD_TALL_F16"); return e ? atoi(e) : 1; }();
+  if (pair_on && tall_on && (mfma_bf16 & 255) == 2 && nrb == 3 && hout == 32 && hin == 32 && n_layers >= 2) return (n_layers + 1) / 2;
+  return n_layers;
+}
+
 static int wgrad_dispatch(const dss2_wgrad_args& a, void* stream, const dss2::WgradBatch& wb) {
   using namespace dss2;
   if (a.n_split <= 0 || !a.slab) { set_error("wgrad: n_split/slab missing"); return 2; }

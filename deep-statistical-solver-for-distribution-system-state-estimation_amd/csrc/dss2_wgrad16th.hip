@@ -44,16 +44,27 @@ __device__ __forceinline__ void store_planes_h2(char* img, int off0, const f32x4
   }
 }
 
-template <int NRB, int NMAT, bool RS2, bool PC>
+// PAIR (round 6; hout = hin = 32: the reference driver's model on 70-bus grids, seven H -> H layers per launch): at that width one wave of
+// eight multiplies and half the staging lanes idle, while a tile still costs its barriers and latencies.  TWO layers share a workgroup's walk:
+// columns 0..31 of the G-side image / of the X planes are layer 2 z's, columns 32..63 layer 2 z + 1's (per-thread base pointers); waves (0, 0)
+// and (1, 1) multiply; the two layers share the running exponents.  157 -> ~90 us per launch of seven layers at 1024 tiles.
+template <int NRB, int NMAT, bool RS2, bool PC, bool PAIR = false>
 __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_args p, int nibg, const WgradBatch wb, int hb) {
   constexpr int TR = 32 * NRB, ZC = W16TH_ZC, XW = W16TH_XW, NT = W16TH_NT, LDZF = W16TH_LDZF;
   constexpr int PLANES = NMAT * 2 * ZC * 64 + 2 * XW * 64;
   constexpr int PBUF = TR * LDZF * 4 > PLANES ? TR * LDZF * 4 : PLANES;      // one set of planes; the tile's fp32 G fits in it
   constexpr int UBYTES = 2 * PBUF;      // two sets of planes always fit (two planes per operand): one barrier per chunk
-  const float* __restrict__ Gp = wb.n > 0 ? wb.G[blockIdx.z] : p.G;
-  const float* __restrict__ Xp = wb.n > 0 ? wb.X[blockIdx.z] : p.X;
-  float* __restrict__ slabp = wb.n > 0 ? wb.slab[blockIdx.z] : p.slab;
-  const float* __restrict__ rs2 = RS2 ? (wb.n > 0 ? wb.rowscale2[blockIdx.z] : p.rowscale2) : nullptr;
+  const int zl = PAIR ? 2 * (int)blockIdx.z : (int)blockIdx.z;      // (first) layer of this workgroup
+  const bool hasB = PAIR && zl + 1 < wb.n;                          // (uniform) the pair's second layer exists
+  const float* __restrict__ Gp = wb.n > 0 ? wb.G[zl] : p.G;
+  const float* __restrict__ Xp = wb.n > 0 ? wb.X[zl] : p.X;
+  float* __restrict__ slabp = wb.n > 0 ? wb.slab[zl] : p.slab;
+  const float* __restrict__ rs2 = RS2 ? (wb.n > 0 ? wb.rowscale2[zl] : p.rowscale2) : nullptr;
+  // the pair's second layer (PAIR only; a missing one reads the first layer's rows and stores nothing)
+  const float* __restrict__ GpB = hasB ? wb.G[zl + 1] : Gp;
+  const float* __restrict__ XpB = hasB ? wb.X[zl + 1] : Xp;
+  float* __restrict__ slabB = hasB ? wb.slab[zl + 1] : slabp;
+  const float* __restrict__ rs2B = (RS2 && hasB) ? wb.rowscale2[zl + 1] : nullptr;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Zf1 = smem;                                              // [TR][LDZF]  P G
   char* const U = reinterpret_cast<char*>(Zf1 + TR * LDZF);       // two sets of planes [NMAT][2 planes][ZC columns][64 B] + [2 planes][XW columns][64 B];
@@ -70,16 +81,23 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
   const int slice = blockIdx.x, ysl = blockIdx.y;
   const int obg = ysl / nibg, ibg = ysl - obg * nibg;
   const int gcol0 = obg * ZC, xcol0 = ibg * XW;
-  const bool in_active = (xcol0 + ibw * 32) < p.hin && (gcol0 + obh * 32) < p.hout;
+  const bool in_active = PAIR ? (ibw == obh && ibw < 2 && (obh == 0 || hasB)) : ((xcol0 + ibw * 32) < p.hin && (gcol0 + obh * 32) < p.hout);
 
   // whole-tile units: one row of four columns per row block (a wave covers four whole rows of the fp32 image)
   const int q16 = tid & 15, r32 = tid >> 4;
-  const bool gcol_ok = gcol0 + 4 * q16 < p.hout;
+  const int lyr_w = PAIR ? (q16 >> 3) : 0;      // (PAIR) which layer of the pair this thread's whole-tile columns belong to
+  const bool gcol_ok = PAIR ? (4 * (q16 & 7) < p.hout && (lyr_w == 0 || hasB)) : (gcol0 + 4 * q16 < p.hout);
   // chunk units: rows (2 rp, 2 rp + 1) of four columns, the thread map of wgrad16b_kernel within each half of the workgroup
   const int t8 = tid & 255, cg = t8 & 15, rp = (t8 >> 4) ^ ((t8 & 1) << 1);
   const int z_off = tph2_off(4 * cg, 2 * rp), x_off = tph2_off(64 * role + 4 * cg, 2 * rp);
-  const uint32_t xcb = (xcol0 + 64 * role + 4 * cg < p.hin) ? (uint32_t)(64 * role + 4 * cg) * 4u : 0u;      // (columns beyond hin: group 0, never stored)
-  const bool zcol_ok = gcol0 + 4 * cg < p.hout;
+  const int lyr_c = PAIR ? (cg >> 3) : 0;
+  const uint32_t xcb = PAIR ? ((role == 0 && 4 * (cg & 7) < p.hin && (lyr_c == 0 || hasB)) ? (uint32_t)(4 * (cg & 7)) * 4u : 0u)
+                            : ((xcol0 + 64 * role + 4 * cg < p.hin) ? (uint32_t)(64 * role + 4 * cg) * 4u : 0u);      // (columns beyond hin: group 0, never stored)
+  const bool zcol_ok = PAIR ? (4 * (cg & 7) < p.hout && (lyr_c == 0 || hasB)) : (gcol0 + 4 * cg < p.hout);
+  // per-thread bases (PAIR: the layer the thread's columns belong to)
+  const float* __restrict__ Gw_ = lyr_w ? GpB : Gp;
+  const float* __restrict__ Gc_ = lyr_c ? GpB : Gp;
+  const float* __restrict__ Xc_ = lyr_c ? XpB : Xp;
 
   f32x16 acc[NMAT];
 #pragma unroll
@@ -107,10 +125,11 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
   f32x4 pgw[NRB], px[NPX][2], pgc[2];
   f32x3_t prs[PRS ? NRB : 1];
   int2 pel[NEL];
-  const uint32_t gw_col = gcol_ok ? (uint32_t)(4 * q16) * 4u : 0u, gc_col = zcol_ok ? (uint32_t)(4 * cg) * 4u : 0u;
-  const float* __restrict__ rsb = RS2 ? (rs2 ? rs2 : Gp) : nullptr;      // (layers without row scales: any readable rows; never used)
+  const uint32_t gw_col = gcol_ok ? (uint32_t)(4 * (PAIR ? (q16 & 7) : q16)) * 4u : 0u, gc_col = zcol_ok ? (uint32_t)(4 * (PAIR ? (cg & 7) : cg)) * 4u : 0u;
+  const float* __restrict__ rs2_t = lyr_w ? rs2B : rs2;                      // the row scales of THIS thread's layer (NULL: a plain layer)
+  const float* __restrict__ rsb = RS2 ? (rs2_t ? rs2_t : Gp) : nullptr;      // (layers without row scales: any readable rows; never used)
   auto load_tile_g = [&](int tile, int ts, int R) {
-    const char* gb = reinterpret_cast<const char*>(Gp + (size_t)ts * p.ldg + gcol0);
+    const char* gb = reinterpret_cast<const char*>(Gw_ + (size_t)ts * p.ldg + gcol0);
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) {
       const int r = r32 + 32 * rb;
@@ -126,7 +145,7 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
     }
   };
   auto load_x = [&](int ts, int R, f32x4 (&dst)[2], int c) {
-    const char* xb = reinterpret_cast<const char*>(Xp + (size_t)ts * p.ldx + xcol0);
+    const char* xb = reinterpret_cast<const char*>(Xc_ + (size_t)ts * p.ldx + xcol0);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int r = 32 * c + 2 * rp + u;
@@ -136,7 +155,7 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
     }
   };
   auto load_gc = [&](int ts, int R, int c) {
-    const char* gb = reinterpret_cast<const char*>(Gp + (size_t)ts * p.ldg + gcol0);
+    const char* gb = reinterpret_cast<const char*>(Gc_ + (size_t)ts * p.ldg + gcol0);
     if (role == 0) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -202,12 +221,12 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
       bsum += pgw[rb];
     }
     if constexpr (RS2) {
-      if (rs2) {
+      if (rs2 || rs2B) {      // (uniform; a thread whose layer has no row scales adds zeros)
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
           f32x4 d = {0.f, 0.f, 0.f, 0.f};
-          if constexpr (PRS) d = f32x4{prs[rb][0], prs[rb][1], prs[rb][2], 0.f};
-          else if (r32 + 32 * rb < R) d = *reinterpret_cast<const f32x4*>(rs2 + (size_t)(ts + r32 + 32 * rb) * 4);
+          if constexpr (PRS) { if (rs2_t) d = f32x4{prs[rb][0], prs[rb][1], prs[rb][2], 0.f}; }
+          else if (rs2_t && r32 + 32 * rb < R) d = *reinterpret_cast<const f32x4*>(rs2_t + (size_t)(ts + r32 + 32 * rb) * 4);
 #pragma unroll
           for (int m = 0; m < NMAT; ++m) bs2[m] += pgw[rb] * d[m];
         }
@@ -354,23 +373,26 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
 
   // ---- one slab per tile-list slice blockIdx.x; the y-slices tile the [nmat*hout, hin] matrix
   const size_t stride = (size_t)p.nmat * p.hout * p.hin + p.hout + (rs2 ? (size_t)p.nmat * p.hout : 0);
+  const size_t strideB = (size_t)p.nmat * p.hout * p.hin + p.hout + (rs2B ? (size_t)p.nmat * p.hout : 0);
   float* out = slabp + (size_t)slice * (wb.slab_stride > 0 ? (size_t)wb.slab_stride : stride);
+  float* outB = slabB + (size_t)slice * (wb.slab_stride > 0 ? (size_t)wb.slab_stride : strideB);      // (PAIR: the second layer's slab)
   const int fin = Ex + Eg + hb - 28;      // acc = 2^(14 - Ex) 2^(14 - hb - Eg) dW
   if (in_active) {
-    const int i = xcol0 + ibw * 32 + c32;
+    const int i = PAIR ? c32 : xcol0 + ibw * 32 + c32;
+    float* ow = (PAIR && obh) ? outB : out;
     if (i < p.hin) {
 #pragma unroll
       for (int m = 0; m < NMAT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int o = gcol0 + obh * 32 + acc_row(r, half);
-          if (o < p.hout) out[((size_t)m * p.hout + o) * p.hin + i] = ldexpf(acc[m][r], fin);
+          const int o = PAIR ? acc_row(r, half) : gcol0 + obh * 32 + acc_row(r, half);
+          if (o < p.hout) ow[((size_t)m * p.hout + o) * p.hin + i] = ldexpf(acc[m][r], fin);
         }
     }
   }
   if (ibg == 0) {   // (uniform) column sums: the 32 threads that share a column group meet in LDS, fixed order
     f32x4* red = reinterpret_cast<f32x4*>(smem);          // [1 + NMAT][NT]
-    const int nsum = rs2 ? 1 + NMAT : 1;
+    const int nsum = (rs2 || rs2B) ? 1 + NMAT : 1;
     __syncthreads();
     red[tid] = bsum;
     if constexpr (RS2) {
@@ -382,6 +404,13 @@ __global__ void __launch_bounds__(W16TH_NT) wgrad16th_kernel(const dss2_wgrad_ar
       const int which = j / ZC, col = j - which * ZC;
       float s = 0.f;
       for (int r = 0; r < 32; ++r) s += red[which * NT + r * 16 + (col >> 2)][col & 3];
+      if constexpr (PAIR) {      // columns 0..31: the first layer, 32..63: the second (its scaled sums only where it has row scales)
+        const int lb = col >> 5, o = col & 31;
+        float* ob = lb ? outB : out;
+        if (o < p.hout && (lb == 0 || hasB) && (which == 0 || (lb ? rs2B : rs2) != nullptr))
+          ob[(size_t)p.nmat * p.hout * p.hin + (which == 0 ? 0 : p.hout + (size_t)(which - 1) * p.hout) + o] = s;
+        continue;
+      }
       const int o = gcol0 + col;
       if (o < p.hout) out[(size_t)p.nmat * p.hout * p.hin + (which == 0 ? 0 : p.hout + (size_t)(which - 1) * p.hout) + o] = s;
     }
@@ -409,14 +438,15 @@ bool wgrad16th_covers(const dss2_wgrad_args& a) {
          wgrad16th_lds_bytes(a.nrb, a.nmat, a.ell_width) <= (size_t)kMaxLdsBytes;
 }
 
-template <int NRB, int NMAT, bool RS2, bool PC>
+template <int NRB, int NMAT, bool RS2, bool PC, bool PAIR = false>
 static int launch16th(const dss2_wgrad_args& a, hipStream_t stream, const WgradBatch& wb) {
   static std::atomic<uint32_t> lds_done{0};
-  auto kern = wgrad16th_kernel<NRB, NMAT, RS2, PC>;
+  auto kern = wgrad16th_kernel<NRB, NMAT, RS2, PC, PAIR>;
   if (ensure_max_lds(reinterpret_cast<const void*>(kern), lds_done, "wgrad(f16x3, tall tiles)")) return 1;
   const int nobg = (a.hout + W16TH_ZC - 1) / W16TH_ZC, nibg = (a.hin + W16TH_XW - 1) / W16TH_XW;
   const int hb = (a.mfma_bf16 >> 8) & 255;
-  hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg, wb.n > 0 ? wb.n : 1), dim3(W16TH_NT), wgrad16th_lds_bytes(a.nrb, a.nmat, a.ell_width), stream, a, nibg, wb, hb);
+  const int nz = wb.n > 0 ? (PAIR ? (wb.n + 1) / 2 : wb.n) : 1;
+  hipLaunchKernelGGL(kern, dim3(a.n_split, nobg * nibg, nz), dim3(W16TH_NT), wgrad16th_lds_bytes(a.nrb, a.nmat, a.ell_width), stream, a, nibg, wb, hb);
   return check_launch("wgrad(f16x3, tall tiles)");
 }
 
@@ -427,6 +457,12 @@ int launch_wgrad16th(const dss2_wgrad_args& a, hipStream_t stream, const WgradBa
       set_error("wgrad(f16x3, tall tiles): layer %d has a misaligned operand", l); return 2;
     }
     rs2 = rs2 || wb.rowscale2[l] != nullptr;
+  }
+  // two layers per workgroup where a layer is one 32-column block (DSS2_WGRAD_TALL_PAIR=0: one layer per workgroup as before)
+  static const int pair_on = [] { const char* e = getenv("DSS2_WGRAD_TALL_PAIR"); return e ? atoi(e) : 1; }();
+  if (pair_on && a.nrb == 3 && a.hout == 32 && a.hin == 32 && wb.n >= 2) {
+    if (a.nmat == 2) return rs2 ? launch16th<3, 2, true, false, true>(a, stream, wb) : launch16th<3, 2, false, false, true>(a, stream, wb);
+    return rs2 ? launch16th<3, 3, true, false, true>(a, stream, wb) : launch16th<3, 3, false, false, true>(a, stream, wb);
   }
 #define DSS2_TALLH(NRB, PC) \
   if (a.nrb == NRB) { \

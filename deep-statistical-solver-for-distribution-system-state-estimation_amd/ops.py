@@ -339,7 +339,9 @@ def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Seq
     lds = _lib.lib().dss2_wgrad_lds_bytes_ex(ts.nrb, nmat, hout, hin, ts.max_nnzT, ts.ellT, int(FL.WGRAD_BF16))
     per_cu = _wgrad_per_cu(int(lds))
     ys = _lib.lib().dss2_wgrad_y_slices(ts.nrb, nmat, hout, hin, ts.ellT, int(FL.WGRAD_BF16), int(first_rowscale2 is not None))
-    n_split = min(ts.ntiles, max(1, (256 * per_cu) // (nl * ys)))       # the layers share the chip
+    mode = _wgrad_mode(ts, nmat, int(FL.WGRAD_BF16), getattr(topo, "hint", None) is not None)
+    nz = int(_lib.lib().dss2_wgrad_batched_groups(ts.nrb, hout, hin, mode, nl))      # workgroup groups along z (two 32-column layers may share one)
+    n_split = min(ts.ntiles, max(1, (256 * per_cu) // (nz * ys)))       # the layers share the chip
     stride = nmat * hout * hin + hout
     lens = [stride + (nmat * hout if (first_rowscale2 is not None and l == 0) else 0) for l in range(nl)]
     total = sum(lens)
@@ -350,7 +352,7 @@ def wgrad_batched(topo: Topology, Gs: Sequence[torch.Tensor], hout: int, Xs: Seq
         if g_.stride(0) != a.ldg or x_.stride(0) != a.ldx or g_.shape != Gs[0].shape or x_.shape != Xs[0].shape:
             raise ValueError("wgrad_batched: layers must share shapes and leading dimensions")
     a.n_split, a.nmat, a.nrb, a.ntiles = n_split, nmat, ts.nrb, ts.ntiles
-    a.mfma_bf16 = _wgrad_mode(ts, nmat, int(FL.WGRAD_BF16), getattr(topo, "hint", None) is not None)
+    a.mfma_bf16 = mode
     a.tile_start = ts.tile_start.data_ptr()
     a.rowptrT, a.colT, a.wT, a.max_nnz = topo.rowptrT.data_ptr(), topo.colT.data_ptr(), topo.wT.data_ptr(), ts.max_nnzT
     a.ell_width, a.ell_tiles = ts.ellT, _ptr(ts.ellT_tiles)

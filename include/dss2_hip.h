@@ -435,6 +435,9 @@ size_t dss2_wgrad_lds_bytes_ex(int nrb, int nmat, int hout, int hin, int max_nnz
 /* workgroups the launch puts on each of the n_split tile-list slices (> 1 only for the bf16x6 kernel at H > 128): a caller
  * that wants one workgroup per CU divides its n_split by it                                                                */
 int dss2_wgrad_y_slices(int nrb, int nmat, int hout, int hin, int ell_width, int mfma_bf16, int has_rowscale2);
+/* workgroup groups along grid.z of dss2_wgrad_batched for n_layers layers (one per layer; (n_layers + 1) / 2 where the f16x3 tall-tile kernel
+ * walks two 32-column layers per workgroup, round 6): n_split x y_slices x this = the launch's workgroups */
+int dss2_wgrad_batched_groups(int nrb, int hout, int hin, int mfma_bf16, int n_layers);
 
 /* The same for n_layers (<= 8) layers of IDENTICAL shape and leading dimensions in one launch (one grid
  * slice per layer): Gs / Xs / slabs are HOST arrays of device pointers replacing args->G / X / slab;
