@@ -296,15 +296,21 @@ __global__ void __launch_bounds__(256) edge_combine_kernel(const EdgeCombineArgs
 // rowptr -> col/ent -> x/ea).
 // ------------------------------------------------------------------------------------------
 
-template <int FPL, bool BWD>
+// HALF (round 6; FPL = 1, h <= 32: the reference driver's dim_hid on 70-bus grids, where this kernel serves the inner blocks' backward with U):
+// a lane is a hidden unit, so at h <= 32 half of every wave idled -- here the two halves of a wave take two ROWS (lane & 31 = hidden unit,
+// lane >> 5 = which row of the pair); a slot that is empty in one row of the pair is computed on row 0's operands and masked.  Forward and
+// backward form z with the same fma chain as before: the recomputed gates are the forward's.
+template <int FPL, bool BWD, bool HALF = false>
 __global__ void __launch_bounds__(256) edge_tile_kernel(const EdgeTileArgs p) {
+  static_assert(!HALF || FPL == 1, "HALF: one hidden unit per lane");
   extern __shared__ __attribute__((aligned(16))) float esm[];
   const int TM = p.TM, D = p.D;
   float* xs = esm;                                   // [TM][8]
   float* eaL = xs + TM * FN;                         // [D*TM][8]  (6 used; 8 keeps 16-byte rows)
   int* other = reinterpret_cast<int*>(eaL + D * TM * 8);   // [D*TM] local other node, -1 = empty slot
   __shared__ float red[BWD ? 256 * (FC + 1) : 1];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = HALF ? (tid & 31) : (tid & 63);      // (HALF: the hidden unit)
+  const int sub = HALF ? ((tid >> 5) & 1) : 0;                              // (HALF: which row of the wave's pair)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float w[FPL][FC], b[FPL];
 #pragma unroll
@@ -347,18 +353,22 @@ __global__ void __launch_bounds__(256) edge_tile_kernel(const EdgeTileArgs p) {
   }
   __syncthreads();
 
-  for (int r = wave; r < R; r += 4) {
+  for (int r0 = HALF ? 2 * wave : wave; r0 < R; r0 += HALF ? 8 : 4) {
+    const bool rv = !HALF || r0 + sub < R;            // (HALF: the pair's second row may lie beyond the tile)
+    const int r = rv ? r0 + sub : r0;
     const f32x4 xa = *reinterpret_cast<const f32x4*>(xs + r * FN), xb = *reinterpret_cast<const f32x4*>(xs + r * FN + 4);
     float accv[FPL], grow[FPL];
 #pragma unroll
     for (int f = 0; f < FPL; ++f) {
       accv[f] = 0.f;
       const int j = lane + 64 * f;
-      grow[f] = (BWD && !p.by_source && j < p.h) ? p.dS[(int64_t)(ts + r) * p.h + j] : 0.f;   // one load per row
+      grow[f] = (BWD && !p.by_source && j < p.h && rv) ? p.dS[(int64_t)(ts + r) * p.h + j] : 0.f;   // one load per row
     }
     for (int k = 0; k < D; ++k) {
-      const int o = other[k * TM + r];
-      if (o < 0) continue;                            // wave-uniform
+      const int o_ = other[k * TM + r];
+      const bool valid = rv && o_ >= 0;
+      if (HALF ? __builtin_amdgcn_ballot_w64(valid) == 0 : o_ < 0) continue;      // wave-uniform
+      const int o = (HALF && !valid) ? 0 : o_;        // (an empty slot of one row of the pair: any staged row; masked below)
       const f32x4 oa = *reinterpret_cast<const f32x4*>(xs + o * FN), ob = *reinterpret_cast<const f32x4*>(xs + o * FN + 4);
       const f32x4 e0 = *reinterpret_cast<const f32x4*>(eaL + (k * TM + r) * 8), e1 = *reinterpret_cast<const f32x4*>(eaL + (k * TM + r) * 8 + 4);
       // c = [x_tgt | x_src | ea]; rows are targets (by_source == 0) or sources (by_source == 1)
@@ -371,10 +381,11 @@ __global__ void __launch_bounds__(256) edge_tile_kernel(const EdgeTileArgs p) {
         c[FN + q] = bs ? xa[q] : oa[q];
         c[FN + 4 + q] = bs ? xb[q] : ob[q];
       }
+      // (HALF: an empty slot's edge features were never staged -- whatever LDS held, possibly not finite: 0 * that would poison dW1)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) c[2 * FN + q] = e0[q];
-      c[2 * FN + 4] = e1[0];
-      c[2 * FN + 5] = e1[1];
+      for (int q = 0; q < 4; ++q) c[2 * FN + q] = (!HALF || valid) ? e0[q] : 0.f;
+      c[2 * FN + 4] = (!HALF || valid) ? e1[0] : 0.f;
+      c[2 * FN + 5] = (!HALF || valid) ? e1[1] : 0.f;
       const int64_t tg = bs ? (int64_t)(ts + o) : (int64_t)(ts + r);
 #pragma unroll
       for (int f = 0; f < FPL; ++f) {
@@ -383,10 +394,10 @@ __global__ void __launch_bounds__(256) edge_tile_kernel(const EdgeTileArgs p) {
 #pragma unroll
         for (int q = 0; q < FC; ++q) z = fmaf(w[f][q], c[q], z);
         if (!BWD) {
-          accv[f] += relu_nan(z);
+          accv[f] += (!HALF || valid) ? relu_nan(z) : 0.f;
         } else {
-          const float g = p.by_source ? ((j < p.h) ? p.dS[tg * p.h + j] : 0.f) : grow[f];
-          const float dz = relu_open(z) ? g : 0.f;
+          const float g = p.by_source ? ((j < p.h && (!HALF || valid)) ? p.dS[tg * p.h + j] : 0.f) : grow[f];
+          const float dz = (relu_open(z) && (!HALF || valid)) ? g : 0.f;
           accv[f] += dz;
           if (!p.by_source) {
             db[f] += dz;
@@ -399,7 +410,7 @@ __global__ void __launch_bounds__(256) edge_tile_kernel(const EdgeTileArgs p) {
 #pragma unroll
     for (int f = 0; f < FPL; ++f) {
       const int j = lane + 64 * f;
-      if (j < p.h) {
+      if (j < p.h && rv) {
         if (!BWD) p.S[(int64_t)(ts + r) * p.h + j] = accv[f];
         else if (p.U) p.U[(int64_t)(ts + r) * p.ldu + j] = accv[f];
       }
@@ -410,8 +421,8 @@ __global__ void __launch_bounds__(256) edge_tile_kernel(const EdgeTileArgs p) {
   if (!BWD) return;
   if (p.by_source || !p.slab) return;
   float* out = p.slab + (size_t)blockIdx.x * ((size_t)p.h * FC + p.h);
-  for (int wv = 0; wv < 4; ++wv) {
-    if (wave == wv) {
+  for (int wv = 0; wv < (HALF ? 8 : 4); ++wv) {      // fixed order: wave 0 .. 3 (HALF: wave 0's first rows, its second rows, wave 1's ...)
+    if (HALF ? (wave == (wv >> 1) && sub == (wv & 1)) : wave == wv) {
 #pragma unroll
       for (int f = 0; f < FPL; ++f) {
         const int j = lane + 64 * f;
@@ -845,7 +856,9 @@ static int launch_edge_tile(const EdgeTileArgs& a, int grid, hipStream_t s) {
   const size_t lds = ((size_t)a.TM * FN + (size_t)a.D * a.TM * 8) * 4 + (size_t)a.D * a.TM * 4;
   const int fpl = (a.h + 63) / 64;
 #define L(FPL) hipLaunchKernelGGL((edge_tile_kernel<FPL, BWD>), dim3(grid), dim3(256), lds, s, a)
-  if (fpl == 1) L(1); else if (fpl == 2) L(2); else if (fpl == 3) L(3); else L(4);
+  static const int half_on = [] { const char* e = getenv("DSS2_EDGE_TILE_HALF"); return e ? atoi(e) : 1; }();      // 0: a wave per row at every width
+  if (a.h <= 32 && half_on) hipLaunchKernelGGL((edge_tile_kernel<1, BWD, true>), dim3(grid), dim3(256), lds, s, a);
+  else if (fpl == 1) L(1); else if (fpl == 2) L(2); else if (fpl == 3) L(3); else L(4);
 #undef L
   return check_launch(BWD ? "edge_tile_bwd" : "edge_tile_fwd");
 }
