@@ -116,7 +116,9 @@ def test_edge_aggregation_tall_tiles_without_input_gradient(pkg, oracle, grid, h
 
 
 @pytest.mark.parametrize("mfma", ["bf16x6", "fp32-mfma", "valu"])     # first Linear as bf16x6 (default), on fp32 MFMAs, VALU tile kernels
-@pytest.mark.parametrize("grid,hid", [("cigre14", 128), ("ober_sub", 32), ("cigre14_reswitched", 256), ("cigre14", 64)])
+# (ober_sub / ober179 at dim_hid 32 with the input gradient: the VALU tile kernel with two rows per wave, round 6 -- 70 rows per tile, and 179: an odd count,
+#  the last pair's second row lies beyond the tile)
+@pytest.mark.parametrize("grid,hid", [("cigre14", 128), ("ober_sub", 32), ("cigre14_reswitched", 256), ("cigre14", 64), ("ober179", 32)])
 def test_edge_aggregation_fwd_bwd(pkg, oracle, grid, hid, mfma, monkeypatch):
     monkeypatch.setenv("DSS2_EDGE_MFMA", "0" if mfma == "valu" else "1")      # read per call by the library
     monkeypatch.setenv("DSS2_EDGE_BF16", "1" if mfma == "bf16x6" else "0")
