@@ -92,6 +92,10 @@ __device__ __forceinline__ void split2_pair(float a, float b, uint32_t& h, uint3
   h = __builtin_bit_cast(uint32_t, hh);
   l = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{ra, rb}, f16x2));
 }
+// 2^e as a float, e in [-126, 127] (the kernels' scale exponents are within +-114: exp_of clamps).  Scaling by it with v_mul_f32 is bit for bit what
+// v_ldexp_f32 does -- at HALF the issue cost: tools/micro/valu_rates.hip (end of round 6) measures v_mul / v_add / v_sub / v_fmac / v_and / v_mov at ~1.0
+// wave-instructions per SIMD and ns, v_ldexp / v_cvt_* / v_max / v_min / v_cmp / v_cndmask / v_lshl_or at ~0.53, v_fma_mixlo_f16 at 0.27.
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t)(e + 127) << 23); }
 // ReLU with torch's non-finite semantics (nn.ReLU, /root/reference/networks.py:269: a NaN stays a NaN): `!(v <= 0) ? v : 0` is one
 // v_cmp_nle_f32 + one v_cndmask_b32 -- what fmaxf(v, 0.f) costs too (the compiler quiets fmaxf's operand with a second v_max_f32), but
 // v_max_f32 returns the OTHER operand for a NaN: max(NaN, 0) = 0 turned a NaN weight into a dead column and a FINITE loss where the

@@ -51,8 +51,9 @@ __device__ __forceinline__ void s6_store_split(__bf16* dst, const f32x4 v) {
 template <int S6_PLANE>
 __device__ __forceinline__ void s6_store_split_h(__bf16* dst, const f32x4 v, int e) {
   uint32_t h0, l0, h1, l1;
-  split2_pair(ldexpf(v[0], e), ldexpf(v[1], e), h0, l0);
-  split2_pair(ldexpf(v[2], e), ldexpf(v[3], e), h1, l1);
+  const float s = pow2f(e);      // (v_mul_f32: half the issue cycles of v_ldexp_f32, the same bits)
+  split2_pair(v[0] * s, v[1] * s, h0, l0);
+  split2_pair(v[2] * s, v[3] * s, h1, l1);
   *reinterpret_cast<u32x2_s6*>(dst) = u32x2_s6{h0, h1};
   *reinterpret_cast<u32x2_s6*>(dst + S6_PLANE) = u32x2_s6{l0, l1};
 }
@@ -294,6 +295,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     const bf16x8* __restrict__ bp16 = reinterpret_cast<const bf16x8*>(L.Bp);
     f32x16 acc[NRB][NMAT];
     [[maybe_unused]] int ue[NMAT];      // (F16) what takes the scales out of matrix m's accumulators for the lane's output column: -(ea + ew[m][column])
+    [[maybe_unused]] float su[NMAT];      // (F16) 2^ue
 
     // ---- tile GEMM, 16 k per step: B fragments (L2) ping-pong one step ahead, A fragments (LDS planes) one row block ahead;
     // one memory request per MFMA gap (dss2_gemm_chain_sp.hip)
@@ -368,7 +370,10 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     if constexpr (F16) {      // (requested here, behind the GEMM phase: its fragment registers are free; used in the hand-off behind the barrier)
       const int* whdr = reinterpret_cast<const int*>(reinterpret_cast<const char*>(L.Bp) + (size_t)NMAT * ncg * nks * 2048) + cg * 32 + c32;
 #pragma unroll
-      for (int m = 0; m < NMAT; ++m) ue[m] = -(ea + whdr[m * ncg * 32]);
+      for (int m = 0; m < NMAT; ++m) {
+        ue[m] = -(ea + whdr[m * ncg * 32]);
+        su[m] = ldexpf(1.f, ue[m] < -126 ? -126 : (ue[m] > 127 ? 127 : ue[m]));      // (the hand-off multiplies: dss2_gemm_chain_sp.hip)
+      }
     }
     const bool has_pre = DIR != 2 && L.prebias != nullptr, has_dm = DIR == 0 && L.dmask != nullptr, has_rs = DIR != 1 && L.relu_src != nullptr, has_add = DIR == 0 && L.add_src != nullptr;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -406,7 +411,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (rb * 32 + 8 * (r >> 2) < 8 * RPA) slot0[(rb * 32 + acc_row(r, half)) * 32 + c32] = F16 ? ldexpf(acc[rb][m][r], ue[m]) : acc[rb][m][r];
+            if (rb * 32 + 8 * (r >> 2) < 8 * RPA) slot0[(rb * 32 + acc_row(r, half)) * 32 + c32] = F16 ? acc[rb][m][r] * su[m] : acc[rb][m][r];
       };
       put(NMAT - 1);
       wave_lds_sync();

@@ -49,10 +49,11 @@ __device__ __forceinline__ int tph_off(int col, int row) { return col * 64 + (((
 // rows (2 rp, 2 rp + 1) x columns (c0 .. c0+3) scaled by 2^e -> the two planes of a transposed image with NCOLS columns
 template <int NCOLS>
 __device__ __forceinline__ void store_planes_h(char* img, int off0, const f32x4 v0, const f32x4 v1, int e) {
+  const float s = pow2f(e);      // (v_mul_f32: half the issue cycles of v_ldexp_f32, the same bits)
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     uint32_t h, l;
-    split2_pair(ldexpf(v0[q], e), ldexpf(v1[q], e), h, l);
+    split2_pair(v0[q] * s, v1[q] * s, h, l);
     char* dst = img + off0 + q * 64;
     *reinterpret_cast<uint32_t*>(dst) = h;
     *reinterpret_cast<uint32_t*>(dst + NCOLS * 64) = l;
