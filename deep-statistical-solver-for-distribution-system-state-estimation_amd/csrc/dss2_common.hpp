@@ -96,6 +96,11 @@ __device__ __forceinline__ void split2_pair(float a, float b, uint32_t& h, uint3
 // v_ldexp_f32 does -- at HALF the issue cost: tools/micro/valu_rates.hip (end of round 6) measures v_mul / v_add / v_sub / v_fmac / v_and / v_mov at ~1.0
 // wave-instructions per SIMD and ns, v_ldexp / v_cvt_* / v_max / v_min / v_cmp / v_cndmask / v_lshl_or at ~0.53, v_fma_mixlo_f16 at 0.27.
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t)(e + 127) << 23); }
+// v & (bit k of `word` ? ~0 : 0): a gate as v_bfe_i32 (the bit sign-extended: 0 or -1) + v_and_b32 -- six issue cycles per wave against ten for the
+// `(word >> k) & 1 ? v : 0` form (v_and + v_cmp + v_cndmask); a closed gate gives +0 whatever v holds, an open one v's bits (a NaN stays a NaN).
+__device__ __forceinline__ float gate_bit(float v, uint32_t word, int k) {
+  return __uint_as_float(__float_as_uint(v) & (uint32_t)__builtin_amdgcn_sbfe((int)word, k, 1));
+}
 // ReLU with torch's non-finite semantics (nn.ReLU, /root/reference/networks.py:269: a NaN stays a NaN): `!(v <= 0) ? v : 0` is one
 // v_cmp_nle_f32 + one v_cndmask_b32 -- what fmaxf(v, 0.f) costs too (the compiler quiets fmaxf's operand with a second v_max_f32), but
 // v_max_f32 returns the OTHER operand for a NaN: max(NaN, 0) = 0 turned a NaN weight into a dead column and a FINITE loss where the

@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) U[i][q] = ((gate_word >> (4 * i + q)) & 1u) ? U[i][q] : 0.f;
+          for (int q = 0; q < 4; ++q) U[i][q] = gate_bit(U[i][q], gate_word, 4 * i + q);
       } else if (has_rs) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)

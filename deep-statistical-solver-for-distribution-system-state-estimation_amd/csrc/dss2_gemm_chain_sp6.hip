@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
 #pragma unroll
         for (int i = 0; i < RPA; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) U[i][q] = ((gate_bits[i >> 3] >> ((i & 7) * 4 + q)) & 1u) ? U[i][q] : 0.f;
+          for (int q = 0; q < 4; ++q) U[i][q] = gate_bit(U[i][q], gate_bits[i >> 3], (i & 7) * 4 + q);
       }
       if (has_add) {
 #pragma unroll
