@@ -119,14 +119,27 @@ __device__ __forceinline__ void relu_nan4(f32x4& v) {
       : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3));
   v = f32x4{a, b, c, d};
 }
+// (two v_max3_f32 with |.| source modifiers, NaN operands ignored as by v_max_f32.  The fmaxf(fabsf(..)) form compiled to SEVEN four-cycle
+//  instructions per vector: the compiler canonicalises every |x| with a v_max_f32 |x|, |x| of its own before the three that do the work --
+//  56 instructions per layer and wave in the chains' tile maximum, 42 per tile and lane in the weight gradient's: end of round 6, tools/micro/valu_rates.hip)
 __device__ __forceinline__ float absmax4(float m, const f32x4 v) {
-  return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  asm("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|" : "+v"(m) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+  return m;
 }
 // max over the wave of non-negative values, in every lane (DPP row shifts and broadcasts: six VALU instructions; six ds_bpermute
 // round trips cost the weight-gradient kernel ~1000 cycles per tile).  v_max_f32 ignores NaN operands.
+// (one v_max_f32 with the DPP operand instead of v_mov_dpp + a canonicalising v_max + v_max; s_nop 1: the two wait states between a VALU write of a
+//  register and a DPP read of it, which the compiler cannot insert inside an asm block.  Rows outside ROWS keep their value; a lane without a source reads 0.)
 template <int CTRL, int ROWS>
 __device__ __forceinline__ float dpp_max(float v) {
-  return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, true)));
+  static_assert((CTRL == 0x111 || CTRL == 0x112 || CTRL == 0x114 || CTRL == 0x118) ? ROWS == 0xf : ((CTRL == 0x142 && ROWS == 0xa) || (CTRL == 0x143 && ROWS == 0xc)), "dpp_max: control / row mask");
+  if constexpr (CTRL == 0x111) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v));
+  else if constexpr (CTRL == 0x112) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v));
+  else if constexpr (CTRL == 0x114) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v));
+  else if constexpr (CTRL == 0x118) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v));
+  else if constexpr (CTRL == 0x142) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf bound_ctrl:1" : "+v"(v));
+  else asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf bound_ctrl:1" : "+v"(v));
+  return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
   v = dpp_max<0x111, 0xf>(v);      // row_shr:1
