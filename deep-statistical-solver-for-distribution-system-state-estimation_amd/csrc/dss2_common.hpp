@@ -122,6 +122,19 @@ __device__ __forceinline__ void relu_nan4(f32x4& v) {
 // (two v_max3_f32 with |.| source modifiers, NaN operands ignored as by v_max_f32.  The fmaxf(fabsf(..)) form compiled to SEVEN four-cycle
 //  instructions per vector: the compiler canonicalises every |x| with a v_max_f32 |x|, |x| of its own before the three that do the work --
 //  56 instructions per layer and wave in the chains' tile maximum, 42 per tile and lane in the weight gradient's: end of round 6, tools/micro/valu_rates.hip)
+// relu_nan4 that also shifts the four compare masks -- "open" = !(x <= 0), which IS the sign-bit word's bit of the value ReLU stores (+0, positive or
+// NaN) -- into `word` from below, element 3 first: word = 16 word + (m3 m2 m1 m0).  Called for the lane's pieces 7 .. 0 it leaves bit 4 i + q = element q
+// of piece i, the layout of y_bits / gate_bits.  v_addc_co_u32 takes the lane mask as its carry: one instruction per value where v_min_u32 +
+// v_lshl_or_b32 on the stored value were two (four issue cycles each: tools/micro/valu_rates.hip).
+__device__ __forceinline__ void relu_nan4_bits(f32x4& v, uint32_t& word) {
+  float a = v[0], b = v[1], c = v[2], d = v[3];
+  unsigned long long m0, m1, m2, m3, co;
+  asm("v_cmp_nge_f32_e64 %4, 0, %0\n\tv_cmp_nge_f32_e64 %5, 0, %1\n\tv_cmp_nge_f32_e64 %6, 0, %2\n\tv_cmp_nge_f32_e64 %7, 0, %3\n\t"
+      "v_cndmask_b32_e64 %0, 0, %0, %4\n\tv_cndmask_b32_e64 %1, 0, %1, %5\n\tv_cndmask_b32_e64 %2, 0, %2, %6\n\tv_cndmask_b32_e64 %3, 0, %3, %7\n\t"
+      "v_addc_co_u32_e64 %8, %9, %8, %8, %7\n\tv_addc_co_u32_e64 %8, %9, %8, %8, %6\n\tv_addc_co_u32_e64 %8, %9, %8, %8, %5\n\tv_addc_co_u32_e64 %8, %9, %8, %8, %4"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "+v"(word), "=&s"(co));
+  v = f32x4{a, b, c, d};
+}
 __device__ __forceinline__ float absmax4(float m, const f32x4 v) {
   asm("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|" : "+v"(m) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
   return m;

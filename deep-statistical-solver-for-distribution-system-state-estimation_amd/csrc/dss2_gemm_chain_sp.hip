@@ -591,6 +591,7 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
 #pragma unroll
       for (int i = 0; i < (F16 ? 8 : 1); ++i) { const int row = rowv + 8 * i; psr[i] = *reinterpret_cast<const f32x3_e*>(pr0 + (size_t)(uint32_t)((row < R ? row : 0) * 16)); }
     }
+    uint32_t relu_word = 0u;      // the ReLU's compare masks as the lane's sign-bit word (layers that write y_bits)
 #pragma unroll
     for (int i = 0; i < 8; ++i) U[i] += bias4;
     if (col_ok) {
@@ -620,8 +621,13 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
                              //  one-instruction `v_max_f32 0, x` turned a NaN weight into a finite loss, dss2_common.hpp relu_nan.
                              //  Four compares, then their four selects: left to itself the compiler pairs every v_cmp (VCC) with its
                              //  v_cndmask behind an `s_nop 1` -- a third issue slot per value, 32 per layer and wave)
+        if (L.y_bits && !has_add) {      // (uniform) the sign-bit word rides in the compares: relu_nan4_bits
 #pragma unroll
-        for (int i = 0; i < 8; ++i) relu_nan4(U[i]);
+          for (int i = 7; i >= 0; --i) relu_nan4_bits(U[i], relu_word);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) relu_nan4(U[i]);
+        }
       }
       if (gbits) {
 #pragma unroll
@@ -653,14 +659,8 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
       if ((L.relu & 1) && !has_add) {
         // behind a ReLU (and no residual) a stored value is +0, positive or NaN: "open" = its bit pattern is not zero -- v_min_u32 +
         // v_lshl_or_b32 per value instead of compare, select and or; NaN counts as open, as in relu_open (torch's threshold_backward)
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {      // (asm: the compiler rewrites umin(x, 1) as x != 0 -- compare, s_nop, select -- again)
-            uint32_t t;
-            asm("v_min_u32 %0, 1, %1" : "=v"(t) : "v"(__float_as_uint(U[i][q])));
-            word |= t << (4 * i + q);
-          }
+        // (round 6: the bits are the ReLU's own compare masks, shifted into relu_word there -- before: v_min_u32 + v_lshl_or_b32 per stored value)
+        word = relu_word;
         uint32_t valid = 0u;
 #pragma unroll
         for (int i = 0; i < 8; ++i) valid |= (col_ok && rowv + 8 * i < R) ? (0xFu << (4 * i)) : 0u;
