@@ -472,6 +472,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
     S6STAMP(2 + li * 6 + 5);
     // ---- epilogue: bias / folded bias / masks / dropout / ReLU / gate / residual -> HBM and, split, the next layer's planes
     const bool keep = li + 1 < ct.n;
+    [[maybe_unused]] uint32_t relu_words[NGW] = {};      // (forward chains) the ReLU's compare masks as the lane's sign-bit words
 #pragma unroll
     for (int i = 0; i < RPA; ++i) U[i] += bias4;
     if (col_ok) {
@@ -496,10 +497,13 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
           U[i] *= dropout_mult4(drop_seed, drop_off, (uint32_t)L.drop_id, (uint32_t)grow_of(i), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
       }
       if (DIR != 2 && (L.relu & 1)) {
+        if (DIR == 1 && L.y_bits) {      // (uniform; end of round 6) the sign-bit words ride in the ReLU's compares: relu_nan4_bits, dss2_common.hpp
 #pragma unroll
-        for (int i = 0; i < RPA; ++i)
+          for (int i = RPA - 1; i >= 0; --i) relu_nan4_bits(U[i], relu_words[i >> 3]);
+        } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) U[i][q] = relu_nan(U[i][q]);
+          for (int i = 0; i < RPA; ++i) relu_nan4(U[i]);
+        }
       }
       if (has_rs) {
 #pragma unroll
@@ -520,11 +524,18 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
 #pragma unroll
       for (int w = 0; w < NGW; ++w) {
         uint32_t word = 0u;
+        if (DIR == 1 && (L.relu & 1)) {      // (uniform) behind the forward set's ReLU the bits are its compare masks (no residual in that set)
+          uint32_t valid = 0u;
 #pragma unroll
-        for (int i = 8 * w; i < 8 * w + 8 && i < RPA; ++i) {
-          const bool in_y = col_ok && rowv + 8 * i < R;      // (pad rows and pad columns: zero bits)
+          for (int i = 8 * w; i < 8 * w + 8 && i < RPA; ++i) valid |= (col_ok && rowv + 8 * i < R) ? (0xFu << ((i & 7) * 4)) : 0u;      // (pad rows and pad columns: zero bits)
+          word = relu_words[w] & valid;
+        } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) word |= ((in_y && relu_open(U[i][q])) ? 1u : 0u) << ((i & 7) * 4 + q);
+          for (int i = 8 * w; i < 8 * w + 8 && i < RPA; ++i) {
+            const bool in_y = col_ok && rowv + 8 * i < R;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) word |= ((in_y && relu_open(U[i][q])) ? 1u : 0u) << ((i & 7) * 4 + q);
+          }
         }
         yb[w * 64] = word;
       }
