@@ -101,6 +101,18 @@ __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t
 __device__ __forceinline__ float gate_bit(float v, uint32_t word, int k) {
   return __uint_as_float(__float_as_uint(v) & (uint32_t)__builtin_amdgcn_sbfe((int)word, k, 1));
 }
+// four values gated by bits k0 .. k0 + 3 of `word` in one block: the four masks live for four instructions (left to the scheduler, a lane's 32 .. 96
+// v_bfe_i32 are hoisted in front of their v_and_b32 -- as many live registers, which the 192-row chain does not have: 29 -> 205 spilled)
+template <int K0>
+__device__ __forceinline__ void gate_bits4(f32x4& v, uint32_t word) {
+  float a = v[0], b = v[1], c = v[2], d = v[3];
+  uint32_t t0, t1, t2, t3;
+  asm("v_bfe_i32 %4, %8, %9, 1\n\tv_bfe_i32 %5, %8, %10, 1\n\tv_bfe_i32 %6, %8, %11, 1\n\tv_bfe_i32 %7, %8, %12, 1\n\t"
+      "v_and_b32 %0, %0, %4\n\tv_and_b32 %1, %1, %5\n\tv_and_b32 %2, %2, %6\n\tv_and_b32 %3, %3, %7"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(word), "n"(K0), "n"(K0 + 1), "n"(K0 + 2), "n"(K0 + 3));
+  v = f32x4{a, b, c, d};
+}
 // ReLU with torch's non-finite semantics (nn.ReLU, /root/reference/networks.py:269: a NaN stays a NaN): `!(v <= 0) ? v : 0` is one
 // v_cmp_nle_f32 + one v_cndmask_b32 -- what fmaxf(v, 0.f) costs too (the compiler quiets fmaxf's operand with a second v_max_f32), but
 // v_max_f32 returns the OTHER operand for a NaN: max(NaN, 0) = 0 turned a NaN weight into a dead column and a FINITE loss where the
@@ -136,6 +148,9 @@ __device__ __forceinline__ void relu_nan4_bits(f32x4& v, uint32_t& word) {
   v = f32x4{a, b, c, d};
 }
 __device__ __forceinline__ float absmax4(float m, const f32x4 v) {
+#ifdef DSS2_ABSMAX_C
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#endif
   asm("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|" : "+v"(m) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
   return m;
 }
@@ -145,6 +160,9 @@ __device__ __forceinline__ float absmax4(float m, const f32x4 v) {
 //  register and a DPP read of it, which the compiler cannot insert inside an asm block.  Rows outside ROWS keep their value; a lane without a source reads 0.)
 template <int CTRL, int ROWS>
 __device__ __forceinline__ float dpp_max(float v) {
+#ifdef DSS2_DPP_C
+  return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, true)));
+#endif
   static_assert((CTRL == 0x111 || CTRL == 0x112 || CTRL == 0x114 || CTRL == 0x118) ? ROWS == 0xf : ((CTRL == 0x142 && ROWS == 0xa) || (CTRL == 0x143 && ROWS == 0xc)), "dpp_max: control / row mask");
   if constexpr (CTRL == 0x111) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v));
   else if constexpr (CTRL == 0x112) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v));

@@ -630,10 +630,16 @@ __global__ void __launch_bounds__(NW * 64, 2) gemm_chain_sp_kernel(const dss2_ge
         }
       }
       if (gbits) {
+        // (piece i's four gates from bits 4 (i & 7) ..: gate_bits4, dss2_common.hpp; the switch folds once the loop is unrolled)
+        auto gate_piece = [&](int i) {
+          const uint32_t w_ = gate_word;
+          switch (i & 7) {
+            case 0: gate_bits4<0>(U[i], w_); break;   case 1: gate_bits4<4>(U[i], w_); break;   case 2: gate_bits4<8>(U[i], w_); break;   case 3: gate_bits4<12>(U[i], w_); break;
+            case 4: gate_bits4<16>(U[i], w_); break;  case 5: gate_bits4<20>(U[i], w_); break;  case 6: gate_bits4<24>(U[i], w_); break;  default: gate_bits4<28>(U[i], w_); break;
+          }
+        };
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) U[i][q] = gate_bit(U[i][q], gate_word, 4 * i + q);
+        for (int i = 0; i < 8; ++i) gate_piece(i);
       } else if (has_rs) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)

@@ -75,6 +75,10 @@ __device__ __forceinline__ void s6_store_split_h(__bf16* dst, const f32x4 v, int
 template <int NRB, int NMAT, int DIR, int HM = 0, bool F16 = false, int RPA = 4 * NRB>
 __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(const dss2_gemm_prop_args p, const ChainTable ct, const dss2_chain_head hd) {
   constexpr int TM = 32 * NRB, S6_PLANE = s6_plane(NRB), S6_REGION = s6_region(NRB);
+  // 96 rows: the accumulator hand-off's scales as v_mul_f32 and the sign-bit words from the ReLU's compare masks (end of round 6, dss2_common.hpp).  192 rows keep
+  // v_ldexp_f32 and the bits formed from the stored values: 288 accumulator registers leave no room -- with the products' float scales live across the hand-off the
+  // data-gradient kernel spills 205 registers instead of 29 (179-bus step 1.34 -> 1.46 ms), with the compare-mask words the forward one 91 instead of 59
+  constexpr bool S6_MUL = NRB <= 3, S6_RELU_BITS = NRB <= 3;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -411,7 +415,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (rb * 32 + 8 * (r >> 2) < 8 * RPA) slot0[(rb * 32 + acc_row(r, half)) * 32 + c32] = F16 ? acc[rb][m][r] * su[m] : acc[rb][m][r];
+            if (rb * 32 + 8 * (r >> 2) < 8 * RPA) slot0[(rb * 32 + acc_row(r, half)) * 32 + c32] = F16 ? (S6_MUL ? acc[rb][m][r] * su[m] : ldexpf(acc[rb][m][r], ue[m])) : acc[rb][m][r];
       };
       put(NMAT - 1);
       wave_lds_sync();
@@ -497,7 +501,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
           U[i] *= dropout_mult4(drop_seed, drop_off, (uint32_t)L.drop_id, (uint32_t)grow_of(i), (uint32_t)(col0 >> 2), p.drop_thr, p.drop_scale);
       }
       if (DIR != 2 && (L.relu & 1)) {
-        if (DIR == 1 && L.y_bits) {      // (uniform; end of round 6) the sign-bit words ride in the ReLU's compares: relu_nan4_bits, dss2_common.hpp
+        if (S6_RELU_BITS && DIR == 1 && L.y_bits) {      // (uniform; end of round 6) the sign-bit words ride in the ReLU's compares: relu_nan4_bits, dss2_common.hpp
 #pragma unroll
           for (int i = RPA - 1; i >= 0; --i) relu_nan4_bits(U[i], relu_words[i >> 3]);
         } else {
@@ -506,10 +510,16 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
         }
       }
       if (has_rs) {
+        // (piece i's four gates from bits 4 (i & 7) ..: gate_bits4, dss2_common.hpp; the switch folds once the loop is unrolled)
+        auto gate_piece = [&](int i) {
+          const uint32_t w_ = gate_bits[i >> 3];
+          switch (i & 7) {
+            case 0: gate_bits4<0>(U[i], w_); break;   case 1: gate_bits4<4>(U[i], w_); break;   case 2: gate_bits4<8>(U[i], w_); break;   case 3: gate_bits4<12>(U[i], w_); break;
+            case 4: gate_bits4<16>(U[i], w_); break;  case 5: gate_bits4<20>(U[i], w_); break;  case 6: gate_bits4<24>(U[i], w_); break;  default: gate_bits4<28>(U[i], w_); break;
+          }
+        };
 #pragma unroll
-        for (int i = 0; i < RPA; ++i)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) U[i][q] = gate_bit(U[i][q], gate_bits[i >> 3], (i & 7) * 4 + q);
+        for (int i = 0; i < RPA; ++i) gate_piece(i);
       }
       if (has_add) {
 #pragma unroll
@@ -524,7 +534,7 @@ __global__ void __launch_bounds__(256, NRB <= 3 ? 2 : 1) gemm_chain_sp6_kernel(c
 #pragma unroll
       for (int w = 0; w < NGW; ++w) {
         uint32_t word = 0u;
-        if (DIR == 1 && (L.relu & 1)) {      // (uniform) behind the forward set's ReLU the bits are its compare masks (no residual in that set)
+        if (S6_RELU_BITS && DIR == 1 && (L.relu & 1)) {      // (uniform) behind the forward set's ReLU the bits are its compare masks (no residual in that set)
           uint32_t valid = 0u;
 #pragma unroll
           for (int i = 8 * w; i < 8 * w + 8 && i < RPA; ++i) valid |= (col_ok && rowv + 8 * i < R) ? (0xFu << ((i & 7) * 4)) : 0u;      // (pad rows and pad columns: zero bits)
